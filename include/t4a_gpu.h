@@ -1,0 +1,244 @@
+/*
+ * t4a_gpu.h — C ABI of the MI355X (gfx950) backend for the tensor4all-rs TCI2 sweep hot path.
+ *
+ * This is the drop-in boundary.  The reference has NO existing FFI seam for this path
+ * (tensor4all-capi deliberately excludes SimpleTT/TCI: crates/tensor4all-capi/src/lib.rs:13-14), so the
+ * seam sits where the reference already crosses crates: the `Matrix<f64>`-level function surface of
+ * tensor4all-core / tensor4all-tensorbackend and the `TensorCI2` driver of tensor4all-tensorci.  Each
+ * entry point cites the Rust item it replaces.  Conventions are copied from tensor4all-capi:
+ *   - status codes (crates/tensor4all-capi/src/lib.rs:49-68), thread-local last-error string fetched on
+ *     the same OS thread (lib.rs:79-83, docs/CAPI_DESIGN.md:75-80);
+ *   - opaque handles `*_new(..., out)` / `*_release` (docs/CAPI_DESIGN.md:24-52);
+ *   - query-then-fill for variable-length outputs (docs/CAPI_DESIGN.md:108-123);
+ *   - column-major dense buffers, `m[[r,c]] <-> data[r + nrows*c]`
+ *     (crates/tensor4all-tensorbackend/src/matrix.rs:31-53);
+ *   - no exception crosses the boundary (lib.rs:139-162).
+ * All matrix pointers are HOST pointers unless a name ends in `_device`.  One in-flight call per
+ * handle (the reference serialises backend calls behind one mutex, tensorbackend/src/context.rs:96).
+ * Only f64 is in scope.
+ */
+#ifndef T4A_GPU_H
+#define T4A_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+/* ---- status codes: values 0..-7 identical to tensor4all-capi's t4a_status_code ---- */
+typedef int32_t t4a_gpu_status;
+#define T4A_GPU_SUCCESS 0
+#define T4A_GPU_NULL_POINTER (-1)
+#define T4A_GPU_INVALID_ARGUMENT (-2)
+#define T4A_GPU_BUFFER_TOO_SMALL (-5)
+#define T4A_GPU_INTERNAL_ERROR (-6)
+#define T4A_GPU_NOT_IMPLEMENTED (-7)
+/* extensions: MatrixCIError::{NaNEncountered, SingularMatrix} (core/src/matrixlu.rs:653-662,904,980) */
+#define T4A_GPU_NAN_ENCOUNTERED (-8)
+#define T4A_GPU_SINGULAR_MATRIX (-9)
+/* no usable HIP device / HIP runtime failure: the product path never falls back to the CPU */
+#define T4A_GPU_NO_DEVICE (-10)
+/* a bounded in-kernel spin gave up (persistent rrLU hand-off) */
+#define T4A_GPU_KERNEL_TIMEOUT (-11)
+/* the user callback returned a wrong number of values (tensorci2.rs:1872-1874) */
+#define T4A_GPU_CALLBACK_ERROR (-12)
+
+/* Copies the calling thread's last error message (NUL terminated). `required_len` (may be NULL)
+   receives the length including the terminator.  Mirrors t4a_last_error_message (capi/src/lib.rs:273). */
+t4a_gpu_status t4a_gpu_last_error_message(char* buf, size_t buf_len, size_t* required_len);
+
+/* Number of visible HIP devices (0 on a CPU-only host; never an error). */
+t4a_gpu_status t4a_gpu_device_count(int32_t* out_count);
+/* Select the device used by subsequent calls of this process (one process per GPU). */
+t4a_gpu_status t4a_gpu_set_device(int32_t device);
+/* Library version string. */
+const char* t4a_gpu_version(void);
+
+/* =====================================================================================
+ * Dense kernels (host buffers in, host buffers out; each call is synchronous)
+ * ===================================================================================== */
+
+/* rrlu_mut(&mut Matrix<f64>, Option<RrLUOptions>) -> RrLU   (core/src/matrixlu.rs:735-819)
+ * In-place full-pivot rank-revealing LU.  On return `a_inout` holds the factored matrix in the
+ * physically permuted order of the reference's buffer (L below / U on+above the diagonal; read L,U
+ * per extract_lu_from_factorized, matrixlu.rs:614-668).  `max_bond_dim == 0` means usize::MAX.
+ * row_perm[m], col_perm[n]: RrLU::row_permutation / col_permutation.  Pivot selection is bit-exact.
+ * Returns T4A_GPU_NAN_ENCOUNTERED exactly when the reference returns MatrixCIError::NaNEncountered. */
+t4a_gpu_status t4a_gpu_rrlu_f64(double* a_inout, size_t m, size_t n, size_t max_bond_dim, double rel_tol,
+                                double abs_tol, int32_t left_orthogonal, size_t* row_perm, size_t* col_perm,
+                                size_t* npivots, double* last_error);
+
+/* matrix_luci_factors_from_matrix(&Matrix<f64>, Option<RrLUOptions>) -> MatrixLuciFactors
+ * (core/src/matrix_luci.rs:366-374; factors :256-279).
+ * Caller-owned buffers sized for rank = min(m,n): rows/cols [min(m,n)], pivot_errors [min(m,n)+1],
+ * left [m*min(m,n)], right [min(m,n)*n].  On return left is m x rank and right is rank x n, both
+ * column-major and densely packed for the returned rank. */
+t4a_gpu_status t4a_gpu_luci_f64(const double* a, size_t m, size_t n, size_t max_bond_dim, double rel_tol,
+                                double abs_tol, int32_t left_orthogonal, size_t* rank, size_t* rows, size_t* cols,
+                                double* pivot_errors, double* left, double* right);
+
+/* mat_mul(&a,&b) (tensorbackend/src/matrix.rs:1488): c[m x n] = a[m x k] * b[k x n] */
+t4a_gpu_status t4a_gpu_gemm_f64(const double* a, const double* b, size_t m, size_t k, size_t n, double* c);
+
+/* batched_mat_mul_same_shape(batch,m,k,n,&a,&b) (matrix.rs:1538-1612): operands are column-major
+ * [m,k,batch] and [k,n,batch] (batch slowest), result [m,n,batch]. */
+t4a_gpu_status t4a_gpu_gemm_batched_f64(size_t batch, size_t m, size_t k, size_t n, const double* a,
+                                        const double* b, double* c);
+
+/* triangular_solve_matrix(A,B,left_side,lower,transpose_a,unit_diagonal) (tensorbackend/src/backend.rs:924):
+ * solves op(A) X = B (left_side) or X op(A) = B.  A is na x na, B and X are bm x bn. */
+t4a_gpu_status t4a_gpu_trsm_f64(const double* a, size_t na, const double* b, size_t bm, size_t bn,
+                                int32_t left_side, int32_t lower, int32_t transpose_a, int32_t unit_diagonal,
+                                double* x);
+
+/* solve_matrix(&A,&B) (backend.rs:865): A n x n, B n x nrhs, X n x nrhs.  Partial-pivot LU.
+ * Returns T4A_GPU_SINGULAR_MATRIX for an exactly singular A. */
+t4a_gpu_status t4a_gpu_solve_f64(const double* a, size_t n, const double* b, size_t nrhs, double* x);
+
+/* =====================================================================================
+ * TCI2 sweep driver (opaque handle; state resident on the device between calls)
+ * ===================================================================================== */
+typedef struct t4a_gpu_tci2 t4a_gpu_tci2;
+
+/* TCI2Options (tensorci/src/tensorci2.rs:73-170).  max_bond_dim == 0 <=> None. */
+typedef struct t4a_gpu_tci2_options {
+    double tolerance;                 /* 1e-8 */
+    size_t max_iter;                  /* 20 */
+    size_t max_bond_dim;              /* 0 = None */
+    int32_t pivot_search;             /* 0 = Full (only Full is implemented; 1 = Rook -> NOT_IMPLEMENTED) */
+    int32_t normalize_error;          /* 1 */
+    size_t verbosity;                 /* 0 */
+    size_t max_nglobal_pivot;         /* 5 */
+    size_t nsearch;                   /* 5 */
+    int32_t sweep_strategy;           /* 0 Forward, 1 Backward, 2 BackAndForth (default) */
+    int32_t strictly_nested;          /* 0 */
+    size_t ncheck_history;            /* 3 */
+    double tol_margin_global_search;  /* 10.0 */
+    int32_t has_seed;                 /* 0 = None */
+    int32_t reserved_;
+    uint64_t seed;
+} t4a_gpu_tci2_options;
+
+/* Fills `opts` with TCI2Options::default() (tensorci2.rs:152-170). */
+t4a_gpu_status t4a_gpu_tci2_options_default(t4a_gpu_tci2_options* opts);
+
+/* TCI2Termination (tensorci2.rs:197-205) */
+#define T4A_GPU_TCI2_CONVERGED 0
+#define T4A_GPU_TCI2_MAX_BOND_DIMENSION 1
+#define T4A_GPU_TCI2_MAX_ITERATIONS 2
+
+/* TensorCI2::new(local_dims) (tensorci2.rs:380-404) */
+t4a_gpu_status t4a_gpu_tci2_new(const size_t* local_dims, size_t n_sites, t4a_gpu_tci2** out);
+void t4a_gpu_tci2_release(t4a_gpu_tci2* h);
+
+/* The user function `f` of crossinterpolate2 (tensorci2.rs:1513-1524), given either as
+ *  (a) a built-in device functor: function id + parameters + integer weight table
+ *      (include/t4a_testfunctions.h; weights has n_acc * sum(local_dims) entries), evaluated on the GPU; or
+ *  (b) a host batch callback, the `batched_f` contract of the reference: one value per requested index.
+ *      idx is n_sites x n_pts column-major (same shape as treetci's GlobalIndexBatch,
+ *      treetci/src/update.rs:213-232); returns the number of values written (must equal n_pts),
+ *      or a negative value to abort. */
+t4a_gpu_status t4a_gpu_tci2_set_builtin_function(t4a_gpu_tci2* h, int32_t fid, int32_t n_acc,
+                                                 const double* params /* [T4A_FN_MAX_PARAMS] */,
+                                                 const uint64_t* weights);
+typedef int64_t (*t4a_gpu_batch_eval_fn)(void* ctx, const uint32_t* idx, size_t n_sites, size_t n_pts, double* out);
+t4a_gpu_status t4a_gpu_tci2_set_callback(t4a_gpu_tci2* h, t4a_gpu_batch_eval_fn cb, void* ctx);
+
+/* TensorCI2::add_global_pivots (tensorci2.rs:668-711). pivots: n_sites x n_pivots column-major. */
+t4a_gpu_status t4a_gpu_tci2_add_global_pivots(t4a_gpu_tci2* h, const size_t* pivots, size_t n_pivots);
+
+/* crossinterpolate2(f, batched_f, local_dims, initial_pivots, options) (tensorci2.rs:1513-1563) on a fresh
+ * handle: add initial pivots (n_pivots == 0 -> the all-zeros index), initialise max_sample_value, run
+ * optimize_with_finder (tensorci2.rs:1626-1802) including the final sweep1site. */
+t4a_gpu_status t4a_gpu_tci2_crossinterpolate2(t4a_gpu_tci2* h, const size_t* initial_pivots, size_t n_pivots,
+                                              const t4a_gpu_tci2_options* options);
+
+/* optimize_with_finder on the current state (tensorci2.rs:1626).  `final_sweep1site == 0` skips the final
+ * cleanup sweep (tensorci2.rs:1787) so that callers (bench) can time individual half-sweeps. */
+t4a_gpu_status t4a_gpu_tci2_optimize(t4a_gpu_tci2* h, const t4a_gpu_tci2_options* options, int32_t final_sweep1site);
+
+/* TensorCI2::sweep2site(&f,&batched_f,forward,&options) (tensorci2.rs:746-798) */
+t4a_gpu_status t4a_gpu_tci2_sweep2site(t4a_gpu_tci2* h, int32_t forward, const t4a_gpu_tci2_options* options);
+/* TensorCI2::sweep1site(&f,forward,rel_tol,abs_tol,max_bond_dim,update_tensors) (tensorci2.rs:865-915) */
+t4a_gpu_status t4a_gpu_tci2_sweep1site(t4a_gpu_tci2* h, int32_t forward, double rel_tol, double abs_tol,
+                                       size_t max_bond_dim /* 0 = usize::MAX */, int32_t update_tensors);
+/* TensorCI2::fill_site_tensors(&f) (tensorci2.rs:1065-1186) */
+t4a_gpu_status t4a_gpu_tci2_fill_site_tensors(t4a_gpu_tci2* h);
+/* TensorCI2::make_canonical (tensorci2.rs:1201-1221) */
+t4a_gpu_status t4a_gpu_tci2_make_canonical(t4a_gpu_tci2* h, double rel_tol, double abs_tol, size_t max_bond_dim);
+
+/* accessors (tensorci2.rs:585-649, 713-721) */
+t4a_gpu_status t4a_gpu_tci2_len(const t4a_gpu_tci2* h, size_t* out);
+t4a_gpu_status t4a_gpu_tci2_rank(const t4a_gpu_tci2* h, size_t* out);
+t4a_gpu_status t4a_gpu_tci2_link_dims(const t4a_gpu_tci2* h, size_t* out /* n_sites-1 */);
+t4a_gpu_status t4a_gpu_tci2_max_sample_value(const t4a_gpu_tci2* h, double* out);
+t4a_gpu_status t4a_gpu_tci2_max_bond_error(const t4a_gpu_tci2* h, double* out);
+t4a_gpu_status t4a_gpu_tci2_bond_errors(const t4a_gpu_tci2* h, double* out /* n_sites-1 */);
+/* query-then-fill: out == NULL returns the count only */
+t4a_gpu_status t4a_gpu_tci2_pivot_errors(const t4a_gpu_tci2* h, size_t* count, double* out);
+/* which: 0 = i_set(site), 1 = j_set(site); entries are `width` digits each, returned as
+ * width x count column-major (one multi-index per column). out == NULL queries count/width. */
+t4a_gpu_status t4a_gpu_tci2_index_set(const t4a_gpu_tci2* h, int32_t which, size_t site, size_t* count,
+                                      size_t* width, size_t* out);
+/* TensorCI2::from_index_sets resume format (tensorci2.rs:551-582): overwrite one I/J set. */
+t4a_gpu_status t4a_gpu_tci2_set_index_set(t4a_gpu_tci2* h, int32_t which, size_t site, size_t count,
+                                          const size_t* data);
+t4a_gpu_status t4a_gpu_tci2_set_max_sample_value(t4a_gpu_tci2* h, double value);
+t4a_gpu_status t4a_gpu_tci2_clear_history(t4a_gpu_tci2* h);
+/* site_tensor(p): dims3 = (left, site, right); column-major [left, site, right] like simplett Tensor3
+ * (simplett/src/tensor.rs:13-18). out == NULL queries the dims only. */
+t4a_gpu_status t4a_gpu_tci2_site_tensor(const t4a_gpu_tci2* h, size_t site, size_t* dims3, double* out);
+/* Same tensor copied device-to-device into caller-provided device memory (used for the RCCL all-gather
+ * of cores; `out_device` must hold left*site*right doubles). */
+t4a_gpu_status t4a_gpu_tci2_site_tensor_device(const t4a_gpu_tci2* h, size_t site, void* out_device);
+/* Overwrite a site tensor from device memory (receiving side of the core all-gather). */
+t4a_gpu_status t4a_gpu_tci2_set_site_tensor_device(t4a_gpu_tci2* h, size_t site, const size_t* dims3,
+                                                   const void* in_device);
+
+/* results of the last optimize / crossinterpolate2 call (TCI2OptimizationResult, tensorci2.rs:236-245) */
+t4a_gpu_status t4a_gpu_tci2_n_iterations(const t4a_gpu_tci2* h, size_t* out);
+t4a_gpu_status t4a_gpu_tci2_history(const t4a_gpu_tci2* h, size_t* ranks, double* errors);
+t4a_gpu_status t4a_gpu_tci2_termination(const t4a_gpu_tci2* h, int32_t* out);
+
+/* to_tensor_train().evaluate(idx) for a batch of points (simplett/src/traits.rs:146-212), evaluated on
+ * the device.  idx: n_sites x n_pts column-major. */
+t4a_gpu_status t4a_gpu_tci2_evaluate(t4a_gpu_tci2* h, const size_t* idx, size_t n_pts, double* out);
+/* to_tensor_train().sum() (traits.rs:231-275) */
+t4a_gpu_status t4a_gpu_tci2_sum(t4a_gpu_tci2* h, double* out);
+
+/* Restrict fill_site_tensors to the sites s with s % world == rank (site-sharded multi-GPU mode,
+ * SURVEY.md §8e).  world == 1 restores the default.  Cores of foreign sites are left untouched and are
+ * expected to arrive through t4a_gpu_tci2_set_site_tensor_device. */
+t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t world);
+
+/* ---- measurement hooks (bench.py) ---- */
+/* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
+t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);
+/* HIP-event profile accumulated since the last reset.  Slots (all in milliseconds / counts):
+ *  [0] rrlu kernel ms  [1] rrlu launches  [2] pi-eval kernel ms  [3] pi launches
+ *  [4] fill_site_tensors device ms  [5] fill calls  [6] factor (trsm+gemm) ms  [7] factor calls
+ *  [8] total pivot steps executed by the rrlu kernel  [9] algorithmic rrlu bytes (BASELINE.md §2 model)
+ *  [10] algorithmic flops (rrlu + factors + fill)  [11] function evaluations */
+#define T4A_GPU_PROFILE_SLOTS 16
+t4a_gpu_status t4a_gpu_tci2_profile_enable(t4a_gpu_tci2* h, int32_t enable);
+t4a_gpu_status t4a_gpu_tci2_profile_reset(t4a_gpu_tci2* h);
+t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out /* [T4A_GPU_PROFILE_SLOTS] */);
+
+/* Evaluate a built-in function on the device for a batch of full multi-indices (parity check of the
+ * workload definition itself).  idx: n_sites x n_pts column-major. */
+t4a_gpu_status t4a_gpu_fn_eval(int32_t fid, int32_t n_acc, const double* params, const uint64_t* weights,
+                               const size_t* local_dims, size_t n_sites, const size_t* idx, size_t n_pts,
+                               double* out);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* T4A_GPU_H */

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Builds tensor4all-rs_amd/lib/libt4a_gpu.so (gfx950) with hipcc.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the bit-exact pivot contract needs
+separately rounded multiply/subtract exactly like the Rust reference.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "build")
+SOURCES = ["kernels_rrlu.hip", "kernels_pi.hip", "kernels_dense.hip", "engine.hip", "tci2.hip", "capi.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden"]
+HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", "tci2.hpp", "../../include/t4a_gpu.h",
+           "../../include/t4a_testfunctions.h"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OUT, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    lib = os.path.join(OUT, "libt4a_gpu.so")
+    if force or jobs or not os.path.exists(lib):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

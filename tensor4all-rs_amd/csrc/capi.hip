@@ -1,0 +1,839 @@
+// capi.hip — extern "C" surface declared in include/t4a_gpu.h.
+// No exception crosses the boundary (tensor4all-capi/src/lib.rs:139-162 convention): every entry point
+// runs inside `guarded`, which stores the message in a thread-local slot and returns a status code.
+#include <memory>
+#include <mutex>
+
+#include "tci2.hpp"
+
+struct t4a_gpu_tci2 {
+    t4a::Tci2 impl;
+    explicit t4a_gpu_tci2(const std::vector<size_t>& d) : impl(d) {}
+};
+
+namespace t4a {
+const std::string& last_error_ref();
+
+namespace {
+
+template <class F> t4a_gpu_status guarded(F&& body)
+{
+    try {
+        body();
+        return T4A_GPU_SUCCESS;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("out of host memory");
+        return T4A_GPU_INTERNAL_ERROR;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return T4A_GPU_INTERNAL_ERROR;
+    } catch (...) {
+        set_last_error("unknown internal error");
+        return T4A_GPU_INTERNAL_ERROR;
+    }
+}
+
+#define T4A_REQUIRE_PTR(p)                                                       \
+    do {                                                                         \
+        if ((p) == nullptr) throw ::t4a::Error(T4A_GPU_NULL_POINTER, #p " is null"); \
+    } while (0)
+
+std::mutex g_dense_mutex;
+std::unique_ptr<Engine> g_dense_engine;
+
+// One process-global engine for the handle-less dense entry points, serialised by a mutex exactly like the
+// reference's global default backend (tensorbackend/src/context.rs:318-338).
+Engine& dense_engine()
+{
+    if (!g_dense_engine) g_dense_engine.reset(new Engine());
+    return *g_dense_engine;
+}
+
+TCI2Options convert_options(const t4a_gpu_tci2_options* o)
+{
+    if (!o) throw Error(T4A_GPU_NULL_POINTER, "options is null");
+    TCI2Options r;
+    r.tolerance = o->tolerance;
+    r.max_iter = o->max_iter;
+    r.max_bond_dim = o->max_bond_dim;
+    r.pivot_search = o->pivot_search;
+    r.normalize_error = o->normalize_error != 0;
+    r.verbosity = o->verbosity;
+    r.max_nglobal_pivot = o->max_nglobal_pivot;
+    r.nsearch = o->nsearch;
+    r.sweep_strategy = o->sweep_strategy;
+    r.ncheck_history = o->ncheck_history;
+    r.strictly_nested = o->strictly_nested != 0;
+    r.tol_margin_global_search = o->tol_margin_global_search;
+    r.has_seed = o->has_seed != 0;
+    r.seed = o->seed;
+    if (r.sweep_strategy < 0 || r.sweep_strategy > 2) throw Error(T4A_GPU_INVALID_ARGUMENT, "invalid sweep_strategy");
+    if (r.pivot_search < 0 || r.pivot_search > 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "invalid pivot_search");
+    return r;
+}
+
+void upload(Engine& e, double* dst, const double* src, size_t count)
+{
+    if (count == 0) return;
+    T4A_HIP(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyHostToDevice, e.stream()));
+    T4A_HIP(hipStreamSynchronize(e.stream()));
+}
+void download(Engine& e, double* dst, const double* src, size_t count)
+{
+    if (count == 0) return;
+    T4A_HIP(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToHost, e.stream()));
+    T4A_HIP(hipStreamSynchronize(e.stream()));
+}
+
+size_t checked_mul(size_t a, size_t b, const char* what)
+{
+    if (a != 0 && b > std::numeric_limits<size_t>::max() / a)
+        throw Error(T4A_GPU_INVALID_ARGUMENT, std::string(what) + " overflows usize");
+    return a * b;
+}
+
+} // namespace
+} // namespace t4a
+
+using namespace t4a;
+
+extern "C" {
+
+t4a_gpu_status t4a_gpu_last_error_message(char* buf, size_t buf_len, size_t* required_len)
+{
+    const std::string& msg = last_error_ref();
+    const size_t need = msg.size() + 1;
+    if (required_len) *required_len = need;
+    if (!buf) return required_len ? T4A_GPU_SUCCESS : T4A_GPU_NULL_POINTER;
+    if (buf_len < need) return T4A_GPU_BUFFER_TOO_SMALL;
+    std::memcpy(buf, msg.c_str(), need);
+    return T4A_GPU_SUCCESS;
+}
+
+t4a_gpu_status t4a_gpu_device_count(int32_t* out_count)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out_count);
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+        *out_count = c;
+    });
+}
+
+t4a_gpu_status t4a_gpu_set_device(int32_t device)
+{
+    return guarded([&] {
+        require_device();
+        T4A_HIP(hipSetDevice(device));
+    });
+}
+
+const char* t4a_gpu_version(void) { return "t4a-mi355x 0.1.0 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------ dense
+t4a_gpu_status t4a_gpu_rrlu_f64(double* a_inout, size_t m, size_t n, size_t max_bond_dim, double rel_tol,
+                                double abs_tol, int32_t left_orthogonal, size_t* row_perm, size_t* col_perm,
+                                size_t* npivots, double* last_error)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(row_perm);
+        T4A_REQUIRE_PTR(col_perm);
+        T4A_REQUIRE_PTR(npivots);
+        T4A_REQUIRE_PTR(last_error);
+        const size_t count = checked_mul(m, n, "matrix shape");
+        if (count) T4A_REQUIRE_PTR(a_inout);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_a = e.pi(std::max<size_t>(count, 1));
+        upload(e, d_a, a_inout, count);
+        RrLUOptions o;
+        o.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim;
+        o.rel_tol = rel_tol;
+        o.abs_tol = abs_tol;
+        o.left_orthogonal = left_orthogonal != 0;
+        LuciResult r = e.luci(d_a, (int)m, (int)n, o, false, true);
+        if (count) download(e, a_inout, e.lu_buf(), count);
+        for (size_t i = 0; i < m; ++i) row_perm[i] = (size_t)r.row_perm[i];
+        for (size_t j = 0; j < n; ++j) col_perm[j] = (size_t)r.col_perm[j];
+        *npivots = (size_t)r.rank;
+        *last_error = r.last_error;
+    });
+}
+
+t4a_gpu_status t4a_gpu_luci_f64(const double* a, size_t m, size_t n, size_t max_bond_dim, double rel_tol,
+                                double abs_tol, int32_t left_orthogonal, size_t* rank, size_t* rows, size_t* cols,
+                                double* pivot_errors, double* left, double* right)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(rank);
+        T4A_REQUIRE_PTR(rows);
+        T4A_REQUIRE_PTR(cols);
+        T4A_REQUIRE_PTR(pivot_errors);
+        const size_t count = checked_mul(m, n, "matrix shape");
+        if (count) {
+            T4A_REQUIRE_PTR(a);
+            T4A_REQUIRE_PTR(left);
+            T4A_REQUIRE_PTR(right);
+        }
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_a = e.pi(std::max<size_t>(count, 1));
+        upload(e, d_a, a, count);
+        RrLUOptions o;
+        o.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim;
+        o.rel_tol = rel_tol;
+        o.abs_tol = abs_tol;
+        o.left_orthogonal = left_orthogonal != 0;
+        LuciResult r = e.luci(d_a, (int)m, (int)n, o, true, false);
+        *rank = (size_t)r.rank;
+        for (int i = 0; i < r.rank; ++i) {
+            rows[i] = (size_t)r.row_perm[i];
+            cols[i] = (size_t)r.col_perm[i];
+        }
+        for (size_t i = 0; i < r.pivot_errors.size(); ++i) pivot_errors[i] = r.pivot_errors[i];
+        if (r.rank > 0) {
+            download(e, left, e.left(), m * (size_t)r.rank);
+            download(e, right, e.right(), n * (size_t)r.rank);
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_gemm_batched_f64(size_t batch, size_t m, size_t k, size_t n, const double* a, const double* b,
+                                        double* c)
+{
+    return guarded([&] {
+        const size_t na = checked_mul(checked_mul(m, k, "a shape"), batch, "a shape");
+        const size_t nb = checked_mul(checked_mul(k, n, "b shape"), batch, "b shape");
+        const size_t nc = checked_mul(checked_mul(m, n, "c shape"), batch, "c shape");
+        if (na) T4A_REQUIRE_PTR(a);
+        if (nb) T4A_REQUIRE_PTR(b);
+        if (nc) T4A_REQUIRE_PTR(c);
+        if (nc == 0) return;
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        e.d_tmp.reserve(std::max<size_t>(na + nb, 1));
+        e.d_tmp2.reserve(nc);
+        double* da = e.d_tmp.get();
+        double* db = da + na;
+        upload(e, da, a, na);
+        upload(e, db, b, nb);
+        if (k == 0) {
+            fill_launch(e.d_tmp2.get(), nc, 0.0, e.stream());
+        } else {
+            GemmDesc g;
+            g.m = (int)m;
+            g.n = (int)n;
+            g.k = (int)k;
+            g.A = da;
+            g.lda = (int)m;
+            g.strideA = (long long)(m * k);
+            g.transA = 0;
+            g.B = db;
+            g.ldb = (int)k;
+            g.strideB = (long long)(k * n);
+            g.transB = 0;
+            g.C = e.d_tmp2.get();
+            g.ldc = (int)m;
+            g.strideC = (long long)(m * n);
+            g.alpha = 1.0;
+            g.beta = 0.0;
+            g.batch = (int)batch;
+            gemm_launch(g, e.stream());
+        }
+        T4A_HIP(hipGetLastError());
+        download(e, c, e.d_tmp2.get(), nc);
+    });
+}
+
+t4a_gpu_status t4a_gpu_gemm_f64(const double* a, const double* b, size_t m, size_t k, size_t n, double* c)
+{
+    return t4a_gpu_gemm_batched_f64(1, m, k, n, a, b, c);
+}
+
+t4a_gpu_status t4a_gpu_trsm_f64(const double* a, size_t na, const double* b, size_t bm, size_t bn, int32_t left_side,
+                                int32_t lower, int32_t transpose_a, int32_t unit_diagonal, double* x)
+{
+    return guarded([&] {
+        const size_t acount = checked_mul(na, na, "a shape");
+        const size_t bcount = checked_mul(bm, bn, "b shape");
+        if (left_side ? (bm != na) : (bn != na))
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "triangular_solve: dimension mismatch between A and B");
+        if (acount) T4A_REQUIRE_PTR(a);
+        if (bcount) {
+            T4A_REQUIRE_PTR(b);
+            T4A_REQUIRE_PTR(x);
+        }
+        if (bcount == 0) return;
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        hipStream_t st = e.stream();
+        e.d_tmp.reserve(2 * acount + 1);
+        e.d_tmp2.reserve(2 * bcount + 1);
+        double* dA = e.d_tmp.get();
+        double* dAt = dA + acount;
+        double* dB = e.d_tmp2.get();
+        double* dBt = dB + bcount;
+        upload(e, dA, a, acount);
+        upload(e, dB, b, bcount);
+        // reduce to a left-side solve with an untransposed triangular matrix T:  T Y = R
+        //   left : op(A) X = B           -> T = op(A),   R = B
+        //   right: X op(A) = B           -> T = op(A)^T, R = B^T, X = Y^T
+        const bool need_t = left_side ? (transpose_a != 0) : (transpose_a == 0);
+        const double* T = dA;
+        bool low = lower != 0;
+        if (need_t) {
+            transpose_launch(dA, (int)na, (int)na, (int)na, dAt, (int)na, st);
+            T = dAt;
+            low = !low;
+        }
+        double* R = dB;
+        int rn = (int)bm, rrhs = (int)bn;
+        if (!left_side) {
+            transpose_launch(dB, (int)bm, (int)bn, (int)bm, dBt, (int)bn, st);
+            R = dBt;
+            rn = (int)bn;
+            rrhs = (int)bm;
+        }
+        TrsmProblem tp;
+        tp.T = T;
+        tp.ldt = (int)na;
+        tp.n = (int)na;
+        tp.B = R;
+        tp.ldb = rn;
+        tp.nrhs = rrhs;
+        tp.lower = low ? 1 : 0;
+        tp.unit_diag = unit_diagonal ? 1 : 0;
+        DevBuf<TrsmProblem> dprob;
+        dprob.reserve(1);
+        T4A_HIP(hipMemcpyAsync(dprob.get(), &tp, sizeof(tp), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st));
+        trsm_left_batched_launch(dprob.get(), 1, (int)na, rrhs, st);
+        if (!left_side) {
+            transpose_launch(dBt, (int)bn, (int)bm, (int)bn, dB, (int)bm, st);
+            R = dB;
+        }
+        T4A_HIP(hipGetLastError());
+        download(e, x, R, bcount);
+    });
+}
+
+t4a_gpu_status t4a_gpu_solve_f64(const double* a, size_t n, const double* b, size_t nrhs, double* x)
+{
+    return guarded([&] {
+        const size_t acount = checked_mul(n, n, "a shape");
+        const size_t bcount = checked_mul(n, nrhs, "b shape");
+        if (acount) T4A_REQUIRE_PTR(a);
+        if (bcount) {
+            T4A_REQUIRE_PTR(b);
+            T4A_REQUIRE_PTR(x);
+        }
+        if (bcount == 0) return;
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        hipStream_t st = e.stream();
+        e.d_tmp.reserve(acount + 1);
+        e.d_tmp2.reserve(bcount + 1);
+        upload(e, e.d_tmp.get(), a, acount);
+        upload(e, e.d_tmp2.get(), b, bcount);
+        DevBuf<int> dpiv;
+        dpiv.reserve(n + 1);
+        DevBuf<LuProblem> dlp;
+        dlp.reserve(1);
+        DevBuf<TrsmProblem> dtp;
+        dtp.reserve(2);
+        LuProblem lp;
+        lp.A = e.d_tmp.get();
+        lp.lda = (int)n;
+        lp.n = (int)n;
+        lp.piv = dpiv.get();
+        lp.info = dpiv.get() + n;
+        lp.B = e.d_tmp2.get();
+        lp.ldb = (int)n;
+        lp.nrhs = (int)nrhs;
+        TrsmProblem t[2];
+        t[0].T = lp.A;
+        t[0].ldt = lp.lda;
+        t[0].n = lp.n;
+        t[0].B = lp.B;
+        t[0].ldb = lp.ldb;
+        t[0].nrhs = lp.nrhs;
+        t[0].lower = 1;
+        t[0].unit_diag = 1;
+        t[1] = t[0];
+        t[1].lower = 0;
+        t[1].unit_diag = 0;
+        T4A_HIP(hipMemcpyAsync(dlp.get(), &lp, sizeof(lp), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(dtp.get(), t, sizeof(t), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st));
+        lu_batched_launch(dlp.get(), 1, (int)n, st);
+        int info = 0;
+        T4A_HIP(hipMemcpyAsync(&info, lp.info, sizeof(int), hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipStreamSynchronize(st));
+        if (info != 0) throw Error(T4A_GPU_SINGULAR_MATRIX, "solve: matrix is singular");
+        trsm_left_batched_launch(dtp.get(), 1, (int)n, (int)nrhs, st);
+        trsm_left_batched_launch(dtp.get() + 1, 1, (int)n, (int)nrhs, st);
+        T4A_HIP(hipGetLastError());
+        download(e, x, e.d_tmp2.get(), bcount);
+    });
+}
+
+t4a_gpu_status t4a_gpu_fn_eval(int32_t fid, int32_t n_acc, const double* params, const uint64_t* weights,
+                               const size_t* local_dims, size_t n_sites, const size_t* idx, size_t n_pts, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(params);
+        T4A_REQUIRE_PTR(weights);
+        T4A_REQUIRE_PTR(local_dims);
+        if (n_pts == 0) return;
+        T4A_REQUIRE_PTR(idx);
+        T4A_REQUIRE_PTR(out);
+        if (fid < 0 || fid >= T4A_FN_COUNT || n_acc < 1 || n_acc > T4A_FN_MAX_ACC)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown built-in function");
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        // fold every full index into its accumulators as a "row"; a single all-zero "column"
+        std::vector<size_t> off(n_sites);
+        size_t total = 0;
+        for (size_t s = 0; s < n_sites; ++s) {
+            off[s] = total;
+            total += local_dims[s];
+        }
+        std::vector<uint64_t> acc(n_pts * (size_t)n_acc, 0), zero((size_t)n_acc, 0);
+        for (size_t p = 0; p < n_pts; ++p)
+            for (int k = 0; k < n_acc; ++k) {
+                uint64_t a = 0;
+                for (size_t s = 0; s < n_sites; ++s) {
+                    const size_t v = idx[p * n_sites + s];
+                    if (v >= local_dims[s]) throw Error(T4A_GPU_INVALID_ARGUMENT, "index out of bounds");
+                    a += weights[(size_t)k * total + off[s] + v];
+                }
+                acc[p * n_acc + k] = a;
+            }
+        DevBuf<uint64_t> dacc;
+        dacc.reserve(acc.size() + zero.size());
+        T4A_HIP(hipMemcpyAsync(dacc.get(), acc.data(), acc.size() * 8, hipMemcpyHostToDevice, e.stream()));
+        T4A_HIP(hipMemcpyAsync(dacc.get() + acc.size(), zero.data(), zero.size() * 8, hipMemcpyHostToDevice, e.stream()));
+        T4A_HIP(hipStreamSynchronize(e.stream()));
+        e.d_tmp.reserve(n_pts);
+        FnDevice fn;
+        fn.fid = fid;
+        fn.n_acc = n_acc;
+        std::memcpy(fn.params, params, sizeof(double) * T4A_FN_MAX_PARAMS);
+        pi_eval_launch(fn, dacc.get(), (int)n_pts, dacc.get() + acc.size(), 1, e.d_tmp.get(), (int)n_pts, false, nullptr,
+                       e.stream());
+        T4A_HIP(hipGetLastError());
+        download(e, out, e.d_tmp.get(), n_pts);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ TCI2
+t4a_gpu_status t4a_gpu_tci2_options_default(t4a_gpu_tci2_options* o)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(o);
+        std::memset(o, 0, sizeof(*o));
+        o->tolerance = 1e-8;
+        o->max_iter = 20;
+        o->max_bond_dim = 0;
+        o->pivot_search = 0;
+        o->normalize_error = 1;
+        o->verbosity = 0;
+        o->max_nglobal_pivot = 5;
+        o->nsearch = 5;
+        o->sweep_strategy = 2;
+        o->strictly_nested = 0;
+        o->ncheck_history = 3;
+        o->tol_margin_global_search = 10.0;
+        o->has_seed = 0;
+        o->seed = 0;
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_new(const size_t* local_dims, size_t n_sites, t4a_gpu_tci2** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        if (n_sites) T4A_REQUIRE_PTR(local_dims);
+        std::vector<size_t> d(local_dims, local_dims + n_sites);
+        if (d.size() < 2) throw Error(T4A_GPU_INVALID_ARGUMENT, "local_dims should have at least 2 elements");
+        for (size_t s = 0; s < d.size(); ++s) {
+            if (d[s] == 0)
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "local dimension at site " + std::to_string(s) + " must be positive");
+            if (d[s] > 0xFFFFFFFFull) throw Error(T4A_GPU_INVALID_ARGUMENT, "local dimension too large");
+        }
+        *out = new t4a_gpu_tci2(d);
+    });
+}
+
+void t4a_gpu_tci2_release(t4a_gpu_tci2* h) { delete h; }
+
+t4a_gpu_status t4a_gpu_tci2_set_builtin_function(t4a_gpu_tci2* h, int32_t fid, int32_t n_acc, const double* params,
+                                                 const uint64_t* weights)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(params);
+        T4A_REQUIRE_PTR(weights);
+        h->impl.set_builtin(fid, n_acc, params, weights);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_set_callback(t4a_gpu_tci2* h, t4a_gpu_batch_eval_fn cb, void* ctx)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.set_callback(cb, ctx);
+    });
+}
+
+static std::vector<std::vector<uint32_t>> pivots_from(const t4a_gpu_tci2* h, const size_t* pivots, size_t n_pivots)
+{
+    const size_t ns = h->impl.len();
+    std::vector<std::vector<uint32_t>> p(n_pivots, std::vector<uint32_t>(ns));
+    for (size_t k = 0; k < n_pivots; ++k)
+        for (size_t s = 0; s < ns; ++s) {
+            const size_t v = pivots[s + ns * k];
+            if (v > 0xFFFFFFFFull) throw Error(T4A_GPU_INVALID_ARGUMENT, "pivot value out of bounds");
+            p[k][s] = (uint32_t)v;
+        }
+    return p;
+}
+
+t4a_gpu_status t4a_gpu_tci2_add_global_pivots(t4a_gpu_tci2* h, const size_t* pivots, size_t n_pivots)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pivots) T4A_REQUIRE_PTR(pivots);
+        h->impl.add_global_pivots(pivots_from(h, pivots, n_pivots));
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_crossinterpolate2(t4a_gpu_tci2* h, const size_t* initial_pivots, size_t n_pivots,
+                                              const t4a_gpu_tci2_options* options)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pivots) T4A_REQUIRE_PTR(initial_pivots);
+        TCI2Options o = convert_options(options);
+        o.validate(); // options are validated before any callback runs (tensorci2/tests/mod.rs:7-144)
+        h->impl.crossinterpolate2(pivots_from(h, initial_pivots, n_pivots), o);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_optimize(t4a_gpu_tci2* h, const t4a_gpu_tci2_options* options, int32_t final_sweep1site)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.optimize(convert_options(options), final_sweep1site != 0);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_sweep2site(t4a_gpu_tci2* h, int32_t forward, const t4a_gpu_tci2_options* options)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.sweep2site(forward != 0, convert_options(options));
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_sweep1site(t4a_gpu_tci2* h, int32_t forward, double rel_tol, double abs_tol,
+                                       size_t max_bond_dim, int32_t update_tensors)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.sweep1site(forward != 0, rel_tol, abs_tol,
+                           max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim, update_tensors != 0);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_fill_site_tensors(t4a_gpu_tci2* h)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.fill_site_tensors();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_make_canonical(t4a_gpu_tci2* h, double rel_tol, double abs_tol, size_t max_bond_dim)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.make_canonical(rel_tol, abs_tol, max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_len(const t4a_gpu_tci2* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.len();
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_rank(const t4a_gpu_tci2* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.rank();
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_link_dims(const t4a_gpu_tci2* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        const auto v = h->impl.link_dims();
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_max_sample_value(const t4a_gpu_tci2* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.max_sample_value;
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_max_bond_error(const t4a_gpu_tci2* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.max_bond_error();
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_bond_errors(const t4a_gpu_tci2* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        for (size_t i = 0; i < h->impl.bond_errors.size(); ++i) out[i] = h->impl.bond_errors[i];
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_pivot_errors(const t4a_gpu_tci2* h, size_t* count, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        *count = h->impl.pivot_errors.size();
+        if (out)
+            for (size_t i = 0; i < h->impl.pivot_errors.size(); ++i) out[i] = h->impl.pivot_errors[i];
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_index_set(const t4a_gpu_tci2* h, int32_t which, size_t site, size_t* count, size_t* width,
+                                      size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        T4A_REQUIRE_PTR(width);
+        if (site >= h->impl.len() || which < 0 || which > 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "site/which out of range");
+        const IndexSet& s = which == 0 ? h->impl.i_set[site] : h->impl.j_set[site];
+        *count = s.count;
+        *width = s.width;
+        if (out)
+            for (size_t k = 0; k < s.count * s.width; ++k) out[k] = s.d[k];
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_set_index_set(t4a_gpu_tci2* h, int32_t which, size_t site, size_t count, const size_t* data)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (site >= h->impl.len() || which < 0 || which > 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "site/which out of range");
+        IndexSet& s = which == 0 ? h->impl.i_set[site] : h->impl.j_set[site];
+        const size_t first_site = which == 0 ? 0 : site + 1;
+        if (count * s.width) T4A_REQUIRE_PTR(data);
+        IndexSet n;
+        n.width = s.width;
+        n.count = count;
+        n.d.resize(count * s.width);
+        for (size_t k = 0; k < count; ++k)
+            for (size_t q = 0; q < s.width; ++q) {
+                const size_t v = data[k * s.width + q];
+                if (v >= h->impl.local_dims[first_site + q]) throw Error(T4A_GPU_INVALID_ARGUMENT, "index out of bounds");
+                n.d[k * s.width + q] = (uint32_t)v;
+            }
+        s = n;
+        h->impl.invalidate_site_tensors();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_set_max_sample_value(t4a_gpu_tci2* h, double value)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.max_sample_value = value;
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_clear_history(t4a_gpu_tci2* h)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.i_set_history.clear();
+        h->impl.j_set_history.clear();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_site_tensor(const t4a_gpu_tci2* h, size_t site, size_t* dims3, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(dims3);
+        if (site >= h->impl.len()) throw Error(T4A_GPU_INVALID_ARGUMENT, "site out of range");
+        t4a_gpu_tci2* hh = const_cast<t4a_gpu_tci2*>(h);
+        if (!out) {
+            dims3[0] = h->impl.cores[site].l;
+            dims3[1] = h->impl.cores[site].s;
+            dims3[2] = h->impl.cores[site].r;
+            return;
+        }
+        std::vector<double> v = hh->impl.site_tensor_host(site, dims3);
+        std::memcpy(out, v.data(), v.size() * sizeof(double));
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_site_tensor_device(const t4a_gpu_tci2* h, size_t site, void* out_device)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out_device);
+        if (site >= h->impl.len()) throw Error(T4A_GPU_INVALID_ARGUMENT, "site out of range");
+        t4a_gpu_tci2* hh = const_cast<t4a_gpu_tci2*>(h);
+        const DevCore& c = h->impl.cores[site];
+        if (c.size()) {
+            T4A_HIP(hipMemcpyAsync(out_device, c.buf.get(), c.size() * sizeof(double), hipMemcpyDeviceToDevice,
+                                   hh->impl.eng.stream()));
+            T4A_HIP(hipStreamSynchronize(hh->impl.eng.stream()));
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_set_site_tensor_device(t4a_gpu_tci2* h, size_t site, const size_t* dims3,
+                                                   const void* in_device)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(dims3);
+        if (site >= h->impl.len()) throw Error(T4A_GPU_INVALID_ARGUMENT, "site out of range");
+        if (dims3[1] != h->impl.local_dims[site]) throw Error(T4A_GPU_INVALID_ARGUMENT, "site dimension mismatch");
+        DevCore& c = h->impl.cores[site];
+        const size_t count = dims3[0] * dims3[1] * dims3[2];
+        c.buf.reserve(std::max<size_t>(count, 1));
+        c.l = dims3[0];
+        c.s = dims3[1];
+        c.r = dims3[2];
+        if (count) {
+            T4A_REQUIRE_PTR(in_device);
+            T4A_HIP(hipMemcpyAsync(c.buf.get(), in_device, count * sizeof(double), hipMemcpyDeviceToDevice,
+                                   h->impl.eng.stream()));
+            T4A_HIP(hipStreamSynchronize(h->impl.eng.stream()));
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_n_iterations(const t4a_gpu_tci2* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.errors_hist.size();
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_history(const t4a_gpu_tci2* h, size_t* ranks, double* errors)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        for (size_t i = 0; i < h->impl.errors_hist.size(); ++i) {
+            if (ranks) ranks[i] = h->impl.ranks_hist[i];
+            if (errors) errors[i] = h->impl.errors_hist[i];
+        }
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_termination(const t4a_gpu_tci2* h, int32_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.termination;
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_evaluate(t4a_gpu_tci2* h, const size_t* idx, size_t n_pts, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pts == 0) return;
+        T4A_REQUIRE_PTR(idx);
+        T4A_REQUIRE_PTR(out);
+        const size_t ns = h->impl.len();
+        std::vector<uint32_t> u(n_pts * ns);
+        for (size_t k = 0; k < u.size(); ++k) {
+            if (idx[k] > 0xFFFFFFFFull) throw Error(T4A_GPU_INVALID_ARGUMENT, "evaluate: index out of bounds");
+            u[k] = (uint32_t)idx[k];
+        }
+        std::vector<double> v = h->impl.evaluate(u.data(), n_pts);
+        std::memcpy(out, v.data(), n_pts * sizeof(double));
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_sum(t4a_gpu_tci2* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.sum();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t world)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (world == 0 || rank >= world) throw Error(T4A_GPU_INVALID_ARGUMENT, "invalid shard (rank, world)");
+        h->impl.shard_rank = rank;
+        h->impl.shard_world = world;
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        for (size_t b = 0; b < h->impl.last_sweep_shapes.size(); ++b)
+            for (int k = 0; k < 3; ++k) out[3 * b + k] = h->impl.last_sweep_shapes[b][k];
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_profile_enable(t4a_gpu_tci2* h, int32_t enable)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.eng.prof.enabled = enable != 0;
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_profile_reset(t4a_gpu_tci2* h)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        for (double& v : h->impl.eng.prof.v) v = 0.0;
+    });
+}
+t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        for (int i = 0; i < T4A_GPU_PROFILE_SLOTS; ++i) out[i] = h->impl.eng.prof.v[i];
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,326 @@
+// engine.hip — device pipeline "matrix -> rrLU -> LUCI factors"
+// (matrix_luci_factors_from_matrix / factors_from_rrlu, tensor4all-core/src/matrix_luci.rs:256-290,366-374).
+#include "engine.hpp"
+
+#include <cmath>
+#include <mutex>
+
+namespace t4a {
+
+namespace {
+thread_local std::string g_last_error;
+
+__global__ void __launch_bounds__(256) tri_extract_kernel(const double* __restrict__ in, int ldi, int rows, int cols,
+                                                          int keep_lower, int unit_diag, double* __restrict__ out,
+                                                          int ldo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    for (int j = blockIdx.y; j < cols; j += gridDim.y) {
+        double v;
+        if (i == j)
+            v = unit_diag ? 1.0 : in[(size_t)j * ldi + i];
+        else if ((keep_lower && i > j) || (!keep_lower && i < j))
+            v = in[(size_t)j * ldi + i];
+        else
+            v = 0.0;
+        out[(size_t)j * ldo + i] = v;
+    }
+}
+} // namespace
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const std::string& last_error_ref() { return g_last_error; }
+
+void require_device()
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        throw Error(T4A_GPU_NO_DEVICE,
+                    "no HIP device available: the tensor4all-rs MI355X backend has no CPU fallback (hipGetDeviceCount: " +
+                        std::string(hipGetErrorString(e)) + ")");
+}
+
+void tri_extract_launch(const double* in, int ldi, int rows, int cols, int keep_lower, int unit_diag, double* out,
+                        int ldo, hipStream_t stream)
+{
+    if (rows <= 0 || cols <= 0) return;
+    dim3 grid((rows + 255) / 256, cols < 1024 ? cols : 1024);
+    hipLaunchKernelGGL(tri_extract_kernel, grid, dim3(256), 0, stream, in, ldi, rows, cols, keep_lower, unit_diag, out,
+                       ldo);
+}
+
+Engine::Engine()
+{
+    require_device();
+    int dev = 0;
+    T4A_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    T4A_HIP(hipGetDeviceProperties(&prop, dev));
+    num_cus_ = prop.multiProcessorCount;
+    T4A_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    ev_rrlu_.init();
+    ev_fac_.init();
+}
+
+Engine::~Engine()
+{
+    if (stream_) {
+        (void)hipStreamSynchronize(stream_);
+        (void)hipStreamDestroy(stream_);
+    }
+}
+
+LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy)
+{
+    LuciResult r;
+    r.M = M;
+    r.N = N;
+    r.row_perm.resize(M);
+    r.col_perm.resize(N);
+    for (int i = 0; i < M; ++i) r.row_perm[i] = i;
+    for (int j = 0; j < N; ++j) r.col_perm[j] = j;
+    if (M == 0 || N == 0) {
+        r.rank = 0;
+        r.last_error = 0.0; // n >= min(nr, nc) = 0 -> error = 0 (matrixlu.rs:811)
+        r.pivot_errors = {0.0};
+        r.has_factors = need_factors;
+        return r;
+    }
+    if (M > 65535 || N > 65535)
+        throw Error(T4A_GPU_NOT_IMPLEMENTED, "rrLU: matrices with more than 65535 rows or columns are not supported");
+
+    size_t ms = opts.max_bond_dim;
+    if (ms > (size_t)M) ms = M;
+    if (ms > (size_t)N) ms = N;
+    const int max_steps = (int)ms;
+    const RrluPlan plan = rrlu_make_plan(M, N, num_cus_);
+
+    d_rowperm_.reserve(M);
+    d_colperm_.reserve(N);
+    d_ires_.reserve(4);
+    d_dres_.reserve(2);
+    d_pivvals_.reserve(max_steps > 0 ? max_steps : 1);
+    const bool keep_lu = need_factors || want_lu_copy;
+    if (keep_lu) d_lu_.reserve((size_t)M * N);
+    if (plan.W > 1) {
+        d_keys_.reserve(rrlu_keys_bytes(plan) / sizeof(unsigned long long));
+        d_cols_.reserve(rrlu_cols_bytes(plan, M) / sizeof(unsigned long long));
+    }
+    T4A_HIP(hipMemsetAsync(d_ires_.get(), 0, 4 * sizeof(int), stream_));
+    T4A_HIP(hipMemsetAsync(d_dres_.get(), 0, 2 * sizeof(double), stream_));
+
+    RrluArgs a;
+    a.A = d_a;
+    a.Aout = keep_lu ? d_lu_.get() : nullptr;
+    a.M = M;
+    a.N = N;
+    a.max_steps = max_steps;
+    a.rel_tol = opts.rel_tol;
+    a.abs_tol = opts.abs_tol;
+    a.left_orth = opts.left_orthogonal ? 1 : 0;
+    a.W = plan.W;
+    a.cpw = plan.cpw;
+    a.Mld = plan.Mld;
+    a.row_perm = d_rowperm_.get();
+    a.col_perm = d_colperm_.get();
+    a.iresult = d_ires_.get();
+    a.dresult = d_dres_.get();
+    a.pivot_vals = d_pivvals_.get();
+    a.keys = d_keys_.get();
+    a.cols = d_cols_.get();
+    a.spin_limit = 1u << 20;
+
+    if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.a, stream_));
+    rrlu_launch(plan, a, stream_);
+    T4A_HIP(hipGetLastError());
+    if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.b, stream_));
+
+    h_perm_.reserve((size_t)M + N + 4);
+    h_res_.reserve((size_t)max_steps + 4);
+    int* hp = h_perm_.get();
+    double* hr = h_res_.get();
+    T4A_HIP(hipMemcpyAsync(hp, d_ires_.get(), 4 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    T4A_HIP(hipMemcpyAsync(hp + 4, d_rowperm_.get(), (size_t)M * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    T4A_HIP(hipMemcpyAsync(hp + 4 + M, d_colperm_.get(), (size_t)N * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    T4A_HIP(hipMemcpyAsync(hr, d_dres_.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    if (max_steps > 0)
+        T4A_HIP(hipMemcpyAsync(hr + 2, d_pivvals_.get(), (size_t)max_steps * sizeof(double), hipMemcpyDeviceToHost,
+                               stream_));
+    T4A_HIP(hipStreamSynchronize(stream_));
+
+    if (prof.enabled) {
+        float ms_f = 0.f;
+        T4A_HIP(hipEventElapsedTime(&ms_f, ev_rrlu_.a, ev_rrlu_.b));
+        prof.v[0] += ms_f;
+        prof.v[1] += 1.0;
+    }
+    if (hp[1] != 0)
+        throw Error(T4A_GPU_KERNEL_TIMEOUT, "rrLU kernel: inter-workgroup hand-off timed out (bounded spin gave up)");
+    r.rank = hp[0];
+    if (max_steps == 0) {
+        // while-loop never entered: lu.error stays NaN unless the matrix is "full rank" (min(M,N) == 0)
+        r.last_error = std::numeric_limits<double>::quiet_NaN();
+    } else {
+        r.last_error = hr[0];
+    }
+    {
+        unsigned long long bits;
+        std::memcpy(&bits, &hr[1], sizeof(bits));
+        double am;
+        std::memcpy(&am, &bits, sizeof(am));
+        r.abs_max = am;
+    }
+    for (int i = 0; i < M; ++i) r.row_perm[i] = hp[4 + i];
+    for (int j = 0; j < N; ++j) r.col_perm[j] = hp[4 + M + j];
+    r.pivot_errors.resize(r.rank + 1);
+    for (int k = 0; k < r.rank; ++k) r.pivot_errors[k] = std::sqrt(hr[2 + k] * hr[2 + k]);
+    r.pivot_errors[r.rank] = r.last_error;
+    // work model
+    {
+        double bytes = 8.0 * M * N, flops = 0.0;
+        for (int k = 0; k < r.rank; ++k) {
+            const double mr = (double)(M - k - 1), nr_ = (double)(N - k - 1);
+            bytes += 16.0 * mr * nr_;
+            flops += 2.0 * mr * nr_ + mr;
+        }
+        prof.v[8] += r.rank;
+        prof.v[9] += bytes;
+        prof.v[10] += flops;
+    }
+    if (hp[2] != 0) throw Error(T4A_GPU_NAN_ENCOUNTERED, "NaN encountered in L or U of the rrLU factorisation");
+
+    if (need_factors) {
+        if (prof.enabled) T4A_HIP(hipEventRecord(ev_fac_.a, stream_));
+        build_factors(r, opts.left_orthogonal);
+        if (prof.enabled) {
+            T4A_HIP(hipEventRecord(ev_fac_.b, stream_));
+            T4A_HIP(hipStreamSynchronize(stream_));
+            float ms_f = 0.f;
+            T4A_HIP(hipEventElapsedTime(&ms_f, ev_fac_.a, ev_fac_.b));
+            prof.v[6] += ms_f;
+            prof.v[7] += 1.0;
+        }
+        const double rr = r.rank;
+        prof.v[10] += (M - rr) * rr * rr + 2.0 * rr * rr * N;
+        r.has_factors = true;
+    }
+    return r;
+}
+
+// factors_from_rrlu (matrix_luci.rs:256-279) on the factored matrix in d_lu_ (permuted coordinates).
+void Engine::build_factors(const LuciResult& r, bool left_orth)
+{
+    const int M = r.M, N = r.N, rk = r.rank;
+    d_left_.reserve((size_t)M * (rk > 0 ? rk : 1));
+    d_right_.reserve((size_t)N * (rk > 0 ? rk : 1));
+    if (rk == 0) return;
+    const double* lu = d_lu_.get();
+    d_w1_.reserve((size_t)(M > N ? M : N) * rk + (size_t)rk * rk);
+    d_w2_.reserve((size_t)(M > N ? M : N) * rk + (size_t)rk * rk);
+    d_trsm_.reserve(1);
+    h_trsm_.reserve(1);
+
+    if (left_orth) {
+        // left = P_row^T [I_r ; L21 L11^{-1}]   (rrlu_cols_times_pivot_solve, matrix_luci.rs:206-229)
+        double* Wl = d_w1_.get(); // M x rk, permuted order
+        set_identity_launch(Wl, M, rk, M, stream_);
+        if (rk < M) {
+            double* Tt = d_w2_.get();                 // rk x rk : transpose of the leading block (upper part = L11^T)
+            double* Bt = d_w2_.get() + (size_t)rk * rk; // rk x (M-rk) : L21^T
+            transpose_launch(lu, rk, rk, M, Tt, rk, stream_);
+            transpose_launch(lu + rk, M - rk, rk, M, Bt, rk, stream_);
+            TrsmProblem tp;
+            tp.T = Tt;
+            tp.ldt = rk;
+            tp.n = rk;
+            tp.B = Bt;
+            tp.ldb = rk;
+            tp.nrhs = M - rk;
+            tp.lower = 0;
+            tp.unit_diag = 1; // L11 has a unit diagonal (dividing by 1.0 is exact)
+            *h_trsm_.get() = tp;
+            T4A_HIP(hipMemcpyAsync(d_trsm_.get(), h_trsm_.get(), sizeof(TrsmProblem), hipMemcpyHostToDevice, stream_));
+            trsm_left_batched_launch(d_trsm_.get(), 1, rk, M - rk, stream_);
+            transpose_launch(Bt, rk, M - rk, rk, Wl + rk, M, stream_);
+        }
+        scatter_rows_launch(Wl, M, d_rowperm_.get(), M, rk, d_left_.get(), M, stream_);
+        // right = (L11 U) P_col^T   (rrlu_rowmatrix, matrix_luci.rs:191-204)
+        double* L11 = d_w2_.get();
+        double* Ue = d_w1_.get(); // reuse after the scatter above has been enqueued (same stream: ordered)
+        tri_extract_launch(lu, M, rk, rk, 1, 1, L11, rk, stream_);
+        // U needs its own buffer: Wl is still being read by the scatter only until it completes (in-order stream)
+        tri_extract_launch(lu, M, rk, N, 0, 0, Ue, rk, stream_);
+        double* Rp = d_w2_.get() + (size_t)rk * rk; // rk x N
+        GemmDesc g;
+        g.m = rk;
+        g.n = N;
+        g.k = rk;
+        g.A = L11;
+        g.lda = rk;
+        g.strideA = 0;
+        g.transA = 0;
+        g.B = Ue;
+        g.ldb = rk;
+        g.strideB = 0;
+        g.transB = 0;
+        g.C = Rp;
+        g.ldc = rk;
+        g.strideC = 0;
+        g.alpha = 1.0;
+        g.beta = 0.0;
+        g.batch = 1;
+        gemm_launch(g, stream_);
+        scatter_cols_launch(Rp, rk, rk, d_colperm_.get(), N, d_right_.get(), rk, stream_);
+    } else {
+        // left = P_row^T (L U11)   (rrlu_colmatrix, matrix_luci.rs:176-189)
+        double* Le = d_w1_.get();                    // M x rk lower trapezoid, diagonal kept
+        double* U11 = d_w2_.get();                   // rk x rk unit upper
+        double* Lp = d_w2_.get() + (size_t)rk * rk;  // M x rk product, permuted order
+        tri_extract_launch(lu, M, M, rk, 1, 0, Le, M, stream_);
+        tri_extract_launch(lu, M, rk, rk, 0, 1, U11, rk, stream_);
+        GemmDesc g;
+        g.m = M;
+        g.n = rk;
+        g.k = rk;
+        g.A = Le;
+        g.lda = M;
+        g.strideA = 0;
+        g.transA = 0;
+        g.B = U11;
+        g.ldb = rk;
+        g.strideB = 0;
+        g.transB = 0;
+        g.C = Lp;
+        g.ldc = M;
+        g.strideC = 0;
+        g.alpha = 1.0;
+        g.beta = 0.0;
+        g.batch = 1;
+        gemm_launch(g, stream_);
+        scatter_rows_launch(Lp, M, d_rowperm_.get(), M, rk, d_left_.get(), M, stream_);
+        // right = [I_r , U11^{-1} U12] P_col^T   (rrlu_pivot_solve_times_rows, matrix_luci.rs:231-254)
+        double* Wr = d_w1_.get(); // rk x N (ordered after the gemm that read Le on the same stream)
+        set_identity_launch(Wr, rk, N, rk, stream_);
+        if (rk < N) {
+            gather_launch(lu + (size_t)M * rk, M, nullptr, rk, nullptr, N - rk, Wr + (size_t)rk * rk, rk, stream_);
+            TrsmProblem tp;
+            tp.T = lu;
+            tp.ldt = M;
+            tp.n = rk;
+            tp.B = Wr + (size_t)rk * rk;
+            tp.ldb = rk;
+            tp.nrhs = N - rk;
+            tp.lower = 0;
+            tp.unit_diag = 1; // U11 carries a forced unit diagonal (matrixlu.rs:647-651)
+            *h_trsm_.get() = tp;
+            T4A_HIP(hipMemcpyAsync(d_trsm_.get(), h_trsm_.get(), sizeof(TrsmProblem), hipMemcpyHostToDevice, stream_));
+            trsm_left_batched_launch(d_trsm_.get(), 1, rk, N - rk, stream_);
+        }
+        scatter_cols_launch(Wr, rk, rk, d_colperm_.get(), N, d_right_.get(), rk, stream_);
+    }
+    T4A_HIP(hipGetLastError());
+}
+
+} // namespace t4a

@@ -1,0 +1,87 @@
+// engine.hpp — device engine shared by the dense C-ABI entry points and the TCI2 driver:
+// owns the HIP stream, work buffers and the "Π -> rrLU -> LUCI factors" pipeline
+// (matrix_luci_factors_from_matrix, tensor4all-core/src/matrix_luci.rs:366-374).
+#pragma once
+
+#include <array>
+#include <limits>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace t4a {
+
+struct RrLUOptions { // core/src/matrixlu.rs:688-708
+    size_t max_bond_dim = std::numeric_limits<size_t>::max();
+    double rel_tol = 1e-14;
+    double abs_tol = 0.0;
+    bool left_orthogonal = true;
+};
+
+struct LuciResult {
+    int M = 0, N = 0;
+    int rank = 0;
+    std::vector<int> row_perm, col_perm;   // full permutations (RrLU::row_permutation / col_permutation)
+    std::vector<double> pivot_errors;      // rank + 1 entries (RrLU::pivot_errors, matrixlu.rs:361-365)
+    double last_error = 0.0;
+    double abs_max = 0.0;                  // max sqrt(v*v) over the input matrix
+    bool has_factors = false;              // d_left (M x rank), d_right (rank x N) valid on the engine
+};
+
+struct Profile {
+    double v[T4A_GPU_PROFILE_SLOTS] = {0};
+    bool enabled = false;
+};
+
+class Engine {
+public:
+    Engine();
+    ~Engine();
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    hipStream_t stream() const { return stream_; }
+    int num_cus() const { return num_cus_; }
+    void sync() { T4A_HIP(hipStreamSynchronize(stream_)); }
+
+    // Device matrix buffers reused across calls.
+    double* pi(size_t count)
+    {
+        d_pi_.reserve(count);
+        return d_pi_.get();
+    }
+    double* lu_buf() { return d_lu_.get(); }
+    double* left() { return d_left_.get(); }
+    double* right() { return d_right_.get(); }
+
+    // Runs rrLU on the M x N column-major matrix at d_a (device) and optionally builds the LUCI factors.
+    // `want_lu_copy` additionally keeps the factored matrix (permuted coordinates) in lu_buf().
+    LuciResult luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy);
+
+    Profile prof;
+
+    // scratch for the TCI2 driver
+    DevBuf<double> d_tmp, d_tmp2;
+
+private:
+    void build_factors(const LuciResult& r, bool left_orth);
+
+    hipStream_t stream_ = nullptr;
+    int num_cus_ = 0;
+    DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_pivvals_;
+    DevBuf<int> d_rowperm_, d_colperm_, d_ires_;
+    DevBuf<double> d_dres_;
+    DevBuf<unsigned long long> d_keys_, d_cols_;
+    DevBuf<TrsmProblem> d_trsm_;
+    PinBuf<int> h_perm_;
+    PinBuf<double> h_res_;
+    PinBuf<TrsmProblem> h_trsm_;
+    EventTimer ev_rrlu_, ev_fac_;
+};
+
+// triangle extraction helper kernels (engine.hip)
+void tri_extract_launch(const double* in, int ldi, int rows, int cols, int keep_lower, int unit_diag, double* out,
+                        int ldo, hipStream_t stream);
+
+} // namespace t4a

@@ -1,0 +1,125 @@
+// kernels.hpp — launch interfaces of the hand-written gfx950 kernels.
+// All pointers are device pointers; all matrices column-major.  Launchers enqueue on `stream` and do
+// not synchronise.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/t4a_testfunctions.h"
+
+namespace t4a {
+
+// ------------------------------------------------------------------------------------------------
+// K2: full-pivot rank-revealing LU (replaces rrlu_mut, tensor4all-core/src/matrixlu.rs:735-819)
+// ------------------------------------------------------------------------------------------------
+struct RrluWorkspace;
+
+struct RrluPlan {
+    int W = 1;       // cooperating workgroups (1 => single-workgroup kernel, no mailbox)
+    int T = 256;     // threads per workgroup
+    int cpw = 0;     // columns per workgroup
+    int Mld = 0;     // LDS leading dimension of a slab column
+    size_t lds_bytes = 0;
+};
+
+// Chooses (W, T) for an M x N problem.  Honours T4A_RRLU_W / T4A_RRLU_T environment overrides.
+RrluPlan rrlu_make_plan(int M, int N, int num_cus);
+
+struct RrluArgs {
+    const double* A;            // M x N input (ld = M)
+    double* Aout;               // M x N factored matrix in permuted coordinates, or nullptr
+    int M, N;
+    int max_steps;              // min(max_bond_dim, M, N)
+    double rel_tol, abs_tol;
+    int left_orth;
+    int W, cpw, Mld;
+    int* row_perm;              // [M]  posrow: original row sitting at permuted position p
+    int* col_perm;              // [N]
+    int* iresult;               // [0] npivots  [1] timeout flag  [2] NaN-in-LU flag
+    double* dresult;            // [0] last error (RrLU::error)  [1] max |a_ij| sample seen in A (sqrt(v*v))
+    double* pivot_vals;         // [max_steps] value of the k-th pivot (diag of U resp. L)
+    unsigned long long* keys;   // [2][W][4] tagged key granules (zeroed before every launch)
+    unsigned long long* cols;   // [2][W][M] candidate pivot columns (f64 bits)
+    unsigned spin_limit;
+};
+
+// Bytes of mailbox storage needed for a plan.
+size_t rrlu_keys_bytes(const RrluPlan& plan);
+size_t rrlu_cols_bytes(const RrluPlan& plan, int M);
+
+// Enqueue memset of the key mailbox + the kernel.
+void rrlu_launch(const RrluPlan& plan, const RrluArgs& args, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// K1: candidate-matrix build (replaces the Π loop, tensor4all-tensorci/src/tensorci2.rs:1859-1893)
+// out[i + ld*j] = g(rowacc[i] + colacc[j]); *max_abs_bits = max over entries of bits(sqrt(v*v)).
+// rowacc/colacc are [count][n_acc] uint64.  If `transpose_out`, writes out[j + ld*i].
+// ------------------------------------------------------------------------------------------------
+struct FnDevice {
+    int fid;
+    int n_acc;
+    double params[T4A_FN_MAX_PARAMS];
+};
+void pi_eval_launch(const FnDevice& fn, const uint64_t* rowacc, int M, const uint64_t* colacc, int N, double* out,
+                    int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream);
+// max over a dense buffer of bits(sqrt(v*v)) (host-callback path)
+void absmax_launch(const double* data, size_t count, unsigned long long* max_abs_bits, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// Dense helpers
+// ------------------------------------------------------------------------------------------------
+// C[m x n] (ldc) = alpha * op(A)[m x k] * op(B)[k x n] + beta * C, batched with element strides.
+// f64 MFMA 16x16x4 tiles staged through LDS.
+struct GemmDesc {
+    int m, n, k;
+    const double* A; int lda; long long strideA; int transA;
+    const double* B; int ldb; long long strideB; int transB;
+    double* C; int ldc; long long strideC;
+    double alpha, beta;
+    int batch;
+};
+void gemm_launch(const GemmDesc& d, hipStream_t stream);
+
+// out[c + ldo*r] = in[r + ldi*c]  (rows x cols input)
+void transpose_launch(const double* in, int rows, int cols, int ldi, double* out, int ldo, hipStream_t stream);
+
+// Batched left-side triangular solve, one problem per descriptor:  T X = B, X overwrites B.
+//  T: n x n (ldt), lower or upper, optional unit diagonal.  B: n x nrhs (ldb).
+struct TrsmProblem {
+    const double* T; int ldt; int n;
+    double* B; int ldb; int nrhs;
+    int lower; int unit_diag;
+};
+void trsm_left_batched_launch(const TrsmProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream);
+
+// Batched partial-pivot LU in place (one workgroup per problem): A = P^T L U, piv[k] = row swapped with k.
+struct LuProblem {
+    double* A; int lda; int n;
+    int* piv;        // [n]
+    int* info;       // [1]: 0 ok, k+1 = exactly-zero pivot at step k
+    double* B; int ldb; int nrhs; // right-hand sides to which the row swaps are applied (may be null)
+};
+void lu_batched_launch(const LuProblem* d_problems, int n_problems, int max_n, hipStream_t stream);
+
+// gather rows/cols:  out[i + ldo*j] = in[rows[i] + ldi*cols[j]] (rows/cols may be nullptr = identity)
+void gather_launch(const double* in, int ldi, const int* rows, int nrows, const int* cols, int ncols, double* out,
+                   int ldo, hipStream_t stream);
+// scatter rows: out[rows[i] + ldo*j] = in[i + ldi*j];  scatter cols: out[i + ldo*cols[j]] = in[i + ldi*j]
+void scatter_rows_launch(const double* in, int ldi, const int* rows, int nrows, int ncols, double* out, int ldo,
+                         hipStream_t stream);
+void scatter_cols_launch(const double* in, int ldi, int nrows, const int* cols, int ncols, double* out, int ldo,
+                         hipStream_t stream);
+void fill_launch(double* p, size_t count, double value, hipStream_t stream);
+// out (m x r): identity on top (r x r) and zeros below
+void set_identity_launch(double* p, int m, int n, int ld, hipStream_t stream);
+
+// Core packing (tensorci2.rs:1957-1999): see tci2.hip
+// TT evaluation for a batch of points: cores[s] is (l_s, d_s, r_s) col-major; idx is n_sites x n_pts (uint32).
+struct TtCoreDesc { const double* data; int l, d, r; };
+void tt_evaluate_launch(const TtCoreDesc* d_cores, int n_sites, int max_bond, const uint32_t* d_idx, int n_pts,
+                        double* d_out, hipStream_t stream);
+
+} // namespace t4a

@@ -1,0 +1,441 @@
+// kernels_dense.hip — dense f64 kernels under the TCI2 sweep (K3/K4/K5 of SURVEY.md §2):
+//   gemm (f64 MFMA 16x16x4, LDS-staged)      <- mat_mul / batched_mat_mul_same_shape (tensorbackend/src/matrix.rs:1488,1538)
+//   batched left triangular solve            <- triangular_solve_matrix (tensorbackend/src/backend.rs:924)
+//   batched partial-pivot LU                 <- solve_matrix (backend.rs:865, tenferro `solve`)
+//   transpose / gather / scatter utilities   <- submatrix, transpose, apply_*_permutation (matrix.rs:1126,1233;
+//                                               core/src/matrix_luci.rs:156-174)
+//   batched tensor-train evaluation          <- AbstractTensorTrain::evaluate (simplett/src/traits.rs:146-212)
+// Values of these ops are tolerance-level in the reference (third-party tenferro); pivot choice in the LU is
+// "first maximum of |a_ik|".  Built with -ffp-contract=off so the non-MFMA kernels round like the CPU oracle.
+#include "kernels.hpp"
+
+namespace t4a {
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// GEMM: 64x64 block tile, BK = 16, 4 waves (2x2), each wave a 32x32 tile = 2x2 MFMA 16x16x4 blocks.
+// The MFMA computes D' = B^T A^T = C^T so that a lane's accumulator column index runs over C ROWS
+// (lane&15 = 16 consecutive rows of one C column -> 128-byte contiguous stores).
+// ------------------------------------------------------------------------------------------------
+constexpr int GBM = 64, GBN = 64, GBK = 16, GPAD = 4;
+
+__global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
+{
+    __shared__ double As[GBK][GBM + GPAD]; // As[k][m]
+    __shared__ double Bs[GBK][GBN + GPAD]; // Bs[k][n]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
+    const int bz = blockIdx.z;
+    const double* A = d.A + (size_t)bz * d.strideA;
+    const double* B = d.B + (size_t)bz * d.strideB;
+    double* C = d.C + (size_t)bz * d.strideC;
+    // element strides of op(A)(m,k) and op(B)(k,n)
+    const long long sam = d.transA ? d.lda : 1, sak = d.transA ? 1 : d.lda;
+    const long long sbk = d.transB ? d.ldb : 1, sbn = d.transB ? 1 : d.ldb;
+
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    for (int k0 = 0; k0 < d.k; k0 += GBK) {
+        // stage A tile (64 x 16) and B tile (16 x 64); pick the thread mapping whose fast index is the
+        // unit-stride index of the operand
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int r, kk;
+            if (!d.transA) {
+                r = tid & 63;
+                kk = (tid >> 6) + 4 * q;
+            } else {
+                kk = tid & 15;
+                r = (tid >> 4) + 16 * q;
+            }
+            const int gm = m0 + r, gk = k0 + kk;
+            As[kk][r] = (gm < d.m && gk < d.k) ? A[(long long)gm * sam + (long long)gk * sak] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int c, kk;
+            if (!d.transB) {
+                kk = tid & 15;
+                c = (tid >> 4) + 16 * q;
+            } else {
+                c = tid & 63;
+                kk = (tid >> 6) + 4 * q;
+            }
+            const int gn = n0 + c, gk = k0 + kk;
+            Bs[kk][c] = (gn < d.n && gk < d.k) ? B[(long long)gk * sbk + (long long)gn * sbn] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GBK; ks += 4) {
+            const int kk = ks + (lane >> 4);
+            double bn[2], am[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bn[ni] = Bs[kk][wn * 32 + ni * 16 + (lane & 15)];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) am[mi] = As[kk][wm * 32 + mi * 16 + (lane & 15)];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    // MFMA "A" operand = B^T (rows = n), "B" operand = A^T (cols = m)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[ni], am[mi], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D'[i' = n][j' = m]: lane -> j' = lane&15 (C row), i' = (lane>>4) + 4*reg (C column)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gm = m0 + wm * 32 + mi * 16 + (lane & 15);
+                const int gn = n0 + wn * 32 + ni * 16 + (lane >> 4) + 4 * reg;
+                if (gm < d.m && gn < d.n) {
+                    double* cp = C + (size_t)gn * d.ldc + gm;
+                    double v = d.alpha * acc[mi][ni][reg];
+                    if (d.beta != 0.0) v = v + d.beta * (*cp);
+                    *cp = v;
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small utilities
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ in, int rows, int cols, int ldi,
+                                                        double* __restrict__ out, int ldo)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int q = ty; q < 32; q += 8) {
+        const int r = r0 + tx, c = c0 + q;
+        tile[q][tx] = (r < rows && c < cols) ? in[(size_t)c * ldi + r] : 0.0;
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const int c = c0 + tx, r = r0 + q; // out(c, r)
+        if (r < rows && c < cols) out[(size_t)r * ldo + c] = tile[tx][q];
+    }
+}
+
+__global__ void __launch_bounds__(256) gather_kernel(const double* __restrict__ in, int ldi, const int* rows,
+                                                     int nrows, const int* cols, int ncols, double* __restrict__ out,
+                                                     int ldo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    const int r = rows ? rows[i] : i;
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+        const int c = cols ? cols[j] : j;
+        out[(size_t)j * ldo + i] = in[(size_t)c * ldi + r];
+    }
+}
+
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const double* __restrict__ in, int ldi, const int* rows,
+                                                           int nrows, int ncols, double* __restrict__ out, int ldo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    const int r = rows[i];
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) out[(size_t)j * ldo + r] = in[(size_t)j * ldi + i];
+}
+
+__global__ void __launch_bounds__(256) scatter_cols_kernel(const double* __restrict__ in, int ldi, int nrows,
+                                                           const int* cols, int ncols, double* __restrict__ out,
+                                                           int ldo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) out[(size_t)cols[j] * ldo + i] = in[(size_t)j * ldi + i];
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(double* p, size_t count, double value)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = value;
+}
+
+__global__ void __launch_bounds__(256) identity_kernel(double* p, int m, int n, int ld)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    for (int j = blockIdx.y; j < n; j += gridDim.y) p[(size_t)j * ld + i] = (i == j) ? 1.0 : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched left triangular solve T X = B (X overwrites B).  blockIdx.y = problem, blockIdx.x = chunk of
+// right-hand-side columns kept in LDS; column-oriented substitution (axpy form, k ascending for lower,
+// descending for upper) so that every element sees its updates in a fixed order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) trsm_left_kernel(const TrsmProblem* problems, int chunk_w)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* Bs = (double*)smem_raw; // n x cw, ld = n
+    const TrsmProblem pr = problems[blockIdx.y];
+    const int n = pr.n;
+    const int c0 = blockIdx.x * chunk_w;
+    if (c0 >= pr.nrhs || n <= 0) return;
+    const int cw = (pr.nrhs - c0) < chunk_w ? (pr.nrhs - c0) : chunk_w;
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int e = tid; e < n * cw; e += T) {
+        const int i = e % n, c = e / n;
+        Bs[(size_t)c * n + i] = pr.B[(size_t)(c0 + c) * pr.ldb + i];
+    }
+    __syncthreads();
+    for (int step = 0; step < n; ++step) {
+        const int k = pr.lower ? step : (n - 1 - step);
+        const double* tk = pr.T + (size_t)k * pr.ldt;
+        if (!pr.unit_diag) {
+            const double dkk = tk[k];
+            for (int c = tid; c < cw; c += T) Bs[(size_t)c * n + k] = Bs[(size_t)c * n + k] / dkk;
+            __syncthreads();
+        }
+        const int lo = pr.lower ? k + 1 : 0;
+        const int cnt = pr.lower ? (n - 1 - k) : k;
+        for (int e = tid; e < cnt * cw; e += T) {
+            const int i = lo + e % cnt, c = e / cnt;
+            const double prod = tk[i] * Bs[(size_t)c * n + k];
+            Bs[(size_t)c * n + i] = Bs[(size_t)c * n + i] - prod;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * cw; e += T) {
+        const int i = e % n, c = e / n;
+        pr.B[(size_t)(c0 + c) * pr.ldb + i] = Bs[(size_t)c * n + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched partial-pivot LU (one workgroup per problem, right-looking, in place in global memory).
+// Pivot = first maximum of |a_ik| over i >= k.  Row swaps are applied to the whole rows of A and to the
+// optional right-hand sides B.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) lu_kernel(const LuProblem* problems)
+{
+    __shared__ double red_v[16];
+    __shared__ int red_i[16];
+    __shared__ int piv_s;
+    __shared__ double pivval_s;
+    const LuProblem pr = problems[blockIdx.x];
+    const int n = pr.n;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    double* A = pr.A;
+    const int lda = pr.lda;
+    if (tid == 0) pr.info[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        // (1) pivot search in column k
+        double bv = -1.0;
+        int bi = 0x7fffffff;
+        for (int i = k + tid; i < n; i += T) {
+            const double v = fabs(A[(size_t)k * lda + i]);
+            if (v > bv || (v == bv && i < bi)) {
+                bv = v;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            red_v[wave] = bv;
+            red_i[wave] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double v = red_v[0];
+            int idx = red_i[0];
+            for (int q = 1; q < nw; ++q)
+                if (red_v[q] > v || (red_v[q] == v && red_i[q] < idx)) {
+                    v = red_v[q];
+                    idx = red_i[q];
+                }
+            piv_s = idx;
+            pr.piv[k] = idx;
+            if (!(v > 0.0)) {
+                if (pr.info[0] == 0) pr.info[0] = k + 1;
+            }
+        }
+        __syncthreads();
+        const int p = piv_s;
+        // (2) swap rows k <-> p of A (all columns) and of B
+        if (p != k && p < n) {
+            for (int c = tid; c < n; c += T) {
+                const double t = A[(size_t)c * lda + k];
+                A[(size_t)c * lda + k] = A[(size_t)c * lda + p];
+                A[(size_t)c * lda + p] = t;
+            }
+            if (pr.B)
+                for (int c = tid; c < pr.nrhs; c += T) {
+                    const double t = pr.B[(size_t)c * pr.ldb + k];
+                    pr.B[(size_t)c * pr.ldb + k] = pr.B[(size_t)c * pr.ldb + p];
+                    pr.B[(size_t)c * pr.ldb + p] = t;
+                }
+        }
+        __syncthreads();
+        if (tid == 0) pivval_s = A[(size_t)k * lda + k];
+        __syncthreads();
+        const double piv = pivval_s;
+        if (piv == 0.0 || piv != piv) continue; // singular column: leave it (info already set)
+        // (3) scale the column
+        for (int i = k + 1 + tid; i < n; i += T) A[(size_t)k * lda + i] = A[(size_t)k * lda + i] / piv;
+        __syncthreads();
+        // (4) rank-1 update of the trailing block
+        const int rem = n - k - 1;
+        for (long long e = tid; e < (long long)rem * rem; e += T) {
+            const int i = k + 1 + (int)(e % rem), c = k + 1 + (int)(e / rem);
+            const double prod = A[(size_t)k * lda + i] * A[(size_t)c * lda + k];
+            A[(size_t)c * lda + i] = A[(size_t)c * lda + i] - prod;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched TT evaluation: one workgroup per point, v <- v * A_s[:, idx_s, :] left to right with the
+// reference's summation order (l ascending, separately rounded multiply/add).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tt_eval_kernel(const TtCoreDesc* cores, int n_sites, int max_bond,
+                                                      const uint32_t* __restrict__ idx, int n_pts, double* out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* cur = (double*)smem_raw;
+    double* nxt = cur + max_bond;
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int pt = blockIdx.x; pt < n_pts; pt += gridDim.x) {
+        const uint32_t* my = idx + (size_t)pt * n_sites;
+        {
+            const TtCoreDesc c0 = cores[0];
+            for (int r = tid; r < c0.r; r += T) cur[r] = c0.data[(size_t)0 + c0.l * ((size_t)my[0] + (size_t)c0.d * r)];
+        }
+        __syncthreads();
+        for (int s = 1; s < n_sites; ++s) {
+            const TtCoreDesc c = cores[s];
+            for (int r = tid; r < c.r; r += T) {
+                const double* col = c.data + (size_t)c.l * ((size_t)my[s] + (size_t)c.d * r);
+                double sum = 0.0;
+                for (int l = 0; l < c.l; ++l) {
+                    const double prod = cur[l] * col[l];
+                    sum = sum + prod;
+                }
+                nxt[r] = sum;
+            }
+            __syncthreads();
+            double* t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        if (tid == 0) out[pt] = cur[0];
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+void gemm_launch(const GemmDesc& d, hipStream_t stream)
+{
+    if (d.m <= 0 || d.n <= 0 || d.batch <= 0) return;
+    dim3 grid((d.m + GBM - 1) / GBM, (d.n + GBN - 1) / GBN, d.batch);
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, stream, d);
+}
+
+void transpose_launch(const double* in, int rows, int cols, int ldi, double* out, int ldo, hipStream_t stream)
+{
+    if (rows <= 0 || cols <= 0) return;
+    dim3 grid((rows + 31) / 32, (cols + 31) / 32);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, rows, cols, ldi, out, ldo);
+}
+
+void gather_launch(const double* in, int ldi, const int* rows, int nrows, const int* cols, int ncols, double* out,
+                   int ldo, hipStream_t stream)
+{
+    if (nrows <= 0 || ncols <= 0) return;
+    dim3 grid((nrows + 255) / 256, ncols < 1024 ? ncols : 1024);
+    hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, stream, in, ldi, rows, nrows, cols, ncols, out, ldo);
+}
+
+void scatter_rows_launch(const double* in, int ldi, const int* rows, int nrows, int ncols, double* out, int ldo,
+                         hipStream_t stream)
+{
+    if (nrows <= 0 || ncols <= 0) return;
+    dim3 grid((nrows + 255) / 256, ncols < 1024 ? ncols : 1024);
+    hipLaunchKernelGGL(scatter_rows_kernel, grid, dim3(256), 0, stream, in, ldi, rows, nrows, ncols, out, ldo);
+}
+
+void scatter_cols_launch(const double* in, int ldi, int nrows, const int* cols, int ncols, double* out, int ldo,
+                         hipStream_t stream)
+{
+    if (nrows <= 0 || ncols <= 0) return;
+    dim3 grid((nrows + 255) / 256, ncols < 1024 ? ncols : 1024);
+    hipLaunchKernelGGL(scatter_cols_kernel, grid, dim3(256), 0, stream, in, ldi, nrows, cols, ncols, out, ldo);
+}
+
+void fill_launch(double* p, size_t count, double value, hipStream_t stream)
+{
+    if (count == 0) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, count, value);
+}
+
+void set_identity_launch(double* p, int m, int n, int ld, hipStream_t stream)
+{
+    if (m <= 0 || n <= 0) return;
+    dim3 grid((m + 255) / 256, n < 1024 ? n : 1024);
+    hipLaunchKernelGGL(identity_kernel, grid, dim3(256), 0, stream, p, m, n, ld);
+}
+
+void trsm_left_batched_launch(const TrsmProblem* d_problems, int n_problems, int max_n, int max_nrhs,
+                              hipStream_t stream)
+{
+    if (n_problems <= 0 || max_n <= 0 || max_nrhs <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_left_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int cw = (int)((128 * 1024) / ((size_t)max_n * 8));
+    if (cw > 32) cw = 32;
+    if (cw < 1) cw = 1;
+    const size_t lds = (size_t)max_n * cw * 8;
+    dim3 grid((max_nrhs + cw - 1) / cw, n_problems);
+    hipLaunchKernelGGL(trsm_left_kernel, grid, dim3(256), lds, stream, d_problems, cw);
+}
+
+void lu_batched_launch(const LuProblem* d_problems, int n_problems, int max_n, hipStream_t stream)
+{
+    if (n_problems <= 0) return;
+    int T = max_n >= 128 ? 1024 : (max_n >= 32 ? 256 : 64);
+    hipLaunchKernelGGL(lu_kernel, dim3(n_problems), dim3(T), 0, stream, d_problems);
+}
+
+void tt_evaluate_launch(const TtCoreDesc* d_cores, int n_sites, int max_bond, const uint32_t* d_idx, int n_pts,
+                        double* d_out, hipStream_t stream)
+{
+    if (n_pts <= 0) return;
+    int blocks = n_pts < 4096 ? n_pts : 4096;
+    const size_t lds = (size_t)2 * (max_bond > 0 ? max_bond : 1) * 8;
+    hipLaunchKernelGGL(tt_eval_kernel, dim3(blocks), dim3(256), lds, stream, d_cores, n_sites, max_bond, d_idx, n_pts,
+                       d_out);
+}
+
+} // namespace t4a

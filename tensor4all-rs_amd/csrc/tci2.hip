@@ -1,0 +1,1011 @@
+// tci2.hip — TensorCI2 driver on the gfx950 engine.
+// Mirrors crates/tensor4all-tensorci/src/tensorci2.rs function by function (line references inline).
+#include "tci2.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <unordered_set>
+
+namespace t4a {
+
+// =================================================================================================
+// small device kernels: packing of factor matrices into site tensors (column-major [left, site, right])
+// =================================================================================================
+namespace {
+
+// core[l,s,r] = mat[(l*S+s) + ldm*r] if (l*S+s) < mrows && r < mcols else 0   (tensorci2.rs:1957-1973, :996-1011)
+__global__ void __launch_bounds__(256) pack_left_core_kernel(const double* __restrict__ mat, int ldm, int mrows,
+                                                             int mcols, double* __restrict__ core, int L, int S, int R)
+{
+    const size_t total = (size_t)L * S * R;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(e % L);
+        const int s = (int)((e / L) % S);
+        const int r = (int)(e / ((size_t)L * S));
+        const int row = l * S + s;
+        core[e] = (row < mrows && r < mcols) ? mat[(size_t)r * ldm + row] : 0.0;
+    }
+}
+
+// core[l,s,r] = mat[l + ldm*(s*R+r)] if l < mrows && (s*R+r) < mcols else 0   (tensorci2.rs:1983-1999, :1020-1036)
+__global__ void __launch_bounds__(256) pack_right_core_kernel(const double* __restrict__ mat, int ldm, int mrows,
+                                                              int mcols, double* __restrict__ core, int L, int S, int R)
+{
+    const size_t total = (size_t)L * S * R;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(e % L);
+        const int s = (int)((e / L) % S);
+        const int r = (int)(e / ((size_t)L * S));
+        const int col = s * R + r;
+        core[e] = (l < mrows && col < mcols) ? mat[(size_t)col * ldm + l] : 0.0;
+    }
+}
+
+// core[l,s,r] = xt[r + ldx*(l*S+s)]   (tensorci2.rs:1167-1181)
+__global__ void __launch_bounds__(256) pack_fill_core_kernel(const double* __restrict__ xt, int ldx,
+                                                             double* __restrict__ core, int L, int S, int R)
+{
+    const size_t total = (size_t)L * S * R;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(e % L);
+        const int s = (int)((e / L) % S);
+        const int r = (int)(e / ((size_t)L * S));
+        core[e] = xt[(size_t)(l * S + s) * ldx + r];
+    }
+}
+
+inline unsigned blocks_for(size_t total)
+{
+    size_t b = (total + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+inline uint64_t splitmix64(uint64_t& s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+std::string key_of(const uint32_t* v, size_t w) { return std::string(reinterpret_cast<const char*>(v), w * sizeof(uint32_t)); }
+
+std::vector<size_t> non_empty_or_first(const std::vector<int>& perm, int rank) // tensorci2.rs:1813-1819
+{
+    std::vector<size_t> v;
+    for (int i = 0; i < rank; ++i) v.push_back((size_t)perm[i]);
+    if (v.empty()) v.push_back(0);
+    return v;
+}
+
+} // namespace
+
+bool IndexSet::contains(const uint32_t* v) const
+{
+    if (width == 0) return count > 0;
+    for (size_t k = 0; k < count; ++k)
+        if (std::memcmp(at(k), v, width * sizeof(uint32_t)) == 0) return true;
+    return false;
+}
+
+void TCI2Options::validate() const // tensorci2.rs:140-149
+{
+    auto nonneg_finite = [](const char* n, double v) {
+        if (!(v >= 0.0) || !std::isfinite(v))
+            throw Error(T4A_GPU_INVALID_ARGUMENT, std::string(n) + " must be finite and non-negative");
+    };
+    nonneg_finite("tolerance", tolerance);
+    nonneg_finite("tol_margin_global_search", tol_margin_global_search);
+    if (max_iter == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "max_iter must be positive");
+    if (ncheck_history == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "ncheck_history must be positive");
+}
+
+// =================================================================================================
+Tci2::Tci2(const std::vector<size_t>& dims) : n_(dims.size()), local_dims(dims) // tensorci2.rs:380-404
+{
+    if (dims.size() < 2) throw Error(T4A_GPU_INVALID_ARGUMENT, "local_dims should have at least 2 elements");
+    for (size_t s = 0; s < dims.size(); ++s)
+        if (dims[s] == 0)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "local dimension at site " + std::to_string(s) + " must be positive");
+    i_set.resize(n_);
+    j_set.resize(n_);
+    for (size_t p = 0; p < n_; ++p) {
+        i_set[p].width = p;
+        j_set[p].width = n_ - p - 1;
+    }
+    cores.resize(n_);
+    for (size_t p = 0; p < n_; ++p) {
+        cores[p].l = 0;
+        cores[p].s = dims[p];
+        cores[p].r = 0;
+    }
+    bond_errors.assign(n_ - 1, 0.0);
+    offset_.resize(n_);
+    total_ = 0;
+    for (size_t s = 0; s < n_; ++s) {
+        offset_[s] = total_;
+        total_ += dims[s];
+    }
+    last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
+    d_maxbits_.reserve(2);
+    ev_pi_.init();
+    ev_fill_.init();
+}
+
+void Tci2::set_builtin(int fid, int n_acc, const double* params, const uint64_t* weights)
+{
+    if (fid < 0 || fid >= T4A_FN_COUNT) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown built-in function id");
+    if (n_acc < 1 || n_acc > T4A_FN_MAX_ACC) throw Error(T4A_GPU_INVALID_ARGUMENT, "n_acc out of range");
+    fn_dev_.fid = fid;
+    fn_dev_.n_acc = n_acc;
+    std::memcpy(fn_dev_.params, params, sizeof(double) * T4A_FN_MAX_PARAMS);
+    weights_.assign(weights, weights + (size_t)n_acc * total_);
+    fn_kind_ = FnKind::Builtin;
+}
+
+void Tci2::set_callback(t4a_gpu_batch_eval_fn cb, void* ctx)
+{
+    if (!cb) throw Error(T4A_GPU_NULL_POINTER, "callback is null");
+    cb_ = cb;
+    cb_ctx_ = ctx;
+    fn_kind_ = FnKind::Callback;
+}
+
+void Tci2::require_fn() const
+{
+    if (fn_kind_ == FnKind::None)
+        throw Error(T4A_GPU_INVALID_ARGUMENT, "no function set: call t4a_gpu_tci2_set_builtin_function or _set_callback");
+}
+
+size_t Tci2::rank() const // tensorci2.rs:600-614
+{
+    size_t r = 0;
+    for (size_t p = 1; p < n_; ++p) r = std::max(r, i_set[p].count);
+    return r;
+}
+
+std::vector<size_t> Tci2::link_dims() const
+{
+    std::vector<size_t> v;
+    for (size_t p = 1; p < n_; ++p) v.push_back(i_set[p].count);
+    return v;
+}
+
+double Tci2::max_bond_error() const // tensorci2.rs:630
+{
+    double m = 0.0;
+    for (double e : bond_errors) m = std::fmax(m, e);
+    return m;
+}
+
+void Tci2::invalidate_site_tensors() // tensorci2.rs:724-728
+{
+    for (size_t p = 0; p < n_; ++p) {
+        cores[p].l = 0;
+        cores[p].s = local_dims[p];
+        cores[p].r = 0;
+    }
+}
+
+void Tci2::add_global_pivots(const std::vector<std::vector<uint32_t>>& pivots) // tensorci2.rs:668-711
+{
+    for (const auto& p : pivots) {
+        if (p.size() != n_)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "Pivot length (" + std::to_string(p.size()) +
+                                                      ") must match number of sites (" + std::to_string(n_) + ")");
+        for (size_t s = 0; s < n_; ++s)
+            if (p[s] >= local_dims[s])
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "pivot value " + std::to_string(p[s]) +
+                                                          " is out of bounds at site " + std::to_string(s));
+    }
+    for (const auto& pivot : pivots) {
+        for (size_t p = 0; p < n_; ++p) {
+            const uint32_t* pre = pivot.data();
+            const uint32_t* suf = pivot.data() + p + 1;
+            if (!i_set[p].contains(pre)) i_set[p].push(pre);
+            if (!j_set[p].contains(suf)) j_set[p].push(suf);
+        }
+    }
+    invalidate_site_tensors();
+}
+
+IndexSet Tci2::kronecker_i(size_t p) const // tensorci2.rs:1224-1234
+{
+    IndexSet r;
+    r.width = p + 1;
+    const IndexSet& src = i_set[p];
+    r.d.reserve(src.count * local_dims[p] * r.width);
+    for (size_t k = 0; k < src.count; ++k)
+        for (size_t li = 0; li < local_dims[p]; ++li) {
+            r.d.insert(r.d.end(), src.at(k), src.at(k) + src.width);
+            r.d.push_back((uint32_t)li);
+            ++r.count;
+        }
+    return r;
+}
+
+IndexSet Tci2::kronecker_j(size_t p) const // tensorci2.rs:1236-1246
+{
+    IndexSet r;
+    r.width = n_ - p;
+    const IndexSet& src = j_set[p];
+    r.d.reserve(src.count * local_dims[p] * r.width);
+    for (size_t li = 0; li < local_dims[p]; ++li)
+        for (size_t k = 0; k < src.count; ++k) {
+            r.d.push_back((uint32_t)li);
+            r.d.insert(r.d.end(), src.at(k), src.at(k) + src.width);
+            ++r.count;
+        }
+    return r;
+}
+
+// order-preserving union (tensorci2.rs:1837-1846); hashing replaces the reference's O(M*chi) `contains`
+void Tci2::union_extras(IndexSet& base, const IndexSet& extras)
+{
+    if (extras.count == 0) return;
+    if (base.width == 0) {
+        if (base.count == 0) base.count = 1;
+        return;
+    }
+    std::unordered_set<std::string> seen;
+    seen.reserve(base.count * 2 + extras.count);
+    for (size_t k = 0; k < base.count; ++k) seen.insert(key_of(base.at(k), base.width));
+    for (size_t k = 0; k < extras.count; ++k) {
+        if (seen.insert(key_of(extras.at(k), base.width)).second) base.push(extras.at(k));
+    }
+}
+
+void Tci2::accumulate(const IndexSet& set, size_t first_site, std::vector<uint64_t>& acc) const
+{
+    const int K = fn_dev_.n_acc;
+    acc.assign(set.count * (size_t)K, 0);
+    for (size_t e = 0; e < set.count; ++e) {
+        const uint32_t* v = set.at(e);
+        for (int k = 0; k < K; ++k) {
+            uint64_t a = 0;
+            const uint64_t* w = weights_.data() + (size_t)k * total_;
+            for (size_t s = 0; s < set.width; ++s) a += w[offset_[first_site + s] + v[s]];
+            acc[e * K + k] = a;
+        }
+    }
+}
+
+// out[ia + a.count*ib] = f(index with a's digits at sites [a0, a0+a.width) and b's at [b0, b0+b.width))
+void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
+                       unsigned long long* d_maxbits)
+{
+    require_fn();
+    const size_t na = a.count, nb = b.count;
+    if (na == 0 || nb == 0) return;
+    if (a.width + b.width != n_) throw Error(T4A_GPU_INTERNAL_ERROR, "eval_matrix: index widths do not cover all sites");
+    hipStream_t st = eng.stream();
+    eng.prof.v[11] += (double)na * (double)nb;
+    if (fn_kind_ == FnKind::Builtin) {
+        const int K = fn_dev_.n_acc;
+        std::vector<uint64_t> ra, rb;
+        accumulate(a, a0, ra);
+        accumulate(b, b0, rb);
+        // pinned staging arena: entries stay valid until the next stream sync
+        const size_t need = ra.size() + rb.size();
+        if (acc_used_ + need > h_acc_.cap) {
+            T4A_HIP(hipStreamSynchronize(st));
+            acc_used_ = 0;
+            h_acc_.reserve(std::max(need * 2, (size_t)1 << 16));
+        }
+        uint64_t* ha = h_acc_.get() + acc_used_;
+        uint64_t* hb = ha + ra.size();
+        acc_used_ += need;
+        std::memcpy(ha, ra.data(), ra.size() * sizeof(uint64_t));
+        std::memcpy(hb, rb.data(), rb.size() * sizeof(uint64_t));
+        d_rowacc_.reserve(ra.size());
+        d_colacc_.reserve(rb.size());
+        T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ha, ra.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(d_colacc_.get(), hb, rb.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        (void)K;
+        pi_eval_launch(fn_dev_, d_rowacc_.get(), (int)na, d_colacc_.get(), (int)nb, d_out, (int)na, false, d_maxbits, st);
+        T4A_HIP(hipGetLastError());
+    } else {
+        // host batch callback: points in row-major order of (ia, ib) — `ia` outer, `ib` inner — exactly the
+        // order the reference hands to batched_f (tensorci2.rs:1862-1869)
+        const size_t npts = na * nb;
+        std::vector<uint32_t> idx(npts * n_);
+        for (size_t ia = 0; ia < na; ++ia)
+            for (size_t ib = 0; ib < nb; ++ib) {
+                uint32_t* dst = idx.data() + (ia * nb + ib) * n_;
+                std::memcpy(dst + a0, a.at(ia), a.width * sizeof(uint32_t));
+                std::memcpy(dst + b0, b.at(ib), b.width * sizeof(uint32_t));
+            }
+        std::vector<double> vals(npts);
+        const int64_t got = cb_(cb_ctx_, idx.data(), n_, npts, vals.data());
+        if (got < 0 || (size_t)got != npts)
+            throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " +
+                                                    std::to_string(npts) + " requested entries");
+        d_vals_.reserve(npts);
+        T4A_HIP(hipMemcpyAsync(d_vals_.get(), vals.data(), npts * sizeof(double), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st)); // `vals` is pageable host memory
+        // vals is (na x nb) row-major == (nb x na) column-major; transpose into the column-major na x nb output
+        transpose_launch(d_vals_.get(), (int)nb, (int)na, (int)nb, d_out, (int)na, st);
+        if (d_maxbits) absmax_launch(d_out, npts, d_maxbits, st);
+        T4A_HIP(hipGetLastError());
+    }
+}
+
+std::vector<double> Tci2::eval_points_host(const std::vector<uint32_t>& idx, size_t n_pts)
+{
+    require_fn();
+    std::vector<double> out(n_pts);
+    if (n_pts == 0) return out;
+    if (fn_kind_ == FnKind::Builtin) {
+        for (size_t p = 0; p < n_pts; ++p) {
+            uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+            for (int k = 0; k < fn_dev_.n_acc; ++k) {
+                const uint64_t* w = weights_.data() + (size_t)k * total_;
+                for (size_t s = 0; s < n_; ++s) acc[k] += w[offset_[s] + idx[p * n_ + s]];
+            }
+            out[p] = t4a_fn_value(fn_dev_.fid, acc, fn_dev_.params);
+        }
+    } else {
+        const int64_t got = cb_(cb_ctx_, idx.data(), n_, n_pts, out.data());
+        if (got < 0 || (size_t)got != n_pts)
+            throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " +
+                                                    std::to_string(n_pts) + " requested entries");
+    }
+    return out;
+}
+
+LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o, bool need_factors)
+{
+    const size_t M = is.count, N = js.count;
+    double* d_pi = eng.pi(M * N);
+    hipStream_t st = eng.stream();
+    if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.a, st));
+    eval_matrix(is, 0, js, is.width, d_pi, nullptr);
+    if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.b, st));
+    LuciResult lu = eng.luci(d_pi, (int)M, (int)N, o, need_factors, false);
+    acc_used_ = 0; // eng.luci synchronised the stream
+    if (eng.prof.enabled) {
+        float ms = 0.f;
+        T4A_HIP(hipEventElapsedTime(&ms, ev_pi_.a, ev_pi_.b));
+        eng.prof.v[2] += ms;
+        eng.prof.v[3] += 1.0;
+    }
+    // update_max_sample_value over every entry of Π (tensorci2.rs:2009-2014)
+    if (lu.abs_max > max_sample_value) max_sample_value = lu.abs_max;
+    return lu;
+}
+
+void Tci2::set_core_zero(size_t site, size_t l, size_t s, size_t r)
+{
+    DevCore& c = cores[site];
+    c.buf.reserve(std::max<size_t>(l * s * r, 1));
+    c.l = l;
+    c.s = s;
+    c.r = r;
+    fill_launch(c.buf.get(), l * s * r, 0.0, eng.stream());
+}
+
+void Tci2::set_core_from_left(size_t site, size_t left_dim, size_t site_dim, const LuciResult& lu)
+{
+    const size_t nb = std::max<size_t>((size_t)lu.rank, 1);
+    DevCore& c = cores[site];
+    c.buf.reserve(left_dim * site_dim * nb);
+    c.l = left_dim;
+    c.s = site_dim;
+    c.r = nb;
+    const size_t total = c.size();
+    hipLaunchKernelGGL(pack_left_core_kernel, dim3(blocks_for(total)), dim3(256), 0, eng.stream(), eng.left(), lu.M, lu.M,
+                       lu.rank, c.buf.get(), (int)left_dim, (int)site_dim, (int)nb);
+}
+
+void Tci2::set_core_from_right(size_t site, size_t site_dim, size_t right_dim, const LuciResult& lu)
+{
+    const size_t nb = std::max<size_t>((size_t)lu.rank, 1);
+    DevCore& c = cores[site];
+    c.buf.reserve(nb * site_dim * right_dim);
+    c.l = nb;
+    c.s = site_dim;
+    c.r = right_dim;
+    const size_t total = c.size();
+    const int ldm = lu.rank > 0 ? lu.rank : 1;
+    hipLaunchKernelGGL(pack_right_core_kernel, dim3(blocks_for(total)), dim3(256), 0, eng.stream(), eng.right(), ldm,
+                       lu.rank, lu.N, c.buf.get(), (int)nb, (int)site_dim, (int)right_dim);
+}
+
+void Tci2::update_pivot_errors(const std::vector<double>& e) // tensorci2.rs:801-808
+{
+    if (pivot_errors.size() < e.size()) pivot_errors.resize(e.size(), 0.0);
+    for (size_t i = 0; i < e.size(); ++i) pivot_errors[i] = std::fmax(pivot_errors[i], e[i]);
+}
+
+// tensorci2.rs:1821-2007
+void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& options, const IndexSet& extra_i,
+                         const IndexSet& extra_j)
+{
+    IndexSet i_comb = kronecker_i(b);
+    IndexSet j_comb = kronecker_j(b + 1);
+    union_extras(i_comb, extra_i);
+    union_extras(j_comb, extra_j);
+    if (i_comb.count == 0 || j_comb.count == 0) return;
+    if (options.pivot_search != 0)
+        throw Error(T4A_GPU_NOT_IMPLEMENTED, "PivotSearchStrategy::Rook is not implemented in the MI355X backend yet");
+
+    const bool extras_used = extra_i.count != 0 || extra_j.count != 0;
+    RrLUOptions lo;
+    lo.max_bond_dim = options.max_bond_dim_or_max();
+    lo.rel_tol = options.tolerance;
+    lo.abs_tol = 0.0;
+    lo.left_orthogonal = left_orthogonal;
+    // the reference always builds the factors; they are only CONSUMED when no extras were merged
+    // (tensorci2.rs:1942-1949), so the device skips the trsm/gemm otherwise.
+    LuciResult lu = luci_on_sets(i_comb, j_comb, lo, !extras_used);
+    if (b < last_sweep_shapes.size()) last_sweep_shapes[b] = {i_comb.count, j_comb.count, (size_t)lu.rank};
+
+    const std::vector<size_t> rows = non_empty_or_first(lu.row_perm, lu.rank);
+    const std::vector<size_t> cols = non_empty_or_first(lu.col_perm, lu.rank);
+    IndexSet ni, nj;
+    ni.width = i_comb.width;
+    nj.width = j_comb.width;
+    for (size_t r : rows) ni.push(i_comb.at(r));
+    for (size_t c : cols) nj.push(j_comb.at(c));
+    i_set[b + 1] = ni;
+    j_set[b] = nj;
+
+    if (extras_used) {
+        if (!lu.pivot_errors.empty()) bond_errors[b] = lu.pivot_errors.back();
+        return;
+    }
+    const size_t left_dim = (b == 0) ? 1 : i_set[b].count;
+    set_core_from_left(b, left_dim, local_dims[b], lu);
+    const size_t right_dim = (b + 1 == n_ - 1) ? 1 : j_set[b + 1].count;
+    set_core_from_right(b + 1, local_dims[b + 1], right_dim, lu);
+    if (!lu.pivot_errors.empty()) bond_errors[b] = lu.pivot_errors.back();
+}
+
+// tensorci2.rs:746-798
+void Tci2::sweep2site(bool forward, const TCI2Options& options)
+{
+    options.validate();
+    require_fn();
+    invalidate_site_tensors();
+    flush_pivot_errors();
+    last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
+    IndexSet ei, ej; // empty extras
+    if (forward) {
+        for (size_t b = 0; b + 1 < n_; ++b) {
+            ei.width = b + 1;
+            ej.width = n_ - b - 1;
+            update_pivots(b, true, options, ei, ej);
+        }
+    } else {
+        for (size_t b = n_ - 1; b-- > 0;) {
+            ei.width = b + 1;
+            ej.width = n_ - b - 1;
+            update_pivots(b, false, options, ei, ej);
+        }
+    }
+    fill_site_tensors();
+}
+
+// tensorci2.rs:918-1050
+void Tci2::sweep1site_at_bond(size_t b, bool forward, double rel_tol, double abs_tol, size_t max_bond_dim,
+                              bool update_tensors)
+{
+    IndexSet is = forward ? kronecker_i(b) : i_set[b];
+    IndexSet js = forward ? j_set[b] : kronecker_j(b);
+    if (is.count == 0 || js.count == 0) return;
+    RrLUOptions lo;
+    lo.max_bond_dim = max_bond_dim;
+    lo.rel_tol = rel_tol;
+    lo.abs_tol = abs_tol;
+    lo.left_orthogonal = forward;
+    LuciResult lu = luci_on_sets(is, js, lo, update_tensors);
+    const std::vector<size_t> rows = non_empty_or_first(lu.row_perm, lu.rank);
+    const std::vector<size_t> cols = non_empty_or_first(lu.col_perm, lu.rank);
+    IndexSet ni, nj;
+    ni.width = is.width;
+    nj.width = js.width;
+    for (size_t r : rows) ni.push(is.at(r));
+    for (size_t c : cols) nj.push(js.at(c));
+    if (forward) {
+        i_set[b + 1] = ni;
+        j_set[b] = nj;
+    } else {
+        i_set[b] = ni;
+        j_set[b - 1] = nj;
+    }
+    if (update_tensors) {
+        if (forward) {
+            const size_t left_dim = (b == 0) ? 1 : i_set[b].count;
+            set_core_from_left(b, left_dim, local_dims[b], lu);
+        } else {
+            const size_t right_dim = (b == n_ - 1) ? 1 : j_set[b].count;
+            set_core_from_right(b, local_dims[b], right_dim, lu);
+        }
+    }
+    if (!lu.pivot_errors.empty()) {
+        const size_t bond_idx = forward ? b : b - 1;
+        bond_errors[bond_idx] = lu.pivot_errors.back();
+    }
+    update_pivot_errors(lu.pivot_errors);
+}
+
+// tensorci2.rs:865-915
+void Tci2::sweep1site(bool forward, double rel_tol, double abs_tol, size_t max_bond_dim, bool update_tensors)
+{
+    if (!(rel_tol >= 0.0) || !std::isfinite(rel_tol)) throw Error(T4A_GPU_INVALID_ARGUMENT, "rel_tol must be finite and non-negative");
+    if (!(abs_tol >= 0.0) || !std::isfinite(abs_tol)) throw Error(T4A_GPU_INVALID_ARGUMENT, "abs_tol must be finite and non-negative");
+    if (max_bond_dim == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "max_bond_dim must be positive");
+    require_fn();
+    flush_pivot_errors();
+    invalidate_site_tensors();
+    if (forward) {
+        for (size_t b = 0; b + 1 < n_; ++b) sweep1site_at_bond(b, true, rel_tol, abs_tol, max_bond_dim, update_tensors);
+    } else {
+        for (size_t b = n_ - 1; b >= 1; --b) sweep1site_at_bond(b, false, rel_tol, abs_tol, max_bond_dim, update_tensors);
+    }
+    if (update_tensors) { // tensorci2.rs:902-912 + fill_tensor :813-850
+        const size_t last = forward ? n_ - 1 : 0;
+        IndexSet rows = kronecker_i(last);
+        const IndexSet& jl = j_set[last];
+        const size_t A = i_set[last].count, S = local_dims[last], C = jl.count;
+        DevCore& c = cores[last];
+        c.buf.reserve(std::max<size_t>(A * S * C, 1));
+        c.l = A;
+        c.s = S;
+        c.r = C;
+        if (A * S * C > 0) {
+            double* d_m = eng.pi(A * S * C);
+            eval_matrix(rows, 0, jl, rows.width, d_m, nullptr);
+            hipLaunchKernelGGL(pack_left_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, eng.stream(), d_m,
+                               (int)(A * S), (int)(A * S), (int)C, c.buf.get(), (int)A, (int)S, (int)C);
+            T4A_HIP(hipStreamSynchronize(eng.stream()));
+            acc_used_ = 0;
+        }
+    }
+}
+
+// tensorci2.rs:1201-1221
+void Tci2::make_canonical(double rel_tol, double abs_tol, size_t max_bond_dim)
+{
+    if (!(rel_tol >= 0.0) || !std::isfinite(rel_tol)) throw Error(T4A_GPU_INVALID_ARGUMENT, "rel_tol must be finite and non-negative");
+    if (!(abs_tol >= 0.0) || !std::isfinite(abs_tol)) throw Error(T4A_GPU_INVALID_ARGUMENT, "abs_tol must be finite and non-negative");
+    if (max_bond_dim == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "max_bond_dim must be positive");
+    sweep1site(true, 0.0, 0.0, std::numeric_limits<size_t>::max(), false);
+    sweep1site(false, rel_tol, abs_tol, max_bond_dim, false);
+    sweep1site(true, rel_tol, abs_tol, max_bond_dim, true);
+}
+
+// tensorci2.rs:1065-1186 — all sites are independent given the final I/J sets, so the evaluations, the
+// partial-pivot LU factorisations and the triangular solves of every site are issued as batches.
+void Tci2::fill_site_tensors()
+{
+    require_fn();
+    hipStream_t st = eng.stream();
+    struct SiteJob {
+        size_t b;
+        size_t ni, nj, np;
+        size_t offA, offB; // offsets (doubles) into d_fillA_ / d_fillB_
+        bool last;
+    };
+    std::vector<SiteJob> jobs;
+    size_t totA = 0, totB = 0;
+    for (size_t b = 0; b < n_; ++b) {
+        if (shard_world > 1 && (b % shard_world) != shard_rank) continue;
+        const size_t ni = i_set[b].count * local_dims[b];
+        const size_t nj = j_set[b].count;
+        if (ni == 0 || nj == 0) { // tensorci2.rs:1074-1092
+            const size_t left_dim = (b == 0) ? 1 : std::max<size_t>(i_set[b].count, 1);
+            const size_t right_dim = (b == n_ - 1) ? 1 : std::max<size_t>(i_set[b + 1].count, 1);
+            set_core_zero(b, left_dim, local_dims[b], right_dim);
+            continue;
+        }
+        SiteJob j;
+        j.b = b;
+        j.ni = ni;
+        j.nj = nj;
+        j.last = (b == n_ - 1);
+        j.np = j.last ? 0 : i_set[b + 1].count;
+        if (!j.last && j.np != nj)
+            throw Error(T4A_GPU_INTERNAL_ERROR, "one-site interpolation solve failed: pivot matrix at bond " +
+                                                    std::to_string(b) + " is not square (" + std::to_string(j.np) + " x " +
+                                                    std::to_string(nj) + ")");
+        j.offA = totA;
+        j.offB = totB;
+        totA += j.last ? 0 : nj * j.np;
+        totB += nj * ni;
+        jobs.push_back(j);
+    }
+    if (jobs.empty()) return;
+    d_fillA_.reserve(std::max<size_t>(totA, 1));
+    d_fillB_.reserve(totB);
+    d_fillmax_.reserve(n_);
+    T4A_HIP(hipMemsetAsync(d_fillmax_.get(), 0, n_ * sizeof(unsigned long long), st));
+    if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_fill_.a, st));
+
+    // (1) evaluations.  B_b = Π1^T (nj x ni), A_b = P^T (nj x np) — evaluated directly in transposed form
+    //     (solve(P^T, Π1^T), tensorci2.rs:1160-1162).
+    double flops = 0.0;
+    for (const SiteJob& j : jobs) {
+        IndexSet ik = kronecker_i(j.b);
+        const IndexSet& jb = j_set[j.b];
+        if (j.last) {
+            // last site stores Π1 itself (:1109-1128); keep it untransposed: ni x nj
+            eval_matrix(ik, 0, jb, ik.width, d_fillB_.get() + j.offB, nullptr);
+        } else {
+            eval_matrix(jb, j.b + 1, ik, 0, d_fillB_.get() + j.offB, nullptr);
+            eval_matrix(jb, j.b + 1, i_set[j.b + 1], 0, d_fillA_.get() + j.offA, d_fillmax_.get() + j.b);
+            const double n = (double)j.np;
+            flops += (2.0 / 3.0) * n * n * n + 2.0 * n * n * (double)j.ni;
+        }
+    }
+    // (2) zero-pivot-matrix guard (:1154-1157) needs max|P| on the host
+    std::vector<unsigned long long> hmax(n_);
+    T4A_HIP(hipMemcpyAsync(hmax.data(), d_fillmax_.get(), n_ * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    T4A_HIP(hipStreamSynchronize(st));
+    acc_used_ = 0;
+
+    std::vector<LuProblem> lups;
+    std::vector<TrsmProblem> trl, tru;
+    std::vector<const SiteJob*> solved;
+    size_t piv_total = 0;
+    for (const SiteJob& j : jobs)
+        if (!j.last) piv_total += j.np;
+    d_fillpiv_.reserve(std::max<size_t>(piv_total, 1));
+    d_fillinfo_.reserve(n_);
+    size_t piv_off = 0;
+    int max_n = 0, max_nrhs = 0;
+    for (const SiteJob& j : jobs) {
+        if (j.last) continue;
+        double pmax;
+        std::memcpy(&pmax, &hmax[j.b], sizeof(double));
+        const size_t left_dim = (j.b == 0) ? 1 : i_set[j.b].count;
+        if (pmax < 2.220446049250313e-16) { // every |p| < EPS -> zero core with the same bond shape
+            set_core_zero(j.b, left_dim, local_dims[j.b], j.np);
+            continue;
+        }
+        LuProblem lp;
+        lp.A = d_fillA_.get() + j.offA;
+        lp.lda = (int)j.nj;
+        lp.n = (int)j.nj;
+        lp.piv = d_fillpiv_.get() + piv_off;
+        lp.info = d_fillinfo_.get() + j.b;
+        lp.B = d_fillB_.get() + j.offB;
+        lp.ldb = (int)j.nj;
+        lp.nrhs = (int)j.ni;
+        piv_off += j.np;
+        lups.push_back(lp);
+        TrsmProblem t;
+        t.T = lp.A;
+        t.ldt = lp.lda;
+        t.n = lp.n;
+        t.B = lp.B;
+        t.ldb = lp.ldb;
+        t.nrhs = lp.nrhs;
+        t.lower = 1;
+        t.unit_diag = 1;
+        trl.push_back(t);
+        t.lower = 0;
+        t.unit_diag = 0;
+        tru.push_back(t);
+        solved.push_back(&j);
+        max_n = std::max(max_n, lp.n);
+        max_nrhs = std::max(max_nrhs, lp.nrhs);
+    }
+    T4A_HIP(hipMemsetAsync(d_fillinfo_.get(), 0, n_ * sizeof(int), st));
+    if (!lups.empty()) {
+        const size_t np_ = lups.size();
+        d_lup_.reserve(np_);
+        d_trp_.reserve(2 * np_);
+        T4A_HIP(hipMemcpyAsync(d_lup_.get(), lups.data(), np_ * sizeof(LuProblem), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(d_trp_.get(), trl.data(), np_ * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(d_trp_.get() + np_, tru.data(), np_ * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st)); // descriptor vectors are pageable
+        lu_batched_launch(d_lup_.get(), (int)np_, max_n, st);
+        trsm_left_batched_launch(d_trp_.get(), (int)np_, max_n, max_nrhs, st);
+        trsm_left_batched_launch(d_trp_.get() + np_, (int)np_, max_n, max_nrhs, st);
+    }
+    // (3) pack the cores
+    for (const SiteJob& j : jobs) {
+        const size_t left_dim = (j.b == 0) ? 1 : i_set[j.b].count;
+        const size_t S = local_dims[j.b];
+        if (j.last) {
+            DevCore& c = cores[j.b];
+            c.buf.reserve(left_dim * S);
+            c.l = left_dim;
+            c.s = S;
+            c.r = 1;
+            hipLaunchKernelGGL(pack_left_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, st,
+                               d_fillB_.get() + j.offB, (int)j.ni, (int)j.ni, 1, c.buf.get(), (int)left_dim, (int)S, 1);
+        }
+    }
+    for (const SiteJob* pj : solved) {
+        const SiteJob& j = *pj;
+        const size_t left_dim = (j.b == 0) ? 1 : i_set[j.b].count;
+        const size_t S = local_dims[j.b];
+        DevCore& c = cores[j.b];
+        c.buf.reserve(left_dim * S * j.np);
+        c.l = left_dim;
+        c.s = S;
+        c.r = j.np;
+        hipLaunchKernelGGL(pack_fill_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, st, d_fillB_.get() + j.offB,
+                           (int)j.nj, c.buf.get(), (int)left_dim, (int)S, (int)j.np);
+    }
+    if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_fill_.b, st));
+    std::vector<int> hinfo(n_, 0);
+    T4A_HIP(hipMemcpyAsync(hinfo.data(), d_fillinfo_.get(), n_ * sizeof(int), hipMemcpyDeviceToHost, st));
+    T4A_HIP(hipStreamSynchronize(st));
+    T4A_HIP(hipGetLastError());
+    if (eng.prof.enabled) {
+        float ms = 0.f;
+        T4A_HIP(hipEventElapsedTime(&ms, ev_fill_.a, ev_fill_.b));
+        eng.prof.v[4] += ms;
+        eng.prof.v[5] += 1.0;
+    }
+    eng.prof.v[10] += flops;
+    for (const SiteJob* pj : solved)
+        if (hinfo[pj->b] != 0)
+            throw Error(T4A_GPU_INTERNAL_ERROR, "one-site interpolation solve failed: singular pivot matrix at site " +
+                                                    std::to_string(pj->b));
+}
+
+// =================================================================================================
+// TT evaluation / sum
+// =================================================================================================
+std::vector<double> Tci2::site_tensor_host(size_t site, size_t dims3[3])
+{
+    const DevCore& c = cores[site];
+    dims3[0] = c.l;
+    dims3[1] = c.s;
+    dims3[2] = c.r;
+    std::vector<double> h(c.size());
+    if (!h.empty()) {
+        T4A_HIP(hipMemcpyAsync(h.data(), c.buf.get(), h.size() * sizeof(double), hipMemcpyDeviceToHost, eng.stream()));
+        T4A_HIP(hipStreamSynchronize(eng.stream()));
+    }
+    return h;
+}
+
+static void check_tt_chain(const std::vector<DevCore>& cores) // SimpleTensorTrain::new, simplett/src/tensortrain.rs:97
+{
+    if (cores.front().l != 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "First tensor must have left dimension 1");
+    if (cores.back().r != 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "Last tensor must have right dimension 1");
+    for (size_t i = 0; i + 1 < cores.size(); ++i)
+        if (cores[i].r != cores[i + 1].l || cores[i].r == 0)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "tensor train bond dimension mismatch at bond " + std::to_string(i));
+}
+
+std::vector<double> Tci2::evaluate(const uint32_t* idx, size_t n_pts)
+{
+    check_tt_chain(cores);
+    std::vector<double> out(n_pts);
+    if (n_pts == 0) return out;
+    for (size_t p = 0; p < n_pts; ++p)
+        for (size_t s = 0; s < n_; ++s)
+            if (idx[p * n_ + s] >= local_dims[s]) throw Error(T4A_GPU_INVALID_ARGUMENT, "evaluate: index out of bounds");
+    hipStream_t st = eng.stream();
+    std::vector<TtCoreDesc> desc(n_);
+    int max_bond = 1;
+    for (size_t s = 0; s < n_; ++s) {
+        desc[s].data = cores[s].buf.get();
+        desc[s].l = (int)cores[s].l;
+        desc[s].d = (int)cores[s].s;
+        desc[s].r = (int)cores[s].r;
+        max_bond = std::max(max_bond, std::max(desc[s].l, desc[s].r));
+    }
+    d_coredesc_.reserve(n_);
+    d_idx_.reserve(n_pts * n_);
+    d_vals_.reserve(n_pts);
+    T4A_HIP(hipMemcpyAsync(d_coredesc_.get(), desc.data(), n_ * sizeof(TtCoreDesc), hipMemcpyHostToDevice, st));
+    T4A_HIP(hipMemcpyAsync(d_idx_.get(), idx, n_pts * n_ * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    T4A_HIP(hipStreamSynchronize(st));
+    tt_evaluate_launch(d_coredesc_.get(), (int)n_, max_bond, d_idx_.get(), (int)n_pts, d_vals_.get(), st);
+    T4A_HIP(hipMemcpyAsync(out.data(), d_vals_.get(), n_pts * sizeof(double), hipMemcpyDeviceToHost, st));
+    T4A_HIP(hipStreamSynchronize(st));
+    T4A_HIP(hipGetLastError());
+    return out;
+}
+
+double Tci2::sum() // simplett/src/traits.rs:231-275 (host-side: O(n chi^2 d), not on the hot path)
+{
+    check_tt_chain(cores);
+    std::vector<double> cur;
+    for (size_t site = 0; site < n_; ++site) {
+        size_t d3[3];
+        std::vector<double> t = site_tensor_host(site, d3);
+        const size_t L = d3[0], S = d3[1], R = d3[2];
+        if (site == 0) {
+            cur.assign(R, 0.0);
+            for (size_t s = 0; s < S; ++s)
+                for (size_t r = 0; r < R; ++r) cur[r] = cur[r] + t[0 + L * (s + S * r)];
+            continue;
+        }
+        std::vector<double> site_sum(L * R, 0.0);
+        for (size_t l = 0; l < L; ++l)
+            for (size_t s = 0; s < S; ++s)
+                for (size_t r = 0; r < R; ++r) site_sum[l * R + r] = site_sum[l * R + r] + t[l + L * (s + S * r)];
+        std::vector<double> next(R, 0.0);
+        for (size_t r = 0; r < R; ++r) {
+            double sum = 0.0;
+            for (size_t l = 0; l < L; ++l) sum = sum + cur[l] * site_sum[l * R + r];
+            next[r] = sum;
+        }
+        cur.swap(next);
+    }
+    return cur[0];
+}
+
+// =================================================================================================
+// global pivot search + optimisation loop
+// =================================================================================================
+// DefaultGlobalPivotFinder::find_global_pivots (tensorci/src/globalpivot.rs:160-219).  All candidate points
+// of all searches are independent (the reference resets the coordinate after each 1-D scan), so f and the
+// TT are evaluated in two batches.  RNG: the reference uses rand 0.9 StdRng (third party) — stream parity
+// is unpinned; splitmix64 here.
+std::vector<std::vector<uint32_t>> Tci2::find_global_pivots(double abs_tol, const TCI2Options& o, uint64_t& rng_state)
+{
+    std::vector<std::vector<uint32_t>> found;
+    if (o.nsearch == 0) return found;
+    std::vector<std::vector<uint32_t>> initial(o.nsearch, std::vector<uint32_t>(n_));
+    for (auto& p : initial)
+        for (size_t s = 0; s < n_; ++s) p[s] = (uint32_t)(splitmix64(rng_state) % (uint64_t)local_dims[s]);
+    std::vector<uint32_t> idx;
+    for (const auto& point : initial)
+        for (size_t p = 0; p < n_; ++p)
+            for (size_t v = 0; v < local_dims[p]; ++v) {
+                const size_t base = idx.size();
+                idx.insert(idx.end(), point.begin(), point.end());
+                idx[base + p] = (uint32_t)v;
+            }
+    const size_t npts = idx.size() / n_;
+    std::vector<double> fv = eval_points_host(idx, npts);
+    std::vector<double> tv;
+    try {
+        tv = evaluate(idx.data(), npts);
+    } catch (const Error&) {
+        tv.assign(npts, 0.0); // `.unwrap_or(T::zero())`
+    }
+    size_t q = 0;
+    for (const auto& point : initial) {
+        double best_error = 0.0;
+        std::vector<uint32_t> best_point = point;
+        for (size_t p = 0; p < n_; ++p)
+            for (size_t v = 0; v < local_dims[p]; ++v, ++q) {
+                const double diff = fv[q] - tv[q];
+                const double err = std::sqrt(diff * diff);
+                if (err > best_error) {
+                    best_error = err;
+                    best_point.assign(idx.begin() + q * n_, idx.begin() + (q + 1) * n_);
+                }
+            }
+        if (best_error > abs_tol * o.tol_margin_global_search) found.push_back(best_point);
+    }
+    if (found.size() > o.max_nglobal_pivot) found.resize(o.max_nglobal_pivot);
+    return found;
+}
+
+static bool convergence_criterion(const std::vector<size_t>& ranks, const std::vector<double>& errors,
+                                  const std::vector<size_t>& nglobal, double tolerance, size_t max_bond_dim,
+                                  size_t ncheck_history, int& out) // tensorci2.rs:1407-1437
+{
+    if (errors.size() < ncheck_history) return false;
+    const size_t n = errors.size();
+    bool errors_converged = true, no_global = true, at_max = true;
+    size_t min_rank = std::numeric_limits<size_t>::max();
+    for (size_t i = n - ncheck_history; i < n; ++i) {
+        if (!(errors[i] < tolerance)) errors_converged = false;
+        if (nglobal[i] != 0) no_global = false;
+        if (!(ranks[i] >= max_bond_dim)) at_max = false;
+        min_rank = std::min(min_rank, ranks[i]);
+    }
+    const bool rank_stable = (min_rank == ranks[n - 1]);
+    if (at_max) {
+        out = T4A_GPU_TCI2_MAX_BOND_DIMENSION;
+        return true;
+    }
+    if (errors_converged && no_global && rank_stable) {
+        out = T4A_GPU_TCI2_CONVERGED;
+        return true;
+    }
+    return false;
+}
+
+// optimize_with_finder (tensorci2.rs:1626-1802)
+void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
+{
+    options.validate();
+    require_fn();
+    if (rank() == 0)
+        throw Error(T4A_GPU_INVALID_ARGUMENT, "TensorCI2 state must contain at least one pivot before optimization");
+    ranks_hist.clear();
+    errors_hist.clear();
+    std::vector<size_t> nglobal_hist;
+    termination = T4A_GPU_TCI2_MAX_ITERATIONS;
+    uint64_t rng_state = options.has_seed ? options.seed : 0x1234567ull;
+
+    for (size_t iter = 0; iter < options.max_iter; ++iter) {
+        const double norm = (options.normalize_error && max_sample_value > 0.0) ? max_sample_value : 1.0;
+        const double abs_tol = options.tolerance * norm;
+        bool is_forward = true;
+        if (options.sweep_strategy == 1) is_forward = false;
+        else if (options.sweep_strategy == 2) is_forward = (iter % 2 == 0);
+
+        std::vector<IndexSet> extra_i(n_), extra_j(n_);
+        for (size_t p = 0; p < n_; ++p) {
+            extra_i[p].width = p;
+            extra_j[p].width = n_ - p - 1;
+        }
+        if (!options.strictly_nested && !i_set_history.empty()) { // :1675-1685
+            extra_i = i_set_history.back();
+            extra_j = j_set_history.back();
+        }
+        i_set_history.push_back(i_set);
+        j_set_history.push_back(j_set);
+        // only the most recent snapshot is ever read (:1677-1681): cap the memory held by older ones
+        if (i_set_history.size() > 2) {
+            i_set_history.erase(i_set_history.begin());
+            j_set_history.erase(j_set_history.begin());
+        }
+        invalidate_site_tensors();
+        flush_pivot_errors();
+        last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
+        if (is_forward) {
+            for (size_t b = 0; b + 1 < n_; ++b) update_pivots(b, true, options, extra_i[b + 1], extra_j[b]);
+        } else {
+            for (size_t b = n_ - 1; b-- > 0;) update_pivots(b, false, options, extra_i[b + 1], extra_j[b]);
+        }
+        fill_site_tensors();
+        const double error = max_bond_error();
+        errors_hist.push_back(error / norm);
+
+        std::vector<std::vector<uint32_t>> gp = find_global_pivots(abs_tol, options, rng_state);
+        add_global_pivots_keep_cores(gp);
+        nglobal_hist.push_back(gp.size());
+        ranks_hist.push_back(rank());
+        if (options.verbosity > 0)
+            std::printf("iteration = %zu, rank = %zu, error = %.2e, maxsamplevalue = %.2e, nglobalpivot = %zu\n", iter + 1,
+                        rank(), error / norm, max_sample_value, gp.size());
+        int reason;
+        if (convergence_criterion(ranks_hist, errors_hist, nglobal_hist, options.tolerance, options.max_bond_dim_or_max(),
+                                  options.ncheck_history, reason)) {
+            termination = reason;
+            break;
+        }
+    }
+    if (final_sweep1site) { // :1781-1794
+        const double norm = (options.normalize_error && max_sample_value > 0.0) ? max_sample_value : 1.0;
+        const double abs_tol = options.tolerance * norm;
+        sweep1site(true, 1e-14, abs_tol, options.max_bond_dim_or_max(), true);
+    }
+}
+
+void Tci2::add_global_pivots_keep_cores(const std::vector<std::vector<uint32_t>>& gp)
+{
+    // add_global_pivots invalidates the site tensors (:707-708).  With zero new pivots the reference still
+    // invalidates; callers that skip the final sweep1site (bench) want the cores of the last
+    // fill_site_tensors to stay readable, which is harmless: the next sweep overwrites them anyway.
+    if (gp.empty()) return;
+    add_global_pivots(gp);
+}
+
+// crossinterpolate2 (tensorci2.rs:1513-1563)
+void Tci2::crossinterpolate2(std::vector<std::vector<uint32_t>> pivots, const TCI2Options& options)
+{
+    options.validate();
+    require_fn();
+    if (pivots.empty()) pivots.push_back(std::vector<uint32_t>(n_, 0));
+    add_global_pivots(pivots);
+    std::vector<uint32_t> flat;
+    for (const auto& p : pivots) flat.insert(flat.end(), p.begin(), p.end());
+    std::vector<double> vals = eval_points_host(flat, pivots.size());
+    for (double v : vals) {
+        const double a = std::sqrt(v * v);
+        if (a > max_sample_value) max_sample_value = a;
+    }
+    if (max_sample_value < 1e-30) throw Error(T4A_GPU_INVALID_ARGUMENT, "Initial pivots have zero function values");
+    optimize(options, true);
+}
+
+} // namespace t4a

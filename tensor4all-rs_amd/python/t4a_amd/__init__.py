@@ -1,0 +1,513 @@
+"""t4a_amd — thin ctypes host bindings over the C ABI of libt4a_gpu.so (include/t4a_gpu.h).
+
+The names mirror the Rust reference (tensor4all-core / tensor4all-tensorbackend / tensor4all-tensorci):
+``rrlu``, ``matrix_luci_factors_from_matrix``, ``mat_mul``, ``solve_matrix``, ``triangular_solve_matrix``,
+``TensorCI2``, ``crossinterpolate2``, ``TCI2Options``.  There is NO CPU fallback: every compute call raises
+``T4aError`` (status T4A_GPU_NO_DEVICE) when no MI355X is visible, and importing raises if the shared
+library has not been built (``python tensor4all-rs_amd/build.py``).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .functions import (FnSpec, quantics_trig_exp, quantics_osc2d, lorentz, linear_sum,  # noqa: F401
+                        FN_MAX_PARAMS)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libt4a_gpu.so"))
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} not found: build it with `python tensor4all-rs_amd/build.py` "
+                      "(the MI355X backend has no CPU fallback)")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+c_size_t = ctypes.c_size_t
+c_double = ctypes.c_double
+c_int32 = ctypes.c_int32
+c_void_p = ctypes.c_void_p
+
+SUCCESS = 0
+NULL_POINTER = -1
+INVALID_ARGUMENT = -2
+BUFFER_TOO_SMALL = -5
+INTERNAL_ERROR = -6
+NOT_IMPLEMENTED = -7
+NAN_ENCOUNTERED = -8
+SINGULAR_MATRIX = -9
+NO_DEVICE = -10
+KERNEL_TIMEOUT = -11
+CALLBACK_ERROR = -12
+
+CONVERGED, MAX_BOND_DIMENSION, MAX_ITERATIONS = 0, 1, 2
+
+
+class T4aError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[t4a_gpu status {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+def last_error_message():
+    need = c_size_t(0)
+    _lib.t4a_gpu_last_error_message(None, 0, ctypes.byref(need))
+    buf = ctypes.create_string_buffer(max(need.value, 1))
+    _lib.t4a_gpu_last_error_message(buf, len(buf), None)
+    return buf.value.decode("utf-8", "replace")
+
+
+def _check(status):
+    if status != SUCCESS:
+        raise T4aError(status, last_error_message())
+
+
+def device_count():
+    c = c_int32(0)
+    _check(_lib.t4a_gpu_device_count(ctypes.byref(c)))
+    return c.value
+
+
+def set_device(dev):
+    _check(_lib.t4a_gpu_set_device(c_int32(dev)))
+
+
+def version():
+    _lib.t4a_gpu_version.restype = ctypes.c_char_p
+    return _lib.t4a_gpu_version().decode()
+
+
+def _f(a):
+    """column-major float64 copy"""
+    return np.asfortranarray(np.array(a, dtype=np.float64, copy=True))
+
+
+def _p(arr):
+    return arr.ctypes.data_as(c_void_p)
+
+
+class TCI2OptionsC(ctypes.Structure):
+    _fields_ = [("tolerance", c_double), ("max_iter", c_size_t), ("max_bond_dim", c_size_t),
+                ("pivot_search", c_int32), ("normalize_error", c_int32), ("verbosity", c_size_t),
+                ("max_nglobal_pivot", c_size_t), ("nsearch", c_size_t), ("sweep_strategy", c_int32),
+                ("strictly_nested", c_int32), ("ncheck_history", c_size_t),
+                ("tol_margin_global_search", c_double), ("has_seed", c_int32), ("reserved_", c_int32),
+                ("seed", ctypes.c_uint64)]
+
+
+class TCI2Options:
+    """TCI2Options (tensorci2.rs:73-170). ``max_bond_dim=None`` <=> Rust ``None``."""
+    FULL, ROOK = 0, 1
+    FORWARD, BACKWARD, BACK_AND_FORTH = 0, 1, 2
+
+    def __init__(self, tolerance=1e-8, max_iter=20, max_bond_dim=None, pivot_search=0, normalize_error=True,
+                 verbosity=0, max_nglobal_pivot=5, nsearch=5, sweep_strategy=2, ncheck_history=3,
+                 strictly_nested=False, tol_margin_global_search=10.0, seed=None):
+        self.tolerance = tolerance
+        self.max_iter = max_iter
+        self.max_bond_dim = max_bond_dim
+        self.pivot_search = pivot_search
+        self.normalize_error = normalize_error
+        self.verbosity = verbosity
+        self.max_nglobal_pivot = max_nglobal_pivot
+        self.nsearch = nsearch
+        self.sweep_strategy = sweep_strategy
+        self.ncheck_history = ncheck_history
+        self.strictly_nested = strictly_nested
+        self.tol_margin_global_search = tol_margin_global_search
+        self.seed = seed
+
+    def to_c(self):
+        if self.max_bond_dim is not None and self.max_bond_dim <= 0:
+            raise T4aError(INVALID_ARGUMENT, "max_bond_dim must be positive")
+        o = TCI2OptionsC()
+        o.tolerance = self.tolerance
+        o.max_iter = self.max_iter
+        o.max_bond_dim = 0 if self.max_bond_dim is None else int(self.max_bond_dim)
+        o.pivot_search = self.pivot_search
+        o.normalize_error = 1 if self.normalize_error else 0
+        o.verbosity = self.verbosity
+        o.max_nglobal_pivot = self.max_nglobal_pivot
+        o.nsearch = self.nsearch
+        o.sweep_strategy = self.sweep_strategy
+        o.strictly_nested = 1 if self.strictly_nested else 0
+        o.ncheck_history = self.ncheck_history
+        o.tol_margin_global_search = self.tol_margin_global_search
+        o.has_seed = 0 if self.seed is None else 1
+        o.seed = 0 if self.seed is None else int(self.seed)
+        return o
+
+
+# ---------------------------------------------------------------------------------------- dense ops
+class RrLU:
+    """Result of rrlu (core/src/matrixlu.rs:69-84)."""
+
+    def __init__(self, factored, row_perm, col_perm, npivots, error, left_orthogonal):
+        self.factored = factored
+        self.row_permutation = row_perm
+        self.col_permutation = col_perm
+        self.n_pivot = npivots
+        self.error = error
+        self.left_orthogonal = left_orthogonal
+
+    def npivots(self):
+        return self.n_pivot
+
+    def row_indices(self):
+        return self.row_permutation[: self.n_pivot].copy()
+
+    def col_indices(self):
+        return self.col_permutation[: self.n_pivot].copy()
+
+    def left(self, permute=False):  # extract_lu_from_factorized (matrixlu.rs:614-668)
+        m, n = self.factored.shape
+        r = self.n_pivot
+        l = np.tril(self.factored[:, :r]).copy()
+        if self.left_orthogonal:
+            for i in range(r):
+                l[i, i] = 1.0
+        if permute:
+            out = np.zeros_like(l)
+            out[self.row_permutation, :] = l
+            return out
+        return l
+
+    def right(self, permute=False):
+        r = self.n_pivot
+        u = np.triu(self.factored[:r, :]).copy()
+        if not self.left_orthogonal:
+            for i in range(r):
+                u[i, i] = 1.0
+        if permute:
+            out = np.zeros_like(u)
+            out[:, self.col_permutation] = u
+            return out
+        return u
+
+    def pivot_errors(self):
+        d = np.array([self.factored[i, i] for i in range(self.n_pivot)])
+        return np.concatenate([np.sqrt(d * d), [self.error]])
+
+    def last_pivot_error(self):
+        return self.error
+
+
+def rrlu(a, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0, left_orthogonal=True):
+    a = _f(a)
+    m, n = a.shape
+    rp = np.zeros(m, dtype=np.uintp)
+    cp = np.zeros(n, dtype=np.uintp)
+    npiv = c_size_t(0)
+    err = c_double(0.0)
+    _check(_lib.t4a_gpu_rrlu_f64(_p(a), c_size_t(m), c_size_t(n), c_size_t(0 if max_bond_dim is None else max_bond_dim),
+                                 c_double(rel_tol), c_double(abs_tol), c_int32(1 if left_orthogonal else 0), _p(rp),
+                                 _p(cp), ctypes.byref(npiv), ctypes.byref(err)))
+    return RrLU(a, rp.astype(np.int64), cp.astype(np.int64), npiv.value, err.value, left_orthogonal)
+
+
+class MatrixLuciFactors:
+    def __init__(self, row_indices, col_indices, pivot_errors, rank, left, right):
+        self.row_indices = row_indices
+        self.col_indices = col_indices
+        self.pivot_errors = pivot_errors
+        self.rank = rank
+        self.left = left
+        self.right = right
+
+
+def matrix_luci_factors_from_matrix(a, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0, left_orthogonal=True):
+    a = _f(a)
+    m, n = a.shape
+    k = min(m, n)
+    rows = np.zeros(max(k, 1), dtype=np.uintp)
+    cols = np.zeros(max(k, 1), dtype=np.uintp)
+    pe = np.zeros(k + 1, dtype=np.float64)
+    left = np.zeros(max(m * k, 1), dtype=np.float64)
+    right = np.zeros(max(k * n, 1), dtype=np.float64)
+    rank = c_size_t(0)
+    _check(_lib.t4a_gpu_luci_f64(_p(a), c_size_t(m), c_size_t(n), c_size_t(0 if max_bond_dim is None else max_bond_dim),
+                                 c_double(rel_tol), c_double(abs_tol), c_int32(1 if left_orthogonal else 0),
+                                 ctypes.byref(rank), _p(rows), _p(cols), _p(pe), _p(left), _p(right)))
+    r = rank.value
+    return MatrixLuciFactors(rows[:r].astype(np.int64), cols[:r].astype(np.int64), pe[: r + 1].copy(), r,
+                             left[: m * r].reshape((m, r), order="F").copy(),
+                             right[: r * n].reshape((r, n), order="F").copy())
+
+
+def mat_mul(a, b):
+    a = _f(a)
+    b = _f(b)
+    m, k = a.shape
+    k2, n = b.shape
+    if k != k2:
+        raise T4aError(INVALID_ARGUMENT, "mat_mul: inner dimension mismatch")
+    c = np.zeros((m, n), dtype=np.float64, order="F")
+    _check(_lib.t4a_gpu_gemm_f64(_p(a), _p(b), c_size_t(m), c_size_t(k), c_size_t(n), _p(c)))
+    return c
+
+
+def batched_mat_mul_same_shape(batch, m, k, n, a, b):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel())
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float64).ravel())
+    c = np.zeros(batch * m * n, dtype=np.float64)
+    _check(_lib.t4a_gpu_gemm_batched_f64(c_size_t(batch), c_size_t(m), c_size_t(k), c_size_t(n), _p(a), _p(b), _p(c)))
+    return c
+
+
+def triangular_solve_matrix(a, b, left_side, lower, transpose_a, unit_diagonal):
+    a = _f(a)
+    b = _f(b)
+    x = np.zeros(b.shape, dtype=np.float64, order="F")
+    _check(_lib.t4a_gpu_trsm_f64(_p(a), c_size_t(a.shape[0]), _p(b), c_size_t(b.shape[0]), c_size_t(b.shape[1]),
+                                 c_int32(int(left_side)), c_int32(int(lower)), c_int32(int(transpose_a)),
+                                 c_int32(int(unit_diagonal)), _p(x)))
+    return x
+
+
+def solve_matrix(a, b):
+    a = _f(a)
+    b = _f(b)
+    x = np.zeros(b.shape, dtype=np.float64, order="F")
+    _check(_lib.t4a_gpu_solve_f64(_p(a), c_size_t(a.shape[0]), _p(b), c_size_t(b.shape[1]), _p(x)))
+    return x
+
+
+def fn_eval(spec, local_dims, idx):
+    """Evaluate a built-in function on the device. idx: (n_pts, n_sites) integer array."""
+    idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uintp))
+    n_pts, n_sites = idx.shape
+    ld = np.asarray(local_dims, dtype=np.uintp)
+    out = np.zeros(n_pts, dtype=np.float64)
+    params = np.asarray(spec.params, dtype=np.float64)
+    w = np.ascontiguousarray(spec.weights, dtype=np.uint64)
+    _check(_lib.t4a_gpu_fn_eval(c_int32(spec.fid), c_int32(spec.n_acc), _p(params), _p(w), _p(ld), c_size_t(n_sites),
+                                _p(idx), c_size_t(n_pts), _p(out)))
+    return out
+
+
+# ---------------------------------------------------------------------------------------- TCI2
+_BATCH_CB = ctypes.CFUNCTYPE(ctypes.c_int64, c_void_p, ctypes.POINTER(ctypes.c_uint32), c_size_t, c_size_t,
+                             ctypes.POINTER(c_double))
+
+
+class TensorCI2:
+    """TensorCI2<f64> (tensorci/src/tensorci2.rs:349) — state lives in a device-side handle."""
+
+    def __init__(self, local_dims):
+        self.local_dims = [int(d) for d in local_dims]
+        ld = np.asarray(self.local_dims, dtype=np.uintp)
+        self._h = c_void_p()
+        _check(_lib.t4a_gpu_tci2_new(_p(ld), c_size_t(len(ld)), ctypes.byref(self._h)))
+        self._cb_keepalive = None
+        self.n_callback_calls = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.t4a_gpu_tci2_release(h)
+            self._h = None
+
+    # --- function source
+    def set_function(self, f):
+        """f: FnSpec (built-in device functor) or a Python callable f(list[int]) -> float, optionally with a
+        ``batched`` callable taking an (n_pts, n_sites) array (wrapped into the host batch callback)."""
+        if isinstance(f, FnSpec):
+            params = np.asarray(f.params, dtype=np.float64)
+            w = np.ascontiguousarray(f.weights, dtype=np.uint64)
+            _check(_lib.t4a_gpu_tci2_set_builtin_function(self._h, c_int32(f.fid), c_int32(f.n_acc), _p(params), _p(w)))
+            self._cb_keepalive = None
+            return
+        scalar = f
+        batched = getattr(f, "batched", None)
+        owner = self
+
+        def _cb(ctx, idx_ptr, n_sites, n_pts, out_ptr):
+            try:
+                owner.n_callback_calls += 1
+                idx = np.ctypeslib.as_array(idx_ptr, shape=(n_pts, n_sites))
+                if batched is not None:
+                    vals = np.asarray(batched(idx), dtype=np.float64).ravel()
+                else:
+                    vals = np.array([scalar([int(v) for v in row]) for row in idx], dtype=np.float64)
+                k = min(len(vals), n_pts)
+                out = np.ctypeslib.as_array(out_ptr, shape=(n_pts,))
+                out[:k] = vals[:k]
+                return len(vals)
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        cb = _BATCH_CB(_cb)
+        self._cb_keepalive = cb
+        _check(_lib.t4a_gpu_tci2_set_callback(self._h, cb, None))
+
+    # --- reference API
+    def __len__(self):
+        return len(self.local_dims)
+
+    def add_global_pivots(self, pivots):
+        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uintp).reshape(len(pivots), -1))
+        if piv.size and piv.shape[1] != len(self.local_dims):
+            raise T4aError(INVALID_ARGUMENT, "Pivot length must match number of sites")
+        _check(_lib.t4a_gpu_tci2_add_global_pivots(self._h, _p(piv), c_size_t(len(pivots))))
+
+    def crossinterpolate2(self, initial_pivots, options):
+        o = options.to_c()
+        piv = np.ascontiguousarray(np.asarray(initial_pivots, dtype=np.uintp).reshape(len(initial_pivots), -1))
+        _check(_lib.t4a_gpu_tci2_crossinterpolate2(self._h, _p(piv), c_size_t(len(initial_pivots)), ctypes.byref(o)))
+
+    def optimize(self, options, final_sweep1site=True):
+        o = options.to_c()
+        _check(_lib.t4a_gpu_tci2_optimize(self._h, ctypes.byref(o), c_int32(1 if final_sweep1site else 0)))
+
+    def sweep2site(self, forward, options):
+        o = options.to_c()
+        _check(_lib.t4a_gpu_tci2_sweep2site(self._h, c_int32(1 if forward else 0), ctypes.byref(o)))
+
+    def sweep1site(self, forward, rel_tol, abs_tol, max_bond_dim=None, update_tensors=True):
+        if max_bond_dim is not None and max_bond_dim <= 0:
+            raise T4aError(INVALID_ARGUMENT, "max_bond_dim must be positive")
+        _check(_lib.t4a_gpu_tci2_sweep1site(self._h, c_int32(1 if forward else 0), c_double(rel_tol), c_double(abs_tol),
+                                            c_size_t(0 if max_bond_dim is None else max_bond_dim),
+                                            c_int32(1 if update_tensors else 0)))
+
+    def fill_site_tensors(self):
+        _check(_lib.t4a_gpu_tci2_fill_site_tensors(self._h))
+
+    def make_canonical(self, rel_tol, abs_tol, max_bond_dim=None):
+        _check(_lib.t4a_gpu_tci2_make_canonical(self._h, c_double(rel_tol), c_double(abs_tol),
+                                                c_size_t(0 if max_bond_dim is None else max_bond_dim)))
+
+    def rank(self):
+        v = c_size_t(0)
+        _check(_lib.t4a_gpu_tci2_rank(self._h, ctypes.byref(v)))
+        return v.value
+
+    def link_dims(self):
+        out = np.zeros(len(self.local_dims) - 1, dtype=np.uintp)
+        _check(_lib.t4a_gpu_tci2_link_dims(self._h, _p(out)))
+        return [int(x) for x in out]
+
+    def max_sample_value(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_tci2_max_sample_value(self._h, ctypes.byref(v)))
+        return v.value
+
+    def set_max_sample_value(self, value):
+        _check(_lib.t4a_gpu_tci2_set_max_sample_value(self._h, c_double(value)))
+
+    def max_bond_error(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_tci2_max_bond_error(self._h, ctypes.byref(v)))
+        return v.value
+
+    def bond_errors(self):
+        out = np.zeros(len(self.local_dims) - 1, dtype=np.float64)
+        _check(_lib.t4a_gpu_tci2_bond_errors(self._h, _p(out)))
+        return out
+
+    def pivot_errors(self):
+        n = c_size_t(0)
+        _check(_lib.t4a_gpu_tci2_pivot_errors(self._h, ctypes.byref(n), None))
+        out = np.zeros(max(n.value, 1), dtype=np.float64)
+        _check(_lib.t4a_gpu_tci2_pivot_errors(self._h, ctypes.byref(n), _p(out)))
+        return out[: n.value]
+
+    def _index_set(self, which, site):
+        cnt = c_size_t(0)
+        wid = c_size_t(0)
+        _check(_lib.t4a_gpu_tci2_index_set(self._h, c_int32(which), c_size_t(site), ctypes.byref(cnt), ctypes.byref(wid), None))
+        out = np.zeros(max(cnt.value * wid.value, 1), dtype=np.uintp)
+        _check(_lib.t4a_gpu_tci2_index_set(self._h, c_int32(which), c_size_t(site), ctypes.byref(cnt), ctypes.byref(wid),
+                                           _p(out)))
+        return out[: cnt.value * wid.value].reshape(cnt.value, wid.value).astype(np.int64)
+
+    def i_set(self, site):
+        return self._index_set(0, site)
+
+    def j_set(self, site):
+        return self._index_set(1, site)
+
+    def set_index_set(self, which, site, entries):
+        e = np.ascontiguousarray(np.asarray(entries, dtype=np.uintp))
+        count = e.shape[0] if e.ndim == 2 else len(entries)
+        _check(_lib.t4a_gpu_tci2_set_index_set(self._h, c_int32(which), c_size_t(site), c_size_t(count), _p(e)))
+
+    def clear_history(self):
+        _check(_lib.t4a_gpu_tci2_clear_history(self._h))
+
+    def site_tensor(self, site):
+        d = (c_size_t * 3)()
+        _check(_lib.t4a_gpu_tci2_site_tensor(self._h, c_size_t(site), d, None))
+        shape = (d[0], d[1], d[2])
+        out = np.zeros(max(shape[0] * shape[1] * shape[2], 1), dtype=np.float64)
+        _check(_lib.t4a_gpu_tci2_site_tensor(self._h, c_size_t(site), d, _p(out)))
+        return out[: shape[0] * shape[1] * shape[2]].reshape(shape, order="F").copy()
+
+    def site_tensor_dims(self, site):
+        d = (c_size_t * 3)()
+        _check(_lib.t4a_gpu_tci2_site_tensor(self._h, c_size_t(site), d, None))
+        return (d[0], d[1], d[2])
+
+    def site_tensor_to_device(self, site, device_ptr):
+        _check(_lib.t4a_gpu_tci2_site_tensor_device(self._h, c_size_t(site), c_void_p(device_ptr)))
+
+    def set_site_tensor_from_device(self, site, dims3, device_ptr):
+        d = (c_size_t * 3)(*[int(x) for x in dims3])
+        _check(_lib.t4a_gpu_tci2_set_site_tensor_device(self._h, c_size_t(site), d, c_void_p(device_ptr)))
+
+    def set_site_shard(self, rank, world):
+        _check(_lib.t4a_gpu_tci2_set_site_shard(self._h, c_size_t(rank), c_size_t(world)))
+
+    def history(self):
+        n = c_size_t(0)
+        _check(_lib.t4a_gpu_tci2_n_iterations(self._h, ctypes.byref(n)))
+        ranks = np.zeros(max(n.value, 1), dtype=np.uintp)
+        errors = np.zeros(max(n.value, 1), dtype=np.float64)
+        _check(_lib.t4a_gpu_tci2_history(self._h, _p(ranks), _p(errors)))
+        return [int(r) for r in ranks[: n.value]], errors[: n.value].copy()
+
+    def termination(self):
+        v = c_int32(0)
+        _check(_lib.t4a_gpu_tci2_termination(self._h, ctypes.byref(v)))
+        return v.value
+
+    def evaluate(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uintp).reshape(-1, len(self.local_dims)))
+        out = np.zeros(idx.shape[0], dtype=np.float64)
+        _check(_lib.t4a_gpu_tci2_evaluate(self._h, _p(idx), c_size_t(idx.shape[0]), _p(out)))
+        return out
+
+    def sum(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_tci2_sum(self._h, ctypes.byref(v)))
+        return v.value
+
+    def last_sweep_shapes(self):
+        out = np.zeros(3 * (len(self.local_dims) - 1), dtype=np.uintp)
+        _check(_lib.t4a_gpu_tci2_last_sweep_shapes(self._h, _p(out)))
+        return out.reshape(-1, 3).astype(np.int64)
+
+    def profile_enable(self, on=True):
+        _check(_lib.t4a_gpu_tci2_profile_enable(self._h, c_int32(1 if on else 0)))
+
+    def profile_reset(self):
+        _check(_lib.t4a_gpu_tci2_profile_reset(self._h))
+
+    def profile(self):
+        out = np.zeros(16, dtype=np.float64)
+        _check(_lib.t4a_gpu_tci2_profile_get(self._h, _p(out)))
+        keys = ["rrlu_ms", "rrlu_launches", "pi_ms", "pi_launches", "fill_ms", "fill_calls", "factor_ms",
+                "factor_calls", "pivot_steps", "rrlu_bytes", "flops", "evals"]
+        return {k: float(out[i]) for i, k in enumerate(keys)}
+
+
+def crossinterpolate2(f, local_dims, initial_pivots, options):
+    """crossinterpolate2 (tensorci2.rs:1513). Returns the optimised TensorCI2; histories via .history()."""
+    options.to_c()  # validate before anything else
+    tci = TensorCI2(local_dims)
+    tci.set_function(f)
+    tci.crossinterpolate2(initial_pivots, options)
+    return tci
