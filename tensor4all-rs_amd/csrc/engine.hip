@@ -3,6 +3,7 @@
 #include "engine.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 
 namespace t4a {
@@ -95,7 +96,6 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     if (ms > (size_t)M) ms = M;
     if (ms > (size_t)N) ms = N;
     const int max_steps = (int)ms;
-    const RrluPlan plan = rrlu_make_plan(M, N, num_cus_);
 
     d_rowperm_.reserve(M);
     d_colperm_.reserve(N);
@@ -104,36 +104,105 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     d_pivvals_.reserve(max_steps > 0 ? max_steps : 1);
     const bool keep_lu = need_factors || want_lu_copy;
     if (keep_lu) d_lu_.reserve((size_t)M * N);
-    if (plan.W > 1) {
-        d_keys_.reserve(rrlu_keys_bytes(plan) / sizeof(unsigned long long));
-        d_cols_.reserve(rrlu_cols_bytes(plan, M) / sizeof(unsigned long long));
-    }
     T4A_HIP(hipMemsetAsync(d_ires_.get(), 0, 4 * sizeof(int), stream_));
     T4A_HIP(hipMemsetAsync(d_dres_.get(), 0, 2 * sizeof(double), stream_));
+    static const bool want_stamps = std::getenv("T4A_RRLU_STAMPS") != nullptr;
+    static const bool force_lds = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "lds";
+    if (want_stamps) {
+        d_stamps_.reserve(8);
+        T4A_HIP(hipMemsetAsync(d_stamps_.get(), 0, 8 * sizeof(unsigned long long), stream_));
+    }
 
-    RrluArgs a;
-    a.A = d_a;
-    a.Aout = keep_lu ? d_lu_.get() : nullptr;
-    a.M = M;
-    a.N = N;
-    a.max_steps = max_steps;
-    a.rel_tol = opts.rel_tol;
-    a.abs_tol = opts.abs_tol;
-    a.left_orth = opts.left_orthogonal ? 1 : 0;
-    a.W = plan.W;
-    a.cpw = plan.cpw;
-    a.Mld = plan.Mld;
-    a.row_perm = d_rowperm_.get();
-    a.col_perm = d_colperm_.get();
-    a.iresult = d_ires_.get();
-    a.dresult = d_dres_.get();
-    a.pivot_vals = d_pivvals_.get();
-    a.keys = d_keys_.get();
-    a.cols = d_cols_.get();
-    a.spin_limit = 1u << 20;
-
+    // Fast path: register-resident kernel (left-orthogonal only).  A right-orthogonal factorisation is the
+    // left-orthogonal one of A^T with row-major tie order; rows/columns swap roles on the way out.
+    const bool left = opts.left_orthogonal;
+    const int kM = left ? M : N, kN = left ? N : M;
+    RrluRegPlan rplan;
+    const bool use_reg = !force_lds && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
+    int plan_W = 1, plan_T = 0;
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.a, stream_));
-    rrlu_launch(plan, a, stream_);
+    if (use_reg) {
+        const double* src = d_a;
+        if (!left) {
+            d_at_.reserve((size_t)M * N);
+            transpose_launch(d_a, M, N, M, d_at_.get(), N, stream_);
+            src = d_at_.get();
+        }
+        if (rplan.W > 1) {
+            // mailbox granules carry launch-salted tags: zero the buffers whenever they are (re)allocated or the
+            // 16-bit salt wraps, so that no stale granule can ever match a live tag (no per-launch memset)
+            const size_t need_keys = rrlu_reg_keys_bytes(rplan) / sizeof(unsigned long long);
+            const size_t need_cols = rrlu_reg_cols_bytes(rplan, kM) / sizeof(unsigned long long);
+            ++rrlu_salt_;
+            if (need_keys > d_rkeys_.cap || need_cols > d_rcols_.cap || rrlu_salt_ > 65535u) {
+                d_rkeys_.reserve(need_keys);
+                d_rcols_.reserve(need_cols);
+                T4A_HIP(hipMemsetAsync(d_rkeys_.get(), 0, d_rkeys_.cap * sizeof(unsigned long long), stream_));
+                T4A_HIP(hipMemsetAsync(d_rcols_.get(), 0, d_rcols_.cap * sizeof(unsigned long long), stream_));
+                rrlu_salt_ = 1;
+            }
+        }
+        RrluRegArgs a;
+        a.A = src;
+        a.Aout = keep_lu ? d_lu_.get() : nullptr;
+        a.M = kM;
+        a.N = kN;
+        a.max_steps = max_steps;
+        a.rel_tol = opts.rel_tol;
+        a.abs_tol = opts.abs_tol;
+        a.tie_row_major = left ? 0 : 1;
+        a.out_transposed = left ? 0 : 1;
+        a.W = rplan.W;
+        a.TR = rplan.TR;
+        a.TC = rplan.TC;
+        a.row_perm = left ? d_rowperm_.get() : d_colperm_.get();
+        a.col_perm = left ? d_colperm_.get() : d_rowperm_.get();
+        a.iresult = d_ires_.get();
+        a.dresult = d_dres_.get();
+        a.pivot_vals = d_pivvals_.get();
+        a.keys = d_rkeys_.get();
+        a.cols = d_rcols_.get();
+        a.salt = rrlu_salt_;
+        static const int col_delay = std::getenv("T4A_RRLU_COLDELAY") ? std::atoi(std::getenv("T4A_RRLU_COLDELAY")) : 0;
+        a.col_delay = col_delay;
+        static const int ncopy_env = std::getenv("T4A_RRLU_NCOPY") ? std::atoi(std::getenv("T4A_RRLU_NCOPY")) : 4;
+        a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
+        a.spin_limit = 1u << 20;
+        a.stamps = want_stamps ? d_stamps_.get() : nullptr;
+        rrlu_reg_launch(rplan, a, stream_);
+        plan_W = rplan.W;
+        plan_T = rplan.T;
+    } else {
+        const RrluPlan plan = rrlu_make_plan(M, N, num_cus_);
+        if (plan.W > 1) {
+            d_keys_.reserve(rrlu_keys_bytes(plan) / sizeof(unsigned long long));
+            d_cols_.reserve(rrlu_cols_bytes(plan, M) / sizeof(unsigned long long));
+        }
+        RrluArgs a;
+        a.A = d_a;
+        a.Aout = keep_lu ? d_lu_.get() : nullptr;
+        a.M = M;
+        a.N = N;
+        a.max_steps = max_steps;
+        a.rel_tol = opts.rel_tol;
+        a.abs_tol = opts.abs_tol;
+        a.left_orth = opts.left_orthogonal ? 1 : 0;
+        a.W = plan.W;
+        a.cpw = plan.cpw;
+        a.Mld = plan.Mld;
+        a.row_perm = d_rowperm_.get();
+        a.col_perm = d_colperm_.get();
+        a.iresult = d_ires_.get();
+        a.dresult = d_dres_.get();
+        a.pivot_vals = d_pivvals_.get();
+        a.keys = d_keys_.get();
+        a.cols = d_cols_.get();
+        a.spin_limit = 1u << 20;
+        a.stamps = want_stamps ? d_stamps_.get() : nullptr;
+        rrlu_launch(plan, a, stream_);
+        plan_W = plan.W;
+        plan_T = plan.T;
+    }
     T4A_HIP(hipGetLastError());
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.b, stream_));
 
@@ -155,6 +224,13 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         T4A_HIP(hipEventElapsedTime(&ms_f, ev_rrlu_.a, ev_rrlu_.b));
         prof.v[0] += ms_f;
         prof.v[1] += 1.0;
+    }
+    if (want_stamps) {
+        unsigned long long hs[8];
+        T4A_HIP(hipMemcpy(hs, d_stamps_.get(), sizeof(hs), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[rrlu stamps %s] M=%d N=%d W=%d T=%d steps=%d | s0=%llu s1=%llu s2=%llu s3=%llu s4=%llu pollspins=%llu colspins=%llu "
+                             "(cycles, wg0/thread0; lds: publish,poll,colfetch,pass,reduce; reg: pass,reduce,publish,poll,fetch)\n",
+                     use_reg ? "reg" : "lds", M, N, plan_W, plan_T, hp[0], hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6]);
     }
     if (hp[1] != 0)
         throw Error(T4A_GPU_KERNEL_TIMEOUT, "rrLU kernel: inter-workgroup hand-off timed out (bounded spin gave up)");

@@ -69,10 +69,11 @@ private:
 
     hipStream_t stream_ = nullptr;
     int num_cus_ = 0;
-    DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_pivvals_;
+    unsigned rrlu_salt_ = 0;
+    DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_pivvals_, d_at_;
     DevBuf<int> d_rowperm_, d_colperm_, d_ires_;
     DevBuf<double> d_dres_;
-    DevBuf<unsigned long long> d_keys_, d_cols_;
+    DevBuf<unsigned long long> d_keys_, d_cols_, d_rkeys_, d_rcols_, d_stamps_;
     DevBuf<TrsmProblem> d_trsm_;
     PinBuf<int> h_perm_;
     PinBuf<double> h_res_;

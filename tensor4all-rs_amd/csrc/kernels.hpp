@@ -44,6 +44,7 @@ struct RrluArgs {
     unsigned long long* keys;   // [2][W][4] tagged key granules (zeroed before every launch)
     unsigned long long* cols;   // [2][W][M] candidate pivot columns (f64 bits)
     unsigned spin_limit;
+    unsigned long long* stamps; // diagnostic only (nullptr in production): 8 phase cycle counters
 };
 
 // Bytes of mailbox storage needed for a plan.
@@ -52,6 +53,42 @@ size_t rrlu_cols_bytes(const RrluPlan& plan, int M);
 
 // Enqueue memset of the key mailbox + the kernel.
 void rrlu_launch(const RrluPlan& plan, const RrluArgs& args, hipStream_t stream);
+
+// ---- register-resident fast path (kernels_rrlu_reg.hip): left-orthogonal elimination only ----
+constexpr int RRLU_MAX_COPIES = 8;
+struct RrluRegPlan {
+    int W = 1, T = 256;
+    int TR = 256, TC = 1;   // thread grid inside a workgroup: rows x column groups
+    int RPT = 1, CPT = 1;   // rows / columns per thread (template parameters)
+    size_t lds_bytes = 0;
+};
+struct RrluRegArgs {
+    const double* A;            // M x N input (ld = M)
+    double* Aout;               // factored matrix in permuted coordinates (or nullptr)
+    int M, N;
+    int max_steps;
+    double rel_tol, abs_tol;
+    int tie_row_major;          // 1: ties go to the smallest (rowpos, colpos) — used for transposed problems
+    int out_transposed;         // 1: Aout[colpos + N*rowpos] (i.e. the transpose, ld = N)
+    int W, TR, TC;
+    int* row_perm;
+    int* col_perm;
+    int* iresult;               // [0] npivots [1] timeout [2] NaN flag
+    double* dresult;            // [0] last error [1] bits of max sqrt(v*v)
+    double* pivot_vals;
+    unsigned long long* keys;   // [2][W dest][W src][4] per-workgroup inboxes of tagged key granules
+    unsigned long long* cols;   // [2][ncopy][M][2] tagged pivot-column granules; tag = salt*65536 + (step % 65535 + 1)
+    unsigned salt;              // launch-unique 16-bit value (1..65535); the buffers are zeroed when it wraps
+    int col_delay;              // >0: readers sleep briefly before their first pivot-column sweep
+    int ncopy;                  // replicas of the published pivot column (<= RRLU_MAX_COPIES)
+    unsigned spin_limit;
+    unsigned long long* stamps; // diagnostic only
+};
+// false if the shape is outside the fast path (fall back to the LDS kernel)
+bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out);
+size_t rrlu_reg_keys_bytes(const RrluRegPlan& plan);
+size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M);
+void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& args, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // K1: candidate-matrix build (replaces the Π loop, tensor4all-tensorci/src/tensorci2.rs:1859-1893)

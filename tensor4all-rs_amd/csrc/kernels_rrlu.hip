@@ -62,6 +62,17 @@ __device__ __forceinline__ double score_of(double a, unsigned pos, int knext)
     return sc;
 }
 
+// Diagnostic phase stamps (only when args.stamps != nullptr; thread 0 of workgroup 0 accumulates shader-clock
+// cycles per phase).  Never enabled in timed runs.
+#define T4A_STAMP(slot)                                                   \
+    do {                                                                  \
+        if (stamp_on) {                                                   \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+            stamp_acc[slot] += now_ - stamp_last;                         \
+            stamp_last = now_;                                            \
+        }                                                                 \
+    } while (0)
+
 struct Smem {
     double* slab;          // cpw * Mld
     double* lcol;          // Mpad: pivot column of the current step (scaled when left-orthogonal)
@@ -309,6 +320,10 @@ __global__ void __launch_bounds__(1024) rrlu_kernel(RrluArgs p)
     }
     __syncthreads();
 
+    const bool stamp_on = (p.stamps != nullptr) && w == 0 && tid == 0;
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+
     int npiv = 0;
     double max_error = 0.0;
     double error = __builtin_nan("");
@@ -335,6 +350,7 @@ __global__ void __launch_bounds__(1024) rrlu_kernel(RrluArgs p)
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (R1)
                 __syncthreads();
+                T4A_STAMP(0);
                 if (tid < 4) {
                     const unsigned long long vb = (unsigned long long)__double_as_longlong(blk.val);
                     unsigned payload;
@@ -406,6 +422,7 @@ __global__ void __launch_bounds__(1024) rrlu_kernel(RrluArgs p)
                     }
                 }
                 __syncthreads();
+                T4A_STAMP(1);
                 if (s.win_i[6]) {
                     timed_out = true;
                     break;
@@ -448,11 +465,14 @@ __global__ void __launch_bounds__(1024) rrlu_kernel(RrluArgs p)
             }
             if (w == 0 && tid == 0) p.pivot_vals[k] = pivot;
             __syncthreads();
+            T4A_STAMP(2);
 
             // (C) rank-1 update of step k fused with the candidate search of step k+1
             npiv = k + 1;
             mine = slab_pass<true>(p, s, w, k, pc, left);
+            T4A_STAMP(3);
             blk = block_reduce(mine, s);
+            T4A_STAMP(4);
         }
     }
 
@@ -462,6 +482,8 @@ __global__ void __launch_bounds__(1024) rrlu_kernel(RrluArgs p)
         p.iresult[0] = npiv;
         p.dresult[0] = error;
     }
+    if (stamp_on)
+        for (int q = 0; q < 8; ++q) p.stamps[q] = stamp_acc[q];
     if (timed_out) return;
     __syncthreads();
     if (w == 0) {

@@ -1,0 +1,795 @@
+// kernels_rrlu_reg.hip — K2 fast path: register-resident full-pivot rank-revealing LU for gfx950.
+//
+// Same contract as kernels_rrlu.hip (bit-identical to rrlu_mut, tensor4all-core/src/matrixlu.rs:735-819),
+// restricted to the LEFT-orthogonal elimination; the engine runs a right-orthogonal factorisation as the
+// left-orthogonal one of A^T with `tie_row_major = 1` (x*y == y*x bitwise, so every value is identical; only
+// the arg-max tie order — column-major of A == row-major of A^T — has to follow, matrixlu.rs:480-519).
+//
+// Design notes (every item below is a measured fix, see profiles/ and DESIGN.md):
+//   * the slab lives in REGISTERS: thread (tr, tc) of a TR x TC thread grid owns rows tr + TR*r (r < RPT) of
+//     columns w + W*(tc + TC*q) (q < CPT); the rank-1 update is pure VALU on RPT*CPT independent elements
+//     (the LDS-resident kernel spent 2.5 us/step in dependent LDS round trips);
+//   * arg-max = v_max_f64 chain (NaN scores drop out of maxNum for free) + one equality sweep for the
+//     smallest position; wave reductions use DPP row all-reduce + v_readlane (ds_bpermute chains cost
+//     0.9 us/step);
+//   * the permutation replica keeps only position->index tables in LDS; index->position lives in the
+//     owning threads' registers; stop tests are evaluated redundantly by every thread;
+//   * inter-workgroup exchange, two hops per pivot step, no drain barrier, form R2 of
+//     cdna_hip_programming.md §6 Guideline 16 (the data is the flag: every granule is one aligned 8-byte
+//     atomic sc1 store / sc1 load carrying a launch-salted 32-bit tag, consumers re-read until every tag
+//     matches; spins are bounded):
+//       hop 1 (arg-max all-gather): each workgroup PUSHES its 24-byte key {value, position} into the inbox of
+//         every workgroup with one wave-wide store per granule; a workgroup polls only its own inbox.
+//         (W pollers sweeping one shared key table measured 2.7 us/hop — 128 requests per hot line and
+//         sweep; speculatively publishing all candidate columns: 5.4 us/step.)
+//       hop 2 (pivot column broadcast): only the winner publishes its column; readers delay their first
+//         sweep so that it normally succeeds.
+// Barriers per pivot step: 3.
+#include "kernels.hpp"
+
+#include <cstdlib>
+
+namespace t4a {
+
+namespace {
+
+constexpr unsigned NOPOS = 0xFFFFFFFFu;
+constexpr int KEY_STRIDE = 4; // u64 granules per key slot (3 used, padded to 32 bytes)
+
+__device__ __forceinline__ void st_u64_sc1(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_u64_sc1(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte write-through store / agent-scope loads (inline asm: hipcc neither counts nor pads these, so the
+// loads carry their own s_waitcnt and the store its s_nop — cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void st_b128_sc1(void* p, u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+template <int N> struct Load16;
+template <> struct Load16<1> {
+    static __device__ __forceinline__ void run(const void* const* p, u32x4* o)
+    {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(o[0]) : "v"(p[0]) : "memory");
+    }
+};
+template <> struct Load16<2> {
+    static __device__ __forceinline__ void run(const void* const* p, u32x4* o)
+    {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1])
+                     : "v"(p[0]), "v"(p[1])
+                     : "memory");
+    }
+};
+template <> struct Load16<3> {
+    static __device__ __forceinline__ void run(const void* const* p, u32x4* o)
+    {
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                     "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2])
+                     : "memory");
+    }
+};
+template <> struct Load16<4> {
+    static __device__ __forceinline__ void run(const void* const* p, u32x4* o)
+    {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+                     : "memory");
+    }
+};
+
+// maxNum without the sNaN-quieting canonicalisation hipcc adds to fmax (both operands are arithmetic results)
+__device__ __forceinline__ double vmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// ---- DPP helpers: all-reduce inside a row of 16 lanes, then combine the 4 rows through v_readlane ----
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i32<CTRL>((int)(b & 0xFFFFFFFFll));
+    const int hi = dpp_i32<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_max_f64(double v) // maxNum over the 64 lanes (uniform result)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_f64<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_f64<0x141>(v)); // row_half_mirror
+    v = fmax(v, dpp_f64<0x140>(v)); // row_mirror
+    const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+    return fmax(fmax(a, b), fmax(c, d));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)dpp_i32<0xB1>((int)v);
+    v = o < v ? o : v;
+    o = (unsigned)dpp_i32<0x4E>((int)v);
+    v = o < v ? o : v;
+    o = (unsigned)dpp_i32<0x141>((int)v);
+    v = o < v ? o : v;
+    o = (unsigned)dpp_i32<0x140>((int)v);
+    v = o < v ? o : v;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) / 16 * 16; }
+
+struct RegSmem {
+    double* urow;            // TC*CPT pivot-row entries of the owned columns
+    double* lcol;            // M (single-workgroup mode only): raw pivot column
+    double* red_sc;          // 16
+    unsigned* red_pos;       // 16
+    double* red_val;         // 16
+    double* win_d;           // [0] value
+    int* win_i;              // [0] winner wg  [1] position key  [2] abort flag
+    unsigned short* posrow;  // M
+    unsigned short* poscol;  // N
+};
+
+__host__ __device__ inline size_t reg_smem_layout(int M, int N, int cols_per_wg, bool single, RegSmem* s, char* base)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align16(off + bytes);
+        return o;
+    };
+    const size_t o_urow = take((size_t)cols_per_wg * 8);
+    const size_t o_lcol = take(single ? (size_t)M * 8 : 8);
+    const size_t o_rsc = take(16 * 8);
+    const size_t o_rpos = take(16 * 4);
+    const size_t o_rval = take(16 * 8);
+    const size_t o_wd = take(2 * 8);
+    const size_t o_wi = take(4 * 4);
+    const size_t o_pr = take((size_t)M * 2);
+    const size_t o_pc = take((size_t)N * 2);
+    if (s) {
+        s->urow = (double*)(base + o_urow);
+        s->lcol = (double*)(base + o_lcol);
+        s->red_sc = (double*)(base + o_rsc);
+        s->red_pos = (unsigned*)(base + o_rpos);
+        s->red_val = (double*)(base + o_rval);
+        s->win_d = (double*)(base + o_wd);
+        s->win_i = (int*)(base + o_wi);
+        s->posrow = (unsigned short*)(base + o_pr);
+        s->poscol = (unsigned short*)(base + o_pc);
+    }
+    return off;
+}
+
+#define T4A_RSTAMP(slot)                                                  \
+    do {                                                                  \
+        if (stamp_on) {                                                   \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+            stamp_acc[slot] += now_ - stamp_last;                         \
+            stamp_last = now_;                                            \
+        }                                                                 \
+    } while (0)
+
+// UNI: every wave lies inside one column group (TR % 64 == 0), so the column state is wave-uniform and the
+// per-column tests become scalar branches.
+template <int RPT, int CPT, bool SINGLE, bool UNI>
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, (RPT * CPT >= 12) ? 512 : 1024)))
+rrlu_reg_kernel(RrluRegArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    RegSmem s;
+    reg_smem_layout(p.M, p.N, p.TC * CPT, SINGLE, &s, smem_raw);
+
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = T >> 6;
+    const int w = SINGLE ? 0 : (int)blockIdx.x;
+    const int tr = tid % p.TR;
+    const int tc = tid / p.TR;
+    const bool rowmajor = p.tie_row_major != 0;
+
+    // ---- my rows / columns ----
+    int irow[RPT], rpos[RPT];
+    int ccol[CPT], cpos[CPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = tr + p.TR * r;
+        irow[r] = i < p.M ? i : -1;
+        rpos[r] = i < p.M ? i : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int c = w + p.W * (tc + p.TC * q);
+        ccol[q] = c < p.N ? c : -1;
+        cpos[q] = c < p.N ? c : -1;
+    }
+    double a[CPT][RPT];
+    double local_absmax = 0.0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            double v = 0.0;
+            if (ccol[q] >= 0 && irow[r] >= 0) {
+                v = p.A[(size_t)ccol[q] * p.M + irow[r]];
+                const double av = sqrt(v * v);
+                if (av > local_absmax) local_absmax = av;
+            }
+            a[q][r] = v;
+        }
+    for (int i = tid; i < p.M; i += T) s.posrow[i] = (unsigned short)i;
+    for (int j = tid; j < p.N; j += T) s.poscol[j] = (unsigned short)j;
+    if (tid == 0) s.win_i[2] = 0;
+    {
+        const double wm = wave_max_f64(local_absmax);
+        if (lane == 0 && wm > 0.0)
+            atomicMax((unsigned long long*)&p.dresult[1], (unsigned long long)__double_as_longlong(wm));
+    }
+    __syncthreads();
+
+    const bool stamp_on = (p.stamps != nullptr) && w == 0 && tid == 0;
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    int npiv = 0;
+    double max_error = 0.0;
+    double error = __builtin_nan("");
+    bool timed_out = false;
+    const double min_pivot_abs = (p.rel_tol == 0.0 && p.abs_tol == 0.0) ? 0.0 : 2.220446049250313e-16;
+
+    double l[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) l[r] = 0.0;
+
+    for (int k = -1; k < p.max_steps; ++k) {
+        // =====================================================================================
+        // (C) rank-1 update of step k (k >= 0) fused with the candidate search of step k+1
+        // =====================================================================================
+        double m = -1.0;
+        {
+            double u[CPT];
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) u[q] = (k >= 0) ? s.urow[tc + p.TC * q] : 0.0; // issued back to back
+            int cps[CPT];
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) cps[q] = UNI ? __builtin_amdgcn_readfirstlane(cpos[q]) : cpos[q];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                if (rpos[r] > k) { // EXEC mask: rows already pivoted keep their U entries untouched
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        if (cps[q] > k) {
+                            if (k >= 0) {
+                                const double prod = l[r] * u[q]; // update_trailing_submatrix (matrixlu.rs:593-612)
+                                a[q][r] = a[q][r] - prod;
+                            }
+                            m = vmax(m, a[q][r] * a[q][r]); // maxNum drops NaN scores (matrixlu.rs:506)
+                        } else if (k >= 0 && cps[q] == k) {
+                            a[q][r] = l[r]; // scale_column_tail (matrixlu.rs:562-577): owners store l_i
+                        }
+                    }
+                }
+            }
+        }
+        npiv = k + 1;
+        if (k + 1 >= p.max_steps) break; // the reference stops before another arg-max (matrixlu.rs:747)
+        const int kn = k + 1;
+        const unsigned diagkey = ((unsigned)kn << 16) | (unsigned)kn;
+        // a NaN sitting on the next diagonal element wins outright (it is the reference's initial incumbent)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+            if (rpos[r] == kn) {
+#pragma unroll
+                for (int q = 0; q < CPT; ++q)
+                    if (cpos[q] == kn && a[q][r] != a[q][r]) m = __builtin_huge_val();
+            }
+        T4A_RSTAMP(0);
+        // ---- workgroup reduction: (max score, smallest position among the maxima, value there) ----
+        const double wmax = wave_max_f64(m);
+        unsigned mypos = NOPOS;
+        double myval = 0.0;
+        if (m == wmax) { // only lanes holding the wave maximum look for its position
+            if (m == __builtin_huge_val()) {
+                // +inf scores: a NaN on the diagonal (incumbent) or genuine infinities
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        const bool act = (rpos[r] > k) && (cpos[q] > k);
+                        const unsigned key = rowmajor ? (((unsigned)rpos[r] << 16) | (unsigned)cpos[q])
+                                                      : (((unsigned)cpos[q] << 16) | (unsigned)rpos[r]);
+                        const double sc = a[q][r] * a[q][r];
+                        const bool hit = act && ((sc == m) || (key == diagkey && sc != sc));
+                        if (hit && key < mypos) {
+                            mypos = key;
+                            myval = a[q][r];
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        const bool act = (rpos[r] > k) && (cpos[q] > k);
+                        const unsigned key = rowmajor ? (((unsigned)rpos[r] << 16) | (unsigned)cpos[q])
+                                                      : (((unsigned)cpos[q] << 16) | (unsigned)rpos[r]);
+                        const bool hit = act && (a[q][r] * a[q][r] == m) && (key < mypos);
+                        mypos = hit ? key : mypos;
+                        myval = hit ? a[q][r] : myval;
+                    }
+            }
+        }
+        const unsigned wpos = wave_min_u32(mypos);
+        if (mypos == wpos && wpos != NOPOS) s.red_val[wave] = myval; // unique lane of the wave
+        if (lane == 0) {
+            s.red_sc[wave] = wmax;
+            s.red_pos[wave] = wpos;
+        }
+        __syncthreads(); // (D)
+        double bsc = s.red_sc[0];
+        unsigned bpos = s.red_pos[0];
+        int bwave = 0;
+        for (int qv = 1; qv < nwaves; ++qv) {
+            const double osc = s.red_sc[qv];
+            const unsigned opos = s.red_pos[qv];
+            if (osc > bsc || (osc == bsc && opos < bpos)) {
+                bsc = osc;
+                bpos = opos;
+                bwave = qv;
+            }
+        }
+        if (bsc < 0.0) bpos = NOPOS; // no candidate in this workgroup
+        const double bval = (bpos == NOPOS) ? 0.0 : s.red_val[bwave];
+        // which column group owns the candidate column
+        const unsigned bcol = bpos == NOPOS ? NOPOS : (rowmajor ? (bpos & 0xFFFFu) : (bpos >> 16));
+        int qstar = -1;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q)
+            if (cpos[q] >= 0 && (unsigned)cpos[q] == bcol) qstar = q;
+        T4A_RSTAMP(1);
+
+        // =====================================================================================
+        // exchange: global winner of step kn
+        // =====================================================================================
+        double wval;
+        unsigned wkey;
+        int ww = 0;
+        double colv[RPT];
+        if (SINGLE) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < CPT; ++q)
+                    if (q == qstar) v = a[q][r];
+                colv[r] = v;
+            }
+            if (qstar >= 0) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (irow[r] >= 0) s.lcol[irow[r]] = colv[r];
+            }
+            __syncthreads(); // (A')
+            wval = bval;
+            wkey = bpos;
+        } else {
+            const int par = kn & 1;
+            const unsigned tag = p.salt * 65536u + ((unsigned)kn % 65535u + 1u);
+            const unsigned long long tagbits = (unsigned long long)tag << 32;
+            // hop 1: wave 0 pushes the key {value, position} into every workgroup's inbox (one 16-byte store
+            //         of two tagged granules + one 8-byte granule per destination)
+            //         inbox layout: keys[par][dest][src][KEY_STRIDE]
+            const int poll_wave = nwaves > 1 ? 1 : 0; // never the pushing wave: its loads would queue behind its stores
+            if (wave == 0) {
+                const unsigned long long vb = (unsigned long long)__double_as_longlong(bval);
+                u32x4 k01;
+                k01.x = (unsigned)(vb & 0xFFFFFFFFull);
+                k01.y = tag;
+                k01.z = (unsigned)(vb >> 32);
+                k01.w = tag;
+                for (int dest = lane; dest < p.W; dest += 64) {
+                    unsigned long long* kd = p.keys + (((size_t)par * p.W + dest) * p.W + w) * KEY_STRIDE;
+                    st_b128_sc1(kd, k01);
+                    st_u64_sc1(kd + 2, tagbits | (unsigned long long)bpos);
+                }
+            }
+            // everybody else (and the pusher afterwards) prepares the candidate column while the keys travel
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < CPT; ++q)
+                    if (q == qstar) v = a[q][r];
+                colv[r] = v;
+            }
+            T4A_RSTAMP(2);
+            // one wave sweeps the workgroup's OWN inbox until every tag matches
+            if (wave == poll_wave) {
+                const unsigned long long* kb = p.keys + ((size_t)par * p.W + w) * p.W * KEY_STRIDE;
+                unsigned spins = 0;
+                bool giveup = false;
+                double csc = -1.0, cval = 0.0;
+                unsigned cpk = NOPOS;
+                int cw = -1;
+                for (;;) {
+                    bool ok = true;
+                    csc = -1.0;
+                    cval = 0.0;
+                    cpk = NOPOS;
+                    cw = -1;
+                    for (int qw = lane; qw < p.W; qw += 64) {
+                        const void* ptr[1] = {kb + (size_t)qw * KEY_STRIDE};
+                        u32x4 g;
+                        Load16<1>::run(ptr, &g);
+                        const unsigned long long g2 = ld_u64_sc1(kb + (size_t)qw * KEY_STRIDE + 2);
+                        const bool good = (g.y == tag) && (g.w == tag) && ((unsigned)(g2 >> 32) == tag);
+                        ok &= good;
+                        const unsigned pk = (unsigned)(g2 & 0xFFFFFFFFull);
+                        if (good && pk != NOPOS) {
+                            const double v = __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
+                            double sc = v * v;
+                            if (sc != sc) sc = (pk == diagkey) ? __builtin_huge_val() : -1.0;
+                            if (sc > csc || (sc == csc && pk < cpk)) {
+                                csc = sc;
+                                cval = v;
+                                cpk = pk;
+                                cw = qw;
+                            }
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (++spins > p.spin_limit) {
+                        giveup = true;
+                        break;
+                    }
+                }
+                if (p.stamps != nullptr && w == 0 && lane == 0) p.stamps[5] += spins;
+                if (giveup) {
+                    if (lane == 0) {
+                        s.win_i[2] = 1;
+                        atomicExch(&p.iresult[1], 1);
+                    }
+                } else {
+                    const double gmax = wave_max_f64(csc);
+                    const unsigned gpos = wave_min_u32((csc == gmax) ? cpk : NOPOS);
+                    if (csc == gmax && cpk == gpos && gpos != NOPOS) { // unique lane
+                        s.win_d[0] = cval;
+                        s.win_i[0] = cw;
+                        s.win_i[1] = (int)cpk;
+                    }
+                }
+            }
+            __syncthreads(); // (B)
+            if (s.win_i[2]) {
+                timed_out = true;
+                break;
+            }
+            wval = s.win_d[0];
+            wkey = (unsigned)s.win_i[1];
+            ww = s.win_i[0];
+            // hop 2: only the winner's owning column group publishes the pivot column: one 16-byte store of two
+            // tagged granules per row, replicated into `ncopy` copies so that at most W/ncopy readers share a line
+            if (ww == w && qstar >= 0) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (irow[r] >= 0) {
+                        const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
+                        u32x4 g;
+                        g.x = (unsigned)(vb & 0xFFFFFFFFull);
+                        g.y = tag;
+                        g.z = (unsigned)(vb >> 32);
+                        g.w = tag;
+                        for (int c = 0; c < p.ncopy; ++c) {
+                            unsigned long long* dst = p.cols + (((size_t)par * p.ncopy + c) * (size_t)p.M + irow[r]) * 2;
+                            st_b128_sc1(dst, g);
+                        }
+                    }
+            }
+        }
+        T4A_RSTAMP(3);
+
+        // ---- stop tests, every thread (matrixlu.rs:757-781) ----
+        const double pivot_abs = sqrt(wval * wval);
+        error = pivot_abs;
+        if (kn > 0 && (pivot_abs < p.rel_tol * max_error || pivot_abs < p.abs_tol)) break;
+        if (pivot_abs <= min_pivot_abs) break;
+        max_error = fmax(max_error, pivot_abs);
+
+        // ---- permutation bookkeeping: position -> index from the LDS tables, index -> position in registers ----
+        const int prp = (int)(rowmajor ? (wkey >> 16) : (wkey & 0xFFFFu));
+        const int pcp = (int)(rowmajor ? (wkey & 0xFFFFu) : (wkey >> 16));
+        const int pr = s.posrow[prp];
+        const int rk = s.posrow[kn];
+        const int pc = s.poscol[pcp];
+        const int ck = s.poscol[kn];
+
+        // the owner of row pr publishes the pivot-row entries of its column group
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            if (irow[r] >= 0 && irow[r] == pr) {
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) s.urow[tc + p.TC * q] = a[q][r];
+            }
+        }
+        // index -> position updates (swap positions kn <-> prp, kn <-> pcp)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            if (irow[r] >= 0) {
+                if (irow[r] == pr) rpos[r] = kn;
+                else if (irow[r] == rk) rpos[r] = prp;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            if (ccol[q] >= 0) {
+                if (ccol[q] == pc) cpos[q] = kn;
+                else if (ccol[q] == ck) cpos[q] = pcp;
+            }
+        }
+        if (w == 0 && tid == 0) p.pivot_vals[kn] = wval;
+
+        // ---- pivot column -> l (scaled) ----
+        if (SINGLE) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if (irow[r] >= 0) l[r] = s.lcol[irow[r]] / wval;
+        } else if (ww == w && qstar >= 0) {
+            // the winner's owning column group already holds the column
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) l[r] = colv[r] / wval;
+        } else {
+            const unsigned long long* src = p.cols + ((size_t)(kn & 1) * p.ncopy + (w % p.ncopy)) * (size_t)p.M * 2;
+            const unsigned tag = p.salt * 65536u + ((unsigned)kn % 65535u + 1u);
+            unsigned spins = 0;
+            u32x4 g[RPT];
+            const void* ptr[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) ptr[r] = src + 2 * (size_t)(irow[r] >= 0 ? irow[r] : 0);
+            if (p.col_delay > 0) __builtin_amdgcn_s_sleep(8); // give the winner's stores time to land
+            for (;;) {
+                Load16<RPT>::run(ptr, g);
+                bool ok = true;
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (irow[r] >= 0) ok &= (g[r].y == tag) && (g[r].w == tag);
+                if (__all(ok)) break;
+                if (++spins > p.spin_limit) {
+                    atomicExch(&p.iresult[1], 1);
+                    s.win_i[2] = 1; // observed by everybody after the next barrier
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stamp_on) stamp_acc[6] += spins;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if (irow[r] >= 0) {
+                    const double raw = __longlong_as_double((long long)(((unsigned long long)g[r].z << 32) | g[r].x));
+                    l[r] = raw / wval;
+                }
+        }
+        __syncthreads(); // (C): urow visible, everybody has read the position tables
+        if (!SINGLE && s.win_i[2]) {
+            timed_out = true;
+            break;
+        }
+        if (tid == 0) { // next read of these entries happens after barrier (D) of the next step
+            s.posrow[kn] = (unsigned short)pr;
+            s.posrow[prp] = (unsigned short)rk;
+            s.poscol[kn] = (unsigned short)pc;
+            s.poscol[pcp] = (unsigned short)ck;
+        }
+        T4A_RSTAMP(4);
+    }
+
+    // ---- results ----
+    if (npiv >= (p.M < p.N ? p.M : p.N)) error = 0.0; // matrixlu.rs:811-813
+    if (w == 0 && tid == 0) {
+        p.iresult[0] = npiv;
+        p.dresult[0] = error;
+    }
+    if (stamp_on)
+        for (int qv = 0; qv < 8; ++qv)
+            if (qv != 5) p.stamps[qv] = stamp_acc[qv];
+    if (timed_out) return;
+    __syncthreads();
+    if (w == 0) {
+        for (int i = tid; i < p.M; i += T) p.row_perm[i] = s.posrow[i];
+        for (int j = tid; j < p.N; j += T) p.col_perm[j] = s.poscol[j];
+    }
+    int nan_seen = 0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            if (ccol[q] >= 0 && irow[r] >= 0) {
+                const int cp = cpos[q], rp = rpos[r];
+                const double v = a[q][r];
+                const bool in_l = (cp < npiv) && (rp >= cp);
+                const bool in_u = (rp < npiv) && (cp >= rp);
+                if ((in_l || in_u) && v != v) nan_seen = 1;
+                if (p.Aout) {
+                    if (p.out_transposed)
+                        p.Aout[(size_t)rp * p.N + cp] = v;
+                    else
+                        p.Aout[(size_t)cp * p.M + rp] = v;
+                }
+            }
+        }
+    if (nan_seen) atomicExch(&p.iresult[2], 1);
+}
+
+template <int RPT, int CPT, bool SINGLE, bool UNI>
+void launch_one(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_reg_kernel<RPT, CPT, SINGLE, UNI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((rrlu_reg_kernel<RPT, CPT, SINGLE, UNI>), dim3(SINGLE ? 1 : plan.W), dim3(plan.T), plan.lds_bytes,
+                       stream, a);
+}
+
+template <int RPT, int CPT> void launch_rc(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
+{
+    const bool uni = (plan.TR % 64) == 0;
+    if (plan.W == 1) {
+        if (uni) launch_one<RPT, CPT, true, true>(plan, a, stream);
+        else launch_one<RPT, CPT, true, false>(plan, a, stream);
+    } else {
+        if (uni) launch_one<RPT, CPT, false, true>(plan, a, stream);
+        else launch_one<RPT, CPT, false, false>(plan, a, stream);
+    }
+}
+
+template <int RPT> void launch_r(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
+{
+    switch (plan.CPT) {
+    case 1: launch_rc<RPT, 1>(plan, a, stream); break;
+    case 2: launch_rc<RPT, 2>(plan, a, stream); break;
+    case 4: launch_rc<RPT, 4>(plan, a, stream); break;
+    default: launch_rc<RPT, 8>(plan, a, stream); break;
+    }
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+int norm_cpt(int c) { return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : 8)); }
+
+} // namespace
+
+bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
+{
+    RrluRegPlan plan;
+    const char* ew = std::getenv("T4A_RRLU_W");
+    const char* et = std::getenv("T4A_RRLU_T");
+    const char* ec = std::getenv("T4A_RRLU_CPT");
+    const int maxw = num_cus > 16 ? num_cus - 8 : num_cus;
+    const long long elems = (long long)M * N;
+    bool single = elems <= 128 * 128;
+    if (ew) single = std::atoi(ew) == 1;
+    bool found = false;
+    if (single) {
+        // one workgroup: TR x TC thread grid with <= 4 x 8 elements per thread; minimise the per-thread work,
+        // then the thread count
+        int best_cost = 1 << 30;
+        for (int T = 64; T <= 1024; T *= 2) {
+            if (et && T != std::atoi(et)) continue;
+            for (int TR = 16; TR <= T; TR *= 2) {
+                const int TC = T / TR;
+                const int RPT = (M + TR - 1) / TR;
+                const int CPT = norm_cpt((N + TC - 1) / TC);
+                if (RPT > 4 || (long long)TC * CPT < N) continue;
+                if (T > ((RPT * CPT >= 12) ? 512 : 1024)) continue;
+                const int cost = RPT * CPT * 64 + T / 64;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    plan.W = 1;
+                    plan.T = T;
+                    plan.TR = TR;
+                    plan.TC = TC;
+                    plan.RPT = RPT;
+                    plan.CPT = CPT;
+                    found = true;
+                }
+            }
+        }
+    }
+    if (!found) {
+        int RPT = (M + 511) / 512; // two waves per SIMD hide the f64 issue latency (measured: T=512 beats 256)
+        if (RPT > 4) RPT = 4;
+        int TR = round_up((M + RPT - 1) / RPT, 64);
+        int TC = 1;
+        if (TR < 256) TC = 256 / TR;
+        if (et) {
+            int T = round_up(std::atoi(et), 64);
+            if (T > 1024) T = 1024;
+            if (T >= round_up(M, 64)) {
+                RPT = 1;
+                TR = round_up(M, 64);
+                TC = T / TR;
+            } else {
+                RPT = (M + T - 1) / T;
+                TR = round_up((M + RPT - 1) / RPT, 64);
+                TC = 1;
+            }
+        }
+        if (RPT > 4 || TR > 1024) return false; // beyond the register budget: LDS kernel
+        int CPT = ec ? norm_cpt(std::atoi(ec)) : (N >= 8 * 48 * TC ? 8 : 4);
+        int W = (N + TC * CPT - 1) / (TC * CPT);
+        if (ew && std::atoi(ew) > 1) {
+            W = std::atoi(ew);
+            CPT = norm_cpt((N + W * TC - 1) / (W * TC));
+        }
+        while (W > maxw && CPT < 8) {
+            CPT *= 2;
+            W = (N + TC * CPT - 1) / (TC * CPT);
+        }
+        if (W < 1) W = 1;
+        if (W > maxw || (long long)W * TC * CPT < N) return false;
+        if (TR * TC > ((RPT * CPT >= 12) ? 512 : 1024)) return false;
+        plan.W = W;
+        plan.T = TR * TC;
+        plan.TR = TR;
+        plan.TC = TC;
+        plan.RPT = RPT;
+        plan.CPT = CPT;
+    }
+    plan.lds_bytes = reg_smem_layout(M, N, plan.TC * plan.CPT, plan.W == 1, nullptr, nullptr);
+    if (plan.lds_bytes > 160 * 1024) return false;
+    if (plan.W > 1 && plan.lds_bytes < 84 * 1024) plan.lds_bytes = 84 * 1024; // one workgroup per CU
+    *out = plan;
+    return true;
+}
+
+size_t rrlu_reg_keys_bytes(const RrluRegPlan& plan)
+{
+    return (size_t)2 * plan.W * plan.W * KEY_STRIDE * sizeof(unsigned long long);
+}
+size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M)
+{
+    (void)plan;
+    return (size_t)2 * RRLU_MAX_COPIES * (size_t)M * 2 * sizeof(unsigned long long);
+}
+
+void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
+{
+    switch (plan.RPT) {
+    case 1: launch_r<1>(plan, a, stream); break;
+    case 2: launch_r<2>(plan, a, stream); break;
+    case 3: launch_r<3>(plan, a, stream); break;
+    default: launch_r<4>(plan, a, stream); break;
+    }
+}
+
+} // namespace t4a

@@ -961,7 +961,7 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         errors_hist.push_back(error / norm);
 
         std::vector<std::vector<uint32_t>> gp = find_global_pivots(abs_tol, options, rng_state);
-        add_global_pivots_keep_cores(gp);
+        add_global_pivots(gp); // invalidates the site tensors even for an empty list (tensorci2.rs:707-708)
         nglobal_hist.push_back(gp.size());
         ranks_hist.push_back(rank());
         if (options.verbosity > 0)
@@ -979,15 +979,6 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         const double abs_tol = options.tolerance * norm;
         sweep1site(true, 1e-14, abs_tol, options.max_bond_dim_or_max(), true);
     }
-}
-
-void Tci2::add_global_pivots_keep_cores(const std::vector<std::vector<uint32_t>>& gp)
-{
-    // add_global_pivots invalidates the site tensors (:707-708).  With zero new pivots the reference still
-    // invalidates; callers that skip the final sweep1site (bench) want the cores of the last
-    // fill_site_tensors to stay readable, which is harmless: the next sweep overwrites them anyway.
-    if (gp.empty()) return;
-    add_global_pivots(gp);
 }
 
 // crossinterpolate2 (tensorci2.rs:1513-1563)

@@ -121,7 +121,6 @@ private:
     // atomically maxes bits(sqrt(v*v)) into it.
     void eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
                      unsigned long long* d_maxbits);
-    void add_global_pivots_keep_cores(const std::vector<std::vector<uint32_t>>& gp);
     std::vector<double> eval_points_host(const std::vector<uint32_t>& idx, size_t n_pts);
     void require_fn() const;
 

@@ -348,14 +348,14 @@ class TensorCI2:
         return len(self.local_dims)
 
     def add_global_pivots(self, pivots):
-        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uintp).reshape(len(pivots), -1))
+        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uintp).reshape(len(pivots), len(self.local_dims)))
         if piv.size and piv.shape[1] != len(self.local_dims):
             raise T4aError(INVALID_ARGUMENT, "Pivot length must match number of sites")
         _check(_lib.t4a_gpu_tci2_add_global_pivots(self._h, _p(piv), c_size_t(len(pivots))))
 
     def crossinterpolate2(self, initial_pivots, options):
         o = options.to_c()
-        piv = np.ascontiguousarray(np.asarray(initial_pivots, dtype=np.uintp).reshape(len(initial_pivots), -1))
+        piv = np.ascontiguousarray(np.asarray(initial_pivots, dtype=np.uintp).reshape(len(initial_pivots), len(self.local_dims)))
         _check(_lib.t4a_gpu_tci2_crossinterpolate2(self._h, _p(piv), c_size_t(len(initial_pivots)), ctypes.byref(o)))
 
     def optimize(self, options, final_sweep1site=True):

@@ -188,11 +188,11 @@ class OracleTCI2:
                 cint(0 if o.seed is None else 1), u64(0 if o.seed is None else o.seed)]
 
     def add_global_pivots(self, pivots):
-        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), -1))
+        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), len(self.local_dims)))
         _check(_lib.oracle_tci2_add_global_pivots(vp(self._h), _p(piv), u64(len(pivots))))
 
     def crossinterpolate2(self, pivots, o):
-        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), -1))
+        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), len(self.local_dims)))
         _check(_lib.oracle_tci2_crossinterpolate2(vp(self._h), _p(piv), u64(len(pivots)), *self._opt_args(o)))
 
     def optimize(self, o, final_sweep1site=True):

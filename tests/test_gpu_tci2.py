@@ -1,0 +1,369 @@
+"""GPU parity tests of the TCI2 sweep driver, through the C ABI (t4a_gpu_tci2_*).
+
+Contract (BASELINE.json north_star): pivot index selection bit-exact against the CPU oracle; core entries and TT
+evaluations within 1e-10 (relative to max|f|, stated at each assert).  The known-answer cases are the reference's
+own tests (crates/tensor4all-tensorci/src/tensorci2/tests/mod.rs), run through the host-callback path; the
+built-in device-functor path is checked against the oracle on the BASELINE configs at sizes the oracle finishes
+in seconds, and through size-independent properties at the full cfg3 size.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+PARITY = dict(nsearch=0, max_nglobal_pivot=0)  # like the reference's own doc tests (tensorci2.rs:188-193)
+
+
+@pytest.fixture(scope="module")
+def t4a():
+    import t4a_amd
+    if t4a_amd.device_count() < 1:
+        pytest.fail("no MI355X visible: the product path has no CPU fallback")
+    return t4a_amd
+
+
+def both(t4a, f, local_dims):
+    g = t4a.TensorCI2(local_dims)
+    g.set_function(f)
+    o = ob.OracleTCI2(local_dims)
+    o.set_function(f)
+    return g, o
+
+
+def assert_same_sets(g, o, n):
+    for p in range(n):
+        assert np.array_equal(g.i_set(p), o.i_set(p)), f"I set differs at site {p}"
+        assert np.array_equal(g.j_set(p), o.j_set(p)), f"J set differs at site {p}"
+
+
+def assert_cores_close(g, o, n, tol, scale=1.0):
+    for p in range(n):
+        a, b = g.site_tensor(p), o.site_tensor(p)
+        assert a.shape == b.shape, f"core shape differs at site {p}: {a.shape} vs {b.shape}"
+        if a.size:
+            assert np.abs(a - b).max() <= tol * max(scale, np.abs(b).max()), f"core values differ at site {p}"
+
+
+# ------------------------------------------------------------------------------------------------
+# built-in device functors vs oracle (bit-exact pivots)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nbits,maxb", [(8, None), (12, 16), (20, 64)])
+def test_cfg2_quantics_cos_exp(t4a, nbits, maxb):
+    # BASELINE config 2: d=20 quantics of cos(10x) exp(-x), tol 1e-8, chi_max 64
+    from t4a_amd.functions import quantics_trig_exp
+    spec = quantics_trig_exp(nbits)
+    opts = t4a.TCI2Options(tolerance=1e-8, max_bond_dim=maxb, seed=42, **PARITY)
+    g, o = both(t4a, spec, [2] * nbits)
+    g.crossinterpolate2([[0] * nbits], opts)
+    o.crossinterpolate2([[0] * nbits], opts)
+    assert_same_sets(g, o, nbits)
+    gr, ge = g.history()
+    orr, oe = o.history()
+    assert gr == orr
+    assert np.array_equal(ge, oe)  # bond errors are pivot magnitudes of the bit-exact rrLU
+    assert g.termination() == o.termination()
+    assert g.max_sample_value() == o.max_sample_value()
+    assert np.array_equal(g.pivot_errors(), o.pivot_errors())
+    assert_cores_close(g, o, nbits, 1e-10)
+    rng = np.random.default_rng(5)
+    pts = rng.integers(0, 2, size=(500, nbits))
+    exact = ob.fn_eval(spec, pts)
+    tv = g.evaluate(pts)
+    assert np.abs(tv - o.evaluate(pts)).max() <= 1e-10  # |f| <= 1
+    assert np.abs(tv - exact).max() <= 1e-6
+
+
+@pytest.mark.parametrize("nsites,maxb", [(12, 16), (16, 48)])
+def test_cfg3_osc2d_reduced(t4a, nsites, maxb):
+    # BASELINE config 3 at reduced depth/rank: interleaved 2-variable oscillatory integrand
+    from t4a_amd.functions import quantics_osc2d
+    spec = quantics_osc2d(nsites, k1=3, k2=5, k3=7, eps=0.1, k4=11, delta=0.3)
+    opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=maxb, max_iter=8, seed=42, **PARITY)
+    g, o = both(t4a, spec, [2] * nsites)
+    piv = [[0] * nsites]
+    g.crossinterpolate2(piv, opts)
+    o.crossinterpolate2(piv, opts)
+    assert_same_sets(g, o, nsites)
+    assert g.history()[0] == o.history()[0]
+    assert np.array_equal(g.history()[1], o.history()[1])
+    assert np.array_equal(g.last_sweep_shapes(), o.last_sweep_shapes())
+    rng = np.random.default_rng(6)
+    pts = rng.integers(0, 2, size=(500, nsites))
+    assert np.abs(g.evaluate(pts) - o.evaluate(pts)).max() <= 1e-10 * max(1.0, g.max_sample_value())
+
+
+def test_lorentz_builtin_matches_oracle_and_reference_bounds(t4a):
+    from t4a_amd.functions import lorentz
+    spec = lorentz([10] * 5)
+    opts = t4a.TCI2Options(tolerance=1e-8, max_iter=20, **PARITY)
+    g, o = both(t4a, spec, [10] * 5)
+    g.crossinterpolate2([[1] * 5], opts)
+    o.crossinterpolate2([[1] * 5], opts)
+    assert_same_sets(g, o, 5)
+    assert g.history()[1][-1] < 1e-6  # tensorci2/tests/mod.rs:945-1002
+    pts = np.array([[0] * 5, [1, 2, 3, 4, 5], [9] * 5])
+    exp = 1.0 / ((pts ** 2).sum(axis=1) + 1.0)
+    assert np.abs(g.evaluate(pts) - exp).max() < 1e-6
+    assert_cores_close(g, o, 5, 1e-10)
+
+
+def test_stepwise_api_parity(t4a):
+    """sweep2site / sweep1site / make_canonical / fill_site_tensors, one call at a time (tensorci2.rs:746,865,1201,1065)."""
+    from t4a_amd.functions import quantics_trig_exp
+    n = 10
+    spec = quantics_trig_exp(n, a=25.0, b=0.5, cc=0.5, cs=1.0)
+    g, o = both(t4a, spec, [2] * n)
+    piv = [[0, 1] * (n // 2)]
+    g.add_global_pivots(piv)
+    o.add_global_pivots(piv)
+    opts = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=12, **PARITY)
+    for forward in (True, False, True):
+        g.sweep2site(forward, opts)
+        o.sweep2site(forward, opts)
+        assert_same_sets(g, o, n)
+        assert np.array_equal(g.bond_errors(), o.bond_errors())
+        assert g.max_sample_value() == o.max_sample_value()
+        assert_cores_close(g, o, n, 1e-10)
+    g.sweep1site(False, 1e-12, 0.0, None, True)
+    o.sweep1site(False, 1e-12, 0.0, None, True)
+    assert_same_sets(g, o, n)
+    assert np.array_equal(g.pivot_errors(), o.pivot_errors())
+    assert_cores_close(g, o, n, 1e-10)
+    g.sweep1site(True, 1e-9, 1e-12, 6, True)
+    o.sweep1site(True, 1e-9, 1e-12, 6, True)
+    assert_same_sets(g, o, n)
+    assert_cores_close(g, o, n, 1e-10)
+    assert max(g.link_dims()) <= 6
+    g.fill_site_tensors()
+    o.fill_site_tensors()
+    assert_cores_close(g, o, n, 1e-10)
+    assert abs(g.sum() - o.sum()) <= 1e-10 * 2 ** n
+
+
+def test_history_extras_are_merged_like_the_reference(t4a):
+    """optimize loop without strict nesting: iteration t merges the I/J sets saved at the start of t-1
+    (tensorci2.rs:1675-1689) — the per-bond (M, N, rank) log must agree with the oracle."""
+    from t4a_amd.functions import quantics_osc2d
+    n = 14
+    spec = quantics_osc2d(n, k1=5, k2=9, k3=3, eps=0.2)
+    g, o = both(t4a, spec, [2] * n)
+    piv = [[0] * n, [1] * n]
+    g.add_global_pivots(piv)
+    o.add_global_pivots(piv)
+    g.set_max_sample_value(1.0)
+    o.set_max_sample_value(1.0)
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=24, max_iter=5, ncheck_history=6, **PARITY)
+    g.optimize(opts, final_sweep1site=False)
+    o.optimize(opts, final_sweep1site=False)
+    assert np.array_equal(g.last_sweep_shapes(), o.last_sweep_shapes())
+    assert_same_sets(g, o, n)
+    assert g.history()[0] == o.history()[0]
+    assert np.array_equal(g.history()[1], o.history()[1])
+    # add_global_pivots (even with an empty list) invalidated the cores on both sides (tensorci2.rs:707-708)
+    assert g.site_tensor_dims(0) == (0, 2, 0)
+    g.fill_site_tensors()
+    o.fill_site_tensors()
+    assert_cores_close(g, o, n, 1e-10)
+
+
+def test_strictly_nested_and_sweep_strategies(t4a):
+    from t4a_amd.functions import quantics_trig_exp
+    n = 9
+    spec = quantics_trig_exp(n, a=40.0, b=2.0)
+    for strategy in (0, 1, 2):
+        opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=10, max_iter=6, strictly_nested=True,
+                               sweep_strategy=strategy, **PARITY)
+        g, o = both(t4a, spec, [2] * n)
+        g.crossinterpolate2([[0] * n], opts)
+        o.crossinterpolate2([[0] * n], opts)
+        assert_same_sets(g, o, n)
+        assert_cores_close(g, o, n, 1e-10)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's known-answer tests through the host batch-callback path
+# ------------------------------------------------------------------------------------------------
+def test_product_function_exact_and_sweep1site(t4a):
+    # tensorci2/tests/mod.rs:146-196
+    f = lambda idx: float((idx[0] + 1) * (idx[1] + 1) * (idx[2] + 1))
+    t = t4a.crossinterpolate2(f, [3, 3, 3], [[1, 1, 1]], t4a.TCI2Options(tolerance=1e-12, max_iter=20, seed=1))
+    t.sweep1site(True, 1e-14, 0.0, None, True)
+    pts = np.array([[i, j, k] for i in range(3) for j in range(3) for k in range(3)])
+    assert np.abs(t.evaluate(pts) - np.array([f(p) for p in pts])).max() < 1e-10
+
+
+def test_rank2_function(t4a):
+    # :397-440
+    t = t4a.crossinterpolate2(lambda idx: float(idx[0] + idx[1]), [4, 4], [[1, 1]],
+                              t4a.TCI2Options(tolerance=1e-12, max_iter=10, seed=1))
+    assert t.rank() <= 2
+    pts = np.array([[i, j] for i in range(4) for j in range(4)])
+    assert np.abs(t.evaluate(pts) - pts.sum(axis=1)).max() < 1e-10
+
+
+def test_pivot_errors_match_diagonal(t4a):
+    # :478-509
+    diag = [1.0, 1e-5, 0.0]
+    t = t4a.crossinterpolate2(lambda idx: diag[idx[0]] if idx[0] == idx[1] else 0.0, [3, 3], [[0, 0]],
+                              t4a.TCI2Options(tolerance=1e-8, seed=1))
+    pe = t.pivot_errors()
+    assert len(pe) == 3
+    assert np.abs(pe - np.array(diag)).max() < 1e-14
+
+
+def test_constant_sum(t4a):
+    # :686-723
+    t = t4a.crossinterpolate2(lambda idx: 2.5, [2] * 5, [[0] * 5], t4a.TCI2Options(seed=1))
+    assert abs(t.sum() - 80.0) < 1e-8
+
+
+def test_sin_quantics_regression(t4a):
+    # :728-768 (issue #227)
+    r = 6
+
+    def f(idx):
+        q = sum(int(b) << (r - 1 - i) for i, b in enumerate(idx))
+        return math.sin(10.0 * q / 2 ** r)
+
+    t = t4a.crossinterpolate2(f, [2] * r, [[0, 1, 0, 0, 0, 0]], t4a.TCI2Options(tolerance=1e-10, max_iter=20, seed=1))
+    pts = np.array([[(q >> (r - 1 - i)) & 1 for i in range(r)] for q in range(2 ** r)])
+    assert np.abs(t.evaluate(pts) - np.array([f(p) for p in pts])).max() < 1e-8
+
+
+def test_zero_subdomain_regression(t4a):
+    # :1355-1411 (issue #598)
+    weights, alphas = [1.3, 0.9, 0.9], [2.8, 5.4, 0.7]
+    centers = [(0.4, 0.1), (3.8, -0.8), (-5.5, -2.1)]
+    box_l, r, prefix = 12.0, 10, [2, 3]
+
+    def f(free):
+        ix = iy = 0
+        for n, fused in enumerate(prefix + [int(v) for v in free]):
+            shift = r - 1 - n
+            ix |= (fused & 1) << shift
+            iy |= ((fused >> 1) & 1) << shift
+        step = 2.0 * box_l / 2 ** r
+        x, y = -box_l + ix * step, -box_l + iy * step
+        return sum(weights[i] * math.exp(-alphas[i] * ((x - centers[i][0]) ** 2 + (y - centers[i][1]) ** 2))
+                   for i in range(3))
+
+    nfree = r - len(prefix)
+    t = t4a.crossinterpolate2(f, [4] * nfree, [], t4a.TCI2Options(tolerance=1e-8, max_bond_dim=64, max_iter=20,
+                                                                     normalize_error=False, seed=1))
+    assert t.link_dims() == [1] * (nfree - 1)
+    assert t.termination() == t4a.CONVERGED
+
+
+def test_callback_path_matches_oracle_bitwise_pivots(t4a):
+    f = lambda idx: 1.0 / (1.0 + 0.3 * idx[0] + 0.7 * idx[1] * idx[2] + 0.11 * idx[3])
+    f.batched = lambda pts: [f(p) for p in pts]
+    opts = t4a.TCI2Options(tolerance=1e-10, max_iter=8, **PARITY)
+    g, o = both(t4a, f, [5, 4, 3, 6])
+    g.crossinterpolate2([[1, 1, 1, 1]], opts)
+    o.crossinterpolate2([[1, 1, 1, 1]], opts)
+    assert_same_sets(g, o, 4)
+    assert_cores_close(g, o, 4, 1e-10)
+
+
+def test_batch_callback_length_is_checked(t4a):
+    # :557-589 — a callback returning a wrong number of values is an error, not a crash
+    f = lambda idx: float(idx[0] + 2 * idx[1])
+    f.batched = lambda pts: [f(p) for p in pts][:-1]
+    with pytest.raises(t4a.T4aError) as e:
+        t4a.crossinterpolate2(f, [4, 4], [[1, 1]], t4a.TCI2Options(**PARITY))
+    assert e.value.code == t4a.CALLBACK_ERROR
+    assert "requested entries" in e.value.message
+
+
+def test_options_are_validated_before_any_callback(t4a):
+    # :7-144
+    calls = {"n": 0}
+
+    def f(idx):
+        calls["n"] += 1
+        return 1.0
+
+    for bad in (dict(tolerance=-1.0), dict(tolerance=float("nan")), dict(max_iter=0), dict(ncheck_history=0),
+                dict(max_bond_dim=0), dict(tol_margin_global_search=float("inf"))):
+        with pytest.raises(t4a.T4aError) as e:
+            t4a.crossinterpolate2(f, [2, 2], [[0, 0]], t4a.TCI2Options(**bad))
+        assert e.value.code == t4a.INVALID_ARGUMENT
+    assert calls["n"] == 0
+
+
+def test_errors_for_bad_state(t4a):
+    t = t4a.TensorCI2([2, 2])
+    t.set_function(lambda idx: 1.0)
+    with pytest.raises(t4a.T4aError):
+        t.optimize(t4a.TCI2Options(**PARITY))  # no pivots yet (tensorci2.rs:1640-1645)
+    with pytest.raises(t4a.T4aError):
+        t.add_global_pivots([[0, 5]])  # out of bounds, transactional (:668-690)
+    with pytest.raises(t4a.T4aError):
+        t4a.TensorCI2([3])  # needs at least two sites (:381-385)
+    with pytest.raises(t4a.T4aError):
+        t4a.crossinterpolate2(lambda idx: 0.0, [2, 2], [[0, 0]], t4a.TCI2Options(**PARITY))  # zero pivots (:1550-1554)
+    with pytest.raises(t4a.T4aError) as e:
+        t4a.crossinterpolate2(lambda idx: 1.0, [2, 2], [[0, 0]], t4a.TCI2Options(pivot_search=1, **PARITY))
+    assert e.value.code == t4a.NOT_IMPLEMENTED  # Rook is a declared gap, never a silent fallback
+
+
+def test_default_global_pivot_finder_runs(t4a):
+    # default options (nsearch = 5): RNG stream is not pinned by the reference, accuracy is
+    from t4a_amd.functions import lorentz
+    t = t4a.crossinterpolate2(lorentz([6] * 4), [6] * 4, [[1] * 4], t4a.TCI2Options(tolerance=1e-9, seed=42))
+    rng = np.random.default_rng(3)
+    pts = rng.integers(0, 6, size=(200, 4))
+    exp = 1.0 / ((pts ** 2).sum(axis=1) + 1.0)
+    assert np.abs(t.evaluate(pts) - exp).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# full size (BASELINE config 3: d = 30, chi_max = 256)
+# ------------------------------------------------------------------------------------------------
+def _cfg3(t4a):
+    from t4a_amd.functions import quantics_osc2d
+    n, chi = 30, 256
+    spec = quantics_osc2d(n, k1=37, k2=53, k3=211, eps=0.1, k4=97, delta=0.3)
+    t = t4a.TensorCI2([2] * n)
+    t.set_function(spec)
+    t.add_global_pivots([[0] * n])
+    t.set_max_sample_value(1.0)
+    opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=10, ncheck_history=20, **PARITY)
+    t.optimize(opts, final_sweep1site=False)
+    return spec, t, n, chi
+
+
+def test_cfg3_full_size_half_sweep_matches_oracle(t4a):
+    """Saturate chi = 256 on the device, hand the I/J sets to the oracle (the from_index_sets resume format,
+    tensorci2.rs:551-582) and run ONE more half-sweep on both sides: pivots bit-exact, TT values to 1e-10."""
+    spec, g, n, chi = _cfg3(t4a)
+    assert max(g.link_dims()) == chi  # the workload saturates the bond dimension cap
+    # determinism at full size (multi-workgroup rrLU): a second device run selects identical pivots
+    _, g2, _, _ = _cfg3(t4a)
+    assert_same_sets(g, g2, n)
+    o = ob.OracleTCI2([2] * n)
+    o.set_function(spec)
+    for p in range(n):
+        o.set_index_set(0, p, g.i_set(p))
+        o.set_index_set(1, p, g.j_set(p))
+    o.set_max_sample_value(g.max_sample_value())
+    g.clear_history()
+    o.clear_history()
+    one = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=1, ncheck_history=20, **PARITY)
+    g.optimize(one, final_sweep1site=False)
+    o.optimize(one, final_sweep1site=False)
+    assert np.array_equal(g.last_sweep_shapes(), o.last_sweep_shapes())
+    assert_same_sets(g, o, n)
+    assert np.array_equal(g.history()[1], o.history()[1])
+    assert g.max_sample_value() == o.max_sample_value()
+    g.fill_site_tensors()
+    o.fill_site_tensors()
+    rng = np.random.default_rng(0)
+    pts = rng.integers(0, 2, size=(300, n))
+    gv, ov = g.evaluate(pts), o.evaluate(pts)
+    scale = max(1.0, np.abs(ov).max())
+    assert np.abs(gv - ov).max() <= 1e-10 * scale
