@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — TCI2 full-sweep benchmark (BASELINE.json metric) on N MI355X of one node.
+
+One "step" = one FULL TCI2 sweep (forward half-sweep + backward half-sweep, each = update_pivots over all
+bonds + fill_site_tensors, i.e. two iterations of optimize_with_finder, tensorci2.rs:1659-1776) at saturated
+rank, for the configuration the metric is quoted on: d = 30 binary sites (interleaved quantics of a 2-variable
+oscillatory integrand), chi_max = 256, fp64, tolerance 1e-12, nsearch = 0 (BASELINE.json configs[2]; configs[1]
+— cos(10x)exp(-x) at d=20 — has exact TT rank 2 and is a parity case, not a bench line).
+
+N = 1 : the cfg3 sweep itself.
+N > 1 : weak scaling over PartitionedTT-style patches (BASELINE.json configs[4]): rank p
+        interpolates the patch of the same integrand whose leading log2(N) bits are fixed to p (30 active sites,
+        chi_max 256 per patch — per-GPU work is fixed), and after every sweep the patch cores are all-gathered
+        over RCCL/xGMI (the only exchange step this path has).  The update_pivots chain of one TCI does not
+        shard (bond b+1 needs the pivots of bond b), so there is no data-path collective inside a sweep.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).  Inputs are generated on the device
+(built-in functor), so the timed region starts with everything resident in HBM.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tensor4all-rs_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+N_SITES = 30
+CHI = 256
+# chosen so that the converged link dimensions are exactly min(2^b, 2^(d-b), 256) (tools/probe_rank.py)
+K1, K2, K3, EPS, K4, DELTA = 37, 53, 2111, 0.5, 16411, 0.5
+
+
+def patch_spec(rank, world):
+    """Built-in function of patch `rank` out of `world` (= 2^b) patches: the leading b bits (alternating x, y)
+    of a (30 + b)-bit interleaved quantics grid are fixed; the 30 remaining bits are the active sites."""
+    import numpy as np
+    from t4a_amd.functions import FnSpec, FN_QUANTICS_OSC2D
+    b = int(round(math.log2(world))) if world > 1 else 0
+    bx, by = (b + 1) // 2, b // 2  # extra MSBs of x and y
+    nbx, nby = N_SITES // 2 + bx, N_SITES // 2 + by
+    # prefix bits of this patch: bit j of `rank` (MSB first) goes to x if j even else y
+    px = py = 0
+    for j in range(b):
+        bit = (rank >> (b - 1 - j)) & 1
+        if j % 2 == 0:
+            px = (px << 1) | bit
+        else:
+            py = (py << 1) | bit
+    w = np.zeros((2, 2 * N_SITES), dtype=np.uint64)
+    # active site s: after the b prefix bits the interleaving continues; site s is global bit position b + s
+    cx, cy = bx, by  # how many bits of x / y are already consumed
+    for s in range(N_SITES):
+        g = b + s
+        if g % 2 == 0:
+            w[0, 2 * s + 1] = np.uint64(1) << np.uint64(nbx - 1 - cx)
+            cx += 1
+        else:
+            w[1, 2 * s + 1] = np.uint64(1) << np.uint64(nby - 1 - cy)
+            cy += 1
+    assert cx == nbx and cy == nby
+    # fold the constant prefix contribution into BOTH entries of site 0 (the accumulators are plain sums)
+    offx = np.uint64(px) << np.uint64(nbx - bx) if bx else np.uint64(0)
+    offy = np.uint64(py) << np.uint64(nby - by) if by else np.uint64(0)
+    w[0, 0] += offx
+    w[0, 1] += offx
+    w[1, 0] += offy
+    w[1, 1] += offy
+    return FnSpec(FN_QUANTICS_OSC2D, [K1, K2, K3, EPS, K4, DELTA, nbx, nby], w, [2] * N_SITES)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import t4a_amd
+
+    if not torch.cuda.is_available() or t4a_amd.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the TCI2 backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    t4a_amd.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    spec = patch_spec(rank, world)
+    tci = t4a_amd.TensorCI2([2] * N_SITES)
+    tci.set_function(spec)
+    tci.add_global_pivots([[0] * N_SITES])
+    tci.set_max_sample_value(1.0)
+    tci.set_keep_site_tensors(True)  # keep the cores of the last fill_site_tensors for the patch-core gather
+
+    def opts(iters):
+        return t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=CHI, max_iter=iters, ncheck_history=10 ** 6,
+                                   nsearch=0, max_nglobal_pivot=0, seed=42)
+
+    # all-gather buffer for the patch cores (N > 1): every core padded to the cap shape (chi, 2, chi)
+    core_cap = CHI * 2 * CHI
+    if world > 1:
+        send = torch.zeros(N_SITES * core_cap, dtype=torch.float64, device="cuda")
+        recv = torch.zeros(world * N_SITES * core_cap, dtype=torch.float64, device="cuda")
+
+    def gather_cores():
+        if world == 1:
+            return
+        for s in range(N_SITES):
+            d = tci.site_tensor_dims(s)
+            if d[0] * d[1] * d[2] > 0:
+                tci.site_tensor_to_device(s, send.data_ptr() + 8 * s * core_cap)
+        dist.all_gather_into_tensor(recv, send)
+
+    def full_sweep():
+        tci.optimize(opts(2), final_sweep1site=False)  # forward + backward half-sweep, each with fill_site_tensors
+        gather_cores()
+
+    # ---- untimed: grow the rank to saturation, then W warm-up sweeps ----
+    tci.optimize(opts(10), final_sweep1site=False)
+    if max(tci.link_dims()) != CHI:
+        raise SystemExit(f"rank did not saturate: link dims {tci.link_dims()}")
+    for _ in range(args.warmup):
+        full_sweep()
+
+    # ---- timed region: exactly K full sweeps ----
+    tci.profile_enable(True)
+    tci.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_sweep()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = tci.profile()
+    tci.profile_enable(False)
+
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    fl_t = torch.tensor([prof["flops"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fl_t, op=dist.ReduceOp.SUM)
+    dt_max = float(dt_t.item())
+    flops_all = float(fl_t.item())
+
+    if rank == 0:
+        steps = args.steps
+        shapes = tci.last_sweep_shapes()
+        # dominant kernel = the rrLU instantiation with the largest total time (the mid-chain bonds)
+        rrlu_ms_avg = prof["dom_ms"] / max(prof["dom_launches"], 1)
+        bytes_per_launch = prof["dom_bytes"] / max(prof["dom_launches"], 1)
+        code = prof["dom_code"]
+        if code >= 0:
+            kname = "t4a::rrlu_reg_kernel<%d, %d, %s, %s>" % (code // 1000, (code % 1000) // 10,
+                                                               "true" if (code % 10) & 2 else "false",
+                                                               "true" if (code % 10) & 1 else "false")
+        else:
+            kname = "t4a::rrlu_kernel<%s>" % ("true" if code == -1 else "false")
+        achieved = bytes_per_launch / (rrlu_ms_avg * 1e-3) / 1e9 if rrlu_ms_avg > 0 else 0.0
+        out = {
+            "metric": "TCI2 full-sweep GF/s (d=30, chi=256 fp64)",
+            "value": flops_all / dt_max / 1e9,
+            "unit": "GF/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / steps * 1e3,
+            "full_sweep_sec": dt_max / steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "TensorCI2 d=30 interleaved-quantics 2-variable oscillatory integrand, chi_max=256, "
+                            "tol=1e-12, nsearch=0 (BASELINE.json configs[2]); one step = forward+backward half-sweep "
+                            "incl. fill_site_tensors" + ("" if world == 1 else f"; {world} patches (leading bits fixed), "
+                                                         "one per GPU, RCCL all-gather of patch cores per sweep"),
+                "n_sites": N_SITES, "local_dim": 2, "chi_max": CHI,
+                "function": {"k1": K1, "k2": K2, "k3": K3, "eps": EPS, "k4": K4, "delta": DELTA},
+                "parallelism": "single GPU" if world == 1 else f"patch-farm x{world}",
+                "mid_bond_MNr": [int(x) for x in shapes[N_SITES // 2]],
+                "pivot_steps_per_sweep": prof["pivot_steps"] / steps,
+                "evals_per_sweep": prof["evals"] / steps,
+                "flops_per_sweep": prof["flops"] / steps,
+            },
+            "breakdown_ms_per_sweep": {
+                "rrlu_kernel": prof["rrlu_ms"] / steps, "pi_eval_kernel": prof["pi_ms"] / steps,
+                "fill_site_tensors": prof["fill_ms"] / steps, "luci_factors": prof["factor_ms"] / steps,
+            },
+            "roofline": {
+                "kernel": kname + " (full-pivot rank-revealing LU, one launch per bond)",
+                "launches": prof["dom_launches"],
+                "share_of_rrlu_time": prof["dom_ms"] / max(prof["rrlu_ms"], 1e-30),
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": rrlu_ms_avg,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "note": "streaming model 8MN + sum_k 16(M-k-1)(N-k-1) bytes (BASELINE.md §2); the slab is register "
+                        "resident, the kernel is bound by the per-pivot inter-workgroup exchange latency",
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tci, spec)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tci, spec):
+    """The CPU oracle (C++ restatement of the reference algorithm, single thread) timed on ONE full sweep started
+    from the device's saturated I/J sets.  Reported baseline, not the optimisation target."""
+    import oracle_binding as ob
+    import t4a_amd
+    o = ob.OracleTCI2([2] * N_SITES)
+    o.set_function(spec)
+    for p in range(N_SITES):
+        o.set_index_set(0, p, tci.i_set(p))
+        o.set_index_set(1, p, tci.j_set(p))
+    o.set_max_sample_value(tci.max_sample_value())
+    tci.clear_history()
+    o.clear_history()
+    opts = t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=CHI, max_iter=2, ncheck_history=10 ** 6, nsearch=0,
+                               max_nglobal_pivot=0, seed=42)
+    # identical work on the device gives the flop count of exactly this sweep
+    tci.profile_enable(True)
+    tci.profile_reset()
+    tci.optimize(opts, final_sweep1site=False)
+    flops = tci.profile()["flops"]
+    tci.profile_enable(False)
+    t0 = time.perf_counter()
+    o.optimize(opts, final_sweep1site=False)
+    sec = time.perf_counter() - t0
+    same = all((tci.i_set(p).shape == o.i_set(p).shape) and (tci.i_set(p) == o.i_set(p)).all() for p in range(N_SITES))
+    return {"value": flops / sec / 1e9, "unit": "GF/s", "cores": 1, "kind": "port", "full_sweep_sec": sec,
+            "sample": "1 full sweep (2 half-sweeps incl. fill_site_tensors) of the same d=30 chi=256 workload, started "
+                      "from the device's saturated index sets; oracle = oracle/ C++ restatement, -O3, no FMA",
+            "pivots_identical_to_device": bool(same)}
+
+
+if __name__ == "__main__":
+    main()

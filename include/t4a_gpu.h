@@ -216,6 +216,12 @@ t4a_gpu_status t4a_gpu_tci2_sum(t4a_gpu_tci2* h, double* out);
  * expected to arrive through t4a_gpu_tci2_set_site_tensor_device. */
 t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t world);
 
+/* add_global_pivots invalidates the site tensors even when the pivot list is empty (tensorci2.rs:707-708), so
+ * after optimize_with_finder without a final sweep1site the cores of the last fill_site_tensors are gone.  With
+ * keep != 0 an EMPTY pivot list leaves them in place (the index sets did not change, so they are still the cores
+ * of the current sets).  Default 0 = reference behaviour. */
+t4a_gpu_status t4a_gpu_tci2_set_keep_site_tensors(t4a_gpu_tci2* h, int32_t keep);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);
@@ -223,7 +229,9 @@ t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out
  *  [0] rrlu kernel ms  [1] rrlu launches  [2] pi-eval kernel ms  [3] pi launches
  *  [4] fill_site_tensors device ms  [5] fill calls  [6] factor (trsm+gemm) ms  [7] factor calls
  *  [8] total pivot steps executed by the rrlu kernel  [9] algorithmic rrlu bytes (BASELINE.md §2 model)
- *  [10] algorithmic flops (rrlu + factors + fill)  [11] function evaluations */
+ *  [10] algorithmic flops (rrlu + factors + fill)  [11] function evaluations
+ *  [12..15] the rrLU kernel instantiation with the largest total time: ms, launches, algorithmic bytes,
+ *           code = RPT*1000 + CPT*10 + 2*single_workgroup + wave_uniform_columns (negative: LDS kernel) */
 #define T4A_GPU_PROFILE_SLOTS 16
 t4a_gpu_status t4a_gpu_tci2_profile_enable(t4a_gpu_tci2* h, int32_t enable);
 t4a_gpu_status t4a_gpu_tci2_profile_reset(t4a_gpu_tci2* h);

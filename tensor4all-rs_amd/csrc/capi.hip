@@ -803,6 +803,14 @@ t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t 
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_set_keep_site_tensors(t4a_gpu_tci2* h, int32_t keep)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.keep_site_tensors = keep != 0;
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out)
 {
     return guarded([&] {
@@ -825,6 +833,7 @@ t4a_gpu_status t4a_gpu_tci2_profile_reset(t4a_gpu_tci2* h)
     return guarded([&] {
         T4A_REQUIRE_PTR(h);
         for (double& v : h->impl.eng.prof.v) v = 0.0;
+        h->impl.eng.variant_stats_.clear();
     });
 }
 t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out)
@@ -833,6 +842,16 @@ t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out)
         T4A_REQUIRE_PTR(h);
         T4A_REQUIRE_PTR(out);
         for (int i = 0; i < T4A_GPU_PROFILE_SLOTS; ++i) out[i] = h->impl.eng.prof.v[i];
+        // slots 12..15: the rrLU kernel instantiation with the largest total time
+        double best = -1.0;
+        for (const auto& kv : h->impl.eng.variant_stats_)
+            if (kv.second[0] > best) {
+                best = kv.second[0];
+                out[12] = kv.second[0];
+                out[13] = kv.second[1];
+                out[14] = kv.second[2];
+                out[15] = (double)kv.first;
+            }
     });
 }
 

@@ -119,7 +119,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     const int kM = left ? M : N, kN = left ? N : M;
     RrluRegPlan rplan;
     const bool use_reg = !force_lds && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
-    int plan_W = 1, plan_T = 0;
+    int plan_W = 1, plan_T = 0, plan_code = 0;
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.a, stream_));
     if (use_reg) {
         const double* src = d_a;
@@ -172,6 +172,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         rrlu_reg_launch(rplan, a, stream_);
         plan_W = rplan.W;
         plan_T = rplan.T;
+        plan_code = rplan.RPT * 1000 + rplan.CPT * 10 + (rplan.W == 1 ? 2 : 0) + ((rplan.TR % 64) == 0 ? 1 : 0);
     } else {
         const RrluPlan plan = rrlu_make_plan(M, N, num_cus_);
         if (plan.W > 1) {
@@ -202,6 +203,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         rrlu_launch(plan, a, stream_);
         plan_W = plan.W;
         plan_T = plan.T;
+        plan_code = plan.W == 1 ? -1 : -2; // LDS kernel (single / multi workgroup)
     }
     T4A_HIP(hipGetLastError());
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.b, stream_));
@@ -219,10 +221,10 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
                                stream_));
     T4A_HIP(hipStreamSynchronize(stream_));
 
+    float rrlu_ms_this = 0.f;
     if (prof.enabled) {
-        float ms_f = 0.f;
-        T4A_HIP(hipEventElapsedTime(&ms_f, ev_rrlu_.a, ev_rrlu_.b));
-        prof.v[0] += ms_f;
+        T4A_HIP(hipEventElapsedTime(&rrlu_ms_this, ev_rrlu_.a, ev_rrlu_.b));
+        prof.v[0] += rrlu_ms_this;
         prof.v[1] += 1.0;
     }
     if (want_stamps) {
@@ -264,6 +266,12 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         prof.v[8] += r.rank;
         prof.v[9] += bytes;
         prof.v[10] += flops;
+        if (prof.enabled) { // per kernel-instantiation statistics (the dominant one feeds bench.py's roofline)
+            auto& vs = variant_stats_[plan_code];
+            vs[0] += rrlu_ms_this;
+            vs[1] += 1.0;
+            vs[2] += bytes;
+        }
     }
     if (hp[2] != 0) throw Error(T4A_GPU_NAN_ENCOUNTERED, "NaN encountered in L or U of the rrLU factorisation");
 

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <array>
+#include <map>
 #include <limits>
 #include <vector>
 
@@ -60,6 +61,8 @@ public:
     LuciResult luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy);
 
     Profile prof;
+    // rrLU launch statistics per kernel instantiation: code -> {ms, launches, algorithmic bytes}
+    std::map<int, std::array<double, 3>> variant_stats_;
 
     // scratch for the TCI2 driver
     DevBuf<double> d_tmp, d_tmp2;

@@ -961,7 +961,8 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         errors_hist.push_back(error / norm);
 
         std::vector<std::vector<uint32_t>> gp = find_global_pivots(abs_tol, options, rng_state);
-        add_global_pivots(gp); // invalidates the site tensors even for an empty list (tensorci2.rs:707-708)
+        // invalidates the site tensors even for an empty list (tensorci2.rs:707-708) unless the caller opted out
+        if (!(gp.empty() && keep_site_tensors)) add_global_pivots(gp);
         nglobal_hist.push_back(gp.size());
         ranks_hist.push_back(rank());
         if (options.verbosity > 0)

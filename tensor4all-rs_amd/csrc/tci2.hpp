@@ -98,6 +98,7 @@ public:
     int termination = T4A_GPU_TCI2_MAX_ITERATIONS;
     std::vector<std::array<size_t, 3>> last_sweep_shapes;
     size_t shard_rank = 0, shard_world = 1;
+    bool keep_site_tensors = false;
     Engine eng;
 
 private:

@@ -458,6 +458,9 @@ class TensorCI2:
         d = (c_size_t * 3)(*[int(x) for x in dims3])
         _check(_lib.t4a_gpu_tci2_set_site_tensor_device(self._h, c_size_t(site), d, c_void_p(device_ptr)))
 
+    def set_keep_site_tensors(self, keep=True):
+        _check(_lib.t4a_gpu_tci2_set_keep_site_tensors(self._h, c_int32(1 if keep else 0)))
+
     def set_site_shard(self, rank, world):
         _check(_lib.t4a_gpu_tci2_set_site_shard(self._h, c_size_t(rank), c_size_t(world)))
 
@@ -501,7 +504,9 @@ class TensorCI2:
         _check(_lib.t4a_gpu_tci2_profile_get(self._h, _p(out)))
         keys = ["rrlu_ms", "rrlu_launches", "pi_ms", "pi_launches", "fill_ms", "fill_calls", "factor_ms",
                 "factor_calls", "pivot_steps", "rrlu_bytes", "flops", "evals"]
-        return {k: float(out[i]) for i, k in enumerate(keys)}
+        d = {k: float(out[i]) for i, k in enumerate(keys)}
+        d.update(dom_ms=float(out[12]), dom_launches=float(out[13]), dom_bytes=float(out[14]), dom_code=int(out[15]))
+        return d
 
 
 def crossinterpolate2(f, local_dims, initial_pivots, options):

@@ -1,0 +1,100 @@
+"""Multi-GPU orchestration of the parts of the TCI2 path that shard: one process per GPU,
+torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+
+ * patch farm (BASELINE.json configs[4]; reference: partitionedtt::adaptiveinterpolate runs one independent
+   crossinterpolate2 per patch, crates/tensor4all-partitionedtt/src/adaptive_interpolation.rs:151-330):
+   patches are dealt round-robin to ranks, every rank interpolates its patches, then the patch cores are
+   all-gathered (the only exchange step).  FIFO patch order is preserved when re-assembling.
+ * site-sharded fill_site_tensors (configs[3]; tensorci2.rs:1065-1186: sites are independent given the final
+   I/J sets): rank r fills the sites s with s % world == r, then cores are all-gathered.
+
+The local compute is injected (`run_patch`, `fill_sites`) so that the same orchestration runs with the device
+handle in production and with the CPU oracle in tests/test_cpu_parallel.py.
+"""
+import numpy as np
+
+
+def patches_of_rank(n_patches, rank, world):
+    """Static round-robin farm: patch p runs on rank p % world (FIFO order inside a rank)."""
+    return [p for p in range(n_patches) if p % world == rank]
+
+
+def pack_cores(cores):
+    """cores: list of (l, s, r) float64 arrays (Fortran order = simplett Tensor3 layout) -> (header, flat)."""
+    header = np.array([d for c in cores for d in c.shape], dtype=np.int64)
+    flat = np.concatenate([np.asarray(c, dtype=np.float64).ravel(order="F") for c in cores]) if cores else np.zeros(0)
+    return header, flat
+
+
+def unpack_cores(header, flat):
+    cores, off = [], 0
+    for k in range(0, len(header), 3):
+        l, s, r = (int(x) for x in header[k:k + 3])
+        n = l * s * r
+        cores.append(np.array(flat[off:off + n]).reshape((l, s, r), order="F"))
+        off += n
+    return cores
+
+
+def all_gather_variable(dist, torch, arr, device, dtype):
+    """all-gather of per-rank 1-D arrays of different lengths (sizes first, then padded payload)."""
+    world = dist.get_world_size()
+    n = torch.tensor([len(arr)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    send = torch.zeros(cap, dtype=dtype, device=device)
+    if len(arr):
+        send[:len(arr)] = torch.as_tensor(arr, dtype=dtype, device=device)
+    recv = [torch.zeros(cap, dtype=dtype, device=device) for _ in range(world)]
+    dist.all_gather(recv, send)
+    return [recv[r][:sizes[r]].cpu().numpy() for r in range(world)]
+
+
+def run_patch_farm(dist, torch, n_patches, run_patch, device="cpu"):
+    """run_patch(p) -> list of core arrays of patch p.  Returns the cores of ALL patches, in patch order, on
+    every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = patches_of_rank(n_patches, rank, world)
+    headers, flats, counts = [], [], []
+    for p in mine:
+        h, f = pack_cores(run_patch(p))
+        headers.append(h)
+        flats.append(f)
+        counts.append(len(h) // 3)
+    hdr = np.concatenate([np.array([len(mine)], dtype=np.int64), np.array(counts, dtype=np.int64)] + headers) \
+        if mine else np.array([0], dtype=np.int64)
+    payload = np.concatenate(flats) if flats else np.zeros(0)
+    all_hdr = all_gather_variable(dist, torch, hdr, device, torch.int64)
+    all_pay = all_gather_variable(dist, torch, payload, device, torch.float64)
+    result = [None] * n_patches
+    for r in range(world):
+        h, f = all_hdr[r], all_pay[r]
+        npat = int(h[0])
+        cnts = [int(x) for x in h[1:1 + npat]]
+        hoff, foff = 1 + npat, 0
+        for k, p in enumerate(patches_of_rank(n_patches, r, world)):
+            hh = h[hoff:hoff + 3 * cnts[k]]
+            size = int(sum(int(hh[i]) * int(hh[i + 1]) * int(hh[i + 2]) for i in range(0, len(hh), 3)))
+            result[p] = unpack_cores(hh, f[foff:foff + size])
+            hoff += 3 * cnts[k]
+            foff += size
+    return result
+
+
+def sharded_fill(dist, torch, n_sites, fill_my_sites, get_core, set_core, device="cpu"):
+    """Site-sharded fill_site_tensors + core all-gather.  fill_my_sites(rank, world) fills the local sites;
+    get_core(s) -> array, set_core(s, array) installs a core received from another rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    fill_my_sites(rank, world)
+    mine = [s for s in range(n_sites) if s % world == rank]
+    h, f = pack_cores([get_core(s) for s in mine])
+    all_hdr = all_gather_variable(dist, torch, h, device, torch.int64)
+    all_pay = all_gather_variable(dist, torch, f, device, torch.float64)
+    for r in range(world):
+        if r == rank:
+            continue
+        cores = unpack_cores(all_hdr[r], all_pay[r])
+        for s, c in zip([s for s in range(n_sites) if s % world == r], cores):
+            set_core(s, c)

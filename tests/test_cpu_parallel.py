@@ -1,0 +1,86 @@
+"""world_size-2 gloo tests of the N > 1 orchestration (tensor4all-rs_amd/python/t4a_amd/parallel.py).
+The local compute is the CPU oracle here (tests may use it); production injects the device handle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _patch_fn(p):
+    # patch p of f(i,j,k,l) = 1/(1 + i + 2j + 3k + 4l + 0.5p): the patch index plays the projected leading site
+    return lambda idx: 1.0 / (1.0 + idx[0] + 2 * idx[1] + 3 * idx[2] + 4 * idx[3] + 0.5 * p)
+
+
+def _run_patch(p):
+    import oracle_binding as ob
+    from t4a_amd import TCI2Options
+    t = ob.OracleTCI2([3, 3, 3, 3])
+    t.set_function(_patch_fn(p))
+    t.crossinterpolate2([[1, 1, 1, 1]], TCI2Options(tolerance=1e-10, nsearch=0, max_nglobal_pivot=0))
+    return [t.site_tensor(s) for s in range(4)]
+
+
+def _worker(rank, world, port, n_patches, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from t4a_amd import parallel
+    cores = parallel.run_patch_farm(dist, torch, n_patches, _run_patch)
+    np.save(os.path.join(out_dir, f"farm_{rank}.npy"),
+            np.concatenate([c.ravel(order="F") for pc in cores for c in pc]))
+
+    # site-sharded fill: every rank holds the same index sets; rank r fills sites s % world == r
+    import oracle_binding as ob
+    from t4a_amd import TCI2Options
+    t = ob.OracleTCI2([3, 3, 3, 3])
+    t.set_function(_patch_fn(0))
+    t.crossinterpolate2([[1, 1, 1, 1]], TCI2Options(tolerance=1e-10, nsearch=0, max_nglobal_pivot=0))
+    full = [t.site_tensor(s) for s in range(4)]
+    store = {}
+
+    def fill_my_sites(r, w):
+        for s in range(4):
+            if s % w == r:
+                store[s] = full[s].copy()  # stands for the local fill of site s
+
+    parallel.sharded_fill(dist, torch, 4, fill_my_sites, lambda s: store[s], lambda s, c: store.__setitem__(s, c))
+    assert sorted(store) == [0, 1, 2, 3]
+    for s in range(4):
+        assert store[s].shape == full[s].shape and np.array_equal(store[s], full[s])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_patches", [3, 4])
+def test_patch_farm_and_sharded_fill_two_ranks(tmp_path, n_patches):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_patches, str(tmp_path)), nprocs=world, join=True)
+    ref = np.concatenate([c.ravel(order="F") for p in range(n_patches) for c in _run_patch(p)])
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"farm_{r}.npy"))
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_patch_assignment_is_round_robin_and_order_preserving():
+    from t4a_amd.parallel import patches_of_rank, pack_cores, unpack_cores
+    assert patches_of_rank(7, 0, 2) == [0, 2, 4, 6]
+    assert patches_of_rank(7, 1, 2) == [1, 3, 5]
+    assert sorted(sum((patches_of_rank(64, r, 8) for r in range(8)), [])) == list(range(64))
+    rng = np.random.default_rng(0)
+    cores = [np.asfortranarray(rng.normal(size=s)) for s in [(1, 2, 3), (3, 2, 4), (4, 2, 1)]]
+    h, f = pack_cores(cores)
+    back = unpack_cores(h, f)
+    assert all(np.array_equal(a, b) for a, b in zip(cores, back))

@@ -327,7 +327,7 @@ def test_default_global_pivot_finder_runs(t4a):
 def _cfg3(t4a):
     from t4a_amd.functions import quantics_osc2d
     n, chi = 30, 256
-    spec = quantics_osc2d(n, k1=37, k2=53, k3=211, eps=0.1, k4=97, delta=0.3)
+    spec = quantics_osc2d(n, k1=37, k2=53, k3=2111, eps=0.5, k4=16411, delta=0.5)  # bench.py workload
     t = t4a.TensorCI2([2] * n)
     t.set_function(spec)
     t.add_global_pivots([[0] * n])
@@ -341,7 +341,8 @@ def test_cfg3_full_size_half_sweep_matches_oracle(t4a):
     """Saturate chi = 256 on the device, hand the I/J sets to the oracle (the from_index_sets resume format,
     tensorci2.rs:551-582) and run ONE more half-sweep on both sides: pivots bit-exact, TT values to 1e-10."""
     spec, g, n, chi = _cfg3(t4a)
-    assert max(g.link_dims()) == chi  # the workload saturates the bond dimension cap
+    # the workload saturates the cap: link dims are exactly min(2^b, 2^(d-b), chi) (BASELINE.md §2 profile)
+    assert g.link_dims() == [min(2 ** (b + 1), 2 ** (n - b - 1), chi) for b in range(n - 1)]
     # determinism at full size (multi-workgroup rrLU): a second device run selects identical pivots
     _, g2, _, _ = _cfg3(t4a)
     assert_same_sets(g, g2, n)
