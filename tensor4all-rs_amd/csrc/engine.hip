@@ -165,7 +165,9 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.salt = rrlu_salt_;
         static const int col_delay = std::getenv("T4A_RRLU_COLDELAY") ? std::atoi(std::getenv("T4A_RRLU_COLDELAY")) : 0;
         a.col_delay = col_delay;
-        static const int ncopy_env = std::getenv("T4A_RRLU_NCOPY") ? std::atoi(std::getenv("T4A_RRLU_NCOPY")) : 4;
+        static const int poll_delay = std::getenv("T4A_RRLU_POLLDELAY") ? std::atoi(std::getenv("T4A_RRLU_POLLDELAY")) : 1;
+        a.poll_delay = poll_delay;
+        static const int ncopy_env = std::getenv("T4A_RRLU_NCOPY") ? std::atoi(std::getenv("T4A_RRLU_NCOPY")) : 1;
         a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
         a.spin_limit = 1u << 20;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
@@ -230,9 +232,9 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     if (want_stamps) {
         unsigned long long hs[8];
         T4A_HIP(hipMemcpy(hs, d_stamps_.get(), sizeof(hs), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[rrlu stamps %s] M=%d N=%d W=%d T=%d steps=%d | s0=%llu s1=%llu s2=%llu s3=%llu s4=%llu pollspins=%llu colspins=%llu "
+        std::fprintf(stderr, "[rrlu stamps %s] M=%d N=%d W=%d T=%d steps=%d | s0=%llu s1=%llu s2=%llu s3=%llu s4=%llu pollspins=%llu colspins=%llu s7=%llu "
                              "(cycles, wg0/thread0; lds: publish,poll,colfetch,pass,reduce; reg: pass,reduce,publish,poll,fetch)\n",
-                     use_reg ? "reg" : "lds", M, N, plan_W, plan_T, hp[0], hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6]);
+                     use_reg ? "reg" : "lds", M, N, plan_W, plan_T, hp[0], hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
     }
     if (hp[1] != 0)
         throw Error(T4A_GPU_KERNEL_TIMEOUT, "rrLU kernel: inter-workgroup hand-off timed out (bounded spin gave up)");

@@ -80,6 +80,7 @@ struct RrluRegArgs {
     unsigned long long* cols;   // [2][ncopy][M][2] tagged pivot-column granules; tag = salt*65536 + (step % 65535 + 1)
     unsigned salt;              // launch-unique 16-bit value (1..65535); the buffers are zeroed when it wraps
     int col_delay;              // >0: readers sleep briefly before their first pivot-column sweep
+    int poll_delay;             // >0: the polling wave sleeps ~1000 cycles before its first key sweep
     int ncopy;                  // replicas of the published pivot column (<= RRLU_MAX_COPIES)
     unsigned spin_limit;
     unsigned long long* stamps; // diagnostic only

@@ -200,7 +200,7 @@ __host__ __device__ inline size_t reg_smem_layout(int M, int N, int cols_per_wg,
 // UNI: every wave lies inside one column group (TR % 64 == 0), so the column state is wave-uniform and the
 // per-column tests become scalar branches.
 template <int RPT, int CPT, bool SINGLE, bool UNI>
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, (RPT * CPT >= 12) ? 512 : 1024)))
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, (RPT * CPT >= 24) ? 256 : 512)))
 rrlu_reg_kernel(RrluRegArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -350,25 +350,41 @@ rrlu_reg_kernel(RrluRegArgs p)
         }
         const unsigned wpos = wave_min_u32(mypos);
         if (mypos == wpos && wpos != NOPOS) s.red_val[wave] = myval; // unique lane of the wave
+        if (wpos == NOPOS && lane == 0) s.red_val[wave] = 0.0;
         if (lane == 0) {
             s.red_sc[wave] = wmax;
             s.red_pos[wave] = wpos;
         }
+        T4A_RSTAMP(7);
         __syncthreads(); // (D)
-        double bsc = s.red_sc[0];
-        unsigned bpos = s.red_pos[0];
-        int bwave = 0;
-        for (int qv = 1; qv < nwaves; ++qv) {
-            const double osc = s.red_sc[qv];
-            const unsigned opos = s.red_pos[qv];
-            if (osc > bsc || (osc == bsc && opos < bpos)) {
-                bsc = osc;
-                bpos = opos;
-                bwave = qv;
+        // all LDS reads of the cross-wave reduction are issued together (<= 16 waves)
+        constexpr int NWMAX = (RPT * CPT >= 24) ? 4 : 8; // = maximum workgroup size / 64
+        double rsc[NWMAX], rvl[NWMAX];
+        unsigned rps[NWMAX];
+#pragma unroll
+        for (int qv = 0; qv < NWMAX; ++qv) {
+            if (qv < nwaves) {
+                rsc[qv] = s.red_sc[qv];
+                rps[qv] = s.red_pos[qv];
+                rvl[qv] = s.red_val[qv];
             }
         }
-        if (bsc < 0.0) bpos = NOPOS; // no candidate in this workgroup
-        const double bval = (bpos == NOPOS) ? 0.0 : s.red_val[bwave];
+        double bsc = rsc[0];
+        unsigned bpos = rps[0];
+        double bval = rvl[0];
+#pragma unroll
+        for (int qv = 1; qv < NWMAX; ++qv) {
+            if (qv < nwaves) {
+                const bool better = rsc[qv] > bsc || (rsc[qv] == bsc && rps[qv] < bpos);
+                bsc = better ? rsc[qv] : bsc;
+                bpos = better ? rps[qv] : bpos;
+                bval = better ? rvl[qv] : bval;
+            }
+        }
+        if (bsc < 0.0) {
+            bpos = NOPOS; // no candidate in this workgroup
+            bval = 0.0;
+        }
         // which column group owns the candidate column
         const unsigned bcol = bpos == NOPOS ? NOPOS : (rowmajor ? (bpos & 0xFFFFu) : (bpos >> 16));
         int qstar = -1;
@@ -411,14 +427,10 @@ rrlu_reg_kernel(RrluRegArgs p)
             const int poll_wave = nwaves > 1 ? 1 : 0; // never the pushing wave: its loads would queue behind its stores
             if (wave == 0) {
                 const unsigned long long vb = (unsigned long long)__double_as_longlong(bval);
-                u32x4 k01;
-                k01.x = (unsigned)(vb & 0xFFFFFFFFull);
-                k01.y = tag;
-                k01.z = (unsigned)(vb >> 32);
-                k01.w = tag;
                 for (int dest = lane; dest < p.W; dest += 64) {
                     unsigned long long* kd = p.keys + (((size_t)par * p.W + dest) * p.W + w) * KEY_STRIDE;
-                    st_b128_sc1(kd, k01);
+                    st_u64_sc1(kd + 0, tagbits | (vb & 0xFFFFFFFFull));
+                    st_u64_sc1(kd + 1, tagbits | (vb >> 32));
                     st_u64_sc1(kd + 2, tagbits | (unsigned long long)bpos);
                 }
             }
@@ -434,42 +446,59 @@ rrlu_reg_kernel(RrluRegArgs p)
             T4A_RSTAMP(2);
             // one wave sweeps the workgroup's OWN inbox until every tag matches
             if (wave == poll_wave) {
+                if (p.poll_delay > 0) __builtin_amdgcn_s_sleep(16); // skip the sweep that would certainly fail
                 const unsigned long long* kb = p.keys + ((size_t)par * p.W + w) * p.W * KEY_STRIDE;
                 unsigned spins = 0;
                 bool giveup = false;
                 double csc = -1.0, cval = 0.0;
                 unsigned cpk = NOPOS;
                 int cw = -1;
+                // all loads of one sweep are issued back to back (one memory round trip per sweep)
+                constexpr int KPL = 4; // keys per lane: W <= 256
+                unsigned long long g[KPL][3];
                 for (;;) {
                     bool ok = true;
-                    csc = -1.0;
-                    cval = 0.0;
-                    cpk = NOPOS;
-                    cw = -1;
-                    for (int qw = lane; qw < p.W; qw += 64) {
-                        const void* ptr[1] = {kb + (size_t)qw * KEY_STRIDE};
-                        u32x4 g;
-                        Load16<1>::run(ptr, &g);
-                        const unsigned long long g2 = ld_u64_sc1(kb + (size_t)qw * KEY_STRIDE + 2);
-                        const bool good = (g.y == tag) && (g.w == tag) && ((unsigned)(g2 >> 32) == tag);
-                        ok &= good;
-                        const unsigned pk = (unsigned)(g2 & 0xFFFFFFFFull);
-                        if (good && pk != NOPOS) {
-                            const double v = __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
-                            double sc = v * v;
-                            if (sc != sc) sc = (pk == diagkey) ? __builtin_huge_val() : -1.0;
-                            if (sc > csc || (sc == csc && pk < cpk)) {
-                                csc = sc;
-                                cval = v;
-                                cpk = pk;
-                                cw = qw;
-                            }
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        const int qw = lane + 64 * j;
+                        if (qw < p.W) {
+                            g[j][0] = ld_u64_sc1(kb + (size_t)qw * KEY_STRIDE);
+                            g[j][1] = ld_u64_sc1(kb + (size_t)qw * KEY_STRIDE + 1);
+                            g[j][2] = ld_u64_sc1(kb + (size_t)qw * KEY_STRIDE + 2);
                         }
+                    }
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        const int qw = lane + 64 * j;
+                        if (qw < p.W)
+                            ok &= ((unsigned)(g[j][0] >> 32) == tag) && ((unsigned)(g[j][1] >> 32) == tag) &&
+                                  ((unsigned)(g[j][2] >> 32) == tag);
                     }
                     if (__all(ok)) break;
                     if (++spins > p.spin_limit) {
                         giveup = true;
                         break;
+                    }
+                }
+                if (!giveup) {
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        const int qw = lane + 64 * j;
+                        if (qw < p.W) {
+                            const unsigned pk = (unsigned)(g[j][2] & 0xFFFFFFFFull);
+                            if (pk != NOPOS) {
+                                const double v = __longlong_as_double(
+                                    (long long)(((g[j][1] & 0xFFFFFFFFull) << 32) | (g[j][0] & 0xFFFFFFFFull)));
+                                double sc = v * v;
+                                if (sc != sc) sc = (pk == diagkey) ? __builtin_huge_val() : -1.0;
+                                if (sc > csc || (sc == csc && pk < cpk)) {
+                                    csc = sc;
+                                    cval = v;
+                                    cpk = pk;
+                                    cw = qw;
+                                }
+                            }
+                        }
                     }
                 }
                 if (p.stamps != nullptr && w == 0 && lane == 0) p.stamps[5] += spins;
@@ -503,14 +532,10 @@ rrlu_reg_kernel(RrluRegArgs p)
                 for (int r = 0; r < RPT; ++r)
                     if (irow[r] >= 0) {
                         const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
-                        u32x4 g;
-                        g.x = (unsigned)(vb & 0xFFFFFFFFull);
-                        g.y = tag;
-                        g.z = (unsigned)(vb >> 32);
-                        g.w = tag;
                         for (int c = 0; c < p.ncopy; ++c) {
                             unsigned long long* dst = p.cols + (((size_t)par * p.ncopy + c) * (size_t)p.M + irow[r]) * 2;
-                            st_b128_sc1(dst, g);
+                            st_u64_sc1(dst, tagbits | (vb & 0xFFFFFFFFull));
+                            st_u64_sc1(dst + 1, tagbits | (vb >> 32));
                         }
                     }
             }
@@ -557,6 +582,25 @@ rrlu_reg_kernel(RrluRegArgs p)
         }
         if (w == 0 && tid == 0) p.pivot_vals[kn] = wval;
 
+        // issue the pivot-column loads (issuing them before the bookkeeping measured worse: more first-sweep misses)
+        const bool need_fetch = !SINGLE && !(ww == w && qstar >= 0);
+        const unsigned long long* colsrc =
+            SINGLE ? nullptr : p.cols + ((size_t)((k + 1) & 1) * p.ncopy + (w % p.ncopy)) * (size_t)p.M * 2;
+        unsigned long long cg0[RPT], cg1[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            cg0[r] = 0ull;
+            cg1[r] = 0ull;
+        }
+        if (need_fetch) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if (irow[r] >= 0) {
+                    cg0[r] = ld_u64_sc1(colsrc + 2 * (size_t)irow[r]);
+                    cg1[r] = ld_u64_sc1(colsrc + 2 * (size_t)irow[r] + 1);
+                }
+        }
+
         // ---- pivot column -> l (scaled) ----
         if (SINGLE) {
 #pragma unroll
@@ -567,33 +611,32 @@ rrlu_reg_kernel(RrluRegArgs p)
 #pragma unroll
             for (int r = 0; r < RPT; ++r) l[r] = colv[r] / wval;
         } else {
-            const unsigned long long* src = p.cols + ((size_t)(kn & 1) * p.ncopy + (w % p.ncopy)) * (size_t)p.M * 2;
             const unsigned tag = p.salt * 65536u + ((unsigned)kn % 65535u + 1u);
             unsigned spins = 0;
-            u32x4 g[RPT];
-            const void* ptr[RPT];
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) ptr[r] = src + 2 * (size_t)(irow[r] >= 0 ? irow[r] : 0);
-            if (p.col_delay > 0) __builtin_amdgcn_s_sleep(8); // give the winner's stores time to land
             for (;;) {
-                Load16<RPT>::run(ptr, g);
                 bool ok = true;
 #pragma unroll
                 for (int r = 0; r < RPT; ++r)
-                    if (irow[r] >= 0) ok &= (g[r].y == tag) && (g[r].w == tag);
+                    if (irow[r] >= 0) ok &= ((unsigned)(cg0[r] >> 32) == tag) && ((unsigned)(cg1[r] >> 32) == tag);
                 if (__all(ok)) break;
                 if (++spins > p.spin_limit) {
                     atomicExch(&p.iresult[1], 1);
                     s.win_i[2] = 1; // observed by everybody after the next barrier
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (irow[r] >= 0) {
+                        cg0[r] = ld_u64_sc1(colsrc + 2 * (size_t)irow[r]);
+                        cg1[r] = ld_u64_sc1(colsrc + 2 * (size_t)irow[r] + 1);
+                    }
             }
             if (stamp_on) stamp_acc[6] += spins;
 #pragma unroll
             for (int r = 0; r < RPT; ++r)
                 if (irow[r] >= 0) {
-                    const double raw = __longlong_as_double((long long)(((unsigned long long)g[r].z << 32) | g[r].x));
+                    const double raw = __longlong_as_double(
+                        (long long)(((cg1[r] & 0xFFFFFFFFull) << 32) | (cg0[r] & 0xFFFFFFFFull)));
                     l[r] = raw / wval;
                 }
         }
@@ -703,14 +746,14 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
         // one workgroup: TR x TC thread grid with <= 4 x 8 elements per thread; minimise the per-thread work,
         // then the thread count
         int best_cost = 1 << 30;
-        for (int T = 64; T <= 1024; T *= 2) {
+        for (int T = 64; T <= 512; T *= 2) {
             if (et && T != std::atoi(et)) continue;
             for (int TR = 16; TR <= T; TR *= 2) {
                 const int TC = T / TR;
                 const int RPT = (M + TR - 1) / TR;
                 const int CPT = norm_cpt((N + TC - 1) / TC);
                 if (RPT > 4 || (long long)TC * CPT < N) continue;
-                if (T > ((RPT * CPT >= 12) ? 512 : 1024)) continue;
+                if (T > ((RPT * CPT >= 24) ? 256 : 512)) continue;
                 const int cost = RPT * CPT * 64 + T / 64;
                 if (cost < best_cost) {
                     best_cost = cost;
@@ -757,7 +800,7 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
         }
         if (W < 1) W = 1;
         if (W > maxw || (long long)W * TC * CPT < N) return false;
-        if (TR * TC > ((RPT * CPT >= 12) ? 512 : 1024)) return false;
+        if (TR * TC > ((RPT * CPT >= 24) ? 256 : 512)) return false;
         plan.W = W;
         plan.T = TR * TC;
         plan.TR = TR;
