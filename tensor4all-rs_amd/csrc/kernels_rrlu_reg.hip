@@ -18,10 +18,11 @@
 //     cdna_hip_programming.md §6 Guideline 16 (the data is the flag: every granule is one aligned 8-byte
 //     atomic sc1 store / sc1 load carrying a launch-salted 32-bit tag, consumers re-read until every tag
 //     matches; spins are bounded):
-//       hop 1 (arg-max all-gather): each workgroup PUSHES its 24-byte key {value, position} into the inbox of
-//         every workgroup with one wave-wide store per granule; a workgroup polls only its own inbox.
-//         (W pollers sweeping one shared key table measured 2.7 us/hop — 128 requests per hot line and
-//         sweep; speculatively publishing all candidate columns: 5.4 us/step.)
+//       hop 1 (arg-max all-gather): each workgroup stores ONE 16-byte key {value, position} into a shared table;
+//         one wave per workgroup sweeps the table (sc1 loads of unchanged lines are L2 hits, ~270 cycles —
+//         tools/ld_bench.hip).  Measured alternatives (tools/xchg_bench.hip, W = 86, cycles per round):
+//         shared table 3 860, per-workgroup inboxes 5 690; speculatively publishing every workgroup's
+//         candidate column instead of hop 2: 5.4 us/step.
 //       hop 2 (pivot column broadcast): only the winner publishes its column; readers delay their first
 //         sweep so that it normally succeeds.
 // Barriers per pivot step: 3.
@@ -421,18 +422,17 @@ rrlu_reg_kernel(RrluRegArgs p)
             const int par = kn & 1;
             const unsigned tag = p.salt * 65536u + ((unsigned)kn % 65535u + 1u);
             const unsigned long long tagbits = (unsigned long long)tag << 32;
-            // hop 1: wave 0 pushes the key {value, position} into every workgroup's inbox (one 16-byte store
-            //         of two tagged granules + one 8-byte granule per destination)
-            //         inbox layout: keys[par][dest][src][KEY_STRIDE]
-            const int poll_wave = nwaves > 1 ? 1 : 0; // never the pushing wave: its loads would queue behind its stores
-            if (wave == 0) {
+            // hop 1 (arg-max all-gather): ONE 16-byte key per workgroup in a shared table keys[par][W][2]:
+            //   g0 = tag16 | value bits 63..16,  g1 = tag16 | value bits 15..0 | position (32 bits).
+            // The table is zeroed before every launch, tag16 = step + 1 (never 0).  Measured
+            // (tools/xchg_bench.hip, W = 86): shared table 3 860 cycles/round, per-workgroup inboxes 5 690.
+            const int poll_wave = nwaves > 1 ? 1 : 0; // not the storing wave: its loads would queue behind its stores
+            const unsigned long long tag16 = (unsigned long long)((unsigned)kn % 65535u + 1u);
+            if (wave == 0 && lane == 0) {
                 const unsigned long long vb = (unsigned long long)__double_as_longlong(bval);
-                for (int dest = lane; dest < p.W; dest += 64) {
-                    unsigned long long* kd = p.keys + (((size_t)par * p.W + dest) * p.W + w) * KEY_STRIDE;
-                    st_u64_sc1(kd + 0, tagbits | (vb & 0xFFFFFFFFull));
-                    st_u64_sc1(kd + 1, tagbits | (vb >> 32));
-                    st_u64_sc1(kd + 2, tagbits | (unsigned long long)bpos);
-                }
+                unsigned long long* kd = p.keys + ((size_t)par * p.W + w) * 2;
+                st_u64_sc1(kd + 0, (tag16 << 48) | (vb >> 16));
+                st_u64_sc1(kd + 1, (tag16 << 48) | ((vb & 0xFFFFull) << 32) | (unsigned long long)bpos);
             }
             // everybody else (and the pusher afterwards) prepares the candidate column while the keys travel
 #pragma unroll
@@ -444,10 +444,10 @@ rrlu_reg_kernel(RrluRegArgs p)
                 colv[r] = v;
             }
             T4A_RSTAMP(2);
-            // one wave sweeps the workgroup's OWN inbox until every tag matches
+            // one wave sweeps the shared key table until every tag matches
             if (wave == poll_wave) {
-                if (p.poll_delay > 0) __builtin_amdgcn_s_sleep(16); // skip the sweep that would certainly fail
-                const unsigned long long* kb = p.keys + ((size_t)par * p.W + w) * p.W * KEY_STRIDE;
+                for (int d = 0; d < p.poll_delay; ++d) __builtin_amdgcn_s_sleep(1); // skip sweeps that would certainly fail
+                const unsigned long long* kb = p.keys + (size_t)par * p.W * 2;
                 unsigned spins = 0;
                 bool giveup = false;
                 double csc = -1.0, cval = 0.0;
@@ -455,24 +455,21 @@ rrlu_reg_kernel(RrluRegArgs p)
                 int cw = -1;
                 // all loads of one sweep are issued back to back (one memory round trip per sweep)
                 constexpr int KPL = 4; // keys per lane: W <= 256
-                unsigned long long g[KPL][3];
+                unsigned long long g[KPL][2];
                 for (;;) {
                     bool ok = true;
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) {
                         const int qw = lane + 64 * j;
                         if (qw < p.W) {
-                            g[j][0] = ld_u64_sc1(kb + (size_t)qw * KEY_STRIDE);
-                            g[j][1] = ld_u64_sc1(kb + (size_t)qw * KEY_STRIDE + 1);
-                            g[j][2] = ld_u64_sc1(kb + (size_t)qw * KEY_STRIDE + 2);
+                            g[j][0] = ld_u64_sc1(kb + 2 * (size_t)qw);
+                            g[j][1] = ld_u64_sc1(kb + 2 * (size_t)qw + 1);
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) {
                         const int qw = lane + 64 * j;
-                        if (qw < p.W)
-                            ok &= ((unsigned)(g[j][0] >> 32) == tag) && ((unsigned)(g[j][1] >> 32) == tag) &&
-                                  ((unsigned)(g[j][2] >> 32) == tag);
+                        if (qw < p.W) ok &= ((g[j][0] >> 48) == tag16) && ((g[j][1] >> 48) == tag16);
                     }
                     if (__all(ok)) break;
                     if (++spins > p.spin_limit) {
@@ -485,10 +482,10 @@ rrlu_reg_kernel(RrluRegArgs p)
                     for (int j = 0; j < KPL; ++j) {
                         const int qw = lane + 64 * j;
                         if (qw < p.W) {
-                            const unsigned pk = (unsigned)(g[j][2] & 0xFFFFFFFFull);
+                            const unsigned pk = (unsigned)(g[j][1] & 0xFFFFFFFFull);
                             if (pk != NOPOS) {
-                                const double v = __longlong_as_double(
-                                    (long long)(((g[j][1] & 0xFFFFFFFFull) << 32) | (g[j][0] & 0xFFFFFFFFull)));
+                                const unsigned long long vb = (g[j][0] << 16) | ((g[j][1] >> 32) & 0xFFFFull);
+                                const double v = __longlong_as_double((long long)vb);
                                 double sc = v * v;
                                 if (sc != sc) sc = (pk == diagkey) ? __builtin_huge_val() : -1.0;
                                 if (sc > csc || (sc == csc && pk < cpk)) {
@@ -788,7 +785,7 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
             }
         }
         if (RPT > 4 || TR > 1024) return false; // beyond the register budget: LDS kernel
-        int CPT = ec ? norm_cpt(std::atoi(ec)) : (N >= 8 * 48 * TC ? 8 : 4);
+        int CPT = ec ? norm_cpt(std::atoi(ec)) : 4; // more, thinner workgroups win once the key table is shared (measured)
         int W = (N + TC * CPT - 1) / (TC * CPT);
         if (ew && std::atoi(ew) > 1) {
             W = std::atoi(ew);
@@ -817,7 +814,7 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
 
 size_t rrlu_reg_keys_bytes(const RrluRegPlan& plan)
 {
-    return (size_t)2 * plan.W * plan.W * KEY_STRIDE * sizeof(unsigned long long);
+    return (size_t)2 * plan.W * 2 * sizeof(unsigned long long);
 }
 size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M)
 {
@@ -827,6 +824,8 @@ size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M)
 
 void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
 {
+    // the key table carries 16-bit step tags: zero it before every launch (2.7 KiB at W = 86)
+    if (plan.W > 1) (void)hipMemsetAsync(a.keys, 0, rrlu_reg_keys_bytes(plan), stream);
     switch (plan.RPT) {
     case 1: launch_r<1>(plan, a, stream); break;
     case 2: launch_r<2>(plan, a, stream); break;

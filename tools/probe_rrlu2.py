@@ -3,11 +3,10 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M, N, R = 685, 688, 256
 cfgs = []
-for T in ("384", "512", "768", "256"):
-    for CPT in ("8", "4", "2"):
-        cfgs.append({"T4A_RRLU_T": T, "T4A_RRLU_CPT": CPT})
-cfgs.append({"T4A_RRLU_T": "384", "T4A_RRLU_CPT": "8", "T4A_RRLU_NCOPY": "1"})
-cfgs.append({"T4A_RRLU_T": "384", "T4A_RRLU_CPT": "8", "T4A_RRLU_COLDELAY": "1"})
+for T in ("384", "704"):
+    for CPT in ("4", "2"):
+        for PD in ("0", "8", "16", "24", "32"):
+            cfgs.append({"T4A_RRLU_T": T, "T4A_RRLU_CPT": CPT, "T4A_RRLU_POLLDELAY": PD})
 for c in cfgs:
     env = dict(os.environ); env.update(c); env["T4A_RRLU_STAMPS"] = "1"
     p = subprocess.run(["timeout", "120", sys.executable, os.path.join(ROOT, "tools", "probe_rrlu.py"), "child", str(M), str(N), str(R)],
