@@ -147,8 +147,13 @@ def main():
     tci.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full_sweep()
+    if world == 1:
+        # K full sweeps = 2K iterations of optimize_with_finder in one call: fill_site_tensors of iteration t runs on
+        # its own stream and overlaps with the bond updates of iteration t+1 (they only need the index sets)
+        tci.optimize(opts(2 * args.steps), final_sweep1site=False)
+    else:
+        for _ in range(args.steps):
+            full_sweep()  # the patch-core all-gather needs the cores after every sweep
     barrier()
     dt = time.perf_counter() - t0
     prof = tci.profile()

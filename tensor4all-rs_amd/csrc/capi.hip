@@ -306,6 +306,7 @@ t4a_gpu_status t4a_gpu_trsm_f64(const double* a, size_t na, const double* b, siz
         tp.nrhs = rrhs;
         tp.lower = low ? 1 : 0;
         tp.unit_diag = unit_diagonal ? 1 : 0;
+        tp.skip_flag = nullptr;
         DevBuf<TrsmProblem> dprob;
         dprob.reserve(1);
         T4A_HIP(hipMemcpyAsync(dprob.get(), &tp, sizeof(tp), hipMemcpyHostToDevice, st));
@@ -353,6 +354,7 @@ t4a_gpu_status t4a_gpu_solve_f64(const double* a, size_t n, const double* b, siz
         lp.B = e.d_tmp2.get();
         lp.ldb = (int)n;
         lp.nrhs = (int)nrhs;
+        lp.pmax_bits = nullptr;
         TrsmProblem t[2];
         t[0].T = lp.A;
         t[0].ldt = lp.lda;
@@ -362,6 +364,7 @@ t4a_gpu_status t4a_gpu_solve_f64(const double* a, size_t n, const double* b, siz
         t[0].nrhs = lp.nrhs;
         t[0].lower = 1;
         t[0].unit_diag = 1;
+        t[0].skip_flag = nullptr;
         t[1] = t[0];
         t[1].lower = 0;
         t[1].unit_diag = 0;
@@ -689,6 +692,7 @@ t4a_gpu_status t4a_gpu_tci2_site_tensor(const t4a_gpu_tci2* h, size_t site, size
         T4A_REQUIRE_PTR(dims3);
         if (site >= h->impl.len()) throw Error(T4A_GPU_INVALID_ARGUMENT, "site out of range");
         t4a_gpu_tci2* hh = const_cast<t4a_gpu_tci2*>(h);
+        hh->impl.fill_wait();
         if (!out) {
             dims3[0] = h->impl.cores[site].l;
             dims3[1] = h->impl.cores[site].s;
@@ -707,6 +711,7 @@ t4a_gpu_status t4a_gpu_tci2_site_tensor_device(const t4a_gpu_tci2* h, size_t sit
         T4A_REQUIRE_PTR(out_device);
         if (site >= h->impl.len()) throw Error(T4A_GPU_INVALID_ARGUMENT, "site out of range");
         t4a_gpu_tci2* hh = const_cast<t4a_gpu_tci2*>(h);
+        hh->impl.fill_wait();
         const DevCore& c = h->impl.cores[site];
         if (c.size()) {
             T4A_HIP(hipMemcpyAsync(out_device, c.buf.get(), c.size() * sizeof(double), hipMemcpyDeviceToDevice,
@@ -724,6 +729,7 @@ t4a_gpu_status t4a_gpu_tci2_set_site_tensor_device(t4a_gpu_tci2* h, size_t site,
         T4A_REQUIRE_PTR(dims3);
         if (site >= h->impl.len()) throw Error(T4A_GPU_INVALID_ARGUMENT, "site out of range");
         if (dims3[1] != h->impl.local_dims[site]) throw Error(T4A_GPU_INVALID_ARGUMENT, "site dimension mismatch");
+        h->impl.fill_wait();
         DevCore& c = h->impl.cores[site];
         const size_t count = dims3[0] * dims3[1] * dims3[2];
         c.buf.reserve(std::max<size_t>(count, 1));

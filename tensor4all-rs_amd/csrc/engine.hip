@@ -97,15 +97,24 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     if (ms > (size_t)N) ms = N;
     const int max_steps = (int)ms;
 
-    d_rowperm_.reserve(M);
-    d_colperm_.reserve(N);
-    d_ires_.reserve(4);
-    d_dres_.reserve(2);
-    d_pivvals_.reserve(max_steps > 0 ? max_steps : 1);
+    // one packed result block: [dresult 2 f64][iresult 4 i32][pivot_vals max_steps f64][row_perm M i32][col_perm N i32]
+    // -> one memset of the 32-byte header, one device-to-host copy per bond
+    const size_t off_piv = 32;
+    const size_t off_rp = off_piv + sizeof(double) * (size_t)(max_steps > 0 ? max_steps : 1);
+    const size_t off_cp = off_rp + sizeof(int) * (size_t)M;
+    const size_t out_bytes = off_cp + sizeof(int) * (size_t)N;
+    d_out_.reserve(out_bytes);
+    h_out_.reserve(out_bytes);
+    double* d_dres = reinterpret_cast<double*>(d_out_.get());
+    int* d_ires = reinterpret_cast<int*>(d_out_.get() + 16);
+    double* d_pivvals = reinterpret_cast<double*>(d_out_.get() + off_piv);
+    int* d_rowperm = reinterpret_cast<int*>(d_out_.get() + off_rp);
+    int* d_colperm = reinterpret_cast<int*>(d_out_.get() + off_cp);
+    d_rowperm_ptr_ = d_rowperm;
+    d_colperm_ptr_ = d_colperm;
     const bool keep_lu = need_factors || want_lu_copy;
     if (keep_lu) d_lu_.reserve((size_t)M * N);
-    T4A_HIP(hipMemsetAsync(d_ires_.get(), 0, 4 * sizeof(int), stream_));
-    T4A_HIP(hipMemsetAsync(d_dres_.get(), 0, 2 * sizeof(double), stream_));
+    T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
     static const bool want_stamps = std::getenv("T4A_RRLU_STAMPS") != nullptr;
     static const bool force_lds = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "lds";
     if (want_stamps) {
@@ -155,11 +164,11 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.W = rplan.W;
         a.TR = rplan.TR;
         a.TC = rplan.TC;
-        a.row_perm = left ? d_rowperm_.get() : d_colperm_.get();
-        a.col_perm = left ? d_colperm_.get() : d_rowperm_.get();
-        a.iresult = d_ires_.get();
-        a.dresult = d_dres_.get();
-        a.pivot_vals = d_pivvals_.get();
+        a.row_perm = left ? d_rowperm : d_colperm;
+        a.col_perm = left ? d_colperm : d_rowperm;
+        a.iresult = d_ires;
+        a.dresult = d_dres;
+        a.pivot_vals = d_pivvals;
         a.keys = d_rkeys_.get();
         a.cols = d_rcols_.get();
         a.salt = rrlu_salt_;
@@ -193,11 +202,11 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.W = plan.W;
         a.cpw = plan.cpw;
         a.Mld = plan.Mld;
-        a.row_perm = d_rowperm_.get();
-        a.col_perm = d_colperm_.get();
-        a.iresult = d_ires_.get();
-        a.dresult = d_dres_.get();
-        a.pivot_vals = d_pivvals_.get();
+        a.row_perm = d_rowperm;
+        a.col_perm = d_colperm;
+        a.iresult = d_ires;
+        a.dresult = d_dres;
+        a.pivot_vals = d_pivvals;
         a.keys = d_keys_.get();
         a.cols = d_cols_.get();
         a.spin_limit = 1u << 20;
@@ -210,19 +219,21 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     T4A_HIP(hipGetLastError());
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.b, stream_));
 
-    h_perm_.reserve((size_t)M + N + 4);
-    h_res_.reserve((size_t)max_steps + 4);
-    int* hp = h_perm_.get();
-    double* hr = h_res_.get();
-    T4A_HIP(hipMemcpyAsync(hp, d_ires_.get(), 4 * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    T4A_HIP(hipMemcpyAsync(hp + 4, d_rowperm_.get(), (size_t)M * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    T4A_HIP(hipMemcpyAsync(hp + 4 + M, d_colperm_.get(), (size_t)N * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    T4A_HIP(hipMemcpyAsync(hr, d_dres_.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    if (max_steps > 0)
-        T4A_HIP(hipMemcpyAsync(hr + 2, d_pivvals_.get(), (size_t)max_steps * sizeof(double), hipMemcpyDeviceToHost,
-                               stream_));
+    T4A_HIP(hipMemcpyAsync(h_out_.get(), d_out_.get(), out_bytes, hipMemcpyDeviceToHost, stream_));
     T4A_HIP(hipStreamSynchronize(stream_));
 
+    // host views of the packed block (hp: [4 + M + N] ints, hr: [2 + max_steps] doubles, as before)
+    std::vector<int>& hpv = h_ints_;
+    hpv.resize(4 + (size_t)M + N);
+    std::memcpy(hpv.data(), h_out_.get() + 16, 4 * sizeof(int));
+    std::memcpy(hpv.data() + 4, h_out_.get() + off_rp, sizeof(int) * (size_t)M);
+    std::memcpy(hpv.data() + 4 + M, h_out_.get() + off_cp, sizeof(int) * (size_t)N);
+    std::vector<double>& hrv = h_dbls_;
+    hrv.resize(2 + (size_t)(max_steps > 0 ? max_steps : 1));
+    std::memcpy(hrv.data(), h_out_.get(), 2 * sizeof(double));
+    std::memcpy(hrv.data() + 2, h_out_.get() + off_piv, sizeof(double) * (size_t)(max_steps > 0 ? max_steps : 1));
+    const int* hp = hpv.data();
+    const double* hr = hrv.data();
     float rrlu_ms_this = 0.f;
     if (prof.enabled) {
         T4A_HIP(hipEventElapsedTime(&rrlu_ms_this, ev_rrlu_.a, ev_rrlu_.b));
@@ -326,12 +337,13 @@ void Engine::build_factors(const LuciResult& r, bool left_orth)
             tp.nrhs = M - rk;
             tp.lower = 0;
             tp.unit_diag = 1; // L11 has a unit diagonal (dividing by 1.0 is exact)
+            tp.skip_flag = nullptr;
             *h_trsm_.get() = tp;
             T4A_HIP(hipMemcpyAsync(d_trsm_.get(), h_trsm_.get(), sizeof(TrsmProblem), hipMemcpyHostToDevice, stream_));
             trsm_left_batched_launch(d_trsm_.get(), 1, rk, M - rk, stream_);
             transpose_launch(Bt, rk, M - rk, rk, Wl + rk, M, stream_);
         }
-        scatter_rows_launch(Wl, M, d_rowperm_.get(), M, rk, d_left_.get(), M, stream_);
+        scatter_rows_launch(Wl, M, d_rowperm_ptr_, M, rk, d_left_.get(), M, stream_);
         // right = (L11 U) P_col^T   (rrlu_rowmatrix, matrix_luci.rs:191-204)
         double* L11 = d_w2_.get();
         double* Ue = d_w1_.get(); // reuse after the scatter above has been enqueued (same stream: ordered)
@@ -358,7 +370,7 @@ void Engine::build_factors(const LuciResult& r, bool left_orth)
         g.beta = 0.0;
         g.batch = 1;
         gemm_launch(g, stream_);
-        scatter_cols_launch(Rp, rk, rk, d_colperm_.get(), N, d_right_.get(), rk, stream_);
+        scatter_cols_launch(Rp, rk, rk, d_colperm_ptr_, N, d_right_.get(), rk, stream_);
     } else {
         // left = P_row^T (L U11)   (rrlu_colmatrix, matrix_luci.rs:176-189)
         double* Le = d_w1_.get();                    // M x rk lower trapezoid, diagonal kept
@@ -385,7 +397,7 @@ void Engine::build_factors(const LuciResult& r, bool left_orth)
         g.beta = 0.0;
         g.batch = 1;
         gemm_launch(g, stream_);
-        scatter_rows_launch(Lp, M, d_rowperm_.get(), M, rk, d_left_.get(), M, stream_);
+        scatter_rows_launch(Lp, M, d_rowperm_ptr_, M, rk, d_left_.get(), M, stream_);
         // right = [I_r , U11^{-1} U12] P_col^T   (rrlu_pivot_solve_times_rows, matrix_luci.rs:231-254)
         double* Wr = d_w1_.get(); // rk x N (ordered after the gemm that read Le on the same stream)
         set_identity_launch(Wr, rk, N, rk, stream_);
@@ -400,11 +412,12 @@ void Engine::build_factors(const LuciResult& r, bool left_orth)
             tp.nrhs = N - rk;
             tp.lower = 0;
             tp.unit_diag = 1; // U11 carries a forced unit diagonal (matrixlu.rs:647-651)
+            tp.skip_flag = nullptr;
             *h_trsm_.get() = tp;
             T4A_HIP(hipMemcpyAsync(d_trsm_.get(), h_trsm_.get(), sizeof(TrsmProblem), hipMemcpyHostToDevice, stream_));
             trsm_left_batched_launch(d_trsm_.get(), 1, rk, N - rk, stream_);
         }
-        scatter_cols_launch(Wr, rk, rk, d_colperm_.get(), N, d_right_.get(), rk, stream_);
+        scatter_cols_launch(Wr, rk, rk, d_colperm_ptr_, N, d_right_.get(), rk, stream_);
     }
     T4A_HIP(hipGetLastError());
 }

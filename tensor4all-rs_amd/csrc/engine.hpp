@@ -73,13 +73,15 @@ private:
     hipStream_t stream_ = nullptr;
     int num_cus_ = 0;
     unsigned rrlu_salt_ = 0;
-    DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_pivvals_, d_at_;
-    DevBuf<int> d_rowperm_, d_colperm_, d_ires_;
-    DevBuf<double> d_dres_;
+    DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_at_;
+    DevBuf<char> d_out_;
+    PinBuf<char> h_out_;
+    int* d_rowperm_ptr_ = nullptr;
+    int* d_colperm_ptr_ = nullptr;
+    std::vector<int> h_ints_;
+    std::vector<double> h_dbls_;
     DevBuf<unsigned long long> d_keys_, d_cols_, d_rkeys_, d_rcols_, d_stamps_;
     DevBuf<TrsmProblem> d_trsm_;
-    PinBuf<int> h_perm_;
-    PinBuf<double> h_res_;
     PinBuf<TrsmProblem> h_trsm_;
     EventTimer ev_rrlu_, ev_fac_;
 };

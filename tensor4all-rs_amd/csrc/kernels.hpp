@@ -130,6 +130,7 @@ struct TrsmProblem {
     const double* T; int ldt; int n;
     double* B; int ldb; int nrhs;
     int lower; int unit_diag;
+    const int* skip_flag;   // optional: the problem is skipped when *skip_flag != 0
 };
 void trsm_left_batched_launch(const TrsmProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream);
 
@@ -139,6 +140,7 @@ struct LuProblem {
     int* piv;        // [n]
     int* info;       // [1]: 0 ok, k+1 = exactly-zero pivot at step k
     double* B; int ldb; int nrhs; // right-hand sides to which the row swaps are applied (may be null)
+    const unsigned long long* pmax_bits; // optional: bits of max|a_ij|; below EPS the problem is flagged info = -1
 };
 void lu_batched_launch(const LuProblem* d_problems, int n_problems, int max_n, hipStream_t stream);
 

@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256) trsm_left_kernel(const TrsmProblem* probl
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* Bs = (double*)smem_raw; // n x cw, ld = n
     const TrsmProblem pr = problems[blockIdx.y];
+    if (pr.skip_flag && *pr.skip_flag != 0) return;
     const int n = pr.n;
     const int c0 = blockIdx.x * chunk_w;
     if (c0 >= pr.nrhs || n <= 0) return;
@@ -234,6 +235,13 @@ __global__ void __launch_bounds__(1024) lu_kernel(const LuProblem* problems)
     const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
     double* A = pr.A;
     const int lda = pr.lda;
+    if (pr.pmax_bits) { // zero-pivot-matrix guard (tensorci2.rs:1154-1157): every |p| < EPS
+        const double pmax = __longlong_as_double((long long)*pr.pmax_bits);
+        if (pmax < 2.220446049250313e-16) {
+            if (tid == 0) pr.info[0] = -1;
+            return;
+        }
+    }
     if (tid == 0) pr.info[0] = 0;
     for (int k = 0; k < n; ++k) {
         // (1) pivot search in column k

@@ -3,7 +3,9 @@
 #include "tci2.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <unordered_set>
 
@@ -44,14 +46,16 @@ __global__ void __launch_bounds__(256) pack_right_core_kernel(const double* __re
 
 // core[l,s,r] = xt[r + ldx*(l*S+s)]   (tensorci2.rs:1167-1181)
 __global__ void __launch_bounds__(256) pack_fill_core_kernel(const double* __restrict__ xt, int ldx,
-                                                             double* __restrict__ core, int L, int S, int R)
+                                                             double* __restrict__ core, int L, int S, int R,
+                                                             const int* info)
 {
     const size_t total = (size_t)L * S * R;
+    const bool zero = info && *info == -1; // numerically zero pivot matrix: zero core (tensorci2.rs:1154-1157)
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int l = (int)(e % L);
         const int s = (int)((e / L) % S);
         const int r = (int)(e / ((size_t)L * S));
-        core[e] = xt[(size_t)(l * S + s) * ldx + r];
+        core[e] = zero ? 0.0 : xt[(size_t)(l * S + s) * ldx + r];
     }
 }
 
@@ -133,6 +137,14 @@ Tci2::Tci2(const std::vector<size_t>& dims) : n_(dims.size()), local_dims(dims) 
     d_maxbits_.reserve(2);
     ev_pi_.init();
     ev_fill_.init();
+}
+
+Tci2::~Tci2()
+{
+    if (fill_stream_) {
+        (void)hipStreamSynchronize(fill_stream_);
+        (void)hipStreamDestroy(fill_stream_);
+    }
 }
 
 void Tci2::set_builtin(int fid, int n_acc, const double* params, const uint64_t* weights)
@@ -217,13 +229,18 @@ IndexSet Tci2::kronecker_i(size_t p) const // tensorci2.rs:1224-1234
     IndexSet r;
     r.width = p + 1;
     const IndexSet& src = i_set[p];
-    r.d.reserve(src.count * local_dims[p] * r.width);
-    for (size_t k = 0; k < src.count; ++k)
-        for (size_t li = 0; li < local_dims[p]; ++li) {
-            r.d.insert(r.d.end(), src.at(k), src.at(k) + src.width);
-            r.d.push_back((uint32_t)li);
-            ++r.count;
+    const size_t d = local_dims[p];
+    r.count = src.count * d;
+    r.d.resize(r.count * r.width);
+    uint32_t* out = r.d.data();
+    for (size_t k = 0; k < src.count; ++k) {
+        const uint32_t* in = src.at(k);
+        for (size_t li = 0; li < d; ++li) {
+            if (src.width) std::memcpy(out, in, src.width * sizeof(uint32_t));
+            out[src.width] = (uint32_t)li;
+            out += r.width;
         }
+    }
     return r;
 }
 
@@ -232,12 +249,15 @@ IndexSet Tci2::kronecker_j(size_t p) const // tensorci2.rs:1236-1246
     IndexSet r;
     r.width = n_ - p;
     const IndexSet& src = j_set[p];
-    r.d.reserve(src.count * local_dims[p] * r.width);
-    for (size_t li = 0; li < local_dims[p]; ++li)
+    const size_t d = local_dims[p];
+    r.count = src.count * d;
+    r.d.resize(r.count * r.width);
+    uint32_t* out = r.d.data();
+    for (size_t li = 0; li < d; ++li)
         for (size_t k = 0; k < src.count; ++k) {
-            r.d.push_back((uint32_t)li);
-            r.d.insert(r.d.end(), src.at(k), src.at(k) + src.width);
-            ++r.count;
+            out[0] = (uint32_t)li;
+            if (src.width) std::memcpy(out + 1, src.at(k), src.width * sizeof(uint32_t));
+            out += r.width;
         }
     return r;
 }
@@ -250,11 +270,42 @@ void Tci2::union_extras(IndexSet& base, const IndexSet& extras)
         if (base.count == 0) base.count = 1;
         return;
     }
-    std::unordered_set<std::string> seen;
-    seen.reserve(base.count * 2 + extras.count);
-    for (size_t k = 0; k < base.count; ++k) seen.insert(key_of(base.at(k), base.width));
+    // open-addressing table of (hash, index+1); digits are compared on a hash hit, so the result is exactly the
+    // reference's `contains`-based union
+    const size_t w = base.width;
+    auto hash_of = [w](const uint32_t* v) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (size_t i = 0; i < w; ++i) {
+            h ^= v[i];
+            h *= 0x100000001b3ull;
+        }
+        return h ^ (h >> 29);
+    };
+    size_t cap = 16;
+    while (cap < 2 * (base.count + extras.count)) cap <<= 1;
+    std::vector<uint32_t> slot(cap, 0);
+    base.d.reserve((base.count + extras.count) * w);
+    auto insert = [&](size_t idx) {
+        size_t pos = hash_of(base.at(idx)) & (cap - 1);
+        while (slot[pos]) pos = (pos + 1) & (cap - 1);
+        slot[pos] = (uint32_t)idx + 1;
+    };
+    for (size_t k = 0; k < base.count; ++k) insert(k);
     for (size_t k = 0; k < extras.count; ++k) {
-        if (seen.insert(key_of(extras.at(k), base.width)).second) base.push(extras.at(k));
+        const uint32_t* e = extras.at(k);
+        size_t pos = hash_of(e) & (cap - 1);
+        bool found = false;
+        while (slot[pos]) {
+            if (std::memcmp(base.at(slot[pos] - 1), e, w * sizeof(uint32_t)) == 0) {
+                found = true;
+                break;
+            }
+            pos = (pos + 1) & (cap - 1);
+        }
+        if (!found) {
+            base.push(e);
+            slot[pos] = (uint32_t)base.count; // index of the new entry + 1
+        }
     }
 }
 
@@ -300,12 +351,12 @@ void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
         acc_used_ += need;
         std::memcpy(ha, ra.data(), ra.size() * sizeof(uint64_t));
         std::memcpy(hb, rb.data(), rb.size() * sizeof(uint64_t));
-        d_rowacc_.reserve(ra.size());
-        d_colacc_.reserve(rb.size());
-        T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ha, ra.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        T4A_HIP(hipMemcpyAsync(d_colacc_.get(), hb, rb.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        d_rowacc_.reserve(need);
+        T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ha, need * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         (void)K;
-        pi_eval_launch(fn_dev_, d_rowacc_.get(), (int)na, d_colacc_.get(), (int)nb, d_out, (int)na, false, d_maxbits, st);
+        (void)hb;
+        pi_eval_launch(fn_dev_, d_rowacc_.get(), (int)na, d_rowacc_.get() + ra.size(), (int)nb, d_out, (int)na, false,
+                       d_maxbits, st);
         T4A_HIP(hipGetLastError());
     } else {
         // host batch callback: points in row-major order of (ia, ib) — `ia` outer, `ib` inner — exactly the
@@ -361,9 +412,17 @@ LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
     const size_t M = is.count, N = js.count;
     double* d_pi = eng.pi(M * N);
     hipStream_t st = eng.stream();
+    static const bool host_prof = std::getenv("T4A_HOST_PROFILE") != nullptr;
+    static double hp_eval = 0;
+    static long hp_n = 0;
+    const auto hp_t0 = std::chrono::steady_clock::now();
     if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.a, st));
     eval_matrix(is, 0, js, is.width, d_pi, nullptr);
     if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.b, st));
+    if (host_prof) {
+        hp_eval += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hp_t0).count();
+        if (++hp_n % 580 == 0) std::fprintf(stderr, "[host profile] eval_matrix host part %.1f us per bond\n", 1e3 * hp_eval / hp_n);
+    }
     LuciResult lu = eng.luci(d_pi, (int)M, (int)N, o, need_factors, false);
     acc_used_ = 0; // eng.luci synchronised the stream
     if (eng.prof.enabled) {
@@ -424,11 +483,16 @@ void Tci2::update_pivot_errors(const std::vector<double>& e) // tensorci2.rs:801
 void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& options, const IndexSet& extra_i,
                          const IndexSet& extra_j)
 {
+    static const bool host_prof = std::getenv("T4A_HOST_PROFILE") != nullptr;
+    static double hp_sets = 0, hp_luci = 0, hp_post = 0;
+    static long hp_n = 0;
+    const auto hp_t0 = std::chrono::steady_clock::now();
     IndexSet i_comb = kronecker_i(b);
     IndexSet j_comb = kronecker_j(b + 1);
     union_extras(i_comb, extra_i);
     union_extras(j_comb, extra_j);
     if (i_comb.count == 0 || j_comb.count == 0) return;
+    const auto hp_t1 = std::chrono::steady_clock::now();
     if (options.pivot_search != 0)
         throw Error(T4A_GPU_NOT_IMPLEMENTED, "PivotSearchStrategy::Rook is not implemented in the MI355X backend yet");
 
@@ -441,6 +505,7 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     // the reference always builds the factors; they are only CONSUMED when no extras were merged
     // (tensorci2.rs:1942-1949), so the device skips the trsm/gemm otherwise.
     LuciResult lu = luci_on_sets(i_comb, j_comb, lo, !extras_used);
+    const auto hp_t2 = std::chrono::steady_clock::now();
     if (b < last_sweep_shapes.size()) last_sweep_shapes[b] = {i_comb.count, j_comb.count, (size_t)lu.rank};
 
     const std::vector<size_t> rows = non_empty_or_first(lu.row_perm, lu.rank);
@@ -452,6 +517,15 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     for (size_t c : cols) nj.push(j_comb.at(c));
     i_set[b + 1] = ni;
     j_set[b] = nj;
+    if (host_prof) {
+        const auto hp_t3 = std::chrono::steady_clock::now();
+        hp_sets += std::chrono::duration<double, std::milli>(hp_t1 - hp_t0).count();
+        hp_luci += std::chrono::duration<double, std::milli>(hp_t2 - hp_t1).count();
+        hp_post += std::chrono::duration<double, std::milli>(hp_t3 - hp_t2).count();
+        if (++hp_n % 580 == 0)
+            std::fprintf(stderr, "[host profile] per bond: build sets %.1f us, luci_on_sets (host+device) %.1f us, post %.1f us\n",
+                         1e3 * hp_sets / hp_n, 1e3 * hp_luci / hp_n, 1e3 * hp_post / hp_n);
+    }
 
     if (extras_used) {
         if (!lu.pivot_errors.empty()) bond_errors[b] = lu.pivot_errors.back();
@@ -469,6 +543,7 @@ void Tci2::sweep2site(bool forward, const TCI2Options& options)
 {
     options.validate();
     require_fn();
+    fill_wait();
     invalidate_site_tensors();
     flush_pivot_errors();
     last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
@@ -539,6 +614,7 @@ void Tci2::sweep1site(bool forward, double rel_tol, double abs_tol, size_t max_b
     if (!(abs_tol >= 0.0) || !std::isfinite(abs_tol)) throw Error(T4A_GPU_INVALID_ARGUMENT, "abs_tol must be finite and non-negative");
     if (max_bond_dim == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "max_bond_dim must be positive");
     require_fn();
+    fill_wait();
     flush_pivot_errors();
     invalidate_site_tensors();
     if (forward) {
@@ -580,14 +656,49 @@ void Tci2::make_canonical(double rel_tol, double abs_tol, size_t max_bond_dim)
 
 // tensorci2.rs:1065-1186 — all sites are independent given the final I/J sets, so the evaluations, the
 // partial-pivot LU factorisations and the triangular solves of every site are issued as batches.
-void Tci2::fill_site_tensors()
+// The whole fill runs on its own stream.  With `async` (optimize loop, nsearch == 0, built-in functor) the host
+// does not wait: the next half-sweep's bond updates only need the index sets, so the fill overlaps with them
+// (the rrLU chain leaves most CUs idle).  Errors (singular pivot matrix) surface at the next fill_wait().
+void Tci2::fill_site_tensors() { fill_site_tensors_impl(false); }
+
+void Tci2::fill_wait()
+{
+    if (!fill_inflight_) return;
+    fill_inflight_ = false;
+    T4A_HIP(hipStreamSynchronize(fill_stream_));
+    T4A_HIP(hipGetLastError());
+    if (eng.prof.enabled && fill_timed_) {
+        float ms = 0.f;
+        T4A_HIP(hipEventElapsedTime(&ms, ev_fill_.a, ev_fill_.b));
+        eng.prof.v[4] += ms;
+        eng.prof.v[5] += 1.0;
+    }
+    fill_timed_ = false;
+    for (size_t k = 0; k < fill_solved_sites_.size(); ++k)
+        if (h_fillinfo_.get()[fill_solved_sites_[k]] > 0) {
+            const size_t site = fill_solved_sites_[k];
+            fill_solved_sites_.clear();
+            throw Error(T4A_GPU_INTERNAL_ERROR, "one-site interpolation solve failed: singular pivot matrix at site " +
+                                                    std::to_string(site));
+        }
+    fill_solved_sites_.clear();
+}
+
+void Tci2::fill_site_tensors_impl(bool async)
 {
     require_fn();
-    hipStream_t st = eng.stream();
+    fill_wait(); // the scratch arenas of the previous fill are free again
+    if (!fill_stream_) T4A_HIP(hipStreamCreateWithFlags(&fill_stream_, hipStreamNonBlocking));
+    const bool builtin = fn_kind_ == FnKind::Builtin;
+    if (!builtin) async = false;
+    // everything of this fill is ordered after the work already enqueued on the main stream
+    T4A_HIP(hipStreamSynchronize(eng.stream()));
+    hipStream_t st = fill_stream_;
     struct SiteJob {
         size_t b;
         size_t ni, nj, np;
         size_t offA, offB; // offsets (doubles) into d_fillA_ / d_fillB_
+        size_t accJ, accK, accI; // offsets (u64) into the accumulator arena: J_b, kron_i(b), I_{b+1}
         bool last;
     };
     std::vector<SiteJob> jobs;
@@ -599,7 +710,12 @@ void Tci2::fill_site_tensors()
         if (ni == 0 || nj == 0) { // tensorci2.rs:1074-1092
             const size_t left_dim = (b == 0) ? 1 : std::max<size_t>(i_set[b].count, 1);
             const size_t right_dim = (b == n_ - 1) ? 1 : std::max<size_t>(i_set[b + 1].count, 1);
-            set_core_zero(b, left_dim, local_dims[b], right_dim);
+            DevCore& c = cores[b];
+            c.buf.reserve(std::max<size_t>(left_dim * local_dims[b] * right_dim, 1));
+            c.l = left_dim;
+            c.s = local_dims[b];
+            c.r = right_dim;
+            fill_launch(c.buf.get(), c.size(), 0.0, st);
             continue;
         }
         SiteJob j;
@@ -614,58 +730,98 @@ void Tci2::fill_site_tensors()
                                                     std::to_string(nj) + ")");
         j.offA = totA;
         j.offB = totB;
+        j.accJ = j.accK = j.accI = 0;
         totA += j.last ? 0 : nj * j.np;
         totB += nj * ni;
         jobs.push_back(j);
     }
-    if (jobs.empty()) return;
+    if (jobs.empty()) {
+        T4A_HIP(hipStreamSynchronize(st));
+        return;
+    }
     d_fillA_.reserve(std::max<size_t>(totA, 1));
     d_fillB_.reserve(totB);
     d_fillmax_.reserve(n_);
+    d_fillinfo_.reserve(n_);
+    h_fillinfo_.reserve(n_);
     T4A_HIP(hipMemsetAsync(d_fillmax_.get(), 0, n_ * sizeof(unsigned long long), st));
-    if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_fill_.a, st));
+    T4A_HIP(hipMemsetAsync(d_fillinfo_.get(), 0, n_ * sizeof(int), st));
+    fill_timed_ = eng.prof.enabled;
+    if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.a, st));
 
     // (1) evaluations.  B_b = Π1^T (nj x ni), A_b = P^T (nj x np) — evaluated directly in transposed form
     //     (solve(P^T, Π1^T), tensorci2.rs:1160-1162).
     double flops = 0.0;
-    for (const SiteJob& j : jobs) {
-        IndexSet ik = kronecker_i(j.b);
-        const IndexSet& jb = j_set[j.b];
-        if (j.last) {
-            // last site stores Π1 itself (:1109-1128); keep it untransposed: ni x nj
-            eval_matrix(ik, 0, jb, ik.width, d_fillB_.get() + j.offB, nullptr);
-        } else {
-            eval_matrix(jb, j.b + 1, ik, 0, d_fillB_.get() + j.offB, nullptr);
-            eval_matrix(jb, j.b + 1, i_set[j.b + 1], 0, d_fillA_.get() + j.offA, d_fillmax_.get() + j.b);
-            const double n = (double)j.np;
-            flops += (2.0 / 3.0) * n * n * n + 2.0 * n * n * (double)j.ni;
+    if (builtin) {
+        // all accumulators of all sites: one pinned block, one host-to-device copy, then the kernels
+        const int K = fn_dev_.n_acc;
+        std::vector<uint64_t> acc_all, tmp;
+        for (SiteJob& j : jobs) {
+            IndexSet ik = kronecker_i(j.b);
+            accumulate(j_set[j.b], j.b + 1, tmp);
+            j.accJ = acc_all.size();
+            acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
+            accumulate(ik, 0, tmp);
+            j.accK = acc_all.size();
+            acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
+            if (!j.last) {
+                accumulate(i_set[j.b + 1], 0, tmp);
+                j.accI = acc_all.size();
+                acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
+            }
         }
+        h_fillacc_.reserve(acc_all.size());
+        d_fillacc_.reserve(acc_all.size());
+        std::memcpy(h_fillacc_.get(), acc_all.data(), acc_all.size() * sizeof(uint64_t));
+        T4A_HIP(hipMemcpyAsync(d_fillacc_.get(), h_fillacc_.get(), acc_all.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        const uint64_t* da = d_fillacc_.get();
+        for (const SiteJob& j : jobs) {
+            eng.prof.v[11] += (double)j.ni * j.nj + (double)j.np * j.nj;
+            if (j.last) {
+                // last site stores Π1 itself (:1109-1128): ni x nj
+                pi_eval_launch(fn_dev_, da + j.accK, (int)j.ni, da + j.accJ, (int)j.nj, d_fillB_.get() + j.offB, (int)j.ni,
+                               false, nullptr, st);
+            } else {
+                pi_eval_launch(fn_dev_, da + j.accJ, (int)j.nj, da + j.accK, (int)j.ni, d_fillB_.get() + j.offB, (int)j.nj,
+                               false, nullptr, st);
+                pi_eval_launch(fn_dev_, da + j.accJ, (int)j.nj, da + j.accI, (int)j.np, d_fillA_.get() + j.offA, (int)j.nj,
+                               false, d_fillmax_.get() + j.b, st);
+                const double n = (double)j.np;
+                flops += (2.0 / 3.0) * n * n * n + 2.0 * n * n * (double)j.ni;
+            }
+            (void)K;
+        }
+    } else {
+        // host callback: evaluated synchronously through eval_matrix (main stream), then continue on `st`
+        for (const SiteJob& j : jobs) {
+            IndexSet ik = kronecker_i(j.b);
+            const IndexSet& jb = j_set[j.b];
+            if (j.last) {
+                eval_matrix(ik, 0, jb, ik.width, d_fillB_.get() + j.offB, nullptr);
+            } else {
+                eval_matrix(jb, j.b + 1, ik, 0, d_fillB_.get() + j.offB, nullptr);
+                eval_matrix(jb, j.b + 1, i_set[j.b + 1], 0, d_fillA_.get() + j.offA, d_fillmax_.get() + j.b);
+                const double n = (double)j.np;
+                flops += (2.0 / 3.0) * n * n * n + 2.0 * n * n * (double)j.ni;
+            }
+        }
+        T4A_HIP(hipStreamSynchronize(eng.stream()));
+        acc_used_ = 0;
     }
-    // (2) zero-pivot-matrix guard (:1154-1157) needs max|P| on the host
-    std::vector<unsigned long long> hmax(n_);
-    T4A_HIP(hipMemcpyAsync(hmax.data(), d_fillmax_.get(), n_ * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    T4A_HIP(hipStreamSynchronize(st));
-    acc_used_ = 0;
 
+    // (2) batched solve; the zero-pivot-matrix guard (:1154-1157) is evaluated on the device: lu_kernel reads
+    //     max|P| and flags info = -1, the solves skip flagged problems and the packing writes a zero core
     std::vector<LuProblem> lups;
     std::vector<TrsmProblem> trl, tru;
-    std::vector<const SiteJob*> solved;
     size_t piv_total = 0;
     for (const SiteJob& j : jobs)
         if (!j.last) piv_total += j.np;
     d_fillpiv_.reserve(std::max<size_t>(piv_total, 1));
-    d_fillinfo_.reserve(n_);
     size_t piv_off = 0;
     int max_n = 0, max_nrhs = 0;
+    fill_solved_sites_.clear();
     for (const SiteJob& j : jobs) {
         if (j.last) continue;
-        double pmax;
-        std::memcpy(&pmax, &hmax[j.b], sizeof(double));
-        const size_t left_dim = (j.b == 0) ? 1 : i_set[j.b].count;
-        if (pmax < 2.220446049250313e-16) { // every |p| < EPS -> zero core with the same bond shape
-            set_core_zero(j.b, left_dim, local_dims[j.b], j.np);
-            continue;
-        }
         LuProblem lp;
         lp.A = d_fillA_.get() + j.offA;
         lp.lda = (int)j.nj;
@@ -675,6 +831,7 @@ void Tci2::fill_site_tensors()
         lp.B = d_fillB_.get() + j.offB;
         lp.ldb = (int)j.nj;
         lp.nrhs = (int)j.ni;
+        lp.pmax_bits = d_fillmax_.get() + j.b;
         piv_off += j.np;
         lups.push_back(lp);
         TrsmProblem t;
@@ -686,23 +843,27 @@ void Tci2::fill_site_tensors()
         t.nrhs = lp.nrhs;
         t.lower = 1;
         t.unit_diag = 1;
+        t.skip_flag = lp.info;
         trl.push_back(t);
         t.lower = 0;
         t.unit_diag = 0;
         tru.push_back(t);
-        solved.push_back(&j);
+        fill_solved_sites_.push_back(j.b);
         max_n = std::max(max_n, lp.n);
         max_nrhs = std::max(max_nrhs, lp.nrhs);
     }
-    T4A_HIP(hipMemsetAsync(d_fillinfo_.get(), 0, n_ * sizeof(int), st));
     if (!lups.empty()) {
         const size_t np_ = lups.size();
         d_lup_.reserve(np_);
         d_trp_.reserve(2 * np_);
-        T4A_HIP(hipMemcpyAsync(d_lup_.get(), lups.data(), np_ * sizeof(LuProblem), hipMemcpyHostToDevice, st));
-        T4A_HIP(hipMemcpyAsync(d_trp_.get(), trl.data(), np_ * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
-        T4A_HIP(hipMemcpyAsync(d_trp_.get() + np_, tru.data(), np_ * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
-        T4A_HIP(hipStreamSynchronize(st)); // descriptor vectors are pageable
+        h_fillprob_.reserve(np_ * sizeof(LuProblem) + 2 * np_ * sizeof(TrsmProblem));
+        char* hb = h_fillprob_.get();
+        std::memcpy(hb, lups.data(), np_ * sizeof(LuProblem));
+        std::memcpy(hb + np_ * sizeof(LuProblem), trl.data(), np_ * sizeof(TrsmProblem));
+        std::memcpy(hb + np_ * sizeof(LuProblem) + np_ * sizeof(TrsmProblem), tru.data(), np_ * sizeof(TrsmProblem));
+        T4A_HIP(hipMemcpyAsync(d_lup_.get(), hb, np_ * sizeof(LuProblem), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(d_trp_.get(), hb + np_ * sizeof(LuProblem), 2 * np_ * sizeof(TrsmProblem),
+                               hipMemcpyHostToDevice, st));
         lu_batched_launch(d_lup_.get(), (int)np_, max_n, st);
         trsm_left_batched_launch(d_trp_.get(), (int)np_, max_n, max_nrhs, st);
         trsm_left_batched_launch(d_trp_.get() + np_, (int)np_, max_n, max_nrhs, st);
@@ -711,44 +872,29 @@ void Tci2::fill_site_tensors()
     for (const SiteJob& j : jobs) {
         const size_t left_dim = (j.b == 0) ? 1 : i_set[j.b].count;
         const size_t S = local_dims[j.b];
+        DevCore& c = cores[j.b];
         if (j.last) {
-            DevCore& c = cores[j.b];
             c.buf.reserve(left_dim * S);
             c.l = left_dim;
             c.s = S;
             c.r = 1;
             hipLaunchKernelGGL(pack_left_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, st,
                                d_fillB_.get() + j.offB, (int)j.ni, (int)j.ni, 1, c.buf.get(), (int)left_dim, (int)S, 1);
+        } else {
+            c.buf.reserve(left_dim * S * j.np);
+            c.l = left_dim;
+            c.s = S;
+            c.r = j.np;
+            hipLaunchKernelGGL(pack_fill_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, st,
+                               d_fillB_.get() + j.offB, (int)j.nj, c.buf.get(), (int)left_dim, (int)S, (int)j.np,
+                               (const int*)(d_fillinfo_.get() + j.b));
         }
     }
-    for (const SiteJob* pj : solved) {
-        const SiteJob& j = *pj;
-        const size_t left_dim = (j.b == 0) ? 1 : i_set[j.b].count;
-        const size_t S = local_dims[j.b];
-        DevCore& c = cores[j.b];
-        c.buf.reserve(left_dim * S * j.np);
-        c.l = left_dim;
-        c.s = S;
-        c.r = j.np;
-        hipLaunchKernelGGL(pack_fill_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, st, d_fillB_.get() + j.offB,
-                           (int)j.nj, c.buf.get(), (int)left_dim, (int)S, (int)j.np);
-    }
-    if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_fill_.b, st));
-    std::vector<int> hinfo(n_, 0);
-    T4A_HIP(hipMemcpyAsync(hinfo.data(), d_fillinfo_.get(), n_ * sizeof(int), hipMemcpyDeviceToHost, st));
-    T4A_HIP(hipStreamSynchronize(st));
-    T4A_HIP(hipGetLastError());
-    if (eng.prof.enabled) {
-        float ms = 0.f;
-        T4A_HIP(hipEventElapsedTime(&ms, ev_fill_.a, ev_fill_.b));
-        eng.prof.v[4] += ms;
-        eng.prof.v[5] += 1.0;
-    }
+    if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.b, st));
+    T4A_HIP(hipMemcpyAsync(h_fillinfo_.get(), d_fillinfo_.get(), n_ * sizeof(int), hipMemcpyDeviceToHost, st));
     eng.prof.v[10] += flops;
-    for (const SiteJob* pj : solved)
-        if (hinfo[pj->b] != 0)
-            throw Error(T4A_GPU_INTERNAL_ERROR, "one-site interpolation solve failed: singular pivot matrix at site " +
-                                                    std::to_string(pj->b));
+    fill_inflight_ = true;
+    if (!async) fill_wait();
 }
 
 // =================================================================================================
@@ -756,6 +902,7 @@ void Tci2::fill_site_tensors()
 // =================================================================================================
 std::vector<double> Tci2::site_tensor_host(size_t site, size_t dims3[3])
 {
+    fill_wait();
     const DevCore& c = cores[site];
     dims3[0] = c.l;
     dims3[1] = c.s;
@@ -779,6 +926,7 @@ static void check_tt_chain(const std::vector<DevCore>& cores) // SimpleTensorTra
 
 std::vector<double> Tci2::evaluate(const uint32_t* idx, size_t n_pts)
 {
+    fill_wait();
     check_tt_chain(cores);
     std::vector<double> out(n_pts);
     if (n_pts == 0) return out;
@@ -919,6 +1067,7 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
     require_fn();
     if (rank() == 0)
         throw Error(T4A_GPU_INVALID_ARGUMENT, "TensorCI2 state must contain at least one pivot before optimization");
+    fill_wait();
     ranks_hist.clear();
     errors_hist.clear();
     std::vector<size_t> nglobal_hist;
@@ -956,7 +1105,8 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         } else {
             for (size_t b = n_ - 1; b-- > 0;) update_pivots(b, false, options, extra_i[b + 1], extra_j[b]);
         }
-        fill_site_tensors();
+        // the cores are not needed by the next half-sweep unless the global pivot search evaluates the TT
+        fill_site_tensors_impl(options.nsearch == 0 && !options.strictly_nested);
         const double error = max_bond_error();
         errors_hist.push_back(error / norm);
 
@@ -975,6 +1125,7 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
             break;
         }
     }
+    fill_wait(); // the cores of the last iteration are complete (deferred solve errors surface here)
     if (final_sweep1site) { // :1781-1794
         const double norm = (options.normalize_error && max_sample_value > 0.0) ? max_sample_value : 1.0;
         const double abs_tol = options.tolerance * norm;

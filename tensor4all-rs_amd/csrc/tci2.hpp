@@ -61,6 +61,7 @@ struct DevCore {
 class Tci2 {
 public:
     explicit Tci2(const std::vector<size_t>& local_dims);
+    ~Tci2();
 
     // function source
     void set_builtin(int fid, int n_acc, const double* params, const uint64_t* weights);
@@ -77,6 +78,8 @@ public:
     void sweep2site(bool forward, const TCI2Options& options);
     void sweep1site(bool forward, double rel_tol, double abs_tol, size_t max_bond_dim, bool update_tensors);
     void fill_site_tensors();
+    void fill_site_tensors_impl(bool async);
+    void fill_wait(); // completes an asynchronous fill (and reports its deferred errors)
     void make_canonical(double rel_tol, double abs_tol, size_t max_bond_dim);
     void invalidate_site_tensors();
     void flush_pivot_errors() { pivot_errors.clear(); }
@@ -154,6 +157,13 @@ private:
     DevBuf<TrsmProblem> d_trp_;
     DevBuf<unsigned long long> d_fillmax_;
     EventTimer ev_pi_, ev_fill_;
+    hipStream_t fill_stream_ = nullptr;
+    bool fill_inflight_ = false, fill_timed_ = false;
+    std::vector<size_t> fill_solved_sites_;
+    PinBuf<int> h_fillinfo_;
+    PinBuf<uint64_t> h_fillacc_;
+    DevBuf<uint64_t> d_fillacc_;
+    PinBuf<char> h_fillprob_;
 };
 
 } // namespace t4a
