@@ -100,6 +100,19 @@ t4a_gpu_status t4a_gpu_trsm_f64(const double* a, size_t na, const double* b, siz
  * Returns T4A_GPU_SINGULAR_MATRIX for an exactly singular A. */
 t4a_gpu_status t4a_gpu_solve_f64(const double* a, size_t n, const double* b, size_t nrhs, double* x);
 
+/* svd_backend(&a) (tensorbackend/src/backend.rs:709-731): thin SVD, k = min(m,n); u is m x k, s has k entries in
+ * non-increasing order, vt is k x n ("backend convention", simplett/src/compression.rs:254-287).  One-sided Jacobi.
+ * Returns T4A_GPU_INVALID_ARGUMENT for an empty or non-finite matrix. */
+t4a_gpu_status t4a_gpu_svd_f64(const double* a, size_t m, size_t n, double* u, double* s, double* vt);
+
+/* qr_backend(&a) (backend.rs:742-760): thin QR, q is m x k, r is k x n upper trapezoidal.  Householder. */
+t4a_gpu_status t4a_gpu_qr_f64(const double* a, size_t m, size_t n, double* q, double* r);
+
+/* full_piv_lu_matrix(&a) (backend.rs:1022-1037) for a square n x n matrix: P A Q^T = L U with n x n factors;
+ * row k of P (Q) carries its 1 in the column of the k-th pivot row (column), which is how
+ * core/src/matrixluci/dense.rs:120-139 reads them.  Elimination order = rrlu_mut with zero tolerances. */
+t4a_gpu_status t4a_gpu_full_piv_lu_f64(const double* a, size_t n, double* p, double* l, double* u, double* q);
+
 /* =====================================================================================
  * TCI2 sweep driver (opaque handle; state resident on the device between calls)
  * ===================================================================================== */
@@ -221,6 +234,45 @@ t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t 
  * keep != 0 an EMPTY pivot list leaves them in place (the index sets did not change, so they are still the cores
  * of the current sets).  Default 0 = reference behaviour. */
 t4a_gpu_status t4a_gpu_tci2_set_keep_site_tensors(t4a_gpu_tci2* h, int32_t keep);
+
+/* =====================================================================================
+ * SimpleTensorTrain<f64> (opaque handle; site tensors resident on the device)
+ * tensor4all-simplett: tensortrain.rs:97, traits.rs:75-355, compression.rs:375-507, cache.rs:558-744
+ * ===================================================================================== */
+typedef struct t4a_gpu_tt t4a_gpu_tt;
+
+/* SimpleTensorTrain::new(tensors) (tensortrain.rs:97-124).  dims3 is 3 x n_sites (left, site, right per site),
+ * cores the site tensors concatenated, each column-major [left, site, right].  Same validation as the reference:
+ * first left == 1, last right == 1, neighbouring bonds equal. */
+t4a_gpu_status t4a_gpu_tt_new(const size_t* dims3, size_t n_sites, const double* cores, t4a_gpu_tt** out);
+void t4a_gpu_tt_release(t4a_gpu_tt* h);
+t4a_gpu_status t4a_gpu_tt_clone(const t4a_gpu_tt* h, t4a_gpu_tt** out);
+t4a_gpu_status t4a_gpu_tt_len(const t4a_gpu_tt* h, size_t* out);
+t4a_gpu_status t4a_gpu_tt_dims(const t4a_gpu_tt* h, size_t* dims3 /* 3 x n_sites */);
+t4a_gpu_status t4a_gpu_tt_site_tensor(const t4a_gpu_tt* h, size_t site, double* out);
+/* AbstractTensorTrain::evaluate (traits.rs:146-212) for a batch: idx is n_sites x n_pts column-major. */
+t4a_gpu_status t4a_gpu_tt_evaluate(t4a_gpu_tt* h, const size_t* idx, size_t n_pts, double* out);
+/* sum (traits.rs:231-275), norm2 = <tt|tt> (traits.rs:289-354) */
+t4a_gpu_status t4a_gpu_tt_sum(t4a_gpu_tt* h, double* out);
+t4a_gpu_status t4a_gpu_tt_norm2(t4a_gpu_tt* h, double* out);
+/* SimpleTensorTrain::compress(&CompressionOptions) (compression.rs:375-507).
+ * method: 0 LU, 1 CI, 2 SVD (compression.rs:40-52); max_bond_dim == 0 <=> None. */
+#define T4A_GPU_COMPRESS_LU 0
+#define T4A_GPU_COMPRESS_CI 1
+#define T4A_GPU_COMPRESS_SVD 2
+t4a_gpu_status t4a_gpu_tt_compress(t4a_gpu_tt* h, int32_t method, double tolerance, size_t max_bond_dim,
+                                   int32_t normalize_error);
+/* TTCache::evaluate_many(indices, split) (cache.rs:558-688): split == 0 <=> None (find_split_heuristic,
+ * cache.rs:690-744); *used_split (may be NULL) reports the split position that was used. */
+t4a_gpu_status t4a_gpu_tt_evaluate_many(t4a_gpu_tt* h, const size_t* idx, size_t n_pts, size_t split, double* out,
+                                        size_t* used_split);
+
+/* TensorCI2::to_tensor_train (tensorci2.rs:640-660): a device-to-device copy of the current site tensors. */
+t4a_gpu_status t4a_gpu_tci2_to_tensor_train(t4a_gpu_tci2* h, t4a_gpu_tt** out);
+/* TensorCI2::from_tensor_train(tt, TensorCI2FromTensorTrainOptions{tolerance, max_bond_dim, max_iter})
+ * (tensorci/src/conversion.rs:66-121).  max_bond_dim == 0 <=> None; defaults 1e-12 / None / 3. */
+t4a_gpu_status t4a_gpu_tci2_from_tensor_train(const t4a_gpu_tt* tt, double tolerance, size_t max_bond_dim,
+                                              size_t max_iter, t4a_gpu_tci2** out);
 
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */

@@ -1,0 +1,239 @@
+// oracle/oracle_capi_tt.cpp — TEST INFRASTRUCTURE ONLY (see t4a_oracle_tt.hpp header).
+// C entry points for the tensor-train side of the CPU restatement (SURVEY.md §8 rows a14–a18).
+#include "t4a_oracle_tt.hpp"
+
+#include <cstring>
+#include <memory>
+
+using namespace t4a_oracle;
+
+namespace {
+thread_local std::string g_tt_error;
+
+template <class F> int guarded(F&& body)
+{
+    try {
+        body();
+        return 0;
+    } catch (const OracleError& e) {
+        g_tt_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_tt_error = e.what();
+        return ERR_INTERNAL;
+    }
+}
+
+Matrix from_ptr(const double* a, size_t m, size_t n)
+{
+    Matrix x(m, n);
+    if (m != 0 && n != 0) std::memcpy(x.a.data(), a, m * n * sizeof(double));
+    return x;
+}
+void to_ptr(const Matrix& x, double* out)
+{
+    if (!x.a.empty()) std::memcpy(out, x.a.data(), x.a.size() * sizeof(double));
+}
+
+struct OracleTT {
+    SimpleTensorTrain tt;
+};
+} // namespace
+
+extern "C" {
+
+const char* oracle_tt_last_error() { return g_tt_error.c_str(); }
+
+int oracle_qr_f64(const double* a, uint64_t m, uint64_t n, double* q, double* r)
+{
+    return guarded([&] {
+        QrResult d = qr_thin(from_ptr(a, m, n));
+        to_ptr(d.q, q);
+        to_ptr(d.r, r);
+    });
+}
+
+int oracle_svd_f64(const double* a, uint64_t m, uint64_t n, double* u, double* s, double* vt)
+{
+    return guarded([&] {
+        SvdResult d = svd_thin(from_ptr(a, m, n));
+        to_ptr(d.u, u);
+        for (size_t i = 0; i < d.s.size(); ++i) s[i] = d.s[i];
+        to_ptr(d.vt, vt);
+    });
+}
+
+int oracle_full_piv_lu_f64(const double* a, uint64_t n, double* p, double* l, double* u, double* q)
+{
+    return guarded([&] {
+        FullPivLu d = full_piv_lu(from_ptr(a, n, n));
+        to_ptr(d.p, p);
+        to_ptr(d.l, l);
+        to_ptr(d.u, u);
+        to_ptr(d.q, q);
+    });
+}
+
+// ---- SimpleTensorTrain handle ----
+void* oracle_tt_new(uint64_t n_sites, const uint64_t* dims3 /* 3 x n_sites */, const double* data)
+{
+    void* out = nullptr;
+    guarded([&] {
+        std::vector<Tensor3> ts;
+        size_t off = 0;
+        for (size_t s = 0; s < n_sites; ++s) {
+            Tensor3 t(dims3[3 * s], dims3[3 * s + 1], dims3[3 * s + 2]);
+            if (!t.d.empty()) std::memcpy(t.d.data(), data + off, t.d.size() * sizeof(double));
+            off += t.d.size();
+            ts.push_back(std::move(t));
+        }
+        auto* h = new OracleTT;
+        try {
+            h->tt = SimpleTensorTrain::make(std::move(ts));
+        } catch (...) {
+            delete h;
+            throw;
+        }
+        out = h;
+    });
+    return out;
+}
+void oracle_tt_release(void* h) { delete static_cast<OracleTT*>(h); }
+uint64_t oracle_tt_len(void* h) { return static_cast<OracleTT*>(h)->tt.len(); }
+
+int oracle_tt_dims(void* h, uint64_t* dims3)
+{
+    return guarded([&] {
+        auto& tt = static_cast<OracleTT*>(h)->tt;
+        for (size_t s = 0; s < tt.len(); ++s) {
+            dims3[3 * s] = tt.tensors[s].l;
+            dims3[3 * s + 1] = tt.tensors[s].s;
+            dims3[3 * s + 2] = tt.tensors[s].r;
+        }
+    });
+}
+int oracle_tt_site_tensor(void* h, uint64_t site, double* out)
+{
+    return guarded([&] {
+        auto& tt = static_cast<OracleTT*>(h)->tt;
+        if (site >= tt.len()) throw OracleError(ERR_INVALID_ARGUMENT, "site out of range");
+        const auto& t = tt.tensors[site];
+        if (!t.d.empty()) std::memcpy(out, t.d.data(), t.d.size() * sizeof(double));
+    });
+}
+int oracle_tt_evaluate(void* h, const uint64_t* idx /* n_sites x n_pts col-major */, uint64_t n_pts, double* out)
+{
+    return guarded([&] {
+        auto& tt = static_cast<OracleTT*>(h)->tt;
+        const size_t n = tt.len();
+        MultiIndex mi(n);
+        for (size_t p = 0; p < n_pts; ++p) {
+            for (size_t s = 0; s < n; ++s) mi[s] = idx[s + n * p];
+            out[p] = tt.evaluate(mi);
+        }
+    });
+}
+int oracle_tt_sum(void* h, double* out)
+{
+    return guarded([&] { *out = static_cast<OracleTT*>(h)->tt.sum(); });
+}
+int oracle_tt_norm2(void* h, double* out)
+{
+    return guarded([&] { *out = tt_norm2(static_cast<OracleTT*>(h)->tt); });
+}
+int oracle_tt_full_tensor(void* h, double* out)
+{
+    return guarded([&] {
+        std::vector<double> v = tt_full_tensor(static_cast<OracleTT*>(h)->tt);
+        if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(double));
+    });
+}
+int oracle_tt_compress(void* h, int method, double tolerance, uint64_t max_bond_dim, int normalize_error)
+{
+    return guarded([&] {
+        if (method < 0 || method > 2) throw OracleError(ERR_INVALID_ARGUMENT, "unknown compression method");
+        CompressionOptions o;
+        o.method = (CompressionMethod)method;
+        o.tolerance = tolerance;
+        o.max_bond_dim = max_bond_dim;
+        o.normalize_error = normalize_error != 0;
+        compress(static_cast<OracleTT*>(h)->tt, o);
+    });
+}
+// TTCache::evaluate_many on a fresh cache; split == 0 -> heuristic. *used_split reports the split.
+int oracle_tt_evaluate_many(void* h, const uint64_t* idx, uint64_t n_pts, uint64_t split, double* out,
+                            uint64_t* used_split)
+{
+    return guarded([&] {
+        auto& tt = static_cast<OracleTT*>(h)->tt;
+        const size_t n = tt.len();
+        std::vector<MultiIndex> pts(n_pts, MultiIndex(n));
+        for (size_t p = 0; p < n_pts; ++p)
+            for (size_t s = 0; s < n; ++s) pts[p][s] = idx[s + n * p];
+        TTCache cache(tt);
+        if (used_split) *used_split = (split || pts.empty()) ? split : cache.find_split_heuristic(pts);
+        std::vector<double> v = cache.evaluate_many(pts, split);
+        for (size_t p = 0; p < v.size(); ++p) out[p] = v[p];
+    });
+}
+
+// tensorci2_from_tensor_train: returns the pieces of the resulting TensorCI2 through query calls.
+struct OracleConv {
+    std::unique_ptr<TensorCI2> tci;
+};
+void* oracle_tci2_from_tt(void* tt_h, double tolerance, uint64_t max_bond_dim, uint64_t max_iter)
+{
+    void* out = nullptr;
+    guarded([&] {
+        FromTensorTrainOptions o;
+        o.tolerance = tolerance;
+        o.max_bond_dim = max_bond_dim;
+        o.max_iter = max_iter;
+        auto* c = new OracleConv;
+        try {
+            c->tci.reset(new TensorCI2(tensorci2_from_tensor_train(static_cast<OracleTT*>(tt_h)->tt, o)));
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        out = c;
+    });
+    return out;
+}
+void oracle_conv_release(void* h) { delete static_cast<OracleConv*>(h); }
+int oracle_conv_index_set(void* h, int which, uint64_t site, uint64_t* count, uint64_t* width, uint64_t* out)
+{
+    return guarded([&] {
+        auto& t = *static_cast<OracleConv*>(h)->tci;
+        const auto& set = which == 0 ? t.i_set.at(site) : t.j_set.at(site);
+        const size_t w = which == 0 ? site : t.len() - site - 1;
+        *count = set.size();
+        *width = w;
+        if (out)
+            for (size_t k = 0; k < set.size(); ++k)
+                for (size_t s = 0; s < w; ++s) out[s + w * k] = set[k][s];
+    });
+}
+int oracle_conv_site_tensor(void* h, uint64_t site, uint64_t* dims3, double* out)
+{
+    return guarded([&] {
+        auto& t = *static_cast<OracleConv*>(h)->tci;
+        const auto& x = t.site_tensors.at(site);
+        dims3[0] = x.l;
+        dims3[1] = x.s;
+        dims3[2] = x.r;
+        if (out && !x.d.empty()) std::memcpy(out, x.d.data(), x.d.size() * sizeof(double));
+    });
+}
+int oracle_conv_scalars(void* h, double* max_sample_value, uint64_t* n_pivot_errors, double* pivot_errors)
+{
+    return guarded([&] {
+        auto& t = *static_cast<OracleConv*>(h)->tci;
+        *max_sample_value = t.max_sample_value;
+        *n_pivot_errors = t.pivot_errors.size();
+        if (pivot_errors)
+            for (size_t k = 0; k < t.pivot_errors.size(); ++k) pivot_errors[k] = t.pivot_errors[k];
+    });
+}
+
+} // extern "C"

@@ -11,6 +11,12 @@ struct t4a_gpu_tci2 {
     explicit t4a_gpu_tci2(const std::vector<size_t>& d) : impl(d) {}
 };
 
+struct t4a_gpu_tt {
+    t4a::TensorTrain impl;
+    t4a_gpu_tt(const std::vector<std::array<size_t, 3>>& d, const double* data) : impl(d, data) {}
+    t4a_gpu_tt(const std::vector<t4a::DevCore>& cores, hipStream_t src) : impl(cores, src) {}
+};
+
 namespace t4a {
 const std::string& last_error_ref();
 
@@ -858,6 +864,264 @@ t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out)
                 out[14] = kv.second[2];
                 out[15] = (double)kv.first;
             }
+    });
+}
+
+
+// ------------------------------------------------------------------------------------------------ svd / qr / full-piv LU
+t4a_gpu_status t4a_gpu_svd_f64(const double* a, size_t m, size_t n, double* u, double* s, double* vt)
+{
+    return guarded([&] {
+        const size_t count = checked_mul(m, n, "matrix shape");
+        if (count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD of an empty matrix");
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "svd: dimensions above 65535 are not supported");
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(u);
+        T4A_REQUIRE_PTR(s);
+        T4A_REQUIRE_PTR(vt);
+        const size_t k = std::min(m, n);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_a = e.pi(count);
+        upload(e, d_a, a, count);
+        e.d_tmp.reserve(m * k + k + k * n);
+        double* d_u = e.d_tmp.get();
+        double* d_s = d_u + m * k;
+        double* d_vt = d_s + k;
+        e.svd(d_a, (int)m, (int)n, d_u, d_s, d_vt);
+        download(e, u, d_u, m * k);
+        download(e, s, d_s, k);
+        download(e, vt, d_vt, k * n);
+    });
+}
+
+t4a_gpu_status t4a_gpu_qr_f64(const double* a, size_t m, size_t n, double* q, double* r)
+{
+    return guarded([&] {
+        const size_t count = checked_mul(m, n, "matrix shape");
+        if (count == 0) return;
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "qr: dimensions above 65535 are not supported");
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(q);
+        T4A_REQUIRE_PTR(r);
+        const size_t k = std::min(m, n);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_a = e.pi(count);
+        upload(e, d_a, a, count);
+        e.d_tmp.reserve(m * k + k * n);
+        double* d_q = e.d_tmp.get();
+        double* d_r = d_q + m * k;
+        e.qr(d_a, (int)m, (int)n, d_q, d_r);
+        download(e, q, d_q, m * k);
+        download(e, r, d_r, k * n);
+    });
+}
+
+t4a_gpu_status t4a_gpu_full_piv_lu_f64(const double* a, size_t n, double* p, double* l, double* u, double* q)
+{
+    return guarded([&] {
+        const size_t count = checked_mul(n, n, "matrix shape");
+        if (count == 0) return;
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(p);
+        T4A_REQUIRE_PTR(l);
+        T4A_REQUIRE_PTR(u);
+        T4A_REQUIRE_PTR(q);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_a = e.pi(count);
+        upload(e, d_a, a, count);
+        RrLUOptions o;
+        o.rel_tol = 0.0;
+        o.abs_tol = 0.0;
+        o.left_orthogonal = true;
+        LuciResult r = e.luci(d_a, (int)n, (int)n, o, false, true);
+        // square factors: L = [lower trapezoid of the first rank columns | identity columns], U = [first rank rows ; 0]
+        e.d_tmp.reserve(2 * count);
+        double* d_l = e.d_tmp.get();
+        double* d_u = d_l + count;
+        hipStream_t st = e.stream();
+        set_identity_launch(d_l, (int)n, (int)n, (int)n, st);
+        fill_launch(d_u, count, 0.0, st);
+        if (r.rank > 0) {
+            tri_extract_launch(e.lu_buf(), (int)n, (int)n, r.rank, 1, 1, d_l, (int)n, st);
+            tri_extract_launch(e.lu_buf(), (int)n, r.rank, (int)n, 0, 0, d_u, (int)n, st);
+        }
+        T4A_HIP(hipGetLastError());
+        download(e, l, d_l, count);
+        download(e, u, d_u, count);
+        std::memset(p, 0, count * sizeof(double));
+        std::memset(q, 0, count * sizeof(double));
+        for (size_t k = 0; k < n; ++k) {
+            p[k + n * (size_t)r.row_perm[k]] = 1.0;
+            q[k + n * (size_t)r.col_perm[k]] = 1.0;
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ SimpleTensorTrain
+extern "C++" {
+static std::vector<uint32_t> narrow_indices(const size_t* idx, size_t count)
+{
+    std::vector<uint32_t> u(count);
+    for (size_t k = 0; k < count; ++k) {
+        if (idx[k] > 0xFFFFFFFFull) throw Error(T4A_GPU_INVALID_ARGUMENT, "index out of bounds");
+        u[k] = (uint32_t)idx[k];
+    }
+    return u;
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_tt_new(const size_t* dims3, size_t n_sites, const double* cores, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        if (n_sites) T4A_REQUIRE_PTR(dims3);
+        require_device();
+        std::vector<std::array<size_t, 3>> d(n_sites);
+        for (size_t s = 0; s < n_sites; ++s) {
+            d[s] = {dims3[3 * s], dims3[3 * s + 1], dims3[3 * s + 2]};
+            checked_mul(checked_mul(d[s][0], d[s][1], "tensor shape"), d[s][2], "tensor shape");
+        }
+        *out = new t4a_gpu_tt(d, cores);
+    });
+}
+
+void t4a_gpu_tt_release(t4a_gpu_tt* h) { delete h; }
+
+t4a_gpu_status t4a_gpu_tt_clone(const t4a_gpu_tt* h, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = new t4a_gpu_tt(h->impl.cores, h->impl.eng.stream());
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_len(const t4a_gpu_tt* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.len();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_dims(const t4a_gpu_tt* h, size_t* dims3)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (h->impl.len()) T4A_REQUIRE_PTR(dims3);
+        for (size_t s = 0; s < h->impl.len(); ++s) {
+            dims3[3 * s] = h->impl.cores[s].l;
+            dims3[3 * s + 1] = h->impl.cores[s].s;
+            dims3[3 * s + 2] = h->impl.cores[s].r;
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_site_tensor(const t4a_gpu_tt* h, size_t site, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        std::vector<double> v = const_cast<t4a_gpu_tt*>(h)->impl.site_tensor_host(site);
+        if (!v.empty()) {
+            T4A_REQUIRE_PTR(out);
+            std::memcpy(out, v.data(), v.size() * sizeof(double));
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_evaluate(t4a_gpu_tt* h, const size_t* idx, size_t n_pts, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pts == 0) return;
+        T4A_REQUIRE_PTR(idx);
+        T4A_REQUIRE_PTR(out);
+        std::vector<uint32_t> u = narrow_indices(idx, checked_mul(n_pts, h->impl.len(), "index buffer"));
+        std::vector<double> v = h->impl.evaluate(u.data(), n_pts);
+        std::memcpy(out, v.data(), n_pts * sizeof(double));
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_sum(t4a_gpu_tt* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.sum();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_norm2(t4a_gpu_tt* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.norm2();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_compress(t4a_gpu_tt* h, int32_t method, double tolerance, size_t max_bond_dim,
+                                   int32_t normalize_error)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (method < 0 || method > 2) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown compression method");
+        CompressionOptions o;
+        o.method = (CompressionMethod)method;
+        o.tolerance = tolerance;
+        o.max_bond_dim = max_bond_dim;
+        o.normalize_error = normalize_error != 0;
+        h->impl.compress(o);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_evaluate_many(t4a_gpu_tt* h, const size_t* idx, size_t n_pts, size_t split, double* out,
+                                        size_t* used_split)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (used_split) *used_split = split;
+        if (n_pts == 0) return; // cache.rs:563-565
+        T4A_REQUIRE_PTR(idx);
+        T4A_REQUIRE_PTR(out);
+        std::vector<uint32_t> u = narrow_indices(idx, checked_mul(n_pts, h->impl.len(), "index buffer"));
+        const size_t s = h->impl.evaluate_many(u.data(), n_pts, split, out);
+        if (used_split) *used_split = s;
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_to_tensor_train(t4a_gpu_tci2* h, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        h->impl.fill_wait();
+        *out = new t4a_gpu_tt(h->impl.cores, h->impl.eng.stream());
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_from_tensor_train(const t4a_gpu_tt* tt, double tolerance, size_t max_bond_dim,
+                                              size_t max_iter, t4a_gpu_tci2** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(tt);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        if (tt->impl.len() < 2)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "TensorCI2 conversion requires at least 2 tensor-train sites");
+        FromTensorTrainOptions o;
+        o.tolerance = tolerance;
+        o.max_bond_dim = max_bond_dim;
+        o.max_iter = max_iter;
+        std::unique_ptr<t4a_gpu_tci2> h(new t4a_gpu_tci2(tt->impl.site_dims()));
+        h->impl.assign_from_tensor_train(tt->impl, o);
+        *out = h.release();
     });
 }
 

@@ -423,3 +423,96 @@ void Engine::build_factors(const LuciResult& r, bool left_orth)
 }
 
 } // namespace t4a
+
+// ------------------------------------------------------------------------------------------------
+// lu.left(true) / lu.right(true), SVD, QR
+// ------------------------------------------------------------------------------------------------
+namespace t4a {
+
+void Engine::lu_permuted_factors(const LuciResult& r, bool left_orth)
+{
+    const int M = r.M, N = r.N, rk = r.rank;
+    d_left_.reserve((size_t)M * (rk > 0 ? rk : 1));
+    d_right_.reserve((size_t)N * (rk > 0 ? rk : 1));
+    if (rk == 0 || M == 0 || N == 0) return;
+    const double* lu = d_lu_.get();
+    d_w1_.reserve((size_t)(M > N ? M : N) * rk + (size_t)rk * rk);
+    double* L = d_w1_.get();
+    // L: lower trapezoid of the first rk columns (unit diagonal when left-orthogonal), rows back in original order
+    tri_extract_launch(lu, M, M, rk, 1, left_orth ? 1 : 0, L, M, stream_);
+    scatter_rows_launch(L, M, d_rowperm_ptr_, M, rk, d_left_.get(), M, stream_);
+    d_w2_.reserve((size_t)(M > N ? M : N) * rk + (size_t)rk * rk);
+    double* U = d_w2_.get();
+    tri_extract_launch(lu, M, rk, N, 0, left_orth ? 0 : 1, U, rk, stream_);
+    scatter_cols_launch(U, rk, rk, d_colperm_ptr_, N, d_right_.get(), rk, stream_);
+    T4A_HIP(hipGetLastError());
+}
+
+void Engine::svd(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt)
+{
+    if (M <= 0 || N <= 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "svd: empty matrix");
+    const bool flip = M < N;
+    const int m = flip ? N : M, n = flip ? M : N;
+    d_sw_.reserve((size_t)m * n);
+    d_sv_.reserve((size_t)n * n);
+    d_su_.reserve((size_t)m * n);
+    d_svs_.reserve((size_t)n * n);
+    d_ssig_.reserve((size_t)n + m);
+    d_sflags_.reserve((size_t)n + 4);
+    int* flags = d_sflags_.get(); // [0] rotated [1] n_dead [2] non-finite, [4..] dead[n]
+    T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int) * ((size_t)n + 4), stream_));
+    nonfinite_flag_launch(d_a, (size_t)M * N, flags + 2, stream_);
+    double* W = d_sw_.get();
+    if (flip)
+        transpose_launch(d_a, M, N, M, W, N, stream_);
+    else
+        T4A_HIP(hipMemcpyAsync(W, d_a, sizeof(double) * (size_t)M * N, hipMemcpyDeviceToDevice, stream_));
+    double* V = d_sv_.get();
+    fill_launch(V, (size_t)n * n, 0.0, stream_);
+    set_identity_launch(V, n, n, n, stream_);
+    const int max_sweeps = 60;
+    int h[4] = {0, 0, 0, 0};
+    if (jacobi_fits_small(m, n)) {
+        jacobi_small_launch(W, m, V, n, max_sweeps, stream_);
+    } else {
+        for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+            T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int), stream_));
+            jacobi_sweep_launch(W, m, V, n, flags, stream_);
+            T4A_HIP(hipMemcpyAsync(h, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
+            T4A_HIP(hipStreamSynchronize(stream_));
+            if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
+            if (!h[0]) break;
+        }
+    }
+    // the taller factor (m x n) and the square one (n x n): write straight to the outputs where no transpose is needed
+    double* Ubig = flip ? d_su_.get() : d_u;   // m x n
+    double* Vsq = flip ? d_u : d_svs_.get();   // n x n
+    svd_finalize_launch(W, m, V, n, d_ssig_.get(), Ubig, d_s, Vsq, flags + 4, flags + 1, stream_);
+    T4A_HIP(hipMemcpyAsync(h, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
+    T4A_HIP(hipStreamSynchronize(stream_));
+    if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
+    if (h[1] > 0) svd_complete_launch(Ubig, m, n, flags + 4, d_ssig_.get() + n, stream_);
+    if (flip)
+        transpose_launch(Ubig, m, n, m, d_vt, n, stream_); // Vt (M x N) = U'^T, U' is N x M
+    else
+        transpose_launch(Vsq, n, n, n, d_vt, n, stream_);  // Vt (N x N) = V^T
+    T4A_HIP(hipGetLastError());
+}
+
+void Engine::qr(const double* d_a, int M, int N, double* d_q, double* d_r)
+{
+    const int k = M < N ? M : N;
+    if (k <= 0) return;
+    d_sw_.reserve((size_t)M * N);
+    d_ssig_.reserve((size_t)3 * k);
+    double* W = d_sw_.get();
+    T4A_HIP(hipMemcpyAsync(W, d_a, sizeof(double) * (size_t)M * N, hipMemcpyDeviceToDevice, stream_));
+    double* diag = d_ssig_.get();
+    double* tau = diag + k;
+    double* v0s = tau + k;
+    qr_factor_launch(W, M, N, diag, tau, v0s, stream_);
+    qr_form_launch(W, M, N, diag, tau, v0s, d_q, d_r, stream_);
+    T4A_HIP(hipGetLastError());
+}
+
+} // namespace t4a

@@ -55,10 +55,25 @@ public:
     double* lu_buf() { return d_lu_.get(); }
     double* left() { return d_left_.get(); }
     double* right() { return d_right_.get(); }
+    void reserve_factors(size_t left_count, size_t right_count)
+    {
+        d_left_.reserve(left_count > 0 ? left_count : 1);
+        d_right_.reserve(right_count > 0 ? right_count : 1);
+    }
 
     // Runs rrLU on the M x N column-major matrix at d_a (device) and optionally builds the LUCI factors.
     // `want_lu_copy` additionally keeps the factored matrix (permuted coordinates) in lu_buf().
     LuciResult luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy);
+
+    // RrLU::left(true) / RrLU::right(true) (matrixlu.rs:263-326) of the factorisation kept by the last
+    // luci(..., want_lu_copy = true): left() is M x rank, right() is rank x N afterwards.
+    void lu_permuted_factors(const LuciResult& r, bool left_orth);
+
+    // thin SVD (svd_backend, tensorbackend/src/backend.rs:709): d_u M x k, d_s k, d_vt k x N with k = min(M, N);
+    // one-sided Jacobi.  Throws INVALID_ARGUMENT for non-finite input.
+    void svd(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt);
+    // thin QR (qr_backend, backend.rs:742): d_q M x k, d_r k x N; Householder.
+    void qr(const double* d_a, int M, int N, double* d_q, double* d_r);
 
     Profile prof;
     // rrLU launch statistics per kernel instantiation: code -> {ms, launches, algorithmic bytes}
@@ -84,6 +99,9 @@ private:
     DevBuf<TrsmProblem> d_trsm_;
     PinBuf<TrsmProblem> h_trsm_;
     EventTimer ev_rrlu_, ev_fac_;
+    // SVD / QR workspaces
+    DevBuf<double> d_sw_, d_sv_, d_su_, d_svs_, d_ssig_;
+    DevBuf<int> d_sflags_;
 };
 
 // triangle extraction helper kernels (engine.hip)

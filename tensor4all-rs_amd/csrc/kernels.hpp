@@ -162,4 +162,37 @@ struct TtCoreDesc { const double* data; int l, d, r; };
 void tt_evaluate_launch(const TtCoreDesc* d_cores, int n_sites, int max_bond, const uint32_t* d_idx, int n_pts,
                         double* d_out, hipStream_t stream);
 
+
+// ------------------------------------------------------------------------------------------------
+// kernels_tt.hip — tensor-train reshapes, sum / norm2, TTCache environments
+// ------------------------------------------------------------------------------------------------
+// mode 0: core -> left matrix (row l*S+s)   1: left matrix -> core   2: core -> right matrix (col s*R+r)   3: back
+void core_reshape_launch(const double* in, int L, int S, int R, int mode, double* out, hipStream_t stream);
+void tt_sum_launch(const TtCoreDesc* d_cores, int n_sites, int max_bond, double* d_out, hipStream_t stream);
+void tt_norm2_step_launch(const TtCoreDesc& core, const double* d_cur, bool first, double* d_nxt, hipStream_t stream);
+void tt_env_left_launch(const TtCoreDesc* d_cores, int split, int max_bond, const uint32_t* d_idx, int n_items,
+                        double* d_out, int ld, hipStream_t stream);
+void tt_env_right_launch(const TtCoreDesc* d_cores, int n_sites, int split, int max_bond, const uint32_t* d_idx,
+                         int n_items, double* d_out, int ld, hipStream_t stream);
+void tt_env_dot_launch(const double* d_left, const double* d_right, int len, int ld, const uint32_t* d_il,
+                       const uint32_t* d_ir, size_t n_pts, double* d_out, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// kernels_linalg.hip — one-sided Jacobi SVD and Householder QR building blocks
+// ------------------------------------------------------------------------------------------------
+void nonfinite_flag_launch(const double* data, size_t count, int* d_flag, hipStream_t stream);
+bool jacobi_fits_small(int m, int n);
+// all sweeps inside one workgroup (m >= n, n <= 128)
+void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream);
+// one full sweep = n-1 tournament rounds, one launch per round; *d_rotated is set when any pair rotated
+void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream);
+// sigma = column norms, sorted non-increasing; U = W / sigma, Vs = V gathered; dead[j] = 1 for sigma == 0
+void svd_finalize_launch(const double* W, int m, const double* V, int n, double* sig_tmp, double* U, double* S,
+                         double* Vs, int* d_dead, int* d_ndead, hipStream_t stream);
+void svd_complete_launch(double* U, int m, int n, int* d_dead, double* tmp_m, hipStream_t stream);
+// Householder QR in place: reflectors stay below the diagonal of A, R's diagonal goes to diag[]
+void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double* v0s, hipStream_t stream);
+void qr_form_launch(const double* A, int m, int n, const double* diag, const double* tau, const double* v0s, double* Q,
+                    double* R, hipStream_t stream);
+
 } // namespace t4a

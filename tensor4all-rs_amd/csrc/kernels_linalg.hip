@@ -1,0 +1,410 @@
+// kernels_linalg.hip — thin SVD and thin QR for gfx950:
+//   svd_backend (tensor4all-tensorbackend/src/backend.rs:709-731)  -> one-sided Jacobi (Hestenes), round-robin
+//                                                                     pair ordering, one workgroup per column pair
+//   qr_backend  (tensor4all-tensorbackend/src/backend.rs:742-760)  -> Householder, one workgroup per trailing column
+// The reference forwards both to tenferro-rs (faer); values are tolerance-level there (reconstruction 1e-10,
+// backend/tests/mod.rs:58-110), so the contract here is: singular values non-increasing, U/V orthonormal,
+// U diag(S) Vt == A and Q R == A to rounding.
+#include "kernels.hpp"
+
+namespace t4a {
+
+namespace {
+
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return __shfl(v, 0, 64);
+}
+
+// Sum over the whole workgroup, identical on every thread.  `red` holds one slot per wave.
+__device__ inline double block_sum(double v, double* red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[w];
+    __syncthreads();
+    return t;
+}
+
+// circle-method tournament: pair `k` of round `r` among np (even) players
+__device__ inline void rr_pair(int np, int r, int k, int* a, int* b)
+{
+    const int q = np - 1;
+    int x, y;
+    if (k == 0) {
+        x = q;
+        y = r % q;
+    } else {
+        x = (r + k) % q;
+        y = (r - k + q) % q;
+    }
+    *a = x < y ? x : y;
+    *b = x < y ? y : x;
+}
+
+struct Rot {
+    double c, s;
+    int apply;
+};
+__device__ inline Rot jacobi_rotation(double alpha, double beta, double gamma)
+{
+    Rot r;
+    r.c = 1.0;
+    r.s = 0.0;
+    r.apply = 0;
+    const double eps = 2.220446049250313e-16;
+    if (gamma == 0.0 || !(fabs(gamma) > eps * sqrt(alpha * beta))) return r;
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    r.c = 1.0 / sqrt(1.0 + t * t);
+    r.s = r.c * t;
+    r.apply = 1;
+    return r;
+}
+
+// One tournament round, one workgroup per pair (large problems).
+__global__ void __launch_bounds__(256) jacobi_round_kernel(double* W, int m, double* V, int n, int np, int round,
+                                                           int* rotated)
+{
+    __shared__ double red[4];
+    int i, j;
+    rr_pair(np, round, blockIdx.x, &i, &j);
+    if (j >= n) return;
+    double* wi = W + (size_t)m * i;
+    double* wj = W + (size_t)m * j;
+    double a = 0.0, b = 0.0, g = 0.0;
+    for (int r = threadIdx.x; r < m; r += blockDim.x) {
+        const double x = wi[r], y = wj[r];
+        a += x * x;
+        b += y * y;
+        g += x * y;
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    g = block_sum(g, red);
+    const Rot rot = jacobi_rotation(a, b, g);
+    if (!rot.apply) return;
+    if (threadIdx.x == 0) *rotated = 1;
+    for (int r = threadIdx.x; r < m; r += blockDim.x) {
+        const double x = wi[r], y = wj[r];
+        wi[r] = rot.c * x - rot.s * y;
+        wj[r] = rot.s * x + rot.c * y;
+    }
+    double* vi = V + (size_t)n * i;
+    double* vj = V + (size_t)n * j;
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        const double x = vi[r], y = vj[r];
+        vi[r] = rot.c * x - rot.s * y;
+        vj[r] = rot.s * x + rot.c * y;
+    }
+}
+
+// Whole Jacobi iteration inside one workgroup (small problems): one wave per pair, all sweeps in-kernel,
+// W and V staged through LDS when they fit.
+__global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, int m, double* Vg, int n, int np,
+                                                            int max_sweeps, int use_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int s_rot;
+    double* W = Wg;
+    double* V = Vg;
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (use_lds) {
+        W = (double*)smem_raw;
+        V = W + (size_t)m * n;
+        for (int e = tid; e < m * n; e += T) W[e] = Wg[e];
+        for (int e = tid; e < n * n; e += T) V[e] = Vg[e];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < np - 1; ++round) {
+            for (int k = wave; k < np / 2; k += nw) {
+                int i, j;
+                rr_pair(np, round, k, &i, &j);
+                if (j >= n) continue;
+                double* wi = W + (size_t)m * i;
+                double* wj = W + (size_t)m * j;
+                double a = 0.0, b = 0.0, g = 0.0;
+                for (int r = lane; r < m; r += 64) {
+                    const double x = wi[r], y = wj[r];
+                    a += x * x;
+                    b += y * y;
+                    g += x * y;
+                }
+                a = wave_sum(a);
+                b = wave_sum(b);
+                g = wave_sum(g);
+                const Rot rot = jacobi_rotation(a, b, g);
+                if (!rot.apply) continue;
+                if (lane == 0) s_rot = 1;
+                for (int r = lane; r < m; r += 64) {
+                    const double x = wi[r], y = wj[r];
+                    wi[r] = rot.c * x - rot.s * y;
+                    wj[r] = rot.s * x + rot.c * y;
+                }
+                double* vi = V + (size_t)n * i;
+                double* vj = V + (size_t)n * j;
+                for (int r = lane; r < n; r += 64) {
+                    const double x = vi[r], y = vj[r];
+                    vi[r] = rot.c * x - rot.s * y;
+                    vj[r] = rot.s * x + rot.c * y;
+                }
+            }
+            __syncthreads();
+        }
+        const int any = s_rot;
+        __syncthreads();
+        if (!any) break;
+    }
+    if (use_lds) {
+        for (int e = tid; e < m * n; e += T) Wg[e] = W[e];
+        for (int e = tid; e < n * n; e += T) Vg[e] = V[e];
+    }
+}
+
+__global__ void __launch_bounds__(256) col_norms_kernel(const double* __restrict__ W, int m, int n, double* sig)
+{
+    __shared__ double red[4];
+    const int j = blockIdx.x;
+    const double* w = W + (size_t)m * j;
+    double a = 0.0;
+    for (int r = threadIdx.x; r < m; r += blockDim.x) a += w[r] * w[r];
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) sig[j] = sqrt(a);
+}
+
+// Sort by (sigma descending, index ascending) with a counting rank, normalise U, gather V.
+__global__ void __launch_bounds__(256) svd_sort_scatter_kernel(const double* __restrict__ W, int m, const double* V,
+                                                               int n, const double* __restrict__ sig, double* U,
+                                                               double* S, double* Vs, int* dead, int* n_dead)
+{
+    __shared__ double red[4];
+    const int j = blockIdx.x;
+    const double sj = sig[j];
+    double cnt = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double si = sig[i];
+        if (si > sj || (si == sj && i < j)) cnt += 1.0;
+    }
+    const int rank = (int)block_sum(cnt, red);
+    if (threadIdx.x == 0) {
+        S[rank] = sj;
+        dead[rank] = sj > 0.0 ? 0 : 1;
+        if (!(sj > 0.0)) atomicAdd(n_dead, 1);
+    }
+    const double* w = W + (size_t)m * j;
+    double* u = U + (size_t)m * rank;
+    for (int r = threadIdx.x; r < m; r += blockDim.x) u[r] = sj > 0.0 ? w[r] / sj : 0.0;
+    const double* v = V + (size_t)n * j;
+    double* vs = Vs + (size_t)n * rank;
+    for (int r = threadIdx.x; r < n; r += blockDim.x) vs[r] = v[r];
+}
+
+// Replace the dead (sigma == 0) columns of U by unit vectors orthogonal to all live ones (rare path).
+__global__ void __launch_bounds__(256) svd_complete_kernel(double* U, int m, int n, int* dead, double* tmp)
+{
+    __shared__ double red[4];
+    __shared__ int s_best;
+    __shared__ double sb[256];
+    __shared__ int si[256];
+    for (int j = 0; j < n; ++j) {
+        if (!dead[j]) continue;
+        // row with the largest residual 1 - sum_k u(i,k)^2 (first maximum)
+        double best = -2.0;
+        int besti = m;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k)
+                if (!dead[k]) s += U[i + (size_t)m * k] * U[i + (size_t)m * k];
+            const double res = 1.0 - s;
+            if (res > best) {
+                best = res;
+                besti = i;
+            }
+        }
+        // serial combine through LDS (small, rare)
+        sb[threadIdx.x] = best;
+        si[threadIdx.x] = besti;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double bb = -2.0;
+            int bi = 0;
+            for (int t = 0; t < (int)blockDim.x; ++t)
+                if (sb[t] > bb || (sb[t] == bb && si[t] < bi)) {
+                    bb = sb[t];
+                    bi = si[t];
+                }
+            s_best = bi;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += blockDim.x) tmp[i] = (i == s_best) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass)
+            for (int k = 0; k < n; ++k) {
+                if (dead[k]) continue;
+                double d = 0.0;
+                for (int i = threadIdx.x; i < m; i += blockDim.x) d += U[i + (size_t)m * k] * tmp[i];
+                d = block_sum(d, red);
+                for (int i = threadIdx.x; i < m; i += blockDim.x) tmp[i] -= d * U[i + (size_t)m * k];
+                __syncthreads();
+            }
+        double nn = 0.0;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) nn += tmp[i] * tmp[i];
+        nn = sqrt(block_sum(nn, red));
+        for (int i = threadIdx.x; i < m; i += blockDim.x) U[i + (size_t)m * j] = nn > 0.0 ? tmp[i] / nn : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) dead[j] = 0;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) nonfinite_kernel(const double* __restrict__ data, size_t count, int* flag)
+{
+    int bad = 0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+        const double v = data[e];
+        if (!(fabs(v) <= 1.79769313486231570e308)) bad = 1;
+    }
+    if (bad) *flag = 1;
+}
+
+// ------------------------------------------------------------------------------------------------ QR
+// Step j: every workgroup rebuilds the reflector of column j (read-only) and applies it to its own
+// trailing column c = j + 1 + blockIdx.x; column j itself is left untouched (its R entry goes to diag[]).
+__global__ void __launch_bounds__(256) qr_step_kernel(double* A, int m, int n, int j, double* diag, double* tau,
+                                                      double* v0s)
+{
+    __shared__ double red[4];
+    const double* x = A + (size_t)m * j;
+    double nn = 0.0;
+    for (int i = j + threadIdx.x; i < m; i += blockDim.x) nn += x[i] * x[i];
+    nn = block_sum(nn, red);
+    const double nrm = sqrt(nn);
+    const double x0 = x[j];
+    const double alpha = x0 >= 0.0 ? -nrm : nrm;
+    const double v0 = x0 - alpha;
+    // v.v = v0^2 + (||x||^2 - x0^2); recompute the tail sum directly for accuracy
+    double tail = 0.0;
+    for (int i = j + 1 + threadIdx.x; i < m; i += blockDim.x) tail += x[i] * x[i];
+    tail = block_sum(tail, red);
+    const double vv = v0 * v0 + tail;
+    const double t = (nrm == 0.0) ? 0.0 : 2.0 / vv;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        diag[j] = (nrm == 0.0) ? 0.0 : alpha;
+        tau[j] = t;
+        v0s[j] = v0;
+    }
+    const int c = j + 1 + blockIdx.x;
+    if (c >= n || t == 0.0) return;
+    double* y = A + (size_t)m * c;
+    double dot = 0.0;
+    for (int i = j + threadIdx.x; i < m; i += blockDim.x) dot += (i == j ? v0 : x[i]) * y[i];
+    dot = block_sum(dot, red);
+    const double f = t * dot;
+    for (int i = j + threadIdx.x; i < m; i += blockDim.x) y[i] -= f * (i == j ? v0 : x[i]);
+}
+
+// Q <- H_j Q on columns c = j + blockIdx.x (columns left of j are untouched unit vectors)
+__global__ void __launch_bounds__(256) qr_applyq_kernel(const double* __restrict__ A, int m, int j, const double* tau,
+                                                        const double* v0s, double* Q)
+{
+    __shared__ double red[4];
+    const double t = tau[j];
+    if (t == 0.0) return;
+    const double v0 = v0s[j];
+    const double* x = A + (size_t)m * j;
+    double* y = Q + (size_t)m * (j + blockIdx.x);
+    double dot = 0.0;
+    for (int i = j + threadIdx.x; i < m; i += blockDim.x) dot += (i == j ? v0 : x[i]) * y[i];
+    dot = block_sum(dot, red);
+    const double f = t * dot;
+    for (int i = j + threadIdx.x; i < m; i += blockDim.x) y[i] -= f * (i == j ? v0 : x[i]);
+}
+
+__global__ void __launch_bounds__(256) qr_extract_r_kernel(const double* __restrict__ A, int m, int n, int k,
+                                                           const double* diag, double* R)
+{
+    const int j = blockIdx.x;
+    for (int i = threadIdx.x; i < k; i += blockDim.x)
+        R[i + (size_t)k * j] = i < j ? A[i + (size_t)m * j] : (i == j ? diag[i] : 0.0);
+}
+
+} // namespace
+
+void nonfinite_flag_launch(const double* data, size_t count, int* d_flag, hipStream_t stream)
+{
+    if (count == 0) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, data, count, d_flag);
+}
+
+bool jacobi_fits_small(int m, int n) { return n <= 128 && m <= 2048; }
+
+void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_small_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        attr_set = true;
+    }
+    const int np = n + (n & 1);
+    const size_t bytes = ((size_t)m * n + (size_t)n * n) * 8;
+    const int use_lds = bytes <= 144 * 1024 ? 1 : 0;
+    int T = 64 * (np / 2 > 0 ? np / 2 : 1);
+    if (T > 1024) T = 1024;
+    hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(T), use_lds ? bytes : 0, stream, W, m, V, n, np, max_sweeps,
+                       use_lds);
+}
+
+void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream)
+{
+    const int np = n + (n & 1);
+    for (int round = 0; round < np - 1; ++round)
+        hipLaunchKernelGGL(jacobi_round_kernel, dim3(np / 2), dim3(256), 0, stream, W, m, V, n, np, round, d_rotated);
+}
+
+void svd_finalize_launch(const double* W, int m, const double* V, int n, double* sig_tmp, double* U, double* S,
+                         double* Vs, int* d_dead, int* d_ndead, hipStream_t stream)
+{
+    hipLaunchKernelGGL(col_norms_kernel, dim3(n), dim3(256), 0, stream, W, m, n, sig_tmp);
+    hipLaunchKernelGGL(svd_sort_scatter_kernel, dim3(n), dim3(256), 0, stream, W, m, V, n, sig_tmp, U, S, Vs, d_dead,
+                       d_ndead);
+}
+
+void svd_complete_launch(double* U, int m, int n, int* d_dead, double* tmp_m, hipStream_t stream)
+{
+    hipLaunchKernelGGL(svd_complete_kernel, dim3(1), dim3(256), 0, stream, U, m, n, d_dead, tmp_m);
+}
+
+void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double* v0s, hipStream_t stream)
+{
+    const int k = m < n ? m : n;
+    for (int j = 0; j < k; ++j) {
+        const int trailing = n - j - 1;
+        hipLaunchKernelGGL(qr_step_kernel, dim3(trailing > 0 ? trailing : 1), dim3(256), 0, stream, A, m, n, j, diag,
+                           tau, v0s);
+    }
+}
+
+void qr_form_launch(const double* A, int m, int n, const double* diag, const double* tau, const double* v0s, double* Q,
+                    double* R, hipStream_t stream)
+{
+    const int k = m < n ? m : n;
+    if (k == 0) return;
+    hipLaunchKernelGGL(qr_extract_r_kernel, dim3(n), dim3(256), 0, stream, A, m, n, k, diag, R);
+    set_identity_launch(Q, m, k, m, stream);
+    for (int j = k - 1; j >= 0; --j)
+        hipLaunchKernelGGL(qr_applyq_kernel, dim3(k - j), dim3(256), 0, stream, A, m, j, tau, v0s, Q);
+}
+
+} // namespace t4a

@@ -35,7 +35,6 @@ namespace t4a {
 namespace {
 
 constexpr unsigned NOPOS = 0xFFFFFFFFu;
-constexpr int KEY_STRIDE = 4; // u64 granules per key slot (3 used, padded to 32 bytes)
 
 __device__ __forceinline__ void st_u64_sc1(unsigned long long* p, unsigned long long v)
 {

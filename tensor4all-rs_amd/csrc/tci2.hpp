@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "tt.hpp"
 
 namespace t4a {
 
@@ -52,10 +53,10 @@ struct TCI2Options { // tensorci2.rs:73-170
     void validate() const;
 };
 
-struct DevCore {
-    DevBuf<double> buf;
-    size_t l = 0, s = 0, r = 0;
-    size_t size() const { return l * s * r; }
+struct FromTensorTrainOptions { // tensorci/src/conversion.rs:20-36
+    double tolerance = 1e-12;
+    size_t max_bond_dim = 0; // 0 == None
+    size_t max_iter = 3;
 };
 
 class Tci2 {
@@ -87,6 +88,10 @@ public:
     std::vector<double> evaluate(const uint32_t* idx, size_t n_pts); // idx n_sites x n_pts col-major
     double sum();
     std::vector<double> site_tensor_host(size_t site, size_t dims3[3]);
+
+    // TensorCI2::from_tensor_train (tensorci/src/conversion.rs:66-121): replaces the I/J sets, site tensors,
+    // pivot errors and max_sample_value of this (freshly constructed) object.  `tt` is left untouched.
+    void assign_from_tensor_train(const TensorTrain& tt, const FromTensorTrainOptions& options);
 
     // state (public like the accessors of the reference)
     size_t n_;

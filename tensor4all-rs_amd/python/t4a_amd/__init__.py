@@ -488,6 +488,26 @@ class TensorCI2:
         _check(_lib.t4a_gpu_tci2_sum(self._h, ctypes.byref(v)))
         return v.value
 
+    def to_tensor_train(self):
+        """TensorCI2::to_tensor_train — a device-resident SimpleTensorTrain."""
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tci2_to_tensor_train(self._h, ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
+    @classmethod
+    def from_tensor_train(cls, tt, tolerance=1e-12, max_bond_dim=None, max_iter=3):
+        """TensorCI2::from_tensor_train (tensorci/src/conversion.rs:66-121)."""
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tci2_from_tensor_train(tt._h, c_double(tolerance),
+                                                   c_size_t(0 if max_bond_dim is None else max_bond_dim),
+                                                   c_size_t(max_iter), ctypes.byref(h)))
+        self = cls.__new__(cls)
+        self.local_dims = [int(d) for d in tt.site_dims()]
+        self._h = h
+        self._cb_keepalive = None
+        self.n_callback_calls = 0
+        return self
+
     def last_sweep_shapes(self):
         out = np.zeros(3 * (len(self.local_dims) - 1), dtype=np.uintp)
         _check(_lib.t4a_gpu_tci2_last_sweep_shapes(self._h, _p(out)))
@@ -516,3 +536,166 @@ def crossinterpolate2(f, local_dims, initial_pivots, options):
     tci.set_function(f)
     tci.crossinterpolate2(initial_pivots, options)
     return tci
+
+
+# ---------------------------------------------------------------------------------------- svd / qr / full-piv LU
+def svd_backend(a):
+    """svd_backend (tensorbackend/src/backend.rs:709): thin (u, s, vt)."""
+    a = _f(a)
+    m, n = a.shape
+    k = min(m, n)
+    u = np.zeros((m, k), order="F")
+    s = np.zeros(k)
+    vt = np.zeros((k, n), order="F")
+    _check(_lib.t4a_gpu_svd_f64(_p(a), c_size_t(m), c_size_t(n), _p(u), _p(s), _p(vt)))
+    return u, s, vt
+
+
+def qr_backend(a):
+    """qr_backend (tensorbackend/src/backend.rs:742): thin (q, r)."""
+    a = _f(a)
+    m, n = a.shape
+    k = min(m, n)
+    q = np.zeros((m, k), order="F")
+    r = np.zeros((k, n), order="F")
+    _check(_lib.t4a_gpu_qr_f64(_p(a), c_size_t(m), c_size_t(n), _p(q), _p(r)))
+    return q, r
+
+
+def full_piv_lu_matrix(a):
+    """full_piv_lu_matrix (tensorbackend/src/backend.rs:1022): (p, l, u, q) with p @ a @ q.T == l @ u."""
+    a = _f(a)
+    n = a.shape[0]
+    if a.shape[1] != n:
+        raise T4aError(INVALID_ARGUMENT, "full_piv_lu expects a square matrix")
+    out = [np.zeros((n, n), order="F") for _ in range(4)]
+    _check(_lib.t4a_gpu_full_piv_lu_f64(_p(a), c_size_t(n), *[_p(x) for x in out]))
+    return tuple(out)
+
+
+# ---------------------------------------------------------------------------------------- SimpleTensorTrain
+COMPRESS_LU, COMPRESS_CI, COMPRESS_SVD = 0, 1, 2
+
+
+class SimpleTensorTrain:
+    """SimpleTensorTrain<f64> (simplett/src/tensortrain.rs:97) — site tensors live on the device."""
+
+    def __init__(self, cores):
+        cores = [np.asarray(c, dtype=np.float64) for c in cores]
+        for c in cores:
+            if c.ndim != 3:
+                raise T4aError(INVALID_ARGUMENT, "site tensors must have three legs (left, site, right)")
+        dims = np.array([c.shape for c in cores], dtype=np.uintp).reshape(-1)
+        flat = np.ascontiguousarray(np.concatenate([c.reshape(-1, order="F") for c in cores])
+                                    if cores else np.zeros(1))
+        self._h = c_void_p()
+        _check(_lib.t4a_gpu_tt_new(_p(dims) if len(cores) else None, c_size_t(len(cores)), _p(flat),
+                                   ctypes.byref(self._h)))
+
+    @classmethod
+    def _adopt(cls, handle):
+        self = cls.__new__(cls)
+        self._h = handle
+        return self
+
+    @classmethod
+    def constant(cls, site_dims, value):
+        """SimpleTensorTrain::constant (tensortrain.rs:166-211)."""
+        cores = [np.ones((1, int(d), 1)) for d in site_dims]
+        if cores:
+            cores[-1] = cores[-1] * value
+        return cls(cores)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.t4a_gpu_tt_release(h)
+            self._h = None
+
+    def clone(self):
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tt_clone(self._h, ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
+    def __len__(self):
+        v = c_size_t(0)
+        _check(_lib.t4a_gpu_tt_len(self._h, ctypes.byref(v)))
+        return v.value
+
+    def dims(self):
+        d = np.zeros(max(3 * len(self), 1), dtype=np.uintp)
+        _check(_lib.t4a_gpu_tt_dims(self._h, _p(d)))
+        return d[:3 * len(self)].reshape(-1, 3).astype(np.int64)
+
+    def site_dims(self):
+        return [int(x) for x in self.dims()[:, 1]]
+
+    def link_dims(self):
+        return [int(x) for x in self.dims()[1:, 0]]
+
+    def rank(self):
+        ld = self.link_dims()
+        return max(ld) if ld else 1
+
+    def site_tensor(self, site):
+        l, s, r = (int(x) for x in self.dims()[site])
+        buf = np.zeros(max(l * s * r, 1))
+        _check(_lib.t4a_gpu_tt_site_tensor(self._h, c_size_t(site), _p(buf)))
+        return buf[:l * s * r].reshape((l, s, r), order="F")
+
+    def site_tensors(self):
+        return [self.site_tensor(s) for s in range(len(self))]
+
+    def evaluate(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uintp).reshape(-1, len(self)))
+        out = np.zeros(idx.shape[0])
+        _check(_lib.t4a_gpu_tt_evaluate(self._h, _p(idx), c_size_t(idx.shape[0]), _p(out)))
+        return out
+
+    def sum(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_tt_sum(self._h, ctypes.byref(v)))
+        return v.value
+
+    def norm2(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_tt_norm2(self._h, ctypes.byref(v)))
+        return v.value
+
+    def norm(self):
+        return float(np.sqrt(self.norm2()))
+
+    def compress(self, method=COMPRESS_LU, tolerance=1e-12, max_bond_dim=None, normalize_error=True):
+        """compress(&CompressionOptions) (compression.rs:375); defaults = CompressionOptions::default()."""
+        _check(_lib.t4a_gpu_tt_compress(self._h, c_int32(method), c_double(tolerance),
+                                        c_size_t(0 if max_bond_dim is None else max_bond_dim),
+                                        c_int32(1 if normalize_error else 0)))
+
+    def compressed(self, **kw):
+        t = self.clone()
+        t.compress(**kw)
+        return t
+
+    def evaluate_many(self, idx, split=None, return_split=False):
+        """TTCache::evaluate_many (cache.rs:558)."""
+        n = len(self)
+        idx = np.asarray(idx, dtype=np.uintp)
+        if idx.size == 0:
+            return (np.zeros(0), split) if return_split else np.zeros(0)
+        if idx.ndim != 2 or idx.shape[1] != n:
+            raise T4aError(INVALID_ARGUMENT, f"index length mismatch: expected {n}")
+        idx = np.ascontiguousarray(idx)
+        out = np.zeros(idx.shape[0])
+        used = c_size_t(0)
+        if split is not None and split <= 0:
+            raise T4aError(INVALID_ARGUMENT, f"Invalid split position: {split} (n_sites={n})")
+        _check(_lib.t4a_gpu_tt_evaluate_many(self._h, _p(idx), c_size_t(idx.shape[0]),
+                                             c_size_t(0 if split is None else split), _p(out), ctypes.byref(used)))
+        return (out, used.value) if return_split else out
+
+    def full_tensor(self):
+        """full_tensor (tensortrain.rs:374): all values, leftmost site fastest."""
+        sd = self.site_dims()
+        total = int(np.prod(sd))
+        grids = np.indices(sd[::-1]).reshape(len(sd), -1)[::-1].T  # leftmost fastest
+        return self.evaluate(grids.reshape(total, len(sd)))

@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "t4a_oracle.hpp")] + [
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp",
+                                                  "t4a_oracle_tt.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -294,3 +295,174 @@ class OracleTCI2:
         v = dbl(0)
         _check(_lib.oracle_tci2_sum(vp(self._h), ctypes.byref(v)))
         return v.value
+
+
+# ------------------------------------------------------------------------------------------------
+# tensor-train side (oracle/t4a_oracle_tt.hpp)
+# ------------------------------------------------------------------------------------------------
+_lib.oracle_tt_last_error.restype = ctypes.c_char_p
+_lib.oracle_tt_new.restype = vp
+_lib.oracle_tci2_from_tt.restype = vp
+_lib.oracle_tt_len.restype = u64
+_lib.oracle_tt_len.argtypes = [vp]
+_lib.oracle_tt_release.argtypes = [vp]
+_lib.oracle_conv_release.argtypes = [vp]
+
+
+def _check_tt(st):
+    if st != 0:
+        e = OracleError.__new__(OracleError)
+        e.code = st
+        RuntimeError.__init__(e, f"[oracle status {st}] {_lib.oracle_tt_last_error().decode()}")
+        raise e
+
+
+def qr(a):
+    a = _f(a)
+    m, n = a.shape
+    k = min(m, n)
+    q = np.zeros((m, k), order="F")
+    r = np.zeros((k, n), order="F")
+    _check_tt(_lib.oracle_qr_f64(_p(a), u64(m), u64(n), _p(q), _p(r)))
+    return q, r
+
+
+def svd(a):
+    a = _f(a)
+    m, n = a.shape
+    k = min(m, n)
+    u = np.zeros((m, k), order="F")
+    s = np.zeros(k)
+    vt = np.zeros((k, n), order="F")
+    _check_tt(_lib.oracle_svd_f64(_p(a), u64(m), u64(n), _p(u), _p(s), _p(vt)))
+    return u, s, vt
+
+
+def full_piv_lu(a):
+    a = _f(a)
+    n = a.shape[0]
+    out = [np.zeros((n, n), order="F") for _ in range(4)]
+    _check_tt(_lib.oracle_full_piv_lu_f64(_p(a), u64(n), *[_p(x) for x in out]))
+    return tuple(out)  # p, l, u, q
+
+
+def _idx_cols(idx, n):
+    idx = np.asarray(idx, dtype=np.uint64).reshape(-1, n)
+    return np.ascontiguousarray(idx), idx.shape[0]  # row-major (n_pts, n) == col-major n x n_pts
+
+
+class OracleTT:
+    """SimpleTensorTrain<f64> restatement; cores are numpy arrays of shape (l, s, r)."""
+
+    def __init__(self, cores):
+        cores = [np.asarray(c, dtype=np.float64) for c in cores]
+        dims = np.array([c.shape for c in cores], dtype=np.uint64).reshape(-1)
+        flat = np.concatenate([c.reshape(-1, order="F") for c in cores]) if cores else np.zeros(0)
+        flat = np.ascontiguousarray(flat)
+        self._h = _lib.oracle_tt_new(u64(len(cores)), _p(dims), _p(flat))
+        if not self._h:
+            _check_tt(-2)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.oracle_tt_release(self._h)
+            self._h = None
+
+    def __len__(self):
+        return int(_lib.oracle_tt_len(self._h))
+
+    def dims(self):
+        d = np.zeros(3 * len(self), dtype=np.uint64)
+        _check_tt(_lib.oracle_tt_dims(vp(self._h), _p(d)))
+        return d.reshape(-1, 3).astype(int)
+
+    def link_dims(self):
+        return [int(x) for x in self.dims()[:-1, 2]]
+
+    def rank(self):
+        ld = self.link_dims()
+        return max(ld) if ld else 1
+
+    def cores(self):
+        out = []
+        for s, (l, d, r) in enumerate(self.dims()):
+            buf = np.zeros(l * d * r)
+            _check_tt(_lib.oracle_tt_site_tensor(vp(self._h), u64(s), _p(buf)))
+            out.append(buf.reshape((l, d, r), order="F"))
+        return out
+
+    def evaluate(self, idx):
+        idx, npts = _idx_cols(idx, len(self))
+        out = np.zeros(npts)
+        _check_tt(_lib.oracle_tt_evaluate(vp(self._h), _p(idx), u64(npts), _p(out)))
+        return out
+
+    def sum(self):
+        v = dbl(0)
+        _check_tt(_lib.oracle_tt_sum(vp(self._h), ctypes.byref(v)))
+        return v.value
+
+    def norm2(self):
+        v = dbl(0)
+        _check_tt(_lib.oracle_tt_norm2(vp(self._h), ctypes.byref(v)))
+        return v.value
+
+    def full_tensor(self):
+        d = self.dims()
+        out = np.zeros(int(np.prod(d[:, 1])))
+        _check_tt(_lib.oracle_tt_full_tensor(vp(self._h), _p(out)))
+        return out
+
+    def compress(self, method=0, tolerance=1e-12, max_bond_dim=None, normalize_error=True):
+        _check_tt(_lib.oracle_tt_compress(vp(self._h), cint(method), dbl(tolerance), u64(max_bond_dim or 0),
+                                          cint(int(normalize_error))))
+
+    def evaluate_many(self, idx, split=None):
+        idx, npts = _idx_cols(idx, len(self))
+        out = np.zeros(npts)
+        used = u64(0)
+        _check_tt(_lib.oracle_tt_evaluate_many(vp(self._h), _p(idx), u64(npts), u64(split or 0), _p(out),
+                                               ctypes.byref(used)))
+        return out, int(used.value)
+
+    def to_tci2(self, tolerance=1e-12, max_bond_dim=None, max_iter=3):
+        h = _lib.oracle_tci2_from_tt(vp(self._h), dbl(tolerance), u64(max_bond_dim or 0), u64(max_iter))
+        if not h:
+            _check_tt(-2)
+        try:
+            n = len(self)
+            res = {"i_set": [], "j_set": [], "cores": []}
+            for which, key in ((0, "i_set"), (1, "j_set")):
+                for site in range(n):
+                    cnt, w = u64(0), u64(0)
+                    _check_tt(_lib.oracle_conv_index_set(vp(h), cint(which), u64(site), ctypes.byref(cnt),
+                                                         ctypes.byref(w), None))
+                    buf = np.zeros(max(cnt.value * w.value, 1), dtype=np.uint64)
+                    _check_tt(_lib.oracle_conv_index_set(vp(h), cint(which), u64(site), ctypes.byref(cnt),
+                                                         ctypes.byref(w), _p(buf)))
+                    res[key].append([tuple(int(x) for x in buf[k * w.value:(k + 1) * w.value])
+                                     for k in range(cnt.value)])
+            for site in range(n):
+                d3 = np.zeros(3, dtype=np.uint64)
+                _check_tt(_lib.oracle_conv_site_tensor(vp(h), u64(site), _p(d3), None))
+                buf = np.zeros(max(int(np.prod(d3)), 1))
+                _check_tt(_lib.oracle_conv_site_tensor(vp(h), u64(site), _p(d3), _p(buf)))
+                res["cores"].append(buf[:int(np.prod(d3))].reshape(tuple(int(x) for x in d3), order="F"))
+            mx, npe = dbl(0), u64(0)
+            _check_tt(_lib.oracle_conv_scalars(vp(h), ctypes.byref(mx), ctypes.byref(npe), None))
+            pe = np.zeros(max(npe.value, 1))
+            _check_tt(_lib.oracle_conv_scalars(vp(h), ctypes.byref(mx), ctypes.byref(npe), _p(pe)))
+            res["max_sample_value"] = mx.value
+            res["pivot_errors"] = pe[:npe.value]
+            return res
+        finally:
+            _lib.oracle_conv_release(vp(h))
+
+
+def constant_tt(site_dims, value):
+    """SimpleTensorTrain::constant (tensortrain.rs:166-211)."""
+    n = len(site_dims)
+    cores = [np.ones((1, d, 1)) for d in site_dims]
+    if n:
+        cores[-1] = cores[-1] * value
+    return cores

@@ -1,0 +1,282 @@
+"""Pins the tensor-train side of the CPU oracle (oracle/t4a_oracle_tt.hpp) against the reference's own
+known-answer tests.  Data transcribed from (values only):
+  * crates/tensor4all-tensorbackend/src/backend/tests/mod.rs:58-110,338-366   (QR / SVD reconstruction, full-piv LU)
+  * crates/tensor4all-simplett/src/compression/tests/mod.rs                   (compress LU/CI/SVD, threshold rules)
+  * crates/tensor4all-simplett/src/cache/tests/mod.rs                         (TTCache::evaluate_many)
+  * crates/tensor4all-tensorci/src/conversion/tests/mod.rs                    (TensorCI2::from_tensor_train)
+CPU only.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from t4a_amd import TCI2Options
+
+RNG = np.random.default_rng(20260821)
+
+
+def tt_preserves_values():
+    """compression/tests/mod.rs:24-66"""
+    t0 = np.zeros((1, 2, 2))
+    t0[0, 0, 0], t0[0, 0, 1], t0[0, 1, 0], t0[0, 1, 1] = 1.0, 0.5, 0.0, 1.0
+    t1 = np.zeros((2, 3, 2))
+    for l in range(2):
+        for s in range(3):
+            for r in range(2):
+                t1[l, s, r] = (l + s + r) * 0.1 + 0.1
+    t2 = np.zeros((2, 2, 1))
+    t2[0, 0, 0], t2[0, 1, 0], t2[1, 0, 0], t2[1, 1, 0] = 1.0, 0.5, 0.5, 1.0
+    return [t0, t1, t2]
+
+
+def tt_rank3():
+    """compression/tests/mod.rs:68-84"""
+    t0 = np.zeros((1, 2, 3))
+    for s in range(2):
+        for r in range(3):
+            t0[0, s, r] = s + r + 1
+    t1 = np.zeros((3, 2, 1))
+    for l in range(3):
+        for s in range(2):
+            t1[l, s, 0] = l + s + 1
+    return [t0, t1]
+
+
+def tt_two_scale():
+    """compression/tests/mod.rs:210-240: bond carries exactly the singular values 1e6 and 1e-3"""
+    h = math.sqrt(0.5)
+    vec = [[h, h], [h, -h]]
+    coeff = [1.0e6, 1.0e-3]
+    t0 = np.zeros((1, 2, 2))
+    t1 = np.zeros((2, 2, 1))
+    for c in range(2):
+        for s in range(2):
+            t0[0, s, c] = coeff[c] * vec[c][s]
+            t1[c, s, 0] = vec[c][s]
+    return [t0, t1]
+
+
+def random_tt(site_dims, chi, rng=RNG):
+    n = len(site_dims)
+    bonds = [1] + [chi] * (n - 1) + [1]
+    return [rng.uniform(-1, 1, size=(bonds[i], site_dims[i], bonds[i + 1])) for i in range(n)]
+
+
+def dense(cores):
+    out = cores[0]
+    for c in cores[1:]:
+        out = np.tensordot(out, c, axes=([-1], [0]))
+    return out.reshape(out.shape[1:-1])
+
+
+# ---------------------------------------------------------------------------------------------- a14
+def test_qr_reconstructs_reference_matrix():
+    a = np.array([[1.0, 2.0], [3.0, 4.0]])  # col-major [1,3,2,4] (backend/tests/mod.rs:59-61)
+    q, r = ob.qr(a)
+    assert q.shape == (2, 2) and r.shape == (2, 2)
+    assert np.abs(q @ r - a).max() < 1e-10
+    assert abs(r[1, 0]) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (5, 3), (3, 5), (16, 8), (33, 33), (1, 4), (4, 1)])
+def test_qr_svd_properties(shape):
+    a = RNG.standard_normal(shape)
+    k = min(shape)
+    q, r = ob.qr(a)
+    assert np.abs(q @ r - a).max() < 1e-10 and np.abs(q.T @ q - np.eye(k)).max() < 1e-12
+    assert np.abs(np.tril(r, -1)).max() == 0.0
+    u, s, vt = ob.svd(a)
+    assert np.all(np.diff(s) <= 0) and np.all(s >= 0)
+    assert np.abs((u * s) @ vt - a).max() < 1e-10
+    assert np.abs(u.T @ u - np.eye(k)).max() < 1e-12 and np.abs(vt @ vt.T - np.eye(k)).max() < 1e-12
+    assert np.abs(s - np.linalg.svd(a, compute_uv=False)).max() < 1e-12 * max(1.0, s[0])
+
+
+def test_svd_rank_deficient_keeps_orthonormal_factors():
+    a = RNG.standard_normal((6, 2)) @ RNG.standard_normal((2, 5))
+    u, s, vt = ob.svd(a)
+    assert np.abs((u * s) @ vt - a).max() < 1e-10
+    assert s[2] < 1e-12 * s[0]
+    assert np.abs(u.T @ u - np.eye(5)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(5)).max() < 1e-10
+    z = np.zeros((4, 3))
+    u, s, vt = ob.svd(z)
+    assert np.all(s == 0) and np.abs(u.T @ u - np.eye(3)).max() < 1e-12
+
+
+def test_full_piv_lu_square_factors():
+    a = np.array([[0.0, 1.0], [2.0, 3.0]])  # backend/tests/mod.rs:353-366
+    p, l, u, q = ob.full_piv_lu(a)
+    for x in (p, l, u, q):
+        assert x.shape == (2, 2)
+    assert np.abs(p @ a @ q.T - l @ u).max() < 1e-12
+    a = RNG.standard_normal((7, 7))
+    p, l, u, q = ob.full_piv_lu(a)
+    assert np.abs(p @ a @ q.T - l @ u).max() < 1e-12
+    assert np.abs(np.triu(l, 1)).max() == 0 and np.abs(np.tril(u, -1)).max() == 0
+    # complete pivoting: every multiplier is bounded by 1 and |u_kk| dominates its row of U
+    assert np.abs(l).max() <= 1.0
+    assert all(abs(u[k, k]) >= np.abs(u[k, k:]).max() for k in range(7))
+
+
+# ---------------------------------------------------------------------------------------------- a15 / a16
+def test_evaluate_sum_norm2_against_dense():
+    cores = random_tt([2, 3, 2, 4], 3)
+    tt = ob.OracleTT(cores)
+    full = dense(cores)
+    assert np.abs(tt.full_tensor() - full.reshape(-1, order="F")).max() < 1e-13
+    assert abs(tt.sum() - full.sum()) < 1e-12
+    assert abs(tt.norm2() - (full ** 2).sum()) < 1e-11
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_compress_constant(method):
+    tt = ob.OracleTT(ob.constant_tt([2, 3, 2], 1.0))
+    before = tt.sum()
+    tt.compress(method=method)
+    assert abs(before - 12.0) < 1e-14 and abs(tt.sum() - before) < 1e-10
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_compress_preserves_values(method):
+    cores = tt_preserves_values()
+    tt = ob.OracleTT(cores)
+    before = tt.sum()
+    full = tt.full_tensor()
+    tt.compress(method=method)
+    assert abs(tt.sum() - before) < 1e-8
+    assert np.abs(tt.full_tensor() - full).max() < 1e-10
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_compress_with_max_bond_dim(method):
+    tt = ob.OracleTT(tt_rank3())
+    n0 = math.sqrt(tt.norm2())
+    tt.compress(method=method, max_bond_dim=2, tolerance=1e-12)
+    assert tt.rank() <= 2
+    assert abs(n0 - math.sqrt(tt.norm2())) < 0.1 * n0
+
+
+def test_normalize_error_selects_relative_or_absolute_threshold():
+    cores = tt_two_scale()
+    rel = ob.OracleTT(cores)
+    assert rel.rank() == 2
+    rel.compress(method=2, tolerance=1e-6, normalize_error=True)
+    assert rel.rank() == 1  # threshold 1e-6 * 1e6 = 1 drops the 1e-3 component
+    ab = ob.OracleTT(cores)
+    ab.compress(method=2, tolerance=1e-6, normalize_error=False)
+    assert ab.rank() == 2
+    src = ob.OracleTT(cores)
+    idx = [[l, r] for l in range(2) for r in range(2)]
+    assert np.abs(ab.evaluate(idx) - src.evaluate(idx)).max() < 1e-6
+
+
+def test_cfg1_compress_roundtrip():
+    """BASELINE config 1: d=10, d_loc=2, chi=8; compress(SVD, 1e-12) keeps all 1024 values to 1e-10."""
+    cores = random_tt([2] * 10, 8, np.random.default_rng(1))
+    tt = ob.OracleTT(cores)
+    full = tt.full_tensor()
+    for method in (2, 0, 1):
+        c = ob.OracleTT(cores)
+        c.compress(method=method, tolerance=1e-12)
+        assert c.link_dims() == [2, 4, 8, 8, 8, 8, 8, 4, 2]
+        assert np.abs(c.full_tensor() - full).max() < 1e-10 * np.abs(full).max()
+
+
+# ---------------------------------------------------------------------------------------------- a17
+def test_ttcache_evaluate_many_constant():
+    tt = ob.OracleTT(ob.constant_tt([2, 3, 2], 2.0))
+    idx = [[0, 0, 0], [0, 1, 0], [1, 2, 1], [0, 0, 1]]
+    v, split = tt.evaluate_many(idx)
+    assert split == 2  # candidates n/4=0 (skipped), n/2=1 (2+4 unique halves), 3n/4=2 (3+2): cheapest wins
+    assert v.shape == (4,) and np.abs(v - 2.0).max() < 1e-10
+
+
+def test_ttcache_evaluate_many_matches_single_bitwise():
+    cores = random_tt([2, 3, 2, 2, 3, 2], 4)
+    tt = ob.OracleTT(cores)
+    idx = np.stack([RNG.integers(0, d, size=200) for d in [2, 3, 2, 2, 3, 2]], axis=1)
+    single = tt.evaluate(idx)
+    full = dense(cores)
+    want = full[tuple(idx.T)]
+    for split in (None, 1, 3, 5, 6):
+        v, used = tt.evaluate_many(idx, split)
+        assert np.abs(v - want).max() < 1e-12
+        assert used == (split or used) and 1 <= used <= 6
+    # the left-to-right chain of evaluate() is the split == n case
+    v, _ = tt.evaluate_many(idx, 6)
+    assert np.array_equal(v, single)
+
+
+def test_ttcache_errors():
+    tt = ob.OracleTT(ob.constant_tt([2, 2], 1.0))
+    v, _ = tt.evaluate_many(np.zeros((0, 2), dtype=int))
+    assert v.size == 0
+    for bad in (10,):
+        with pytest.raises(ob.OracleError):
+            tt.evaluate_many([[0, 0], [1, 1]], bad)
+    with pytest.raises(ob.OracleError):
+        tt.evaluate([[0, 2]])
+
+
+# ---------------------------------------------------------------------------------------------- a18
+def test_from_tensor_train_constant_roundtrip():
+    tt = ob.OracleTT(ob.constant_tt([2, 3, 2], 2.5))
+    res = tt.to_tci2()
+    rt = ob.OracleTT(res["cores"])
+    assert abs(rt.evaluate([[1, 2, 1]])[0] - 2.5) < 1e-12
+    assert [len(x) for x in res["i_set"]] == [1, 1, 1] and [len(x) for x in res["j_set"]] == [1, 1, 1]
+    assert res["i_set"][0] == [()] and res["j_set"][2] == [()]
+    assert abs(res["max_sample_value"] - 2.5) < 1e-15
+
+
+def test_from_tensor_train_respects_max_bond_dim():
+    res = ob.OracleTT(ob.constant_tt([2, 2, 2], 1.0)).to_tci2(max_bond_dim=1)
+    assert all(c.shape[2] <= 1 for c in res["cores"][:-1])
+
+
+def _tci_source(f, dims, pivot, **opt):
+    o = ob.OracleTCI2(dims)
+    o.set_function(f)
+    o.crossinterpolate2([pivot], TCI2Options(nsearch=0, max_nglobal_pivot=0, **opt))
+    return o
+
+
+def test_from_tensor_train_preserves_nontrivial_tensor():
+    """conversion/tests/mod.rs:91-131: f = (i+1)(j+2) + (k+3) on 3^3"""
+    src = _tci_source(lambda i: (i[0] + 1.0) * (i[1] + 2.0) + (i[2] + 3.0), [3, 3, 3], [2, 2, 2],
+                      tolerance=1e-12, max_iter=10)
+    cores = [src.site_tensor(p) for p in range(3)]
+    tt = ob.OracleTT(cores)
+    full = tt.full_tensor()
+    res = tt.to_tci2()
+    conv = ob.OracleTT(res["cores"])
+    assert conv.link_dims() == src.link_dims()
+    assert np.abs(conv.full_tensor() - full).max() < 1e-10
+    # nesting of the produced sets: every I_{p+1} entry extends an I_p entry, every J_p entry extends a J_{p+1} entry
+    for p in range(2):
+        assert all(e[:-1] in res["i_set"][p] for e in res["i_set"][p + 1])
+        assert all(e[1:] in res["j_set"][p + 1] for e in res["j_set"][p])
+
+
+def test_from_tensor_train_lorentz_grid():
+    """conversion/tests/mod.rs:39-89 (real part of the coefficient): 1/(1+sum (i+1)^2) on 4^4, chi <= 5"""
+    src = _tci_source(lambda i: 1.0 / (1.0 + sum((x + 1.0) ** 2 for x in i)), [4] * 4, [0] * 4, tolerance=1e-12,
+                      max_iter=20, max_bond_dim=5)
+    tt = ob.OracleTT([src.site_tensor(p) for p in range(4)])
+    full = tt.full_tensor()
+    res = tt.to_tci2(tolerance=1e-12, max_bond_dim=5)
+    conv = ob.OracleTT(res["cores"])
+    assert conv.link_dims() == src.link_dims()
+    assert np.abs(conv.full_tensor() - full).max() < 1e-10
+
+
+def test_from_tensor_train_rejects_bad_options():
+    tt = ob.OracleTT(ob.constant_tt([2, 2], 1.0))
+    with pytest.raises(ob.OracleError):
+        tt.to_tci2(tolerance=-1.0)
+    with pytest.raises(ob.OracleError):
+        tt.to_tci2(max_iter=1)
+    with pytest.raises(ob.OracleError):
+        ob.OracleTT(ob.constant_tt([2], 1.0)).to_tci2()
