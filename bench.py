@@ -221,7 +221,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(kname),
+                "traffic_source": "profiles/r01_pmc_dominant_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two "
+                                  "separate passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch "
+                                  "(gfx950 FETCH_SIZE correction); null when the kernel name does not match",
                 "avg_launch_ms": rrlu_ms_avg,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "streaming model 8MN + sum_k 16(M-k-1)(N-k-1) bytes (BASELINE.md §2); the slab is register "
@@ -234,6 +237,19 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kname):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (bench.py itself cannot run under
+    rocprofv3 --pmc); only reported when the summary is for the kernel instantiation that dominated this run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dominant_kernel.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    short = kname.replace("t4a::", "")
+    return d["hbm_bytes_per_launch"] if short and short in d.get("kernel", "") else None
 
 
 def cpu_baseline(tci, spec):

@@ -82,6 +82,23 @@ t4a_gpu_status t4a_gpu_luci_f64(const double* a, size_t m, size_t n, size_t max_
                                 double abs_tol, int32_t left_orthogonal, size_t* rank, size_t* rows, size_t* cols,
                                 double* pivot_errors, double* left, double* right);
 
+/* matrix_luci_factors_from_blocks(nrows, ncols, fill_block, RrLUOptions) (core/src/matrix_luci.rs:440-456): the lazy
+ * block-rook kernel behind PivotSearchStrategy::Rook (matrixluci/block_rook.rs:71-190, factors.rs:43-113).
+ * fill_block(ctx, rows, nrows, cols, ncols, out) must write out[i + nrows*j] = A[rows[i], cols[j]]
+ * (matrixluci/source.rs:15-24); this backend only ever asks for one full column or one full row per call and
+ * never for the whole matrix.  Output buffers as for t4a_gpu_luci_f64. */
+typedef void (*t4a_gpu_fill_block_fn)(void* ctx, const size_t* rows, size_t nrows, const size_t* cols, size_t ncols,
+                                      double* out);
+t4a_gpu_status t4a_gpu_luci_blocks_f64(size_t m, size_t n, t4a_gpu_fill_block_fn fill_block, void* ctx,
+                                       size_t max_bond_dim, double rel_tol, double abs_tol, int32_t left_orthogonal,
+                                       size_t* rank, size_t* rows, size_t* cols, double* pivot_errors, double* left,
+                                       double* right);
+/* Same kernel on a dense column-major matrix that is already in memory (LazyBlockRookKernel on a dense source,
+ * matrixluci/block_rook/tests.rs:36-52). */
+t4a_gpu_status t4a_gpu_luci_rook_f64(const double* a, size_t m, size_t n, size_t max_bond_dim, double rel_tol,
+                                     double abs_tol, int32_t left_orthogonal, size_t* rank, size_t* rows, size_t* cols,
+                                     double* pivot_errors, double* left, double* right);
+
 /* mat_mul(&a,&b) (tensorbackend/src/matrix.rs:1488): c[m x n] = a[m x k] * b[k x n] */
 t4a_gpu_status t4a_gpu_gemm_f64(const double* a, const double* b, size_t m, size_t k, size_t n, double* c);
 
@@ -123,7 +140,7 @@ typedef struct t4a_gpu_tci2_options {
     double tolerance;                 /* 1e-8 */
     size_t max_iter;                  /* 20 */
     size_t max_bond_dim;              /* 0 = None */
-    int32_t pivot_search;             /* 0 = Full (only Full is implemented; 1 = Rook -> NOT_IMPLEMENTED) */
+    int32_t pivot_search;             /* 0 = Full, 1 = Rook (lazy block-rook search, tensorci2.rs:286-296) */
     int32_t normalize_error;          /* 1 */
     size_t verbosity;                 /* 0 */
     size_t max_nglobal_pivot;         /* 5 */

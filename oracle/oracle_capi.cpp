@@ -55,6 +55,7 @@ struct OracleTci {
     bool has_batched = false;
     OptimizationResult last;
     double last_seconds = 0.0;
+    int pivot_search = 0; // PivotSearchStrategy applied to every subsequent call
 };
 
 TCI2Options make_options(double tolerance, uint64_t max_iter, uint64_t max_bond_dim, int normalize_error,
@@ -285,6 +286,7 @@ int oracle_tci2_crossinterpolate2(void* h, const uint64_t* pivots, uint64_t npiv
         TCI2Options opt = make_options(tolerance, max_iter, max_bond_dim, normalize_error, max_nglobal_pivot, nsearch,
                                        sweep_strategy, ncheck_history, strictly_nested, tol_margin, has_seed, seed);
         auto t0 = std::chrono::steady_clock::now();
+        opt.pivot_search = (PivotSearchStrategy)o->pivot_search;
         o->last = crossinterpolate2(*o->tci, o->f, o->has_batched ? &o->batched : nullptr, p, opt);
         o->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     });
@@ -300,6 +302,7 @@ int oracle_tci2_optimize(void* h, double tolerance, uint64_t max_iter, uint64_t 
         TCI2Options opt = make_options(tolerance, max_iter, max_bond_dim, normalize_error, max_nglobal_pivot, nsearch,
                                        sweep_strategy, ncheck_history, strictly_nested, tol_margin, has_seed, seed);
         auto t0 = std::chrono::steady_clock::now();
+        opt.pivot_search = (PivotSearchStrategy)o->pivot_search;
         o->last = optimize(*o->tci, o->f, o->has_batched ? &o->batched : nullptr, opt, final_sweep1site != 0);
         o->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     });
@@ -312,6 +315,7 @@ int oracle_tci2_sweep2site(void* h, int forward, double tolerance, uint64_t max_
         TCI2Options opt;
         opt.tolerance = tolerance;
         opt.max_bond_dim = (size_t)max_bond_dim;
+        opt.pivot_search = (PivotSearchStrategy)o->pivot_search;
         auto t0 = std::chrono::steady_clock::now();
         o->tci->sweep2site(o->f, o->has_batched ? &o->batched : nullptr, forward != 0, opt);
         o->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -436,6 +440,48 @@ int oracle_tci2_set_index_set(void* h, int which, uint64_t site, uint64_t count,
         for (size_t k = 0; k < count; ++k)
             for (size_t s = 0; s < w; ++s) set[k][s] = data[s + w * k];
         (which == 0 ? o->tci->i_set[site] : o->tci->j_set[site]) = set;
+    });
+}
+
+int oracle_tci2_set_pivot_search(void* h, int strategy)
+{
+    return guarded([&] {
+        if (strategy < 0 || strategy > 1) throw OracleError(ERR_INVALID_ARGUMENT, "invalid pivot_search");
+        static_cast<OracleTci*>(h)->pivot_search = strategy;
+    });
+}
+
+// lazy_matrix_luci_factors_from_blocks on a dense column-major matrix (block source = gather); also reports the
+// largest block (rows x cols) the kernel asked for.
+int oracle_luci_rook_f64(const double* a, uint64_t m, uint64_t n, uint64_t max_bond_dim, double rel_tol, double abs_tol,
+                         int left_orthogonal, uint64_t* rank, uint64_t* rows, uint64_t* cols, double* pivot_errors,
+                         double* left, double* right, uint64_t* max_block)
+{
+    return guarded([&] {
+        RrLUOptions o;
+        o.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : (size_t)max_bond_dim;
+        o.rel_tol = rel_tol;
+        o.abs_tol = abs_tol;
+        o.left_orthogonal = left_orthogonal != 0;
+        size_t biggest = 0;
+        BlockFn src = [&](const std::vector<size_t>& r, const std::vector<size_t>& c, double* out) {
+            biggest = std::max(biggest, r.size() * c.size());
+            for (size_t j = 0; j < c.size(); ++j)
+                for (size_t i = 0; i < r.size(); ++i) out[i + r.size() * j] = a[r[i] + m * c[j]];
+        };
+        // the factor gathers (full pivot rows/columns) are not part of the pivot search
+        PivotSelectionCore sel = rook::factorize_lazy(m, n, src, o);
+        if (max_block) *max_block = biggest;
+        MatrixLuciFactors f = lazy_matrix_luci_factors_from_blocks(m, n, src, o);
+        (void)sel;
+        *rank = f.rank;
+        for (size_t i = 0; i < f.rank; ++i) {
+            rows[i] = f.row_indices[i];
+            cols[i] = f.col_indices[i];
+        }
+        for (size_t i = 0; i < f.pivot_errors.size(); ++i) pivot_errors[i] = f.pivot_errors[i];
+        if (!f.left.a.empty()) std::memcpy(left, f.left.a.data(), f.left.a.size() * sizeof(double));
+        if (!f.right.a.empty()) std::memcpy(right, f.right.a.data(), f.right.a.size() * sizeof(double));
     });
 }
 

@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <functional>
 #include <limits>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -462,6 +463,10 @@ inline MatrixLuciFactors matrix_luci_factors_from_matrix(const Matrix& a, const 
     return factors_from_rrlu(lu);
 }
 
+} // namespace t4a_oracle
+#include "t4a_oracle_rook.hpp" // lazy block-rook kernel (PivotSearchStrategy::Rook)
+namespace t4a_oracle {
+
 // ---------------------------------------------------------------------------------------------
 // Tensor3 / SimpleTensorTrain — tensor4all-simplett (types.rs:34-268, traits.rs:146-355)
 // Tensor3 is column-major [left, site, right].
@@ -802,16 +807,70 @@ struct TensorCI2 { // :349-368
             if (!contains(j_comb, e)) j_comb.push_back(e);
         if (i_comb.empty() || j_comb.empty()) return;
 
-        if (options.pivot_search != PivotSearchStrategy::Full)
-            throw OracleError(-7, "PivotSearchStrategy::Rook is not restated in the oracle yet");
-
-        Matrix pi = eval_pi(i_comb, j_comb, f, batched, true);
         RrLUOptions lo;
         lo.max_bond_dim = options.max_bond_dim_or_max();
         lo.rel_tol = options.tolerance;
         lo.abs_tol = 0.0;
         lo.left_orthogonal = left_orthogonal;
-        MatrixLuciFactors factors = matrix_luci_factors_from_matrix(pi, lo);
+        MatrixLuciFactors factors;
+        if (options.pivot_search == PivotSearchStrategy::Full) {
+            Matrix pi = eval_pi(i_comb, j_comb, f, batched, true);
+            factors = matrix_luci_factors_from_matrix(pi, lo);
+        } else {
+            // LazyPiEvaluator (:2035-2142): (row, col) cache, only missing entries are evaluated, the
+            // running sample maximum starts at tci.max_sample_value and is written back afterwards
+            std::map<std::pair<size_t, size_t>, double> cache;
+            double sampled_max = max_sample_value;
+            bool length_error = false;
+            BlockFn fill = [&](const std::vector<size_t>& rows, const std::vector<size_t>& cols, double* out) {
+                if (length_error) {
+                    std::fill(out, out + rows.size() * cols.size(), 0.0);
+                    return;
+                }
+                std::vector<std::array<size_t, 3>> missing;
+                std::vector<MultiIndex> missing_idx;
+                for (size_t jp = 0; jp < cols.size(); ++jp)
+                    for (size_t ip = 0; ip < rows.size(); ++ip) {
+                        const size_t oi = ip + rows.size() * jp;
+                        auto it = cache.find({rows[ip], cols[jp]});
+                        if (it != cache.end()) {
+                            out[oi] = it->second;
+                        } else {
+                            missing.push_back({oi, rows[ip], cols[jp]});
+                            missing_idx.push_back(concat(i_comb[rows[ip]], j_comb[cols[jp]]));
+                        }
+                    }
+                if (missing.empty()) return;
+                std::vector<double> vals;
+                if (batched && *batched) {
+                    vals = (*batched)(missing_idx);
+                } else {
+                    for (const auto& mi : missing_idx) vals.push_back(f(mi));
+                }
+                if (vals.size() != missing.size()) {
+                    length_error = true;
+                    for (const auto& m : missing) out[m[0]] = 0.0;
+                    return;
+                }
+                n_evals += missing.size();
+                for (size_t k = 0; k < missing.size(); ++k) {
+                    out[missing[k][0]] = vals[k];
+                    cache[{missing[k][1], missing[k][2]}] = vals[k];
+                    const double av = std::sqrt(vals[k] * vals[k]);
+                    if (av > sampled_max) sampled_max = av;
+                }
+            };
+            bool failed = false;
+            try {
+                factors = lazy_matrix_luci_factors_from_blocks(i_comb.size(), j_comb.size(), fill, lo);
+            } catch (const OracleError&) {
+                if (!length_error) throw;
+                failed = true;
+            }
+            if (length_error || failed)
+                throw OracleError(ERR_INVALID_ARGUMENT, "batch callback returned a wrong number of values");
+            max_sample_value = sampled_max;
+        }
         if (b < last_sweep_shapes.size()) last_sweep_shapes[b] = {i_comb.size(), j_comb.size(), factors.rank};
 
         const std::vector<size_t> rows = non_empty_or_first(factors.row_indices);

@@ -868,6 +868,122 @@ t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out)
 }
 
 
+// ------------------------------------------------------------------------------------------------ lazy block-rook LUCI
+extern "C++" {
+static void rook_outputs(Engine& e, const LuciResult& r, size_t m, size_t n, size_t* rank, size_t* rows, size_t* cols,
+                         double* pivot_errors, double* left, double* right)
+{
+    *rank = (size_t)r.rank;
+    for (int i = 0; i < r.rank; ++i) {
+        rows[i] = (size_t)r.row_perm[i];
+        cols[i] = (size_t)r.col_perm[i];
+    }
+    for (size_t i = 0; i < r.pivot_errors.size(); ++i) pivot_errors[i] = r.pivot_errors[i];
+    if (r.rank > 0) {
+        download(e, left, e.left(), m * (size_t)r.rank);
+        download(e, right, e.right(), n * (size_t)r.rank);
+    }
+}
+static RookWork& dense_rook_work()
+{
+    static RookWork w; // guarded by g_dense_mutex like the dense engine itself
+    return w;
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_luci_blocks_f64(size_t m, size_t n, t4a_gpu_fill_block_fn fill_block, void* ctx,
+                                       size_t max_bond_dim, double rel_tol, double abs_tol, int32_t left_orthogonal,
+                                       size_t* rank, size_t* rows, size_t* cols, double* pivot_errors, double* left,
+                                       double* right)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(rank);
+        T4A_REQUIRE_PTR(rows);
+        T4A_REQUIRE_PTR(cols);
+        T4A_REQUIRE_PTR(pivot_errors);
+        const size_t count = checked_mul(m, n, "matrix shape");
+        if (count) {
+            T4A_REQUIRE_PTR(fill_block);
+            T4A_REQUIRE_PTR(left);
+            T4A_REQUIRE_PTR(right);
+        }
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "luci: dimensions above 65535 are not supported");
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        hipStream_t st = e.stream();
+        std::vector<size_t> all_rows(m), all_cols(n);
+        for (size_t i = 0; i < m; ++i) all_rows[i] = i;
+        for (size_t j = 0; j < n; ++j) all_cols[j] = j;
+        std::vector<double> hbuf(std::max(m, n));
+        RookSource src;
+        src.M = (int)m;
+        src.N = (int)n;
+        src.column = [&](int c, double* d_out) {
+            const size_t cc = (size_t)c;
+            fill_block(ctx, all_rows.data(), m, &cc, 1, hbuf.data());
+            T4A_HIP(hipMemcpyAsync(d_out, hbuf.data(), m * sizeof(double), hipMemcpyHostToDevice, st));
+            T4A_HIP(hipStreamSynchronize(st));
+        };
+        src.row = [&](int r, double* d_out) {
+            const size_t rr = (size_t)r;
+            fill_block(ctx, &rr, 1, all_cols.data(), n, hbuf.data());
+            T4A_HIP(hipMemcpyAsync(d_out, hbuf.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+            T4A_HIP(hipStreamSynchronize(st));
+        };
+        RrLUOptions o;
+        o.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim;
+        o.rel_tol = rel_tol;
+        o.abs_tol = abs_tol;
+        o.left_orthogonal = left_orthogonal != 0;
+        LuciResult r = rook_luci(e, dense_rook_work(), src, o, nullptr, nullptr);
+        rook_outputs(e, r, m, n, rank, rows, cols, pivot_errors, left, right);
+    });
+}
+
+t4a_gpu_status t4a_gpu_luci_rook_f64(const double* a, size_t m, size_t n, size_t max_bond_dim, double rel_tol,
+                                     double abs_tol, int32_t left_orthogonal, size_t* rank, size_t* rows, size_t* cols,
+                                     double* pivot_errors, double* left, double* right)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(rank);
+        T4A_REQUIRE_PTR(rows);
+        T4A_REQUIRE_PTR(cols);
+        T4A_REQUIRE_PTR(pivot_errors);
+        const size_t count = checked_mul(m, n, "matrix shape");
+        if (count) {
+            T4A_REQUIRE_PTR(a);
+            T4A_REQUIRE_PTR(left);
+            T4A_REQUIRE_PTR(right);
+        }
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "luci: dimensions above 65535 are not supported");
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        hipStream_t st = e.stream();
+        // the dense source lives on the device: A (m x n) and its transpose (rows contiguous)
+        e.d_tmp2.reserve(2 * std::max<size_t>(count, 1));
+        double* d_a = e.d_tmp2.get();
+        double* d_at = d_a + count;
+        upload(e, d_a, a, count);
+        if (count) transpose_launch(d_a, (int)m, (int)n, (int)m, d_at, (int)n, st);
+        RookSource src;
+        src.M = (int)m;
+        src.N = (int)n;
+        src.column = [&](int c, double* d_out) {
+            T4A_HIP(hipMemcpyAsync(d_out, d_a + (size_t)c * m, m * sizeof(double), hipMemcpyDeviceToDevice, st));
+        };
+        src.row = [&](int r, double* d_out) {
+            T4A_HIP(hipMemcpyAsync(d_out, d_at + (size_t)r * n, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        };
+        RrLUOptions o;
+        o.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim;
+        o.rel_tol = rel_tol;
+        o.abs_tol = abs_tol;
+        o.left_orthogonal = left_orthogonal != 0;
+        LuciResult r = rook_luci(e, dense_rook_work(), src, o, nullptr, nullptr);
+        rook_outputs(e, r, m, n, rank, rows, cols, pivot_errors, left, right);
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ svd / qr / full-piv LU
 t4a_gpu_status t4a_gpu_svd_f64(const double* a, size_t m, size_t n, double* u, double* s, double* vt)
 {

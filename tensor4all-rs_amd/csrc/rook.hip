@@ -1,0 +1,430 @@
+// rook.hip — see rook.hpp.  The search is driven from the host (one small device-to-host read per visited
+// column / row, exactly the places where the reference's rook_pivot looks at an argmax); all arithmetic — the
+// residuals A[r,c] - A[r,J] (A[I,J]^{-1} A[I,c]), the partial-pivot LU of the pivot block, the triangular solves —
+// runs on the device in the reference's operation order (solve_matrix then mat_mul, block_rook.rs:33-42).
+#include "rook.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace t4a {
+
+namespace {
+
+__global__ void __launch_bounds__(256) rook_gather_vec_kernel(const double* __restrict__ v, const int* __restrict__ idx,
+                                                              int k, double* __restrict__ out)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) out[j] = v[idx[j]];
+}
+
+// b <- P b with the LAPACK-style pivot sequence of the LU (row j swapped with piv[j], j ascending)
+__global__ void rook_apply_swaps_kernel(const int* __restrict__ piv, int k, double* b)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int j = 0; j < k; ++j) {
+            const int p = piv[j];
+            if (p != j) {
+                const double t = b[j];
+                b[j] = b[p];
+                b[p] = t;
+            }
+        }
+}
+
+// block-wide "first strict maximum in ascending index order" (block_rook.rs:46-61); out: [0] index (as double,
+// -1 when nothing beat the initial -1), [1] max |residual|
+__device__ inline void block_argmax(double bv, int bi, double* out)
+{
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const double ov = sv[threadIdx.x + off];
+            const int oi = si[threadIdx.x + off];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = sv[0] < 0.0 ? -1.0 : (double)si[0];
+        out[1] = sv[0] < 0.0 ? 0.0 : sv[0];
+    }
+}
+
+// residual of column `a_c` over the not-selected rows: a_c[i] - sum_j A[i, J[j]] * x[j]   (mat_mul order: j ascending)
+__global__ void __launch_bounds__(256) rook_col_residual_kernel(const double* __restrict__ a_c,
+                                                                const double* __restrict__ A, int M,
+                                                                const int* __restrict__ J, int k,
+                                                                const double* __restrict__ x,
+                                                                const int* __restrict__ row_selected, double* out)
+{
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        if (row_selected[i]) continue;
+        double acc = 0.0;
+        for (int j = 0; j < k; ++j) {
+            const double prod = A[(size_t)i + (size_t)M * J[j]] * x[j];
+            acc = acc + prod;
+        }
+        const double r = k > 0 ? a_c[i] - acc : a_c[i];
+        const double v = fabs(r);
+        if (v > bv) {
+            bv = v;
+            bi = i;
+        }
+    }
+    block_argmax(bv, bi, out);
+}
+
+// residual of row `a_r` over the not-selected columns: a_r[c] - sum_j y[j] * X[j, c]
+__global__ void __launch_bounds__(256) rook_row_residual_kernel(const double* __restrict__ a_r,
+                                                                const double* __restrict__ X, int N, int k,
+                                                                const double* __restrict__ y,
+                                                                const int* __restrict__ col_selected, double* out)
+{
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        if (col_selected[c]) continue;
+        double acc = 0.0;
+        for (int j = 0; j < k; ++j) {
+            const double prod = y[j] * X[(size_t)j + (size_t)k * c];
+            acc = acc + prod;
+        }
+        const double r = k > 0 ? a_r[c] - acc : a_r[c];
+        const double v = fabs(r);
+        if (v > bv) {
+            bv = v;
+            bi = c;
+        }
+    }
+    block_argmax(bv, bi, out);
+}
+
+__global__ void rook_set_flag_kernel(int* flags, int idx) { flags[idx] = 1; }
+
+} // namespace
+
+LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLUOptions& opts, double* sampled_max,
+                     double* n_evaluated)
+{
+    const int M = src.M, N = src.N;
+    hipStream_t st = eng.stream();
+    LuciResult out;
+    out.M = M;
+    out.N = N;
+    out.row_perm.resize(M);
+    out.col_perm.resize(N);
+    const int full_rank = std::min(M, N);
+    if (full_rank == 0) { // block_rook.rs:127-134
+        for (int i = 0; i < M; ++i) out.row_perm[i] = i;
+        for (int j = 0; j < N; ++j) out.col_perm[j] = j;
+        out.rank = 0;
+        out.pivot_errors = {0.0};
+        out.last_error = 0.0;
+        out.has_factors = true;
+        eng.reserve_factors(1, 1);
+        return out;
+    }
+    const int max_bond = (int)std::min<size_t>(opts.max_bond_dim, (size_t)full_rank);
+    const int kcap = std::max(max_bond, 1);
+
+    w.A.reserve((size_t)M * N);
+    w.At.reserve((size_t)M * N);
+    w.P.reserve((size_t)kcap * kcap);
+    w.X.reserve((size_t)kcap * std::max(M, N) + (size_t)std::max(M, N) * kcap);
+    w.vec.reserve(2 * (size_t)kcap);
+    w.res.reserve(4);
+    w.I.reserve(kcap);
+    w.J.reserve(kcap);
+    w.rowsel.reserve(M);
+    w.colsel.reserve(N);
+    w.piv.reserve(kcap);
+    w.info.reserve(1);
+    w.maxbits.reserve(1);
+    w.lup.reserve(1);
+    w.trp.reserve(4);
+    T4A_HIP(hipMemsetAsync(w.rowsel.get(), 0, sizeof(int) * M, st));
+    T4A_HIP(hipMemsetAsync(w.colsel.get(), 0, sizeof(int) * N, st));
+    T4A_HIP(hipMemsetAsync(w.maxbits.get(), 0, sizeof(unsigned long long), st));
+    T4A_HIP(hipMemsetAsync(w.info.get(), 0, sizeof(int), st));
+
+    std::vector<char> col_seen(N, 0), row_seen(M, 0), row_sel(M, 0), col_sel(N, 0);
+    size_t n_rows_seen = 0, n_cols_seen = 0;
+    double evals = 0.0;
+    auto visit_col = [&](int c) {
+        if (col_seen[c]) return;
+        src.column(c, w.A.get() + (size_t)M * c);
+        absmax_launch(w.A.get() + (size_t)M * c, (size_t)M, w.maxbits.get(), st);
+        col_seen[c] = 1;
+        ++n_cols_seen;
+        evals += (double)(M - (long)n_rows_seen); // entries not already cached through a visited row
+    };
+    auto visit_row = [&](int r) {
+        if (row_seen[r]) return;
+        src.row(r, w.At.get() + (size_t)N * r);
+        absmax_launch(w.At.get() + (size_t)N * r, (size_t)N, w.maxbits.get(), st);
+        row_seen[r] = 1;
+        ++n_rows_seen;
+        evals += (double)(N - (long)n_cols_seen);
+    };
+
+    std::vector<int> sel_rows, sel_cols;
+    std::vector<double> accepted;
+    double max_error = 0.0;
+    double last_error = std::numeric_limits<double>::quiet_NaN();
+    double hres[2];
+    double* d_b = w.vec.get();
+    double* d_y = w.vec.get() + kcap;
+    TrsmProblem tp[4];
+    LuProblem lp;
+
+    auto upload_sel = [&]() {
+        const int k = (int)sel_rows.size();
+        if (k == 0) return;
+        T4A_HIP(hipMemcpyAsync(w.I.get(), sel_rows.data(), sizeof(int) * k, hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(w.J.get(), sel_cols.data(), sizeof(int) * k, hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st));
+    };
+    // gather Rw = A[I, :] (k x N, ld k) out of the row cache At (N x M, row r contiguous)
+    auto gather_rows = [&](double* dst, int k) {
+        double* tmp = w.X.get() + (size_t)kcap * std::max(M, N); // N x k
+        gather_launch(w.At.get(), N, nullptr, N, w.I.get(), k, tmp, N, st);
+        transpose_launch(tmp, N, k, N, dst, k, st);
+    };
+    auto factor_step = [&](int k) { // P = A[I,J] -> LU in place; X = P^{-1} A[I,:]
+        gather_launch(w.A.get(), M, w.I.get(), k, w.J.get(), k, w.P.get(), k, st);
+        gather_rows(w.X.get(), k);
+        lp.A = w.P.get();
+        lp.lda = k;
+        lp.n = k;
+        lp.piv = w.piv.get();
+        lp.info = w.info.get();
+        lp.B = w.X.get();
+        lp.ldb = k;
+        lp.nrhs = N;
+        lp.pmax_bits = nullptr;
+        for (int q = 0; q < 4; ++q) {
+            tp[q].T = w.P.get();
+            tp[q].ldt = k;
+            tp[q].n = k;
+            tp[q].ldb = k;
+            tp[q].skip_flag = nullptr;
+        }
+        tp[0].B = w.X.get(); // L X' = P_swap Rw
+        tp[0].nrhs = N;
+        tp[0].lower = 1;
+        tp[0].unit_diag = 1;
+        tp[1].B = w.X.get(); // U X = X'
+        tp[1].nrhs = N;
+        tp[1].lower = 0;
+        tp[1].unit_diag = 0;
+        tp[2].B = d_b;       // single right-hand side (column visits)
+        tp[2].nrhs = 1;
+        tp[2].lower = 1;
+        tp[2].unit_diag = 1;
+        tp[3].B = d_b;
+        tp[3].nrhs = 1;
+        tp[3].lower = 0;
+        tp[3].unit_diag = 0;
+        T4A_HIP(hipMemcpyAsync(w.lup.get(), &lp, sizeof(lp), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(w.trp.get(), tp, sizeof(tp), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st)); // lp / tp are pageable
+        lu_batched_launch(w.lup.get(), 1, k, st);
+        trsm_left_batched_launch(w.trp.get() + 0, 1, k, N, st);
+        trsm_left_batched_launch(w.trp.get() + 1, 1, k, N, st);
+    };
+    auto read_result = [&](int fallback) -> std::pair<int, double> {
+        int hinfo = 0;
+        T4A_HIP(hipMemcpyAsync(hres, w.res.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipMemcpyAsync(&hinfo, w.info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipStreamSynchronize(st));
+        if (hinfo != 0)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "residual pivot solve failed: singular pivot matrix in the rook search");
+        const int idx = hres[0] < 0.0 ? fallback : (int)hres[0];
+        return {idx, hres[1]};
+    };
+
+    while ((int)sel_rows.size() < max_bond) {
+        const int k = (int)sel_rows.size();
+        // remaining_indices (:63-69): ascending, selected ones skipped
+        int first_row = -1, first_col = -1, n_rem_rows = 0, n_rem_cols = 0;
+        for (int i = 0; i < M; ++i)
+            if (!row_sel[i]) {
+                if (first_row < 0) first_row = i;
+                ++n_rem_rows;
+            }
+        for (int j = 0; j < N; ++j)
+            if (!col_sel[j]) {
+                if (first_col < 0) first_col = j;
+                ++n_rem_cols;
+            }
+        if (n_rem_rows == 0 || n_rem_cols == 0) break;
+        if (k > 0) factor_step(k);
+
+        // rook_pivot (:71-118)
+        int cur_col = first_col, cur_row = first_row;
+        double pivot_abs = 0.0;
+        const int max_steps = n_rem_rows + n_rem_cols + 1;
+        for (int it = 0; it < max_steps; ++it) {
+            visit_col(cur_col);
+            const double* a_c = w.A.get() + (size_t)M * cur_col;
+            if (k > 0) {
+                hipLaunchKernelGGL(rook_gather_vec_kernel, dim3(1), dim3(256), 0, st, a_c, w.I.get(), k, d_b);
+                hipLaunchKernelGGL(rook_apply_swaps_kernel, dim3(1), dim3(64), 0, st, w.piv.get(), k, d_b);
+                trsm_left_batched_launch(w.trp.get() + 2, 1, k, 1, st);
+                trsm_left_batched_launch(w.trp.get() + 3, 1, k, 1, st);
+            }
+            hipLaunchKernelGGL(rook_col_residual_kernel, dim3(1), dim3(256), 0, st, a_c, w.A.get(), M, w.J.get(), k, d_b,
+                               w.rowsel.get(), w.res.get());
+            cur_row = read_result(first_row).first;
+
+            visit_row(cur_row);
+            const double* a_r = w.At.get() + (size_t)N * cur_row;
+            if (k > 0) hipLaunchKernelGGL(rook_gather_vec_kernel, dim3(1), dim3(256), 0, st, a_r, w.J.get(), k, d_y);
+            hipLaunchKernelGGL(rook_row_residual_kernel, dim3(1), dim3(256), 0, st, a_r, w.X.get(), N, k, d_y,
+                               w.colsel.get(), w.res.get());
+            const auto rr = read_result(first_col);
+            pivot_abs = rr.second;
+            const int next_col = rr.first;
+            if (next_col == cur_col) break;
+            cur_col = next_col; // also the answer of the fall-through branch (:108-117): same row residual again
+        }
+        T4A_HIP(hipGetLastError());
+
+        // factorize_lazy stop rules (:158-176)
+        last_error = pivot_abs;
+        if (k > 0 && (pivot_abs < opts.rel_tol * max_error || pivot_abs < opts.abs_tol)) break;
+        if (pivot_abs < 2.220446049250313e-16) break;
+        max_error = std::fmax(max_error, pivot_abs);
+        sel_rows.push_back(cur_row);
+        sel_cols.push_back(cur_col);
+        accepted.push_back(pivot_abs);
+        row_sel[cur_row] = 1;
+        col_sel[cur_col] = 1;
+        hipLaunchKernelGGL(rook_set_flag_kernel, dim3(1), dim3(1), 0, st, w.rowsel.get(), cur_row);
+        hipLaunchKernelGGL(rook_set_flag_kernel, dim3(1), dim3(1), 0, st, w.colsel.get(), cur_col);
+        visit_col(cur_col); // both are already cached: the selected row / column were the last ones visited
+        visit_row(cur_row);
+        upload_sel();
+    }
+
+    const int rank = (int)sel_rows.size();
+    if (rank >= full_rank)
+        last_error = 0.0;
+    else if (rank == max_bond && rank > 0)
+        last_error = accepted[rank - 1];
+    accepted.push_back(last_error);
+    out.rank = rank;
+    out.pivot_errors = accepted;
+    out.last_error = last_error;
+    {
+        int p = 0;
+        for (int r : sel_rows) out.row_perm[p++] = r;
+        for (int i = 0; i < M; ++i)
+            if (!row_sel[i]) out.row_perm[p++] = i;
+        p = 0;
+        for (int c : sel_cols) out.col_perm[p++] = c;
+        for (int j = 0; j < N; ++j)
+            if (!col_sel[j]) out.col_perm[p++] = j;
+    }
+
+    // CrossFactors + factors_to_public (factors.rs:58-101, matrix_luci.rs:109-135)
+    eng.reserve_factors((size_t)M * std::max(rank, 1), (size_t)std::max(rank, 1) * N);
+    if (rank > 0) {
+        const int k = rank;
+        gather_launch(w.A.get(), M, w.I.get(), k, w.J.get(), k, w.P.get(), k, st); // pivot
+        if (opts.left_orthogonal) {
+            // left = (P^T \ C^T)^T with C = A[:, J]; right = A[I, :]
+            double* Pt = w.X.get();                       // k x k
+            double* Ct = w.X.get() + (size_t)kcap * kcap; // k x M
+            transpose_launch(w.P.get(), k, k, k, Pt, k, st);
+            double* C = eng.left(); // stage C (M x k) in the output buffer, transpose, solve, transpose back
+            gather_launch(w.A.get(), M, nullptr, M, w.J.get(), k, C, M, st);
+            transpose_launch(C, M, k, M, Ct, k, st);
+            lp.A = Pt;
+            lp.lda = k;
+            lp.n = k;
+            lp.piv = w.piv.get();
+            lp.info = w.info.get();
+            lp.B = Ct;
+            lp.ldb = k;
+            lp.nrhs = M;
+            lp.pmax_bits = nullptr;
+            tp[0].T = Pt;
+            tp[0].ldt = k;
+            tp[0].n = k;
+            tp[0].B = Ct;
+            tp[0].ldb = k;
+            tp[0].nrhs = M;
+            tp[0].lower = 1;
+            tp[0].unit_diag = 1;
+            tp[0].skip_flag = nullptr;
+            tp[1] = tp[0];
+            tp[1].lower = 0;
+            tp[1].unit_diag = 0;
+            T4A_HIP(hipMemcpyAsync(w.lup.get(), &lp, sizeof(lp), hipMemcpyHostToDevice, st));
+            T4A_HIP(hipMemcpyAsync(w.trp.get(), tp, 2 * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
+            T4A_HIP(hipStreamSynchronize(st));
+            lu_batched_launch(w.lup.get(), 1, k, st);
+            trsm_left_batched_launch(w.trp.get() + 0, 1, k, M, st);
+            trsm_left_batched_launch(w.trp.get() + 1, 1, k, M, st);
+            transpose_launch(Ct, k, M, k, eng.left(), M, st);
+            gather_rows(eng.right(), k);
+        } else {
+            // left = A[:, J]; right = P \ A[I, :]
+            gather_launch(w.A.get(), M, nullptr, M, w.J.get(), k, eng.left(), M, st);
+            gather_rows(eng.right(), k);
+            lp.A = w.P.get();
+            lp.lda = k;
+            lp.n = k;
+            lp.piv = w.piv.get();
+            lp.info = w.info.get();
+            lp.B = eng.right();
+            lp.ldb = k;
+            lp.nrhs = N;
+            lp.pmax_bits = nullptr;
+            tp[0].T = w.P.get();
+            tp[0].ldt = k;
+            tp[0].n = k;
+            tp[0].B = eng.right();
+            tp[0].ldb = k;
+            tp[0].nrhs = N;
+            tp[0].lower = 1;
+            tp[0].unit_diag = 1;
+            tp[0].skip_flag = nullptr;
+            tp[1] = tp[0];
+            tp[1].lower = 0;
+            tp[1].unit_diag = 0;
+            T4A_HIP(hipMemcpyAsync(w.lup.get(), &lp, sizeof(lp), hipMemcpyHostToDevice, st));
+            T4A_HIP(hipMemcpyAsync(w.trp.get(), tp, 2 * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
+            T4A_HIP(hipStreamSynchronize(st));
+            lu_batched_launch(w.lup.get(), 1, k, st);
+            trsm_left_batched_launch(w.trp.get() + 0, 1, k, N, st);
+            trsm_left_batched_launch(w.trp.get() + 1, 1, k, N, st);
+        }
+    }
+    unsigned long long bits = 0;
+    int hinfo = 0;
+    T4A_HIP(hipMemcpyAsync(&bits, w.maxbits.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
+    T4A_HIP(hipMemcpyAsync(&hinfo, w.info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
+    T4A_HIP(hipStreamSynchronize(st));
+    T4A_HIP(hipGetLastError());
+    if (hinfo != 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "factor solve failed: singular pivot matrix");
+    double mx;
+    std::memcpy(&mx, &bits, sizeof(mx));
+    out.abs_max = mx;
+    if (sampled_max && mx > *sampled_max) *sampled_max = mx;
+    if (n_evaluated) *n_evaluated += evals;
+    out.has_factors = true;
+    return out;
+}
+
+} // namespace t4a

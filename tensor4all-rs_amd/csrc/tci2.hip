@@ -436,6 +436,62 @@ LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
     return lu;
 }
 
+// PivotSearchStrategy::Rook (tensorci2.rs:1904-1929): the candidate matrix is never materialised; the lazy
+// block-rook kernel asks for full rows / columns of Pi, which are evaluated on demand (LazyPiEvaluator, :2035-2142).
+LuciResult Tci2::rook_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o)
+{
+    require_fn();
+    const size_t M = is.count, N = js.count;
+    hipStream_t st = eng.stream();
+    RookSource src;
+    src.M = (int)M;
+    src.N = (int)N;
+    if (fn_kind_ == FnKind::Builtin) {
+        const size_t K = (size_t)fn_dev_.n_acc;
+        std::vector<uint64_t> ra, rb;
+        accumulate(is, 0, ra);
+        accumulate(js, is.width, rb);
+        d_rowacc_.reserve(ra.size() + rb.size());
+        T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ra.data(), ra.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(d_rowacc_.get() + ra.size(), rb.data(), rb.size() * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st)); // ra / rb are pageable
+        const uint64_t* d_ra = d_rowacc_.get();
+        const uint64_t* d_rb = d_rowacc_.get() + ra.size();
+        src.column = [=](int c, double* out) {
+            pi_eval_launch(fn_dev_, d_ra, (int)M, d_rb + (size_t)c * K, 1, out, (int)M, false, nullptr, st);
+        };
+        src.row = [=](int r, double* out) {
+            pi_eval_launch(fn_dev_, d_ra + (size_t)r * K, 1, d_rb, (int)N, out, 1, false, nullptr, st);
+        };
+    } else {
+        auto eval_points = [this, st, &is, &js](size_t r0, size_t nr, size_t c0, size_t nc, double* out) {
+            const size_t npts = nr * nc;
+            std::vector<uint32_t> idx(npts * n_);
+            for (size_t a = 0; a < nr; ++a)
+                for (size_t b = 0; b < nc; ++b) {
+                    uint32_t* dst = idx.data() + (a * nc + b) * n_;
+                    std::memcpy(dst, is.at(r0 + a), is.width * sizeof(uint32_t));
+                    std::memcpy(dst + is.width, js.at(c0 + b), js.width * sizeof(uint32_t));
+                }
+            std::vector<double> vals(npts);
+            const int64_t got = cb_(cb_ctx_, idx.data(), n_, npts, vals.data());
+            if (got < 0 || (size_t)got != npts)
+                throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " +
+                                                        std::to_string(npts) + " requested entries");
+            T4A_HIP(hipMemcpyAsync(out, vals.data(), npts * sizeof(double), hipMemcpyHostToDevice, st));
+            T4A_HIP(hipStreamSynchronize(st));
+        };
+        src.column = [=](int c, double* out) { eval_points(0, M, (size_t)c, 1, out); };
+        src.row = [=](int r, double* out) { eval_points((size_t)r, 1, 0, N, out); };
+    }
+    double sampled = max_sample_value;
+    LuciResult lu = rook_luci(eng, rook_work_, src, o, &sampled, &eng.prof.v[11]);
+    acc_used_ = 0;
+    max_sample_value = sampled; // tci.max_sample_value = evaluator.sampled_max() (tensorci2.rs:1926)
+    return lu;
+}
+
 void Tci2::set_core_zero(size_t site, size_t l, size_t s, size_t r)
 {
     DevCore& c = cores[site];
@@ -493,8 +549,6 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     union_extras(j_comb, extra_j);
     if (i_comb.count == 0 || j_comb.count == 0) return;
     const auto hp_t1 = std::chrono::steady_clock::now();
-    if (options.pivot_search != 0)
-        throw Error(T4A_GPU_NOT_IMPLEMENTED, "PivotSearchStrategy::Rook is not implemented in the MI355X backend yet");
 
     const bool extras_used = extra_i.count != 0 || extra_j.count != 0;
     RrLUOptions lo;
@@ -504,7 +558,8 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     lo.left_orthogonal = left_orthogonal;
     // the reference always builds the factors; they are only CONSUMED when no extras were merged
     // (tensorci2.rs:1942-1949), so the device skips the trsm/gemm otherwise.
-    LuciResult lu = luci_on_sets(i_comb, j_comb, lo, !extras_used);
+    LuciResult lu = options.pivot_search == 0 ? luci_on_sets(i_comb, j_comb, lo, !extras_used)
+                                              : rook_on_sets(i_comb, j_comb, lo);
     const auto hp_t2 = std::chrono::steady_clock::now();
     if (b < last_sweep_shapes.size()) last_sweep_shapes[b] = {i_comb.count, j_comb.count, (size_t)lu.rank};
 

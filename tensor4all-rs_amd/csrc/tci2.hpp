@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "rook.hpp"
 #include "tt.hpp"
 
 namespace t4a {
@@ -137,6 +138,8 @@ private:
         LuciResult lu;
     };
     LuciResult luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o, bool need_factors);
+    LuciResult rook_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o);
+    RookWork rook_work_;
     void update_pivots(size_t b, bool left_orthogonal, const TCI2Options& options, const IndexSet& extra_i,
                        const IndexSet& extra_j);
     void sweep1site_at_bond(size_t b, bool forward, double rel_tol, double abs_tol, size_t max_bond_dim,

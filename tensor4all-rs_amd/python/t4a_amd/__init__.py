@@ -235,6 +235,55 @@ def matrix_luci_factors_from_matrix(a, max_bond_dim=None, rel_tol=1e-14, abs_tol
                              right[: r * n].reshape((r, n), order="F").copy())
 
 
+def _luci_outputs(m, n):
+    k = min(m, n)
+    return (np.zeros(max(k, 1), dtype=np.uintp), np.zeros(max(k, 1), dtype=np.uintp), np.zeros(k + 1),
+            np.zeros(max(m * k, 1)), np.zeros(max(k * n, 1)), c_size_t(0))
+
+
+def _luci_result(m, n, rows, cols, pe, left, right, rank):
+    r = rank.value
+    return MatrixLuciFactors(rows[:r].astype(np.int64), cols[:r].astype(np.int64), pe[: r + 1].copy(), r,
+                             left[: m * r].reshape((m, r), order="F").copy(),
+                             right[: r * n].reshape((r, n), order="F").copy())
+
+
+def matrix_luci_factors_rook(a, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0, left_orthogonal=True):
+    """LazyBlockRookKernel + CrossFactors on a dense matrix (core/src/matrixluci/block_rook.rs)."""
+    a = _f(a)
+    m, n = a.shape
+    rows, cols, pe, left, right, rank = _luci_outputs(m, n)
+    _check(_lib.t4a_gpu_luci_rook_f64(_p(a), c_size_t(m), c_size_t(n),
+                                      c_size_t(0 if max_bond_dim is None else max_bond_dim), c_double(rel_tol),
+                                      c_double(abs_tol), c_int32(1 if left_orthogonal else 0), ctypes.byref(rank),
+                                      _p(rows), _p(cols), _p(pe), _p(left), _p(right)))
+    return _luci_result(m, n, rows, cols, pe, left, right, rank)
+
+
+_FILL_BLOCK_CB = ctypes.CFUNCTYPE(None, c_void_p, ctypes.POINTER(c_size_t), c_size_t, ctypes.POINTER(c_size_t), c_size_t,
+                                  ctypes.POINTER(c_double))
+
+
+def matrix_luci_factors_from_blocks(nrows, ncols, fill_block, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0,
+                                    left_orthogonal=True):
+    """matrix_luci_factors_from_blocks (core/src/matrix_luci.rs:440): ``fill_block(rows, cols)`` returns the
+    len(rows) x len(cols) block of the candidate matrix."""
+    def _cb(ctx, rows, nr, cols, nc, out):
+        r = [rows[i] for i in range(nr)]
+        c = [cols[j] for j in range(nc)]
+        blk = np.asarray(fill_block(r, c), dtype=np.float64).reshape(nr, nc)
+        flat = np.asfortranarray(blk).reshape(-1, order="F")
+        ctypes.memmove(out, flat.ctypes.data, flat.size * 8)
+
+    cb = _FILL_BLOCK_CB(_cb)
+    rows, cols, pe, left, right, rank = _luci_outputs(nrows, ncols)
+    _check(_lib.t4a_gpu_luci_blocks_f64(c_size_t(nrows), c_size_t(ncols), cb, None,
+                                        c_size_t(0 if max_bond_dim is None else max_bond_dim), c_double(rel_tol),
+                                        c_double(abs_tol), c_int32(1 if left_orthogonal else 0), ctypes.byref(rank),
+                                        _p(rows), _p(cols), _p(pe), _p(left), _p(right)))
+    return _luci_result(nrows, ncols, rows, cols, pe, left, right, rank)
+
+
 def mat_mul(a, b):
     a = _f(a)
     b = _f(b)

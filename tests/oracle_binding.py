@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp",
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp",
                                                   "t4a_oracle_tt.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
@@ -88,6 +88,26 @@ def luci(a, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0, left_orthogonal=True)
     r = int(rank.value)
     return dict(rank=r, rows=rows[:r].astype(np.int64), cols=cols[:r].astype(np.int64), pivot_errors=pe[: r + 1].copy(),
                 left=left[: m * r].reshape((m, r), order="F").copy(), right=right[: r * n].reshape((r, n), order="F").copy())
+
+
+def luci_rook(a, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0, left_orthogonal=True):
+    """lazy block-rook LUCI (matrix_luci.rs:302-326) on a dense matrix; returns a dict incl. `max_block`."""
+    a = _f(a)
+    m, n = a.shape
+    k = min(m, n)
+    rows = np.zeros(max(k, 1), dtype=np.uint64)
+    cols = np.zeros(max(k, 1), dtype=np.uint64)
+    pe = np.zeros(k + 1)
+    left = np.zeros(max(m * k, 1))
+    right = np.zeros(max(k * n, 1))
+    rank, mb = u64(0), u64(0)
+    _check(_lib.oracle_luci_rook_f64(_p(a), u64(m), u64(n), u64(0 if max_bond_dim is None else max_bond_dim),
+                                     dbl(rel_tol), dbl(abs_tol), cint(int(left_orthogonal)), ctypes.byref(rank),
+                                     _p(rows), _p(cols), _p(pe), _p(left), _p(right), ctypes.byref(mb)))
+    r = int(rank.value)
+    return dict(rank=r, row_indices=rows[:r].astype(np.int64), col_indices=cols[:r].astype(np.int64),
+                pivot_errors=pe[:r + 1].copy(), left=left[:m * r].reshape((m, r), order="F"),
+                right=right[:r * n].reshape((r, n), order="F"), max_block=int(mb.value))
 
 
 def gemm(a, b):
@@ -187,6 +207,9 @@ class OracleTCI2:
                 cint(int(o.normalize_error)), u64(o.max_nglobal_pivot), u64(o.nsearch), cint(o.sweep_strategy),
                 u64(o.ncheck_history), cint(int(o.strictly_nested)), dbl(o.tol_margin_global_search),
                 cint(0 if o.seed is None else 1), u64(0 if o.seed is None else o.seed)]
+
+    def set_pivot_search(self, strategy):
+        _check(_lib.oracle_tci2_set_pivot_search(vp(self._h), cint(strategy)))
 
     def add_global_pivots(self, pivots):
         piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), len(self.local_dims)))
