@@ -178,6 +178,8 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.poll_delay = poll_delay;
         static const int ncopy_env = std::getenv("T4A_RRLU_NCOPY") ? std::atoi(std::getenv("T4A_RRLU_NCOPY")) : 1;
         a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
+        static const int spec_env = std::getenv("T4A_RRLU_SPEC") ? std::atoi(std::getenv("T4A_RRLU_SPEC")) : 0;
+        a.spec = spec_env ? 1 : 0;
         a.spin_limit = 1u << 20;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
         rrlu_reg_launch(rplan, a, stream_);

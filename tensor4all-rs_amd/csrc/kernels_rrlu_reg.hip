@@ -442,6 +442,18 @@ rrlu_reg_kernel(RrluRegArgs p)
                     if (q == qstar) v = a[q][r];
                 colv[r] = v;
             }
+            // speculative mode: EVERY workgroup publishes its candidate column together with its key, so the winner's
+            // column is already in flight while the keys are gathered (one hand-off per pivot step instead of two)
+            if (p.spec && qstar >= 0) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (irow[r] >= 0) {
+                        const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
+                        unsigned long long* dst = p.cols + (((size_t)par * p.W + w) * (size_t)p.M + irow[r]) * 2;
+                        st_u64_sc1(dst, tagbits | (vb & 0xFFFFFFFFull));
+                        st_u64_sc1(dst + 1, tagbits | (vb >> 32));
+                    }
+            }
             T4A_RSTAMP(2);
             // one wave sweeps the shared key table until every tag matches
             if (wave == poll_wave) {
@@ -523,7 +535,7 @@ rrlu_reg_kernel(RrluRegArgs p)
             ww = s.win_i[0];
             // hop 2: only the winner's owning column group publishes the pivot column: one 16-byte store of two
             // tagged granules per row, replicated into `ncopy` copies so that at most W/ncopy readers share a line
-            if (ww == w && qstar >= 0) {
+            if (!p.spec && ww == w && qstar >= 0) {
 #pragma unroll
                 for (int r = 0; r < RPT; ++r)
                     if (irow[r] >= 0) {
@@ -581,7 +593,9 @@ rrlu_reg_kernel(RrluRegArgs p)
         // issue the pivot-column loads (issuing them before the bookkeeping measured worse: more first-sweep misses)
         const bool need_fetch = !SINGLE && !(ww == w && qstar >= 0);
         const unsigned long long* colsrc =
-            SINGLE ? nullptr : p.cols + ((size_t)((k + 1) & 1) * p.ncopy + (w % p.ncopy)) * (size_t)p.M * 2;
+            SINGLE ? nullptr
+                   : (p.spec ? p.cols + ((size_t)((k + 1) & 1) * p.W + ww) * (size_t)p.M * 2
+                             : p.cols + ((size_t)((k + 1) & 1) * p.ncopy + (w % p.ncopy)) * (size_t)p.M * 2);
         unsigned long long cg0[RPT], cg1[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
@@ -817,8 +831,8 @@ size_t rrlu_reg_keys_bytes(const RrluRegPlan& plan)
 }
 size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M)
 {
-    (void)plan;
-    return (size_t)2 * RRLU_MAX_COPIES * (size_t)M * 2 * sizeof(unsigned long long);
+    const size_t slots = (size_t)(plan.W > RRLU_MAX_COPIES ? plan.W : RRLU_MAX_COPIES); // speculative mode: one per workgroup
+    return (size_t)2 * slots * (size_t)M * 2 * sizeof(unsigned long long);
 }
 
 void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)

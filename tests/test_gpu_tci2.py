@@ -307,8 +307,10 @@ def test_errors_for_bad_state(t4a):
     with pytest.raises(t4a.T4aError):
         t4a.crossinterpolate2(lambda idx: 0.0, [2, 2], [[0, 0]], t4a.TCI2Options(**PARITY))  # zero pivots (:1550-1554)
     with pytest.raises(t4a.T4aError) as e:
-        t4a.crossinterpolate2(lambda idx: 1.0, [2, 2], [[0, 0]], t4a.TCI2Options(pivot_search=1, **PARITY))
-    assert e.value.code == t4a.NOT_IMPLEMENTED  # Rook is a declared gap, never a silent fallback
+        t4a.crossinterpolate2(lambda idx: 1.0, [2, 2], [[0, 0]], t4a.TCI2Options(pivot_search=2, **PARITY))
+    assert e.value.code == t4a.INVALID_ARGUMENT  # only Full (0) and Rook (1) exist (tensorci2.rs:286-296)
+    r = t4a.crossinterpolate2(lambda idx: 1.0, [2, 2], [[0, 0]], t4a.TCI2Options(pivot_search=1, **PARITY))
+    assert r.link_dims() == [1] and abs(r.evaluate([[1, 1]])[0] - 1.0) < 1e-12
 
 
 def test_default_global_pivot_finder_runs(t4a):
