@@ -200,7 +200,7 @@ __host__ __device__ inline size_t reg_smem_layout(int M, int N, int cols_per_wg,
 // UNI: every wave lies inside one column group (TR % 64 == 0), so the column state is wave-uniform and the
 // per-column tests become scalar branches.
 template <int RPT, int CPT, bool SINGLE, bool UNI>
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, (RPT * CPT >= 24) ? 256 : 512)))
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, (RPT * CPT > 24) ? 256 : 512)))
 rrlu_reg_kernel(RrluRegArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -358,7 +358,7 @@ rrlu_reg_kernel(RrluRegArgs p)
         T4A_RSTAMP(7);
         __syncthreads(); // (D)
         // all LDS reads of the cross-wave reduction are issued together (<= 16 waves)
-        constexpr int NWMAX = (RPT * CPT >= 24) ? 4 : 8; // = maximum workgroup size / 64
+        constexpr int NWMAX = (RPT * CPT > 24) ? 4 : 8; // = maximum workgroup size / 64
         double rsc[NWMAX], rvl[NWMAX];
         unsigned rps[NWMAX];
 #pragma unroll
@@ -763,7 +763,7 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
                 const int RPT = (M + TR - 1) / TR;
                 const int CPT = norm_cpt((N + TC - 1) / TC);
                 if (RPT > 4 || (long long)TC * CPT < N) continue;
-                if (T > ((RPT * CPT >= 24) ? 256 : 512)) continue;
+                if (T > ((RPT * CPT > 24) ? 256 : 512)) continue;
                 const int cost = RPT * CPT * 64 + T / 64;
                 if (cost < best_cost) {
                     best_cost = cost;
@@ -810,7 +810,7 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
         }
         if (W < 1) W = 1;
         if (W > maxw || (long long)W * TC * CPT < N) return false;
-        if (TR * TC > ((RPT * CPT >= 24) ? 256 : 512)) return false;
+        if (TR * TC > ((RPT * CPT > 24) ? 256 : 512)) return false;
         plan.W = W;
         plan.T = TR * TC;
         plan.TR = TR;

@@ -69,6 +69,17 @@ def test_low_rank_and_truncation(t4a, shape, r):
     assert_rrlu_bit_exact(t4a, a, rel_tol=0.0, abs_tol=1e-3)
 
 
+@pytest.mark.parametrize("shape,maxb", [((1024, 1024), 300), ((1370, 1376), 200), ((1536, 1536), 128),
+                                        ((2048, 1000), 150), ((3000, 500), 100), ((500, 3000), 100)])
+@pytest.mark.parametrize("left", [True, False])
+def test_cfg4_sized_matrices(t4a, shape, maxb, left):
+    """BASELINE config 4 (chi = 512) candidate matrices are 1024..1536 on a side: register-resident kernel with
+    3 rows x 8 columns per thread up to M = 1536, LDS-resident fallback beyond."""
+    rng = np.random.default_rng(shape[0] + maxb)
+    a = rng.uniform(-1, 1, size=shape)
+    assert_rrlu_bit_exact(t4a, a, max_bond_dim=maxb, left_orthogonal=left)
+
+
 def test_ties_follow_permuted_positions(t4a):
     # many exactly equal |entries|: the winner must be the first in column-major order of the permuted block
     rng = np.random.default_rng(3)
