@@ -116,20 +116,31 @@ def main():
         return t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=CHI, max_iter=iters, ncheck_history=10 ** 6,
                                    nsearch=0, max_nglobal_pivot=0, seed=42)
 
-    # all-gather buffer for the patch cores (N > 1): every core padded to the cap shape (chi, 2, chi)
+    # all-gather buffers for the patch cores (N > 1): every core padded to the cap shape (chi, 2, chi); two buffer pairs
+    # so that the gather of sweep k overlaps with the bond updates of sweep k+1
     core_cap = CHI * 2 * CHI
     if world > 1:
-        send = torch.zeros(N_SITES * core_cap, dtype=torch.float64, device="cuda")
-        recv = torch.zeros(world * N_SITES * core_cap, dtype=torch.float64, device="cuda")
+        send = [torch.zeros(N_SITES * core_cap, dtype=torch.float64, device="cuda") for _ in range(2)]
+        recv = [torch.zeros(world * N_SITES * core_cap, dtype=torch.float64, device="cuda") for _ in range(2)]
+        done = [None, None]   # torch events: the all-gather that last used buffer pair k has finished
+        n_gathers = [0]
 
     def gather_cores():
+        """RCCL all-gather of this rank's patch cores, issued without stalling the host: the device-to-device export
+        is ordered after the fill_site_tensors still in flight and the collective waits for it on the device."""
         if world == 1:
             return
-        for s in range(N_SITES):
-            d = tci.site_tensor_dims(s)
-            if d[0] * d[1] * d[2] > 0:
-                tci.site_tensor_to_device(s, send.data_ptr() + 8 * s * core_cap)
-        dist.all_gather_into_tensor(recv, send)
+        k = n_gathers[0] % 2
+        n_gathers[0] += 1
+        if done[k] is not None:
+            done[k].synchronize()          # finished a full sweep ago: no stall, just the buffer-reuse guarantee
+        stream = torch.cuda.current_stream()
+        tci.export_site_tensors_async(send[k].data_ptr(), core_cap, stream.cuda_stream)
+        work = dist.all_gather_into_tensor(recv[k], send[k], async_op=True)
+        work.wait()                        # stream-level dependency only
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        done[k] = ev
 
     def full_sweep():
         tci.optimize(opts(2), final_sweep1site=False)  # forward + backward half-sweep, each with fill_site_tensors

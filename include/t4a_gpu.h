@@ -252,6 +252,14 @@ t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t 
  * of the current sets).  Default 0 = reference behaviour. */
 t4a_gpu_status t4a_gpu_tci2_set_keep_site_tensors(t4a_gpu_tci2* h, int32_t keep);
 
+/* Multi-GPU core gather without a host stall: copies every site tensor to dst_device + site * stride (stride in
+ * doubles, >= the largest site tensor) on the stream of the fill_site_tensors that may still be in flight, and makes
+ * `consumer_stream` (a hipStream_t, e.g. the stream an RCCL all-gather is issued from) wait for the copies.  With
+ * keep != 0 (above) optimize() leaves its last fill_site_tensors in flight, so the next sweep's bond updates overlap
+ * with it; errors of that fill are reported by the next call that reads a site tensor. */
+t4a_gpu_status t4a_gpu_tci2_export_site_tensors_async(t4a_gpu_tci2* h, void* dst_device, size_t stride,
+                                                      void* consumer_stream);
+
 /* =====================================================================================
  * SimpleTensorTrain<f64> (opaque handle; site tensors resident on the device)
  * tensor4all-simplett: tensortrain.rs:97, traits.rs:75-355, compression.rs:375-507, cache.rs:558-744

@@ -751,6 +751,17 @@ t4a_gpu_status t4a_gpu_tci2_set_site_tensor_device(t4a_gpu_tci2* h, size_t site,
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_export_site_tensors_async(t4a_gpu_tci2* h, void* dst_device, size_t stride,
+                                                      void* consumer_stream)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(dst_device);
+        h->impl.export_site_tensors_async(static_cast<double*>(dst_device), stride,
+                                          static_cast<hipStream_t>(consumer_stream));
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_n_iterations(const t4a_gpu_tci2* h, size_t* out)
 {
     return guarded([&] {

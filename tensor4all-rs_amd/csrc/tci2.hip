@@ -141,6 +141,7 @@ Tci2::Tci2(const std::vector<size_t>& dims) : n_(dims.size()), local_dims(dims) 
 
 Tci2::~Tci2()
 {
+    if (export_event_) (void)hipEventDestroy(export_event_);
     if (fill_stream_) {
         (void)hipStreamSynchronize(fill_stream_);
         (void)hipStreamDestroy(fill_stream_);
@@ -952,6 +953,22 @@ void Tci2::fill_site_tensors_impl(bool async)
     if (!async) fill_wait();
 }
 
+// Copies every site tensor to dst + site * stride (doubles) WITHOUT blocking the host: the copies are ordered after a
+// fill that is still in flight (same stream) and `consumer` waits for them through an event.
+void Tci2::export_site_tensors_async(double* d_dst, size_t stride, hipStream_t consumer)
+{
+    hipStream_t st = fill_inflight_ ? fill_stream_ : eng.stream();
+    for (size_t s = 0; s < n_; ++s) {
+        const DevCore& c = cores[s];
+        if (c.size() > stride) throw Error(T4A_GPU_BUFFER_TOO_SMALL, "export_site_tensors: stride smaller than a site tensor");
+        if (c.size())
+            T4A_HIP(hipMemcpyAsync(d_dst + s * stride, c.buf.get(), c.size() * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    if (!export_event_) T4A_HIP(hipEventCreateWithFlags(&export_event_, hipEventDisableTiming));
+    T4A_HIP(hipEventRecord(export_event_, st));
+    T4A_HIP(hipStreamWaitEvent(consumer, export_event_, 0));
+}
+
 // =================================================================================================
 // TT evaluation / sum
 // =================================================================================================
@@ -1122,7 +1139,9 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
     require_fn();
     if (rank() == 0)
         throw Error(T4A_GPU_INVALID_ARGUMENT, "TensorCI2 state must contain at least one pivot before optimization");
-    fill_wait();
+    // pipelined mode (keep_site_tensors): a fill left in flight by the previous call keeps running beside the bond
+    // updates below (they only touch the index sets); it is completed by the next fill or the first reader of a core
+    if (!keep_site_tensors) fill_wait();
     ranks_hist.clear();
     errors_hist.clear();
     std::vector<size_t> nglobal_hist;
@@ -1180,7 +1199,9 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
             break;
         }
     }
-    fill_wait(); // the cores of the last iteration are complete (deferred solve errors surface here)
+    // the cores of the last iteration are complete (deferred solve errors surface here); in pipelined mode the wait
+    // is left to the first reader (site_tensor*, evaluate, export_site_tensors_async, the next fill)
+    if (!keep_site_tensors || final_sweep1site) fill_wait();
     if (final_sweep1site) { // :1781-1794
         const double norm = (options.normalize_error && max_sample_value > 0.0) ? max_sample_value : 1.0;
         const double abs_tol = options.tolerance * norm;

@@ -507,6 +507,12 @@ class TensorCI2:
         d = (c_size_t * 3)(*[int(x) for x in dims3])
         _check(_lib.t4a_gpu_tci2_set_site_tensor_device(self._h, c_size_t(site), d, c_void_p(device_ptr)))
 
+    def export_site_tensors_async(self, device_ptr, stride, consumer_stream):
+        """Enqueue device-to-device copies of all cores to device_ptr + site*stride*8 and make `consumer_stream`
+        (an integer hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream) wait for them."""
+        _check(_lib.t4a_gpu_tci2_export_site_tensors_async(self._h, c_void_p(device_ptr), c_size_t(stride),
+                                                           c_void_p(consumer_stream)))
+
     def set_keep_site_tensors(self, keep=True):
         _check(_lib.t4a_gpu_tci2_set_keep_site_tensors(self._h, c_int32(1 if keep else 0)))
 

@@ -370,3 +370,43 @@ def test_cfg3_full_size_half_sweep_matches_oracle(t4a):
     gv, ov = g.evaluate(pts), o.evaluate(pts)
     scale = max(1.0, np.abs(ov).max())
     assert np.abs(gv - ov).max() <= 1e-10 * scale
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 4 size (d = 40, chi_max = 512): candidate matrices 1024..1536 on a side
+# ------------------------------------------------------------------------------------------------
+def test_cfg4_full_size_half_sweep_matches_oracle(t4a):
+    """Same protocol as the cfg3 test at d = 40, chi = 512 (25 592 pivot steps per full sweep): the device saturates
+    the cap, the oracle resumes from the device's index sets and both run one more half-sweep."""
+    from t4a_amd.functions import quantics_osc2d
+    n, chi = 40, 512
+    spec = quantics_osc2d(n, k1=37, k2=53, k3=20011, eps=0.5, k4=1048583, delta=0.5)
+    g = t4a.TensorCI2([2] * n)
+    g.set_function(spec)
+    g.add_global_pivots([[0] * n])
+    g.set_max_sample_value(1.0)
+    g.optimize(t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=12, ncheck_history=20, **PARITY),
+               final_sweep1site=False)
+    assert g.link_dims() == [min(2 ** (b + 1), 2 ** (n - b - 1), chi) for b in range(n - 1)]
+    o = ob.OracleTCI2([2] * n)
+    o.set_function(spec)
+    for p in range(n):
+        o.set_index_set(0, p, g.i_set(p))
+        o.set_index_set(1, p, g.j_set(p))
+    o.set_max_sample_value(g.max_sample_value())
+    g.clear_history()
+    o.clear_history()
+    one = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=1, ncheck_history=20, **PARITY)
+    g.optimize(one, final_sweep1site=False)
+    o.optimize(one, final_sweep1site=False)
+    assert np.array_equal(g.last_sweep_shapes(), o.last_sweep_shapes())
+    assert int(g.last_sweep_shapes()[:, 0].max()) >= 1024
+    assert_same_sets(g, o, n)
+    assert np.array_equal(g.history()[1], o.history()[1])
+    assert g.max_sample_value() == o.max_sample_value()
+    g.fill_site_tensors()
+    o.fill_site_tensors()
+    rng = np.random.default_rng(0)
+    pts = rng.integers(0, 2, size=(200, n))
+    gv, ov = g.evaluate(pts), o.evaluate(pts)
+    assert np.abs(gv - ov).max() <= 1e-10 * max(1.0, np.abs(ov).max())
