@@ -18,7 +18,8 @@ def _free_port():
     return p
 
 
-def test_pipelined_export_and_rccl_all_gather():
+@pytest.fixture(scope="module")
+def rccl():
     import torch
     import torch.distributed as dist
     import t4a_amd
@@ -28,7 +29,15 @@ def test_pipelined_export_and_rccl_all_gather():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_pipelined_export_and_rccl_all_gather(rccl):
+    import torch
+    import t4a_amd
+    dist = rccl
+    if True:
         n, chi = 14, 16
         spec = t4a_amd.quantics_trig_exp(n)  # cos(10x) exp(-x): low rank, so the capped interpolant is accurate
         tci = t4a_amd.TensorCI2([2] * n)
@@ -58,5 +67,72 @@ def test_pipelined_export_and_rccl_all_gather():
         pts = np.random.default_rng(0).integers(0, 2, size=(50, n))
         from oracle_binding import fn_eval
         assert np.abs(tci.evaluate(pts) - fn_eval(spec, pts)).max() < 1e-6
-    finally:
-        dist.destroy_process_group()
+
+
+def test_patch_farm_on_device_matches_oracle(rccl):
+    """BASELINE config 5 in miniature: independent crossinterpolate2 runs on patches of the bench integrand
+    (leading bits projected), farmed through parallel.run_patch_farm over RCCL; every patch equals the oracle's."""
+    import torch
+    import t4a_amd
+    import bench
+    import oracle_binding as ob
+    from t4a_amd import parallel
+    n_patches, chi = 4, 24
+    opt = t4a_amd.TCI2Options(tolerance=1e-9, max_bond_dim=chi, max_iter=4, nsearch=0, max_nglobal_pivot=0)
+    n = bench.N_SITES
+
+    def run_patch(p):
+        t = t4a_amd.TensorCI2([2] * n)
+        t.set_function(bench.patch_spec(p, n_patches))
+        t.crossinterpolate2([[0] * n], opt)
+        return [t.site_tensor(s) for s in range(n)]
+
+    farmed = parallel.run_patch_farm(rccl, torch, n_patches, run_patch, device="cuda")
+    assert len(farmed) == n_patches
+    for p in range(n_patches):
+        o = ob.OracleTCI2([2] * n)
+        o.set_function(bench.patch_spec(p, n_patches))
+        o.crossinterpolate2([[0] * n], opt)
+        for s in range(n):
+            a, b = farmed[p][s], o.site_tensor(s)
+            assert a.shape == b.shape, f"patch {p} site {s}"
+            assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), f"patch {p} site {s}"
+    # patches differ from each other (the projected bits matter)
+    assert not np.array_equal(farmed[0][n - 1], farmed[1][n - 1]) or not np.array_equal(farmed[0][0], farmed[1][0])
+
+
+def test_site_sharded_fill_on_device_is_bitwise_the_unsharded_fill(rccl):
+    """BASELINE config 4's sharding: with identical index sets, rank r fills the sites s % world == r and the cores
+    are exchanged through device pointers; the assembled train is bitwise the unsharded fill_site_tensors."""
+    import torch
+    import t4a_amd
+    n, chi, world = 16, 24, 2
+    spec = t4a_amd.quantics_osc2d(n, k1=3, k2=5, k3=11, eps=0.5, k4=101, delta=0.5)
+    opt = t4a_amd.TCI2Options(tolerance=1e-10, max_bond_dim=chi, max_iter=4, nsearch=0, max_nglobal_pivot=0)
+    ref = t4a_amd.TensorCI2([2] * n)
+    ref.set_function(spec)
+    ref.add_global_pivots([[0] * n])
+    ref.optimize(opt, final_sweep1site=False)
+    ref.fill_site_tensors()
+    shards = []
+    for r in range(world):
+        t = t4a_amd.TensorCI2([2] * n)
+        t.set_function(spec)
+        for p in range(n):
+            t.set_index_set(0, p, ref.i_set(p))
+            t.set_index_set(1, p, ref.j_set(p))
+        t.set_site_shard(r, world)
+        t.fill_site_tensors()
+        shards.append(t)
+    buf = torch.zeros(chi * 2 * chi, dtype=torch.float64, device="cuda")
+    for s in range(n):
+        owner, other = shards[s % world], shards[(s + 1) % world]
+        dims = owner.site_tensor_dims(s)
+        owner.site_tensor_to_device(s, buf.data_ptr())
+        torch.cuda.synchronize()
+        other.set_site_tensor_from_device(s, dims, buf.data_ptr())
+    for t in shards:
+        for s in range(n):
+            assert np.array_equal(t.site_tensor(s), ref.site_tensor(s)), f"site {s}"
+    pts = np.random.default_rng(1).integers(0, 2, size=(64, n))
+    assert np.array_equal(shards[0].evaluate(pts), ref.evaluate(pts))
