@@ -282,23 +282,49 @@ rrlu_reg_kernel(RrluRegArgs p)
             int cps[CPT];
 #pragma unroll
             for (int q = 0; q < CPT; ++q) cps[q] = UNI ? __builtin_amdgcn_readfirstlane(cpos[q]) : cpos[q];
+#ifdef T4A_RRLU_FLAT_PASS // measured: the pass itself gets 15 % shorter, the step does not (the exchange dominates)
+            {
+                // branch-free form: every element is updated speculatively and selected by its activity masks
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                if (rpos[r] > k) { // EXEC mask: rows already pivoted keep their U entries untouched
+                for (int r = 0; r < RPT; ++r) {
+                    const bool ract = rpos[r] > k;
 #pragma unroll
                     for (int q = 0; q < CPT; ++q) {
-                        if (cps[q] > k) {
-                            if (k >= 0) {
-                                const double prod = l[r] * u[q]; // update_trailing_submatrix (matrixlu.rs:593-612)
-                                a[q][r] = a[q][r] - prod;
+                        const bool act = ract && (cps[q] > k);
+                        double t = a[q][r];
+                        if (k >= 0) {
+                            const double prod = l[r] * u[q]; // update_trailing_submatrix (matrixlu.rs:593-612)
+                            const double upd = t - prod;
+                            const bool piv = ract && (cps[q] == k); // scale_column_tail: owners store l_i
+                            t = act ? upd : (piv ? l[r] : t);
+                            a[q][r] = t;
+                        }
+                        const double sc = vmax(m, t * t); // maxNum drops NaN scores (matrixlu.rs:506)
+                        m = act ? sc : m;
+                    }
+                }
+            }
+#else
+            {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    if (rpos[r] > k) { // EXEC mask: rows already pivoted keep their U entries untouched
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) {
+                            if (cps[q] > k) {
+                                if (k >= 0) {
+                                    const double prod = l[r] * u[q]; // update_trailing_submatrix (matrixlu.rs:593-612)
+                                    a[q][r] = a[q][r] - prod;
+                                }
+                                m = vmax(m, a[q][r] * a[q][r]); // maxNum drops NaN scores (matrixlu.rs:506)
+                            } else if (k >= 0 && cps[q] == k) {
+                                a[q][r] = l[r]; // scale_column_tail (matrixlu.rs:562-577): owners store l_i
                             }
-                            m = vmax(m, a[q][r] * a[q][r]); // maxNum drops NaN scores (matrixlu.rs:506)
-                        } else if (k >= 0 && cps[q] == k) {
-                            a[q][r] = l[r]; // scale_column_tail (matrixlu.rs:562-577): owners store l_i
                         }
                     }
                 }
             }
+#endif
         }
         npiv = k + 1;
         if (k + 1 >= p.max_steps) break; // the reference stops before another arg-max (matrixlu.rs:747)
