@@ -299,6 +299,38 @@ t4a_gpu_status t4a_gpu_tci2_to_tensor_train(t4a_gpu_tci2* h, t4a_gpu_tt** out);
 t4a_gpu_status t4a_gpu_tci2_from_tensor_train(const t4a_gpu_tt* tt, double tolerance, size_t max_bond_dim,
                                               size_t max_iter, t4a_gpu_tci2** out);
 
+/* =====================================================================================
+ * Adaptive patching driver (BASELINE config 5): partitionedtt::adaptiveinterpolate
+ * crates/tensor4all-partitionedtt/src/adaptive_interpolation.rs:58-262
+ * ===================================================================================== */
+typedef struct t4a_gpu_ptt t4a_gpu_ptt;
+
+/* adaptiveinterpolate(f, batched_f, site_indices, initial_pivots, AdaptiveInterpolateOptions{tci_options, patch_order,
+ * n_initial_pivots, recycle_pivots}).  Sites are identified by their position; `patch_order` is a permutation of
+ * 0..n_sites-1 or NULL for the natural order (adaptive_interpolation.rs:336-354).  initial_pivots is n_sites x n_pivots
+ * column-major.  One crossinterpolate2 runs on the device per patch; a patch is accepted when it terminated Converged
+ * with final error <= tolerance (:357-359), otherwise it is split along the next unprojected site of patch_order.
+ * The built-in variant restricts the integer weight tables of the device functor to the active sites of every patch. */
+t4a_gpu_status t4a_gpu_adaptive_interpolate_builtin(const size_t* local_dims, size_t n_sites, int32_t fid, int32_t n_acc,
+                                                    const double* params, const uint64_t* weights,
+                                                    const size_t* initial_pivots, size_t n_pivots,
+                                                    const t4a_gpu_tci2_options* tci_options, const size_t* patch_order,
+                                                    size_t n_initial_pivots, int32_t recycle_pivots, t4a_gpu_ptt** out);
+t4a_gpu_status t4a_gpu_adaptive_interpolate_callback(const size_t* local_dims, size_t n_sites, t4a_gpu_batch_eval_fn cb,
+                                                     void* ctx, const size_t* initial_pivots, size_t n_pivots,
+                                                     const t4a_gpu_tci2_options* tci_options, const size_t* patch_order,
+                                                     size_t n_initial_pivots, int32_t recycle_pivots, t4a_gpu_ptt** out);
+void t4a_gpu_ptt_release(t4a_gpu_ptt* h);
+/* PartitionedTT::len: number of accepted patches (FIFO acceptance order). */
+t4a_gpu_status t4a_gpu_ptt_len(const t4a_gpu_ptt* h, size_t* out);
+/* Projector of patch k: `count` projected sites, positions ascending; positions / values may be NULL to query. */
+t4a_gpu_status t4a_gpu_ptt_projector(const t4a_gpu_ptt* h, size_t k, size_t* count, size_t* positions, size_t* values);
+/* SubDomainTT of patch k as a tensor train over ALL sites (projected sites carry copy-selector tensors,
+ * adaptive_interpolation.rs:514-660); the new handle owns a device copy. */
+t4a_gpu_status t4a_gpu_ptt_patch_tt(const t4a_gpu_ptt* h, size_t k, t4a_gpu_tt** out);
+/* Sum over the patches at a batch of full multi-indices (idx: n_sites x n_pts column-major). */
+t4a_gpu_status t4a_gpu_ptt_evaluate(t4a_gpu_ptt* h, const size_t* idx, size_t n_pts, double* out);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);

@@ -4,11 +4,16 @@
 #include <memory>
 #include <mutex>
 
+#include "patching.hpp"
 #include "tci2.hpp"
 
 struct t4a_gpu_tci2 {
     t4a::Tci2 impl;
     explicit t4a_gpu_tci2(const std::vector<size_t>& d) : impl(d) {}
+};
+
+struct t4a_gpu_ptt {
+    std::unique_ptr<t4a::PartitionedTT> impl;
 };
 
 struct t4a_gpu_tt {
@@ -1249,6 +1254,131 @@ t4a_gpu_status t4a_gpu_tci2_from_tensor_train(const t4a_gpu_tt* tt, double toler
         std::unique_ptr<t4a_gpu_tci2> h(new t4a_gpu_tci2(tt->impl.site_dims()));
         h->impl.assign_from_tensor_train(tt->impl, o);
         *out = h.release();
+    });
+}
+
+
+// ------------------------------------------------------------------------------------------------ adaptive patching
+extern "C++" {
+static t4a_gpu_ptt* run_adaptive(const size_t* local_dims, size_t n_sites, const FullFunction& f,
+                                 const size_t* initial_pivots, size_t n_pivots, const t4a_gpu_tci2_options* tci_options,
+                                 const size_t* patch_order, size_t n_initial_pivots, int32_t recycle_pivots)
+{
+    if (n_sites) T4A_REQUIRE_PTR(local_dims);
+    if (n_pivots) T4A_REQUIRE_PTR(initial_pivots);
+    AdaptiveOptions ao;
+    ao.tci = convert_options(tci_options);
+    ao.n_initial_pivots = n_initial_pivots;
+    ao.recycle_pivots = recycle_pivots != 0;
+    if (patch_order) ao.patch_order.assign(patch_order, patch_order + n_sites);
+    std::vector<size_t> dims(local_dims, local_dims + n_sites);
+    std::vector<std::vector<uint32_t>> piv(n_pivots, std::vector<uint32_t>(n_sites));
+    for (size_t k = 0; k < n_pivots; ++k)
+        for (size_t s = 0; s < n_sites; ++s) {
+            const size_t v = initial_pivots[s + n_sites * k];
+            // out-of-range values are reported by the driver's own validation; keep them representable
+            piv[k][s] = v > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)v;
+        }
+    require_device();
+    std::unique_ptr<t4a_gpu_ptt> h(new t4a_gpu_ptt);
+    h->impl = adaptive_interpolate(dims, f, piv, ao);
+    return h.release();
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_adaptive_interpolate_builtin(const size_t* local_dims, size_t n_sites, int32_t fid, int32_t n_acc,
+                                                    const double* params, const uint64_t* weights,
+                                                    const size_t* initial_pivots, size_t n_pivots,
+                                                    const t4a_gpu_tci2_options* tci_options, const size_t* patch_order,
+                                                    size_t n_initial_pivots, int32_t recycle_pivots, t4a_gpu_ptt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        T4A_REQUIRE_PTR(params);
+        T4A_REQUIRE_PTR(weights);
+        if (fid < 0 || fid >= T4A_FN_COUNT) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown built-in function id");
+        if (n_acc < 1 || n_acc > T4A_FN_MAX_ACC) throw Error(T4A_GPU_INVALID_ARGUMENT, "n_acc out of range");
+        FullFunction f;
+        f.builtin = true;
+        f.fid = fid;
+        f.n_acc = n_acc;
+        std::memcpy(f.params, params, sizeof(double) * T4A_FN_MAX_PARAMS);
+        size_t total = 0;
+        for (size_t s = 0; s < n_sites; ++s) total += local_dims ? local_dims[s] : 0;
+        f.weights.assign(weights, weights + (size_t)n_acc * total);
+        *out = run_adaptive(local_dims, n_sites, f, initial_pivots, n_pivots, tci_options, patch_order, n_initial_pivots,
+                            recycle_pivots);
+    });
+}
+
+t4a_gpu_status t4a_gpu_adaptive_interpolate_callback(const size_t* local_dims, size_t n_sites, t4a_gpu_batch_eval_fn cb,
+                                                     void* ctx, const size_t* initial_pivots, size_t n_pivots,
+                                                     const t4a_gpu_tci2_options* tci_options, const size_t* patch_order,
+                                                     size_t n_initial_pivots, int32_t recycle_pivots, t4a_gpu_ptt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        T4A_REQUIRE_PTR(cb);
+        FullFunction f;
+        f.builtin = false;
+        f.cb = cb;
+        f.ctx = ctx;
+        *out = run_adaptive(local_dims, n_sites, f, initial_pivots, n_pivots, tci_options, patch_order, n_initial_pivots,
+                            recycle_pivots);
+    });
+}
+
+void t4a_gpu_ptt_release(t4a_gpu_ptt* h) { delete h; }
+
+t4a_gpu_status t4a_gpu_ptt_len(const t4a_gpu_ptt* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl->patches.size();
+    });
+}
+
+t4a_gpu_status t4a_gpu_ptt_projector(const t4a_gpu_ptt* h, size_t k, size_t* count, size_t* positions, size_t* values)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        if (k >= h->impl->patches.size()) throw Error(T4A_GPU_INVALID_ARGUMENT, "patch index out of range");
+        const auto& pr = h->impl->patches[k].projector;
+        *count = pr.size();
+        size_t i = 0;
+        for (const auto& kv : pr) {
+            if (positions) positions[i] = kv.first;
+            if (values) values[i] = kv.second;
+            ++i;
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_ptt_patch_tt(const t4a_gpu_ptt* h, size_t k, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        if (k >= h->impl->patches.size()) throw Error(T4A_GPU_INVALID_ARGUMENT, "patch index out of range");
+        *out = new t4a_gpu_tt(h->impl->patches[k].cores, h->impl->eng.stream());
+    });
+}
+
+t4a_gpu_status t4a_gpu_ptt_evaluate(t4a_gpu_ptt* h, const size_t* idx, size_t n_pts, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pts == 0) return;
+        T4A_REQUIRE_PTR(idx);
+        T4A_REQUIRE_PTR(out);
+        std::vector<uint32_t> u = narrow_indices(idx, checked_mul(n_pts, h->impl->dims.size(), "index buffer"));
+        std::vector<double> v = h->impl->evaluate(u.data(), n_pts);
+        std::memcpy(out, v.data(), n_pts * sizeof(double));
     });
 }
 

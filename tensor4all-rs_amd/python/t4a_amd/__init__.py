@@ -754,3 +754,94 @@ class SimpleTensorTrain:
         total = int(np.prod(sd))
         grids = np.indices(sd[::-1]).reshape(len(sd), -1)[::-1].T  # leftmost fastest
         return self.evaluate(grids.reshape(total, len(sd)))
+
+
+# ---------------------------------------------------------------------------------------- adaptive patching
+class PartitionedTT:
+    """Result of adaptiveinterpolate (partitionedtt/src/adaptive_interpolation.rs): patches in FIFO acceptance order."""
+
+    def __init__(self, handle, local_dims):
+        self._h = handle
+        self.local_dims = [int(d) for d in local_dims]
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.t4a_gpu_ptt_release(h)
+            self._h = None
+
+    def __len__(self):
+        v = c_size_t(0)
+        _check(_lib.t4a_gpu_ptt_len(self._h, ctypes.byref(v)))
+        return v.value
+
+    def projector(self, k):
+        cnt = c_size_t(0)
+        _check(_lib.t4a_gpu_ptt_projector(self._h, c_size_t(k), ctypes.byref(cnt), None, None))
+        pos = np.zeros(max(cnt.value, 1), dtype=np.uintp)
+        val = np.zeros(max(cnt.value, 1), dtype=np.uintp)
+        _check(_lib.t4a_gpu_ptt_projector(self._h, c_size_t(k), ctypes.byref(cnt), _p(pos), _p(val)))
+        return {int(pos[i]): int(val[i]) for i in range(cnt.value)}
+
+    def projectors(self):
+        return [self.projector(k) for k in range(len(self))]
+
+    def patch(self, k):
+        """SubDomainTT of patch k as a SimpleTensorTrain over all sites."""
+        h = c_void_p()
+        _check(_lib.t4a_gpu_ptt_patch_tt(self._h, c_size_t(k), ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
+    def evaluate(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uintp).reshape(-1, len(self.local_dims)))
+        out = np.zeros(idx.shape[0])
+        _check(_lib.t4a_gpu_ptt_evaluate(self._h, _p(idx), c_size_t(idx.shape[0]), _p(out)))
+        return out
+
+    def dense(self):
+        """all values, site 0 fastest (the order of the reference's dense test helper)"""
+        sd = self.local_dims
+        grids = np.indices(sd[::-1]).reshape(len(sd), -1)[::-1].T
+        return self.evaluate(grids)
+
+
+def adaptiveinterpolate(f, local_dims, initial_pivots, options, patch_order=None, n_initial_pivots=5,
+                        recycle_pivots=False):
+    """partitionedtt::adaptiveinterpolate (adaptive_interpolation.rs:58).  `f` as for TensorCI2.set_function."""
+    o = options.to_c()
+    ld = np.asarray([int(d) for d in local_dims], dtype=np.uintp)
+    n = len(ld)
+    piv = np.ascontiguousarray(np.asarray(initial_pivots, dtype=np.uintp).reshape(len(initial_pivots), n))
+    po = None if patch_order is None else np.ascontiguousarray(np.asarray(patch_order, dtype=np.uintp))
+    h = c_void_p()
+    common = (_p(piv) if len(initial_pivots) else None, c_size_t(len(initial_pivots)), ctypes.byref(o),
+              None if po is None else _p(po), c_size_t(n_initial_pivots), c_int32(1 if recycle_pivots else 0),
+              ctypes.byref(h))
+    if isinstance(f, FnSpec):
+        params = np.asarray(f.params, dtype=np.float64)
+        w = np.ascontiguousarray(f.weights, dtype=np.uint64)
+        _check(_lib.t4a_gpu_adaptive_interpolate_builtin(_p(ld), c_size_t(n), c_int32(f.fid), c_int32(f.n_acc), _p(params),
+                                                         _p(w), *common))
+    else:
+        scalar = f
+        batched = getattr(f, "batched", None)
+
+        def _cb(ctx, idx_ptr, n_sites, n_pts, out_ptr):
+            try:
+                idx = np.ctypeslib.as_array(idx_ptr, shape=(n_pts, n_sites))
+                if batched is not None:
+                    vals = np.asarray(batched(idx), dtype=np.float64).ravel()
+                else:
+                    vals = np.array([scalar([int(v) for v in row]) for row in idx], dtype=np.float64)
+                k = min(len(vals), n_pts)
+                out = np.ctypeslib.as_array(out_ptr, shape=(n_pts,))
+                out[:k] = vals[:k]
+                return len(vals)
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        cb = _BATCH_CB(_cb)
+        _check(_lib.t4a_gpu_adaptive_interpolate_callback(_p(ld), c_size_t(n), cb, None, *common))
+    return PartitionedTT(h, local_dims)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp",
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp", "t4a_oracle_patch.hpp",
                                                   "t4a_oracle_tt.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
@@ -489,3 +489,80 @@ def constant_tt(site_dims, value):
     if n:
         cores[-1] = cores[-1] * value
     return cores
+
+
+# ------------------------------------------------------------------------------------------------
+# adaptive patching driver (oracle/t4a_oracle_patch.hpp)
+# ------------------------------------------------------------------------------------------------
+_lib.oracle_adaptive_interpolate.restype = vp
+_lib.oracle_fn_new.restype = vp
+_lib.oracle_ptt_len.restype = u64
+_lib.oracle_ptt_len.argtypes = [vp]
+_lib.oracle_ptt_release.argtypes = [vp]
+
+
+class OraclePartitionedTT:
+    """Result of adaptiveinterpolate: patches in acceptance order, each with its projector and full-length cores."""
+
+    def __init__(self, handle, n_sites):
+        self._h = handle
+        self.n_sites = n_sites
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.oracle_ptt_release(vp(self._h))
+            self._h = None
+
+    def __len__(self):
+        return int(_lib.oracle_ptt_len(vp(self._h)))
+
+    def projector(self, k):
+        cnt = u64(0)
+        _check(_lib.oracle_ptt_projector(vp(self._h), u64(k), ctypes.byref(cnt), None, None))
+        pos = np.zeros(max(cnt.value, 1), dtype=np.uint64)
+        val = np.zeros(max(cnt.value, 1), dtype=np.uint64)
+        _check(_lib.oracle_ptt_projector(vp(self._h), u64(k), ctypes.byref(cnt), _p(pos), _p(val)))
+        return {int(pos[i]): int(val[i]) for i in range(cnt.value)}
+
+    def cores(self, k):
+        out = []
+        for s in range(self.n_sites):
+            d3 = np.zeros(3, dtype=np.uint64)
+            _check(_lib.oracle_ptt_site_tensor(vp(self._h), u64(k), u64(s), _p(d3), None))
+            buf = np.zeros(max(int(np.prod(d3)), 1))
+            _check(_lib.oracle_ptt_site_tensor(vp(self._h), u64(k), u64(s), _p(d3), _p(buf)))
+            out.append(buf[:int(np.prod(d3))].reshape(tuple(int(x) for x in d3), order="F"))
+        return out
+
+    def evaluate(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64).reshape(-1, self.n_sites))
+        out = np.zeros(idx.shape[0])
+        _check(_lib.oracle_ptt_evaluate(vp(self._h), _p(idx), u64(idx.shape[0]), _p(out)))
+        return out
+
+    def dense(self, dims):
+        """all values, site 0 fastest (the order of the reference's dense_f64 test helper)"""
+        grids = np.indices(list(dims)[::-1]).reshape(len(dims), -1)[::-1].T
+        return self.evaluate(grids)
+
+
+def adaptiveinterpolate(f, dims, initial_pivots, options, patch_order=None, n_initial_pivots=5, recycle_pivots=False,
+                        pivot_search=0):
+    """partitionedtt::adaptiveinterpolate restatement.  `f` as for OracleTCI2.set_function."""
+    src = OracleTCI2.__new__(OracleTCI2)  # function holder only: any number of sites >= 1
+    src.local_dims = [int(d) for d in dims]
+    ld = np.asarray(src.local_dims, dtype=np.uint64)
+    src._h = _lib.oracle_fn_new(_p(ld), u64(len(ld)))
+    src._keep = None
+    src.set_function(f)
+    src.set_pivot_search(pivot_search)
+    piv = np.ascontiguousarray(np.asarray(initial_pivots, dtype=np.uint64).reshape(len(initial_pivots), len(dims)))
+    po = None if patch_order is None else np.ascontiguousarray(np.asarray(patch_order, dtype=np.uint64))
+    h = _lib.oracle_adaptive_interpolate(vp(src._h), _p(piv), u64(len(initial_pivots)), *OracleTCI2._opt_args(options),
+                                         None if po is None else _p(po), u64(n_initial_pivots),
+                                         cint(int(recycle_pivots)))
+    if not h:
+        raise OracleError(-2)
+    r = OraclePartitionedTT(h, len(dims))
+    r._src = src
+    return r
