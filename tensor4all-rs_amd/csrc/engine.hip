@@ -73,6 +73,45 @@ Engine::~Engine()
     }
 }
 
+// Buffers the next luci(M, N, opts) call would clear with two memsets (result header, key table): the caller may hand
+// them to the kernel it launches right before (pi_eval_launch) instead.  Only for the register-resident rrLU path.
+ZeroJob Engine::prepare_zero(int M, int N, const RrLUOptions& opts)
+{
+    ZeroJob z;
+    prezero_valid_ = false;
+    if (M <= 0 || N <= 0 || M > 65535 || N > 65535) return z;
+    static const bool force_lds = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "lds";
+    const bool left = opts.left_orthogonal;
+    const int kM = left ? M : N, kN = left ? N : M;
+    RrluRegPlan rplan;
+    if (force_lds || !rrlu_reg_make_plan(kM, kN, num_cus_, &rplan)) return z;
+    size_t ms = opts.max_bond_dim;
+    if (ms > (size_t)M) ms = M;
+    if (ms > (size_t)N) ms = N;
+    const size_t out_bytes = (32 + sizeof(double) * (ms > 0 ? ms : 1) + sizeof(int) * ((size_t)M + N) + 7) / 8 * 8;
+    d_out_.reserve(out_bytes);
+    h_out_.reserve(out_bytes);
+    z.p0 = reinterpret_cast<unsigned long long*>(d_out_.get());
+    z.n0 = 4;
+    if (rplan.W > 1) {
+        const size_t need_keys = rrlu_reg_keys_bytes(rplan) / sizeof(unsigned long long);
+        const size_t need_cols = rrlu_reg_cols_bytes(rplan, kM) / sizeof(unsigned long long);
+        if (need_keys > d_rkeys_.cap || need_cols > d_rcols_.cap) { // same (re)allocation rule as luci()
+            d_rkeys_.reserve(need_keys);
+            d_rcols_.reserve(need_cols);
+            T4A_HIP(hipMemsetAsync(d_rkeys_.get(), 0, d_rkeys_.cap * sizeof(unsigned long long), stream_));
+            T4A_HIP(hipMemsetAsync(d_rcols_.get(), 0, d_rcols_.cap * sizeof(unsigned long long), stream_));
+            rrlu_salt_ = 0;
+        }
+        z.p1 = d_rkeys_.get();
+        z.n1 = (int)need_keys;
+    }
+    prezero_valid_ = true;
+    prezero_M_ = M;
+    prezero_N_ = N;
+    return z;
+}
+
 LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy)
 {
     LuciResult r;
@@ -102,7 +141,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     const size_t off_piv = 32;
     const size_t off_rp = off_piv + sizeof(double) * (size_t)(max_steps > 0 ? max_steps : 1);
     const size_t off_cp = off_rp + sizeof(int) * (size_t)M;
-    const size_t out_bytes = off_cp + sizeof(int) * (size_t)N;
+    const size_t out_bytes = (off_cp + sizeof(int) * (size_t)N + 7) / 8 * 8;
     d_out_.reserve(out_bytes);
     h_out_.reserve(out_bytes);
     double* d_dres = reinterpret_cast<double*>(d_out_.get());
@@ -114,7 +153,9 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     d_colperm_ptr_ = d_colperm;
     const bool keep_lu = need_factors || want_lu_copy;
     if (keep_lu) d_lu_.reserve((size_t)M * N);
-    T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
+    const bool prezeroed = prezero_valid_ && prezero_M_ == M && prezero_N_ == N;
+    prezero_valid_ = false;
+    if (!prezeroed) T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
     static const bool want_stamps = std::getenv("T4A_RRLU_STAMPS") != nullptr;
     static const bool force_lds = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "lds";
     if (want_stamps) {
@@ -129,6 +170,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     RrluRegPlan rplan;
     const bool use_reg = !force_lds && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     int plan_W = 1, plan_T = 0, plan_code = 0;
+    bool mirrored = false;
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.a, stream_));
     if (use_reg) {
         const double* src = d_a;
@@ -182,7 +224,12 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.spec = spec_env ? 1 : 0;
         a.spin_limit = 1u << 20;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
-        rrlu_reg_launch(rplan, a, stream_);
+        // results land in the pinned mirror straight from the kernel: no device-to-host copy afterwards
+        std::memset(h_out_.get(), 0, 32);
+        a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());
+        a.block_u64 = (int)(out_bytes / 8);
+        mirrored = true;
+        rrlu_reg_launch(rplan, a, stream_, prezeroed);
         plan_W = rplan.W;
         plan_T = rplan.T;
         plan_code = rplan.RPT * 1000 + rplan.CPT * 10 + (rplan.W == 1 ? 2 : 0) + ((rplan.TR % 64) == 0 ? 1 : 0);
@@ -221,7 +268,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     T4A_HIP(hipGetLastError());
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.b, stream_));
 
-    T4A_HIP(hipMemcpyAsync(h_out_.get(), d_out_.get(), out_bytes, hipMemcpyDeviceToHost, stream_));
+    if (!mirrored) T4A_HIP(hipMemcpyAsync(h_out_.get(), d_out_.get(), out_bytes, hipMemcpyDeviceToHost, stream_));
     T4A_HIP(hipStreamSynchronize(stream_));
 
     // host views of the packed block (hp: [4 + M + N] ints, hr: [2 + max_steps] doubles, as before)

@@ -65,6 +65,10 @@ public:
     // `want_lu_copy` additionally keeps the factored matrix (permuted coordinates) in lu_buf().
     LuciResult luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy);
 
+    // see engine.hip: fused clearing of the buffers the next luci() call needs zeroed
+    ZeroJob prepare_zero(int M, int N, const RrLUOptions& opts);
+    void cancel_prezero() { prezero_valid_ = false; }
+
     // RrLU::left(true) / RrLU::right(true) (matrixlu.rs:263-326) of the factorisation kept by the last
     // luci(..., want_lu_copy = true): left() is M x rank, right() is rank x N afterwards.
     void lu_permuted_factors(const LuciResult& r, bool left_orth);
@@ -88,6 +92,8 @@ private:
     hipStream_t stream_ = nullptr;
     int num_cus_ = 0;
     unsigned rrlu_salt_ = 0;
+    bool prezero_valid_ = false;
+    int prezero_M_ = 0, prezero_N_ = 0;
     DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_at_;
     DevBuf<char> d_out_;
     PinBuf<char> h_out_;

@@ -85,12 +85,18 @@ struct RrluRegArgs {
     int spec;                   // 1: every workgroup publishes its candidate column with its key (cols is [2][W][M][2])
     unsigned spin_limit;
     unsigned long long* stamps; // diagnostic only
+    // optional host-visible (pinned) mirror of the packed result block that starts at `dresult`
+    // ([dresult 2 f64][iresult 4 i32][pivot_vals][row_perm][col_perm]): workgroup 0 copies the block there at the end
+    // of the kernel and the flag setters write their flags directly, so no device-to-host copy is needed afterwards
+    unsigned long long* h_block;
+    int block_u64;
 };
 // false if the shape is outside the fast path (fall back to the LDS kernel)
 bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out);
 size_t rrlu_reg_keys_bytes(const RrluRegPlan& plan);
 size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M);
-void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& args, hipStream_t stream);
+// keys_zeroed: the caller already cleared the key table on this stream (e.g. fused into the Π kernel)
+void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& args, hipStream_t stream, bool keys_zeroed = false);
 
 // ------------------------------------------------------------------------------------------------
 // K1: candidate-matrix build (replaces the Π loop, tensor4all-tensorci/src/tensorci2.rs:1859-1893)
@@ -102,8 +108,17 @@ struct FnDevice {
     int n_acc;
     double params[T4A_FN_MAX_PARAMS];
 };
+// Two small buffers (counts in 64-bit words) that block (0,0) of the Π kernel clears on the way: lets the caller
+// drop the separate memsets of the rrLU result header and key table (one dispatch + gap each per bond).
+struct ZeroJob {
+    unsigned long long* p0 = nullptr;
+    int n0 = 0;
+    unsigned long long* p1 = nullptr;
+    int n1 = 0;
+};
 void pi_eval_launch(const FnDevice& fn, const uint64_t* rowacc, int M, const uint64_t* colacc, int N, double* out,
-                    int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream);
+                    int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream,
+                    const ZeroJob& zero = ZeroJob());
 // max over a dense buffer of bits(sqrt(v*v)) (host-callback path)
 void absmax_launch(const double* data, size_t count, unsigned long long* max_abs_bits, hipStream_t stream);
 

@@ -540,6 +540,7 @@ rrlu_reg_kernel(RrluRegArgs p)
                     if (lane == 0) {
                         s.win_i[2] = 1;
                         atomicExch(&p.iresult[1], 1);
+                        if (p.h_block) ((volatile int*)p.h_block)[5] = 1;
                     }
                 } else {
                     const double gmax = wave_max_f64(csc);
@@ -657,6 +658,7 @@ rrlu_reg_kernel(RrluRegArgs p)
                 if (__all(ok)) break;
                 if (++spins > p.spin_limit) {
                     atomicExch(&p.iresult[1], 1);
+                    if (p.h_block) ((volatile int*)p.h_block)[5] = 1;
                     s.win_i[2] = 1; // observed by everybody after the next barrier
                     break;
                 }
@@ -724,7 +726,20 @@ rrlu_reg_kernel(RrluRegArgs p)
                 }
             }
         }
-    if (nan_seen) atomicExch(&p.iresult[2], 1);
+    if (nan_seen) {
+        atomicExch(&p.iresult[2], 1);
+        if (p.h_block) ((volatile int*)p.h_block)[6] = 1;
+    }
+    // host-visible mirror of the packed result block (everything but the two flag words, which their setters write)
+    if (p.h_block && w == 0) {
+        __syncthreads(); // this workgroup's writes to the device block (perms, pivot values, npiv, error) are visible
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p.dresult);
+        for (int e = tid; e < p.block_u64; e += T) {
+            if (e == 2 || e == 3) continue;
+            p.h_block[e] = (e == 1) ? ld_u64_sc1(src + 1) : src[e]; // [1] = max |a| bits: atomics of all workgroups
+        }
+        if (tid == 0) ((volatile int*)p.h_block)[4] = npiv;
+    }
 }
 
 template <int RPT, int CPT, bool SINGLE, bool UNI>
@@ -861,10 +876,10 @@ size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M)
     return (size_t)2 * slots * (size_t)M * 2 * sizeof(unsigned long long);
 }
 
-void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
+void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream, bool keys_zeroed)
 {
     // the key table carries 16-bit step tags: zero it before every launch (2.7 KiB at W = 86)
-    if (plan.W > 1) (void)hipMemsetAsync(a.keys, 0, rrlu_reg_keys_bytes(plan), stream);
+    if (plan.W > 1 && !keys_zeroed) (void)hipMemsetAsync(a.keys, 0, rrlu_reg_keys_bytes(plan), stream);
     switch (plan.RPT) {
     case 1: launch_r<1>(plan, a, stream); break;
     case 2: launch_r<2>(plan, a, stream); break;

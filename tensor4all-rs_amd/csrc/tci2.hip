@@ -326,12 +326,12 @@ void Tci2::accumulate(const IndexSet& set, size_t first_site, std::vector<uint64
 }
 
 // out[ia + a.count*ib] = f(index with a's digits at sites [a0, a0+a.width) and b's at [b0, b0+b.width))
-void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
-                       unsigned long long* d_maxbits)
+bool Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
+                       unsigned long long* d_maxbits, const ZeroJob* zero)
 {
     require_fn();
     const size_t na = a.count, nb = b.count;
-    if (na == 0 || nb == 0) return;
+    if (na == 0 || nb == 0) return false;
     if (a.width + b.width != n_) throw Error(T4A_GPU_INTERNAL_ERROR, "eval_matrix: index widths do not cover all sites");
     hipStream_t st = eng.stream();
     eng.prof.v[11] += (double)na * (double)nb;
@@ -357,8 +357,9 @@ void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
         (void)K;
         (void)hb;
         pi_eval_launch(fn_dev_, d_rowacc_.get(), (int)na, d_rowacc_.get() + ra.size(), (int)nb, d_out, (int)na, false,
-                       d_maxbits, st);
+                       d_maxbits, st, zero ? *zero : ZeroJob());
         T4A_HIP(hipGetLastError());
+        return zero != nullptr;
     } else {
         // host batch callback: points in row-major order of (ia, ib) — `ia` outer, `ib` inner — exactly the
         // order the reference hands to batched_f (tensorci2.rs:1862-1869)
@@ -383,6 +384,7 @@ void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
         if (d_maxbits) absmax_launch(d_out, npts, d_maxbits, st);
         T4A_HIP(hipGetLastError());
     }
+    return false;
 }
 
 std::vector<double> Tci2::eval_points_host(const std::vector<uint32_t>& idx, size_t n_pts)
@@ -418,7 +420,9 @@ LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
     static long hp_n = 0;
     const auto hp_t0 = std::chrono::steady_clock::now();
     if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.a, st));
-    eval_matrix(is, 0, js, is.width, d_pi, nullptr);
+    // the Π kernel clears the rrLU result header and key table on its way (two memset dispatches less per bond)
+    const ZeroJob zero = eng.prepare_zero((int)M, (int)N, o);
+    if (!eval_matrix(is, 0, js, is.width, d_pi, nullptr, zero.p0 ? &zero : nullptr)) eng.cancel_prezero();
     if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.b, st));
     if (host_prof) {
         hp_eval += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hp_t0).count();

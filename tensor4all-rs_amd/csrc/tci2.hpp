@@ -130,8 +130,9 @@ private:
     // Evaluate f into a device matrix: out[ia + a.count*ib] = f(index with a's digits at sites
     // [a0, a0+a.width) and b's digits at [b0, b0+b.width)).  If d_maxbits != nullptr the kernel also
     // atomically maxes bits(sqrt(v*v)) into it.
-    void eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
-                     unsigned long long* d_maxbits);
+    // returns true when `zero` was handed to (and cleared by) the device evaluation kernel
+    bool eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
+                     unsigned long long* d_maxbits, const ZeroJob* zero = nullptr);
     std::vector<double> eval_points_host(const std::vector<uint32_t>& idx, size_t n_pts);
     void require_fn() const;
 
