@@ -269,6 +269,11 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.b, stream_));
 
     if (!mirrored) T4A_HIP(hipMemcpyAsync(h_out_.get(), d_out_.get(), out_bytes, hipMemcpyDeviceToHost, stream_));
+    if (overlap_hook) { // the device is busy for the next ~millisecond: do the caller's independent host work now
+        std::function<void()> hook;
+        hook.swap(overlap_hook);
+        hook();
+    }
     T4A_HIP(hipStreamSynchronize(stream_));
 
     // host views of the packed block (hp: [4 + M + N] ints, hr: [2 + max_steps] doubles, as before)

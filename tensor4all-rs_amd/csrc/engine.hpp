@@ -4,6 +4,7 @@
 #pragma once
 
 #include <array>
+#include <functional>
 #include <map>
 #include <limits>
 #include <vector>
@@ -78,6 +79,10 @@ public:
     void svd(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt);
     // thin QR (qr_backend, backend.rs:742): d_q M x k, d_r k x N; Householder.
     void qr(const double* d_a, int M, int N, double* d_q, double* d_r);
+
+    // Host work that does not depend on the running factorisation: executed once, after the kernels of the next luci()
+    // call have been enqueued and before the host blocks on them (then cleared).
+    std::function<void()> overlap_hook;
 
     Profile prof;
     // rrLU launch statistics per kernel instantiation: code -> {ms, launches, algorithmic bytes}

@@ -327,7 +327,8 @@ void Tci2::accumulate(const IndexSet& set, size_t first_site, std::vector<uint64
 
 // out[ia + a.count*ib] = f(index with a's digits at sites [a0, a0+a.width) and b's at [b0, b0+b.width))
 bool Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
-                       unsigned long long* d_maxbits, const ZeroJob* zero)
+                       unsigned long long* d_maxbits, const ZeroJob* zero, const std::vector<uint64_t>* acc_a,
+                       const std::vector<uint64_t>* acc_b)
 {
     require_fn();
     const size_t na = a.count, nb = b.count;
@@ -337,9 +338,13 @@ bool Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
     eng.prof.v[11] += (double)na * (double)nb;
     if (fn_kind_ == FnKind::Builtin) {
         const int K = fn_dev_.n_acc;
-        std::vector<uint64_t> ra, rb;
-        accumulate(a, a0, ra);
-        accumulate(b, b0, rb);
+        std::vector<uint64_t> ra_own, rb_own;
+        if (!acc_a) accumulate(a, a0, ra_own);
+        if (!acc_b) accumulate(b, b0, rb_own);
+        const std::vector<uint64_t>& ra = acc_a ? *acc_a : ra_own;
+        const std::vector<uint64_t>& rb = acc_b ? *acc_b : rb_own;
+        if (ra.size() != na * (size_t)K || rb.size() != nb * (size_t)K)
+            throw Error(T4A_GPU_INTERNAL_ERROR, "eval_matrix: prepared accumulators have the wrong size");
         // pinned staging arena: entries stay valid until the next stream sync
         const size_t need = ra.size() + rb.size();
         if (acc_used_ + need > h_acc_.cap) {
@@ -410,7 +415,21 @@ std::vector<double> Tci2::eval_points_host(const std::vector<uint32_t>& idx, siz
     return out;
 }
 
-LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o, bool need_factors)
+// kron(I_b, d_b) + extras (rows) or kron(d_{b+1}, J_{b+1}) + extras (columns) of bond `bond`, with accumulators
+void Tci2::build_side(size_t bond, bool cols, const IndexSet& extra, SidePrep& out) const
+{
+    out.valid = false;
+    out.bond = bond;
+    out.cols = cols;
+    out.set = cols ? kronecker_j(bond + 1) : kronecker_i(bond);
+    union_extras(out.set, extra);
+    out.acc.clear();
+    if (fn_kind_ == FnKind::Builtin) accumulate(out.set, cols ? bond + 1 : 0, out.acc);
+    out.valid = true;
+}
+
+LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o, bool need_factors,
+                              const std::vector<uint64_t>* acc_rows, const std::vector<uint64_t>* acc_cols)
 {
     const size_t M = is.count, N = js.count;
     double* d_pi = eng.pi(M * N);
@@ -422,7 +441,8 @@ LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
     if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.a, st));
     // the Π kernel clears the rrLU result header and key table on its way (two memset dispatches less per bond)
     const ZeroJob zero = eng.prepare_zero((int)M, (int)N, o);
-    if (!eval_matrix(is, 0, js, is.width, d_pi, nullptr, zero.p0 ? &zero : nullptr)) eng.cancel_prezero();
+    if (!eval_matrix(is, 0, js, is.width, d_pi, nullptr, zero.p0 ? &zero : nullptr, acc_rows, acc_cols))
+        eng.cancel_prezero();
     if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.b, st));
     if (host_prof) {
         hp_eval += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hp_t0).count();
@@ -548,11 +568,29 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     static double hp_sets = 0, hp_luci = 0, hp_post = 0;
     static long hp_n = 0;
     const auto hp_t0 = std::chrono::steady_clock::now();
-    IndexSet i_comb = kronecker_i(b);
-    IndexSet j_comb = kronecker_j(b + 1);
-    union_extras(i_comb, extra_i);
-    union_extras(j_comb, extra_j);
+    // one side may have been built while the previous bond's kernels were running (it does not depend on them)
+    SidePrep ready;
+    if (prep_.valid && prep_.bond == b) std::swap(ready, prep_);
+    prep_.valid = false;
+    const bool have_rows = ready.valid && !ready.cols, have_cols = ready.valid && ready.cols;
+    IndexSet i_own, j_own;
+    if (!have_rows) {
+        i_own = kronecker_i(b);
+        union_extras(i_own, extra_i);
+    }
+    if (!have_cols) {
+        j_own = kronecker_j(b + 1);
+        union_extras(j_own, extra_j);
+    }
+    const IndexSet& i_comb = have_rows ? ready.set : i_own;
+    const IndexSet& j_comb = have_cols ? ready.set : j_own;
+    const bool acc_ready = ready.valid && fn_kind_ == FnKind::Builtin;
     if (i_comb.count == 0 || j_comb.count == 0) return;
+    if (prefetch_.wanted) { // schedule the independent side of the NEXT bond behind this bond's kernel launches
+        const Prefetch pf = prefetch_;
+        prefetch_.wanted = false;
+        eng.overlap_hook = [this, pf]() { build_side(pf.bond, pf.cols, *pf.extra, prep_); };
+    }
     const auto hp_t1 = std::chrono::steady_clock::now();
 
     const bool extras_used = extra_i.count != 0 || extra_j.count != 0;
@@ -563,8 +601,15 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     lo.left_orthogonal = left_orthogonal;
     // the reference always builds the factors; they are only CONSUMED when no extras were merged
     // (tensorci2.rs:1942-1949), so the device skips the trsm/gemm otherwise.
-    LuciResult lu = options.pivot_search == 0 ? luci_on_sets(i_comb, j_comb, lo, !extras_used)
-                                              : rook_on_sets(i_comb, j_comb, lo);
+    LuciResult lu = options.pivot_search == 0
+                        ? luci_on_sets(i_comb, j_comb, lo, !extras_used, (acc_ready && have_rows) ? &ready.acc : nullptr,
+                                       (acc_ready && have_cols) ? &ready.acc : nullptr)
+                        : rook_on_sets(i_comb, j_comb, lo);
+    if (eng.overlap_hook) { // not consumed (rook path / empty matrix): run it now so the next bond still finds it
+        std::function<void()> hook;
+        hook.swap(eng.overlap_hook);
+        hook();
+    }
     const auto hp_t2 = std::chrono::steady_clock::now();
     if (b < last_sweep_shapes.size()) last_sweep_shapes[b] = {i_comb.count, j_comb.count, (size_t)lu.rank};
 
@@ -607,6 +652,8 @@ void Tci2::sweep2site(bool forward, const TCI2Options& options)
     invalidate_site_tensors();
     flush_pivot_errors();
     last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
+    prep_.valid = false;
+    prefetch_.wanted = false;
     IndexSet ei, ej; // empty extras
     if (forward) {
         for (size_t b = 0; b + 1 < n_; ++b) {
@@ -1178,11 +1225,28 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         invalidate_site_tensors();
         flush_pivot_errors();
         last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
+        prep_.valid = false;
         if (is_forward) {
-            for (size_t b = 0; b + 1 < n_; ++b) update_pivots(b, true, options, extra_i[b + 1], extra_j[b]);
+            for (size_t b = 0; b + 1 < n_; ++b) {
+                // bond b+1 reads J_{b+2}, which bond b does not touch: its column side can be built ahead
+                prefetch_.wanted = b + 2 < n_;
+                prefetch_.bond = b + 1;
+                prefetch_.cols = true;
+                prefetch_.extra = prefetch_.wanted ? &extra_j[b + 1] : nullptr;
+                update_pivots(b, true, options, extra_i[b + 1], extra_j[b]);
+            }
         } else {
-            for (size_t b = n_ - 1; b-- > 0;) update_pivots(b, false, options, extra_i[b + 1], extra_j[b]);
+            for (size_t b = n_ - 1; b-- > 0;) {
+                // bond b-1 reads I_{b-1}, which bond b does not touch: its row side can be built ahead
+                prefetch_.wanted = b > 0;
+                prefetch_.bond = b - 1;
+                prefetch_.cols = false;
+                prefetch_.extra = prefetch_.wanted ? &extra_i[b] : nullptr;
+                update_pivots(b, false, options, extra_i[b + 1], extra_j[b]);
+            }
         }
+        prefetch_.wanted = false;
+        prep_.valid = false;
         // the cores are not needed by the next half-sweep unless the global pivot search evaluates the TT
         fill_site_tensors_impl(options.nsearch == 0 && !options.strictly_nested);
         const double error = max_bond_error();

@@ -132,14 +132,33 @@ private:
     // atomically maxes bits(sqrt(v*v)) into it.
     // returns true when `zero` was handed to (and cleared by) the device evaluation kernel
     bool eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
-                     unsigned long long* d_maxbits, const ZeroJob* zero = nullptr);
+                     unsigned long long* d_maxbits, const ZeroJob* zero = nullptr,
+                     const std::vector<uint64_t>* acc_a = nullptr, const std::vector<uint64_t>* acc_b = nullptr);
     std::vector<double> eval_points_host(const std::vector<uint32_t>& idx, size_t n_pts);
     void require_fn() const;
 
     struct BondOut {
         LuciResult lu;
     };
-    LuciResult luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o, bool need_factors);
+    // One side (rows or columns) of the candidate matrix of a bond, built ahead of time: the combined index set
+    // (Kronecker product + history extras) and, for built-in functions, its integer accumulators.
+    struct SidePrep {
+        bool valid = false;
+        size_t bond = 0;
+        bool cols = false;
+        IndexSet set;
+        std::vector<uint64_t> acc;
+    };
+    SidePrep prep_;                 // filled by the overlap hook while the previous bond's kernels run
+    struct Prefetch {
+        bool wanted = false;
+        size_t bond = 0;
+        bool cols = false;
+        const IndexSet* extra = nullptr;
+    } prefetch_;                    // set by the sweep loop: which side of which bond is independent of the current one
+    void build_side(size_t bond, bool cols, const IndexSet& extra, SidePrep& out) const;
+    LuciResult luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o, bool need_factors,
+                            const std::vector<uint64_t>* acc_rows = nullptr, const std::vector<uint64_t>* acc_cols = nullptr);
     LuciResult rook_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o);
     RookWork rook_work_;
     void update_pivots(size_t b, bool left_orthogonal, const TCI2Options& options, const IndexSet& extra_i,
