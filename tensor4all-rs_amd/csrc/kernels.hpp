@@ -119,6 +119,15 @@ struct ZeroJob {
 void pi_eval_launch(const FnDevice& fn, const uint64_t* rowacc, int M, const uint64_t* colacc, int N, double* out,
                     int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream,
                     const ZeroJob& zero = ZeroJob());
+// Several independent matrices in one launch (fill_site_tensors: two per site): blockIdx.z = job.
+struct PiJob {
+    const uint64_t* rowacc;
+    const uint64_t* colacc;
+    double* out;
+    unsigned long long* max_abs_bits; // may be null
+    int M, N, ld, pad_;
+};
+void pi_eval_batched_launch(const FnDevice& fn, const PiJob* d_jobs, int n_jobs, int max_M, int max_N, hipStream_t stream);
 // max over a dense buffer of bits(sqrt(v*v)) (host-callback path)
 void absmax_launch(const double* data, size_t count, unsigned long long* max_abs_bits, hipStream_t stream);
 

@@ -55,6 +55,28 @@ __global__ void __launch_bounds__(256) pi_eval_kernel(FnDevice fn, const uint64_
     wave_absmax_commit(av, max_abs_bits);
 }
 
+__global__ void __launch_bounds__(256) pi_eval_batched_kernel(FnDevice fn, const PiJob* __restrict__ jobs)
+{
+    const PiJob jb = jobs[blockIdx.z];
+    double av = 0.0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * (int)blockDim.x >= jb.M) return; // whole block outside this (smaller) job
+    uint64_t racc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+    if (i < jb.M)
+        for (int k = 0; k < fn.n_acc; ++k) racc[k] = jb.rowacc[(size_t)i * fn.n_acc + k];
+    for (int j = blockIdx.y; j < jb.N; j += gridDim.y) {
+        if (i < jb.M) {
+            uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+            for (int k = 0; k < fn.n_acc; ++k) acc[k] = racc[k] + jb.colacc[(size_t)j * fn.n_acc + k];
+            const double v = t4a_fn_value(fn.fid, acc, fn.params);
+            jb.out[(size_t)j * jb.ld + i] = v;
+            const double a = sqrt(v * v);
+            if (a > av) av = a;
+        }
+    }
+    wave_absmax_commit(av, jb.max_abs_bits);
+}
+
 __global__ void __launch_bounds__(256) absmax_kernel(const double* __restrict__ data, size_t count,
                                                      unsigned long long* max_abs_bits)
 {
@@ -79,6 +101,14 @@ void pi_eval_launch(const FnDevice& fn, const uint64_t* rowacc, int M, const uin
     dim3 grid((M + 255) / 256, gy);
     hipLaunchKernelGGL(pi_eval_kernel, grid, block, 0, stream, fn, rowacc, M, colacc, N, out, ld,
                        transpose_out ? 1 : 0, max_abs_bits, zero);
+}
+
+void pi_eval_batched_launch(const FnDevice& fn, const PiJob* d_jobs, int n_jobs, int max_M, int max_N, hipStream_t stream)
+{
+    if (n_jobs <= 0 || max_M <= 0 || max_N <= 0) return;
+    const int gy = max_N < 512 ? max_N : 512;
+    dim3 grid((max_M + 255) / 256, gy, n_jobs);
+    hipLaunchKernelGGL(pi_eval_batched_kernel, grid, dim3(256), 0, stream, fn, d_jobs);
 }
 
 void absmax_launch(const double* data, size_t count, unsigned long long* max_abs_bits, hipStream_t stream)

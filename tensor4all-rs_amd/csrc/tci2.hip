@@ -59,6 +59,29 @@ __global__ void __launch_bounds__(256) pack_fill_core_kernel(const double* __res
     }
 }
 
+// all cores of one fill_site_tensors in a single launch (blockIdx.y = site job)
+struct PackJob {
+    const double* src;
+    double* core;
+    const int* info; // null for the last site
+    int ld, L, S, R, last, pad_;
+};
+__global__ void __launch_bounds__(256) pack_fill_batched_kernel(const PackJob* __restrict__ jobs)
+{
+    const PackJob j = jobs[blockIdx.y];
+    const size_t total = (size_t)j.L * j.S * j.R;
+    const bool zero = j.info && *j.info == -1; // numerically zero pivot matrix: zero core (tensorci2.rs:1154-1157)
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(e % j.L);
+        const int s = (int)((e / j.L) % j.S);
+        const int r = (int)(e / ((size_t)j.L * j.S));
+        if (j.last)
+            j.core[e] = j.src[(size_t)r * j.ld + (l * j.S + s)]; // Pi1 itself (tensorci2.rs:1109-1128), R == 1
+        else
+            j.core[e] = zero ? 0.0 : j.src[(size_t)(l * j.S + s) * j.ld + r]; // (tensorci2.rs:1167-1181)
+    }
+}
+
 inline unsigned blocks_for(size_t total)
 {
     size_t b = (total + 255) / 256;
@@ -848,97 +871,65 @@ void Tci2::fill_site_tensors_impl(bool async)
     }
     d_fillA_.reserve(std::max<size_t>(totA, 1));
     d_fillB_.reserve(totB);
-    d_fillmax_.reserve(n_);
-    d_fillinfo_.reserve(n_);
+    // max|P| bits (n_ u64) and solve status (n_ ints) share one allocation -> one memset
+    d_fillmax_.reserve(n_ + (n_ + 1) / 2);
+    unsigned long long* d_max = d_fillmax_.get();
+    int* d_info = reinterpret_cast<int*>(d_fillmax_.get() + n_);
     h_fillinfo_.reserve(n_);
-    T4A_HIP(hipMemsetAsync(d_fillmax_.get(), 0, n_ * sizeof(unsigned long long), st));
-    T4A_HIP(hipMemsetAsync(d_fillinfo_.get(), 0, n_ * sizeof(int), st));
+    T4A_HIP(hipMemsetAsync(d_fillmax_.get(), 0, (n_ + (n_ + 1) / 2) * sizeof(unsigned long long), st));
     fill_timed_ = eng.prof.enabled;
     if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.a, st));
 
-    // (1) evaluations.  B_b = Π1^T (nj x ni), A_b = P^T (nj x np) — evaluated directly in transposed form
-    //     (solve(P^T, Π1^T), tensorci2.rs:1160-1162).
-    double flops = 0.0;
-    if (builtin) {
-        // all accumulators of all sites: one pinned block, one host-to-device copy, then the kernels
-        const int K = fn_dev_.n_acc;
-        std::vector<uint64_t> acc_all, tmp;
-        for (SiteJob& j : jobs) {
-            IndexSet ik = kronecker_i(j.b);
-            accumulate(j_set[j.b], j.b + 1, tmp);
-            j.accJ = acc_all.size();
-            acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
-            accumulate(ik, 0, tmp);
-            j.accK = acc_all.size();
-            acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
-            if (!j.last) {
-                accumulate(i_set[j.b + 1], 0, tmp);
-                j.accI = acc_all.size();
-                acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
-            }
-        }
-        h_fillacc_.reserve(acc_all.size());
-        d_fillacc_.reserve(acc_all.size());
-        std::memcpy(h_fillacc_.get(), acc_all.data(), acc_all.size() * sizeof(uint64_t));
-        T4A_HIP(hipMemcpyAsync(d_fillacc_.get(), h_fillacc_.get(), acc_all.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        const uint64_t* da = d_fillacc_.get();
-        for (const SiteJob& j : jobs) {
-            eng.prof.v[11] += (double)j.ni * j.nj + (double)j.np * j.nj;
-            if (j.last) {
-                // last site stores Π1 itself (:1109-1128): ni x nj
-                pi_eval_launch(fn_dev_, da + j.accK, (int)j.ni, da + j.accJ, (int)j.nj, d_fillB_.get() + j.offB, (int)j.ni,
-                               false, nullptr, st);
-            } else {
-                pi_eval_launch(fn_dev_, da + j.accJ, (int)j.nj, da + j.accK, (int)j.ni, d_fillB_.get() + j.offB, (int)j.nj,
-                               false, nullptr, st);
-                pi_eval_launch(fn_dev_, da + j.accJ, (int)j.nj, da + j.accI, (int)j.np, d_fillA_.get() + j.offA, (int)j.nj,
-                               false, d_fillmax_.get() + j.b, st);
-                const double n = (double)j.np;
-                flops += (2.0 / 3.0) * n * n * n + 2.0 * n * n * (double)j.ni;
-            }
-            (void)K;
-        }
-    } else {
-        // host callback: evaluated synchronously through eval_matrix (main stream), then continue on `st`
-        for (const SiteJob& j : jobs) {
-            IndexSet ik = kronecker_i(j.b);
-            const IndexSet& jb = j_set[j.b];
-            if (j.last) {
-                eval_matrix(ik, 0, jb, ik.width, d_fillB_.get() + j.offB, nullptr);
-            } else {
-                eval_matrix(jb, j.b + 1, ik, 0, d_fillB_.get() + j.offB, nullptr);
-                eval_matrix(jb, j.b + 1, i_set[j.b + 1], 0, d_fillA_.get() + j.offA, d_fillmax_.get() + j.b);
-                const double n = (double)j.np;
-                flops += (2.0 / 3.0) * n * n * n + 2.0 * n * n * (double)j.ni;
-            }
-        }
-        T4A_HIP(hipStreamSynchronize(eng.stream()));
-        acc_used_ = 0;
+    // core shapes are known up front: allocate them now so that every device address below is final
+    for (const SiteJob& j : jobs) {
+        const size_t left_dim = (j.b == 0) ? 1 : i_set[j.b].count;
+        const size_t S = local_dims[j.b];
+        DevCore& c = cores[j.b];
+        c.l = left_dim;
+        c.s = S;
+        c.r = j.last ? 1 : j.np;
+        c.buf.reserve(std::max<size_t>(c.size(), 1));
     }
 
-    // (2) batched solve; the zero-pivot-matrix guard (:1154-1157) is evaluated on the device: lu_kernel reads
-    //     max|P| and flags info = -1, the solves skip flagged problems and the packing writes a zero core
+    // solve descriptors (device addresses only): built before the upload so that ONE host-to-device copy carries
+    // the accumulators, the evaluation jobs, the LU / triangular-solve problems and the packing jobs
     std::vector<LuProblem> lups;
     std::vector<TrsmProblem> trl, tru;
+    std::vector<PackJob> packs;
     size_t piv_total = 0;
     for (const SiteJob& j : jobs)
         if (!j.last) piv_total += j.np;
     d_fillpiv_.reserve(std::max<size_t>(piv_total, 1));
     size_t piv_off = 0;
     int max_n = 0, max_nrhs = 0;
+    size_t max_core = 1;
     fill_solved_sites_.clear();
+    double flops = 0.0;
     for (const SiteJob& j : jobs) {
+        const DevCore& c = cores[j.b];
+        PackJob pk;
+        pk.src = d_fillB_.get() + j.offB;
+        pk.core = c.buf.get();
+        pk.L = (int)c.l;
+        pk.S = (int)c.s;
+        pk.R = (int)c.r;
+        pk.last = j.last ? 1 : 0;
+        pk.ld = j.last ? (int)j.ni : (int)j.nj;
+        pk.info = j.last ? nullptr : (const int*)(d_info + j.b);
+        pk.pad_ = 0;
+        packs.push_back(pk);
+        max_core = std::max(max_core, c.size());
         if (j.last) continue;
         LuProblem lp;
         lp.A = d_fillA_.get() + j.offA;
         lp.lda = (int)j.nj;
         lp.n = (int)j.nj;
         lp.piv = d_fillpiv_.get() + piv_off;
-        lp.info = d_fillinfo_.get() + j.b;
+        lp.info = d_info + j.b;
         lp.B = d_fillB_.get() + j.offB;
         lp.ldb = (int)j.nj;
         lp.nrhs = (int)j.ni;
-        lp.pmax_bits = d_fillmax_.get() + j.b;
+        lp.pmax_bits = d_max + j.b;
         piv_off += j.np;
         lups.push_back(lp);
         TrsmProblem t;
@@ -958,47 +949,138 @@ void Tci2::fill_site_tensors_impl(bool async)
         fill_solved_sites_.push_back(j.b);
         max_n = std::max(max_n, lp.n);
         max_nrhs = std::max(max_nrhs, lp.nrhs);
+        const double n = (double)j.np;
+        flops += (2.0 / 3.0) * n * n * n + 2.0 * n * n * (double)j.ni;
     }
-    if (!lups.empty()) {
-        const size_t np_ = lups.size();
-        d_lup_.reserve(np_);
-        d_trp_.reserve(2 * np_);
-        h_fillprob_.reserve(np_ * sizeof(LuProblem) + 2 * np_ * sizeof(TrsmProblem));
-        char* hb = h_fillprob_.get();
-        std::memcpy(hb, lups.data(), np_ * sizeof(LuProblem));
-        std::memcpy(hb + np_ * sizeof(LuProblem), trl.data(), np_ * sizeof(TrsmProblem));
-        std::memcpy(hb + np_ * sizeof(LuProblem) + np_ * sizeof(TrsmProblem), tru.data(), np_ * sizeof(TrsmProblem));
-        T4A_HIP(hipMemcpyAsync(d_lup_.get(), hb, np_ * sizeof(LuProblem), hipMemcpyHostToDevice, st));
-        T4A_HIP(hipMemcpyAsync(d_trp_.get(), hb + np_ * sizeof(LuProblem), 2 * np_ * sizeof(TrsmProblem),
-                               hipMemcpyHostToDevice, st));
-        lu_batched_launch(d_lup_.get(), (int)np_, max_n, st);
-        trsm_left_batched_launch(d_trp_.get(), (int)np_, max_n, max_nrhs, st);
-        trsm_left_batched_launch(d_trp_.get() + np_, (int)np_, max_n, max_nrhs, st);
-    }
-    // (3) pack the cores
-    for (const SiteJob& j : jobs) {
-        const size_t left_dim = (j.b == 0) ? 1 : i_set[j.b].count;
-        const size_t S = local_dims[j.b];
-        DevCore& c = cores[j.b];
-        if (j.last) {
-            c.buf.reserve(left_dim * S);
-            c.l = left_dim;
-            c.s = S;
-            c.r = 1;
-            hipLaunchKernelGGL(pack_left_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, st,
-                               d_fillB_.get() + j.offB, (int)j.ni, (int)j.ni, 1, c.buf.get(), (int)left_dim, (int)S, 1);
-        } else {
-            c.buf.reserve(left_dim * S * j.np);
-            c.l = left_dim;
-            c.s = S;
-            c.r = j.np;
-            hipLaunchKernelGGL(pack_fill_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, st,
-                               d_fillB_.get() + j.offB, (int)j.nj, c.buf.get(), (int)left_dim, (int)S, (int)j.np,
-                               (const int*)(d_fillinfo_.get() + j.b));
+    const size_t np_ = lups.size();
+    const size_t bytes_lu = np_ * sizeof(LuProblem), bytes_tr = 2 * np_ * sizeof(TrsmProblem);
+    const size_t bytes_pk = packs.size() * sizeof(PackJob);
+    auto up8 = [](size_t v) { return (v + 7) / 8 * 8; };
+
+    // (1) evaluations.  B_b = Pi1^T (nj x ni), A_b = P^T (nj x np) — evaluated directly in transposed form
+    //     (solve(P^T, Pi1^T), tensorci2.rs:1160-1162).
+    const LuProblem* d_lups = nullptr;
+    const TrsmProblem* d_trs = nullptr;
+    const PackJob* d_packs = nullptr;
+    if (builtin) {
+        std::vector<uint64_t> acc_all, tmp;
+        for (SiteJob& j : jobs) {
+            IndexSet ik = kronecker_i(j.b);
+            accumulate(j_set[j.b], j.b + 1, tmp);
+            j.accJ = acc_all.size();
+            acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
+            accumulate(ik, 0, tmp);
+            j.accK = acc_all.size();
+            acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
+            if (!j.last) {
+                accumulate(i_set[j.b + 1], 0, tmp);
+                j.accI = acc_all.size();
+                acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
+            }
         }
+        const size_t bytes_acc = acc_all.size() * sizeof(uint64_t);
+        const size_t n_pi = 2 * jobs.size();
+        const size_t off_pi = up8(bytes_acc), off_lu = up8(off_pi + n_pi * sizeof(PiJob));
+        const size_t off_tr = up8(off_lu + bytes_lu), off_pk = up8(off_tr + bytes_tr);
+        const size_t total_bytes = up8(off_pk + bytes_pk);
+        h_fillacc_.reserve(total_bytes / 8);
+        d_fillacc_.reserve(total_bytes / 8);
+        char* hb = reinterpret_cast<char*>(h_fillacc_.get());
+        char* db = reinterpret_cast<char*>(d_fillacc_.get());
+        const uint64_t* da = d_fillacc_.get();
+        std::memcpy(hb, acc_all.data(), bytes_acc);
+        std::vector<PiJob> pis;
+        int max_M = 0, max_N = 0;
+        for (const SiteJob& j : jobs) {
+            eng.prof.v[11] += (double)j.ni * j.nj + (double)j.np * j.nj;
+            PiJob q;
+            q.pad_ = 0;
+            if (j.last) { // last site stores Pi1 itself (:1109-1128): ni x nj
+                q.rowacc = da + j.accK;
+                q.M = (int)j.ni;
+                q.colacc = da + j.accJ;
+                q.N = (int)j.nj;
+                q.out = d_fillB_.get() + j.offB;
+                q.ld = (int)j.ni;
+                q.max_abs_bits = nullptr;
+                pis.push_back(q);
+            } else {
+                q.rowacc = da + j.accJ;
+                q.M = (int)j.nj;
+                q.colacc = da + j.accK;
+                q.N = (int)j.ni;
+                q.out = d_fillB_.get() + j.offB;
+                q.ld = (int)j.nj;
+                q.max_abs_bits = nullptr;
+                pis.push_back(q);
+                q.colacc = da + j.accI;
+                q.N = (int)j.np;
+                q.out = d_fillA_.get() + j.offA;
+                q.max_abs_bits = d_max + j.b;
+                pis.push_back(q);
+            }
+        }
+        for (const PiJob& q : pis) {
+            max_M = std::max(max_M, q.M);
+            max_N = std::max(max_N, q.N);
+        }
+        std::memcpy(hb + off_pi, pis.data(), pis.size() * sizeof(PiJob));
+        if (np_) {
+            std::memcpy(hb + off_lu, lups.data(), bytes_lu);
+            std::memcpy(hb + off_tr, trl.data(), np_ * sizeof(TrsmProblem));
+            std::memcpy(hb + off_tr + np_ * sizeof(TrsmProblem), tru.data(), np_ * sizeof(TrsmProblem));
+        }
+        std::memcpy(hb + off_pk, packs.data(), bytes_pk);
+        T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st));
+        pi_eval_batched_launch(fn_dev_, reinterpret_cast<const PiJob*>(db + off_pi), (int)pis.size(), max_M, max_N, st);
+        d_lups = reinterpret_cast<const LuProblem*>(db + off_lu);
+        d_trs = reinterpret_cast<const TrsmProblem*>(db + off_tr);
+        d_packs = reinterpret_cast<const PackJob*>(db + off_pk);
+    } else {
+        // host callback: evaluated synchronously through eval_matrix (main stream), then continue on `st`
+        for (const SiteJob& j : jobs) {
+            IndexSet ik = kronecker_i(j.b);
+            const IndexSet& jb = j_set[j.b];
+            if (j.last) {
+                eval_matrix(ik, 0, jb, ik.width, d_fillB_.get() + j.offB, nullptr);
+            } else {
+                eval_matrix(jb, j.b + 1, ik, 0, d_fillB_.get() + j.offB, nullptr);
+                eval_matrix(jb, j.b + 1, i_set[j.b + 1], 0, d_fillA_.get() + j.offA, d_max + j.b);
+            }
+        }
+        T4A_HIP(hipStreamSynchronize(eng.stream()));
+        acc_used_ = 0;
+        const size_t off_tr = up8(bytes_lu), off_pk = up8(off_tr + bytes_tr), total_bytes = up8(off_pk + bytes_pk);
+        h_fillacc_.reserve(total_bytes / 8 + 1);
+        d_fillacc_.reserve(total_bytes / 8 + 1);
+        char* hb = reinterpret_cast<char*>(h_fillacc_.get());
+        char* db = reinterpret_cast<char*>(d_fillacc_.get());
+        if (np_) {
+            std::memcpy(hb, lups.data(), bytes_lu);
+            std::memcpy(hb + off_tr, trl.data(), np_ * sizeof(TrsmProblem));
+            std::memcpy(hb + off_tr + np_ * sizeof(TrsmProblem), tru.data(), np_ * sizeof(TrsmProblem));
+        }
+        std::memcpy(hb + off_pk, packs.data(), bytes_pk);
+        T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st));
+        d_lups = reinterpret_cast<const LuProblem*>(db);
+        d_trs = reinterpret_cast<const TrsmProblem*>(db + off_tr);
+        d_packs = reinterpret_cast<const PackJob*>(db + off_pk);
+    }
+
+    // (2) batched solve; the zero-pivot-matrix guard (:1154-1157) is evaluated on the device: lu_kernel reads
+    //     max|P| and flags info = -1, the solves skip flagged problems and the packing writes a zero core
+    if (np_) {
+        lu_batched_launch(d_lups, (int)np_, max_n, st);
+        trsm_left_batched_launch(d_trs, (int)np_, max_n, max_nrhs, st);
+        trsm_left_batched_launch(d_trs + np_, (int)np_, max_n, max_nrhs, st);
+    }
+    // (3) pack all cores in one launch
+    {
+        dim3 grid(blocks_for(max_core) > 64 ? 64 : blocks_for(max_core), (unsigned)packs.size());
+        hipLaunchKernelGGL(pack_fill_batched_kernel, grid, dim3(256), 0, st, d_packs);
     }
     if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.b, st));
-    T4A_HIP(hipMemcpyAsync(h_fillinfo_.get(), d_fillinfo_.get(), n_ * sizeof(int), hipMemcpyDeviceToHost, st));
+    T4A_HIP(hipMemcpyAsync(h_fillinfo_.get(), d_info, n_ * sizeof(int), hipMemcpyDeviceToHost, st));
     eng.prof.v[10] += flops;
     fill_inflight_ = true;
     if (!async) fill_wait();
