@@ -168,6 +168,10 @@ struct LuProblem {
     const unsigned long long* pmax_bits; // optional: bits of max|a_ij|; below EPS the problem is flagged info = -1
 };
 void lu_batched_launch(const LuProblem* d_problems, int n_problems, int max_n, hipStream_t stream);
+// Blocked variant that also applies the forward substitution to the right-hand sides: A = P^T L U, B <- L^{-1} P B
+// (bitwise the result of lu_batched_launch followed by the unit-lower triangular solve).  Returns false when
+// max_n > 1024 (nothing was launched; use the two-step path).
+bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream);
 
 // gather rows/cols:  out[i + ldo*j] = in[rows[i] + ldi*cols[j]] (rows/cols may be nullptr = identity)
 void gather_launch(const double* in, int ldi, const int* rows, int nrows, const int* cols, int ncols, double* out,

@@ -318,6 +318,200 @@ __global__ void __launch_bounds__(1024) lu_kernel(const LuProblem* problems)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Blocked partial-pivot LU with the forward substitution of the right-hand sides folded in:
+//   A = P^T L U in place,   B <- L^{-1} P B.
+// Right-looking over column panels of width nb; per panel one `lu_panel_kernel` launch (one workgroup per problem
+// factors the m x w panel in LDS) and one `lu_update_kernel` launch (one workgroup per nb-wide column tile of [A | B]:
+// applies the panel's row swaps, then the w rank-1 updates of its columns with the L panel held in LDS).  Every
+// element sees exactly the update sequence of the unblocked algorithm (k ascending, separately rounded multiply and
+// subtract), so the factors are bitwise those of `lu_kernel` followed by the unit-lower `trsm_left_kernel`.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lu_panel_kernel(const LuProblem* problems, int kb, int nb)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ double red_v[4];
+    __shared__ int red_i[4];
+    __shared__ int piv_s;
+    __shared__ double pivval_s;
+    const LuProblem pr = problems[blockIdx.x];
+    const int n = pr.n;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    if (kb == 0) {
+        if (pr.pmax_bits) { // zero-pivot-matrix guard (tensorci2.rs:1154-1157): every |p| < EPS
+            const double pmax = __longlong_as_double((long long)*pr.pmax_bits);
+            if (pmax < 2.220446049250313e-16) {
+                if (tid == 0) pr.info[0] = -1;
+                return;
+            }
+        }
+        if (tid == 0) pr.info[0] = 0;
+    } else if (pr.info[0] == -1) {
+        return;
+    }
+    if (kb >= n) return;
+    const int m = n - kb, w = (n - kb) < nb ? (n - kb) : nb;
+    const int ldp = m | 1; // odd leading dimension: conflict-free row and column walks
+    double* P = (double*)smem_raw;
+    double* A = pr.A;
+    const int lda = pr.lda;
+    for (int e = tid; e < m * w; e += T) {
+        const int i = e % m, c = e / m;
+        P[(size_t)c * ldp + i] = A[(size_t)(kb + c) * lda + kb + i];
+    }
+    __syncthreads();
+    for (int j = 0; j < w; ++j) {
+        double bv = -1.0;
+        int bi = 0x7fffffff;
+        for (int i = j + tid; i < m; i += T) {
+            const double v = fabs(P[(size_t)j * ldp + i]);
+            if (v > bv || (v == bv && i < bi)) {
+                bv = v;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            red_v[wave] = bv;
+            red_i[wave] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double v = red_v[0];
+            int idx = red_i[0];
+            for (int q = 1; q < nw; ++q)
+                if (red_v[q] > v || (red_v[q] == v && red_i[q] < idx)) {
+                    v = red_v[q];
+                    idx = red_i[q];
+                }
+            piv_s = idx;
+            pr.piv[kb + j] = kb + idx;
+            if (!(v > 0.0)) {
+                if (pr.info[0] == 0) pr.info[0] = kb + j + 1;
+            }
+        }
+        __syncthreads();
+        const int p = piv_s;
+        if (p != j && p < m)
+            for (int c = tid; c < w; c += T) {
+                const double t = P[(size_t)c * ldp + j];
+                P[(size_t)c * ldp + j] = P[(size_t)c * ldp + p];
+                P[(size_t)c * ldp + p] = t;
+            }
+        __syncthreads();
+        if (tid == 0) pivval_s = P[(size_t)j * ldp + j];
+        __syncthreads();
+        const double piv = pivval_s;
+        if (piv == 0.0 || piv != piv) continue; // singular column: left as it is (info already set)
+        for (int i = j + 1 + tid; i < m; i += T) P[(size_t)j * ldp + i] = P[(size_t)j * ldp + i] / piv;
+        __syncthreads();
+        const int remr = m - j - 1, remc = w - j - 1;
+        for (int e = tid; e < remr * remc; e += T) {
+            const int i = j + 1 + e % remr, c = j + 1 + e / remr;
+            const double prod = P[(size_t)j * ldp + i] * P[(size_t)c * ldp + j];
+            P[(size_t)c * ldp + i] = P[(size_t)c * ldp + i] - prod;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < m * w; e += T) {
+        const int i = e % m, c = e / m;
+        A[(size_t)(kb + c) * lda + kb + i] = P[(size_t)c * ldp + i];
+    }
+}
+
+__global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problems, int kb, int nb)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const LuProblem pr = problems[blockIdx.y];
+    const int n = pr.n;
+    if (kb >= n || pr.info[0] == -1) return;
+    // tiles: ceil(n / nb) tiles over the columns of A, then ceil(nrhs / nb) tiles over the columns of B
+    const int ta = (n + nb - 1) / nb;
+    const int nrhs = pr.B ? pr.nrhs : 0;
+    const int t = blockIdx.x;
+    const bool in_a = t < ta;
+    const int c0 = in_a ? t * nb : (t - ta) * nb; // first column inside A resp. B
+    if (!in_a && c0 >= nrhs) return;
+    if (in_a && c0 == kb) return;                 // the panel itself
+    const int m = n - kb, w = (n - kb) < nb ? (n - kb) : nb;
+    const int lim = in_a ? n : nrhs;
+    const int tc = (lim - c0) < nb ? (lim - c0) : nb;
+    const bool left = in_a && c0 < kb;            // columns of L already final: row swaps only
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int ldp = m | 1;
+    double* L = (double*)smem_raw;               // m x w panel (L below, U11 on / above its diagonal)
+    double* Tt = L + (size_t)ldp * nb;           // m x tc tile
+    // column c of the tile in global memory (rows kb..n-1)
+    auto gcol = [&](int c) -> double* {
+        return in_a ? pr.A + (size_t)(c0 + c) * pr.lda + kb : pr.B + (size_t)(c0 + c) * pr.ldb + kb;
+    };
+    for (int c = 0; c < tc; ++c) {
+        double* g = gcol(c);
+        for (int i = tid; i < m; i += T) Tt[(size_t)c * ldp + i] = g[i];
+    }
+    if (!left)
+        for (int e = tid; e < m * w; e += T) {
+            const int i = e % m, c = e / m;
+            L[(size_t)c * ldp + i] = pr.A[(size_t)(kb + c) * pr.lda + kb + i];
+        }
+    __syncthreads();
+    // (a) the panel's row swaps, in order
+    if (tid < tc) {
+        double* col = Tt + (size_t)tid * ldp;
+        for (int j = 0; j < w; ++j) {
+            const int p = pr.piv[kb + j] - kb;
+            if (p != j && p >= 0 && p < m) {
+                const double t = col[j];
+                col[j] = col[p];
+                col[p] = t;
+            }
+        }
+    }
+    __syncthreads();
+    if (!left) {
+        // (b) rows kb..kb+w-1 of U (and of L^{-1} P B): forward substitution with the unit lower L11, k ascending
+        for (int j = 0; j < w; ++j) {
+            const double piv = L[(size_t)j * ldp + j];
+            if (!(piv == 0.0 || piv != piv)) { // a singular column was skipped by the panel kernel as well
+                const int cnt = w - j - 1;
+                for (int e = tid; e < cnt * tc; e += T) {
+                    const int i = j + 1 + e % cnt, c = e / cnt;
+                    const double prod = L[(size_t)j * ldp + i] * Tt[(size_t)c * ldp + j];
+                    Tt[(size_t)c * ldp + i] = Tt[(size_t)c * ldp + i] - prod;
+                }
+            }
+            __syncthreads();
+        }
+        // (c) trailing rows: w rank-1 updates per element, k ascending
+        const int rem = m - w;
+        for (int e = tid; e < rem * tc; e += T) {
+            const int i = w + e % rem, c = e / rem;
+            double t = Tt[(size_t)c * ldp + i];
+            for (int j = 0; j < w; ++j) {
+                const double piv = L[(size_t)j * ldp + j];
+                if (piv == 0.0 || piv != piv) continue;
+                const double prod = L[(size_t)j * ldp + i] * Tt[(size_t)c * ldp + j];
+                t = t - prod;
+            }
+            Tt[(size_t)c * ldp + i] = t;
+        }
+        __syncthreads();
+    }
+    for (int c = 0; c < tc; ++c) {
+        double* g = gcol(c);
+        for (int i = tid; i < m; i += T) g[i] = Tt[(size_t)c * ldp + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched TT evaluation: one workgroup per point, v <- v * A_s[:, idx_s, :] left to right with the
 // reference's summation order (l ascending, separately rounded multiply/add).
 // ------------------------------------------------------------------------------------------------
@@ -434,6 +628,35 @@ void lu_batched_launch(const LuProblem* d_problems, int n_problems, int max_n, h
     if (n_problems <= 0) return;
     int T = max_n >= 128 ? 1024 : (max_n >= 32 ? 256 : 64);
     hipLaunchKernelGGL(lu_kernel, dim3(n_problems), dim3(T), 0, stream, d_problems);
+}
+
+bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream)
+{
+    if (n_problems <= 0 || max_n <= 0) return true;
+    int nb;
+    if (max_n <= 256) nb = 32;
+    else if (max_n <= 512) nb = 16;
+    else if (max_n <= 1024) nb = 8;
+    else return false; // panel does not fit the LDS: the caller falls back to lu_kernel + trsm
+    static bool attr_set = false;
+    if (!attr_set) {
+        // (the panel kernel also has a few static LDS words: stay below the 160 KiB total)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_panel_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_update_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    const int ldp = max_n | 1;
+    const size_t lds_panel = (size_t)ldp * nb * 8;
+    const size_t lds_update = (size_t)ldp * nb * 8 * 2;
+    const int tiles = (max_n + nb - 1) / nb + (max_nrhs + nb - 1) / nb + 1;
+    for (int kb = 0; kb < max_n; kb += nb) {
+        hipLaunchKernelGGL(lu_panel_kernel, dim3(n_problems), dim3(256), lds_panel, stream, d_problems, kb, nb);
+        hipLaunchKernelGGL(lu_update_kernel, dim3(tiles, n_problems), dim3(256), lds_update, stream, d_problems, kb, nb);
+    }
+    return true;
 }
 
 void tt_evaluate_launch(const TtCoreDesc* d_cores, int n_sites, int max_bond, const uint32_t* d_idx, int n_pts,

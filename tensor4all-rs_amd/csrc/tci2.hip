@@ -1070,8 +1070,12 @@ void Tci2::fill_site_tensors_impl(bool async)
     // (2) batched solve; the zero-pivot-matrix guard (:1154-1157) is evaluated on the device: lu_kernel reads
     //     max|P| and flags info = -1, the solves skip flagged problems and the packing writes a zero core
     if (np_) {
-        lu_batched_launch(d_lups, (int)np_, max_n, st);
-        trsm_left_batched_launch(d_trs, (int)np_, max_n, max_nrhs, st);
+        // blocked LU with the unit-lower forward substitution of the right-hand sides folded in; beyond its size limit
+        // the unblocked kernel + explicit forward solve (bitwise the same result)
+        if (!lu_forward_blocked_launch(d_lups, (int)np_, max_n, max_nrhs, st)) {
+            lu_batched_launch(d_lups, (int)np_, max_n, st);
+            trsm_left_batched_launch(d_trs, (int)np_, max_n, max_nrhs, st);
+        }
         trsm_left_batched_launch(d_trs + np_, (int)np_, max_n, max_nrhs, st);
     }
     // (3) pack all cores in one launch
