@@ -9,6 +9,8 @@
 // "first maximum of |a_ik|".  Built with -ffp-contract=off so the non-MFMA kernels round like the CPU oracle.
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace t4a {
 
 namespace {
@@ -617,6 +619,12 @@ void trsm_left_batched_launch(const TrsmProblem* d_problems, int n_problems, int
     }
     int cw = (int)((128 * 1024) / ((size_t)max_n * 8));
     if (cw > 32) cw = 32;
+    // the substitution is a chain of max_n dependent steps per workgroup: prefer many thin column chunks (>= ~2000
+    // workgroups in flight) over few wide ones
+    static const int cw_env = std::getenv("T4A_TRSM_CW") ? std::atoi(std::getenv("T4A_TRSM_CW")) : 0;
+    const long long total_cols = (long long)n_problems * max_nrhs;
+    while (cw > 4 && total_cols / cw < 2048) cw /= 2;
+    if (cw_env > 0) cw = cw_env;
     if (cw < 1) cw = 1;
     const size_t lds = (size_t)max_n * cw * 8;
     dim3 grid((max_nrhs + cw - 1) / cw, n_problems);
