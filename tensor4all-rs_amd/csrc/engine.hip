@@ -112,7 +112,8 @@ ZeroJob Engine::prepare_zero(int M, int N, const RrLUOptions& opts)
     return z;
 }
 
-LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy)
+LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy,
+                        const FusedPi* fused)
 {
     LuciResult r;
     r.M = M;
@@ -169,12 +170,21 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     const int kM = left ? M : N, kN = left ? N : M;
     RrluRegPlan rplan;
     const bool use_reg = !force_lds && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
+    bool fuse = false;
+    if (fused) {
+        fuse = use_reg && rplan.RPT * rplan.CPT <= RRLU_FUSED_MAX_VALUES;
+        if (!fuse) { // this plan cannot build the matrix in registers: materialise it like the Π kernel would
+            double* buf = pi((size_t)M * N);
+            pi_eval_launch(fused->fn, fused->d_rowacc, M, fused->d_colacc, N, buf, M, false, nullptr, stream_);
+            d_a = buf;
+        }
+    }
     int plan_W = 1, plan_T = 0, plan_code = 0;
     bool mirrored = false;
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.a, stream_));
     if (use_reg) {
         const double* src = d_a;
-        if (!left) {
+        if (!left && !fuse) {
             d_at_.reserve((size_t)M * N);
             transpose_launch(d_a, M, N, M, d_at_.get(), N, stream_);
             src = d_at_.get();
@@ -226,6 +236,16 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
         // results land in the pinned mirror straight from the kernel: no device-to-host copy afterwards
         std::memset(h_out_.get(), 0, 32);
+        a.fused = fuse ? 1 : 0;
+        if (fuse) { // the kernel's rows are the matrix rows (left) or the matrix columns (right-orthogonal = transposed)
+            a.rowacc = left ? fused->d_rowacc : fused->d_colacc;
+            a.colacc = left ? fused->d_colacc : fused->d_rowacc;
+            a.fn = fused->fn;
+        } else {
+            a.rowacc = nullptr;
+            a.colacc = nullptr;
+            std::memset(&a.fn, 0, sizeof(a.fn));
+        }
         a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());
         a.block_u64 = (int)(out_bytes / 8);
         mirrored = true;

@@ -31,6 +31,14 @@ struct LuciResult {
     bool has_factors = false;              // d_left (M x rank), d_right (rank x N) valid on the engine
 };
 
+// Candidate matrix given implicitly: entry (i, j) = fn(rowacc[i] + colacc[j]) (device accumulators [count][n_acc]).
+// The register-resident rrLU kernel builds it straight into its registers; other paths materialise it first.
+struct FusedPi {
+    FnDevice fn;
+    const uint64_t* d_rowacc;
+    const uint64_t* d_colacc;
+};
+
 struct Profile {
     double v[T4A_GPU_PROFILE_SLOTS] = {0};
     bool enabled = false;
@@ -64,7 +72,9 @@ public:
 
     // Runs rrLU on the M x N column-major matrix at d_a (device) and optionally builds the LUCI factors.
     // `want_lu_copy` additionally keeps the factored matrix (permuted coordinates) in lu_buf().
-    LuciResult luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy);
+    // `fused` != nullptr: d_a is ignored (may be null) and the matrix is defined by the accumulators.
+    LuciResult luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy,
+                    const FusedPi* fused = nullptr);
 
     // see engine.hip: fused clearing of the buffers the next luci() call needs zeroed
     ZeroJob prepare_zero(int M, int N, const RrLUOptions& opts);

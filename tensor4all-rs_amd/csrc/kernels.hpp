@@ -54,8 +54,16 @@ size_t rrlu_cols_bytes(const RrluPlan& plan, int M);
 // Enqueue memset of the key mailbox + the kernel.
 void rrlu_launch(const RrluPlan& plan, const RrluArgs& args, hipStream_t stream);
 
+// built-in device functor (include/t4a_testfunctions.h): id, number of integer accumulators, parameters
+struct FnDevice {
+    int fid;
+    int n_acc;
+    double params[T4A_FN_MAX_PARAMS];
+};
+
 // ---- register-resident fast path (kernels_rrlu_reg.hip): left-orthogonal elimination only ----
 constexpr int RRLU_MAX_COPIES = 8;
+constexpr int RRLU_FUSED_MAX_VALUES = 16; // fused Π build only for plans with RPT * CPT <= this
 struct RrluRegPlan {
     int W = 1, T = 256;
     int TR = 256, TC = 1;   // thread grid inside a workgroup: rows x column groups
@@ -90,6 +98,12 @@ struct RrluRegArgs {
     // of the kernel and the flag setters write their flags directly, so no device-to-host copy is needed afterwards
     unsigned long long* h_block;
     int block_u64;
+    // fused candidate-matrix build: when `fused` != 0 the kernel never reads A; entry (i, j) of ITS row / column
+    // numbering is fn(rowacc[i] + colacc[j]) (accumulators [count][fn.n_acc] uint64, see kernels_pi.hip)
+    int fused;
+    const uint64_t* rowacc;
+    const uint64_t* colacc;
+    FnDevice fn;
 };
 // false if the shape is outside the fast path (fall back to the LDS kernel)
 bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out);
@@ -103,11 +117,6 @@ void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& args, hipStream
 // out[i + ld*j] = g(rowacc[i] + colacc[j]); *max_abs_bits = max over entries of bits(sqrt(v*v)).
 // rowacc/colacc are [count][n_acc] uint64.  If `transpose_out`, writes out[j + ld*i].
 // ------------------------------------------------------------------------------------------------
-struct FnDevice {
-    int fid;
-    int n_acc;
-    double params[T4A_FN_MAX_PARAMS];
-};
 // Two small buffers (counts in 64-bit words) that block (0,0) of the Π kernel clears on the way: lets the caller
 // drop the separate memsets of the rrLU result header and key table (one dispatch + gap each per bond).
 struct ZeroJob {

@@ -234,18 +234,49 @@ rrlu_reg_kernel(RrluRegArgs p)
     }
     double a[CPT][RPT];
     double local_absmax = 0.0;
+    if (RPT * CPT <= RRLU_FUSED_MAX_VALUES && p.fused) { // (larger slabs spill around the inlined functor)
+        // the candidate matrix is built straight into the registers (tensorci2.rs:1859-1893): no Π in memory at all
+        const int K = p.fn.n_acc;
+        uint64_t racc[RPT][T4A_FN_MAX_ACC];
 #pragma unroll
-    for (int q = 0; q < CPT; ++q)
+        for (int r = 0; r < RPT; ++r)
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            double v = 0.0;
-            if (ccol[q] >= 0 && irow[r] >= 0) {
-                v = p.A[(size_t)ccol[q] * p.M + irow[r]];
-                const double av = sqrt(v * v);
-                if (av > local_absmax) local_absmax = av;
+            for (int k = 0; k < T4A_FN_MAX_ACC; ++k)
+                racc[r][k] = (irow[r] >= 0 && k < K) ? p.rowacc[(size_t)irow[r] * K + k] : 0ull;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            uint64_t cacc[T4A_FN_MAX_ACC];
+#pragma unroll
+            for (int k = 0; k < T4A_FN_MAX_ACC; ++k)
+                cacc[k] = (ccol[q] >= 0 && k < K) ? p.colacc[(size_t)ccol[q] * K + k] : 0ull;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                double v = 0.0;
+                if (ccol[q] >= 0 && irow[r] >= 0) {
+                    uint64_t acc[T4A_FN_MAX_ACC];
+#pragma unroll
+                    for (int k = 0; k < T4A_FN_MAX_ACC; ++k) acc[k] = racc[r][k] + cacc[k];
+                    v = t4a_fn_value(p.fn.fid, acc, p.fn.params);
+                    const double av = sqrt(v * v);
+                    if (av > local_absmax) local_absmax = av;
+                }
+                a[q][r] = v;
             }
-            a[q][r] = v;
         }
+    } else {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q)
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                double v = 0.0;
+                if (ccol[q] >= 0 && irow[r] >= 0) {
+                    v = p.A[(size_t)ccol[q] * p.M + irow[r]];
+                    const double av = sqrt(v * v);
+                    if (av > local_absmax) local_absmax = av;
+                }
+                a[q][r] = v;
+            }
+    }
     for (int i = tid; i < p.M; i += T) s.posrow[i] = (unsigned short)i;
     for (int j = tid; j < p.N; j += T) s.poscol[j] = (unsigned short)j;
     if (tid == 0) s.win_i[2] = 0;

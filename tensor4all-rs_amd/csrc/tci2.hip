@@ -348,6 +348,36 @@ void Tci2::accumulate(const IndexSet& set, size_t first_site, std::vector<uint64
     }
 }
 
+// Accumulators of both index sets -> pinned arena -> device (one asynchronous copy on the main stream).
+void Tci2::stage_accumulators(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, const std::vector<uint64_t>* acc_a,
+                              const std::vector<uint64_t>* acc_b, const uint64_t** d_ra, const uint64_t** d_rb)
+{
+    hipStream_t st = eng.stream();
+    const size_t K = (size_t)fn_dev_.n_acc;
+    std::vector<uint64_t> ra_own, rb_own;
+    if (!acc_a) accumulate(a, a0, ra_own);
+    if (!acc_b) accumulate(b, b0, rb_own);
+    const std::vector<uint64_t>& ra = acc_a ? *acc_a : ra_own;
+    const std::vector<uint64_t>& rb = acc_b ? *acc_b : rb_own;
+    if (ra.size() != a.count * K || rb.size() != b.count * K)
+        throw Error(T4A_GPU_INTERNAL_ERROR, "prepared accumulators have the wrong size");
+    // pinned staging arena: entries stay valid until the next stream sync
+    const size_t need = ra.size() + rb.size();
+    if (acc_used_ + need > h_acc_.cap) {
+        T4A_HIP(hipStreamSynchronize(st));
+        acc_used_ = 0;
+        h_acc_.reserve(std::max(need * 2, (size_t)1 << 16));
+    }
+    uint64_t* ha = h_acc_.get() + acc_used_;
+    acc_used_ += need;
+    std::memcpy(ha, ra.data(), ra.size() * sizeof(uint64_t));
+    std::memcpy(ha + ra.size(), rb.data(), rb.size() * sizeof(uint64_t));
+    d_rowacc_.reserve(need);
+    T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ha, need * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    *d_ra = d_rowacc_.get();
+    *d_rb = d_rowacc_.get() + ra.size();
+}
+
 // out[ia + a.count*ib] = f(index with a's digits at sites [a0, a0+a.width) and b's at [b0, b0+b.width))
 bool Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
                        unsigned long long* d_maxbits, const ZeroJob* zero, const std::vector<uint64_t>* acc_a,
@@ -360,32 +390,10 @@ bool Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
     hipStream_t st = eng.stream();
     eng.prof.v[11] += (double)na * (double)nb;
     if (fn_kind_ == FnKind::Builtin) {
-        const int K = fn_dev_.n_acc;
-        std::vector<uint64_t> ra_own, rb_own;
-        if (!acc_a) accumulate(a, a0, ra_own);
-        if (!acc_b) accumulate(b, b0, rb_own);
-        const std::vector<uint64_t>& ra = acc_a ? *acc_a : ra_own;
-        const std::vector<uint64_t>& rb = acc_b ? *acc_b : rb_own;
-        if (ra.size() != na * (size_t)K || rb.size() != nb * (size_t)K)
-            throw Error(T4A_GPU_INTERNAL_ERROR, "eval_matrix: prepared accumulators have the wrong size");
-        // pinned staging arena: entries stay valid until the next stream sync
-        const size_t need = ra.size() + rb.size();
-        if (acc_used_ + need > h_acc_.cap) {
-            T4A_HIP(hipStreamSynchronize(st));
-            acc_used_ = 0;
-            h_acc_.reserve(std::max(need * 2, (size_t)1 << 16));
-        }
-        uint64_t* ha = h_acc_.get() + acc_used_;
-        uint64_t* hb = ha + ra.size();
-        acc_used_ += need;
-        std::memcpy(ha, ra.data(), ra.size() * sizeof(uint64_t));
-        std::memcpy(hb, rb.data(), rb.size() * sizeof(uint64_t));
-        d_rowacc_.reserve(need);
-        T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ha, need * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        (void)K;
-        (void)hb;
-        pi_eval_launch(fn_dev_, d_rowacc_.get(), (int)na, d_rowacc_.get() + ra.size(), (int)nb, d_out, (int)na, false,
-                       d_maxbits, st, zero ? *zero : ZeroJob());
+        const uint64_t *d_ra = nullptr, *d_rb = nullptr;
+        stage_accumulators(a, a0, b, b0, acc_a, acc_b, &d_ra, &d_rb);
+        pi_eval_launch(fn_dev_, d_ra, (int)na, d_rb, (int)nb, d_out, (int)na, false, d_maxbits, st,
+                       zero ? *zero : ZeroJob());
         T4A_HIP(hipGetLastError());
         return zero != nullptr;
     } else {
@@ -455,8 +463,20 @@ LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
                               const std::vector<uint64_t>* acc_rows, const std::vector<uint64_t>* acc_cols)
 {
     const size_t M = is.count, N = js.count;
-    double* d_pi = eng.pi(M * N);
     hipStream_t st = eng.stream();
+    static const bool no_fuse = std::getenv("T4A_NO_FUSED_PI") != nullptr;
+    if (fn_kind_ == FnKind::Builtin && !no_fuse && M > 0 && N > 0) {
+        // built-in functor: only the accumulators travel; the rrLU kernel evaluates Pi into its registers
+        FusedPi fp;
+        fp.fn = fn_dev_;
+        stage_accumulators(is, 0, js, is.width, acc_rows, acc_cols, &fp.d_rowacc, &fp.d_colacc);
+        eng.prof.v[11] += (double)M * (double)N;
+        LuciResult lu = eng.luci(nullptr, (int)M, (int)N, o, need_factors, false, &fp);
+        acc_used_ = 0;
+        if (lu.abs_max > max_sample_value) max_sample_value = lu.abs_max;
+        return lu;
+    }
+    double* d_pi = eng.pi(M * N);
     static const bool host_prof = std::getenv("T4A_HOST_PROFILE") != nullptr;
     static double hp_eval = 0;
     static long hp_n = 0;
