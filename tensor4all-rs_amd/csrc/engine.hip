@@ -77,39 +77,13 @@ Engine::~Engine()
 // them to the kernel it launches right before (pi_eval_launch) instead.  Only for the register-resident rrLU path.
 ZeroJob Engine::prepare_zero(int M, int N, const RrLUOptions& opts)
 {
-    ZeroJob z;
+    // The register-resident kernel now leaves its result header and the next key table clean itself (see the end of
+    // rrlu_reg_kernel), so there is nothing left to fold into the evaluation kernel.
+    (void)M;
+    (void)N;
+    (void)opts;
     prezero_valid_ = false;
-    if (M <= 0 || N <= 0 || M > 65535 || N > 65535) return z;
-    static const bool force_lds = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "lds";
-    const bool left = opts.left_orthogonal;
-    const int kM = left ? M : N, kN = left ? N : M;
-    RrluRegPlan rplan;
-    if (force_lds || !rrlu_reg_make_plan(kM, kN, num_cus_, &rplan)) return z;
-    size_t ms = opts.max_bond_dim;
-    if (ms > (size_t)M) ms = M;
-    if (ms > (size_t)N) ms = N;
-    const size_t out_bytes = (32 + sizeof(double) * (ms > 0 ? ms : 1) + sizeof(int) * ((size_t)M + N) + 7) / 8 * 8;
-    d_out_.reserve(out_bytes);
-    h_out_.reserve(out_bytes);
-    z.p0 = reinterpret_cast<unsigned long long*>(d_out_.get());
-    z.n0 = 4;
-    if (rplan.W > 1) {
-        const size_t need_keys = rrlu_reg_keys_bytes(rplan) / sizeof(unsigned long long);
-        const size_t need_cols = rrlu_reg_cols_bytes(rplan, kM) / sizeof(unsigned long long);
-        if (need_keys > d_rkeys_.cap || need_cols > d_rcols_.cap) { // same (re)allocation rule as luci()
-            d_rkeys_.reserve(need_keys);
-            d_rcols_.reserve(need_cols);
-            T4A_HIP(hipMemsetAsync(d_rkeys_.get(), 0, d_rkeys_.cap * sizeof(unsigned long long), stream_));
-            T4A_HIP(hipMemsetAsync(d_rcols_.get(), 0, d_rcols_.cap * sizeof(unsigned long long), stream_));
-            rrlu_salt_ = 0;
-        }
-        z.p1 = d_rkeys_.get();
-        z.n1 = (int)need_keys;
-    }
-    prezero_valid_ = true;
-    prezero_M_ = M;
-    prezero_N_ = N;
-    return z;
+    return ZeroJob();
 }
 
 LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy,
@@ -154,9 +128,11 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     d_colperm_ptr_ = d_colperm;
     const bool keep_lu = need_factors || want_lu_copy;
     if (keep_lu) d_lu_.reserve((size_t)M * N);
-    const bool prezeroed = prezero_valid_ && prezero_M_ == M && prezero_N_ == N;
-    prezero_valid_ = false;
-    if (!prezeroed) T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
+    // the register kernel resets the header at its end; everything else (first use, regrown buffer, LDS kernel, a launch
+    // that did not finish cleanly) clears it here
+    const bool header_clean = header_clean_ && d_out_.get() == header_ptr_;
+    header_clean_ = false;
+    if (!header_clean) T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
     static const bool want_stamps = std::getenv("T4A_RRLU_STAMPS") != nullptr;
     static const bool force_lds = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "lds";
     if (want_stamps) {
@@ -189,19 +165,31 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
             transpose_launch(d_a, M, N, M, d_at_.get(), N, stream_);
             src = d_at_.get();
         }
+        bool keys_ready = false;
+        unsigned long long* keys_this = nullptr;
+        unsigned long long* keys_next = nullptr;
+        int keys_half = 0;
         if (rplan.W > 1) {
             // mailbox granules carry launch-salted tags: zero the buffers whenever they are (re)allocated or the
-            // 16-bit salt wraps, so that no stale granule can ever match a live tag (no per-launch memset)
-            const size_t need_keys = rrlu_reg_keys_bytes(rplan) / sizeof(unsigned long long);
+            // 16-bit salt wraps, so that no stale granule can ever match a live tag (no per-launch memset).
+            // The key table exists twice: a launch polls one copy and clears the other one for its successor.
+            const size_t need_keys = 2 * (rrlu_reg_keys_bytes(rplan) / sizeof(unsigned long long));
             const size_t need_cols = rrlu_reg_cols_bytes(rplan, kM) / sizeof(unsigned long long);
             ++rrlu_salt_;
-            if (need_keys > d_rkeys_.cap || need_cols > d_rcols_.cap || rrlu_salt_ > 65535u) {
+            if (need_keys > d_rkeys_.cap || need_cols > d_rcols_.cap || rrlu_salt_ > 65535u || !keys_clean_) {
+                d_rkeys_.reserve(2 * (size_t)(2 * 256 * 2)); // room for any W up to 256 in both copies
                 d_rkeys_.reserve(need_keys);
                 d_rcols_.reserve(need_cols);
                 T4A_HIP(hipMemsetAsync(d_rkeys_.get(), 0, d_rkeys_.cap * sizeof(unsigned long long), stream_));
                 T4A_HIP(hipMemsetAsync(d_rcols_.get(), 0, d_rcols_.cap * sizeof(unsigned long long), stream_));
                 rrlu_salt_ = 1;
+                keys_clean_ = true;
             }
+            keys_half = (int)(d_rkeys_.cap / 2);
+            keys_this = d_rkeys_.get() + (size_t)key_parity_ * keys_half;
+            keys_next = d_rkeys_.get() + (size_t)(1 - key_parity_) * keys_half;
+            key_parity_ = 1 - key_parity_;
+            keys_ready = true;
         }
         RrluRegArgs a;
         a.A = src;
@@ -221,8 +209,10 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.iresult = d_ires;
         a.dresult = d_dres;
         a.pivot_vals = d_pivvals;
-        a.keys = d_rkeys_.get();
+        a.keys = keys_this;
         a.cols = d_rcols_.get();
+        a.keys_next = keys_next;
+        a.keys_next_u64 = keys_ready ? keys_half : 0;
         a.salt = rrlu_salt_;
         static const int col_delay = std::getenv("T4A_RRLU_COLDELAY") ? std::atoi(std::getenv("T4A_RRLU_COLDELAY")) : 0;
         a.col_delay = col_delay;
@@ -249,7 +239,8 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());
         a.block_u64 = (int)(out_bytes / 8);
         mirrored = true;
-        rrlu_reg_launch(rplan, a, stream_, prezeroed);
+        keys_clean_ = false; // becomes true again once the launch is known to have finished cleanly
+        rrlu_reg_launch(rplan, a, stream_, true);
         plan_W = rplan.W;
         plan_T = rplan.T;
         plan_code = rplan.RPT * 1000 + rplan.CPT * 10 + (rplan.W == 1 ? 2 : 0) + ((rplan.TR % 64) == 0 ? 1 : 0);
@@ -323,6 +314,11 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     }
     if (hp[1] != 0)
         throw Error(T4A_GPU_KERNEL_TIMEOUT, "rrLU kernel: inter-workgroup hand-off timed out (bounded spin gave up)");
+    if (mirrored) { // the kernel ran to its end: header and next key table were left clean by workgroup 0
+        header_clean_ = true;
+        header_ptr_ = d_out_.get();
+        keys_clean_ = true;
+    }
     r.rank = hp[0];
     if (max_steps == 0) {
         // while-loop never entered: lu.error stays NaN unless the matrix is "full rank" (min(M,N) == 0)

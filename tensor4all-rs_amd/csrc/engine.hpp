@@ -107,8 +107,10 @@ private:
     hipStream_t stream_ = nullptr;
     int num_cus_ = 0;
     unsigned rrlu_salt_ = 0;
+    bool header_clean_ = false, keys_clean_ = false;
+    char* header_ptr_ = nullptr;
+    int key_parity_ = 0;
     bool prezero_valid_ = false;
-    int prezero_M_ = 0, prezero_N_ = 0;
     DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_at_;
     DevBuf<char> d_out_;
     PinBuf<char> h_out_;

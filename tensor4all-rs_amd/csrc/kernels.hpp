@@ -98,6 +98,10 @@ struct RrluRegArgs {
     // of the kernel and the flag setters write their flags directly, so no device-to-host copy is needed afterwards
     unsigned long long* h_block;
     int block_u64;
+    // key table of the NEXT multi-workgroup launch (the two tables alternate): cleared by workgroup 0 at the very end
+    // of this launch together with the accumulated max|a| word, so that no memset is needed between launches
+    unsigned long long* keys_next;
+    int keys_next_u64;
     // fused candidate-matrix build: when `fused` != 0 the kernel never reads A; entry (i, j) of ITS row / column
     // numbering is fn(rowacc[i] + colacc[j]) (accumulators [count][fn.n_acc] uint64, see kernels_pi.hip)
     int fused;

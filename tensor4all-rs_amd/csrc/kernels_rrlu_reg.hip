@@ -770,6 +770,11 @@ rrlu_reg_kernel(RrluRegArgs p)
             p.h_block[e] = (e == 1) ? ld_u64_sc1(src + 1) : src[e]; // [1] = max |a| bits: atomics of all workgroups
         }
         if (tid == 0) ((volatile int*)p.h_block)[4] = npiv;
+        // leave the device side clean for the next launch: the max|a| word is only ever raised by the atomics of the
+        // load phase (all long done), and nobody touches the other key table during this launch
+        __syncthreads();
+        if (tid == 0) reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull;
+        for (int e = tid; e < p.keys_next_u64; e += T) p.keys_next[e] = 0ull;
     }
 }
 
