@@ -410,3 +410,20 @@ def test_cfg4_full_size_half_sweep_matches_oracle(t4a):
     pts = rng.integers(0, 2, size=(200, n))
     gv, ov = g.evaluate(pts), o.evaluate(pts)
     assert np.abs(gv - ov).max() <= 1e-10 * max(1.0, np.abs(ov).max())
+
+
+def test_global_pivot_search_matches_oracle_stream(t4a):
+    """DefaultGlobalPivotFinder (globalpivot.rs:160-219) with nsearch > 0: the reference draws from rand 0.9 StdRng
+    ("parity unpinned"); device and oracle share one splitmix64 stream, so with a seed they must add the same
+    global pivots and end in the same state."""
+    from t4a_amd.functions import lorentz
+    spec = lorentz([5] * 5)
+    g, o = both(t4a, spec, [5] * 5)
+    opt = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=12, max_iter=8, nsearch=6, max_nglobal_pivot=3, seed=7)
+    g.crossinterpolate2([[2] * 5], opt)
+    o.crossinterpolate2([[2] * 5], opt)
+    assert_same_sets(g, o, 5)
+    rg, eg = g.history()
+    ro, eo = o.history()
+    assert list(rg) == list(ro) and np.allclose(eg, eo, rtol=1e-9, atol=1e-15)
+    assert g.termination() == o.termination()
