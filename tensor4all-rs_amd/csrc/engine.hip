@@ -73,19 +73,6 @@ Engine::~Engine()
     }
 }
 
-// Buffers the next luci(M, N, opts) call would clear with two memsets (result header, key table): the caller may hand
-// them to the kernel it launches right before (pi_eval_launch) instead.  Only for the register-resident rrLU path.
-ZeroJob Engine::prepare_zero(int M, int N, const RrLUOptions& opts)
-{
-    // The register-resident kernel now leaves its result header and the next key table clean itself (see the end of
-    // rrlu_reg_kernel), so there is nothing left to fold into the evaluation kernel.
-    (void)M;
-    (void)N;
-    (void)opts;
-    prezero_valid_ = false;
-    return ZeroJob();
-}
-
 LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy,
                         const FusedPi* fused)
 {

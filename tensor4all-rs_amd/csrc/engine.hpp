@@ -76,10 +76,6 @@ public:
     LuciResult luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy,
                     const FusedPi* fused = nullptr);
 
-    // see engine.hip: fused clearing of the buffers the next luci() call needs zeroed
-    ZeroJob prepare_zero(int M, int N, const RrLUOptions& opts);
-    void cancel_prezero() { prezero_valid_ = false; }
-
     // RrLU::left(true) / RrLU::right(true) (matrixlu.rs:263-326) of the factorisation kept by the last
     // luci(..., want_lu_copy = true): left() is M x rank, right() is rank x N afterwards.
     void lu_permuted_factors(const LuciResult& r, bool left_orth);
@@ -110,7 +106,6 @@ private:
     bool header_clean_ = false, keys_clean_ = false;
     char* header_ptr_ = nullptr;
     int key_parity_ = 0;
-    bool prezero_valid_ = false;
     DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_at_;
     DevBuf<char> d_out_;
     PinBuf<char> h_out_;

@@ -113,7 +113,7 @@ struct RrluRegArgs {
 bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out);
 size_t rrlu_reg_keys_bytes(const RrluRegPlan& plan);
 size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M);
-// keys_zeroed: the caller already cleared the key table on this stream (e.g. fused into the Π kernel)
+// keys_zeroed: the key table is already clear (the previous launch left it clean, see RrluRegArgs::keys_next)
 void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& args, hipStream_t stream, bool keys_zeroed = false);
 
 // ------------------------------------------------------------------------------------------------
@@ -121,17 +121,8 @@ void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& args, hipStream
 // out[i + ld*j] = g(rowacc[i] + colacc[j]); *max_abs_bits = max over entries of bits(sqrt(v*v)).
 // rowacc/colacc are [count][n_acc] uint64.  If `transpose_out`, writes out[j + ld*i].
 // ------------------------------------------------------------------------------------------------
-// Two small buffers (counts in 64-bit words) that block (0,0) of the Π kernel clears on the way: lets the caller
-// drop the separate memsets of the rrLU result header and key table (one dispatch + gap each per bond).
-struct ZeroJob {
-    unsigned long long* p0 = nullptr;
-    int n0 = 0;
-    unsigned long long* p1 = nullptr;
-    int n1 = 0;
-};
 void pi_eval_launch(const FnDevice& fn, const uint64_t* rowacc, int M, const uint64_t* colacc, int N, double* out,
-                    int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream,
-                    const ZeroJob& zero = ZeroJob());
+                    int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream);
 // Several independent matrices in one launch (fill_site_tensors: two per site): blockIdx.z = job.
 struct PiJob {
     const uint64_t* rowacc;

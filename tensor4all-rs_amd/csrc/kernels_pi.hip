@@ -27,12 +27,8 @@ __device__ __forceinline__ void wave_absmax_commit(double av, unsigned long long
 __global__ void __launch_bounds__(256) pi_eval_kernel(FnDevice fn, const uint64_t* __restrict__ rowacc, int M,
                                                       const uint64_t* __restrict__ colacc, int N,
                                                       double* __restrict__ out, int ld, int transpose_out,
-                                                      unsigned long long* max_abs_bits, ZeroJob zero)
+                                                      unsigned long long* max_abs_bits)
 {
-    if (blockIdx.x == 0 && blockIdx.y == 0) { // fused memsets for the kernel that follows on this stream
-        for (int e = threadIdx.x; e < zero.n0; e += blockDim.x) zero.p0[e] = 0ull;
-        for (int e = threadIdx.x; e < zero.n1; e += blockDim.x) zero.p1[e] = 0ull;
-    }
     // blockIdx.y walks columns (grid-stride), threads walk rows: coalesced column-major stores
     double av = 0.0;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,15 +88,14 @@ __global__ void __launch_bounds__(256) absmax_kernel(const double* __restrict__ 
 } // namespace
 
 void pi_eval_launch(const FnDevice& fn, const uint64_t* rowacc, int M, const uint64_t* colacc, int N, double* out,
-                    int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream,
-                    const ZeroJob& zero)
+                    int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream)
 {
     if (M <= 0 || N <= 0) return;
     dim3 block(256);
     int gy = N < 2048 ? N : 2048;
     dim3 grid((M + 255) / 256, gy);
     hipLaunchKernelGGL(pi_eval_kernel, grid, block, 0, stream, fn, rowacc, M, colacc, N, out, ld,
-                       transpose_out ? 1 : 0, max_abs_bits, zero);
+                       transpose_out ? 1 : 0, max_abs_bits);
 }
 
 void pi_eval_batched_launch(const FnDevice& fn, const PiJob* d_jobs, int n_jobs, int max_M, int max_N, hipStream_t stream)

@@ -379,23 +379,21 @@ void Tci2::stage_accumulators(const IndexSet& a, size_t a0, const IndexSet& b, s
 }
 
 // out[ia + a.count*ib] = f(index with a's digits at sites [a0, a0+a.width) and b's at [b0, b0+b.width))
-bool Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
-                       unsigned long long* d_maxbits, const ZeroJob* zero, const std::vector<uint64_t>* acc_a,
+void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
+                       unsigned long long* d_maxbits, const std::vector<uint64_t>* acc_a,
                        const std::vector<uint64_t>* acc_b)
 {
     require_fn();
     const size_t na = a.count, nb = b.count;
-    if (na == 0 || nb == 0) return false;
+    if (na == 0 || nb == 0) return;
     if (a.width + b.width != n_) throw Error(T4A_GPU_INTERNAL_ERROR, "eval_matrix: index widths do not cover all sites");
     hipStream_t st = eng.stream();
     eng.prof.v[11] += (double)na * (double)nb;
     if (fn_kind_ == FnKind::Builtin) {
         const uint64_t *d_ra = nullptr, *d_rb = nullptr;
         stage_accumulators(a, a0, b, b0, acc_a, acc_b, &d_ra, &d_rb);
-        pi_eval_launch(fn_dev_, d_ra, (int)na, d_rb, (int)nb, d_out, (int)na, false, d_maxbits, st,
-                       zero ? *zero : ZeroJob());
+        pi_eval_launch(fn_dev_, d_ra, (int)na, d_rb, (int)nb, d_out, (int)na, false, d_maxbits, st);
         T4A_HIP(hipGetLastError());
-        return zero != nullptr;
     } else {
         // host batch callback: points in row-major order of (ia, ib) — `ia` outer, `ib` inner — exactly the
         // order the reference hands to batched_f (tensorci2.rs:1862-1869)
@@ -420,7 +418,6 @@ bool Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
         if (d_maxbits) absmax_launch(d_out, npts, d_maxbits, st);
         T4A_HIP(hipGetLastError());
     }
-    return false;
 }
 
 std::vector<double> Tci2::eval_points_host(const std::vector<uint32_t>& idx, size_t n_pts)
@@ -482,10 +479,7 @@ LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
     static long hp_n = 0;
     const auto hp_t0 = std::chrono::steady_clock::now();
     if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.a, st));
-    // the Π kernel clears the rrLU result header and key table on its way (two memset dispatches less per bond)
-    const ZeroJob zero = eng.prepare_zero((int)M, (int)N, o);
-    if (!eval_matrix(is, 0, js, is.width, d_pi, nullptr, zero.p0 ? &zero : nullptr, acc_rows, acc_cols))
-        eng.cancel_prezero();
+    eval_matrix(is, 0, js, is.width, d_pi, nullptr, acc_rows, acc_cols);
     if (eng.prof.enabled) T4A_HIP(hipEventRecord(ev_pi_.b, st));
     if (host_prof) {
         hp_eval += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hp_t0).count();

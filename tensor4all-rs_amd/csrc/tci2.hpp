@@ -130,10 +130,9 @@ private:
     // Evaluate f into a device matrix: out[ia + a.count*ib] = f(index with a's digits at sites
     // [a0, a0+a.width) and b's digits at [b0, b0+b.width)).  If d_maxbits != nullptr the kernel also
     // atomically maxes bits(sqrt(v*v)) into it.
-    // returns true when `zero` was handed to (and cleared by) the device evaluation kernel
-    bool eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
-                     unsigned long long* d_maxbits, const ZeroJob* zero = nullptr,
-                     const std::vector<uint64_t>* acc_a = nullptr, const std::vector<uint64_t>* acc_b = nullptr);
+    void eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
+                     unsigned long long* d_maxbits, const std::vector<uint64_t>* acc_a = nullptr,
+                     const std::vector<uint64_t>* acc_b = nullptr);
     void stage_accumulators(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, const std::vector<uint64_t>* acc_a,
                             const std::vector<uint64_t>* acc_b, const uint64_t** d_ra, const uint64_t** d_rb);
     std::vector<double> eval_points_host(const std::vector<uint32_t>& idx, size_t n_pts);
