@@ -158,7 +158,7 @@ def main():
     tci.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    if world == 1:
+    if world == 1 and not os.environ.get("T4A_BENCH_PER_SWEEP"):
         # K full sweeps = 2K iterations of optimize_with_finder in one call: fill_site_tensors of iteration t runs on
         # its own stream and overlaps with the bond updates of iteration t+1 (they only need the index sets)
         tci.optimize(opts(2 * args.steps), final_sweep1site=False)
