@@ -60,7 +60,17 @@ Engine::Engine()
     hipDeviceProp_t prop;
     T4A_HIP(hipGetDeviceProperties(&prop, dev));
     num_cus_ = prop.multiProcessorCount;
-    T4A_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    // highest priority: the latency-critical chain of bond updates gets its own hardware queue, separate from the
+    // (lowest-priority) fill_site_tensors stream that runs beside it
+    {
+        int least = 0, greatest = 0;
+        T4A_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        static const bool flat = std::getenv("T4A_FLAT_PRIORITY") != nullptr;
+        if (flat || least == greatest)
+            T4A_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        else
+            T4A_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest));
+    }
     ev_rrlu_.init();
     ev_fac_.init();
 }

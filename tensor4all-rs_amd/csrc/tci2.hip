@@ -832,7 +832,15 @@ void Tci2::fill_site_tensors_impl(bool async)
 {
     require_fn();
     fill_wait(); // the scratch arenas of the previous fill are free again
-    if (!fill_stream_) T4A_HIP(hipStreamCreateWithFlags(&fill_stream_, hipStreamNonBlocking));
+    if (!fill_stream_) {
+        int least = 0, greatest = 0;
+        T4A_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        static const bool flat = std::getenv("T4A_FLAT_PRIORITY") != nullptr;
+        if (flat || least == greatest)
+            T4A_HIP(hipStreamCreateWithFlags(&fill_stream_, hipStreamNonBlocking));
+        else
+            T4A_HIP(hipStreamCreateWithPriority(&fill_stream_, hipStreamNonBlocking, least));
+    }
     const bool builtin = fn_kind_ == FnKind::Builtin;
     if (!builtin) async = false;
     // everything of this fill is ordered after the work already enqueued on the main stream
