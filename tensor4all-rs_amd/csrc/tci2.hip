@@ -456,6 +456,29 @@ void Tci2::build_side(size_t bond, bool cols, const IndexSet& extra, SidePrep& o
     out.valid = true;
 }
 
+void Tci2::invalidate_fill_cache()
+{
+    for (auto& f : fill_cache_) f.valid = false;
+}
+
+// Accumulators fill_site_tensors needs for site b (tensorci2.rs:1101-1145): J_b, kron(I_b, d_b) and I_{b+1}.
+void Tci2::prepare_fill_site(size_t b)
+{
+    if (fn_kind_ != FnKind::Builtin || b >= n_) return;
+    if (fill_cache_.size() != n_) fill_cache_.assign(n_, FillAcc());
+    if (shard_world > 1 && (b % shard_world) != shard_rank) return;
+    FillAcc& f = fill_cache_[b];
+    f.valid = false;
+    if (i_set[b].count == 0 || j_set[b].count == 0) return;
+    accumulate(j_set[b], b + 1, f.accJ);
+    accumulate(kronecker_i(b), 0, f.accK);
+    if (b + 1 < n_)
+        accumulate(i_set[b + 1], 0, f.accI);
+    else
+        f.accI.clear();
+    f.valid = true;
+}
+
 LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o, bool need_factors,
                               const std::vector<uint64_t>* acc_rows, const std::vector<uint64_t>* acc_cols)
 {
@@ -623,10 +646,18 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     const IndexSet& j_comb = have_cols ? ready.set : j_own;
     const bool acc_ready = ready.valid && fn_kind_ == FnKind::Builtin;
     if (i_comb.count == 0 || j_comb.count == 0) return;
-    if (prefetch_.wanted) { // schedule the independent side of the NEXT bond behind this bond's kernel launches
+    if (prefetch_.wanted || prefetch_.fill_site >= 0 || prefetch_.flush_fill) {
+        // host work that does not depend on this bond: the independent side of the NEXT bond and the fill
+        // accumulators of a site that is already final; runs while this bond's kernels are in flight
         const Prefetch pf = prefetch_;
         prefetch_.wanted = false;
-        eng.overlap_hook = [this, pf]() { build_side(pf.bond, pf.cols, *pf.extra, prep_); };
+        prefetch_.fill_site = -1;
+        prefetch_.flush_fill = false;
+        eng.overlap_hook = [this, pf]() {
+            if (pf.wanted) build_side(pf.bond, pf.cols, *pf.extra, prep_);
+            if (pf.fill_site >= 0) prepare_fill_site((size_t)pf.fill_site);
+            if (pf.flush_fill) flush_deferred_fill(); // the previous half-sweep's fill: its stream operations go out now
+        };
     }
     const auto hp_t1 = std::chrono::steady_clock::now();
 
@@ -805,8 +836,18 @@ void Tci2::make_canonical(double rel_tol, double abs_tol, size_t max_bond_dim)
 // (the rrLU chain leaves most CUs idle).  Errors (singular pivot matrix) surface at the next fill_wait().
 void Tci2::fill_site_tensors() { fill_site_tensors_impl(false); }
 
+void Tci2::flush_deferred_fill()
+{
+    if (fill_deferred_.empty()) return;
+    std::vector<std::function<void()>> ops;
+    ops.swap(fill_deferred_);
+    for (auto& f : ops) f();
+    fill_inflight_ = true;
+}
+
 void Tci2::fill_wait()
 {
+    flush_deferred_fill();
     if (!fill_inflight_) return;
     fill_inflight_ = false;
     T4A_HIP(hipStreamSynchronize(fill_stream_));
@@ -831,6 +872,12 @@ void Tci2::fill_wait()
 void Tci2::fill_site_tensors_impl(bool async)
 {
     require_fn();
+    // accumulators built ahead are only trusted when optimize() vouches for them (same half-sweep, sets final)
+    const bool trust_cache = fill_cache_trusted_;
+    fill_cache_trusted_ = false;
+    static const bool host_prof_fill = std::getenv("T4A_HOST_PROFILE") != nullptr;
+    const auto hpf_t0 = std::chrono::steady_clock::now();
+    if (!trust_cache) invalidate_fill_cache();
     fill_wait(); // the scratch arenas of the previous fill are free again
     if (!fill_stream_) {
         int least = 0, greatest = 0;
@@ -843,6 +890,19 @@ void Tci2::fill_site_tensors_impl(bool async)
     }
     const bool builtin = fn_kind_ == FnKind::Builtin;
     if (!builtin) async = false;
+    // deferred mode (optimize only): everything up to the upload buffer is prepared now, the ~25 stream operations are
+    // issued later from an overlap hook, when the host would otherwise wait for a long bond-update kernel
+    static const bool defer_env = std::getenv("T4A_FILL_DEFER") != nullptr; // measured: no net gain (the fill then
+    // overlaps the long mid-chain kernels and slows them down by as much as the host time it hides)
+    const bool defer = async && builtin && fill_defer_requested_ && defer_env;
+    fill_defer_requested_ = false;
+    std::vector<std::function<void()>> ops;
+    auto dev = [&](std::function<void()> f) {
+        if (defer)
+            ops.push_back(std::move(f));
+        else
+            f();
+    };
     // everything of this fill is ordered after the work already enqueued on the main stream
     T4A_HIP(hipStreamSynchronize(eng.stream()));
     hipStream_t st = fill_stream_;
@@ -867,7 +927,11 @@ void Tci2::fill_site_tensors_impl(bool async)
             c.l = left_dim;
             c.s = local_dims[b];
             c.r = right_dim;
-            fill_launch(c.buf.get(), c.size(), 0.0, st);
+            {
+                double* ptr = c.buf.get();
+                const size_t cnt = c.size();
+                dev([=]() { fill_launch(ptr, cnt, 0.0, st); });
+            }
             continue;
         }
         SiteJob j;
@@ -888,6 +952,7 @@ void Tci2::fill_site_tensors_impl(bool async)
         jobs.push_back(j);
     }
     if (jobs.empty()) {
+        for (auto& f : ops) f();
         T4A_HIP(hipStreamSynchronize(st));
         return;
     }
@@ -898,9 +963,17 @@ void Tci2::fill_site_tensors_impl(bool async)
     unsigned long long* d_max = d_fillmax_.get();
     int* d_info = reinterpret_cast<int*>(d_fillmax_.get() + n_);
     h_fillinfo_.reserve(n_);
-    T4A_HIP(hipMemsetAsync(d_fillmax_.get(), 0, (n_ + (n_ + 1) / 2) * sizeof(unsigned long long), st));
-    fill_timed_ = eng.prof.enabled;
-    if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.a, st));
+    {
+        unsigned long long* ptr = d_fillmax_.get();
+        const size_t bytes = (n_ + (n_ + 1) / 2) * sizeof(unsigned long long);
+        const bool timed = eng.prof.enabled;
+        hipEvent_t eva = ev_fill_.a;
+        fill_timed_ = timed;
+        dev([=]() {
+            T4A_HIP(hipMemsetAsync(ptr, 0, bytes, st));
+            if (timed) T4A_HIP(hipEventRecord(eva, st));
+        });
+    }
 
     // core shapes are known up front: allocate them now so that every device address below is final
     for (const SiteJob& j : jobs) {
@@ -985,21 +1058,24 @@ void Tci2::fill_site_tensors_impl(bool async)
     const TrsmProblem* d_trs = nullptr;
     const PackJob* d_packs = nullptr;
     if (builtin) {
-        std::vector<uint64_t> acc_all, tmp;
+        std::vector<uint64_t> acc_all;
+        const size_t Kacc = (size_t)fn_dev_.n_acc;
         for (SiteJob& j : jobs) {
-            IndexSet ik = kronecker_i(j.b);
-            accumulate(j_set[j.b], j.b + 1, tmp);
+            const bool cached = fill_cache_.size() == n_ && fill_cache_[j.b].valid &&
+                                fill_cache_[j.b].accJ.size() == j.nj * Kacc && fill_cache_[j.b].accK.size() == j.ni * Kacc &&
+                                (j.last || fill_cache_[j.b].accI.size() == j.np * Kacc);
+            if (!cached) prepare_fill_site(j.b); // sites that became final only with the last bonds of the sweep
+            const FillAcc& f = fill_cache_[j.b];
             j.accJ = acc_all.size();
-            acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
-            accumulate(ik, 0, tmp);
+            acc_all.insert(acc_all.end(), f.accJ.begin(), f.accJ.end());
             j.accK = acc_all.size();
-            acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
+            acc_all.insert(acc_all.end(), f.accK.begin(), f.accK.end());
             if (!j.last) {
-                accumulate(i_set[j.b + 1], 0, tmp);
                 j.accI = acc_all.size();
-                acc_all.insert(acc_all.end(), tmp.begin(), tmp.end());
+                acc_all.insert(acc_all.end(), f.accI.begin(), f.accI.end());
             }
         }
+        invalidate_fill_cache();
         const size_t bytes_acc = acc_all.size() * sizeof(uint64_t);
         const size_t n_pi = 2 * jobs.size();
         const size_t off_pi = up8(bytes_acc), off_lu = up8(off_pi + n_pi * sizeof(PiJob));
@@ -1053,8 +1129,15 @@ void Tci2::fill_site_tensors_impl(bool async)
             std::memcpy(hb + off_tr + np_ * sizeof(TrsmProblem), tru.data(), np_ * sizeof(TrsmProblem));
         }
         std::memcpy(hb + off_pk, packs.data(), bytes_pk);
-        T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st));
-        pi_eval_batched_launch(fn_dev_, reinterpret_cast<const PiJob*>(db + off_pi), (int)pis.size(), max_M, max_N, st);
+        {
+            const FnDevice fn = fn_dev_;
+            const PiJob* dj = reinterpret_cast<const PiJob*>(db + off_pi);
+            const int npi = (int)pis.size();
+            dev([=]() {
+                T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st));
+                pi_eval_batched_launch(fn, dj, npi, max_M, max_N, st);
+            });
+        }
         d_lups = reinterpret_cast<const LuProblem*>(db + off_lu);
         d_trs = reinterpret_cast<const TrsmProblem*>(db + off_tr);
         d_packs = reinterpret_cast<const PackJob*>(db + off_pk);
@@ -1091,24 +1174,42 @@ void Tci2::fill_site_tensors_impl(bool async)
 
     // (2) batched solve; the zero-pivot-matrix guard (:1154-1157) is evaluated on the device: lu_kernel reads
     //     max|P| and flags info = -1, the solves skip flagged problems and the packing writes a zero core
-    if (np_) {
-        // blocked LU with the unit-lower forward substitution of the right-hand sides folded in; beyond its size limit
-        // the unblocked kernel + explicit forward solve (bitwise the same result)
-        if (!lu_forward_blocked_launch(d_lups, (int)np_, max_n, max_nrhs, st)) {
-            lu_batched_launch(d_lups, (int)np_, max_n, st);
-            trsm_left_batched_launch(d_trs, (int)np_, max_n, max_nrhs, st);
-        }
-        trsm_left_batched_launch(d_trs + np_, (int)np_, max_n, max_nrhs, st);
-    }
-    // (3) pack all cores in one launch
     {
-        dim3 grid(blocks_for(max_core) > 64 ? 64 : blocks_for(max_core), (unsigned)packs.size());
-        hipLaunchKernelGGL(pack_fill_batched_kernel, grid, dim3(256), 0, st, d_packs);
+        const int npr = (int)np_;
+        const unsigned gx = blocks_for(max_core) > 64 ? 64 : blocks_for(max_core), gy = (unsigned)packs.size();
+        const bool timed = fill_timed_;
+        hipEvent_t evb = ev_fill_.b;
+        int* hinfo = h_fillinfo_.get();
+        const size_t info_bytes = n_ * sizeof(int);
+        dev([=]() {
+            if (npr) {
+                // blocked LU with the unit-lower forward substitution of the right-hand sides folded in; beyond its size
+                // limit the unblocked kernel + explicit forward solve (bitwise the same result)
+                if (!lu_forward_blocked_launch(d_lups, npr, max_n, max_nrhs, st)) {
+                    lu_batched_launch(d_lups, npr, max_n, st);
+                    trsm_left_batched_launch(d_trs, npr, max_n, max_nrhs, st);
+                }
+                trsm_left_batched_launch(d_trs + npr, npr, max_n, max_nrhs, st);
+            }
+            // (3) pack all cores in one launch
+            hipLaunchKernelGGL(pack_fill_batched_kernel, dim3(gx, gy), dim3(256), 0, st, d_packs);
+            if (timed) T4A_HIP(hipEventRecord(evb, st));
+            T4A_HIP(hipMemcpyAsync(hinfo, d_info, info_bytes, hipMemcpyDeviceToHost, st));
+        });
     }
-    if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.b, st));
-    T4A_HIP(hipMemcpyAsync(h_fillinfo_.get(), d_info, n_ * sizeof(int), hipMemcpyDeviceToHost, st));
     eng.prof.v[10] += flops;
-    fill_inflight_ = true;
+    if (defer) {
+        fill_deferred_ = std::move(ops);
+        fill_inflight_ = false;
+    } else {
+        fill_inflight_ = true;
+    }
+    if (host_prof_fill && !defer) {
+        static double acc_ms = 0;
+        static long calls = 0;
+        acc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hpf_t0).count();
+        if (++calls % 20 == 0) std::fprintf(stderr, "[host profile] fill_site_tensors host part %.1f us per call\n", 1e3 * acc_ms / calls);
+    }
     if (!async) fill_wait();
 }
 
@@ -1334,6 +1435,13 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         flush_pivot_errors();
         last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
         prep_.valid = false;
+        invalidate_fill_cache();
+        const bool fill_ahead = fn_kind_ == FnKind::Builtin && options.pivot_search == 0;
+        // a fill deferred by the previous iteration is issued from the hook of the 9th bond of this half-sweep (the
+        // first kernels that are long enough to hide the host work); shorter chains: from the last bond
+        const size_t nb_ = n_ - 1;
+        const size_t flush_k = nb_ > 9 ? 8 : nb_ - 1;
+        const size_t flush_at_fwd = flush_k, flush_at_bwd = nb_ - 1 - flush_k;
         if (is_forward) {
             for (size_t b = 0; b + 1 < n_; ++b) {
                 // bond b+1 reads J_{b+2}, which bond b does not touch: its column side can be built ahead
@@ -1341,6 +1449,9 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
                 prefetch_.bond = b + 1;
                 prefetch_.cols = true;
                 prefetch_.extra = prefetch_.wanted ? &extra_j[b + 1] : nullptr;
+                // site b-1 only reads I_{b-1}, J_{b-1}, I_b: final since bond b-1 (forward bonds write I_{b+1}, J_b)
+                prefetch_.fill_site = (fill_ahead && b >= 1) ? (long)(b - 1) : -1;
+                prefetch_.flush_fill = (b == flush_at_fwd);
                 update_pivots(b, true, options, extra_i[b + 1], extra_j[b]);
             }
         } else {
@@ -1350,12 +1461,19 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
                 prefetch_.bond = b - 1;
                 prefetch_.cols = false;
                 prefetch_.extra = prefetch_.wanted ? &extra_i[b] : nullptr;
+                // site b+2 reads I_{b+2}, J_{b+2}, I_{b+3}: final since bond b+1 (backward bonds write I_{b+1}, J_b)
+                prefetch_.fill_site = (fill_ahead && b + 2 < n_) ? (long)(b + 2) : -1;
+                prefetch_.flush_fill = (b == flush_at_bwd);
                 update_pivots(b, false, options, extra_i[b + 1], extra_j[b]);
             }
         }
         prefetch_.wanted = false;
+        prefetch_.fill_site = -1;
         prep_.valid = false;
         // the cores are not needed by the next half-sweep unless the global pivot search evaluates the TT
+        flush_deferred_fill(); // (normally already gone; guarantees the order of consecutive fills)
+        fill_cache_trusted_ = fill_ahead;
+        fill_defer_requested_ = fill_ahead && iter + 1 < options.max_iter;
         fill_site_tensors_impl(options.nsearch == 0 && !options.strictly_nested);
         const double error = max_bond_error();
         errors_hist.push_back(error / norm);
@@ -1377,6 +1495,7 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
     }
     // the cores of the last iteration are complete (deferred solve errors surface here); in pipelined mode the wait
     // is left to the first reader (site_tensor*, evaluate, export_site_tensors_async, the next fill)
+    flush_deferred_fill();
     if (!keep_site_tensors || final_sweep1site) fill_wait();
     if (final_sweep1site) { // :1781-1794
         const double norm = (options.normalize_error && max_sample_value > 0.0) ? max_sample_value : 1.0;

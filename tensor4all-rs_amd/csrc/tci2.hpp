@@ -156,7 +156,22 @@ private:
         size_t bond = 0;
         bool cols = false;
         const IndexSet* extra = nullptr;
-    } prefetch_;                    // set by the sweep loop: which side of which bond is independent of the current one
+        long fill_site = -1;        // a site whose I/J sets are already final: its fill accumulators can be built now
+        bool flush_fill = false;    // issue the stream operations of the previous half-sweep's (deferred) fill
+    } prefetch_;
+    // accumulators of fill_site_tensors (J_b, kron_i(b), I_{b+1}) built ahead of time, site by site, while the bond
+    // updates of the same half-sweep are running; only valid inside optimize() between the bond loop and its fill
+    struct FillAcc {
+        bool valid = false;
+        std::vector<uint64_t> accJ, accK, accI;
+    };
+    std::vector<FillAcc> fill_cache_;
+    bool fill_cache_trusted_ = false;
+    bool fill_defer_requested_ = false;
+    std::vector<std::function<void()>> fill_deferred_; // stream operations of a prepared, not yet issued fill
+    void flush_deferred_fill();
+    void prepare_fill_site(size_t b);
+    void invalidate_fill_cache();                    // set by the sweep loop: which side of which bond is independent of the current one
     void build_side(size_t bond, bool cols, const IndexSet& extra, SidePrep& out) const;
     LuciResult luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLUOptions& o, bool need_factors,
                             const std::vector<uint64_t>* acc_rows = nullptr, const std::vector<uint64_t>* acc_cols = nullptr);
