@@ -874,6 +874,12 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
                 TC = 1;
             }
         }
+        if (const char* etr = std::getenv("T4A_RRLU_TR")) { // experiment: explicit thread grid TR x TC
+            TR = round_up(std::atoi(etr), 64);
+            RPT = (M + TR - 1) / TR;
+            TC = std::getenv("T4A_RRLU_TC") ? std::atoi(std::getenv("T4A_RRLU_TC")) : 1;
+            if (TC < 1) TC = 1;
+        }
         if (RPT > 4 || TR > 1024) return false; // beyond the register budget: LDS kernel
         int CPT = ec ? norm_cpt(std::atoi(ec)) : 4; // more, thinner workgroups win once the key table is shared (measured)
         int W = (N + TC * CPT - 1) / (TC * CPT);
