@@ -165,6 +165,7 @@ Tci2::Tci2(const std::vector<size_t>& dims) : n_(dims.size()), local_dims(dims) 
 Tci2::~Tci2()
 {
     if (export_event_) (void)hipEventDestroy(export_event_);
+    if (fill_graph_exec_) (void)hipGraphExecDestroy(fill_graph_exec_);
     if (fill_stream_) {
         (void)hipStreamSynchronize(fill_stream_);
         (void)hipStreamDestroy(fill_stream_);
@@ -836,12 +837,62 @@ void Tci2::make_canonical(double rel_tol, double abs_tol, size_t max_bond_dim)
 // (the rrLU chain leaves most CUs idle).  Errors (singular pivot matrix) surface at the next fill_wait().
 void Tci2::fill_site_tensors() { fill_site_tensors_impl(false); }
 
+// Issues the stream operations of one fill.  Fills of consecutive sweeps at saturated rank are operation-for-operation
+// identical (same device addresses, shapes and pinned staging buffer), so the sequence is captured into a HIP graph the
+// second time a signature is seen and replayed afterwards: one submission instead of ~25, which also keeps the
+// runtime's submission path free for the latency-critical bond updates on the main stream.
+void Tci2::issue_fill_ops(std::vector<std::function<void()>>& ops, const std::vector<uint64_t>& sig)
+{
+    hipStream_t st = fill_stream_;
+    static const bool use_graph = std::getenv("T4A_NO_FILL_GRAPH") == nullptr;
+    if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.a, st));
+    bool done = false;
+    if (use_graph && !fill_graph_broken_) {
+        if (fill_graph_exec_ && sig == fill_graph_sig_) {
+            T4A_HIP(hipGraphLaunch(fill_graph_exec_, st));
+            done = true;
+        } else if (sig == fill_last_sig_) { // second time in a row: worth capturing
+            if (fill_graph_exec_) {
+                (void)hipGraphExecDestroy(fill_graph_exec_);
+                fill_graph_exec_ = nullptr;
+            }
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                try {
+                    for (auto& f : ops) f();
+                } catch (...) {
+                    ok = false;
+                }
+                if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) ok = false;
+            }
+            if (ok && hipGraphInstantiate(&fill_graph_exec_, graph, nullptr, nullptr, 0) != hipSuccess) {
+                fill_graph_exec_ = nullptr;
+                ok = false;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ok) {
+                fill_graph_sig_ = sig;
+                T4A_HIP(hipGraphLaunch(fill_graph_exec_, st));
+                done = true;
+            } else {
+                (void)hipGetLastError();
+                fill_graph_broken_ = true; // never try again on this handle; fall through to the direct issue
+            }
+        }
+    }
+    fill_last_sig_ = sig;
+    if (!done)
+        for (auto& f : ops) f();
+    if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.b, st));
+}
+
 void Tci2::flush_deferred_fill()
 {
     if (fill_deferred_.empty()) return;
     std::vector<std::function<void()>> ops;
     ops.swap(fill_deferred_);
-    for (auto& f : ops) f();
+    issue_fill_ops(ops, fill_deferred_sig_);
     fill_inflight_ = true;
 }
 
@@ -877,6 +928,14 @@ void Tci2::fill_site_tensors_impl(bool async)
     fill_cache_trusted_ = false;
     static const bool host_prof_fill = std::getenv("T4A_HOST_PROFILE") != nullptr;
     const auto hpf_t0 = std::chrono::steady_clock::now();
+    static double hpf_sec[6] = {0, 0, 0, 0, 0, 0};
+    auto hpf_mark = [&](int k, std::chrono::steady_clock::time_point& t) {
+        if (!host_prof_fill) return;
+        const auto now = std::chrono::steady_clock::now();
+        hpf_sec[k] += std::chrono::duration<double, std::micro>(now - t).count();
+        t = now;
+    };
+    auto hpf_t = hpf_t0;
     if (!trust_cache) invalidate_fill_cache();
     fill_wait(); // the scratch arenas of the previous fill are free again
     if (!fill_stream_) {
@@ -896,13 +955,10 @@ void Tci2::fill_site_tensors_impl(bool async)
     // overlaps the long mid-chain kernels and slows them down by as much as the host time it hides)
     const bool defer = async && builtin && fill_defer_requested_ && defer_env;
     fill_defer_requested_ = false;
-    std::vector<std::function<void()>> ops;
-    auto dev = [&](std::function<void()> f) {
-        if (defer)
-            ops.push_back(std::move(f));
-        else
-            f();
-    };
+    std::vector<std::function<void()>> ops; // the stream operations of this fill, in order (no event records)
+    std::vector<uint64_t> sig;              // everything those operations depend on: equal signature <=> same graph
+    auto dev = [&](std::function<void()> f) { ops.push_back(std::move(f)); };
+    auto sg = [&](uint64_t v) { sig.push_back(v); };
     // everything of this fill is ordered after the work already enqueued on the main stream
     T4A_HIP(hipStreamSynchronize(eng.stream()));
     hipStream_t st = fill_stream_;
@@ -930,6 +986,9 @@ void Tci2::fill_site_tensors_impl(bool async)
             {
                 double* ptr = c.buf.get();
                 const size_t cnt = c.size();
+                sg(0xF111ull);
+                sg((uint64_t)(uintptr_t)ptr);
+                sg((uint64_t)cnt);
                 dev([=]() { fill_launch(ptr, cnt, 0.0, st); });
             }
             continue;
@@ -951,10 +1010,15 @@ void Tci2::fill_site_tensors_impl(bool async)
         totB += nj * ni;
         jobs.push_back(j);
     }
+    hpf_mark(0, hpf_t);
     if (jobs.empty()) {
         for (auto& f : ops) f();
         T4A_HIP(hipStreamSynchronize(st));
         return;
+    }
+    if (!builtin) { // host-callback mode stays immediate (its evaluations are synchronous anyway)
+        for (auto& f : ops) f();
+        ops.clear();
     }
     d_fillA_.reserve(std::max<size_t>(totA, 1));
     d_fillB_.reserve(totB);
@@ -966,13 +1030,15 @@ void Tci2::fill_site_tensors_impl(bool async)
     {
         unsigned long long* ptr = d_fillmax_.get();
         const size_t bytes = (n_ + (n_ + 1) / 2) * sizeof(unsigned long long);
-        const bool timed = eng.prof.enabled;
-        hipEvent_t eva = ev_fill_.a;
-        fill_timed_ = timed;
-        dev([=]() {
-            T4A_HIP(hipMemsetAsync(ptr, 0, bytes, st));
-            if (timed) T4A_HIP(hipEventRecord(eva, st));
-        });
+        fill_timed_ = eng.prof.enabled;
+        sg((uint64_t)(uintptr_t)ptr);
+        sg((uint64_t)bytes);
+        dev([=]() { T4A_HIP(hipMemsetAsync(ptr, 0, bytes, st)); });
+        if (!builtin) {
+            if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.a, st));
+            for (auto& f : ops) f();
+            ops.clear();
+        }
     }
 
     // core shapes are known up front: allocate them now so that every device address below is final
@@ -1047,6 +1113,7 @@ void Tci2::fill_site_tensors_impl(bool async)
         const double n = (double)j.np;
         flops += (2.0 / 3.0) * n * n * n + 2.0 * n * n * (double)j.ni;
     }
+    hpf_mark(1, hpf_t);
     const size_t np_ = lups.size();
     const size_t bytes_lu = np_ * sizeof(LuProblem), bytes_tr = 2 * np_ * sizeof(TrsmProblem);
     const size_t bytes_pk = packs.size() * sizeof(PackJob);
@@ -1076,6 +1143,7 @@ void Tci2::fill_site_tensors_impl(bool async)
             }
         }
         invalidate_fill_cache();
+        hpf_mark(2, hpf_t);
         const size_t bytes_acc = acc_all.size() * sizeof(uint64_t);
         const size_t n_pi = 2 * jobs.size();
         const size_t off_pi = up8(bytes_acc), off_lu = up8(off_pi + n_pi * sizeof(PiJob));
@@ -1133,6 +1201,17 @@ void Tci2::fill_site_tensors_impl(bool async)
             const FnDevice fn = fn_dev_;
             const PiJob* dj = reinterpret_cast<const PiJob*>(db + off_pi);
             const int npi = (int)pis.size();
+            sg((uint64_t)(uintptr_t)db);
+            sg((uint64_t)(uintptr_t)hb);
+            sg((uint64_t)total_bytes);
+            sg((uint64_t)npi);
+            sg(((uint64_t)(uint32_t)max_M << 32) | (uint32_t)max_N);
+            sg((uint64_t)fn.fid * 16 + (uint64_t)fn.n_acc);
+            for (int q = 0; q < T4A_FN_MAX_PARAMS; ++q) {
+                uint64_t bits;
+                std::memcpy(&bits, &fn.params[q], sizeof(bits));
+                sg(bits);
+            }
             dev([=]() {
                 T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st));
                 pi_eval_batched_launch(fn, dj, npi, max_M, max_N, st);
@@ -1177,10 +1256,16 @@ void Tci2::fill_site_tensors_impl(bool async)
     {
         const int npr = (int)np_;
         const unsigned gx = blocks_for(max_core) > 64 ? 64 : blocks_for(max_core), gy = (unsigned)packs.size();
-        const bool timed = fill_timed_;
-        hipEvent_t evb = ev_fill_.b;
         int* hinfo = h_fillinfo_.get();
         const size_t info_bytes = n_ * sizeof(int);
+        sg((uint64_t)npr);
+        sg(((uint64_t)(uint32_t)max_n << 32) | (uint32_t)max_nrhs);
+        sg(((uint64_t)gx << 32) | gy);
+        sg((uint64_t)(uintptr_t)d_lups);
+        sg((uint64_t)(uintptr_t)d_trs);
+        sg((uint64_t)(uintptr_t)d_packs);
+        sg((uint64_t)(uintptr_t)d_info);
+        sg((uint64_t)(uintptr_t)hinfo);
         dev([=]() {
             if (npr) {
                 // blocked LU with the unit-lower forward substitution of the right-hand sides folded in; beyond its size
@@ -1193,22 +1278,33 @@ void Tci2::fill_site_tensors_impl(bool async)
             }
             // (3) pack all cores in one launch
             hipLaunchKernelGGL(pack_fill_batched_kernel, dim3(gx, gy), dim3(256), 0, st, d_packs);
-            if (timed) T4A_HIP(hipEventRecord(evb, st));
             T4A_HIP(hipMemcpyAsync(hinfo, d_info, info_bytes, hipMemcpyDeviceToHost, st));
         });
     }
+    hpf_mark(3, hpf_t);
     eng.prof.v[10] += flops;
-    if (defer) {
+    if (!builtin) {
+        for (auto& f : ops) f();
+        if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.b, st));
+        fill_inflight_ = true;
+    } else if (defer) {
         fill_deferred_ = std::move(ops);
+        fill_deferred_sig_ = std::move(sig);
         fill_inflight_ = false;
     } else {
+        issue_fill_ops(ops, sig);
         fill_inflight_ = true;
     }
     if (host_prof_fill && !defer) {
         static double acc_ms = 0;
         static long calls = 0;
         acc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hpf_t0).count();
-        if (++calls % 20 == 0) std::fprintf(stderr, "[host profile] fill_site_tensors host part %.1f us per call\n", 1e3 * acc_ms / calls);
+        hpf_mark(4, hpf_t);
+        if (++calls % 20 == 0)
+            std::fprintf(stderr, "[host profile] fill_site_tensors host part %.1f us per call (wait+jobs %.1f, descriptors %.1f, "
+                                 "accumulators %.1f, staging %.1f, issue %.1f)\n",
+                         1e3 * acc_ms / calls, hpf_sec[0] / calls, hpf_sec[1] / calls, hpf_sec[2] / calls, hpf_sec[3] / calls,
+                         hpf_sec[4] / calls);
     }
     if (!async) fill_wait();
 }
@@ -1440,7 +1536,9 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         // a fill deferred by the previous iteration is issued from the hook of the 9th bond of this half-sweep (the
         // first kernels that are long enough to hide the host work); shorter chains: from the last bond
         const size_t nb_ = n_ - 1;
-        const size_t flush_k = nb_ > 9 ? 8 : nb_ - 1;
+        static const int defer_k = std::getenv("T4A_FILL_DEFER") ? std::atoi(std::getenv("T4A_FILL_DEFER")) : 8;
+        const size_t want_k = defer_k > 0 ? (size_t)defer_k : 8;
+        const size_t flush_k = nb_ > want_k + 1 ? want_k : nb_ - 1;
         const size_t flush_at_fwd = flush_k, flush_at_bwd = nb_ - 1 - flush_k;
         if (is_forward) {
             for (size_t b = 0; b + 1 < n_; ++b) {

@@ -170,6 +170,10 @@ private:
     bool fill_defer_requested_ = false;
     std::vector<std::function<void()>> fill_deferred_; // stream operations of a prepared, not yet issued fill
     void flush_deferred_fill();
+    void issue_fill_ops(std::vector<std::function<void()>>& ops, const std::vector<uint64_t>& sig);
+    std::vector<uint64_t> fill_deferred_sig_, fill_last_sig_, fill_graph_sig_;
+    hipGraphExec_t fill_graph_exec_ = nullptr;
+    bool fill_graph_broken_ = false;
     void prepare_fill_site(size_t b);
     void invalidate_fill_cache();                    // set by the sweep loop: which side of which bond is independent of the current one
     void build_side(size_t bond, bool cols, const IndexSet& extra, SidePrep& out) const;
