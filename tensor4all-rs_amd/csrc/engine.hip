@@ -213,7 +213,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.salt = rrlu_salt_;
         static const int col_delay = std::getenv("T4A_RRLU_COLDELAY") ? std::atoi(std::getenv("T4A_RRLU_COLDELAY")) : 0;
         a.col_delay = col_delay;
-        static const int poll_delay = std::getenv("T4A_RRLU_POLLDELAY") ? std::atoi(std::getenv("T4A_RRLU_POLLDELAY")) : 16;
+        static const int poll_delay = std::getenv("T4A_RRLU_POLLDELAY") ? std::atoi(std::getenv("T4A_RRLU_POLLDELAY")) : 12;
         a.poll_delay = poll_delay;
         static const int ncopy_env = std::getenv("T4A_RRLU_NCOPY") ? std::atoi(std::getenv("T4A_RRLU_NCOPY")) : 1;
         a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
