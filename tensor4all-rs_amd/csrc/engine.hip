@@ -219,6 +219,8 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
         static const int spec_env = std::getenv("T4A_RRLU_SPEC") ? std::atoi(std::getenv("T4A_RRLU_SPEC")) : 0;
         a.spec = spec_env ? 1 : 0;
+        static const int key16_env = std::getenv("T4A_RRLU_KEY16") ? std::atoi(std::getenv("T4A_RRLU_KEY16")) : 1;
+        a.key16 = key16_env ? 1 : 0;
         a.spin_limit = 1u << 20;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
         // results land in the pinned mirror straight from the kernel: no device-to-host copy afterwards

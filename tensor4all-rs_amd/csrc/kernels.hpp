@@ -90,6 +90,7 @@ struct RrluRegArgs {
     int col_delay;              // >0: readers sleep briefly before their first pivot-column sweep
     int poll_delay;             // >0: the polling wave sleeps ~1000 cycles before its first key sweep
     int ncopy;                  // replicas of the published pivot column (<= RRLU_MAX_COPIES)
+    int key16;                  // 1: the poller reads every key with one 16-byte load
     int spec;                   // 1: every workgroup publishes its candidate column with its key (cols is [2][W][M][2])
     unsigned spin_limit;
     unsigned long long* stamps; // diagnostic only

@@ -526,12 +526,28 @@ rrlu_reg_kernel(RrluRegArgs p)
                 unsigned long long g[KPL][2];
                 for (;;) {
                     bool ok = true;
+                    if (p.key16) { // one 16-byte load per key instead of two 8-byte ones
+                        const void* ptrs[KPL];
+                        u32x4 got[KPL];
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) {
-                        const int qw = lane + 64 * j;
-                        if (qw < p.W) {
-                            g[j][0] = ld_u64_sc1(kb + 2 * (size_t)qw);
-                            g[j][1] = ld_u64_sc1(kb + 2 * (size_t)qw + 1);
+                        for (int j = 0; j < KPL; ++j) {
+                            const int qw = lane + 64 * j;
+                            ptrs[j] = kb + 2 * (size_t)(qw < p.W ? qw : 0);
+                        }
+                        Load16<KPL>::run(ptrs, got);
+#pragma unroll
+                        for (int j = 0; j < KPL; ++j) {
+                            g[j][0] = ((unsigned long long)got[j].y << 32) | got[j].x;
+                            g[j][1] = ((unsigned long long)got[j].w << 32) | got[j].z;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < KPL; ++j) {
+                            const int qw = lane + 64 * j;
+                            if (qw < p.W) {
+                                g[j][0] = ld_u64_sc1(kb + 2 * (size_t)qw);
+                                g[j][1] = ld_u64_sc1(kb + 2 * (size_t)qw + 1);
+                            }
                         }
                     }
 #pragma unroll
