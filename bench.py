@@ -242,7 +242,7 @@ def main():
                         "resident, the kernel is bound by the per-pivot inter-workgroup exchange latency",
             },
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:  # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(tci, spec)
         print(json.dumps(out), flush=True)
     if world > 1:
