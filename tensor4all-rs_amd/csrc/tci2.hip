@@ -948,7 +948,8 @@ void Tci2::fill_site_tensors_impl(bool async)
             T4A_HIP(hipStreamCreateWithPriority(&fill_stream_, hipStreamNonBlocking, least));
     }
     const bool builtin = fn_kind_ == FnKind::Builtin;
-    if (!builtin) async = false;
+    static const bool sync_fill = std::getenv("T4A_SYNC_FILL") != nullptr; // measurement switch: no overlap at all
+    if (!builtin || sync_fill) async = false;
     // deferred mode (optimize only): everything up to the upload buffer is prepared now, the ~25 stream operations are
     // issued later from an overlap hook, when the host would otherwise wait for a long bond-update kernel
     static const bool defer_env = std::getenv("T4A_FILL_DEFER") != nullptr; // measured: no net gain (the fill then
