@@ -46,6 +46,16 @@ def test_no_silent_cpu_fallback():
     with pytest.raises(t4a_amd.T4aError) as e:
         t4a_amd.mat_mul(np.eye(2), np.eye(2))
     assert e.value.code == t4a_amd.NO_DEVICE
+    # the widened rows fail the same way: tensor-train handle, SVD / QR, rook LUCI, adaptive patching
+    for call in (lambda: t4a_amd.SimpleTensorTrain.constant([2, 2], 1.0),
+                 lambda: t4a_amd.svd_backend(np.eye(3)),
+                 lambda: t4a_amd.qr_backend(np.eye(3)),
+                 lambda: t4a_amd.full_piv_lu_matrix(np.eye(3)),
+                 lambda: t4a_amd.matrix_luci_factors_rook(np.eye(3)),
+                 lambda: t4a_amd.adaptiveinterpolate(lambda i: 1.0, [2, 2], [[0, 0]], t4a_amd.TCI2Options())):
+        with pytest.raises(t4a_amd.T4aError) as e:
+            call()
+        assert e.value.code == t4a_amd.NO_DEVICE, e.value
 
 
 def test_argument_validation_happens_before_the_device_is_touched():
