@@ -84,7 +84,7 @@ struct RrluRegArgs {
     int* iresult;               // [0] npivots [1] timeout [2] NaN flag
     double* dresult;            // [0] last error [1] bits of max sqrt(v*v)
     double* pivot_vals;
-    unsigned long long* keys;   // [2][W dest][W src][4] per-workgroup inboxes of tagged key granules
+    unsigned long long* keys;   // [2][W][2] shared key table of THIS launch: two 16-bit-tagged granules per workgroup and step parity
     unsigned long long* cols;   // [2][ncopy][M][2] tagged pivot-column granules; tag = salt*65536 + (step % 65535 + 1)
     unsigned salt;              // launch-unique 16-bit value (1..65535); the buffers are zeroed when it wraps
     int col_delay;              // >0: readers sleep briefly before their first pivot-column sweep

@@ -25,6 +25,9 @@
 //         candidate column instead of hop 2: 5.4 us/step.
 //       hop 2 (pivot column broadcast): only the winner publishes its column; readers delay their first
 //         sweep so that it normally succeeds.
+//   * no stream operation besides the launch: built-in functors are evaluated straight into the slab (p.fused),
+//     results are mirrored into pinned host memory by workgroup 0, which also resets the device header and clears
+//     the key table of the next launch (two alternating tables).
 // Barriers per pivot step: 3.
 #include "kernels.hpp"
 
@@ -936,7 +939,7 @@ size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M)
 
 void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream, bool keys_zeroed)
 {
-    // the key table carries 16-bit step tags: zero it before every launch (2.7 KiB at W = 86)
+    // the key table carries 16-bit step tags and must start zeroed: normally the previous launch cleared it
     if (plan.W > 1 && !keys_zeroed) (void)hipMemsetAsync(a.keys, 0, rrlu_reg_keys_bytes(plan), stream);
     switch (plan.RPT) {
     case 1: launch_r<1>(plan, a, stream); break;
