@@ -237,6 +237,13 @@ def main():
                                   "separate passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch "
                                   "(gfx950 FETCH_SIZE correction); null when the kernel name does not match",
                 "avg_launch_ms": rrlu_ms_avg,
+                # the kernel is a chain of dependent pivot steps, each with two memory-side hand-offs between workgroups:
+                # the honest bound is latency, not bandwidth (tools/hop_bench.hip: one store->load hop = 1040-1240 cycles)
+                "latency_view": {
+                    "pivot_steps_per_launch": float(shapes[N_SITES // 2][2]),
+                    "us_per_pivot_step": 1e3 * rrlu_ms_avg / max(float(shapes[N_SITES // 2][2]), 1.0),
+                    "two_hop_floor_us": 2 * 1140 / 2400.0,
+                },
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "streaming model 8MN + sum_k 16(M-k-1)(N-k-1) bytes (BASELINE.md §2); the slab is register "
                         "resident, the kernel is bound by the per-pivot inter-workgroup exchange latency",
