@@ -213,8 +213,9 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.salt = rrlu_salt_;
         static const int col_delay = std::getenv("T4A_RRLU_COLDELAY") ? std::atoi(std::getenv("T4A_RRLU_COLDELAY")) : 0;
         a.col_delay = col_delay;
-        static const int poll_delay = std::getenv("T4A_RRLU_POLLDELAY") ? std::atoi(std::getenv("T4A_RRLU_POLLDELAY")) : 12;
-        a.poll_delay = poll_delay;
+        // measured optimum of the poller's initial sleep (tools/probe_delay.py): 12 units below ~100 workgroups, 14 above
+        static const int poll_delay_env = std::getenv("T4A_RRLU_POLLDELAY") ? std::atoi(std::getenv("T4A_RRLU_POLLDELAY")) : -1;
+        a.poll_delay = poll_delay_env >= 0 ? poll_delay_env : (rplan.W > 100 ? 14 : 12);
         static const int ncopy_env = std::getenv("T4A_RRLU_NCOPY") ? std::atoi(std::getenv("T4A_RRLU_NCOPY")) : 1;
         a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
         static const int spec_env = std::getenv("T4A_RRLU_SPEC") ? std::atoi(std::getenv("T4A_RRLU_SPEC")) : 0;

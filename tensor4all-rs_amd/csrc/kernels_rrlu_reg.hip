@@ -827,13 +827,14 @@ template <int RPT> void launch_r(const RrluRegPlan& plan, const RrluRegArgs& a, 
     switch (plan.CPT) {
     case 1: launch_rc<RPT, 1>(plan, a, stream); break;
     case 2: launch_rc<RPT, 2>(plan, a, stream); break;
+    case 3: launch_rc<RPT, 3>(plan, a, stream); break;
     case 4: launch_rc<RPT, 4>(plan, a, stream); break;
     default: launch_rc<RPT, 8>(plan, a, stream); break;
     }
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
-int norm_cpt(int c) { return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : 8)); }
+int norm_cpt(int c) { return c <= 1 ? 1 : (c <= 2 ? 2 : (c == 3 ? 3 : (c <= 4 ? 4 : 8))); }
 
 } // namespace
 
@@ -900,14 +901,20 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
             if (TC < 1) TC = 1;
         }
         if (RPT > 4 || TR > 1024) return false; // beyond the register budget: LDS kernel
-        int CPT = ec ? norm_cpt(std::atoi(ec)) : 4; // more, thinner workgroups win once the key table is shared (measured)
+        // more, thinner workgroups win once the key table is shared (measured: 3 columns per thread and 230 workgroups
+        // beat 4 / 172 by 3.5 % at 685 x 688); fall back to 4 and 8 when that would need more workgroups than CUs
+        int CPT = ec ? norm_cpt(std::atoi(ec)) : 3;
         int W = (N + TC * CPT - 1) / (TC * CPT);
+        if (!ec && W > maxw) {
+            CPT = 4;
+            W = (N + TC * CPT - 1) / (TC * CPT);
+        }
         if (ew && std::atoi(ew) > 1) {
             W = std::atoi(ew);
             CPT = norm_cpt((N + W * TC - 1) / (W * TC));
         }
         while (W > maxw && CPT < 8) {
-            CPT *= 2;
+            CPT = CPT == 3 ? 4 : CPT * 2;
             W = (N + TC * CPT - 1) / (TC * CPT);
         }
         if (W < 1) W = 1;
