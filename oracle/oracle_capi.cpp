@@ -3,6 +3,7 @@
 // restatement through ctypes.  Nothing in the product (tensor4all-rs_amd/) links this.
 #include "t4a_oracle.hpp"
 #include "t4a_oracle_patch.hpp"
+#include "t4a_oracle_tree.hpp"
 
 #include "../include/t4a_testfunctions.h"
 
@@ -586,6 +587,265 @@ int oracle_ptt_evaluate(void* h, const uint64_t* idx, uint64_t n_pts, double* ou
             for (const auto& sd : r->patches) acc = acc + sd.tt.evaluate(mi);
             out[p] = acc;
         }
+    });
+}
+
+// ---- TreeTCI (t4a_oracle_tree.hpp) ----
+struct OracleTree {
+    std::unique_ptr<TreeTCI2> st;
+    TreeBatchFn eval;
+    TreeNetwork net;
+    bool has_net = false;
+    TreeOptimizeResult last;
+};
+
+static TreeTciOptions make_tree_options(double tolerance, uint64_t max_iter, uint64_t max_bond_dim, int normalize_error,
+                                        int enable_global_pivots, uint64_t nsearch, uint64_t max_nglobal_pivot,
+                                        double tol_margin, int has_seed, uint64_t seed)
+{
+    TreeTciOptions o;
+    o.tolerance = tolerance;
+    o.max_iter = (size_t)max_iter;
+    o.has_max_bond_dim = max_bond_dim != 0;
+    o.max_bond_dim = (size_t)max_bond_dim;
+    o.normalize_error = normalize_error != 0;
+    o.enable_global_pivots = enable_global_pivots != 0;
+    o.nsearch = (size_t)nsearch;
+    o.max_nglobal_pivot = (size_t)max_nglobal_pivot;
+    o.tol_margin_global_search = tol_margin;
+    o.has_seed = has_seed != 0;
+    o.seed = seed;
+    return o;
+}
+
+// edges: 2 * n_edges site numbers; the function is taken from `fn_handle` (oracle_fn_new / oracle_tci2_new holder)
+void* oracle_tree_new(void* fn_handle, const uint64_t* local_dims, uint64_t n_sites, const uint64_t* edges, uint64_t n_edges)
+{
+    void* out = nullptr;
+    guarded([&] {
+        std::vector<TreeEdge> es;
+        for (size_t k = 0; k < n_edges; ++k) es.emplace_back((size_t)edges[2 * k], (size_t)edges[2 * k + 1]);
+        TreeGraph g((size_t)n_sites, es);
+        std::vector<size_t> d(local_dims, local_dims + n_sites);
+        auto* t = new OracleTree();
+        try {
+            t->st.reset(new TreeTCI2(d, g));
+        } catch (...) {
+            delete t;
+            throw;
+        }
+        if (fn_handle) t->eval = tree_batch_from_scalar(static_cast<OracleTci*>(fn_handle)->f);
+        out = t;
+    });
+    return out;
+}
+void oracle_tree_release(void* h) { delete static_cast<OracleTree*>(h); }
+
+int oracle_tree_add_global_pivots(void* h, const uint64_t* pivots, uint64_t n_pivots)
+{
+    return guarded([&] {
+        auto* t = static_cast<OracleTree*>(h);
+        const size_t n = t->st->local_dims.size();
+        std::vector<MultiIndex> pv;
+        for (size_t k = 0; k < n_pivots; ++k) pv.emplace_back(pivots + k * n, pivots + (k + 1) * n);
+        t->st->add_global_pivots(pv);
+    });
+}
+
+static void write_index_list(const std::vector<MultiIndex>& v, uint64_t* count, uint64_t* out)
+{
+    *count = v.size();
+    if (!out) return;
+    size_t o = 0;
+    for (const auto& c : v)
+        for (size_t x : c) out[o++] = x;
+}
+
+int oracle_tree_subregion(void* h, uint64_t u, uint64_t v, uint64_t* nl, uint64_t* left, uint64_t* nr, uint64_t* right)
+{
+    return guarded([&] {
+        auto keys = static_cast<OracleTree*>(h)->st->graph.subregion_vertices(TreeEdge(u, v));
+        *nl = keys.first.size();
+        *nr = keys.second.size();
+        if (left) std::copy(keys.first.begin(), keys.first.end(), left);
+        if (right) std::copy(keys.second.begin(), keys.second.end(), right);
+    });
+}
+// distances to every edge of the graph in sorted edge order
+int oracle_tree_distance_edges(void* h, uint64_t u, uint64_t v, uint64_t* out)
+{
+    return guarded([&] {
+        auto& g = static_cast<OracleTree*>(h)->st->graph;
+        auto d = g.distance_edges(TreeEdge(u, v));
+        size_t k = 0;
+        for (const TreeEdge& e : g.edges()) out[k++] = d.at(e);
+    });
+}
+int oracle_tree_candidate_edges(void* h, uint64_t u, uint64_t v, uint64_t* count, uint64_t* out)
+{
+    return guarded([&] {
+        auto c = static_cast<OracleTree*>(h)->st->graph.candidate_edges(TreeEdge(u, v));
+        *count = c.size();
+        if (out)
+            for (size_t k = 0; k < c.size(); ++k) {
+                out[2 * k] = c[k].u;
+                out[2 * k + 1] = c[k].v;
+            }
+    });
+}
+int oracle_tree_edges(void* h, uint64_t* out)
+{
+    return guarded([&] {
+        size_t k = 0;
+        for (const TreeEdge& e : static_cast<OracleTree*>(h)->st->graph.edges()) {
+            out[2 * k] = e.u;
+            out[2 * k + 1] = e.v;
+            ++k;
+        }
+    });
+}
+int oracle_tree_candidates(void* h, uint64_t u, uint64_t v, uint64_t* nl, uint64_t* left, uint64_t* nr, uint64_t* right)
+{
+    return guarded([&] {
+        std::vector<MultiIndex> l, r;
+        default_proposer_candidates(*static_cast<OracleTree*>(h)->st, TreeEdge(u, v), l, r);
+        write_index_list(l, nl, left);
+        write_index_list(r, nr, right);
+    });
+}
+int oracle_tree_push_history(void* h, const uint64_t* key, uint64_t key_len, const uint64_t* cols, uint64_t count)
+{
+    return guarded([&] {
+        auto* t = static_cast<OracleTree*>(h);
+        SubtreeKey k(key, key + key_len);
+        std::vector<MultiIndex> v;
+        for (size_t c = 0; c < count; ++c) v.emplace_back(cols + c * key_len, cols + (c + 1) * key_len);
+        PivotTable tab;
+        tab[k] = v;
+        t->st->ijset_history.push_back(tab);
+    });
+}
+int oracle_tree_pivots(void* h, const uint64_t* key, uint64_t key_len, uint64_t* count, uint64_t* out)
+{
+    return guarded([&] {
+        SubtreeKey k(key, key + key_len);
+        write_index_list(static_cast<OracleTree*>(h)->st->pivots_of(k), count, out);
+    });
+}
+int oracle_tree_update_edge(void* h, uint64_t u, uint64_t v, uint64_t max_bond_dim, double rel_tol, double abs_tol,
+                            uint64_t* rank, uint64_t* rows, uint64_t* cols, double* pivot_errors)
+{
+    return guarded([&] {
+        auto* t = static_cast<OracleTree*>(h);
+        RrLUOptions o;
+        o.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : (size_t)max_bond_dim;
+        o.rel_tol = rel_tol;
+        o.abs_tol = abs_tol;
+        o.left_orthogonal = true;
+        MatrixLuciFactors sel = tree_update_edge(*t->st, TreeEdge(u, v), t->eval, o);
+        *rank = sel.rank;
+        for (size_t k = 0; k < sel.row_indices.size(); ++k) {
+            if (rows) rows[k] = sel.row_indices[k];
+            if (cols) cols[k] = sel.col_indices[k];
+        }
+        if (pivot_errors)
+            for (size_t k = 0; k < sel.pivot_errors.size(); ++k) pivot_errors[k] = sel.pivot_errors[k];
+        t->has_net = false;
+    });
+}
+int oracle_tree_optimize(void* h, int with_initial, const uint64_t* pivots, uint64_t n_pivots, double tolerance,
+                         uint64_t max_iter, uint64_t max_bond_dim, int normalize_error, int enable_global_pivots,
+                         uint64_t nsearch, uint64_t max_nglobal_pivot, double tol_margin, int has_seed, uint64_t seed,
+                         uint64_t* n_iter, uint64_t* ranks, double* errors)
+{
+    return guarded([&] {
+        auto* t = static_cast<OracleTree*>(h);
+        TreeTciOptions o = make_tree_options(tolerance, max_iter, max_bond_dim, normalize_error, enable_global_pivots, nsearch,
+                                             max_nglobal_pivot, tol_margin, has_seed, seed);
+        if (with_initial) {
+            const size_t n = t->st->local_dims.size();
+            std::vector<MultiIndex> pv;
+            for (size_t k = 0; k < n_pivots; ++k) pv.emplace_back(pivots + k * n, pivots + (k + 1) * n);
+            t->last = tree_crossinterpolate2(*t->st, t->eval, pv, o);
+        } else {
+            t->last = tree_optimize(*t->st, t->eval, o);
+        }
+        t->has_net = false;
+        *n_iter = t->last.ranks.size();
+        for (size_t k = 0; k < t->last.ranks.size(); ++k) {
+            if (ranks) ranks[k] = t->last.ranks[k];
+            if (errors) errors[k] = t->last.errors[k];
+        }
+    });
+}
+int oracle_tree_bond_errors(void* h, double* out)
+{
+    return guarded([&] {
+        size_t k = 0;
+        for (const auto& kv : static_cast<OracleTree*>(h)->st->bond_errors) out[k++] = kv.second;
+    });
+}
+int oracle_tree_pivot_errors(void* h, uint64_t* count, double* out)
+{
+    return guarded([&] {
+        const auto& e = static_cast<OracleTree*>(h)->st->pivot_errors;
+        *count = e.size();
+        if (out) std::copy(e.begin(), e.end(), out);
+    });
+}
+double oracle_tree_max_sample_value(void* h) { return static_cast<OracleTree*>(h)->st->max_sample_value; }
+void oracle_tree_set_max_sample_value(void* h, double v) { static_cast<OracleTree*>(h)->st->max_sample_value = v; }
+double oracle_tree_max_bond_error(void* h) { return static_cast<OracleTree*>(h)->st->max_bond_error(); }
+uint64_t oracle_tree_max_bond_dim(void* h) { return static_cast<OracleTree*>(h)->st->max_bond_dim(); }
+void oracle_tree_flush_pivot_errors(void* h) { static_cast<OracleTree*>(h)->st->flush_pivot_errors(); }
+
+int oracle_tree_materialize(void* h, uint64_t center_site)
+{
+    return guarded([&] {
+        auto* t = static_cast<OracleTree*>(h);
+        t->net = tree_materialize(*t->st, t->eval, (size_t)center_site);
+        t->has_net = true;
+    });
+}
+int oracle_tree_site_tensor(void* h, uint64_t site, uint64_t* ndims, uint64_t* dims, double* out)
+{
+    return guarded([&] {
+        auto* t = static_cast<OracleTree*>(h);
+        if (!t->has_net) throw OracleError(ERR_INVALID_ARGUMENT, "materialize first");
+        const auto& st = t->net.tensors.at(site);
+        *ndims = st.dims.size();
+        if (dims) std::copy(st.dims.begin(), st.dims.end(), dims);
+        if (out) std::copy(st.data.begin(), st.data.end(), out);
+    });
+}
+int oracle_tree_evaluate(void* h, const uint64_t* idx, uint64_t n_pts, double* out)
+{
+    return guarded([&] {
+        auto* t = static_cast<OracleTree*>(h);
+        if (!t->has_net) throw OracleError(ERR_INVALID_ARGUMENT, "materialize first");
+        const size_t n = t->st->local_dims.size();
+        MultiIndex mi(n);
+        for (size_t p = 0; p < n_pts; ++p) {
+            for (size_t s = 0; s < n; ++s) mi[s] = idx[s + n * p];
+            out[p] = t->net.evaluate(mi);
+        }
+    });
+}
+int oracle_tree_find_global_pivots(void* h, uint64_t nsearch, uint64_t max_nglobal_pivot, double tol_margin, double abs_tol,
+                                   uint64_t seed, uint64_t* count, uint64_t* out)
+{
+    return guarded([&] {
+        auto* t = static_cast<OracleTree*>(h);
+        auto pv = tree_find_global_pivots(*t->st, t->eval, nsearch, max_nglobal_pivot, tol_margin, abs_tol, seed);
+        write_index_list(pv, count, out);
+    });
+}
+int oracle_solve_right_full_piv_lu(const double* pi1, uint64_t rows, uint64_t cols, const double* p, double* x)
+{
+    return guarded([&] {
+        std::vector<double> a(pi1, pi1 + rows * cols), b(p, p + cols * cols);
+        auto r = tree_detail::solve_right_full_piv_lu(a, rows, cols, b, cols, cols);
+        std::copy(r.begin(), r.end(), x);
     });
 }
 

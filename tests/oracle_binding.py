@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp", "t4a_oracle_patch.hpp",
-                                                  "t4a_oracle_tt.hpp")] + [
+                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -566,3 +566,206 @@ def adaptiveinterpolate(f, dims, initial_pivots, options, patch_order=None, n_in
     r = OraclePartitionedTT(h, len(dims))
     r._src = src
     return r
+
+
+# ------------------------------------------------------------------------------------------------ TreeTCI
+_lib.oracle_tree_new.restype = vp
+_lib.oracle_tree_max_sample_value.restype = dbl
+_lib.oracle_tree_max_bond_error.restype = dbl
+_lib.oracle_tree_max_bond_dim.restype = u64
+for _n in ("oracle_tree_release", "oracle_tree_max_sample_value", "oracle_tree_max_bond_error", "oracle_tree_max_bond_dim",
+           "oracle_tree_flush_pivot_errors"):
+    getattr(_lib, _n).argtypes = [vp]
+_lib.oracle_tree_set_max_sample_value.argtypes = [vp, dbl]
+
+
+class TreeOptions:
+    """TreeTciOptions (treetci/src/optimize.rs:13-76)."""
+
+    def __init__(self, tolerance=1e-8, max_iter=20, max_bond_dim=None, normalize_error=True, enable_global_pivots=True,
+                 nsearch=5, max_nglobal_pivot=5, tol_margin_global_search=10.0, seed=None):
+        self.tolerance = tolerance
+        self.max_iter = max_iter
+        self.max_bond_dim = max_bond_dim
+        self.normalize_error = normalize_error
+        self.enable_global_pivots = enable_global_pivots
+        self.nsearch = nsearch
+        self.max_nglobal_pivot = max_nglobal_pivot
+        self.tol_margin_global_search = tol_margin_global_search
+        self.seed = seed
+
+    def args(self):
+        return [dbl(self.tolerance), u64(self.max_iter), u64(0 if self.max_bond_dim is None else self.max_bond_dim),
+                cint(int(self.normalize_error)), cint(int(self.enable_global_pivots)), u64(self.nsearch),
+                u64(self.max_nglobal_pivot), dbl(self.tol_margin_global_search), cint(0 if self.seed is None else 1),
+                u64(0 if self.seed is None else self.seed)]
+
+
+class OracleTreeTCI2:
+    """TreeTCI2 restatement (oracle/t4a_oracle_tree.hpp).  `f` as for OracleTCI2.set_function; edges = [(u, v), ...]."""
+
+    def __init__(self, local_dims, edges, f=None):
+        self.local_dims = [int(d) for d in local_dims]
+        self.n = len(self.local_dims)
+        self._src = None
+        fh = None
+        if f is not None:
+            src = OracleTCI2.__new__(OracleTCI2)
+            src.local_dims = self.local_dims
+            ld = np.asarray(self.local_dims, dtype=np.uint64)
+            src._h = _lib.oracle_fn_new(_p(ld), u64(len(ld)))
+            src._keep = None
+            src.set_function(f)
+            self._src = src
+            fh = vp(src._h)
+        ld = np.asarray(self.local_dims, dtype=np.uint64)
+        e = np.ascontiguousarray(np.asarray(edges, dtype=np.uint64).reshape(-1, 2))
+        self.n_edges = len(e)
+        self._h = _lib.oracle_tree_new(fh, _p(ld), u64(self.n), _p(e), u64(len(e)))
+        if not self._h:
+            raise OracleError(-2)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.oracle_tree_release(self._h)
+            self._h = None
+
+    def _two_lists(self, fn, u, v, wl=None, wr=None):
+        nl, nr = u64(0), u64(0)
+        _check(fn(vp(self._h), u64(u), u64(v), ctypes.byref(nl), None, ctypes.byref(nr), None))
+        return nl.value, nr.value
+
+    def edges(self):
+        out = np.zeros((self.n_edges, 2), dtype=np.uint64)
+        _check(_lib.oracle_tree_edges(vp(self._h), _p(out)))
+        return [tuple(int(x) for x in r) for r in out]
+
+    def subregion_vertices(self, u, v):
+        nl, nr = self._two_lists(_lib.oracle_tree_subregion, u, v)
+        l, r = np.zeros(nl, dtype=np.uint64), np.zeros(nr, dtype=np.uint64)
+        _check(_lib.oracle_tree_subregion(vp(self._h), u64(u), u64(v), ctypes.byref(u64(0)), _p(l), ctypes.byref(u64(0)), _p(r)))
+        return [int(x) for x in l], [int(x) for x in r]
+
+    def distance_edges(self, u, v):
+        out = np.zeros(self.n_edges, dtype=np.uint64)
+        _check(_lib.oracle_tree_distance_edges(vp(self._h), u64(u), u64(v), _p(out)))
+        return {e: int(d) for e, d in zip(self.edges(), out)}
+
+    def candidate_edges(self, u, v):
+        c = u64(0)
+        _check(_lib.oracle_tree_candidate_edges(vp(self._h), u64(u), u64(v), ctypes.byref(c), None))
+        out = np.zeros((c.value, 2), dtype=np.uint64)
+        _check(_lib.oracle_tree_candidate_edges(vp(self._h), u64(u), u64(v), ctypes.byref(c), _p(out)))
+        return [tuple(int(x) for x in r) for r in out]
+
+    def add_global_pivots(self, pivots):
+        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), self.n))
+        _check(_lib.oracle_tree_add_global_pivots(vp(self._h), _p(piv), u64(len(pivots))))
+
+    def candidates(self, u, v):
+        lk, rk = self.subregion_vertices(u, v)
+        nl, nr = self._two_lists(_lib.oracle_tree_candidates, u, v)
+        l = np.zeros((nl, len(lk)), dtype=np.uint64)
+        r = np.zeros((nr, len(rk)), dtype=np.uint64)
+        _check(_lib.oracle_tree_candidates(vp(self._h), u64(u), u64(v), ctypes.byref(u64(0)), _p(l), ctypes.byref(u64(0)), _p(r)))
+        return l.astype(np.int64), r.astype(np.int64)
+
+    def push_history(self, key, cols):
+        k = np.ascontiguousarray(np.asarray(sorted(key), dtype=np.uint64))
+        c = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64).reshape(len(cols), len(k)))
+        _check(_lib.oracle_tree_push_history(vp(self._h), _p(k), u64(len(k)), _p(c), u64(len(cols))))
+
+    def pivots(self, key):
+        k = np.ascontiguousarray(np.asarray(sorted(key), dtype=np.uint64))
+        c = u64(0)
+        _check(_lib.oracle_tree_pivots(vp(self._h), _p(k), u64(len(k)), ctypes.byref(c), None))
+        out = np.zeros((c.value, len(k)), dtype=np.uint64)
+        _check(_lib.oracle_tree_pivots(vp(self._h), _p(k), u64(len(k)), ctypes.byref(c), _p(out)))
+        return out.astype(np.int64)
+
+    def update_edge(self, u, v, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0):
+        lc, rc = self.candidates(u, v)
+        cap = min(len(lc), len(rc))
+        rows, cols = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64)
+        errs = np.zeros(cap + 1)
+        rank = u64(0)
+        _check(_lib.oracle_tree_update_edge(vp(self._h), u64(u), u64(v), u64(0 if max_bond_dim is None else max_bond_dim),
+                                            dbl(rel_tol), dbl(abs_tol), ctypes.byref(rank), _p(rows), _p(cols), _p(errs)))
+        r = rank.value
+        return {"rank": r, "row_indices": rows[:r].astype(np.int64), "col_indices": cols[:r].astype(np.int64),
+                "pivot_errors": errs[:r + 1].copy()}
+
+    def _run(self, with_initial, pivots, o):
+        ranks = np.zeros(o.max_iter, dtype=np.uint64)
+        errors = np.zeros(o.max_iter)
+        n_iter = u64(0)
+        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), self.n)) if len(pivots) else np.zeros((0, self.n), dtype=np.uint64)
+        _check(_lib.oracle_tree_optimize(vp(self._h), cint(with_initial), _p(piv), u64(len(pivots)), *o.args(),
+                                         ctypes.byref(n_iter), _p(ranks), _p(errors)))
+        k = n_iter.value
+        return [int(x) for x in ranks[:k]], [float(x) for x in errors[:k]]
+
+    def optimize(self, o):
+        return self._run(0, [], o)
+
+    def crossinterpolate2(self, pivots, o):
+        return self._run(1, pivots, o)
+
+    def bond_errors(self):
+        out = np.zeros(self.n_edges)
+        _check(_lib.oracle_tree_bond_errors(vp(self._h), _p(out)))
+        return out
+
+    def pivot_errors(self):
+        c = u64(0)
+        _check(_lib.oracle_tree_pivot_errors(vp(self._h), ctypes.byref(c), None))
+        out = np.zeros(c.value)
+        _check(_lib.oracle_tree_pivot_errors(vp(self._h), ctypes.byref(c), _p(out)))
+        return out
+
+    def flush_pivot_errors(self):
+        _lib.oracle_tree_flush_pivot_errors(vp(self._h))
+
+    def max_sample_value(self):
+        return _lib.oracle_tree_max_sample_value(vp(self._h))
+
+    def set_max_sample_value(self, v):
+        _lib.oracle_tree_set_max_sample_value(vp(self._h), dbl(v))
+
+    def max_bond_error(self):
+        return _lib.oracle_tree_max_bond_error(vp(self._h))
+
+    def max_bond_dim(self):
+        return int(_lib.oracle_tree_max_bond_dim(vp(self._h)))
+
+    def materialize(self, center_site=0):
+        _check(_lib.oracle_tree_materialize(vp(self._h), u64(center_site)))
+
+    def site_tensor(self, site):
+        nd = u64(0)
+        dims = np.zeros(self.n + 1, dtype=np.uint64)
+        _check(_lib.oracle_tree_site_tensor(vp(self._h), u64(site), ctypes.byref(nd), _p(dims), None))
+        shape = [int(x) for x in dims[:nd.value]]
+        out = np.zeros(int(np.prod(shape)))
+        _check(_lib.oracle_tree_site_tensor(vp(self._h), u64(site), ctypes.byref(nd), _p(dims), _p(out)))
+        return out.reshape(shape, order="F")
+
+    def evaluate(self, idx):
+        cols, n_pts = _idx_cols(idx, self.n)
+        out = np.zeros(n_pts)
+        _check(_lib.oracle_tree_evaluate(vp(self._h), _p(cols), u64(n_pts), _p(out)))
+        return out
+
+    def find_global_pivots(self, nsearch, max_nglobal_pivot, tol_margin, abs_tol, seed):
+        c = u64(0)
+        out = np.zeros((max(max_nglobal_pivot, 1), self.n), dtype=np.uint64)
+        _check(_lib.oracle_tree_find_global_pivots(vp(self._h), u64(nsearch), u64(max_nglobal_pivot), dbl(tol_margin),
+                                                   dbl(abs_tol), u64(seed), ctypes.byref(c), _p(out)))
+        return out[:c.value].astype(np.int64)
+
+
+def solve_right_full_piv_lu(pi1, p):
+    a, b = _f(pi1), _f(p)
+    x = np.zeros(a.shape, order="F")
+    _check(_lib.oracle_solve_right_full_piv_lu(_p(a), u64(a.shape[0]), u64(a.shape[1]), _p(b), _p(x)))
+    return x
