@@ -331,6 +331,82 @@ t4a_gpu_status t4a_gpu_ptt_patch_tt(const t4a_gpu_ptt* h, size_t k, t4a_gpu_tt**
 /* Sum over the patches at a batch of full multi-indices (idx: n_sites x n_pts column-major). */
 t4a_gpu_status t4a_gpu_ptt_evaluate(t4a_gpu_ptt* h, const size_t* idx, size_t n_pts, double* out);
 
+/* =====================================================================================
+ * Tree tensor cross interpolation: tensor4all-treetci
+ * crates/tensor4all-treetci/src/{graph,state,proposer,update,optimize,materialize,globalpivot,api}.rs
+ * The batch evaluator of that crate, Fn(GlobalIndexBatch) with a column-major (n_sites, n_points) index buffer
+ * (batch.rs:13-66, update.rs:213-232), IS t4a_gpu_batch_eval_fn.
+ * ===================================================================================== */
+typedef struct t4a_gpu_treetci t4a_gpu_treetci;
+
+/* TreeTciOptions (optimize.rs:13-76).  max_bond_dim == 0 <=> None, has_seed == 0 <=> seed None. */
+typedef struct t4a_gpu_treetci_options {
+    double tolerance;                 /* 1e-8 */
+    size_t max_iter;                  /* 20 */
+    size_t max_bond_dim;              /* 0 */
+    int32_t normalize_error;          /* 1 */
+    int32_t enable_global_pivots;     /* 1 */
+    size_t nsearch;                   /* 5 */
+    size_t max_nglobal_pivot;         /* 5 */
+    double tol_margin_global_search;  /* 10.0 */
+    int32_t has_seed;                 /* 0 */
+    uint64_t seed;
+} t4a_gpu_treetci_options;
+t4a_gpu_status t4a_gpu_treetci_options_default(t4a_gpu_treetci_options* opts);
+
+/* TreeTciGraph::new(n_sites, edges) + TreeTCI2::new(local_dims, graph) (graph.rs:51-106, state.rs:66-103).
+ * edges: 2 * n_edges site numbers (u0, v0, u1, v1, ...); the graph must be a tree. */
+t4a_gpu_status t4a_gpu_treetci_new(const size_t* local_dims, size_t n_sites, const size_t* edges, size_t n_edges,
+                                   t4a_gpu_treetci** out);
+void t4a_gpu_treetci_release(t4a_gpu_treetci* h);
+/* function source: as t4a_gpu_tci2_set_builtin_function / _set_callback */
+t4a_gpu_status t4a_gpu_treetci_set_builtin_function(t4a_gpu_treetci* h, int32_t fid, int32_t n_acc, const double* params,
+                                                    const uint64_t* weights);
+t4a_gpu_status t4a_gpu_treetci_set_callback(t4a_gpu_treetci* h, t4a_gpu_batch_eval_fn cb, void* ctx);
+/* TreeTCI2::add_global_pivots (state.rs:110-165): pivots is n_sites x n_pivots column-major. */
+t4a_gpu_status t4a_gpu_treetci_add_global_pivots(t4a_gpu_treetci* h, const size_t* pivots, size_t n_pivots);
+/* graph.rs:150-156 subregion_vertices(edge): the sorted site lists on the u side and on the v side (query with NULL). */
+t4a_gpu_status t4a_gpu_treetci_subregion_vertices(const t4a_gpu_treetci* h, size_t u, size_t v, size_t* n_left,
+                                                  size_t* left, size_t* n_right, size_t* right);
+/* DefaultProposer::candidates (proposer.rs:57-88): left is (|left key| x n_left), right (|right key| x n_right),
+ * both column-major; pass NULL buffers to query the counts. */
+t4a_gpu_status t4a_gpu_treetci_candidates(const t4a_gpu_treetci* h, size_t u, size_t v, size_t* n_left, size_t* left,
+                                          size_t* n_right, size_t* right);
+/* update_edge with the default proposer (update.rs:22-115): candidate matrix on the device -> full-pivot rrLU ->
+ * new pivot tables of both sides, bond error, pivot errors, max_sample_value.  rows / cols (>= min(n_left, n_right)
+ * entries) receive the selected candidate numbers, pivot_errors rank + 1 values; all three may be NULL. */
+t4a_gpu_status t4a_gpu_treetci_update_edge(t4a_gpu_treetci* h, size_t u, size_t v, size_t max_bond_dim, double rel_tol,
+                                           double abs_tol, size_t* rank, size_t* rows, size_t* cols, double* pivot_errors);
+/* optimize_default (optimize.rs:80-220) / crossinterpolate2 with the default proposer (api.rs:21-96; the tree network
+ * is obtained afterwards with _materialize).  ranks / errors need max_iter entries; n_iter receives the sweep count. */
+t4a_gpu_status t4a_gpu_treetci_optimize(t4a_gpu_treetci* h, const t4a_gpu_treetci_options* options, size_t* n_iter,
+                                        size_t* ranks, double* errors);
+t4a_gpu_status t4a_gpu_treetci_crossinterpolate2(t4a_gpu_treetci* h, const size_t* initial_pivots, size_t n_pivots,
+                                                 const t4a_gpu_treetci_options* options, size_t* n_iter, size_t* ranks,
+                                                 double* errors);
+/* find_global_pivots (globalpivot.rs:24-172): out is n_sites x count column-major, at most max_nglobal_pivot columns. */
+t4a_gpu_status t4a_gpu_treetci_find_global_pivots(t4a_gpu_treetci* h, size_t nsearch, size_t max_nglobal_pivot,
+                                                  double tol_margin, double abs_tol, uint64_t seed, size_t* count,
+                                                  size_t* out);
+/* state accessors (state.rs:41-58, :168-199).  key: sorted site list of a subtree; out is |key| x count column-major. */
+t4a_gpu_status t4a_gpu_treetci_pivots(const t4a_gpu_treetci* h, const size_t* key, size_t key_len, size_t* count,
+                                      size_t* out);
+t4a_gpu_status t4a_gpu_treetci_bond_errors(const t4a_gpu_treetci* h, double* out /* per edge, sorted edge order */);
+t4a_gpu_status t4a_gpu_treetci_pivot_errors(const t4a_gpu_treetci* h, size_t* count, double* out);
+t4a_gpu_status t4a_gpu_treetci_flush_pivot_errors(t4a_gpu_treetci* h);
+t4a_gpu_status t4a_gpu_treetci_max_sample_value(const t4a_gpu_treetci* h, double* out);
+t4a_gpu_status t4a_gpu_treetci_set_max_sample_value(t4a_gpu_treetci* h, double value);
+t4a_gpu_status t4a_gpu_treetci_max_bond_error(const t4a_gpu_treetci* h, double* out);
+t4a_gpu_status t4a_gpu_treetci_max_bond_dim(const t4a_gpu_treetci* h, size_t* out);
+/* to_treetn(state, evaluate, center_site) (materialize.rs:17-166): builds one dense tensor per site on the device,
+ * index order [site, incoming bonds (sorted neighbours except the parent), bond to the parent]; non-root sites solve
+ * T * P = Pi1 by full-pivot LU, a numerically zero P gives a zero tensor. */
+t4a_gpu_status t4a_gpu_treetci_materialize(t4a_gpu_treetci* h, size_t center_site);
+/* ndims / dims (<= n_sites + 1 entries) / column-major data of one materialised site tensor; out may be NULL. */
+t4a_gpu_status t4a_gpu_treetci_site_tensor(t4a_gpu_treetci* h, size_t site, size_t* ndims, size_t* dims, double* out);
+/* TreeTN::evaluate of the materialised network at full multi-indices (idx: n_sites x n_pts column-major). */
+t4a_gpu_status t4a_gpu_treetci_evaluate(t4a_gpu_treetci* h, const size_t* idx, size_t n_pts, double* out);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);

@@ -6,10 +6,16 @@
 
 #include "patching.hpp"
 #include "tci2.hpp"
+#include "tree.hpp"
 
 struct t4a_gpu_tci2 {
     t4a::Tci2 impl;
     explicit t4a_gpu_tci2(const std::vector<size_t>& d) : impl(d) {}
+};
+
+struct t4a_gpu_treetci {
+    t4a::TreeTci impl;
+    t4a_gpu_treetci(const std::vector<size_t>& d, const t4a::TreeGraph& g) : impl(d, g) {}
 };
 
 struct t4a_gpu_ptt {
@@ -1379,6 +1385,326 @@ t4a_gpu_status t4a_gpu_ptt_evaluate(t4a_gpu_ptt* h, const size_t* idx, size_t n_
         T4A_REQUIRE_PTR(out);
         std::vector<uint32_t> u = narrow_indices(idx, checked_mul(n_pts, h->impl->dims.size(), "index buffer"));
         std::vector<double> v = h->impl->evaluate(u.data(), n_pts);
+        std::memcpy(out, v.data(), n_pts * sizeof(double));
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ TreeTCI
+t4a_gpu_status t4a_gpu_treetci_options_default(t4a_gpu_treetci_options* o)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(o);
+        std::memset(o, 0, sizeof(*o));
+        o->tolerance = 1e-8;
+        o->max_iter = 20;
+        o->max_bond_dim = 0;
+        o->normalize_error = 1;
+        o->enable_global_pivots = 1;
+        o->nsearch = 5;
+        o->max_nglobal_pivot = 5;
+        o->tol_margin_global_search = 10.0;
+        o->has_seed = 0;
+        o->seed = 0;
+    });
+}
+
+extern "C++" {
+static TreeTciOptions convert_tree_options(const t4a_gpu_treetci_options* o)
+{
+    TreeTciOptions r;
+    if (!o) return r;
+    r.tolerance = o->tolerance;
+    r.max_iter = o->max_iter;
+    r.max_bond_dim = o->max_bond_dim;
+    r.normalize_error = o->normalize_error != 0;
+    r.enable_global_pivots = o->enable_global_pivots != 0;
+    r.nsearch = o->nsearch;
+    r.max_nglobal_pivot = o->max_nglobal_pivot;
+    r.tol_margin_global_search = o->tol_margin_global_search;
+    r.has_seed = o->has_seed != 0;
+    r.seed = o->seed;
+    return r;
+}
+static void write_index_set(const IndexSet& s, size_t* count, size_t* out)
+{
+    *count = s.count;
+    if (out)
+        for (size_t k = 0; k < s.count * s.width; ++k) out[k] = s.d[k];
+}
+static void write_history(const t4a_gpu_treetci* h, size_t* n_iter, size_t* ranks, double* errors)
+{
+    if (n_iter) *n_iter = h->impl.ranks_hist.size();
+    for (size_t k = 0; k < h->impl.ranks_hist.size(); ++k) {
+        if (ranks) ranks[k] = h->impl.ranks_hist[k];
+        if (errors) errors[k] = h->impl.errors_hist[k];
+    }
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_treetci_new(const size_t* local_dims, size_t n_sites, const size_t* edges, size_t n_edges,
+                                   t4a_gpu_treetci** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        if (n_sites) T4A_REQUIRE_PTR(local_dims);
+        if (n_edges) T4A_REQUIRE_PTR(edges);
+        std::vector<TreeEdge> es;
+        for (size_t k = 0; k < n_edges; ++k) es.emplace_back(edges[2 * k], edges[2 * k + 1]);
+        TreeGraph g(n_sites, es); // graph errors are reported before the device is touched
+        std::vector<size_t> d(local_dims, local_dims + n_sites);
+        if (!(d.size() > 1)) throw Error(T4A_GPU_INVALID_ARGUMENT, "local_dims should have at least 2 elements");
+        for (size_t s = 0; s < d.size(); ++s)
+            if (d[s] == 0)
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "local dimension at site " + std::to_string(s) + " must be positive");
+        *out = new t4a_gpu_treetci(d, g);
+    });
+}
+
+void t4a_gpu_treetci_release(t4a_gpu_treetci* h) { delete h; }
+
+t4a_gpu_status t4a_gpu_treetci_set_builtin_function(t4a_gpu_treetci* h, int32_t fid, int32_t n_acc, const double* params,
+                                                    const uint64_t* weights)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(params);
+        T4A_REQUIRE_PTR(weights);
+        h->impl.set_builtin(fid, n_acc, params, weights);
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_set_callback(t4a_gpu_treetci* h, t4a_gpu_batch_eval_fn cb, void* ctx)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.set_callback(cb, ctx);
+    });
+}
+
+extern "C++" {
+static std::vector<std::vector<uint32_t>> tree_pivots_from(const t4a_gpu_treetci* h, const size_t* pivots, size_t n_pivots)
+{
+    const size_t ns = h->impl.local_dims.size();
+    std::vector<std::vector<uint32_t>> p(n_pivots, std::vector<uint32_t>(ns));
+    for (size_t k = 0; k < n_pivots; ++k)
+        for (size_t s = 0; s < ns; ++s) {
+            const size_t v = pivots[s + ns * k];
+            if (v > 0xFFFFFFFFull) throw Error(T4A_GPU_INVALID_ARGUMENT, "pivot value out of bounds");
+            p[k][s] = (uint32_t)v;
+        }
+    return p;
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_treetci_add_global_pivots(t4a_gpu_treetci* h, const size_t* pivots, size_t n_pivots)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pivots) T4A_REQUIRE_PTR(pivots);
+        h->impl.add_global_pivots(tree_pivots_from(h, pivots, n_pivots));
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_subregion_vertices(const t4a_gpu_treetci* h, size_t u, size_t v, size_t* n_left,
+                                                  size_t* left, size_t* n_right, size_t* right)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(n_left);
+        T4A_REQUIRE_PTR(n_right);
+        const auto keys = h->impl.graph.subregion_vertices(TreeEdge(u, v));
+        *n_left = keys.first.size();
+        *n_right = keys.second.size();
+        if (left) std::copy(keys.first.begin(), keys.first.end(), left);
+        if (right) std::copy(keys.second.begin(), keys.second.end(), right);
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_candidates(const t4a_gpu_treetci* h, size_t u, size_t v, size_t* n_left, size_t* left,
+                                          size_t* n_right, size_t* right)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(n_left);
+        T4A_REQUIRE_PTR(n_right);
+        IndexSet l, r;
+        h->impl.candidates(TreeEdge(u, v), l, r);
+        write_index_set(l, n_left, left);
+        write_index_set(r, n_right, right);
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_update_edge(t4a_gpu_treetci* h, size_t u, size_t v, size_t max_bond_dim, double rel_tol,
+                                           double abs_tol, size_t* rank, size_t* rows, size_t* cols, double* pivot_errors)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        RrLUOptions o;
+        o.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim;
+        o.rel_tol = rel_tol;
+        o.abs_tol = abs_tol;
+        o.left_orthogonal = true;
+        const EdgeSelection sel = h->impl.update_edge(TreeEdge(u, v), o);
+        if (rank) *rank = sel.rank;
+        for (size_t k = 0; k < sel.rank; ++k) {
+            if (rows) rows[k] = sel.row_indices[k];
+            if (cols) cols[k] = sel.col_indices[k];
+        }
+        if (pivot_errors)
+            for (size_t k = 0; k < sel.pivot_errors.size(); ++k) pivot_errors[k] = sel.pivot_errors[k];
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_optimize(t4a_gpu_treetci* h, const t4a_gpu_treetci_options* options, size_t* n_iter,
+                                        size_t* ranks, double* errors)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        const TreeTciOptions o = convert_tree_options(options);
+        o.validate(); // before any callback runs (optimize/tests.rs:10-75)
+        h->impl.optimize(o);
+        write_history(h, n_iter, ranks, errors);
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_crossinterpolate2(t4a_gpu_treetci* h, const size_t* initial_pivots, size_t n_pivots,
+                                                 const t4a_gpu_treetci_options* options, size_t* n_iter, size_t* ranks,
+                                                 double* errors)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pivots) T4A_REQUIRE_PTR(initial_pivots);
+        const TreeTciOptions o = convert_tree_options(options);
+        o.validate();
+        h->impl.crossinterpolate2(tree_pivots_from(h, initial_pivots, n_pivots), o);
+        write_history(h, n_iter, ranks, errors);
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_find_global_pivots(t4a_gpu_treetci* h, size_t nsearch, size_t max_nglobal_pivot,
+                                                  double tol_margin, double abs_tol, uint64_t seed, size_t* count,
+                                                  size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        const auto pv = h->impl.find_global_pivots(nsearch, max_nglobal_pivot, tol_margin, abs_tol, seed);
+        *count = pv.size();
+        const size_t ns = h->impl.local_dims.size();
+        if (out)
+            for (size_t k = 0; k < pv.size(); ++k)
+                for (size_t s = 0; s < ns; ++s) out[s + ns * k] = pv[k][s];
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_pivots(const t4a_gpu_treetci* h, const size_t* key, size_t key_len, size_t* count,
+                                      size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        if (key_len) T4A_REQUIRE_PTR(key);
+        SubtreeKey k(key, key + key_len);
+        std::sort(k.begin(), k.end());
+        k.erase(std::unique(k.begin(), k.end()), k.end());
+        write_index_set(h->impl.pivots_of(k), count, out);
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_bond_errors(const t4a_gpu_treetci* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        size_t k = 0;
+        for (const auto& kv : h->impl.bond_errors) out[k++] = kv.second;
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_pivot_errors(const t4a_gpu_treetci* h, size_t* count, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        *count = h->impl.pivot_errors.size();
+        if (out) std::copy(h->impl.pivot_errors.begin(), h->impl.pivot_errors.end(), out);
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_flush_pivot_errors(t4a_gpu_treetci* h)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.flush_pivot_errors();
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_max_sample_value(const t4a_gpu_treetci* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.max_sample_value;
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_set_max_sample_value(t4a_gpu_treetci* h, double value)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.max_sample_value = value;
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_max_bond_error(const t4a_gpu_treetci* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.max_bond_error();
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_max_bond_dim(const t4a_gpu_treetci* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.max_bond_dim();
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_materialize(t4a_gpu_treetci* h, size_t center_site)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.materialize(center_site);
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_site_tensor(t4a_gpu_treetci* h, size_t site, size_t* ndims, size_t* dims, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(ndims);
+        std::vector<size_t> d;
+        const std::vector<double> v = h->impl.site_tensor_host(site, d);
+        *ndims = d.size();
+        if (dims) std::copy(d.begin(), d.end(), dims);
+        if (out && !v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(double));
+    });
+}
+
+t4a_gpu_status t4a_gpu_treetci_evaluate(t4a_gpu_treetci* h, const size_t* idx, size_t n_pts, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pts == 0) return;
+        T4A_REQUIRE_PTR(idx);
+        T4A_REQUIRE_PTR(out);
+        std::vector<uint32_t> u = narrow_indices(idx, checked_mul(n_pts, h->impl.local_dims.size(), "index buffer"));
+        std::vector<double> v = h->impl.evaluate(u.data(), n_pts);
         std::memcpy(out, v.data(), n_pts * sizeof(double));
     });
 }

@@ -845,3 +845,231 @@ def adaptiveinterpolate(f, local_dims, initial_pivots, options, patch_order=None
         cb = _BATCH_CB(_cb)
         _check(_lib.t4a_gpu_adaptive_interpolate_callback(_p(ld), c_size_t(n), cb, None, *common))
     return PartitionedTT(h, local_dims)
+
+
+# ---------------------------------------------------------------------------------------- tree TCI (tensor4all-treetci)
+class TreeTciOptionsC(ctypes.Structure):
+    _fields_ = [("tolerance", c_double), ("max_iter", c_size_t), ("max_bond_dim", c_size_t),
+                ("normalize_error", c_int32), ("enable_global_pivots", c_int32), ("nsearch", c_size_t),
+                ("max_nglobal_pivot", c_size_t), ("tol_margin_global_search", c_double), ("has_seed", c_int32),
+                ("seed", ctypes.c_uint64)]
+
+
+class TreeTciOptions:
+    """TreeTciOptions (treetci/src/optimize.rs:13-76)."""
+
+    def __init__(self, tolerance=1e-8, max_iter=20, max_bond_dim=None, normalize_error=True, enable_global_pivots=True,
+                 nsearch=5, max_nglobal_pivot=5, tol_margin_global_search=10.0, seed=None):
+        self.tolerance = tolerance
+        self.max_iter = max_iter
+        self.max_bond_dim = max_bond_dim
+        self.normalize_error = normalize_error
+        self.enable_global_pivots = enable_global_pivots
+        self.nsearch = nsearch
+        self.max_nglobal_pivot = max_nglobal_pivot
+        self.tol_margin_global_search = tol_margin_global_search
+        self.seed = seed
+
+    def to_c(self):
+        o = TreeTciOptionsC()
+        _check(_lib.t4a_gpu_treetci_options_default(ctypes.byref(o)))
+        o.tolerance = self.tolerance
+        o.max_iter = self.max_iter
+        o.max_bond_dim = 0 if self.max_bond_dim is None else self.max_bond_dim
+        o.normalize_error = int(self.normalize_error)
+        o.enable_global_pivots = int(self.enable_global_pivots)
+        o.nsearch = self.nsearch
+        o.max_nglobal_pivot = self.max_nglobal_pivot
+        o.tol_margin_global_search = self.tol_margin_global_search
+        o.has_seed = 0 if self.seed is None else 1
+        o.seed = 0 if self.seed is None else self.seed
+        return o
+
+
+class TreeTCI2:
+    """TreeTCI2<f64> on a TreeTciGraph (treetci/src/state.rs:41, graph.rs:44); edges = [(u, v), ...]."""
+
+    def __init__(self, local_dims, edges):
+        self.local_dims = [int(d) for d in local_dims]
+        self.n = len(self.local_dims)
+        ld = np.asarray(self.local_dims, dtype=np.uintp)
+        e = np.ascontiguousarray(np.asarray(edges, dtype=np.uintp).reshape(-1, 2))
+        self.n_edges = len(e)
+        self._h = c_void_p()
+        self._cb_keepalive = None
+        self.n_callback_calls = 0
+        _check(_lib.t4a_gpu_treetci_new(_p(ld), c_size_t(self.n), _p(e), c_size_t(len(e)), ctypes.byref(self._h)))
+        self._edges = sorted((min(int(a), int(b)), max(int(a), int(b))) for a, b in e)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.t4a_gpu_treetci_release(h)
+            self._h = None
+
+    def set_function(self, f):
+        """f as for TensorCI2.set_function; the batch callback receives the GlobalIndexBatch layout."""
+        if isinstance(f, FnSpec):
+            params = np.asarray(f.params, dtype=np.float64)
+            w = np.ascontiguousarray(f.weights, dtype=np.uint64)
+            _check(_lib.t4a_gpu_treetci_set_builtin_function(self._h, c_int32(f.fid), c_int32(f.n_acc), _p(params), _p(w)))
+            self._cb_keepalive = None
+            return
+        scalar = f
+        batched = getattr(f, "batched", None)
+        owner = self
+
+        def _cb(ctx, idx_ptr, n_sites, n_pts, out_ptr):
+            try:
+                owner.n_callback_calls += 1
+                idx = np.ctypeslib.as_array(idx_ptr, shape=(n_pts, n_sites))
+                if batched is not None:
+                    vals = np.asarray(batched(idx), dtype=np.float64).ravel()
+                else:
+                    vals = np.array([scalar([int(v) for v in row]) for row in idx], dtype=np.float64)
+                k = min(len(vals), n_pts)
+                out = np.ctypeslib.as_array(out_ptr, shape=(n_pts,))
+                out[:k] = vals[:k]
+                return len(vals)
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        cb = _BATCH_CB(_cb)
+        self._cb_keepalive = cb
+        _check(_lib.t4a_gpu_treetci_set_callback(self._h, cb, None))
+
+    def edges(self):
+        return list(self._edges)
+
+    def add_global_pivots(self, pivots):
+        piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uintp).reshape(len(pivots), self.n))
+        _check(_lib.t4a_gpu_treetci_add_global_pivots(self._h, _p(piv), c_size_t(len(pivots))))
+
+    def subregion_vertices(self, u, v):
+        nl, nr = c_size_t(0), c_size_t(0)
+        _check(_lib.t4a_gpu_treetci_subregion_vertices(self._h, c_size_t(u), c_size_t(v), ctypes.byref(nl), None,
+                                                       ctypes.byref(nr), None))
+        l, r = np.zeros(nl.value, dtype=np.uintp), np.zeros(nr.value, dtype=np.uintp)
+        _check(_lib.t4a_gpu_treetci_subregion_vertices(self._h, c_size_t(u), c_size_t(v), ctypes.byref(nl), _p(l),
+                                                       ctypes.byref(nr), _p(r)))
+        return [int(x) for x in l], [int(x) for x in r]
+
+    def candidates(self, u, v):
+        lk, rk = self.subregion_vertices(u, v)
+        nl, nr = c_size_t(0), c_size_t(0)
+        _check(_lib.t4a_gpu_treetci_candidates(self._h, c_size_t(u), c_size_t(v), ctypes.byref(nl), None, ctypes.byref(nr), None))
+        l = np.zeros((nl.value, len(lk)), dtype=np.uintp)
+        r = np.zeros((nr.value, len(rk)), dtype=np.uintp)
+        _check(_lib.t4a_gpu_treetci_candidates(self._h, c_size_t(u), c_size_t(v), ctypes.byref(nl), _p(l), ctypes.byref(nr), _p(r)))
+        return l.astype(np.int64), r.astype(np.int64)
+
+    def update_edge(self, u, v, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0):
+        nl, nr = c_size_t(0), c_size_t(0)
+        _check(_lib.t4a_gpu_treetci_candidates(self._h, c_size_t(u), c_size_t(v), ctypes.byref(nl), None, ctypes.byref(nr), None))
+        cap = min(nl.value, nr.value)
+        rows, cols = np.zeros(cap, dtype=np.uintp), np.zeros(cap, dtype=np.uintp)
+        errs = np.zeros(cap + 1)
+        rank = c_size_t(0)
+        _check(_lib.t4a_gpu_treetci_update_edge(self._h, c_size_t(u), c_size_t(v),
+                                                c_size_t(0 if max_bond_dim is None else max_bond_dim), c_double(rel_tol),
+                                                c_double(abs_tol), ctypes.byref(rank), _p(rows), _p(cols), _p(errs)))
+        r = rank.value
+        return {"rank": r, "row_indices": rows[:r].astype(np.int64), "col_indices": cols[:r].astype(np.int64),
+                "pivot_errors": errs[:r + 1].copy()}
+
+    def _history(self, fn, *args):
+        o = args[-1]
+        ranks = np.zeros(max(o.max_iter, 1), dtype=np.uintp)
+        errors = np.zeros(max(o.max_iter, 1))
+        n_iter = c_size_t(0)
+        _check(fn(self._h, *args[:-1], ctypes.byref(o), ctypes.byref(n_iter), _p(ranks), _p(errors)))
+        k = n_iter.value
+        return [int(x) for x in ranks[:k]], [float(x) for x in errors[:k]]
+
+    def optimize(self, options):
+        """optimize_default: returns (ranks, errors) per sweep."""
+        return self._history(_lib.t4a_gpu_treetci_optimize, options.to_c())
+
+    def crossinterpolate2(self, initial_pivots, options):
+        piv = np.ascontiguousarray(np.asarray(initial_pivots, dtype=np.uintp).reshape(len(initial_pivots), self.n))
+        return self._history(_lib.t4a_gpu_treetci_crossinterpolate2, _p(piv), c_size_t(len(initial_pivots)), options.to_c())
+
+    def find_global_pivots(self, nsearch, max_nglobal_pivot, tol_margin, abs_tol, seed):
+        c = c_size_t(0)
+        out = np.zeros((max(max_nglobal_pivot, 1), self.n), dtype=np.uintp)
+        _check(_lib.t4a_gpu_treetci_find_global_pivots(self._h, c_size_t(nsearch), c_size_t(max_nglobal_pivot),
+                                                       c_double(tol_margin), c_double(abs_tol), ctypes.c_uint64(seed),
+                                                       ctypes.byref(c), _p(out)))
+        return out[:c.value].astype(np.int64)
+
+    def pivots(self, key):
+        k = np.ascontiguousarray(np.asarray(sorted(key), dtype=np.uintp))
+        c = c_size_t(0)
+        _check(_lib.t4a_gpu_treetci_pivots(self._h, _p(k), c_size_t(len(k)), ctypes.byref(c), None))
+        out = np.zeros((c.value, len(k)), dtype=np.uintp)
+        _check(_lib.t4a_gpu_treetci_pivots(self._h, _p(k), c_size_t(len(k)), ctypes.byref(c), _p(out)))
+        return out.astype(np.int64)
+
+    def bond_errors(self):
+        out = np.zeros(self.n_edges)
+        _check(_lib.t4a_gpu_treetci_bond_errors(self._h, _p(out)))
+        return out
+
+    def pivot_errors(self):
+        c = c_size_t(0)
+        _check(_lib.t4a_gpu_treetci_pivot_errors(self._h, ctypes.byref(c), None))
+        out = np.zeros(c.value)
+        _check(_lib.t4a_gpu_treetci_pivot_errors(self._h, ctypes.byref(c), _p(out)))
+        return out
+
+    def flush_pivot_errors(self):
+        _check(_lib.t4a_gpu_treetci_flush_pivot_errors(self._h))
+
+    def max_sample_value(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_treetci_max_sample_value(self._h, ctypes.byref(v)))
+        return v.value
+
+    def set_max_sample_value(self, value):
+        _check(_lib.t4a_gpu_treetci_set_max_sample_value(self._h, c_double(value)))
+
+    def max_bond_error(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_treetci_max_bond_error(self._h, ctypes.byref(v)))
+        return v.value
+
+    def max_bond_dim(self):
+        v = c_size_t(0)
+        _check(_lib.t4a_gpu_treetci_max_bond_dim(self._h, ctypes.byref(v)))
+        return v.value
+
+    def materialize(self, center_site=0):
+        """to_treetn: per-site dense tensors [site, incoming bonds..., bond to the parent] on the device."""
+        _check(_lib.t4a_gpu_treetci_materialize(self._h, c_size_t(center_site)))
+
+    def site_tensor(self, site):
+        nd = c_size_t(0)
+        dims = np.zeros(self.n + 1, dtype=np.uintp)
+        _check(_lib.t4a_gpu_treetci_site_tensor(self._h, c_size_t(site), ctypes.byref(nd), _p(dims), None))
+        shape = [int(x) for x in dims[:nd.value]]
+        out = np.zeros(int(np.prod(shape)))
+        _check(_lib.t4a_gpu_treetci_site_tensor(self._h, c_size_t(site), ctypes.byref(nd), _p(dims), _p(out)))
+        return out.reshape(shape, order="F")
+
+    def evaluate(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uintp).reshape(-1, self.n))
+        out = np.zeros(idx.shape[0], dtype=np.float64)
+        _check(_lib.t4a_gpu_treetci_evaluate(self._h, _p(idx), c_size_t(idx.shape[0]), _p(out)))
+        return out
+
+
+def tree_crossinterpolate2(f, local_dims, edges, initial_pivots, options, center_site=None):
+    """treetci::crossinterpolate2 (api.rs:21-96) with the default proposer: returns (tree, ranks, errors) with the
+    network materialised around `center_site` (default 0)."""
+    t = TreeTCI2(local_dims, edges)
+    t.set_function(f)
+    ranks, errors = t.crossinterpolate2(initial_pivots, options)
+    t.materialize(0 if center_site is None else center_site)
+    return t, ranks, errors
