@@ -132,6 +132,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     if (!header_clean) T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
     static const bool want_stamps = std::getenv("T4A_RRLU_STAMPS") != nullptr;
     static const bool force_lds = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "lds";
+    static const bool force_global = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "global";
     if (want_stamps) {
         d_stamps_.reserve(8);
         T4A_HIP(hipMemsetAsync(d_stamps_.get(), 0, 8 * sizeof(unsigned long long), stream_));
@@ -142,7 +143,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     const bool left = opts.left_orthogonal;
     const int kM = left ? M : N, kN = left ? N : M;
     RrluRegPlan rplan;
-    const bool use_reg = !force_lds && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
+    const bool use_reg = !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     bool fuse = false;
     if (fused) {
         fuse = use_reg && rplan.RPT * rplan.CPT <= RRLU_FUSED_MAX_VALUES;
@@ -244,6 +245,29 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         plan_W = rplan.W;
         plan_T = rplan.T;
         plan_code = rplan.RPT * 1000 + rplan.CPT * 10 + (rplan.W == 1 ? 2 : 0) + ((rplan.TR % 64) == 0 ? 1 : 0);
+    } else if (force_global || rrlu_make_plan(M, N, num_cus_).lds_bytes > 160 * 1024) {
+        // neither the register file nor the LDS of the chip holds this matrix: HBM-resident kernel pair per pivot step
+        const int gb = rrlu_global_blocks(M, N);
+        d_gints_.reserve(rrlu_global_int_words(M, N, gb));
+        d_gdbls_.reserve(rrlu_global_double_words(M, N, gb));
+        RrluGlobalArgs a{};
+        a.A = d_a;
+        a.Aout = keep_lu ? d_lu_.get() : nullptr;
+        a.M = M;
+        a.N = N;
+        a.max_steps = max_steps;
+        a.rel_tol = opts.rel_tol;
+        a.abs_tol = opts.abs_tol;
+        a.left_orth = opts.left_orthogonal ? 1 : 0;
+        a.row_perm = d_rowperm;
+        a.col_perm = d_colperm;
+        a.iresult = d_ires;
+        a.dresult = d_dres;
+        a.pivot_vals = d_pivvals;
+        rrlu_global_launch(a, d_gints_.get(), d_gdbls_.get(), stream_);
+        plan_W = gb;
+        plan_T = 256;
+        plan_code = -3; // HBM-resident kernel
     } else {
         const RrluPlan plan = rrlu_make_plan(M, N, num_cus_);
         if (plan.W > 1) {

@@ -116,6 +116,8 @@ private:
     DevBuf<unsigned long long> d_keys_, d_cols_, d_rkeys_, d_rcols_, d_stamps_;
     DevBuf<TrsmProblem> d_trsm_;
     PinBuf<TrsmProblem> h_trsm_;
+    DevBuf<int> d_gints_;      // HBM-resident rrLU workspace
+    DevBuf<double> d_gdbls_;
     EventTimer ev_rrlu_, ev_fac_;
     // SVD / QR workspaces
     DevBuf<double> d_sw_, d_sv_, d_su_, d_svs_, d_ssig_;

@@ -54,6 +54,33 @@ size_t rrlu_cols_bytes(const RrluPlan& plan, int M);
 // Enqueue memset of the key mailbox + the kernel.
 void rrlu_launch(const RrluPlan& plan, const RrluArgs& args, hipStream_t stream);
 
+// ---- HBM-resident fallback (kernels_rrlu_global.hip): any shape up to 65535 x 65535, two launches per pivot step ----
+struct RrluGlobalArgs {
+    const double* A;            // M x N input (ld = M), left untouched
+    double* Aout;               // factored matrix in permuted coordinates (ld = M) or nullptr
+    int M, N;
+    int max_steps;
+    double rel_tol, abs_tol;
+    int left_orth;
+    int* row_perm;
+    int* col_perm;
+    int* iresult;               // [0] npivots [2] NaN flag
+    double* dresult;            // [0] last error [1] bits of max sqrt(v*v)
+    double* pivot_vals;
+    // workspace views, filled by rrlu_global_launch
+    double* W;                  // working copy
+    int *rowpos, *colpos, *posrow, *poscol;
+    double *partials_sc, *partials_val;
+    unsigned* partials_pos;
+    int* partials_ij;
+    int* istate;                // [0] ticket counter [1] stop flag [2] pivot row [3] pivot column (physical) [4] npivots
+    double* dstate;             // [0] pivot [1] max_error [2] lu.error
+};
+int rrlu_global_blocks(int M, int N);
+size_t rrlu_global_int_words(int M, int N, int blocks);
+size_t rrlu_global_double_words(int M, int N, int blocks);
+void rrlu_global_launch(RrluGlobalArgs args, int* iwork, double* dwork, hipStream_t stream);
+
 // built-in device functor (include/t4a_testfunctions.h): id, number of integer accumulators, parameters
 struct FnDevice {
     int fid;

@@ -1,0 +1,124 @@
+"""HBM-resident rrLU fallback (kernels_rrlu_global.hip): shapes that fit neither the register-resident nor the
+LDS-resident kernel (tree hubs: d*chi*chi x d*chi) against the CPU oracle, bit-exact pivots; plus the same kernel forced
+onto small fuzz cases (ties, NaN, rank deficiency, both orthogonalities) in a subprocess with T4A_RRLU_IMPL=global."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def t4a():
+    import t4a_amd
+    if t4a_amd.device_count() < 1:
+        pytest.fail("no MI355X visible: the product path has no CPU fallback")
+    return t4a_amd
+
+
+def check(t4a, a, **kw):
+    lu = t4a.rrlu(a, **kw)
+    f, rp, cp, npiv, err = ob.rrlu(a, **kw)
+    assert lu.npivots() == npiv
+    assert np.array_equal(lu.row_permutation, rp) and np.array_equal(lu.col_permutation, cp)
+    assert np.array_equal(lu.factored, f)
+    assert lu.error == err or (np.isnan(lu.error) and np.isnan(err))
+    return lu
+
+
+@pytest.mark.parametrize("shape", [(8192, 128), (8300, 131), (20000, 40), (16384, 96), (2500, 2500), (65535, 8)])
+@pytest.mark.parametrize("left", [True, False])
+def test_tall_and_large_shapes_match_oracle(t4a, shape, left):
+    m, n = shape
+    rng = np.random.default_rng(m + n)
+    r = 24
+    a = rng.standard_normal((m, r)) @ rng.standard_normal((r, n)) + 1e-7 * rng.standard_normal((m, n))
+    g = check(t4a, a, max_bond_dim=20, rel_tol=1e-12, left_orthogonal=left)
+    k = min(20, n)
+    assert g.npivots() == k
+    # the factors reproduce the selected cross: L U = A[rows, cols] to rounding
+    l, u = g.left(), g.right()
+    rows, cols = np.asarray(g.row_indices()), np.asarray(g.col_indices())
+    assert np.abs((l @ u)[:k][:, :k] - a[np.ix_(rows, cols)]).max() < 1e-9 * np.abs(a).max()
+
+
+def test_tolerance_stop_and_full_rank_error(t4a):
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((9000, 6)) @ rng.standard_normal((6, 70))
+    g = check(t4a, a, rel_tol=1e-10)
+    assert g.npivots() == 6
+    b = rng.standard_normal((9000, 5))
+    g = check(t4a, b, rel_tol=0.0, abs_tol=0.0)
+    assert g.npivots() == 5 and g.last_pivot_error() == 0.0
+
+
+def test_integer_ties_take_the_first_column_major_maximum(t4a):
+    rng = np.random.default_rng(4)
+    a = rng.integers(-3, 4, size=(8200, 24)).astype(np.float64)
+    check(t4a, a, max_bond_dim=12, rel_tol=0.0)
+    check(t4a, a, max_bond_dim=12, rel_tol=0.0, left_orthogonal=False)
+
+
+SCRIPT = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tensor4all-rs_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import t4a_amd
+import oracle_binding as ob
+rng = np.random.default_rng(11)
+n_checked = 0
+for case in range(120):
+    m, n = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    kind = case % 6
+    if kind == 0:
+        a = rng.standard_normal((m, n))
+    elif kind == 1:
+        r = int(rng.integers(1, 6))
+        a = rng.standard_normal((m, r)) @ rng.standard_normal((r, n))
+    elif kind == 2:
+        a = rng.integers(-2, 3, size=(m, n)).astype(np.float64)
+    elif kind == 3:
+        a = np.zeros((m, n))
+    elif kind == 4:
+        a = rng.standard_normal((m, n)) * 1e-13
+    else:
+        a = rng.standard_normal((m, n))
+        a[int(rng.integers(0, m)), int(rng.integers(0, n))] = np.nan
+    kw = dict(left_orthogonal=bool(case % 2), rel_tol=[1e-14, 0.0, 1e-6][case % 3], abs_tol=[0.0, 0.0, 1e-3, 1e-12][case % 4],
+              max_bond_dim=[None, 3, 1, 40][case % 4])
+    try:
+        o = ob.rrlu(a, **kw)
+        oerr = None
+    except ob.OracleError as e:
+        o, oerr = None, e.code
+    try:
+        g = t4a_amd.rrlu(a, **kw)
+        gerr = None
+    except t4a_amd.T4aError as e:
+        g, gerr = None, e.code
+    assert gerr == oerr, (case, m, n, kw, gerr, oerr)
+    if o is None:
+        continue
+    f, rp, cp, npiv, err = o
+    assert g.npivots() == npiv, (case, m, n, kw)
+    assert np.array_equal(g.row_permutation, rp) and np.array_equal(g.col_permutation, cp), (case, m, n, kw)
+    assert np.array_equal(g.factored, f, equal_nan=True), (case, m, n, kw)
+    assert g.error == err or (np.isnan(g.error) and np.isnan(err)), (case, m, n, kw)
+    n_checked += 1
+print("checked", n_checked)
+'''
+
+
+def test_forced_global_kernel_fuzz_is_bit_exact(t4a):
+    env = dict(os.environ, T4A_RRLU_IMPL="global")
+    out = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + SCRIPT], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "checked" in out.stdout and int(out.stdout.split("checked")[-1]) >= 90

@@ -1,6 +1,6 @@
 """Tree TCI probe: the 2-variable oscillatory integrand on a "two-chain" tree (x bits and y bits as two chains joined at
 their most significant bits) versus the interleaved linear chain; device time per optimisation, optional oracle check.
-Usage: python tools/probe_tree.py [n_sites] [max_bond_dim] [oracle]"""
+Usage: python tools/probe_tree.py [n_sites] [max_bond_dim] [oracle|-] [hard]"""
 import os
 import sys
 import time
@@ -16,14 +16,17 @@ from t4a_amd.functions import quantics_osc2d
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 chi = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 with_oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"
-f = quantics_osc2d(n, eps=0.1)
+hard = len(sys.argv) > 4 and sys.argv[4] == "hard"
+f = quantics_osc2d(n, 37, 53, 2111, 0.5, 16411, 0.5) if hard else quantics_osc2d(n, eps=0.1)
 two_chain = [(0, 1)] + [(s, s + 2) for s in range(n - 2)]
+# y chain hanging off the middle of the x chain: a genuine degree-3 vertex (candidate rows d * chi * chi there)
+t_tree = [(2 * (n // 4), 1)] + [(s, s + 2) for s in range(n - 2)]
 chain = [(s, s + 1) for s in range(n - 1)]
 rng = np.random.default_rng(7)
 pts = rng.integers(0, 2, size=(2000, n))
 import oracle_binding as ob
 exact = ob.fn_eval(f, pts)
-for name, edges in (("two-chain tree", two_chain), ("interleaved chain", chain)):
+for name, edges in (("two-chain tree", two_chain), ("T tree", t_tree), ("interleaved chain", chain)):
     opt = t4a_amd.TreeTciOptions(tolerance=1e-9, max_iter=6, max_bond_dim=chi, enable_global_pivots=False)
     t = t4a_amd.TreeTCI2([2] * n, edges)
     t.set_function(f)
