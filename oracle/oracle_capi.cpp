@@ -4,6 +4,7 @@
 #include "t4a_oracle.hpp"
 #include "t4a_oracle_patch.hpp"
 #include "t4a_oracle_tree.hpp"
+#include "t4a_oracle_quantics.hpp"
 
 #include "../include/t4a_testfunctions.h"
 
@@ -846,6 +847,170 @@ int oracle_solve_right_full_piv_lu(const double* pi1, uint64_t rows, uint64_t co
         std::vector<double> a(pi1, pi1 + rows * cols), b(p, p + cols * cols);
         auto r = tree_detail::solve_right_full_piv_lu(a, rows, cols, b, cols, cols);
         std::copy(r.begin(), r.end(), x);
+    });
+}
+
+// ---- quantics front end (t4a_oracle_quantics.hpp) ----
+typedef double (*coord_cb_t)(void* ctx, const double* x, uint64_t n);
+typedef double (*grididx_cb_t)(void* ctx, const uint64_t* idx, uint64_t n);
+
+static QtciOptions make_qtci_options(double tolerance, uint64_t max_bond_dim, uint64_t max_iter, uint64_t n_random, int unfolding,
+                                     int normalize_error, int has_seed, uint64_t seed)
+{
+    QtciOptions o;
+    o.tolerance = tolerance;
+    o.max_bond_dim = (size_t)max_bond_dim;
+    o.max_iter = (size_t)max_iter;
+    o.n_random_init_pivot = (size_t)n_random;
+    o.unfolding = unfolding ? Unfolding::Fused : Unfolding::Interleaved;
+    o.normalize_error = normalize_error != 0;
+    o.has_seed = has_seed != 0;
+    o.seed = seed;
+    return o;
+}
+static std::vector<std::vector<size_t>> grid_pivots(const uint64_t* pivots, uint64_t n_pivots, size_t n_vars)
+{
+    std::vector<std::vector<size_t>> p;
+    for (size_t k = 0; k < n_pivots; ++k) p.emplace_back(pivots + k * n_vars, pivots + (k + 1) * n_vars);
+    return p;
+}
+
+void* oracle_qtci_continuous(const uint64_t* rs, uint64_t n_vars, const double* lower, const double* upper, int include_endpoint,
+                             int grid_unfolding, coord_cb_t cb, void* ctx, int has_pivots, const uint64_t* pivots,
+                             uint64_t n_pivots, double tolerance, uint64_t max_bond_dim, uint64_t max_iter, uint64_t n_random,
+                             int unfolding, int normalize_error, int has_seed, uint64_t seed)
+{
+    void* out = nullptr;
+    guarded([&] {
+        QuanticsGrid grid(std::vector<size_t>(rs, rs + n_vars), grid_unfolding ? Unfolding::Fused : Unfolding::Interleaved, true,
+                          std::vector<double>(lower, lower + n_vars), std::vector<double>(upper, upper + n_vars),
+                          include_endpoint != 0);
+        auto pv = grid_pivots(pivots, has_pivots ? n_pivots : 0, n_vars);
+        CoordFn f = [cb, ctx](const std::vector<double>& x) { return cb(ctx, x.data(), x.size()); };
+        out = new QuanticsTensorCI2(quanticscrossinterpolate(
+            grid, f, has_pivots ? &pv : nullptr,
+            make_qtci_options(tolerance, max_bond_dim, max_iter, n_random, unfolding, normalize_error, has_seed, seed)));
+    });
+    return out;
+}
+void* oracle_qtci_discrete(const uint64_t* sizes, uint64_t n_vars, grididx_cb_t cb, void* ctx, int has_pivots,
+                           const uint64_t* pivots, uint64_t n_pivots, double tolerance, uint64_t max_bond_dim, uint64_t max_iter,
+                           uint64_t n_random, int unfolding, int normalize_error, int has_seed, uint64_t seed)
+{
+    void* out = nullptr;
+    guarded([&] {
+        auto pv = grid_pivots(pivots, has_pivots ? n_pivots : 0, n_vars);
+        GridIdxFn f = [cb, ctx](const std::vector<size_t>& idx) {
+            std::vector<uint64_t> v(idx.begin(), idx.end());
+            return cb(ctx, v.data(), v.size());
+        };
+        out = new QuanticsTensorCI2(quanticscrossinterpolate_discrete(
+            std::vector<size_t>(sizes, sizes + n_vars), f, has_pivots ? &pv : nullptr,
+            make_qtci_options(tolerance, max_bond_dim, max_iter, n_random, unfolding, normalize_error, has_seed, seed)));
+    });
+    return out;
+}
+void* oracle_qtci_from_arrays(const double* xvals, const uint64_t* sizes, uint64_t n_vars, coord_cb_t cb, void* ctx, int has_pivots,
+                              const uint64_t* pivots, uint64_t n_pivots, double tolerance, uint64_t max_bond_dim,
+                              uint64_t max_iter, uint64_t n_random, int unfolding, int normalize_error, int has_seed, uint64_t seed)
+{
+    void* out = nullptr;
+    guarded([&] {
+        std::vector<std::vector<double>> xv;
+        size_t off = 0;
+        for (size_t d = 0; d < n_vars; ++d) {
+            xv.emplace_back(xvals + off, xvals + off + sizes[d]);
+            off += sizes[d];
+        }
+        auto pv = grid_pivots(pivots, has_pivots ? n_pivots : 0, n_vars);
+        CoordFn f = [cb, ctx](const std::vector<double>& x) { return cb(ctx, x.data(), x.size()); };
+        out = new QuanticsTensorCI2(quanticscrossinterpolate_from_arrays(
+            xv, f, has_pivots ? &pv : nullptr,
+            make_qtci_options(tolerance, max_bond_dim, max_iter, n_random, unfolding, normalize_error, has_seed, seed)));
+    });
+    return out;
+}
+void oracle_qtci_release(void* h) { delete static_cast<QuanticsTensorCI2*>(h); }
+uint64_t oracle_qtci_n_sites(void* h) { return static_cast<QuanticsTensorCI2*>(h)->tt.len(); }
+uint64_t oracle_qtci_n_vars(void* h) { return static_cast<QuanticsTensorCI2*>(h)->grid.n_vars(); }
+int oracle_qtci_is_discretized(void* h) { return static_cast<QuanticsTensorCI2*>(h)->grid.discretized ? 1 : 0; }
+uint64_t oracle_qtci_cache_size(void* h) { return static_cast<QuanticsTensorCI2*>(h)->cache.size(); }
+uint64_t oracle_qtci_n_iterations(void* h) { return static_cast<QuanticsTensorCI2*>(h)->ranks.size(); }
+int oracle_qtci_history(void* h, uint64_t* ranks, double* errors)
+{
+    return guarded([&] {
+        auto* q = static_cast<QuanticsTensorCI2*>(h);
+        for (size_t k = 0; k < q->ranks.size(); ++k) {
+            ranks[k] = q->ranks[k];
+            errors[k] = q->errors[k];
+        }
+    });
+}
+int oracle_qtci_evaluate(void* h, const uint64_t* grididx, uint64_t n_pts, double* out)
+{
+    return guarded([&] {
+        auto* q = static_cast<QuanticsTensorCI2*>(h);
+        const size_t nv = q->grid.n_vars();
+        for (size_t p = 0; p < n_pts; ++p) out[p] = q->evaluate(std::vector<size_t>(grididx + p * nv, grididx + (p + 1) * nv));
+    });
+}
+int oracle_qtci_sum(void* h, double* sum, double* integral)
+{
+    return guarded([&] {
+        auto* q = static_cast<QuanticsTensorCI2*>(h);
+        *sum = q->sum();
+        *integral = q->integral();
+    });
+}
+int oracle_qtci_site_tensor(void* h, uint64_t site, uint64_t* dims3, double* out)
+{
+    return guarded([&] {
+        const auto& t = static_cast<QuanticsTensorCI2*>(h)->tt.tensors.at(site);
+        dims3[0] = t.l;
+        dims3[1] = t.s;
+        dims3[2] = t.r;
+        if (out && !t.d.empty()) std::memcpy(out, t.d.data(), t.d.size() * sizeof(double));
+    });
+}
+int oracle_qtci_cachedata(void* h, uint64_t* quantics, double* values)
+{
+    return guarded([&] {
+        auto* q = static_cast<QuanticsTensorCI2*>(h);
+        size_t k = 0, o = 0;
+        for (const auto& kv : q->cache) {
+            for (size_t v : kv.first) quantics[o++] = v;
+            values[k++] = kv.second;
+        }
+    });
+}
+// which: 0 grididx -> quantics, 1 quantics -> grididx, 2 quantics -> origcoord (out_d), 3 local dimensions, 4 grid step (out_d)
+int oracle_qtci_grid(void* h, int which, const uint64_t* in, uint64_t* out_u, double* out_d)
+{
+    return guarded([&] {
+        const QuanticsGrid& g = static_cast<QuanticsTensorCI2*>(h)->grid;
+        if (which == 0) {
+            auto q = g.grididx_to_quantics(std::vector<size_t>(in, in + g.n_vars()));
+            std::copy(q.begin(), q.end(), out_u);
+        } else if (which == 1) {
+            auto x = g.quantics_to_grididx(MultiIndex(in, in + g.sites.size()));
+            std::copy(x.begin(), x.end(), out_u);
+        } else if (which == 2) {
+            auto x = g.quantics_to_origcoord(MultiIndex(in, in + g.sites.size()));
+            std::copy(x.begin(), x.end(), out_d);
+        } else if (which == 3) {
+            auto d = g.local_dimensions();
+            std::copy(d.begin(), d.end(), out_u);
+        } else {
+            auto st = g.grid_step();
+            std::copy(st.begin(), st.end(), out_d);
+        }
+    });
+}
+int oracle_qtci_tree_pivots(void* h, const uint64_t* key, uint64_t key_len, uint64_t* count, uint64_t* out)
+{
+    return guarded([&] {
+        SubtreeKey k(key, key + key_len);
+        write_index_list(static_cast<QuanticsTensorCI2*>(h)->tci->pivots_of(k), count, out);
     });
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp", "t4a_oracle_patch.hpp",
-                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp")] + [
+                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp", "t4a_oracle_quantics.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -769,3 +769,169 @@ def solve_right_full_piv_lu(pi1, p):
     x = np.zeros(a.shape, order="F")
     _check(_lib.oracle_solve_right_full_piv_lu(_p(a), u64(a.shape[0]), u64(a.shape[1]), _p(b), _p(x)))
     return x
+
+
+# ------------------------------------------------------------------------------------------------ quantics front end
+INTERLEAVED, FUSED = 0, 1
+_COORD_CB = ctypes.CFUNCTYPE(dbl, vp, ctypes.POINTER(dbl), u64)
+_GRIDIDX_CB = ctypes.CFUNCTYPE(dbl, vp, ctypes.POINTER(u64), u64)
+for _n in ("oracle_qtci_continuous", "oracle_qtci_discrete", "oracle_qtci_from_arrays"):
+    getattr(_lib, _n).restype = vp
+for _n in ("oracle_qtci_n_sites", "oracle_qtci_n_vars", "oracle_qtci_cache_size", "oracle_qtci_n_iterations"):
+    getattr(_lib, _n).restype = u64
+    getattr(_lib, _n).argtypes = [vp]
+_lib.oracle_qtci_release.argtypes = [vp]
+_lib.oracle_qtci_is_discretized.argtypes = [vp]
+
+
+class QtciOptions:
+    """QtciOptions (quanticstci/src/options.rs:9-45); `seed` fixes the random initial pivots (reference: rand::rng())."""
+
+    def __init__(self, tolerance=1e-8, max_bond_dim=None, max_iter=200, n_random_init_pivot=5, unfolding_scheme=INTERLEAVED,
+                 normalize_error=True, seed=None):
+        self.tolerance = tolerance
+        self.max_bond_dim = max_bond_dim
+        self.max_iter = max_iter
+        self.n_random_init_pivot = n_random_init_pivot
+        self.unfolding_scheme = unfolding_scheme
+        self.normalize_error = normalize_error
+        self.seed = seed
+
+    def args(self):
+        return [dbl(self.tolerance), u64(0 if self.max_bond_dim is None else self.max_bond_dim), u64(self.max_iter),
+                u64(self.n_random_init_pivot), cint(self.unfolding_scheme), cint(int(self.normalize_error)),
+                cint(0 if self.seed is None else 1), u64(0 if self.seed is None else self.seed)]
+
+
+def _pivot_args(pivots, n_vars):
+    if pivots is None:
+        return [cint(0), None, u64(0)], None
+    piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), n_vars))
+    return [cint(1), _p(piv), u64(len(pivots))], piv
+
+
+class OracleQuanticsTCI2:
+    """QuanticsTensorCI2 restatement (oracle/t4a_oracle_quantics.hpp)."""
+
+    def __init__(self, handle, keep):
+        if not handle:
+            raise OracleError(-2)
+        self._h = handle
+        self._keep = keep
+        self.n_vars = int(_lib.oracle_qtci_n_vars(vp(handle)))
+        self.n_sites = int(_lib.oracle_qtci_n_sites(vp(handle)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.oracle_qtci_release(self._h)
+            self._h = None
+
+    def history(self):
+        k = int(_lib.oracle_qtci_n_iterations(vp(self._h)))
+        ranks, errors = np.zeros(k, dtype=np.uint64), np.zeros(k)
+        _check(_lib.oracle_qtci_history(vp(self._h), _p(ranks), _p(errors)))
+        return [int(x) for x in ranks], [float(x) for x in errors]
+
+    def is_discretized(self):
+        return bool(_lib.oracle_qtci_is_discretized(vp(self._h)))
+
+    def evaluate(self, grididx):
+        g = np.ascontiguousarray(np.asarray(grididx, dtype=np.uint64).reshape(-1, self.n_vars))
+        out = np.zeros(g.shape[0])
+        _check(_lib.oracle_qtci_evaluate(vp(self._h), _p(g), u64(g.shape[0]), _p(out)))
+        return out
+
+    def sum(self):
+        s, i = dbl(0), dbl(0)
+        _check(_lib.oracle_qtci_sum(vp(self._h), ctypes.byref(s), ctypes.byref(i)))
+        return s.value
+
+    def integral(self):
+        s, i = dbl(0), dbl(0)
+        _check(_lib.oracle_qtci_sum(vp(self._h), ctypes.byref(s), ctypes.byref(i)))
+        return i.value
+
+    def cores(self):
+        out = []
+        for site in range(self.n_sites):
+            d = np.zeros(3, dtype=np.uint64)
+            _check(_lib.oracle_qtci_site_tensor(vp(self._h), u64(site), _p(d), None))
+            a = np.zeros(int(d.prod()))
+            _check(_lib.oracle_qtci_site_tensor(vp(self._h), u64(site), _p(d), _p(a)))
+            out.append(a.reshape([int(x) for x in d], order="F"))
+        return out
+
+    def link_dims(self):
+        return [c.shape[2] for c in self.cores()[:-1]]
+
+    def rank(self):
+        return max(self.link_dims()) if self.n_sites > 1 else 1
+
+    def cachedata(self):
+        k = int(_lib.oracle_qtci_cache_size(vp(self._h)))
+        q, v = np.zeros((k, self.n_sites), dtype=np.uint64), np.zeros(k)
+        _check(_lib.oracle_qtci_cachedata(vp(self._h), _p(q), _p(v)))
+        return {tuple(int(x) for x in row): float(val) for row, val in zip(q, v)}
+
+    def _grid(self, which, arr, n_out, floats=False):
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.uint64))
+        ou, od = np.zeros(max(n_out, 1), dtype=np.uint64), np.zeros(max(n_out, 1))
+        _check(_lib.oracle_qtci_grid(vp(self._h), cint(which), _p(a), _p(ou), _p(od)))
+        return [float(x) for x in od[:n_out]] if floats else [int(x) for x in ou[:n_out]]
+
+    def grididx_to_quantics(self, g):
+        return self._grid(0, g, self.n_sites)
+
+    def quantics_to_grididx(self, q):
+        return self._grid(1, q, self.n_vars)
+
+    def quantics_to_origcoord(self, q):
+        return self._grid(2, q, self.n_vars, floats=True)
+
+    def local_dimensions(self):
+        return self._grid(3, [0], self.n_sites)
+
+    def grid_step(self):
+        return self._grid(4, [0], self.n_vars, floats=True)
+
+    def tree_pivots(self, key):
+        k = np.ascontiguousarray(np.asarray(sorted(key), dtype=np.uint64))
+        c = u64(0)
+        _check(_lib.oracle_qtci_tree_pivots(vp(self._h), _p(k), u64(len(k)), ctypes.byref(c), None))
+        out = np.zeros((c.value, len(k)), dtype=np.uint64)
+        _check(_lib.oracle_qtci_tree_pivots(vp(self._h), _p(k), u64(len(k)), ctypes.byref(c), _p(out)))
+        return out.astype(np.int64)
+
+
+def quanticscrossinterpolate(rs, f, lower=None, upper=None, include_endpoint=False, grid_unfolding=INTERLEAVED,
+                             initial_pivots=None, options=None):
+    """quanticscrossinterpolate(&DiscretizedGrid, f(coords), initial_pivots, options) restatement."""
+    options = options or QtciOptions()
+    rs_a = np.asarray(rs, dtype=np.uint64)
+    nv = len(rs_a)
+    lo = np.asarray([0.0] * nv if lower is None else lower, dtype=np.float64)
+    up = np.asarray([1.0] * nv if upper is None else upper, dtype=np.float64)
+    cb = _COORD_CB(lambda ctx, x, n: float(f([x[i] for i in range(n)])))
+    pa, keep = _pivot_args(initial_pivots, nv)
+    h = _lib.oracle_qtci_continuous(_p(rs_a), u64(nv), _p(lo), _p(up), cint(int(include_endpoint)), cint(grid_unfolding), cb,
+                                    None, *pa, *options.args())
+    return OracleQuanticsTCI2(h, (cb, keep))
+
+
+def quanticscrossinterpolate_discrete(sizes, f, initial_pivots=None, options=None):
+    options = options or QtciOptions()
+    sz = np.asarray(sizes, dtype=np.uint64)
+    cb = _GRIDIDX_CB(lambda ctx, idx, n: float(f([int(idx[i]) for i in range(n)])))
+    pa, keep = _pivot_args(initial_pivots, len(sz))
+    h = _lib.oracle_qtci_discrete(_p(sz), u64(len(sz)), cb, None, *pa, *options.args())
+    return OracleQuanticsTCI2(h, (cb, keep))
+
+
+def quanticscrossinterpolate_from_arrays(xvals, f, initial_pivots=None, options=None):
+    options = options or QtciOptions()
+    sz = np.asarray([len(x) for x in xvals], dtype=np.uint64)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in xvals]) if len(xvals) else np.zeros(0))
+    cb = _COORD_CB(lambda ctx, x, n: float(f([x[i] for i in range(n)])))
+    pa, keep = _pivot_args(initial_pivots, len(sz))
+    h = _lib.oracle_qtci_from_arrays(_p(flat), _p(sz), u64(len(sz)), cb, None, *pa, *options.args())
+    return OracleQuanticsTCI2(h, (cb, keep))
