@@ -407,6 +407,73 @@ t4a_gpu_status t4a_gpu_treetci_site_tensor(t4a_gpu_treetci* h, size_t site, size
 /* TreeTN::evaluate of the materialised network at full multi-indices (idx: n_sites x n_pts column-major). */
 t4a_gpu_status t4a_gpu_treetci_evaluate(t4a_gpu_treetci* h, const size_t* idx, size_t n_pts, double* out);
 
+/* =====================================================================================
+ * Quantics front end: tensor4all-quanticstci
+ * crates/tensor4all-quanticstci/src/{options.rs,quantics_tci.rs}
+ * Grid conventions (crate quanticsgrids @ 8214b72, un-vendored; restated from its published algorithm): R_d bits per
+ * variable, most significant bit first, 0-based grid indices; unfolding 0 = Interleaved (one binary site per bit level
+ * and variable), 1 = Fused (one site per bit level, value = sum_d bit_d * 2^d, first variable least significant).
+ * ===================================================================================== */
+typedef struct t4a_gpu_qtci t4a_gpu_qtci;
+/* f: Fn(&[f64]) -> f64 evaluated for a batch: coords is n_vars x n_pts column-major; returns the number of values written */
+typedef int64_t (*t4a_gpu_coord_eval_fn)(void* ctx, const double* coords, size_t n_vars, size_t n_pts, double* out);
+/* f: Fn(&[usize]) -> f64 on 0-based grid indices, same batch layout */
+typedef int64_t (*t4a_gpu_grididx_eval_fn)(void* ctx, const size_t* grididx, size_t n_vars, size_t n_pts, double* out);
+
+/* QtciOptions (options.rs:9-45).  max_bond_dim == 0 <=> None.  The random initial pivots use rand::rng() in the
+ * reference; here a fixed stream unless has_seed is set. */
+typedef struct t4a_gpu_qtci_options {
+    double tolerance;              /* 1e-8 */
+    size_t max_bond_dim;           /* 0 */
+    size_t max_iter;               /* 200 */
+    size_t n_random_init_pivot;    /* 5 */
+    int32_t unfolding_scheme;      /* 0 Interleaved */
+    int32_t normalize_error;       /* 1 */
+    int32_t has_seed;              /* 0 */
+    uint64_t seed;
+} t4a_gpu_qtci_options;
+t4a_gpu_status t4a_gpu_qtci_options_default(t4a_gpu_qtci_options* opts);
+
+/* quanticscrossinterpolate(&DiscretizedGrid, f, initial_pivots, options) (quantics_tci.rs:175-307).  The grid is given by
+ * its builder arguments: bits per variable, bounds (NULL = 0 / 1), include_endpoint and the grid's own unfolding scheme.
+ * initial_pivots: n_vars x n_pivots grid indices, column-major; has_pivots == 0 <=> None (first grid point).
+ * Every distinct quantics point is evaluated once (cachedata); all misses of one candidate matrix reach `f` in one call. */
+t4a_gpu_status t4a_gpu_quanticscrossinterpolate(const size_t* rs, size_t n_vars, const double* lower, const double* upper,
+                                                int32_t include_endpoint, int32_t grid_unfolding, t4a_gpu_coord_eval_fn f,
+                                                void* ctx, int32_t has_pivots, const size_t* initial_pivots, size_t n_pivots,
+                                                const t4a_gpu_qtci_options* options, t4a_gpu_qtci** out);
+/* quanticscrossinterpolate_discrete(size, f, initial_pivots, options) (:434-560): power-of-two sizes, equal in every
+ * direction; unfolding from the options. */
+t4a_gpu_status t4a_gpu_quanticscrossinterpolate_discrete(const size_t* sizes, size_t n_vars, t4a_gpu_grididx_eval_fn f,
+                                                         void* ctx, int32_t has_pivots, const size_t* initial_pivots,
+                                                         size_t n_pivots, const t4a_gpu_qtci_options* options,
+                                                         t4a_gpu_qtci** out);
+/* quanticscrossinterpolate_from_arrays(xvals, f, ..) (:309-432): xvals concatenated, sizes[d] values per variable;
+ * uniform coordinates -> discretized grid with the end point included, otherwise coordinate lookup on an inherent grid. */
+t4a_gpu_status t4a_gpu_quanticscrossinterpolate_from_arrays(const double* xvals, const size_t* sizes, size_t n_vars,
+                                                            t4a_gpu_coord_eval_fn f, void* ctx, int32_t has_pivots,
+                                                            const size_t* initial_pivots, size_t n_pivots,
+                                                            const t4a_gpu_qtci_options* options, t4a_gpu_qtci** out);
+void t4a_gpu_qtci_release(t4a_gpu_qtci* h);
+/* QuanticsTensorCI2 accessors (:53-173) */
+t4a_gpu_status t4a_gpu_qtci_evaluate(t4a_gpu_qtci* h, const size_t* grididx, size_t n_pts, double* out);
+t4a_gpu_status t4a_gpu_qtci_sum(t4a_gpu_qtci* h, double* out);
+t4a_gpu_status t4a_gpu_qtci_integral(t4a_gpu_qtci* h, double* out);
+t4a_gpu_status t4a_gpu_qtci_n_sites(const t4a_gpu_qtci* h, size_t* n_sites, size_t* n_vars, int32_t* is_discretized);
+t4a_gpu_status t4a_gpu_qtci_link_dims(const t4a_gpu_qtci* h, size_t* out /* n_sites - 1 */);
+t4a_gpu_status t4a_gpu_qtci_history(const t4a_gpu_qtci* h, size_t* n_iter, size_t* ranks, double* errors);
+/* tensor_train(): a new handle owning a device copy of the cores */
+t4a_gpu_status t4a_gpu_qtci_tensor_train(t4a_gpu_qtci* h, t4a_gpu_tt** out);
+/* tci(): pivot table of the underlying TreeTCI2 for a subtree key */
+t4a_gpu_status t4a_gpu_qtci_tree_pivots(const t4a_gpu_qtci* h, const size_t* key, size_t key_len, size_t* count, size_t* out);
+/* cachedata(): count entries; quantics is n_sites x count column-major (NULL to query); user_calls / user_points (may
+ * be NULL) report how often and for how many points the user function was called */
+t4a_gpu_status t4a_gpu_qtci_cachedata(const t4a_gpu_qtci* h, size_t* count, size_t* quantics, double* values,
+                                      size_t* user_calls, size_t* user_points);
+/* grid conversions: which = 0 grididx -> quantics, 1 quantics -> grididx, 2 quantics -> origcoord (out_d),
+ * 3 local_dimensions, 4 grid_step (out_d) */
+t4a_gpu_status t4a_gpu_qtci_grid(const t4a_gpu_qtci* h, int32_t which, const size_t* in, size_t* out_u, double* out_d);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);

@@ -7,6 +7,7 @@
 #include "patching.hpp"
 #include "tci2.hpp"
 #include "tree.hpp"
+#include "quantics.hpp"
 
 struct t4a_gpu_tci2 {
     t4a::Tci2 impl;
@@ -16,6 +17,10 @@ struct t4a_gpu_tci2 {
 struct t4a_gpu_treetci {
     t4a::TreeTci impl;
     t4a_gpu_treetci(const std::vector<size_t>& d, const t4a::TreeGraph& g) : impl(d, g) {}
+};
+
+struct t4a_gpu_qtci {
+    std::unique_ptr<t4a::QuanticsTci> impl;
 };
 
 struct t4a_gpu_ptt {
@@ -1706,6 +1711,286 @@ t4a_gpu_status t4a_gpu_treetci_evaluate(t4a_gpu_treetci* h, const size_t* idx, s
         std::vector<uint32_t> u = narrow_indices(idx, checked_mul(n_pts, h->impl.local_dims.size(), "index buffer"));
         std::vector<double> v = h->impl.evaluate(u.data(), n_pts);
         std::memcpy(out, v.data(), n_pts * sizeof(double));
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ quantics front end
+t4a_gpu_status t4a_gpu_qtci_options_default(t4a_gpu_qtci_options* o)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(o);
+        std::memset(o, 0, sizeof(*o));
+        o->tolerance = 1e-8;
+        o->max_bond_dim = 0;
+        o->max_iter = 200;
+        o->n_random_init_pivot = 5;
+        o->unfolding_scheme = 0;
+        o->normalize_error = 1;
+        o->has_seed = 0;
+        o->seed = 0;
+    });
+}
+
+extern "C++" {
+static QtciOptions convert_qtci_options(const t4a_gpu_qtci_options* o)
+{
+    QtciOptions r;
+    if (!o) return r;
+    r.tolerance = o->tolerance;
+    r.max_bond_dim = o->max_bond_dim;
+    r.max_iter = o->max_iter;
+    r.n_random_init_pivot = o->n_random_init_pivot;
+    if (o->unfolding_scheme != 0 && o->unfolding_scheme != 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown unfolding scheme");
+    r.unfolding = o->unfolding_scheme ? Unfolding::Fused : Unfolding::Interleaved;
+    r.normalize_error = o->normalize_error != 0;
+    r.has_seed = o->has_seed != 0;
+    r.seed = o->seed;
+    r.to_treetci_options().validate();
+    return r;
+}
+static std::vector<std::vector<size_t>> qtci_pivots(const size_t* pivots, size_t n_pivots, size_t n_vars)
+{
+    std::vector<std::vector<size_t>> p;
+    for (size_t k = 0; k < n_pivots; ++k) p.emplace_back(pivots + k * n_vars, pivots + (k + 1) * n_vars);
+    return p;
+}
+static void qtci_run(t4a_gpu_qtci** out, std::unique_ptr<QuanticsTci> q, int32_t has_pivots, const size_t* pivots,
+                     size_t n_pivots, const QtciOptions& o)
+{
+    const auto pv = qtci_pivots(pivots, has_pivots ? n_pivots : 0, q->grid.n_vars());
+    q->run(has_pivots ? &pv : nullptr, o);
+    auto* h = new t4a_gpu_qtci();
+    h->impl = std::move(q);
+    *out = h;
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_quanticscrossinterpolate(const size_t* rs, size_t n_vars, const double* lower, const double* upper,
+                                                int32_t include_endpoint, int32_t grid_unfolding, t4a_gpu_coord_eval_fn f,
+                                                void* ctx, int32_t has_pivots, const size_t* initial_pivots, size_t n_pivots,
+                                                const t4a_gpu_qtci_options* options, t4a_gpu_qtci** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        T4A_REQUIRE_PTR(rs);
+        T4A_REQUIRE_PTR(f);
+        if (has_pivots && n_pivots) T4A_REQUIRE_PTR(initial_pivots);
+        const QtciOptions o = convert_qtci_options(options);
+        QuanticsGrid grid(std::vector<size_t>(rs, rs + n_vars), grid_unfolding ? Unfolding::Fused : Unfolding::Interleaved, true,
+                          lower ? std::vector<double>(lower, lower + n_vars) : std::vector<double>(),
+                          upper ? std::vector<double>(upper, upper + n_vars) : std::vector<double>(), include_endpoint != 0);
+        qtci_run(out, std::unique_ptr<QuanticsTci>(new QuanticsTci(grid, f, nullptr, ctx, {})), has_pivots, initial_pivots,
+                 n_pivots, o);
+    });
+}
+
+t4a_gpu_status t4a_gpu_quanticscrossinterpolate_discrete(const size_t* sizes, size_t n_vars, t4a_gpu_grididx_eval_fn f,
+                                                         void* ctx, int32_t has_pivots, const size_t* initial_pivots,
+                                                         size_t n_pivots, const t4a_gpu_qtci_options* options,
+                                                         t4a_gpu_qtci** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        T4A_REQUIRE_PTR(f);
+        if (n_vars == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "this method requires at least one grid dimension, got an empty size");
+        T4A_REQUIRE_PTR(sizes);
+        if (has_pivots && n_pivots) T4A_REQUIRE_PTR(initial_pivots);
+        const QtciOptions o = convert_qtci_options(options);
+        const std::vector<size_t> sz(sizes, sizes + n_vars);
+        for (size_t s : sz)
+            if (s == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "this method only supports grid sizes that are powers of 2");
+        qtci_check_sizes(sz);
+        const size_t r = (size_t)std::log2((double)sz[0]);
+        QuanticsGrid grid(std::vector<size_t>(n_vars, r), o.unfolding, false);
+        qtci_run(out, std::unique_ptr<QuanticsTci>(new QuanticsTci(grid, nullptr, f, ctx, {})), has_pivots, initial_pivots,
+                 n_pivots, o);
+    });
+}
+
+t4a_gpu_status t4a_gpu_quanticscrossinterpolate_from_arrays(const double* xvals, const size_t* sizes, size_t n_vars,
+                                                            t4a_gpu_coord_eval_fn f, void* ctx, int32_t has_pivots,
+                                                            const size_t* initial_pivots, size_t n_pivots,
+                                                            const t4a_gpu_qtci_options* options, t4a_gpu_qtci** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        T4A_REQUIRE_PTR(f);
+        if (n_vars == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "xvals must not be empty");
+        T4A_REQUIRE_PTR(sizes);
+        if (has_pivots && n_pivots) T4A_REQUIRE_PTR(initial_pivots);
+        const QtciOptions o = convert_qtci_options(options);
+        std::vector<std::vector<double>> xv;
+        size_t off = 0;
+        for (size_t d = 0; d < n_vars; ++d) {
+            if (sizes[d]) T4A_REQUIRE_PTR(xvals);
+            xv.emplace_back(xvals + off, xvals + off + sizes[d]);
+            off += sizes[d];
+        }
+        const bool uniform = qtci_check_xvals_uniform(xv);
+        std::vector<size_t> rs;
+        for (const auto& x : xv) rs.push_back((size_t)std::log2((double)x.size()));
+        if (uniform) {
+            std::vector<double> lo, up;
+            for (const auto& x : xv) {
+                lo.push_back(x.front());
+                up.push_back(x.back());
+            }
+            QuanticsGrid grid(rs, o.unfolding, true, lo, up, true);
+            qtci_run(out, std::unique_ptr<QuanticsTci>(new QuanticsTci(grid, f, nullptr, ctx, {})), has_pivots, initial_pivots,
+                     n_pivots, o);
+        } else {
+            QuanticsGrid grid(rs, o.unfolding, false);
+            qtci_run(out, std::unique_ptr<QuanticsTci>(new QuanticsTci(grid, f, nullptr, ctx, xv)), has_pivots, initial_pivots,
+                     n_pivots, o);
+        }
+    });
+}
+
+void t4a_gpu_qtci_release(t4a_gpu_qtci* h) { delete h; }
+
+t4a_gpu_status t4a_gpu_qtci_evaluate(t4a_gpu_qtci* h, const size_t* grididx, size_t n_pts, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pts == 0) return;
+        T4A_REQUIRE_PTR(grididx);
+        T4A_REQUIRE_PTR(out);
+        const std::vector<double> v = h->impl->evaluate(grididx, n_pts);
+        std::memcpy(out, v.data(), n_pts * sizeof(double));
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_sum(t4a_gpu_qtci* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl->sum();
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_integral(t4a_gpu_qtci* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl->integral();
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_n_sites(const t4a_gpu_qtci* h, size_t* n_sites, size_t* n_vars, int32_t* is_discretized)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_sites) *n_sites = h->impl->grid.n_sites();
+        if (n_vars) *n_vars = h->impl->grid.n_vars();
+        if (is_discretized) *is_discretized = h->impl->grid.discretized ? 1 : 0;
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_link_dims(const t4a_gpu_qtci* h, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        const auto ld = h->impl->tt->link_dims();
+        if (!ld.empty()) T4A_REQUIRE_PTR(out);
+        std::copy(ld.begin(), ld.end(), out);
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_history(const t4a_gpu_qtci* h, size_t* n_iter, size_t* ranks, double* errors)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        const auto& t = *h->impl->tci;
+        if (n_iter) *n_iter = t.ranks_hist.size();
+        for (size_t k = 0; k < t.ranks_hist.size(); ++k) {
+            if (ranks) ranks[k] = t.ranks_hist[k];
+            if (errors) errors[k] = t.errors_hist[k];
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_tensor_train(t4a_gpu_qtci* h, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        *out = new t4a_gpu_tt(h->impl->tt->cores, h->impl->tt->eng.stream());
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_tree_pivots(const t4a_gpu_qtci* h, const size_t* key, size_t key_len, size_t* count, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        if (key_len) T4A_REQUIRE_PTR(key);
+        SubtreeKey k(key, key + key_len);
+        std::sort(k.begin(), k.end());
+        write_index_set(h->impl->tci->pivots_of(k), count, out);
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_cachedata(const t4a_gpu_qtci* h, size_t* count, size_t* quantics, double* values,
+                                      size_t* user_calls, size_t* user_points)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        *count = h->impl->cache.size();
+        if (user_calls) *user_calls = h->impl->n_user_calls;
+        if (user_points) *user_points = h->impl->n_user_points;
+        if (!quantics && !values) return;
+        size_t k = 0;
+        const size_t ns = h->impl->grid.n_sites();
+        for (const auto& kv : h->impl->cache) {
+            if (quantics)
+                for (size_t s = 0; s < ns; ++s) quantics[k * ns + s] = kv.first[s];
+            if (values) values[k] = kv.second;
+            ++k;
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_qtci_grid(const t4a_gpu_qtci* h, int32_t which, const size_t* in, size_t* out_u, double* out_d)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        const QuanticsGrid& g = h->impl->grid;
+        const size_t ns = g.n_sites(), nv = g.n_vars();
+        if (which == 0) {
+            T4A_REQUIRE_PTR(in);
+            T4A_REQUIRE_PTR(out_u);
+            std::vector<uint32_t> q(ns);
+            g.grididx_to_quantics(in, q.data());
+            std::copy(q.begin(), q.end(), out_u);
+        } else if (which == 1 || which == 2) {
+            T4A_REQUIRE_PTR(in);
+            std::vector<uint32_t> q = narrow_indices(in, ns);
+            if (which == 1) {
+                T4A_REQUIRE_PTR(out_u);
+                g.quantics_to_grididx(q.data(), out_u);
+            } else {
+                T4A_REQUIRE_PTR(out_d);
+                g.quantics_to_origcoord(q.data(), out_d);
+            }
+        } else if (which == 3) {
+            T4A_REQUIRE_PTR(out_u);
+            const auto d = g.local_dimensions();
+            std::copy(d.begin(), d.end(), out_u);
+        } else if (which == 4) {
+            T4A_REQUIRE_PTR(out_d);
+            const auto st = g.grid_step();
+            std::copy(st.begin(), st.end(), out_d);
+        } else {
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown grid query");
+        }
+        (void)nv;
     });
 }
 

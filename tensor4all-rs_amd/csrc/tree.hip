@@ -803,6 +803,43 @@ std::vector<double> TreeTci::site_tensor_host(size_t site, std::vector<size_t>& 
     return out;
 }
 
+// out[l + L*(s + S*r)] = in[s + S*(r + R*l)]
+__global__ void chain_core_kernel(const double* __restrict__ in, int S, int R, int L, double* __restrict__ out)
+{
+    const size_t total = (size_t)S * R * L;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t l = e % (size_t)L;
+        const size_t s = (e / (size_t)L) % (size_t)S;
+        const size_t r = e / ((size_t)L * (size_t)S);
+        out[e] = in[s + (size_t)S * (r + (size_t)R * l)];
+    }
+}
+
+std::vector<DevCore> TreeTci::chain_cores()
+{
+    if (!has_net_ || net_root_ != 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "chain_cores: materialise the network around site 0 first");
+    const size_t n = local_dims.size();
+    const auto edges = graph.edges();
+    for (size_t k = 0; k + 1 < n; ++k)
+        if (!(edges[k] == TreeEdge(k, k + 1))) throw Error(T4A_GPU_INVALID_ARGUMENT, "chain_cores: the graph is not the linear chain 0-1-...-n");
+    std::vector<DevCore> cores(n);
+    hipStream_t st = eng.stream();
+    for (size_t k = 0; k < n; ++k) {
+        const SiteTensor& t = net_[k];
+        DevCore& c = cores[k];
+        c.s = t.dims[0];
+        c.r = (k + 1 < n) ? t.dims[1] : 1;
+        c.l = (k > 0) ? t.dims.back() : 1;
+        c.buf.reserve(c.size());
+        const size_t total = c.size();
+        const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 1024);
+        hipLaunchKernelGGL(chain_core_kernel, dim3(blocks), dim3(256), 0, st, t.data.get(), (int)c.s, (int)c.r, (int)c.l, c.buf.get());
+    }
+    T4A_HIP(hipGetLastError());
+    T4A_HIP(hipStreamSynchronize(st));
+    return cores;
+}
+
 // ------------------------------------------------------------------------------------------------ tree contraction
 // One workgroup per point.  Sites are visited leaves first; the message of a site towards its parent,
 //   m[o] = sum over the incoming bond indices (in_0 fastest) of T[x_site, in_0, .., in_{k-1}, o] * prod_a m_a[in_a],

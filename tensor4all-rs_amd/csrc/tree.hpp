@@ -93,6 +93,9 @@ public:
     void materialize(size_t center_site); // to_treetn: the site tensors stay on the device
     std::vector<double> evaluate(const uint32_t* idx, size_t n_pts); // idx n_sites x n_pts col-major
     std::vector<double> site_tensor_host(size_t site, std::vector<size_t>& dims);
+    // treetn_to_tensor_train bridge for a linear chain materialised around site 0 (quanticstci/src/quantics_tci.rs:284-292):
+    // site tensors [d, bond to k+1, bond to k-1] -> cores (l, s, r), device to device
+    std::vector<DevCore> chain_cores();
 
     void flush_pivot_errors() { pivot_errors.clear(); }
     double max_bond_error() const;

@@ -1073,3 +1073,213 @@ def tree_crossinterpolate2(f, local_dims, edges, initial_pivots, options, center
     ranks, errors = t.crossinterpolate2(initial_pivots, options)
     t.materialize(0 if center_site is None else center_site)
     return t, ranks, errors
+
+
+# ---------------------------------------------------------------------------------------- quantics front end (tensor4all-quanticstci)
+INTERLEAVED, FUSED = 0, 1
+_COORD_CB = ctypes.CFUNCTYPE(ctypes.c_int64, c_void_p, ctypes.POINTER(c_double), c_size_t, c_size_t, ctypes.POINTER(c_double))
+_GRIDIDX_CB = ctypes.CFUNCTYPE(ctypes.c_int64, c_void_p, ctypes.POINTER(c_size_t), c_size_t, c_size_t, ctypes.POINTER(c_double))
+
+
+class QtciOptionsC(ctypes.Structure):
+    _fields_ = [("tolerance", c_double), ("max_bond_dim", c_size_t), ("max_iter", c_size_t), ("n_random_init_pivot", c_size_t),
+                ("unfolding_scheme", c_int32), ("normalize_error", c_int32), ("has_seed", c_int32), ("seed", ctypes.c_uint64)]
+
+
+class QtciOptions:
+    """QtciOptions (quanticstci/src/options.rs:9-45); `seed` fixes the random initial pivots."""
+
+    def __init__(self, tolerance=1e-8, max_bond_dim=None, max_iter=200, n_random_init_pivot=5, unfolding_scheme=INTERLEAVED,
+                 normalize_error=True, seed=None):
+        self.tolerance = tolerance
+        self.max_bond_dim = max_bond_dim
+        self.max_iter = max_iter
+        self.n_random_init_pivot = n_random_init_pivot
+        self.unfolding_scheme = unfolding_scheme
+        self.normalize_error = normalize_error
+        self.seed = seed
+
+    def to_c(self):
+        o = QtciOptionsC()
+        _check(_lib.t4a_gpu_qtci_options_default(ctypes.byref(o)))
+        o.tolerance = self.tolerance
+        o.max_bond_dim = 0 if self.max_bond_dim is None else self.max_bond_dim
+        o.max_iter = self.max_iter
+        o.n_random_init_pivot = self.n_random_init_pivot
+        o.unfolding_scheme = self.unfolding_scheme
+        o.normalize_error = int(self.normalize_error)
+        o.has_seed = 0 if self.seed is None else 1
+        o.seed = 0 if self.seed is None else self.seed
+        return o
+
+
+def _batch_wrapper(f, cb_type, dtype, as_int):
+    """f(point) -> float, optionally with f.batched((n_pts, n_vars) array) -> values."""
+    batched = getattr(f, "batched", None)
+
+    def _cb(ctx, ptr, n_vars, n_pts, out_ptr):
+        try:
+            pts = np.ctypeslib.as_array(ptr, shape=(n_pts, n_vars))
+            if batched is not None:
+                vals = np.asarray(batched(pts), dtype=np.float64).ravel()
+            elif as_int:
+                vals = np.array([f([int(v) for v in row]) for row in pts], dtype=np.float64)
+            else:
+                vals = np.array([f([float(v) for v in row]) for row in pts], dtype=np.float64)
+            k = min(len(vals), n_pts)
+            np.ctypeslib.as_array(out_ptr, shape=(n_pts,))[:k] = vals[:k]
+            return len(vals)
+        except Exception:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    return cb_type(_cb)
+
+
+def _qtci_pivots(pivots, n_vars):
+    if pivots is None:
+        return [c_int32(0), None, c_size_t(0)], None
+    piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uintp).reshape(len(pivots), n_vars))
+    return [c_int32(1), _p(piv), c_size_t(len(pivots))], piv
+
+
+class QuanticsTensorCI2:
+    """QuanticsTensorCI2<f64> (quanticstci/src/quantics_tci.rs:53-173): tensor train + grid + evaluation cache."""
+
+    def __init__(self, handle, keep):
+        self._h = handle
+        self._keep = keep
+        ns, nv, disc = c_size_t(0), c_size_t(0), c_int32(0)
+        _check(_lib.t4a_gpu_qtci_n_sites(self._h, ctypes.byref(ns), ctypes.byref(nv), ctypes.byref(disc)))
+        self.n_sites, self.n_vars, self._disc = ns.value, nv.value, bool(disc.value)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.t4a_gpu_qtci_release(h)
+            self._h = None
+
+    def is_discretized(self):
+        return self._disc
+
+    def evaluate(self, grididx):
+        g = np.ascontiguousarray(np.asarray(grididx, dtype=np.uintp).reshape(-1, self.n_vars))
+        out = np.zeros(g.shape[0])
+        _check(_lib.t4a_gpu_qtci_evaluate(self._h, _p(g), c_size_t(g.shape[0]), _p(out)))
+        return out
+
+    def sum(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_qtci_sum(self._h, ctypes.byref(v)))
+        return v.value
+
+    def integral(self):
+        v = c_double(0)
+        _check(_lib.t4a_gpu_qtci_integral(self._h, ctypes.byref(v)))
+        return v.value
+
+    def link_dims(self):
+        out = np.zeros(max(self.n_sites - 1, 1), dtype=np.uintp)
+        _check(_lib.t4a_gpu_qtci_link_dims(self._h, _p(out)))
+        return [int(x) for x in out[:self.n_sites - 1]]
+
+    def rank(self):
+        ld = self.link_dims()
+        return max(ld) if ld else 1
+
+    def history(self):
+        n = c_size_t(0)
+        _check(_lib.t4a_gpu_qtci_history(self._h, ctypes.byref(n), None, None))
+        ranks, errors = np.zeros(max(n.value, 1), dtype=np.uintp), np.zeros(max(n.value, 1))
+        _check(_lib.t4a_gpu_qtci_history(self._h, ctypes.byref(n), _p(ranks), _p(errors)))
+        return [int(x) for x in ranks[:n.value]], [float(x) for x in errors[:n.value]]
+
+    def tensor_train(self):
+        h = c_void_p()
+        _check(_lib.t4a_gpu_qtci_tensor_train(self._h, ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
+    def tree_pivots(self, key):
+        k = np.ascontiguousarray(np.asarray(sorted(key), dtype=np.uintp))
+        c = c_size_t(0)
+        _check(_lib.t4a_gpu_qtci_tree_pivots(self._h, _p(k), c_size_t(len(k)), ctypes.byref(c), None))
+        out = np.zeros((c.value, len(k)), dtype=np.uintp)
+        _check(_lib.t4a_gpu_qtci_tree_pivots(self._h, _p(k), c_size_t(len(k)), ctypes.byref(c), _p(out)))
+        return out.astype(np.int64)
+
+    def cachedata(self):
+        c = c_size_t(0)
+        _check(_lib.t4a_gpu_qtci_cachedata(self._h, ctypes.byref(c), None, None, None, None))
+        q, v = np.zeros((c.value, self.n_sites), dtype=np.uintp), np.zeros(c.value)
+        _check(_lib.t4a_gpu_qtci_cachedata(self._h, ctypes.byref(c), _p(q), _p(v), None, None))
+        return {tuple(int(x) for x in row): float(val) for row, val in zip(q, v)}
+
+    def user_call_stats(self):
+        c, calls, pts = c_size_t(0), c_size_t(0), c_size_t(0)
+        _check(_lib.t4a_gpu_qtci_cachedata(self._h, ctypes.byref(c), None, None, ctypes.byref(calls), ctypes.byref(pts)))
+        return calls.value, pts.value
+
+    def _grid(self, which, arr, n_out, floats=False):
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.uintp))
+        ou, od = np.zeros(max(n_out, 1), dtype=np.uintp), np.zeros(max(n_out, 1))
+        _check(_lib.t4a_gpu_qtci_grid(self._h, c_int32(which), _p(a), _p(ou), _p(od)))
+        return [float(x) for x in od[:n_out]] if floats else [int(x) for x in ou[:n_out]]
+
+    def grididx_to_quantics(self, g):
+        return self._grid(0, g, self.n_sites)
+
+    def quantics_to_grididx(self, q):
+        return self._grid(1, q, self.n_vars)
+
+    def quantics_to_origcoord(self, q):
+        return self._grid(2, q, self.n_vars, floats=True)
+
+    def local_dimensions(self):
+        return self._grid(3, [0], self.n_sites)
+
+    def grid_step(self):
+        return self._grid(4, [0], self.n_vars, floats=True)
+
+
+def quanticscrossinterpolate(rs, f, lower=None, upper=None, include_endpoint=False, grid_unfolding=INTERLEAVED,
+                             initial_pivots=None, options=None):
+    """quanticscrossinterpolate(&DiscretizedGrid::builder(rs)..., f(coords), initial_pivots, options)."""
+    options = options or QtciOptions()
+    rs_a = np.asarray(rs, dtype=np.uintp)
+    nv = len(rs_a)
+    lo = None if lower is None else np.asarray(lower, dtype=np.float64)
+    up = None if upper is None else np.asarray(upper, dtype=np.float64)
+    cb = _batch_wrapper(f, _COORD_CB, np.float64, False)
+    pa, keep = _qtci_pivots(initial_pivots, nv)
+    o = options.to_c()
+    h = c_void_p()
+    _check(_lib.t4a_gpu_quanticscrossinterpolate(_p(rs_a), c_size_t(nv), None if lo is None else _p(lo),
+                                                 None if up is None else _p(up), c_int32(int(include_endpoint)),
+                                                 c_int32(grid_unfolding), cb, None, *pa, ctypes.byref(o), ctypes.byref(h)))
+    return QuanticsTensorCI2(h, (cb, keep))
+
+
+def quanticscrossinterpolate_discrete(sizes, f, initial_pivots=None, options=None):
+    options = options or QtciOptions()
+    sz = np.asarray(sizes, dtype=np.uintp)
+    cb = _batch_wrapper(f, _GRIDIDX_CB, np.uintp, True)
+    pa, keep = _qtci_pivots(initial_pivots, len(sz))
+    o = options.to_c()
+    h = c_void_p()
+    _check(_lib.t4a_gpu_quanticscrossinterpolate_discrete(_p(sz), c_size_t(len(sz)), cb, None, *pa, ctypes.byref(o),
+                                                          ctypes.byref(h)))
+    return QuanticsTensorCI2(h, (cb, keep))
+
+
+def quanticscrossinterpolate_from_arrays(xvals, f, initial_pivots=None, options=None):
+    options = options or QtciOptions()
+    sz = np.asarray([len(x) for x in xvals], dtype=np.uintp)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in xvals]) if len(xvals) else np.zeros(1))
+    cb = _batch_wrapper(f, _COORD_CB, np.float64, False)
+    pa, keep = _qtci_pivots(initial_pivots, len(sz))
+    o = options.to_c()
+    h = c_void_p()
+    _check(_lib.t4a_gpu_quanticscrossinterpolate_from_arrays(_p(flat), _p(sz), c_size_t(len(sz)), cb, None, *pa,
+                                                             ctypes.byref(o), ctypes.byref(h)))
+    return QuanticsTensorCI2(h, (cb, keep))

@@ -53,7 +53,8 @@ def test_no_silent_cpu_fallback():
                  lambda: t4a_amd.full_piv_lu_matrix(np.eye(3)),
                  lambda: t4a_amd.matrix_luci_factors_rook(np.eye(3)),
                  lambda: t4a_amd.adaptiveinterpolate(lambda i: 1.0, [2, 2], [[0, 0]], t4a_amd.TCI2Options()),
-                 lambda: t4a_amd.TreeTCI2([2, 2, 2], [(0, 1), (1, 2)])):
+                 lambda: t4a_amd.TreeTCI2([2, 2, 2], [(0, 1), (1, 2)]),
+                 lambda: t4a_amd.quanticscrossinterpolate_discrete([4, 4], lambda i: 1.0)):
         with pytest.raises(t4a_amd.T4aError) as e:
             call()
         assert e.value.code == t4a_amd.NO_DEVICE, e.value
@@ -72,6 +73,9 @@ def test_argument_validation_happens_before_the_device_is_touched():
     assert e.value.code == t4a_amd.INVALID_ARGUMENT
     with pytest.raises(t4a_amd.T4aError):
         t4a_amd.mat_mul(np.zeros((2, 3)), np.zeros((2, 3)))
+    with pytest.raises(t4a_amd.T4aError) as e:  # quanticstci/src/quantics_tci.rs:449-472
+        t4a_amd.quanticscrossinterpolate_discrete([5, 5], lambda i: 1.0)
+    assert e.value.code == t4a_amd.INVALID_ARGUMENT
     # tree graphs are validated on the host (treetci/src/graph.rs:51-106)
     for dims, edges in (([2, 2, 2], [(0, 1)]), ([2, 2, 2], [(0, 1), (1, 1)]), ([2, 2, 2, 2], [(0, 1), (1, 2), (0, 2)])):
         with pytest.raises(t4a_amd.T4aError) as e:
