@@ -474,6 +474,21 @@ t4a_gpu_status t4a_gpu_qtci_cachedata(const t4a_gpu_qtci* h, size_t* count, size
  * 3 local_dimensions, 4 grid_step (out_d) */
 t4a_gpu_status t4a_gpu_qtci_grid(const t4a_gpu_qtci* h, int32_t which, const size_t* in, size_t* out_u, double* out_d);
 
+/* quanticscrossinterpolate_batched (quanticstci/src/batched/mod.rs:50-191): vector / tensor valued f.  The callback
+ * writes out[c + n_components * p] for every point p and returns n_components * n_pts; every coordinate reaches it once
+ * for all components.  The result is a tensor train with one extra (component selector) site of dimension
+ * prod(output_dims) (combine_component_tts, :193-318); ranks / errors (max_iter entries) are the element-wise maxima over
+ * the per-component runs. */
+typedef int64_t (*t4a_gpu_coord_eval_vec_fn)(void* ctx, const double* coords, size_t n_vars, size_t n_pts,
+                                             size_t n_components, double* out);
+t4a_gpu_status t4a_gpu_quanticscrossinterpolate_batched(const size_t* rs, size_t n_vars, const double* lower,
+                                                        const double* upper, int32_t include_endpoint, int32_t grid_unfolding,
+                                                        t4a_gpu_coord_eval_vec_fn f, void* ctx, const size_t* output_dims,
+                                                        size_t n_output_dims, int32_t has_pivots, const size_t* initial_pivots,
+                                                        size_t n_pivots, const t4a_gpu_qtci_options* options,
+                                                        t4a_gpu_tt** out_tt, size_t* n_iter, size_t* ranks, double* errors,
+                                                        size_t* user_points);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);

@@ -1014,4 +1014,56 @@ int oracle_qtci_tree_pivots(void* h, const uint64_t* key, uint64_t key_len, uint
     });
 }
 
+// ---- batched quantics (vector valued) ----
+typedef int (*coord_vec_cb_t)(void* ctx, const double* x, uint64_t n, double* out, uint64_t max_out); // returns the count
+
+void* oracle_qtci_batched(const uint64_t* rs, uint64_t n_vars, const double* lower, const double* upper, int include_endpoint,
+                          int grid_unfolding, coord_vec_cb_t cb, void* ctx, const uint64_t* output_dims, uint64_t n_output_dims,
+                          int has_pivots, const uint64_t* pivots, uint64_t n_pivots, double tolerance, uint64_t max_bond_dim,
+                          uint64_t max_iter, uint64_t n_random, int unfolding, int normalize_error, int has_seed, uint64_t seed)
+{
+    void* out = nullptr;
+    guarded([&] {
+        QuanticsGrid grid(std::vector<size_t>(rs, rs + n_vars), grid_unfolding ? Unfolding::Fused : Unfolding::Interleaved, true,
+                          std::vector<double>(lower, lower + n_vars), std::vector<double>(upper, upper + n_vars),
+                          include_endpoint != 0);
+        auto pv = grid_pivots(pivots, has_pivots ? n_pivots : 0, n_vars);
+        std::vector<size_t> od(output_dims, output_dims + n_output_dims);
+        size_t cap = 1;
+        for (size_t d : od) cap *= std::max<size_t>(d, 1);
+        CoordVecFn f = [cb, ctx, cap](const std::vector<double>& x) {
+            std::vector<double> v(cap + 8);
+            const int k = cb(ctx, x.data(), x.size(), v.data(), v.size());
+            v.resize(k < 0 ? 0 : (size_t)k);
+            return v;
+        };
+        out = new QuanticsBatchedResult(quanticscrossinterpolate_batched(
+            grid, f, od, has_pivots ? &pv : nullptr,
+            make_qtci_options(tolerance, max_bond_dim, max_iter, n_random, unfolding, normalize_error, has_seed, seed)));
+    });
+    return out;
+}
+void oracle_qtci_batched_release(void* h) { delete static_cast<QuanticsBatchedResult*>(h); }
+uint64_t oracle_qtci_batched_len(void* h) { return static_cast<QuanticsBatchedResult*>(h)->tt.len(); }
+uint64_t oracle_qtci_batched_user_calls(void* h) { return static_cast<QuanticsBatchedResult*>(h)->n_user_calls; }
+uint64_t oracle_qtci_batched_n_iterations(void* h) { return static_cast<QuanticsBatchedResult*>(h)->ranks.size(); }
+int oracle_qtci_batched_history(void* h, uint64_t* ranks, double* errors)
+{
+    return guarded([&] {
+        auto* r = static_cast<QuanticsBatchedResult*>(h);
+        for (size_t k = 0; k < r->ranks.size(); ++k) ranks[k] = r->ranks[k];
+        for (size_t k = 0; k < r->errors.size(); ++k) errors[k] = r->errors[k];
+    });
+}
+int oracle_qtci_batched_site_tensor(void* h, uint64_t site, uint64_t* dims3, double* out)
+{
+    return guarded([&] {
+        const auto& t = static_cast<QuanticsBatchedResult*>(h)->tt.tensors.at(site);
+        dims3[0] = t.l;
+        dims3[1] = t.s;
+        dims3[2] = t.r;
+        if (out && !t.d.empty()) std::memcpy(out, t.d.data(), t.d.size() * sizeof(double));
+    });
+}
+
 } // extern "C"

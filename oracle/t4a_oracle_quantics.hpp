@@ -9,6 +9,8 @@
 //                    SimpleTensorTrain :284-292), quanticscrossinterpolate_from_arrays :309-432 (validation, uniform grids ->
 //                    DiscretizedGrid with include_endpoint, otherwise coordinate lookup on an inherent grid),
 //                    quanticscrossinterpolate_discrete :434-560.
+//   batched/mod.rs   quanticscrossinterpolate_batched :50-191 (one scalar run per output component over a shared
+//                    coordinate-keyed cache), combine_component_tts :193-318 (block-diagonal direct sum + selector site).
 // The grid itself lives in the un-vendored crate `quanticsgrids` @ git rev 8214b72 (Cargo.toml:83).  Its published
 // algorithm (QuanticsGrids.jl) is restated here: R_d bits per variable, most significant bit first; unfolding
 // `Interleaved` = one binary site per (bit level, variable), levels outermost; `Fused` = one site per bit level whose
@@ -19,6 +21,7 @@
 // from rand::rng() in the reference (non-reproducible by construction); splitmix64 here.
 #pragma once
 
+#include <cstring>
 #include <memory>
 
 #include "t4a_oracle_tree.hpp"
@@ -318,6 +321,111 @@ inline QuanticsTensorCI2 quanticscrossinterpolate_from_arrays(const std::vector<
         for (size_t d = 0; d < idx.size(); ++d) x[d] = coords[d][idx[d]];
         return f(x);
     }, initial_pivots, options);
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched/mod.rs — vector / tensor valued functions
+// ---------------------------------------------------------------------------------------------
+using CoordVecFn = std::function<std::vector<double>(const std::vector<double>&)>;
+
+// :193-318
+inline SimpleTensorTrain combine_component_tts(const std::vector<SimpleTensorTrain>& comps)
+{
+    if (comps.empty()) throw OracleError(ERR_INVALID_ARGUMENT, "no component tensor trains to combine");
+    const size_t n = comps[0].len();
+    if (n == 0) throw OracleError(ERR_INVALID_ARGUMENT, "component tensor trains must have at least one site");
+    for (const auto& tt : comps) {
+        if (tt.len() != n) throw OracleError(ERR_INVALID_ARGUMENT, "components have different site counts");
+        for (size_t s = 0; s < n; ++s)
+            if (tt.tensors[s].s != comps[0].tensors[s].s) throw OracleError(ERR_INVALID_ARGUMENT, "components have different site dimensions");
+    }
+    std::vector<Tensor3> out;
+    for (size_t s = 0; s < n; ++s) {
+        size_t total_r = 0, total_l = 0;
+        for (const auto& tt : comps) {
+            total_r += tt.tensors[s].r;
+            total_l += tt.tensors[s].l;
+        }
+        const size_t sd = comps[0].tensors[s].s;
+        Tensor3 c(s == 0 ? 1 : total_l, sd, total_r);
+        size_t lo = 0, ro = 0;
+        for (const auto& tt : comps) {
+            const Tensor3& t = tt.tensors[s];
+            for (size_t l = 0; l < t.l; ++l)
+                for (size_t x = 0; x < sd; ++x)
+                    for (size_t r = 0; r < t.r; ++r) c.at((s == 0 ? 0 : lo) + l, x, ro + r) = t.at(l, x, r);
+            lo += t.l;
+            ro += t.r;
+        }
+        out.push_back(c);
+    }
+    size_t total_r = 0;
+    for (const auto& tt : comps) total_r += tt.tensors[n - 1].r;
+    Tensor3 sel(total_r, comps.size(), 1);
+    size_t off = 0;
+    for (size_t c = 0; c < comps.size(); ++c) {
+        for (size_t i = 0; i < comps[c].tensors[n - 1].r; ++i) sel.at(off + i, c, 0) = 1.0;
+        off += comps[c].tensors[n - 1].r;
+    }
+    out.push_back(sel);
+    return SimpleTensorTrain::make(out);
+}
+
+struct QuanticsBatchedResult {
+    SimpleTensorTrain tt;
+    std::vector<size_t> output_dims;
+    std::vector<size_t> ranks;
+    std::vector<double> errors;
+    size_t n_user_calls = 0;
+};
+
+// :50-191
+inline QuanticsBatchedResult quanticscrossinterpolate_batched(const QuanticsGrid& grid, const CoordVecFn& f,
+                                                              const std::vector<size_t>& output_dims,
+                                                              const std::vector<std::vector<size_t>>* initial_pivots,
+                                                              const QtciOptions& options)
+{
+    if (output_dims.empty()) throw OracleError(ERR_INVALID_ARGUMENT, "output_dims must not be empty");
+    size_t n_comp = 1;
+    for (size_t d : output_dims) n_comp *= d;
+    if (n_comp == 0) throw OracleError(ERR_INVALID_ARGUMENT, "product of output_dims must be positive");
+    QuanticsBatchedResult res;
+    res.output_dims = output_dims;
+    std::map<std::vector<uint64_t>, std::vector<double>> cache;
+    std::vector<SimpleTensorTrain> comps;
+    for (size_t comp = 0; comp < n_comp; ++comp) {
+        std::string short_result;
+        CoordFn scalar = [&, comp](const std::vector<double>& x) {
+            std::vector<uint64_t> key(x.size());
+            for (size_t d = 0; d < x.size(); ++d) std::memcpy(&key[d], &x[d], sizeof(double));
+            auto it = cache.find(key);
+            if (it == cache.end()) {
+                ++res.n_user_calls;
+                it = cache.emplace(key, f(x)).first;
+            }
+            if (comp >= it->second.size()) {
+                short_result = "callback returned " + std::to_string(it->second.size()) + " components, expected at least " +
+                               std::to_string(comp + 1);
+                return 0.0;
+            }
+            return it->second[comp];
+        };
+        std::unique_ptr<QuanticsTensorCI2> q;
+        try {
+            q.reset(new QuanticsTensorCI2(quanticscrossinterpolate(grid, scalar, initial_pivots, options)));
+        } catch (...) {
+            if (!short_result.empty()) throw OracleError(ERR_INVALID_ARGUMENT, short_result);
+            throw;
+        }
+        if (!short_result.empty()) throw OracleError(ERR_INVALID_ARGUMENT, short_result);
+        comps.push_back(q->tt);
+        if (res.ranks.size() < q->ranks.size()) res.ranks.resize(q->ranks.size(), 0);
+        if (res.errors.size() < q->errors.size()) res.errors.resize(q->errors.size(), 0.0);
+        for (size_t k = 0; k < q->ranks.size(); ++k) res.ranks[k] = std::max(res.ranks[k], q->ranks[k]);
+        for (size_t k = 0; k < q->errors.size(); ++k) res.errors[k] = std::max(res.errors[k], q->errors[k]);
+    }
+    res.tt = combine_component_tts(comps);
+    return res;
 }
 
 } // namespace t4a_oracle

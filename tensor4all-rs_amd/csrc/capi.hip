@@ -1994,4 +1994,36 @@ t4a_gpu_status t4a_gpu_qtci_grid(const t4a_gpu_qtci* h, int32_t which, const siz
     });
 }
 
+t4a_gpu_status t4a_gpu_quanticscrossinterpolate_batched(const size_t* rs, size_t n_vars, const double* lower,
+                                                        const double* upper, int32_t include_endpoint, int32_t grid_unfolding,
+                                                        t4a_gpu_coord_eval_vec_fn f, void* ctx, const size_t* output_dims,
+                                                        size_t n_output_dims, int32_t has_pivots, const size_t* initial_pivots,
+                                                        size_t n_pivots, const t4a_gpu_qtci_options* options,
+                                                        t4a_gpu_tt** out_tt, size_t* n_iter, size_t* ranks, double* errors,
+                                                        size_t* user_points)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out_tt);
+        *out_tt = nullptr;
+        T4A_REQUIRE_PTR(rs);
+        T4A_REQUIRE_PTR(f);
+        if (n_output_dims) T4A_REQUIRE_PTR(output_dims);
+        if (has_pivots && n_pivots) T4A_REQUIRE_PTR(initial_pivots);
+        const QtciOptions o = convert_qtci_options(options);
+        QuanticsGrid grid(std::vector<size_t>(rs, rs + n_vars), grid_unfolding ? Unfolding::Fused : Unfolding::Interleaved, true,
+                          lower ? std::vector<double>(lower, lower + n_vars) : std::vector<double>(),
+                          upper ? std::vector<double>(upper, upper + n_vars) : std::vector<double>(), include_endpoint != 0);
+        const auto pv = qtci_pivots(initial_pivots, has_pivots ? n_pivots : 0, n_vars);
+        QuanticsBatchedResult r = quantics_batched(grid, f, ctx, std::vector<size_t>(output_dims, output_dims + n_output_dims),
+                                                   has_pivots ? &pv : nullptr, o);
+        if (n_iter) *n_iter = r.ranks.size();
+        for (size_t k = 0; k < r.ranks.size(); ++k) {
+            if (ranks) ranks[k] = r.ranks[k];
+            if (errors) errors[k] = r.errors[k];
+        }
+        if (user_points) *user_points = r.n_user_points;
+        *out_tt = new t4a_gpu_tt(r.tt->cores, r.tt->eng.stream());
+    });
+}
+
 } // extern "C"

@@ -2,6 +2,7 @@
 #include "quantics.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 
 namespace t4a {
@@ -289,6 +290,150 @@ double QuanticsTci::integral() // :130-141
     double step = 1.0;
     for (double v : grid.grid_step()) step = step * v;
     return s * step;
+}
+
+// ------------------------------------------------------------------------------------------------ batched/mod.rs
+std::unique_ptr<TensorTrain> combine_component_tts(std::vector<std::unique_ptr<TensorTrain>>& comps) // :193-318
+{
+    if (comps.empty()) throw Error(T4A_GPU_INVALID_ARGUMENT, "no component tensor trains to combine");
+    const size_t n = comps[0]->len();
+    if (n == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "component tensor trains must have at least one site");
+    for (size_t c = 0; c < comps.size(); ++c) {
+        if (comps[c]->len() != n)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "component " + std::to_string(c) + " has " + std::to_string(comps[c]->len()) +
+                                                      " sites, expected " + std::to_string(n));
+        for (size_t s = 0; s < n; ++s)
+            if (comps[c]->cores[s].s != comps[0]->cores[s].s)
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "component " + std::to_string(c) + " site " + std::to_string(s) + " has a different site_dim");
+    }
+    // pure data movement: the blocks are placed on the host and the combined train is uploaded once
+    std::vector<std::array<size_t, 3>> dims3;
+    std::vector<double> data;
+    for (size_t s = 0; s < n; ++s) {
+        size_t total_l = 0, total_r = 0;
+        for (auto& tt : comps) {
+            total_l += tt->cores[s].l;
+            total_r += tt->cores[s].r;
+        }
+        const size_t L = s == 0 ? 1 : total_l, S = comps[0]->cores[s].s, R = total_r;
+        const size_t base = data.size();
+        data.resize(base + L * S * R, 0.0);
+        size_t lo = 0, ro = 0;
+        for (auto& tt : comps) {
+            const DevCore& c = tt->cores[s];
+            const std::vector<double> h = tt->site_tensor_host(s);
+            for (size_t r = 0; r < c.r; ++r)
+                for (size_t x = 0; x < S; ++x)
+                    for (size_t l = 0; l < c.l; ++l)
+                        data[base + ((s == 0 ? 0 : lo) + l) + L * (x + S * (ro + r))] = h[l + c.l * (x + S * r)];
+            lo += c.l;
+            ro += c.r;
+        }
+        dims3.push_back({L, S, R});
+    }
+    size_t total_r = 0;
+    for (auto& tt : comps) total_r += tt->cores[n - 1].r;
+    const size_t base = data.size();
+    data.resize(base + total_r * comps.size(), 0.0);
+    size_t off = 0;
+    for (size_t c = 0; c < comps.size(); ++c) {
+        for (size_t i = 0; i < comps[c]->cores[n - 1].r; ++i) data[base + (off + i) + total_r * c] = 1.0;
+        off += comps[c]->cores[n - 1].r;
+    }
+    dims3.push_back({total_r, comps.size(), 1});
+    return std::unique_ptr<TensorTrain>(new TensorTrain(dims3, data.data()));
+}
+
+namespace {
+struct BatchedShared {
+    t4a_gpu_coord_eval_vec_fn f;
+    void* ctx;
+    size_t n_comp;
+    size_t comp;
+    struct KeyHash {
+        size_t operator()(const std::vector<uint64_t>& v) const
+        {
+            uint64_t h = 0xcbf29ce484222325ull;
+            for (uint64_t x : v) h = (h ^ x) * 0x100000001b3ull;
+            return (size_t)h;
+        }
+    };
+    std::unordered_map<std::vector<uint64_t>, std::vector<double>, KeyHash> cache; // coordinate bits -> all components
+    size_t n_user_calls = 0, n_user_points = 0;
+    std::string short_result;
+};
+
+int64_t batched_component_cb(void* vctx, const double* coords, size_t n_vars, size_t n_pts, double* out)
+{
+    BatchedShared& sh = *static_cast<BatchedShared*>(vctx);
+    std::vector<size_t> miss;
+    std::vector<std::vector<uint64_t>> keys(n_pts, std::vector<uint64_t>(n_vars));
+    for (size_t p = 0; p < n_pts; ++p) {
+        std::memcpy(keys[p].data(), coords + p * n_vars, n_vars * sizeof(double));
+        if (!sh.cache.count(keys[p])) {
+            sh.cache.emplace(keys[p], std::vector<double>()); // placeholder: identical coordinates inside one batch
+            miss.push_back(p);
+        }
+    }
+    if (!miss.empty()) {
+        std::vector<double> x(miss.size() * n_vars), vals(miss.size() * sh.n_comp);
+        for (size_t m = 0; m < miss.size(); ++m) std::memcpy(x.data() + m * n_vars, coords + miss[m] * n_vars, n_vars * sizeof(double));
+        const int64_t got = sh.f(sh.ctx, x.data(), n_vars, miss.size(), sh.n_comp, vals.data());
+        ++sh.n_user_calls;
+        sh.n_user_points += miss.size();
+        if (got < 0 || (size_t)got != miss.size() * sh.n_comp) {
+            const size_t per_point = got < 0 ? 0 : (size_t)got / std::max<size_t>(miss.size(), 1);
+            sh.short_result = "callback returned " + std::to_string(per_point) + " components, expected at least " +
+                              std::to_string(sh.n_comp);
+            return -1;
+        }
+        for (size_t m = 0; m < miss.size(); ++m)
+            sh.cache[keys[miss[m]]].assign(vals.begin() + m * sh.n_comp, vals.begin() + (m + 1) * sh.n_comp);
+    }
+    for (size_t p = 0; p < n_pts; ++p) out[p] = sh.cache[keys[p]][sh.comp];
+    return (int64_t)n_pts;
+}
+} // namespace
+
+QuanticsBatchedResult quantics_batched(const QuanticsGrid& grid, t4a_gpu_coord_eval_vec_fn f, void* ctx,
+                                       const std::vector<size_t>& output_dims,
+                                       const std::vector<std::vector<size_t>>* initial_pivots, const QtciOptions& options)
+{
+    if (output_dims.empty()) throw Error(T4A_GPU_INVALID_ARGUMENT, "output_dims must not be empty");
+    size_t n_comp = 1;
+    for (size_t d : output_dims) {
+        if (d != 0 && n_comp > (size_t)-1 / d) throw Error(T4A_GPU_INVALID_ARGUMENT, "product of output_dims overflowed usize");
+        n_comp *= d;
+    }
+    if (n_comp == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "product of output_dims must be positive, got 0");
+    if (!grid.discretized) throw Error(T4A_GPU_INVALID_ARGUMENT, "a discretized grid is required");
+    BatchedShared sh;
+    sh.f = f;
+    sh.ctx = ctx;
+    sh.n_comp = n_comp;
+    QuanticsBatchedResult res;
+    res.output_dims = output_dims;
+    std::vector<std::unique_ptr<TensorTrain>> comps;
+    for (size_t comp = 0; comp < n_comp; ++comp) {
+        sh.comp = comp;
+        QuanticsTci q(grid, &batched_component_cb, nullptr, &sh, {});
+        try {
+            q.run(initial_pivots, options);
+        } catch (const Error&) {
+            if (!sh.short_result.empty()) throw Error(T4A_GPU_CALLBACK_ERROR, sh.short_result);
+            throw;
+        }
+        const auto& t = *q.tci;
+        if (res.ranks.size() < t.ranks_hist.size()) res.ranks.resize(t.ranks_hist.size(), 0);
+        if (res.errors.size() < t.errors_hist.size()) res.errors.resize(t.errors_hist.size(), 0.0);
+        for (size_t k = 0; k < t.ranks_hist.size(); ++k) res.ranks[k] = std::max(res.ranks[k], t.ranks_hist[k]);
+        for (size_t k = 0; k < t.errors_hist.size(); ++k) res.errors[k] = std::max(res.errors[k], t.errors_hist[k]);
+        comps.push_back(std::move(q.tt));
+    }
+    res.tt = combine_component_tts(comps);
+    res.n_user_calls = sh.n_user_calls;
+    res.n_user_points = sh.n_user_points;
+    return res;
 }
 
 } // namespace t4a

@@ -84,6 +84,21 @@ private:
     std::vector<std::vector<double>> xvals_;
 };
 
+// quanticscrossinterpolate_batched (batched/mod.rs:50-191): one scalar interpolation per output component over a shared
+// coordinate-keyed cache (each coordinate reaches the user once, for all components), then combine_component_tts
+// (:193-318): block-diagonal direct sum of the component trains plus a component selector site.
+struct QuanticsBatchedResult {
+    std::unique_ptr<TensorTrain> tt;
+    std::vector<size_t> output_dims;
+    std::vector<size_t> ranks;   // element-wise maximum over the components
+    std::vector<double> errors;
+    size_t n_user_calls = 0, n_user_points = 0;
+};
+QuanticsBatchedResult quantics_batched(const QuanticsGrid& grid, t4a_gpu_coord_eval_vec_fn f, void* ctx,
+                                       const std::vector<size_t>& output_dims,
+                                       const std::vector<std::vector<size_t>>* initial_pivots, const QtciOptions& options);
+std::unique_ptr<TensorTrain> combine_component_tts(std::vector<std::unique_ptr<TensorTrain>>& comps);
+
 // quanticscrossinterpolate_from_arrays / _discrete input checks (:322-375, :449-472)
 void qtci_check_sizes(const std::vector<size_t>& sizes);
 bool qtci_check_xvals_uniform(const std::vector<std::vector<double>>& xvals);

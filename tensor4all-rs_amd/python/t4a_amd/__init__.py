@@ -1283,3 +1283,48 @@ def quanticscrossinterpolate_from_arrays(xvals, f, initial_pivots=None, options=
     _check(_lib.t4a_gpu_quanticscrossinterpolate_from_arrays(_p(flat), _p(sz), c_size_t(len(sz)), cb, None, *pa,
                                                              ctypes.byref(o), ctypes.byref(h)))
     return QuanticsTensorCI2(h, (cb, keep))
+
+
+_COORD_VEC_CB = ctypes.CFUNCTYPE(ctypes.c_int64, c_void_p, ctypes.POINTER(c_double), c_size_t, c_size_t, c_size_t,
+                                 ctypes.POINTER(c_double))
+
+
+def quanticscrossinterpolate_batched(rs, f, output_dims, lower=None, upper=None, include_endpoint=False,
+                                     grid_unfolding=INTERLEAVED, initial_pivots=None, options=None):
+    """quanticscrossinterpolate_batched (quanticstci/src/batched/mod.rs:50): f(coords) -> prod(output_dims) components.
+    Returns (SimpleTensorTrain with one extra component site, ranks, errors, number of points the user function saw)."""
+    options = options or QtciOptions()
+    rs_a = np.asarray(rs, dtype=np.uintp)
+    nv = len(rs_a)
+    lo = None if lower is None else np.asarray(lower, dtype=np.float64)
+    up = None if upper is None else np.asarray(upper, dtype=np.float64)
+    od = np.asarray(output_dims, dtype=np.uintp)
+
+    def _cb(ctx, ptr, n_vars, n_pts, n_comp, out_ptr):
+        try:
+            pts = np.ctypeslib.as_array(ptr, shape=(n_pts, n_vars))
+            out = np.ctypeslib.as_array(out_ptr, shape=(n_pts, n_comp))
+            total = 0
+            for p, row in enumerate(pts):
+                vals = np.asarray(f([float(v) for v in row]), dtype=np.float64).ravel()
+                k = min(len(vals), n_comp)
+                out[p, :k] = vals[:k]
+                total += len(vals)
+            return total
+        except Exception:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    cb = _COORD_VEC_CB(_cb)
+    pa, keep = _qtci_pivots(initial_pivots, nv)
+    o = options.to_c()
+    h = c_void_p()
+    n_iter, upts = c_size_t(0), c_size_t(0)
+    ranks, errors = np.zeros(max(options.max_iter, 1), dtype=np.uintp), np.zeros(max(options.max_iter, 1))
+    _check(_lib.t4a_gpu_quanticscrossinterpolate_batched(
+        _p(rs_a), c_size_t(nv), None if lo is None else _p(lo), None if up is None else _p(up), c_int32(int(include_endpoint)),
+        c_int32(grid_unfolding), cb, None, _p(od) if len(od) else None, c_size_t(len(od)), *pa, ctypes.byref(o), ctypes.byref(h),
+        ctypes.byref(n_iter), _p(ranks), _p(errors), ctypes.byref(upts)))
+    k = n_iter.value
+    return SimpleTensorTrain._adopt(h), [int(x) for x in ranks[:k]], [float(x) for x in errors[:k]], upts.value

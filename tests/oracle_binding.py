@@ -935,3 +935,68 @@ def quanticscrossinterpolate_from_arrays(xvals, f, initial_pivots=None, options=
     pa, keep = _pivot_args(initial_pivots, len(sz))
     h = _lib.oracle_qtci_from_arrays(_p(flat), _p(sz), u64(len(sz)), cb, None, *pa, *options.args())
     return OracleQuanticsTCI2(h, (cb, keep))
+
+
+_COORD_VEC_CB = ctypes.CFUNCTYPE(cint, vp, ctypes.POINTER(dbl), u64, ctypes.POINTER(dbl), u64)
+_lib.oracle_qtci_batched.restype = vp
+for _n in ("oracle_qtci_batched_len", "oracle_qtci_batched_user_calls", "oracle_qtci_batched_n_iterations"):
+    getattr(_lib, _n).restype = u64
+    getattr(_lib, _n).argtypes = [vp]
+_lib.oracle_qtci_batched_release.argtypes = [vp]
+
+
+class OracleQuanticsBatched:
+    def __init__(self, h, keep):
+        if not h:
+            raise OracleError(-2)
+        self._h, self._keep = h, keep
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.oracle_qtci_batched_release(self._h)
+            self._h = None
+
+    def cores(self):
+        out = []
+        for site in range(int(_lib.oracle_qtci_batched_len(vp(self._h)))):
+            d = np.zeros(3, dtype=np.uint64)
+            _check(_lib.oracle_qtci_batched_site_tensor(vp(self._h), u64(site), _p(d), None))
+            a = np.zeros(int(d.prod()))
+            _check(_lib.oracle_qtci_batched_site_tensor(vp(self._h), u64(site), _p(d), _p(a)))
+            out.append(a.reshape([int(x) for x in d], order="F"))
+        return out
+
+    def tensor_train(self):
+        return OracleTT(self.cores())
+
+    def user_calls(self):
+        return int(_lib.oracle_qtci_batched_user_calls(vp(self._h)))
+
+    def history(self):
+        k = int(_lib.oracle_qtci_batched_n_iterations(vp(self._h)))
+        ranks, errors = np.zeros(max(k, 1), dtype=np.uint64), np.zeros(max(k, 1))
+        _check(_lib.oracle_qtci_batched_history(vp(self._h), _p(ranks), _p(errors)))
+        return [int(x) for x in ranks[:k]], [float(x) for x in errors[:k]]
+
+
+def quanticscrossinterpolate_batched(rs, f, output_dims, lower=None, upper=None, include_endpoint=False,
+                                     grid_unfolding=INTERLEAVED, initial_pivots=None, options=None):
+    """quanticscrossinterpolate_batched restatement; f(coords) -> sequence of components."""
+    options = options or QtciOptions()
+    rs_a = np.asarray(rs, dtype=np.uint64)
+    nv = len(rs_a)
+    lo = np.asarray([0.0] * nv if lower is None else lower, dtype=np.float64)
+    up = np.asarray([1.0] * nv if upper is None else upper, dtype=np.float64)
+    od = np.asarray(output_dims, dtype=np.uint64)
+
+    def _cb(ctx, x, n, out, max_out):
+        vals = list(f([x[i] for i in range(n)]))
+        for k, v in enumerate(vals[:max_out]):
+            out[k] = float(v)
+        return len(vals)
+
+    cb = _COORD_VEC_CB(_cb)
+    pa, keep = _pivot_args(initial_pivots, nv)
+    h = _lib.oracle_qtci_batched(_p(rs_a), u64(nv), _p(lo), _p(up), cint(int(include_endpoint)), cint(grid_unfolding), cb, None,
+                                 _p(od) if len(od) else None, u64(len(od)), *pa, *options.args())
+    return OracleQuanticsBatched(h, (cb, keep))

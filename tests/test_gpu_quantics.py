@@ -168,3 +168,54 @@ def test_two_variable_function_matches_oracle_at_scale(t4a):
     assert np.abs(got - exact).max() < 1e-6
     assert np.abs(got - o.evaluate(pts)).max() < 1e-9
     assert g.integral() == pytest.approx(o.integral(), rel=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ batched (vector valued)
+def _bits(i, r):
+    return [(i >> (r - 1 - b)) & 1 for b in range(r)]
+
+
+def test_reference_batched_cases(t4a):
+    # batched/tests/mod.rs:6-129, 158-211
+    f2 = lambda x: [math.sin(2 * math.pi * x[0]) + 1.0, math.cos(2 * math.pi * x[0])]
+    tt, ranks, errors, _ = t4a.quanticscrossinterpolate_batched([6], f2, [2], [0.0], [1.0],
+                                                               options=t4a.QtciOptions(tolerance=1e-8, seed=1))
+    assert len(tt) == 7 and len(ranks) == len(errors) > 0
+    pts = np.array([_bits(i, 6) + [c] for i in range(64) for c in range(2)])
+    exact = np.array([f2([i / 64.0])[c] for i in range(64) for c in range(2)])
+    assert np.abs(tt.evaluate(pts) - exact).max() < 1e-6
+    o = ob.quanticscrossinterpolate_batched([6], f2, [2], [0.0], [1.0], options=ob.QtciOptions(tolerance=1e-8, seed=1))
+    assert ranks == o.history()[0]
+    for a, b in zip(tt.site_tensors(), o.cores()):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    f4 = lambda x: [(c + 1.0) * (x[0] + 1.0) for c in range(4)]
+    tt, _, _, _ = t4a.quanticscrossinterpolate_batched([4], f4, [2, 2], [0.0], [1.0], options=t4a.QtciOptions(tolerance=1e-8, seed=2))
+    assert len(tt) == 5 and tt.site_dims()[-1] == 4
+    pts = np.array([_bits(i, 4) + [c] for i in range(16) for c in range(4)])
+    exact = np.array([f4([i / 16.0])[c] for i in range(16) for c in range(4)])
+    assert np.abs(tt.evaluate(pts) - exact).max() < 1e-8
+    s = t4a.quanticscrossinterpolate([4], lambda x: x[0] * x[0], [0.0], [1.0], options=t4a.QtciOptions(tolerance=1e-8, seed=3))
+    b, _, _, _ = t4a.quanticscrossinterpolate_batched([4], lambda x: [x[0] * x[0]], [1], [0.0], [1.0],
+                                                     options=t4a.QtciOptions(tolerance=1e-8, seed=3))
+    assert s.n_sites == 4 and len(b) == 5
+    assert np.abs(s.evaluate(np.arange(16).reshape(-1, 1)) - b.evaluate(np.array([_bits(i, 4) + [0] for i in range(16)]))).max() < 1e-10
+
+
+def test_reference_batched_errors_and_shared_cache(t4a):
+    # batched/tests/mod.rs:131-156, 213-280
+    for od in ([], [0]):
+        with pytest.raises(t4a.T4aError) as e:
+            t4a.quanticscrossinterpolate_batched([4], lambda x: [], od, [0.0], [1.0])
+        assert e.value.code == t4a.INVALID_ARGUMENT
+    with pytest.raises(t4a.T4aError) as e:
+        t4a.quanticscrossinterpolate_batched([2], lambda x: [1.0], [2], [0.0], [1.0])
+    assert "expected at least 2" in str(e.value)
+    calls = []
+
+    def f(x):
+        calls.append(x[0])
+        return [x[0] + 1.0, x[0] * x[0] + 1.0]
+
+    tt, _, _, user_points = t4a.quanticscrossinterpolate_batched([3], f, [2], [0.0], [1.0],
+                                                                 options=t4a.QtciOptions(tolerance=1e-8, n_random_init_pivot=0))
+    assert len(tt) == 4 and len(calls) == user_points <= 8 and len(set(calls)) == len(calls)

@@ -154,3 +154,51 @@ def test_grid_unfolding_conventions():
     pts = np.array([[i, j] for i in range(8) for j in range(8)])
     exact = 1.0 + pts[:, 0] + 10.0 * pts[:, 1]
     assert np.allclose(q.evaluate(pts), exact, atol=1e-8) and np.allclose(qf.evaluate(pts), exact, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ batched (vector valued)
+def _eval_components(tt, q, n_comp):
+    return np.array([tt.evaluate([list(q) + [c]])[0] for c in range(n_comp)])
+
+
+def test_batched_two_components_1d():
+    # batched/tests/mod.rs:6-71
+    f = lambda x: [math.sin(2 * math.pi * x[0]) + 1.0, math.cos(2 * math.pi * x[0])]
+    r = ob.quanticscrossinterpolate_batched([6], f, [2], [0.0], [1.0], options=QtciOptions(tolerance=1e-8, seed=1))
+    tt = r.tensor_train()
+    assert len(tt) == 7
+    for i in range(64):
+        q = [(i >> (5 - b)) & 1 for b in range(6)]
+        assert np.abs(_eval_components(tt, q, 2) - np.array(f([i / 64.0]))).max() < 1e-6
+
+
+def test_batched_matrix_valued_and_scalar_equivalent():
+    # batched/tests/mod.rs:73-129, 158-211
+    f = lambda x: [(c + 1.0) * (x[0] + 1.0) for c in range(4)]
+    r = ob.quanticscrossinterpolate_batched([4], f, [2, 2], [0.0], [1.0], options=QtciOptions(tolerance=1e-8, seed=2))
+    tt = r.tensor_train()
+    assert len(tt) == 5
+    for i in range(16):
+        q = [(i >> (3 - b)) & 1 for b in range(4)]
+        assert np.abs(_eval_components(tt, q, 4) - np.array(f([i / 16.0]))).max() < 1e-8
+    s = ob.quanticscrossinterpolate([4], lambda x: x[0] * x[0], [0.0], [1.0], options=QtciOptions(tolerance=1e-8, seed=3))
+    b = ob.quanticscrossinterpolate_batched([4], lambda x: [x[0] * x[0]], [1], [0.0], [1.0], options=QtciOptions(tolerance=1e-8, seed=3))
+    bt = b.tensor_train()
+    assert s.n_sites == 4 and len(bt) == 5
+    for i in range(16):
+        q = [(i >> (3 - b_)) & 1 for b_ in range(4)]
+        assert abs(s.evaluate([[i]])[0] - bt.evaluate([q + [0]])[0]) < 1e-10
+
+
+def test_batched_errors_and_shared_cache():
+    # batched/tests/mod.rs:131-156, 213-280
+    with pytest.raises(ob.OracleError):
+        ob.quanticscrossinterpolate_batched([4], lambda x: [], [], [0.0], [1.0])
+    with pytest.raises(ob.OracleError):
+        ob.quanticscrossinterpolate_batched([4], lambda x: [], [0], [0.0], [1.0])
+    with pytest.raises(ob.OracleError) as e:
+        ob.quanticscrossinterpolate_batched([2], lambda x: [1.0], [2], [0.0], [1.0])
+    assert "expected at least 2" in str(e.value)
+    r = ob.quanticscrossinterpolate_batched([3], lambda x: [x[0] + 1.0, x[0] * x[0] + 1.0], [2], [0.0], [1.0],
+                                            options=QtciOptions(tolerance=1e-8, n_random_init_pivot=0))
+    assert len(r.tensor_train()) == 4 and r.user_calls() <= 8
