@@ -4,14 +4,16 @@
 //
 // The matrix stays in HBM and is never physically permuted: rowpos/colpos map a physical row / column to its position
 // in the reference's swapped buffer, so "first strict maximum in column-major order" (matrixlu.rs:480-519) becomes
-// "largest v*v, ties to the smallest (colpos, rowpos)".  Two launches per pivot step:
+// "largest v*v, ties to the smallest (colpos, rowpos)".  Three launches per pivot step:
 //   argmax  — every workgroup scans a slice of the trailing submatrix; the last one to finish reduces the partial
-//             winners, applies the stop rules (matrixlu.rs:757-791), swaps the positions and scales the pivot column
-//             (left-orthogonal, :562-577) or pivot row (:579-591);
+//             winners, applies the stop rules (matrixlu.rs:757-791) and swaps the positions;
+//   scale   — the pivot column (left-orthogonal, :562-577) or pivot row (:579-591) divided by the pivot;
 //   update  — t - x*y on the trailing submatrix with separately rounded multiply and subtract (:593-612).
 // Every launch returns immediately once the stop flag is set, so the host enqueues max_steps steps without reading back.
 // HBM-bound: 16 bytes per trailing element and step, exactly the algorithmic traffic of the reference loop.
 #include "kernels.hpp"
+
+#include <cstdlib>
 
 namespace t4a {
 
@@ -156,7 +158,6 @@ __global__ void __launch_bounds__(256) rg_argmax_kernel(RrluGlobalArgs p, int k)
         }
     }
     g = g_block_reduce(g, red);
-    __shared__ int s_stop;
     if (tid == 0) {
         const double pivot_abs = sqrt(g.val * g.val);
         const double max_error = p.dstate[1];
@@ -188,23 +189,27 @@ __global__ void __launch_bounds__(256) rg_argmax_kernel(RrluGlobalArgs p, int k)
             p.istate[1] = 1;
         }
         p.istate[0] = 0; // ticket counter for the next step
-        s_stop = stop;
         __threadfence();
     }
-    __syncthreads();
-    if (s_stop) return;
-    __threadfence(); // acquire: thread 0's position updates must not be served from a stale L1 line
-    const double pivot = g.val;
-    if (p.left_orth) { // scale_column_tail
-        double* col = p.W + (size_t)g.pj * (size_t)p.M;
-        for (int i = tid; i < p.M; i += blockDim.x)
-            if (p.rowpos[i] > k) col[i] = col[i] / pivot;
-    } else { // scale_row_tail
-        for (int j = tid; j < p.N; j += blockDim.x)
-            if (p.colpos[j] > k) {
-                double* q = p.W + (size_t)j * (size_t)p.M + g.pi;
-                *q = *q / pivot;
-            }
+}
+
+// scale_column_tail (left-orthogonal, matrixlu.rs:562-577) or scale_row_tail (:579-591) of the step decided by the search
+__global__ void __launch_bounds__(256) rg_scale_kernel(RrluGlobalArgs p, int k)
+{
+    if (p.istate[1] != 0) return;
+    const int pr = p.istate[2], pc = p.istate[3];
+    const double pivot = p.dstate[0];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p.left_orth) {
+        if (gid < p.M && p.rowpos[gid] > k) {
+            double* q = p.W + (size_t)pc * (size_t)p.M + gid;
+            *q = *q / pivot;
+        }
+    } else {
+        if (gid < p.N && p.colpos[gid] > k) {
+            double* q = p.W + (size_t)gid * (size_t)p.M + pr;
+            *q = *q / pivot;
+        }
     }
 }
 
@@ -282,8 +287,12 @@ void rrlu_global_launch(RrluGlobalArgs a, int* iwork, double* dwork, hipStream_t
     a.dstate = a.partials_val + blocks;
     (void)hipMemsetAsync(a.istate, 0, 16 * sizeof(int), stream);
     hipLaunchKernelGGL(rg_init_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    // the search ends with one same-address atomic per workgroup (they serialise in L2, ~40 ns each): a moderate grid (512) is the measured optimum
+    static const int acap = std::getenv("T4A_RG_ABLOCKS") ? std::atoi(std::getenv("T4A_RG_ABLOCKS")) : 512;
+    const int ablocks = blocks < acap ? blocks : acap;
     for (int k = 0; k < a.max_steps; ++k) {
-        hipLaunchKernelGGL(rg_argmax_kernel, dim3(blocks), dim3(256), 0, stream, a, k);
+        hipLaunchKernelGGL(rg_argmax_kernel, dim3(ablocks), dim3(256), 0, stream, a, k);
+        hipLaunchKernelGGL(rg_scale_kernel, dim3(((a.left_orth ? a.M : a.N) + 255) / 256), dim3(256), 0, stream, a, k);
         if (k + 1 < a.M && k + 1 < a.N) hipLaunchKernelGGL(rg_update_kernel, dim3(blocks), dim3(256), 0, stream, a, k);
     }
     hipLaunchKernelGGL(rg_final_kernel, dim3(blocks), dim3(256), 0, stream, a);
