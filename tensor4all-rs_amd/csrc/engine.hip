@@ -100,8 +100,10 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         r.has_factors = need_factors;
         return r;
     }
-    if (M > 65535 || N > 65535)
-        throw Error(T4A_GPU_NOT_IMPLEMENTED, "rrLU: matrices with more than 65535 rows or columns are not supported");
+    // the register- and LDS-resident kernels pack positions into 16 bits; larger matrices go to the HBM-resident kernel
+    const bool huge = M > 65535 || N > 65535;
+    if ((size_t)M * (size_t)N > ((size_t)1 << 33))
+        throw Error(T4A_GPU_NOT_IMPLEMENTED, "rrLU: matrices with more than 2^33 entries are not supported");
 
     size_t ms = opts.max_bond_dim;
     if (ms > (size_t)M) ms = M;
@@ -143,7 +145,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     const bool left = opts.left_orthogonal;
     const int kM = left ? M : N, kN = left ? N : M;
     RrluRegPlan rplan;
-    const bool use_reg = !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
+    const bool use_reg = !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     bool fuse = false;
     if (fused) {
         fuse = use_reg && rplan.RPT * rplan.CPT <= RRLU_FUSED_MAX_VALUES;
@@ -245,7 +247,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         plan_W = rplan.W;
         plan_T = rplan.T;
         plan_code = rplan.RPT * 1000 + rplan.CPT * 10 + (rplan.W == 1 ? 2 : 0) + ((rplan.TR % 64) == 0 ? 1 : 0);
-    } else if (force_global || rrlu_make_plan(M, N, num_cus_).lds_bytes > 160 * 1024) {
+    } else if (huge || force_global || rrlu_make_plan(M, N, num_cus_).lds_bytes > 160 * 1024) {
         // neither the register file nor the LDS of the chip holds this matrix: HBM-resident kernel pair per pivot step
         const int gb = rrlu_global_blocks(M, N);
         d_gints_.reserve(rrlu_global_int_words(M, N, gb));

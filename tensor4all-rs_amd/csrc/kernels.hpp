@@ -54,7 +54,7 @@ size_t rrlu_cols_bytes(const RrluPlan& plan, int M);
 // Enqueue memset of the key mailbox + the kernel.
 void rrlu_launch(const RrluPlan& plan, const RrluArgs& args, hipStream_t stream);
 
-// ---- HBM-resident fallback (kernels_rrlu_global.hip): any shape up to 65535 x 65535, two launches per pivot step ----
+// ---- HBM-resident fallback (kernels_rrlu_global.hip): any shape, three launches per pivot step ----
 struct RrluGlobalArgs {
     const double* A;            // M x N input (ld = M), left untouched
     double* Aout;               // factored matrix in permuted coordinates (ld = M) or nullptr
@@ -71,7 +71,7 @@ struct RrluGlobalArgs {
     double* W;                  // working copy
     int *rowpos, *colpos, *posrow, *poscol;
     double *partials_sc, *partials_val;
-    unsigned* partials_pos;
+    unsigned long long* partials_pos;
     int* partials_ij;
     int* istate;                // [0] ticket counter [1] stop flag [2] pivot row [3] pivot column (physical) [4] npivots
     double* dstate;             // [0] pivot [1] max_error [2] lu.error

@@ -4,7 +4,7 @@
 //
 // The matrix stays in HBM and is never physically permuted: rowpos/colpos map a physical row / column to its position
 // in the reference's swapped buffer, so "first strict maximum in column-major order" (matrixlu.rs:480-519) becomes
-// "largest v*v, ties to the smallest (colpos, rowpos)".  Three launches per pivot step:
+// "largest v*v, ties to the smallest (colpos, rowpos)" (64-bit position keys: no 65535 limit here).  Three launches per pivot step:
 //   argmax  — every workgroup scans a slice of the trailing submatrix; the last one to finish reduces the partial
 //             winners, applies the stop rules (matrixlu.rs:757-791) and swaps the positions;
 //   scale   — the pivot column (left-orthogonal, :562-577) or pivot row (:579-591) divided by the pivot;
@@ -21,21 +21,22 @@ namespace {
 
 struct GCand {
     double sc, val;
-    unsigned pos; // colpos << 16 | rowpos
-    int pi, pj;   // physical row / column
+    unsigned long long pos; // colpos << 32 | rowpos
+    int pi, pj;             // physical row / column
 };
+constexpr unsigned long long G_NOPOS = ~0ull;
 
-__device__ __forceinline__ bool g_beats(double sa, unsigned pa, double sb, unsigned pb)
+__device__ __forceinline__ bool g_beats(double sa, unsigned long long pa, double sb, unsigned long long pb)
 {
     return (sa > sb) || (sa == sb && pa < pb);
 }
 
 // a NaN square only wins when it sits on the first scanned element (the reference seeds its maximum with it)
-__device__ __forceinline__ double g_score(double a, unsigned pos, int k)
+__device__ __forceinline__ double g_score(double a, unsigned long long pos, int k)
 {
     double sc = a * a;
     if (sc != sc) {
-        const unsigned diag = ((unsigned)k << 16) | (unsigned)k;
+        const unsigned long long diag = ((unsigned long long)k << 32) | (unsigned long long)k;
         sc = (pos == diag) ? __builtin_huge_val() : -1.0;
     }
     return sc;
@@ -47,7 +48,7 @@ __device__ __forceinline__ GCand g_block_reduce(GCand c, GCand* red)
         GCand o;
         o.sc = __shfl_xor(c.sc, off);
         o.val = __shfl_xor(c.val, off);
-        o.pos = (unsigned)__shfl_xor((int)c.pos, off);
+        o.pos = (unsigned long long)__shfl_xor((long long)c.pos, off);
         o.pi = __shfl_xor(c.pi, off);
         o.pj = __shfl_xor(c.pj, off);
         if (g_beats(o.sc, o.pos, c.sc, c.pos)) c = o;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) rg_argmax_kernel(RrluGlobalArgs p, int k)
     GCand best;
     best.sc = -2.0;
     best.val = 0.0;
-    best.pos = 0xFFFFFFFFu;
+    best.pos = G_NOPOS;
     best.pi = 0;
     best.pj = 0;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + tid; e < total; e += stride) {
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(256) rg_argmax_kernel(RrluGlobalArgs p, int k)
         const int rp = p.rowpos[i];
         if (cp < k || rp < k) continue;
         const double a = p.W[e];
-        const unsigned pos = ((unsigned)cp << 16) | (unsigned)rp;
+        const unsigned long long pos = ((unsigned long long)cp << 32) | (unsigned long long)rp;
         const double sc = g_score(a, pos, k);
         if (g_beats(sc, pos, best.sc, best.pos)) {
             best.sc = sc;
@@ -143,12 +144,12 @@ __global__ void __launch_bounds__(256) rg_argmax_kernel(RrluGlobalArgs p, int k)
     GCand g;
     g.sc = -2.0;
     g.val = 0.0;
-    g.pos = 0xFFFFFFFFu;
+    g.pos = G_NOPOS;
     g.pi = 0;
     g.pj = 0;
     for (int b = tid; b < (int)gridDim.x; b += blockDim.x) {
         const double sc = p.partials_sc[b];
-        const unsigned pos = p.partials_pos[b];
+        const unsigned long long pos = p.partials_pos[b];
         if (g_beats(sc, pos, g.sc, g.pos)) {
             g.sc = sc;
             g.val = p.partials_val[b];
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(256) rg_argmax_kernel(RrluGlobalArgs p, int k)
         if (!stop) {
             p.dstate[1] = fmax(max_error, pivot_abs);
             p.dstate[0] = g.val;
-            const int prp = (int)(g.pos & 0xFFFFu), pcp = (int)(g.pos >> 16);
+            const int prp = (int)(g.pos & 0xFFFFFFFFull), pcp = (int)(g.pos >> 32);
             const int pr = g.pi, pc = g.pj;
             const int rk = p.posrow[k];
             p.posrow[k] = pr;
@@ -259,8 +260,8 @@ __global__ void __launch_bounds__(256) rg_final_kernel(RrluGlobalArgs p)
 
 } // namespace
 
-size_t rrlu_global_int_words(int M, int N, int blocks) { return 2 * (size_t)M + 2 * (size_t)N + 3 * (size_t)blocks + 16; }
-size_t rrlu_global_double_words(int M, int N, int blocks) { return (size_t)M * (size_t)N + 2 * (size_t)blocks + 8; }
+size_t rrlu_global_int_words(int M, int N, int blocks) { return 2 * (size_t)M + 2 * (size_t)N + 2 * (size_t)blocks + 16; }
+size_t rrlu_global_double_words(int M, int N, int blocks) { return (size_t)M * (size_t)N + 3 * (size_t)blocks + 8; }
 
 int rrlu_global_blocks(int M, int N)
 {
@@ -279,12 +280,12 @@ void rrlu_global_launch(RrluGlobalArgs a, int* iwork, double* dwork, hipStream_t
     a.posrow = a.colpos + a.N;
     a.poscol = a.posrow + a.M;
     a.partials_ij = a.poscol + a.N;
-    a.partials_pos = reinterpret_cast<unsigned*>(a.partials_ij + 2 * (size_t)blocks);
-    a.istate = reinterpret_cast<int*>(a.partials_pos + blocks);
+    a.istate = a.partials_ij + 2 * (size_t)blocks;
     a.W = dwork;
     a.partials_sc = a.W + (size_t)a.M * (size_t)a.N;
     a.partials_val = a.partials_sc + blocks;
-    a.dstate = a.partials_val + blocks;
+    a.partials_pos = reinterpret_cast<unsigned long long*>(a.partials_val + blocks);
+    a.dstate = a.partials_val + 2 * (size_t)blocks;
     (void)hipMemsetAsync(a.istate, 0, 16 * sizeof(int), stream);
     hipLaunchKernelGGL(rg_init_kernel, dim3(blocks), dim3(256), 0, stream, a);
     // the search ends with one same-address atomic per workgroup (they serialise in L2, ~40 ns each): a moderate grid (512) is the measured optimum

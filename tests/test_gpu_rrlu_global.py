@@ -48,6 +48,17 @@ def test_tall_and_large_shapes_match_oracle(t4a, shape, left):
     assert np.abs((l @ u)[:k][:, :k] - a[np.ix_(rows, cols)]).max() < 1e-9 * np.abs(a).max()
 
 
+def test_more_than_65535_rows_or_columns(t4a):
+    # the 16-bit position packing of the resident kernels does not apply to the HBM kernel
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((70001, 3)) @ rng.standard_normal((3, 5)) + 1e-9 * rng.standard_normal((70001, 5))
+    g = check(t4a, a, rel_tol=1e-6)
+    assert g.npivots() == 3
+    check(t4a, a.T.copy(), rel_tol=1e-6, left_orthogonal=False)
+    f = t4a.matrix_luci_factors_from_matrix(a, rel_tol=1e-6)
+    assert f.rank == 3 and np.abs(f.left @ f.right - a).max() < 1e-6
+
+
 def test_tolerance_stop_and_full_rank_error(t4a):
     rng = np.random.default_rng(3)
     a = rng.standard_normal((9000, 6)) @ rng.standard_normal((6, 70))
