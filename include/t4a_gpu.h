@@ -368,7 +368,13 @@ t4a_gpu_status t4a_gpu_treetci_add_global_pivots(t4a_gpu_treetci* h, const size_
 /* graph.rs:150-156 subregion_vertices(edge): the sorted site lists on the u side and on the v side (query with NULL). */
 t4a_gpu_status t4a_gpu_treetci_subregion_vertices(const t4a_gpu_treetci* h, size_t u, size_t v, size_t* n_left,
                                                   size_t* left, size_t* n_right, size_t* right);
-/* DefaultProposer::candidates (proposer.rs:57-88): left is (|left key| x n_left), right (|right key| x n_right),
+/* Proposer used by _candidates / _update_edge / _optimize / _crossinterpolate2 (proposer.rs:43-249): 0 DefaultProposer
+ * (neighbour product), 1 SimpleProposer::seeded(seed) (d*chi random candidates per side), 2
+ * TruncatedDefaultProposer::seeded(seed) (ordered sample of d*chi default candidates per side — keeps the matrices of
+ * branching vertices at d*chi x d*chi).  The reference draws from rand SmallRng seeded through std DefaultHasher; the
+ * stream here is splitmix64 ("parity unpinned"). */
+t4a_gpu_status t4a_gpu_treetci_set_proposer(t4a_gpu_treetci* h, int32_t kind, uint64_t seed);
+/* PivotCandidateProposer::candidates of the selected proposer (default: proposer.rs:57-88): left is (|left key| x n_left), right (|right key| x n_right),
  * both column-major; pass NULL buffers to query the counts. */
 t4a_gpu_status t4a_gpu_treetci_candidates(const t4a_gpu_treetci* h, size_t u, size_t v, size_t* n_left, size_t* left,
                                           size_t* n_right, size_t* right);

@@ -709,10 +709,16 @@ int oracle_tree_candidates(void* h, uint64_t u, uint64_t v, uint64_t* nl, uint64
 {
     return guarded([&] {
         std::vector<MultiIndex> l, r;
-        default_proposer_candidates(*static_cast<OracleTree*>(h)->st, TreeEdge(u, v), l, r);
+        tree_candidates(*static_cast<OracleTree*>(h)->st, TreeEdge(u, v), l, r);
         write_index_list(l, nl, left);
         write_index_list(r, nr, right);
     });
+}
+void oracle_tree_set_proposer(void* h, int kind, uint64_t seed)
+{
+    auto* t = static_cast<OracleTree*>(h);
+    t->st->proposer = kind;
+    t->st->proposer_seed = seed;
 }
 int oracle_tree_push_history(void* h, const uint64_t* key, uint64_t key_len, const uint64_t* cols, uint64_t count)
 {

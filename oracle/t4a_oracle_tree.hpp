@@ -18,7 +18,9 @@
 // from the leaves towards the root.  Parity: the pivot selection is the bit-exact rrLU of t4a_oracle.hpp; the
 // full-pivot solve of materialize.rs goes through tenferro in the reference ("parity unpinned", tolerance level);
 // the global pivot finder uses rand 0.9 StdRng there ("parity unpinned": splitmix64 here); SimpleProposer /
-// TruncatedDefaultProposer (rand SmallRng + std DefaultHasher streams) are not restated.
+// TruncatedDefaultProposer (proposer.rs:90-249, :357-409) draw from rand SmallRng seeded through std DefaultHasher in the
+// reference — both third party / unspecified streams, "parity unpinned": the structure (candidate counts d * chi, ordered
+// sampling without replacement, union with the history) is restated on a splitmix64 stream.
 #pragma once
 
 #include <deque>
@@ -230,6 +232,8 @@ struct TreeTCI2 { // state.rs:41-58
     std::vector<double> pivot_errors;
     double max_sample_value = 0.0;
     std::vector<PivotTable> ijset_history;
+    int proposer = 0;            // 0 DefaultProposer, 1 SimpleProposer, 2 TruncatedDefaultProposer
+    uint64_t proposer_seed = 0;  // ::seeded(seed)
 
     TreeTCI2(const std::vector<size_t>& dims, const TreeGraph& g) : local_dims(dims), graph(g)
     {
@@ -372,6 +376,77 @@ inline void default_proposer_candidates(const TreeTCI2& st, const TreeEdge& edge
     jcand = side(pq.second, keys.second);
 }
 
+// proposer.rs:357-387 rng_for_edge: one stream per (seed, proposer, edge, history length, current pivot counts)
+inline OracleRng tree_rng_for_edge(const TreeTCI2& st, const TreeEdge& edge, uint64_t seed, uint64_t tag)
+{
+    auto keys = st.graph.subregion_vertices(edge);
+    auto ncols = [&](const SubtreeKey& k) {
+        auto it = st.ijset.find(k);
+        return it == st.ijset.end() ? (uint64_t)0 : (uint64_t)it->second.size();
+    };
+    uint64_t h = seed;
+    for (uint64_t v : {tag, ((uint64_t)edge.u << 32) | (uint64_t)edge.v, (uint64_t)st.ijset_history.size(), ncols(keys.first),
+                       ncols(keys.second)}) {
+        OracleRng m(h ^ v);
+        h = m.next();
+    }
+    return OracleRng(h);
+}
+
+// proposer.rs:389-409 sample_ordered_candidates: `max_size` distinct candidates in their original order
+inline std::vector<MultiIndex> tree_sample_ordered(const std::vector<MultiIndex>& cand, size_t max_size, OracleRng& rng)
+{
+    if (cand.size() <= max_size) return cand;
+    std::vector<size_t> idx(cand.size());
+    for (size_t k = 0; k < idx.size(); ++k) idx[k] = k;
+    for (size_t k = idx.size() - 1; k > 0; --k) std::swap(idx[k], idx[rng.range(k + 1)]);
+    idx.resize(max_size);
+    std::sort(idx.begin(), idx.end());
+    std::vector<MultiIndex> out;
+    for (size_t k : idx) out.push_back(cand[k]);
+    return out;
+}
+
+// PivotCandidateProposer::candidates for the proposer selected on the state (proposer.rs:57-249)
+inline void tree_candidates(const TreeTCI2& st, const TreeEdge& edge, std::vector<MultiIndex>& icand, std::vector<MultiIndex>& jcand)
+{
+    if (st.proposer == 0) {
+        default_proposer_candidates(st, edge, icand, jcand);
+        return;
+    }
+    auto pq = st.graph.separate_vertices(edge);
+    auto keys = st.graph.subregion_vertices(edge);
+    const size_t ichi = st.local_dims[pq.first] * st.pivots_of(keys.first).size();
+    const size_t jchi = st.local_dims[pq.second] * st.pivots_of(keys.second).size();
+    if (st.proposer == 1) { // SimpleProposer :127-160
+        OracleRng rng = tree_rng_for_edge(st, edge, st.proposer_seed, 0x73696d706c65ull);
+        auto random = [&](const SubtreeKey& key, size_t size) {
+            std::vector<MultiIndex> out;
+            for (size_t k = 0; k < size; ++k) {
+                MultiIndex c;
+                for (size_t site : key) c.push_back(rng.range(st.local_dims[site]));
+                out.push_back(c);
+            }
+            return out;
+        };
+        const PivotTable* history = st.ijset_history.empty() ? nullptr : &st.ijset_history.back();
+        auto iset = random(keys.first, ichi);
+        auto jset = random(keys.second, jchi);
+        icand = tree_detail::union_with_history(iset, history, keys.first);
+        jcand = tree_detail::union_with_history(jset, history, keys.second);
+        return;
+    }
+    if (st.proposer == 2) { // TruncatedDefaultProposer :205-249
+        std::vector<MultiIndex> di, dj;
+        default_proposer_candidates(st, edge, di, dj);
+        OracleRng rng = tree_rng_for_edge(st, edge, st.proposer_seed, 0x7472756e63ull);
+        icand = tree_sample_ordered(di, ichi, rng);
+        jcand = tree_sample_ordered(dj, jchi, rng);
+        return;
+    }
+    throw OracleError(ERR_INVALID_ARGUMENT, "unknown proposer");
+}
+
 // update.rs:143-243
 inline std::vector<double> evaluate_candidate_matrix(size_t n_sites, const SubtreeKey& left_key,
                                                      const std::vector<MultiIndex>& left, const SubtreeKey& right_key,
@@ -411,12 +486,12 @@ inline std::vector<double> evaluate_candidate_matrix(size_t n_sites, const Subtr
     return values;
 }
 
-// update.rs:22-115 with the default proposer
+// update.rs:22-115
 inline MatrixLuciFactors tree_update_edge(TreeTCI2& st, const TreeEdge& edge, const TreeBatchFn& evaluate, const RrLUOptions& options)
 {
     auto keys = st.graph.subregion_vertices(edge);
     std::vector<MultiIndex> lc, rc;
-    default_proposer_candidates(st, edge, lc, rc);
+    tree_candidates(st, edge, lc, rc);
     if (lc.empty() || rc.empty()) throw OracleError(ERR_INVALID_ARGUMENT, "proposer returned empty candidate list");
     std::vector<double> values =
         evaluate_candidate_matrix(st.local_dims.size(), keys.first, lc, keys.second, rc, st.local_dims, evaluate);

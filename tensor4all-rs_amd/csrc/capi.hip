@@ -1511,6 +1511,16 @@ t4a_gpu_status t4a_gpu_treetci_add_global_pivots(t4a_gpu_treetci* h, const size_
     });
 }
 
+t4a_gpu_status t4a_gpu_treetci_set_proposer(t4a_gpu_treetci* h, int32_t kind, uint64_t seed)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (kind < 0 || kind > 2) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown proposer");
+        h->impl.proposer = kind;
+        h->impl.proposer_seed = seed;
+    });
+}
+
 t4a_gpu_status t4a_gpu_treetci_subregion_vertices(const t4a_gpu_treetci* h, size_t u, size_t v, size_t* n_left,
                                                   size_t* left, size_t* n_right, size_t* right)
 {

@@ -277,7 +277,75 @@ uint64_t splitmix64(uint64_t& s)
 
 } // namespace
 
-void TreeTci::candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) const // :57-88
+void TreeTci::candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) const
+{
+    if (proposer == 0) {
+        default_candidates(edge, left, right);
+        return;
+    }
+    graph.require_edge(edge);
+    const auto keys = graph.subregion_vertices(edge);
+    auto ncols = [&](const SubtreeKey& k) {
+        auto it = ijset.find(k);
+        return it == ijset.end() ? (uint64_t)0 : (uint64_t)it->second.count;
+    };
+    // rng_for_edge (:357-387): one stream per (seed, proposer, edge, history length, current pivot counts)
+    const uint64_t tag = proposer == 1 ? 0x73696d706c65ull : 0x7472756e63ull;
+    uint64_t h = proposer_seed;
+    for (uint64_t v : {tag, ((uint64_t)edge.u << 32) | (uint64_t)edge.v, (uint64_t)ijset_history.size(), ncols(keys.first),
+                       ncols(keys.second)}) {
+        uint64_t m = h ^ v;
+        h = splitmix64(m);
+    }
+    uint64_t rng = h;
+    const size_t ichi = local_dims[edge.u] * pivots_of(keys.first).count;
+    const size_t jchi = local_dims[edge.v] * pivots_of(keys.second).count;
+    const std::map<SubtreeKey, IndexSet>* history = ijset_history.empty() ? nullptr : &ijset_history.back();
+    auto hist_of = [&](const SubtreeKey& key) -> const IndexSet* {
+        if (!history) return nullptr;
+        auto it = history->find(key);
+        return it == history->end() ? nullptr : &it->second;
+    };
+    if (proposer == 1) { // SimpleProposer (:127-160): d * chi uniformly random candidates per side
+        auto random = [&](const SubtreeKey& key, size_t size) {
+            IndexSet out;
+            out.width = key.size();
+            std::vector<uint32_t> c(key.size());
+            for (size_t k = 0; k < size; ++k) {
+                for (size_t s = 0; s < key.size(); ++s) c[s] = (uint32_t)(splitmix64(rng) % (uint64_t)local_dims[key[s]]);
+                out.push(c.data());
+            }
+            return out;
+        };
+        const IndexSet iset = random(keys.first, ichi);
+        const IndexSet jset = random(keys.second, jchi);
+        left = union_with_history(iset, hist_of(keys.first));
+        right = union_with_history(jset, hist_of(keys.second));
+        return;
+    }
+    if (proposer == 2) { // TruncatedDefaultProposer (:205-249): ordered sample of the default candidates
+        IndexSet di, dj;
+        default_candidates(edge, di, dj);
+        auto sample = [&](const IndexSet& cand, size_t max_size) { // sample_ordered_candidates (:389-409)
+            if (cand.count <= max_size) return cand;
+            std::vector<size_t> idx(cand.count);
+            for (size_t k = 0; k < idx.size(); ++k) idx[k] = k;
+            for (size_t k = idx.size() - 1; k > 0; --k) std::swap(idx[k], idx[(size_t)(splitmix64(rng) % (uint64_t)(k + 1))]);
+            idx.resize(max_size);
+            std::sort(idx.begin(), idx.end());
+            IndexSet out;
+            out.width = cand.width;
+            for (size_t k : idx) out.push(cand.at(k));
+            return out;
+        };
+        left = sample(di, ichi);
+        right = sample(dj, jchi);
+        return;
+    }
+    throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown proposer");
+}
+
+void TreeTci::default_candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) const // :57-88
 {
     graph.require_edge(edge);
     const auto keys = graph.subregion_vertices(edge);

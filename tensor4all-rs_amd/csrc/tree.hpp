@@ -83,7 +83,11 @@ public:
     void set_callback(t4a_gpu_batch_eval_fn cb, void* ctx);
 
     void add_global_pivots(const std::vector<std::vector<uint32_t>>& pivots);
-    void candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) const; // DefaultProposer
+    // PivotCandidateProposer::candidates of the selected proposer (proposer.rs:57-249)
+    void candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) const;
+    void default_candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) const; // DefaultProposer :57-88
+    int proposer = 0;           // 0 DefaultProposer, 1 SimpleProposer, 2 TruncatedDefaultProposer
+    uint64_t proposer_seed = 0; // ::seeded(seed); rand SmallRng / DefaultHasher streams of the reference are "parity unpinned"
     EdgeSelection update_edge(const TreeEdge& edge, const RrLUOptions& options);
     void optimize(const TreeTciOptions& options);
     void crossinterpolate2(std::vector<std::vector<uint32_t>> pivots, const TreeTciOptions& options);

@@ -943,6 +943,10 @@ class TreeTCI2:
     def edges(self):
         return list(self._edges)
 
+    def set_proposer(self, kind, seed=0):
+        """0 DefaultProposer, 1 SimpleProposer::seeded(seed), 2 TruncatedDefaultProposer::seeded(seed)"""
+        _check(_lib.t4a_gpu_treetci_set_proposer(self._h, c_int32(kind), ctypes.c_uint64(seed)))
+
     def add_global_pivots(self, pivots):
         piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uintp).reshape(len(pivots), self.n))
         _check(_lib.t4a_gpu_treetci_add_global_pivots(self._h, _p(piv), c_size_t(len(pivots))))

@@ -577,6 +577,7 @@ for _n in ("oracle_tree_release", "oracle_tree_max_sample_value", "oracle_tree_m
            "oracle_tree_flush_pivot_errors"):
     getattr(_lib, _n).argtypes = [vp]
 _lib.oracle_tree_set_max_sample_value.argtypes = [vp, dbl]
+_lib.oracle_tree_set_proposer.argtypes = [vp, cint, u64]
 
 
 class TreeOptions:
@@ -669,6 +670,10 @@ class OracleTreeTCI2:
         r = np.zeros((nr, len(rk)), dtype=np.uint64)
         _check(_lib.oracle_tree_candidates(vp(self._h), u64(u), u64(v), ctypes.byref(u64(0)), _p(l), ctypes.byref(u64(0)), _p(r)))
         return l.astype(np.int64), r.astype(np.int64)
+
+    def set_proposer(self, kind, seed=0):
+        """0 DefaultProposer, 1 SimpleProposer::seeded(seed), 2 TruncatedDefaultProposer::seeded(seed)"""
+        _lib.oracle_tree_set_proposer(vp(self._h), cint(kind), u64(seed))
 
     def push_history(self, key, cols):
         k = np.ascontiguousarray(np.asarray(sorted(key), dtype=np.uint64))

@@ -290,3 +290,48 @@ def test_star_graph_with_many_incoming_bonds(t4a):
         assert g.site_tensor(0).ndim == (6 if center == 0 else 6)
         assert np.abs(g.evaluate(pts) - o.evaluate(pts)).max() <= 1e-10
         assert np.abs(g.evaluate(pts) - exact).max() < 1e-8
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_random_proposers_match_oracle(t4a, kind):
+    # SimpleProposer / TruncatedDefaultProposer on the same splitmix64 stream as the oracle (proposer/tests.rs:117-166)
+    g = t4a.TreeTCI2([2] * 7, SAMPLE_EDGES)
+    o = OracleTreeTCI2([2] * 7, SAMPLE_EDGES)
+    for t in (g, o):
+        t.add_global_pivots([[0] * 7, [1, 0, 1, 0, 1, 0, 1]])
+        t.set_proposer(kind, 7)
+    for (u, v) in SAMPLE_EDGES:
+        gi, gj = g.candidates(u, v)
+        oi, oj = o.candidates(u, v)
+        assert gi.tolist() == oi.tolist() and gj.tolist() == oj.tolist()
+    dims = [3, 2, 3, 2, 2, 3, 2]
+    g, o = _pair(t4a, dims, SAMPLE_EDGES, _branched_fn)
+    for t in (g, o):
+        t.set_proposer(kind, 5)
+    opt = TreeOptions(tolerance=1e-10, max_iter=12, seed=3)
+    og = o.crossinterpolate2([[0] * 7], opt)
+    gg = g.crossinterpolate2([[0] * 7], gopts(t4a, opt))
+    assert gg[0] == og[0] and np.allclose(gg[1], og[1], rtol=0, atol=1e-12)
+    assert_same_state(g, o, SAMPLE_EDGES)
+    with pytest.raises(t4a.T4aError):
+        g.set_proposer(3)
+
+
+def test_truncated_proposer_keeps_hub_matrices_small(t4a):
+    # star with 4 arms of 3 binary sites: the hub's default candidate count is d * chi^3, the truncated one d * chi
+    edges, n = [], 13
+    for arm in range(4):
+        first = 1 + 3 * arm
+        edges += [(0, first), (first, first + 1), (first + 1, first + 2)]
+    f = lambda idx: float(np.cos(0.4 * sum((k % 5 + 1) * v for k, v in enumerate(idx))) + 0.05 * idx[1] * idx[12])
+    g = t4a.TreeTCI2([2] * n, edges)
+    g.set_function(f)
+    g.set_proposer(2, 1)
+    ranks, errors = g.crossinterpolate2([[0] * n], t4a.TreeTciOptions(tolerance=1e-8, max_iter=10, seed=2))
+    li, ri = g.candidates(0, 1)
+    chi = len(g.pivots(g.subregion_vertices(0, 1)[0]))
+    assert len(li) <= 2 * chi
+    g.materialize(0)
+    rng = np.random.default_rng(3)
+    pts = rng.integers(0, 2, size=(300, n))
+    assert np.abs(g.evaluate(pts) - np.array([f(p) for p in pts])).max() < 1e-5

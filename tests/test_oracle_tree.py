@@ -210,3 +210,33 @@ def test_crossinterpolate2_rejects_zero_initial_pivots():
     t = OracleTreeTCI2([2, 2], [(0, 1)], lambda idx: 0.0)
     with pytest.raises(ob.OracleError):
         t.crossinterpolate2([[0, 0]], TreeOptions())
+
+
+def test_simple_and_truncated_proposers():
+    # proposer/tests.rs:117-166: deterministic for a fixed seed, d * chi candidates per side, ordered subset of the default
+    t = OracleTreeTCI2([2] * 7, SAMPLE_EDGES)
+    t.add_global_pivots([[0] * 7, [1, 0, 1, 0, 1, 0, 1]])
+    default_i, default_j = t.candidates(1, 3)
+    t.set_proposer(1, 7)
+    first, second = t.candidates(1, 3), t.candidates(1, 3)
+    assert first[0].tolist() == second[0].tolist() and first[1].tolist() == second[1].tolist()
+    assert len(first[0]) > 0 and first[0].shape[1] == 3 and first[1].shape[1] == 4
+    t.set_proposer(2, 7)
+    ti, tj = t.candidates(1, 3)
+    assert t.candidates(1, 3)[0].tolist() == ti.tolist()
+    assert len(ti) == 4 and len(tj) == 4 and tj.tolist() == default_j.tolist()
+    pos = [default_i.tolist().index(c) for c in ti.tolist()]
+    assert pos == sorted(pos) and len(set(pos)) == 4
+    t.set_proposer(2, 8)
+    assert t.candidates(1, 3)[1].tolist() == default_j.tolist()
+
+
+def test_truncated_proposer_interpolates_branched_tree():
+    dims = [3, 2, 3, 2, 2, 3, 2]
+    t = OracleTreeTCI2(dims, SAMPLE_EDGES, _branched_fn)
+    t.set_proposer(2, 5)
+    ranks, errors = t.crossinterpolate2([[0] * 7], TreeOptions(tolerance=1e-10, max_iter=12, seed=3))
+    assert errors[-1] < 1e-8
+    t.materialize(0)
+    pts = np.array(list(itertools.product(*[range(d) for d in dims])))
+    assert np.max(np.abs(t.evaluate(pts) - np.array([_branched_fn(p) for p in pts]))) < 1e-6
