@@ -1,6 +1,7 @@
 // oracle/oracle_capi_tt.cpp — TEST INFRASTRUCTURE ONLY (see t4a_oracle_tt.hpp header).
 // C entry points for the tensor-train side of the CPU restatement (SURVEY.md §8 rows a14–a18).
 #include "t4a_oracle_tt.hpp"
+#include "t4a_oracle_tensor.hpp"
 
 #include <cstring>
 #include <memory>
@@ -233,6 +234,72 @@ int oracle_conv_scalars(void* h, double* max_sample_value, uint64_t* n_pivot_err
         *n_pivot_errors = t.pivot_errors.size();
         if (pivot_errors)
             for (size_t k = 0; k < t.pivot_errors.size(); ++k) pivot_errors[k] = t.pivot_errors[k];
+    });
+}
+
+// ---- dense labelled tensors (t4a_oracle_tensor.hpp) ----
+static DenseTensor make_tensor(const double* d, const uint64_t* dims, const int64_t* labels, uint64_t rank)
+{
+    DenseTensor t;
+    t.dims.assign(dims, dims + rank);
+    t.labels.assign(labels, labels + rank);
+    t.data.assign(d, d + t.size());
+    return t;
+}
+int oracle_tensor_contract(const double* a, const uint64_t* adims, const int64_t* alabels, uint64_t ra, const double* b,
+                           const uint64_t* bdims, const int64_t* blabels, uint64_t rb, double* out, uint64_t* out_dims,
+                           int64_t* out_labels, uint64_t* out_rank)
+{
+    return guarded([&] {
+        DenseTensor o = tensor_contract_pair(make_tensor(a, adims, alabels, ra), make_tensor(b, bdims, blabels, rb));
+        *out_rank = o.dims.size();
+        for (size_t k = 0; k < o.dims.size(); ++k) {
+            out_dims[k] = o.dims[k];
+            out_labels[k] = o.labels[k];
+        }
+        if (out) std::copy(o.data.begin(), o.data.end(), out);
+    });
+}
+uint64_t oracle_svd_retained_rank(const double* s, uint64_t n, double threshold, int scale, int measure, int rule)
+{
+    SvdPolicy p;
+    p.threshold = threshold;
+    p.scale = scale;
+    p.measure = measure;
+    p.rule = rule;
+    return svd_retained_rank(std::vector<double>(s, s + n), p);
+}
+uint64_t oracle_qr_retained_rank(const double* r, uint64_t k, uint64_t n, double rtol)
+{
+    return qr_retained_rank(std::vector<double>(r, r + k * n), k, n, rtol);
+}
+// u: m x min(m,n) capacity, s: min(m,n), v: n x min(m,n) capacity
+int oracle_tensor_svd(const double* t, const uint64_t* dims, const int64_t* labels, uint64_t rank, const int64_t* left,
+                      uint64_t n_left, int truncate, double threshold, int scale, int measure, int rule, uint64_t max_bond_dim,
+                      uint64_t* r_out, double* u, double* s, double* v)
+{
+    return guarded([&] {
+        SvdPolicy p;
+        p.threshold = threshold;
+        p.scale = scale;
+        p.measure = measure;
+        p.rule = rule;
+        TensorSvdResult o = tensor_svd(make_tensor(t, dims, labels, rank), std::vector<int64_t>(left, left + n_left), truncate != 0, p,
+                                       max_bond_dim == (uint64_t)-1 ? 0 : max_bond_dim, max_bond_dim != (uint64_t)-1);
+        *r_out = o.rank;
+        std::copy(o.u.begin(), o.u.end(), u);
+        std::copy(o.s.begin(), o.s.end(), s);
+        std::copy(o.v.begin(), o.v.end(), v);
+    });
+}
+int oracle_tensor_qr(const double* t, const uint64_t* dims, const int64_t* labels, uint64_t rank, const int64_t* left,
+                     uint64_t n_left, int truncate, double rtol, uint64_t* r_out, double* q, double* r)
+{
+    return guarded([&] {
+        TensorQrResult o = tensor_qr(make_tensor(t, dims, labels, rank), std::vector<int64_t>(left, left + n_left), truncate != 0, rtol);
+        *r_out = o.rank;
+        std::copy(o.q.begin(), o.q.end(), q);
+        std::copy(o.r.begin(), o.r.end(), r);
     });
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp", "t4a_oracle_patch.hpp",
-                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp", "t4a_oracle_quantics.hpp")] + [
+                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp", "t4a_oracle_quantics.hpp", "t4a_oracle_tensor.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -1005,3 +1005,80 @@ def quanticscrossinterpolate_batched(rs, f, output_dims, lower=None, upper=None,
     h = _lib.oracle_qtci_batched(_p(rs_a), u64(nv), _p(lo), _p(up), cint(int(include_endpoint)), cint(grid_unfolding), cb, None,
                                  _p(od) if len(od) else None, u64(len(od)), *pa, *options.args())
     return OracleQuanticsBatched(h, (cb, keep))
+
+
+# ------------------------------------------------------------------------------------------------ dense labelled tensors
+i64 = ctypes.c_int64
+_lib.oracle_svd_retained_rank.restype = u64
+_lib.oracle_qr_retained_rank.restype = u64
+NO_MAX = (1 << 64) - 1
+
+
+def _tensor_args(t, labels):
+    a = np.asfortranarray(np.array(t, dtype=np.float64))
+    dims = np.asarray(a.shape, dtype=np.uint64)
+    lab = np.asarray(labels, dtype=np.int64)
+    assert len(lab) == a.ndim
+    return a, dims, lab
+
+
+def tensor_contract(a, a_labels, b, b_labels):
+    """contract_pair: returns (array, labels)"""
+    a, ad, al = _tensor_args(a, a_labels)
+    b, bd, bl = _tensor_args(b, b_labels)
+    cap = a.ndim + b.ndim
+    od, ol, orank = np.zeros(max(cap, 1), dtype=np.uint64), np.zeros(max(cap, 1), dtype=np.int64), u64(0)
+    _check_tt(_lib.oracle_tensor_contract(_p(a), _p(ad), _p(al), u64(a.ndim), _p(b), _p(bd), _p(bl), u64(b.ndim), None, _p(od),
+                                          _p(ol), ctypes.byref(orank)))
+    shape = [int(x) for x in od[:orank.value]]
+    out = np.zeros(int(np.prod(shape)) if shape else 1)
+    _check_tt(_lib.oracle_tensor_contract(_p(a), _p(ad), _p(al), u64(a.ndim), _p(b), _p(bd), _p(bl), u64(b.ndim), _p(out), _p(od),
+                                          _p(ol), ctypes.byref(orank)))
+    return out.reshape(shape, order="F"), [int(x) for x in ol[:orank.value]]
+
+
+def svd_retained_rank(s, threshold=1e-12, scale=0, measure=0, rule=0):
+    s = np.asarray(s, dtype=np.float64)
+    return int(_lib.oracle_svd_retained_rank(_p(s) if len(s) else None, u64(len(s)), dbl(threshold), cint(scale), cint(measure), cint(rule)))
+
+
+def qr_retained_rank(r, k, n, rtol):
+    r = np.asarray(r, dtype=np.float64)
+    return int(_lib.oracle_qr_retained_rank(_p(r) if len(r) else None, u64(k), u64(n), dbl(rtol)))
+
+
+def _split_shapes(shape, labels, left):
+    ld = [shape[labels.index(x)] for x in left]
+    rd = [d for d, x in zip(shape, labels) if x not in left]
+    return ld, rd
+
+
+def tensor_svd(t, labels, left, truncate=True, threshold=1e-12, scale=0, measure=0, rule=0, max_bond_dim=None):
+    """svd_with: returns (U [left.., r], S (r), V [right.., r])"""
+    a, dims, lab = _tensor_args(t, labels)
+    lf = np.asarray(left, dtype=np.int64)
+    ld, rd = _split_shapes(list(a.shape), list(labels), list(left)) if all(x in labels for x in left) else ([1], [1])
+    m, n = int(np.prod(ld)), int(np.prod(rd))
+    k = max(min(m, n), 1)
+    u, s, v = np.zeros(m * k), np.zeros(k), np.zeros(n * k)
+    r = u64(0)
+    _check_tt(_lib.oracle_tensor_svd(_p(a), _p(dims), _p(lab), u64(a.ndim), _p(lf), u64(len(lf)), cint(int(truncate)),
+                                     dbl(threshold), cint(scale), cint(measure), cint(rule),
+                                     u64(NO_MAX if max_bond_dim is None else max_bond_dim), ctypes.byref(r), _p(u), _p(s), _p(v)))
+    rr = r.value
+    return (u[:m * rr].reshape(ld + [rr], order="F"), s[:rr].copy(), v[:n * rr].reshape(rd + [rr], order="F"))
+
+
+def tensor_qr(t, labels, left, truncate=True, rtol=1e-15):
+    """qr_with: returns (Q [left.., r], R [r, right..])"""
+    a, dims, lab = _tensor_args(t, labels)
+    lf = np.asarray(left, dtype=np.int64)
+    ld, rd = _split_shapes(list(a.shape), list(labels), list(left)) if all(x in labels for x in left) else ([1], [1])
+    m, n = int(np.prod(ld)), int(np.prod(rd))
+    k = max(min(m, n), 1)
+    q, rr_ = np.zeros(m * k), np.zeros(k * n)
+    r = u64(0)
+    _check_tt(_lib.oracle_tensor_qr(_p(a), _p(dims), _p(lab), u64(a.ndim), _p(lf), u64(len(lf)), cint(int(truncate)), dbl(rtol),
+                                    ctypes.byref(r), _p(q), _p(rr_)))
+    rr = r.value
+    return q[:m * rr].reshape(ld + [rr], order="F"), rr_[:rr * n].reshape([rr] + rd, order="F")
