@@ -495,6 +495,41 @@ t4a_gpu_status t4a_gpu_quanticscrossinterpolate_batched(const size_t* rs, size_t
                                                         t4a_gpu_tt** out_tt, size_t* n_iter, size_t* ranks, double* errors,
                                                         size_t* user_points);
 
+/* =====================================================================================
+ * Dense labelled tensors: the einsum / linalg seam of tensor4all-core's dynamic-index layer
+ * crates/tensor4all-core/src/defaults/{contract.rs:334-343, svd.rs:150-395, qr.rs:74-328, idx_tensor.rs:5278-5345},
+ * index_ops.rs:660-696.  Tensors are column-major with one int64 label per axis (the caller's DynIndex ids); rank <= 16.
+ * ===================================================================================== */
+/* SvdTruncationPolicy (truncation.rs:137-147).  NULL = the default policy: relative, per value, 1e-12 (svd.rs:80-87). */
+typedef struct t4a_gpu_svd_policy {
+    double threshold;
+    int32_t scale;    /* 0 Relative, 1 Absolute */
+    int32_t measure;  /* 0 Value, 1 SquaredValue */
+    int32_t rule;     /* 0 PerValue, 1 DiscardedTailSum */
+} t4a_gpu_svd_policy;
+/* compute_retained_rank (svd.rs:150-211) and compute_retained_rank_qr_from_dense (qr.rs:74-117; r is k x n column-major):
+ * pure host functions, usable without a device. */
+t4a_gpu_status t4a_gpu_svd_retained_rank(const double* s, size_t n, const t4a_gpu_svd_policy* policy, size_t* out);
+t4a_gpu_status t4a_gpu_qr_retained_rank(const double* r, size_t k, size_t n, double rtol, size_t* out);
+/* contract_pair(lhs, rhs): every common label is contracted; the result carries lhs's free axes then rhs's free axes, each in
+ * operand order (no common label = outer product).  out may be NULL to query out_rank / out_dims / out_labels. */
+t4a_gpu_status t4a_gpu_tensor_contract_f64(const double* a, const size_t* a_dims, const int64_t* a_labels, size_t a_rank,
+                                           const double* b, const size_t* b_dims, const int64_t* b_labels, size_t b_rank,
+                                           double* out, size_t* out_dims, int64_t* out_labels, size_t* out_rank);
+/* svd_with(t, left_inds, options): unfold with the left labels first (in the given order) and the remaining axes in tensor
+ * order, thin SVD, rank r = min(retained rank, max_bond_dim) >= 1 (truncate == 0: r = min(m, n)).
+ * u: [left dims.., r], s: r values, v: [right dims.., r] (= V, not V^H).  Capacities: m*min(m,n), min(m,n), n*min(m,n).
+ * has_max_bond_dim != 0 with max_bond_dim == 0 is an error (svd.rs:281-292). */
+t4a_gpu_status t4a_gpu_tensor_svd_f64(const double* t, const size_t* dims, const int64_t* labels, size_t rank,
+                                      const int64_t* left_labels, size_t n_left, int32_t truncate,
+                                      const t4a_gpu_svd_policy* policy, int32_t has_max_bond_dim, size_t max_bond_dim,
+                                      size_t* r, double* u, double* s, double* v);
+/* qr_with(t, left_inds, options): q: [left dims.., r], r_factor: [r, right dims..]; truncate != 0 keeps the leading r rows
+ * with r = number of rows of R whose norm is >= rtol * (largest row norm) (has_rtol == 0: default 1e-15). */
+t4a_gpu_status t4a_gpu_tensor_qr_f64(const double* t, const size_t* dims, const int64_t* labels, size_t rank,
+                                     const int64_t* left_labels, size_t n_left, int32_t truncate, int32_t has_rtol, double rtol,
+                                     size_t* r, double* q, double* r_factor);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);

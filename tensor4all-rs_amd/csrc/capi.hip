@@ -8,6 +8,7 @@
 #include "tci2.hpp"
 #include "tree.hpp"
 #include "quantics.hpp"
+#include "tensorops.hpp"
 
 struct t4a_gpu_tci2 {
     t4a::Tci2 impl;
@@ -2033,6 +2034,184 @@ t4a_gpu_status t4a_gpu_quanticscrossinterpolate_batched(const size_t* rs, size_t
         }
         if (user_points) *user_points = r.n_user_points;
         *out_tt = new t4a_gpu_tt(r.tt->cores, r.tt->eng.stream());
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ dense labelled tensors
+extern "C++" {
+static SvdPolicy convert_policy(const t4a_gpu_svd_policy* p)
+{
+    SvdPolicy r;
+    if (!p) return r;
+    r.threshold = p->threshold;
+    r.scale = p->scale;
+    r.measure = p->measure;
+    r.rule = p->rule;
+    if (r.scale < 0 || r.scale > 1 || r.measure < 0 || r.measure > 1 || r.rule < 0 || r.rule > 1)
+        throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown SVD truncation policy field");
+    return r;
+}
+static TensorView host_view(const size_t* dims, const int64_t* labels, size_t rank)
+{
+    TensorView v;
+    v.d_data = nullptr;
+    if (rank) {
+        T4A_REQUIRE_PTR(dims);
+        T4A_REQUIRE_PTR(labels);
+    }
+    v.dims.assign(dims, dims + rank);
+    v.labels.assign(labels, labels + rank);
+    size_t n = 1;
+    for (size_t d : v.dims) n = checked_mul(n, d, "tensor shape");
+    return v;
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_svd_retained_rank(const double* s, size_t n, const t4a_gpu_svd_policy* policy, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        if (n) T4A_REQUIRE_PTR(s);
+        *out = svd_retained_rank(s, n, convert_policy(policy));
+    });
+}
+
+t4a_gpu_status t4a_gpu_qr_retained_rank(const double* r, size_t k, size_t n, double rtol, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        if (checked_mul(k, n, "R shape")) T4A_REQUIRE_PTR(r);
+        *out = qr_retained_rank(r, k, n, rtol);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_contract_f64(const double* a, const size_t* a_dims, const int64_t* a_labels, size_t a_rank,
+                                           const double* b, const size_t* b_dims, const int64_t* b_labels, size_t b_rank,
+                                           double* out, size_t* out_dims, int64_t* out_labels, size_t* out_rank)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out_rank);
+        TensorView va = host_view(a_dims, a_labels, a_rank), vb = host_view(b_dims, b_labels, b_rank);
+        const ContractPlan plan = plan_contract_pair(va, vb); // index errors before the device is touched
+        *out_rank = plan.out_dims.size();
+        for (size_t k = 0; k < plan.out_dims.size(); ++k) {
+            if (out_dims) out_dims[k] = plan.out_dims[k];
+            if (out_labels) out_labels[k] = plan.out_labels[k];
+        }
+        if (!out) return;
+        const size_t na = va.size(), nb = vb.size(), nc = checked_mul(plan.M, plan.N, "result shape");
+        if (nc == 0) return;
+        if (na) T4A_REQUIRE_PTR(a);
+        if (nb) T4A_REQUIRE_PTR(b);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_in = e.pi(na + nb + nc);
+        upload(e, d_in, a, na);
+        upload(e, d_in + na, b, nb);
+        va.d_data = d_in;
+        vb.d_data = d_in + na;
+        tensor_contract_pair(e, va, vb, plan, d_in + na + nb);
+        download(e, out, d_in + na + nb, nc);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_svd_f64(const double* t, const size_t* dims, const int64_t* labels, size_t rank,
+                                      const int64_t* left_labels, size_t n_left, int32_t truncate,
+                                      const t4a_gpu_svd_policy* policy, int32_t has_max_bond_dim, size_t max_bond_dim,
+                                      size_t* r, double* u, double* s, double* v)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(r);
+        TensorView tv = host_view(dims, labels, rank);
+        if (n_left) T4A_REQUIRE_PTR(left_labels);
+        const UnfoldPlan un = plan_unfold_split(tv, std::vector<int64_t>(left_labels, left_labels + n_left));
+        SvdPolicy pol = convert_policy(policy);
+        if (truncate) { // validated before any linear algebra (svd/tests/mod.rs:120-160)
+            if (has_max_bond_dim && max_bond_dim == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "max_bond_dim must be positive when specified");
+            if (!std::isfinite(pol.threshold) || pol.threshold < 0.0)
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "Invalid SVD truncation threshold: threshold must be finite and non-negative");
+        }
+        const size_t m = un.m, n = un.n, k = std::min(m, n), count = tv.size();
+        if (count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD of an empty tensor");
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "svd: unfolded dimensions above 65535 are not supported");
+        T4A_REQUIRE_PTR(t);
+        T4A_REQUIRE_PTR(u);
+        T4A_REQUIRE_PTR(s);
+        T4A_REQUIRE_PTR(v);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_t = e.pi(2 * count);
+        upload(e, d_t, t, count);
+        tv.d_data = d_t;
+        double* d_mat = d_t + count;
+        tensor_permute(e, tv, un.perm, d_mat);
+        e.d_tmp.reserve(m * k + k + k * n + n * k);
+        double* d_u = e.d_tmp.get();
+        double* d_s = d_u + m * k;
+        double* d_vt = d_s + k;
+        double* d_v = d_vt + k * n;
+        e.svd(d_mat, (int)m, (int)n, d_u, d_s, d_vt);
+        std::vector<double> hs(k);
+        download(e, hs.data(), d_s, k);
+        size_t keep = k;
+        if (truncate) {
+            keep = svd_retained_rank(hs.data(), k, pol);
+            if (has_max_bond_dim) keep = std::min(keep, max_bond_dim);
+            keep = std::max<size_t>(keep, 1);
+        } else {
+            keep = std::max<size_t>(k, 1);
+        }
+        keep = std::min(keep, k);
+        *r = keep;
+        std::copy(hs.begin(), hs.begin() + keep, s);
+        download(e, u, d_u, m * keep);
+        // V [n x keep] = (first `keep` rows of V^T)^T
+        transpose_launch(d_vt, (int)keep, (int)n, (int)k, d_v, (int)n, e.stream());
+        T4A_HIP(hipGetLastError());
+        download(e, v, d_v, n * keep);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_qr_f64(const double* t, const size_t* dims, const int64_t* labels, size_t rank,
+                                     const int64_t* left_labels, size_t n_left, int32_t truncate, int32_t has_rtol, double rtol,
+                                     size_t* r, double* q, double* r_factor)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(r);
+        TensorView tv = host_view(dims, labels, rank);
+        if (n_left) T4A_REQUIRE_PTR(left_labels);
+        const UnfoldPlan un = plan_unfold_split(tv, std::vector<int64_t>(left_labels, left_labels + n_left));
+        const double tol = has_rtol ? rtol : 1e-15; // default_qr_rtol (qr.rs:62-66)
+        if (truncate && (!std::isfinite(tol) || tol < 0.0))
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "Invalid rtol value: rtol must be finite and non-negative");
+        const size_t m = un.m, n = un.n, k = std::min(m, n), count = tv.size();
+        if (count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "QR of an empty tensor");
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "qr: unfolded dimensions above 65535 are not supported");
+        T4A_REQUIRE_PTR(t);
+        T4A_REQUIRE_PTR(q);
+        T4A_REQUIRE_PTR(r_factor);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_t = e.pi(2 * count);
+        upload(e, d_t, t, count);
+        tv.d_data = d_t;
+        double* d_mat = d_t + count;
+        tensor_permute(e, tv, un.perm, d_mat);
+        e.d_tmp.reserve(m * k + 2 * k * n);
+        double* d_q = e.d_tmp.get();
+        double* d_r = d_q + m * k;
+        double* d_rk = d_r + k * n;
+        e.qr(d_mat, (int)m, (int)n, d_q, d_r);
+        std::vector<double> hr(k * n);
+        download(e, hr.data(), d_r, k * n);
+        size_t keep = k;
+        if (truncate) keep = std::min(qr_retained_rank(hr.data(), k, n, tol), k);
+        *r = keep;
+        download(e, q, d_q, m * keep);
+        // leading `keep` rows of R with leading dimension keep
+        gather_launch(d_r, (int)k, nullptr, (int)keep, nullptr, (int)n, d_rk, (int)keep, e.stream());
+        T4A_HIP(hipGetLastError());
+        download(e, r_factor, d_rk, keep * n);
     });
 }
 

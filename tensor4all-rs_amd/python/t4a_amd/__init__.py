@@ -1332,3 +1332,104 @@ def quanticscrossinterpolate_batched(rs, f, output_dims, lower=None, upper=None,
         ctypes.byref(n_iter), _p(ranks), _p(errors), ctypes.byref(upts)))
     k = n_iter.value
     return SimpleTensorTrain._adopt(h), [int(x) for x in ranks[:k]], [float(x) for x in errors[:k]], upts.value
+
+
+# ---------------------------------------------------------------------------------------- dense labelled tensors (tensor4all-core defaults)
+class SvdPolicyC(ctypes.Structure):
+    _fields_ = [("threshold", c_double), ("scale", c_int32), ("measure", c_int32), ("rule", c_int32)]
+
+
+RELATIVE, ABSOLUTE = 0, 1
+VALUE, SQUARED_VALUE = 0, 1
+PER_VALUE, DISCARDED_TAIL_SUM = 0, 1
+
+
+class SvdTruncationPolicy:
+    """SvdTruncationPolicy (core/src/truncation.rs:137): threshold x scale x measure x rule."""
+
+    def __init__(self, threshold=1e-12, scale=RELATIVE, measure=VALUE, rule=PER_VALUE):
+        self.threshold, self.scale, self.measure, self.rule = threshold, scale, measure, rule
+
+    def to_c(self):
+        return SvdPolicyC(self.threshold, self.scale, self.measure, self.rule)
+
+
+def svd_retained_rank(s, policy=None):
+    """compute_retained_rank (defaults/svd.rs:150): host-side rule, no device needed."""
+    s = np.ascontiguousarray(np.asarray(s, dtype=np.float64))
+    out = c_size_t(0)
+    pc = None if policy is None else policy.to_c()
+    _check(_lib.t4a_gpu_svd_retained_rank(_p(s) if len(s) else None, c_size_t(len(s)), None if pc is None else ctypes.byref(pc),
+                                          ctypes.byref(out)))
+    return out.value
+
+
+def qr_retained_rank(r, k, n, rtol):
+    """compute_retained_rank_qr_from_dense (defaults/qr.rs:74): r is k x n column-major."""
+    r = np.ascontiguousarray(np.asarray(r, dtype=np.float64))
+    out = c_size_t(0)
+    _check(_lib.t4a_gpu_qr_retained_rank(_p(r) if len(r) else None, c_size_t(k), c_size_t(n), c_double(rtol), ctypes.byref(out)))
+    return out.value
+
+
+def _labelled(t, labels):
+    a = np.asfortranarray(np.array(t, dtype=np.float64))
+    lab = np.asarray(labels, dtype=np.int64)
+    if len(lab) != a.ndim:
+        raise T4aError(INVALID_ARGUMENT, "one label per tensor axis is required")
+    return a, np.asarray(a.shape, dtype=np.uintp), lab
+
+
+def contract_pair(a, a_labels, b, b_labels):
+    """contract_pair (defaults/contract.rs:334): returns (array, labels) with lhs free axes then rhs free axes."""
+    a, ad, al = _labelled(a, a_labels)
+    b, bd, bl = _labelled(b, b_labels)
+    cap = max(a.ndim + b.ndim, 1)
+    od, ol, orank = np.zeros(cap, dtype=np.uintp), np.zeros(cap, dtype=np.int64), c_size_t(0)
+    args = [_p(a), _p(ad), _p(al), c_size_t(a.ndim), _p(b), _p(bd), _p(bl), c_size_t(b.ndim)]
+    _check(_lib.t4a_gpu_tensor_contract_f64(*args, None, _p(od), _p(ol), ctypes.byref(orank)))
+    shape = [int(x) for x in od[:orank.value]]
+    out = np.zeros(int(np.prod(shape)) if shape else 1)
+    _check(_lib.t4a_gpu_tensor_contract_f64(*args, _p(out), _p(od), _p(ol), ctypes.byref(orank)))
+    return out.reshape(shape, order="F"), [int(x) for x in ol[:orank.value]]
+
+
+def _split(shape, labels, left):
+    labels = list(labels)
+    if not all(x in labels for x in left):
+        return [1], [1]
+    return [shape[labels.index(x)] for x in left], [d for d, x in zip(shape, labels) if x not in left]
+
+
+def tensor_svd(t, labels, left, truncate=True, policy=None, max_bond_dim=None):
+    """svd_with (defaults/svd.rs:347): returns (U [left.., r], S (r), V [right.., r])."""
+    a, dims, lab = _labelled(t, labels)
+    lf = np.asarray(left, dtype=np.int64)
+    ld, rd = _split(list(a.shape), labels, list(left))
+    m, n = int(np.prod(ld)), int(np.prod(rd))
+    k = max(min(m, n), 1)
+    u, s, v = np.zeros(m * k), np.zeros(k), np.zeros(n * k)
+    r = c_size_t(0)
+    pc = None if policy is None else policy.to_c()
+    _check(_lib.t4a_gpu_tensor_svd_f64(_p(a), _p(dims), _p(lab), c_size_t(a.ndim), _p(lf) if len(lf) else None, c_size_t(len(lf)),
+                                       c_int32(int(truncate)), None if pc is None else ctypes.byref(pc),
+                                       c_int32(0 if max_bond_dim is None else 1), c_size_t(0 if max_bond_dim is None else max_bond_dim),
+                                       ctypes.byref(r), _p(u), _p(s), _p(v)))
+    rr = r.value
+    return u[:m * rr].reshape(ld + [rr], order="F"), s[:rr].copy(), v[:n * rr].reshape(rd + [rr], order="F")
+
+
+def tensor_qr(t, labels, left, truncate=True, rtol=None):
+    """qr_with (defaults/qr.rs:206): returns (Q [left.., r], R [r, right..])."""
+    a, dims, lab = _labelled(t, labels)
+    lf = np.asarray(left, dtype=np.int64)
+    ld, rd = _split(list(a.shape), labels, list(left))
+    m, n = int(np.prod(ld)), int(np.prod(rd))
+    k = max(min(m, n), 1)
+    q, rf = np.zeros(m * k), np.zeros(k * n)
+    r = c_size_t(0)
+    _check(_lib.t4a_gpu_tensor_qr_f64(_p(a), _p(dims), _p(lab), c_size_t(a.ndim), _p(lf) if len(lf) else None, c_size_t(len(lf)),
+                                      c_int32(int(truncate)), c_int32(0 if rtol is None else 1), c_double(0.0 if rtol is None else rtol),
+                                      ctypes.byref(r), _p(q), _p(rf)))
+    rr = r.value
+    return q[:m * rr].reshape(ld + [rr], order="F"), rf[:rr * n].reshape([rr] + rd, order="F")

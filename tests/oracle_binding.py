@@ -1038,12 +1038,12 @@ def tensor_contract(a, a_labels, b, b_labels):
 
 
 def svd_retained_rank(s, threshold=1e-12, scale=0, measure=0, rule=0):
-    s = np.asarray(s, dtype=np.float64)
+    s = np.ascontiguousarray(np.asarray(s, dtype=np.float64))
     return int(_lib.oracle_svd_retained_rank(_p(s) if len(s) else None, u64(len(s)), dbl(threshold), cint(scale), cint(measure), cint(rule)))
 
 
 def qr_retained_rank(r, k, n, rtol):
-    r = np.asarray(r, dtype=np.float64)
+    r = np.ascontiguousarray(np.asarray(r, dtype=np.float64))
     return int(_lib.oracle_qr_retained_rank(_p(r) if len(r) else None, u64(k), u64(n), dbl(rtol)))
 
 

@@ -1,0 +1,77 @@
+"""GPU tests of the dense labelled-tensor seam through the C ABI: contract_pair, svd_with, qr_with against
+the CPU oracle, numpy and the reference's fixtures (crates/tensor4all-core/src/defaults/{svd,qr}/tests/mod.rs)."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def t4a():
+    import t4a_amd
+    if t4a_amd.device_count() < 1:
+        pytest.fail("no MI355X visible: the product path has no CPU fallback")
+    return t4a_amd
+
+
+def test_reference_fixtures(t4a):
+    # qr/tests/mod.rs:42-60, 102-119; svd/tests/mod.rs:100-118
+    t = np.array([1.0, 2.0, 3.0, 4.0]).reshape((1, 2, 2), order="F")
+    q, r = t4a.tensor_qr(t, [1, 2, 3], [2, 3], truncate=False)
+    assert q.shape == (2, 2, 1) and r.shape == (1, 1)
+    assert np.allclose((q.reshape(4, 1, order="F") @ r.reshape(1, 1, order="F")).ravel(), [1, 2, 3, 4])
+    u, s, v = t4a.tensor_svd(np.array([[3.0, 0.0], [0.0, 1.0]]), [10, 11], [10], max_bond_dim=1)
+    assert u.shape == (2, 1) and s.shape == (1,) and v.shape == (2, 1) and s[0] == pytest.approx(3.0)
+    q, r = t4a.tensor_qr(np.array([[1.0, 0.0], [0.0, 1e-14]]), [10, 11], [10], rtol=1e-10)
+    assert q.shape == (2, 1) and r.shape == (1, 2)
+
+
+def test_contract_pair_matches_einsum_and_oracle(t4a):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((3, 4, 5))
+    b = rng.standard_normal((5, 2, 3))
+    c, labels = t4a.contract_pair(a, [1, 2, 3], b, [3, 4, 1])
+    oc, ol = ob.tensor_contract(a, [1, 2, 3], b, [3, 4, 1])
+    assert labels == ol == [2, 4] and np.abs(c - np.einsum("iaj,jbi->ab", a, b)).max() < 1e-12
+    assert np.abs(c - oc).max() < 1e-12
+    c, labels = t4a.contract_pair(a, [1, 2, 3], b, [6, 7, 8])
+    assert labels == [1, 2, 3, 6, 7, 8] and np.abs(c - np.einsum("abc,def->abcdef", a, b)).max() < 1e-12
+    c, labels = t4a.contract_pair(a, [1, 2, 3], a, [1, 2, 3])
+    assert labels == [] and abs(float(c) - np.sum(a * a)) < 1e-10
+    # a chain of environment-style contractions at tensor-network sizes: (chi, d, chi) cores
+    chi, d = 48, 4
+    x, y = rng.standard_normal((chi, d, chi)), rng.standard_normal((chi, d, chi))
+    c, labels = t4a.contract_pair(x, [0, 1, 2], y, [2, 3, 4])
+    assert labels == [0, 1, 3, 4] and np.abs(c - np.einsum("abc,cde->abde", x, y)).max() < 1e-10
+    big_a, big_b = rng.standard_normal((7, 3, 11, 2)), rng.standard_normal((2, 5, 3, 6))
+    c, labels = t4a.contract_pair(big_a, [10, 20, 30, 40], big_b, [40, 50, 20, 60])
+    assert labels == [10, 30, 50, 60] and np.abs(c - np.einsum("ajck,kbjd->acbd", big_a, big_b)).max() < 1e-11
+
+
+def test_svd_and_qr_reconstruct_and_match_oracle(t4a):
+    rng = np.random.default_rng(0)
+    t = rng.standard_normal((3, 4, 2, 5))
+    labels = [7, 3, 9, 1]
+    u, s, v = t4a.tensor_svd(t, labels, [9, 7])
+    ou, os_, ov = ob.tensor_svd(t, labels, [9, 7])
+    assert u.shape == ou.shape == (2, 3, 6) and v.shape == (4, 5, 6)
+    assert np.abs(np.einsum("cak,k,bdk->abcd", u, s, v) - t).max() < 1e-12
+    assert np.abs(s - os_).max() < 1e-12 * os_[0]
+    uu = u.reshape(6, 6, order="F")
+    assert np.abs(uu.T @ uu - np.eye(6)).max() < 1e-12
+    q, r = t4a.tensor_qr(t, labels, [3])
+    oq, orr = ob.tensor_qr(t, labels, [3])
+    assert q.shape == oq.shape == (4, 4) and r.shape == orr.shape == (4, 3, 2, 5)
+    assert np.abs(np.einsum("bk,kacd->abcd", q, r) - t).max() < 1e-12
+    assert np.abs(q - oq).max() < 1e-11 and np.abs(r - orr).max() < 1e-11
+    low = np.einsum("ia,ja->ij", rng.standard_normal((60, 3)), rng.standard_normal((80, 3))).reshape(60, 8, 10, order="F")
+    for kw in (dict(policy=t4a.SvdTruncationPolicy(1e-10)), dict(policy=t4a.SvdTruncationPolicy(1e-20), max_bond_dim=3),
+               dict(policy=t4a.SvdTruncationPolicy(1e-8, t4a.RELATIVE, t4a.SQUARED_VALUE, t4a.DISCARDED_TAIL_SUM))):
+        u, s, v = t4a.tensor_svd(low, [1, 2, 3], [1], **kw)
+        assert len(s) == 3 and np.abs(np.einsum("ik,k,abk->iab", u, s, v) - low).max() < 1e-10
+    u, s, v = t4a.tensor_svd(low, [1, 2, 3], [3, 2], truncate=False)  # wide unfolding 80 x 60, all 60 kept
+    assert len(s) == 60 and np.abs(np.einsum("bak,k,ik->iab", u, s, v) - low).max() < 1e-10
+    q, r = t4a.tensor_qr(low, [1, 2, 3], [1], rtol=1e-10)
+    assert np.abs(np.einsum("ik,kab->iab", q, r) - low).max() < 1e-10 and q.shape[1] == ob.tensor_qr(low, [1, 2, 3], [1], rtol=1e-10)[0].shape[1]
