@@ -219,3 +219,28 @@ def test_reference_batched_errors_and_shared_cache(t4a):
     tt, _, _, user_points = t4a.quanticscrossinterpolate_batched([3], f, [2], [0.0], [1.0],
                                                                  options=t4a.QtciOptions(tolerance=1e-8, n_random_init_pivot=0))
     assert len(tt) == 4 and len(calls) == user_points <= 8 and len(set(calls)) == len(calls)
+
+
+def test_three_variables_and_unequal_bits_match_oracle(t4a):
+    # 3 variables fused (site dimension 8) and interleaved; unequal bits per variable through the grid builder arguments
+    f3 = lambda x: math.cos(3.0 * x[0] + 2.0 * x[1] - x[2]) + 0.5 * x[0] * x[2] + 1.0
+    for scheme in (0, 1):
+        go, oo = opts(t4a, tolerance=1e-9, n_random_init_pivot=3, seed=21, max_iter=10)
+        g = t4a.quanticscrossinterpolate([4, 4, 4], f3, [0.0] * 3, [1.0, 2.0, 0.5], grid_unfolding=scheme, options=go)
+        o = ob.quanticscrossinterpolate([4, 4, 4], f3, [0.0] * 3, [1.0, 2.0, 0.5], grid_unfolding=scheme, options=oo)
+        assert g.local_dimensions() == ([8] * 4 if scheme else [2] * 12)
+        assert_same(g, o)
+        rng = np.random.default_rng(scheme)
+        pts = rng.integers(0, 16, size=(200, 3))
+        exact = np.array([f3([p[0] / 16.0, p[1] / 8.0, p[2] / 32.0]) for p in pts])
+        assert np.abs(g.evaluate(pts) - exact).max() < 1e-6
+    f2 = lambda x: 1.0 / (1.0 + x[0] + 3.0 * x[1] * x[1])
+    for scheme in (0, 1):
+        go, oo = opts(t4a, tolerance=1e-10, n_random_init_pivot=2, seed=5, max_iter=10)
+        g = t4a.quanticscrossinterpolate([5, 3], f2, [0.0, 0.0], [1.0, 1.0], include_endpoint=True, grid_unfolding=scheme, options=go)
+        o = ob.quanticscrossinterpolate([5, 3], f2, [0.0, 0.0], [1.0, 1.0], include_endpoint=True, grid_unfolding=scheme, options=oo)
+        assert g.local_dimensions() == o.local_dimensions() == ([4, 4, 4, 2, 2] if scheme else [2] * 8)
+        assert_same(g, o)
+        pts = np.array([[i, j] for i in range(32) for j in range(8)])
+        exact = np.array([f2([p[0] / 31.0, p[1] / 7.0]) for p in pts])
+        assert np.abs(g.evaluate(pts) - exact).max() < 1e-7

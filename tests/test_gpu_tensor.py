@@ -75,3 +75,43 @@ def test_svd_and_qr_reconstruct_and_match_oracle(t4a):
     assert len(s) == 60 and np.abs(np.einsum("bak,k,ik->iab", u, s, v) - low).max() < 1e-10
     q, r = t4a.tensor_qr(low, [1, 2, 3], [1], rtol=1e-10)
     assert np.abs(np.einsum("ik,kab->iab", q, r) - low).max() < 1e-10 and q.shape[1] == ob.tensor_qr(low, [1, 2, 3], [1], rtol=1e-10)[0].shape[1]
+
+
+def test_random_contractions_and_factorisations(t4a):
+    rng = np.random.default_rng(7)
+    letters = "abcdefghij"
+    for case in range(25):
+        ra, rb = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        n_common = int(rng.integers(0, min(ra, rb) + 1))
+        la = list(rng.choice(10, size=ra, replace=False))
+        free_b = [x for x in range(10, 20)]
+        lb = list(rng.choice(la, size=n_common, replace=False)) + list(rng.choice(free_b, size=rb - n_common, replace=False))
+        lb = [int(x) for x in rng.permutation(lb)]
+        la = [int(x) for x in la]
+        dim_of = {x: int(rng.integers(1, 5)) for x in set(la) | set(lb)}
+        a = rng.standard_normal([dim_of[x] for x in la])
+        b = rng.standard_normal([dim_of[x] for x in lb])
+        c, labels = t4a.contract_pair(a, la, b, lb)
+        names = {x: letters[i] for i, x in enumerate(sorted(set(la)))}
+        names.update({x: letters[len(names) + i] for i, x in enumerate(sorted(set(lb) - set(la)))})
+        out = [x for x in la if x not in lb] + [x for x in lb if x not in la]
+        assert labels == out, (case, la, lb)
+        spec = "".join(names[x] for x in la) + "," + "".join(names[x] for x in lb) + "->" + "".join(names[x] for x in out)
+        ref = np.einsum(spec, a, b)
+        assert c.shape == ref.shape and np.abs(c - ref).max() < 1e-11, (case, spec)
+    for case in range(12):
+        rank = int(rng.integers(2, 5))
+        dims = [int(rng.integers(1, 6)) for _ in range(rank)]
+        labels = [int(x) for x in rng.choice(50, size=rank, replace=False)]
+        t = rng.standard_normal(dims)
+        nl = int(rng.integers(1, rank))
+        left = [int(x) for x in rng.choice(labels, size=nl, replace=False)]
+        u, s, v = t4a.tensor_svd(t, labels, left, truncate=False)
+        perm = [labels.index(x) for x in left] + [k for k in range(rank) if labels[k] not in left]
+        mat = np.transpose(t, perm).reshape(int(np.prod([dims[p] for p in perm[:nl]])), -1, order="F")
+        k = min(mat.shape)
+        um, vm = u.reshape(mat.shape[0], k, order="F"), v.reshape(mat.shape[1], k, order="F")
+        assert np.abs((um * s) @ vm.T - mat).max() < 1e-11, (case, dims, labels, left)
+        assert np.abs(s - np.linalg.svd(mat, compute_uv=False)).max() < 1e-11
+        q, r = t4a.tensor_qr(t, labels, left, truncate=False)
+        assert np.abs(q.reshape(mat.shape[0], k, order="F") @ r.reshape(k, mat.shape[1], order="F") - mat).max() < 1e-11

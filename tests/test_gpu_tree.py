@@ -335,3 +335,56 @@ def test_truncated_proposer_keeps_hub_matrices_small(t4a):
     rng = np.random.default_rng(3)
     pts = rng.integers(0, 2, size=(300, n))
     assert np.abs(g.evaluate(pts) - np.array([f(p) for p in pts])).max() < 1e-5
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_trees_and_options_match_oracle(t4a, seed):
+    """Random trees (Pruefer-free construction: every new site attaches to a random earlier one), random local dimensions,
+    random options and proposers: pivot tables, histories and materialised tensors equal the oracle's."""
+    rng = np.random.default_rng(900 + seed)
+    for case in range(4):
+        n = int(rng.integers(3, 9))
+        dims = [int(rng.integers(2, 4)) for _ in range(n)]
+        edges = [(int(rng.integers(0, k)), k) for k in range(1, n)]
+        w = rng.standard_normal(n)
+        c = rng.standard_normal((n, n)) * 0.15
+        kind = int(rng.integers(0, 3))
+
+        def f(idx, w=w, c=c, kind=kind):
+            x = np.asarray(idx, dtype=np.float64)
+            if kind == 0:
+                return float(np.cos(w @ x) + 0.3)
+            if kind == 1:
+                return float(1.0 / (1.5 + np.abs(w) @ x + x @ np.abs(c) @ x))
+            return float(np.exp(-0.2 * (w @ x) ** 2) + 0.1 * x[0] * x[-1])
+
+        g, o = _pair(t4a, dims, edges, f)
+        prop = int(rng.choice([0, 0, 1, 2]))
+        for t in (g, o):
+            t.set_proposer(prop, 11 + case)
+        opt = TreeOptions(tolerance=float(10.0 ** rng.integers(-10, -3)), max_iter=int(rng.integers(2, 7)),
+                          max_bond_dim=None if rng.random() < 0.5 else int(rng.integers(1, 6)),
+                          normalize_error=bool(rng.integers(0, 2)), enable_global_pivots=bool(rng.integers(0, 2)),
+                          nsearch=int(rng.integers(1, 6)), max_nglobal_pivot=int(rng.integers(1, 4)), seed=int(rng.integers(0, 100)))
+        ctx = f"seed {seed} case {case}: dims {dims} edges {edges} kind {kind} proposer {prop} opts {vars(opt)}"
+        first = [int(rng.integers(0, d)) for d in dims]
+        if f(first) == 0.0:
+            first = [0] * n
+        og = o.crossinterpolate2([first], opt)
+        gg = g.crossinterpolate2([first], gopts(t4a, opt))
+        assert gg[0] == og[0], ctx
+        assert np.allclose(gg[1], og[1], rtol=0, atol=1e-11), ctx
+        assert_same_state(g, o, edges)
+        center = int(rng.integers(0, n))
+        try:
+            o.materialize(center)
+        except ob.OracleError:
+            # e.g. a bond-dimension-saturated stop right after global pivots were injected: the two sides of an edge hold
+            # different pivot counts and to_treetn refuses (materialize.rs:40-48) — on both sides
+            with pytest.raises(t4a.T4aError):
+                g.materialize(center)
+            continue
+        g.materialize(center)
+        pts = np.array(list(itertools.product(*[range(d) for d in dims])))
+        ge, oe = g.evaluate(pts), o.evaluate(pts)
+        assert np.abs(ge - oe).max() <= 1e-9 * max(1.0, np.abs(oe).max()), ctx
