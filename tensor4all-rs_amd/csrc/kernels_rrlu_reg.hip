@@ -846,7 +846,8 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
     const char* ec = std::getenv("T4A_RRLU_CPT");
     const int maxw = num_cus > 16 ? num_cus - 8 : num_cus;
     const long long elems = (long long)M * N;
-    bool single = elems <= 128 * 128;
+    static const long long single_max = std::getenv("T4A_RRLU_SINGLE_MAX") ? std::atoll(std::getenv("T4A_RRLU_SINGLE_MAX")) : 64 * 64;
+    bool single = elems <= single_max;
     if (ew) single = std::atoi(ew) == 1;
     bool found = false;
     if (single) {

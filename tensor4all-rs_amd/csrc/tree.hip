@@ -2,6 +2,7 @@
 #include "tree.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <deque>
@@ -505,11 +506,21 @@ std::vector<double> TreeTci::eval_points(const std::vector<uint32_t>& idx, size_
 EdgeSelection TreeTci::update_edge(const TreeEdge& edge, const RrLUOptions& options) // :22-115
 {
     require_fn();
+    static const bool host_prof = std::getenv("T4A_HOST_PROFILE") != nullptr;
+    static double hp[4] = {0, 0, 0, 0};
+    static long hp_n = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    const auto t0 = now();
     const auto keys = graph.subregion_vertices(edge);
     IndexSet lc, rc;
     candidates(edge, lc, rc);
     if (lc.count == 0 || rc.count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "proposer returned empty candidate list for edge");
     const size_t M = lc.count, N = rc.count;
+    const auto t1 = now();
+    auto t2 = t1;
     RrLUOptions o = options;
     o.left_orthogonal = true;
     LuciResult lu;
@@ -519,6 +530,7 @@ EdgeSelection TreeTci::update_edge(const TreeEdge& edge, const RrLUOptions& opti
         std::vector<uint64_t> ra, rb;
         accumulate(lc, keys.first, ra);
         accumulate(rc, keys.second, rb);
+        t2 = now();
         d_acc_.reserve(ra.size() + rb.size());
         hipStream_t st = eng.stream();
         T4A_HIP(hipMemcpyAsync(d_acc_.get(), ra.data(), ra.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -532,6 +544,15 @@ EdgeSelection TreeTci::update_edge(const TreeEdge& edge, const RrLUOptions& opti
         double* d_pi = eng.pi(M * N);
         eval_matrix(lc, keys.first, rc, keys.second, d_pi, false, nullptr);
         lu = eng.luci(d_pi, (int)M, (int)N, o, false, false);
+    }
+    if (host_prof) {
+        const auto t3 = now();
+        hp[0] += us(t0, t1);
+        hp[1] += us(t1, t2);
+        hp[2] += us(t2, t3);
+        if (++hp_n % 200 == 0)
+            std::fprintf(stderr, "[host profile] tree update_edge: candidates %.1f us, accumulators %.1f us, upload+rrLU+wait %.1f us (avg of %ld)\n",
+                         hp[0] / hp_n, hp[1] / hp_n, hp[2] / hp_n, hp_n);
     }
     if (lu.abs_max > max_sample_value) max_sample_value = lu.abs_max;
 
