@@ -221,8 +221,10 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.poll_delay = poll_delay_env >= 0 ? poll_delay_env : (rplan.W > 100 ? 14 : 12);
         static const int ncopy_env = std::getenv("T4A_RRLU_NCOPY") ? std::atoi(std::getenv("T4A_RRLU_NCOPY")) : 1;
         a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
-        static const int spec_env = std::getenv("T4A_RRLU_SPEC") ? std::atoi(std::getenv("T4A_RRLU_SPEC")) : 0;
-        a.spec = spec_env ? 1 : 0;
+        static const int spec_env = std::getenv("T4A_RRLU_SPEC") ? std::atoi(std::getenv("T4A_RRLU_SPEC")) : 2;
+        a.spec = spec_env < 0 ? 0 : (spec_env > 2 ? 2 : spec_env);
+        static const double spec_frac_env = std::getenv("T4A_RRLU_SPECFRAC") ? std::atof(std::getenv("T4A_RRLU_SPECFRAC")) : 0.66;
+        a.spec_frac = spec_frac_env;
         static const int key16_env = std::getenv("T4A_RRLU_KEY16") ? std::atoi(std::getenv("T4A_RRLU_KEY16")) : 1;
         a.key16 = key16_env ? 1 : 0;
         a.spin_limit = 1u << 20;

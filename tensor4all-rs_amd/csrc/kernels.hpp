@@ -118,7 +118,9 @@ struct RrluRegArgs {
     int poll_delay;             // >0: the polling wave sleeps ~1000 cycles before its first key sweep
     int ncopy;                  // replicas of the published pivot column (<= RRLU_MAX_COPIES)
     int key16;                  // 1: the poller reads every key with one 16-byte load
-    int spec;                   // 1: every workgroup publishes its candidate column with its key (cols is [2][W][M][2])
+    int spec;                   // 1: every workgroup publishes its candidate column with its key (cols is [2][W][M][2]);
+                                // 2: only those whose candidate score is >= spec_frac * (previous pivot)^2
+    double spec_frac;
     unsigned spin_limit;
     unsigned long long* stamps; // diagnostic only
     // optional host-visible (pinned) mirror of the packed result block that starts at `dresult`

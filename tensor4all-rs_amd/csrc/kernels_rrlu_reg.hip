@@ -29,6 +29,10 @@
 //     results are mirrored into pinned host memory by workgroup 0, which also resets the device header and clears
 //     the key table of the next launch (two alternating tables).
 // Barriers per pivot step: 3.
+// Thresholded speculative publication of the pivot column is compiled in (measured on MI355X: 42.1 -> 40.8 ms of rrLU per
+// sweep at d = 30, chi = 256; selecting the mode through RrluRegArgs::spec at run time costs the default path 2 ms of
+// code-generation noise, so it is a build-time choice).  Remove the define to get the run-time switch back.
+#define T4A_RRLU_SPEC2 1
 #include "kernels.hpp"
 
 #include <cstdlib>
@@ -191,6 +195,12 @@ __host__ __device__ inline size_t reg_smem_layout(int M, int N, int cols_per_wg,
     return off;
 }
 
+// thresholded speculative column publication compiled in (T4A_RRLU_SPEC2) or selected at run time (RrluRegArgs::spec)
+#ifdef T4A_RRLU_SPEC2
+#define T4A_SPEC(p) 2
+#else
+#define T4A_SPEC(p) ((p).spec)
+#endif
 #define T4A_RSTAMP(slot)                                                  \
     do {                                                                  \
         if (stamp_on) {                                                   \
@@ -303,6 +313,8 @@ rrlu_reg_kernel(RrluRegArgs p)
     double l[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) l[r] = 0.0;
+    double prev_sq = __builtin_huge_val(); // square of the previous pivot (thresholded speculation: nobody speculates first)
+    const double spec_frac = p.spec_frac;
 
     for (int k = -1; k < p.max_steps; ++k) {
         // =====================================================================================
@@ -460,6 +472,7 @@ rrlu_reg_kernel(RrluRegArgs p)
         unsigned wkey;
         int ww = 0;
         double colv[RPT];
+        bool early_pub = false;
         if (SINGLE) {
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
@@ -504,7 +517,10 @@ rrlu_reg_kernel(RrluRegArgs p)
             }
             // speculative mode: EVERY workgroup publishes its candidate column together with its key, so the winner's
             // column is already in flight while the keys are gathered (one hand-off per pivot step instead of two)
-            if (p.spec && qstar >= 0) {
+            // thresholded mode (spec == 2): only workgroups whose candidate is within a factor of the previous pivot publish
+            // early (a handful per step instead of all W), the others catch up after the gather if they win
+            early_pub = T4A_SPEC(p) == 1 || (T4A_SPEC(p) == 2 && bsc >= spec_frac * prev_sq);
+            if (early_pub && qstar >= 0) {
 #pragma unroll
                 for (int r = 0; r < RPT; ++r)
                     if (irow[r] >= 0) {
@@ -612,7 +628,17 @@ rrlu_reg_kernel(RrluRegArgs p)
             ww = s.win_i[0];
             // hop 2: only the winner's owning column group publishes the pivot column: one 16-byte store of two
             // tagged granules per row, replicated into `ncopy` copies so that at most W/ncopy readers share a line
-            if (!p.spec && ww == w && qstar >= 0) {
+            if (T4A_SPEC(p) == 2 && !early_pub && ww == w && qstar >= 0) { // the winner did not speculate: publish into its slot now
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (irow[r] >= 0) {
+                        const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
+                        unsigned long long* dst = p.cols + (((size_t)par * p.W + w) * (size_t)p.M + irow[r]) * 2;
+                        st_u64_sc1(dst, tagbits | (vb & 0xFFFFFFFFull));
+                        st_u64_sc1(dst + 1, tagbits | (vb >> 32));
+                    }
+            }
+            if (!T4A_SPEC(p) && ww == w && qstar >= 0) {
 #pragma unroll
                 for (int r = 0; r < RPT; ++r)
                     if (irow[r] >= 0) {
@@ -625,6 +651,25 @@ rrlu_reg_kernel(RrluRegArgs p)
                     }
             }
         }
+        const bool need_fetch = !SINGLE && !(ww == w && qstar >= 0);
+        const unsigned long long* colsrc =
+            SINGLE ? nullptr
+                   : (T4A_SPEC(p) ? p.cols + ((size_t)((k + 1) & 1) * p.W + ww) * (size_t)p.M * 2
+                             : p.cols + ((size_t)((k + 1) & 1) * p.ncopy + (w % p.ncopy)) * (size_t)p.M * 2);
+        unsigned long long cg0[RPT], cg1[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            cg0[r] = 0ull;
+            cg1[r] = 0ull;
+        }
+        if (need_fetch && T4A_SPEC(p) == 2) { // the winner most likely published with its key: the column is already there
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if (irow[r] >= 0) {
+                    cg0[r] = ld_u64_sc1(colsrc + 2 * (size_t)irow[r]);
+                    cg1[r] = ld_u64_sc1(colsrc + 2 * (size_t)irow[r] + 1);
+                }
+        }
         T4A_RSTAMP(3);
 
         // ---- stop tests, every thread (matrixlu.rs:757-781) ----
@@ -633,6 +678,7 @@ rrlu_reg_kernel(RrluRegArgs p)
         if (kn > 0 && (pivot_abs < p.rel_tol * max_error || pivot_abs < p.abs_tol)) break;
         if (pivot_abs <= min_pivot_abs) break;
         max_error = fmax(max_error, pivot_abs);
+        prev_sq = wval * wval;
 
         // ---- permutation bookkeeping: position -> index from the LDS tables, index -> position in registers ----
         const int prp = (int)(rowmajor ? (wkey >> 16) : (wkey & 0xFFFFu));
@@ -667,19 +713,9 @@ rrlu_reg_kernel(RrluRegArgs p)
         }
         if (w == 0 && tid == 0) p.pivot_vals[kn] = wval;
 
-        // issue the pivot-column loads (issuing them before the bookkeeping measured worse: more first-sweep misses)
-        const bool need_fetch = !SINGLE && !(ww == w && qstar >= 0);
-        const unsigned long long* colsrc =
-            SINGLE ? nullptr
-                   : (p.spec ? p.cols + ((size_t)((k + 1) & 1) * p.W + ww) * (size_t)p.M * 2
-                             : p.cols + ((size_t)((k + 1) & 1) * p.ncopy + (w % p.ncopy)) * (size_t)p.M * 2);
-        unsigned long long cg0[RPT], cg1[RPT];
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            cg0[r] = 0ull;
-            cg1[r] = 0ull;
-        }
-        if (need_fetch) {
+        // issue the pivot-column loads (issuing them before the bookkeeping measured worse: more first-sweep misses; in the
+        // thresholded speculative mode they were already issued straight after the gather)
+        if (need_fetch && T4A_SPEC(p) != 2) {
 #pragma unroll
             for (int r = 0; r < RPT; ++r)
                 if (irow[r] >= 0) {
