@@ -1001,6 +1001,7 @@ int oracle_qtci_grid(void* h, int which, const uint64_t* in, uint64_t* out_u, do
             auto x = g.quantics_to_grididx(MultiIndex(in, in + g.sites.size()));
             std::copy(x.begin(), x.end(), out_u);
         } else if (which == 2) {
+            if (!g.discretized) throw OracleError(ERR_INVALID_ARGUMENT, "original coordinates are only available for discretized grids");
             auto x = g.quantics_to_origcoord(MultiIndex(in, in + g.sites.size()));
             std::copy(x.begin(), x.end(), out_d);
         } else if (which == 3) {

@@ -1988,6 +1988,9 @@ t4a_gpu_status t4a_gpu_qtci_grid(const t4a_gpu_qtci* h, int32_t which, const siz
                 g.quantics_to_grididx(q.data(), out_u);
             } else {
                 T4A_REQUIRE_PTR(out_d);
+                // cachedata_origcoord (quantics_tci.rs:156-173): only discretized grids carry coordinates
+                if (!g.discretized)
+                    throw Error(T4A_GPU_INVALID_ARGUMENT, "original coordinates are only available for discretized grids");
                 g.quantics_to_origcoord(q.data(), out_d);
             }
         } else if (which == 3) {

@@ -51,6 +51,9 @@ def test_reference_discrete_cases(t4a):
     assert_same(g, ob.quanticscrossinterpolate_discrete([4, 4], f, None, oo))
     one = t4a.quanticscrossinterpolate_discrete([4], lambda idx: 1.0, None, go)
     assert one.integral() == pytest.approx(one.sum(), abs=1e-10) and one.integral() == pytest.approx(4.0, abs=1e-8)
+    with pytest.raises(t4a.T4aError) as e:  # tests/mod.rs:236-253: cachedata_origcoord on an inherent grid
+        one.quantics_to_origcoord([0, 0])
+    assert "original coordinates are only available for discretized grids" in str(e.value)
     prod = lambda idx: float(idx[0] * idx[1])
     g = t4a.quanticscrossinterpolate_discrete([4, 4], prod, [[0, 0], [1, 2]], go)
     assert g.evaluate([[3, 3]])[0] == pytest.approx(9.0, abs=1e-8)

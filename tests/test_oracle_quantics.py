@@ -67,6 +67,9 @@ def test_discrete_integral_returns_sum():
     q = ob.quanticscrossinterpolate_discrete([4], lambda idx: 1.0, None,
                                              QtciOptions(tolerance=1e-10, n_random_init_pivot=3, unfolding_scheme=FUSED, seed=3))
     assert q.integral() == pytest.approx(q.sum(), abs=1e-10) and q.integral() == pytest.approx(4.0, abs=1e-8)
+    with pytest.raises(ob.OracleError) as e:  # tests/mod.rs:236-253: cachedata_origcoord on an inherent grid
+        q.quantics_to_origcoord([0, 0])
+    assert "original coordinates are only available for discretized grids" in str(e.value)
 
 
 def test_continuous_grid_interpolation_and_cache_coordinates():
