@@ -865,12 +865,14 @@ template <int RPT> void launch_r(const RrluRegPlan& plan, const RrluRegArgs& a, 
     case 2: launch_rc<RPT, 2>(plan, a, stream); break;
     case 3: launch_rc<RPT, 3>(plan, a, stream); break;
     case 4: launch_rc<RPT, 4>(plan, a, stream); break;
+    case 5: launch_rc<RPT, 5>(plan, a, stream); break;
+    case 6: launch_rc<RPT, 6>(plan, a, stream); break;
     default: launch_rc<RPT, 8>(plan, a, stream); break;
     }
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
-int norm_cpt(int c) { return c <= 1 ? 1 : (c <= 2 ? 2 : (c == 3 ? 3 : (c <= 4 ? 4 : 8))); }
+int norm_cpt(int c) { return c <= 1 ? 1 : (c <= 6 ? c : 8); }
 
 } // namespace
 
@@ -951,7 +953,7 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
             CPT = norm_cpt((N + W * TC - 1) / (W * TC));
         }
         while (W > maxw && CPT < 8) {
-            CPT = CPT == 3 ? 4 : CPT * 2;
+            CPT = CPT < 6 ? CPT + 1 : 8; // 3 -> 4 -> 5 -> 6 -> 8 columns per thread
             W = (N + TC * CPT - 1) / (TC * CPT);
         }
         if (W < 1) W = 1;
