@@ -17,8 +17,12 @@ __global__ void work_kernel(volatile unsigned* host_flag, unsigned seq, int spin
     }
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    if (argc > 1) { // "spin": ask the runtime to busy-wait in its synchronisation calls
+        const hipError_t e = hipSetDeviceFlags(hipDeviceScheduleSpin);
+        std::printf("hipSetDeviceFlags(hipDeviceScheduleSpin) -> %d\n", (int)e);
+    }
     hipStream_t st;
     hipStreamCreate(&st);
     unsigned* flag;
