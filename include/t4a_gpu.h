@@ -530,6 +530,29 @@ t4a_gpu_status t4a_gpu_tensor_qr_f64(const double* t, const size_t* dims, const 
                                      const int64_t* left_labels, size_t n_left, int32_t truncate, int32_t has_rtol, double rtol,
                                      size_t* r, double* q, double* r_factor);
 
+/* Device-resident labelled tensors: the same three operations without a host round trip per call (environment /
+ * zip-up style chains keep their intermediates in HBM).  A handle owns its column-major payload, dims and labels. */
+typedef struct t4a_gpu_tensor t4a_gpu_tensor;
+t4a_gpu_status t4a_gpu_tensor_new(const double* data, const size_t* dims, const int64_t* labels, size_t rank,
+                                  t4a_gpu_tensor** out);
+void t4a_gpu_tensor_release(t4a_gpu_tensor* h);
+t4a_gpu_status t4a_gpu_tensor_rank(const t4a_gpu_tensor* h, size_t* rank);
+t4a_gpu_status t4a_gpu_tensor_dims(const t4a_gpu_tensor* h, size_t* dims, int64_t* labels);
+t4a_gpu_status t4a_gpu_tensor_to_host(const t4a_gpu_tensor* h, double* out);
+/* permute_indices: new axis k is the axis carrying labels[k] */
+t4a_gpu_status t4a_gpu_tensor_permute(const t4a_gpu_tensor* h, const int64_t* labels, t4a_gpu_tensor** out);
+/* replace label `from` by `to` (DynIndex replacement / priming on the caller's side) */
+t4a_gpu_status t4a_gpu_tensor_relabel(t4a_gpu_tensor* h, int64_t from, int64_t to);
+t4a_gpu_status t4a_gpu_tensor_contract(const t4a_gpu_tensor* a, const t4a_gpu_tensor* b, t4a_gpu_tensor** out);
+/* svd_with: u carries [left.., bond_label], s is a rank-1 tensor [bond_label] of singular values, v carries
+ * [right.., bond_label_v]; qr_with: q [left.., bond_label], r [bond_label, right..] */
+t4a_gpu_status t4a_gpu_tensor_svd(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t truncate,
+                                  const t4a_gpu_svd_policy* policy, int32_t has_max_bond_dim, size_t max_bond_dim,
+                                  int64_t bond_label, int64_t bond_label_v, t4a_gpu_tensor** u, t4a_gpu_tensor** s,
+                                  t4a_gpu_tensor** v);
+t4a_gpu_status t4a_gpu_tensor_qr(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t truncate,
+                                 int32_t has_rtol, double rtol, int64_t bond_label, t4a_gpu_tensor** q, t4a_gpu_tensor** r);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);

@@ -20,6 +20,26 @@ struct t4a_gpu_treetci {
     t4a_gpu_treetci(const std::vector<size_t>& d, const t4a::TreeGraph& g) : impl(d, g) {}
 };
 
+struct t4a_gpu_tensor {
+    t4a::DevBuf<double> buf;
+    std::vector<size_t> dims;
+    std::vector<int64_t> labels;
+    size_t size() const
+    {
+        size_t n = 1;
+        for (size_t d : dims) n *= d;
+        return n;
+    }
+    t4a::TensorView view() const
+    {
+        t4a::TensorView v;
+        v.d_data = buf.get();
+        v.dims = dims;
+        v.labels = labels;
+        return v;
+    }
+};
+
 struct t4a_gpu_qtci {
     std::unique_ptr<t4a::QuanticsTci> impl;
 };
@@ -2215,6 +2235,243 @@ t4a_gpu_status t4a_gpu_tensor_qr_f64(const double* t, const size_t* dims, const 
         gather_launch(d_r, (int)k, nullptr, (int)keep, nullptr, (int)n, d_rk, (int)keep, e.stream());
         T4A_HIP(hipGetLastError());
         download(e, r_factor, d_rk, keep * n);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ device-resident labelled tensors
+extern "C++" {
+static std::unique_ptr<t4a_gpu_tensor> make_tensor(const std::vector<size_t>& dims, const std::vector<int64_t>& labels)
+{
+    std::unique_ptr<t4a_gpu_tensor> t(new t4a_gpu_tensor());
+    t->dims = dims;
+    t->labels = labels;
+    t->buf.reserve(std::max<size_t>(t->size(), 1));
+    return t;
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_tensor_new(const double* data, const size_t* dims, const int64_t* labels, size_t rank,
+                                  t4a_gpu_tensor** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        TensorView hv = host_view(dims, labels, rank);
+        if (rank > (size_t)TENSOR_MAX_RANK) throw Error(T4A_GPU_NOT_IMPLEMENTED, "tensor rank above 16");
+        for (size_t a = 0; a < rank; ++a)
+            for (size_t b = a + 1; b < rank; ++b)
+                if (labels[a] == labels[b]) throw Error(T4A_GPU_INVALID_ARGUMENT, "duplicate index in tensor");
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        auto t = make_tensor(hv.dims, hv.labels);
+        if (t->size()) {
+            T4A_REQUIRE_PTR(data);
+            upload(e, t->buf.get(), data, t->size());
+        }
+        *out = t.release();
+    });
+}
+
+void t4a_gpu_tensor_release(t4a_gpu_tensor* h) { delete h; }
+
+t4a_gpu_status t4a_gpu_tensor_rank(const t4a_gpu_tensor* h, size_t* rank)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(rank);
+        *rank = h->dims.size();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_dims(const t4a_gpu_tensor* h, size_t* dims, int64_t* labels)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (dims) std::copy(h->dims.begin(), h->dims.end(), dims);
+        if (labels) std::copy(h->labels.begin(), h->labels.end(), labels);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_to_host(const t4a_gpu_tensor* h, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (h->size() == 0) return;
+        T4A_REQUIRE_PTR(out);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        download(dense_engine(), out, h->buf.get(), h->size());
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_permute(const t4a_gpu_tensor* h, const int64_t* labels, t4a_gpu_tensor** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        const size_t r = h->dims.size();
+        if (r) T4A_REQUIRE_PTR(labels);
+        std::vector<size_t> perm(r);
+        std::vector<char> used(r, 0);
+        for (size_t k = 0; k < r; ++k) {
+            auto it = std::find(h->labels.begin(), h->labels.end(), labels[k]);
+            if (it == h->labels.end()) throw Error(T4A_GPU_INVALID_ARGUMENT, "permute: index not found in tensor");
+            perm[k] = (size_t)(it - h->labels.begin());
+            if (used[perm[k]]) throw Error(T4A_GPU_INVALID_ARGUMENT, "permute: duplicate index");
+            used[perm[k]] = 1;
+        }
+        std::vector<size_t> nd(r);
+        std::vector<int64_t> nl(r);
+        for (size_t k = 0; k < r; ++k) {
+            nd[k] = h->dims[perm[k]];
+            nl[k] = h->labels[perm[k]];
+        }
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        auto t = make_tensor(nd, nl);
+        tensor_permute(e, h->view(), perm, t->buf.get());
+        e.sync();
+        *out = t.release();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_relabel(t4a_gpu_tensor* h, int64_t from, int64_t to)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        auto it = std::find(h->labels.begin(), h->labels.end(), from);
+        if (it == h->labels.end()) throw Error(T4A_GPU_INVALID_ARGUMENT, "relabel: index not found in tensor");
+        if (from != to && std::find(h->labels.begin(), h->labels.end(), to) != h->labels.end())
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "relabel: the new label is already present");
+        *it = to;
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_contract(const t4a_gpu_tensor* a, const t4a_gpu_tensor* b, t4a_gpu_tensor** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(b);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        const TensorView va = a->view(), vb = b->view();
+        const ContractPlan plan = plan_contract_pair(va, vb);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        auto t = make_tensor(plan.out_dims, plan.out_labels);
+        tensor_contract_pair(e, va, vb, plan, t->buf.get());
+        e.sync();
+        *out = t.release();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_svd(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t truncate,
+                                  const t4a_gpu_svd_policy* policy, int32_t has_max_bond_dim, size_t max_bond_dim,
+                                  int64_t bond_label, int64_t bond_label_v, t4a_gpu_tensor** u, t4a_gpu_tensor** s,
+                                  t4a_gpu_tensor** v)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(t);
+        T4A_REQUIRE_PTR(u);
+        T4A_REQUIRE_PTR(s);
+        T4A_REQUIRE_PTR(v);
+        *u = *s = *v = nullptr;
+        if (n_left) T4A_REQUIRE_PTR(left_labels);
+        const TensorView tv = t->view();
+        const std::vector<int64_t> left(left_labels, left_labels + n_left);
+        const UnfoldPlan un = plan_unfold_split(tv, left);
+        SvdPolicy pol = convert_policy(policy);
+        if (truncate) {
+            if (has_max_bond_dim && max_bond_dim == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "max_bond_dim must be positive when specified");
+            if (!std::isfinite(pol.threshold) || pol.threshold < 0.0)
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "Invalid SVD truncation threshold: threshold must be finite and non-negative");
+        }
+        const size_t m = un.m, n = un.n, k = std::min(m, n), count = tv.size();
+        if (count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD of an empty tensor");
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "svd: unfolded dimensions above 65535 are not supported");
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_mat = e.pi(count);
+        tensor_permute(e, tv, un.perm, d_mat);
+        e.d_tmp.reserve(m * k + k + k * n);
+        double* d_u = e.d_tmp.get();
+        double* d_s = d_u + m * k;
+        double* d_vt = d_s + k;
+        e.svd(d_mat, (int)m, (int)n, d_u, d_s, d_vt);
+        std::vector<double> hs(k);
+        download(e, hs.data(), d_s, k);
+        size_t keep = k;
+        if (truncate) {
+            keep = svd_retained_rank(hs.data(), k, pol);
+            if (has_max_bond_dim) keep = std::min(keep, max_bond_dim);
+        }
+        keep = std::min(std::max<size_t>(keep, 1), k);
+        std::vector<size_t> ud = un.left_dims, vd = un.right_dims;
+        std::vector<int64_t> ul = left, vl;
+        for (size_t a = n_left; a < un.perm.size(); ++a) vl.push_back(tv.labels[un.perm[a]]);
+        ud.push_back(keep);
+        ul.push_back(bond_label);
+        vd.push_back(keep);
+        vl.push_back(bond_label_v);
+        auto tu = make_tensor(ud, ul), ts = make_tensor({keep}, {bond_label}), tvv = make_tensor(vd, vl);
+        T4A_HIP(hipMemcpyAsync(tu->buf.get(), d_u, m * keep * sizeof(double), hipMemcpyDeviceToDevice, e.stream()));
+        T4A_HIP(hipMemcpyAsync(ts->buf.get(), d_s, keep * sizeof(double), hipMemcpyDeviceToDevice, e.stream()));
+        transpose_launch(d_vt, (int)keep, (int)n, (int)k, tvv->buf.get(), (int)n, e.stream());
+        T4A_HIP(hipGetLastError());
+        e.sync();
+        *u = tu.release();
+        *s = ts.release();
+        *v = tvv.release();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_qr(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t truncate,
+                                 int32_t has_rtol, double rtol, int64_t bond_label, t4a_gpu_tensor** q, t4a_gpu_tensor** r)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(t);
+        T4A_REQUIRE_PTR(q);
+        T4A_REQUIRE_PTR(r);
+        *q = *r = nullptr;
+        if (n_left) T4A_REQUIRE_PTR(left_labels);
+        const TensorView tv = t->view();
+        const std::vector<int64_t> left(left_labels, left_labels + n_left);
+        const UnfoldPlan un = plan_unfold_split(tv, left);
+        const double tol = has_rtol ? rtol : 1e-15;
+        if (truncate && (!std::isfinite(tol) || tol < 0.0))
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "Invalid rtol value: rtol must be finite and non-negative");
+        const size_t m = un.m, n = un.n, k = std::min(m, n), count = tv.size();
+        if (count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "QR of an empty tensor");
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "qr: unfolded dimensions above 65535 are not supported");
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        double* d_mat = e.pi(count);
+        tensor_permute(e, tv, un.perm, d_mat);
+        e.d_tmp.reserve(m * k + k * n);
+        double* d_q = e.d_tmp.get();
+        double* d_r = d_q + m * k;
+        e.qr(d_mat, (int)m, (int)n, d_q, d_r);
+        size_t keep = k;
+        if (truncate) {
+            std::vector<double> hr(k * n);
+            download(e, hr.data(), d_r, k * n);
+            keep = std::min(qr_retained_rank(hr.data(), k, n, tol), k);
+        }
+        std::vector<size_t> qd = un.left_dims, rd{keep};
+        std::vector<int64_t> ql = left, rl{bond_label};
+        qd.push_back(keep);
+        ql.push_back(bond_label);
+        for (size_t a = n_left; a < un.perm.size(); ++a) {
+            rd.push_back(tv.dims[un.perm[a]]);
+            rl.push_back(tv.labels[un.perm[a]]);
+        }
+        auto tq = make_tensor(qd, ql), tr = make_tensor(rd, rl);
+        T4A_HIP(hipMemcpyAsync(tq->buf.get(), d_q, m * keep * sizeof(double), hipMemcpyDeviceToDevice, e.stream()));
+        gather_launch(d_r, (int)k, nullptr, (int)keep, nullptr, (int)n, tr->buf.get(), (int)keep, e.stream());
+        T4A_HIP(hipGetLastError());
+        e.sync();
+        *q = tq.release();
+        *r = tr.release();
     });
 }
 

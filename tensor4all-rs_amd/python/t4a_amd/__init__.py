@@ -1433,3 +1433,80 @@ def tensor_qr(t, labels, left, truncate=True, rtol=None):
                                       ctypes.byref(r), _p(q), _p(rf)))
     rr = r.value
     return q[:m * rr].reshape(ld + [rr], order="F"), rf[:rr * n].reshape([rr] + rd, order="F")
+
+
+class LabelledTensor:
+    """Device-resident dense tensor with one integer label per axis (the dense payload of an IdxTensor): contractions and
+    factorisations chain on the GPU without host round trips."""
+
+    def __init__(self, data=None, labels=None, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
+        a, dims, lab = _labelled(data, labels)
+        self._h = c_void_p()
+        _check(_lib.t4a_gpu_tensor_new(_p(a), _p(dims) if a.ndim else None, _p(lab) if a.ndim else None, c_size_t(a.ndim),
+                                       ctypes.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.t4a_gpu_tensor_release(h)
+            self._h = None
+
+    def _meta(self):
+        r = c_size_t(0)
+        _check(_lib.t4a_gpu_tensor_rank(self._h, ctypes.byref(r)))
+        dims, labels = np.zeros(max(r.value, 1), dtype=np.uintp), np.zeros(max(r.value, 1), dtype=np.int64)
+        _check(_lib.t4a_gpu_tensor_dims(self._h, _p(dims), _p(labels)))
+        return [int(x) for x in dims[:r.value]], [int(x) for x in labels[:r.value]]
+
+    @property
+    def dims(self):
+        return self._meta()[0]
+
+    @property
+    def labels(self):
+        return self._meta()[1]
+
+    def to_numpy(self):
+        dims, _ = self._meta()
+        out = np.zeros(int(np.prod(dims)) if dims else 1)
+        _check(_lib.t4a_gpu_tensor_to_host(self._h, _p(out)))
+        return out.reshape(dims, order="F")
+
+    def permute(self, labels):
+        lab = np.asarray(labels, dtype=np.int64)
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tensor_permute(self._h, _p(lab) if len(lab) else None, ctypes.byref(h)))
+        return LabelledTensor(_handle=h)
+
+    def relabel(self, old, new):
+        _check(_lib.t4a_gpu_tensor_relabel(self._h, ctypes.c_int64(old), ctypes.c_int64(new)))
+        return self
+
+    def contract(self, other):
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tensor_contract(self._h, other._h, ctypes.byref(h)))
+        return LabelledTensor(_handle=h)
+
+    __mul__ = contract
+
+    def svd(self, left, bond_label, bond_label_v=None, truncate=True, policy=None, max_bond_dim=None):
+        lf = np.asarray(left, dtype=np.int64)
+        pc = None if policy is None else policy.to_c()
+        u, s, v = c_void_p(), c_void_p(), c_void_p()
+        _check(_lib.t4a_gpu_tensor_svd(self._h, _p(lf) if len(lf) else None, c_size_t(len(lf)), c_int32(int(truncate)),
+                                       None if pc is None else ctypes.byref(pc), c_int32(0 if max_bond_dim is None else 1),
+                                       c_size_t(0 if max_bond_dim is None else max_bond_dim), ctypes.c_int64(bond_label),
+                                       ctypes.c_int64(bond_label if bond_label_v is None else bond_label_v),
+                                       ctypes.byref(u), ctypes.byref(s), ctypes.byref(v)))
+        return LabelledTensor(_handle=u), LabelledTensor(_handle=s), LabelledTensor(_handle=v)
+
+    def qr(self, left, bond_label, truncate=True, rtol=None):
+        lf = np.asarray(left, dtype=np.int64)
+        q, r = c_void_p(), c_void_p()
+        _check(_lib.t4a_gpu_tensor_qr(self._h, _p(lf) if len(lf) else None, c_size_t(len(lf)), c_int32(int(truncate)),
+                                      c_int32(0 if rtol is None else 1), c_double(0.0 if rtol is None else rtol),
+                                      ctypes.c_int64(bond_label), ctypes.byref(q), ctypes.byref(r)))
+        return LabelledTensor(_handle=q), LabelledTensor(_handle=r)

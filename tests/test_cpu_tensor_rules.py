@@ -63,3 +63,9 @@ def test_index_validation_precedes_the_device():
     with pytest.raises(t.T4aError) as e:
         t.contract_pair(np.ones((2, 2)), [1, 2], np.ones((2, 2)), [2, 3])
     assert e.value.code == t.NO_DEVICE
+    with pytest.raises(t.T4aError) as e:
+        t.LabelledTensor(np.ones((2, 2)), [1, 1])
+    assert e.value.code == t.INVALID_ARGUMENT
+    with pytest.raises(t.T4aError) as e:
+        t.LabelledTensor(np.ones((2, 2)), [1, 2])
+    assert e.value.code == t.NO_DEVICE

@@ -115,3 +115,56 @@ def test_random_contractions_and_factorisations(t4a):
         assert np.abs(s - np.linalg.svd(mat, compute_uv=False)).max() < 1e-11
         q, r = t4a.tensor_qr(t, labels, left, truncate=False)
         assert np.abs(q.reshape(mat.shape[0], k, order="F") @ r.reshape(k, mat.shape[1], order="F") - mat).max() < 1e-11
+
+
+def test_device_resident_tensor_chain(t4a):
+    """MPS-style chain on device handles: environment contraction, QR sweep (left-canonical form), SVD truncation —
+    no host copies between the steps; checked against numpy at the end."""
+    rng = np.random.default_rng(3)
+    n, d, chi = 6, 3, 7
+    bonds = [1] + [chi] * (n - 1) + [1]
+    cores = [rng.standard_normal((bonds[k], d, bonds[k + 1])) for k in range(n)]
+    # labels: bond k -> 100 + k, site k -> k
+    T = [t4a.LabelledTensor(cores[k], [100 + k, k, 101 + k]) for k in range(n)]
+    assert T[2].dims == [chi, d, chi] and T[2].labels == [102, 2, 103]
+    # full contraction of the chain into one tensor over the site labels
+    full = T[0]
+    for k in range(1, n):
+        full = full * T[k]
+    ref = cores[0]
+    for k in range(1, n):
+        ref = np.tensordot(ref, cores[k], axes=([-1], [0]))
+    assert full.labels == [100] + list(range(n)) + [100 + n]
+    assert np.abs(full.to_numpy() - ref).max() < 1e-9 * np.abs(ref).max()
+    # norm via environments <psi|psi>: bra labels primed (+1000 on the bonds)
+    env = None
+    for k in range(n):
+        bra = t4a.LabelledTensor(cores[k], [1100 + k, k, 1101 + k])
+        env = (T[k] * bra) if env is None else ((env * T[k]) * bra)
+    nrm = float(env.to_numpy().ravel()[0])
+    assert abs(nrm - np.sum(ref * ref)) < 1e-9 * nrm
+    # QR sweep to the right: Q replaces the core, R is absorbed into the next one
+    W = list(T)
+    for k in range(n - 1):
+        q, r = W[k].qr([100 + k, k], 500 + k, truncate=False)
+        nxt = r * W[k + 1]                      # [500+k, k+1, 102+k]
+        W[k] = q.relabel(500 + k, 101 + k)
+        W[k + 1] = nxt.relabel(500 + k, 101 + k).permute([101 + k, k + 1, 102 + k])
+        qm = W[k].to_numpy().reshape(-1, W[k].dims[-1], order="F")
+        assert np.abs(qm.T @ qm - np.eye(qm.shape[1])).max() < 1e-11
+    again = W[0]
+    for k in range(1, n):
+        again = again * W[k]
+    assert np.abs(again.to_numpy() - ref).max() < 1e-9 * np.abs(ref).max()
+    # SVD of the two-site tensor at the centre with a rank cap, reconstruction error = discarded weight
+    two = T[2] * T[3]                           # [102, 2, 3, 104]
+    u, s, v = two.svd([102, 2], 700, 701, policy=t4a.SvdTruncationPolicy(1e-14), max_bond_dim=4)
+    assert u.labels == [102, 2, 700] and s.labels == [700] and v.labels == [3, 104, 701] and s.dims == [4]
+    sm = np.linalg.svd(two.to_numpy().reshape(chi * d, d * chi, order="F"), compute_uv=False)
+    assert np.abs(s.to_numpy() - sm[:4]).max() < 1e-11
+    rec = np.einsum("abk,k,cdk->abcd", u.to_numpy(), s.to_numpy(), v.to_numpy())
+    assert abs(np.linalg.norm(rec - two.to_numpy()) - np.sqrt(np.sum(sm[4:] ** 2))) < 1e-9
+    with pytest.raises(t4a.T4aError):
+        T[0].permute([100, 0])
+    with pytest.raises(t4a.T4aError):
+        T[0].relabel(0, 100)
