@@ -23,8 +23,11 @@
 //         tools/ld_bench.hip).  Measured alternatives (tools/xchg_bench.hip, W = 86, cycles per round):
 //         shared table 3 860, per-workgroup inboxes 5 690; speculatively publishing every workgroup's
 //         candidate column instead of hop 2: 5.4 us/step.
-//       hop 2 (pivot column broadcast): only the winner publishes its column; readers delay their first
-//         sweep so that it normally succeeds.
+//       hop 2 (pivot column broadcast): every workgroup has a slot for its candidate column; a workgroup whose
+//         candidate score is >= spec_frac * (previous pivot)^2 — ~55 of 230 at the mid bond — stores it together with
+//         its key, so the winner's column is normally already in flight while the keys are gathered and the readers issue
+//         their column loads straight after the gather; a winner that did not speculate publishes afterwards (the tagged
+//         granules make both cases one reader loop).
 //   * no stream operation besides the launch: built-in functors are evaluated straight into the slab (p.fused),
 //     results are mirrored into pinned host memory by workgroup 0, which also resets the device header and clears
 //     the key table of the next launch (two alternating tables).
