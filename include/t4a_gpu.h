@@ -553,6 +553,18 @@ t4a_gpu_status t4a_gpu_tensor_svd(const t4a_gpu_tensor* t, const int64_t* left_l
 t4a_gpu_status t4a_gpu_tensor_qr(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t truncate,
                                  int32_t has_rtol, double rtol, int64_t bond_label, t4a_gpu_tensor** q, t4a_gpu_tensor** r);
 
+/* factorize(t, left_inds, FactorizeOptions{alg, canonical, max_bond_dim, svd_policy, qr_rtol}) / factorize_full_rank
+ * (defaults/factorize.rs:86-118, :399-425): left carries [left.., bond_label], right [bond_label, right..] and
+ * left * right == t.  alg: 0 SVD (canonical 0 Left: left = U, right = S V^H; 1 Right: left = U S, right = V^H),
+ * 1 QR (left = Q, right = R), 2 LU (rrLU with rel_tol 1e-14, permuted L and U, left-orthogonal for Left), 3 CI
+ * (MatrixLUCI factors).  full_rank != 0: no truncation (rel_tol 0 for LU / CI).  singular_values (capacity min(m, n),
+ * may be NULL) is written for SVD only; rank receives the bond dimension. */
+t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t alg,
+                                        int32_t canonical, int32_t full_rank, const t4a_gpu_svd_policy* policy,
+                                        int32_t has_max_bond_dim, size_t max_bond_dim, int32_t has_qr_rtol, double qr_rtol,
+                                        int64_t bond_label, t4a_gpu_tensor** left, t4a_gpu_tensor** right, size_t* rank,
+                                        double* singular_values);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);

@@ -303,4 +303,24 @@ int oracle_tensor_qr(const double* t, const uint64_t* dims, const int64_t* label
     });
 }
 
+int oracle_tensor_factorize(const double* t, const uint64_t* dims, const int64_t* labels, uint64_t rank, const int64_t* left,
+                            uint64_t n_left, int alg, int canonical, int full_rank, double threshold, int scale, int measure, int rule,
+                            uint64_t max_bond_dim, double qr_rtol, uint64_t* r_out, double* lout, double* rout, double* sv)
+{
+    return guarded([&] {
+        SvdPolicy p;
+        p.threshold = threshold;
+        p.scale = scale;
+        p.measure = measure;
+        p.rule = rule;
+        TensorFactorizeResult o = tensor_factorize(make_tensor(t, dims, labels, rank), std::vector<int64_t>(left, left + n_left), alg,
+                                                   canonical, full_rank != 0, p, max_bond_dim == (uint64_t)-1 ? 0 : max_bond_dim,
+                                                   max_bond_dim != (uint64_t)-1, qr_rtol);
+        *r_out = o.rank;
+        std::copy(o.left.begin(), o.left.end(), lout);
+        std::copy(o.right.begin(), o.right.end(), rout);
+        if (sv) std::copy(o.singular_values.begin(), o.singular_values.end(), sv);
+    });
+}
+
 } // extern "C"

@@ -11,6 +11,9 @@
 //                           svd_with :347-395 (U [left.., bond], S diagonal, V [right.., bond] = conj(V^H) permuted)
 //   defaults/qr.rs          compute_retained_rank_qr_from_dense :74-117 (row norms of R against rtol * max row norm;
 //                           the LEADING r rows are kept), qr_with :206-328
+//   defaults/factorize.rs   factorize :86-118 over FactorizeAlg {SVD, QR, LU, CI} x Canonical {Left, Right}: SVD :482-559 (S absorbed
+//                           into the right / left factor), QR :561-622, LU :624-733 (rrLU, rel_tol 1e-14, permuted L and U),
+//                           CI :735-834 (MatrixLUCI factors), the *_full_rank variants (no truncation, rel_tol 0)
 //   truncation.rs           SvdTruncationPolicy :137-147 (default: relative, per value, 1e-12 — svd.rs:80-87)
 // Indices are integer labels here (no prime levels / tags / structured storage / AD).  The factorisations themselves go
 // through tenferro in the reference ("parity unpinned"): restated with the one-sided Jacobi SVD and Householder QR of
@@ -279,6 +282,70 @@ inline TensorQrResult tensor_qr(const DenseTensor& t, const std::vector<int64_t>
     o.r.resize(r * n);
     for (size_t j = 0; j < n; ++j)
         for (size_t i = 0; i < r; ++i) o.r[i + r * j] = d.r(i, j);
+    return o;
+}
+
+struct TensorFactorizeResult {
+    size_t rank = 0;
+    std::vector<double> left, right; // left: [left.., rank], right: [rank, right..]
+    std::vector<double> singular_values; // SVD only
+    std::vector<size_t> left_dims, right_dims;
+};
+// alg: 0 SVD, 1 QR, 2 LU, 3 CI; canonical: 0 Left, 1 Right
+inline TensorFactorizeResult tensor_factorize(const DenseTensor& t, const std::vector<int64_t>& left, int alg, int canonical,
+                                              bool full_rank, const SvdPolicy& policy, size_t max_bond_dim, bool has_max_bond_dim,
+                                              double qr_rtol)
+{
+    TensorFactorizeResult o;
+    if (alg == 0) {
+        TensorSvdResult d = tensor_svd(t, left, !full_rank, policy, max_bond_dim, has_max_bond_dim && !full_rank);
+        const size_t r = d.rank;
+        size_t m = 1, n = 1;
+        for (size_t x : d.left_dims) m *= x;
+        for (size_t x : d.right_dims) n *= x;
+        o.rank = r;
+        o.left_dims = d.left_dims;
+        o.right_dims = d.right_dims;
+        o.singular_values = d.s;
+        o.left.resize(m * r);
+        o.right.resize(r * n);
+        for (size_t j = 0; j < r; ++j)
+            for (size_t i = 0; i < m; ++i) o.left[i + m * j] = canonical == 0 ? d.u[i + m * j] : d.u[i + m * j] * d.s[j];
+        for (size_t j = 0; j < n; ++j)
+            for (size_t i = 0; i < r; ++i) o.right[i + r * j] = canonical == 0 ? d.s[i] * d.v[j + n * i] : d.v[j + n * i];
+        return o;
+    }
+    if (alg == 1) {
+        TensorQrResult d = tensor_qr(t, left, !full_rank, qr_rtol);
+        o.rank = d.rank;
+        o.left = d.q;
+        o.right = d.r;
+        o.left_dims = d.left_dims;
+        o.right_dims = d.right_dims;
+        return o;
+    }
+    UnfoldResult un = tensor_unfold_split(t, left);
+    RrLUOptions lo;
+    lo.max_bond_dim = (full_rank || !has_max_bond_dim) ? std::numeric_limits<size_t>::max() : max_bond_dim;
+    lo.rel_tol = full_rank ? 0.0 : 1e-14;
+    lo.abs_tol = 0.0;
+    lo.left_orthogonal = canonical == 0;
+    o.left_dims = un.left_dims;
+    o.right_dims = un.right_dims;
+    if (alg == 2) {
+        RrLU lu = rrlu(un.m, lo);
+        o.rank = lu.npivots();
+        o.left = lu.left(true).a;
+        o.right = lu.right(true).a;
+    } else if (alg == 3) {
+        MatrixLuciFactors f = matrix_luci_factors_from_matrix(un.m, lo);
+        o.rank = f.rank;
+        o.left = f.left.a;
+        o.right = f.right.a;
+    } else {
+        throw OracleError(ERR_INVALID_ARGUMENT, "unknown factorization algorithm");
+    }
+    if (o.rank == 0) throw OracleError(ERR_INVALID_ARGUMENT, "Failed to create bond index: dimension 0");
     return o;
 }
 

@@ -2475,4 +2475,114 @@ t4a_gpu_status t4a_gpu_tensor_qr(const t4a_gpu_tensor* t, const int64_t* left_la
     });
 }
 
+t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t alg,
+                                        int32_t canonical, int32_t full_rank, const t4a_gpu_svd_policy* policy,
+                                        int32_t has_max_bond_dim, size_t max_bond_dim, int32_t has_qr_rtol, double qr_rtol,
+                                        int64_t bond_label, t4a_gpu_tensor** left, t4a_gpu_tensor** right, size_t* rank,
+                                        double* singular_values)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(t);
+        T4A_REQUIRE_PTR(left);
+        T4A_REQUIRE_PTR(right);
+        *left = *right = nullptr;
+        if (n_left) T4A_REQUIRE_PTR(left_labels);
+        if (alg < 0 || alg > 3) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown factorization algorithm");
+        if (canonical < 0 || canonical > 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown canonical direction");
+        const TensorView tv = t->view();
+        const std::vector<int64_t> lf(left_labels, left_labels + n_left);
+        const UnfoldPlan un = plan_unfold_split(tv, lf);
+        const bool trunc = full_rank == 0;
+        SvdPolicy pol = convert_policy(policy);
+        if (alg == 0 && trunc) {
+            if (has_max_bond_dim && max_bond_dim == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "max_bond_dim must be positive when specified");
+            if (!std::isfinite(pol.threshold) || pol.threshold < 0.0)
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "Invalid SVD truncation threshold: threshold must be finite and non-negative");
+        }
+        const double tol = has_qr_rtol ? qr_rtol : 1e-15;
+        if (alg == 1 && trunc && (!std::isfinite(tol) || tol < 0.0))
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "Invalid rtol value: rtol must be finite and non-negative");
+        const size_t m = un.m, n = un.n, k = std::min(m, n), count = tv.size();
+        if (count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "factorization of an empty tensor");
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "factorize: unfolded dimensions above 65535 are not supported");
+        std::vector<int64_t> right_labels;
+        for (size_t a = n_left; a < un.perm.size(); ++a) right_labels.push_back(tv.labels[un.perm[a]]);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        hipStream_t st = e.stream();
+        double* d_mat = e.pi(count);
+        tensor_permute(e, tv, un.perm, d_mat);
+        size_t keep = 0;
+        auto finish = [&](const double* d_l, int ldl, const double* d_r, int ldr) {
+            // d_l: m x keep (ld ldl), d_r: keep x n (ld ldr) -> handles
+            std::vector<size_t> ld = un.left_dims, rd{keep};
+            std::vector<int64_t> ll = lf, rl{bond_label};
+            ld.push_back(keep);
+            ll.push_back(bond_label);
+            rd.insert(rd.end(), un.right_dims.begin(), un.right_dims.end());
+            rl.insert(rl.end(), right_labels.begin(), right_labels.end());
+            auto tl = make_tensor(ld, ll), tr = make_tensor(rd, rl);
+            gather_launch(d_l, ldl, nullptr, (int)m, nullptr, (int)keep, tl->buf.get(), (int)m, st);
+            gather_launch(d_r, ldr, nullptr, (int)keep, nullptr, (int)n, tr->buf.get(), (int)keep, st);
+            T4A_HIP(hipGetLastError());
+            e.sync();
+            if (rank) *rank = keep;
+            *left = tl.release();
+            *right = tr.release();
+        };
+        if (alg == 0) { // SVD
+            e.d_tmp.reserve(m * k + k + k * n);
+            e.d_tmp2.reserve(std::max(m, n) * k);
+            double* d_u = e.d_tmp.get();
+            double* d_s = d_u + m * k;
+            double* d_vt = d_s + k;
+            e.svd(d_mat, (int)m, (int)n, d_u, d_s, d_vt);
+            std::vector<double> hs(k);
+            download(e, hs.data(), d_s, k);
+            keep = k;
+            if (trunc) {
+                keep = svd_retained_rank(hs.data(), k, pol);
+                if (has_max_bond_dim) keep = std::min(keep, max_bond_dim);
+            }
+            keep = std::min(std::max<size_t>(keep, 1), k);
+            if (singular_values) std::copy(hs.begin(), hs.begin() + keep, singular_values);
+            if (canonical == 0) { // right = S V^H
+                diag_scale_launch(d_vt, (int)k, (int)keep, (int)n, d_s, true, e.d_tmp2.get(), (int)keep, st);
+                finish(d_u, (int)m, e.d_tmp2.get(), (int)keep);
+            } else { // left = U S
+                diag_scale_launch(d_u, (int)m, (int)m, (int)keep, d_s, false, e.d_tmp2.get(), (int)m, st);
+                finish(e.d_tmp2.get(), (int)m, d_vt, (int)k);
+            }
+        } else if (alg == 1) { // QR
+            e.d_tmp.reserve(m * k + k * n);
+            double* d_q = e.d_tmp.get();
+            double* d_r = d_q + m * k;
+            e.qr(d_mat, (int)m, (int)n, d_q, d_r);
+            keep = k;
+            if (trunc) {
+                std::vector<double> hr(k * n);
+                download(e, hr.data(), d_r, k * n);
+                keep = std::min(qr_retained_rank(hr.data(), k, n, tol), k);
+            }
+            finish(d_q, (int)m, d_r, (int)k);
+        } else { // LU / CI on the rrLU kernels
+            RrLUOptions lo;
+            lo.max_bond_dim = (!trunc || !has_max_bond_dim) ? std::numeric_limits<size_t>::max() : max_bond_dim;
+            lo.rel_tol = trunc ? 1e-14 : 0.0;
+            lo.abs_tol = 0.0;
+            lo.left_orthogonal = canonical == 0;
+            if (alg == 2) {
+                LuciResult r = e.luci(d_mat, (int)m, (int)n, lo, false, true);
+                e.lu_permuted_factors(r, lo.left_orthogonal);
+                keep = (size_t)r.rank;
+            } else {
+                LuciResult r = e.luci(d_mat, (int)m, (int)n, lo, true, false);
+                keep = (size_t)r.rank;
+            }
+            if (keep == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "Failed to create bond index: dimension 0");
+            finish(e.left(), (int)m, e.right(), (int)keep);
+        }
+    });
+}
+
 } // extern "C"

@@ -88,6 +88,16 @@ __global__ void __launch_bounds__(256) permute_kernel(const double* __restrict__
     }
 }
 
+__global__ void __launch_bounds__(256) diag_scale_kernel(const double* __restrict__ in, int ldi, int rows, int cols,
+                                                         const double* __restrict__ s, int by_row, double* __restrict__ out, int ldo)
+{
+    const size_t total = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % (size_t)rows), j = (int)(e / (size_t)rows);
+        out[i + (size_t)ldo * j] = in[i + (size_t)ldi * j] * (by_row ? s[i] : s[j]);
+    }
+}
+
 void validate(const TensorView& t, const char* who)
 {
     if (t.dims.size() != t.labels.size()) throw Error(T4A_GPU_INVALID_ARGUMENT, std::string(who) + ": dims / labels length mismatch");
@@ -229,6 +239,15 @@ UnfoldPlan plan_unfold_split(const TensorView& t, const std::vector<int64_t>& le
         }
     }
     return p;
+}
+
+void diag_scale_launch(const double* in, int ldi, int rows, int cols, const double* sv, bool by_row, double* out, int ldo,
+                       hipStream_t stream)
+{
+    const size_t total = (size_t)rows * cols;
+    if (total == 0) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(diag_scale_kernel, dim3(blocks), dim3(256), 0, stream, in, ldi, rows, cols, sv, by_row ? 1 : 0, out, ldo);
 }
 
 } // namespace t4a

@@ -55,4 +55,8 @@ struct UnfoldPlan {
 };
 UnfoldPlan plan_unfold_split(const TensorView& t, const std::vector<int64_t>& left);
 
+// out[i + ldo*j] = in[i + ldi*j] * (by_row ? s[i] : s[j])   (S absorbed into a factor, factorize.rs:519-557)
+void diag_scale_launch(const double* in, int ldi, int rows, int cols, const double* s, bool by_row, double* out, int ldo,
+                       hipStream_t stream);
+
 } // namespace t4a

@@ -1510,3 +1510,27 @@ class LabelledTensor:
                                       c_int32(0 if rtol is None else 1), c_double(0.0 if rtol is None else rtol),
                                       ctypes.c_int64(bond_label), ctypes.byref(q), ctypes.byref(r)))
         return LabelledTensor(_handle=q), LabelledTensor(_handle=r)
+
+
+FACTORIZE_SVD, FACTORIZE_QR, FACTORIZE_LU, FACTORIZE_CI = 0, 1, 2, 3
+CANONICAL_LEFT, CANONICAL_RIGHT = 0, 1
+
+
+def _factorize(self, left, bond_label, alg=FACTORIZE_SVD, canonical=CANONICAL_LEFT, full_rank=False, policy=None,
+               max_bond_dim=None, qr_rtol=None):
+    """factorize / factorize_full_rank (core/src/defaults/factorize.rs:86): returns (left, right, rank, singular values or None)"""
+    lf = np.asarray(left, dtype=np.int64)
+    pc = None if policy is None else policy.to_c()
+    hl, hr, rank = c_void_p(), c_void_p(), c_size_t(0)
+    dims = self.dims
+    sv = np.zeros(max(int(np.prod(dims)), 1))
+    _check(_lib.t4a_gpu_tensor_factorize(self._h, _p(lf) if len(lf) else None, c_size_t(len(lf)), c_int32(alg), c_int32(canonical),
+                                         c_int32(int(full_rank)), None if pc is None else ctypes.byref(pc),
+                                         c_int32(0 if max_bond_dim is None else 1), c_size_t(0 if max_bond_dim is None else max_bond_dim),
+                                         c_int32(0 if qr_rtol is None else 1), c_double(0.0 if qr_rtol is None else qr_rtol),
+                                         ctypes.c_int64(bond_label), ctypes.byref(hl), ctypes.byref(hr), ctypes.byref(rank), _p(sv)))
+    return (LabelledTensor(_handle=hl), LabelledTensor(_handle=hr), rank.value,
+            sv[:rank.value].copy() if alg == FACTORIZE_SVD else None)
+
+
+LabelledTensor.factorize = _factorize

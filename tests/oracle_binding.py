@@ -1082,3 +1082,26 @@ def tensor_qr(t, labels, left, truncate=True, rtol=1e-15):
                                     ctypes.byref(r), _p(q), _p(rr_)))
     rr = r.value
     return q[:m * rr].reshape(ld + [rr], order="F"), rr_[:rr * n].reshape([rr] + rd, order="F")
+
+
+SVD, QR, LU, CI = 0, 1, 2, 3
+LEFT, RIGHT = 0, 1
+
+
+def tensor_factorize(t, labels, left, alg=SVD, canonical=LEFT, full_rank=False, threshold=1e-12, scale=0, measure=0, rule=0,
+                     max_bond_dim=None, qr_rtol=1e-15):
+    """factorize: returns (left [left.., r], right [r, right..], singular values or None)"""
+    a, dims, lab = _tensor_args(t, labels)
+    lf = np.asarray(left, dtype=np.int64)
+    ld, rd = _split_shapes(list(a.shape), list(labels), list(left))
+    m, n = int(np.prod(ld)), int(np.prod(rd))
+    k = max(min(m, n), 1)
+    lo, ro, sv = np.zeros(m * k), np.zeros(k * n), np.zeros(k)
+    r = u64(0)
+    _check_tt(_lib.oracle_tensor_factorize(_p(a), _p(dims), _p(lab), u64(a.ndim), _p(lf), u64(len(lf)), cint(alg), cint(canonical),
+                                           cint(int(full_rank)), dbl(threshold), cint(scale), cint(measure), cint(rule),
+                                           u64(NO_MAX if max_bond_dim is None else max_bond_dim), dbl(qr_rtol), ctypes.byref(r),
+                                           _p(lo), _p(ro), _p(sv)))
+    rr = r.value
+    return (lo[:m * rr].reshape(ld + [rr], order="F"), ro[:rr * n].reshape([rr] + rd, order="F"),
+            sv[:rr].copy() if alg == SVD else None)

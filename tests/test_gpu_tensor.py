@@ -168,3 +168,39 @@ def test_device_resident_tensor_chain(t4a):
         T[0].permute([100, 0])
     with pytest.raises(t4a.T4aError):
         T[0].relabel(0, 100)
+
+
+@pytest.mark.parametrize("alg", [0, 1, 2, 3])
+@pytest.mark.parametrize("canonical", [0, 1])
+def test_factorize_matches_oracle(t4a, alg, canonical):
+    # defaults/factorize.rs:86-834 — SVD / QR / LU / CI with Left / Right canonical forms on device handles
+    rng = np.random.default_rng(10 * alg + canonical)
+    t = rng.standard_normal((4, 3, 5, 2))
+    labels = [1, 2, 3, 4]
+    T = t4a.LabelledTensor(t, labels)
+    l, r, rank, sv = T.factorize([3, 1], 900, alg=alg, canonical=canonical)
+    ol, orr, osv = ob.tensor_factorize(t, labels, [3, 1], alg=alg, canonical=canonical)
+    assert l.labels == [3, 1, 900] and r.labels == [900, 2, 4] and rank == 6 == ol.shape[-1]
+    assert np.abs(np.einsum("cak,kbd->abcd", l.to_numpy(), r.to_numpy()) - t).max() < 1e-11
+    if alg in (2, 3):  # rrLU based: bit-exact pivots -> identical factors up to the triangular solves
+        assert np.abs(l.to_numpy() - ol).max() < 1e-10 and np.abs(r.to_numpy() - orr).max() < 1e-10
+    if alg == 0:
+        assert np.abs(sv - osv).max() < 1e-12 * osv[0]
+        lm, rm = l.to_numpy().reshape(20, 6, order="F"), r.to_numpy().reshape(6, 6, order="F")
+        iso = lm.T @ lm if canonical == 0 else rm @ rm.T
+        assert np.abs(iso - np.eye(6)).max() < 1e-11
+    low = np.einsum("ia,ja->ij", rng.standard_normal((40, 3)), rng.standard_normal((30, 3))).reshape(40, 6, 5, order="F")
+    L = t4a.LabelledTensor(low, [7, 8, 9])
+    l, r, rank, sv = L.factorize([7], 901, alg=alg, canonical=canonical, qr_rtol=1e-10)
+    assert rank == 3 == ob.tensor_factorize(low, [7, 8, 9], [7], alg=alg, canonical=canonical, qr_rtol=1e-10)[0].shape[-1]
+    assert np.abs(np.einsum("ik,kab->iab", l.to_numpy(), r.to_numpy()) - low).max() < 1e-10
+    l, r, rank, sv = L.factorize([7], 902, alg=alg, canonical=canonical, full_rank=True)
+    assert np.abs(np.einsum("ik,kab->iab", l.to_numpy(), r.to_numpy()) - low).max() < 1e-10
+    if alg != 1:
+        l, r, rank, sv = T.factorize([3, 1], 903, alg=alg, canonical=canonical, max_bond_dim=3)
+        assert rank == 3 and l.dims == [5, 4, 3]
+    with pytest.raises(t4a.T4aError):
+        T.factorize([3, 1], 904, alg=7)
+    if alg in (2, 3):
+        with pytest.raises(t4a.T4aError):
+            t4a.LabelledTensor(np.zeros((3, 4)), [1, 2]).factorize([1], 905, alg=alg)

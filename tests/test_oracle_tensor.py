@@ -89,3 +89,32 @@ def test_contract_pair_matches_einsum_and_index_order():
         ob.tensor_contract(a, [1, 2, 3], b, [1, 4, 6])  # common index 1 has dims 3 vs 5
     with pytest.raises(ob.OracleError):
         ob.tensor_contract(a, [1, 1, 3], b, [6, 7, 8])
+
+
+@pytest.mark.parametrize("alg", [ob.SVD, ob.QR, ob.LU, ob.CI])
+@pytest.mark.parametrize("canonical", [ob.LEFT, ob.RIGHT])
+def test_factorize_reconstructs_and_is_canonical(alg, canonical):
+    # defaults/factorize.rs: every algorithm returns left [left.., bond] * right [bond, right..] == t
+    rng = np.random.default_rng(10 * alg + canonical)
+    t = rng.standard_normal((4, 3, 5, 2))
+    labels = [1, 2, 3, 4]
+    l, r, sv = ob.tensor_factorize(t, labels, [3, 1], alg=alg, canonical=canonical)
+    k = l.shape[-1]
+    assert l.shape == (5, 4, k) and r.shape == (k, 3, 2) and k == 6
+    assert np.abs(np.einsum("cak,kbd->abcd", l, r) - t).max() < 1e-11
+    lm, rm = l.reshape(20, k, order="F"), r.reshape(k, 6, order="F")
+    if alg == ob.SVD:
+        assert sv is not None and np.all(np.diff(sv) <= 0)
+        iso = lm.T @ lm if canonical == ob.LEFT else rm @ rm.T
+        assert np.abs(iso - np.eye(k)).max() < 1e-11
+    if alg == ob.QR:
+        assert np.abs(lm.T @ lm - np.eye(k)).max() < 1e-11
+    low = np.einsum("ia,ja->ij", rng.standard_normal((12, 2)), rng.standard_normal((10, 2))).reshape(12, 5, 2, order="F")
+    l, r, sv = ob.tensor_factorize(low, [7, 8, 9], [7], alg=alg, canonical=canonical, qr_rtol=1e-10)
+    assert l.shape[-1] == 2 and np.abs(np.einsum("ik,kab->iab", l, r) - low).max() < 1e-10
+    l, r, sv = ob.tensor_factorize(low, [7, 8, 9], [7], alg=alg, canonical=canonical, full_rank=True)
+    assert l.shape[-1] == (10 if alg in (ob.SVD, ob.QR) else l.shape[-1])
+    assert np.abs(np.einsum("ik,kab->iab", l, r) - low).max() < 1e-10
+    if alg != ob.QR:
+        l, r, sv = ob.tensor_factorize(t, labels, [3, 1], alg=alg, canonical=canonical, max_bond_dim=3)
+        assert l.shape[-1] == 3
