@@ -2,6 +2,7 @@
 // C entry points for the tensor-train side of the CPU restatement (SURVEY.md §8 rows a14–a18).
 #include "t4a_oracle_tt.hpp"
 #include "t4a_oracle_tensor.hpp"
+#include "t4a_oracle_aci.hpp"
 
 #include <cstring>
 #include <memory>
@@ -321,6 +322,174 @@ int oracle_tensor_factorize(const double* t, const uint64_t* dims, const int64_t
         std::copy(o.right.begin(), o.right.end(), rout);
         if (sv) std::copy(o.singular_values.begin(), o.singular_values.end(), sv);
     });
+}
+
+// ---- tensor4all-aci: elementwise / elementwise_batched (t4a_oracle_aci.hpp) ----
+struct oracle_aci_options {
+    uint64_t max_iters, min_iters;
+    int32_t has_max_bond_dim;
+    uint64_t max_bond_dim;
+    double tolerance;
+    int32_t scale_tolerance;
+    uint64_t rng_seed;
+    int32_t enable_global_guard;
+    uint64_t nsearch_global_pivots, max_nglobal_pivot, nsweeps_global_search;
+    double tol_margin_global_search;
+};
+typedef int (*oracle_aci_op_fn)(void* user, const double* values, uint64_t n_inputs, uint64_t n_points, double* out);
+
+namespace {
+struct OracleAci {
+    AciResult res;
+};
+AciOp make_aci_op(int op_kind, oracle_aci_op_fn cb, void* user)
+{
+    if (op_kind == 1)
+        return [](const double* v, size_t K, size_t np, double* out) {
+            for (size_t p = 0; p < np; ++p) {
+                double acc = v[K * p];
+                for (size_t k = 1; k < K; ++k) acc = acc * v[k + K * p];
+                out[p] = acc;
+            }
+        };
+    if (op_kind == 2)
+        return [](const double* v, size_t K, size_t np, double* out) {
+            for (size_t p = 0; p < np; ++p) {
+                double acc = v[K * p];
+                for (size_t k = 1; k < K; ++k) acc = acc + v[k + K * p];
+                out[p] = acc;
+            }
+        };
+    if (!cb) throw OracleError(ERR_INVALID_ARGUMENT, "operator callback is null");
+    return [cb, user](const double* v, size_t K, size_t np, double* out) {
+        if (cb(user, v, K, np, out) != 0) throw OracleError(ERR_INVALID_ARGUMENT, "operator callback failed");
+    };
+}
+AciOptions convert_aci(const oracle_aci_options* o, void* guess)
+{
+    AciOptions a;
+    if (o) {
+        a.max_iters = o->max_iters;
+        a.min_iters = o->min_iters;
+        a.has_max_bond_dim = o->has_max_bond_dim != 0;
+        a.max_bond_dim = o->max_bond_dim;
+        a.tolerance = o->tolerance;
+        a.scale_tolerance = o->scale_tolerance != 0;
+        a.rng_seed = o->rng_seed;
+        a.enable_global_guard = o->enable_global_guard != 0;
+        a.nsearch_global_pivots = o->nsearch_global_pivots;
+        a.max_nglobal_pivot = o->max_nglobal_pivot;
+        a.nsweeps_global_search = o->nsweeps_global_search;
+        a.tol_margin_global_search = o->tol_margin_global_search;
+    }
+    if (guess) {
+        a.has_initial_guess = true;
+        a.initial_guess = static_cast<OracleTT*>(guess)->tt;
+    }
+    return a;
+}
+} // namespace
+
+void* oracle_aci_elementwise(void* const* inputs, uint64_t n_inputs, int op_kind, oracle_aci_op_fn cb, void* user,
+                             const oracle_aci_options* opts, void* initial_guess)
+{
+    OracleAci* h = nullptr;
+    const int rc = guarded([&] {
+        std::vector<SimpleTensorTrain> in;
+        for (uint64_t k = 0; k < n_inputs; ++k) in.push_back(static_cast<OracleTT*>(inputs[k])->tt);
+        auto r = std::make_unique<OracleAci>();
+        r->res = elementwise_batched(make_aci_op(op_kind, cb, user), in, convert_aci(opts, initial_guess));
+        h = r.release();
+    });
+    return rc == 0 ? h : nullptr;
+}
+void oracle_aci_release(void* h) { delete static_cast<OracleAci*>(h); }
+void* oracle_aci_tensor_train(void* h)
+{
+    auto* t = new OracleTT;
+    t->tt = static_cast<OracleAci*>(h)->res.tensor_train;
+    return t;
+}
+uint64_t oracle_aci_n_iters(void* h) { return static_cast<OracleAci*>(h)->res.ranks.size(); }
+int oracle_aci_termination(void* h) { return (int)static_cast<OracleAci*>(h)->res.termination; }
+void oracle_aci_history(void* h, uint64_t* ranks, double* errors, uint64_t* nglobal)
+{
+    const AciResult& r = static_cast<OracleAci*>(h)->res;
+    for (size_t i = 0; i < r.ranks.size(); ++i) {
+        ranks[i] = r.ranks[i];
+        errors[i] = r.errors[i];
+        nglobal[i] = r.nglobal_pivots[i];
+    }
+}
+
+// ElementwiseProblem stepping interface (state.rs) for white-box parity tests
+namespace {
+struct OracleAciProblem {
+    std::unique_ptr<ElementwiseProblem> p;
+    AciOptions o;
+    AciOp op;
+};
+} // namespace
+void* oracle_aci_problem_new(void* const* inputs, uint64_t n_inputs, int op_kind, oracle_aci_op_fn cb, void* user,
+                             const oracle_aci_options* opts, void* initial_guess)
+{
+    OracleAciProblem* h = nullptr;
+    const int rc = guarded([&] {
+        std::vector<SimpleTensorTrain> in;
+        for (uint64_t k = 0; k < n_inputs; ++k) in.push_back(static_cast<OracleTT*>(inputs[k])->tt);
+        auto r = std::make_unique<OracleAciProblem>();
+        r->o = convert_aci(opts, initial_guess);
+        r->op = make_aci_op(op_kind, cb, user);
+        r->p = std::make_unique<ElementwiseProblem>(std::move(in), r->o);
+        h = r.release();
+    });
+    return rc == 0 ? h : nullptr;
+}
+void oracle_aci_problem_release(void* h) { delete static_cast<OracleAciProblem*>(h); }
+int oracle_aci_problem_local_update(void* h, uint64_t bond, int left_orthogonal)
+{
+    return guarded([&] {
+        auto* s = static_cast<OracleAciProblem*>(h);
+        s->p->local_update(bond, left_orthogonal != 0, s->o, s->op);
+    });
+}
+int oracle_aci_problem_add_global_pivots(void* h, const uint64_t* pivots /* n_sites x n col-major */, uint64_t n, uint64_t* added)
+{
+    return guarded([&] {
+        auto* s = static_cast<OracleAciProblem*>(h);
+        const size_t ns = s->p->len();
+        std::vector<MultiIndex> pv(n, MultiIndex(ns));
+        for (size_t p = 0; p < n; ++p)
+            for (size_t q = 0; q < ns; ++q) pv[p][q] = pivots[q + ns * p];
+        *added = s->p->add_global_pivots(pv);
+    });
+}
+void* oracle_aci_problem_solution(void* h)
+{
+    auto* t = new OracleTT;
+    t->tt = static_cast<OracleAciProblem*>(h)->p->solution;
+    return t;
+}
+// frame shape (rows, cols) or (0, 0) when absent; data column-major
+int oracle_aci_problem_frame(void* h, int right, uint64_t input, uint64_t site, uint64_t* rows, uint64_t* cols, double* out)
+{
+    return guarded([&] {
+        auto* s = static_cast<OracleAciProblem*>(h);
+        const auto& fr = right ? s->p->right_frames : s->p->left_frames;
+        if (input >= fr.size() || site >= fr[input].size()) throw OracleError(ERR_INVALID_ARGUMENT, "frame index out of range");
+        const AciFrame& f = fr[input][site];
+        *rows = f.present ? f.m.nr : 0;
+        *cols = f.present ? f.m.nc : 0;
+        if (out && f.present) to_ptr(f.m, out);
+    });
+}
+void oracle_aci_problem_errors(void* h, double* pivot_errors, double* pivot_scales)
+{
+    auto* s = static_cast<OracleAciProblem*>(h);
+    for (size_t b = 0; b < s->p->pivot_errors.size(); ++b) {
+        pivot_errors[b] = s->p->pivot_errors[b];
+        pivot_scales[b] = s->p->pivot_scales[b];
+    }
 }
 
 } // extern "C"

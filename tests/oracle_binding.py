@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp", "t4a_oracle_patch.hpp",
-                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp", "t4a_oracle_quantics.hpp", "t4a_oracle_tensor.hpp")] + [
+                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp", "t4a_oracle_quantics.hpp", "t4a_oracle_tensor.hpp", "t4a_oracle_aci.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -1105,3 +1105,138 @@ def tensor_factorize(t, labels, left, alg=SVD, canonical=LEFT, full_rank=False, 
     rr = r.value
     return (lo[:m * rr].reshape(ld + [rr], order="F"), ro[:rr * n].reshape([rr] + rd, order="F"),
             sv[:rr].copy() if alg == SVD else None)
+
+
+# ---- tensor4all-aci (oracle/t4a_oracle_aci.hpp) ----
+class _AciOptionsC(ctypes.Structure):
+    _fields_ = [("max_iters", u64), ("min_iters", u64), ("has_max_bond_dim", ctypes.c_int32), ("max_bond_dim", u64),
+                ("tolerance", dbl), ("scale_tolerance", ctypes.c_int32), ("rng_seed", u64), ("enable_global_guard", ctypes.c_int32),
+                ("nsearch_global_pivots", u64), ("max_nglobal_pivot", u64), ("nsweeps_global_search", u64),
+                ("tol_margin_global_search", dbl)]
+
+
+class AciOptions:
+    """AciOptions (crates/tensor4all-aci/src/options.rs:37-168), same defaults"""
+
+    def __init__(self, max_iters=20, min_iters=2, max_bond_dim=None, tolerance=1e-12, scale_tolerance=True, initial_guess=None,
+                 rng_seed=0, enable_global_guard=True, nsearch_global_pivots=5, max_nglobal_pivot=5, nsweeps_global_search=100,
+                 tol_margin_global_search=10.0):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+    def to_c(self):
+        return _AciOptionsC(self.max_iters, self.min_iters, 0 if self.max_bond_dim is None else 1, self.max_bond_dim or 0,
+                            self.tolerance, int(self.scale_tolerance), self.rng_seed, int(self.enable_global_guard),
+                            self.nsearch_global_pivots, self.max_nglobal_pivot, self.nsweeps_global_search,
+                            self.tol_margin_global_search)
+
+
+ACI_OP_FN = ctypes.CFUNCTYPE(cint, vp, ctypes.POINTER(dbl), u64, u64, ctypes.POINTER(dbl))
+ACI_CALLBACK, ACI_PRODUCT, ACI_SUM = 0, 1, 2
+_lib.oracle_aci_elementwise.restype = vp
+_lib.oracle_aci_tensor_train.restype = vp
+_lib.oracle_aci_n_iters.restype = u64
+_lib.oracle_aci_problem_new.restype = vp
+_lib.oracle_aci_problem_solution.restype = vp
+
+
+def _tt_from_handle(h):
+    t = OracleTT.__new__(OracleTT)
+    t._h = h
+    return t
+
+
+def _aci_op(op):
+    """op: ACI_PRODUCT / ACI_SUM or a python callable values (n_inputs, n_points) -> (n_points,)"""
+    if not callable(op):
+        return int(op), ACI_OP_FN(), None
+
+    def tramp(user, values, n_inputs, n_points, out):
+        try:
+            v = np.ctypeslib.as_array(values, shape=(n_points * n_inputs,)).reshape((n_inputs, n_points), order="F")
+            np.ctypeslib.as_array(out, shape=(n_points,))[:] = op(v)
+            return 0
+        except Exception:  # noqa: BLE001
+            return 1
+    cb = ACI_OP_FN(tramp)
+    return ACI_CALLBACK, cb, cb
+
+
+def _aci_inputs(inputs):
+    tts = [t if isinstance(t, OracleTT) else OracleTT(t) for t in inputs]
+    arr = (vp * len(tts))(*[t._h for t in tts])
+    return tts, arr
+
+
+class AciResult:
+    pass
+
+
+def aci_elementwise(op, inputs, options=None):
+    """elementwise_batched (elementwise.rs:107); inputs: lists of (l, s, r) cores or OracleTT"""
+    o = options or AciOptions()
+    tts, arr = _aci_inputs(inputs)
+    kind, cb, keep = _aci_op(op)
+    guess = None if o.initial_guess is None else (o.initial_guess if isinstance(o.initial_guess, OracleTT) else OracleTT(o.initial_guess))
+    oc = o.to_c()
+    h = _lib.oracle_aci_elementwise(arr, u64(len(tts)), cint(kind), cb, None, ctypes.byref(oc), vp(guess._h) if guess else None)
+    if not h:
+        _check_tt(-2)
+    try:
+        r = AciResult()
+        r.tensor_train = _tt_from_handle(_lib.oracle_aci_tensor_train(vp(h)))
+        n = int(_lib.oracle_aci_n_iters(vp(h)))
+        ranks, errs, ng = np.zeros(n, dtype=np.uint64), np.zeros(n), np.zeros(n, dtype=np.uint64)
+        _lib.oracle_aci_history(vp(h), _p(ranks), _p(errs), _p(ng))
+        r.ranks, r.errors, r.nglobal_pivots = [int(x) for x in ranks], list(errs), [int(x) for x in ng]
+        r.termination = int(_lib.oracle_aci_termination(vp(h)))
+        return r
+    finally:
+        _lib.oracle_aci_release(vp(h))
+
+
+class OracleAciProblem:
+    """ElementwiseProblem (state.rs:24) stepping interface"""
+
+    def __init__(self, op, inputs, options=None):
+        o = options or AciOptions()
+        self._tts, arr = _aci_inputs(inputs)
+        kind, cb, self._keep = _aci_op(op)
+        guess = None if o.initial_guess is None else (o.initial_guess if isinstance(o.initial_guess, OracleTT) else OracleTT(o.initial_guess))
+        oc = o.to_c()
+        self._h = _lib.oracle_aci_problem_new(arr, u64(len(self._tts)), cint(kind), cb, None, ctypes.byref(oc),
+                                              vp(guess._h) if guess else None)
+        if not self._h:
+            _check_tt(-2)
+        self.n_sites = len(self._tts[0])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.oracle_aci_problem_release(vp(self._h))
+            self._h = None
+
+    def local_update(self, bond, left_orthogonal):
+        _check_tt(_lib.oracle_aci_problem_local_update(vp(self._h), u64(bond), cint(int(left_orthogonal))))
+
+    def add_global_pivots(self, pivots):
+        pv = np.asfortranarray(np.asarray(pivots, dtype=np.uint64).reshape(-1, self.n_sites).T)
+        added = u64(0)
+        _check_tt(_lib.oracle_aci_problem_add_global_pivots(vp(self._h), _p(pv), u64(pv.shape[1]), ctypes.byref(added)))
+        return int(added.value)
+
+    def solution(self):
+        return _tt_from_handle(_lib.oracle_aci_problem_solution(vp(self._h)))
+
+    def frame(self, right, input, site):
+        r, c = u64(0), u64(0)
+        _check_tt(_lib.oracle_aci_problem_frame(vp(self._h), cint(int(right)), u64(input), u64(site), ctypes.byref(r), ctypes.byref(c), None))
+        if r.value == 0:
+            return None
+        out = np.zeros(r.value * c.value)
+        _check_tt(_lib.oracle_aci_problem_frame(vp(self._h), cint(int(right)), u64(input), u64(site), ctypes.byref(r), ctypes.byref(c), _p(out)))
+        return out.reshape((r.value, c.value), order="F")
+
+    def errors(self):
+        e, sc = np.zeros(self.n_sites - 1), np.zeros(self.n_sites - 1)
+        _lib.oracle_aci_problem_errors(vp(self._h), _p(e), _p(sc))
+        return e, sc
