@@ -565,6 +565,59 @@ t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* 
                                         int64_t bond_label, t4a_gpu_tensor** left, t4a_gpu_tensor** right, size_t* rank,
                                         double* singular_values);
 
+/* ---- tensor4all-aci: Alternating Cross Interpolation of an elementwise operator over tensor trains ----
+ * (crates/tensor4all-aci/src: elementwise.rs:107-218, state.rs:24-925, local.rs:299-394, global_guard.rs:49-181).
+ * Inputs are device-resident trains (t4a_gpu_tt handles); the local candidate matrices are built, pivoted (rrLU) and
+ * factorised on the device. */
+typedef struct t4a_gpu_aci_options { /* AciOptions (options.rs:37-168) */
+    size_t max_iters;                 /* 20 */
+    size_t min_iters;                 /* 2 */
+    int32_t has_max_bond_dim;         /* 0 <=> None */
+    size_t max_bond_dim;
+    double tolerance;                 /* 1e-12 */
+    int32_t scale_tolerance;          /* 1 */
+    uint64_t rng_seed;                /* 0 */
+    int32_t enable_global_guard;      /* 1 */
+    size_t nsearch_global_pivots;     /* 5 */
+    size_t max_nglobal_pivot;         /* 5 */
+    size_t nsweeps_global_search;     /* 100 */
+    double tol_margin_global_search;  /* 10.0 */
+} t4a_gpu_aci_options;
+t4a_gpu_status t4a_gpu_aci_options_default(t4a_gpu_aci_options* opts);
+/* elementwise_batched's operator (batch.rs:33-217): values[input + n_inputs * point] -> out[point]; non-zero return stops
+ * the sweep with T4A_GPU_CALLBACK_ERROR. */
+typedef int32_t (*t4a_gpu_aci_op_fn)(void* user, const double* values, size_t n_inputs, size_t n_points, double* out);
+/* op_kind: 0 callback `op`, 1 product of the inputs, 2 sum of the inputs (both fused into the candidate-matrix kernel) */
+#define T4A_GPU_ACI_OP_CALLBACK 0
+#define T4A_GPU_ACI_OP_PRODUCT 1
+#define T4A_GPU_ACI_OP_SUM 2
+/* elementwise_batched (elementwise.rs:107): initial_guess == NULL -> AciOptions::initial_guess None (random guess: the
+ * reference draws ChaCha8 normals, this library a splitmix64 stream — pass the guess for a reproducible match).  ranks /
+ * errors / nglobal_pivots need max_iters entries (NULL allowed); termination: 0 Converged, 1 RankLimited, 2 MaxIterations. */
+t4a_gpu_status t4a_gpu_aci_elementwise(const t4a_gpu_tt* const* inputs, size_t n_inputs, int32_t op_kind, t4a_gpu_aci_op_fn op,
+                                       void* user, const t4a_gpu_aci_options* options, const t4a_gpu_tt* initial_guess,
+                                       t4a_gpu_tt** result, size_t* n_iters, size_t* ranks, double* errors,
+                                       size_t* nglobal_pivots, int32_t* termination);
+/* ElementwiseProblem (state.rs:24-109) stepped bond by bond; the inputs must outlive the problem. */
+typedef struct t4a_gpu_aci_problem t4a_gpu_aci_problem;
+t4a_gpu_status t4a_gpu_aci_problem_new(const t4a_gpu_tt* const* inputs, size_t n_inputs, int32_t op_kind, t4a_gpu_aci_op_fn op,
+                                       void* user, const t4a_gpu_aci_options* options, const t4a_gpu_tt* initial_guess,
+                                       t4a_gpu_aci_problem** out);
+void t4a_gpu_aci_problem_release(t4a_gpu_aci_problem* h);
+/* local_update (state.rs:729-860) */
+t4a_gpu_status t4a_gpu_aci_problem_local_update(t4a_gpu_aci_problem* h, size_t bond, int32_t left_orthogonal);
+/* add_global_pivots (state.rs:551-652): pivots is n_sites x n_pivots column-major; added = injected pivot count */
+t4a_gpu_status t4a_gpu_aci_problem_add_global_pivots(t4a_gpu_aci_problem* h, const size_t* pivots, size_t n_pivots,
+                                                     size_t* added);
+/* find_global_pivots (global_guard.rs:49): out is n_sites x count column-major, capacity max_nglobal_pivot columns */
+t4a_gpu_status t4a_gpu_aci_problem_find_global_pivots(t4a_gpu_aci_problem* h, uint64_t seed, size_t* count, size_t* out);
+t4a_gpu_status t4a_gpu_aci_problem_solution(t4a_gpu_aci_problem* h, t4a_gpu_tt** out);
+/* left (right == 0) / right frame of `input` at `site` (0..n_sites): shape (0, 0) when absent; out may be NULL */
+t4a_gpu_status t4a_gpu_aci_problem_frame(t4a_gpu_aci_problem* h, int32_t right, size_t input, size_t site, size_t* rows,
+                                         size_t* cols, double* out);
+/* per bond: last pivot error and largest sampled operator magnitude (n_sites - 1 entries each) */
+t4a_gpu_status t4a_gpu_aci_problem_errors(const t4a_gpu_aci_problem* h, double* pivot_errors, double* pivot_scales);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */
 t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out);

@@ -9,6 +9,7 @@
 #include "tree.hpp"
 #include "quantics.hpp"
 #include "tensorops.hpp"
+#include "aci.hpp"
 
 struct t4a_gpu_tci2 {
     t4a::Tci2 impl;
@@ -2582,6 +2583,203 @@ t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* 
             if (keep == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "Failed to create bond index: dimension 0");
             finish(e.left(), (int)m, e.right(), (int)keep);
         }
+    });
+}
+
+// ---- tensor4all-aci ----
+t4a_gpu_status t4a_gpu_aci_options_default(t4a_gpu_aci_options* o)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(o);
+        const AciOptions d;
+        o->max_iters = d.max_iters;
+        o->min_iters = d.min_iters;
+        o->has_max_bond_dim = 0;
+        o->max_bond_dim = 0;
+        o->tolerance = d.tolerance;
+        o->scale_tolerance = 1;
+        o->rng_seed = 0;
+        o->enable_global_guard = 1;
+        o->nsearch_global_pivots = d.nsearch_global_pivots;
+        o->max_nglobal_pivot = d.max_nglobal_pivot;
+        o->nsweeps_global_search = d.nsweeps_global_search;
+        o->tol_margin_global_search = d.tol_margin_global_search;
+    });
+}
+
+} // extern "C"
+
+struct t4a_gpu_aci_problem {
+    std::unique_ptr<t4a::AciProblem> impl;
+};
+
+namespace {
+AciOptions convert_aci(const t4a_gpu_aci_options* o)
+{
+    AciOptions a;
+    if (o) {
+        a.max_iters = o->max_iters;
+        a.min_iters = o->min_iters;
+        a.has_max_bond_dim = o->has_max_bond_dim != 0;
+        a.max_bond_dim = o->max_bond_dim;
+        a.tolerance = o->tolerance;
+        a.scale_tolerance = o->scale_tolerance != 0;
+        a.rng_seed = o->rng_seed;
+        a.enable_global_guard = o->enable_global_guard != 0;
+        a.nsearch_global_pivots = o->nsearch_global_pivots;
+        a.max_nglobal_pivot = o->max_nglobal_pivot;
+        a.nsweeps_global_search = o->nsweeps_global_search;
+        a.tol_margin_global_search = o->tol_margin_global_search;
+    }
+    return a;
+}
+AciHostOp make_aci_op(int32_t kind, t4a_gpu_aci_op_fn op, void* user)
+{
+    if (kind < 0 || kind > 2) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown ACI operator kind");
+    if (kind != 0) return {};
+    if (!op) throw Error(T4A_GPU_NULL_POINTER, "operator callback is null");
+    return [op, user](const double* v, size_t K, size_t np, double* out) {
+        if (op(user, v, K, np, out) != 0) throw Error(T4A_GPU_CALLBACK_ERROR, "operator callback reported an error");
+    };
+}
+std::vector<TensorTrain*> aci_inputs(const t4a_gpu_tt* const* inputs, size_t n)
+{
+    if (n == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "inputs must not be empty");
+    if (!inputs) throw Error(T4A_GPU_NULL_POINTER, "inputs is null");
+    std::vector<TensorTrain*> v(n);
+    for (size_t k = 0; k < n; ++k) {
+        if (!inputs[k]) throw Error(T4A_GPU_NULL_POINTER, "input tensor train is null");
+        v[k] = const_cast<TensorTrain*>(&inputs[k]->impl);
+    }
+    return v;
+}
+} // namespace
+
+extern "C" {
+
+t4a_gpu_status t4a_gpu_aci_elementwise(const t4a_gpu_tt* const* inputs, size_t n_inputs, int32_t op_kind, t4a_gpu_aci_op_fn op,
+                                       void* user, const t4a_gpu_aci_options* options, const t4a_gpu_tt* initial_guess,
+                                       t4a_gpu_tt** result, size_t* n_iters, size_t* ranks, double* errors,
+                                       size_t* nglobal_pivots, int32_t* termination)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(result);
+        *result = nullptr;
+        const AciOptions o = convert_aci(options);
+        o.validate();
+        std::vector<TensorTrain*> in = aci_inputs(inputs, n_inputs);
+        AciHostOp hop = make_aci_op(op_kind, op, user);
+        require_device();
+        if (n_iters) *n_iters = 0;
+        if (in[0] && in[0]->len() == 1) {
+            std::unique_ptr<TensorTrain> tt = aci_one_site(in, (AciOpKind)op_kind, hop);
+            *result = new t4a_gpu_tt(tt->cores, tt->eng.stream());
+            if (termination) *termination = 0;
+            return;
+        }
+        AciProblem p(in, initial_guess ? &initial_guess->impl : nullptr, o, (AciOpKind)op_kind, hop);
+        p.run();
+        std::unique_ptr<TensorTrain> tt = p.solution_tt();
+        tt->eng.sync();
+        *result = new t4a_gpu_tt(tt->cores, tt->eng.stream());
+        if (n_iters) *n_iters = p.ranks.size();
+        for (size_t i = 0; i < p.ranks.size(); ++i) {
+            if (ranks) ranks[i] = p.ranks[i];
+            if (errors) errors[i] = p.errors[i];
+            if (nglobal_pivots) nglobal_pivots[i] = p.nglobal_pivots[i];
+        }
+        if (termination) *termination = (int32_t)p.termination;
+    });
+}
+
+t4a_gpu_status t4a_gpu_aci_problem_new(const t4a_gpu_tt* const* inputs, size_t n_inputs, int32_t op_kind, t4a_gpu_aci_op_fn op,
+                                       void* user, const t4a_gpu_aci_options* options, const t4a_gpu_tt* initial_guess,
+                                       t4a_gpu_aci_problem** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        const AciOptions o = convert_aci(options);
+        o.validate();
+        std::vector<TensorTrain*> in = aci_inputs(inputs, n_inputs);
+        AciHostOp hop = make_aci_op(op_kind, op, user);
+        require_device();
+        auto h = std::make_unique<t4a_gpu_aci_problem>();
+        h->impl = std::make_unique<AciProblem>(in, initial_guess ? &initial_guess->impl : nullptr, o, (AciOpKind)op_kind, hop);
+        *out = h.release();
+    });
+}
+
+void t4a_gpu_aci_problem_release(t4a_gpu_aci_problem* h) { delete h; }
+
+t4a_gpu_status t4a_gpu_aci_problem_local_update(t4a_gpu_aci_problem* h, size_t bond, int32_t left_orthogonal)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl->local_update(bond, left_orthogonal != 0);
+    });
+}
+
+t4a_gpu_status t4a_gpu_aci_problem_add_global_pivots(t4a_gpu_aci_problem* h, const size_t* pivots, size_t n_pivots, size_t* added)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_pivots) T4A_REQUIRE_PTR(pivots);
+        const size_t n = h->impl->len();
+        std::vector<std::vector<uint32_t>> pv(n_pivots, std::vector<uint32_t>(n));
+        for (size_t p = 0; p < n_pivots; ++p)
+            for (size_t s = 0; s < n; ++s) {
+                if (pivots[s + n * p] > 0xFFFFFFFFull) throw Error(T4A_GPU_INVALID_ARGUMENT, "global pivot index out of bounds");
+                pv[p][s] = (uint32_t)pivots[s + n * p];
+            }
+        const size_t a = h->impl->add_global_pivots(pv);
+        if (added) *added = a;
+    });
+}
+
+t4a_gpu_status t4a_gpu_aci_problem_find_global_pivots(t4a_gpu_aci_problem* h, uint64_t seed, size_t* count, size_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(count);
+        const auto pv = h->impl->find_global_pivots(seed);
+        *count = pv.size();
+        const size_t n = h->impl->len();
+        if (out)
+            for (size_t p = 0; p < pv.size(); ++p)
+                for (size_t s = 0; s < n; ++s) out[s + n * p] = pv[p][s];
+    });
+}
+
+t4a_gpu_status t4a_gpu_aci_problem_solution(t4a_gpu_aci_problem* h, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        std::unique_ptr<TensorTrain> tt = h->impl->solution_tt();
+        tt->eng.sync();
+        *out = new t4a_gpu_tt(tt->cores, tt->eng.stream());
+    });
+}
+
+t4a_gpu_status t4a_gpu_aci_problem_frame(t4a_gpu_aci_problem* h, int32_t right, size_t input, size_t site, size_t* rows,
+                                         size_t* cols, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(rows);
+        T4A_REQUIRE_PTR(cols);
+        const std::vector<double> f = h->impl->frame_host(right != 0, input, site, rows, cols);
+        if (out) std::copy(f.begin(), f.end(), out);
+    });
+}
+
+t4a_gpu_status t4a_gpu_aci_problem_errors(const t4a_gpu_aci_problem* h, double* pivot_errors, double* pivot_scales)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (pivot_errors) std::copy(h->impl->pivot_errors.begin(), h->impl->pivot_errors.end(), pivot_errors);
+        if (pivot_scales) std::copy(h->impl->pivot_scales.begin(), h->impl->pivot_scales.end(), pivot_scales);
     });
 }
 

@@ -1534,3 +1534,149 @@ def _factorize(self, left, bond_label, alg=FACTORIZE_SVD, canonical=CANONICAL_LE
 
 
 LabelledTensor.factorize = _factorize
+
+
+# ---- tensor4all-aci: elementwise operations on tensor trains by alternating cross interpolation ----
+class AciOptionsC(ctypes.Structure):
+    _fields_ = [("max_iters", c_size_t), ("min_iters", c_size_t), ("has_max_bond_dim", c_int32), ("max_bond_dim", c_size_t),
+                ("tolerance", c_double), ("scale_tolerance", c_int32), ("rng_seed", ctypes.c_uint64),
+                ("enable_global_guard", c_int32), ("nsearch_global_pivots", c_size_t), ("max_nglobal_pivot", c_size_t),
+                ("nsweeps_global_search", c_size_t), ("tol_margin_global_search", c_double)]
+
+
+class AciOptions:
+    """AciOptions (crates/tensor4all-aci/src/options.rs:37-168), same defaults.  initial_guess: SimpleTensorTrain, list of
+    cores or None (random guess; the library's stream is not the reference's ChaCha8 one)."""
+
+    def __init__(self, max_iters=20, min_iters=2, max_bond_dim=None, tolerance=1e-12, scale_tolerance=True, initial_guess=None,
+                 rng_seed=0, enable_global_guard=True, nsearch_global_pivots=5, max_nglobal_pivot=5, nsweeps_global_search=100,
+                 tol_margin_global_search=10.0):
+        self.max_iters, self.min_iters, self.max_bond_dim, self.tolerance = max_iters, min_iters, max_bond_dim, tolerance
+        self.scale_tolerance, self.initial_guess, self.rng_seed = scale_tolerance, initial_guess, rng_seed
+        self.enable_global_guard, self.nsearch_global_pivots = enable_global_guard, nsearch_global_pivots
+        self.max_nglobal_pivot, self.nsweeps_global_search = max_nglobal_pivot, nsweeps_global_search
+        self.tol_margin_global_search = tol_margin_global_search
+
+    def to_c(self):
+        return AciOptionsC(self.max_iters, self.min_iters, 0 if self.max_bond_dim is None else 1, self.max_bond_dim or 0,
+                           self.tolerance, int(self.scale_tolerance), self.rng_seed, int(self.enable_global_guard),
+                           self.nsearch_global_pivots, self.max_nglobal_pivot, self.nsweeps_global_search,
+                           self.tol_margin_global_search)
+
+
+ACI_OP_FN = ctypes.CFUNCTYPE(c_int32, c_void_p, ctypes.POINTER(c_double), c_size_t, c_size_t, ctypes.POINTER(c_double))
+ACI_CALLBACK, ACI_PRODUCT, ACI_SUM = 0, 1, 2
+ACI_CONVERGED, ACI_RANK_LIMITED, ACI_MAX_ITERATIONS = 0, 1, 2
+
+
+def _aci_op(op):
+    """ACI_PRODUCT / ACI_SUM (fused on the device) or a callable values (n_inputs, n_points) -> n_points values"""
+    if not callable(op):
+        return int(op), ACI_OP_FN(), None
+    err = []
+
+    def tramp(user, values, n_inputs, n_points, out):
+        try:
+            v = np.ctypeslib.as_array(values, shape=(n_points * n_inputs,)).reshape((n_inputs, n_points), order="F")
+            np.ctypeslib.as_array(out, shape=(n_points,))[:] = op(v)
+            return 0
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+            return 1
+    cb = ACI_OP_FN(tramp)
+    return ACI_CALLBACK, cb, (cb, err)
+
+
+def _aci_inputs(inputs, options):
+    tts = [t if isinstance(t, SimpleTensorTrain) else SimpleTensorTrain(t) for t in inputs]
+    arr = (c_void_p * max(len(tts), 1))(*[t._h for t in tts])
+    g = options.initial_guess
+    guess = None if g is None else (g if isinstance(g, SimpleTensorTrain) else SimpleTensorTrain(g))
+    return tts, arr, guess
+
+
+class AciResult:
+    """AciResult (result.rs): tensor_train, ranks, errors, nglobal_pivots, termination"""
+
+
+def elementwise_batched(op, inputs, options=None):
+    """elementwise_batched (crates/tensor4all-aci/src/elementwise.rs:107)"""
+    o = options or AciOptions()
+    tts, arr, guess = _aci_inputs(inputs, o)
+    kind, cb, keep = _aci_op(op)
+    oc = o.to_c()
+    cap = max(int(o.max_iters), 1)
+    ranks, errs, ng = np.zeros(cap, dtype=np.uintp), np.zeros(cap), np.zeros(cap, dtype=np.uintp)
+    h, n, term = c_void_p(), c_size_t(0), c_int32(0)
+    _check(_lib.t4a_gpu_aci_elementwise(arr if tts else None, c_size_t(len(tts)), c_int32(kind), cb, None, ctypes.byref(oc),
+                                        guess._h if guess else None, ctypes.byref(h), ctypes.byref(n), _p(ranks), _p(errs), _p(ng),
+                                        ctypes.byref(term)))
+    r = AciResult()
+    r.tensor_train = SimpleTensorTrain._adopt(h)
+    r.ranks, r.errors = [int(x) for x in ranks[:n.value]], [float(x) for x in errs[:n.value]]
+    r.nglobal_pivots, r.termination = [int(x) for x in ng[:n.value]], term.value
+    return r
+
+
+def elementwise(op, inputs, options=None):
+    """elementwise (elementwise.rs:311): scalar operator values[n_inputs] -> value"""
+    if not callable(op):
+        return elementwise_batched(op, inputs, options)
+    return elementwise_batched(lambda v: np.array([op(v[:, p]) for p in range(v.shape[1])]), inputs, options)
+
+
+class ElementwiseProblem:
+    """ElementwiseProblem (state.rs:24-109) stepped bond by bond"""
+
+    def __init__(self, op, inputs, options=None):
+        o = options or AciOptions()
+        self._tts, arr, self._guess = _aci_inputs(inputs, o)
+        kind, cb, self._keep = _aci_op(op)
+        oc = o.to_c()
+        self._h = c_void_p()
+        _check(_lib.t4a_gpu_aci_problem_new(arr if self._tts else None, c_size_t(len(self._tts)), c_int32(kind), cb, None,
+                                            ctypes.byref(oc), self._guess._h if self._guess else None, ctypes.byref(self._h)))
+        self.n_sites = len(self._tts[0])
+        self.max_nglobal_pivot = o.max_nglobal_pivot
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.t4a_gpu_aci_problem_release(h)
+            self._h = None
+
+    def local_update(self, bond, left_orthogonal):
+        _check(_lib.t4a_gpu_aci_problem_local_update(self._h, c_size_t(bond), c_int32(int(left_orthogonal))))
+
+    def add_global_pivots(self, pivots):
+        pv = np.asfortranarray(np.asarray(pivots, dtype=np.uintp).reshape(-1, self.n_sites).T)
+        added = c_size_t(0)
+        _check(_lib.t4a_gpu_aci_problem_add_global_pivots(self._h, _p(pv), c_size_t(pv.shape[1]), ctypes.byref(added)))
+        return added.value
+
+    def find_global_pivots(self, seed):
+        out = np.zeros((self.n_sites, max(self.max_nglobal_pivot, 1)), dtype=np.uintp, order="F")
+        count = c_size_t(0)
+        _check(_lib.t4a_gpu_aci_problem_find_global_pivots(self._h, ctypes.c_uint64(seed), ctypes.byref(count), _p(out)))
+        return [[int(x) for x in out[:, p]] for p in range(count.value)]
+
+    def solution(self):
+        h = c_void_p()
+        _check(_lib.t4a_gpu_aci_problem_solution(self._h, ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
+    def frame(self, right, input, site):
+        r, c = c_size_t(0), c_size_t(0)
+        _check(_lib.t4a_gpu_aci_problem_frame(self._h, c_int32(int(right)), c_size_t(input), c_size_t(site), ctypes.byref(r),
+                                              ctypes.byref(c), None))
+        if r.value == 0:
+            return None
+        out = np.zeros(r.value * c.value)
+        _check(_lib.t4a_gpu_aci_problem_frame(self._h, c_int32(int(right)), c_size_t(input), c_size_t(site), ctypes.byref(r),
+                                              ctypes.byref(c), _p(out)))
+        return out.reshape((r.value, c.value), order="F")
+
+    def errors(self):
+        e, sc = np.zeros(max(self.n_sites - 1, 1)), np.zeros(max(self.n_sites - 1, 1))
+        _check(_lib.t4a_gpu_aci_problem_errors(self._h, _p(e), _p(sc)))
+        return e[:self.n_sites - 1], sc[:self.n_sites - 1]
