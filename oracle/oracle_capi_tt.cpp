@@ -464,6 +464,17 @@ int oracle_aci_problem_add_global_pivots(void* h, const uint64_t* pivots /* n_si
         *added = s->p->add_global_pivots(pv);
     });
 }
+int oracle_aci_problem_find_global_pivots(void* h, uint64_t seed, uint64_t* count, uint64_t* out /* n_sites x max_nglobal_pivot */)
+{
+    return guarded([&] {
+        auto* s = static_cast<OracleAciProblem*>(h);
+        const std::vector<MultiIndex> pv = aci_find_global_pivots(*s->p, s->op, s->o, seed);
+        *count = pv.size();
+        const size_t ns = s->p->len();
+        for (size_t p = 0; p < pv.size(); ++p)
+            for (size_t q = 0; q < ns; ++q) out[q + ns * p] = pv[p][q];
+    });
+}
 void* oracle_aci_problem_solution(void* h)
 {
     auto* t = new OracleTT;

@@ -1224,6 +1224,12 @@ class OracleAciProblem:
         _check_tt(_lib.oracle_aci_problem_add_global_pivots(vp(self._h), _p(pv), u64(pv.shape[1]), ctypes.byref(added)))
         return int(added.value)
 
+    def find_global_pivots(self, seed, max_nglobal_pivot=5):
+        out = np.zeros((self.n_sites, max(max_nglobal_pivot, 1)), dtype=np.uint64, order="F")
+        count = u64(0)
+        _check_tt(_lib.oracle_aci_problem_find_global_pivots(vp(self._h), u64(seed), ctypes.byref(count), _p(out)))
+        return [[int(x) for x in out[:, p]] for p in range(count.value)]
+
     def solution(self):
         return _tt_from_handle(_lib.oracle_aci_problem_solution(vp(self._h)))
 

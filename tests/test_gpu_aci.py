@@ -197,3 +197,63 @@ def test_errors(t4a):
     assert e.value.code == t4a.CALLBACK_ERROR
     with pytest.raises(t4a.T4aError):
         t4a.elementwise_batched(7, [good])
+
+
+def test_global_guard_search_and_injection_match_the_oracle(t4a):
+    # a rank-capped first sweep leaves large errors: the guard's walks (same splitmix64 starts on both sides) must return the
+    # same pivots, and sweeping on after the injection must keep the frames identical
+    site_dims, link = [2, 3, 2, 3, 2, 3], [2, 4, 5, 4, 2]
+    ins = [lcg_tt(site_dims, link, 3), lcg_tt(site_dims, link, 4)]
+    guess = [np.ones((1, d, 1)) for d in site_dims]
+    kw = dict(initial_guess=guess, tolerance=1e-12, nsearch_global_pivots=6, max_nglobal_pivot=4)
+    p = t4a.ElementwiseProblem(t4a.ACI_PRODUCT, ins, t4a.AciOptions(**kw))
+    o = ob.OracleAciProblem(ob.ACI_PRODUCT, ins, ob.AciOptions(**kw))
+    n = len(site_dims)
+    for b in range(n - 1):
+        p.local_update(b, True)
+        o.local_update(b, True)
+    found = 0
+    for seed in (1, 2, 3):
+        pd, po = p.find_global_pivots(seed), o.find_global_pivots(seed, 4)
+        assert pd == po
+        found += len(pd)
+        if pd:
+            assert p.add_global_pivots(pd) == o.add_global_pivots(po)
+        for sweep in (1, 2):
+            order = reversed(range(n - 1)) if sweep % 2 else range(n - 1)
+            for b in order:
+                p.local_update(b, sweep % 2 == 0)
+                o.local_update(b, sweep % 2 == 0)
+        assert p.solution().link_dims() == o.solution().link_dims()
+        for k in range(2):
+            for s in range(n + 1):
+                for right in (False, True):
+                    fo, fd = o.frame(right, k, s), p.frame(right, k, s)
+                    assert (fo is None) == (fd is None) and (fo is None or np.array_equal(fo, fd))
+    assert found > 0
+    exact = (dense(ins[0]) * dense(ins[1])).ravel()
+    assert np.abs(tt_values(p.solution(), site_dims) - exact).max() < 1e-9 * np.abs(exact).max()
+
+
+def test_random_shapes_match_the_oracle(t4a):
+    rng = np.random.default_rng(2024)
+    for case in range(10):
+        n = int(rng.integers(2, 8))
+        site_dims = [int(x) for x in rng.integers(2, 5, size=n)]
+        link = [int(min(x, np.prod(site_dims[:b + 1]), np.prod(site_dims[b + 1:]))) for b, x in enumerate(rng.integers(1, 5, size=n - 1))]
+        K = int(rng.integers(1, 4))
+        ins = [lcg_tt(site_dims, link, 100 * case + k + 1) for k in range(K)]
+        glink = [int(min(x, np.prod(site_dims[:b + 1]), np.prod(site_dims[b + 1:]))) for b, x in enumerate(rng.integers(1, 7, size=n - 1))]
+        guess = [rng.standard_normal(c.shape) for c in lcg_tt(site_dims, glink, 1)]
+        op_d, op_o = (t4a.ACI_PRODUCT, ob.ACI_PRODUCT) if case % 2 == 0 else (t4a.ACI_SUM, ob.ACI_SUM)
+        kw = dict(initial_guess=guess, tolerance=1e-12, enable_global_guard=bool(case % 3 == 0), max_iters=12)
+        rd = t4a.elementwise_batched(op_d, ins, t4a.AciOptions(**kw))
+        ro = ob.aci_elementwise(op_o, ins, ob.AciOptions(**kw))
+        assert rd.ranks == ro.ranks and rd.nglobal_pivots == ro.nglobal_pivots and rd.termination == ro.termination, case
+        assert np.array_equal(rd.errors, ro.errors), case
+        dn = [dense(t) for t in ins]
+        exact = (np.prod(dn, axis=0) if case % 2 == 0 else np.sum(dn, axis=0)).ravel()
+        vd = tt_values(rd.tensor_train, site_dims)
+        assert np.abs(vd - np.asarray(ro.tensor_train.evaluate(grid(site_dims)))).max() <= 1e-10 * max(np.abs(exact).max(), 1e-300), case
+        if rd.termination == 0:
+            assert np.abs(vd - exact).max() < 1e-8 * np.abs(exact).max(), case
