@@ -565,6 +565,17 @@ t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* 
                                         int64_t bond_label, t4a_gpu_tensor** left, t4a_gpu_tensor** right, size_t* rank,
                                         double* singular_values);
 
+/* Bridge between the tensor-train handles and the labelled tensors (tensor4all-treetn/src/simplett_bridge.rs).
+ * _tt_to_tensors = tensor_train_to_treetn_with_names_and_site_indices (:118, :706-794) on a chain: out[s] carries the legs
+ * [bond_labels[s-1], site_labels[s], bond_labels[s]], the two boundary legs of dimension 1 dropped (a single site gives
+ * [site_labels[0]]); bond_labels has n_sites - 1 entries, out n_sites handles (all released again on failure).
+ * _tensors_to_tt = treetn_to_tensor_train (:172-277): tensors[s] must have exactly one leg that is not shared with a chain
+ * neighbour (its site index); the bond of tensors[s] and tensors[s+1] is the one label they share; legs are permuted to
+ * (left bond, site, right bond) whatever their order. */
+t4a_gpu_status t4a_gpu_tt_to_tensors(const t4a_gpu_tt* tt, const int64_t* site_labels, const int64_t* bond_labels,
+                                     t4a_gpu_tensor** out);
+t4a_gpu_status t4a_gpu_tensors_to_tt(const t4a_gpu_tensor* const* tensors, size_t n_sites, t4a_gpu_tt** out);
+
 /* ---- tensor4all-aci: Alternating Cross Interpolation of an elementwise operator over tensor trains ----
  * (crates/tensor4all-aci/src: elementwise.rs:107-218, state.rs:24-925, local.rs:299-394, global_guard.rs:49-181).
  * Inputs are device-resident trains (t4a_gpu_tt handles); the local candidate matrices are built, pivoted (rrLU) and

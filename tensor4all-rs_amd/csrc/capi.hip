@@ -2586,6 +2586,109 @@ t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* 
     });
 }
 
+// ---- simplett_bridge.rs: chain of labelled tensors <-> tensor train ----
+t4a_gpu_status t4a_gpu_tt_to_tensors(const t4a_gpu_tt* tt, const int64_t* site_labels, const int64_t* bond_labels,
+                                     t4a_gpu_tensor** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(tt);
+        const size_t n = tt->impl.len();
+        if (n == 0) return;
+        T4A_REQUIRE_PTR(site_labels);
+        T4A_REQUIRE_PTR(out);
+        if (n > 1) T4A_REQUIRE_PTR(bond_labels);
+        for (size_t s = 0; s < n; ++s) out[s] = nullptr;
+        std::vector<int64_t> all(site_labels, site_labels + n);
+        if (n > 1) all.insert(all.end(), bond_labels, bond_labels + n - 1);
+        std::sort(all.begin(), all.end());
+        if (std::adjacent_find(all.begin(), all.end()) != all.end())
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "tensor_train_to_treetn: site and bond indices must be distinct");
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        const_cast<t4a_gpu_tt*>(tt)->impl.eng.sync();
+        std::vector<std::unique_ptr<t4a_gpu_tensor>> made;
+        for (size_t s = 0; s < n; ++s) {
+            const DevCore& c = tt->impl.cores[s];
+            std::vector<size_t> dims;
+            std::vector<int64_t> labels;
+            if (s > 0) {
+                dims.push_back(c.l);
+                labels.push_back(bond_labels[s - 1]);
+            }
+            dims.push_back(c.s);
+            labels.push_back(site_labels[s]);
+            if (s + 1 < n) {
+                dims.push_back(c.r);
+                labels.push_back(bond_labels[s]);
+            }
+            auto t = make_tensor(dims, labels); // boundary legs have dimension 1: the column-major data is unchanged
+            if (c.size())
+                T4A_HIP(hipMemcpyAsync(t->buf.get(), c.buf.get(), c.size() * sizeof(double), hipMemcpyDeviceToDevice, e.stream()));
+            made.push_back(std::move(t));
+        }
+        e.sync();
+        for (size_t s = 0; s < n; ++s) out[s] = made[s].release();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensors_to_tt(const t4a_gpu_tensor* const* tensors, size_t n_sites, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        require_device();
+        if (n_sites == 0) {
+            *out = new t4a_gpu_tt(std::vector<std::array<size_t, 3>>{}, nullptr);
+            return;
+        }
+        T4A_REQUIRE_PTR(tensors);
+        for (size_t s = 0; s < n_sites; ++s) T4A_REQUIRE_PTR(tensors[s]);
+        auto shared = [&](size_t a, size_t b) { // the one label two neighbours share
+            std::vector<int64_t> common;
+            for (int64_t l : tensors[a]->labels)
+                if (std::find(tensors[b]->labels.begin(), tensors[b]->labels.end(), l) != tensors[b]->labels.end()) common.push_back(l);
+            if (common.size() != 1)
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "treetn_to_tensor_train: missing chain edge between nodes " + std::to_string(a) + " and " +
+                                                          std::to_string(b));
+            return common[0];
+        };
+        std::vector<int64_t> bonds(n_sites > 0 ? n_sites - 1 : 0);
+        for (size_t s = 0; s + 1 < n_sites; ++s) bonds[s] = shared(s, s + 1);
+        for (size_t a = 0; a < n_sites; ++a) // a chain: no label may connect nodes that are not neighbours
+            for (size_t b = a + 2; b < n_sites; ++b)
+                for (int64_t l : tensors[a]->labels)
+                    if (std::find(tensors[b]->labels.begin(), tensors[b]->labels.end(), l) != tensors[b]->labels.end())
+                        throw Error(T4A_GPU_INVALID_ARGUMENT, "treetn_to_tensor_train: expected a chain with " + std::to_string(n_sites - 1) + " edges");
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        std::vector<DevCore> cores(n_sites);
+        for (size_t s = 0; s < n_sites; ++s) {
+            const t4a_gpu_tensor* t = tensors[s];
+            const size_t want = 1 + (s > 0 ? 1 : 0) + (s + 1 < n_sites ? 1 : 0);
+            if (t->labels.size() != want)
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "treetn_to_tensor_train: node " + std::to_string(s) + " must have exactly one site index");
+            std::vector<size_t> perm;
+            auto pos = [&](int64_t l) { return (size_t)(std::find(t->labels.begin(), t->labels.end(), l) - t->labels.begin()); };
+            size_t site_axis = 0;
+            for (size_t a = 0; a < t->labels.size(); ++a)
+                if ((s == 0 || t->labels[a] != bonds[s - 1]) && (s + 1 >= n_sites || t->labels[a] != bonds[s])) site_axis = a;
+            if (s > 0) perm.push_back(pos(bonds[s - 1]));
+            perm.push_back(site_axis);
+            if (s + 1 < n_sites) perm.push_back(pos(bonds[s]));
+            DevCore& c = cores[s];
+            c.l = s > 0 ? t->dims[perm[0]] : 1;
+            c.s = t->dims[site_axis];
+            c.r = s + 1 < n_sites ? t->dims[perm.back()] : 1;
+            if (c.l == 0 || c.s == 0 || c.r == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "treetn_to_tensor_train: a resulting core has a zero dimension");
+            c.buf.reserve(c.size());
+            tensor_permute(e, t->view(), perm, c.buf.get());
+        }
+        T4A_HIP(hipGetLastError());
+        e.sync();
+        *out = new t4a_gpu_tt(cores, e.stream());
+    });
+}
+
 // ---- tensor4all-aci ----
 t4a_gpu_status t4a_gpu_aci_options_default(t4a_gpu_aci_options* o)
 {

@@ -1680,3 +1680,23 @@ class ElementwiseProblem:
         e, sc = np.zeros(max(self.n_sites - 1, 1)), np.zeros(max(self.n_sites - 1, 1))
         _check(_lib.t4a_gpu_aci_problem_errors(self._h, _p(e), _p(sc)))
         return e[:self.n_sites - 1], sc[:self.n_sites - 1]
+
+
+def tensor_train_to_tensors(tt, site_labels, bond_labels):
+    """tensor_train_to_treetn_with_names_and_site_indices on a chain (treetn/src/simplett_bridge.rs:118, :706-794): one
+    device-resident LabelledTensor per site with legs [bond s-1, site s, bond s] (boundary legs dropped)"""
+    n = len(tt)
+    sl, bl = np.asarray(site_labels, dtype=np.int64), np.asarray(bond_labels, dtype=np.int64)
+    if len(sl) != n or len(bl) != max(n - 1, 0):
+        raise T4aError(INVALID_ARGUMENT, "tensor_train_to_treetn: site_indices / bond count must match the tensor-train length")
+    out = (c_void_p * max(n, 1))()
+    _check(_lib.t4a_gpu_tt_to_tensors(tt._h, _p(sl) if n else None, _p(bl) if n > 1 else None, out))
+    return [LabelledTensor(_handle=c_void_p(out[s])) for s in range(n)]
+
+
+def tensors_to_tensor_train(tensors):
+    """treetn_to_tensor_train for a chain of LabelledTensors (simplett_bridge.rs:172-277)"""
+    arr = (c_void_p * max(len(tensors), 1))(*[t._h for t in tensors])
+    h = c_void_p()
+    _check(_lib.t4a_gpu_tensors_to_tt(arr if tensors else None, c_size_t(len(tensors)), ctypes.byref(h)))
+    return SimpleTensorTrain._adopt(h)

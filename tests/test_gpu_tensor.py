@@ -204,3 +204,38 @@ def test_factorize_matches_oracle(t4a, alg, canonical):
     if alg in (2, 3):
         with pytest.raises(t4a.T4aError):
             t4a.LabelledTensor(np.zeros((3, 4)), [1, 2]).factorize([1], 905, alg=alg)
+
+
+def test_chain_bridge_between_tensor_trains_and_labelled_tensors(t4a):
+    # treetn/src/simplett_bridge.rs: tensor_train_to_treetn (:706-794) and treetn_to_tensor_train (:172-277) on the dense seam
+    rng = np.random.default_rng(8)
+    shapes = [(1, 2, 3), (3, 4, 2), (2, 3, 4), (4, 2, 1)]
+    cores = [rng.standard_normal(s) for s in shapes]
+    tt = t4a.SimpleTensorTrain(cores)
+    ts = t4a.tensor_train_to_tensors(tt, [10, 11, 12, 13], [20, 21, 22])
+    assert [t.labels for t in ts] == [[10, 20], [20, 11, 21], [21, 12, 22], [22, 13]]
+    assert np.array_equal(ts[0].to_numpy(), cores[0][0]) and np.array_equal(ts[1].to_numpy(), cores[1])
+    assert np.array_equal(ts[3].to_numpy(), cores[3][:, :, 0])
+    # contract the whole chain on the device and compare with the dense train
+    full = ts[0]
+    for t in ts[1:]:
+        full = full * t
+    ref = np.einsum("aib,bjc,ckd,dle->ijkl", *cores)
+    assert full.labels == [10, 11, 12, 13] and np.abs(full.to_numpy() - ref).max() < 1e-12
+    # back: legs in any order
+    shuffled = [ts[0].permute([20, 10]), ts[1].permute([21, 20, 11]), ts[2], ts[3].permute([13, 22])]
+    back = t4a.tensors_to_tensor_train(shuffled)
+    assert [tuple(d) for d in back.dims()] == shapes
+    for s in range(4):
+        assert np.array_equal(back.site_tensor(s), cores[s])
+    # the doc test of the bridge: a single site
+    one = t4a.SimpleTensorTrain([np.array([1.0, 2.0]).reshape(1, 2, 1)])
+    (t,) = t4a.tensor_train_to_tensors(one, [5], [])
+    assert t.labels == [5] and np.array_equal(t.to_numpy(), [1.0, 2.0])
+    assert np.array_equal(t4a.tensors_to_tensor_train([t]).site_tensor(0).ravel(), [1.0, 2.0])
+    with pytest.raises(t4a.T4aError):  # not a chain: the first and the last tensor share an index
+        t4a.tensors_to_tensor_train([ts[0], ts[1], ts[0]])
+    with pytest.raises(t4a.T4aError):  # two site indices on one node
+        t4a.tensors_to_tensor_train([full, ts[3]])
+    with pytest.raises(t4a.T4aError):
+        t4a.tensor_train_to_tensors(tt, [10, 11, 12, 13], [20, 21, 10])
