@@ -565,6 +565,16 @@ t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* 
                                         int64_t bond_label, t4a_gpu_tensor** left, t4a_gpu_tensor** right, size_t* rank,
                                         double* singular_values);
 
+/* SimpleTensorTrain arithmetic on the device (tensor4all-simplett/src/arithmetic.rs:34-180, tensortrain.rs:264-345,
+ * :449-583).  add / sub: direct sum of the cores ([A | B], block diagonal, [A; B]; sub negates the last core of b first);
+ * scale = scale_mut (the last core carries the factor); reverse swaps site order and the bond legs; partial_sum(dims) sums
+ * the listed sites out (all sites summed: a one-site train of dimension 1 holding the scalar). */
+t4a_gpu_status t4a_gpu_tt_add(const t4a_gpu_tt* a, const t4a_gpu_tt* b, t4a_gpu_tt** out);
+t4a_gpu_status t4a_gpu_tt_sub(const t4a_gpu_tt* a, const t4a_gpu_tt* b, t4a_gpu_tt** out);
+t4a_gpu_status t4a_gpu_tt_scale(t4a_gpu_tt* h, double factor);
+t4a_gpu_status t4a_gpu_tt_reverse(const t4a_gpu_tt* h, t4a_gpu_tt** out);
+t4a_gpu_status t4a_gpu_tt_partial_sum(const t4a_gpu_tt* h, const size_t* dims, size_t n_dims, t4a_gpu_tt** out);
+
 /* Bridge between the tensor-train handles and the labelled tensors (tensor4all-treetn/src/simplett_bridge.rs).
  * _tt_to_tensors = tensor_train_to_treetn_with_names_and_site_indices (:118, :706-794) on a chain: out[s] carries the legs
  * [bond_labels[s-1], site_labels[s], bond_labels[s]], the two boundary legs of dimension 1 dropped (a single site gives

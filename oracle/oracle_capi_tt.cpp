@@ -324,6 +324,33 @@ int oracle_tensor_factorize(const double* t, const uint64_t* dims, const int64_t
     });
 }
 
+// ---- SimpleTensorTrain arithmetic ----
+void* oracle_tt_binary(void* a, void* b, int op /* 0 add, 1 sub */)
+{
+    OracleTT* h = nullptr;
+    const int rc = guarded([&] {
+        auto r = std::make_unique<OracleTT>();
+        const SimpleTensorTrain& x = static_cast<OracleTT*>(a)->tt;
+        const SimpleTensorTrain& y = static_cast<OracleTT*>(b)->tt;
+        r->tt = op == 0 ? tt_add(x, y) : tt_sub(x, y);
+        h = r.release();
+    });
+    return rc == 0 ? h : nullptr;
+}
+void* oracle_tt_unary(void* a, int op /* 0 scale, 1 reverse, 2 partial_sum */, double factor, const uint64_t* dims, uint64_t n_dims)
+{
+    OracleTT* h = nullptr;
+    const int rc = guarded([&] {
+        auto r = std::make_unique<OracleTT>();
+        const SimpleTensorTrain& x = static_cast<OracleTT*>(a)->tt;
+        if (op == 0) r->tt = tt_scale(x, factor);
+        else if (op == 1) r->tt = tt_reverse(x);
+        else r->tt = tt_partial_sum(x, std::vector<size_t>(dims, dims + n_dims));
+        h = r.release();
+    });
+    return rc == 0 ? h : nullptr;
+}
+
 // ---- tensor4all-aci: elementwise / elementwise_batched (t4a_oracle_aci.hpp) ----
 struct oracle_aci_options {
     uint64_t max_iters, min_iters;

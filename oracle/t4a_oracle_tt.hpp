@@ -728,4 +728,101 @@ inline TensorCI2 tensorci2_from_tensor_train(SimpleTensorTrain tt, const FromTen
     return tci;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SimpleTensorTrain arithmetic — tensor4all-simplett/src/arithmetic.rs:34-180, tensortrain.rs:264-345, :449-583
+// ---------------------------------------------------------------------------------------------
+inline SimpleTensorTrain tt_scale(const SimpleTensorTrain& a, double factor) // scale_mut / scale: the LAST core carries it
+{
+    SimpleTensorTrain r = a;
+    if (!r.tensors.empty())
+        for (double& v : r.tensors.back().d) v = v * factor;
+    return r;
+}
+
+inline SimpleTensorTrain tt_add(const SimpleTensorTrain& a, const SimpleTensorTrain& b) // arithmetic.rs:34-159 (direct sum)
+{
+    if (a.len() != b.len()) throw OracleError(ERR_INVALID_ARGUMENT, "Cannot add tensor trains of different lengths");
+    if (a.len() == 0) return b;
+    const size_t n = a.len();
+    SimpleTensorTrain r;
+    for (size_t i = 0; i < n; ++i) {
+        const Tensor3& x = a.tensors[i];
+        const Tensor3& y = b.tensors[i];
+        if (x.s != y.s) throw OracleError(ERR_INVALID_ARGUMENT, "Site dimensions mismatch");
+        const bool first = i == 0, last = i == n - 1;
+        const size_t l0 = first ? 0 : x.l, r0 = last ? 0 : x.r; // offsets of b's block
+        Tensor3 t(first ? 1 : x.l + y.l, x.s, last ? 1 : x.r + y.r);
+        if (first && last) {
+            for (size_t q = 0; q < x.s; ++q) t.at(0, q, 0) = x.at(0, q, 0) + y.at(0, q, 0);
+        } else {
+            for (size_t rr = 0; rr < x.r; ++rr)
+                for (size_t q = 0; q < x.s; ++q)
+                    for (size_t l = 0; l < x.l; ++l) t.at(l, q, rr) = x.at(l, q, rr);
+            for (size_t rr = 0; rr < y.r; ++rr)
+                for (size_t q = 0; q < y.s; ++q)
+                    for (size_t l = 0; l < y.l; ++l) t.at(l0 + l, q, r0 + rr) = y.at(l, q, rr);
+        }
+        r.tensors.push_back(std::move(t));
+    }
+    return r; // from_tensors_unchecked
+}
+
+inline SimpleTensorTrain tt_sub(const SimpleTensorTrain& a, const SimpleTensorTrain& b) { return tt_add(a, tt_scale(b, -1.0)); } // :161-175
+
+inline SimpleTensorTrain tt_reverse(const SimpleTensorTrain& a) // tensortrain.rs:327-345
+{
+    SimpleTensorTrain r;
+    for (size_t i = a.len(); i-- > 0;) {
+        const Tensor3& x = a.tensors[i];
+        Tensor3 t(x.r, x.s, x.l);
+        for (size_t l = 0; l < x.l; ++l)
+            for (size_t q = 0; q < x.s; ++q)
+                for (size_t rr = 0; rr < x.r; ++rr) t.at(rr, q, l) = x.at(l, q, rr);
+        r.tensors.push_back(std::move(t));
+    }
+    return r;
+}
+
+inline SimpleTensorTrain tt_partial_sum(const SimpleTensorTrain& a, const std::vector<size_t>& dims) // tensortrain.rs:449-583
+{
+    const size_t n = a.len();
+    if (n == 0) return SimpleTensorTrain();
+    for (size_t d : dims)
+        if (d >= n) throw OracleError(ERR_INVALID_ARGUMENT, "Dimension out of range");
+    std::vector<Tensor3> out;
+    Matrix tprod(1, 1);
+    tprod(0, 0) = 1.0;
+    for (size_t site = 0; site < n; ++site) {
+        const Tensor3& t = a.tensors[site];
+        if (std::find(dims.begin(), dims.end(), site) != dims.end()) {
+            Matrix ss(t.l, t.r);
+            for (size_t l = 0; l < t.l; ++l)
+                for (size_t r = 0; r < t.r; ++r) {
+                    double acc = 0.0;
+                    for (size_t q = 0; q < t.s; ++q) acc = acc + t.at(l, q, r);
+                    ss(l, r) = acc;
+                }
+            tprod = mat_mul(tprod, ss);
+        } else {
+            const Matrix prod = mat_mul(tprod, Matrix(t.l, t.s * t.r, t.d.data()));
+            Tensor3 nt(tprod.nr, t.s, t.r);
+            nt.d = prod.a;
+            out.push_back(std::move(nt));
+            tprod = Matrix(t.r, t.r);
+            for (size_t i = 0; i < t.r; ++i) tprod(i, i) = 1.0;
+        }
+    }
+    if (out.empty()) {
+        Tensor3 t(1, 1, 1);
+        t.d[0] = tprod(0, 0);
+        return SimpleTensorTrain::make({t});
+    }
+    Tensor3& last = out.back();
+    const Matrix c = mat_mul(Matrix(last.l * last.s, last.r, last.d.data()), tprod);
+    Tensor3 nl(last.l, last.s, tprod.nc);
+    nl.d = c.a;
+    last = std::move(nl);
+    return SimpleTensorTrain::make(std::move(out));
+}
+
 } // namespace t4a_oracle

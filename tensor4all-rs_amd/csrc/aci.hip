@@ -114,6 +114,12 @@ void host_builtin(AciOpKind kind, const double* v, size_t K, size_t np, double* 
 
 } // namespace
 
+void seq_matmul_launch(const double* A, int lda, const double* B, int ldb, double* C, int ldc, size_t M, size_t N, size_t K,
+                       hipStream_t stream)
+{
+    matmul(A, lda, B, ldb, C, ldc, M, N, K, stream);
+}
+
 void AciOptions::validate() const
 {
     if (max_iters == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "max_iters must be at least 1");

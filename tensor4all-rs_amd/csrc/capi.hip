@@ -2586,6 +2586,66 @@ t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* 
     });
 }
 
+// ---- SimpleTensorTrain arithmetic ----
+extern "C++" {
+static t4a_gpu_tt* wrap_tt(std::unique_ptr<TensorTrain> r)
+{
+    r->eng.sync();
+    return new t4a_gpu_tt(r->cores, r->eng.stream());
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_tt_add(const t4a_gpu_tt* a, const t4a_gpu_tt* b, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(b);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        *out = wrap_tt(const_cast<t4a_gpu_tt*>(a)->impl.add(const_cast<t4a_gpu_tt*>(b)->impl, false));
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_sub(const t4a_gpu_tt* a, const t4a_gpu_tt* b, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(b);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        *out = wrap_tt(const_cast<t4a_gpu_tt*>(a)->impl.add(const_cast<t4a_gpu_tt*>(b)->impl, true));
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_scale(t4a_gpu_tt* h, double factor)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.scale(factor);
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_reverse(const t4a_gpu_tt* h, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        *out = wrap_tt(const_cast<t4a_gpu_tt*>(h)->impl.reverse());
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_partial_sum(const t4a_gpu_tt* h, const size_t* dims, size_t n_dims, t4a_gpu_tt** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        if (n_dims) T4A_REQUIRE_PTR(dims);
+        *out = wrap_tt(const_cast<t4a_gpu_tt*>(h)->impl.partial_sum(std::vector<size_t>(dims, dims + n_dims)));
+    });
+}
+
 // ---- simplett_bridge.rs: chain of labelled tensors <-> tensor train ----
 t4a_gpu_status t4a_gpu_tt_to_tensors(const t4a_gpu_tt* tt, const int64_t* site_labels, const int64_t* bond_labels,
                                      t4a_gpu_tensor** out)

@@ -216,6 +216,10 @@ void scatter_rows_launch(const double* in, int ldi, const int* rows, int nrows, 
 void scatter_cols_launch(const double* in, int ldi, int nrows, const int* cols, int ncols, double* out, int ldo,
                          hipStream_t stream);
 void fill_launch(double* p, size_t count, double value, hipStream_t stream);
+// C (M x N, ldc) = A (M x K, lda) * B (K x N, ldb) with every entry accumulated k-ascending, multiply and add rounded
+// separately: the order the oracle's mat_mul restates for the reference's third-party matmul (aci.hip)
+void seq_matmul_launch(const double* A, int lda, const double* B, int ldb, double* C, int ldc, size_t M, size_t N, size_t K,
+                       hipStream_t stream);
 // out (m x r): identity on top (r x r) and zeros below
 void set_identity_launch(double* p, int m, int n, int ld, hipStream_t stream);
 

@@ -3,6 +3,7 @@
 // every floating-point operation runs in the gfx950 kernels of kernels_tt.hip / kernels_dense.hip /
 // kernels_linalg.hip / kernels_rrlu*.hip.
 #include "tt.hpp"
+#include "tensorops.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -491,6 +492,171 @@ size_t TensorTrain::evaluate_many(const uint32_t* idx, size_t n_pts, size_t spli
     eng.sync();
     T4A_HIP(hipGetLastError());
     return split;
+}
+
+// ---------------------------------------------------------------------------------------------
+// arithmetic (simplett/src/arithmetic.rs:34-180, tensortrain.rs:264-345, :449-583)
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) tt_scale_kernel(double* p, size_t n, double f)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = p[e] * f;
+}
+__global__ void __launch_bounds__(256) tt_add2_kernel(const double* a, const double* b, double* out, size_t n)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) out[e] = a[e] + b[e];
+}
+// out (l x r) = sum over the site index, s ascending from 0.0 (tensortrain.rs:486-496)
+__global__ void __launch_bounds__(256) tt_site_sum_kernel(const double* core, int l, int s, int r, double* out)
+{
+    const size_t total = (size_t)l * r;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t li = e % (size_t)l, ri = e / (size_t)l;
+        double acc = 0.0;
+        for (int q = 0; q < s; ++q) acc = acc + core[li + (size_t)l * (q + (size_t)s * ri)];
+        out[e] = acc;
+    }
+}
+unsigned blocks_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 4096); }
+} // namespace
+
+void TensorTrain::scale(double factor)
+{
+    if (cores.empty()) return;
+    DevCore& c = cores.back();
+    if (c.size()) hipLaunchKernelGGL(tt_scale_kernel, dim3(blocks_for(c.size())), dim3(256), 0, eng.stream(), c.buf.get(), c.size(), factor);
+    T4A_HIP(hipGetLastError());
+    eng.sync();
+}
+
+std::unique_ptr<TensorTrain> TensorTrain::add(TensorTrain& other, bool subtract)
+{
+    if (len() != other.len())
+        throw Error(T4A_GPU_INVALID_ARGUMENT, "Cannot add tensor trains of different lengths: " + std::to_string(len()) + " vs " +
+                                                  std::to_string(other.len()));
+    other.eng.sync();
+    if (cores.empty()) return std::make_unique<TensorTrain>(other.cores, other.eng.stream());
+    const size_t n = len();
+    for (size_t i = 0; i < n; ++i)
+        if (cores[i].s != other.cores[i].s)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "Site dimensions mismatch at site " + std::to_string(i) + ": " + std::to_string(cores[i].s) +
+                                                      " vs " + std::to_string(other.cores[i].s));
+    hipStream_t st = eng.stream();
+    // sub = add(other.scale(-1)) (arithmetic.rs:161-175): the factor sits on the last core of `other`
+    DevBuf<double> neg;
+    const DevCore& ol = other.cores.back();
+    const double* other_last = ol.buf.get();
+    if (subtract) {
+        neg.reserve(std::max<size_t>(ol.size(), 1));
+        T4A_HIP(hipMemcpyAsync(neg.get(), ol.buf.get(), ol.size() * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (ol.size()) hipLaunchKernelGGL(tt_scale_kernel, dim3(blocks_for(ol.size())), dim3(256), 0, st, neg.get(), ol.size(), -1.0);
+        other_last = neg.get();
+    }
+    std::vector<DevCore> out(n);
+    for (size_t i = 0; i < n; ++i) {
+        const DevCore& x = cores[i];
+        const DevCore& y = other.cores[i];
+        const double* yp = i == n - 1 ? other_last : y.buf.get();
+        const bool first = i == 0, last = i == n - 1;
+        DevCore& t = out[i];
+        t.l = first ? 1 : x.l + y.l;
+        t.s = x.s;
+        t.r = last ? 1 : x.r + y.r;
+        t.buf.reserve(std::max<size_t>(t.size(), 1));
+        if (first && last) {
+            hipLaunchKernelGGL(tt_add2_kernel, dim3(blocks_for(t.size())), dim3(256), 0, st, x.buf.get(), yp, t.buf.get(), t.size());
+            continue;
+        }
+        fill_launch(t.buf.get(), t.size(), 0.0, st);
+        // a core (l, s, r) viewed as l x (s r): the block of `other` starts at row l0 and column s * r0
+        const size_t l0 = first ? 0 : x.l, r0 = last ? 0 : x.r;
+        gather_launch(x.buf.get(), (int)x.l, nullptr, (int)x.l, nullptr, (int)(x.s * x.r), t.buf.get(), (int)t.l, st);
+        gather_launch(yp, (int)y.l, nullptr, (int)y.l, nullptr, (int)(y.s * y.r), t.buf.get() + l0 + t.l * (t.s * r0), (int)t.l, st);
+    }
+    T4A_HIP(hipGetLastError());
+    eng.sync();
+    return std::make_unique<TensorTrain>(out, st);
+}
+
+std::unique_ptr<TensorTrain> TensorTrain::reverse()
+{
+    hipStream_t st = eng.stream();
+    const size_t n = len();
+    std::vector<DevCore> out(n);
+    for (size_t i = 0; i < n; ++i) {
+        const DevCore& x = cores[n - 1 - i];
+        DevCore& t = out[i];
+        t.l = x.r;
+        t.s = x.s;
+        t.r = x.l;
+        t.buf.reserve(std::max<size_t>(t.size(), 1));
+        TensorView v;
+        v.d_data = x.buf.get();
+        v.dims = {x.l, x.s, x.r};
+        v.labels = {0, 1, 2};
+        if (t.size()) tensor_permute(eng, v, {2, 1, 0}, t.buf.get());
+    }
+    T4A_HIP(hipGetLastError());
+    eng.sync();
+    return std::make_unique<TensorTrain>(out, st);
+}
+
+std::unique_ptr<TensorTrain> TensorTrain::partial_sum(const std::vector<size_t>& dims)
+{
+    const size_t n = len();
+    hipStream_t st = eng.stream();
+    if (n == 0) return std::make_unique<TensorTrain>(std::vector<DevCore>{}, st);
+    for (size_t d : dims)
+        if (d >= n) throw Error(T4A_GPU_INVALID_ARGUMENT, "Dimension " + std::to_string(d) + " out of range (0.." + std::to_string(n) + ")");
+    std::vector<DevCore> out;
+    DevBuf<double> tprod, next, ssum;
+    size_t tr = 1, tc = 1; // tprod is tr x tc
+    tprod.reserve(1);
+    fill_launch(tprod.get(), 1, 1.0, st);
+    for (size_t site = 0; site < n; ++site) {
+        const DevCore& t = cores[site];
+        if (std::find(dims.begin(), dims.end(), site) != dims.end()) {
+            ssum.reserve(std::max<size_t>(t.l * t.r, 1));
+            hipLaunchKernelGGL(tt_site_sum_kernel, dim3(blocks_for(t.l * t.r)), dim3(256), 0, st, t.buf.get(), (int)t.l, (int)t.s, (int)t.r,
+                               ssum.get());
+            next.reserve(std::max<size_t>(tr * t.r, 1));
+            seq_matmul_launch(tprod.get(), (int)tr, ssum.get(), (int)t.l, next.get(), (int)tr, tr, t.r, t.l, st);
+            eng.sync(); // `tprod` is replaced: nothing may still read the old buffer
+            std::swap(tprod, next);
+            tc = t.r;
+        } else {
+            DevCore c;
+            c.l = tr;
+            c.s = t.s;
+            c.r = t.r;
+            c.buf.reserve(std::max<size_t>(c.size(), 1));
+            seq_matmul_launch(tprod.get(), (int)tr, t.buf.get(), (int)t.l, c.buf.get(), (int)tr, tr, t.s * t.r, t.l, st);
+            out.push_back(std::move(c));
+            tr = tc = t.r;
+            eng.sync();
+            tprod.reserve(tr * tr);
+            set_identity_launch(tprod.get(), (int)tr, (int)tr, (int)tr, st);
+        }
+    }
+    if (out.empty()) { // everything summed: a one-site train wrapping the scalar
+        DevCore c;
+        c.l = c.s = c.r = 1;
+        c.buf.reserve(1);
+        T4A_HIP(hipMemcpyAsync(c.buf.get(), tprod.get(), sizeof(double), hipMemcpyDeviceToDevice, st));
+        out.push_back(std::move(c));
+    } else { // the trailing product goes into the last kept core
+        DevCore& last = out.back();
+        DevBuf<double> nl;
+        nl.reserve(std::max<size_t>(last.l * last.s * tc, 1));
+        seq_matmul_launch(last.buf.get(), (int)(last.l * last.s), tprod.get(), (int)tr, nl.get(), (int)(last.l * last.s), last.l * last.s, tc,
+                          last.r, st);
+        eng.sync();
+        last.buf = std::move(nl);
+        last.r = tc;
+    }
+    T4A_HIP(hipGetLastError());
+    eng.sync();
+    return std::make_unique<TensorTrain>(out, st);
 }
 
 } // namespace t4a

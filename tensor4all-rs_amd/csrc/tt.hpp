@@ -4,6 +4,7 @@
 #pragma once
 
 #include <array>
+#include <memory>
 #include <vector>
 
 #include "engine.hpp"
@@ -42,6 +43,11 @@ public:
     double sum();
     double norm2();
     void compress(const CompressionOptions& options);
+    // arithmetic.rs:34-180, tensortrain.rs:264-345, :449-583 — results are new device-resident trains
+    std::unique_ptr<TensorTrain> add(TensorTrain& other, bool subtract);
+    void scale(double factor); // scale_mut: the last core carries the factor
+    std::unique_ptr<TensorTrain> reverse();
+    std::unique_ptr<TensorTrain> partial_sum(const std::vector<size_t>& dims);
     // TTCache::evaluate_many; split == 0 -> find_split_heuristic.  Returns the split that was used.
     size_t evaluate_many(const uint32_t* idx, size_t n_pts, size_t split, double* out);
     size_t find_split_heuristic(const uint32_t* idx, size_t n_pts) const;

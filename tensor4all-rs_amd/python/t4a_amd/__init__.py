@@ -672,6 +672,41 @@ class SimpleTensorTrain:
         _check(_lib.t4a_gpu_tt_clone(self._h, ctypes.byref(h)))
         return SimpleTensorTrain._adopt(h)
 
+    # arithmetic (simplett/src/arithmetic.rs:34-180, tensortrain.rs:264-345, :449-583)
+    def add(self, other):
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tt_add(self._h, other._h, ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
+    def sub(self, other):
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tt_sub(self._h, other._h, ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
+    __add__, __sub__ = add, sub
+
+    def scale_mut(self, factor):
+        _check(_lib.t4a_gpu_tt_scale(self._h, c_double(factor)))
+
+    def scale(self, factor):
+        r = self.clone()
+        r.scale_mut(factor)
+        return r
+
+    def negate(self):
+        return self.scale(-1.0)
+
+    def reverse(self):
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tt_reverse(self._h, ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
+    def partial_sum(self, dims):
+        d = np.asarray(list(dims), dtype=np.uintp)
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tt_partial_sum(self._h, _p(d) if len(d) else None, c_size_t(len(d)), ctypes.byref(h)))
+        return SimpleTensorTrain._adopt(h)
+
     def __len__(self):
         v = c_size_t(0)
         _check(_lib.t4a_gpu_tt_len(self._h, ctypes.byref(v)))

@@ -436,6 +436,29 @@ class OracleTT:
         _check_tt(_lib.oracle_tt_full_tensor(vp(self._h), _p(out)))
         return out
 
+    def _wrap(self, h):
+        if not h:
+            _check_tt(-2)
+        t = OracleTT.__new__(OracleTT)
+        t._h = h
+        return t
+
+    def add(self, other):
+        return self._wrap(_lib.oracle_tt_binary(vp(self._h), vp(other._h), cint(0)))
+
+    def sub(self, other):
+        return self._wrap(_lib.oracle_tt_binary(vp(self._h), vp(other._h), cint(1)))
+
+    def scale(self, factor):
+        return self._wrap(_lib.oracle_tt_unary(vp(self._h), cint(0), dbl(factor), None, u64(0)))
+
+    def reverse(self):
+        return self._wrap(_lib.oracle_tt_unary(vp(self._h), cint(1), dbl(0.0), None, u64(0)))
+
+    def partial_sum(self, dims):
+        d = np.asarray(list(dims), dtype=np.uint64)
+        return self._wrap(_lib.oracle_tt_unary(vp(self._h), cint(2), dbl(0.0), _p(d) if len(d) else None, u64(len(d))))
+
     def compress(self, method=0, tolerance=1e-12, max_bond_dim=None, normalize_error=True):
         _check_tt(_lib.oracle_tt_compress(vp(self._h), cint(method), dbl(tolerance), u64(max_bond_dim or 0),
                                           cint(int(normalize_error))))
@@ -1134,6 +1157,8 @@ class AciOptions:
 ACI_OP_FN = ctypes.CFUNCTYPE(cint, vp, ctypes.POINTER(dbl), u64, u64, ctypes.POINTER(dbl))
 ACI_CALLBACK, ACI_PRODUCT, ACI_SUM = 0, 1, 2
 _lib.oracle_aci_elementwise.restype = vp
+_lib.oracle_tt_binary.restype = vp
+_lib.oracle_tt_unary.restype = vp
 _lib.oracle_aci_tensor_train.restype = vp
 _lib.oracle_aci_n_iters.restype = u64
 _lib.oracle_aci_problem_new.restype = vp

@@ -328,3 +328,74 @@ def test_from_tensor_train_random_train_matches_oracle(t4a, max_iter):
     g.set_function(lambda i: float(tt.evaluate([list(i)])[0]))
     g.sweep2site(True, t4a.TCI2Options(tolerance=1e-12, nsearch=0, max_nglobal_pivot=0))
     assert g.max_bond_error() < 1e-10 * np.abs(full).max()
+
+
+# ---- arithmetic: add / sub / scale / reverse / partial_sum (simplett/src/arithmetic.rs, tensortrain.rs:264-583) ----
+def _grid_pts(dims):
+    import itertools
+    return np.array(list(itertools.product(*[range(d) for d in dims])), dtype=np.uint32)
+
+
+def _rank1_cores(*vectors):
+    return [np.asarray(v, dtype=float).reshape(1, -1, 1) for v in vectors]
+
+
+def test_tt_arithmetic_reference_fixtures(t4a):
+    # tensortrain/tests/mod.rs:64-90, :297-403, :441-512
+    tt = t4a.SimpleTensorTrain([np.ones((1, 2, 1)), np.ones((1, 2, 1))])
+    tt.scale_mut(3.0)
+    assert abs(tt.sum() - 12.0) < 1e-10
+    tt = t4a.SimpleTensorTrain(_rank1_cores([1, 2], [1, 2, 3]))
+    rev = tt.reverse()
+    assert rev.site_dims() == [3, 2] and rev.evaluate([[2, 1]])[0] == tt.evaluate([[1, 2]])[0]
+    ones = t4a.SimpleTensorTrain([np.ones((1, 2, 1)), np.ones((1, 3, 1)), np.ones((1, 2, 1))])
+    r = ones.partial_sum([0, 1, 2])
+    assert len(r) == 1 and abs(r.sum() - 12.0) < 1e-12
+    r = ones.partial_sum([])
+    assert len(r) == 3 and np.abs(r.evaluate(_grid_pts([2, 3, 2])) - 1.0).max() < 1e-12
+    tt = t4a.SimpleTensorTrain(_rank1_cores([1, 2, 3], [1, 2, 3, 4], [1, 2]))
+    r = tt.partial_sum([1])
+    assert len(r) == 2 and np.abs(r.evaluate(_grid_pts([3, 2])) - np.array([(1 + i) * 10.0 * (1 + k) for i, k in _grid_pts([3, 2])])).max() < 1e-10
+    r = tt.partial_sum([0, 2])
+    assert len(r) == 1 and np.abs(r.evaluate(_grid_pts([4])) - 18.0 * np.arange(1, 5)).max() < 1e-10
+    a = t4a.SimpleTensorTrain(_rank1_cores([1, 2, 3], [1, 1, 1], [1, 1]))
+    b = t4a.SimpleTensorTrain(_rank1_cores([1, 1, 1], [1, 2, 3], [1, 1]))
+    pts = _grid_pts([3, 3, 2])
+    assert np.abs((a + b).evaluate(pts) - np.array([2.0 + i + j for i, j, k in pts])).max() < 1e-12
+    assert np.abs((a - b).evaluate(pts) - np.array([float(i) - float(j) for i, j, k in pts])).max() < 1e-12
+    assert np.abs(a.scale(2.5).evaluate([[i, 0, 0] for i in range(3)]) - 2.5 * np.arange(1, 4)).max() < 1e-12
+    one = t4a.SimpleTensorTrain(_rank1_cores([1, 2])) + t4a.SimpleTensorTrain(_rank1_cores([10, 20]))
+    assert np.array_equal(one.evaluate([[0], [1]]), [11.0, 22.0]) and [tuple(d) for d in one.dims()] == [(1, 2, 1)]
+    with pytest.raises(t4a.T4aError):
+        a + t4a.SimpleTensorTrain(_rank1_cores([1, 2, 3], [1, 1, 1]))
+    with pytest.raises(t4a.T4aError):
+        a + t4a.SimpleTensorTrain(_rank1_cores([1, 2, 3], [1, 1], [1, 1]))
+    with pytest.raises(t4a.T4aError):
+        tt.partial_sum([3])
+
+
+def test_tt_arithmetic_matches_oracle_bitwise(t4a):
+    rng = np.random.default_rng(21)
+    sa = [(1, 2, 3), (3, 4, 5), (5, 3, 4), (4, 2, 2), (2, 3, 1)]
+    sb = [(1, 2, 2), (2, 4, 6), (6, 3, 3), (3, 2, 4), (4, 3, 1)]
+    ca, cb = [rng.standard_normal(s) for s in sa], [rng.standard_normal(s) for s in sb]
+    da, db = t4a.SimpleTensorTrain(ca), t4a.SimpleTensorTrain(cb)
+    oa, ob_ = ob.OracleTT(ca), ob.OracleTT(cb)
+
+    def same(d, o):
+        oc = o.cores()
+        assert [tuple(x) for x in d.dims()] == [c.shape for c in oc]
+        for s, c in enumerate(oc):
+            assert np.array_equal(d.site_tensor(s), c), s
+    same(da.add(db), oa.add(ob_))
+    same(da.sub(db), oa.sub(ob_))
+    same(da.scale(-0.37), oa.scale(-0.37))
+    same(da.reverse(), oa.reverse())
+    for dims in ([], [0], [4], [1, 3], [0, 1], [3, 4], [0, 2, 4], [0, 1, 2, 3, 4]):
+        same(da.partial_sum(dims), oa.partial_sum(dims))
+    # add then compress: the usual pipeline around the sweep
+    s = da.add(db)
+    dense = np.einsum("aib,bjc,ckd,dle,emf->ijklm", *ca) + np.einsum("aib,bjc,ckd,dle,emf->ijklm", *cb)
+    assert np.abs(s.evaluate(_grid_pts([2, 4, 3, 2, 3])).reshape(dense.shape) - dense).max() < 1e-12
+    s.compress(tolerance=1e-13)
+    assert np.abs(s.evaluate(_grid_pts([2, 4, 3, 2, 3])).reshape(dense.shape) - dense).max() < 1e-10

@@ -280,3 +280,74 @@ def test_from_tensor_train_rejects_bad_options():
         tt.to_tci2(max_iter=1)
     with pytest.raises(ob.OracleError):
         ob.OracleTT(ob.constant_tt([2], 1.0)).to_tci2()
+
+
+# ---- SimpleTensorTrain arithmetic (simplett/src/arithmetic.rs, tensortrain.rs:264-583; fixtures of tensortrain/tests/mod.rs) ----
+def _rank1(*vectors):
+    return ob.OracleTT([np.asarray(v, dtype=float).reshape(1, -1, 1) for v in vectors])
+
+
+def _grid(dims):
+    import itertools
+    return list(itertools.product(*[range(d) for d in dims]))
+
+
+def test_tt_scale_reverse_fixtures():
+    # tests/mod.rs:64-90: constant(&[2, 2], 1).scale_mut(3) sums to 12; reverse swaps the site order
+    tt = ob.OracleTT([np.ones((1, 2, 1)), np.ones((1, 2, 1))]).scale(3.0)
+    assert abs(tt.sum() - 12.0) < 1e-10
+    tt = _rank1([1, 2], [1, 2, 3])
+    rev = tt.reverse()
+    assert [int(d[1]) for d in rev.dims()] == [3, 2]
+    assert rev.evaluate([[2, 1]])[0] == tt.evaluate([[1, 2]])[0]
+    rng = np.random.default_rng(0)
+    cores = [rng.standard_normal(s) for s in [(1, 2, 3), (3, 3, 2), (2, 2, 1)]]
+    tt = ob.OracleTT(cores)
+    pts = _grid([2, 3, 2])
+    assert np.array_equal(tt.reverse().evaluate([p[::-1] for p in pts]), tt.evaluate(pts)) or \
+        np.abs(tt.reverse().evaluate([p[::-1] for p in pts]) - tt.evaluate(pts)).max() < 1e-14
+    assert [c.shape for c in tt.reverse().cores()] == [(1, 2, 2), (2, 3, 3), (3, 2, 1)]
+
+
+def test_tt_partial_sum_fixtures():
+    # tests/mod.rs:297-403
+    tt = ob.OracleTT([np.ones((1, 2, 1)), np.ones((1, 3, 1)), np.ones((1, 2, 1))])
+    r = tt.partial_sum([0, 1, 2])
+    assert len(r) == 1 and abs(r.sum() - tt.sum()) < 1e-12 and abs(tt.sum() - 12.0) < 1e-12
+    r = tt.partial_sum([])
+    assert len(r) == 3 and np.abs(r.evaluate(_grid([2, 3, 2])) - tt.evaluate(_grid([2, 3, 2]))).max() < 1e-12
+    tt = _rank1([1, 2, 3], [1, 2, 3, 4], [1, 2])
+    r = tt.partial_sum([1])
+    assert len(r) == 2
+    for i, k in _grid([3, 2]):
+        assert abs(r.evaluate([[i, k]])[0] - (1 + i) * 10.0 * (1 + k)) < 1e-10
+    r = tt.partial_sum([0, 2])
+    assert len(r) == 1
+    for j in range(4):
+        assert abs(r.evaluate([[j]])[0] - 18.0 * (1 + j)) < 1e-10
+    with pytest.raises(ob.OracleError):
+        tt.partial_sum([3])
+    rng = np.random.default_rng(1)
+    cores = [rng.standard_normal(s) for s in [(1, 2, 3), (3, 3, 4), (4, 2, 2), (2, 3, 1)]]
+    full = np.einsum("aib,bjc,ckd,dle->ijkl", *cores)
+    r = ob.OracleTT(cores).partial_sum([1, 3])
+    assert np.abs(r.evaluate(_grid([2, 2])).reshape(2, 2) - full.sum(axis=(1, 3))).max() < 1e-12
+
+
+def test_tt_addition_fixtures():
+    # tests/mod.rs:441-512
+    a, b = _rank1([1, 2, 3], [1, 1, 1], [1, 1]), _rank1([1, 1, 1], [1, 2, 3], [1, 1])
+    pts = _grid([3, 3, 2])
+    exp_add = np.array([(1 + i) + (1 + j) for i, j, k in pts], dtype=float)
+    exp_sub = np.array([i - j for i, j, k in pts], dtype=float)
+    assert np.abs(a.add(b).evaluate(pts) - exp_add).max() < 1e-12
+    assert np.abs(a.sub(b).evaluate(pts) - exp_sub).max() < 1e-12
+    assert a.add(b).link_dims() == [2, 2]
+    for i in range(3):
+        assert abs(a.scale(2.5).evaluate([[i, 0, 0]])[0] - 2.5 * (1 + i)) < 1e-12
+    one_a, one_b = _rank1([1, 2]), _rank1([10, 20])  # single site: bonds stay 1
+    assert np.array_equal(one_a.add(one_b).evaluate([[0], [1]]), [11.0, 22.0])
+    with pytest.raises(ob.OracleError):
+        a.add(_rank1([1, 2, 3], [1, 1, 1]))
+    with pytest.raises(ob.OracleError):
+        a.add(_rank1([1, 2, 3], [1, 1], [1, 1]))
