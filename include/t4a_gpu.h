@@ -572,6 +572,8 @@ t4a_gpu_status t4a_gpu_tensor_factorize(const t4a_gpu_tensor* t, const int64_t* 
 t4a_gpu_status t4a_gpu_tt_add(const t4a_gpu_tt* a, const t4a_gpu_tt* b, t4a_gpu_tt** out);
 t4a_gpu_status t4a_gpu_tt_sub(const t4a_gpu_tt* a, const t4a_gpu_tt* b, t4a_gpu_tt** out);
 t4a_gpu_status t4a_gpu_tt_scale(t4a_gpu_tt* h, double factor);
+/* inner_product (simplett/src/contraction.rs:82-186): sum over all indices of a * b, two MFMA GEMMs per site */
+t4a_gpu_status t4a_gpu_tt_inner_product(const t4a_gpu_tt* a, const t4a_gpu_tt* b, double* out);
 t4a_gpu_status t4a_gpu_tt_reverse(const t4a_gpu_tt* h, t4a_gpu_tt** out);
 t4a_gpu_status t4a_gpu_tt_partial_sum(const t4a_gpu_tt* h, const size_t* dims, size_t n_dims, t4a_gpu_tt** out);
 

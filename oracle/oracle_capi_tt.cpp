@@ -337,6 +337,10 @@ void* oracle_tt_binary(void* a, void* b, int op /* 0 add, 1 sub */)
     });
     return rc == 0 ? h : nullptr;
 }
+int oracle_tt_inner_product(void* a, void* b, double* out)
+{
+    return guarded([&] { *out = tt_inner_product(static_cast<OracleTT*>(a)->tt, static_cast<OracleTT*>(b)->tt); });
+}
 void* oracle_tt_unary(void* a, int op /* 0 scale, 1 reverse, 2 partial_sum */, double factor, const uint64_t* dims, uint64_t n_dims)
 {
     OracleTT* h = nullptr;

@@ -769,6 +769,24 @@ inline SimpleTensorTrain tt_add(const SimpleTensorTrain& a, const SimpleTensorTr
 
 inline SimpleTensorTrain tt_sub(const SimpleTensorTrain& a, const SimpleTensorTrain& b) { return tt_add(a, tt_scale(b, -1.0)); } // :161-175
 
+// contraction.rs:82-186 inner_product: the environment ("ij,isk,jsl->kl") is tenferro einsum in the reference (contraction
+// order backend-defined); restated as env^T * A followed by (env^T A)^T * B, k ascending
+inline double tt_inner_product(const SimpleTensorTrain& a, const SimpleTensorTrain& b)
+{
+    if (a.len() != b.len()) throw OracleError(ERR_INVALID_ARGUMENT, "Cannot compute inner_product product of tensor trains with different lengths");
+    if (a.len() == 0) return 0.0;
+    Matrix env(1, 1);
+    env(0, 0) = 1.0;
+    for (size_t i = 0; i < a.len(); ++i) {
+        const Tensor3& x = a.tensors[i];
+        const Tensor3& y = b.tensors[i];
+        if (x.s != y.s) throw OracleError(ERR_INVALID_ARGUMENT, "Site dimensions mismatch");
+        const Matrix tmp = mat_mul(transpose(env), Matrix(x.l, x.s * x.r, x.d.data())); // (L_b) x (S R_a)
+        env = mat_mul(transpose(Matrix(y.l * x.s, x.r, tmp.a.data())), Matrix(y.l * y.s, y.r, y.d.data()));
+    }
+    return env(0, 0);
+}
+
 inline SimpleTensorTrain tt_reverse(const SimpleTensorTrain& a) // tensortrain.rs:327-345
 {
     SimpleTensorTrain r;

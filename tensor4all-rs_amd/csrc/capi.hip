@@ -2625,6 +2625,16 @@ t4a_gpu_status t4a_gpu_tt_scale(t4a_gpu_tt* h, double factor)
     });
 }
 
+t4a_gpu_status t4a_gpu_tt_inner_product(const t4a_gpu_tt* a, const t4a_gpu_tt* b, double* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(b);
+        T4A_REQUIRE_PTR(out);
+        *out = const_cast<t4a_gpu_tt*>(a)->impl.inner_product(const_cast<t4a_gpu_tt*>(b)->impl);
+    });
+}
+
 t4a_gpu_status t4a_gpu_tt_reverse(const t4a_gpu_tt* h, t4a_gpu_tt** out)
 {
     return guarded([&] {

@@ -578,6 +578,71 @@ std::unique_ptr<TensorTrain> TensorTrain::add(TensorTrain& other, bool subtract)
     return std::make_unique<TensorTrain>(out, st);
 }
 
+double TensorTrain::inner_product(TensorTrain& other)
+{
+    if (len() != other.len())
+        throw Error(T4A_GPU_INVALID_ARGUMENT, "Cannot compute inner_product product of tensor trains with different lengths: " +
+                                                  std::to_string(len()) + " vs " + std::to_string(other.len()));
+    if (cores.empty()) return 0.0;
+    other.eng.sync();
+    hipStream_t st = eng.stream();
+    DevBuf<double> env, tmp, nxt;
+    env.reserve(1);
+    fill_launch(env.get(), 1, 1.0, st);
+    size_t ea = 1, eb = 1; // env is ea x eb (bond of this, bond of other)
+    for (size_t i = 0; i < len(); ++i) {
+        const DevCore& x = cores[i];
+        const DevCore& y = other.cores[i];
+        if (x.s != y.s)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "Site dimensions mismatch at site " + std::to_string(i) + ": " + std::to_string(x.s) + " vs " +
+                                                      std::to_string(y.s));
+        // tmp (eb x S R_a) = env^T * X,  then env' (R_a x R_b) = tmp^T (R_a x eb S) * Y (eb S x R_b)
+        tmp.reserve(std::max<size_t>(eb * x.s * x.r, 1));
+        nxt.reserve(std::max<size_t>(x.r * y.r, 1));
+        GemmDesc g{};
+        g.m = (int)eb;
+        g.n = (int)(x.s * x.r);
+        g.k = (int)ea;
+        g.A = env.get();
+        g.lda = (int)ea;
+        g.transA = 1;
+        g.B = x.buf.get();
+        g.ldb = (int)x.l;
+        g.transB = 0;
+        g.C = tmp.get();
+        g.ldc = (int)eb;
+        g.alpha = 1.0;
+        g.beta = 0.0;
+        g.batch = 1;
+        gemm_launch(g, st);
+        GemmDesc h{};
+        h.m = (int)x.r;
+        h.n = (int)y.r;
+        h.k = (int)(eb * x.s);
+        h.A = tmp.get();
+        h.lda = (int)(eb * x.s);
+        h.transA = 1;
+        h.B = y.buf.get();
+        h.ldb = (int)(y.l * y.s);
+        h.transB = 0;
+        h.C = nxt.get();
+        h.ldc = (int)x.r;
+        h.alpha = 1.0;
+        h.beta = 0.0;
+        h.batch = 1;
+        gemm_launch(h, st);
+        eng.sync();
+        std::swap(env, nxt);
+        ea = x.r;
+        eb = y.r;
+    }
+    double v = 0.0;
+    T4A_HIP(hipGetLastError());
+    T4A_HIP(hipMemcpyAsync(&v, env.get(), sizeof(double), hipMemcpyDeviceToHost, st));
+    eng.sync();
+    return v;
+}
+
 std::unique_ptr<TensorTrain> TensorTrain::reverse()
 {
     hipStream_t st = eng.stream();

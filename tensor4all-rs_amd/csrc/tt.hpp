@@ -46,6 +46,7 @@ public:
     // arithmetic.rs:34-180, tensortrain.rs:264-345, :449-583 — results are new device-resident trains
     std::unique_ptr<TensorTrain> add(TensorTrain& other, bool subtract);
     void scale(double factor); // scale_mut: the last core carries the factor
+    double inner_product(TensorTrain& other); // contraction.rs:82-186, two MFMA GEMMs per site
     std::unique_ptr<TensorTrain> reverse();
     std::unique_ptr<TensorTrain> partial_sum(const std::vector<size_t>& dims);
     // TTCache::evaluate_many; split == 0 -> find_split_heuristic.  Returns the split that was used.

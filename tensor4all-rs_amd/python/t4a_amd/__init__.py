@@ -696,6 +696,12 @@ class SimpleTensorTrain:
     def negate(self):
         return self.scale(-1.0)
 
+    def inner_product(self, other):
+        """inner_product (contraction.rs:82-186)"""
+        v = c_double(0)
+        _check(_lib.t4a_gpu_tt_inner_product(self._h, other._h, ctypes.byref(v)))
+        return v.value
+
     def reverse(self):
         h = c_void_p()
         _check(_lib.t4a_gpu_tt_reverse(self._h, ctypes.byref(h)))

@@ -449,6 +449,11 @@ class OracleTT:
     def sub(self, other):
         return self._wrap(_lib.oracle_tt_binary(vp(self._h), vp(other._h), cint(1)))
 
+    def inner_product(self, other):
+        v = dbl(0)
+        _check_tt(_lib.oracle_tt_inner_product(vp(self._h), vp(other._h), ctypes.byref(v)))
+        return v.value
+
     def scale(self, factor):
         return self._wrap(_lib.oracle_tt_unary(vp(self._h), cint(0), dbl(factor), None, u64(0)))
 

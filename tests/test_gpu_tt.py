@@ -399,3 +399,24 @@ def test_tt_arithmetic_matches_oracle_bitwise(t4a):
     assert np.abs(s.evaluate(_grid_pts([2, 4, 3, 2, 3])).reshape(dense.shape) - dense).max() < 1e-12
     s.compress(tolerance=1e-13)
     assert np.abs(s.evaluate(_grid_pts([2, 4, 3, 2, 3])).reshape(dense.shape) - dense).max() < 1e-10
+
+
+def test_tt_inner_product(t4a):
+    # contraction/tests/mod.rs:8-68, :177-185 and parity with the oracle / the dense sum
+    c = t4a.SimpleTensorTrain.constant
+    assert abs(c([2, 3], 2.0).inner_product(c([2, 3], 3.0)) - 36.0) < 1e-10
+    assert abs(c([2, 3, 2], 1.0).inner_product(c([2, 3, 2], 2.0)) - 24.0) < 1e-10
+    rng = np.random.default_rng(31)
+    sa = [(1, 2, 7), (7, 3, 20), (20, 2, 33), (33, 4, 9), (9, 2, 1)]
+    sb = [(1, 2, 5), (5, 3, 18), (18, 2, 40), (40, 4, 6), (6, 2, 1)]
+    ca, cb = [rng.standard_normal(s) for s in sa], [rng.standard_normal(s) for s in sb]
+    da, db = t4a.SimpleTensorTrain(ca), t4a.SimpleTensorTrain(cb)
+    pts = _grid_pts([2, 3, 2, 4, 2])
+    exact = float(np.dot(da.evaluate(pts), db.evaluate(pts)))
+    got, ref = da.inner_product(db), ob.OracleTT(ca).inner_product(ob.OracleTT(cb))
+    assert abs(got - ref) < 1e-10 * abs(ref) and abs(got - exact) < 1e-10 * abs(exact)
+    assert abs(da.inner_product(da) - da.norm2()) < 1e-10 * da.norm2()
+    with pytest.raises(t4a.T4aError):
+        da.inner_product(c([2, 3], 1.0))
+    with pytest.raises(t4a.T4aError):
+        da.inner_product(c([2, 3, 2, 4, 3], 1.0))

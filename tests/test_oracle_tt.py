@@ -351,3 +351,21 @@ def test_tt_addition_fixtures():
         a.add(_rank1([1, 2, 3], [1, 1, 1]))
     with pytest.raises(ob.OracleError):
         a.add(_rank1([1, 2, 3], [1, 1], [1, 1]))
+
+
+def test_tt_inner_product_fixtures():
+    # contraction/tests/mod.rs:8-68, :112-128, :177-185
+    c = lambda dims, v: ob.OracleTT([np.ones((1, d, 1)) * (v if i == 0 else 1.0) for i, d in enumerate(dims)])
+    assert abs(c([2, 3], 2.0).inner_product(c([2, 3], 3.0)) - 36.0) < 1e-10
+    assert abs(c([2, 3, 2], 1.0).inner_product(c([2, 3, 2], 2.0)) - 24.0) < 1e-10
+    t0a = np.array([[s + r + 1.0 for r in range(2)] for s in range(3)]).reshape(1, 3, 2)
+    t1a = np.array([[l + s + 1.0 for s in range(2)] for l in range(2)]).reshape(2, 2, 1)
+    a = ob.OracleTT([t0a, t1a])
+    b = _rank1([0.5, 1.0, 1.5], [0.6, 0.9])
+    pts = _grid([3, 2])
+    assert abs(a.inner_product(b) - float(np.dot(a.evaluate(pts), b.evaluate(pts)))) < 1e-10
+    assert ob.OracleTT([]).inner_product(ob.OracleTT([])) == 0.0
+    with pytest.raises(ob.OracleError):
+        a.inner_product(_rank1([1, 2, 3]))
+    with pytest.raises(ob.OracleError):
+        a.inner_product(_rank1([1, 2, 3, 4], [1, 2]))
