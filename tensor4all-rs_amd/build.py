@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "build")
 SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "kernels_rrlu_global.hip", "kernels_pi.hip", "kernels_dense.hip", "kernels_linalg.hip",
            "kernels_tt.hip", "engine.hip", "rook.hip", "tt.hip", "tci2.hip", "conversion.hip", "patching.hip", "tree.hip", "quantics.hip", "tensorops.hip", "aci.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-fvisibility=hidden"]
+         "-fvisibility=hidden"] + os.environ.get("T4A_EXTRA_FLAGS", "").split()  # e.g. -DT4A_RRLU_TRACE (tools/trace_arrivals.py)
 HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
            "../../include/t4a_testfunctions.h"]
 

@@ -3,6 +3,7 @@
 #include "engine.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -243,6 +244,18 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         }
         a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());
         a.block_u64 = (int)(out_bytes / 8);
+        a.trace = nullptr;
+#ifdef T4A_RRLU_TRACE
+        static const char* trace_file = std::getenv("T4A_RRLU_TRACE_FILE");
+        const size_t trace_words = (size_t)rplan.W * (1 + 4 * (size_t)(max_steps + 1));
+        const bool tracing = trace_file && rplan.W > 1 && kM > 600 && trace_dumps_ >= 20 && trace_dumps_ < 24;
+        if (trace_file && rplan.W > 1 && kM > 600) ++trace_dumps_;
+        if (tracing) {
+            d_trace_.reserve(trace_words);
+            T4A_HIP(hipMemsetAsync(d_trace_.get(), 0, trace_words * 8, stream_));
+            a.trace = d_trace_.get();
+        }
+#endif
         mirrored = true;
         keys_clean_ = false; // becomes true again once the launch is known to have finished cleanly
         rrlu_reg_launch(rplan, a, stream_, true);
@@ -315,6 +328,19 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     }
     T4A_HIP(hipStreamSynchronize(stream_));
 
+#ifdef T4A_RRLU_TRACE
+    if (mirrored && d_trace_.get() && std::getenv("T4A_RRLU_TRACE_FILE") && trace_dumps_ > 20 && trace_dumps_ <= 24 && plan_W > 1) {
+        const size_t words = (size_t)plan_W * (1 + 4 * (size_t)(max_steps + 1));
+        std::vector<unsigned long long> ht(words);
+        T4A_HIP(hipMemcpy(ht.data(), d_trace_.get(), words * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(std::getenv("T4A_RRLU_TRACE_FILE"), "ab")) {
+            const long long hdr[4] = {M, N, plan_W, max_steps};
+            std::fwrite(hdr, sizeof(hdr), 1, f);
+            std::fwrite(ht.data(), 8, words, f);
+            std::fclose(f);
+        }
+    }
+#endif
     // host views of the packed block (hp: [4 + M + N] ints, hr: [2 + max_steps] doubles, as before)
     std::vector<int>& hpv = h_ints_;
     hpv.resize(4 + (size_t)M + N);

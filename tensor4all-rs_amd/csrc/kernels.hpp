@@ -132,6 +132,9 @@ struct RrluRegArgs {
     // of this launch together with the accumulated max|a| word, so that no memset is needed between launches
     unsigned long long* keys_next;
     int keys_next_u64;
+    // arrival trace (only read by builds with -DT4A_RRLU_TRACE, nullptr otherwise): [W] XCC ids, then per step and
+    // workgroup the real-time clock at key publication and at the end of the key gather
+    unsigned long long* trace;
     // fused candidate-matrix build: when `fused` != 0 the kernel never reads A; entry (i, j) of ITS row / column
     // numbering is fn(rowacc[i] + colacc[j]) (accumulators [count][fn.n_acc] uint64, see kernels_pi.hip)
     int fused;

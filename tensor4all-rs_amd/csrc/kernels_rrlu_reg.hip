@@ -303,6 +303,13 @@ rrlu_reg_kernel(RrluRegArgs p)
     }
     __syncthreads();
 
+#ifdef T4A_RRLU_TRACE
+    if (p.trace && tid == 0 && !SINGLE) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.trace[w] = xcc & 0xF;
+    }
+#endif
     const bool stamp_on = (p.stamps != nullptr) && w == 0 && tid == 0;
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -388,6 +395,9 @@ rrlu_reg_kernel(RrluRegArgs p)
                     if (cpos[q] == kn && a[q][r] != a[q][r]) m = __builtin_huge_val();
             }
         T4A_RSTAMP(0);
+#ifdef T4A_RRLU_TRACE
+        if (p.trace && tid == 0 && !SINGLE) p.trace[p.W + ((size_t)kn * p.W + w) * 4 + 3] = wall_clock64(); // pass of step k done
+#endif
         // ---- workgroup reduction: (max score, smallest position among the maxima, value there) ----
         const double wmax = wave_max_f64(m);
         unsigned mypos = NOPOS;
@@ -504,6 +514,9 @@ rrlu_reg_kernel(RrluRegArgs p)
             const int poll_wave = nwaves > 1 ? 1 : 0; // not the storing wave: its loads would queue behind its stores
             const unsigned long long tag16 = (unsigned long long)((unsigned)kn % 65535u + 1u);
             if (wave == 0 && lane == 0) {
+#ifdef T4A_RRLU_TRACE
+                if (p.trace) p.trace[p.W + ((size_t)kn * p.W + w) * 4] = wall_clock64();
+#endif
                 const unsigned long long vb = (unsigned long long)__double_as_longlong(bval);
                 unsigned long long* kd = p.keys + ((size_t)par * p.W + w) * 2;
                 st_u64_sc1(kd + 0, (tag16 << 48) | (vb >> 16));
@@ -622,6 +635,9 @@ rrlu_reg_kernel(RrluRegArgs p)
                 }
             }
             __syncthreads(); // (B)
+#ifdef T4A_RRLU_TRACE
+            if (p.trace && tid == 0) p.trace[p.W + ((size_t)kn * p.W + w) * 4 + 1] = wall_clock64();
+#endif
             if (s.win_i[2]) {
                 timed_out = true;
                 break;
@@ -767,6 +783,9 @@ rrlu_reg_kernel(RrluRegArgs p)
                     l[r] = raw / wval;
                 }
         }
+#ifdef T4A_RRLU_TRACE
+        if (p.trace && tid == 0 && !SINGLE) p.trace[p.W + ((size_t)kn * p.W + w) * 4 + 2] = wall_clock64(); // column of step kn in registers
+#endif
         __syncthreads(); // (C): urow visible, everybody has read the position tables
         if (!SINGLE && s.win_i[2]) {
             timed_out = true;
