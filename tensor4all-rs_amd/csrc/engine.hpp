@@ -119,8 +119,10 @@ private:
     DevBuf<int> d_gints_;      // HBM-resident rrLU workspace
     DevBuf<double> d_gdbls_;
     EventTimer ev_rrlu_, ev_fac_;
+#ifdef T4A_RRLU_TRACE
     DevBuf<unsigned long long> d_trace_; // T4A_RRLU_TRACE_FILE (diagnostic builds only)
     int trace_dumps_ = 0;
+#endif
     // SVD / QR workspaces
     DevBuf<double> d_sw_, d_sv_, d_su_, d_svs_, d_ssig_;
     DevBuf<int> d_sflags_;
