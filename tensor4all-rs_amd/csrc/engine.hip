@@ -227,7 +227,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         static const double spec_frac_env = std::getenv("T4A_RRLU_SPECFRAC") ? std::atof(std::getenv("T4A_RRLU_SPECFRAC")) : 0.66;
         a.spec_frac = spec_frac_env;
         static const int key16_env = std::getenv("T4A_RRLU_KEY16") ? std::atoi(std::getenv("T4A_RRLU_KEY16")) : 1;
-        a.key16 = key16_env ? 1 : 0;
+        a.key16 = key16_env; // bit 0: 16-byte key loads, bit 1: 16-byte key store
         a.spin_limit = 1u << 20;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
         // results land in the pinned mirror straight from the kernel: no device-to-host copy afterwards

@@ -63,6 +63,22 @@ __device__ __forceinline__ void st_b128_sc1(void* p, u32x4 v)
 {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+// one pivot-column row = two tagged 8-byte granules {value lo | tag, value hi | tag}, stored as ONE 16-byte write-through
+// store (a single fabric write; measured against two 8-byte stores with T4A_RRLU_COL_ST8 builds)
+__device__ __forceinline__ void st_col_row(unsigned long long* dst, unsigned long long tagbits, unsigned long long vb)
+{
+#ifdef T4A_RRLU_COL_ST8
+    st_u64_sc1(dst, tagbits | (vb & 0xFFFFFFFFull));
+    st_u64_sc1(dst + 1, tagbits | (vb >> 32));
+#else
+    u32x4 v;
+    v.x = (unsigned)vb;
+    v.y = (unsigned)(tagbits >> 32);
+    v.z = (unsigned)(vb >> 32);
+    v.w = (unsigned)(tagbits >> 32);
+    st_b128_sc1(dst, v);
+#endif
+}
 template <int N> struct Load16;
 template <> struct Load16<1> {
     static __device__ __forceinline__ void run(const void* const* p, u32x4* o)
@@ -519,8 +535,19 @@ rrlu_reg_kernel(RrluRegArgs p)
 #endif
                 const unsigned long long vb = (unsigned long long)__double_as_longlong(bval);
                 unsigned long long* kd = p.keys + ((size_t)par * p.W + w) * 2;
-                st_u64_sc1(kd + 0, (tag16 << 48) | (vb >> 16));
-                st_u64_sc1(kd + 1, (tag16 << 48) | ((vb & 0xFFFFull) << 32) | (unsigned long long)bpos);
+                const unsigned long long k0 = (tag16 << 48) | (vb >> 16);
+                const unsigned long long k1 = (tag16 << 48) | ((vb & 0xFFFFull) << 32) | (unsigned long long)bpos;
+#ifdef T4A_RRLU_KEY_ST8 // the two 8-byte stores of the first versions (A/B builds only)
+                st_u64_sc1(kd + 0, k0);
+                st_u64_sc1(kd + 1, k1);
+#else
+                u32x4 kv; // one 16-byte write-through store: a single fabric write instead of two
+                kv.x = (unsigned)k0;
+                kv.y = (unsigned)(k0 >> 32);
+                kv.z = (unsigned)k1;
+                kv.w = (unsigned)(k1 >> 32);
+                st_b128_sc1(kd, kv);
+#endif
             }
             // everybody else (and the pusher afterwards) prepares the candidate column while the keys travel
 #pragma unroll
@@ -542,8 +569,7 @@ rrlu_reg_kernel(RrluRegArgs p)
                     if (irow[r] >= 0) {
                         const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
                         unsigned long long* dst = p.cols + (((size_t)par * p.W + w) * (size_t)p.M + irow[r]) * 2;
-                        st_u64_sc1(dst, tagbits | (vb & 0xFFFFFFFFull));
-                        st_u64_sc1(dst + 1, tagbits | (vb >> 32));
+                        st_col_row(dst, tagbits, vb);
                     }
             }
             T4A_RSTAMP(2);
@@ -561,7 +587,7 @@ rrlu_reg_kernel(RrluRegArgs p)
                 unsigned long long g[KPL][2];
                 for (;;) {
                     bool ok = true;
-                    if (p.key16) { // one 16-byte load per key instead of two 8-byte ones
+                    if (p.key16 & 1) { // one 16-byte load per key instead of two 8-byte ones
                         const void* ptrs[KPL];
                         u32x4 got[KPL];
 #pragma unroll
@@ -653,8 +679,7 @@ rrlu_reg_kernel(RrluRegArgs p)
                     if (irow[r] >= 0) {
                         const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
                         unsigned long long* dst = p.cols + (((size_t)par * p.W + w) * (size_t)p.M + irow[r]) * 2;
-                        st_u64_sc1(dst, tagbits | (vb & 0xFFFFFFFFull));
-                        st_u64_sc1(dst + 1, tagbits | (vb >> 32));
+                        st_col_row(dst, tagbits, vb);
                     }
             }
             if (!T4A_SPEC(p) && ww == w && qstar >= 0) {

@@ -15,7 +15,7 @@ from .functions import (FnSpec, quantics_trig_exp, quantics_osc2d, lorentz, line
                         FN_MAX_PARAMS)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libt4a_gpu.so"))
+LIB_PATH = os.environ.get("T4A_GPU_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libt4a_gpu.so"))  # env: A/B builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} not found: build it with `python tensor4all-rs_amd/build.py` "
