@@ -186,9 +186,10 @@ def main():
         bytes_per_launch = prof["dom_bytes"] / max(prof["dom_launches"], 1)
         code = prof["dom_code"]
         if code >= 0:
-            kname = "t4a::rrlu_reg_kernel<%d, %d, %s, %s>" % (code // 1000, (code % 1000) // 10,
-                                                               "true" if (code % 10) & 2 else "false",
-                                                               "true" if (code % 10) & 1 else "false")
+            kname = "t4a::rrlu_reg_kernel<%d, %d, %s, %s, %s>" % (code // 1000, (code % 1000) // 10,
+                                                                   "true" if (code % 10) & 2 else "false",
+                                                                   "true" if (code % 10) & 1 else "false",
+                                                                   "true" if (code % 10) & 4 else "false")
         else:
             kname = "t4a::rrlu_kernel<%s>" % ("true" if code == -1 else "false")
         achieved = bytes_per_launch / (rrlu_ms_avg * 1e-3) / 1e9 if rrlu_ms_avg > 0 else 0.0

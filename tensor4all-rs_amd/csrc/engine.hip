@@ -261,7 +261,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         rrlu_reg_launch(rplan, a, stream_, true);
         plan_W = rplan.W;
         plan_T = rplan.T;
-        plan_code = rplan.RPT * 1000 + rplan.CPT * 10 + (rplan.W == 1 ? 2 : 0) + ((rplan.TR % 64) == 0 ? 1 : 0);
+        plan_code = rplan.RPT * 1000 + rplan.CPT * 10 + (a.tie_row_major ? 4 : 0) + (rplan.W == 1 ? 2 : 0) + ((rplan.TR % 64) == 0 ? 1 : 0);
     } else if (huge || force_global || rrlu_make_plan(M, N, num_cus_).lds_bytes > 160 * 1024) {
         // neither the register file nor the LDS of the chip holds this matrix: HBM-resident kernel pair per pivot step
         const int gb = rrlu_global_blocks(M, N);

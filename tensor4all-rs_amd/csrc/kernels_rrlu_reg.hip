@@ -231,7 +231,8 @@ __host__ __device__ inline size_t reg_smem_layout(int M, int N, int cols_per_wg,
 
 // UNI: every wave lies inside one column group (TR % 64 == 0), so the column state is wave-uniform and the
 // per-column tests become scalar branches.
-template <int RPT, int CPT, bool SINGLE, bool UNI>
+// ROWMAJOR: ties of the arg-max break row-major (the right-orthogonal factorisation runs on the transposed matrix).
+template <int RPT, int CPT, bool SINGLE, bool UNI, bool ROWMAJOR>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, (RPT * CPT > 24) ? 256 : 512)))
 rrlu_reg_kernel(RrluRegArgs p)
 {
@@ -247,7 +248,7 @@ rrlu_reg_kernel(RrluRegArgs p)
     const int w = SINGLE ? 0 : (int)blockIdx.x;
     const int tr = tid % p.TR;
     const int tc = tid / p.TR;
-    const bool rowmajor = p.tie_row_major != 0;
+    constexpr bool rowmajor = ROWMAJOR; // tie order of the arg-max: a run-time flag here costs the loop 1.5 %
 
     // ---- my rows / columns ----
     int irow[RPT], rpos[RPT];
@@ -587,7 +588,12 @@ rrlu_reg_kernel(RrluRegArgs p)
                 unsigned long long g[KPL][2];
                 for (;;) {
                     bool ok = true;
-                    if (p.key16 & 1) { // one 16-byte load per key instead of two 8-byte ones
+#ifdef T4A_RRLU_KEY_LD8 // two 8-byte loads per key (A/B builds only); a run-time switch here costs the loop 1 %
+                    const bool key_ld16 = false;
+#else
+                    const bool key_ld16 = true;
+#endif
+                    if (key_ld16) { // one 16-byte load per key instead of two 8-byte ones
                         const void* ptrs[KPL];
                         u32x4 got[KPL];
 #pragma unroll
@@ -880,17 +886,24 @@ rrlu_reg_kernel(RrluRegArgs p)
     }
 }
 
-template <int RPT, int CPT, bool SINGLE, bool UNI>
-void launch_one(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
+template <int RPT, int CPT, bool SINGLE, bool UNI, bool ROWMAJOR>
+void launch_tie(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_reg_kernel<RPT, CPT, SINGLE, UNI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_reg_kernel<RPT, CPT, SINGLE, UNI, ROWMAJOR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((rrlu_reg_kernel<RPT, CPT, SINGLE, UNI>), dim3(SINGLE ? 1 : plan.W), dim3(plan.T), plan.lds_bytes,
+    hipLaunchKernelGGL((rrlu_reg_kernel<RPT, CPT, SINGLE, UNI, ROWMAJOR>), dim3(SINGLE ? 1 : plan.W), dim3(plan.T), plan.lds_bytes,
                        stream, a);
+}
+
+template <int RPT, int CPT, bool SINGLE, bool UNI>
+void launch_one(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
+{
+    if (a.tie_row_major) launch_tie<RPT, CPT, SINGLE, UNI, true>(plan, a, stream);
+    else launch_tie<RPT, CPT, SINGLE, UNI, false>(plan, a, stream);
 }
 
 template <int RPT, int CPT> void launch_rc(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
