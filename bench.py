@@ -268,7 +268,12 @@ def pmc_traffic(kname):
     except (OSError, ValueError):
         return None
     short = kname.replace("t4a::", "")
-    return d["hbm_bytes_per_launch"] if short and short in d.get("kernel", "") else None
+    if not short:
+        return None
+    for name, nbytes in d.get("rrlu_reg_variants", {}).items():
+        if short in name:
+            return nbytes
+    return d["hbm_bytes_per_launch"] if short in d.get("kernel", "") else None
 
 
 def cpu_baseline(tci, spec):

@@ -47,5 +47,7 @@ json.dump({"kernel": dom[0],
                       "(default --steps 5 --warmup 2; two separate passes), summarised by tools/pmc_summary.py",
            "FETCH_SIZE_avg_KB": dom[2], "WRITE_SIZE_avg_KB": dom[3], "hbm_bytes_per_launch": dom[4],
            "correction": "gfx950: FETCH_SIZE counts 128-B read requests at 64 B -> doubled (MI355X_MICROARCH.md §HBM); units are KiB",
-           "dispatches": dom[1]}, open(os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json"), "w"), indent=1)
+           "dispatches": dom[1],
+           # every rrLU register-kernel instantiation of the run (the two tie orders of a shape take turns as the dominant one)
+           "rrlu_reg_variants": {r[0]: r[4] for r in rows if "rrlu_reg_kernel" in r[0]}}, open(os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json"), "w"), indent=1)
 print(dom)
