@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 
 namespace t4a {
@@ -30,6 +31,40 @@ __global__ void __launch_bounds__(256) tri_extract_kernel(const double* __restri
     }
 }
 } // namespace
+
+// ---- process-wide arbiter of the persistent multi-workgroup rrLU kernels ----
+// Their workgroups spin on each other's mailboxes, so all of them must be resident at once: two launches that compete for the
+// same compute units would starve each other until the bounded spins give up.  A single-XCD launch owns one of the eight XCDs
+// for its duration, a chip-wide launch (old register kernel, LDS kernel) owns all of them.
+namespace {
+std::mutex g_xcd_mutex[8];
+std::atomic<int> g_xcd_next{0};
+std::atomic<bool> g_xcd_disabled{false};
+} // namespace
+bool xcd_disabled()
+{
+    static const bool env_off = std::getenv("T4A_NO_XCD") != nullptr;
+    return env_off || g_xcd_disabled.load(std::memory_order_relaxed);
+}
+void xcd_disable() { g_xcd_disabled.store(true, std::memory_order_relaxed); }
+int xcd_assign() { return g_xcd_next.fetch_add(1, std::memory_order_relaxed) & 7; }
+void XcdArbiter::Lock::acquire(int xcc)
+{
+    release();
+    if (xcc >= 0) {
+        g_xcd_mutex[xcc & 7].lock();
+        held_ = 1 << (xcc & 7);
+    } else {
+        for (int i = 0; i < 8; ++i) g_xcd_mutex[i].lock(); // fixed order: no deadlock between two chip-wide owners
+        held_ = 0xFF;
+    }
+}
+void XcdArbiter::Lock::release()
+{
+    for (int i = 7; i >= 0; --i)
+        if (held_ & (1 << i)) g_xcd_mutex[i].unlock();
+    held_ = 0;
+}
 
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const std::string& last_error_ref() { return g_last_error; }
@@ -74,6 +109,8 @@ Engine::Engine()
     }
     ev_rrlu_.init();
     ev_fac_.init();
+    static const int xcc_env = std::getenv("T4A_XCD_ID") ? std::atoi(std::getenv("T4A_XCD_ID")) : -1;
+    xcc_ = xcc_env >= 0 ? (xcc_env & 7) : xcd_assign();
 }
 
 Engine::~Engine()
@@ -87,6 +124,7 @@ Engine::~Engine()
 LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy,
                         const FusedPi* fused)
 {
+    const double* const d_a_in = d_a;
     LuciResult r;
     r.M = M;
     r.N = N;
@@ -146,20 +184,92 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     const bool left = opts.left_orthogonal;
     const int kM = left ? M : N, kN = left ? N : M;
     RrluRegPlan rplan;
-    const bool use_reg = !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
+    RrluXcdPlan xplan;
+    static const bool force_reg = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "reg";
+    // first choice: all workgroups on one XCD (exchange through that XCD's L2); disabled for good once a launch timed out
+    const bool use_xcd = !huge && !force_lds && !force_global && !force_reg && !xcd_disabled() && rrlu_xcd_make_plan(kM, kN, &xplan);
+    const bool use_reg = !use_xcd && !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     bool fuse = false;
+    bool xcd_src_transposed = false;
     if (fused) {
         fuse = use_reg && rplan.RPT * rplan.CPT <= RRLU_FUSED_MAX_VALUES;
         if (!fuse) { // this plan cannot build the matrix in registers: materialise it like the Π kernel would
             double* buf = pi((size_t)M * N);
-            pi_eval_launch(fused->fn, fused->d_rowacc, M, fused->d_colacc, N, buf, M, false, nullptr, stream_);
+            if (use_xcd && !left) { // the kernel works on the transpose: evaluate it in that layout straight away
+                pi_eval_launch(fused->fn, fused->d_colacc, N, fused->d_rowacc, M, buf, N, false, nullptr, stream_);
+                xcd_src_transposed = true;
+            } else {
+                pi_eval_launch(fused->fn, fused->d_rowacc, M, fused->d_colacc, N, buf, M, false, nullptr, stream_);
+            }
             d_a = buf;
         }
     }
     int plan_W = 1, plan_T = 0, plan_code = 0;
     bool mirrored = false;
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.a, stream_));
-    if (use_reg) {
+    XcdArbiter::Lock xcd_lock; // multi-workgroup persistent kernels need their compute units to themselves
+    if (use_xcd) {
+        const double* src = d_a;
+        if (!left && !xcd_src_transposed) {
+            d_at_.reserve((size_t)M * N);
+            transpose_launch(d_a, M, N, M, d_at_.get(), N, stream_);
+            src = d_at_.get();
+        }
+        const size_t need_keys = rrlu_xcd_keys_bytes(xplan) / sizeof(unsigned long long);
+        const size_t need_cols = rrlu_xcd_cols_bytes(xplan, kM) / sizeof(unsigned long long);
+        ++xcd_salt_;
+        if (need_keys > d_xkeys_.cap || need_cols > d_xcols_.cap || xcd_salt_ > 65535u || !d_xticket_.get()) {
+            // granules carry launch-salted tags: clear the mailboxes whenever they move or the 16-bit salt wraps
+            d_xkeys_.reserve(need_keys);
+            d_xcols_.reserve(need_cols);
+            d_xticket_.reserve(4);
+            T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), stream_));
+            T4A_HIP(hipMemsetAsync(d_xcols_.get(), 0, d_xcols_.cap * sizeof(unsigned long long), stream_));
+            T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), stream_));
+            xcd_ticket_base_ = 0;
+            xcd_salt_ = 1;
+        }
+        RrluXcdArgs a;
+        a.A = src;
+        a.Aout = keep_lu ? d_lu_.get() : nullptr;
+        if (keep_lu) d_xurows_.reserve((size_t)(max_steps > 0 ? max_steps : 1) * kN);
+        a.urows = keep_lu ? d_xurows_.get() : nullptr;
+        a.M = kM;
+        a.N = kN;
+        a.max_steps = max_steps;
+        a.rel_tol = opts.rel_tol;
+        a.abs_tol = opts.abs_tol;
+        a.tie_row_major = left ? 0 : 1;
+        a.out_transposed = left ? 0 : 1;
+        a.W = xplan.W;
+        a.xcc = xcc_;
+        a.ticket = d_xticket_.get();
+        a.ticket_base = xcd_ticket_base_;
+        xcd_ticket_base_ += (unsigned)(xplan.grid / 8); // exactly grid / 8 workgroups of a launch land on one XCD
+        a.row_perm = left ? d_rowperm : d_colperm;
+        a.col_perm = left ? d_colperm : d_rowperm;
+        a.iresult = d_ires;
+        a.dresult = d_dres;
+        a.pivot_vals = d_pivvals;
+        a.keys = d_xkeys_.get();
+        a.cols = d_xcols_.get();
+        a.salt = xcd_salt_;
+        static const int xpoll = std::getenv("T4A_XCD_POLLDELAY") ? std::atoi(std::getenv("T4A_XCD_POLLDELAY")) : 0;
+        a.poll_delay = xpoll;
+        static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.66;
+        a.spec_frac = xspec;
+        a.spin_limit = 1u << 20;
+        a.stamps = want_stamps ? d_stamps_.get() : nullptr;
+        std::memset(h_out_.get(), 0, 32);
+        a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());
+        a.block_u64 = (int)(out_bytes / 8);
+        mirrored = true;
+        xcd_lock.acquire(xcc_);
+        rrlu_xcd_launch(xplan, a, stream_);
+        plan_W = xplan.W;
+        plan_T = 512;
+        plan_code = 100000 + xplan.RPT * 100 + xplan.CPT * 10 + (a.tie_row_major ? 4 : 0);
+    } else if (use_reg) {
         const double* src = d_a;
         if (!left && !fuse) {
             d_at_.reserve((size_t)M * N);
@@ -258,6 +368,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
 #endif
         mirrored = true;
         keys_clean_ = false; // becomes true again once the launch is known to have finished cleanly
+        if (rplan.W > 1) xcd_lock.acquire(-1); // chip-wide persistent launch: every XCD
         rrlu_reg_launch(rplan, a, stream_, true);
         plan_W = rplan.W;
         plan_T = rplan.T;
@@ -312,6 +423,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.cols = d_cols_.get();
         a.spin_limit = 1u << 20;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
+        if (plan.W > 1) xcd_lock.acquire(-1);
         rrlu_launch(plan, a, stream_);
         plan_W = plan.W;
         plan_T = plan.T;
@@ -327,6 +439,17 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         hook();
     }
     T4A_HIP(hipStreamSynchronize(stream_));
+    xcd_lock.release();
+    if (use_xcd && reinterpret_cast<const int*>(h_out_.get() + 16)[1] != 0) {
+        // the placement assumption of the single-XCD kernel did not hold (or another process holds the compute units):
+        // never try it again in this process and run this factorisation with the chip-wide kernels
+        xcd_disable();
+        T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
+        T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), stream_));
+        xcd_ticket_base_ = 0;
+        header_clean_ = false;
+        return luci(d_a_in, M, N, opts, need_factors, want_lu_copy, fused);
+    }
 
 #ifdef T4A_RRLU_TRACE
     if (mirrored && d_trace_.get() && std::getenv("T4A_RRLU_TRACE_FILE") && trace_dumps_ > 20 && trace_dumps_ <= 24 && plan_W > 1) {
@@ -364,7 +487,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         T4A_HIP(hipMemcpy(hs, d_stamps_.get(), sizeof(hs), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[rrlu stamps %s] M=%d N=%d W=%d T=%d steps=%d | s0=%llu s1=%llu s2=%llu s3=%llu s4=%llu pollspins=%llu colspins=%llu s7=%llu "
                              "(cycles, wg0/thread0; lds: publish,poll,colfetch,pass,reduce; reg: pass,reduce,publish,poll,fetch)\n",
-                     use_reg ? "reg" : "lds", M, N, plan_W, plan_T, hp[0], hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
+                     use_xcd ? "xcd" : (use_reg ? "reg" : "lds"), M, N, plan_W, plan_T, hp[0], hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
     }
     if (hp[1] != 0)
         throw Error(T4A_GPU_KERNEL_TIMEOUT, "rrLU kernel: inter-workgroup hand-off timed out (bounded spin gave up)");

@@ -44,6 +44,24 @@ struct Profile {
     bool enabled = false;
 };
 
+// process-wide arbiter of the persistent multi-workgroup rrLU kernels (engine.hip)
+bool xcd_disabled();
+void xcd_disable();
+int xcd_assign();
+struct XcdArbiter {
+    class Lock {
+    public:
+        Lock() = default;
+        Lock(const Lock&) = delete;
+        Lock& operator=(const Lock&) = delete;
+        ~Lock() { release(); }
+        void acquire(int xcc); // xcc >= 0: that XCD; -1: the whole chip
+        void release();
+    private:
+        int held_ = 0;
+    };
+};
+
 class Engine {
 public:
     Engine();
@@ -103,6 +121,12 @@ private:
     hipStream_t stream_ = nullptr;
     int num_cus_ = 0;
     unsigned rrlu_salt_ = 0;
+    // single-XCD rrLU kernel: elected XCD, mailboxes, monotonic ticket counter
+    int xcc_ = 0;
+    unsigned xcd_salt_ = 0, xcd_ticket_base_ = 0;
+    DevBuf<unsigned long long> d_xkeys_, d_xcols_;
+    DevBuf<unsigned> d_xticket_;
+    DevBuf<double> d_xurows_;
     bool header_clean_ = false, keys_clean_ = false;
     char* header_ptr_ = nullptr;
     int key_parity_ = 0;

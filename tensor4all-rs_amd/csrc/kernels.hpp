@@ -149,6 +149,46 @@ size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M);
 // keys_zeroed: the key table is already clear (the previous launch left it clean, see RrluRegArgs::keys_next)
 void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& args, hipStream_t stream, bool keys_zeroed = false);
 
+// ---- single-XCD register-resident kernel (kernels_rrlu_xcd.hip): all participating workgroups share one L2 ----
+struct RrluXcdPlan {
+    int W = 1;              // participating workgroups (<= 32, one per compute unit of the elected XCD); agents = 8 W waves
+    int RPT = 1, CPT = 1;   // rows per lane / columns per wave (template parameters)
+    int grid = 8;           // launched workgroups = 8 W (blocks b and b + 8 share an XCD)
+    size_t lds_bytes = 0;
+};
+struct RrluXcdArgs {
+    const double* A;            // M x N input (ld = M)
+    double* Aout;               // factored matrix in permuted coordinates (or nullptr)
+    double* urows;              // [max_steps][N] finished rows of U by original column index (needed when Aout != nullptr)
+    int M, N;
+    int max_steps;
+    double rel_tol, abs_tol;
+    int tie_row_major;          // 1: ties go to the smallest (rowpos, colpos) — transposed problems
+    int out_transposed;         // 1: Aout[colpos + N*rowpos]
+    int W;                      // participating workgroups
+    int xcc;                    // XCC id (HW_REG_XCC_ID) of the elected XCD
+    unsigned* ticket;           // monotonic ticket counter of this engine; ranks are ticket - ticket_base
+    unsigned ticket_base;
+    int* row_perm;
+    int* col_perm;
+    int* iresult;               // [0] npivots [1] timeout [2] NaN flag
+    double* dresult;            // [0] last error [1] bits of max sqrt(v*v)
+    double* pivot_vals;
+    unsigned long long* keys;   // [2][8 W] 16-byte keys {value lo, value hi, meta, tag ^ fold}
+    unsigned long long* cols;   // [2][8 W][M] 16-byte rows {lo, hi, 0, tag ^ fold}
+    unsigned salt;              // launch-unique 16-bit value (1..65535); tag = salt << 16 | (step + 1)
+    int poll_delay;
+    double spec_frac;
+    unsigned spin_limit;
+    unsigned long long* stamps; // diagnostic only
+    unsigned long long* h_block; // pinned mirror of the packed result block (see RrluRegArgs)
+    int block_u64;
+};
+bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out);
+size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan);
+size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int M);
+void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
+
 // ------------------------------------------------------------------------------------------------
 // K1: candidate-matrix build (replaces the Π loop, tensor4all-tensorci/src/tensorci2.rs:1859-1893)
 // out[i + ld*j] = g(rowacc[i] + colacc[j]); *max_abs_bits = max over entries of bits(sqrt(v*v)).

@@ -1,0 +1,852 @@
+// kernels_rrlu_xcd.hip — K2 fast path, round 2: register-resident full-pivot rank-revealing LU whose workgroups all sit on
+// ONE XCD of the MI355X, so that the per-pivot exchange runs through that XCD's own L2 (plain stores keep the line there,
+// `sc1` loads bypass the reader's L1) instead of write-through stores that leave the XCD.
+//
+// Same contract as kernels_rrlu_reg.hip: bit-identical to rrlu_mut (tensor4all-core/src/matrixlu.rs:735-819) for the
+// left-orthogonal elimination; a right-orthogonal factorisation runs as the left-orthogonal one of A^T with the row-major tie
+// order (ROWMAJOR).  Arg-max semantics: matrixlu.rs:480-519 (key v*v, first strict maximum in column-major order of the
+// permuted trailing block, NaN never replaces the incumbent, a NaN at (k,k) stays).
+//
+// Measured background (tools/xcd_bench.hip, MI355X): workgroups b and b + 8 of a grid land on the same XCD (strict round robin,
+// 1024 of 1024 blocks); an all-gather of 32 keys through one XCD's L2 costs ~360 cycles against ~1 500 - 2 300 for the
+// write-through all-gather over the whole chip, a pivot column hand-off 300 - 400 cycles against ~1 800.
+//
+// Structure:
+//   * grid = 8 * W workgroups of 512 threads; only the W workgroups whose HW_REG_XCC_ID equals `xcc` take part (a ticket gives
+//     them their rank), the others return at once.  If the placement assumption ever fails the bounded spins give up and
+//     the host re-runs the factorisation with the chip-wide kernel.
+//   * every WAVE is an agent that owns whole columns: agent g = rank * 8 + wave holds columns g + NW * q (q < CPT) with rows
+//     lane + 64 * r (r < RPT) in registers, so the candidate search, the pivot-row broadcast (v_readlane) and the speculative
+//     publication of the candidate column need no workgroup-level synchronisation at all;
+//   * per pivot step: rank-1 update fused with per-column maxima of |a| -> wave arg-max (DPP) -> one 16-byte key per agent and,
+//     when the candidate is within `spec_frac` of the previous pivot, its column (16 bytes per row) -> wave 0 of every
+//     workgroup gathers the NW keys (sc1 loads, L2 hits) and decides -> barrier (B) -> all 512 threads fetch two rows of the
+//     winner's column, divide by the pivot (shared refined reciprocal, bitwise the IEEE quotient) and park l in LDS ->
+//     barrier (C).  Two barriers per step, no LDS traffic on the search side.
+//   * granules carry a launch-salted tag folded with their payload (d3 = tag ^ d0 ^ d1 ^ d2), so a torn or stale granule
+//     never passes the check and no buffer has to be cleared between launches.
+#include "kernels.hpp"
+
+#include <cstdlib>
+
+namespace t4a {
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned XNOPOS = 0xFFFFFFFFu;
+constexpr unsigned XNOCAND = 1u << 30;
+constexpr int XT = 512;      // threads per workgroup
+constexpr int XWAVES = 8;    // agents per workgroup
+constexpr int XCD_MAX_VALUES = 40; // matrix entries per thread: beyond this the register file of a 512-thread workgroup spills
+constexpr int BUF_SC1 = 16;  // aux bits of the raw buffer loads: sc1 (L1 bypass, served by the XCD's L2)
+
+__device__ __forceinline__ unsigned xcc_id()
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xF;
+}
+// maxNum(a, |b|): a NaN operand drops out (matrixlu.rs:506: a NaN score never replaces the incumbent)
+__device__ __forceinline__ double vmax_abs(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i32<CTRL>((int)(b & 0xFFFFFFFFll));
+    const int hi = dpp_i32<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_max_f64(double v) // maxNum over the 64 lanes (uniform result)
+{
+    v = vmax(v, dpp_f64<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = vmax(v, dpp_f64<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = vmax(v, dpp_f64<0x141>(v)); // row_half_mirror
+    v = vmax(v, dpp_f64<0x140>(v)); // row_mirror
+    const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+    return fmax(fmax(a, b), fmax(c, d));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)dpp_i32<0xB1>((int)v);
+    v = o < v ? o : v;
+    o = (unsigned)dpp_i32<0x4E>((int)v);
+    v = o < v ? o : v;
+    o = (unsigned)dpp_i32<0x141>((int)v);
+    v = o < v ? o : v;
+    o = (unsigned)dpp_i32<0x140>((int)v);
+    v = o < v ? o : v;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ unsigned hi32(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ unsigned lo32(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v)); }
+__device__ __forceinline__ double mk_f64(unsigned lo, unsigned hi)
+{
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Reciprocal of p refined exactly like the f64 division expansion of the compiler (v_rcp_f64 + two Newton steps); with it
+// x / p == fma(fma(-p, x * r, x), r, x * r) bitwise whenever the hardware sequence would not rescale its operands
+// (v_div_scale is the identity while both exponents are far from the ends of the range), see xcd_div below.
+__device__ __forceinline__ double refined_rcp(double p)
+{
+    const double r0 = __builtin_amdgcn_rcp(p);
+    const double e0 = __builtin_fma(-p, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-p, r1, 1.0);
+    return __builtin_fma(r1, e1, r1);
+}
+// biased exponent within [723, 1323] (|v| in 2^-300 .. 2^300): no rescaling, no special case in the division sequence
+__device__ __forceinline__ bool exp_mid(double v) { return (((hi32(v) >> 20) & 0x7FFu) - 723u) <= 600u; }
+__device__ __forceinline__ double xcd_div(double x, double p, double rp, bool p_mid)
+{
+    if (p_mid && exp_mid(x)) {
+        const double q0 = x * rp;
+        const double res = __builtin_fma(-p, q0, x);
+        return __builtin_fma(res, rp, q0);
+    }
+    return x / p; // zeros, denormals, huge ratios, non-finite values: the full IEEE sequence
+}
+
+__host__ __device__ constexpr int xcd_lstr(int rpt) // doubles per lane in the l buffer: even, and odd in units of 16 bytes
+{
+    return ((rpt + 1) / 2) % 2 == 1 ? ((rpt + 1) / 2) * 2 : ((rpt + 1) / 2) * 2 + 2;
+}
+
+__host__ __device__ inline size_t xcd_lds_bytes(int M, int N, int rpt)
+{
+    size_t off = (size_t)64 * xcd_lstr(rpt) * 8; // l buffer
+    off += 16 + 32;                              // winner record: value (+pad), ints
+    off += 64;                                   // phase stamps
+    off += (size_t)((M + 7) & ~7) * 2 + (size_t)((N + 7) & ~7) * 2;
+    return (off + 15) & ~(size_t)15;
+}
+
+// per-phase cycle stamps of rank 0 / thread 0 (T4A_RRLU_STAMPS=1), kept in LDS (diagnostic runs only)
+#define XSTAMP(slot)                                                      \
+    do {                                                                  \
+        if (stamp_on) {                                                   \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+            lds_stamps[slot] += now_ - stamp_last;                        \
+            stamp_last = now_;                                            \
+        }                                                                 \
+    } while (0)
+
+__device__ __forceinline__ double uniform_f64(double v) // a wave-uniform value moved into scalar registers
+{
+    return mk_f64((unsigned)__builtin_amdgcn_readfirstlane((int)lo32(v)), (unsigned)__builtin_amdgcn_readfirstlane((int)hi32(v)));
+}
+
+// LDS layout of one workgroup
+struct XcdSmem {
+    double* lbuf;              // [64][LSTR]: l of row lane + 64 r at lane * LSTR + r (rows beyond M stay 0)
+    double* win_d;             // [0] winner value
+    int* win_i;                // [0] agent [1] meta [2] stop [3] abort [4] rank [5] rk [6] ck [7] pc [8] next diag row [9] next diag col
+    unsigned long long* stamps;
+    unsigned short* posrow;    // position -> row index
+    unsigned short* rowpos;    // row index -> position
+    unsigned short* poscol;    // position -> column index
+};
+__host__ __device__ inline size_t xcd_smem_layout(int M, int N, int rpt, XcdSmem* s, char* base)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off = (off + bytes + 15) & ~(size_t)15;
+        return o;
+    };
+    const size_t o_l = take((size_t)64 * xcd_lstr(rpt) * 8);
+    const size_t o_wd = take(16);
+    const size_t o_wi = take(16 * 4);
+    const size_t o_st = take(8 * 8);
+    const size_t o_pr = take((size_t)M * 2);
+    const size_t o_rp = take((size_t)M * 2);
+    const size_t o_pc = take((size_t)N * 2);
+    if (s) {
+        s->lbuf = (double*)(base + o_l);
+        s->win_d = (double*)(base + o_wd);
+        s->win_i = (int*)(base + o_wi);
+        s->stamps = (unsigned long long*)(base + o_st);
+        s->posrow = (unsigned short*)(base + o_pr);
+        s->rowpos = (unsigned short*)(base + o_rp);
+        s->poscol = (unsigned short*)(base + o_pc);
+    }
+    return off;
+}
+
+template <int RPT, int CPT, bool ROWMAJOR>
+__global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int LSTR = xcd_lstr(RPT);
+    XcdSmem sm;
+    xcd_smem_layout(p.M, p.N, RPT, &sm, smem_raw);
+    double* const lbuf = sm.lbuf;
+    double* const win_d = sm.win_d;
+    int* const win_i = sm.win_i;
+    unsigned long long* const lds_stamps = sm.stamps;
+    unsigned short* const posrow = sm.posrow;
+    unsigned short* const rowpos = sm.rowpos;
+    unsigned short* const poscol = sm.poscol;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- election: only the workgroups that landed on the wanted XCD take part ----
+    if (tid == 0) {
+        int rank = -1;
+        if ((int)xcc_id() == p.xcc) {
+            const unsigned t = atomicAdd(p.ticket, 1u) - p.ticket_base;
+            if (t < (unsigned)p.W) rank = (int)t;
+        }
+        win_i[4] = rank;
+        win_i[3] = 0;
+        win_i[2] = 0;
+        win_i[8] = 0; // the first diagonal element is (row 0, column 0)
+        win_i[9] = 0;
+        for (int e = 0; e < 8; ++e) lds_stamps[e] = 0ull;
+    }
+    __syncthreads();
+    const int rank = __builtin_amdgcn_readfirstlane(win_i[4]);
+    if (rank < 0) return;
+    const int NW = p.W * XWAVES;
+    const int g = rank * XWAVES + wave; // agent id
+    const int M = p.M, N = p.N;
+
+    // ---- my columns (per wave); rows lane + 64 r (per lane) ----
+    int cpos[CPT]; // current position of column g + NW q (-1: beyond N); wave-uniform
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int c = g + NW * q;
+        cpos[q] = c < N ? c : -1;
+    }
+    double a[CPT][RPT];
+    double local_sqmax = 0.0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            double v = 0.0;
+            const int i = lane + 64 * r;
+            if (cpos[q] >= 0 && i < M) {
+                v = p.A[(size_t)(g + NW * q) * M + i];
+                const double sqv = v * v; // max sqrt(v*v) == sqrt(max v*v): one square root per lane below
+                if (sqv > local_sqmax) local_sqmax = sqv;
+            }
+            a[q][r] = v;
+        }
+    for (int i = tid; i < M; i += XT) {
+        posrow[i] = (unsigned short)i;
+        rowpos[i] = (unsigned short)i;
+    }
+    for (int j = tid; j < N; j += XT) poscol[j] = (unsigned short)j;
+    for (int e = tid; e < 64 * LSTR; e += XT) lbuf[e] = 0.0;
+    {
+        const double wm = wave_max_f64(sqrt(local_sqmax));
+        if (lane == 0 && wm > 0.0)
+            atomicMax((unsigned long long*)&p.dresult[1], (unsigned long long)__double_as_longlong(wm));
+    }
+    __syncthreads();
+
+    const bool stamp_on = (p.stamps != nullptr) && rank == 0 && tid == 0;
+    unsigned long long stamp_last = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    const __amdgpu_buffer_rsrc_t keys_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(2u * (unsigned)NW * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cols_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.cols, 0, (int)(2u * (unsigned)NW * (unsigned)M * 16u), 0x00020000);
+
+    int npiv = 0;
+    int nan_seen = 0;
+    double max_error = 0.0;             // kept by the polling waves
+    double error = __builtin_nan("");
+    bool timed_out = false;
+    const double min_pivot_abs = (p.rel_tol == 0.0 && p.abs_tol == 0.0) ? 0.0 : 2.220446049250313e-16;
+    double l[RPT];
+    double u[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) u[q] = 0.0;
+    double prev_sq = __builtin_huge_val(); // nobody speculates on the first step
+    const double spec_frac = p.spec_frac;
+    const int kpl = (NW + 63) >> 6;
+
+    // maxima of the untouched matrix for the first arg-max
+    double mq[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        mq[q] = -1.0;
+        if (cpos[q] >= 0) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) mq[q] = vmax_abs(mq[q], a[q][r]);
+        }
+    }
+
+    for (int kn = 0; kn < p.max_steps; ++kn) {
+        const int k = kn - 1; // rows / columns at positions > k form the trailing block searched for pivot kn
+        const unsigned diagkey = ((unsigned)kn << 10) | (unsigned)kn;
+        int cps[CPT]; // column positions as scalars
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) cps[q] = __builtin_amdgcn_readfirstlane(cpos[q]);
+        // a NaN sitting on the next diagonal element wins outright (it is the reference's initial incumbent): the
+        // diagonal element is (row win_i[8], column win_i[9]), worked out by the polling wave one step ahead
+        {
+            const int dr = __builtin_amdgcn_readfirstlane(win_i[8]);
+            const int dc = __builtin_amdgcn_readfirstlane(win_i[9]);
+#pragma unroll
+            for (int q = 0; q < CPT; ++q)
+                if (g + NW * q == dc) { // one wave of the chip
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r)
+                        if (r == (dr >> 6)) {
+                            const bool dn = (lane == (dr & 63)) & (a[q][r] != a[q][r]);
+                            if (__ballot(dn) != 0ull) mq[q] = __builtin_huge_val();
+                        }
+                }
+        }
+        // ---- wave arg-max: (max score, smallest position among the maxima, value there) ----
+        double m = mq[0];
+#pragma unroll
+        for (int q = 1; q < CPT; ++q) m = vmax(m, mq[q]);
+        const double wmax = uniform_f64(wave_max_f64(m));
+        const double sq = wmax * wmax; // the winning score v*v of this agent
+        unsigned mypos = XNOPOS;
+        double myval = 0.0;
+        int myr = 0;
+        if (wmax >= 0.0) {
+            // while v*v is a normal number, distinct |v| have distinct squares: the equality sweep can compare |v| itself
+            // (and the slots of rows that are already pivoted hold zeros, which cannot match)
+            const bool plain_sq = (sq >= 2.2250738585072014e-308) && (sq < __builtin_huge_val());
+            if (plain_sq) {
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    const bool qhit = (mq[q] == wmax); // (columns outside the trailing block keep mq = -1)
+                    if (__ballot(qhit) != 0ull) {      // wave-uniform: normally one lane of one column
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            const bool hit = qhit & (__builtin_fabs(a[q][r]) == wmax);
+                            if (__ballot(hit) != 0ull) {
+                                const unsigned rp_ = rowpos[(lane + 64 * r) < M ? (lane + 64 * r) : 0];
+                                const unsigned key = ROWMAJOR ? ((rp_ << 10) | (unsigned)cps[q]) : (((unsigned)cps[q] << 10) | rp_);
+                                if (hit && key < mypos) {
+                                    mypos = key;
+                                    myval = a[q][r];
+                                    myr = r;
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+                // zero / subnormal / infinite scores (ties between different |v|) and the NaN incumbent
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    const bool qhit = (mq[q] >= 0.0) & (mq[q] * mq[q] == sq);
+                    if (__ballot(qhit) != 0ull) {
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            const int i = lane + 64 * r;
+                            const unsigned rp_ = rowpos[i < M ? i : 0];
+                            const unsigned key = ROWMAJOR ? ((rp_ << 10) | (unsigned)cps[q]) : (((unsigned)cps[q] << 10) | rp_);
+                            const double sc = a[q][r] * a[q][r];
+                            const bool hit = qhit & (i < M) & ((int)rp_ > k) &
+                                             ((sc == sq) | ((key == diagkey) & (sc != sc) & (sq == __builtin_huge_val())));
+                            if (hit && key < mypos) {
+                                mypos = key;
+                                myval = a[q][r];
+                                myr = r;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned wpos = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(mypos));
+        const int par = kn & 1;
+        const unsigned tag = (p.salt << 16) | (unsigned)(kn + 1);
+        // which of my columns holds the candidate
+        int qstar = -1;
+        if (wpos != XNOPOS) {
+            const int cp = (int)(ROWMAJOR ? (wpos & 1023u) : (wpos >> 10));
+#pragma unroll
+            for (int q = 0; q < CPT; ++q)
+                if (cps[q] == cp) qstar = q;
+        }
+        XSTAMP(1);
+        // ---- publish: one 16-byte key per agent ----
+        if (wpos == XNOPOS) {
+            if (lane == 0) {
+                u32x4 kv;
+                kv.x = 0u;
+                kv.y = 0u;
+                kv.z = XNOCAND;
+                kv.w = tag ^ XNOCAND;
+                reinterpret_cast<u32x4*>(p.keys)[(size_t)par * NW + g] = kv;
+            }
+        } else if (mypos == wpos) { // the unique lane that holds the candidate
+            const unsigned meta = wpos | ((unsigned)(lane + 64 * myr) << 20);
+            u32x4 kv;
+            kv.x = lo32(myval);
+            kv.y = hi32(myval);
+            kv.z = meta;
+            kv.w = tag ^ kv.x ^ kv.y ^ meta;
+            reinterpret_cast<u32x4*>(p.keys)[(size_t)par * NW + g] = kv;
+        }
+        // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
+        // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
+        // keys have been gathered
+        const bool early_pub = (wpos != XNOPOS) && (sq >= spec_frac * prev_sq);
+        u32x4* const myslot = reinterpret_cast<u32x4*>(p.cols) + ((size_t)par * NW + g) * (size_t)M;
+        if (early_pub) {
+#pragma unroll
+            for (int q = 0; q < CPT; ++q)
+                if (q == qstar) {
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        const int i = lane + 64 * r;
+                        if (i < M) {
+                            u32x4 gv;
+                            gv.x = lo32(a[q][r]);
+                            gv.y = hi32(a[q][r]);
+                            gv.z = 0u;
+                            gv.w = tag ^ gv.x ^ gv.y;
+                            myslot[i] = gv;
+                        }
+                    }
+                }
+        }
+        XSTAMP(2);
+
+        // ---- wave 0 gathers the NW keys and decides (matrixlu.rs:480-519 across agents, stop rules :757-781) ----
+        if (wave == 0) {
+            for (int d = 0; d < p.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+            unsigned spins = 0;
+            bool giveup = false;
+            u32x4 kg[4];
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < kpl) {
+                        const int ag = lane + 64 * j;
+                        kg[j] = __builtin_amdgcn_raw_buffer_load_b128(keys_rsrc, (par * NW + (ag < NW ? ag : 0)) * 16, 0, BUF_SC1);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < kpl) {
+                        const int ag = lane + 64 * j;
+                        if (ag < NW) ok &= ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
+                    }
+                }
+                if (__all(ok)) break;
+                if (++spins > p.spin_limit) {
+                    giveup = true;
+                    break;
+                }
+            }
+            if (stamp_on) lds_stamps[5] += spins;
+            if (giveup) {
+                if (lane == 0) {
+                    win_i[3] = 1;
+                    atomicExch(&p.iresult[1], 1);
+                    if (p.h_block) ((volatile int*)p.h_block)[5] = 1;
+                }
+            } else {
+                double csc = -1.0, cval = 0.0;
+                unsigned cpk = XNOPOS, cmeta = 0u;
+                int cag = -1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < kpl) {
+                        const int ag = lane + 64 * j;
+                        if (ag < NW && !(kg[j].z & XNOCAND)) {
+                            const unsigned pk = kg[j].z & 0xFFFFFu;
+                            const double v = mk_f64(kg[j].x, kg[j].y);
+                            double sc = v * v;
+                            if (sc != sc) sc = (pk == diagkey) ? __builtin_huge_val() : -1.0;
+                            if (sc > csc || (sc == csc && pk < cpk)) {
+                                csc = sc;
+                                cval = v;
+                                cpk = pk;
+                                cmeta = kg[j].z;
+                                cag = ag;
+                            }
+                        }
+                    }
+                }
+                const double gmax = wave_max_f64(csc);
+                const unsigned gpos = wave_min_u32((csc == gmax) ? cpk : XNOPOS);
+                const unsigned long long sel = __ballot(csc == gmax && cpk == gpos && gpos != XNOPOS);
+                const int wl = sel ? (int)__builtin_ctzll(sel) : 0;
+                const double wv = readlane_f64(cval, wl);
+                const unsigned wm_ = (unsigned)__builtin_amdgcn_readlane((int)cmeta, wl);
+                const int wa_ = __builtin_amdgcn_readlane(cag, wl);
+                // stop tests on the pivot magnitude sqrt(v*v), in the reference's order; while v*v is a normal number the
+                // square root of the rounded square is |v| itself
+                const double wsq = wv * wv;
+                const double pivot_abs = (wsq >= 2.2250738585072014e-308 && wsq < __builtin_huge_val()) ? __builtin_fabs(wv) : sqrt(wsq);
+                error = pivot_abs;
+                int stop = 0;
+                if (kn > 0 && (pivot_abs < p.rel_tol * max_error || pivot_abs < p.abs_tol)) stop = 1;
+                else if (pivot_abs <= min_pivot_abs) stop = 1;
+                else max_error = fmax(max_error, pivot_abs);
+                // permutation bookkeeping for everybody: who sits at position kn now, and the next diagonal element
+                const unsigned wk_ = wm_ & 0xFFFFFu;
+                const int prp_ = (int)(ROWMAJOR ? (wk_ >> 10) : (wk_ & 1023u));
+                const int pcp_ = (int)(ROWMAJOR ? (wk_ & 1023u) : (wk_ >> 10));
+                const int rk_ = posrow[kn], ck_ = poscol[kn], pc_ = poscol[pcp_];
+                const int rn_ = (kn + 1 < M) ? (int)posrow[kn + 1] : 0, cn_ = (kn + 1 < N) ? (int)poscol[kn + 1] : 0;
+                if (lane == 0) {
+                    win_d[0] = wv;
+                    win_i[0] = wa_;
+                    win_i[1] = (int)wm_;
+                    win_i[2] = stop;
+                    win_i[5] = rk_;
+                    win_i[6] = ck_;
+                    win_i[7] = pc_;
+                    win_i[8] = (prp_ == kn + 1) ? rk_ : rn_; // the row that moves from kn to prp, or the untouched one
+                    win_i[9] = (pcp_ == kn + 1) ? ck_ : cn_;
+                }
+            }
+        }
+        __syncthreads(); // (B)
+        XSTAMP(3);
+        if (win_i[3]) {
+            timed_out = true;
+            break;
+        }
+        if (__builtin_amdgcn_readfirstlane(win_i[2])) break;
+        const double wval = uniform_f64(win_d[0]);
+        const int wag = __builtin_amdgcn_readfirstlane(win_i[0]);
+        const unsigned wmeta = (unsigned)__builtin_amdgcn_readfirstlane(win_i[1]);
+        const int rk = __builtin_amdgcn_readfirstlane(win_i[5]);
+        const int ck = __builtin_amdgcn_readfirstlane(win_i[6]);
+        const int pc = __builtin_amdgcn_readfirstlane(win_i[7]);
+        const unsigned wkey = wmeta & 0xFFFFFu;
+        const int prp = (int)(ROWMAJOR ? (wkey >> 10) : (wkey & 1023u));
+        const int pcp = (int)(ROWMAJOR ? (wkey & 1023u) : (wkey >> 10));
+        const int irow_p = (int)((wmeta >> 20) & 1023u);
+
+        // the winner did not speculate: its column goes out now
+        if (g == wag && !early_pub) {
+#pragma unroll
+            for (int q = 0; q < CPT; ++q)
+                if (q == qstar) {
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        const int i = lane + 64 * r;
+                        if (i < M) {
+                            u32x4 gv;
+                            gv.x = lo32(a[q][r]);
+                            gv.y = hi32(a[q][r]);
+                            gv.z = 0u;
+                            gv.w = tag ^ gv.x ^ gv.y;
+                            myslot[i] = gv;
+                        }
+                    }
+                }
+        }
+        // every thread fetches (at most) two rows of the winner's column
+        const int i0 = tid, i1 = tid + XT;
+        const unsigned slot_off = (unsigned)(par * NW + wag) * (unsigned)M;
+        u32x4 c0, c1;
+        c0.x = c0.y = c0.z = c0.w = 0u;
+        c1 = c0;
+        if (i0 < M) c0 = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i0) * 16u), 0, BUF_SC1);
+        if (i1 < M) c1 = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i1) * 16u), 0, BUF_SC1);
+
+        // ---- while the column travels: permutation tables, pivot row ----
+        if (tid == 0) { // nobody reads the tables between barriers (B) and (C)
+            posrow[prp] = (unsigned short)rk;
+            posrow[kn] = (unsigned short)irow_p;
+            rowpos[rk] = (unsigned short)prp;
+            rowpos[irow_p] = (unsigned short)kn;
+            poscol[pcp] = (unsigned short)ck;
+            poscol[kn] = (unsigned short)pc;
+        }
+        prev_sq = wval * wval;
+        // columns: ck (at kn) goes to pcp, the pivot column pc goes to kn
+#pragma unroll
+        for (int q = 0; q < CPT; ++q)
+            if (g + NW * q == ck) cpos[q] = pcp;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q)
+            if (g + NW * q == pc) cpos[q] = kn;
+        {
+            // the pivot row: its entries in the columns of the trailing block (and the pivot column) are the finished row kn
+            // of U.  They are broadcast as u, saved to the side buffer and replaced by zeros, so that from now on the row
+            // takes part in the update as l = 0 / a = 0 without any row mask.
+            const int ls = irow_p & 63, rs = irow_p >> 6;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if (r == rs) {
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        u[q] = readlane_f64(a[q][r], ls);
+                        const int cq = __builtin_amdgcn_readfirstlane(cpos[q]);
+                        if (cq >= kn) {
+                            if (u[q] != u[q]) nan_seen = 1;
+                            if (p.urows && lane == ls) p.urows[(size_t)kn * N + (g + NW * q)] = u[q];
+                            a[q][r] = (lane == ls) ? 0.0 : a[q][r];
+                        }
+                    }
+                }
+        }
+        if (rank == 0 && tid == 0) p.pivot_vals[kn] = wval;
+
+        // ---- pivot column -> l = column / pivot, parked in LDS for everybody ----
+        {
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (i0 < M) ok &= ((c0.x ^ c0.y ^ c0.z ^ c0.w) == tag);
+                if (i1 < M) ok &= ((c1.x ^ c1.y ^ c1.z ^ c1.w) == tag);
+                if (__all(ok)) break;
+                if (++spins > p.spin_limit) {
+                    atomicExch(&p.iresult[1], 1);
+                    if (p.h_block) ((volatile int*)p.h_block)[5] = 1;
+                    win_i[3] = 1; // observed by everybody after the next barrier
+                    break;
+                }
+                if (i0 < M) c0 = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i0) * 16u), 0, BUF_SC1);
+                if (i1 < M) c1 = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i1) * 16u), 0, BUF_SC1);
+            }
+            if (stamp_on) lds_stamps[6] += spins;
+            const bool p_mid = exp_mid(wval);
+            const double rp = refined_rcp(wval);
+            // (the pivot row itself leaves the trailing block: its l is 0 like that of every row pivoted before, whose
+            // emptied slots already read 0 in the published column)
+            if (i0 < M) lbuf[(i0 & 63) * LSTR + (i0 >> 6)] = (i0 == irow_p) ? 0.0 : xcd_div(mk_f64(c0.x, c0.y), wval, rp, p_mid);
+            if (i1 < M) lbuf[(i1 & 63) * LSTR + (i1 >> 6)] = (i1 == irow_p) ? 0.0 : xcd_div(mk_f64(c1.x, c1.y), wval, rp, p_mid);
+        }
+        XSTAMP(4);
+        __syncthreads(); // (C)
+        if (win_i[3]) {
+            timed_out = true;
+            break;
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) l[r] = lbuf[lane * LSTR + r];
+        XSTAMP(7);
+        // =====================================================================================
+        // elimination step kn: the pivot column keeps l (scale_column_tail, matrixlu.rs:562-577; rows that are already
+        // pivoted get the zeros of their emptied slots), the trailing block gets the rank-1 update
+        // (update_trailing_submatrix, matrixlu.rs:593-612) fused with the per-column maxima for the next arg-max
+        // =====================================================================================
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int cq = __builtin_amdgcn_readfirstlane(cpos[q]);
+            mq[q] = -1.0;
+            if (cq > kn) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const double prod = l[r] * u[q];
+                    a[q][r] = a[q][r] - prod;
+                    mq[q] = vmax_abs(mq[q], a[q][r]);
+                }
+            } else if (cq == kn) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) a[q][r] = l[r];
+            }
+        }
+        npiv = kn + 1;
+        XSTAMP(0);
+    }
+
+    // ---- results ----
+    if (npiv >= (M < N ? M : N)) error = 0.0; // matrixlu.rs:811-813
+    if (rank == 0 && tid == 0) {
+        p.iresult[0] = npiv;
+        p.dresult[0] = error; // tid 0 belongs to the polling wave, which keeps the error
+    }
+    if (stamp_on)
+        for (int e = 0; e < 8; ++e) p.stamps[e] = lds_stamps[e];
+    if (timed_out) return;
+    __syncthreads();
+    if (rank == 0) {
+        for (int i = tid; i < M; i += XT) p.row_perm[i] = posrow[i];
+        for (int j = tid; j < N; j += XT) p.col_perm[j] = poscol[j];
+    }
+    // factored matrix in permuted coordinates: rows of U come from the side buffer (this wave wrote them itself), the rest
+    // (L below the diagonal, the untouched trailing block) from the registers
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = lane + 64 * r;
+            if (cpos[q] >= 0 && i < M) {
+                const int cp = cpos[q], rp = rowpos[i];
+                const bool from_u = (rp < npiv) && (cp >= rp);
+                double v = a[q][r];
+                const bool in_l = (cp < npiv) && (rp > cp);
+                if (in_l && v != v) nan_seen = 1;
+                if (p.Aout) {
+                    if (from_u)
+                        v = __longlong_as_double((long long)__hip_atomic_load(
+                            reinterpret_cast<const unsigned long long*>(p.urows) + ((size_t)rp * N + (g + NW * q)), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT));
+                    if (p.out_transposed)
+                        p.Aout[(size_t)rp * N + cp] = v;
+                    else
+                        p.Aout[(size_t)cp * M + rp] = v;
+                }
+            }
+        }
+    if (nan_seen) {
+        atomicExch(&p.iresult[2], 1);
+        if (p.h_block) ((volatile int*)p.h_block)[6] = 1;
+    }
+    // host-visible mirror of the packed result block (everything but the two flag words, which their setters write)
+    if (p.h_block && rank == 0) {
+        __syncthreads(); // this workgroup's writes to the device block (perms, pivot values, npiv, error) are visible
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p.dresult);
+        for (int e = tid; e < p.block_u64; e += XT) {
+            if (e == 2 || e == 3) continue;
+            p.h_block[e] = (e == 1) ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[e];
+        }
+        if (tid == 0) ((volatile int*)p.h_block)[4] = npiv;
+        __syncthreads();
+        if (tid == 0) reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull; // clean header for the next launch
+    }
+}
+
+template <int RPT, int CPT, bool ROWMAJOR> void xcd_launch_tie(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_xcd_kernel<RPT, CPT, ROWMAJOR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((rrlu_xcd_kernel<RPT, CPT, ROWMAJOR>), dim3(plan.grid), dim3(XT), plan.lds_bytes, stream, a);
+}
+
+template <int RPT, int CPT> void xcd_launch_rc(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    if (a.tie_row_major) xcd_launch_tie<RPT, CPT, true>(plan, a, stream);
+    else xcd_launch_tie<RPT, CPT, false>(plan, a, stream);
+}
+
+template <int RPT> void xcd_launch_r(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    switch (plan.CPT) {
+    case 1: xcd_launch_rc<RPT, 1>(plan, a, stream); break;
+    case 2: xcd_launch_rc<RPT, 2>(plan, a, stream); break;
+    case 3: xcd_launch_rc<RPT, 3>(plan, a, stream); break;
+    default:
+        if constexpr (RPT * 4 <= XCD_MAX_VALUES) xcd_launch_rc<RPT, 4>(plan, a, stream);
+        break;
+    }
+}
+
+// instantiated row counts per lane (a plan rounds RPT up to the next one)
+#ifdef T4A_XCD_DEV
+constexpr int kRpts[] = {2, 12};
+#else
+constexpr int kRpts[] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
+#endif
+int xcd_norm_rpt(int r)
+{
+    for (int v : kRpts)
+        if (r <= v) return v;
+    return -1;
+}
+int xcd_norm_cpt(int c)
+{
+    return c <= 4 ? (c < 1 ? 1 : c) : -1;
+}
+
+} // namespace
+
+bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out)
+{
+    if (M < 1 || N < 1 || M > 1024 || N > 1024) return false;
+    static const int min_elems = std::getenv("T4A_XCD_MIN") ? std::atoi(std::getenv("T4A_XCD_MIN")) : 64 * 64;
+    if ((long long)M * N <= (long long)min_elems) return false; // tiny matrices: the single-workgroup plan of the chip-wide kernel
+    const int rpt = xcd_norm_rpt((M + 63) / 64);
+    if (rpt < 0) return false;
+    // as few columns per agent as the 32 compute units of an XCD allow; small problems use fewer workgroups instead of
+    // spreading one column per agent (fewer keys to gather)
+    static const int w_env = std::getenv("T4A_XCD_W") ? std::atoi(std::getenv("T4A_XCD_W")) : 0;
+    static const int cpt_env = std::getenv("T4A_XCD_CPT") ? std::atoi(std::getenv("T4A_XCD_CPT")) : 0;
+    static const int vmin = std::getenv("T4A_XCD_VMIN") ? std::atoi(std::getenv("T4A_XCD_VMIN")) : 8;
+    int best_cpt = -1, best_w = 0;
+    for (int c = 1; c <= 4; ++c) {
+        const int cpt = xcd_norm_cpt(c);
+        if (cpt != c) continue;
+        if (cpt_env > 0 && cpt != cpt_env) continue;
+        int w = (N + XWAVES * cpt - 1) / (XWAVES * cpt);
+        if (w > 32) continue;
+        if (rpt * cpt > XCD_MAX_VALUES) continue;
+        best_cpt = cpt;
+        best_w = w;
+        if (rpt * cpt >= vmin) break; // enough work per thread: stop trading workgroups for columns
+    }
+    if (best_cpt < 0) return false;
+    if (w_env > 0) {
+        best_w = w_env > 32 ? 32 : w_env;
+        int c = (N + XWAVES * best_w - 1) / (XWAVES * best_w);
+        best_cpt = xcd_norm_cpt(c);
+        if (best_cpt < 0 || rpt * best_cpt > XCD_MAX_VALUES) return false;
+    }
+    RrluXcdPlan plan;
+    plan.W = best_w;
+    plan.RPT = rpt;
+    plan.CPT = best_cpt;
+    plan.grid = 8 * best_w;
+    plan.lds_bytes = xcd_smem_layout(M, N, rpt, nullptr, nullptr);
+    if (plan.lds_bytes < 84 * 1024) plan.lds_bytes = 84 * 1024; // one workgroup per compute unit
+    *out = plan;
+    return true;
+}
+
+size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan) { return (size_t)2 * plan.W * XWAVES * 16; }
+size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int M) { return (size_t)2 * plan.W * XWAVES * (size_t)M * 16; }
+
+void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    switch (plan.RPT) {
+#ifdef T4A_XCD_DEV
+    case 2: xcd_launch_r<2>(plan, a, stream); break;
+    default: xcd_launch_r<12>(plan, a, stream); break;
+#else
+    case 1: xcd_launch_r<1>(plan, a, stream); break;
+    case 2: xcd_launch_r<2>(plan, a, stream); break;
+    case 3: xcd_launch_r<3>(plan, a, stream); break;
+    case 4: xcd_launch_r<4>(plan, a, stream); break;
+    case 6: xcd_launch_r<6>(plan, a, stream); break;
+    case 8: xcd_launch_r<8>(plan, a, stream); break;
+    case 10: xcd_launch_r<10>(plan, a, stream); break;
+    case 12: xcd_launch_r<12>(plan, a, stream); break;
+    default: xcd_launch_r<16>(plan, a, stream); break;
+#endif
+    }
+}
+
+} // namespace t4a
