@@ -35,10 +35,14 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned XNOPOS = 0xFFFFFFFFu;
-constexpr unsigned XNOCAND = 1u << 30;
-constexpr int XT = 512;      // threads per workgroup
-constexpr int XWAVES = 8;    // agents per workgroup
-constexpr int XCD_MAX_VALUES = 40; // matrix entries per thread: beyond this the register file of a 512-thread workgroup spills
+#ifndef T4A_XCD_WAVES
+#define T4A_XCD_WAVES 8
+#endif
+constexpr int XWAVES = T4A_XCD_WAVES; // agents (waves) per workgroup.  Measured: 4 (one wave per SIMD) runs every phase 1.5 - 2x slower — a single wave issues one f64 instruction per 8 cycles, two waves per SIMD reach the 4-cycle rate
+constexpr int XT = 64 * XWAVES;       // threads per workgroup
+constexpr int XCD_MAX_CPT = 4;       // (the key carries the column slot in two bits)
+constexpr int XROWS = (1024 + XT - 1) / XT; // pivot-column rows handled per thread in the division stage (M <= 1024)
+constexpr int XCD_MAX_VALUES = XWAVES == 4 ? 80 : 40; // matrix entries per thread: beyond this the register file of a 512-thread workgroup spills
 constexpr int BUF_SC1 = 16;  // aux bits of the raw buffer loads: sc1 (L1 bypass, served by the XCD's L2)
 
 __device__ __forceinline__ unsigned xcc_id()
@@ -78,14 +82,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double wave_max_f64(double v) // maxNum over the 64 lanes (uniform result)
+__device__ __forceinline__ double wave_max_f64(double v) // maxNum over the 64 lanes (uniform result, in scalar registers)
 {
     v = vmax(v, dpp_f64<0xB1>(v));  // quad_perm [1,0,3,2]
     v = vmax(v, dpp_f64<0x4E>(v));  // quad_perm [2,3,0,1]
     v = vmax(v, dpp_f64<0x141>(v)); // row_half_mirror
-    v = vmax(v, dpp_f64<0x140>(v)); // row_mirror
-    const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
-    return fmax(fmax(a, b), fmax(c, d));
+    v = vmax(v, dpp_f64<0x140>(v)); // row_mirror: every lane of a row holds the row maximum
+    v = vmax(v, dpp_f64<0x142>(v)); // row_bcast15: rows 1..3 see lane 15 of the previous row
+    v = vmax(v, dpp_f64<0x143>(v)); // row_bcast31: rows 2, 3 see lane 31 -> lane 63 holds the wave maximum
+    return readlane_f64(v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
@@ -165,8 +170,8 @@ __device__ __forceinline__ double uniform_f64(double v) // a wave-uniform value 
 // LDS layout of one workgroup
 struct XcdSmem {
     double* lbuf;              // [64][LSTR]: l of row lane + 64 r at lane * LSTR + r (rows beyond M stay 0)
-    double* win_d;             // [0] winner value
-    int* win_i;                // [0] agent [1] meta [2] stop [3] abort [4] rank [5] rk [6] ck [7] pc [8] next diag row [9] next diag col
+    double* win_d;             // 16-byte relay slot: the polling wave hands its key to wave 1, which stores it for it
+    int* win_i;                // [0,1] winner value bits [2] meta [3] agent | rk << 8 | ck << 18 | stop << 28 [4] rank [5] abort [6] next diagonal element: row | column << 10
     unsigned long long* stamps;
     unsigned short* posrow;    // position -> row index
     unsigned short* rowpos;    // row index -> position
@@ -183,7 +188,7 @@ __host__ __device__ inline size_t xcd_smem_layout(int M, int N, int rpt, XcdSmem
     const size_t o_l = take((size_t)64 * xcd_lstr(rpt) * 8);
     const size_t o_wd = take(16);
     const size_t o_wi = take(16 * 4);
-    const size_t o_st = take(8 * 8);
+    const size_t o_st = take(16 * 8);
     const size_t o_pr = take((size_t)M * 2);
     const size_t o_rp = take((size_t)M * 2);
     const size_t o_pc = take((size_t)N * 2);
@@ -199,8 +204,14 @@ __host__ __device__ inline size_t xcd_smem_layout(int M, int N, int rpt, XcdSmem
     return off;
 }
 
+template <int N> using xvec = double __attribute__((ext_vector_type(N)));
+
+// key meta word: bits 0..19 position key (10 + 10 bits, tie order), 20..29 row index of the candidate, 30..31 column slot
+// of the publishing agent.  An agent without a candidate publishes value 0 with the largest position key.
+constexpr unsigned XKEY_NONE = 0xFFFFFu;
+
 template <int RPT, int CPT, bool ROWMAJOR>
-__global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
+__global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd_kernel(RrluXcdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LSTR = xcd_lstr(RPT);
@@ -208,6 +219,7 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
     xcd_smem_layout(p.M, p.N, RPT, &sm, smem_raw);
     double* const lbuf = sm.lbuf;
     double* const win_d = sm.win_d;
+    if (threadIdx.x == 0) { win_d[0] = 0.0; win_d[1] = 0.0; }
     int* const win_i = sm.win_i;
     unsigned long long* const lds_stamps = sm.stamps;
     unsigned short* const posrow = sm.posrow;
@@ -226,11 +238,9 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
             if (t < (unsigned)p.W) rank = (int)t;
         }
         win_i[4] = rank;
-        win_i[3] = 0;
-        win_i[2] = 0;
-        win_i[8] = 0; // the first diagonal element is (row 0, column 0)
-        win_i[9] = 0;
-        for (int e = 0; e < 8; ++e) lds_stamps[e] = 0ull;
+        win_i[5] = 0;
+        win_i[6] = 0; // the first diagonal element is (row 0, column 0)
+        for (int e = 0; e < 16; ++e) lds_stamps[e] = 0ull;
     }
     __syncthreads();
     const int rank = __builtin_amdgcn_readfirstlane(win_i[4]);
@@ -239,14 +249,14 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
     const int g = rank * XWAVES + wave; // agent id
     const int M = p.M, N = p.N;
 
-    // ---- my columns (per wave); rows lane + 64 r (per lane) ----
+    // ---- my columns (per wave): g + NW q; my rows (per lane): lane + 64 r ----
     int cpos[CPT]; // current position of column g + NW q (-1: beyond N); wave-uniform
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
         const int c = g + NW * q;
         cpos[q] = c < N ? c : -1;
     }
-    double a[CPT][RPT];
+    xvec<RPT> a[CPT];
     double local_sqmax = 0.0;
 #pragma unroll
     for (int q = 0; q < CPT; ++q)
@@ -288,7 +298,6 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
     double error = __builtin_nan("");
     bool timed_out = false;
     const double min_pivot_abs = (p.rel_tol == 0.0 && p.abs_tol == 0.0) ? 0.0 : 2.220446049250313e-16;
-    double l[RPT];
     double u[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; ++q) u[q] = 0.0;
@@ -302,68 +311,88 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
     for (int q = 0; q < CPT; ++q) {
         mq[q] = -1.0;
         if (cpos[q] >= 0) {
+            double m0 = -1.0, m1 = -1.0;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) mq[q] = vmax_abs(mq[q], a[q][r]);
+            for (int r = 0; r < RPT; ++r) {
+                if (r & 1) m1 = vmax_abs(m1, a[q][r]);
+                else m0 = vmax_abs(m0, a[q][r]);
+            }
+            mq[q] = vmax(m0, m1);
         }
     }
 
     for (int kn = 0; kn < p.max_steps; ++kn) {
         const int k = kn - 1; // rows / columns at positions > k form the trailing block searched for pivot kn
         const unsigned diagkey = ((unsigned)kn << 10) | (unsigned)kn;
+        const int par = kn & 1;
+        const unsigned tag = (p.salt << 16) | (unsigned)(kn + 1);
         int cps[CPT]; // column positions as scalars
 #pragma unroll
         for (int q = 0; q < CPT; ++q) cps[q] = __builtin_amdgcn_readfirstlane(cpos[q]);
         // a NaN sitting on the next diagonal element wins outright (it is the reference's initial incumbent): the
-        // diagonal element is (row win_i[8], column win_i[9]), worked out by the polling wave one step ahead
+        // diagonal element (win_i[6]) is worked out by the polling wave one step ahead
         {
-            const int dr = __builtin_amdgcn_readfirstlane(win_i[8]);
-            const int dc = __builtin_amdgcn_readfirstlane(win_i[9]);
+            const int dpk = __builtin_amdgcn_readfirstlane(win_i[6]);
+            const int dr = dpk & 1023, dc = dpk >> 10;
 #pragma unroll
             for (int q = 0; q < CPT; ++q)
                 if (g + NW * q == dc) { // one wave of the chip
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r)
-                        if (r == (dr >> 6)) {
-                            const bool dn = (lane == (dr & 63)) & (a[q][r] != a[q][r]);
-                            if (__ballot(dn) != 0ull) mq[q] = __builtin_huge_val();
-                        }
+                    const double dv = a[q][dr >> 6];
+                    if (__ballot((lane == (dr & 63)) & (dv != dv)) != 0ull) mq[q] = __builtin_huge_val();
                 }
         }
-        // ---- wave arg-max: (max score, smallest position among the maxima, value there) ----
+        // ---- wave arg-max: (max score, smallest position among the maxima, value there), all wave-uniform ----
         double m = mq[0];
 #pragma unroll
         for (int q = 1; q < CPT; ++q) m = vmax(m, mq[q]);
-        const double wmax = uniform_f64(wave_max_f64(m));
+        const double wmax = wave_max_f64(m);
         const double sq = wmax * wmax; // the winning score v*v of this agent
-        unsigned mypos = XNOPOS;
-        double myval = 0.0;
-        int myr = 0;
+        unsigned wpos = XKEY_NONE;     // position key of the candidate
+        double cval = 0.0;             // its value
+        int cirow = 0, qstar = 0;      // its row index and my column slot
         if (wmax >= 0.0) {
-            // while v*v is a normal number, distinct |v| have distinct squares: the equality sweep can compare |v| itself
+            bool done = false;
+            // while v*v is a normal number, distinct |v| have distinct squares, so the equality sweep can compare |v| itself
             // (and the slots of rows that are already pivoted hold zeros, which cannot match)
-            const bool plain_sq = (sq >= 2.2250738585072014e-308) && (sq < __builtin_huge_val());
-            if (plain_sq) {
+            if ((sq >= 2.2250738585072014e-308) && (sq < __builtin_huge_val())) {
+                unsigned long long bq[CPT];
+                int nhit = 0;
 #pragma unroll
                 for (int q = 0; q < CPT; ++q) {
-                    const bool qhit = (mq[q] == wmax); // (columns outside the trailing block keep mq = -1)
-                    if (__ballot(qhit) != 0ull) {      // wave-uniform: normally one lane of one column
+                    bq[q] = __ballot(mq[q] == wmax); // (columns outside the trailing block keep mq = -1)
+                    nhit += __builtin_popcountll(bq[q]);
+                }
+                if (nhit == 1) { // one lane of one column holds the maximum: the normal case
 #pragma unroll
-                        for (int r = 0; r < RPT; ++r) {
-                            const bool hit = qhit & (__builtin_fabs(a[q][r]) == wmax);
-                            if (__ballot(hit) != 0ull) {
-                                const unsigned rp_ = rowpos[(lane + 64 * r) < M ? (lane + 64 * r) : 0];
-                                const unsigned key = ROWMAJOR ? ((rp_ << 10) | (unsigned)cps[q]) : (((unsigned)cps[q] << 10) | rp_);
-                                if (hit && key < mypos) {
-                                    mypos = key;
-                                    myval = a[q][r];
-                                    myr = r;
-                                }
+                    for (int q = 0; q < CPT; ++q)
+                        if (bq[q] != 0ull) {
+                            const int hl = (int)__builtin_ctzll(bq[q]);
+                            // which row slot of that lane: per-lane index / count of the slots equal to the maximum
+                            int ridx = 0, rcnt = 0;
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) {
+                                const bool h = (__builtin_fabs(a[q][r]) == wmax);
+                                ridx = h ? r : ridx;
+                                rcnt += h ? 1 : 0;
+                            }
+                            const int rstar = __builtin_amdgcn_readlane(ridx, hl);
+                            const int cnt = __builtin_amdgcn_readlane(rcnt, hl);
+                            if (cnt == 1) {
+                                cirow = hl + 64 * rstar;
+                                const unsigned rp_ = (unsigned)__builtin_amdgcn_readfirstlane((int)rowpos[cirow]);
+                                wpos = ROWMAJOR ? ((rp_ << 10) | (unsigned)cps[q]) : (((unsigned)cps[q] << 10) | rp_);
+                                cval = readlane_f64(a[q][rstar], hl);
+                                qstar = q;
+                                done = true;
                             }
                         }
-                    }
                 }
-            } else {
-                // zero / subnormal / infinite scores (ties between different |v|) and the NaN incumbent
+            }
+            if (!done) {
+                // ties, zero / subnormal / infinite scores and the NaN incumbent: exact sweep on the squares
+                unsigned mypos = XNOPOS;
+                double myval = 0.0;
+                int myrow = 0, myq = 0;
 #pragma unroll
                 for (int q = 0; q < CPT; ++q) {
                     const bool qhit = (mq[q] >= 0.0) & (mq[q] * mq[q] == sq);
@@ -373,54 +402,70 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
                             const int i = lane + 64 * r;
                             const unsigned rp_ = rowpos[i < M ? i : 0];
                             const unsigned key = ROWMAJOR ? ((rp_ << 10) | (unsigned)cps[q]) : (((unsigned)cps[q] << 10) | rp_);
-                            const double sc = a[q][r] * a[q][r];
+                            const double av = a[q][r];
+                            const double sc = av * av;
                             const bool hit = qhit & (i < M) & ((int)rp_ > k) &
                                              ((sc == sq) | ((key == diagkey) & (sc != sc) & (sq == __builtin_huge_val())));
                             if (hit && key < mypos) {
                                 mypos = key;
-                                myval = a[q][r];
-                                myr = r;
+                                myval = av;
+                                myrow = i;
+                                myq = q;
                             }
                         }
                     }
                 }
+                const unsigned wp = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(mypos));
+                if (wp != XNOPOS) {
+                    const unsigned long long sel = __ballot(mypos == wp);
+                    const int hl = (int)__builtin_ctzll(sel);
+                    wpos = wp;
+                    cval = readlane_f64(myval, hl);
+                    cirow = __builtin_amdgcn_readlane(myrow, hl);
+                    qstar = __builtin_amdgcn_readlane(myq, hl);
+                }
             }
-        }
-        const unsigned wpos = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(mypos));
-        const int par = kn & 1;
-        const unsigned tag = (p.salt << 16) | (unsigned)(kn + 1);
-        // which of my columns holds the candidate
-        int qstar = -1;
-        if (wpos != XNOPOS) {
-            const int cp = (int)(ROWMAJOR ? (wpos & 1023u) : (wpos >> 10));
-#pragma unroll
-            for (int q = 0; q < CPT; ++q)
-                if (cps[q] == cp) qstar = q;
         }
         XSTAMP(1);
-        // ---- publish: one 16-byte key per agent ----
-        if (wpos == XNOPOS) {
-            if (lane == 0) {
-                u32x4 kv;
-                kv.x = 0u;
-                kv.y = 0u;
-                kv.z = XNOCAND;
-                kv.w = tag ^ XNOCAND;
-                reinterpret_cast<u32x4*>(p.keys)[(size_t)par * NW + g] = kv;
-            }
-        } else if (mypos == wpos) { // the unique lane that holds the candidate
-            const unsigned meta = wpos | ((unsigned)(lane + 64 * myr) << 20);
+        // ---- publish: one 16-byte key per agent (all fields are wave-uniform) ----
+        // The polling wave must not have a store of its own in flight (vector memory operations complete in order: its key
+        // loads would wait for the acknowledgement of that store), so wave 1 stores the key of wave 0 for it.
+        {
+            const unsigned meta = wpos | ((unsigned)cirow << 20) | ((unsigned)qstar << 30);
             u32x4 kv;
-            kv.x = lo32(myval);
-            kv.y = hi32(myval);
+            kv.x = lo32(cval);
+            kv.y = hi32(cval);
             kv.z = meta;
             kv.w = tag ^ kv.x ^ kv.y ^ meta;
-            reinterpret_cast<u32x4*>(p.keys)[(size_t)par * NW + g] = kv;
+            if (wave == 0) {
+                if (lane == 0) *reinterpret_cast<u32x4*>(win_d) = kv;
+            } else {
+                if (lane == 0) reinterpret_cast<u32x4*>(p.keys)[(size_t)par * NW + g] = kv;
+                if (wave == 1) {
+                    u32x4 k0;
+                    unsigned spins = 0;
+                    for (;;) {
+                        k0 = *reinterpret_cast<volatile u32x4*>(win_d);
+                        if ((k0.x ^ k0.y ^ k0.z ^ k0.w) == tag) break;
+                        if (++spins > p.spin_limit) break; // (the pollers give up on the missing key)
+                    }
+                    if (lane == 0) reinterpret_cast<u32x4*>(p.keys)[(size_t)par * NW + g - 1] = k0;
+                }
+            }
+        }
+        // the polling wave starts its first sweep of the key table before it publishes its column
+        u32x4 kg[4];
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ag = lane + 64 * j;
+                if (j < kpl) kg[j] = __builtin_amdgcn_raw_buffer_load_b128(keys_rsrc, (par * NW + (ag < NW ? ag : 0)) * 16, 0, BUF_SC1);
+            }
         }
         // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
         // keys have been gathered
-        const bool early_pub = (wpos != XNOPOS) && (sq >= spec_frac * prev_sq);
+        const bool early_pub = (wave != 0) && (wpos != XKEY_NONE) && (sq >= spec_frac * prev_sq); // (the polling wave never stores early)
         u32x4* const myslot = reinterpret_cast<u32x4*>(p.cols) + ((size_t)par * NW + g) * (size_t)M;
         if (early_pub) {
 #pragma unroll
@@ -430,9 +475,10 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
                     for (int r = 0; r < RPT; ++r) {
                         const int i = lane + 64 * r;
                         if (i < M) {
+                            const double av = a[q][r];
                             u32x4 gv;
-                            gv.x = lo32(a[q][r]);
-                            gv.y = hi32(a[q][r]);
+                            gv.x = lo32(av);
+                            gv.y = hi32(av);
                             gv.z = 0u;
                             gv.w = tag ^ gv.x ^ gv.y;
                             myslot[i] = gv;
@@ -444,69 +490,116 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
 
         // ---- wave 0 gathers the NW keys and decides (matrixlu.rs:480-519 across agents, stop rules :757-781) ----
         if (wave == 0) {
+            // who sits at position kn and kn + 1 now (tables are stable between barrier (C) and the next (B))
+            const int rk_ = posrow[kn], ck_ = poscol[kn];
+            const int rn_ = (kn + 1 < M) ? (int)posrow[kn + 1] : 0, cn_ = (kn + 1 < N) ? (int)poscol[kn + 1] : 0;
             for (int d = 0; d < p.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             unsigned spins = 0;
             bool giveup = false;
-            u32x4 kg[4];
+            XSTAMP(6);
             for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (j < kpl) {
-                        const int ag = lane + 64 * j;
-                        kg[j] = __builtin_amdgcn_raw_buffer_load_b128(keys_rsrc, (par * NW + (ag < NW ? ag : 0)) * 16, 0, BUF_SC1);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < kpl) {
-                        const int ag = lane + 64 * j;
-                        if (ag < NW) ok &= ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
-                    }
+                    const int ag = lane + 64 * j;
+                    if (j < kpl) ok &= (ag >= NW) | ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
                 }
                 if (__all(ok)) break;
                 if (++spins > p.spin_limit) {
                     giveup = true;
                     break;
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ag = lane + 64 * j;
+                    if (j < kpl) kg[j] = __builtin_amdgcn_raw_buffer_load_b128(keys_rsrc, (par * NW + (ag < NW ? ag : 0)) * 16, 0, BUF_SC1);
+                }
             }
             if (stamp_on) lds_stamps[5] += spins;
+            XSTAMP(8);
             if (giveup) {
                 if (lane == 0) {
-                    win_i[3] = 1;
+                    win_i[5] = 1;
                     atomicExch(&p.iresult[1], 1);
                     if (p.h_block) ((volatile int*)p.h_block)[5] = 1;
                 }
             } else {
-                double csc = -1.0, cval = 0.0;
-                unsigned cpk = XNOPOS, cmeta = 0u;
-                int cag = -1;
+                // winner over all keys.  Normal case: v*v of the largest |v| is a normal number (distinct |v| <=> distinct
+                // scores), no key is a NaN and exactly one key holds the largest |v|: one maximum reduction decides.
+                double wv = 0.0;
+                unsigned wm_ = 0u;
+                int wa_ = 0;
+                bool decided = false;
+                {
+                    double lm = -1.0;
+                    bool anynan = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < kpl) {
-                        const int ag = lane + 64 * j;
-                        if (ag < NW && !(kg[j].z & XNOCAND)) {
-                            const unsigned pk = kg[j].z & 0xFFFFFu;
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < kpl) {
                             const double v = mk_f64(kg[j].x, kg[j].y);
-                            double sc = v * v;
-                            if (sc != sc) sc = (pk == diagkey) ? __builtin_huge_val() : -1.0;
-                            if (sc > csc || (sc == csc && pk < cpk)) {
-                                csc = sc;
-                                cval = v;
-                                cpk = pk;
-                                cmeta = kg[j].z;
-                                cag = ag;
+                            anynan |= (v != v);
+                            lm = vmax_abs(lm, v); // (lanes beyond NW re-read key 0: harmless duplicates)
+                        }
+                    }
+                    const double gm = wave_max_f64(lm);
+                    const double gsq = gm * gm;
+                    if ((__ballot(anynan) == 0ull) && (gsq >= 2.2250738585072014e-308) && (gsq < __builtin_huge_val())) {
+                        unsigned long long hb[4];
+                        int nh = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            hb[j] = 0ull;
+                            if (j < kpl) {
+                                hb[j] = __ballot((lane + 64 * j < NW) & (__builtin_fabs(mk_f64(kg[j].x, kg[j].y)) == gm));
+                                nh += __builtin_popcountll(hb[j]);
                             }
+                        }
+                        if (nh == 1) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (hb[j] != 0ull) {
+                                    const int hl = (int)__builtin_ctzll(hb[j]);
+                                    wv = readlane_f64(mk_f64(kg[j].x, kg[j].y), hl);
+                                    wm_ = (unsigned)__builtin_amdgcn_readlane((int)kg[j].z, hl);
+                                    wa_ = hl + 64 * j;
+                                }
+                            decided = true;
                         }
                     }
                 }
-                const double gmax = wave_max_f64(csc);
-                const unsigned gpos = wave_min_u32((csc == gmax) ? cpk : XNOPOS);
-                const unsigned long long sel = __ballot(csc == gmax && cpk == gpos && gpos != XNOPOS);
-                const int wl = sel ? (int)__builtin_ctzll(sel) : 0;
-                const double wv = readlane_f64(cval, wl);
-                const unsigned wm_ = (unsigned)__builtin_amdgcn_readlane((int)cmeta, wl);
-                const int wa_ = __builtin_amdgcn_readlane(cag, wl);
+                XSTAMP(14);
+                if (!decided) {
+                    // ties between agents, zero / subnormal / infinite scores, the NaN incumbent: exact comparison of
+                    // (v*v, position key).  The only NaN a key can carry is the incumbent on the diagonal, which wins
+                    // outright; an agent without candidate carries value 0 and the largest position key.
+                    double csc = -1.0, cv = 0.0;
+                    unsigned cpk = XNOPOS, cmeta = 0u;
+                    int cag = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < kpl) {
+                            const int ag = lane + 64 * j;
+                            const unsigned pk = (ag < NW) ? (kg[j].z & 0xFFFFFu) : XNOPOS;
+                            const double v = mk_f64(kg[j].x, kg[j].y);
+                            double sc = v * v;
+                            sc = (sc != sc) ? __builtin_huge_val() : sc;
+                            sc = (ag < NW) ? sc : -2.0;
+                            const bool better = (sc > csc) | ((sc == csc) & (pk < cpk));
+                            csc = better ? sc : csc;
+                            cv = better ? v : cv;
+                            cpk = better ? pk : cpk;
+                            cmeta = better ? kg[j].z : cmeta;
+                            cag = better ? ag : cag;
+                        }
+                    }
+                    const double gmax = wave_max_f64(csc);
+                    const unsigned gpos = wave_min_u32((csc == gmax) ? cpk : XNOPOS);
+                    const unsigned long long sel = __ballot((csc == gmax) & (cpk == gpos));
+                    const int wl = sel ? (int)__builtin_ctzll(sel) : 0;
+                    wv = readlane_f64(cv, wl);
+                    wm_ = (unsigned)__builtin_amdgcn_readlane((int)cmeta, wl);
+                    wa_ = __builtin_amdgcn_readlane(cag, wl);
+                }
                 // stop tests on the pivot magnitude sqrt(v*v), in the reference's order; while v*v is a normal number the
                 // square root of the rounded square is |v| itself
                 const double wsq = wv * wv;
@@ -520,38 +613,37 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
                 const unsigned wk_ = wm_ & 0xFFFFFu;
                 const int prp_ = (int)(ROWMAJOR ? (wk_ >> 10) : (wk_ & 1023u));
                 const int pcp_ = (int)(ROWMAJOR ? (wk_ & 1023u) : (wk_ >> 10));
-                const int rk_ = posrow[kn], ck_ = poscol[kn], pc_ = poscol[pcp_];
-                const int rn_ = (kn + 1 < M) ? (int)posrow[kn + 1] : 0, cn_ = (kn + 1 < N) ? (int)poscol[kn + 1] : 0;
+                XSTAMP(15);
                 if (lane == 0) {
-                    win_d[0] = wv;
-                    win_i[0] = wa_;
-                    win_i[1] = (int)wm_;
-                    win_i[2] = stop;
-                    win_i[5] = rk_;
-                    win_i[6] = ck_;
-                    win_i[7] = pc_;
-                    win_i[8] = (prp_ == kn + 1) ? rk_ : rn_; // the row that moves from kn to prp, or the untouched one
-                    win_i[9] = (pcp_ == kn + 1) ? ck_ : cn_;
+                    int4 rec;
+                    rec.x = (int)lo32(wv);
+                    rec.y = (int)hi32(wv);
+                    rec.z = (int)wm_;
+                    rec.w = wa_ | (rk_ << 8) | (ck_ << 18) | (stop << 28);
+                    *reinterpret_cast<int4*>(win_i) = rec;
+                    // next diagonal element: the row / column that moves from kn to the pivot's old position, or the untouched one
+                    win_i[6] = ((prp_ == kn + 1) ? rk_ : rn_) | (((pcp_ == kn + 1) ? ck_ : cn_) << 10);
                 }
+                XSTAMP(9);
             }
         }
         __syncthreads(); // (B)
         XSTAMP(3);
-        if (win_i[3]) {
+        const int4 rec = *reinterpret_cast<const int4*>(win_i);
+        if (win_i[5]) {
             timed_out = true;
             break;
         }
-        if (__builtin_amdgcn_readfirstlane(win_i[2])) break;
-        const double wval = uniform_f64(win_d[0]);
-        const int wag = __builtin_amdgcn_readfirstlane(win_i[0]);
-        const unsigned wmeta = (unsigned)__builtin_amdgcn_readfirstlane(win_i[1]);
-        const int rk = __builtin_amdgcn_readfirstlane(win_i[5]);
-        const int ck = __builtin_amdgcn_readfirstlane(win_i[6]);
-        const int pc = __builtin_amdgcn_readfirstlane(win_i[7]);
+        const int rpk = __builtin_amdgcn_readfirstlane(rec.w);
+        if (rpk >> 28) break; // stop
+        const double wval = mk_f64((unsigned)__builtin_amdgcn_readfirstlane(rec.x), (unsigned)__builtin_amdgcn_readfirstlane(rec.y));
+        const unsigned wmeta = (unsigned)__builtin_amdgcn_readfirstlane(rec.z);
+        const int wag = rpk & 255, rk = (rpk >> 8) & 1023, ck = (rpk >> 18) & 1023;
         const unsigned wkey = wmeta & 0xFFFFFu;
         const int prp = (int)(ROWMAJOR ? (wkey >> 10) : (wkey & 1023u));
         const int pcp = (int)(ROWMAJOR ? (wkey & 1023u) : (wkey >> 10));
         const int irow_p = (int)((wmeta >> 20) & 1023u);
+        const int pc = wag + NW * (int)(wmeta >> 30); // original index of the pivot column
 
         // the winner did not speculate: its column goes out now
         if (g == wag && !early_pub) {
@@ -562,9 +654,10 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
                     for (int r = 0; r < RPT; ++r) {
                         const int i = lane + 64 * r;
                         if (i < M) {
+                            const double av = a[q][r];
                             u32x4 gv;
-                            gv.x = lo32(a[q][r]);
-                            gv.y = hi32(a[q][r]);
+                            gv.x = lo32(av);
+                            gv.y = hi32(av);
                             gv.z = 0u;
                             gv.w = tag ^ gv.x ^ gv.y;
                             myslot[i] = gv;
@@ -572,17 +665,19 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
                     }
                 }
         }
-        // every thread fetches (at most) two rows of the winner's column
-        const int i0 = tid, i1 = tid + XT;
+        // every thread fetches its rows (tid, tid + XT, ...) of the winner's column
         const unsigned slot_off = (unsigned)(par * NW + wag) * (unsigned)M;
-        u32x4 c0, c1;
-        c0.x = c0.y = c0.z = c0.w = 0u;
-        c1 = c0;
-        if (i0 < M) c0 = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i0) * 16u), 0, BUF_SC1);
-        if (i1 < M) c1 = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i1) * 16u), 0, BUF_SC1);
+        u32x4 cc[XROWS];
+#pragma unroll
+        for (int j = 0; j < XROWS; ++j) {
+            cc[j].x = cc[j].y = cc[j].z = cc[j].w = 0u;
+            const int i = tid + XT * j;
+            if (i < M) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i) * 16u), 0, BUF_SC1);
+        }
+        XSTAMP(10);
 
         // ---- while the column travels: permutation tables, pivot row ----
-        if (tid == 0) { // nobody reads the tables between barriers (B) and (C)
+        if (tid == 64) { // (not the polling wave) nobody reads the tables between barriers (B) and (C)
             posrow[prp] = (unsigned short)rk;
             posrow[kn] = (unsigned short)irow_p;
             rowpos[rk] = (unsigned short)prp;
@@ -604,53 +699,79 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
             // takes part in the update as l = 0 / a = 0 without any row mask.
             const int ls = irow_p & 63, rs = irow_p >> 6;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r)
-                if (r == rs) {
-#pragma unroll
-                    for (int q = 0; q < CPT; ++q) {
-                        u[q] = readlane_f64(a[q][r], ls);
-                        const int cq = __builtin_amdgcn_readfirstlane(cpos[q]);
-                        if (cq >= kn) {
-                            if (u[q] != u[q]) nan_seen = 1;
-                            if (p.urows && lane == ls) p.urows[(size_t)kn * N + (g + NW * q)] = u[q];
-                            a[q][r] = (lane == ls) ? 0.0 : a[q][r];
-                        }
-                    }
+            for (int q = 0; q < CPT; ++q) {
+                const double av = a[q][rs];
+                u[q] = readlane_f64(av, ls);
+                const int cq = __builtin_amdgcn_readfirstlane(cpos[q]);
+                if (cq >= kn) {
+                    if (u[q] != u[q]) nan_seen = 1;
+                    if (p.urows && lane == ls) p.urows[(size_t)kn * N + (g + NW * q)] = u[q];
+                    a[q][rs] = (lane == ls) ? 0.0 : av;
                 }
+            }
         }
         if (rank == 0 && tid == 0) p.pivot_vals[kn] = wval;
+        XSTAMP(11);
 
         // ---- pivot column -> l = column / pivot, parked in LDS for everybody ----
         {
             unsigned spins = 0;
             for (;;) {
                 bool ok = true;
-                if (i0 < M) ok &= ((c0.x ^ c0.y ^ c0.z ^ c0.w) == tag);
-                if (i1 < M) ok &= ((c1.x ^ c1.y ^ c1.z ^ c1.w) == tag);
+#pragma unroll
+                for (int j = 0; j < XROWS; ++j)
+                    if (tid + XT * j < M) ok &= ((cc[j].x ^ cc[j].y ^ cc[j].z ^ cc[j].w) == tag);
                 if (__all(ok)) break;
                 if (++spins > p.spin_limit) {
                     atomicExch(&p.iresult[1], 1);
                     if (p.h_block) ((volatile int*)p.h_block)[5] = 1;
-                    win_i[3] = 1; // observed by everybody after the next barrier
+                    win_i[5] = 1; // observed by everybody after the next barrier
                     break;
                 }
-                if (i0 < M) c0 = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i0) * 16u), 0, BUF_SC1);
-                if (i1 < M) c1 = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i1) * 16u), 0, BUF_SC1);
+#pragma unroll
+                for (int j = 0; j < XROWS; ++j) {
+                    const int i = tid + XT * j;
+                    if (i < M) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i) * 16u), 0, BUF_SC1);
+                }
             }
-            if (stamp_on) lds_stamps[6] += spins;
+            XSTAMP(12);
+            // x / p through the shared refined reciprocal (bitwise the IEEE quotient, see refined_rcp); zeros keep the sign
+            // rule through x * rp; anything unusual takes the full division
             const bool p_mid = exp_mid(wval);
             const double rp = refined_rcp(wval);
+            double lq[XROWS];
+            bool slow = false;
+#pragma unroll
+            for (int j = 0; j < XROWS; ++j) {
+                const double x = mk_f64(cc[j].x, cc[j].y);
+                const double q0 = x * rp;
+                const double qf = __builtin_fma(__builtin_fma(-wval, q0, x), rp, q0);
+                lq[j] = (x == 0.0) ? q0 : qf;
+                slow |= !(p_mid & (exp_mid(x) | (x == 0.0)));
+            }
+            if (__ballot(slow) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < XROWS; ++j) {
+                    const double x = mk_f64(cc[j].x, cc[j].y);
+                    if (!(p_mid & (exp_mid(x) | (x == 0.0)))) lq[j] = x / wval;
+                }
+            }
             // (the pivot row itself leaves the trailing block: its l is 0 like that of every row pivoted before, whose
             // emptied slots already read 0 in the published column)
-            if (i0 < M) lbuf[(i0 & 63) * LSTR + (i0 >> 6)] = (i0 == irow_p) ? 0.0 : xcd_div(mk_f64(c0.x, c0.y), wval, rp, p_mid);
-            if (i1 < M) lbuf[(i1 & 63) * LSTR + (i1 >> 6)] = (i1 == irow_p) ? 0.0 : xcd_div(mk_f64(c1.x, c1.y), wval, rp, p_mid);
+#pragma unroll
+            for (int j = 0; j < XROWS; ++j) {
+                const int i = tid + XT * j;
+                if (i < M) lbuf[(i & 63) * LSTR + (i >> 6)] = (i == irow_p) ? 0.0 : lq[j];
+            }
         }
         XSTAMP(4);
         __syncthreads(); // (C)
-        if (win_i[3]) {
+        XSTAMP(13);
+        if (win_i[5]) {
             timed_out = true;
             break;
         }
+        xvec<RPT> l;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) l[r] = lbuf[lane * LSTR + r];
         XSTAMP(7);
@@ -664,15 +785,18 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
             const int cq = __builtin_amdgcn_readfirstlane(cpos[q]);
             mq[q] = -1.0;
             if (cq > kn) {
+                double m0 = -1.0, m1 = -1.0;
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
                     const double prod = l[r] * u[q];
-                    a[q][r] = a[q][r] - prod;
-                    mq[q] = vmax_abs(mq[q], a[q][r]);
+                    const double t = a[q][r] - prod;
+                    a[q][r] = t;
+                    if (r & 1) m1 = vmax_abs(m1, t);
+                    else m0 = vmax_abs(m0, t);
                 }
+                mq[q] = vmax(m0, m1);
             } else if (cq == kn) {
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) a[q][r] = l[r];
+                a[q] = l;
             }
         }
         npiv = kn + 1;
@@ -686,7 +810,7 @@ __global__ void __launch_bounds__(XT) rrlu_xcd_kernel(RrluXcdArgs p)
         p.dresult[0] = error; // tid 0 belongs to the polling wave, which keeps the error
     }
     if (stamp_on)
-        for (int e = 0; e < 8; ++e) p.stamps[e] = lds_stamps[e];
+        for (int e = 0; e < 16; ++e) p.stamps[e] = lds_stamps[e];
     if (timed_out) return;
     __syncthreads();
     if (rank == 0) {
@@ -758,10 +882,10 @@ template <int RPT> void xcd_launch_r(const RrluXcdPlan& plan, const RrluXcdArgs&
     switch (plan.CPT) {
     case 1: xcd_launch_rc<RPT, 1>(plan, a, stream); break;
     case 2: xcd_launch_rc<RPT, 2>(plan, a, stream); break;
-    case 3: xcd_launch_rc<RPT, 3>(plan, a, stream); break;
-    default:
-        if constexpr (RPT * 4 <= XCD_MAX_VALUES) xcd_launch_rc<RPT, 4>(plan, a, stream);
-        break;
+    case 3: if constexpr (RPT * 3 <= XCD_MAX_VALUES) xcd_launch_rc<RPT, 3>(plan, a, stream); break;
+    case 4: if constexpr (RPT * 4 <= XCD_MAX_VALUES) xcd_launch_rc<RPT, 4>(plan, a, stream); break;
+    case 5: if constexpr (RPT * 5 <= XCD_MAX_VALUES && XCD_MAX_CPT >= 5) xcd_launch_rc<RPT, 5>(plan, a, stream); break;
+    default: if constexpr (RPT * 6 <= XCD_MAX_VALUES && XCD_MAX_CPT >= 6) xcd_launch_rc<RPT, 6>(plan, a, stream); break;
     }
 }
 
@@ -769,7 +893,7 @@ template <int RPT> void xcd_launch_r(const RrluXcdPlan& plan, const RrluXcdArgs&
 #ifdef T4A_XCD_DEV
 constexpr int kRpts[] = {2, 12};
 #else
-constexpr int kRpts[] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
+constexpr int kRpts[] = {1, 2, 3, 4, 6, 8, 12, 16};
 #endif
 int xcd_norm_rpt(int r)
 {
@@ -779,7 +903,7 @@ int xcd_norm_rpt(int r)
 }
 int xcd_norm_cpt(int c)
 {
-    return c <= 4 ? (c < 1 ? 1 : c) : -1;
+    return c <= XCD_MAX_CPT ? (c < 1 ? 1 : c) : -1;
 }
 
 } // namespace
@@ -791,22 +915,26 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out)
     if ((long long)M * N <= (long long)min_elems) return false; // tiny matrices: the single-workgroup plan of the chip-wide kernel
     const int rpt = xcd_norm_rpt((M + 63) / 64);
     if (rpt < 0) return false;
-    // as few columns per agent as the 32 compute units of an XCD allow; small problems use fewer workgroups instead of
-    // spreading one column per agent (fewer keys to gather)
+    // columns per agent: the steps are latency bound, so the cost model weighs the update pass (about 24 cycles per matrix
+    // entry of a thread at two waves per SIMD) against the key gather (about 250 cycles per 64 agents) — measured with the
+    // phase stamps at 685 x 688 and 256 x 256
     static const int w_env = std::getenv("T4A_XCD_W") ? std::atoi(std::getenv("T4A_XCD_W")) : 0;
     static const int cpt_env = std::getenv("T4A_XCD_CPT") ? std::atoi(std::getenv("T4A_XCD_CPT")) : 0;
-    static const int vmin = std::getenv("T4A_XCD_VMIN") ? std::atoi(std::getenv("T4A_XCD_VMIN")) : 8;
     int best_cpt = -1, best_w = 0;
-    for (int c = 1; c <= 4; ++c) {
+    long best_cost = 0;
+    for (int c = 1; c <= XCD_MAX_CPT; ++c) {
         const int cpt = xcd_norm_cpt(c);
         if (cpt != c) continue;
         if (cpt_env > 0 && cpt != cpt_env) continue;
-        int w = (N + XWAVES * cpt - 1) / (XWAVES * cpt);
+        const int w = (N + XWAVES * cpt - 1) / (XWAVES * cpt);
         if (w > 32) continue;
         if (rpt * cpt > XCD_MAX_VALUES) continue;
-        best_cpt = cpt;
-        best_w = w;
-        if (rpt * cpt >= vmin) break; // enough work per thread: stop trading workgroups for columns
+        const long cost = 24L * rpt * cpt + 250L * ((w * XWAVES + 63) / 64);
+        if (best_cpt < 0 || cost < best_cost) {
+            best_cpt = cpt;
+            best_w = w;
+            best_cost = cost;
+        }
     }
     if (best_cpt < 0) return false;
     if (w_env > 0) {
@@ -842,7 +970,6 @@ void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t 
     case 4: xcd_launch_r<4>(plan, a, stream); break;
     case 6: xcd_launch_r<6>(plan, a, stream); break;
     case 8: xcd_launch_r<8>(plan, a, stream); break;
-    case 10: xcd_launch_r<10>(plan, a, stream); break;
     case 12: xcd_launch_r<12>(plan, a, stream); break;
     default: xcd_launch_r<16>(plan, a, stream); break;
 #endif
