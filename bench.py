@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the cfg2 / cfg4 / cfg5 single-GPU timings of the aux block")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,14 +185,10 @@ def main():
         # dominant kernel = the rrLU instantiation with the largest total time (the mid-chain bonds)
         rrlu_ms_avg = prof["dom_ms"] / max(prof["dom_launches"], 1)
         bytes_per_launch = prof["dom_bytes"] / max(prof["dom_launches"], 1)
-        code = prof["dom_code"]
-        if code >= 0:
-            kname = "t4a::rrlu_reg_kernel<%d, %d, %s, %s, %s>" % (code // 1000, (code % 1000) // 10,
-                                                                   "true" if (code % 10) & 2 else "false",
-                                                                   "true" if (code % 10) & 1 else "false",
-                                                                   "true" if (code % 10) & 4 else "false")
-        else:
-            kname = "t4a::rrlu_kernel<%s>" % ("true" if code == -1 else "false")
+        kname = rrlu_kernel_name(prof["dom_code"])
+        variants = tci.profile_variants()
+        dom = max(variants, key=lambda v: v["ms"]) if variants else None
+        dom_steps = dom["steps"] / max(dom["launches"], 1) if dom else float(shapes[N_SITES // 2][2])
         achieved = bytes_per_launch / (rrlu_ms_avg * 1e-3) / 1e9 if rrlu_ms_avg > 0 else 0.0
         out = {
             "metric": "TCI2 full-sweep GF/s (d=30, chi=256 fp64)",
@@ -234,34 +231,66 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(kname),
-                "traffic_source": "profiles/r01_pmc_dominant_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two "
+                "traffic_source": "profiles/r02_pmc_dominant_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two "
                                   "separate passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch "
                                   "(gfx950 FETCH_SIZE correction); null when the kernel name does not match",
                 "avg_launch_ms": rrlu_ms_avg,
-                # the kernel is a chain of dependent pivot steps, each with two memory-side hand-offs between workgroups:
-                # the honest bound is latency, not bandwidth (tools/hop_bench.hip: one store->load hop = 1040-1240 cycles)
+                # the kernel is a chain of dependent pivot steps; each step needs one key all-gather and one pivot-column
+                # hand-off between the workgroups of one XCD: the honest bound is latency, not bandwidth.  The floor is the
+                # measured cost of exactly that exchange with no arithmetic around it (tools/xcd_bench.hip on MI355X:
+                # 1 715 cycles per round at 2.38 GHz for 32 workgroups and a 700-row column,
+                # profiles/r02_xcd_bench.log)
                 "latency_view": {
-                    "pivot_steps_per_launch": float(shapes[N_SITES // 2][2]),
-                    "us_per_pivot_step": 1e3 * rrlu_ms_avg / max(float(shapes[N_SITES // 2][2]), 1.0),
-                    "two_hop_floor_us": 2 * 1140 / 2400.0,
+                    "pivot_steps_per_launch": dom_steps,
+                    "us_per_pivot_step": 1e3 * rrlu_ms_avg / max(dom_steps, 1.0),
+                    "exchange_floor_us": XCD_EXCHANGE_FLOOR_US,
+                },
+                "latency_frac": XCD_EXCHANGE_FLOOR_US / max(1e3 * rrlu_ms_avg / max(dom_steps, 1.0), 1e-30),
+                # every rrLU instantiation of the timed region, and their time-weighted aggregate
+                "all_rrlu_kernels": {
+                    "achieved": sum(v["bytes"] for v in variants) / max(sum(v["ms"] for v in variants), 1e-30) / 1e6,
+                    "frac": sum(v["bytes"] for v in variants) / max(sum(v["ms"] for v in variants), 1e-30) / 1e6 / HBM_PEAK_GBS,
+                    "us_per_pivot_step": 1e3 * sum(v["ms"] for v in variants) / max(sum(v["steps"] for v in variants), 1.0),
+                    "variants": [{"kernel": rrlu_kernel_name(v["code"]), "launches": v["launches"], "ms": v["ms"],
+                                  "share": v["ms"] / max(prof["rrlu_ms"], 1e-30),
+                                  "achieved": v["bytes"] / max(v["ms"], 1e-30) / 1e6,
+                                  "us_per_pivot_step": 1e3 * v["ms"] / max(v["steps"], 1.0)}
+                                 for v in sorted(variants, key=lambda v: -v["ms"])],
                 },
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "streaming model 8MN + sum_k 16(M-k-1)(N-k-1) bytes (BASELINE.md §2); the slab is register "
-                        "resident, the kernel is bound by the per-pivot inter-workgroup exchange latency",
+                        "resident (one XCD), the kernel is bound by the per-pivot exchange and instruction latency",
             },
         }
         if world == 1 and not args.no_cpu_baseline:  # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(tci, spec)
+        if world == 1 and not args.no_aux:
+            out["aux"] = aux_timings()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+XCD_EXCHANGE_FLOOR_US = 1715 / 2380.0  # tools/xcd_bench.hip, see latency_view
+
+
+def rrlu_kernel_name(code):
+    """Kernel instantiation behind a profile code (include/t4a_gpu.h, t4a_gpu_tci2_profile_variants)."""
+    code = int(code)
+    if code >= 100000:
+        c = code - 100000
+        return "t4a::rrlu_xcd_kernel<%d, %d, %s>" % (c // 100, (c % 100) // 10, "true" if (c % 10) & 4 else "false")
+    if code >= 0:
+        return "t4a::rrlu_reg_kernel<%d, %d, %s, %s, %s>" % (code // 1000, (code % 1000) // 10, "true" if (code % 10) & 2 else "false",
+                                                            "true" if (code % 10) & 1 else "false", "true" if (code % 10) & 4 else "false")
+    return {-1: "t4a::rrlu_kernel<true>", -2: "t4a::rrlu_kernel<false>"}.get(code, "t4a::rg_* (HBM-resident rrLU)")
+
+
 def pmc_traffic(kname):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (bench.py itself cannot run under
     rocprofv3 --pmc); only reported when the summary is for the kernel instantiation that dominated this run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dominant_kernel.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_dominant_kernel.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -270,42 +299,159 @@ def pmc_traffic(kname):
     short = kname.replace("t4a::", "")
     if not short:
         return None
-    for name, nbytes in d.get("rrlu_reg_variants", {}).items():
+    for name, nbytes in d.get("rrlu_variants", d.get("rrlu_reg_variants", {})).items():
         if short in name:
             return nbytes
     return d["hbm_bytes_per_launch"] if short in d.get("kernel", "") else None
 
 
+def host_cpu():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
 def cpu_baseline(tci, spec):
-    """The CPU oracle (C++ restatement of the reference algorithm, single thread) timed on four full sweeps started
-    from the device's saturated I/J sets.  Reported baseline, not the optimisation target."""
-    import oracle_binding as ob
+    """The CPU oracle (C++ restatement of the reference algorithm) timed on the GPU box's host cores on a bounded sample of the
+    same workload, started from the device's saturated I/J sets.  Two rows: the native build with OpenMP over
+    the candidate-matrix evaluations and the fill sites on all usable cores (the reference's TCI2 path itself is single
+    threaded apart from its BLAS pool), and the same library pinned to one thread.  Reported baseline, not the target."""
+    import subprocess
     import t4a_amd
-    o = ob.OracleTCI2([2] * N_SITES)
-    o.set_function(spec)
-    for p in range(N_SITES):
-        o.set_index_set(0, p, tci.i_set(p))
-        o.set_index_set(1, p, tci.j_set(p))
-    o.set_max_sample_value(tci.max_sample_value())
+    model, nproc, usable = host_cpu()
+    native = os.path.join(ROOT, "oracle", "_native", "liboracle.so")
+    built_native = False
+    try:  # build on THIS machine: -march=native of another host must not be reused
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=300)
+        built_native = os.path.exists(native)
+    except (OSError, subprocess.SubprocessError):
+        built_native = False
+    if built_native:
+        os.environ["T4A_ORACLE_LIB"] = native
+    import oracle_binding as ob
+
+    def prepare():
+        o = ob.OracleTCI2([2] * N_SITES)
+        o.set_function(spec)
+        for p in range(N_SITES):
+            o.set_index_set(0, p, tci.i_set(p))
+            o.set_index_set(1, p, tci.j_set(p))
+        o.set_max_sample_value(tci.max_sample_value())
+        o.clear_history()
+        return o
+
+    def opts(n_sweeps):
+        return t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=CHI, max_iter=2 * n_sweeps, ncheck_history=10 ** 6, nsearch=0,
+                                   max_nglobal_pivot=0, seed=42)
+
+    # flop count of exactly this work: the device's executed flops for the same sweeps, plus the LUCI factors the reference
+    # (and the oracle) builds and discards when history extras were merged (tensorci2.rs:1942-1949) and the device skips
+    n_sweeps = 3
+    o = prepare()
     tci.clear_history()
-    o.clear_history()
-    n_sweeps = 4  # about 11 s of single-thread CPU work: a bounded sample of the same workload
-    opts = t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=CHI, max_iter=2 * n_sweeps, ncheck_history=10 ** 6, nsearch=0,
-                               max_nglobal_pivot=0, seed=42)
-    # identical work on the device gives the flop count of exactly this sweep
     tci.profile_enable(True)
     tci.profile_reset()
-    tci.optimize(opts, final_sweep1site=False)
+    tci.optimize(opts(n_sweeps), final_sweep1site=False)
     flops = tci.profile()["flops"]
     tci.profile_enable(False)
+    shapes = tci.last_sweep_shapes()
+    factor_flops = sum(float((m - r) * r * r + 2.0 * r * r * n) for (m, n, r) in shapes) * 2 * n_sweeps
+    threads_native = ob._lib.oracle_openmp_threads() if built_native else 0
     t0 = time.perf_counter()
-    o.optimize(opts, final_sweep1site=False)
-    sec = time.perf_counter() - t0
+    o.optimize(opts(n_sweeps), final_sweep1site=False)
+    sec_all = time.perf_counter() - t0
     same = all((tci.i_set(p).shape == o.i_set(p).shape) and (tci.i_set(p) == o.i_set(p)).all() for p in range(N_SITES))
-    return {"value": flops / sec / 1e9, "unit": "GF/s", "cores": 1, "kind": "port", "full_sweep_sec": sec / n_sweeps,
-            "sample": "4 full sweeps (8 half-sweeps incl. fill_site_tensors) of the same d=30 chi=256 workload, started "
-                      "from the device's saturated index sets; oracle = oracle/ C++ restatement, -O3, no FMA",
+    rows = [{"threads": max(threads_native, 1), "full_sweep_sec": sec_all / n_sweeps, "value": flops / sec_all / 1e9,
+             "value_incl_discarded_factors": (flops + factor_flops) / sec_all / 1e9,
+             "build": "-O3 -march=native -fopenmp -ffp-contract=off (OpenMP over candidate-matrix evaluations and fill sites)" if built_native
+             else "-O3 -march=x86-64-v2 -ffp-contract=off (prebuilt, scalar)"}]
+    if built_native and threads_native > 1:  # the same library on one thread: the reference's own threading model
+        ob._lib.oracle_set_threads(1)
+        o1 = prepare()
+        t0 = time.perf_counter()
+        o1.optimize(opts(1), final_sweep1site=False)
+        sec1 = time.perf_counter() - t0
+        ob._lib.oracle_set_threads(threads_native)
+        rows.append({"threads": 1, "full_sweep_sec": sec1, "value": flops / n_sweeps / sec1 / 1e9,
+                     "value_incl_discarded_factors": (flops + factor_flops) / n_sweeps / sec1 / 1e9,
+                     "build": "same library, OMP threads = 1"})
+    best = max(rows, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "GF/s", "cores": best["threads"], "kind": "port", "full_sweep_sec": best["full_sweep_sec"],
+            "cpu_model": model, "nproc": nproc, "usable_cores": usable, "rows": rows,
+            "sample": "%d full sweeps (forward + backward half-sweep incl. fill_site_tensors) of the same d=30 chi=256 workload, started "
+                      "from the device's saturated index sets; oracle = oracle/ C++ restatement of the reference algorithm, no FMA; "
+                      "`value` counts the flops the device executes for these sweeps, `value_incl_discarded_factors` adds the LUCI "
+                      "factors the reference builds and discards when history extras are merged" % n_sweeps,
             "pivots_identical_to_device": bool(same)}
+
+
+def aux_timings():
+    """Single-GPU times of the other BASELINE.json configurations (driver-visible regression guard, not the headline):
+    cfg2 (d=20, cos(10x)exp(-x), chi<=64, tol 1e-8) time to solution, cfg4-size (d=40, chi=512) full sweep, cfg5-size (one of the
+    64 patches, 30 active sites, chi=128) full sweep."""
+    import t4a_amd
+    from t4a_amd.functions import quantics_trig_exp
+    out = {}
+    try:
+        spec2 = quantics_trig_exp(20)
+        o2 = t4a_amd.TCI2Options(tolerance=1e-8, max_bond_dim=64, max_iter=20, nsearch=0, max_nglobal_pivot=0, seed=42)
+        best = None
+        for _ in range(3):
+            t = t4a_amd.TensorCI2([2] * 20)
+            t.set_function(spec2)
+            t0 = time.perf_counter()
+            t.crossinterpolate2([[0] * 20], o2)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["cfg2_time_to_solution_ms"] = best * 1e3
+        out["cfg2_rank"] = int(max(t.link_dims()))
+    except Exception as e:  # noqa: BLE001 - auxiliary numbers must never break the bench line
+        out["cfg2_error"] = str(e)
+    try:
+        n_patches, chi5 = 64, 128
+        t = t4a_amd.TensorCI2([2] * N_SITES)
+        t.set_function(patch_spec(17, n_patches))
+        t.add_global_pivots([[0] * N_SITES])
+        t.set_max_sample_value(1.0)
+        o5 = lambda it: t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=chi5, max_iter=it, ncheck_history=10 ** 6, nsearch=0,
+                                            max_nglobal_pivot=0, seed=42)
+        t.optimize(o5(9), final_sweep1site=False)
+        t0 = time.perf_counter()
+        t.optimize(o5(4), final_sweep1site=False)
+        out["cfg5_patch_full_sweep_ms"] = (time.perf_counter() - t0) / 2 * 1e3
+        out["cfg5_patch_max_link_dim"] = int(max(t.link_dims()))
+    except Exception as e:  # noqa: BLE001
+        out["cfg5_error"] = str(e)
+    try:
+        from t4a_amd.functions import quantics_osc2d
+        d4, chi4 = 40, 512
+        spec4 = quantics_osc2d(d4, k1=37, k2=53, k3=20011, eps=0.5, k4=1048583, delta=0.5)  # tools/probe_cfg4.py
+        t = t4a_amd.TensorCI2([2] * d4)
+        t.set_function(spec4)
+        t.add_global_pivots([[0] * d4])
+        t.set_max_sample_value(1.0)
+        o4 = lambda it: t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=chi4, max_iter=it, ncheck_history=10 ** 6, nsearch=0,
+                                            max_nglobal_pivot=0, seed=42)
+        t.optimize(o4(11), final_sweep1site=False)
+        t0 = time.perf_counter()
+        t.optimize(o4(2), final_sweep1site=False)
+        out["cfg4_size_full_sweep_ms"] = (time.perf_counter() - t0) * 1e3
+        out["cfg4_size_max_link_dim"] = int(max(t.link_dims()))
+    except Exception as e:  # noqa: BLE001
+        out["cfg4_error"] = str(e)
+    return out
 
 
 if __name__ == "__main__":

@@ -292,6 +292,25 @@ t4a_gpu_status t4a_gpu_tt_compress(t4a_gpu_tt* h, int32_t method, double toleran
 t4a_gpu_status t4a_gpu_tt_evaluate_many(t4a_gpu_tt* h, const size_t* idx, size_t n_pts, size_t split, double* out,
                                         size_t* used_split);
 
+/* floating_zone(tt, f, local_dims, init_p, early_stop_tol) (tensorci/src/globalsearch.rs:163-243, walk:
+ * tensor4all-core/src/floating_zone.rs:46-103): local search for the multi-index with the largest |f - tt|.  The tensor
+ * train is evaluated on the device (TTCache::evaluate_many per site scan), f is the batch callback.  init_p == NULL: random
+ * starting point (reference: thread rng of rand 0.9, "parity unpinned"; here splitmix64(seed)). */
+t4a_gpu_status t4a_gpu_tt_floating_zone(t4a_gpu_tt* tt, t4a_gpu_batch_eval_fn f, void* ctx, const size_t* local_dims, size_t n_sites,
+                                        const size_t* init_p, uint64_t seed, double early_stop_tol, size_t* pivot_out /* n_sites */,
+                                        double* error_out);
+/* estimate_true_error(tt, f, nsearch, initial_points, rng) (globalsearch.rs:70-118): floating_zone from every starting point,
+ * results sorted by descending error, consecutive duplicates removed.  initial_points: n_sites x n_initial column-major or
+ * NULL (then nsearch random points from splitmix64(seed)).  Query-then-fill: *n_out is always set; BUFFER_TOO_SMALL when
+ * capacity < *n_out (at most nsearch resp. n_initial results). */
+t4a_gpu_status t4a_gpu_tt_estimate_true_error(t4a_gpu_tt* tt, t4a_gpu_batch_eval_fn f, void* ctx, size_t nsearch, const size_t* initial_points,
+                                              size_t n_initial, uint64_t seed, size_t* pivots_out /* n_sites x capacity */,
+                                              double* errors_out /* capacity */, size_t capacity, size_t* n_out);
+/* opt_first_pivot(f, local_dims, first_pivot, max_sweep) (tensorci/src/optfirstpivot.rs:40-74): greedy coordinate search for
+ * a large |f|; host logic over the batch callback (one batch per site scan), no device work. */
+t4a_gpu_status t4a_gpu_opt_first_pivot(t4a_gpu_batch_eval_fn f, void* ctx, const size_t* local_dims, size_t n_sites, const size_t* first_pivot,
+                                       size_t max_sweep, size_t* pivot_out /* n_sites */);
+
 /* TensorCI2::to_tensor_train (tensorci2.rs:640-660): a device-to-device copy of the current site tensors. */
 t4a_gpu_status t4a_gpu_tci2_to_tensor_train(t4a_gpu_tci2* h, t4a_gpu_tt** out);
 /* TensorCI2::from_tensor_train(tt, TensorCI2FromTensorTrainOptions{tolerance, max_bond_dim, max_iter})
@@ -650,11 +669,16 @@ t4a_gpu_status t4a_gpu_tci2_last_sweep_shapes(const t4a_gpu_tci2* h, size_t* out
  *  [8] total pivot steps executed by the rrlu kernel  [9] algorithmic rrlu bytes (BASELINE.md §2 model)
  *  [10] algorithmic flops (rrlu + factors + fill)  [11] function evaluations
  *  [12..15] the rrLU kernel instantiation with the largest total time: ms, launches, algorithmic bytes,
- *           code = RPT*1000 + CPT*10 + 2*single_workgroup + wave_uniform_columns (negative: LDS kernel) */
+ *           code = RPT*1000 + CPT*10 + 4*row_major_ties + 2*single_workgroup + wave_uniform_columns (negative: LDS / HBM
+ *           kernels; >= 100000: single-XCD kernel, see t4a_gpu_tci2_profile_variants) */
 #define T4A_GPU_PROFILE_SLOTS 16
 t4a_gpu_status t4a_gpu_tci2_profile_enable(t4a_gpu_tci2* h, int32_t enable);
 t4a_gpu_status t4a_gpu_tci2_profile_reset(t4a_gpu_tci2* h);
 t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out /* [T4A_GPU_PROFILE_SLOTS] */);
+/* One row {code, ms, launches, algorithmic bytes, pivot steps} per rrLU kernel instantiation used since the last reset
+ * (query-then-fill: out == NULL returns the row count).  code >= 100000: single-XCD kernel,
+ * 100000 + RPT*100 + CPT*10 + 4*row_major_ties; otherwise as slot 15 of t4a_gpu_tci2_profile_get. */
+t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out /* [cap_rows][5] */, size_t cap_rows, size_t* n_rows);
 
 /* Evaluate a built-in function on the device for a batch of full multi-indices (parity check of the
  * workload definition itself).  idx: n_sites x n_pts column-major. */

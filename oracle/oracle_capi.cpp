@@ -2,6 +2,9 @@
 // Plain C entry points so that tests/ and bench.py's cpu_baseline leg can drive the CPU
 // restatement through ctypes.  Nothing in the product (tensor4all-rs_amd/) links this.
 #include "t4a_oracle.hpp"
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
 #include "t4a_oracle_patch.hpp"
 #include "t4a_oracle_tree.hpp"
 #include "t4a_oracle_quantics.hpp"
@@ -246,7 +249,28 @@ int oracle_tci2_set_builtin_fn(void* h, int fid, int n_acc, const double* params
         fn.weights.assign(weights, weights + (size_t)n_acc * tot);
         o->f = fn;
         o->has_batched = false;
+#if defined(_OPENMP)
+        o->tci->parallel_eval = true; // built-in functions are pure: candidate matrices and fill sites may use all host threads
+#endif
     });
+}
+
+// 0: scalar build; otherwise the number of OpenMP threads the `native` build uses
+int oracle_openmp_threads(void)
+{
+#if defined(_OPENMP)
+    return omp_get_max_threads();
+#else
+    return 0;
+#endif
+}
+void oracle_set_threads(int n)
+{
+#if defined(_OPENMP)
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int oracle_tci2_set_callback(void* h, scalar_cb_t cb, batch_cb_t bcb, void* ctx)
@@ -343,6 +367,15 @@ int oracle_tci2_sweep1site(void* h, int forward, double rel_tol, double abs_tol,
         o->tci->sweep1site(o->f, forward != 0, rel_tol, abs_tol,
                            max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : (size_t)max_bond_dim,
                            update_tensors != 0);
+    });
+}
+
+// TensorCI2::make_canonical (tensorci2.rs:1201-1221); max_bond_dim == 0 stands for usize::MAX
+int oracle_tci2_make_canonical(void* h, double rel_tol, double abs_tol, uint64_t max_bond_dim)
+{
+    return guarded([&] {
+        auto* o = static_cast<OracleTci*>(h);
+        o->tci->make_canonical(o->f, rel_tol, abs_tol, max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : (size_t)max_bond_dim);
     });
 }
 

@@ -3,6 +3,7 @@
 #include "t4a_oracle_tt.hpp"
 #include "t4a_oracle_tensor.hpp"
 #include "t4a_oracle_aci.hpp"
+#include "t4a_oracle_search.hpp"
 
 #include <cstring>
 #include <memory>
@@ -532,6 +533,58 @@ void oracle_aci_problem_errors(void* h, double* pivot_errors, double* pivot_scal
         pivot_errors[b] = s->p->pivot_errors[b];
         pivot_scales[b] = s->p->pivot_scales[b];
     }
+}
+
+
+// ---- floating_zone / estimate_true_error / opt_first_pivot (t4a_oracle_search.hpp) ----
+typedef double (*oracle_scalar_fn)(void* ctx, const uint64_t* idx, uint64_t n);
+static ScalarFn wrap_scalar(oracle_scalar_fn f, void* ctx)
+{
+    return [f, ctx](const MultiIndex& idx) {
+        std::vector<uint64_t> u(idx.begin(), idx.end());
+        return f(ctx, u.data(), (uint64_t)u.size());
+    };
+}
+int oracle_tt_floating_zone(void* h, oracle_scalar_fn f, void* ctx, const uint64_t* local_dims, uint64_t n_sites, const uint64_t* init_p,
+                            uint64_t seed, double early_stop_tol, uint64_t* pivot_out, double* error_out)
+{
+    return guarded([&] {
+        auto& tt = static_cast<OracleTT*>(h)->tt;
+        std::vector<size_t> ld(local_dims, local_dims + n_sites);
+        MultiIndex init;
+        if (init_p) init.assign(init_p, init_p + n_sites);
+        auto r = floating_zone(tt, wrap_scalar(f, ctx), ld, init_p ? &init : nullptr, seed, early_stop_tol);
+        for (size_t s = 0; s < r.first.size(); ++s) pivot_out[s] = r.first[s];
+        *error_out = r.second;
+    });
+}
+int oracle_tt_estimate_true_error(void* h, oracle_scalar_fn f, void* ctx, uint64_t nsearch, const uint64_t* initial_points, uint64_t n_initial,
+                                  uint64_t seed, uint64_t* pivots_out, double* errors_out, uint64_t capacity, uint64_t* n_out)
+{
+    return guarded([&] {
+        auto& tt = static_cast<OracleTT*>(h)->tt;
+        const size_t n = tt.len();
+        std::vector<MultiIndex> init;
+        if (initial_points)
+            for (size_t k = 0; k < n_initial; ++k) init.emplace_back(initial_points + k * n, initial_points + (k + 1) * n);
+        auto res = estimate_true_error(tt, wrap_scalar(f, ctx), (size_t)nsearch, initial_points ? &init : nullptr, seed);
+        *n_out = res.size();
+        if (res.size() > capacity) throw OracleError(ERR_INVALID_ARGUMENT, "estimate_true_error: capacity too small");
+        for (size_t k = 0; k < res.size(); ++k) {
+            for (size_t s = 0; s < n; ++s) pivots_out[s + n * k] = res[k].first[s];
+            errors_out[k] = res[k].second;
+        }
+    });
+}
+int oracle_opt_first_pivot(oracle_scalar_fn f, void* ctx, const uint64_t* local_dims, uint64_t n_sites, const uint64_t* first_pivot,
+                           uint64_t max_sweep, uint64_t* pivot_out)
+{
+    return guarded([&] {
+        std::vector<size_t> ld(local_dims, local_dims + n_sites);
+        MultiIndex fp(first_pivot, first_pivot + n_sites);
+        MultiIndex r = opt_first_pivot(wrap_scalar(f, ctx), ld, fp, (size_t)max_sweep);
+        for (size_t s = 0; s < r.size(); ++s) pivot_out[s] = r[s];
+    });
 }
 
 } // extern "C"

@@ -651,6 +651,10 @@ struct TensorCI2 { // :349-368
     // per-bond (M, N, rank) log of the most recent 2-site half-sweep (for the work model)
     std::vector<std::array<size_t, 3>> last_sweep_shapes;
     size_t n_evals = 0;
+    // OpenMP builds only (oracle/Makefile `native`): f is a thread-safe built-in function, so the independent evaluations of a
+    // candidate matrix and the independent sites of fill_site_tensors may run on several host threads (same values, same order
+    // of every reduction).  Never set for Python callbacks.
+    bool parallel_eval = false;
 
     explicit TensorCI2(const std::vector<size_t>& dims) // :380-404
     {
@@ -783,6 +787,17 @@ struct TensorCI2 { // :349-368
                     ++idx;
                 }
         } else {
+#if defined(_OPENMP)
+            if (parallel_eval) {
+                const long long ni = (long long)is.size();
+#pragma omp parallel for schedule(static)
+                for (long long i = 0; i < ni; ++i)
+                    for (size_t j = 0; j < js.size(); ++j) pi((size_t)i, j) = f(concat(is[(size_t)i], js[j]));
+                if (track_max)
+                    for (size_t i = 0; i < is.size(); ++i)
+                        for (size_t j = 0; j < js.size(); ++j) update_max_sample_value(pi(i, j));
+            } else
+#endif
             for (size_t i = 0; i < is.size(); ++i)
                 for (size_t j = 0; j < js.size(); ++j) {
                     const double v = f(concat(is[i], js[j]));
@@ -1037,7 +1052,13 @@ struct TensorCI2 { // :349-368
     void fill_site_tensors(const ScalarFn& f)
     {
         const size_t n = len();
-        for (size_t b = 0; b < n; ++b) {
+        size_t evals = 0;
+        std::string failure; // (exceptions must not leave a parallel region)
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : evals) if (parallel_eval)
+#endif
+        for (long long bb = 0; bb < (long long)n; ++bb) {
+            const size_t b = (size_t)bb;
             std::vector<MultiIndex> i_kron = kronecker_i(b);
             const std::vector<MultiIndex>& j_b = j_set[b];
             if (i_kron.empty() || j_b.empty()) { // :1074-1092
@@ -1050,7 +1071,7 @@ struct TensorCI2 { // :349-368
             Matrix pi1(ni, nj);
             for (size_t i = 0; i < ni; ++i)
                 for (size_t j = 0; j < nj; ++j) pi1(i, j) = f(concat(i_kron[i], j_b[j]));
-            n_evals += ni * nj;
+            evals += ni * nj;
             if (b == n - 1) { // :1109-1128
                 const size_t left_dim = (b == 0) ? 1 : i_set[b].size();
                 const size_t sd = local_dims[b];
@@ -1067,7 +1088,7 @@ struct TensorCI2 { // :349-368
                 Matrix p(np, nj);
                 for (size_t i = 0; i < np; ++i)
                     for (size_t j = 0; j < nj; ++j) p(i, j) = f(concat(i_bp1[i], j_b[j]));
-                n_evals += np * nj;
+                evals += np * nj;
                 const size_t left_dim = (b == 0) ? 1 : i_set[b].size();
                 const size_t sd = local_dims[b];
                 const size_t right_dim = np;
@@ -1082,7 +1103,11 @@ struct TensorCI2 { // :349-368
                 try {
                     x_t = solve(transpose(p), transpose(pi1)); // :1160-1164
                 } catch (const OracleError& e) {
-                    throw OracleError(ERR_INTERNAL, std::string("one-site interpolation solve failed: ") + e.what());
+#if defined(_OPENMP)
+#pragma omp critical
+#endif
+                    failure = std::string("one-site interpolation solve failed: ") + e.what();
+                    continue;
                 }
                 Tensor3 t(left_dim, sd, right_dim);
                 for (size_t l = 0; l < left_dim; ++l)
@@ -1091,6 +1116,8 @@ struct TensorCI2 { // :349-368
                 site_tensors[b] = t;
             }
         }
+        n_evals += evals;
+        if (!failure.empty()) throw OracleError(ERR_INTERNAL, failure);
     }
 };
 

@@ -14,10 +14,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "build")
 SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "kernels_rrlu_xcd.hip", "kernels_rrlu_global.hip", "kernels_pi.hip", "kernels_dense.hip", "kernels_linalg.hip",
-           "kernels_tt.hip", "engine.hip", "rook.hip", "tt.hip", "tci2.hip", "conversion.hip", "patching.hip", "tree.hip", "quantics.hip", "tensorops.hip", "aci.hip", "capi.hip"]
+           "kernels_tt.hip", "engine.hip", "rook.hip", "tt.hip", "globalsearch.hip", "tci2.hip", "conversion.hip", "patching.hip", "tree.hip", "quantics.hip", "tensorops.hip", "aci.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"] + os.environ.get("T4A_EXTRA_FLAGS", "").split()  # e.g. -DT4A_RRLU_TRACE (tools/trace_arrivals.py)
-HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
+HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "globalsearch.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
            "../../include/t4a_testfunctions.h"]
 
 
@@ -32,6 +32,16 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT, exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
+    # objects built with other flags (T4A_EXTRA_FLAGS: trace / A-B / development builds) must not be mixed into this build
+    stamp = os.path.join(OBJ, "flags.stamp")
+    flags_now = " ".join(FLAGS)
+    try:
+        with open(stamp) as f:
+            flags_then = f.read()
+    except OSError:
+        flags_then = None
+    if flags_then != flags_now:
+        force = True
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
     objs = []
@@ -52,6 +62,8 @@ def build(force=False, verbose=True):
     lib = os.path.join(OUT, "libt4a_gpu.so")
     if force or jobs or not os.path.exists(lib):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     return lib
 
 

@@ -2,6 +2,7 @@
 // No exception crosses the boundary (tensor4all-capi/src/lib.rs:139-162 convention): every entry point
 // runs inside `guarded`, which stores the message in a thread-local slot and returns a status code.
 #include <memory>
+#include <initializer_list>
 #include <mutex>
 
 #include "patching.hpp"
@@ -10,6 +11,7 @@
 #include "quantics.hpp"
 #include "tensorops.hpp"
 #include "aci.hpp"
+#include "globalsearch.hpp"
 
 struct t4a_gpu_tci2 {
     t4a::Tci2 impl;
@@ -132,6 +134,14 @@ void download(Engine& e, double* dst, const double* src, size_t count)
     T4A_HIP(hipStreamSynchronize(e.stream()));
 }
 
+// the kernels index with 32-bit integers: larger dimensions are refused before any narrowing cast
+void require_int_dims(std::initializer_list<size_t> dims, const char* what)
+{
+    for (size_t d : dims)
+        if (d > (size_t)std::numeric_limits<int>::max())
+            throw Error(T4A_GPU_INVALID_ARGUMENT, std::string(what) + ": dimension exceeds the 32-bit index range of the device kernels");
+}
+
 size_t checked_mul(size_t a, size_t b, const char* what)
 {
     if (a != 0 && b > std::numeric_limits<size_t>::max() / a)
@@ -188,6 +198,7 @@ t4a_gpu_status t4a_gpu_rrlu_f64(double* a_inout, size_t m, size_t n, size_t max_
         T4A_REQUIRE_PTR(npivots);
         T4A_REQUIRE_PTR(last_error);
         const size_t count = checked_mul(m, n, "matrix shape");
+        require_int_dims({m, n}, "matrix shape");
         if (count) T4A_REQUIRE_PTR(a_inout);
         std::lock_guard<std::mutex> lock(g_dense_mutex);
         Engine& e = dense_engine();
@@ -217,6 +228,7 @@ t4a_gpu_status t4a_gpu_luci_f64(const double* a, size_t m, size_t n, size_t max_
         T4A_REQUIRE_PTR(cols);
         T4A_REQUIRE_PTR(pivot_errors);
         const size_t count = checked_mul(m, n, "matrix shape");
+        require_int_dims({m, n}, "matrix shape");
         if (count) {
             T4A_REQUIRE_PTR(a);
             T4A_REQUIRE_PTR(left);
@@ -252,6 +264,7 @@ t4a_gpu_status t4a_gpu_gemm_batched_f64(size_t batch, size_t m, size_t k, size_t
         const size_t na = checked_mul(checked_mul(m, k, "a shape"), batch, "a shape");
         const size_t nb = checked_mul(checked_mul(k, n, "b shape"), batch, "b shape");
         const size_t nc = checked_mul(checked_mul(m, n, "c shape"), batch, "c shape");
+        require_int_dims({m, n, k, batch}, "gemm shape");
         if (na) T4A_REQUIRE_PTR(a);
         if (nb) T4A_REQUIRE_PTR(b);
         if (nc) T4A_REQUIRE_PTR(c);
@@ -303,6 +316,7 @@ t4a_gpu_status t4a_gpu_trsm_f64(const double* a, size_t na, const double* b, siz
     return guarded([&] {
         const size_t acount = checked_mul(na, na, "a shape");
         const size_t bcount = checked_mul(bm, bn, "b shape");
+        require_int_dims({na, bm, bn}, "trsm shape");
         if (left_side ? (bm != na) : (bn != na))
             throw Error(T4A_GPU_INVALID_ARGUMENT, "triangular_solve: dimension mismatch between A and B");
         if (acount) T4A_REQUIRE_PTR(a);
@@ -370,6 +384,7 @@ t4a_gpu_status t4a_gpu_solve_f64(const double* a, size_t n, const double* b, siz
     return guarded([&] {
         const size_t acount = checked_mul(n, n, "a shape");
         const size_t bcount = checked_mul(n, nrhs, "b shape");
+        require_int_dims({n, nrhs}, "solve shape");
         if (acount) T4A_REQUIRE_PTR(a);
         if (bcount) {
             T4A_REQUIRE_PTR(b);
@@ -916,6 +931,23 @@ t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out)
             }
     });
 }
+t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out, size_t cap_rows, size_t* n_rows)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(n_rows);
+        const auto& vs = h->impl.eng.variant_stats_;
+        *n_rows = vs.size();
+        if (out == nullptr) return; // query
+        if (cap_rows < vs.size()) throw Error(T4A_GPU_BUFFER_TOO_SMALL, "profile_variants: buffer too small");
+        size_t i = 0;
+        for (const auto& kv : vs) {
+            out[5 * i + 0] = (double)kv.first;
+            for (int j = 0; j < 4; ++j) out[5 * i + 1 + j] = kv.second[j];
+            ++i;
+        }
+    });
+}
 
 
 // ------------------------------------------------------------------------------------------------ lazy block-rook LUCI
@@ -952,6 +984,7 @@ t4a_gpu_status t4a_gpu_luci_blocks_f64(size_t m, size_t n, t4a_gpu_fill_block_fn
         T4A_REQUIRE_PTR(cols);
         T4A_REQUIRE_PTR(pivot_errors);
         const size_t count = checked_mul(m, n, "matrix shape");
+        require_int_dims({m, n}, "matrix shape");
         if (count) {
             T4A_REQUIRE_PTR(fill_block);
             T4A_REQUIRE_PTR(left);
@@ -1000,6 +1033,7 @@ t4a_gpu_status t4a_gpu_luci_rook_f64(const double* a, size_t m, size_t n, size_t
         T4A_REQUIRE_PTR(cols);
         T4A_REQUIRE_PTR(pivot_errors);
         const size_t count = checked_mul(m, n, "matrix shape");
+        require_int_dims({m, n}, "matrix shape");
         if (count) {
             T4A_REQUIRE_PTR(a);
             T4A_REQUIRE_PTR(left);
@@ -1039,6 +1073,7 @@ t4a_gpu_status t4a_gpu_svd_f64(const double* a, size_t m, size_t n, double* u, d
 {
     return guarded([&] {
         const size_t count = checked_mul(m, n, "matrix shape");
+        require_int_dims({m, n}, "matrix shape");
         if (count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD of an empty matrix");
         if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "svd: dimensions above 65535 are not supported");
         T4A_REQUIRE_PTR(a);
@@ -1065,6 +1100,7 @@ t4a_gpu_status t4a_gpu_qr_f64(const double* a, size_t m, size_t n, double* q, do
 {
     return guarded([&] {
         const size_t count = checked_mul(m, n, "matrix shape");
+        require_int_dims({m, n}, "matrix shape");
         if (count == 0) return;
         if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "qr: dimensions above 65535 are not supported");
         T4A_REQUIRE_PTR(a);
@@ -1088,6 +1124,7 @@ t4a_gpu_status t4a_gpu_full_piv_lu_f64(const double* a, size_t n, double* p, dou
 {
     return guarded([&] {
         const size_t count = checked_mul(n, n, "matrix shape");
+        require_int_dims({n}, "matrix shape");
         if (count == 0) return;
         T4A_REQUIRE_PTR(a);
         T4A_REQUIRE_PTR(p);
@@ -1258,6 +1295,84 @@ t4a_gpu_status t4a_gpu_tt_evaluate_many(t4a_gpu_tt* h, const size_t* idx, size_t
         std::vector<uint32_t> u = narrow_indices(idx, checked_mul(n_pts, h->impl.len(), "index buffer"));
         const size_t s = h->impl.evaluate_many(u.data(), n_pts, split, out);
         if (used_split) *used_split = s;
+    });
+}
+
+// ---- estimate_true_error / floating_zone / opt_first_pivot (tensorci/src/globalsearch.rs, optfirstpivot.rs) ----
+extern "C++" {
+static t4a::SearchFn wrap_search_fn(t4a_gpu_batch_eval_fn f, void* ctx)
+{
+    return [f, ctx](const uint32_t* idx, size_t n_sites, size_t n_pts, double* out) {
+        const int64_t got = f(ctx, idx, n_sites, n_pts, out);
+        if (got != (int64_t)n_pts)
+            throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " + std::to_string(n_pts) + " points");
+    };
+}
+static std::vector<size_t> dims_vec(const size_t* local_dims, size_t n_sites)
+{
+    return std::vector<size_t>(local_dims, local_dims + n_sites);
+}
+} // extern "C++"
+
+t4a_gpu_status t4a_gpu_tt_floating_zone(t4a_gpu_tt* tt, t4a_gpu_batch_eval_fn f, void* ctx, const size_t* local_dims, size_t n_sites,
+                                        const size_t* init_p, uint64_t seed, double early_stop_tol, size_t* pivot_out, double* error_out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(tt);
+        T4A_REQUIRE_PTR(f);
+        T4A_REQUIRE_PTR(pivot_out);
+        T4A_REQUIRE_PTR(error_out);
+        if (n_sites) T4A_REQUIRE_PTR(local_dims);
+        std::vector<uint32_t> init;
+        if (init_p) init = narrow_indices(init_p, n_sites);
+        auto r = t4a::floating_zone(tt->impl, wrap_search_fn(f, ctx), dims_vec(local_dims, n_sites), init_p ? &init : nullptr, seed, early_stop_tol);
+        for (size_t s = 0; s < r.first.size(); ++s) pivot_out[s] = r.first[s];
+        *error_out = r.second;
+    });
+}
+
+t4a_gpu_status t4a_gpu_tt_estimate_true_error(t4a_gpu_tt* tt, t4a_gpu_batch_eval_fn f, void* ctx, size_t nsearch, const size_t* initial_points,
+                                              size_t n_initial, uint64_t seed, size_t* pivots_out, double* errors_out, size_t capacity,
+                                              size_t* n_out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(tt);
+        T4A_REQUIRE_PTR(f);
+        T4A_REQUIRE_PTR(n_out);
+        const size_t n = tt->impl.len();
+        std::vector<std::vector<uint32_t>> init;
+        if (initial_points) {
+            const std::vector<uint32_t> u = narrow_indices(initial_points, checked_mul(n, n_initial, "initial points"));
+            for (size_t k = 0; k < n_initial; ++k) init.emplace_back(u.begin() + k * n, u.begin() + (k + 1) * n);
+        }
+        const auto res = t4a::estimate_true_error(tt->impl, wrap_search_fn(f, ctx), nsearch, initial_points ? &init : nullptr, seed);
+        *n_out = res.size();
+        if (res.size() > capacity) throw Error(T4A_GPU_BUFFER_TOO_SMALL, "estimate_true_error: output capacity " + std::to_string(capacity) +
+                                                                              " < " + std::to_string(res.size()) + " results");
+        if (!res.empty()) {
+            T4A_REQUIRE_PTR(pivots_out);
+            T4A_REQUIRE_PTR(errors_out);
+        }
+        for (size_t k = 0; k < res.size(); ++k) {
+            for (size_t s = 0; s < n; ++s) pivots_out[s + n * k] = res[k].first[s];
+            errors_out[k] = res[k].second;
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_opt_first_pivot(t4a_gpu_batch_eval_fn f, void* ctx, const size_t* local_dims, size_t n_sites, const size_t* first_pivot,
+                                       size_t max_sweep, size_t* pivot_out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(f);
+        T4A_REQUIRE_PTR(pivot_out);
+        if (n_sites) {
+            T4A_REQUIRE_PTR(local_dims);
+            T4A_REQUIRE_PTR(first_pivot);
+        }
+        const std::vector<uint32_t> fp = narrow_indices(first_pivot, n_sites);
+        const std::vector<uint32_t> r = t4a::opt_first_pivot(wrap_search_fn(f, ctx), dims_vec(local_dims, n_sites), fp, max_sweep);
+        for (size_t s = 0; s < r.size(); ++s) pivot_out[s] = r[s];
     });
 }
 

@@ -539,6 +539,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
             vs[0] += rrlu_ms_this;
             vs[1] += 1.0;
             vs[2] += bytes;
+            vs[3] += r.rank;
         }
     }
     if (hp[2] != 0) throw Error(T4A_GPU_NAN_ENCOUNTERED, "NaN encountered in L or U of the rrLU factorisation");

@@ -109,8 +109,8 @@ public:
     std::function<void()> overlap_hook;
 
     Profile prof;
-    // rrLU launch statistics per kernel instantiation: code -> {ms, launches, algorithmic bytes}
-    std::map<int, std::array<double, 3>> variant_stats_;
+    // rrLU launch statistics per kernel instantiation: code -> {ms, launches, algorithmic bytes, pivot steps}
+    std::map<int, std::array<double, 4>> variant_stats_;
 
     // scratch for the TCI2 driver
     DevBuf<double> d_tmp, d_tmp2;

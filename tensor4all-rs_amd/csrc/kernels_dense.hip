@@ -8,6 +8,7 @@
 // Values of these ops are tolerance-level in the reference (third-party tenferro); pivot choice in the LU is
 // "first maximum of |a_ik|".  Built with -ffp-contract=off so the non-MFMA kernels round like the CPU oracle.
 #include "kernels.hpp"
+#include "common.hpp"
 
 #include <cstdlib>
 
@@ -627,6 +628,8 @@ void trsm_left_batched_launch(const TrsmProblem* d_problems, int n_problems, int
     if (cw_env > 0) cw = cw_env;
     if (cw < 1) cw = 1;
     const size_t lds = (size_t)max_n * cw * 8;
+    if (lds > 160 * 1024) // one right-hand-side column of the triangular system no longer fits the LDS of a compute unit
+        throw Error(T4A_GPU_NOT_IMPLEMENTED, "triangular solve: systems with more than 20480 rows are not supported");
     dim3 grid((max_nrhs + cw - 1) / cw, n_problems);
     hipLaunchKernelGGL(trsm_left_kernel, grid, dim3(256), lds, stream, d_problems, cw);
 }

@@ -38,6 +38,7 @@
 #define T4A_RRLU_SPEC2 1
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace t4a {
@@ -584,7 +585,8 @@ rrlu_reg_kernel(RrluRegArgs p)
                 unsigned cpk = NOPOS;
                 int cw = -1;
                 // all loads of one sweep are issued back to back (one memory round trip per sweep)
-                constexpr int KPL = 4; // keys per lane: W <= 256
+                constexpr int KPL = 4; // keys per lane: W <= 256 (rrlu_reg_make_plan clamps the plan)
+                static_assert(KPL * 64 == 256, "engine.hip reserves 256 key slots per table");
                 unsigned long long g[KPL][2];
                 for (;;) {
                     bool ok = true;
@@ -942,7 +944,8 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
     const char* ew = std::getenv("T4A_RRLU_W");
     const char* et = std::getenv("T4A_RRLU_T");
     const char* ec = std::getenv("T4A_RRLU_CPT");
-    const int maxw = num_cus > 16 ? num_cus - 8 : num_cus;
+    // (the key-table poller reads 4 keys per lane and the engine reserves 256 slots: never plan more workgroups than that)
+    const int maxw = std::min(num_cus > 16 ? num_cus - 8 : num_cus, 256);
     const long long elems = (long long)M * N;
     static const long long single_max = std::getenv("T4A_RRLU_SINGLE_MAX") ? std::atoll(std::getenv("T4A_RRLU_SINGLE_MAX")) : 64 * 64;
     bool single = elems <= single_max;

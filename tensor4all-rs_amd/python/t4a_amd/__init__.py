@@ -340,6 +340,43 @@ _BATCH_CB = ctypes.CFUNCTYPE(ctypes.c_int64, c_void_p, ctypes.POINTER(ctypes.c_u
                              ctypes.POINTER(c_double))
 
 
+def _batch_callback(f):
+    """ctypes batch callback (t4a_gpu_batch_eval_fn) around a Python function: f(list_of_int) -> float, or an object with a
+    `.batched(idx_array[n_pts, n_sites]) -> values` attribute."""
+    scalar = f
+    batched = getattr(f, "batched", None)
+
+    def _cb(ctx, idx_ptr, n_sites, n_pts, out_ptr):
+        try:
+            idx = np.ctypeslib.as_array(idx_ptr, shape=(n_pts, n_sites))
+            if batched is not None:
+                vals = np.asarray(batched(idx), dtype=np.float64).ravel()
+            else:
+                vals = np.array([scalar([int(v) for v in row]) for row in idx], dtype=np.float64)
+            k = min(len(vals), n_pts)
+            out = np.ctypeslib.as_array(out_ptr, shape=(n_pts,))
+            out[:k] = vals[:k]
+            return len(vals)
+        except Exception:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    return _BATCH_CB(_cb)
+
+
+def opt_first_pivot(f, local_dims, first_pivot, max_sweep=1000):
+    """opt_first_pivot (tensorci/src/optfirstpivot.rs:40): greedy coordinate search for a large |f|."""
+    ld = np.asarray(list(local_dims), dtype=np.uintp)
+    fp = np.asarray(list(first_pivot), dtype=np.uintp)
+    if len(fp) != len(ld):
+        raise T4aError(INVALID_ARGUMENT, "first pivot does not fit local_dims")
+    out = np.zeros(max(len(ld), 1), dtype=np.uintp)
+    cb = _batch_callback(f)
+    _check(_lib.t4a_gpu_opt_first_pivot(cb, None, _p(ld), c_size_t(len(ld)), _p(fp), c_size_t(max_sweep), _p(out)))
+    return [int(v) for v in out[:len(ld)]]
+
+
 class TensorCI2:
     """TensorCI2<f64> (tensorci/src/tensorci2.rs:349) — state lives in a device-side handle."""
 
@@ -583,6 +620,14 @@ class TensorCI2:
         d.update(dom_ms=float(out[12]), dom_launches=float(out[13]), dom_bytes=float(out[14]), dom_code=int(out[15]))
         return d
 
+    def profile_variants(self):
+        """Rows {code, ms, launches, bytes, steps} per rrLU kernel instantiation since the last profile_reset."""
+        n = c_size_t(0)
+        _check(_lib.t4a_gpu_tci2_profile_variants(self._h, None, c_size_t(0), ctypes.byref(n)))
+        out = np.zeros((max(n.value, 1), 5), dtype=np.float64)
+        _check(_lib.t4a_gpu_tci2_profile_variants(self._h, _p(out), c_size_t(out.shape[0]), ctypes.byref(n)))
+        return [dict(code=int(r[0]), ms=float(r[1]), launches=float(r[2]), bytes=float(r[3]), steps=float(r[4])) for r in out[: n.value]]
+
 
 def crossinterpolate2(f, local_dims, initial_pivots, options):
     """crossinterpolate2 (tensorci2.rs:1513). Returns the optimised TensorCI2; histories via .history()."""
@@ -788,6 +833,33 @@ class SimpleTensorTrain:
         _check(_lib.t4a_gpu_tt_evaluate_many(self._h, _p(idx), c_size_t(idx.shape[0]),
                                              c_size_t(0 if split is None else split), _p(out), ctypes.byref(used)))
         return (out, used.value) if return_split else out
+
+    def floating_zone(self, f, local_dims=None, init_p=None, early_stop_tol=float(np.finfo(np.float64).max), seed=0):
+        """floating_zone (tensorci/src/globalsearch.rs:163): (pivot, max |f - tt|) of a greedy coordinate search."""
+        ld = np.asarray(self.site_dims() if local_dims is None else list(local_dims), dtype=np.uintp)
+        out = np.zeros(max(len(ld), 1), dtype=np.uintp)
+        err = c_double(0.0)
+        ip = None if init_p is None else np.asarray(list(init_p), dtype=np.uintp)
+        if ip is not None and len(ip) != len(ld):
+            raise T4aError(INVALID_ARGUMENT, "initial pivot does not fit local_dims")
+        cb = _batch_callback(f)
+        _check(_lib.t4a_gpu_tt_floating_zone(self._h, cb, None, _p(ld), c_size_t(len(ld)), None if ip is None else _p(ip),
+                                             ctypes.c_uint64(seed), c_double(early_stop_tol), _p(out), ctypes.byref(err)))
+        return [int(v) for v in out[:len(ld)]], err.value
+
+    def estimate_true_error(self, f, nsearch=100, initial_points=None, seed=0):
+        """estimate_true_error (globalsearch.rs:70): [(pivot, error)] sorted by descending error, duplicates removed."""
+        n = len(self)
+        pts = None if initial_points is None else np.ascontiguousarray(np.asarray(initial_points, dtype=np.uintp).reshape(-1, n))
+        cap = nsearch if pts is None else pts.shape[0]
+        piv = np.zeros((max(cap, 1), n), dtype=np.uintp)
+        errs = np.zeros(max(cap, 1))
+        n_out = c_size_t(0)
+        cb = _batch_callback(f)
+        _check(_lib.t4a_gpu_tt_estimate_true_error(self._h, cb, None, c_size_t(nsearch), None if pts is None else _p(pts),
+                                                   c_size_t(0 if pts is None else pts.shape[0]), ctypes.c_uint64(seed), _p(piv), _p(errs),
+                                                   c_size_t(cap), ctypes.byref(n_out)))
+        return [([int(v) for v in piv[k]], float(errs[k])) for k in range(n_out.value)]
 
     def full_tensor(self):
         """full_tensor (tensortrain.rs:374): all values, leftmost site fastest."""

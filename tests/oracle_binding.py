@@ -7,12 +7,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+# bench.py's cpu_baseline leg may point this at the `make -C oracle native` build (OpenMP, -march=native of the timing host)
+LIB_PATH = os.environ.get("T4A_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp", "t4a_oracle_patch.hpp",
-                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp", "t4a_oracle_quantics.hpp", "t4a_oracle_tensor.hpp", "t4a_oracle_aci.hpp")] + [
+                                                  "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp", "t4a_oracle_quantics.hpp", "t4a_oracle_tensor.hpp", "t4a_oracle_aci.hpp",
+                                                  "t4a_oracle_search.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -21,7 +23,8 @@ def build(force=False):
     return LIB_PATH
 
 
-build()
+if not os.environ.get("T4A_ORACLE_LIB"):
+    build()
 _lib = ctypes.CDLL(LIB_PATH)
 u64 = ctypes.c_uint64
 dbl = ctypes.c_double
@@ -161,6 +164,21 @@ _SCALAR_CB = ctypes.CFUNCTYPE(dbl, vp, ctypes.POINTER(u64), u64)
 _BATCH_CB = ctypes.CFUNCTYPE(cint, vp, ctypes.POINTER(u64), u64, u64, ctypes.POINTER(dbl))
 
 
+def _scalar_cb(f):
+    def _s(ctx, idx, n):
+        return float(f([int(idx[i]) for i in range(n)]))
+    return _SCALAR_CB(_s)
+
+
+def opt_first_pivot(f, local_dims, first_pivot, max_sweep=1000):
+    ld = np.asarray(list(local_dims), dtype=np.uint64)
+    fp = np.asarray(list(first_pivot), dtype=np.uint64)
+    out = np.zeros(max(len(ld), 1), dtype=np.uint64)
+    cb = _scalar_cb(f)
+    _check_tt(_lib.oracle_opt_first_pivot(cb, None, _p(ld), u64(len(ld)), _p(fp), u64(max_sweep), _p(out)))
+    return [int(v) for v in out[:len(ld)]]
+
+
 class OracleTCI2:
     def __init__(self, local_dims):
         self.local_dims = [int(d) for d in local_dims]
@@ -229,6 +247,9 @@ class OracleTCI2:
     def sweep1site(self, forward, rel_tol, abs_tol, max_bond_dim=None, update_tensors=True):
         _check(_lib.oracle_tci2_sweep1site(vp(self._h), cint(int(forward)), dbl(rel_tol), dbl(abs_tol),
                                            u64(0 if max_bond_dim is None else max_bond_dim), cint(int(update_tensors))))
+
+    def make_canonical(self, rel_tol, abs_tol, max_bond_dim=None):
+        _check(_lib.oracle_tci2_make_canonical(vp(self._h), dbl(rel_tol), dbl(abs_tol), u64(0 if max_bond_dim is None else max_bond_dim)))
 
     def fill_site_tensors(self):
         _check(_lib.oracle_tci2_fill_site_tensors(vp(self._h)))
@@ -463,6 +484,29 @@ class OracleTT:
     def partial_sum(self, dims):
         d = np.asarray(list(dims), dtype=np.uint64)
         return self._wrap(_lib.oracle_tt_unary(vp(self._h), cint(2), dbl(0.0), _p(d) if len(d) else None, u64(len(d))))
+
+    def floating_zone(self, f, local_dims, init_p=None, early_stop_tol=float(np.finfo(np.float64).max), seed=0):
+        ld = np.asarray(list(local_dims), dtype=np.uint64)
+        out = np.zeros(max(len(ld), 1), dtype=np.uint64)
+        err = dbl(0.0)
+        ip = None if init_p is None else np.asarray(list(init_p), dtype=np.uint64)
+        cb = _scalar_cb(f)
+        _check_tt(_lib.oracle_tt_floating_zone(vp(self._h), cb, None, _p(ld), u64(len(ld)), None if ip is None else _p(ip), u64(seed),
+                                               dbl(early_stop_tol), _p(out), ctypes.byref(err)))
+        return [int(v) for v in out[:len(ld)]], err.value
+
+    def estimate_true_error(self, f, nsearch=100, initial_points=None, seed=0):
+        n = len(self)
+        pts = None if initial_points is None else np.ascontiguousarray(np.asarray(initial_points, dtype=np.uint64).reshape(-1, n))
+        cap = nsearch if pts is None else pts.shape[0]
+        piv = np.zeros((max(cap, 1), n), dtype=np.uint64)
+        errs = np.zeros(max(cap, 1))
+        n_out = u64(0)
+        cb = _scalar_cb(f)
+        _check_tt(_lib.oracle_tt_estimate_true_error(vp(self._h), cb, None, u64(nsearch), None if pts is None else _p(pts),
+                                                     u64(0 if pts is None else pts.shape[0]), u64(seed), _p(piv), _p(errs), u64(cap),
+                                                     ctypes.byref(n_out)))
+        return [([int(v) for v in piv[k]], float(errs[k])) for k in range(n_out.value)]
 
     def compress(self, method=0, tolerance=1e-12, max_bond_dim=None, normalize_error=True):
         _check_tt(_lib.oracle_tt_compress(vp(self._h), cint(method), dbl(tolerance), u64(max_bond_dim or 0),

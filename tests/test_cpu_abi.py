@@ -83,6 +83,26 @@ def test_argument_validation_happens_before_the_device_is_touched():
         assert e.value.code == t4a_amd.INVALID_ARGUMENT
 
 
+def test_dimensions_beyond_the_32_bit_index_range_are_refused():
+    """The dense entry points take usize shapes but the kernels index with 32-bit integers: a dimension above INT_MAX is an
+    INVALID_ARGUMENT before any narrowing cast (and before the device is touched)."""
+    import t4a_amd
+    lib = ctypes.CDLL(t4a_amd.LIB_PATH)
+    big = ctypes.c_size_t(2 ** 32 + 1)
+    one = ctypes.c_size_t(1)
+    dummy = (ctypes.c_double * 4)()
+    perm = (ctypes.c_size_t * 4)()
+    npiv = ctypes.c_size_t(0)
+    err = ctypes.c_double(0.0)
+    lib.t4a_gpu_rrlu_f64.restype = ctypes.c_int32
+    st = lib.t4a_gpu_rrlu_f64(dummy, big, one, ctypes.c_size_t(0), ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int32(1), perm, perm,
+                              ctypes.byref(npiv), ctypes.byref(err))
+    assert st == t4a_amd.INVALID_ARGUMENT
+    lib.t4a_gpu_gemm_batched_f64.restype = ctypes.c_int32
+    st = lib.t4a_gpu_gemm_batched_f64(one, big, one, one, dummy, dummy, dummy)
+    assert st == t4a_amd.INVALID_ARGUMENT
+
+
 def test_options_default_matches_reference_defaults():
     import t4a_amd
     o = t4a_amd.TCI2OptionsC()

@@ -101,6 +101,67 @@ def test_patch_farm_on_device_matches_oracle(rccl):
     assert not np.array_equal(farmed[0][n - 1], farmed[1][n - 1]) or not np.array_equal(farmed[0][0], farmed[1][0])
 
 
+def test_cfg5_full_size_64_patches_chi128(rccl):
+    """BASELINE.json configs[4] at size on one GPU: 64 static patches (6 leading bits of the d = 30 bench integrand
+    projected, 30 active sites each), per-patch crossinterpolate2 with max_bond_dim = 128, farmed through
+    parallel.run_patch_farm (world size 1 over RCCL).  All 64 patches come back in patch (FIFO) order and tile the domain;
+    a sample of 8 patches is compared with the CPU oracle: bit-exact I/J sets, values to 1e-10."""
+    import torch
+    import t4a_amd
+    import bench
+    import oracle_binding as ob
+    from t4a_amd import parallel
+    n_patches, chi, n = 64, 128, bench.N_SITES
+    opt = t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=9, ncheck_history=10 ** 6, nsearch=0, max_nglobal_pivot=0,
+                              seed=42)
+    sample = [0, 9, 18, 27, 36, 45, 54, 63]
+    kept = {}
+    order = []
+    sums = {}
+
+    def run_patch(p):
+        t = t4a_amd.TensorCI2([2] * n)
+        t.set_function(bench.patch_spec(p, n_patches))
+        t.add_global_pivots([[0] * n])
+        t.set_max_sample_value(1.0)
+        t.optimize(opt, final_sweep1site=False)
+        t.fill_site_tensors()
+        order.append(p)
+        if p in sample:
+            kept[p] = t
+        cores = [t.site_tensor(s) for s in range(n)]
+        sums[p] = [float(np.abs(np.asarray(c)).ravel(order="F").sum()) for c in cores]
+        return cores
+
+    farmed = parallel.run_patch_farm(rccl, torch, n_patches, run_patch, device="cuda")
+    assert order == list(range(n_patches))          # FIFO inside the rank
+    assert len(farmed) == n_patches and all(len(c) == n for c in farmed)
+    # every patch reaches the cap (so its interpolant is a truncation, not exact: values are checked against the oracle below),
+    # arrives at ITS place after packing / all-gather / unpacking, and differs from its neighbour
+    for p in range(n_patches):
+        dims = [c.shape[2] for c in farmed[p][:-1]]
+        assert max(dims) == chi, f"patch {p}: link dims {dims}"
+        assert [float(np.abs(np.asarray(c)).ravel(order="F").sum()) for c in farmed[p]] == sums[p], f"patch {p} was re-assembled out of order"
+        assert sums[p] != sums[(p + 1) % n_patches]
+    # the sample against the oracle
+    for p in sample:
+        o = ob.OracleTCI2([2] * n)
+        o.set_function(bench.patch_spec(p, n_patches))
+        o.add_global_pivots([[0] * n])
+        o.set_max_sample_value(1.0)
+        o.optimize(opt, final_sweep1site=False)
+        o.fill_site_tensors()
+        g = kept[p]
+        for s in range(n):
+            assert np.array_equal(g.i_set(s), o.i_set(s)), f"patch {p}: I set of site {s}"
+            assert np.array_equal(g.j_set(s), o.j_set(s)), f"patch {p}: J set of site {s}"
+        assert np.array_equal(g.bond_errors(), o.bond_errors())
+        for s in range(n):
+            a, b = farmed[p][s], o.site_tensor(s)
+            assert a.shape == b.shape
+            assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), f"patch {p} site {s}"
+
+
 def test_site_sharded_fill_on_device_is_bitwise_the_unsharded_fill(rccl):
     """BASELINE config 4's sharding: with identical index sets, rank r fills the sites s % world == r and the cores
     are exchanged through device pointers; the assembled train is bitwise the unsharded fill_site_tensors."""

@@ -144,6 +144,79 @@ def test_stepwise_api_parity(t4a):
     assert abs(g.sum() - o.sum()) <= 1e-10 * 2 ** n
 
 
+@pytest.mark.parametrize("max_bond_dim", [None, 5])
+def test_make_canonical_matches_oracle(t4a, max_bond_dim):
+    """TensorCI2::make_canonical (tensorci2.rs:1201-1221): exact forward sweep (rel = abs = 0, no rank cap, no tensors),
+    truncating backward sweep, truncating forward sweep with tensors — after global pivots were added, with and without a
+    bond-dimension cap (None = usize::MAX)."""
+    from t4a_amd.functions import quantics_osc2d
+    n = 12
+    spec = quantics_osc2d(n, k1=3, k2=5, k3=7, eps=0.3)
+    g, o = both(t4a, spec, [2] * n)
+    piv = [[0] * n, [1, 0] * (n // 2), [0, 1, 1] * (n // 3), [1] * n]
+    g.add_global_pivots(piv)
+    o.add_global_pivots(piv)
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=16, max_iter=3, ncheck_history=6, **PARITY)
+    g.optimize(opts, final_sweep1site=False)
+    o.optimize(opts, final_sweep1site=False)
+    more = [[1, 1, 0, 0] * (n // 4), [0, 0, 1] * (n // 3)]
+    g.add_global_pivots(more)
+    o.add_global_pivots(more)
+    g.make_canonical(1e-10, 1e-13, max_bond_dim)
+    o.make_canonical(1e-10, 1e-13, max_bond_dim)
+    assert_same_sets(g, o, n)
+    assert np.array_equal(g.bond_errors(), o.bond_errors())
+    assert np.array_equal(g.pivot_errors(), o.pivot_errors())
+    assert g.max_sample_value() == o.max_sample_value()
+    assert_cores_close(g, o, n, 1e-10)
+    if max_bond_dim is not None:
+        assert max(g.link_dims()) <= max_bond_dim
+    assert abs(g.sum() - o.sum()) <= 1e-10 * 2 ** n
+    # argument validation of the reference (validate_nonnegative_finite / validate_positive)
+    with pytest.raises(t4a.T4aError):
+        g.make_canonical(-1.0, 0.0, None)
+    with pytest.raises(t4a.T4aError):
+        g.make_canonical(0.0, float("nan"), None)
+
+
+def test_two_handles_on_two_host_threads(t4a):
+    """Two TensorCI2 handles driven from two host threads at the same time: the persistent multi-workgroup rrLU launches are
+    arbitrated per XCD (engine.hip, XcdArbiter), so both runs finish with the oracle's pivots and no hand-off timeout."""
+    import threading
+    from t4a_amd.functions import quantics_osc2d
+    n = 16
+    specs = [quantics_osc2d(n, k1=5, k2=9, k3=3, eps=0.2), quantics_osc2d(n, k1=7, k2=3, k3=11, eps=0.4)]
+    opts = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=48, max_iter=6, ncheck_history=8, **PARITY)
+    handles, oracles = [], []
+    for spec in specs:
+        g, o = both(t4a, spec, [2] * n)
+        for h in (g, o):
+            h.add_global_pivots([[0] * n, [1] * n])
+            h.set_max_sample_value(1.0)
+        handles.append(g)
+        oracles.append(o)
+    errors = []
+
+    def run(h):
+        try:
+            for _ in range(3):
+                h.optimize(opts, final_sweep1site=False)
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(h,)) for h in handles]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for g, o in zip(handles, oracles):
+        for _ in range(3):
+            o.optimize(opts, final_sweep1site=False)
+        assert_same_sets(g, o, n)
+        assert np.array_equal(g.bond_errors(), o.bond_errors())
+
+
 def test_history_extras_are_merged_like_the_reference(t4a):
     """optimize loop without strict nesting: iteration t merges the I/J sets saved at the start of t-1
     (tensorci2.rs:1675-1689) — the per-bond (M, N, rank) log must agree with the oracle."""
