@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the cfg2 / cfg4 / cfg5 single-GPU timings of the aux block")
+    ap.add_argument("--mode", choices=["headline", "site-shard"], default="headline",
+                    help="headline: BASELINE.json configs[2] (N = 1) / patch farm (N > 1).  site-shard: configs[3] — d = 40, chi = 512, "
+                         "bond chain replicated on every rank, fill_site_tensors sharded by site, one device-resident core "
+                         "all-gather per half-sweep overlapped with the next half-sweep")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +109,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.mode == "site-shard":
+        site_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     spec = patch_spec(rank, world)
     tci = t4a_amd.TensorCI2([2] * N_SITES)
@@ -273,6 +284,76 @@ def main():
 
 
 XCD_EXCHANGE_FLOOR_US = 1715 / 2380.0  # tools/xcd_bench.hip, see latency_view
+
+
+def site_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier):
+    """BASELINE.json configs[3]: TCI2 at d = 40, chi_max = 512.  The update_pivots chain does not shard (bond b + 1 needs
+    the pivots of bond b), so every rank runs it (deterministic: identical pivots everywhere); fill_site_tensors is
+    sharded by site (tensorci2.rs:1065-1186: sites are independent given the I/J sets) and after every half-sweep ONE
+    all-gather moves the padded cores between the GPUs, device to device, overlapped with the next half-sweep's bond
+    updates.  Strong scaling: the total work is fixed, only the fill shrinks with N."""
+    from t4a_amd import parallel
+    from t4a_amd.functions import quantics_osc2d
+    d4, chi4 = 40, 512
+    spec = quantics_osc2d(d4, k1=37, k2=53, k3=20011, eps=0.5, k4=1048583, delta=0.5)  # tools/probe_cfg4.py: saturates 512
+    tci = t4a_amd.TensorCI2([2] * d4)
+    tci.set_function(spec)
+    tci.add_global_pivots([[0] * d4])
+    tci.set_max_sample_value(1.0)
+    tci.set_keep_site_tensors(True)
+    tci.set_site_shard(rank, world)
+
+    def opts(iters):
+        return t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=chi4, max_iter=iters, ncheck_history=10 ** 6, nsearch=0,
+                                   max_nglobal_pivot=0, seed=42)
+
+    cap = chi4 * 2 * chi4
+    xchg = parallel.ShardedCoreExchange(dist if world > 1 else None, torch, d4, cap, parallel.DeviceShardAdapter(tci, torch, cap), "cuda")
+
+    def half_sweep():
+        tci.optimize(opts(1), final_sweep1site=False)  # one half-sweep: all bond updates + the local part of the fill
+        xchg.exchange()
+
+    tci.optimize(opts(11), final_sweep1site=False)      # untimed: grow to saturation
+    if max(tci.link_dims()) != chi4:
+        raise SystemExit(f"rank did not saturate: link dims {tci.link_dims()}")
+    for _ in range(2 * args.warmup):
+        half_sweep()
+    tci.profile_enable(True)
+    tci.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(2 * args.steps):
+        half_sweep()
+    xchg.finish()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = tci.profile()
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    fl_t = torch.tensor([prof["flops"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fl_t, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        # executed flops: the replicated bond chain counts once (it is the same work on every rank), the fill is summed
+        chain_flops = prof["flops"]  # this rank: chain + its share of the fill
+        out = {
+            "metric": "TCI2 full-sweep GF/s (d=40, chi=512 fp64, site-sharded fill)",
+            "value": chain_flops / float(dt_t.item()) / 1e9,
+            "unit": "GF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": float(dt_t.item()) / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "TensorCI2 d=40 interleaved-quantics 2-variable oscillatory integrand, chi_max=512, tol=1e-12, nsearch=0 "
+                                   "(BASELINE.json configs[3]); one step = forward + backward half-sweep; bond chain replicated, "
+                                   "fill_site_tensors sharded by site, one RCCL all-gather of padded cores per half-sweep",
+                       "n_sites": d4, "local_dim": 2, "chi_max": chi4, "parallelism": f"site-shard x{world}",
+                       "gather_bytes_per_half_sweep": int(world * xchg.per_rank * cap * 8)},
+            "breakdown_ms_per_sweep": {"rrlu_kernel": prof["rrlu_ms"] / args.steps, "fill_site_tensors_local": prof["fill_ms"] / args.steps},
+            "note": "value = flops executed by rank 0 (replicated chain + local share of the fill) / wall time; the chain does not "
+                    "shard in the bit-exact mode (SURVEY.md §8e), so N > 1 only shortens the fill",
+        }
+        print(json.dumps(out), flush=True)
 
 
 def rrlu_kernel_name(code):

@@ -259,6 +259,15 @@ t4a_gpu_status t4a_gpu_tci2_set_keep_site_tensors(t4a_gpu_tci2* h, int32_t keep)
  * with it; errors of that fill are reported by the next call that reads a site tensor. */
 t4a_gpu_status t4a_gpu_tci2_export_site_tensors_async(t4a_gpu_tci2* h, void* dst_device, size_t stride,
                                                       void* consumer_stream);
+/* Site-sharded fill_site_tensors (BASELINE.json configs[3]; tensorci2.rs:1065-1186: sites are independent given the I/J
+ * sets) without host staging.  After t4a_gpu_tci2_set_site_shard(rank, world):
+ *   export: the local sites s = rank + world * k go to dst_device + k * stride (doubles), ordered after the fill that may
+ *           still be in flight; `consumer_stream` (the stream the RCCL all-gather is issued from) waits for the copies;
+ *   import: the gathered buffer is [world][per_rank][stride]; every remote site is copied into this handle (shapes follow
+ *           from the replicated index sets) on the handle's stream, after what `producer_stream` has enqueued so far. */
+t4a_gpu_status t4a_gpu_tci2_export_site_shard_async(t4a_gpu_tci2* h, void* dst_device, size_t stride, void* consumer_stream);
+t4a_gpu_status t4a_gpu_tci2_import_site_shard_async(t4a_gpu_tci2* h, const void* src_device, size_t stride, size_t per_rank,
+                                                    void* producer_stream);
 
 /* =====================================================================================
  * SimpleTensorTrain<f64> (opaque handle; site tensors resident on the device)

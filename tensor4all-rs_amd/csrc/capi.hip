@@ -880,6 +880,25 @@ t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t 
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_export_site_shard_async(t4a_gpu_tci2* h, void* dst_device, size_t stride, void* consumer_stream)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(dst_device);
+        h->impl.export_site_shard_async(static_cast<double*>(dst_device), stride, static_cast<hipStream_t>(consumer_stream));
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_import_site_shard_async(t4a_gpu_tci2* h, const void* src_device, size_t stride, size_t per_rank,
+                                                    void* producer_stream)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(src_device);
+        h->impl.import_site_shard_async(static_cast<const double*>(src_device), stride, per_rank, static_cast<hipStream_t>(producer_stream));
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_set_keep_site_tensors(t4a_gpu_tci2* h, int32_t keep)
 {
     return guarded([&] {

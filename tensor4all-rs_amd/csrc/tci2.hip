@@ -1326,6 +1326,49 @@ void Tci2::export_site_tensors_async(double* d_dst, size_t stride, hipStream_t c
     T4A_HIP(hipStreamWaitEvent(consumer, export_event_, 0));
 }
 
+// Site-sharded fill (BASELINE.json configs[3]): the sites s = shard_rank + shard_world * k of this rank go to
+// d_dst + k * stride on the stream of the fill that may still be in flight; `consumer` (the stream of the all-gather) waits.
+void Tci2::export_site_shard_async(double* d_dst, size_t stride, hipStream_t consumer)
+{
+    hipStream_t st = fill_inflight_ ? fill_stream_ : eng.stream();
+    size_t k = 0;
+    for (size_t s = shard_rank; s < n_; s += shard_world, ++k) {
+        const DevCore& c = cores[s];
+        if (c.size() > stride) throw Error(T4A_GPU_BUFFER_TOO_SMALL, "export_site_shard: stride smaller than a site tensor");
+        if (c.size())
+            T4A_HIP(hipMemcpyAsync(d_dst + k * stride, c.buf.get(), c.size() * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    if (!export_event_) T4A_HIP(hipEventCreateWithFlags(&export_event_, hipEventDisableTiming));
+    T4A_HIP(hipEventRecord(export_event_, st));
+    T4A_HIP(hipStreamWaitEvent(consumer, export_event_, 0));
+}
+
+// The other ranks' cores out of the gathered buffer [world][per_rank][stride]: site s of rank r = s % world sits at
+// (r * per_rank + s / world) * stride.  Shapes follow from the (replicated) index sets.  The copies run on this handle's
+// stream after everything `producer` (the all-gather's stream) has enqueued so far; nothing blocks the host.
+void Tci2::import_site_shard_async(const double* d_src, size_t stride, size_t per_rank, hipStream_t producer)
+{
+    fill_wait();
+    if (!import_event_) T4A_HIP(hipEventCreateWithFlags(&import_event_, hipEventDisableTiming));
+    T4A_HIP(hipEventRecord(import_event_, producer));
+    T4A_HIP(hipStreamWaitEvent(eng.stream(), import_event_, 0));
+    for (size_t s = 0; s < n_; ++s) {
+        const size_t r = s % shard_world;
+        if (r == shard_rank) continue;
+        DevCore& c = cores[s];
+        const size_t l = (s == 0) ? 1 : std::max<size_t>(i_set[s].count, 1);
+        const size_t rr = (s + 1 == n_) ? 1 : std::max<size_t>(i_set[s + 1].count, 1);
+        const size_t count = l * local_dims[s] * rr;
+        if (count > stride) throw Error(T4A_GPU_BUFFER_TOO_SMALL, "import_site_shard: stride smaller than a site tensor");
+        c.buf.reserve(std::max<size_t>(count, 1));
+        c.l = l;
+        c.s = local_dims[s];
+        c.r = rr;
+        T4A_HIP(hipMemcpyAsync(c.buf.get(), d_src + (r * per_rank + s / shard_world) * stride, count * sizeof(double),
+                               hipMemcpyDeviceToDevice, eng.stream()));
+    }
+}
+
 // =================================================================================================
 // TT evaluation / sum
 // =================================================================================================

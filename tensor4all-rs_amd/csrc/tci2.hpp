@@ -83,6 +83,8 @@ public:
     void fill_site_tensors_impl(bool async);
     void fill_wait(); // completes an asynchronous fill (and reports its deferred errors)
     void export_site_tensors_async(double* d_dst, size_t stride, hipStream_t consumer);
+    void export_site_shard_async(double* d_dst, size_t stride, hipStream_t consumer);
+    void import_site_shard_async(const double* d_src, size_t stride, size_t per_rank, hipStream_t producer);
     void make_canonical(double rel_tol, double abs_tol, size_t max_bond_dim);
     void invalidate_site_tensors();
     void flush_pivot_errors() { pivot_errors.clear(); }
@@ -207,7 +209,7 @@ private:
     DevBuf<unsigned long long> d_fillmax_;
     EventTimer ev_pi_, ev_fill_;
     hipStream_t fill_stream_ = nullptr;
-    hipEvent_t export_event_ = nullptr;
+    hipEvent_t export_event_ = nullptr, import_event_ = nullptr;
     bool fill_inflight_ = false, fill_timed_ = false;
     std::vector<size_t> fill_solved_sites_;
     PinBuf<int> h_fillinfo_;

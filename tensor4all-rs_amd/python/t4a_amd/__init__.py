@@ -550,6 +550,15 @@ class TensorCI2:
         _check(_lib.t4a_gpu_tci2_export_site_tensors_async(self._h, c_void_p(device_ptr), c_size_t(stride),
                                                            c_void_p(consumer_stream)))
 
+    def export_site_shard_async(self, device_ptr, stride, consumer_stream):
+        """Local sites (set_site_shard) -> device buffer [per_rank][stride], ordered after the fill in flight."""
+        _check(_lib.t4a_gpu_tci2_export_site_shard_async(self._h, c_void_p(device_ptr), c_size_t(stride), c_void_p(consumer_stream)))
+
+    def import_site_shard_async(self, device_ptr, stride, per_rank, producer_stream):
+        """Remote sites out of the gathered device buffer [world][per_rank][stride] into this handle."""
+        _check(_lib.t4a_gpu_tci2_import_site_shard_async(self._h, c_void_p(device_ptr), c_size_t(stride), c_size_t(per_rank),
+                                                         c_void_p(producer_stream)))
+
     def set_keep_site_tensors(self, keep=True):
         _check(_lib.t4a_gpu_tci2_set_keep_site_tensors(self._h, c_int32(1 if keep else 0)))
 

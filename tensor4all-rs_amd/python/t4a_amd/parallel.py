@@ -98,3 +98,91 @@ def sharded_fill(dist, torch, n_sites, fill_my_sites, get_core, set_core, device
         cores = unpack_cores(all_hdr[r], all_pay[r])
         for s, c in zip([s for s in range(n_sites) if s % world == r], cores):
             set_core(s, c)
+
+
+class ShardedCoreExchange:
+    """Device-resident core exchange of the site-sharded fill (BASELINE.json configs[3]): every rank fills the sites
+    s % world == rank, packs them into a padded buffer [per_rank][cap] (cap = largest core), ONE all_gather_into_tensor per
+    half-sweep moves them, every rank unpacks the other ranks' sites.  Two buffer pairs alternate so that the collective of
+    half-sweep k can still be in flight while half-sweep k + 1 runs its bond updates.
+
+    `adapter` hides where the cores live:
+      export_shard(send_tensor)              local cores -> send_tensor viewed as [per_rank, cap]
+      import_shard(recv_tensor, per_rank)    remote cores <- recv_tensor viewed as [world, per_rank, cap]
+    DeviceShardAdapter (below) does both with device-to-device copies through the C ABI; tests/test_cpu_parallel.py runs the
+    same orchestration on gloo with a numpy adapter around the CPU oracle."""
+
+    def __init__(self, dist, torch, n_sites, cap, adapter, device):
+        self.dist, self.torch, self.adapter = dist, torch, adapter
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.per_rank = (n_sites + self.world - 1) // self.world
+        self.cap = cap
+        self.send = [torch.zeros(self.per_rank * cap, dtype=torch.float64, device=device) for _ in range(2)]
+        self.recv = [torch.zeros(self.world * self.per_rank * cap, dtype=torch.float64, device=device) for _ in range(2)]
+        self.pending = [None, None]         # collective handles
+        self.outstanding = [False, False]   # an exchange on this buffer pair has not been imported yet
+        self.count = 0
+
+    def exchange(self):
+        """Called after the local fill of a half-sweep: returns without waiting for the collective on the host."""
+        k = self.count % 2
+        self.count += 1
+        self.finish(k)  # the exchange that used this buffer pair two half-sweeps ago
+        self.adapter.export_shard(self.send[k])
+        work = None
+        if self.world > 1:
+            work = self.dist.all_gather_into_tensor(self.recv[k], self.send[k], async_op=True)
+        else:
+            self.recv[k].copy_(self.send[k])
+        self.pending[k] = work
+        self.outstanding[k] = True
+        return k
+
+    def finish(self, k=None):
+        """Make the cores of exchange k (default: every outstanding one, oldest first) visible in the local handle."""
+        for kk in ([k] if k is not None else [self.count % 2, (self.count + 1) % 2]):
+            if not self.outstanding[kk]:
+                continue
+            if self.pending[kk] is not None:
+                self.pending[kk].wait()  # stream-level dependency on the GPU, completion on gloo
+            self.adapter.import_shard(self.recv[kk], self.per_rank)
+            self.pending[kk] = None
+            self.outstanding[kk] = False
+
+
+class DeviceShardAdapter:
+    """Cores stay in HBM: export / import are device-to-device copies ordered by events (t4a_gpu_tci2_export_site_shard_async,
+    t4a_gpu_tci2_import_site_shard_async); the all-gather runs on torch's current stream."""
+
+    def __init__(self, tci, torch, cap):
+        self.tci, self.torch, self.cap = tci, torch, cap
+
+    def export_shard(self, send):
+        self.tci.export_site_shard_async(send.data_ptr(), self.cap, self.torch.cuda.current_stream().cuda_stream)
+
+    def import_shard(self, recv, per_rank):
+        self.tci.import_site_shard_async(recv.data_ptr(), self.cap, per_rank, self.torch.cuda.current_stream().cuda_stream)
+
+
+class NumpyShardAdapter:
+    """Cores as numpy arrays in a dict {site: array(l, s, r)} (CPU tests over gloo).  dims_of(site) -> (l, s, r) of a remote
+    core, known on every rank from the replicated index sets."""
+
+    def __init__(self, torch, store, n_sites, rank, world, cap, dims_of):
+        self.torch, self.store, self.n_sites, self.rank, self.world, self.cap, self.dims_of = torch, store, n_sites, rank, world, cap, dims_of
+
+    def export_shard(self, send):
+        buf = send.view(-1, self.cap)
+        for k, s in enumerate(range(self.rank, self.n_sites, self.world)):
+            flat = np.asarray(self.store[s], dtype=np.float64).ravel(order="F")
+            buf[k, :flat.size] = self.torch.from_numpy(flat.copy())
+
+    def import_shard(self, recv, per_rank):
+        buf = recv.view(self.world, per_rank, self.cap).numpy()
+        for s in range(self.n_sites):
+            r = s % self.world
+            if r == self.rank:
+                continue
+            l, d, rr = self.dims_of(s)
+            self.store[s] = np.array(buf[r, s // self.world, :l * d * rr]).reshape((l, d, rr), order="F")

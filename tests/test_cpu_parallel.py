@@ -59,6 +59,21 @@ def _worker(rank, world, port, n_patches, out_dir):
     assert sorted(store) == [0, 1, 2, 3]
     for s in range(4):
         assert store[s].shape == full[s].shape and np.array_equal(store[s], full[s])
+    # the same exchange through the padded, double-buffered all_gather_into_tensor path that the device uses
+    # (parallel.ShardedCoreExchange): three half-sweeps, the cores of the last one must be complete on every rank
+    dims = {s: full[s].shape for s in range(4)}
+    cap = max(int(np.prod(d)) for d in dims.values())
+    store2 = {}
+    adapter = parallel.NumpyShardAdapter(torch, store2, 4, rank, world, cap, lambda s: dims[s])
+    xchg = parallel.ShardedCoreExchange(dist, torch, 4, cap, adapter, "cpu")
+    for half_sweep in range(3):
+        for s in range(rank, 4, world):
+            store2[s] = full[s] * (half_sweep + 1.0)   # stands for the local fill of this half-sweep
+        xchg.exchange()
+    xchg.finish()
+    assert sorted(store2) == [0, 1, 2, 3]
+    for s in range(4):
+        assert store2[s].shape == full[s].shape and np.array_equal(store2[s], full[s] * 3.0), s
     dist.barrier()
     dist.destroy_process_group()
 

@@ -101,6 +101,61 @@ def test_patch_farm_on_device_matches_oracle(rccl):
     assert not np.array_equal(farmed[0][n - 1], farmed[1][n - 1]) or not np.array_equal(farmed[0][0], farmed[1][0])
 
 
+def test_device_resident_shard_exchange_matches_unsharded_fill(rccl):
+    """BASELINE.json configs[3] plumbing on one GPU: two handles stand for two ranks (identical index sets, site shards 0 / 1 of
+    2); their local cores travel through parallel.ShardedCoreExchange with the device adapter — device-to-device export into the
+    padded send buffer, all_gather_into_tensor over RCCL (world size 1 per process group, so the two shards are spliced by hand),
+    device-to-device import — and the assembled train is bitwise the unsharded fill_site_tensors."""
+    import torch
+    import t4a_amd
+    from t4a_amd import parallel
+    n, chi, world = 16, 24, 2
+    spec = t4a_amd.quantics_osc2d(n, k1=3, k2=5, k3=11, eps=0.5, k4=101, delta=0.5)
+    opt = t4a_amd.TCI2Options(tolerance=1e-10, max_bond_dim=chi, max_iter=4, nsearch=0, max_nglobal_pivot=0)
+    ref = t4a_amd.TensorCI2([2] * n)
+    ref.set_function(spec)
+    ref.add_global_pivots([[0] * n])
+    ref.optimize(opt, final_sweep1site=False)
+    ref.fill_site_tensors()
+    cap = chi * 2 * chi
+    per_rank = (n + world - 1) // world
+    shards, sends = [], []
+    for r in range(world):
+        t = t4a_amd.TensorCI2([2] * n)
+        t.set_function(spec)
+        t.add_global_pivots([[0] * n])
+        t.optimize(opt, final_sweep1site=False)   # same chain on every "rank": identical index sets
+        t.set_site_shard(r, world)
+        t.fill_site_tensors()                      # local sites only
+        send = torch.zeros(per_rank * cap, dtype=torch.float64, device="cuda")
+        parallel.DeviceShardAdapter(t, torch, cap).export_shard(send)
+        shards.append(t)
+        sends.append(send)
+    gathered = torch.cat(sends)                    # what all_gather_into_tensor delivers: [world][per_rank][cap]
+    # the collective itself (world size 1 group): must reproduce its input
+    out = torch.zeros_like(sends[0])
+    rccl.all_gather_into_tensor(out, sends[0])
+    torch.cuda.synchronize()
+    assert torch.equal(out, sends[0])
+    for r, t in enumerate(shards):
+        parallel.DeviceShardAdapter(t, torch, cap).import_shard(gathered, per_rank)
+        torch.cuda.synchronize()
+        for s in range(n):
+            a, b = t.site_tensor(s), ref.site_tensor(s)
+            assert a.shape == b.shape and np.array_equal(a, b), f"rank {r} site {s}"
+    # the single-process form of the exchange object (world == 1): export, local copy, import round trip
+    one = shards[0]
+    one.set_site_shard(0, 1)
+    one.fill_site_tensors()
+    x = parallel.ShardedCoreExchange(None, torch, n, cap, parallel.DeviceShardAdapter(one, torch, cap), "cuda")
+    x.exchange()
+    x.exchange()
+    x.finish()
+    torch.cuda.synchronize()
+    for s in range(n):
+        assert np.array_equal(one.site_tensor(s), ref.site_tensor(s))
+
+
 def test_cfg5_full_size_64_patches_chi128(rccl):
     """BASELINE.json configs[4] at size on one GPU: 64 static patches (6 leading bits of the d = 30 bench integrand
     projected, 30 active sites each), per-patch crossinterpolate2 with max_bond_dim = 128, farmed through
