@@ -23,12 +23,18 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // The MFMA computes D' = B^T A^T = C^T so that a lane's accumulator column index runs over C ROWS
 // (lane&15 = 16 consecutive rows of one C column -> 128-byte contiguous stores).
 // ------------------------------------------------------------------------------------------------
-constexpr int GBM = 64, GBN = 64, GBK = 16, GPAD = 4;
+constexpr int GBM = 64, GBN = 64, GBK = 32, GPAD = 4; // BK = 32: 32 MFMAs (2 048 cycles) per wave and k-step cover the global-load latency
 
 __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
 {
-    __shared__ double As[GBK][GBM + GPAD]; // As[k][m]
-    __shared__ double Bs[GBK][GBN + GPAD]; // Bs[k][n]
+    // double-buffered LDS tiles: the global loads of tile k + 1 are issued before the MFMAs of tile k and parked in
+    // registers, so their latency hides behind the 16 MFMAs (64 cycles each on gfx950) a wave issues per tile; one barrier
+    // per k-step
+    extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
+    typedef double TileA[GBK][GBM + GPAD];
+    typedef double TileB[GBK][GBN + GPAD];
+    TileA* As = reinterpret_cast<TileA*>(gemm_smem);                      // As[buf][k][m]
+    TileB* Bs = reinterpret_cast<TileB*>(gemm_smem + 2 * sizeof(TileA));  // Bs[buf][k][n]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -48,44 +54,63 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    for (int k0 = 0; k0 < d.k; k0 += GBK) {
-        // stage A tile (64 x 16) and B tile (16 x 64); pick the thread mapping whose fast index is the
-        // unit-stride index of the operand
+    // per-thread staging coordinates: the fast thread index runs along the unit-stride index of the operand
+    constexpr int NQ = GBM * GBK / 256; // elements per thread and operand tile
+    int ar[NQ], ak[NQ], bc[NQ], bk[NQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int r, kk;
-            if (!d.transA) {
-                r = tid & 63;
-                kk = (tid >> 6) + 4 * q;
-            } else {
-                kk = tid & 15;
-                r = (tid >> 4) + 16 * q;
-            }
-            const int gm = m0 + r, gk = k0 + kk;
-            As[kk][r] = (gm < d.m && gk < d.k) ? A[(long long)gm * sam + (long long)gk * sak] : 0.0;
+    for (int q = 0; q < NQ; ++q) {
+        if (!d.transA) {
+            ar[q] = tid & 63;
+            ak[q] = (tid >> 6) + 4 * q;
+        } else {
+            ak[q] = tid & (GBK - 1);
+            ar[q] = tid / GBK + (256 / GBK) * q;
+        }
+        if (!d.transB) {
+            bk[q] = tid & (GBK - 1);
+            bc[q] = tid / GBK + (256 / GBK) * q;
+        } else {
+            bc[q] = tid & 63;
+            bk[q] = (tid >> 6) + 4 * q;
+        }
+    }
+    double ra[NQ], rb[NQ];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int gm = m0 + ar[q], gk = k0 + ak[q];
+            ra[q] = (gm < d.m && gk < d.k) ? A[(long long)gm * sam + (long long)gk * sak] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int c, kk;
-            if (!d.transB) {
-                kk = tid & 15;
-                c = (tid >> 4) + 16 * q;
-            } else {
-                c = tid & 63;
-                kk = (tid >> 6) + 4 * q;
-            }
-            const int gn = n0 + c, gk = k0 + kk;
-            Bs[kk][c] = (gn < d.n && gk < d.k) ? B[(long long)gk * sbk + (long long)gn * sbn] : 0.0;
+        for (int q = 0; q < NQ; ++q) {
+            const int gn = n0 + bc[q], gk = k0 + bk[q];
+            rb[q] = (gn < d.n && gk < d.k) ? B[(long long)gk * sbk + (long long)gn * sbn] : 0.0;
         }
-        __syncthreads();
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) As[buf][ak[q]][ar[q]] = ra[q];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) Bs[buf][bk[q]][bc[q]] = rb[q];
+    };
+
+    const int nk = (d.k + GBK - 1) / GBK;
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * GBK); // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < GBK; ks += 4) {
             const int kk = ks + (lane >> 4);
             double bn[2], am[2];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bn[ni] = Bs[kk][wn * 32 + ni * 16 + (lane & 15)];
+            for (int ni = 0; ni < 2; ++ni) bn[ni] = Bs[buf][kk][wn * 32 + ni * 16 + (lane & 15)];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) am[mi] = As[kk][wm * 32 + mi * 16 + (lane & 15)];
+            for (int mi = 0; mi < 2; ++mi) am[mi] = As[buf][kk][wm * 32 + mi * 16 + (lane & 15)];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -93,6 +118,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
                     // MFMA "A" operand = B^T (rows = n), "B" operand = A^T (cols = m)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[ni], am[mi], acc[mi][ni], 0, 0, 0);
         }
+        if (kt + 1 < nk) store_tile(buf ^ 1); // (the other buffer: last read before the previous barrier)
         __syncthreads();
     }
     // D'[i' = n][j' = m]: lane -> j' = lane&15 (C row), i' = (lane>>4) + 4*reg (C column)
@@ -668,7 +694,13 @@ void gemm_launch(const GemmDesc& d, hipStream_t stream)
 {
     if (d.m <= 0 || d.n <= 0 || d.batch <= 0) return;
     dim3 grid((d.m + GBM - 1) / GBM, (d.n + GBN - 1) / GBN, d.batch);
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, stream, d);
+    constexpr size_t lds = 2 * sizeof(double) * GBK * ((GBM + GPAD) + (GBN + GPAD));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), lds, stream, d);
 }
 
 void transpose_launch(const double* in, int rows, int cols, int ldi, double* out, int ldo, hipStream_t stream)
