@@ -23,7 +23,10 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // The MFMA computes D' = B^T A^T = C^T so that a lane's accumulator column index runs over C ROWS
 // (lane&15 = 16 consecutive rows of one C column -> 128-byte contiguous stores).
 // ------------------------------------------------------------------------------------------------
-constexpr int GBM = 64, GBN = 64, GBK = 32, GPAD = 4; // BK = 32: 32 MFMAs (2 048 cycles) per wave and k-step cover the global-load latency
+// BK = 32: 32 MFMAs (2 048 cycles) per wave and k-step cover the global-load latency.  Measured alternatives at 1024^3 /
+// 2048^3: BK 16 + pad 4 84 / 462 us, BK 32 + pad 4 80 / 463 us (kept), BK 16 + pad 16 (bank-conflict-free operand reads, three
+// workgroups per CU) 103 / 559 us, BK 32 + pad 16 99 / 559 us.
+constexpr int GBM = 64, GBN = 64, GBK = 32, GPAD = 4;
 
 __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
 {
