@@ -515,6 +515,37 @@ def aux_timings():
         out["cfg5_patch_max_link_dim"] = int(max(t.link_dims()))
     except Exception as e:  # noqa: BLE001
         out["cfg5_error"] = str(e)
+    try:  # eight cfg5 patches side by side: every handle runs its rank-revealing LUs on its own XCD (one GPU, 8 host threads)
+        import threading
+        n_patches, chi5 = 64, 128
+
+        def grow(p, out):
+            tp = t4a_amd.TensorCI2([2] * N_SITES)
+            tp.set_function(patch_spec(p, n_patches))
+            tp.add_global_pivots([[0] * N_SITES])
+            tp.set_max_sample_value(1.0)
+            tp.optimize(t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=chi5, max_iter=11, ncheck_history=10 ** 6, nsearch=0,
+                                            max_nglobal_pivot=0, seed=42), final_sweep1site=False)
+            tp.fill_site_tensors()
+            out[p] = float(tp.sum())
+
+        seq, par = {}, {}
+        t0 = time.perf_counter()
+        for p in range(2):
+            grow(p, seq)
+        t_seq = (time.perf_counter() - t0) / 2
+        ths = [threading.Thread(target=grow, args=(p, par)) for p in range(8)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        t_par = (time.perf_counter() - t0) / 8
+        out["cfg5_patch_from_scratch_ms_one_at_a_time"] = t_seq * 1e3
+        out["cfg5_patch_from_scratch_ms_eight_side_by_side"] = t_par * 1e3
+        out["cfg5_side_by_side_results_identical"] = bool(all(par[p] == seq[p] for p in seq))
+    except Exception as e:  # noqa: BLE001
+        out["cfg5_concurrent_error"] = str(e)
     try:
         from t4a_amd.functions import quantics_osc2d
         d4, chi4 = 40, 512
