@@ -110,7 +110,8 @@ Engine::Engine()
     ev_rrlu_.init();
     ev_fac_.init();
     static const int xcc_env = std::getenv("T4A_XCD_ID") ? std::atoi(std::getenv("T4A_XCD_ID")) : -1;
-    xcc_ = xcc_env >= 0 ? (xcc_env & 7) : xcd_assign();
+    // (T4A_XCD_ID=8: an XCC id no workgroup reports — exercises the fallback to the chip-wide kernel in the tests)
+    xcc_ = xcc_env >= 0 ? (xcc_env > 8 ? (xcc_env & 7) : xcc_env) : xcd_assign();
 }
 
 Engine::~Engine()
@@ -440,7 +441,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     }
     T4A_HIP(hipStreamSynchronize(stream_));
     xcd_lock.release();
-    if (use_xcd && reinterpret_cast<const int*>(h_out_.get() + 16)[1] != 0) {
+    if (use_xcd && (reinterpret_cast<const int*>(h_out_.get() + 16)[1] != 0 || reinterpret_cast<const int*>(h_out_.get() + 16)[3] != (int)xcd_salt_)) {
         // the placement assumption of the single-XCD kernel did not hold (or another process holds the compute units):
         // never try it again in this process and run this factorisation with the chip-wide kernels
         xcd_disable();

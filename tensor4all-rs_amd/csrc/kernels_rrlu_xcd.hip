@@ -854,7 +854,12 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             if (e == 2 || e == 3) continue;
             p.h_block[e] = (e == 1) ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[e];
         }
-        if (tid == 0) ((volatile int*)p.h_block)[4] = npiv;
+        if (tid == 0) {
+            ((volatile int*)p.h_block)[4] = npiv;
+            // completion token: the host accepts the result only if rank 0 ran to its end in THIS launch (a launch whose
+            // workgroups never met the elected XCD would otherwise leave an all-zero block behind)
+            ((volatile int*)p.h_block)[7] = (int)p.salt;
+        }
         __syncthreads();
         if (tid == 0) reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull; // clean header for the next launch
     }

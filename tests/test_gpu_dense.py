@@ -205,3 +205,35 @@ def test_function_workload_bit_exact(t4a):
         gpu = t4a.fn_eval(spec, spec.local_dims, idx)
         cpu = ob.fn_eval(spec, idx)
         assert np.array_equal(gpu.view(np.uint64), cpu.view(np.uint64))
+
+
+def test_single_xcd_kernel_falls_back_when_its_placement_assumption_fails():
+    """The single-XCD rrLU kernel elects its workgroups by HW_REG_XCC_ID.  With an XCC id that no workgroup reports
+    (T4A_XCD_ID=8) nobody takes part: the launch ends without the completion token, the engine re-runs the factorisation with
+    the chip-wide kernel and keeps the single-XCD path off — results are bitwise those of the default run and of T4A_NO_XCD=1."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import hashlib, os, sys
+sys.path.insert(0, os.path.join(%r, "tensor4all-rs_amd", "python"))
+import numpy as np, t4a_amd
+rng = np.random.default_rng(3)
+h = hashlib.sha256()
+for shape in ((300, 260), (130, 512), (700, 690)):
+    a = rng.uniform(-1, 1, size=shape)
+    for left in (True, False):
+        lu = t4a_amd.rrlu(a, max_bond_dim=96, left_orthogonal=left)
+        h.update(np.ascontiguousarray(lu.factored).tobytes()); h.update(lu.row_permutation.tobytes()); h.update(lu.col_permutation.tobytes())
+        h.update(np.float64(lu.error).tobytes())
+print("DIGEST", h.hexdigest())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for name, env in (("default", {}), ("no_xcd", {"T4A_NO_XCD": "1"}), ("bad_xcc", {"T4A_XCD_ID": "8"})):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[name] = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert digests["default"] == digests["no_xcd"] == digests["bad_xcc"], digests

@@ -62,6 +62,70 @@ def test_rrlu_random_cases_bitwise(t4a, seed):
         assert lu.error == err or (np.isnan(lu.error) and np.isnan(err)), ctx
 
 
+def _same_outcome(t4a, a, **opts):
+    """Device and oracle either both refuse (NaN in L / U: MatrixCIError::NaNEncountered) or agree bitwise."""
+    try:
+        f, rp, cp, npiv, err = ob.rrlu(a, **opts)
+    except ob.OracleError:
+        with pytest.raises(t4a.T4aError) as e:
+            t4a.rrlu(a, **opts)
+        assert e.value.code == t4a.NAN_ENCOUNTERED
+        return None
+    lu = t4a.rrlu(a, **opts)
+    assert lu.npivots() == npiv
+    assert np.array_equal(lu.row_permutation, rp) and np.array_equal(lu.col_permutation, cp)
+    assert np.array_equal(lu.factored.view(np.uint64), f.view(np.uint64))
+    assert lu.error == err or (np.isnan(lu.error) and np.isnan(err))
+    return lu
+
+
+@pytest.mark.parametrize("left", [True, False])
+def test_rrlu_special_values_on_multi_workgroup_shapes(t4a, left):
+    """Shapes that take the single-XCD kernel (more than 64 x 64 entries, up to 768 x 768) with the values that leave its
+    fast paths: scores that overflow to +inf or underflow to 0 (ties between different |v|: exact sweep on the squares,
+    matrixlu.rs:480-519), subnormal entries, exact zeros, a NaN incumbent on the diagonal, NaN / inf elsewhere, blocks of
+    exact ties — and the pivot divisions that leave the shared-reciprocal fast path (zeros, huge ratios)."""
+    rng = np.random.default_rng(77)
+    kw = dict(left_orthogonal=left)
+    # squares overflow: several distinct huge magnitudes all score +inf; the first in tie order must win
+    a = rng.uniform(-1, 1, size=(90, 130))
+    for (i, j, v) in [(7, 100, 1e200), (60, 3, -3e199), (61, 3, 2e180), (2, 2, 9e170)]:
+        a[i, j] = v
+    _same_outcome(t4a, a, max_bond_dim=12, rel_tol=0.0, abs_tol=0.0, **kw)
+    # squares underflow to 0: every score ties at 0, the diagonal incumbent is kept at every step
+    tiny = rng.uniform(0.5, 1, size=(100, 80)) * 1e-200
+    _same_outcome(t4a, tiny, max_bond_dim=9, rel_tol=0.0, abs_tol=0.0, **kw)
+    _same_outcome(t4a, tiny, **kw)                                     # default tolerances: stops on the first pivot
+    # subnormal entries (the squares are 0, the quotients by the pivot are not)
+    sub = rng.integers(1, 1000, size=(70, 140)).astype(float) * 5e-324 * 1e10
+    _same_outcome(t4a, sub, max_bond_dim=6, rel_tol=0.0, abs_tol=0.0, **kw)
+    # mixed scales in one matrix: quotients far outside 2^+-300 take the full division
+    mixed = rng.uniform(-1, 1, size=(96, 96))
+    mixed[:, ::7] *= 1e-180
+    mixed[::5, :] *= 1e150
+    _same_outcome(t4a, mixed, max_bond_dim=20, rel_tol=0.0, abs_tol=0.0, **kw)
+    # exact zeros: an all-zero matrix, and a low-rank one whose trailing block becomes exactly zero
+    _same_outcome(t4a, np.zeros((100, 100)), **kw)
+    lowrank = np.outer(np.arange(1, 121), np.arange(1, 91)).astype(float)
+    _same_outcome(t4a, lowrank, rel_tol=0.0, abs_tol=0.0, **kw)
+    _same_outcome(t4a, lowrank, **kw)
+    # blocks of exact ties (signed permutation-like matrix)
+    perm = np.zeros((128, 128))
+    perm[np.arange(128), rng.permutation(128)] = rng.choice([-1.0, 1.0], size=128)
+    _same_outcome(t4a, perm, **kw)
+    _same_outcome(t4a, np.kron(perm[:16, :16] + 0.0, np.ones((8, 8))), rel_tol=0.0, abs_tol=0.0, max_bond_dim=40, **kw)
+    # NaN on the first diagonal element (the reference's initial incumbent stays), NaN elsewhere, inf
+    nan0 = rng.uniform(-1, 1, size=(80, 120))
+    nan0[0, 0] = np.nan
+    _same_outcome(t4a, nan0, max_bond_dim=5, **kw)
+    nan1 = rng.uniform(-1, 1, size=(80, 120))
+    nan1[40, 77] = np.nan
+    _same_outcome(t4a, nan1, max_bond_dim=5, **kw)
+    inf1 = rng.uniform(-1, 1, size=(120, 80))
+    inf1[11, 13] = np.inf
+    _same_outcome(t4a, inf1, max_bond_dim=4, **kw)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_tci2_random_option_combinations_match_oracle(t4a, seed):
     """Random option combinations on built-in functions: index sets, error history and termination equal the oracle's."""
