@@ -176,8 +176,8 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     static const bool force_lds = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "lds";
     static const bool force_global = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "global";
     if (want_stamps) {
-        d_stamps_.reserve(16);
-        T4A_HIP(hipMemsetAsync(d_stamps_.get(), 0, 16 * sizeof(unsigned long long), stream_));
+        d_stamps_.reserve(24);
+        T4A_HIP(hipMemsetAsync(d_stamps_.get(), 0, 24 * sizeof(unsigned long long), stream_));
     }
 
     // Fast path: register-resident kernel (left-orthogonal only).  A right-orthogonal factorisation is the
@@ -484,14 +484,14 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         prof.v[1] += 1.0;
     }
     if (want_stamps) {
-        unsigned long long hs[16];
+        unsigned long long hs[24];
         T4A_HIP(hipMemcpy(hs, d_stamps_.get(), sizeof(hs), hipMemcpyDeviceToHost));
         if (use_xcd) {
             const double st = hp[0] > 0 ? (double)hp[0] : 1.0;
             std::fprintf(stderr, "[rrlu stamps xcd] M=%d N=%d W=%d steps=%d cycles/step: pass=%.0f search=%.0f publish=%.0f | prefetch=%.0f keys=%.0f pick=%.0f slow+stop=%.0f recwr=%.0f barB=%.0f | record=%.0f "
-                                 "tables+u=%.0f colwait=%.0f divide=%.0f barC=%.0f lread=%.0f | pollspins=%llu\n",
+                                 "tables+u=%.0f colwait=%.0f divide=%.0f barC=%.0f lread=%.0f | pollspins=%llu | launch (cycles): election=%llu load+init=%llu steps=%llu write-out=%llu\n",
                          M, N, plan_W, hp[0], hs[0] / st, hs[1] / st, hs[2] / st, hs[6] / st, hs[8] / st, hs[14] / st, hs[15] / st, hs[9] / st, hs[3] / st, hs[10] / st, hs[11] / st, hs[12] / st,
-                         hs[4] / st, hs[13] / st, hs[7] / st, hs[5]);
+                         hs[4] / st, hs[13] / st, hs[7] / st, hs[5], hs[16], hs[17], hs[18], hs[19]);
         } else {
             std::fprintf(stderr, "[rrlu stamps %s] M=%d N=%d W=%d T=%d steps=%d | s0=%llu s1=%llu s2=%llu s3=%llu s4=%llu pollspins=%llu colspins=%llu s7=%llu "
                                  "(cycles, wg0/thread0; lds: publish,poll,colfetch,pass,reduce; reg: pass,reduce,publish,poll,fetch)\n",

@@ -143,16 +143,14 @@ __host__ __device__ constexpr int xcd_lstr(int rpt) // doubles per lane in the l
     return ((rpt + 1) / 2) % 2 == 1 ? ((rpt + 1) / 2) * 2 : ((rpt + 1) / 2) * 2 + 2;
 }
 
-__host__ __device__ inline size_t xcd_lds_bytes(int M, int N, int rpt)
-{
-    size_t off = (size_t)64 * xcd_lstr(rpt) * 8; // l buffer
-    off += 16 + 32;                              // winner record: value (+pad), ints
-    off += 64;                                   // phase stamps
-    off += (size_t)((M + 7) & ~7) * 2 + (size_t)((N + 7) & ~7) * 2;
-    return (off + 15) & ~(size_t)15;
-}
-
-// per-phase cycle stamps of rank 0 / thread 0 (T4A_RRLU_STAMPS=1), kept in LDS (diagnostic runs only)
+// per-phase cycle stamps of rank 0 / thread 0 (T4A_RRLU_STAMPS=1), kept in LDS.  Diagnostic builds only
+// (T4A_EXTRA_FLAGS=-DT4A_XCD_STAMPS): the sixteen uniform branches and the live timestamp cost scalar registers and
+// instructions in every step of the production kernel otherwise.
+#ifdef T4A_XCD_STAMPS
+constexpr bool kXcdStamps = true;
+#else
+constexpr bool kXcdStamps = false;
+#endif
 #define XSTAMP(slot)                                                      \
     do {                                                                  \
         if (stamp_on) {                                                   \
@@ -176,6 +174,7 @@ struct XcdSmem {
     unsigned short* posrow;    // position -> row index
     unsigned short* rowpos;    // row index -> position
     unsigned short* poscol;    // position -> column index
+    double* pivots;            // pivot values of this launch (flushed to the result block and its host mirror at the end)
 };
 __host__ __device__ inline size_t xcd_smem_layout(int M, int N, int rpt, XcdSmem* s, char* base)
 {
@@ -192,7 +191,9 @@ __host__ __device__ inline size_t xcd_smem_layout(int M, int N, int rpt, XcdSmem
     const size_t o_pr = take((size_t)M * 2);
     const size_t o_rp = take((size_t)M * 2);
     const size_t o_pc = take((size_t)N * 2);
+    const size_t o_pv = take((size_t)(M < N ? M : N) * 8);
     if (s) {
+        s->pivots = (double*)(base + o_pv);
         s->lbuf = (double*)(base + o_l);
         s->win_d = (double*)(base + o_wd);
         s->win_i = (int*)(base + o_wi);
@@ -229,6 +230,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long t_entry = (kXcdStamps && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- election: only the workgroups that landed on the wanted XCD take part ----
     if (tid == 0) {
@@ -245,6 +247,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     __syncthreads();
     const int rank = __builtin_amdgcn_readfirstlane(win_i[4]);
     if (rank < 0) return;
+    const unsigned long long t_elected = (kXcdStamps && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int NW = p.W * XWAVES;
     const int g = rank * XWAVES + wave; // agent id
     const int M = p.M, N = p.N;
@@ -258,17 +261,25 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     }
     xvec<RPT> a[CPT];
     double local_sqmax = 0.0;
+    // every load is issued before the first one is consumed (clamped addresses instead of branches): the whole matrix is
+    // one round trip to memory per lane, not RPT * CPT dependent ones
 #pragma unroll
     for (int q = 0; q < CPT; ++q)
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            double v = 0.0;
             const int i = lane + 64 * r;
-            if (cpos[q] >= 0 && i < M) {
-                v = p.A[(size_t)(g + NW * q) * M + i];
-                const double sqv = v * v; // max sqrt(v*v) == sqrt(max v*v): one square root per lane below
-                if (sqv > local_sqmax) local_sqmax = sqv;
-            }
+            const bool ok = cpos[q] >= 0 && i < M;
+            a[q][r] = p.A[ok ? (size_t)(g + NW * q) * M + i : (size_t)0];
+        }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = lane + 64 * r;
+            const bool ok = cpos[q] >= 0 && i < M;
+            const double v = ok ? a[q][r] : 0.0;
+            const double sqv = v * v; // max sqrt(v*v) == sqrt(max v*v): one square root per lane below
+            if (sqv > local_sqmax) local_sqmax = sqv; // (NaN never enters, like the branchy form)
             a[q][r] = v;
         }
     for (int i = tid; i < M; i += XT) {
@@ -284,8 +295,9 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     }
     __syncthreads();
 
-    const bool stamp_on = (p.stamps != nullptr) && rank == 0 && tid == 0;
+    const bool stamp_on = kXcdStamps && (p.stamps != nullptr) && rank == 0 && tid == 0;
     unsigned long long stamp_last = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_loop = stamp_last;
 
     const __amdgpu_buffer_rsrc_t keys_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(2u * (unsigned)NW * 16u), 0x00020000);
@@ -710,7 +722,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 }
             }
         }
-        if (rank == 0 && tid == 0) p.pivot_vals[kn] = wval;
+        if (rank == 0 && tid == 64) sm.pivots[kn] = wval;
         XSTAMP(11);
 
         // ---- pivot column -> l = column / pivot, parked in LDS for everybody ----
@@ -804,18 +816,39 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     }
 
     // ---- results ----
+    const unsigned long long t_done = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
     if (npiv >= (M < N ? M : N)) error = 0.0; // matrixlu.rs:811-813
     if (rank == 0 && tid == 0) {
         p.iresult[0] = npiv;
         p.dresult[0] = error; // tid 0 belongs to the polling wave, which keeps the error
     }
-    if (stamp_on)
+    if (stamp_on) {
         for (int e = 0; e < 16; ++e) p.stamps[e] = lds_stamps[e];
+        p.stamps[16] = t_elected - t_entry; // fixed part of a launch: election ...
+        p.stamps[17] = t_loop - t_elected;  // ... matrix load, tables, first maxima ...
+        p.stamps[18] = t_done - t_loop;     // (the pivot steps)
+    }
     if (timed_out) return;
-    __syncthreads();
+    // permutations: the tables are stable since the last barrier; device block and host mirror are written side by side
     if (rank == 0) {
-        for (int i = tid; i < M; i += XT) p.row_perm[i] = posrow[i];
-        for (int j = tid; j < N; j += XT) p.col_perm[j] = poscol[j];
+        int* const h_rp = p.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(p.h_block) + (reinterpret_cast<const char*>(p.row_perm) - reinterpret_cast<const char*>(p.dresult))) : nullptr;
+        int* const h_cp = p.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(p.h_block) + (reinterpret_cast<const char*>(p.col_perm) - reinterpret_cast<const char*>(p.dresult))) : nullptr;
+        for (int i = tid; i < M; i += XT) {
+            const int v = posrow[i];
+            p.row_perm[i] = v;
+            if (h_rp) h_rp[i] = v;
+        }
+        for (int j = tid; j < N; j += XT) {
+            const int v = poscol[j];
+            p.col_perm[j] = v;
+            if (h_cp) h_cp[j] = v;
+        }
+        unsigned long long* const h_pv = p.h_block ? p.h_block + (reinterpret_cast<const char*>(p.pivot_vals) - reinterpret_cast<const char*>(p.dresult)) / 8 : nullptr;
+        for (int e = tid; e < npiv; e += XT) {
+            const double v = sm.pivots[e];
+            p.pivot_vals[e] = v;
+            if (h_pv) h_pv[e] = (unsigned long long)__double_as_longlong(v);
+        }
     }
     // factored matrix in permuted coordinates: rows of U come from the side buffer (this wave wrote them itself), the rest
     // (L below the diagonal, the untouched trailing block) from the registers
@@ -846,22 +879,16 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         atomicExch(&p.iresult[2], 1);
         if (p.h_block) ((volatile int*)p.h_block)[6] = 1;
     }
-    // host-visible mirror of the packed result block (everything but the two flag words, which their setters write)
-    if (p.h_block && rank == 0) {
-        __syncthreads(); // this workgroup's writes to the device block (perms, pivot values, npiv, error) are visible
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p.dresult);
-        for (int e = tid; e < p.block_u64; e += XT) {
-            if (e == 2 || e == 3) continue;
-            p.h_block[e] = (e == 1) ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[e];
-        }
-        if (tid == 0) {
-            ((volatile int*)p.h_block)[4] = npiv;
-            // completion token: the host accepts the result only if rank 0 ran to its end in THIS launch (a launch whose
-            // workgroups never met the elected XCD would otherwise leave an all-zero block behind)
-            ((volatile int*)p.h_block)[7] = (int)p.salt;
-        }
-        __syncthreads();
-        if (tid == 0) reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull; // clean header for the next launch
+    // host-visible header (the pivot values went to the mirror step by step, the two flag words belong to their setters)
+    if (p.h_block && rank == 0 && tid == 0) {
+        p.h_block[0] = (unsigned long long)__double_as_longlong(error);
+        p.h_block[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.dresult) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ((volatile int*)p.h_block)[4] = npiv;
+        // completion token: the host accepts the result only if rank 0 ran to its end in THIS launch (a launch whose
+        // workgroups never met the elected XCD would otherwise leave an all-zero block behind)
+        ((volatile int*)p.h_block)[7] = (int)p.salt;
+        reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull; // clean header for the next launch (every agent's atomicMax is long done)
+        if (stamp_on) p.stamps[19] = __builtin_amdgcn_s_memtime() - t_done; // ... write-out and host mirror
     }
 }
 
