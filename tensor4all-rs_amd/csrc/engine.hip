@@ -219,13 +219,13 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         const size_t need_keys = rrlu_xcd_keys_bytes(xplan) / sizeof(unsigned long long);
         const size_t need_cols = rrlu_xcd_cols_bytes(xplan, kM) / sizeof(unsigned long long);
         ++xcd_salt_;
-        if (need_keys > d_xkeys_.cap || need_cols > d_xcols_.cap || xcd_salt_ > 65535u || !d_xticket_.get()) {
-            // granules carry launch-salted tags: clear the mailboxes whenever they move or the 16-bit salt wraps
-            d_xkeys_.reserve(need_keys);
-            d_xcols_.reserve(need_cols);
+        if (need_keys + need_cols > d_xkeys_.cap || xcd_salt_ > 65535u || !d_xticket_.get()) {
+            // granules carry launch-salted tags: clear the mailbox (keys, then column slots) whenever it moves or the 16-bit
+            // salt wraps.  (Plans differ in where the column slots start; a stale granule of another plan still carries
+            // another launch's salt.)
+            d_xkeys_.reserve(need_keys + need_cols);
             d_xticket_.reserve(4);
             T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), stream_));
-            T4A_HIP(hipMemsetAsync(d_xcols_.get(), 0, d_xcols_.cap * sizeof(unsigned long long), stream_));
             T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), stream_));
             xcd_ticket_base_ = 0;
             xcd_salt_ = 1;
@@ -253,13 +253,9 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.dresult = d_dres;
         a.pivot_vals = d_pivvals;
         a.keys = d_xkeys_.get();
-        a.cols = d_xcols_.get();
         a.salt = xcd_salt_;
-        static const int xpoll = std::getenv("T4A_XCD_POLLDELAY") ? std::atoi(std::getenv("T4A_XCD_POLLDELAY")) : 0;
-        a.poll_delay = xpoll;
         static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.66;
         a.spec_frac = xspec;
-        a.spin_limit = 1u << 20;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
         std::memset(h_out_.get(), 0, 32);
         a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());

@@ -124,7 +124,7 @@ private:
     // single-XCD rrLU kernel: elected XCD, mailboxes, monotonic ticket counter
     int xcc_ = 0;
     unsigned xcd_salt_ = 0, xcd_ticket_base_ = 0;
-    DevBuf<unsigned long long> d_xkeys_, d_xcols_;
+    DevBuf<unsigned long long> d_xkeys_; // mailbox of the single-XCD kernel: keys, then column slots
     DevBuf<unsigned> d_xticket_;
     DevBuf<double> d_xurows_;
     bool header_clean_ = false, keys_clean_ = false;

@@ -174,12 +174,10 @@ struct RrluXcdArgs {
     int* iresult;               // [0] npivots [1] timeout [2] NaN flag
     double* dresult;            // [0] last error [1] bits of max sqrt(v*v)
     double* pivot_vals;
-    unsigned long long* keys;   // [2][8 W] 16-byte keys {value lo, value hi, meta, tag ^ fold}
-    unsigned long long* cols;   // [2][8 W][M] 16-byte rows {lo, hi, 0, tag ^ fold}
+    unsigned long long* keys;   // the mailbox: [2][8 W] 16-byte keys {value lo, value hi, meta, tag ^ fold} followed by
+                                // [2][8 W][64 RPT] 16-byte column rows {lo, hi, 0, tag ^ fold} (rrlu_xcd_keys_bytes + rrlu_xcd_cols_bytes)
     unsigned salt;              // launch-unique 16-bit value (1..65535); tag = salt << 16 | (step + 1)
-    int poll_delay;
     double spec_frac;
-    unsigned spin_limit;
     unsigned long long* stamps; // diagnostic only
     unsigned long long* h_block; // pinned mirror of the packed result block (see RrluRegArgs)
     int block_u64;

@@ -41,7 +41,6 @@ constexpr unsigned XNOPOS = 0xFFFFFFFFu;
 constexpr int XWAVES = T4A_XCD_WAVES; // agents (waves) per workgroup.  Measured: 4 (one wave per SIMD) runs every phase 1.5 - 2x slower — a single wave issues one f64 instruction per 8 cycles, two waves per SIMD reach the 4-cycle rate
 constexpr int XT = 64 * XWAVES;       // threads per workgroup
 constexpr int XCD_MAX_CPT = 4;       // (the key carries the column slot in two bits)
-constexpr int XROWS = (1024 + XT - 1) / XT; // pivot-column rows handled per thread in the division stage (M <= 1024)
 constexpr int XCD_MAX_VALUES = XWAVES == 4 ? 80 : 40; // matrix entries per thread: beyond this the register file of a 512-thread workgroup spills
 constexpr int BUF_SC1 = 16;  // aux bits of the raw buffer loads: sc1 (L1 bypass, served by the XCD's L2)
 
@@ -165,44 +164,34 @@ __device__ __forceinline__ double uniform_f64(double v) // a wave-uniform value 
     return mk_f64((unsigned)__builtin_amdgcn_readfirstlane((int)lo32(v)), (unsigned)__builtin_amdgcn_readfirstlane((int)hi32(v)));
 }
 
-// LDS layout of one workgroup
-struct XcdSmem {
-    double* lbuf;              // [64][LSTR]: l of row lane + 64 r at lane * LSTR + r (rows beyond M stay 0)
-    double* win_d;             // 16-byte relay slot: the polling wave hands its key to wave 1, which stores it for it
-    int* win_i;                // [0,1] winner value bits [2] meta [3] agent | rk << 8 | ck << 18 | stop << 28 [4] rank [5] abort [6] next diagonal element: row | column << 10
-    unsigned long long* stamps;
-    unsigned short* posrow;    // position -> row index
-    unsigned short* rowpos;    // row index -> position
-    unsigned short* poscol;    // position -> column index
-    double* pivots;            // pivot values of this launch (flushed to the result block and its host mirror at the end)
+// LDS layout of one workgroup: every offset is a compile-time constant (tables sized for the largest matrix of the plan
+// family), so no address of it lives in a scalar register across the step loop
+template <int RPT> struct XcdLds {
+    static constexpr int LSTR = xcd_lstr(RPT);
+    static constexpr int o_l = 0;                        // double [64][LSTR]: l of row lane + 64 r at lane * LSTR + r
+    static constexpr int o_wd = o_l + 64 * LSTR * 8;     // 16-byte relay slot: the polling wave hands its key to wave 1
+    static constexpr int o_wi = o_wd + 16;               // int [16]: [0,1] winner value bits [2] meta [3] agent | rk << 8 | ck << 18 | stop << 28 [4] rank [5] abort [6] next diagonal element: row | column << 10
+    static constexpr int o_pp = o_wi + 64;               // u64 [2]: iresult / h_block pointers for the give-up paths
+    static constexpr int o_st = o_pp + 16;               // u64 [16] phase stamps (diagnostic builds)
+    static constexpr int o_pv = o_st + 128;              // double [1024] pivot values of this launch
+    static constexpr int o_pr = o_pv + 1024 * 8;         // u16 [1024] position -> row index
+    static constexpr int o_rp = o_pr + 1024 * 2;         // u16 [1024] row index -> position
+    static constexpr int o_pc = o_rp + 1024 * 2;         // u16 [1024] position -> column index
+    static constexpr int bytes = o_pc + 1024 * 2;
 };
-__host__ __device__ inline size_t xcd_smem_layout(int M, int N, int rpt, XcdSmem* s, char* base)
+constexpr size_t xcd_lds_total(int rpt) { return (size_t)64 * xcd_lstr(rpt) * 8 + 16 + 64 + 16 + 128 + 1024 * 8 + 3 * 1024 * 2; }
+
+// a value the optimiser must treat as unknown: keeps loop-invariant masks / addresses of RARE paths from being hoisted out of
+// the step loop into scalar registers (the kernel is bound by its scalar register file: every hoisted lane mask is a pair)
+__device__ __forceinline__ int opaque_s(int v)
 {
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        const size_t o = off;
-        off = (off + bytes + 15) & ~(size_t)15;
-        return o;
-    };
-    const size_t o_l = take((size_t)64 * xcd_lstr(rpt) * 8);
-    const size_t o_wd = take(16);
-    const size_t o_wi = take(16 * 4);
-    const size_t o_st = take(16 * 8);
-    const size_t o_pr = take((size_t)M * 2);
-    const size_t o_rp = take((size_t)M * 2);
-    const size_t o_pc = take((size_t)N * 2);
-    const size_t o_pv = take((size_t)(M < N ? M : N) * 8);
-    if (s) {
-        s->pivots = (double*)(base + o_pv);
-        s->lbuf = (double*)(base + o_l);
-        s->win_d = (double*)(base + o_wd);
-        s->win_i = (int*)(base + o_wi);
-        s->stamps = (unsigned long long*)(base + o_st);
-        s->posrow = (unsigned short*)(base + o_pr);
-        s->rowpos = (unsigned short*)(base + o_rp);
-        s->poscol = (unsigned short*)(base + o_pc);
-    }
-    return off;
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ int opaque_v(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
 template <int N> using xvec = double __attribute__((ext_vector_type(N)));
@@ -215,17 +204,19 @@ template <int RPT, int CPT, bool ROWMAJOR>
 __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd_kernel(RrluXcdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int LSTR = xcd_lstr(RPT);
-    XcdSmem sm;
-    xcd_smem_layout(p.M, p.N, RPT, &sm, smem_raw);
-    double* const lbuf = sm.lbuf;
-    double* const win_d = sm.win_d;
+    using L = XcdLds<RPT>;
+    constexpr int LSTR = L::LSTR;
+    constexpr int MP = 64 * RPT; // rows of a published column slot (rows beyond M carry zeros)
+    double* const lbuf = reinterpret_cast<double*>(smem_raw + L::o_l);
+    double* const win_d = reinterpret_cast<double*>(smem_raw + L::o_wd);
     if (threadIdx.x == 0) { win_d[0] = 0.0; win_d[1] = 0.0; }
-    int* const win_i = sm.win_i;
-    unsigned long long* const lds_stamps = sm.stamps;
-    unsigned short* const posrow = sm.posrow;
-    unsigned short* const rowpos = sm.rowpos;
-    unsigned short* const poscol = sm.poscol;
+    int* const win_i = reinterpret_cast<int*>(smem_raw + L::o_wi);
+    unsigned long long* const lds_ptrs = reinterpret_cast<unsigned long long*>(smem_raw + L::o_pp);
+    unsigned long long* const lds_stamps = reinterpret_cast<unsigned long long*>(smem_raw + L::o_st);
+    double* const lds_pivots = reinterpret_cast<double*>(smem_raw + L::o_pv);
+    unsigned short* const posrow = reinterpret_cast<unsigned short*>(smem_raw + L::o_pr);
+    unsigned short* const rowpos = reinterpret_cast<unsigned short*>(smem_raw + L::o_rp);
+    unsigned short* const poscol = reinterpret_cast<unsigned short*>(smem_raw + L::o_pc);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -242,6 +233,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         win_i[4] = rank;
         win_i[5] = 0;
         win_i[6] = 0; // the first diagonal element is (row 0, column 0)
+        lds_ptrs[0] = (unsigned long long)p.iresult;
+        lds_ptrs[1] = (unsigned long long)p.h_block;
         for (int e = 0; e < 16; ++e) lds_stamps[e] = 0ull;
     }
     __syncthreads();
@@ -299,10 +292,10 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     unsigned long long stamp_last = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long t_loop = stamp_last;
 
-    const __amdgpu_buffer_rsrc_t keys_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(2u * (unsigned)NW * 16u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t cols_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.cols, 0, (int)(2u * (unsigned)NW * (unsigned)M * 16u), 0x00020000);
+    // one mailbox: [2][NW] keys, then [2][NW][MP] column rows (one buffer resource for every store and load of the exchange)
+    const unsigned cols_base = 2u * (unsigned)NW * 16u;
+    const __amdgpu_buffer_rsrc_t mail =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(cols_base + 2u * (unsigned)NW * (unsigned)MP * 16u), 0x00020000);
 
     int npiv = 0;
     int nan_seen = 0;
@@ -316,6 +309,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     double prev_sq = __builtin_huge_val(); // nobody speculates on the first step
     const double spec_frac = p.spec_frac;
     const int kpl = (NW + 63) >> 6;
+    constexpr unsigned XSPIN = 1u << 20; // bounded spins: a hand-off that does not arrive makes the launch give up
 
     // maxima of the untouched matrix for the first arg-max
     double mq[CPT];
@@ -405,18 +399,19 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 unsigned mypos = XNOPOS;
                 double myval = 0.0;
                 int myrow = 0, myq = 0;
+                const int lane_o = opaque_v(lane), M_o = opaque_s(M); // (nothing of this rare path is hoisted out of the step loop)
 #pragma unroll
                 for (int q = 0; q < CPT; ++q) {
                     const bool qhit = (mq[q] >= 0.0) & (mq[q] * mq[q] == sq);
                     if (__ballot(qhit) != 0ull) {
 #pragma unroll
                         for (int r = 0; r < RPT; ++r) {
-                            const int i = lane + 64 * r;
-                            const unsigned rp_ = rowpos[i < M ? i : 0];
+                            const int i = lane_o + 64 * r;
+                            const unsigned rp_ = rowpos[i < M_o ? i : 0];
                             const unsigned key = ROWMAJOR ? ((rp_ << 10) | (unsigned)cps[q]) : (((unsigned)cps[q] << 10) | rp_);
                             const double av = a[q][r];
                             const double sc = av * av;
-                            const bool hit = qhit & (i < M) & ((int)rp_ > k) &
+                            const bool hit = qhit & (i < M_o) & ((int)rp_ > k) &
                                              ((sc == sq) | ((key == diagkey) & (sc != sc) & (sq == __builtin_huge_val())));
                             if (hit && key < mypos) {
                                 mypos = key;
@@ -449,52 +444,51 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             kv.y = hi32(cval);
             kv.z = meta;
             kv.w = tag ^ kv.x ^ kv.y ^ meta;
+            const int kslot = (par * NW + g) * 16;
             if (wave == 0) {
                 if (lane == 0) *reinterpret_cast<u32x4*>(win_d) = kv;
             } else {
-                if (lane == 0) reinterpret_cast<u32x4*>(p.keys)[(size_t)par * NW + g] = kv;
+                if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0);
                 if (wave == 1) {
                     u32x4 k0;
                     unsigned spins = 0;
                     for (;;) {
                         k0 = *reinterpret_cast<volatile u32x4*>(win_d);
                         if ((k0.x ^ k0.y ^ k0.z ^ k0.w) == tag) break;
-                        if (++spins > p.spin_limit) break; // (the pollers give up on the missing key)
+                        if (++spins > XSPIN) break; // (the pollers give up on the missing key)
                     }
-                    if (lane == 0) reinterpret_cast<u32x4*>(p.keys)[(size_t)par * NW + g - 1] = k0;
+                    if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(k0, mail, kslot - 16, 0, 0);
                 }
             }
         }
         // the polling wave starts its first sweep of the key table before it publishes its column
+        // (lanes beyond NW re-read the last key: a valid duplicate, so neither the arrival check nor the maximum needs a mask)
         u32x4 kg[4];
         if (wave == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int ag = lane + 64 * j;
-                if (j < kpl) kg[j] = __builtin_amdgcn_raw_buffer_load_b128(keys_rsrc, (par * NW + (ag < NW ? ag : 0)) * 16, 0, BUF_SC1);
+                const int ag = min(lane + 64 * j, NW - 1);
+                if (j < kpl) kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + ag) * 16, 0, BUF_SC1);
             }
         }
         // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
         // keys have been gathered
         const bool early_pub = (wave != 0) && (wpos != XKEY_NONE) && (sq >= spec_frac * prev_sq); // (the polling wave never stores early)
-        u32x4* const myslot = reinterpret_cast<u32x4*>(p.cols) + ((size_t)par * NW + g) * (size_t)M;
+        const int myslot = (int)cols_base + ((par * NW + g) * MP + lane) * 16; // byte offset of my row `lane` in the mailbox
         if (early_pub) {
 #pragma unroll
             for (int q = 0; q < CPT; ++q)
                 if (q == qstar) {
 #pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        const int i = lane + 64 * r;
-                        if (i < M) {
-                            const double av = a[q][r];
-                            u32x4 gv;
-                            gv.x = lo32(av);
-                            gv.y = hi32(av);
-                            gv.z = 0u;
-                            gv.w = tag ^ gv.x ^ gv.y;
-                            myslot[i] = gv;
-                        }
+                    for (int r = 0; r < RPT; ++r) { // (rows beyond M hold zeros: every slot row is written, no row mask)
+                        const double av = a[q][r];
+                        u32x4 gv;
+                        gv.x = lo32(av);
+                        gv.y = hi32(av);
+                        gv.z = 0u;
+                        gv.w = tag ^ gv.x ^ gv.y;
+                        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * 1024, 0, 0);
                     }
                 }
         }
@@ -505,26 +499,23 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             // who sits at position kn and kn + 1 now (tables are stable between barrier (C) and the next (B))
             const int rk_ = posrow[kn], ck_ = poscol[kn];
             const int rn_ = (kn + 1 < M) ? (int)posrow[kn + 1] : 0, cn_ = (kn + 1 < N) ? (int)poscol[kn + 1] : 0;
-            for (int d = 0; d < p.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             unsigned spins = 0;
             bool giveup = false;
             XSTAMP(6);
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ag = lane + 64 * j;
-                    if (j < kpl) ok &= (ag >= NW) | ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (j < kpl) ok &= ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
                 if (__all(ok)) break;
-                if (++spins > p.spin_limit) {
+                if (++spins > XSPIN) {
                     giveup = true;
                     break;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int ag = lane + 64 * j;
-                    if (j < kpl) kg[j] = __builtin_amdgcn_raw_buffer_load_b128(keys_rsrc, (par * NW + (ag < NW ? ag : 0)) * 16, 0, BUF_SC1);
+                    const int ag = min(lane + 64 * j, NW - 1);
+                    if (j < kpl) kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + ag) * 16, 0, BUF_SC1);
                 }
             }
             if (stamp_on) lds_stamps[5] += spins;
@@ -532,8 +523,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             if (giveup) {
                 if (lane == 0) {
                     win_i[5] = 1;
-                    atomicExch(&p.iresult[1], 1);
-                    if (p.h_block) ((volatile int*)p.h_block)[5] = 1;
+                    atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
+                    if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
                 }
             } else {
                 // winner over all keys.  Normal case: v*v of the largest |v| is a normal number (distinct |v| <=> distinct
@@ -550,7 +541,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                         if (j < kpl) {
                             const double v = mk_f64(kg[j].x, kg[j].y);
                             anynan |= (v != v);
-                            lm = vmax_abs(lm, v); // (lanes beyond NW re-read key 0: harmless duplicates)
+                            lm = vmax_abs(lm, v); // (duplicates of the last key: harmless for the maximum; if that key wins, the count below is not 1 and the exact path decides)
                         }
                     }
                     const double gm = wave_max_f64(lm);
@@ -562,7 +553,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                         for (int j = 0; j < 4; ++j) {
                             hb[j] = 0ull;
                             if (j < kpl) {
-                                hb[j] = __ballot((lane + 64 * j < NW) & (__builtin_fabs(mk_f64(kg[j].x, kg[j].y)) == gm));
+                                hb[j] = __ballot(__builtin_fabs(mk_f64(kg[j].x, kg[j].y)) == gm);
                                 nh += __builtin_popcountll(hb[j]);
                             }
                         }
@@ -587,10 +578,11 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     double csc = -1.0, cv = 0.0;
                     unsigned cpk = XNOPOS, cmeta = 0u;
                     int cag = 0;
+                    const int lane_o = opaque_v(lane);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (j < kpl) {
-                            const int ag = lane + 64 * j;
+                            const int ag = lane_o + 64 * j;
                             const unsigned pk = (ag < NW) ? (kg[j].z & 0xFFFFFu) : XNOPOS;
                             const double v = mk_f64(kg[j].x, kg[j].y);
                             double sc = v * v;
@@ -664,28 +656,24 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 if (q == qstar) {
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) {
-                        const int i = lane + 64 * r;
-                        if (i < M) {
-                            const double av = a[q][r];
-                            u32x4 gv;
-                            gv.x = lo32(av);
-                            gv.y = hi32(av);
-                            gv.z = 0u;
-                            gv.w = tag ^ gv.x ^ gv.y;
-                            myslot[i] = gv;
-                        }
+                        const double av = a[q][r];
+                        u32x4 gv;
+                        gv.x = lo32(av);
+                        gv.y = hi32(av);
+                        gv.z = 0u;
+                        gv.w = tag ^ gv.x ^ gv.y;
+                        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * 1024, 0, 0);
                     }
                 }
         }
         // every thread fetches its rows (tid, tid + XT, ...) of the winner's column
-        const unsigned slot_off = (unsigned)(par * NW + wag) * (unsigned)M;
-        u32x4 cc[XROWS];
+        // thread tid fetches slot rows tid + XT j = lane + 64 (wave + XWAVES j): valid while wave + XWAVES j < RPT (wave-uniform)
+        constexpr int XR = (RPT + XWAVES - 1) / XWAVES;
+        const int slot_off = (int)cols_base + ((par * NW + wag) * MP + tid) * 16;
+        u32x4 cc[XR];
 #pragma unroll
-        for (int j = 0; j < XROWS; ++j) {
-            cc[j].x = cc[j].y = cc[j].z = cc[j].w = 0u;
-            const int i = tid + XT * j;
-            if (i < M) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i) * 16u), 0, BUF_SC1);
-        }
+        for (int j = 0; j < XR; ++j)
+            if (wave + XWAVES * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * XT * 16, 0, BUF_SC1);
         XSTAMP(10);
 
         // ---- while the column travels: permutation tables, pivot row ----
@@ -722,7 +710,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 }
             }
         }
-        if (rank == 0 && tid == 64) sm.pivots[kn] = wval;
+        if (rank == 0 && tid == 64) lds_pivots[kn] = wval;
         XSTAMP(11);
 
         // ---- pivot column -> l = column / pivot, parked in LDS for everybody ----
@@ -731,50 +719,50 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < XROWS; ++j)
-                    if (tid + XT * j < M) ok &= ((cc[j].x ^ cc[j].y ^ cc[j].z ^ cc[j].w) == tag);
+                for (int j = 0; j < XR; ++j)
+                    if (wave + XWAVES * j < RPT) ok &= ((cc[j].x ^ cc[j].y ^ cc[j].z ^ cc[j].w) == tag);
                 if (__all(ok)) break;
-                if (++spins > p.spin_limit) {
-                    atomicExch(&p.iresult[1], 1);
-                    if (p.h_block) ((volatile int*)p.h_block)[5] = 1;
+                if (++spins > XSPIN) {
+                    atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
+                    if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
                     win_i[5] = 1; // observed by everybody after the next barrier
                     break;
                 }
 #pragma unroll
-                for (int j = 0; j < XROWS; ++j) {
-                    const int i = tid + XT * j;
-                    if (i < M) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(cols_rsrc, (int)((slot_off + (unsigned)i) * 16u), 0, BUF_SC1);
-                }
+                for (int j = 0; j < XR; ++j)
+                    if (wave + XWAVES * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * XT * 16, 0, BUF_SC1);
             }
             XSTAMP(12);
             // x / p through the shared refined reciprocal (bitwise the IEEE quotient, see refined_rcp); zeros keep the sign
             // rule through x * rp; anything unusual takes the full division
             const bool p_mid = exp_mid(wval);
             const double rp = refined_rcp(wval);
-            double lq[XROWS];
+            double lq[XR];
             bool slow = false;
 #pragma unroll
-            for (int j = 0; j < XROWS; ++j) {
-                const double x = mk_f64(cc[j].x, cc[j].y);
-                const double q0 = x * rp;
-                const double qf = __builtin_fma(__builtin_fma(-wval, q0, x), rp, q0);
-                lq[j] = (x == 0.0) ? q0 : qf;
-                slow |= !(p_mid & (exp_mid(x) | (x == 0.0)));
+            for (int j = 0; j < XR; ++j) {
+                lq[j] = 0.0;
+                if (wave + XWAVES * j < RPT) {
+                    const double x = mk_f64(cc[j].x, cc[j].y);
+                    const double q0 = x * rp;
+                    const double qf = __builtin_fma(__builtin_fma(-wval, q0, x), rp, q0);
+                    lq[j] = (x == 0.0) ? q0 : qf;
+                    slow |= !(p_mid & (exp_mid(x) | (x == 0.0)));
+                }
             }
             if (__ballot(slow) != 0ull) {
 #pragma unroll
-                for (int j = 0; j < XROWS; ++j) {
-                    const double x = mk_f64(cc[j].x, cc[j].y);
-                    if (!(p_mid & (exp_mid(x) | (x == 0.0)))) lq[j] = x / wval;
-                }
+                for (int j = 0; j < XR; ++j)
+                    if (wave + XWAVES * j < RPT) {
+                        const double x = mk_f64(cc[j].x, cc[j].y);
+                        if (!(p_mid & (exp_mid(x) | (x == 0.0)))) lq[j] = x / wval;
+                    }
             }
             // (the pivot row itself leaves the trailing block: its l is 0 like that of every row pivoted before, whose
-            // emptied slots already read 0 in the published column)
+            // emptied slots already read 0 in the published column; slot rows beyond M are zeros divided by the pivot)
 #pragma unroll
-            for (int j = 0; j < XROWS; ++j) {
-                const int i = tid + XT * j;
-                if (i < M) lbuf[(i & 63) * LSTR + (i >> 6)] = (i == irow_p) ? 0.0 : lq[j];
-            }
+            for (int j = 0; j < XR; ++j)
+                if (wave + XWAVES * j < RPT) lbuf[lane * LSTR + wave + XWAVES * j] = (tid + XT * j == irow_p) ? 0.0 : lq[j];
         }
         XSTAMP(4);
         __syncthreads(); // (C)
@@ -845,7 +833,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         }
         unsigned long long* const h_pv = p.h_block ? p.h_block + (reinterpret_cast<const char*>(p.pivot_vals) - reinterpret_cast<const char*>(p.dresult)) / 8 : nullptr;
         for (int e = tid; e < npiv; e += XT) {
-            const double v = sm.pivots[e];
+            const double v = lds_pivots[e];
             p.pivot_vals[e] = v;
             if (h_pv) h_pv[e] = (unsigned long long)__double_as_longlong(v);
         }
@@ -980,14 +968,14 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out)
     plan.RPT = rpt;
     plan.CPT = best_cpt;
     plan.grid = 8 * best_w;
-    plan.lds_bytes = xcd_smem_layout(M, N, rpt, nullptr, nullptr);
+    plan.lds_bytes = xcd_lds_total(rpt);
     if (plan.lds_bytes < 84 * 1024) plan.lds_bytes = 84 * 1024; // one workgroup per compute unit
     *out = plan;
     return true;
 }
 
 size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan) { return (size_t)2 * plan.W * XWAVES * 16; }
-size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int M) { return (size_t)2 * plan.W * XWAVES * (size_t)M * 16; }
+size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int) { return (size_t)2 * plan.W * XWAVES * (size_t)(64 * plan.RPT) * 16; } // slots are padded to 64 * RPT rows
 
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
 {
