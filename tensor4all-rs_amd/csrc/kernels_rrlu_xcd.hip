@@ -129,12 +129,12 @@ __device__ __forceinline__ double refined_rcp(double p)
 __device__ __forceinline__ bool exp_mid(double v) { return (((hi32(v) >> 20) & 0x7FFu) - 723u) <= 600u; }
 __device__ __forceinline__ double xcd_div(double x, double p, double rp, bool p_mid)
 {
-    if (p_mid && exp_mid(x)) {
+    if (p_mid && (exp_mid(x) || x == 0.0)) {
         const double q0 = x * rp;
         const double res = __builtin_fma(-p, q0, x);
-        return __builtin_fma(res, rp, q0);
+        return (x == 0.0) ? q0 : __builtin_fma(res, rp, q0);
     }
-    return x / p; // zeros, denormals, huge ratios, non-finite values: the full IEEE sequence
+    return x / p; // denormals, huge ratios, non-finite values: the full IEEE sequence
 }
 
 __host__ __device__ constexpr int xcd_lstr(int rpt) // doubles per lane in the l buffer: even, and odd in units of 16 bytes
@@ -194,11 +194,37 @@ __device__ __forceinline__ int opaque_v(int v)
     return v;
 }
 
-template <int N> using xvec = double __attribute__((ext_vector_type(N)));
 
 // key meta word: bits 0..19 position key (10 + 10 bits, tie order), 20..29 row index of the candidate, 30..31 column slot
 // of the publishing agent.  An agent without a candidate publishes value 0 with the largest position key.
 constexpr unsigned XKEY_NONE = 0xFFFFFu;
+
+// The rank-1 update must run IN PLACE: written as plain C++ the register allocator gives every updated entry a new register
+// and moves the whole block back at the loop's back edge (dozens of v_mov_b64 per step).  Tied operands leave it no choice.
+__device__ __forceinline__ void sub_in_place(double& a, double prod) // a = a - prod (one rounding, like the reference's un-fused update)
+{
+    asm("v_add_f64 %0, %0, -%1" : "+v"(a) : "v"(prod));
+}
+template <int N> using xvec = double __attribute__((ext_vector_type(N)));
+
+// Publication of one owned column: 16-byte granules {lo, hi, 0, tag ^ lo ^ hi}, one per slot row (rows beyond M hold zeros:
+// every slot row is written, no row mask).  One instance per column slot (the marker keeps the instances apart: merged, the
+// compiler would first copy the selected column into a common block of registers).
+template <int Q, int RPT>
+__device__ __forceinline__ void xcd_publish_column(const xvec<RPT>& col, __amdgpu_buffer_rsrc_t mail, int myslot, unsigned tag)
+{
+    asm volatile("; column slot %0" ::"n"(Q));
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const double av = col[r];
+        u32x4 gv;
+        gv.x = lo32(av);
+        gv.y = hi32(av);
+        gv.z = 0u;
+        gv.w = tag ^ gv.x ^ gv.y;
+        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * 1024, 0, 0);
+    }
+}
 
 template <int RPT, int CPT, bool ROWMAJOR>
 __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd_kernel(RrluXcdArgs p)
@@ -252,7 +278,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         const int c = g + NW * q;
         cpos[q] = c < N ? c : -1;
     }
-    xvec<RPT> a[CPT];
+    xvec<RPT> a[CPT]; // ext vectors: the two run-time row-slot accesses become s_set_gpr_idx moves
     double local_sqmax = 0.0;
     // every load is issued before the first one is consumed (clamped addresses instead of branches): the whole matrix is
     // one round trip to memory per lane, not RPT * CPT dependent ones
@@ -308,8 +334,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     for (int q = 0; q < CPT; ++q) u[q] = 0.0;
     double prev_sq = __builtin_huge_val(); // nobody speculates on the first step
     const double spec_frac = p.spec_frac;
-    const int kpl = (NW + 63) >> 6;
     constexpr unsigned XSPIN = 1u << 20; // bounded spins: a hand-off that does not arrive makes the launch give up
+    int dpk = 0; // next diagonal element: row | column << 10 (worked out by the polling wave one step ahead)
 
     // maxima of the untouched matrix for the first arg-max
     double mq[CPT];
@@ -335,10 +361,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         int cps[CPT]; // column positions as scalars
 #pragma unroll
         for (int q = 0; q < CPT; ++q) cps[q] = __builtin_amdgcn_readfirstlane(cpos[q]);
-        // a NaN sitting on the next diagonal element wins outright (it is the reference's initial incumbent): the
-        // diagonal element (win_i[6]) is worked out by the polling wave one step ahead
+        // a NaN sitting on the next diagonal element wins outright (it is the reference's initial incumbent)
         {
-            const int dpk = __builtin_amdgcn_readfirstlane(win_i[6]);
             const int dr = dpk & 1023, dc = dpk >> 10;
 #pragma unroll
             for (int q = 0; q < CPT; ++q)
@@ -373,17 +397,13 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     for (int q = 0; q < CPT; ++q)
                         if (bq[q] != 0ull) {
                             const int hl = (int)__builtin_ctzll(bq[q]);
-                            // which row slot of that lane: per-lane index / count of the slots equal to the maximum
-                            int ridx = 0, rcnt = 0;
+                            // which row slot of that lane: bit RPT - 1 - r of `bits` says slot r holds the maximum
+                            unsigned bits = 0u;
 #pragma unroll
-                            for (int r = 0; r < RPT; ++r) {
-                                const bool h = (__builtin_fabs(a[q][r]) == wmax);
-                                ridx = h ? r : ridx;
-                                rcnt += h ? 1 : 0;
-                            }
-                            const int rstar = __builtin_amdgcn_readlane(ridx, hl);
-                            const int cnt = __builtin_amdgcn_readlane(rcnt, hl);
-                            if (cnt == 1) {
+                            for (int r = 0; r < RPT; ++r) bits = bits + bits + ((__builtin_fabs(a[q][r]) == wmax) ? 1u : 0u);
+                            const unsigned hb_ = (unsigned)__builtin_amdgcn_readlane((int)bits, hl);
+                            if (__builtin_popcount(hb_) == 1) {
+                                const int rstar = RPT - 1 - (int)__builtin_ctz(hb_);
                                 cirow = hl + 64 * rstar;
                                 const unsigned rp_ = (unsigned)__builtin_amdgcn_readfirstlane((int)rowpos[cirow]);
                                 wpos = ROWMAJOR ? ((rp_ << 10) | (unsigned)cps[q]) : (((unsigned)cps[q] << 10) | rp_);
@@ -453,7 +473,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     u32x4 k0;
                     unsigned spins = 0;
                     for (;;) {
-                        k0 = *reinterpret_cast<volatile u32x4*>(win_d);
+                        asm volatile("" ::: "memory"); // (a plain LDS read per turn; a volatile access would go through the flat path)
+                        k0 = *reinterpret_cast<const u32x4*>(win_d);
                         if ((k0.x ^ k0.y ^ k0.z ^ k0.w) == tag) break;
                         if (++spins > XSPIN) break; // (the pollers give up on the missing key)
                     }
@@ -461,15 +482,14 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 }
             }
         }
-        // the polling wave starts its first sweep of the key table before it publishes its column
-        // (lanes beyond NW re-read the last key: a valid duplicate, so neither the arrival check nor the maximum needs a mask)
+        // the polling wave starts its first sweep of the key table before it publishes its column.  Every lane fetches four
+        // keys; lanes beyond NW re-read the last key (a valid duplicate), so neither the arrival check nor the maximum needs
+        // a mask or a count of live groups
         u32x4 kg[4];
         if (wave == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ag = min(lane + 64 * j, NW - 1);
-                if (j < kpl) kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + ag) * 16, 0, BUF_SC1);
-            }
+            for (int j = 0; j < 4; ++j)
+                kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
         }
         // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
@@ -477,20 +497,10 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         const bool early_pub = (wave != 0) && (wpos != XKEY_NONE) && (sq >= spec_frac * prev_sq); // (the polling wave never stores early)
         const int myslot = (int)cols_base + ((par * NW + g) * MP + lane) * 16; // byte offset of my row `lane` in the mailbox
         if (early_pub) {
-#pragma unroll
-            for (int q = 0; q < CPT; ++q)
-                if (q == qstar) {
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) { // (rows beyond M hold zeros: every slot row is written, no row mask)
-                        const double av = a[q][r];
-                        u32x4 gv;
-                        gv.x = lo32(av);
-                        gv.y = hi32(av);
-                        gv.z = 0u;
-                        gv.w = tag ^ gv.x ^ gv.y;
-                        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * 1024, 0, 0);
-                    }
-                }
+            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag);
+            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag);
+            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag);
+            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag);
         }
         XSTAMP(2);
 
@@ -505,18 +515,15 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < kpl) ok &= ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
+                for (int j = 0; j < 4; ++j) ok &= ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
                 if (__all(ok)) break;
                 if (++spins > XSPIN) {
                     giveup = true;
                     break;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ag = min(lane + 64 * j, NW - 1);
-                    if (j < kpl) kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + ag) * 16, 0, BUF_SC1);
-                }
+                for (int j = 0; j < 4; ++j)
+                    kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
             }
             if (stamp_on) lds_stamps[5] += spins;
             XSTAMP(8);
@@ -528,7 +535,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 }
             } else {
                 // winner over all keys.  Normal case: v*v of the largest |v| is a normal number (distinct |v| <=> distinct
-                // scores), no key is a NaN and exactly one key holds the largest |v|: one maximum reduction decides.
+                // scores), no key is a NaN and exactly one key holds the largest |v|: one maximum reduction decides.  (A
+                // duplicate of the last key can only push the count above one: then the exact path decides.)
                 double wv = 0.0;
                 unsigned wm_ = 0u;
                 int wa_ = 0;
@@ -538,11 +546,9 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     bool anynan = false;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (j < kpl) {
-                            const double v = mk_f64(kg[j].x, kg[j].y);
-                            anynan |= (v != v);
-                            lm = vmax_abs(lm, v); // (duplicates of the last key: harmless for the maximum; if that key wins, the count below is not 1 and the exact path decides)
-                        }
+                        const double v = mk_f64(kg[j].x, kg[j].y);
+                        anynan |= (v != v);
+                        lm = vmax_abs(lm, v);
                     }
                     const double gm = wave_max_f64(lm);
                     const double gsq = gm * gm;
@@ -551,11 +557,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                         int nh = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            hb[j] = 0ull;
-                            if (j < kpl) {
-                                hb[j] = __ballot(__builtin_fabs(mk_f64(kg[j].x, kg[j].y)) == gm);
-                                nh += __builtin_popcountll(hb[j]);
-                            }
+                            hb[j] = __ballot(__builtin_fabs(mk_f64(kg[j].x, kg[j].y)) == gm);
+                            nh += __builtin_popcountll(hb[j]);
                         }
                         if (nh == 1) {
 #pragma unroll
@@ -581,20 +584,18 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     const int lane_o = opaque_v(lane);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (j < kpl) {
-                            const int ag = lane_o + 64 * j;
-                            const unsigned pk = (ag < NW) ? (kg[j].z & 0xFFFFFu) : XNOPOS;
-                            const double v = mk_f64(kg[j].x, kg[j].y);
-                            double sc = v * v;
-                            sc = (sc != sc) ? __builtin_huge_val() : sc;
-                            sc = (ag < NW) ? sc : -2.0;
-                            const bool better = (sc > csc) | ((sc == csc) & (pk < cpk));
-                            csc = better ? sc : csc;
-                            cv = better ? v : cv;
-                            cpk = better ? pk : cpk;
-                            cmeta = better ? kg[j].z : cmeta;
-                            cag = better ? ag : cag;
-                        }
+                        const int ag = lane_o + 64 * j;
+                        const unsigned pk = (ag < NW) ? (kg[j].z & 0xFFFFFu) : XNOPOS;
+                        const double v = mk_f64(kg[j].x, kg[j].y);
+                        double sc = v * v;
+                        sc = (sc != sc) ? __builtin_huge_val() : sc;
+                        sc = (ag < NW) ? sc : -2.0;
+                        const bool better = (sc > csc) | ((sc == csc) & (pk < cpk));
+                        csc = better ? sc : csc;
+                        cv = better ? v : cv;
+                        cpk = better ? pk : cpk;
+                        cmeta = better ? kg[j].z : cmeta;
+                        cag = better ? ag : cag;
                     }
                     const double gmax = wave_max_f64(csc);
                     const unsigned gpos = wave_min_u32((csc == gmax) ? cpk : XNOPOS);
@@ -605,9 +606,10 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     wa_ = __builtin_amdgcn_readlane(cag, wl);
                 }
                 // stop tests on the pivot magnitude sqrt(v*v), in the reference's order; while v*v is a normal number the
-                // square root of the rounded square is |v| itself
+                // square root of the rounded square is |v| itself (the software square root stays on the cold path)
                 const double wsq = wv * wv;
-                const double pivot_abs = (wsq >= 2.2250738585072014e-308 && wsq < __builtin_huge_val()) ? __builtin_fabs(wv) : sqrt(wsq);
+                double pivot_abs = __builtin_fabs(wv);
+                if (!(wsq >= 2.2250738585072014e-308 && wsq < __builtin_huge_val())) pivot_abs = sqrt(mk_f64((unsigned)opaque_v((int)lo32(wsq)), hi32(wsq)));
                 error = pivot_abs;
                 int stop = 0;
                 if (kn > 0 && (pivot_abs < p.rel_tol * max_error || pivot_abs < p.abs_tol)) stop = 1;
@@ -633,11 +635,14 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         }
         __syncthreads(); // (B)
         XSTAMP(3);
+        // the record and the flags in one LDS round trip
         const int4 rec = *reinterpret_cast<const int4*>(win_i);
-        if (win_i[5]) {
+        const int4 rec2 = *reinterpret_cast<const int4*>(win_i + 4); // [0] rank [1] abort [2] next diagonal element
+        if (__builtin_amdgcn_readfirstlane(rec2.y)) {
             timed_out = true;
             break;
         }
+        dpk = __builtin_amdgcn_readfirstlane(rec2.z);
         const int rpk = __builtin_amdgcn_readfirstlane(rec.w);
         if (rpk >> 28) break; // stop
         const double wval = mk_f64((unsigned)__builtin_amdgcn_readfirstlane(rec.x), (unsigned)__builtin_amdgcn_readfirstlane(rec.y));
@@ -651,22 +656,11 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
 
         // the winner did not speculate: its column goes out now
         if (g == wag && !early_pub) {
-#pragma unroll
-            for (int q = 0; q < CPT; ++q)
-                if (q == qstar) {
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        const double av = a[q][r];
-                        u32x4 gv;
-                        gv.x = lo32(av);
-                        gv.y = hi32(av);
-                        gv.z = 0u;
-                        gv.w = tag ^ gv.x ^ gv.y;
-                        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * 1024, 0, 0);
-                    }
-                }
+            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag);
+            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag);
+            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag);
+            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag);
         }
-        // every thread fetches its rows (tid, tid + XT, ...) of the winner's column
         // thread tid fetches slot rows tid + XT j = lane + 64 (wave + XWAVES j): valid while wave + XWAVES j < RPT (wave-uniform)
         constexpr int XR = (RPT + XWAVES - 1) / XWAVES;
         const int slot_off = (int)cols_base + ((par * NW + wag) * MP + tid) * 16;
@@ -684,6 +678,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             rowpos[irow_p] = (unsigned short)kn;
             poscol[pcp] = (unsigned short)ck;
             poscol[kn] = (unsigned short)pc;
+            lds_pivots[kn] = wval;
         }
         prev_sq = wval * wval;
         // columns: ck (at kn) goes to pcp, the pivot column pc goes to kn
@@ -702,15 +697,13 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             for (int q = 0; q < CPT; ++q) {
                 const double av = a[q][rs];
                 u[q] = readlane_f64(av, ls);
-                const int cq = __builtin_amdgcn_readfirstlane(cpos[q]);
-                if (cq >= kn) {
+                if (__builtin_amdgcn_readfirstlane(cpos[q]) >= kn) {
                     if (u[q] != u[q]) nan_seen = 1;
-                    if (p.urows && lane == ls) p.urows[(size_t)kn * N + (g + NW * q)] = u[q];
+                    if (p.urows && lane == ls) p.urows[(unsigned)(kn * N + (g + NW * q))] = u[q];
                     a[q][rs] = (lane == ls) ? 0.0 : av;
                 }
             }
         }
-        if (rank == 0 && tid == 64) lds_pivots[kn] = wval;
         XSTAMP(11);
 
         // ---- pivot column -> l = column / pivot, parked in LDS for everybody ----
@@ -725,7 +718,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 if (++spins > XSPIN) {
                     atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
                     if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
-                    win_i[5] = 1; // observed by everybody after the next barrier
+                    win_i[5] = 1; // observed by everybody after the next barrier (B), or after the loop
                     break;
                 }
 #pragma unroll
@@ -767,10 +760,6 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         XSTAMP(4);
         __syncthreads(); // (C)
         XSTAMP(13);
-        if (win_i[5]) {
-            timed_out = true;
-            break;
-        }
         xvec<RPT> l;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) l[r] = lbuf[lane * LSTR + r];
@@ -785,19 +774,22 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             const int cq = __builtin_amdgcn_readfirstlane(cpos[q]);
             mq[q] = -1.0;
             if (cq > kn) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) { // in place (see sub_in_place); un-fused, one rounding per operation like the reference
+                    double t = a[q][r];
+                    sub_in_place(t, l[r] * u[q]);
+                    a[q][r] = t;
+                }
                 double m0 = -1.0, m1 = -1.0;
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
-                    const double prod = l[r] * u[q];
-                    const double t = a[q][r] - prod;
-                    a[q][r] = t;
-                    if (r & 1) m1 = vmax_abs(m1, t);
-                    else m0 = vmax_abs(m0, t);
+                    if (r & 1) m1 = vmax_abs(m1, a[q][r]);
+                    else m0 = vmax_abs(m0, a[q][r]);
                 }
                 mq[q] = vmax(m0, m1);
-            } else if (cq == kn) {
-                a[q] = l;
             }
+            // (the pivot column itself, cq == kn, is left as it is: its registers keep the un-scaled column, and L = column /
+            // pivot is formed by the same division when the factored matrix is written out — the column is never read again)
         }
         npiv = kn + 1;
         XSTAMP(0);
@@ -805,6 +797,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
 
     // ---- results ----
     const unsigned long long t_done = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (win_i[5]) timed_out = true; // (a column wait of the last step that gave up: its flag was set before barrier (C))
     if (npiv >= (M < N ? M : N)) error = 0.0; // matrixlu.rs:811-813
     if (rank == 0 && tid == 0) {
         p.iresult[0] = npiv;
@@ -850,7 +843,11 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 const bool from_u = (rp < npiv) && (cp >= rp);
                 double v = a[q][r];
                 const bool in_l = (cp < npiv) && (rp > cp);
-                if (in_l && v != v) nan_seen = 1;
+                if (in_l) { // scale_column_tail (matrixlu.rs:562-577), deferred: the same division the step itself used
+                    const double pv = lds_pivots[cp];
+                    v = xcd_div(v, pv, refined_rcp(pv), exp_mid(pv));
+                    if (v != v) nan_seen = 1;
+                }
                 if (p.Aout) {
                     if (from_u)
                         v = __longlong_as_double((long long)__hip_atomic_load(
@@ -867,7 +864,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         atomicExch(&p.iresult[2], 1);
         if (p.h_block) ((volatile int*)p.h_block)[6] = 1;
     }
-    // host-visible header (the pivot values went to the mirror step by step, the two flag words belong to their setters)
+    // host-visible header (the pivot values went to the mirror with the permutations, the two flag words belong to their setters)
     if (p.h_block && rank == 0 && tid == 0) {
         p.h_block[0] = (unsigned long long)__double_as_longlong(error);
         p.h_block[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.dresult) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
