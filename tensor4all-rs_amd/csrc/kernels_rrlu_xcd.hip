@@ -81,14 +81,25 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// DPP move whose lanes without a source read 0 (bound_ctrl): no "old" value, so no copy in front of every move.  Only good
+// where those lanes do not matter.
+template <int CTRL> __device__ __forceinline__ double dppz_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_max_f64(double v) // maxNum over the 64 lanes (uniform result, in scalar registers)
 {
-    v = vmax(v, dpp_f64<0xB1>(v));  // quad_perm [1,0,3,2]
-    v = vmax(v, dpp_f64<0x4E>(v));  // quad_perm [2,3,0,1]
-    v = vmax(v, dpp_f64<0x141>(v)); // row_half_mirror
-    v = vmax(v, dpp_f64<0x140>(v)); // row_mirror: every lane of a row holds the row maximum
-    v = vmax(v, dpp_f64<0x142>(v)); // row_bcast15: rows 1..3 see lane 15 of the previous row
-    v = vmax(v, dpp_f64<0x143>(v)); // row_bcast31: rows 2, 3 see lane 31 -> lane 63 holds the wave maximum
+    v = vmax(v, dppz_f64<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = vmax(v, dppz_f64<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = vmax(v, dppz_f64<0x141>(v)); // row_half_mirror
+    v = vmax(v, dppz_f64<0x140>(v)); // row_mirror: every lane of a row holds the row maximum
+    // the two broadcasts have no source for row 0 (and row 1): those lanes see 0 and go wrong, but lane 63, the only one read,
+    // is fed by lanes 15, 31 and 47, which are right: 15 after the row stages, 31 and 47 after row_bcast15
+    v = vmax(v, dppz_f64<0x142>(v)); // row_bcast15: rows 1..3 see lane 15 of the previous row
+    v = vmax(v, dppz_f64<0x143>(v)); // row_bcast31: rows 2, 3 see lane 31 -> lane 63 holds the wave maximum
     return readlane_f64(v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
@@ -398,9 +409,11 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                         if (bq[q] != 0ull) {
                             const int hl = (int)__builtin_ctzll(bq[q]);
                             // which row slot of that lane: bit RPT - 1 - r of `bits` says slot r holds the maximum
+                            // (compare + add-with-carry per slot: bits = 2 bits + (|a| == wmax))
                             unsigned bits = 0u;
 #pragma unroll
-                            for (int r = 0; r < RPT; ++r) bits = bits + bits + ((__builtin_fabs(a[q][r]) == wmax) ? 1u : 0u);
+                            for (int r = 0; r < RPT; ++r)
+                                asm("v_cmp_eq_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"((double)a[q][r]), "s"(wmax) : "vcc");
                             const unsigned hb_ = (unsigned)__builtin_amdgcn_readlane((int)bits, hl);
                             if (__builtin_popcount(hb_) == 1) {
                                 const int rstar = RPT - 1 - (int)__builtin_ctz(hb_);
