@@ -254,7 +254,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.pivot_vals = d_pivvals;
         a.keys = d_xkeys_.get();
         a.salt = xcd_salt_;
-        static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.66;
+        static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.8;
         a.spec_frac = xspec;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
         std::memset(h_out_.get(), 0, 32);
@@ -331,7 +331,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
         static const int spec_env = std::getenv("T4A_RRLU_SPEC") ? std::atoi(std::getenv("T4A_RRLU_SPEC")) : 2;
         a.spec = spec_env < 0 ? 0 : (spec_env > 2 ? 2 : spec_env);
-        static const double spec_frac_env = std::getenv("T4A_RRLU_SPECFRAC") ? std::atof(std::getenv("T4A_RRLU_SPECFRAC")) : 0.66;
+        static const double spec_frac_env = std::getenv("T4A_RRLU_SPECFRAC") ? std::atof(std::getenv("T4A_RRLU_SPECFRAC")) : 0.8;
         a.spec_frac = spec_frac_env;
         static const int key16_env = std::getenv("T4A_RRLU_KEY16") ? std::atoi(std::getenv("T4A_RRLU_KEY16")) : 1;
         a.key16 = key16_env; // bit 0: 16-byte key loads, bit 1: 16-byte key store

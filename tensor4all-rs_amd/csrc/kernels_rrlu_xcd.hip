@@ -181,7 +181,7 @@ template <int RPT> struct XcdLds {
     static constexpr int LSTR = xcd_lstr(RPT);
     static constexpr int o_l = 0;                        // double [64][LSTR]: l of row lane + 64 r at lane * LSTR + r
     static constexpr int o_wd = o_l + 64 * LSTR * 8;     // 16-byte relay slot: the polling wave hands its key to wave 1
-    static constexpr int o_wi = o_wd + 16;               // int [16]: [0,1] winner value bits [2] meta [3] agent | rk << 8 | ck << 18 | stop << 28 [4] rank [5] abort [6] next diagonal element: row | column << 10
+    static constexpr int o_wi = o_wd + 16;               // int [16]: [0,1] winner value bits [2] meta [3] agent | rk << 8 | ck << 18 | stop << 28 [4] abort [5] next diagonal element: row | column << 10 [6] rank
     static constexpr int o_pp = o_wi + 64;               // u64 [2]: iresult / h_block pointers for the give-up paths
     static constexpr int o_st = o_pp + 16;               // u64 [16] phase stamps (diagnostic builds)
     static constexpr int o_pv = o_st + 128;              // double [1024] pivot values of this launch
@@ -267,15 +267,15 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             const unsigned t = atomicAdd(p.ticket, 1u) - p.ticket_base;
             if (t < (unsigned)p.W) rank = (int)t;
         }
-        win_i[4] = rank;
-        win_i[5] = 0;
-        win_i[6] = 0; // the first diagonal element is (row 0, column 0)
+        win_i[6] = rank;
+        win_i[4] = 0;
+        win_i[5] = 0; // the first diagonal element is (row 0, column 0)
         lds_ptrs[0] = (unsigned long long)p.iresult;
         lds_ptrs[1] = (unsigned long long)p.h_block;
         for (int e = 0; e < 16; ++e) lds_stamps[e] = 0ull;
     }
     __syncthreads();
-    const int rank = __builtin_amdgcn_readfirstlane(win_i[4]);
+    const int rank = __builtin_amdgcn_readfirstlane(win_i[6]);
     if (rank < 0) return;
     const unsigned long long t_elected = (kXcdStamps && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int NW = p.W * XWAVES;
@@ -500,6 +500,9 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         // a mask or a count of live groups
         u32x4 kg[4];
         if (wave == 0) {
+#ifdef T4A_XCD_POLLSLEEP
+            __builtin_amdgcn_s_sleep(T4A_XCD_POLLSLEEP);
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
@@ -542,7 +545,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             XSTAMP(8);
             if (giveup) {
                 if (lane == 0) {
-                    win_i[5] = 1;
+                    win_i[4] = 1;
                     atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
                     if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
                 }
@@ -641,21 +644,29 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     rec.w = wa_ | (rk_ << 8) | (ck_ << 18) | (stop << 28);
                     *reinterpret_cast<int4*>(win_i) = rec;
                     // next diagonal element: the row / column that moves from kn to the pivot's old position, or the untouched one
-                    win_i[6] = ((prp_ == kn + 1) ? rk_ : rn_) | (((pcp_ == kn + 1) ? ck_ : cn_) << 10);
+                    win_i[5] = ((prp_ == kn + 1) ? rk_ : rn_) | (((pcp_ == kn + 1) ? ck_ : cn_) << 10);
                 }
                 XSTAMP(9);
             }
         }
         __syncthreads(); // (B)
         XSTAMP(3);
-        // the record and the flags in one LDS round trip
-        const int4 rec = *reinterpret_cast<const int4*>(win_i);
-        const int4 rec2 = *reinterpret_cast<const int4*>(win_i + 4); // [0] rank [1] abort [2] next diagonal element
-        if (__builtin_amdgcn_readfirstlane(rec2.y)) {
+        // the record and the flags in ONE LDS round trip (left to itself the compiler reads the abort flag, the stop bit and the
+        // rest one after the other, each with its own wait)
+        int4 rec;
+        int2 rec2; // [0] abort [1] next diagonal element
+        {
+            int zero = 0;
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(rec), "=&v"(rec2)
+                         : "v"(zero), "n"(L::o_wi), "n"(L::o_wi + 16)
+                         : "memory");
+        }
+        if (__builtin_amdgcn_readfirstlane(rec2.x)) {
             timed_out = true;
             break;
         }
-        dpk = __builtin_amdgcn_readfirstlane(rec2.z);
+        dpk = __builtin_amdgcn_readfirstlane(rec2.y);
         const int rpk = __builtin_amdgcn_readfirstlane(rec.w);
         if (rpk >> 28) break; // stop
         const double wval = mk_f64((unsigned)__builtin_amdgcn_readfirstlane(rec.x), (unsigned)__builtin_amdgcn_readfirstlane(rec.y));
@@ -684,11 +695,17 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         XSTAMP(10);
 
         // ---- while the column travels: permutation tables, pivot row ----
-        if (tid == 64) { // (not the polling wave) nobody reads the tables between barriers (B) and (C)
+        // (nobody reads the tables between barriers (B) and (C); one lane each of three waves that do not poll, so that no wave
+        // reaches barrier (C) a whole table update later than the others)
+        if (tid == 64) {
             posrow[prp] = (unsigned short)rk;
             posrow[kn] = (unsigned short)irow_p;
+        }
+        if (tid == 128) {
             rowpos[rk] = (unsigned short)prp;
             rowpos[irow_p] = (unsigned short)kn;
+        }
+        if (tid == 192) {
             poscol[pcp] = (unsigned short)ck;
             poscol[kn] = (unsigned short)pc;
             lds_pivots[kn] = wval;
@@ -731,7 +748,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 if (++spins > XSPIN) {
                     atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
                     if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
-                    win_i[5] = 1; // observed by everybody after the next barrier (B), or after the loop
+                    win_i[4] = 1; // observed by everybody after the next barrier (B), or after the loop
                     break;
                 }
 #pragma unroll
@@ -810,7 +827,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
 
     // ---- results ----
     const unsigned long long t_done = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (win_i[5]) timed_out = true; // (a column wait of the last step that gave up: its flag was set before barrier (C))
+    if (win_i[4]) timed_out = true; // (a column wait of the last step that gave up: its flag was set before barrier (C))
     if (npiv >= (M < N ? M : N)) error = 0.0; // matrixlu.rs:811-813
     if (rank == 0 && tid == 0) {
         p.iresult[0] = npiv;
