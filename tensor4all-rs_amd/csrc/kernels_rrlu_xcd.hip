@@ -692,6 +692,9 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
 #pragma unroll
         for (int j = 0; j < XR; ++j)
             if (wave + XWAVES * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * XT * 16, 0, BUF_SC1);
+        // (the shared reciprocal of the pivot does not depend on the column: it is formed while the column travels)
+        const bool p_mid = exp_mid(wval);
+        const double rp = refined_rcp(wval);
         XSTAMP(10);
 
         // ---- while the column travels: permutation tables, pivot row ----
@@ -758,8 +761,6 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             XSTAMP(12);
             // x / p through the shared refined reciprocal (bitwise the IEEE quotient, see refined_rcp); zeros keep the sign
             // rule through x * rp; anything unusual takes the full division
-            const bool p_mid = exp_mid(wval);
-            const double rp = refined_rcp(wval);
             double lq[XR];
             bool slow = false;
 #pragma unroll
