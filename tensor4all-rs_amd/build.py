@@ -17,6 +17,9 @@ SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "kernels_rrlu_xcd.hip", "
            "kernels_tt.hip", "engine.hip", "rook.hip", "tt.hip", "globalsearch.hip", "tci2.hip", "conversion.hip", "patching.hip", "tree.hip", "quantics.hip", "tensorops.hip", "aci.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"] + os.environ.get("T4A_EXTRA_FLAGS", "").split()  # e.g. -DT4A_RRLU_TRACE (tools/trace_arrivals.py)
+# per-source flags.  kernels_dense.hip: keep MFMA accumulators in VGPRs — in AGPR form the compiler moves all of them between the
+# two register files at every k-step of the GEMM loop (32 v_accvgpr reads + writes behind a pipeline drain)
+FILE_FLAGS = {"kernels_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "globalsearch.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
            "../../include/t4a_testfunctions.h"]
 
@@ -34,7 +37,7 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     # objects built with other flags (T4A_EXTRA_FLAGS: trace / A-B / development builds) must not be mixed into this build
     stamp = os.path.join(OBJ, "flags.stamp")
-    flags_now = " ".join(FLAGS)
+    flags_now = " ".join(FLAGS) + " | " + repr(sorted(FILE_FLAGS.items()))
     try:
         with open(stamp) as f:
             flags_then = f.read()
@@ -50,7 +53,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -24,25 +24,44 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // (lane&15 = 16 consecutive rows of one C column -> 128-byte contiguous stores).
 // ------------------------------------------------------------------------------------------------
 // BK = 32: 32 MFMAs (2 048 cycles) per wave and k-step cover the global-load latency.  Measured alternatives at 1024^3 /
-// 2048^3: BK 16 + pad 4 84 / 462 us, BK 32 + pad 4 80 / 463 us (kept), BK 16 + pad 16 (bank-conflict-free operand reads, three
-// workgroups per CU) 103 / 559 us, BK 32 + pad 16 99 / 559 us.
-constexpr int GBM = 64, GBN = 64, GBK = 32, GPAD = 4;
+// 2048^3 (round 2, 64 x 64 tiles): BK 16 + pad 4 84 / 462 us, BK 32 + pad 4 80 / 463 us, BK 16 + pad 16 (bank-conflict-free
+// operand reads, three workgroups per CU) 103 / 559 us, BK 32 + pad 16 99 / 559 us.
+// The block tile is 64 x BN with BN = 64 or 32: a grid of 64 x 64 tiles that leaves the chip with fewer than two workgroups
+// per compute unit (1024^3: 256 tiles on 256 CUs, one wave per SIMD, every LDS / barrier stall exposed) is launched with
+// 64 x 32 tiles instead.  Interior tiles advance per-thread pointers and skip every bounds test.
+constexpr int GBM = 64, GBK = 32, GPAD = 4;
 
+template <int BN>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
 {
     // double-buffered LDS tiles: the global loads of tile k + 1 are issued before the MFMAs of tile k and parked in
-    // registers, so their latency hides behind the 16 MFMAs (64 cycles each on gfx950) a wave issues per tile; one barrier
+    // registers, so their latency hides behind the MFMAs (64 cycles each on gfx950) a wave issues per tile; one barrier
     // per k-step
     extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
     typedef double TileA[GBK][GBM + GPAD];
-    typedef double TileB[GBK][GBN + GPAD];
+    typedef double TileB[GBK][BN + GPAD];
     TileA* As = reinterpret_cast<TileA*>(gemm_smem);                      // As[buf][k][m]
     TileB* Bs = reinterpret_cast<TileB*>(gemm_smem + 2 * sizeof(TileA));  // Bs[buf][k][n]
+    constexpr int WN = BN / 2;  // columns of a wave's tile
+    constexpr int NI = WN / 16; // MFMA blocks of a wave along n
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
+    // XCD-aware tile order: workgroups b, b + 8, b + 16, ... of a launch land on the same XCD (its own L2), so XCD x takes
+    // the x-th eighth of the tiles in column-major tile order — a band of B columns with every A row block, all of whose
+    // workgroups walk k together: operands are fetched into each L2 once instead of by every XCD
+    int tile_m = blockIdx.x, tile_n = blockIdx.y;
+    {
+        const int tm = gridDim.x, T = gridDim.x * gridDim.y;
+        if ((T & 7) == 0) {
+            const int bid = blockIdx.x + tm * blockIdx.y;
+            const int t = (bid & 7) * (T >> 3) + (bid >> 3);
+            tile_m = t % tm;
+            tile_n = t / tm;
+        }
+    }
+    const int m0 = tile_m * GBM, n0 = tile_n * BN;
     const int bz = blockIdx.z;
     const double* A = d.A + (size_t)bz * d.strideA;
     const double* B = d.B + (size_t)bz * d.strideB;
@@ -51,17 +70,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
     const long long sam = d.transA ? d.lda : 1, sak = d.transA ? 1 : d.lda;
     const long long sbk = d.transB ? d.ldb : 1, sbn = d.transB ? 1 : d.ldb;
 
-    double4_t acc[2][2];
+    double4_t acc[2][NI];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NI; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     // per-thread staging coordinates: the fast thread index runs along the unit-stride index of the operand
-    constexpr int NQ = GBM * GBK / 256; // elements per thread and operand tile
-    int ar[NQ], ak[NQ], bc[NQ], bk[NQ];
+    constexpr int NQA = GBM * GBK / 256, NQB = BN * GBK / 256; // elements per thread and operand tile
+    int ar[NQA], ak[NQA], bc[NQB], bk[NQB];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < NQA; ++q) {
         if (!d.transA) {
             ar[q] = tid & 63;
             ak[q] = (tid >> 6) + 4 * q;
@@ -69,32 +88,61 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
             ak[q] = tid & (GBK - 1);
             ar[q] = tid / GBK + (256 / GBK) * q;
         }
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
         if (!d.transB) {
             bk[q] = tid & (GBK - 1);
             bc[q] = tid / GBK + (256 / GBK) * q;
         } else {
-            bc[q] = tid & 63;
-            bk[q] = (tid >> 6) + 4 * q;
+            bc[q] = tid & (BN - 1);
+            bk[q] = tid / BN + (256 / BN) * q;
         }
     }
-    double ra[NQ], rb[NQ];
-    auto load_tile = [&](int k0) {
+    // interior tile: every row / column of the tile exists, so only the last (partial) k-tile needs bounds tests
+    const bool interior = (m0 + GBM <= d.m) && (n0 + BN <= d.n);
+    const double* pa[NQA];
+    const double* pb[NQB];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < NQA; ++q) pa[q] = A + (long long)(m0 + (interior ? ar[q] : 0)) * sam + (long long)ak[q] * sak;
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) pb[q] = B + (long long)bk[q] * sbk + (long long)(n0 + (interior ? bc[q] : 0)) * sbn;
+    const long long stepA = (long long)GBK * sak, stepB = (long long)GBK * sbk;
+
+    double ra[NQA], rb[NQB];
+    auto load_tile_checked = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) {
             const int gm = m0 + ar[q], gk = k0 + ak[q];
             ra[q] = (gm < d.m && gk < d.k) ? A[(long long)gm * sam + (long long)gk * sak] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+        for (int q = 0; q < NQB; ++q) {
             const int gn = n0 + bc[q], gk = k0 + bk[q];
             rb[q] = (gn < d.n && gk < d.k) ? B[(long long)gk * sbk + (long long)gn * sbn] : 0.0;
         }
     };
+    auto load_tile_fast = [&]() { // the pointers stand at the tile to load
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) {
+            ra[q] = *pa[q];
+            pa[q] += stepA;
+        }
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            rb[q] = *pb[q];
+            pb[q] += stepB;
+        }
+    };
+    auto load_tile = [&](int kt_) {
+        if (interior && (kt_ + 1) * GBK <= d.k) load_tile_fast();
+        else load_tile_checked(kt_ * GBK);
+    };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) As[buf][ak[q]][ar[q]] = ra[q];
+        for (int q = 0; q < NQA; ++q) As[buf][ak[q]][ar[q]] = ra[q];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) Bs[buf][bk[q]][bc[q]] = rb[q];
+        for (int q = 0; q < NQB; ++q) Bs[buf][bk[q]][bc[q]] = rb[q];
     };
 
     const int nk = (d.k + GBK - 1) / GBK;
@@ -105,19 +153,19 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * GBK); // in flight during the MFMAs below
+        if (kt + 1 < nk) load_tile(kt + 1); // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < GBK; ks += 4) {
             const int kk = ks + (lane >> 4);
-            double bn[2], am[2];
+            double bn[NI], am[2];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bn[ni] = Bs[buf][kk][wn * 32 + ni * 16 + (lane & 15)];
+            for (int ni = 0; ni < NI; ++ni) bn[ni] = Bs[buf][kk][wn * WN + ni * 16 + (lane & 15)];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) am[mi] = As[buf][kk][wm * 32 + mi * 16 + (lane & 15)];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
                     // MFMA "A" operand = B^T (rows = n), "B" operand = A^T (cols = m)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[ni], am[mi], acc[mi][ni], 0, 0, 0);
         }
@@ -128,11 +176,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int gm = m0 + wm * 32 + mi * 16 + (lane & 15);
-                const int gn = n0 + wn * 32 + ni * 16 + (lane >> 4) + 4 * reg;
+                const int gn = n0 + wn * WN + ni * 16 + (lane >> 4) + 4 * reg;
                 if (gm < d.m && gn < d.n) {
                     double* cp = C + (size_t)gn * d.ldc + gm;
                     double v = d.alpha * acc[mi][ni][reg];
@@ -693,17 +741,27 @@ __global__ void __launch_bounds__(256) tt_eval_kernel(const TtCoreDesc* cores, i
 
 } // namespace
 
+template <int BN> static void gemm_launch_bn(const GemmDesc& d, hipStream_t stream)
+{
+    dim3 grid((d.m + GBM - 1) / GBM, (d.n + BN - 1) / BN, d.batch);
+    constexpr size_t lds = 2 * sizeof(double) * GBK * ((GBM + GPAD) + (BN + GPAD));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_kernel<BN>, grid, dim3(256), lds, stream, d);
+}
+
 void gemm_launch(const GemmDesc& d, hipStream_t stream)
 {
     if (d.m <= 0 || d.n <= 0 || d.batch <= 0) return;
-    dim3 grid((d.m + GBM - 1) / GBM, (d.n + GBN - 1) / GBN, d.batch);
-    constexpr size_t lds = 2 * sizeof(double) * GBK * ((GBM + GPAD) + (GBN + GPAD));
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), lds, stream, d);
+    // two workgroups per compute unit hide each other's LDS / barrier stalls: narrower tiles when 64 x 64 ones cannot provide them
+    static const int force_bn = std::getenv("T4A_GEMM_BN") ? std::atoi(std::getenv("T4A_GEMM_BN")) : 0;
+    const long long tiles64 = (long long)((d.m + GBM - 1) / GBM) * ((d.n + 63) / 64) * d.batch;
+    const bool narrow = force_bn ? force_bn == 32 : (tiles64 < 512 && d.n > 32);
+    if (narrow) gemm_launch_bn<32>(d, stream);
+    else gemm_launch_bn<64>(d, stream);
 }
 
 void transpose_launch(const double* in, int rows, int cols, int ldi, double* out, int ldo, hipStream_t stream)
