@@ -245,8 +245,6 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     constexpr int LSTR = L::LSTR;
     constexpr int MP = 64 * RPT; // rows of a published column slot (rows beyond M carry zeros)
     double* const lbuf = reinterpret_cast<double*>(smem_raw + L::o_l);
-    double* const win_d = reinterpret_cast<double*>(smem_raw + L::o_wd);
-    if (threadIdx.x == 0) { win_d[0] = 0.0; win_d[1] = 0.0; }
     int* const win_i = reinterpret_cast<int*>(smem_raw + L::o_wi);
     unsigned long long* const lds_ptrs = reinterpret_cast<unsigned long long*>(smem_raw + L::o_pp);
     unsigned long long* const lds_stamps = reinterpret_cast<unsigned long long*>(smem_raw + L::o_st);
@@ -329,8 +327,10 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     unsigned long long stamp_last = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long t_loop = stamp_last;
 
-    // one mailbox: [2][NW] keys, then [2][NW][MP] column rows (one buffer resource for every store and load of the exchange)
-    const unsigned cols_base = 2u * (unsigned)NW * 16u;
+    // one mailbox: [2][NW] early keys (candidate magnitude only), [2][NW] full keys, then [2][NW][MP] column rows (one buffer
+    // resource for every store and load of the exchange)
+    const unsigned k2_base = 2u * (unsigned)NW * 16u;
+    const unsigned cols_base = 4u * (unsigned)NW * 16u;
     const __amdgpu_buffer_rsrc_t mail =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(cols_base + 2u * (unsigned)NW * (unsigned)MP * 16u), 0x00020000);
 
@@ -388,6 +388,30 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         for (int q = 1; q < CPT; ++q) m = vmax(m, mq[q]);
         const double wmax = wave_max_f64(m);
         const double sq = wmax * wmax; // the winning score v*v of this agent
+        // ---- early key: the magnitude of the candidate goes out before its position is known.  In the normal case (one
+        // agent holds the largest |v|, its square a normal number) the magnitudes alone decide the winner, so the pollers
+        // gather them while every agent is still looking for the row slot and the position of its candidate; the full key
+        // follows below and is only read for the winner.  (No candidate: 0, which sends the pick to the exact path.)
+        const int kslot = (par * NW + g) * 16;
+        {
+            const double k1 = (wmax >= 0.0) ? wmax : 0.0;
+            u32x4 kv;
+            kv.x = lo32(k1);
+            kv.y = hi32(k1);
+            kv.z = 0u;
+            kv.w = tag ^ kv.x ^ kv.y;
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0);
+        }
+        // the polling wave starts its sweep of the early keys now: they travel while it looks for its own candidate's position
+        // (its own stores are acknowledged long before it needs the data, so it publishes like everybody else).  Every lane
+        // fetches four keys; lanes beyond NW re-read the last key (a valid duplicate), so neither the arrival check nor the
+        // maximum needs a mask or a count of live groups
+        u32x4 kg[4], kh[4];
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+        }
         unsigned wpos = XKEY_NONE;     // position key of the candidate
         double cval = 0.0;             // its value
         int cirow = 0, qstar = 0;      // its row index and my column slot
@@ -467,9 +491,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             }
         }
         XSTAMP(1);
-        // ---- publish: one 16-byte key per agent (all fields are wave-uniform) ----
-        // The polling wave must not have a store of its own in flight (vector memory operations complete in order: its key
-        // loads would wait for the acknowledgement of that store), so wave 1 stores the key of wave 0 for it.
+        // ---- full key: value, position, row index, column slot (all fields are wave-uniform) ----
         {
             const unsigned meta = wpos | ((unsigned)cirow << 20) | ((unsigned)qstar << 30);
             u32x4 kv;
@@ -477,40 +499,17 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             kv.y = hi32(cval);
             kv.z = meta;
             kv.w = tag ^ kv.x ^ kv.y ^ meta;
-            const int kslot = (par * NW + g) * 16;
-            if (wave == 0) {
-                if (lane == 0) *reinterpret_cast<u32x4*>(win_d) = kv;
-            } else {
-                if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0);
-                if (wave == 1) {
-                    u32x4 k0;
-                    unsigned spins = 0;
-                    for (;;) {
-                        asm volatile("" ::: "memory"); // (a plain LDS read per turn; a volatile access would go through the flat path)
-                        k0 = *reinterpret_cast<const u32x4*>(win_d);
-                        if ((k0.x ^ k0.y ^ k0.z ^ k0.w) == tag) break;
-                        if (++spins > XSPIN) break; // (the pollers give up on the missing key)
-                    }
-                    if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(k0, mail, kslot - 16, 0, 0);
-                }
-            }
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, (int)k2_base + kslot, 0, 0);
         }
-        // the polling wave starts its first sweep of the key table before it publishes its column.  Every lane fetches four
-        // keys; lanes beyond NW re-read the last key (a valid duplicate), so neither the arrival check nor the maximum needs
-        // a mask or a count of live groups
-        u32x4 kg[4];
-        if (wave == 0) {
-#ifdef T4A_XCD_POLLSLEEP
-            __builtin_amdgcn_s_sleep(T4A_XCD_POLLSLEEP);
-#endif
+        if (wave == 0) { // (the full keys: in flight while the early ones are examined)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
         }
         // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
         // keys have been gathered
-        const bool early_pub = (wave != 0) && (wpos != XKEY_NONE) && (sq >= spec_frac * prev_sq); // (the polling wave never stores early)
+        const bool early_pub = (wave != 0) && (wpos != XKEY_NONE) && (sq >= spec_frac * prev_sq); // (the polling wave never stores a column early: those stores would sit in front of its key loads)
         const int myslot = (int)cols_base + ((par * NW + g) * MP + lane) * 16; // byte offset of my row `lane` in the mailbox
         if (early_pub) {
             if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag);
@@ -543,37 +542,27 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             }
             if (stamp_on) lds_stamps[5] += spins;
             XSTAMP(8);
-            if (giveup) {
-                if (lane == 0) {
-                    win_i[4] = 1;
-                    atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
-                    if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
-                }
-            } else {
-                // winner over all keys.  Normal case: v*v of the largest |v| is a normal number (distinct |v| <=> distinct
-                // scores), no key is a NaN and exactly one key holds the largest |v|: one maximum reduction decides.  (A
-                // duplicate of the last key can only push the count above one: then the exact path decides.)
-                double wv = 0.0;
-                unsigned wm_ = 0u;
-                int wa_ = 0;
+            double wv = 0.0;
+            unsigned wm_ = 0u;
+            int wa_ = 0;
+            if (!giveup) {
+                // winner over all agents.  Normal case: the largest candidate magnitude, its square a normal number (distinct
+                // |v| <=> distinct scores), held by exactly one early key: one maximum reduction decides, and only the winner's
+                // full key is needed.  (A duplicate of the last key can only push the count above one: then the exact path
+                // decides.  A NaN incumbent travels as +inf, no candidate as 0: both end up on the exact path.)
                 bool decided = false;
                 {
                     double lm = -1.0;
-                    bool anynan = false;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const double v = mk_f64(kg[j].x, kg[j].y);
-                        anynan |= (v != v);
-                        lm = vmax_abs(lm, v);
-                    }
+                    for (int j = 0; j < 4; ++j) lm = vmax(lm, mk_f64(kg[j].x, kg[j].y));
                     const double gm = wave_max_f64(lm);
                     const double gsq = gm * gm;
-                    if ((__ballot(anynan) == 0ull) && (gsq >= 2.2250738585072014e-308) && (gsq < __builtin_huge_val())) {
+                    if ((gsq >= 2.2250738585072014e-308) && (gsq < __builtin_huge_val())) {
                         unsigned long long hb[4];
                         int nh = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            hb[j] = __ballot(__builtin_fabs(mk_f64(kg[j].x, kg[j].y)) == gm);
+                            hb[j] = __ballot(mk_f64(kg[j].x, kg[j].y) == gm);
                             nh += __builtin_popcountll(hb[j]);
                         }
                         if (nh == 1) {
@@ -581,9 +570,23 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                             for (int j = 0; j < 4; ++j)
                                 if (hb[j] != 0ull) {
                                     const int hl = (int)__builtin_ctzll(hb[j]);
-                                    wv = readlane_f64(mk_f64(kg[j].x, kg[j].y), hl);
-                                    wm_ = (unsigned)__builtin_amdgcn_readlane((int)kg[j].z, hl);
                                     wa_ = hl + 64 * j;
+                                    // the winner's full key: normally long there; otherwise fetched again until it is
+                                    unsigned kx, ky, kz, kw;
+                                    for (;;) {
+                                        kx = (unsigned)__builtin_amdgcn_readlane((int)kh[j].x, hl);
+                                        ky = (unsigned)__builtin_amdgcn_readlane((int)kh[j].y, hl);
+                                        kz = (unsigned)__builtin_amdgcn_readlane((int)kh[j].z, hl);
+                                        kw = (unsigned)__builtin_amdgcn_readlane((int)kh[j].w, hl);
+                                        if ((kx ^ ky ^ kz ^ kw) == tag) break;
+                                        if (++spins > XSPIN) {
+                                            giveup = true;
+                                            break;
+                                        }
+                                        kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                                    }
+                                    wv = mk_f64(kx, ky);
+                                    wm_ = kz;
                                 }
                             decided = true;
                         }
@@ -592,8 +595,21 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 XSTAMP(14);
                 if (!decided) {
                     // ties between agents, zero / subnormal / infinite scores, the NaN incumbent: exact comparison of
-                    // (v*v, position key).  The only NaN a key can carry is the incumbent on the diagonal, which wins
-                    // outright; an agent without candidate carries value 0 and the largest position key.
+                    // (v*v, position key) over the FULL keys.  The only NaN a key can carry is the incumbent on the diagonal,
+                    // which wins outright; an agent without candidate carries value 0 and the largest position key.
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ok &= ((kh[j].x ^ kh[j].y ^ kh[j].z ^ kh[j].w) == tag);
+                        if (__all(ok)) break;
+                        if (++spins > XSPIN) {
+                            giveup = true;
+                            break;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                    }
                     double csc = -1.0, cv = 0.0;
                     unsigned cpk = XNOPOS, cmeta = 0u;
                     int cag = 0;
@@ -601,8 +617,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int ag = lane_o + 64 * j;
-                        const unsigned pk = (ag < NW) ? (kg[j].z & 0xFFFFFu) : XNOPOS;
-                        const double v = mk_f64(kg[j].x, kg[j].y);
+                        const unsigned pk = (ag < NW) ? (kh[j].z & 0xFFFFFu) : XNOPOS;
+                        const double v = mk_f64(kh[j].x, kh[j].y);
                         double sc = v * v;
                         sc = (sc != sc) ? __builtin_huge_val() : sc;
                         sc = (ag < NW) ? sc : -2.0;
@@ -610,7 +626,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                         csc = better ? sc : csc;
                         cv = better ? v : cv;
                         cpk = better ? pk : cpk;
-                        cmeta = better ? kg[j].z : cmeta;
+                        cmeta = better ? kh[j].z : cmeta;
                         cag = better ? ag : cag;
                     }
                     const double gmax = wave_max_f64(csc);
@@ -621,6 +637,14 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     wm_ = (unsigned)__builtin_amdgcn_readlane((int)cmeta, wl);
                     wa_ = __builtin_amdgcn_readlane(cag, wl);
                 }
+            }
+            if (giveup) {
+                if (lane == 0) {
+                    win_i[4] = 1;
+                    atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
+                    if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
+                }
+            } else {
                 // stop tests on the pivot magnitude sqrt(v*v), in the reference's order; while v*v is a normal number the
                 // square root of the rounded square is |v| itself (the software square root stays on the cold path)
                 const double wsq = wv * wv;
@@ -1002,7 +1026,7 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out)
     return true;
 }
 
-size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan) { return (size_t)2 * plan.W * XWAVES * 16; }
+size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan) { return (size_t)4 * plan.W * XWAVES * 16; } // early keys + full keys, two step parities each
 size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int) { return (size_t)2 * plan.W * XWAVES * (size_t)(64 * plan.RPT) * 16; } // slots are padded to 64 * RPT rows
 
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
