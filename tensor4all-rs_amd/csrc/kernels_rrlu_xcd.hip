@@ -402,16 +402,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             kv.w = tag ^ kv.x ^ kv.y;
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0);
         }
-        // the polling wave starts its sweep of the early keys now: they travel while it looks for its own candidate's position
-        // (its own stores are acknowledged long before it needs the data, so it publishes like everybody else).  Every lane
-        // fetches four keys; lanes beyond NW re-read the last key (a valid duplicate), so neither the arrival check nor the
-        // maximum needs a mask or a count of live groups
         u32x4 kg[4], kh[4];
-        if (wave == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
-        }
         unsigned wpos = XKEY_NONE;     // position key of the candidate
         double cval = 0.0;             // its value
         int cirow = 0, qstar = 0;      // its row index and my column slot
@@ -501,10 +492,15 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
             kv.w = tag ^ kv.x ^ kv.y ^ meta;
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, (int)k2_base + kslot, 0, 0);
         }
-        if (wave == 0) { // (the full keys: in flight while the early ones are examined)
+        // the polling wave sweeps the early keys now — they left their agents a whole position search ago, so this first sweep
+        // normally finds them all (a load only sees what had reached the L2 when it was served: issued earlier it comes back
+        // stale and costs a second round trip).  Every lane fetches four keys; lanes beyond NW re-read the last key (a valid
+        // duplicate), so neither the arrival check nor the maximum needs a mask or a count of live groups.  (The wave's own
+        // stores are acknowledged long before it needs this data, so it publishes like everybody else.)
+        if (wave == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
         }
         // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
@@ -541,6 +537,11 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                     kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
             }
             if (stamp_on) lds_stamps[5] += spins;
+            // the full keys: fetched now (every agent stored its own before it could have seen this step's early keys complete...
+            // almost: a late one is fetched again below), in flight while the early ones are examined
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
             XSTAMP(8);
             double wv = 0.0;
             unsigned wm_ = 0u;
