@@ -203,6 +203,8 @@ struct PiJob {
     int M, N, ld, pad_;
 };
 void pi_eval_batched_launch(const FnDevice& fn, const PiJob* d_jobs, int n_jobs, int max_M, int max_N, hipStream_t stream);
+// count u64 from a pinned (device-visible) host buffer to device memory, as a kernel on `stream`
+void stage_copy_launch(const uint64_t* pinned_src, uint64_t* dst, size_t count, hipStream_t stream);
 // max over a dense buffer of bits(sqrt(v*v)) (host-callback path)
 void absmax_launch(const double* data, size_t count, unsigned long long* max_abs_bits, hipStream_t stream);
 

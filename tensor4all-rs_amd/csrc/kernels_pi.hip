@@ -85,7 +85,23 @@ __global__ void __launch_bounds__(256) absmax_kernel(const double* __restrict__ 
     wave_absmax_commit(av, max_abs_bits);
 }
 
+// accumulators: pinned host arena -> device buffer.  A kernel instead of a DMA copy: the candidate-matrix kernel that follows on
+// the same stream starts a few microseconds sooner behind a kernel than behind an SDMA transfer, and a bond update is a chain
+// of such hand-offs.
+__global__ void __launch_bounds__(256) stage_copy_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 } // namespace
+
+void stage_copy_launch(const uint64_t* pinned_src, uint64_t* dst, size_t count, hipStream_t stream)
+{
+    if (count == 0) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(stage_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pinned_src, dst, count);
+}
 
 void pi_eval_launch(const FnDevice& fn, const uint64_t* rowacc, int M, const uint64_t* colacc, int N, double* out,
                     int ld, bool transpose_out, unsigned long long* max_abs_bits, hipStream_t stream)

@@ -374,7 +374,13 @@ void Tci2::stage_accumulators(const IndexSet& a, size_t a0, const IndexSet& b, s
     std::memcpy(ha, ra.data(), ra.size() * sizeof(uint64_t));
     std::memcpy(ha + ra.size(), rb.data(), rb.size() * sizeof(uint64_t));
     d_rowacc_.reserve(need);
-    T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ha, need * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    static const bool dma_copy = std::getenv("T4A_ACC_DMA") != nullptr;
+    if (dma_copy) {
+        T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ha, need * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    } else {
+        stage_copy_launch(ha, d_rowacc_.get(), need, st);
+        T4A_HIP(hipGetLastError());
+    }
     *d_ra = d_rowacc_.get();
     *d_rb = d_rowacc_.get() + ra.size();
 }
