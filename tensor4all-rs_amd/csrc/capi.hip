@@ -88,13 +88,15 @@ template <class F> t4a_gpu_status guarded(F&& body)
     } while (0)
 
 std::mutex g_dense_mutex;
-std::unique_ptr<Engine> g_dense_engine;
+Engine* g_dense_engine = nullptr;
 
 // One process-global engine for the handle-less dense entry points, serialised by a mutex exactly like the
-// reference's global default backend (tensorbackend/src/context.rs:318-338).
+// reference's global default backend (tensorbackend/src/context.rs:318-338).  It is never destroyed: a destructor that runs
+// during static destruction would call into a HIP runtime that may already be gone (under rocprofv3 that teardown does not
+// return); the process exit reclaims stream and buffers.
 Engine& dense_engine()
 {
-    if (!g_dense_engine) g_dense_engine.reset(new Engine());
+    if (!g_dense_engine) g_dense_engine = new Engine();
     return *g_dense_engine;
 }
 
