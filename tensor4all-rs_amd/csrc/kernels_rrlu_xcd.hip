@@ -18,11 +18,17 @@
 //   * every WAVE is an agent that owns whole columns: agent g = rank * 8 + wave holds columns g + NW * q (q < CPT) with rows
 //     lane + 64 * r (r < RPT) in registers, so the candidate search, the pivot-row broadcast (v_readlane) and the speculative
 //     publication of the candidate column need no workgroup-level synchronisation at all;
-//   * per pivot step: rank-1 update fused with per-column maxima of |a| -> wave arg-max (DPP) -> one 16-byte key per agent and,
-//     when the candidate is within `spec_frac` of the previous pivot, its column (16 bytes per row) -> wave 0 of every
-//     workgroup gathers the NW keys (sc1 loads, L2 hits) and decides -> barrier (B) -> all 512 threads fetch two rows of the
-//     winner's column, divide by the pivot (shared refined reciprocal, bitwise the IEEE quotient) and park l in LDS ->
-//     barrier (C).  Two barriers per step, no LDS traffic on the search side.
+//   * per pivot step: rank-1 update (in place) fused with per-column maxima of |a| -> wave maximum (DPP) -> EARLY key {candidate
+//     magnitude} -> position of the candidate (the early keys travel meanwhile) -> FULL key {value, position, row index, column
+//     slot} and, when the candidate is within `spec_frac` of the previous pivot, its column (16 bytes per row) -> wave 0 of
+//     every workgroup gathers the NW early keys (sc1 loads, L2 hits), picks the winner from the magnitudes and reads only the
+//     winner's full key (ties and special values: exact comparison over all full keys), stop rules, record -> barrier (B) ->
+//     all 512 threads fetch their rows of the winner's column, divide by the pivot (shared refined reciprocal, bitwise the
+//     IEEE quotient) and park l in LDS -> barrier (C).  Two barriers per step, no LDS traffic on the search side.
+//   * the kernel is bound by its instruction stream and its scalar registers, not by arithmetic: compile-time LDS layout, one
+//     buffer resource for the whole mailbox, column slots padded to 64 * RPT rows (no row masks), clamped key addresses (no
+//     agent masks), rare paths fed through opaque registers so that nothing of them is hoisted into the step loop, tied
+//     operands for the update (DESIGN.md 5.1 has the measurements behind each of these).
 //   * granules carry a launch-salted tag folded with their payload (d3 = tag ^ d0 ^ d1 ^ d2), so a torn or stale granule
 //     never passes the check and no buffer has to be cleared between launches.
 #include "kernels.hpp"
@@ -180,7 +186,7 @@ __device__ __forceinline__ double uniform_f64(double v) // a wave-uniform value 
 template <int RPT> struct XcdLds {
     static constexpr int LSTR = xcd_lstr(RPT);
     static constexpr int o_l = 0;                        // double [64][LSTR]: l of row lane + 64 r at lane * LSTR + r
-    static constexpr int o_wd = o_l + 64 * LSTR * 8;     // 16-byte relay slot: the polling wave hands its key to wave 1
+    static constexpr int o_wd = o_l + 64 * LSTR * 8;     // (16 bytes, unused: the key relay slot of the first versions)
     static constexpr int o_wi = o_wd + 16;               // int [16]: [0,1] winner value bits [2] meta [3] agent | rk << 8 | ck << 18 | stop << 28 [4] abort [5] next diagonal element: row | column << 10 [6] rank
     static constexpr int o_pp = o_wi + 64;               // u64 [2]: iresult / h_block pointers for the give-up paths
     static constexpr int o_st = o_pp + 16;               // u64 [16] phase stamps (diagnostic builds)
