@@ -149,6 +149,19 @@ def test_gemm(t4a, m, k, n):
     assert np.array_equal(t4a.mat_mul(ai, bi), ai @ bi)
 
 
+@pytest.mark.parametrize("m,k,n", [(1536, 40, 1536),   # 24 x 24 tiles of 64 x 64: wide-tile kernel, XCD-aware tile order
+                                   (1000, 72, 1100),   # 64 x 32 tiles (16 x 35 of them), ragged edges, remapped tile order
+                                   (1030, 33, 1100),   # 17 x 35 tiles: not a multiple of eight -> plain tile order, partial k-tile
+                                   (64, 4096, 32)])    # one tile, long k (pointer-stepped interior path)
+def test_gemm_tile_variants(t4a, m, k, n):
+    """The two tile widths of gemm_kernel, its interior fast path and both tile orders against exact integer products (every
+    partial sum stays far below 2^53, so any summation order gives the same bits)."""
+    rng = np.random.default_rng(m + 7 * k + 13 * n)
+    ai = rng.integers(-3, 4, size=(m, k)).astype(float)
+    bi = rng.integers(-3, 4, size=(k, n)).astype(float)
+    assert np.array_equal(t4a.mat_mul(ai, bi), ai @ bi)
+
+
 def test_gemm_batched(t4a):
     rng = np.random.default_rng(6)
     batch, m, k, n = 5, 7, 9, 4
