@@ -195,18 +195,29 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     if (fused) {
         fuse = use_reg && rplan.RPT * rplan.CPT <= RRLU_FUSED_MAX_VALUES;
         if (!fuse) { // this plan cannot build the matrix in registers: materialise it like the Π kernel would
+            const uint64_t* ra = fused->d_rowacc;
+            const uint64_t* ca = fused->d_colacc;
+            if (fused->host_resident) { // (the Π kernel re-reads accumulators many times: never over PCIe)
+                const size_t nr = (size_t)M * fused->fn.n_acc, nc = (size_t)N * fused->fn.n_acc;
+                d_accstage_.reserve(nr + nc);
+                stage_copy_launch(ra, d_accstage_.get(), nr, stream_);
+                stage_copy_launch(ca, d_accstage_.get() + nr, nc, stream_);
+                ra = d_accstage_.get();
+                ca = d_accstage_.get() + nr;
+            }
             double* buf = pi((size_t)M * N);
             if (use_xcd && !left) { // the kernel works on the transpose: evaluate it in that layout straight away
-                pi_eval_launch(fused->fn, fused->d_colacc, N, fused->d_rowacc, M, buf, N, false, nullptr, stream_);
+                pi_eval_launch(fused->fn, ca, N, ra, M, buf, N, false, nullptr, stream_);
                 xcd_src_transposed = true;
             } else {
-                pi_eval_launch(fused->fn, fused->d_rowacc, M, fused->d_colacc, N, buf, M, false, nullptr, stream_);
+                pi_eval_launch(fused->fn, ra, M, ca, N, buf, M, false, nullptr, stream_);
             }
             d_a = buf;
         }
     }
     int plan_W = 1, plan_T = 0, plan_code = 0;
     bool mirrored = false;
+    unsigned spin_token = 0u; // non-zero: a single-workgroup launch that announces its completion in the pinned block
     if (prof.enabled) T4A_HIP(hipEventRecord(ev_rrlu_.a, stream_));
     XcdArbiter::Lock xcd_lock; // multi-workgroup persistent kernels need their compute units to themselves
     if (use_xcd) {
@@ -351,6 +362,13 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         }
         a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());
         a.block_u64 = (int)(out_bytes / 8);
+        a.done_token = 0u;
+        static const bool no_token_spin = std::getenv("T4A_NO_TOKEN_SPIN") != nullptr;
+        if (rplan.W == 1 && !prof.enabled && !no_token_spin) {
+            if (++done_token_ == 0u) ++done_token_;
+            a.done_token = done_token_;
+            spin_token = done_token_;
+        }
         a.trace = nullptr;
 #ifdef T4A_RRLU_TRACE
         static const char* trace_file = std::getenv("T4A_RRLU_TRACE_FILE");
@@ -435,7 +453,23 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         hook.swap(overlap_hook);
         hook();
     }
-    T4A_HIP(hipStreamSynchronize(stream_));
+    bool completed = false;
+    if (spin_token != 0u) {
+        // small bond: spin on the token the (only) workgroup writes after its last word to the host; the stream itself is
+        // not waited for (everything that follows on it is ordered behind the kernel anyway).  Bounded: a launch that gave
+        // up returns without a token and is picked up by the synchronisation below.
+        volatile unsigned* tok = reinterpret_cast<volatile unsigned*>(h_out_.get() + 16) + 3;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; ++it) {
+            if (*tok == spin_token) {
+                completed = true;
+                break;
+            }
+            if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!completed) T4A_HIP(hipStreamSynchronize(stream_));
     xcd_lock.release();
     if (use_xcd && (reinterpret_cast<const int*>(h_out_.get() + 16)[1] != 0 || reinterpret_cast<const int*>(h_out_.get() + 16)[3] != (int)xcd_salt_)) {
         // the placement assumption of the single-XCD kernel did not hold (or another process holds the compute units):

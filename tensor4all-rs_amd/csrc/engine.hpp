@@ -37,6 +37,7 @@ struct FusedPi {
     FnDevice fn;
     const uint64_t* d_rowacc;
     const uint64_t* d_colacc;
+    bool host_resident = false; // the accumulators sit in pinned host memory (small bonds: read in place by the fused kernel)
 };
 
 struct Profile {
@@ -128,6 +129,8 @@ private:
     DevBuf<unsigned> d_xticket_;
     DevBuf<double> d_xurows_;
     bool header_clean_ = false, keys_clean_ = false;
+    unsigned done_token_ = 0;              // completion tokens of single-workgroup launches (never 0)
+    DevBuf<uint64_t> d_accstage_;          // device copy of host-resident accumulators when a plan cannot read them in place
     char* header_ptr_ = nullptr;
     int key_parity_ = 0;
     DevBuf<double> d_pi_, d_lu_, d_left_, d_right_, d_w1_, d_w2_, d_at_;

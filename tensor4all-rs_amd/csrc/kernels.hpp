@@ -141,6 +141,10 @@ struct RrluRegArgs {
     const uint64_t* rowacc;
     const uint64_t* colacc;
     FnDevice fn;
+    // single-workgroup launches only: when non-zero, written to int word 7 of h_block after everything else the workgroup sends
+    // to the host (system-scope fence + barrier in front of it), so that the host may spin on it instead of waiting for the
+    // stream — a small bond is a 10 us kernel behind a 12 us completion
+    unsigned done_token;
 };
 // false if the shape is outside the fast path (fall back to the LDS kernel)
 bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out);

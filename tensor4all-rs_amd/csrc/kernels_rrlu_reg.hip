@@ -880,6 +880,11 @@ rrlu_reg_kernel(RrluRegArgs p)
             p.h_block[e] = (e == 1) ? ld_u64_sc1(src + 1) : src[e]; // [1] = max |a| bits: atomics of all workgroups
         }
         if (tid == 0) ((volatile int*)p.h_block)[4] = npiv;
+        if (SINGLE && p.done_token != 0u) { // everything this (only) workgroup sends to the host is out: completion token
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) ((volatile unsigned*)p.h_block)[7] = p.done_token;
+        }
         // leave the device side clean for the next launch: the max|a| word is only ever raised by the atomics of the
         // load phase (all long done), and nobody touches the other key table during this launch
         __syncthreads();

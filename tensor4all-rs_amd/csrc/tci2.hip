@@ -351,7 +351,7 @@ void Tci2::accumulate(const IndexSet& set, size_t first_site, std::vector<uint64
 
 // Accumulators of both index sets -> pinned arena -> device (one asynchronous copy on the main stream).
 void Tci2::stage_accumulators(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, const std::vector<uint64_t>* acc_a,
-                              const std::vector<uint64_t>* acc_b, const uint64_t** d_ra, const uint64_t** d_rb)
+                              const std::vector<uint64_t>* acc_b, const uint64_t** d_ra, const uint64_t** d_rb, bool in_place)
 {
     hipStream_t st = eng.stream();
     const size_t K = (size_t)fn_dev_.n_acc;
@@ -373,6 +373,11 @@ void Tci2::stage_accumulators(const IndexSet& a, size_t a0, const IndexSet& b, s
     acc_used_ += need;
     std::memcpy(ha, ra.data(), ra.size() * sizeof(uint64_t));
     std::memcpy(ha + ra.size(), rb.data(), rb.size() * sizeof(uint64_t));
+    if (in_place) { // pinned memory is device-visible under the same address
+        *d_ra = ha;
+        *d_rb = ha + ra.size();
+        return;
+    }
     d_rowacc_.reserve(need);
     static const bool dma_copy = std::getenv("T4A_ACC_DMA") != nullptr;
     if (dma_copy) {
@@ -496,7 +501,11 @@ LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
         // built-in functor: only the accumulators travel; the rrLU kernel evaluates Pi into its registers
         FusedPi fp;
         fp.fn = fn_dev_;
-        stage_accumulators(is, 0, js, is.width, acc_rows, acc_cols, &fp.d_rowacc, &fp.d_colacc);
+        // small bonds (the single-workgroup plan with the fused candidate-matrix build takes them): the kernel reads the few
+        // hundred bytes of accumulators straight from the pinned arena — no staging kernel in front of a 10 us factorisation
+        static const bool no_in_place = std::getenv("T4A_ACC_STAGE_ALWAYS") != nullptr;
+        fp.host_resident = !no_in_place && (M * N <= (size_t)64 * 64);
+        stage_accumulators(is, 0, js, is.width, acc_rows, acc_cols, &fp.d_rowacc, &fp.d_colacc, fp.host_resident);
         eng.prof.v[11] += (double)M * (double)N;
         LuciResult lu = eng.luci(nullptr, (int)M, (int)N, o, need_factors, false, &fp);
         acc_used_ = 0;

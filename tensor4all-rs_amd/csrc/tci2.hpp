@@ -135,8 +135,9 @@ private:
     void eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, double* d_out,
                      unsigned long long* d_maxbits, const std::vector<uint64_t>* acc_a = nullptr,
                      const std::vector<uint64_t>* acc_b = nullptr);
+    // in_place: hand out the pinned arena addresses themselves (no device copy): small bonds, read once by the fused kernel
     void stage_accumulators(const IndexSet& a, size_t a0, const IndexSet& b, size_t b0, const std::vector<uint64_t>* acc_a,
-                            const std::vector<uint64_t>* acc_b, const uint64_t** d_ra, const uint64_t** d_rb);
+                            const std::vector<uint64_t>* acc_b, const uint64_t** d_ra, const uint64_t** d_rb, bool in_place = false);
     std::vector<double> eval_points_host(const std::vector<uint32_t>& idx, size_t n_pts);
     void require_fn() const;
 
