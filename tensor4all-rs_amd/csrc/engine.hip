@@ -601,6 +601,11 @@ void Engine::build_factors(const LuciResult& r, bool left_orth)
     d_right_.reserve((size_t)N * (rk > 0 ? rk : 1));
     if (rk == 0) return;
     const double* lu = d_lu_.get();
+    static const bool no_small = std::getenv("T4A_NO_SMALL_FACTORS") != nullptr;
+    if (!no_small && luci_factors_small_launch(lu, M, N, rk, d_rowperm_ptr_, d_colperm_ptr_, left_orth, d_left_.get(), d_right_.get(), stream_)) {
+        T4A_HIP(hipGetLastError());
+        return;
+    }
     d_w1_.reserve((size_t)(M > N ? M : N) * rk + (size_t)rk * rk);
     d_w2_.reserve((size_t)(M > N ? M : N) * rk + (size_t)rk * rk);
     d_trsm_.reserve(1);

@@ -227,6 +227,10 @@ struct GemmDesc {
 };
 void gemm_launch(const GemmDesc& d, hipStream_t stream);
 
+// LUCI factors of a small factorisation (rank <= 16, M, N <= 1024) in one launch: lu = factored M x N matrix in permuted coordinates (ld M),
+// left: M x rk (ld M), right: rk x N (ld rk), both in original row / column order.  Returns false when the shape is not taken.
+bool luci_factors_small_launch(const double* lu, int M, int N, int rk, const int* row_perm, const int* col_perm, bool left_orth,
+                               double* left, double* right, hipStream_t stream);
 // out[c + ldo*r] = in[r + ldi*c]  (rows x cols input)
 void transpose_launch(const double* in, int rows, int cols, int ldi, double* out, int ldo, hipStream_t stream);
 

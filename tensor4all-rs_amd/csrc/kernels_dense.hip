@@ -191,6 +191,77 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LUCI factors of a SMALL factorisation in one launch (factors_from_rrlu, tensor4all-core/src/matrix_luci.rs:176-279; rank <= 16):
+//   left-orthogonal:   left = P_row^T [I_r ; L21 L11^{-1}]      right = (L11 U) P_col^T
+//   right-orthogonal:  left = P_row^T (L U11)                   right = [I_r , U11^{-1} U12] P_col^T
+// One thread per row of `left` / column of `right`; the leading r x r block sits in LDS.  The general path (engine.hip) is a
+// chain of ten launches (transposes, trsm, gemm, extracts, scatters): 50 us for a 4 x 4 bond, which is what a launch-bound
+// small problem spends most of its time on.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) luci_factors_small_kernel(const double* __restrict__ lu, int M, int N, int rk,
+                                                                 const int* __restrict__ row_perm, const int* __restrict__ col_perm,
+                                                                 int left_orth, double* left, double* right)
+{
+    extern __shared__ __attribute__((aligned(16))) double fsm[]; // fsm[i + rk * j] = lu(i, j), i, j < rk
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int e = tid; e < rk * rk; e += T) fsm[e] = lu[(e % rk) + (size_t)M * (e / rk)];
+    __syncthreads();
+    const int g = blockIdx.x * T + tid;
+    if (g < M) { // row g (permuted order) of `left`
+        const int i = g;
+        double* out = left + row_perm[i];
+        if (left_orth) {
+            if (i < rk) {
+                for (int j = 0; j < rk; ++j) out[(size_t)M * j] = (i == j) ? 1.0 : 0.0;
+            } else { // x L11 = L21(i, :), L11 unit lower: back substitution from the last column
+                for (int j = rk - 1; j >= 0; --j) {
+                    double v = lu[i + (size_t)M * j];
+                    for (int k = j + 1; k < rk; ++k) v = v - out[(size_t)M * k] * fsm[k + rk * j];
+                    out[(size_t)M * j] = v;
+                }
+            }
+        } else { // (L U11)(i, j) = sum_{k <= min(i, j)} L(i, k) U11(k, j), U11 unit upper, L keeps its diagonal
+            for (int j = 0; j < rk; ++j) {
+                const int kmax = i < j ? i : j;
+                double acc = 0.0;
+                for (int k = 0; k <= kmax; ++k) {
+                    const double lik = (i < rk) ? fsm[i + rk * k] : lu[i + (size_t)M * k];
+                    const double ukj = (k == j) ? 1.0 : fsm[k + rk * j];
+                    acc = acc + lik * ukj;
+                }
+                out[(size_t)M * j] = acc;
+            }
+        }
+    }
+    if (g < N) { // column g (permuted order) of `right`
+        const int j = g;
+        double* out = right + (size_t)rk * col_perm[j];
+        if (left_orth) { // (L11 U)(i, j) = sum_{k <= min(i, j)} L11(i, k) U(k, j), L11 unit lower
+            for (int i = 0; i < rk; ++i) {
+                const int kmax = i < j ? i : j;
+                double acc = 0.0;
+                for (int k = 0; k <= kmax; ++k) {
+                    const double lik = (k == i) ? 1.0 : fsm[i + rk * k];
+                    const double ukj = (j < rk) ? fsm[k + rk * j] : lu[k + (size_t)M * j];
+                    acc = acc + lik * ukj;
+                }
+                out[i] = acc;
+            }
+        } else {
+            if (j < rk) {
+                for (int i = 0; i < rk; ++i) out[i] = (i == j) ? 1.0 : 0.0;
+            } else { // U11 x = U12(:, j), U11 unit upper: back substitution from the last row
+                for (int i = rk - 1; i >= 0; --i) {
+                    double v = lu[i + (size_t)M * j];
+                    for (int k = i + 1; k < rk; ++k) v = v - fsm[i + rk * k] * out[k];
+                    out[i] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // small utilities
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ in, int rows, int cols, int ldi,
@@ -762,6 +833,16 @@ void gemm_launch(const GemmDesc& d, hipStream_t stream)
     const bool narrow = force_bn ? force_bn == 32 : (tiles64 < 512 && d.n > 32);
     if (narrow) gemm_launch_bn<32>(d, stream);
     else gemm_launch_bn<64>(d, stream);
+}
+
+bool luci_factors_small_launch(const double* lu, int M, int N, int rk, const int* row_perm, const int* col_perm, bool left_orth,
+                               double* left, double* right, hipStream_t stream)
+{
+    if (rk < 1 || rk > 16 || M > 1024 || N > 1024) return false; // (a thread walks rk^2 / 2 dependent steps through L2-resident rows: beyond a few hundred the general path wins)
+    const int mx = M > N ? M : N;
+    hipLaunchKernelGGL(luci_factors_small_kernel, dim3((mx + 255) / 256), dim3(256), (size_t)rk * rk * sizeof(double), stream, lu, M, N, rk,
+                       row_perm, col_perm, left_orth ? 1 : 0, left, right);
+    return true;
 }
 
 void transpose_launch(const double* in, int rows, int cols, int ldi, double* out, int ldo, hipStream_t stream)
