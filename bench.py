@@ -76,8 +76,8 @@ def patch_spec(rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the cfg2 / cfg4 / cfg5 single-GPU timings of the aux block")
     ap.add_argument("--mode", choices=["headline", "site-shard"], default="headline",

@@ -994,9 +994,11 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out)
     if ((long long)M * N <= (long long)min_elems) return false; // tiny matrices: the single-workgroup plan of the chip-wide kernel
     const int rpt = xcd_norm_rpt((M + 63) / 64);
     if (rpt < 0) return false;
-    // columns per agent: the steps are latency bound, so the cost model weighs the update pass (about 24 cycles per matrix
-    // entry of a thread at two waves per SIMD) against the key gather (about 250 cycles per 64 agents) — measured with the
-    // phase stamps at 685 x 688 and 256 x 256
+    // columns per agent: as few as the 32 compute units of an XCD allow.  A step costs an agent ~500 cycles per owned column
+    // (update, its share of the search, pivot-row extraction) and the gather is the same four key loads per lane for any
+    // number of agents up to 256 (measured per step: 2.0 - 2.2 us with one column per agent, 2.45 us with two, 2.65 us with
+    // three; T4A_XCD_COST=old restores the round-2 model that traded columns against 64-agent key groups)
+    static const bool old_cost = std::getenv("T4A_XCD_COST") != nullptr;
     static const int w_env = std::getenv("T4A_XCD_W") ? std::atoi(std::getenv("T4A_XCD_W")) : 0;
     static const int cpt_env = std::getenv("T4A_XCD_CPT") ? std::atoi(std::getenv("T4A_XCD_CPT")) : 0;
     int best_cpt = -1, best_w = 0;
@@ -1008,7 +1010,7 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out)
         const int w = (N + XWAVES * cpt - 1) / (XWAVES * cpt);
         if (w > 32) continue;
         if (rpt * cpt > XCD_MAX_VALUES) continue;
-        const long cost = 24L * rpt * cpt + 250L * ((w * XWAVES + 63) / 64);
+        const long cost = old_cost ? 24L * rpt * cpt + 250L * ((w * XWAVES + 63) / 64) : (long)cpt;
         if (best_cpt < 0 || cost < best_cost) {
             best_cpt = cpt;
             best_w = w;
