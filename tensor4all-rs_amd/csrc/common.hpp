@@ -39,41 +39,57 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 // Fails loudly when there is no GPU: the product never falls back to a CPU path.
 void require_device();
 
-// Simple grow-only device buffer.
+// process-wide caches of device blocks, pinned blocks and streams (pool.hip)
+namespace pool {
+void* dev_alloc(size_t bytes, size_t* got);
+void dev_free(void* p, size_t got);
+void* pin_alloc(size_t bytes, size_t* got);
+void pin_free(void* p, size_t got);
+hipStream_t stream_get(int kind); // 0 default priority, 1 highest, 2 lowest; non-blocking streams
+void stream_put(hipStream_t s, int kind);
+int compute_units();
+} // namespace pool
+
+// Simple grow-only device buffer (blocks come from / return to the process-wide cache).
 template <class T> struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
+    size_t bytes_ = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap)
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), bytes_(o.bytes_)
     {
         o.p = nullptr;
         o.cap = 0;
+        o.bytes_ = 0;
     }
     DevBuf& operator=(DevBuf&& o) noexcept
     {
         if (this != &o) {
-            if (p) (void)hipFree(p);
+            if (p) pool::dev_free(p, bytes_);
             p = o.p;
             cap = o.cap;
+            bytes_ = o.bytes_;
             o.p = nullptr;
             o.cap = 0;
+            o.bytes_ = 0;
         }
         return *this;
     }
     ~DevBuf()
     {
-        if (p) (void)hipFree(p);
+        if (p) pool::dev_free(p, bytes_);
     }
     void reserve(size_t n)
     {
         if (n <= cap) return;
-        if (p) T4A_HIP(hipFree(p));
+        if (p) pool::dev_free(p, bytes_);
         p = nullptr;
-        size_t want = n + n / 4 + 64;
-        T4A_HIP(hipMalloc(&p, want * sizeof(T)));
-        cap = want;
+        cap = 0;
+        const size_t want = n + n / 4 + 64;
+        p = static_cast<T*>(pool::dev_alloc(want * sizeof(T), &bytes_));
+        cap = bytes_ / sizeof(T);
     }
     T* get() const { return p; }
 };
@@ -82,21 +98,23 @@ template <class T> struct DevBuf {
 template <class T> struct PinBuf {
     T* p = nullptr;
     size_t cap = 0;
+    size_t bytes_ = 0;
     PinBuf() = default;
     PinBuf(const PinBuf&) = delete;
     PinBuf& operator=(const PinBuf&) = delete;
     ~PinBuf()
     {
-        if (p) (void)hipHostFree(p);
+        if (p) pool::pin_free(p, bytes_);
     }
     void reserve(size_t n)
     {
         if (n <= cap) return;
-        if (p) T4A_HIP(hipHostFree(p));
+        if (p) pool::pin_free(p, bytes_);
         p = nullptr;
-        size_t want = n + n / 4 + 64;
-        T4A_HIP(hipHostMalloc(&p, want * sizeof(T), hipHostMallocDefault));
-        cap = want;
+        cap = 0;
+        const size_t want = n + n / 4 + 64;
+        p = static_cast<T*>(pool::pin_alloc(want * sizeof(T), &bytes_));
+        cap = bytes_ / sizeof(T);
     }
     T* get() const { return p; }
 };

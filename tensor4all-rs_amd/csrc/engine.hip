@@ -91,22 +91,10 @@ void tri_extract_launch(const double* in, int ldi, int rows, int cols, int keep_
 Engine::Engine()
 {
     require_device();
-    int dev = 0;
-    T4A_HIP(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    T4A_HIP(hipGetDeviceProperties(&prop, dev));
-    num_cus_ = prop.multiProcessorCount;
+    num_cus_ = pool::compute_units();
     // highest priority: the latency-critical chain of bond updates gets its own hardware queue, separate from the
-    // (lowest-priority) fill_site_tensors stream that runs beside it
-    {
-        int least = 0, greatest = 0;
-        T4A_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        static const bool flat = std::getenv("T4A_FLAT_PRIORITY") != nullptr;
-        if (flat || least == greatest)
-            T4A_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-        else
-            T4A_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest));
-    }
+    // (lowest-priority) fill_site_tensors stream that runs beside it.  (Streams are recycled through the process-wide cache.)
+    stream_ = pool::stream_get(1);
     ev_rrlu_.init();
     ev_fac_.init();
     static const int xcc_env = std::getenv("T4A_XCD_ID") ? std::atoi(std::getenv("T4A_XCD_ID")) : -1;
@@ -116,10 +104,7 @@ Engine::Engine()
 
 Engine::~Engine()
 {
-    if (stream_) {
-        (void)hipStreamSynchronize(stream_);
-        (void)hipStreamDestroy(stream_);
-    }
+    if (stream_) pool::stream_put(stream_, 1); // (synchronises it)
 }
 
 LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts, bool need_factors, bool want_lu_copy,

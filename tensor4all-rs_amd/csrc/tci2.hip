@@ -166,10 +166,7 @@ Tci2::~Tci2()
 {
     if (export_event_) (void)hipEventDestroy(export_event_);
     if (fill_graph_exec_) (void)hipGraphExecDestroy(fill_graph_exec_);
-    if (fill_stream_) {
-        (void)hipStreamSynchronize(fill_stream_);
-        (void)hipStreamDestroy(fill_stream_);
-    }
+    if (fill_stream_) pool::stream_put(fill_stream_, 2); // (synchronises it)
 }
 
 void Tci2::set_builtin(int fid, int n_acc, const double* params, const uint64_t* weights)
@@ -953,15 +950,7 @@ void Tci2::fill_site_tensors_impl(bool async)
     auto hpf_t = hpf_t0;
     if (!trust_cache) invalidate_fill_cache();
     fill_wait(); // the scratch arenas of the previous fill are free again
-    if (!fill_stream_) {
-        int least = 0, greatest = 0;
-        T4A_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        static const bool flat = std::getenv("T4A_FLAT_PRIORITY") != nullptr;
-        if (flat || least == greatest)
-            T4A_HIP(hipStreamCreateWithFlags(&fill_stream_, hipStreamNonBlocking));
-        else
-            T4A_HIP(hipStreamCreateWithPriority(&fill_stream_, hipStreamNonBlocking, least));
-    }
+    if (!fill_stream_) fill_stream_ = pool::stream_get(2); // lowest priority, recycled through the process-wide cache
     const bool builtin = fn_kind_ == FnKind::Builtin;
     static const bool sync_fill = std::getenv("T4A_SYNC_FILL") != nullptr; // measurement switch: no overlap at all
     if (!builtin || sync_fill) async = false;
