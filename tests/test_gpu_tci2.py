@@ -217,6 +217,32 @@ def test_two_handles_on_two_host_threads(t4a):
         assert np.array_equal(g.bond_errors(), o.bond_errors())
 
 
+def test_recycled_buffers_and_streams_do_not_leak_state_between_handles(t4a):
+    """Handles are created and destroyed in a row with different problem sizes in between, so every device block, pinned block
+    and stream a handle gets was used by another one before (process-wide cache, pool.hip): each solve must still reproduce
+    the oracle's pivots and errors, and repeated solves of the same problem the same site tensors bit for bit."""
+    from t4a_amd.functions import quantics_osc2d
+    first = {}
+    for rep in range(3):
+        for n, chi in ((12, 24), (18, 40), (8, 16)):
+            spec = quantics_osc2d(n, k1=5, k2=9, k3=3, eps=0.2)
+            g, o = both(t4a, spec, [2] * n)
+            opts = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=chi, max_iter=5, ncheck_history=8, **PARITY)
+            for h in (g, o):
+                h.add_global_pivots([[0] * n, [1] * n])
+                h.set_max_sample_value(1.0)
+                h.optimize(opts, final_sweep1site=False)
+            assert_same_sets(g, o, n)
+            assert np.array_equal(g.bond_errors(), o.bond_errors())
+            cores = [np.array(g.site_tensor(s)) for s in range(n)]
+            if (n, chi) in first:
+                for a, b in zip(cores, first[(n, chi)]):
+                    assert np.array_equal(a, b)
+            else:
+                first[(n, chi)] = cores
+            del g
+
+
 def test_history_extras_are_merged_like_the_reference(t4a):
     """optimize loop without strict nesting: iteration t merges the I/J sets saved at the start of t-1
     (tensorci2.rs:1675-1689) — the per-bond (M, N, rank) log must agree with the oracle."""
