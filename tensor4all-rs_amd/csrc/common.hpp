@@ -48,6 +48,9 @@ void pin_free(void* p, size_t got);
 hipStream_t stream_get(int kind); // 0 default priority, 1 highest, 2 lowest; non-blocking streams
 void stream_put(hipStream_t s, int kind);
 int compute_units();
+void quiesce();       // device-wide synchronisation, never concurrent with a graph capture on one of our streams
+void capture_begin(); // bracket hipStreamBeginCapture ... hipStreamEndCapture with these
+void capture_end();
 } // namespace pool
 
 // Simple grow-only device buffer (blocks come from / return to the process-wide cache).

@@ -19,6 +19,7 @@ namespace pool {
 namespace {
 
 std::mutex g_mu;
+std::mutex g_capture_mu; // a device-wide synchronisation must not run while any of our streams records a graph: it would invalidate the capture
 struct PerDevice {
     std::map<size_t, std::vector<void*>> dev_free;  // class bytes -> blocks
     std::vector<hipStream_t> streams[3];            // 0 default priority, 1 highest, 2 lowest
@@ -51,6 +52,15 @@ int current_device()
 }
 
 } // namespace
+
+void quiesce()
+{
+    std::lock_guard<std::mutex> lk(g_capture_mu);
+    (void)hipDeviceSynchronize();
+}
+
+void capture_begin() { g_capture_mu.lock(); }
+void capture_end() { g_capture_mu.unlock(); }
 
 void* dev_alloc(size_t bytes, size_t* got)
 {
@@ -88,7 +98,7 @@ void dev_free(void* p, size_t got)
         return;
     }
     // the block may still be in use by work in flight (hipFree would have waited for it)
-    (void)hipDeviceSynchronize();
+    quiesce();
     const int dev = current_device();
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -134,7 +144,7 @@ void pin_free(void* p, size_t got)
         (void)hipHostFree(p);
         return;
     }
-    (void)hipDeviceSynchronize(); // a kernel may still be writing its result mirror / reading accumulators in place
+    quiesce(); // a kernel may still be writing its result mirror / reading accumulators in place
     std::lock_guard<std::mutex> lk(g_mu);
     g_pin_free[got].push_back(p);
 }

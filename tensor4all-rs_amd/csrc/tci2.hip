@@ -869,6 +869,7 @@ void Tci2::issue_fill_ops(std::vector<std::function<void()>>& ops, const std::ve
                 fill_graph_exec_ = nullptr;
             }
             hipGraph_t graph = nullptr;
+            pool::capture_begin(); // (no device-wide synchronisation of another handle's thread may fall into the capture)
             bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 try {
@@ -878,6 +879,7 @@ void Tci2::issue_fill_ops(std::vector<std::function<void()>>& ops, const std::ve
                 }
                 if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) ok = false;
             }
+            pool::capture_end();
             if (ok && hipGraphInstantiate(&fill_graph_exec_, graph, nullptr, nullptr, 0) != hipSuccess) {
                 fill_graph_exec_ = nullptr;
                 ok = false;

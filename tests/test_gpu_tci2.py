@@ -244,6 +244,43 @@ def test_cfg2_small_problem_parity_and_launch_bound_budget(t4a):
     assert best < 6e-3, f"cfg2 time to solution {best * 1e3:.2f} ms"
 
 
+def test_concurrent_handle_lifecycles(t4a):
+    """Handles are created, run (incl. fills, whose second identical issue is recorded as a graph) and destroyed on several
+    host threads at once: a buffer release on one thread must neither hand out memory another handle still uses nor fall into
+    another thread's graph capture (pool.hip synchronises the device under a lock the capture holds)."""
+    import threading
+    from t4a_amd.functions import quantics_osc2d
+    n = 14
+
+    def solve(k, out, errors):
+        try:
+            spec = quantics_osc2d(n, k1=3 + k, k2=9, k3=5, eps=0.2)
+            g = t4a.TensorCI2([2] * n)
+            g.set_function(spec)
+            g.add_global_pivots([[0] * n, [1] * n])
+            g.set_max_sample_value(1.0)
+            g.optimize(t4a.TCI2Options(tolerance=1e-10, max_bond_dim=32, max_iter=6, ncheck_history=8, **PARITY), final_sweep1site=False)
+            g.fill_site_tensors()
+            g.fill_site_tensors()
+            out[k] = (tuple(g.link_dims()), float(g.sum()))
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append((k, repr(e)))
+
+    ref, errors = {}, []
+    for k in range(4):
+        solve(k, ref, errors)
+    assert not errors, errors
+    for _ in range(3):
+        res = {}
+        threads = [threading.Thread(target=solve, args=(k, res, errors)) for k in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        assert res == ref
+
+
 def test_recycled_buffers_and_streams_do_not_leak_state_between_handles(t4a):
     """Handles are created and destroyed in a row with different problem sizes in between, so every device block, pinned block
     and stream a handle gets was used by another one before (process-wide cache, pool.hip): each solve must still reproduce
