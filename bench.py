@@ -534,13 +534,23 @@ def aux_timings():
         for p in range(2):
             grow(p, seq)
         t_seq = (time.perf_counter() - t0) / 2
-        ths = [threading.Thread(target=grow, args=(p, par)) for p in range(8)]
+        thread_errors = []
+
+        def grow_guarded(p, out):
+            try:
+                grow(p, out)
+            except Exception as e:  # noqa: BLE001 - an exception inside a thread would otherwise vanish
+                thread_errors.append(f"patch {p}: {e}")
+
+        ths = [threading.Thread(target=grow_guarded, args=(p, par)) for p in range(8)]
         t0 = time.perf_counter()
         for th in ths:
             th.start()
         for th in ths:
             th.join()
         t_par = (time.perf_counter() - t0) / 8
+        if thread_errors:
+            raise RuntimeError("; ".join(thread_errors))
         out["cfg5_patch_from_scratch_ms_one_at_a_time"] = t_seq * 1e3
         out["cfg5_patch_from_scratch_ms_eight_side_by_side"] = t_par * 1e3
         out["cfg5_side_by_side_results_identical"] = bool(all(par[p] == seq[p] for p in seq))
