@@ -73,6 +73,21 @@ def patch_spec(rank, world):
     return FnSpec(FN_QUANTICS_OSC2D, [K1, K2, K3, EPS, K4, DELTA, nbx, nby], w, [2] * N_SITES)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with N ranks
+    on this node (one process per GPU, rendezvous on 127.0.0.1).  Called before anything has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,11 +101,17 @@ def main():
                          "all-gather per half-sweep overlapped with the next half-sweep")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by a launcher: start the N ranks ourselves (fresh child processes, nothing has touched the GPU yet)
+        # and leave with the launcher's exit code
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
 
     import numpy as np
     import torch
@@ -104,6 +125,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the RCCL process group has {dist.get_world_size()} ranks")
 
     def barrier():
         if world > 1:
@@ -206,6 +229,7 @@ def main():
             "value": flops_all / dt_max / 1e9,
             "unit": "GF/s",
             "n_gpus": world,
+            "rccl_world_size": dist.get_world_size() if world > 1 else 1,
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / steps * 1e3,

@@ -46,7 +46,49 @@ bool xcd_disabled()
     static const bool env_off = std::getenv("T4A_NO_XCD") != nullptr;
     return env_off || g_xcd_disabled.load(std::memory_order_relaxed);
 }
-void xcd_disable() { g_xcd_disabled.store(true, std::memory_order_relaxed); }
+void xcd_disable()
+{
+    if (!g_xcd_disabled.exchange(true, std::memory_order_relaxed))
+        std::fprintf(stderr, "[t4a] single-XCD rrLU path disabled for this process (workgroup placement did not hold or a launch "
+                             "timed out); the chip-wide kernels take over\n");
+}
+
+// Placement census (once per process, first Engine): the single-XCD kernel assumes that workgroup b of a grid lands on XCD
+// b % 8 (tools/xcd_bench.hip).  On a partitioned device (CPX / NPS modes), under a CU mask or with fewer than 8 XCCs that does
+// not hold and every launch would spin until its bounded polls give up; better to find out with a 10 us kernel.
+namespace {
+__global__ void xcd_census_kernel(unsigned* counts)
+{
+    if (threadIdx.x == 0) {
+        unsigned v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        atomicAdd(&counts[v & 0xF], 1u);
+        if ((v & 0xF) != (blockIdx.x & 7u)) atomicAdd(&counts[16], 1u);
+    }
+}
+std::once_flag g_census_once;
+void xcd_census()
+{
+    if (g_xcd_disabled.load(std::memory_order_relaxed) || std::getenv("T4A_NO_XCD")) return;
+    unsigned* d = nullptr;
+    unsigned h[17] = {0};
+    if (hipMalloc(&d, sizeof(h)) != hipSuccess) return;
+    bool ok = hipMemset(d, 0, sizeof(h)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(xcd_census_kernel, dim3(256), dim3(64), 0, nullptr, d);
+        ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    if (!ok) {
+        (void)hipGetLastError();
+        return;
+    }
+    bool even = true;
+    for (int x = 0; x < 8; ++x) even &= (h[x] == 32u);
+    // (block b on XCC b % 8 is what tools/xcd_bench.hip measured; the kernel itself only needs grid / 8 workgroups per XCC)
+    if (!even) xcd_disable();
+}
+} // namespace
 int xcd_assign() { return g_xcd_next.fetch_add(1, std::memory_order_relaxed) & 7; }
 void XcdArbiter::Lock::acquire(int xcc)
 {
@@ -100,6 +142,7 @@ Engine::Engine()
     static const int xcc_env = std::getenv("T4A_XCD_ID") ? std::atoi(std::getenv("T4A_XCD_ID")) : -1;
     // (T4A_XCD_ID=8: an XCC id no workgroup reports — exercises the fallback to the chip-wide kernel in the tests)
     xcc_ = xcc_env >= 0 ? (xcc_env > 8 ? (xcc_env & 7) : xcc_env) : xcd_assign();
+    std::call_once(g_census_once, xcd_census);
 }
 
 Engine::~Engine()

@@ -8,6 +8,8 @@
 // Values of these ops are tolerance-level in the reference (third-party tenferro); pivot choice in the LU is
 // "first maximum of |a_ik|".  Built with -ffp-contract=off so the non-MFMA kernels round like the CPU oracle.
 #include "kernels.hpp"
+
+#include <atomic>
 #include "common.hpp"
 
 #include <cstdlib>
@@ -816,7 +818,7 @@ template <int BN> static void gemm_launch_bn(const GemmDesc& d, hipStream_t stre
 {
     dim3 grid((d.m + GBM - 1) / GBM, (d.n + BN - 1) / BN, d.batch);
     constexpr size_t lds = 2 * sizeof(double) * GBK * ((GBM + GPAD) + (BN + GPAD));
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false}; // (launches come from several host threads; setting the attribute twice is harmless)
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
@@ -895,7 +897,7 @@ void trsm_left_batched_launch(const TrsmProblem* d_problems, int n_problems, int
                               hipStream_t stream)
 {
     if (n_problems <= 0 || max_n <= 0 || max_nrhs <= 0) return;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false}; // (launches come from several host threads; setting the attribute twice is harmless)
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_left_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -951,7 +953,7 @@ bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int 
     else if (max_n <= 512) nb = 16;
     else if (max_n <= 1024) nb = 8;
     else return false; // panel does not fit the LDS: the caller falls back to lu_kernel + trsm
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false}; // (launches come from several host threads; setting the attribute twice is harmless)
     if (!attr_set) {
         // (the panel kernel also has a few static LDS words: stay below the 160 KiB total)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_panel_kernel),

@@ -7,6 +7,8 @@
 // U diag(S) Vt == A and Q R == A to rounding.
 #include "kernels.hpp"
 
+#include <atomic>
+
 namespace t4a {
 
 namespace {
@@ -351,7 +353,7 @@ bool jacobi_fits_small(int m, int n) { return n <= 128 && m <= 2048; }
 
 void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream)
 {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false}; // (launches come from several host threads; setting the attribute twice is harmless)
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_small_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);

@@ -28,6 +28,8 @@
 //     every spin is bounded and reports T4A_GPU_KERNEL_TIMEOUT instead of hanging.
 #include "kernels.hpp"
 
+#include <atomic>
+
 #include <cstdlib>
 
 namespace t4a {
@@ -560,7 +562,7 @@ size_t rrlu_cols_bytes(const RrluPlan& plan, int M) { return (size_t)2 * plan.W 
 
 void rrlu_launch(const RrluPlan& plan, const RrluArgs& a, hipStream_t stream)
 {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false}; // (launches come from several host threads; setting the attribute twice is harmless)
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -38,6 +38,8 @@
 #define T4A_RRLU_SPEC2 1
 #include "kernels.hpp"
 
+#include <mutex>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -896,12 +898,11 @@ rrlu_reg_kernel(RrluRegArgs p)
 template <int RPT, int CPT, bool SINGLE, bool UNI, bool ROWMAJOR>
 void launch_tie(const RrluRegPlan& plan, const RrluRegArgs& a, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once; // (launches come from several host threads)
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_reg_kernel<RPT, CPT, SINGLE, UNI, ROWMAJOR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL((rrlu_reg_kernel<RPT, CPT, SINGLE, UNI, ROWMAJOR>), dim3(SINGLE ? 1 : plan.W), dim3(plan.T), plan.lds_bytes,
                        stream, a);
 }

@@ -34,6 +34,7 @@
 #include "kernels.hpp"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace t4a {
 
@@ -941,12 +942,11 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
 
 template <int RPT, int CPT, bool ROWMAJOR> void xcd_launch_tie(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once; // (launches come from several host threads)
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_xcd_kernel<RPT, CPT, ROWMAJOR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL((rrlu_xcd_kernel<RPT, CPT, ROWMAJOR>), dim3(plan.grid), dim3(XT), plan.lds_bytes, stream, a);
 }
 

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace t4a {
@@ -27,9 +28,15 @@ struct PerDevice {
 };
 std::map<int, PerDevice> g_dev;
 std::map<size_t, std::vector<void*>> g_pin_free;  // pinned host memory is not per device
-size_t g_cached_bytes = 0;
+size_t g_cached_bytes = 0;      // device blocks in the free lists
+size_t g_cached_pin_bytes = 0;  // pinned blocks in the free list (page-locked memory is the scarcer resource: its own, lower cap)
 constexpr size_t kBypass = (size_t)256 << 20;  // blocks of this size and more go straight to the driver
 constexpr size_t kCacheLimit = (size_t)16 << 30;
+constexpr size_t kPinCacheLimit = (size_t)1 << 30;
+// this thread is recording a graph (it holds g_capture_mu): a release must neither wait for the device (it would invalidate the
+// capture) nor take g_capture_mu again (self-deadlock).  Blocks released meanwhile are parked and handed in at capture_end().
+thread_local bool t_in_capture = false;
+thread_local std::vector<std::pair<void*, size_t>> t_parked_dev, t_parked_pin;
 
 bool disabled()
 {
@@ -51,16 +58,73 @@ int current_device()
     return dev;
 }
 
-} // namespace
-
-void quiesce()
+// device a block was allocated on (a process may drive several devices: the free list of the CURRENT device is the wrong one then)
+int device_of(const void* p)
 {
-    std::lock_guard<std::mutex> lk(g_capture_mu);
-    (void)hipDeviceSynchronize();
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) return attr.device;
+    (void)hipGetLastError();
+    return current_device();
 }
 
-void capture_begin() { g_capture_mu.lock(); }
-void capture_end() { g_capture_mu.unlock(); }
+// hands every cached device block of `dev` back to the driver (allocation failure: the cache itself may be what fills the HBM)
+void trim_device_cache(int dev)
+{
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& kv : g_dev[dev].dev_free) {
+            for (void* b : kv.second) {
+                blocks.push_back(b);
+                g_cached_bytes -= kv.first;
+            }
+            kv.second.clear();
+        }
+    }
+    for (void* b : blocks) (void)hipFree(b);
+}
+
+void trim_pin_cache()
+{
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& kv : g_pin_free) {
+            for (void* b : kv.second) blocks.push_back(b);
+            kv.second.clear();
+        }
+        g_cached_pin_bytes = 0;
+    }
+    for (void* b : blocks) (void)hipHostFree(b);
+}
+
+// device-wide synchronisation outside any graph capture of ours; false when the device reported an (asynchronous) error —
+// a block or stream that may still be in use must not be recycled then
+bool quiesce_ok()
+{
+    std::lock_guard<std::mutex> lk(g_capture_mu);
+    return hipDeviceSynchronize() == hipSuccess;
+}
+
+} // namespace
+
+void quiesce() { (void)quiesce_ok(); }
+
+void capture_begin()
+{
+    g_capture_mu.lock();
+    t_in_capture = true;
+}
+void capture_end()
+{
+    t_in_capture = false;
+    g_capture_mu.unlock();
+    std::vector<std::pair<void*, size_t>> d, h;
+    d.swap(t_parked_dev);
+    h.swap(t_parked_pin);
+    for (auto& b : d) dev_free(b.first, b.second);
+    for (auto& b : h) pin_free(b.first, b.second);
+}
 
 void* dev_alloc(size_t bytes, size_t* got)
 {
@@ -85,7 +149,11 @@ void* dev_alloc(size_t bytes, size_t* got)
         }
     }
     void* p = nullptr;
-    T4A_HIP(hipMalloc(&p, c));
+    if (hipMalloc(&p, c) != hipSuccess) { // the cached blocks of other size classes may be what is in the way: release them, try once more
+        (void)hipGetLastError();
+        trim_device_cache(dev);
+        T4A_HIP(hipMalloc(&p, c));
+    }
     *got = c;
     return p;
 }
@@ -93,14 +161,19 @@ void* dev_alloc(size_t bytes, size_t* got)
 void dev_free(void* p, size_t got)
 {
     if (!p) return;
+    if (t_in_capture) {
+        t_parked_dev.emplace_back(p, got);
+        return;
+    }
     if (disabled() || got >= kBypass) {
-        (void)hipFree(p); // (synchronises the device)
+        std::lock_guard<std::mutex> lk(g_capture_mu); // hipFree synchronises the device: never inside another thread's capture
+        (void)hipFree(p);
         return;
     }
     // the block may still be in use by work in flight (hipFree would have waited for it)
-    quiesce();
-    const int dev = current_device();
-    {
+    const bool idle = quiesce_ok();
+    const int dev = device_of(p);
+    if (idle) {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_cached_bytes + got <= kCacheLimit) {
             g_dev[dev].dev_free[got].push_back(p);
@@ -108,7 +181,7 @@ void dev_free(void* p, size_t got)
             return;
         }
     }
-    (void)hipFree(p);
+    (void)hipFree(p); // over the limit, or the device is in an error state: not ours to hand out again
 }
 
 void* pin_alloc(size_t bytes, size_t* got)
@@ -127,12 +200,17 @@ void* pin_alloc(size_t bytes, size_t* got)
         if (!fl.empty()) {
             void* p = fl.back();
             fl.pop_back();
+            g_cached_pin_bytes -= c;
             *got = c;
             return p;
         }
     }
     void* p = nullptr;
-    T4A_HIP(hipHostMalloc(&p, c, hipHostMallocDefault));
+    if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        trim_pin_cache();
+        T4A_HIP(hipHostMalloc(&p, c, hipHostMallocDefault));
+    }
     *got = c;
     return p;
 }
@@ -140,13 +218,25 @@ void* pin_alloc(size_t bytes, size_t* got)
 void pin_free(void* p, size_t got)
 {
     if (!p) return;
+    if (t_in_capture) {
+        t_parked_pin.emplace_back(p, got);
+        return;
+    }
     if (disabled() || got >= kBypass) {
+        std::lock_guard<std::mutex> lk(g_capture_mu);
         (void)hipHostFree(p);
         return;
     }
-    quiesce(); // a kernel may still be writing its result mirror / reading accumulators in place
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_pin_free[got].push_back(p);
+    const bool idle = quiesce_ok(); // a kernel may still be writing its result mirror / reading accumulators in place
+    if (idle) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_cached_pin_bytes + got <= kPinCacheLimit) {
+            g_pin_free[got].push_back(p);
+            g_cached_pin_bytes += got;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
 }
 
 hipStream_t stream_get(int kind)
@@ -175,8 +265,8 @@ hipStream_t stream_get(int kind)
 void stream_put(hipStream_t s, int kind)
 {
     if (!s) return;
-    (void)hipStreamSynchronize(s);
-    if (disabled()) {
+    const bool idle = hipStreamSynchronize(s) == hipSuccess;
+    if (disabled() || !idle) { // (a stream whose work faulted is not handed to the next handle)
         (void)hipStreamDestroy(s);
         return;
     }

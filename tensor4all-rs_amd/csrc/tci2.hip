@@ -165,6 +165,8 @@ Tci2::Tci2(const std::vector<size_t>& dims) : n_(dims.size()), local_dims(dims) 
 Tci2::~Tci2()
 {
     if (export_event_) (void)hipEventDestroy(export_event_);
+    if (import_event_) (void)hipEventDestroy(import_event_);
+    if (import_stream_) pool::stream_put(import_stream_, 2); // (synchronises it)
     if (fill_graph_exec_) (void)hipGraphExecDestroy(fill_graph_exec_);
     if (fill_stream_) pool::stream_put(fill_stream_, 2); // (synchronises it)
 }
@@ -913,6 +915,10 @@ void Tci2::flush_deferred_fill()
 void Tci2::fill_wait()
 {
     flush_deferred_fill();
+    if (import_inflight_) { // cores of the other ranks' sites (site-sharded fill) still on their way into this handle
+        import_inflight_ = false;
+        T4A_HIP(hipStreamSynchronize(import_stream_));
+    }
     if (!fill_inflight_) return;
     fill_inflight_ = false;
     T4A_HIP(hipStreamSynchronize(fill_stream_));
@@ -1350,14 +1356,20 @@ void Tci2::export_site_shard_async(double* d_dst, size_t stride, hipStream_t con
 }
 
 // The other ranks' cores out of the gathered buffer [world][per_rank][stride]: site s of rank r = s % world sits at
-// (r * per_rank + s / world) * stride.  Shapes follow from the (replicated) index sets.  The copies run on this handle's
-// stream after everything `producer` (the all-gather's stream) has enqueued so far; nothing blocks the host.
+// (r * per_rank + s / world) * stride.  Shapes follow from the (replicated) index sets AS THEY ARE NOW: call this in the same
+// half-sweep as the export on the other ranks (parallel.ShardedCoreExchange does), before the next bond update changes a
+// bond dimension.  The copies run on the handle's import stream after everything `producer` (the all-gather's stream) has
+// enqueued so far; nothing blocks the host, the local fill still in flight is not waited for (it writes other sites), and
+// the first reader of a core (fill_wait) waits for the import.
 void Tci2::import_site_shard_async(const double* d_src, size_t stride, size_t per_rank, hipStream_t producer)
 {
-    fill_wait();
+    if (!import_stream_) import_stream_ = pool::stream_get(2);
+    // at most one import in flight: the one of the previous half-sweep is long done (a whole chain of bond updates ago),
+    // and with it every read of the receive buffer that the caller is about to reuse
+    T4A_HIP(hipStreamSynchronize(import_stream_));
     if (!import_event_) T4A_HIP(hipEventCreateWithFlags(&import_event_, hipEventDisableTiming));
     T4A_HIP(hipEventRecord(import_event_, producer));
-    T4A_HIP(hipStreamWaitEvent(eng.stream(), import_event_, 0));
+    T4A_HIP(hipStreamWaitEvent(import_stream_, import_event_, 0));
     for (size_t s = 0; s < n_; ++s) {
         const size_t r = s % shard_world;
         if (r == shard_rank) continue;
@@ -1371,8 +1383,9 @@ void Tci2::import_site_shard_async(const double* d_src, size_t stride, size_t pe
         c.s = local_dims[s];
         c.r = rr;
         T4A_HIP(hipMemcpyAsync(c.buf.get(), d_src + (r * per_rank + s / shard_world) * stride, count * sizeof(double),
-                               hipMemcpyDeviceToDevice, eng.stream()));
+                               hipMemcpyDeviceToDevice, import_stream_));
     }
+    import_inflight_ = true;
 }
 
 // =================================================================================================

@@ -209,7 +209,8 @@ private:
     DevBuf<TrsmProblem> d_trp_;
     DevBuf<unsigned long long> d_fillmax_;
     EventTimer ev_pi_, ev_fill_;
-    hipStream_t fill_stream_ = nullptr;
+    hipStream_t fill_stream_ = nullptr, import_stream_ = nullptr;
+    bool import_inflight_ = false;
     hipEvent_t export_event_ = nullptr, import_event_ = nullptr;
     bool fill_inflight_ = false, fill_timed_ = false;
     std::vector<size_t> fill_solved_sites_;

@@ -564,6 +564,11 @@ class TensorCI2:
 
     def set_site_shard(self, rank, world):
         _check(_lib.t4a_gpu_tci2_set_site_shard(self._h, c_size_t(rank), c_size_t(world)))
+        self._site_shard = (int(rank), int(world))
+
+    def site_shard(self):
+        """(rank, world) of the site-sharded fill set by set_site_shard ((0, 1): not sharded)."""
+        return getattr(self, "_site_shard", (0, 1))
 
     def history(self):
         n = c_size_t(0)

@@ -103,12 +103,24 @@ def sharded_fill(dist, torch, n_sites, fill_my_sites, get_core, set_core, device
 class ShardedCoreExchange:
     """Device-resident core exchange of the site-sharded fill (BASELINE.json configs[3]): every rank fills the sites
     s % world == rank, packs them into a padded buffer [per_rank][cap] (cap = largest core), ONE all_gather_into_tensor per
-    half-sweep moves them, every rank unpacks the other ranks' sites.  Two buffer pairs alternate so that the collective of
-    half-sweep k can still be in flight while half-sweep k + 1 runs its bond updates.
+    half-sweep moves them, every rank unpacks the other ranks' sites.
+
+    Ordering.  `exchange()` is called right after the local fill of a half-sweep has been issued and does everything for THAT
+    half-sweep without blocking the host: export (ordered after the fill on the device), collective (asynchronous), import
+    (ordered after the collective on the device, on the handle's import stream).  Export and import therefore see the same
+    (replicated) index sets — the importer sizes the remote cores from its own bond dimensions, which is only right while no
+    bond update has run in between.  The data itself may still be travelling while the next half-sweep's bond updates run
+    (they only touch the index sets); the first reader of a core waits for it.  Two buffer pairs alternate, so a buffer is
+    reused two half-sweeps after its collective was issued.
+
+    Shape check.  Every rank also gathers the (l, s, r) of the cores it exported; when a buffer pair comes up for reuse (or at
+    `finish()`), the gathered shapes are compared with the ones the importer assumed and a mismatch raises — the ranks were
+    not replicas of each other (different options, a missed half-sweep), and the imported cores would have been
+    reinterpreted silently.
 
     `adapter` hides where the cores live:
-      export_shard(send_tensor)              local cores -> send_tensor viewed as [per_rank, cap]
-      import_shard(recv_tensor, per_rank)    remote cores <- recv_tensor viewed as [world, per_rank, cap]
+      export_shard(send_tensor) -> [(l, s, r)] of the local sites   local cores -> send_tensor viewed as [per_rank, cap]
+      import_shard(recv_tensor, per_rank) -> {site: (l, s, r)}      remote cores <- recv_tensor viewed as [world, per_rank, cap]
     DeviceShardAdapter (below) does both with device-to-device copies through the C ABI; tests/test_cpu_parallel.py runs the
     same orchestration on gloo with a numpy adapter around the CPU oracle."""
 
@@ -116,53 +128,94 @@ class ShardedCoreExchange:
         self.dist, self.torch, self.adapter = dist, torch, adapter
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        self.n_sites = n_sites
         self.per_rank = (n_sites + self.world - 1) // self.world
         self.cap = cap
+        self.is_cuda = str(device).startswith("cuda")
         self.send = [torch.zeros(self.per_rank * cap, dtype=torch.float64, device=device) for _ in range(2)]
         self.recv = [torch.zeros(self.world * self.per_rank * cap, dtype=torch.float64, device=device) for _ in range(2)]
-        self.pending = [None, None]         # collective handles
-        self.outstanding = [False, False]   # an exchange on this buffer pair has not been imported yet
+        self.send_dims = [torch.zeros(self.per_rank * 3, dtype=torch.int64, device=device) for _ in range(2)]
+        self.recv_dims = [torch.zeros(self.world * self.per_rank * 3, dtype=torch.int64, device=device) for _ in range(2)]
+        self.assumed = [None, None]         # {site: (l, s, r)} the importer used for exchange k
+        self.done = [None, None]            # device event / work handles: everything of exchange k has been enqueued / finished
+        self.outstanding = [False, False]
         self.count = 0
 
     def exchange(self):
-        """Called after the local fill of a half-sweep: returns without waiting for the collective on the host."""
+        """Called after the local fill of a half-sweep: export, all-gather and import of THIS half-sweep, nothing waited for
+        on the host except the (long finished) exchange that used the same buffer pair two half-sweeps ago."""
+        torch = self.torch
         k = self.count % 2
         self.count += 1
-        self.finish(k)  # the exchange that used this buffer pair two half-sweeps ago
-        self.adapter.export_shard(self.send[k])
-        work = None
+        self.finish(k)
+        dims = self.adapter.export_shard(self.send[k])
+        flat = [int(v) for d in dims for v in d] + [0] * (3 * self.per_rank - 3 * len(dims))
+        self.send_dims[k].copy_(torch.tensor(flat, dtype=torch.int64), non_blocking=True)
+        works = []
         if self.world > 1:
-            work = self.dist.all_gather_into_tensor(self.recv[k], self.send[k], async_op=True)
+            works.append(self.dist.all_gather_into_tensor(self.recv[k], self.send[k], async_op=True))
+            works.append(self.dist.all_gather_into_tensor(self.recv_dims[k], self.send_dims[k], async_op=True))
+            for w in works:
+                w.wait()  # RCCL: stream-level dependency only; gloo: completion
         else:
             self.recv[k].copy_(self.send[k])
-        self.pending[k] = work
+            self.recv_dims[k].copy_(self.send_dims[k])
+        self.assumed[k] = self.adapter.import_shard(self.recv[k], self.per_rank)
+        if self.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.done[k] = ev
         self.outstanding[k] = True
         return k
 
     def finish(self, k=None):
-        """Make the cores of exchange k (default: every outstanding one, oldest first) visible in the local handle."""
+        """Completes exchange k (default: every outstanding one, oldest first) on the host and checks the gathered shapes."""
         for kk in ([k] if k is not None else [self.count % 2, (self.count + 1) % 2]):
             if not self.outstanding[kk]:
                 continue
-            if self.pending[kk] is not None:
-                self.pending[kk].wait()  # stream-level dependency on the GPU, completion on gloo
-            self.adapter.import_shard(self.recv[kk], self.per_rank)
-            self.pending[kk] = None
+            if self.done[kk] is not None:
+                self.done[kk].synchronize()
+                self.done[kk] = None
+            got = self.recv_dims[kk].cpu().numpy().reshape(self.world, self.per_rank, 3)
+            for s, want in (self.assumed[kk] or {}).items():
+                have = tuple(int(v) for v in got[s % self.world, s // self.world])
+                if have != tuple(int(v) for v in want):
+                    raise RuntimeError(f"site-sharded core exchange: rank {s % self.world} exported site {s} as {have}, rank "
+                                       f"{self.rank} imported it as {tuple(want)} — the ranks do not hold the same index sets")
+            self.assumed[kk] = None
             self.outstanding[kk] = False
+
+
+def _site_dims(link_dims, local_dims, s):
+    n = len(local_dims)
+    l = 1 if s == 0 else max(int(link_dims[s - 1]), 1)
+    r = 1 if s == n - 1 else max(int(link_dims[s]), 1)
+    return (l, int(local_dims[s]), r)
 
 
 class DeviceShardAdapter:
     """Cores stay in HBM: export / import are device-to-device copies ordered by events (t4a_gpu_tci2_export_site_shard_async,
-    t4a_gpu_tci2_import_site_shard_async); the all-gather runs on torch's current stream."""
+    t4a_gpu_tci2_import_site_shard_async); the all-gather runs on torch's current stream.  Shapes come from the handle's
+    (replicated) bond dimensions at the time of the call."""
 
     def __init__(self, tci, torch, cap):
         self.tci, self.torch, self.cap = tci, torch, cap
 
+    def _dims(self):
+        ld, loc = self.tci.link_dims(), self.tci.local_dims
+        return [_site_dims(ld, loc, s) for s in range(len(loc))]
+
     def export_shard(self, send):
+        rank, world = self.tci.site_shard()
         self.tci.export_site_shard_async(send.data_ptr(), self.cap, self.torch.cuda.current_stream().cuda_stream)
+        dims = self._dims()
+        return [dims[s] for s in range(rank, len(dims), world)]
 
     def import_shard(self, recv, per_rank):
+        rank, world = self.tci.site_shard()
         self.tci.import_site_shard_async(recv.data_ptr(), self.cap, per_rank, self.torch.cuda.current_stream().cuda_stream)
+        dims = self._dims()
+        return {s: dims[s] for s in range(len(dims)) if s % world != rank}
 
 
 class NumpyShardAdapter:
@@ -174,15 +227,21 @@ class NumpyShardAdapter:
 
     def export_shard(self, send):
         buf = send.view(-1, self.cap)
+        dims = []
         for k, s in enumerate(range(self.rank, self.n_sites, self.world)):
             flat = np.asarray(self.store[s], dtype=np.float64).ravel(order="F")
             buf[k, :flat.size] = self.torch.from_numpy(flat.copy())
+            dims.append(tuple(int(v) for v in np.asarray(self.store[s]).shape))
+        return dims
 
     def import_shard(self, recv, per_rank):
         buf = recv.view(self.world, per_rank, self.cap).numpy()
+        used = {}
         for s in range(self.n_sites):
             r = s % self.world
             if r == self.rank:
                 continue
             l, d, rr = self.dims_of(s)
             self.store[s] = np.array(buf[r, s // self.world, :l * d * rr]).reshape((l, d, rr), order="F")
+            used[s] = (int(l), int(d), int(rr))
+        return used

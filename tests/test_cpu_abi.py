@@ -154,3 +154,30 @@ def test_builtin_function_specs_are_consistent_with_the_oracle_evaluation():
     ref = np.cos(2 * np.pi * x) * np.cos(4 * np.pi * y) + 0.25 * np.sin(6 * np.pi * (x + y)) / (1 + x * x + y * y) \
         + 0.5 * np.cos(2 * np.pi * 5 * x * y)
     assert np.abs(ob.fn_eval(spec, idx) - ref).max() < 1e-13
+
+
+def test_bench_gpus_flag_is_checked_against_the_launcher():
+    """bench.py --gpus N: a launcher-provided WORLD_SIZE that disagrees is an error (no silent world-1 run), and the
+    self-launch command line starts N ranks on 127.0.0.1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env,
+                         timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd
+        return 7
+
+    real = subprocess.call
+    subprocess.call = fake_call
+    try:
+        assert bench.self_launch(8) == 7
+    finally:
+        subprocess.call = real
+    cmd = seen["cmd"]
+    assert "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd and cmd[cmd.index("-m") + 1] == "torch.distributed.run"

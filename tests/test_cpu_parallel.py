@@ -74,6 +74,19 @@ def _worker(rank, world, port, n_patches, out_dir):
     assert sorted(store2) == [0, 1, 2, 3]
     for s in range(4):
         assert store2[s].shape == full[s].shape and np.array_equal(store2[s], full[s] * 3.0), s
+    # ranks that are NOT replicas of each other: the importer assumes another bond dimension than the exporter packed.  The
+    # gathered (l, s, r) header exposes it (the old exchange reinterpreted the remote cores silently).
+    wrong = dict(dims)
+    wrong[1 - rank] = (dims[1 - rank][0], dims[1 - rank][1], dims[1 - rank][2] + 1)   # a site of the other rank
+    cap3 = cap + 64
+    bad = parallel.ShardedCoreExchange(dist, torch, 4, cap3, parallel.NumpyShardAdapter(torch, dict(store2), 4, rank, world, cap3,
+                                                                                      lambda s: wrong[s]), "cpu")
+    bad.exchange()
+    try:
+        bad.finish()
+        raise AssertionError("shape mismatch between exporter and importer went unnoticed")
+    except RuntimeError as e:
+        assert "do not hold the same index sets" in str(e)
     dist.barrier()
     dist.destroy_process_group()
 
