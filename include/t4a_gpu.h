@@ -689,6 +689,15 @@ t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out /* [T
  * 100000 + RPT*100 + CPT*10 + 4*row_major_ties; otherwise as slot 15 of t4a_gpu_tci2_profile_get. */
 t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out /* [cap_rows][5] */, size_t cap_rows, size_t* n_rows);
 
+/* Device-side bond chain (the host-free half-sweep of update_pivots, tensorci2.rs:1695-1725 + :1821-2007 for built-in
+ * functors): out[0] half-sweeps enqueued as one chain, out[1] bond updates inside such chains, out[2] chains that fell back to
+ * the per-bond path part-way (a launch gave up), out[3] half-sweeps that were not eligible (host callback, rook search, shapes
+ * beyond the device-dimension kernels) and ran bond by bond. */
+t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out /* [4] */);
+/* enable == 0: this handle runs every half-sweep bond by bond (A/B measurements, tests).  verify != 0: after every chain the
+ * device-side index tables are read back and compared with the host's I / J sets (T4A_GPU_INTERNAL_ERROR on a difference). */
+t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t verify);
+
 /* Evaluate a built-in function on the device for a batch of full multi-indices (parity check of the
  * workload definition itself).  idx: n_sites x n_pts column-major. */
 t4a_gpu_status t4a_gpu_fn_eval(int32_t fid, int32_t n_acc, const double* params, const uint64_t* weights,

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "kernels_rrlu_xcd.hip", "kernels_rrlu_global.hip", "kernels_pi.hip", "kernels_dense.hip", "kernels_linalg.hip",
-           "kernels_tt.hip", "pool.hip", "engine.hip", "rook.hip", "tt.hip", "globalsearch.hip", "tci2.hip", "conversion.hip", "patching.hip", "tree.hip", "quantics.hip", "tensorops.hip", "aci.hip", "capi.hip"]
+SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "kernels_rrlu_xcd.hip", "kernels_rrlu_global.hip", "kernels_pi.hip", "kernels_chain.hip", "kernels_dense.hip", "kernels_linalg.hip",
+           "kernels_tt.hip", "pool.hip", "engine.hip", "rook.hip", "tt.hip", "globalsearch.hip", "tci2.hip", "tci2_chain.hip", "conversion.hip", "patching.hip", "tree.hip", "quantics.hip", "tensorops.hip", "aci.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"] + os.environ.get("T4A_EXTRA_FLAGS", "").split()  # e.g. -DT4A_RRLU_TRACE (tools/trace_arrivals.py)
 # per-source flags.  kernels_dense.hip: keep MFMA accumulators in VGPRs — in AGPR form the compiler moves all of them between the
@@ -22,6 +22,31 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 FILE_FLAGS = {"kernels_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "globalsearch.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
            "../../include/t4a_testfunctions.h"]
+
+
+_INC_CACHE = {}
+
+
+def _includes(path):
+    """Headers a source includes with quotes, transitively (only files that exist next to it / relative to it)."""
+    path = os.path.normpath(path)
+    if path in _INC_CACHE:
+        return _INC_CACHE[path]
+    _INC_CACHE[path] = set()
+    found = set()
+    try:
+        with open(path) as f:
+            text = f.read()
+    except OSError:
+        return found
+    import re
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        cand = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if os.path.exists(cand):
+            found.add(cand)
+            found |= _includes(cand)
+    _INC_CACHE[path] = found
+    return found
 
 
 def _newer(target, deps):
@@ -52,7 +77,7 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
+        if force or _newer(obj, [src] + sorted(_includes(src))):
             jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):

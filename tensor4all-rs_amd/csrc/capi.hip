@@ -699,6 +699,7 @@ t4a_gpu_status t4a_gpu_tci2_index_set(const t4a_gpu_tci2* h, int32_t which, size
         T4A_REQUIRE_PTR(count);
         T4A_REQUIRE_PTR(width);
         if (site >= h->impl.len() || which < 0 || which > 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "site/which out of range");
+        if (out) const_cast<t4a_gpu_tci2*>(h)->impl.sync_digits(); // (after a device-side bond chain the digit tables are decoded on demand)
         const IndexSet& s = which == 0 ? h->impl.i_set[site] : h->impl.j_set[site];
         *count = s.count;
         *width = s.width;
@@ -712,6 +713,7 @@ t4a_gpu_status t4a_gpu_tci2_set_index_set(t4a_gpu_tci2* h, int32_t which, size_t
     return guarded([&] {
         T4A_REQUIRE_PTR(h);
         if (site >= h->impl.len() || which < 0 || which > 1) throw Error(T4A_GPU_INVALID_ARGUMENT, "site/which out of range");
+        h->impl.sync_digits();
         IndexSet& s = which == 0 ? h->impl.i_set[site] : h->impl.j_set[site];
         const size_t first_site = which == 0 ? 0 : site + 1;
         if (count * s.width) T4A_REQUIRE_PTR(data);
@@ -727,6 +729,7 @@ t4a_gpu_status t4a_gpu_tci2_set_index_set(t4a_gpu_tci2* h, int32_t which, size_t
             }
         s = n;
         h->impl.invalidate_site_tensors();
+        h->impl.mark_sets_changed();
     });
 }
 
@@ -742,8 +745,7 @@ t4a_gpu_status t4a_gpu_tci2_clear_history(t4a_gpu_tci2* h)
 {
     return guarded([&] {
         T4A_REQUIRE_PTR(h);
-        h->impl.i_set_history.clear();
-        h->impl.j_set_history.clear();
+        h->impl.clear_history();
     });
 }
 
@@ -970,6 +972,24 @@ t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out,
     });
 }
 
+
+t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        for (int k = 0; k < 4; ++k) out[k] = h->impl.chain_stats[k];
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t verify)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        h->impl.chain_enabled = enable != 0;
+        h->impl.chain_verify = verify != 0;
+    });
+}
 
 // ------------------------------------------------------------------------------------------------ lazy block-rook LUCI
 extern "C++" {

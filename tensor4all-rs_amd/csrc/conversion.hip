@@ -234,14 +234,14 @@ void Tci2::assign_from_tensor_train(const TensorTrain& src, const FromTensorTrai
     // from_parts_for_conversion (tensorci2.rs:406-447)
     i_set = iset;
     j_set = jset;
+    mark_sets_changed();
     for (size_t p = 0; p < n_; ++p) {
         i_set[p].width = p;
         j_set[p].width = n_ - p - 1;
     }
     pivot_errors = perr;
     bond_errors.assign(n_ - 1, 0.0);
-    i_set_history.clear();
-    j_set_history.clear();
+    clear_history();
     // max_site_tensor_abs :426-433
     T4A_HIP(hipMemsetAsync(d_maxbits_.get(), 0, sizeof(unsigned long long), st));
     for (size_t s = 0; s < n_; ++s) absmax_launch(tt[s].buf.get(), tt[s].size(), d_maxbits_.get(), st);

@@ -2,6 +2,7 @@
 // (matrix_luci_factors_from_matrix / factors_from_rrlu, tensor4all-core/src/matrix_luci.rs:256-290,366-374).
 #include "engine.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,7 @@ __global__ void __launch_bounds__(256) tri_extract_kernel(const double* __restri
 // same compute units would starve each other until the bounded spins give up.  A single-XCD launch owns one of the eight XCDs
 // for its duration, a chip-wide launch (old register kernel, LDS kernel) owns all of them.
 namespace {
+constexpr int kXcdSharedMaxW = 28; // single-XCD plans up to this many workgroups leave room for other handles' pass-through workgroups
 std::mutex g_xcd_mutex[8];
 std::atomic<int> g_xcd_next{0};
 std::atomic<bool> g_xcd_disabled{false};
@@ -299,8 +301,15 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         std::memset(h_out_.get(), 0, 32);
         a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());
         a.block_u64 = (int)(out_bytes / 8);
+        a.dims = nullptr;
+        a.dims_swap = 0;
+        a.rowmap = nullptr;
+        std::memset(&a.spec, 0, sizeof(a.spec));
+        a.ts_u64 = 0;
         mirrored = true;
-        xcd_lock.acquire(xcc_);
+        // a launch has 8 W workgroups of which 7 W pass through the other XCDs and need a free compute unit there for a moment:
+        // two handles that each fill (nearly) all 32 compute units of their XCD would block each other's dispatch
+        xcd_lock.acquire(xplan.W > kXcdSharedMaxW ? -1 : xcc_);
         rrlu_xcd_launch(xplan, a, stream_);
         plan_W = xplan.W;
         plan_T = 512;
@@ -391,6 +400,11 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.h_block = reinterpret_cast<unsigned long long*>(h_out_.get());
         a.block_u64 = (int)(out_bytes / 8);
         a.done_token = 0u;
+        a.dims = nullptr;
+        a.dims_swap = 0;
+        a.dev_token = 0u;
+        a.rowmap = nullptr;
+        a.ts_u64 = 0;
         static const bool no_token_spin = std::getenv("T4A_NO_TOKEN_SPIN") != nullptr;
         if (rplan.W == 1 && !prof.enabled && !no_token_spin) {
             if (++done_token_ == 0u) ++done_token_;
@@ -619,6 +633,156 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         r.has_factors = true;
     }
     return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bond chain: the rrLU launches of a half-sweep without a host round trip (tci2_chain.hip)
+// ------------------------------------------------------------------------------------------------
+bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
+{
+    if (kM < 1 || kN < 1 || kM > 65535 || kN > 65535) return false;
+    ChainRrluPlan pl;
+    pl.kM = kM;
+    pl.kN = kN;
+    static const bool no_single = std::getenv("T4A_CHAIN_NO_SINGLE") != nullptr;
+    if (!no_single && (long long)kM * kN <= 64 * 64 && rrlu_reg_make_plan(kM, kN, num_cus_, &pl.reg) && pl.reg.W == 1) {
+        pl.kind = 1;
+        pl.fused = pl.reg.RPT * pl.reg.CPT <= RRLU_FUSED_MAX_VALUES;
+        pl.code = pl.reg.RPT * 1000 + pl.reg.CPT * 10 + 2 + ((pl.reg.TR % 64) == 0 ? 1 : 0); // (+4 for the row-major tie order: chain_rrlu)
+        *out = pl;
+        return true;
+    }
+    if (xcd_disabled() || !rrlu_xcd_make_plan(kM, kN, &pl.xcd, true)) return false;
+    pl.kind = 2;
+    pl.code = 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
+    *out = pl;
+    return true;
+}
+
+void Engine::chain_begin(const std::vector<ChainRrluPlan>& plans)
+{
+    size_t need = 0;
+    int max_w = 0;
+    for (const ChainRrluPlan& pl : plans)
+        if (pl.kind == 2) {
+            const size_t n = (rrlu_xcd_keys_bytes(pl.xcd) + rrlu_xcd_cols_bytes(pl.xcd, pl.kM)) / sizeof(unsigned long long);
+            need = std::max(need, n);
+            max_w = std::max(max_w, pl.xcd.W);
+        }
+    if (need > 0) {
+        if (need > d_xkeys_.cap || !d_xticket_.get()) {
+            d_xkeys_.reserve(need);
+            d_xticket_.reserve(4);
+            T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), stream_));
+            T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), stream_));
+            xcd_ticket_base_ = 0;
+            xcd_salt_ = 0;
+        }
+        chain_lock_.acquire(max_w > kXcdSharedMaxW ? -1 : xcc_);
+    }
+}
+
+void Engine::chain_end() { chain_lock_.release(); }
+
+unsigned Engine::chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_a, const int* d_rowmap, const FusedPi* fused, const int* d_dims,
+                            size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec)
+{
+    double* d_dres = reinterpret_cast<double*>(blk.dev);
+    int* d_ires = reinterpret_cast<int*>(blk.dev + 16);
+    double* d_pivvals = reinterpret_cast<double*>(blk.dev + blk.off_piv);
+    int* d_rowperm = reinterpret_cast<int*>(blk.dev + blk.off_rp);
+    int* d_colperm = reinterpret_cast<int*>(blk.dev + blk.off_cp);
+    const int mn = pl.kM < pl.kN ? pl.kM : pl.kN;
+    const int max_steps = max_bond_dim < (size_t)mn ? (int)max_bond_dim : mn;
+    unsigned token = 0u;
+    if (pl.kind == 2) {
+        if (++xcd_salt_ > 65535u) { // the 16-bit launch salt wraps: stale granules could match again, clear the mailbox
+            T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), stream_));
+            xcd_salt_ = 1;
+        }
+        RrluXcdArgs a;
+        a.A = d_a;
+        a.Aout = nullptr;
+        a.urows = nullptr;
+        a.M = pl.kM;
+        a.N = pl.kN;
+        a.max_steps = max_steps;
+        a.rel_tol = rel_tol;
+        a.abs_tol = abs_tol;
+        a.tie_row_major = left ? 0 : 1;
+        a.out_transposed = left ? 0 : 1;
+        a.W = pl.xcd.W;
+        a.xcc = xcc_;
+        a.ticket = d_xticket_.get();
+        a.ticket_base = xcd_ticket_base_;
+        xcd_ticket_base_ += (unsigned)(pl.xcd.grid / 8);
+        a.row_perm = left ? d_rowperm : d_colperm;
+        a.col_perm = left ? d_colperm : d_rowperm;
+        a.iresult = d_ires;
+        a.dresult = d_dres;
+        a.pivot_vals = d_pivvals;
+        a.keys = d_xkeys_.get();
+        a.salt = xcd_salt_;
+        static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.8;
+        a.spec_frac = xspec;
+        a.stamps = nullptr;
+        a.h_block = reinterpret_cast<unsigned long long*>(blk.host);
+        a.block_u64 = (int)(blk.bytes / 8);
+        a.dims = d_dims;
+        a.dims_swap = left ? 0 : 1;
+        a.rowmap = d_rowmap;
+        if (spec) a.spec = *spec;
+        else std::memset(&a.spec, 0, sizeof(a.spec));
+        a.ts_u64 = (int)(blk.off_ts / 8);
+        rrlu_xcd_launch(pl.xcd, a, stream_);
+        token = xcd_salt_;
+    } else {
+        if (++done_token_ == 0u) ++done_token_;
+        RrluRegArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.A = d_a;
+        a.Aout = nullptr;
+        a.M = pl.kM;
+        a.N = pl.kN;
+        a.max_steps = max_steps;
+        a.rel_tol = rel_tol;
+        a.abs_tol = abs_tol;
+        a.tie_row_major = left ? 0 : 1;
+        a.out_transposed = left ? 0 : 1;
+        a.W = 1;
+        a.TR = pl.reg.TR;
+        a.TC = pl.reg.TC;
+        a.row_perm = left ? d_rowperm : d_colperm;
+        a.col_perm = left ? d_colperm : d_rowperm;
+        a.iresult = d_ires;
+        a.dresult = d_dres;
+        a.pivot_vals = d_pivvals;
+        a.salt = 1;
+        a.ncopy = 1;
+        a.spec = 2;
+        a.spec_frac = 0.8;
+        a.key16 = 1;
+        a.spin_limit = 1u << 20;
+        a.fused = (pl.fused && fused) ? 1 : 0;
+        if (a.fused) { // (the chain hands over the accumulators of the KERNEL's rows and columns)
+            a.rowacc = fused->d_rowacc;
+            a.colacc = fused->d_colacc;
+            a.fn = fused->fn;
+        }
+        a.h_block = reinterpret_cast<unsigned long long*>(blk.host);
+        a.block_u64 = (int)(blk.bytes / 8);
+        a.dims = d_dims;
+        a.dims_swap = left ? 0 : 1;
+        a.rowmap = a.fused ? nullptr : d_rowmap;
+        a.ts_u64 = (int)(blk.off_ts / 8);
+        a.dev_token = done_token_;
+        a.done_token = done_token_; // (also to int word 7 of the host mirror, like the single-XCD kernel's salt)
+        rrlu_reg_launch(pl.reg, a, stream_, true);
+        token = done_token_;
+    }
+    T4A_HIP(hipGetLastError());
+    // this path leaves its own blocks behind: the next luci() call must not trust the "clean header" of its block blindly
+    return token;
 }
 
 // factors_from_rrlu (matrix_luci.rs:256-279) on the factored matrix in d_lu_ (permuted coordinates).

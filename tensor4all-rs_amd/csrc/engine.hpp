@@ -63,6 +63,21 @@ struct XcdArbiter {
     };
 };
 
+// rrLU launch of one bond of a device-side bond chain (tci2_chain.hip): planned for upper bounds, dimensions read on the device
+struct ChainRrluPlan {
+    int kind = 0;        // 1: single-workgroup register kernel   2: single-XCD kernel
+    bool fused = false;  // kind 1: the candidate matrix is built in the registers from the accumulators (no matrix in memory)
+    RrluRegPlan reg;
+    RrluXcdPlan xcd;
+    int kM = 0, kN = 0;  // upper bounds of the matrix the KERNEL sees (transposed for a right-orthogonal factorisation)
+    int code = 0;        // profile code of the kernel instantiation (Engine::variant_stats_)
+};
+struct ChainBlock {      // packed result block of one bond: [dresult 2 f64][iresult 4 i32][pivot values][row perm][col perm]
+    char* dev = nullptr;
+    char* host = nullptr; // pinned mirror, same layout
+    size_t off_piv = 32, off_rp = 0, off_cp = 0, off_ts = 0, bytes = 0; // off_ts: two u64 time stamps of the kernel (0: none)
+};
+
 class Engine {
 public:
     Engine();
@@ -105,6 +120,20 @@ public:
     // thin QR (qr_backend, backend.rs:742): d_q M x k, d_r k x N; Householder.
     void qr(const double* d_a, int M, int N, double* d_q, double* d_r);
 
+    // ---- bond chain: launches without a host round trip (dimensions in device memory) ----
+    bool chain_plan(int kM, int kN, ChainRrluPlan* out) const;
+    // before the first launch of a chain: mailbox capacity for every plan, the XCD (or the whole chip) reserved until chain_end()
+    void chain_begin(const std::vector<ChainRrluPlan>& plans);
+    // rrLU of one bond: `left` as in RrLUOptions::left_orthogonal; d_a: the kernel's matrix (already transposed for !left; read
+    // through d_rowmap with leading dimension d_dims[3] when d_rowmap != nullptr) unless the plan is fused (then `fused` holds
+    // the accumulators of the KERNEL's rows and columns); d_dims: {M, N, poison, lda} of the MATRIX on the device.  Returns the
+    // completion token the kernel writes to iresult[3] of the device block (and to int word 7 of the host mirror).
+    // spec (single-XCD plans only, may be null): the candidate matrix of the NEXT bond for the launch's pass-through workgroups.
+    unsigned chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_a, const int* d_rowmap, const FusedPi* fused, const int* d_dims,
+                        size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec);
+    void chain_end();
+    int xcc() const { return xcc_; }
+
     // Host work that does not depend on the running factorisation: executed once, after the kernels of the next luci()
     // call have been enqueued and before the host blocks on them (then cleared).
     std::function<void()> overlap_hook;
@@ -119,6 +148,7 @@ public:
 private:
     void build_factors(const LuciResult& r, bool left_orth);
 
+    XcdArbiter::Lock chain_lock_;
     hipStream_t stream_ = nullptr;
     int num_cus_ = 0;
     unsigned rrlu_salt_ = 0;

@@ -145,6 +145,14 @@ struct RrluRegArgs {
     // to the host (system-scope fence + barrier in front of it), so that the host may spin on it instead of waiting for the
     // stream — a small bond is a 10 us kernel behind a 12 us completion
     unsigned done_token;
+    // bond chain (kernels_chain.hip; single-workgroup launches only): when `dims` != nullptr the matrix is dims[0] x dims[1]
+    // (dims[1] x dims[0] with dims_swap) instead of M x N — M, N are then the upper bounds the launch was planned for —,
+    // max_steps caps min(M, N), and `dev_token` is written to iresult[3] when the workgroup has run to its end
+    const int* dims;
+    int dims_swap;
+    unsigned dev_token;
+    const int* rowmap;          // non-null: entry (i, j) of the kernel's matrix is A[rowmap[i] + dims[3] * j] (speculative candidate matrix)
+    int ts_u64;                 // > 0: start / end time of the workgroup (wall_clock64) at u64 words ts_u64, ts_u64 + 1 of the result block (single-workgroup launches)
 };
 // false if the shape is outside the fast path (fall back to the LDS kernel)
 bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out);
@@ -154,6 +162,22 @@ size_t rrlu_reg_cols_bytes(const RrluRegPlan& plan, int M);
 void rrlu_reg_launch(const RrluRegPlan& plan, const RrluRegArgs& args, hipStream_t stream, bool keys_zeroed = false);
 
 // ---- single-XCD register-resident kernel (kernels_rrlu_xcd.hip): all participating workgroups share one L2 ----
+// Bond chain: the candidate matrix of the NEXT bond, evaluated speculatively by the launch's pass-through workgroups (the 7/8
+// of the grid that land on the other XCDs and used to return at once) while the elected XCD factorises this bond:
+// out[j * lda + c] = f(acc(c) + ind_acc[j]), candidate c < M * d: child (parent c / d of this bond's dependent list = the
+// kernel's rows, digit c % d), beyond: extra c - M * d; lda = M * d + ne (kernels_chain.hip has the same layout).
+struct XcdSpecArgs {
+    double* out;               // nullptr: nothing to speculate on
+    const uint64_t* dep_acc;   // [M][K] accumulators of the kernel's rows (this bond's dependent list)
+    const uint64_t* w_site;    // weights of the site that extends the dependent side: w + woff[site], row stride `total`
+    const uint64_t* ext_acc;   // [ne][K] accumulators of the next bond's extras
+    const int* ext_cnt;        // -> ne (nullptr: none)
+    const uint64_t* ind_acc;   // [ni][K] independent list of the next bond
+    const int* ind_cnt;        // -> ni
+    unsigned* tile_counter;    // work distribution among the pass-through workgroups (zero before the launch)
+    int total, d;
+    FnDevice fn;
+};
 struct RrluXcdPlan {
     int W = 1;              // participating workgroups (<= 32, one per compute unit of the elected XCD); agents = 8 W waves
     int RPT = 1, CPT = 1;   // rows per lane / columns per wave (template parameters)
@@ -185,8 +209,18 @@ struct RrluXcdArgs {
     unsigned long long* stamps; // diagnostic only
     unsigned long long* h_block; // pinned mirror of the packed result block (see RrluRegArgs)
     int block_u64;
+    // bond chain (kernels_chain.hip): when `dims` != nullptr the matrix is dims[0] x dims[1] (dims[1] x dims[0] with
+    // dims_swap) instead of M x N — M, N are then the upper bounds the launch was planned for — and max_steps caps min(M, N).
+    // Rank 0 writes `salt` to iresult[3] when it has run to its end (the next kernel of the chain checks it).
+    const int* dims;
+    int dims_swap;
+    const int* rowmap;          // non-null: entry (i, j) of the kernel's matrix is A[rowmap[i] + dims[3] * j] (speculative candidate matrix)
+    XcdSpecArgs spec;
+    int ts_u64;                 // > 0: rank 0 stores its start / end time (wall_clock64, 100 MHz) at u64 words ts_u64, ts_u64 + 1 of the result block and its mirror
 };
-bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out);
+// any_size: take every shape the plan family can hold (the bond chain has no other multi-workgroup kernel); otherwise tiny
+// matrices are left to the single-workgroup plan of the chip-wide kernel
+bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size = false);
 size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan);
 size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int M);
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
@@ -211,6 +245,61 @@ void pi_eval_batched_launch(const FnDevice& fn, const PiJob* d_jobs, int n_jobs,
 void stage_copy_launch(const uint64_t* pinned_src, uint64_t* dst, size_t count, hipStream_t stream);
 // max over a dense buffer of bits(sqrt(v*v)) (host-callback path)
 void absmax_launch(const double* data, size_t count, unsigned long long* max_abs_bits, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// Bond chain (kernels_chain.hip): device-resident index-set tables and the per-bond preparation kernel of the host-free
+// half-sweep (replaces the host part of update_pivots, tensorci2.rs:1833-1846, :1934-1949, between two bonds)
+// ------------------------------------------------------------------------------------------------
+constexpr int CHAIN_MAX_SET = 1024; // entries per site a table (and a history table) may hold
+struct ChainTab {
+    uint64_t* code; // [n_sites][cap]      mixed-radix code of the multi-index (kernels_chain.hip)
+    uint64_t* acc;  // [n_sites][cap][K]   integer accumulators of the built-in functor
+    int* cnt;                 // [n_sites]
+};
+// what every kernel of one half-sweep shares
+struct ChainCommon {
+    ChainTab I, J, HI, HJ;    // current sets I_p / J_p, history snapshot (the extras of this iteration, tensorci2.rs:1675-1685)
+    ChainTab mI, mJ;          // pinned host mirrors of I, J: written by the gather, they ARE the host's copy of the sets
+    int cap, K;
+    const uint64_t* w;        // [K][total] weights of the functor
+    int total;
+    const int* ldim;          // [n_sites] local dimensions
+    const int* woff;          // [n_sites] offset of a site in a weight row
+    int forward, use_extras;
+    uint64_t* ind_code;       // [n_bonds][ind_cap]     independent side of every bond (columns forward, rows backward)
+    uint64_t* ind_acc;        // [n_bonds][ind_cap][K]
+    int* ind_cnt;             // [n_bonds]
+    int ind_cap;
+    uint64_t* dep_code;       // [dep_cap]              dependent side of the CURRENT bond (read by the gather, then overwritten)
+    uint64_t* dep_acc;        // [dep_cap][K]
+    int dep_cap;
+    int* rowmap;              // [dep_cap] list position -> candidate of the speculative matrix
+    int* dims;                // [n_bonds][4]: M, N, poison, leading dimension of the matrix the rrLU kernel loads
+    int* hdims;               // pinned mirror of dims (M, N, poison)
+    // housekeeping of a new chain, done by chain_indep_kernel instead of five memset / memcpy operations on the stream:
+    uint64_t* snap_dst;       // != nullptr: tables I, J (two consecutive families: codes, accumulators) are copied here ...
+    int* snap_cnt_dst;        // ... and their counts here: the snapshot that becomes the extras of the next iteration
+    size_t snap_words;        // u64 words of the two families
+    int n_sites;
+    uint64_t* zero_a;         // result blocks of all bonds ...
+    size_t zero_a_words;
+    uint64_t* zero_b;         // ... and dims + tile counters: cleared
+    size_t zero_b_words;
+};
+struct ChainPrepArgs {
+    int b;                    // bond to build (ignored when do_build == 0)
+    int do_build;             // 0: gather only (after the last bond)
+    int with_rowmap;          // the rrLU of this bond loads the speculative matrix through the row map
+    int prev_b;               // previous bond of the half-sweep (< 0: none): its pivots are gathered into I_{prev_b+1}, J_{prev_b}
+    const int* prev_iresult;  // [0] npiv [1] timeout [3] completion token
+    const int* prev_rowperm;
+    const int* prev_colperm;
+    unsigned prev_token;
+};
+void chain_indep_launch(const ChainCommon& c, int n_bonds, hipStream_t stream);
+void chain_prep_launch(const ChainCommon& c, const ChainPrepArgs& a, hipStream_t stream);
+// n_dep_ub / n_ind_ub: upper bounds for the launch grid (the kernel reads the real sizes on the device)
+void chain_pi_launch(const ChainCommon& c, const FnDevice& fn, int b, int n_dep_ub, int n_ind_ub, double* out, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // Dense helpers
@@ -256,7 +345,11 @@ void lu_batched_launch(const LuProblem* d_problems, int n_problems, int max_n, h
 // Blocked variant that also applies the forward substitution to the right-hand sides: A = P^T L U, B <- L^{-1} P B
 // (bitwise the result of lu_batched_launch followed by the unit-lower triangular solve).  Returns false when
 // max_n > 1024 (nothing was launched; use the two-step path).
-bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream);
+// tickets (optional): LU_MAX_PANEL_STEPS zeroed counters; the trailing updates then hand their work items out dynamically and the
+// workgroups that land on XCD avoid_xcc (>= 0) return at once (see lu_update_kernel).
+constexpr int LU_MAX_PANEL_STEPS = 128;
+bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream, int avoid_xcc = -1,
+                               unsigned* tickets = nullptr);
 
 // gather rows/cols:  out[i + ldo*j] = in[rows[i] + ldi*cols[j]] (rows/cols may be nullptr = identity)
 void gather_launch(const double* in, int ldi, const int* rows, int nrows, const int* cols, int ncols, double* out,

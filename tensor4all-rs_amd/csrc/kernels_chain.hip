@@ -1,0 +1,336 @@
+// kernels_chain.hip — device side of the host-free half-sweep ("bond chain").
+//
+// A 2-site half-sweep (tensorci2.rs:1695-1725) is a chain of dependent bond updates: bond b needs the rows I_{b+1} (forward)
+// or the columns J_b (backward) its predecessor selected.  Until round 2 that dependency ran through the host (three launches
+// and a completion round trip per bond).  Here the index sets live on the device as TABLES — per site and side a list of
+// (code, accumulators): `code` identifies the multi-index (mixed-radix number, see below), the accumulators are what the
+// built-in functor needs (include/t4a_testfunctions.h) — and the host part of update_pivots (tensorci2.rs:1833-1846,
+// :1934-1949) becomes three small kernels:
+//
+//   chain_indep_kernel   once per half-sweep, one workgroup per bond: the side of every bond that does NOT depend on the
+//                        chain (forward: the columns kron(d_{b+1}, J_{b+1}) ∪ HJ_b; backward: the rows kron(I_b, d_b) ∪ HI_{b+1}).
+//   chain_prep_kernel    between two rrLU launches, one workgroup: (1) gather — the pivots the previous bond selected
+//                        (permutation prefix of its rrLU, non_empty_or_first, tensorci2.rs:1813-1819) go from that bond's
+//                        row / column lists into the tables I_{b'+1}, J_{b'} (and into their pinned host mirrors: the host's
+//                        master copy is refreshed without any host work); (2) the DEPENDENT side of this bond: Kronecker
+//                        product with the new site (tensorci2.rs:1224-1246) ∪ the history extras that are not yet present,
+//                        order preserving like the reference's `contains` loop (:1837-1846): membership of an extra in the
+//                        Kronecker part is membership of its parent multi-index in the table (hash in LDS), survivors are
+//                        compacted by a prefix sum; (3) the dimensions of the bond, for the kernels behind it on the stream.
+//   (xcd_spec_work,      the candidate matrix of bond b, evaluated SPECULATIVELY while the rrLU of the previous bond is still
+//   kernels_rrlu_xcd.hip) running: that launch occupies one XCD, and its pass-through workgroups on the other seven do this
+//                        instead of returning at once.  The dependent side of bond b can only consist of children of entries
+//                        of the previous bond's dependent list (a pivot is one of its candidates) and of extras, so f is
+//                        evaluated for ALL of those candidates x the independent list; chain_prep_kernel then only writes a
+//                        row map (list position -> candidate) and the rrLU kernel loads its matrix through it.  ~3x more
+//                        evaluations than needed, all of them off the critical path: between two rrLU launches only
+//                        chain_prep_kernel runs.  chain_pi_kernel evaluates a bond nobody could speculate on.
+//
+// Codes.  I_p holds prefixes (i_0 … i_{p-1}), J_p suffixes (j_{p+1} … j_{n-1}); both are numbered so that the Kronecker step
+// is one multiply-add: code(I_{p+1} element (i, s)) = s + d_p * code(i), code(J_{p-1} element (s, j)) = s + d_p * code(j),
+// the empty index has code 0.  The parent of an element is code / d.  A chain is only run on the device when the product of
+// all local dimensions fits 63 bits (tci2_chain.hip).
+//
+// A bond whose predecessor did not complete (bounded spin gave up, capacity exceeded) is POISONED: dimensions 0, every later
+// kernel of the chain does nothing, the host re-runs the half-sweep from that bond with the per-bond path.
+#include "kernels.hpp"
+
+namespace t4a {
+
+namespace {
+
+constexpr int CHAIN_T = 1024;       // threads of a list-building workgroup
+constexpr int CHAIN_HASH = 4096;    // LDS hash slots (tables hold at most CHAIN_MAX_SET = 1024 entries per site)
+
+__device__ __forceinline__ unsigned chain_hash(unsigned long long c)
+{
+    c ^= c >> 33;
+    c *= 0xff51afd7ed558ccdull;
+    c ^= c >> 29;
+    return (unsigned)c & (CHAIN_HASH - 1);
+}
+
+// exclusive prefix sum of one flag per thread over the workgroup; returns the position of this thread, *total the sum
+__device__ __forceinline__ int block_scan_flag(bool flag, int* wave_sums, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    __syncthreads(); // wave_sums may still be read from a previous call
+    if (lane == 0) wave_sums[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < CHAIN_T / 64; ++w) {
+        const int v = wave_sums[w];
+        if (w < wave) base += v;
+        tot += v;
+    }
+    *total = tot;
+    return base + before;
+}
+
+// One side of a bond: out = kron(parent table, d) followed by the extras that are not in it.
+// PARENT_OUTER: (parent outer, s inner: rows, tensorci2.rs:1224-1234) else (s outer, parent inner: columns, :1236-1246).
+// srcpos / rowmap (optional): the candidate index of every list entry for the speculative candidate matrix —
+// parent k sits at position srcpos[k] of the previous bond's dependent list, its child with digit s is candidate
+// srcpos[k] * d + s; extra e is candidate n_prev * d + e.
+// Returns the count (uniform), -1 on capacity overflow.
+template <bool PARENT_OUTER>
+__device__ int build_side(const uint64_t* __restrict__ pcode, const uint64_t* __restrict__ pacc, int np, int d,
+                          const uint64_t* __restrict__ w, int K, int total_w, int w_off, const uint64_t* __restrict__ ecode,
+                          const uint64_t* __restrict__ eacc, int ne, uint64_t* __restrict__ ocode, uint64_t* __restrict__ oacc, int ocap,
+                          const int* srcpos, int n_prev, int* __restrict__ rowmap, unsigned long long* hkeys, int* wave_sums)
+{
+    const int tid = threadIdx.x;
+    const int m0 = np * d;
+    if (m0 > ocap) return -1;
+    if (ne > 0) {
+        for (int e = tid; e < CHAIN_HASH; e += CHAIN_T) hkeys[e] = 0ull;
+        __syncthreads();
+    }
+    // Kronecker part
+    for (int idx = tid; idx < m0; idx += CHAIN_T) {
+        const int i = PARENT_OUTER ? idx / d : idx % np;
+        const int s = PARENT_OUTER ? idx % d : idx / np;
+        const uint64_t c = pcode[i];
+        ocode[idx] = (uint64_t)s + (uint64_t)d * c;
+        for (int k = 0; k < K; ++k) oacc[(size_t)idx * K + k] = pacc[(size_t)i * K + k] + w[(size_t)k * total_w + w_off + s];
+        if (rowmap) rowmap[idx] = srcpos[i] * d + s;
+    }
+    if (ne <= 0) return m0;
+    // hash of the parents, then the extras in order (one per thread and round; ne <= CHAIN_T in practice: one round)
+    for (int i = tid; i < np; i += CHAIN_T) {
+        const unsigned long long key = (unsigned long long)pcode[i] + 1ull;
+        unsigned h = chain_hash(key);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&hkeys[h], 0ull, key);
+            if (old == 0ull || old == key) break;
+            h = (h + 1) & (CHAIN_HASH - 1);
+        }
+    }
+    __syncthreads();
+    int count = m0;
+    for (int base = 0; base < ne; base += CHAIN_T) {
+        const int e = base + tid;
+        bool keep = false;
+        uint64_t c = 0ull;
+        if (e < ne) {
+            c = ecode[e];
+            const unsigned long long key = (unsigned long long)(c / (uint64_t)d) + 1ull;
+            unsigned h = chain_hash(key);
+            keep = true;
+            for (;;) {
+                const unsigned long long v = hkeys[h];
+                if (v == 0ull) break;
+                if (v == key) {
+                    keep = false;
+                    break;
+                }
+                h = (h + 1) & (CHAIN_HASH - 1);
+            }
+        }
+        int tot = 0;
+        const int pos = block_scan_flag(keep, wave_sums, &tot);
+        if (count + tot > ocap) return -1;
+        if (keep) {
+            const int o = count + pos;
+            ocode[o] = c;
+            for (int k = 0; k < K; ++k) oacc[(size_t)o * K + k] = eacc[(size_t)e * K + k];
+            if (rowmap) rowmap[o] = n_prev * d + e;
+        }
+        count += tot;
+    }
+    return count;
+}
+
+// the independent side of every bond of the half-sweep: blockIdx.x = bond
+__global__ void __launch_bounds__(CHAIN_T) chain_indep_kernel(ChainCommon c)
+{
+    __shared__ unsigned long long hkeys[CHAIN_HASH];
+    __shared__ int wave_sums[CHAIN_T / 64];
+    const int b = blockIdx.x;
+    const int K = c.K;
+    const size_t cap = (size_t)c.cap;
+    uint64_t* ocode = c.ind_code + (size_t)b * c.ind_cap;
+    uint64_t* oacc = c.ind_acc + (size_t)b * c.ind_cap * K;
+    int n;
+    if (c.forward) { // columns: kron(d_{b+1}, J_{b+1}) ∪ HJ_b
+        const int np = c.J.cnt[b + 1], ne = c.use_extras ? c.HJ.cnt[b] : 0;
+        n = (np >= 1 && np <= c.cap && ne <= c.cap)
+                ? build_side<false>(c.J.code + (size_t)(b + 1) * cap, c.J.acc + (size_t)(b + 1) * cap * K, np, c.ldim[b + 1], c.w, K, c.total,
+                                    c.woff[b + 1], c.HJ.code + (size_t)b * cap, c.HJ.acc + (size_t)b * cap * K, ne, ocode, oacc, c.ind_cap,
+                                    nullptr, 0, nullptr, hkeys, wave_sums)
+                : -1;
+    } else { // rows: kron(I_b, d_b) ∪ HI_{b+1}
+        const int np = c.I.cnt[b], ne = c.use_extras ? c.HI.cnt[b + 1] : 0;
+        n = (np >= 1 && np <= c.cap && ne <= c.cap)
+                ? build_side<true>(c.I.code + (size_t)b * cap, c.I.acc + (size_t)b * cap * K, np, c.ldim[b], c.w, K, c.total, c.woff[b],
+                                   c.HI.code + (size_t)(b + 1) * cap, c.HI.acc + (size_t)(b + 1) * cap * K, ne, ocode, oacc, c.ind_cap,
+                                   nullptr, 0, nullptr, hkeys, wave_sums)
+                : -1;
+    }
+    if (threadIdx.x == 0) c.ind_cnt[b] = n;
+    // housekeeping of the new chain (grid-stride over all workgroups): nothing of this is read before this kernel has ended
+    const size_t gtid = (size_t)blockIdx.x * CHAIN_T + threadIdx.x, gsz = (size_t)gridDim.x * CHAIN_T;
+    if (c.snap_dst) {
+        for (size_t i = gtid; i < c.snap_words; i += gsz) c.snap_dst[i] = c.I.code[i]; // (I and J families are adjacent)
+        for (size_t i = gtid; i < (size_t)2 * c.n_sites; i += gsz) c.snap_cnt_dst[i] = c.I.cnt[i];
+    }
+    for (size_t i = gtid; i < c.zero_a_words; i += gsz) c.zero_a[i] = 0ull;
+    for (size_t i = gtid; i < c.zero_b_words; i += gsz) c.zero_b[i] = 0ull;
+}
+
+__global__ void __launch_bounds__(CHAIN_T) chain_prep_kernel(ChainCommon c, ChainPrepArgs p)
+{
+    __shared__ unsigned long long hkeys[CHAIN_HASH];
+    __shared__ int wave_sums[CHAIN_T / 64];
+    __shared__ int s_srcpos[CHAIN_MAX_SET];
+    __shared__ int s_poison;
+    const int tid = threadIdx.x;
+    const int K = c.K;
+    const size_t cap = (size_t)c.cap;
+    if (tid == 0) s_poison = 0;
+    __syncthreads();
+
+    // ---- 1. pivots of the previous bond -> tables I_{pb+1}, J_{pb} (device and pinned host mirror) ----
+    int n_prev_dep = 0; // entries of the previous bond's dependent list (candidates' parents)
+    if (p.prev_b >= 0) {
+        const int pb = p.prev_b;
+        const int* pd = c.dims + (size_t)pb * 4;
+        const int pm = pd[0], pn = pd[1];
+        const bool bad = pd[2] != 0 || p.prev_iresult[1] != 0 || p.prev_iresult[3] != (int)p.prev_token || pm <= 0 || pn <= 0;
+        if (bad) {
+            if (tid == 0) s_poison = 1;
+        } else {
+            const int r = p.prev_iresult[0];
+            const int cnt = r > 0 ? r : 1; // non_empty_or_first (tensorci2.rs:1813-1819)
+            if (cnt > c.cap || cnt > pm || cnt > pn) {
+                if (tid == 0) s_poison = 1;
+            } else {
+                n_prev_dep = c.forward ? pm : pn;
+                // forward: rows of the previous bond were its dependent list, columns its independent list; backward: the reverse
+                const uint64_t* rcode = c.forward ? c.dep_code : c.ind_code + (size_t)pb * c.ind_cap;
+                const uint64_t* racc = c.forward ? c.dep_acc : c.ind_acc + (size_t)pb * c.ind_cap * K;
+                const uint64_t* ccode = c.forward ? c.ind_code + (size_t)pb * c.ind_cap : c.dep_code;
+                const uint64_t* cacc = c.forward ? c.ind_acc + (size_t)pb * c.ind_cap * K : c.dep_acc;
+                const size_t oi = (size_t)(pb + 1) * cap, oj = (size_t)pb * cap;
+                for (int k = tid; k < cnt; k += CHAIN_T) {
+                    const int ri = r > 0 ? p.prev_rowperm[k] : 0, ci = r > 0 ? p.prev_colperm[k] : 0;
+                    const uint64_t rc = rcode[ri], cc = ccode[ci];
+                    c.I.code[oi + k] = rc;
+                    c.J.code[oj + k] = cc;
+                    c.mI.code[oi + k] = rc;
+                    c.mJ.code[oj + k] = cc;
+                    for (int q = 0; q < K; ++q) {
+                        const uint64_t ra = racc[(size_t)ri * K + q], ca = cacc[(size_t)ci * K + q];
+                        c.I.acc[(oi + k) * K + q] = ra;
+                        c.J.acc[(oj + k) * K + q] = ca;
+                        c.mI.acc[(oi + k) * K + q] = ra;
+                        c.mJ.acc[(oj + k) * K + q] = ca;
+                    }
+                    s_srcpos[k] = c.forward ? ri : ci; // position of the new parent in the previous dependent list
+                }
+                if (tid == 0) {
+                    c.I.cnt[pb + 1] = cnt;
+                    c.J.cnt[pb] = cnt;
+                    c.mI.cnt[pb + 1] = cnt;
+                    c.mJ.cnt[pb] = cnt;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads(); // the gather has read the old dependent list and written the tables: the list may be overwritten now
+    }
+    if (!p.do_build) return;
+    const int b = p.b;
+    int* dims = c.dims + (size_t)b * 4;
+    int* hdims = c.hdims ? c.hdims + (size_t)b * 4 : nullptr;
+    if (s_poison) {
+        if (tid == 0) {
+            dims[0] = dims[1] = dims[3] = 0;
+            dims[2] = 1;
+            if (hdims) {
+                hdims[0] = hdims[1] = 0;
+                hdims[2] = 1;
+            }
+        }
+        return;
+    }
+
+    // ---- 2. the dependent side of bond b (rows when sweeping forward, columns when sweeping backward) ----
+    const bool mapped = p.prev_b >= 0 && p.with_rowmap;
+    int nd = -1, lda = 0;
+    if (c.forward) {
+        const int np = c.I.cnt[b], ne = c.use_extras ? c.HI.cnt[b + 1] : 0;
+        if (np >= 1 && np <= c.cap && ne <= c.cap)
+            nd = build_side<true>(c.I.code + (size_t)b * cap, c.I.acc + (size_t)b * cap * K, np, c.ldim[b], c.w, K, c.total, c.woff[b],
+                                  c.HI.code + (size_t)(b + 1) * cap, c.HI.acc + (size_t)(b + 1) * cap * K, ne, c.dep_code, c.dep_acc, c.dep_cap,
+                                  s_srcpos, n_prev_dep, mapped ? c.rowmap : nullptr, hkeys, wave_sums);
+        lda = n_prev_dep * c.ldim[b] + ne;
+    } else {
+        const int np = c.J.cnt[b + 1], ne = c.use_extras ? c.HJ.cnt[b] : 0;
+        if (np >= 1 && np <= c.cap && ne <= c.cap)
+            nd = build_side<false>(c.J.code + (size_t)(b + 1) * cap, c.J.acc + (size_t)(b + 1) * cap * K, np, c.ldim[b + 1], c.w, K, c.total,
+                                   c.woff[b + 1], c.HJ.code + (size_t)b * cap, c.HJ.acc + (size_t)b * cap * K, ne, c.dep_code, c.dep_acc,
+                                   c.dep_cap, s_srcpos, n_prev_dep, mapped ? c.rowmap : nullptr, hkeys, wave_sums);
+        lda = n_prev_dep * c.ldim[b + 1] + ne;
+    }
+    if (tid == 0) {
+        const int ni = c.ind_cnt[b];
+        const bool ok = nd > 0 && ni > 0;
+        const int M = c.forward ? nd : ni, N = c.forward ? ni : nd;
+        dims[0] = ok ? M : 0;
+        dims[1] = ok ? N : 0;
+        dims[2] = ok ? 0 : 1;
+        dims[3] = mapped ? lda : (ok ? nd : 0); // leading dimension of the matrix the rrLU kernel loads (its rows = dependent side)
+        if (hdims) {
+            hdims[0] = ok ? M : 0;
+            hdims[1] = ok ? N : 0;
+            hdims[2] = ok ? 0 : 1;
+        }
+    }
+}
+
+// Candidate matrix of a bond nobody speculated on (first bond of a chain, or the previous launch was a single workgroup):
+// out[j * nd + i] = f(dependent i, independent j)
+__global__ void __launch_bounds__(256) chain_pi_kernel(ChainCommon c, FnDevice fn, int b, double* __restrict__ out)
+{
+    const int* dm = c.dims + (size_t)b * 4;
+    if (dm[2] != 0) return;
+    const int K = fn.n_acc;
+    const int nd = c.forward ? dm[0] : dm[1], ni = c.forward ? dm[1] : dm[0];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * (int)blockDim.x >= nd) return;
+    uint64_t racc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+    if (i < nd)
+        for (int k = 0; k < K; ++k) racc[k] = c.dep_acc[(size_t)i * K + k];
+    const uint64_t* ia = c.ind_acc + (size_t)b * c.ind_cap * K;
+    for (int j = blockIdx.y; j < ni; j += gridDim.y) {
+        if (i < nd) {
+            uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+            for (int k = 0; k < K; ++k) acc[k] = racc[k] + ia[(size_t)j * K + k];
+            out[(size_t)j * nd + i] = t4a_fn_value(fn.fid, acc, fn.params);
+        }
+    }
+}
+
+} // namespace
+
+void chain_indep_launch(const ChainCommon& c, int n_bonds, hipStream_t stream)
+{
+    hipLaunchKernelGGL(chain_indep_kernel, dim3(n_bonds), dim3(CHAIN_T), 0, stream, c);
+}
+
+void chain_prep_launch(const ChainCommon& c, const ChainPrepArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(chain_prep_kernel, dim3(1), dim3(CHAIN_T), 0, stream, c, a);
+}
+
+void chain_pi_launch(const ChainCommon& c, const FnDevice& fn, int b, int n_dep_ub, int n_ind_ub, double* out, hipStream_t stream)
+{
+    if (n_dep_ub <= 0 || n_ind_ub <= 0) return;
+    const int gy = n_ind_ub < 2048 ? n_ind_ub : 2048;
+    hipLaunchKernelGGL(chain_pi_kernel, dim3((n_dep_ub + 255) / 256, gy), dim3(256), 0, stream, c, fn, b, out);
+}
+
+} // namespace t4a

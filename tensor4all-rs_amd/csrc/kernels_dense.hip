@@ -664,20 +664,41 @@ __global__ void __launch_bounds__(256) lu_panel_kernel(const LuProblem* problems
     }
 }
 
-__global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problems, int kb, int nb)
+// Work items (tile, problem) are handed out through a ticket counter when `ticket` != nullptr, and workgroups that landed on
+// XCD `avoid_xcc` return without taking any: fill_site_tensors runs beside the bond chain, whose single-XCD rrLU launches keep
+// one XCD occupied almost without a gap (8 us between launches).  A statically mapped grid would leave an eighth of its
+// workgroups waiting for that XCD — this kernel's 130 KiB of LDS do not fit next to an rrLU workgroup — and one launch took as
+// long as two factorisations (measured: 1.35 ms instead of 0.2 ms); a workgroup that only has to return gets its slot at once.
+__global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problems, int kb, int nb, int tiles, int n_problems, int avoid_xcc,
+                                                        unsigned* ticket)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const LuProblem pr = problems[blockIdx.y];
+    __shared__ int s_item;
+    if (avoid_xcc >= 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((int)(xcc & 0xF) == avoid_xcc) return;
+    }
+    const int total_items = tiles * n_problems;
+    bool first = true;
+    for (;;) {
+    __syncthreads(); // (the LDS tiles of the previous item are free)
+    if (threadIdx.x == 0) s_item = ticket ? (int)atomicAdd(ticket, 1u) : (first ? (int)blockIdx.x : total_items);
+    __syncthreads();
+    first = false;
+    const int item = s_item;
+    if (item >= total_items) break;
+    const LuProblem pr = problems[item / tiles];
     const int n = pr.n;
-    if (kb >= n || pr.info[0] == -1) return;
+    if (kb >= n || pr.info[0] == -1) continue;
     // tiles: ceil(n / nb) tiles over the columns of A, then ceil(nrhs / nb) tiles over the columns of B
     const int ta = (n + nb - 1) / nb;
     const int nrhs = pr.B ? pr.nrhs : 0;
-    const int t = blockIdx.x;
+    const int t = item % tiles;
     const bool in_a = t < ta;
     const int c0 = in_a ? t * nb : (t - ta) * nb; // first column inside A resp. B
-    if (!in_a && c0 >= nrhs) return;
-    if (in_a && c0 == kb) return;                 // the panel itself
+    if (!in_a && c0 >= nrhs) continue;
+    if (in_a && c0 == kb) continue;               // the panel itself
     const int m = n - kb, w = (n - kb) < nb ? (n - kb) : nb;
     const int lim = in_a ? n : nrhs;
     const int tc = (lim - c0) < nb ? (lim - c0) : nb;
@@ -771,6 +792,7 @@ __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problem
         double* g = gcol(c);
         for (int i = tid; i < m; i += T) g[i] = Tt[(size_t)c * ldp + i];
     }
+    } // next work item
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -945,7 +967,8 @@ void lu_batched_launch(const LuProblem* d_problems, int n_problems, int max_n, h
     hipLaunchKernelGGL(lu_kernel, dim3(n_problems), dim3(T), 0, stream, d_problems);
 }
 
-bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream)
+bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream, int avoid_xcc,
+                               unsigned* tickets)
 {
     if (n_problems <= 0 || max_n <= 0) return true;
     int nb;
@@ -969,7 +992,12 @@ bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int 
     const int tiles = (max_n + nb - 1) / nb + (max_nrhs + nb - 1) / nb + 1;
     for (int kb = 0; kb < max_n; kb += nb) {
         hipLaunchKernelGGL(lu_panel_kernel, dim3(n_problems), dim3(256), lds_panel, stream, d_problems, kb, nb);
-        hipLaunchKernelGGL(lu_update_kernel, dim3(tiles, n_problems), dim3(256), lds_update, stream, d_problems, kb, nb);
+        // one workgroup per (tile, problem) item; with tickets a few more, so that those which return on the avoided XCD are made up for
+        const int items = tiles * n_problems;
+        unsigned* tk = tickets ? tickets + kb / nb : nullptr;
+        const int grid = tk ? items + items / 7 + 8 : items;
+        hipLaunchKernelGGL(lu_update_kernel, dim3(grid), dim3(256), lds_update, stream, d_problems, kb, nb, tiles, n_problems,
+                           tk ? avoid_xcc : -1, tk);
     }
     return true;
 }

@@ -242,6 +242,19 @@ rrlu_reg_kernel(RrluRegArgs p)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     RegSmem s;
     reg_smem_layout(p.M, p.N, p.TC * CPT, SINGLE, &s, smem_raw);
+    // bond chain (single-workgroup launches): the real dimensions come from device memory; the launch (thread grid, LDS
+    // layout) was planned for the upper bounds p.M x p.N
+    int M = p.M, N = p.N, max_steps = p.max_steps;
+    if (SINGLE && p.dims) {
+        const int d0 = p.dims[0], d1 = p.dims[1];
+        M = p.dims_swap ? d1 : d0;
+        N = p.dims_swap ? d0 : d1;
+        if (M > p.M || N > p.N) M = N = 0;
+        const int mn = M < N ? M : N;
+        max_steps = max_steps < mn ? max_steps : mn;
+        if (mn <= 0) return; // poisoned bond
+    }
+    const unsigned long long ts_begin = (SINGLE && p.ts_u64 > 0) ? wall_clock64() : 0ull;
 
     const int tid = threadIdx.x;
     const int T = blockDim.x;
@@ -259,14 +272,14 @@ rrlu_reg_kernel(RrluRegArgs p)
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int i = tr + p.TR * r;
-        irow[r] = i < p.M ? i : -1;
-        rpos[r] = i < p.M ? i : -1;
+        irow[r] = i < M ? i : -1;
+        rpos[r] = i < M ? i : -1;
     }
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
         const int c = w + p.W * (tc + p.TC * q);
-        ccol[q] = c < p.N ? c : -1;
-        cpos[q] = c < p.N ? c : -1;
+        ccol[q] = c < N ? c : -1;
+        cpos[q] = c < N ? c : -1;
     }
     double a[CPT][RPT];
     double local_absmax = 0.0;
@@ -306,15 +319,15 @@ rrlu_reg_kernel(RrluRegArgs p)
             for (int r = 0; r < RPT; ++r) {
                 double v = 0.0;
                 if (ccol[q] >= 0 && irow[r] >= 0) {
-                    v = p.A[(size_t)ccol[q] * p.M + irow[r]];
+                    v = (SINGLE && p.rowmap) ? p.A[(size_t)ccol[q] * p.dims[3] + p.rowmap[irow[r]]] : p.A[(size_t)ccol[q] * M + irow[r]];
                     const double av = sqrt(v * v);
                     if (av > local_absmax) local_absmax = av;
                 }
                 a[q][r] = v;
             }
     }
-    for (int i = tid; i < p.M; i += T) s.posrow[i] = (unsigned short)i;
-    for (int j = tid; j < p.N; j += T) s.poscol[j] = (unsigned short)j;
+    for (int i = tid; i < M; i += T) s.posrow[i] = (unsigned short)i;
+    for (int j = tid; j < N; j += T) s.poscol[j] = (unsigned short)j;
     if (tid == 0) s.win_i[2] = 0;
     {
         const double wm = wave_max_f64(local_absmax);
@@ -346,7 +359,7 @@ rrlu_reg_kernel(RrluRegArgs p)
     double prev_sq = __builtin_huge_val(); // square of the previous pivot (thresholded speculation: nobody speculates first)
     const double spec_frac = p.spec_frac;
 
-    for (int k = -1; k < p.max_steps; ++k) {
+    for (int k = -1; k < max_steps; ++k) {
         // =====================================================================================
         // (C) rank-1 update of step k (k >= 0) fused with the candidate search of step k+1
         // =====================================================================================
@@ -403,7 +416,7 @@ rrlu_reg_kernel(RrluRegArgs p)
 #endif
         }
         npiv = k + 1;
-        if (k + 1 >= p.max_steps) break; // the reference stops before another arg-max (matrixlu.rs:747)
+        if (k + 1 >= max_steps) break; // the reference stops before another arg-max (matrixlu.rs:747)
         const int kn = k + 1;
         const unsigned diagkey = ((unsigned)kn << 16) | (unsigned)kn;
         // a NaN sitting on the next diagonal element wins outright (it is the reference's initial incumbent)
@@ -572,7 +585,7 @@ rrlu_reg_kernel(RrluRegArgs p)
                 for (int r = 0; r < RPT; ++r)
                     if (irow[r] >= 0) {
                         const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
-                        unsigned long long* dst = p.cols + (((size_t)par * p.W + w) * (size_t)p.M + irow[r]) * 2;
+                        unsigned long long* dst = p.cols + (((size_t)par * p.W + w) * (size_t)M + irow[r]) * 2;
                         st_col_row(dst, tagbits, vb);
                     }
             }
@@ -688,7 +701,7 @@ rrlu_reg_kernel(RrluRegArgs p)
                 for (int r = 0; r < RPT; ++r)
                     if (irow[r] >= 0) {
                         const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
-                        unsigned long long* dst = p.cols + (((size_t)par * p.W + w) * (size_t)p.M + irow[r]) * 2;
+                        unsigned long long* dst = p.cols + (((size_t)par * p.W + w) * (size_t)M + irow[r]) * 2;
                         st_col_row(dst, tagbits, vb);
                     }
             }
@@ -698,7 +711,7 @@ rrlu_reg_kernel(RrluRegArgs p)
                     if (irow[r] >= 0) {
                         const unsigned long long vb = (unsigned long long)__double_as_longlong(colv[r]);
                         for (int c = 0; c < p.ncopy; ++c) {
-                            unsigned long long* dst = p.cols + (((size_t)par * p.ncopy + c) * (size_t)p.M + irow[r]) * 2;
+                            unsigned long long* dst = p.cols + (((size_t)par * p.ncopy + c) * (size_t)M + irow[r]) * 2;
                             st_u64_sc1(dst, tagbits | (vb & 0xFFFFFFFFull));
                             st_u64_sc1(dst + 1, tagbits | (vb >> 32));
                         }
@@ -708,8 +721,8 @@ rrlu_reg_kernel(RrluRegArgs p)
         const bool need_fetch = !SINGLE && !(ww == w && qstar >= 0);
         const unsigned long long* colsrc =
             SINGLE ? nullptr
-                   : (T4A_SPEC(p) ? p.cols + ((size_t)((k + 1) & 1) * p.W + ww) * (size_t)p.M * 2
-                             : p.cols + ((size_t)((k + 1) & 1) * p.ncopy + (w % p.ncopy)) * (size_t)p.M * 2);
+                   : (T4A_SPEC(p) ? p.cols + ((size_t)((k + 1) & 1) * p.W + ww) * (size_t)M * 2
+                             : p.cols + ((size_t)((k + 1) & 1) * p.ncopy + (w % p.ncopy)) * (size_t)M * 2);
         unsigned long long cg0[RPT], cg1[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
@@ -836,7 +849,7 @@ rrlu_reg_kernel(RrluRegArgs p)
     }
 
     // ---- results ----
-    if (npiv >= (p.M < p.N ? p.M : p.N)) error = 0.0; // matrixlu.rs:811-813
+    if (npiv >= (M < N ? M : N)) error = 0.0; // matrixlu.rs:811-813
     if (w == 0 && tid == 0) {
         p.iresult[0] = npiv;
         p.dresult[0] = error;
@@ -847,8 +860,8 @@ rrlu_reg_kernel(RrluRegArgs p)
     if (timed_out) return;
     __syncthreads();
     if (w == 0) {
-        for (int i = tid; i < p.M; i += T) p.row_perm[i] = s.posrow[i];
-        for (int j = tid; j < p.N; j += T) p.col_perm[j] = s.poscol[j];
+        for (int i = tid; i < M; i += T) p.row_perm[i] = s.posrow[i];
+        for (int j = tid; j < N; j += T) p.col_perm[j] = s.poscol[j];
     }
     int nan_seen = 0;
 #pragma unroll
@@ -863,9 +876,9 @@ rrlu_reg_kernel(RrluRegArgs p)
                 if ((in_l || in_u) && v != v) nan_seen = 1;
                 if (p.Aout) {
                     if (p.out_transposed)
-                        p.Aout[(size_t)rp * p.N + cp] = v;
+                        p.Aout[(size_t)rp * N + cp] = v;
                     else
-                        p.Aout[(size_t)cp * p.M + rp] = v;
+                        p.Aout[(size_t)cp * M + rp] = v;
                 }
             }
         }
@@ -882,6 +895,7 @@ rrlu_reg_kernel(RrluRegArgs p)
             p.h_block[e] = (e == 1) ? ld_u64_sc1(src + 1) : src[e]; // [1] = max |a| bits: atomics of all workgroups
         }
         if (tid == 0) ((volatile int*)p.h_block)[4] = npiv;
+        if (SINGLE && p.dims && tid == 0) p.iresult[3] = (int)p.dev_token; // bond chain: seen by the next preparation kernel
         if (SINGLE && p.done_token != 0u) { // everything this (only) workgroup sends to the host is out: completion token
             __threadfence_system();
             __syncthreads();
@@ -890,6 +904,10 @@ rrlu_reg_kernel(RrluRegArgs p)
         // leave the device side clean for the next launch: the max|a| word is only ever raised by the atomics of the
         // load phase (all long done), and nobody touches the other key table during this launch
         __syncthreads();
+        if (SINGLE && p.ts_u64 > 0 && tid == 0) { // bond chain: device-side start / end time of the factorisation (100 MHz)
+            p.h_block[p.ts_u64] = ts_begin;
+            p.h_block[p.ts_u64 + 1] = wall_clock64();
+        }
         if (tid == 0) reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull;
         for (int e = tid; e < p.keys_next_u64; e += T) p.keys_next[e] = 0ull;
     }

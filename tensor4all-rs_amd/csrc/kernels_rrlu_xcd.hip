@@ -33,6 +33,7 @@
 //     never passes the check and no buffer has to be cleared between launches.
 #include "kernels.hpp"
 
+#include <cstddef>
 #include <cstdlib>
 #include <mutex>
 
@@ -244,6 +245,58 @@ __device__ __forceinline__ void xcd_publish_column(const xvec<RPT>& col, __amdgp
     }
 }
 
+// Bond chain: what the pass-through workgroups do instead of returning at once (XcdSpecArgs in kernels.hpp).  Tiles of XT
+// candidates x SPEC_TJ independent entries are handed out through a global counter, so it does not matter how many workgroups
+// there are or where they run.  M = rows of this launch's matrix (= entries of the dependent list).
+constexpr int SPEC_TJ = 16;
+__device__ __forceinline__ const char* kernarg_base() // the kernel-argument segment (the by-value RrluXcdArgs sits at its start)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;
+#endif
+}
+// (not inlined, and handed a pointer into the kernel-argument segment rather than a reference to the by-value argument: the
+// step loop of the kernel is bound by its scalar registers, nothing of this path may leak into its register allocation)
+__device__ __noinline__ void xcd_spec_work(const XcdSpecArgs* spp, int M, int* lds_tile)
+{
+    const XcdSpecArgs& sp = *spp;
+    const int tid = threadIdx.x;
+    const int K = sp.fn.n_acc;
+    const int ne = sp.ext_cnt ? *sp.ext_cnt : 0;
+    const int ni = *sp.ind_cnt;
+    const int nkron = M * sp.d;
+    const int lda = nkron + ne;
+    if (ni <= 0 || lda <= 0) return;
+    const int tiles_c = (lda + XT - 1) / XT, tiles_j = (ni + SPEC_TJ - 1) / SPEC_TJ;
+    const int n_tiles = tiles_c * tiles_j;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *lds_tile = (int)atomicAdd(sp.tile_counter, 1u);
+        __syncthreads();
+        const int t = *lds_tile;
+        if (t >= n_tiles) break;
+        const int cand = (t % tiles_c) * XT + tid;
+        const int j0 = (t / tiles_c) * SPEC_TJ;
+        if (cand >= lda) continue;
+        uint64_t racc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+        if (cand < nkron) {
+            const int par = cand / sp.d, dg = cand % sp.d;
+            for (int k = 0; k < K; ++k) racc[k] = sp.dep_acc[(size_t)par * K + k] + sp.w_site[(size_t)k * sp.total + dg];
+        } else {
+            const int e = cand - nkron;
+            for (int k = 0; k < K; ++k) racc[k] = sp.ext_acc[(size_t)e * K + k];
+        }
+        const int j1 = j0 + SPEC_TJ < ni ? j0 + SPEC_TJ : ni;
+        for (int j = j0; j < j1; ++j) {
+            uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+            for (int k = 0; k < K; ++k) acc[k] = racc[k] + sp.ind_acc[(size_t)j * K + k];
+            sp.out[(size_t)j * lda + cand] = t4a_fn_value(sp.fn.fid, acc, sp.fn.params);
+        }
+    }
+}
+
 template <int RPT, int CPT, bool ROWMAJOR>
 __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd_kernel(RrluXcdArgs p)
 {
@@ -281,11 +334,37 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     }
     __syncthreads();
     const int rank = __builtin_amdgcn_readfirstlane(win_i[6]);
-    if (rank < 0) return;
+    if (rank < 0) {
+        // pass-through workgroup (another XCD).  Bond chain: it evaluates its share of the NEXT bond's candidate matrix first
+        if (p.spec.out && p.dims) {
+            const int m_spec = p.dims[2] != 0 ? 0 : (p.dims_swap ? p.dims[1] : p.dims[0]);
+            if (m_spec > 0 && m_spec <= p.M)
+                xcd_spec_work(reinterpret_cast<const XcdSpecArgs*>(kernarg_base() + offsetof(RrluXcdArgs, spec)), m_spec, win_i + 8);
+        }
+        return;
+    }
+    const unsigned long long ts_begin = p.ts_u64 > 0 ? wall_clock64() : 0ull;
     const unsigned long long t_elected = (kXcdStamps && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int NW = p.W * XWAVES;
     const int g = rank * XWAVES + wave; // agent id
-    const int M = p.M, N = p.N;
+    // bond chain: the real dimensions come from device memory (the launch was planned for the upper bounds p.M x p.N: rows
+    // beyond M are padding zeros like those beyond p.M always were, columns beyond N have no owner)
+    int M = p.M, N = p.N, max_steps = p.max_steps;
+    int lda = p.M; // leading dimension of the source matrix
+    if (p.dims) {
+        const int d0 = __builtin_amdgcn_readfirstlane(p.dims[0]), d1 = __builtin_amdgcn_readfirstlane(p.dims[1]);
+        M = p.dims_swap ? d1 : d0;
+        N = p.dims_swap ? d0 : d1;
+        if (M > p.M || N > p.N) M = N = 0; // (cannot happen: the plan is made for upper bounds; never index out of the plan)
+        const int mn = M < N ? M : N;
+        max_steps = max_steps < mn ? max_steps : mn;
+        if (mn <= 0) return; // poisoned bond: nothing to do (no completion token: the next preparation kernel sees that)
+        lda = p.rowmap ? __builtin_amdgcn_readfirstlane(p.dims[3]) : M;
+    }
+    M = __builtin_amdgcn_readfirstlane(M); // (wave-uniform by construction; tell the compiler)
+    N = __builtin_amdgcn_readfirstlane(N);
+    max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+    lda = __builtin_amdgcn_readfirstlane(lda);
 
     // ---- my columns (per wave): g + NW q; my rows (per lane): lane + 64 r ----
     int cpos[CPT]; // current position of column g + NW q (-1: beyond N); wave-uniform
@@ -298,13 +377,20 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     double local_sqmax = 0.0;
     // every load is issued before the first one is consumed (clamped addresses instead of branches): the whole matrix is
     // one round trip to memory per lane, not RPT * CPT dependent ones
+    int srow[RPT]; // source row of my slot rows (bond chain: through the row map of the speculative candidate matrix)
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = lane + 64 * r;
+        srow[r] = i;
+        if (p.rowmap) srow[r] = p.rowmap[i < M ? i : 0];
+    }
 #pragma unroll
     for (int q = 0; q < CPT; ++q)
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int i = lane + 64 * r;
             const bool ok = cpos[q] >= 0 && i < M;
-            a[q][r] = p.A[ok ? (size_t)(g + NW * q) * M + i : (size_t)0];
+            a[q][r] = p.A[ok ? (size_t)(g + NW * q) * lda + srow[r] : (size_t)0];
         }
 #pragma unroll
     for (int q = 0; q < CPT; ++q)
@@ -371,7 +457,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         }
     }
 
-    for (int kn = 0; kn < p.max_steps; ++kn) {
+    for (int kn = 0; kn < max_steps; ++kn) {
         const int k = kn - 1; // rows / columns at positions > k form the trailing block searched for pivot kn
         const unsigned diagkey = ((unsigned)kn << 10) | (unsigned)kn;
         const int par = kn & 1;
@@ -935,7 +1021,15 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
         // completion token: the host accepts the result only if rank 0 ran to its end in THIS launch (a launch whose
         // workgroups never met the elected XCD would otherwise leave an all-zero block behind)
         ((volatile int*)p.h_block)[7] = (int)p.salt;
+        if (p.ts_u64 > 0) {
+            p.h_block[p.ts_u64] = ts_begin;
+            p.h_block[p.ts_u64 + 1] = wall_clock64();
+        }
         reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull; // clean header for the next launch (every agent's atomicMax is long done)
+        if (p.dims) { // bond chain: the device-side completion token for the next preparation kernel (max |a| stays in the mirror)
+            __threadfence();
+            p.iresult[3] = (int)p.salt;
+        }
         if (stamp_on) p.stamps[19] = __builtin_amdgcn_s_memtime() - t_done; // ... write-out and host mirror
     }
 }
@@ -987,11 +1081,11 @@ int xcd_norm_cpt(int c)
 
 } // namespace
 
-bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out)
+bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size)
 {
     if (M < 1 || N < 1 || M > 1024 || N > 1024) return false;
     static const int min_elems = std::getenv("T4A_XCD_MIN") ? std::atoi(std::getenv("T4A_XCD_MIN")) : 64 * 64;
-    if ((long long)M * N <= (long long)min_elems) return false; // tiny matrices: the single-workgroup plan of the chip-wide kernel
+    if (!any_size && (long long)M * N <= (long long)min_elems) return false; // tiny matrices: the single-workgroup plan of the chip-wide kernel
     const int rpt = xcd_norm_rpt((M + 63) / 64);
     if (rpt < 0) return false;
     // columns per agent: as few as the 32 compute units of an XCD allow.  A step costs an agent ~500 cycles per owned column
@@ -1029,8 +1123,12 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out)
     plan.RPT = rpt;
     plan.CPT = best_cpt;
     plan.grid = 8 * best_w;
+    // (no padding of the LDS request: two workgroups of this kernel cannot share a compute unit anyway — 8 waves of ~200 VGPRs
+    // each — and a padded request keeps other kernels' workgroups that only have to RETURN on this XCD, see lu_update_kernel,
+    // from being placed at all)
     plan.lds_bytes = xcd_lds_total(rpt);
-    if (plan.lds_bytes < 84 * 1024) plan.lds_bytes = 84 * 1024; // one workgroup per compute unit
+    static const bool pad_lds = std::getenv("T4A_XCD_PAD_LDS") != nullptr;
+    if (pad_lds && plan.lds_bytes < 84 * 1024) plan.lds_bytes = 84 * 1024;
     *out = plan;
     return true;
 }

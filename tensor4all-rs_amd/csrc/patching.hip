@@ -230,6 +230,7 @@ std::vector<Pivot> global_diagonal_pivots(const Tci2& tci, const std::vector<siz
 {
     std::vector<Pivot> out;
     std::set<Pivot> seen;
+    const_cast<Tci2&>(tci).sync_digits(); // (after a device-side bond chain the digit tables are decoded on demand)
     for (size_t b = 0; b + 1 < active.size(); ++b) {
         const IndexSet& is = tci.i_set[b + 1];
         const IndexSet& js = tci.j_set[b];

@@ -180,11 +180,15 @@ void Tci2::set_builtin(int fid, int n_acc, const double* params, const uint64_t*
     std::memcpy(fn_dev_.params, params, sizeof(double) * T4A_FN_MAX_PARAMS);
     weights_.assign(weights, weights + (size_t)n_acc * total_);
     fn_kind_ = FnKind::Builtin;
+    chain_.weights_valid = false; // (the accumulators in the device tables belong to the old weights)
+    chain_.tables_valid = false;
+    chain_.snap_serial[0] = chain_.snap_serial[1] = ~0ull;
 }
 
 void Tci2::set_callback(t4a_gpu_batch_eval_fn cb, void* ctx)
 {
     if (!cb) throw Error(T4A_GPU_NULL_POINTER, "callback is null");
+    sync_digits();
     cb_ = cb;
     cb_ctx_ = ctx;
     fn_kind_ = FnKind::Callback;
@@ -237,12 +241,19 @@ void Tci2::add_global_pivots(const std::vector<std::vector<uint32_t>>& pivots) /
                 throw Error(T4A_GPU_INVALID_ARGUMENT, "pivot value " + std::to_string(p[s]) +
                                                           " is out of bounds at site " + std::to_string(s));
     }
+    if (!pivots.empty()) sync_digits();
     for (const auto& pivot : pivots) {
         for (size_t p = 0; p < n_; ++p) {
             const uint32_t* pre = pivot.data();
             const uint32_t* suf = pivot.data() + p + 1;
-            if (!i_set[p].contains(pre)) i_set[p].push(pre);
-            if (!j_set[p].contains(suf)) j_set[p].push(suf);
+            if (!i_set[p].contains(pre)) {
+                i_set[p].push(pre);
+                chain_.tables_valid = false;
+            }
+            if (!j_set[p].contains(suf)) {
+                j_set[p].push(suf);
+                chain_.tables_valid = false;
+            }
         }
     }
     invalidate_site_tensors();
@@ -476,6 +487,10 @@ void Tci2::invalidate_fill_cache()
 void Tci2::prepare_fill_site(size_t b)
 {
     if (fn_kind_ != FnKind::Builtin || b >= n_) return;
+    if (chain_.digits_stale) { // after a bond chain the accumulators are in the pinned mirror of the device tables: no digits needed
+        prepare_fill_site_from_mirror(b);
+        return;
+    }
     if (fill_cache_.size() != n_) fill_cache_.assign(n_, FillAcc());
     if (shard_world > 1 && (b % shard_world) != shard_rank) return;
     FillAcc& f = fill_cache_[b];
@@ -643,6 +658,7 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     static double hp_sets = 0, hp_luci = 0, hp_post = 0;
     static long hp_n = 0;
     const auto hp_t0 = std::chrono::steady_clock::now();
+    sync_digits();
     // one side may have been built while the previous bond's kernels were running (it does not depend on them)
     SidePrep ready;
     if (prep_.valid && prep_.bond == b) std::swap(ready, prep_);
@@ -705,6 +721,7 @@ void Tci2::update_pivots(size_t b, bool left_orthogonal, const TCI2Options& opti
     for (size_t c : cols) nj.push(j_comb.at(c));
     i_set[b + 1] = ni;
     j_set[b] = nj;
+    chain_.tables_valid = false; // (the host path moved the sets: the device tables of the bond chain are stale)
     if (host_prof) {
         const auto hp_t3 = std::chrono::steady_clock::now();
         hp_sets += std::chrono::duration<double, std::milli>(hp_t1 - hp_t0).count();
@@ -738,6 +755,12 @@ void Tci2::sweep2site(bool forward, const TCI2Options& options)
     prep_.valid = false;
     prefetch_.wanted = false;
     IndexSet ei, ej; // empty extras
+    if (chain_enqueue(forward, options, -1, false)) { // built-in functor: the whole half-sweep in one go (tci2_chain.hip)
+        chain_finish(options);
+        fill_site_tensors();
+        return;
+    }
+    sync_digits();
     if (forward) {
         for (size_t b = 0; b + 1 < n_; ++b) {
             ei.width = b + 1;
@@ -758,6 +781,7 @@ void Tci2::sweep2site(bool forward, const TCI2Options& options)
 void Tci2::sweep1site_at_bond(size_t b, bool forward, double rel_tol, double abs_tol, size_t max_bond_dim,
                               bool update_tensors)
 {
+    sync_digits();
     IndexSet is = forward ? kronecker_i(b) : i_set[b];
     IndexSet js = forward ? j_set[b] : kronecker_j(b);
     if (is.count == 0 || js.count == 0) return;
@@ -781,6 +805,7 @@ void Tci2::sweep1site_at_bond(size_t b, bool forward, double rel_tol, double abs
         i_set[b] = ni;
         j_set[b - 1] = nj;
     }
+    chain_.tables_valid = false;
     if (update_tensors) {
         if (forward) {
             const size_t left_dim = (b == 0) ? 1 : i_set[b].count;
@@ -813,6 +838,7 @@ void Tci2::sweep1site(bool forward, double rel_tol, double abs_tol, size_t max_b
         for (size_t b = n_ - 1; b >= 1; --b) sweep1site_at_bond(b, false, rel_tol, abs_tol, max_bond_dim, update_tensors);
     }
     if (update_tensors) { // tensorci2.rs:902-912 + fill_tensor :813-850
+        sync_digits();
         const size_t last = forward ? n_ - 1 : 0;
         IndexSet rows = kronecker_i(last);
         const IndexSet& jl = j_set[last];
@@ -957,6 +983,7 @@ void Tci2::fill_site_tensors_impl(bool async)
     };
     auto hpf_t = hpf_t0;
     if (!trust_cache) invalidate_fill_cache();
+    if (fn_kind_ != FnKind::Builtin) sync_digits();
     fill_wait(); // the scratch arenas of the previous fill are free again
     if (!fill_stream_) fill_stream_ = pool::stream_get(2); // lowest priority, recycled through the process-wide cache
     const bool builtin = fn_kind_ == FnKind::Builtin;
@@ -972,8 +999,12 @@ void Tci2::fill_site_tensors_impl(bool async)
     std::vector<uint64_t> sig;              // everything those operations depend on: equal signature <=> same graph
     auto dev = [&](std::function<void()> f) { ops.push_back(std::move(f)); };
     auto sg = [&](uint64_t v) { sig.push_back(v); };
-    // everything of this fill is ordered after the work already enqueued on the main stream
-    T4A_HIP(hipStreamSynchronize(eng.stream()));
+    // everything of this fill is ordered after the work already enqueued on the main stream (the per-bond path writes site
+    // tensors there).  After a bond chain nothing on the main stream concerns the fill — and the NEXT chain may already be
+    // running on it: no wait then.
+    const bool no_main_sync = fill_no_main_sync_ && fn_kind_ == FnKind::Builtin;
+    fill_no_main_sync_ = false;
+    if (!no_main_sync) T4A_HIP(hipStreamSynchronize(eng.stream()));
     hipStream_t st = fill_stream_;
     struct SiteJob {
         size_t b;
@@ -1036,13 +1067,18 @@ void Tci2::fill_site_tensors_impl(bool async)
     d_fillA_.reserve(std::max<size_t>(totA, 1));
     d_fillB_.reserve(totB);
     // max|P| bits (n_ u64) and solve status (n_ ints) share one allocation -> one memset
-    d_fillmax_.reserve(n_ + (n_ + 1) / 2);
+    // max|P| bits (n_ u64), solve status (n_ ints) and the work tickets of the trailing updates share one allocation -> one memset
+    const size_t fm_words = n_ + (n_ + 1) / 2 + (LU_MAX_PANEL_STEPS + 1) / 2;
+    d_fillmax_.reserve(fm_words);
     unsigned long long* d_max = d_fillmax_.get();
     int* d_info = reinterpret_cast<int*>(d_fillmax_.get() + n_);
+    unsigned* d_tickets = reinterpret_cast<unsigned*>(d_fillmax_.get() + n_ + (n_ + 1) / 2);
+    // beside a bond chain the fill keeps off the chain's XCD where it could not be placed anyway (lu_update_kernel)
+    const int avoid_xcc = (no_main_sync && !xcd_disabled()) ? eng.xcc() : -1;
     h_fillinfo_.reserve(n_);
     {
         unsigned long long* ptr = d_fillmax_.get();
-        const size_t bytes = (n_ + (n_ + 1) / 2) * sizeof(unsigned long long);
+        const size_t bytes = fm_words * sizeof(unsigned long long);
         fill_timed_ = eng.prof.enabled;
         sg((uint64_t)(uintptr_t)ptr);
         sg((uint64_t)bytes);
@@ -1272,6 +1308,7 @@ void Tci2::fill_site_tensors_impl(bool async)
         int* hinfo = h_fillinfo_.get();
         const size_t info_bytes = n_ * sizeof(int);
         sg((uint64_t)npr);
+        sg((uint64_t)(int64_t)avoid_xcc);
         sg(((uint64_t)(uint32_t)max_n << 32) | (uint32_t)max_nrhs);
         sg(((uint64_t)gx << 32) | gy);
         sg((uint64_t)(uintptr_t)d_lups);
@@ -1283,7 +1320,7 @@ void Tci2::fill_site_tensors_impl(bool async)
             if (npr) {
                 // blocked LU with the unit-lower forward substitution of the right-hand sides folded in; beyond its size
                 // limit the unblocked kernel + explicit forward solve (bitwise the same result)
-                if (!lu_forward_blocked_launch(d_lups, npr, max_n, max_nrhs, st)) {
+                if (!lu_forward_blocked_launch(d_lups, npr, max_n, max_nrhs, st, avoid_xcc, d_tickets)) {
                     lu_batched_launch(d_lups, npr, max_n, st);
                     trsm_left_batched_launch(d_trs, npr, max_n, max_nrhs, st);
                 }
@@ -1566,6 +1603,7 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
     std::vector<size_t> nglobal_hist;
     termination = T4A_GPU_TCI2_MAX_ITERATIONS;
     uint64_t rng_state = options.has_seed ? options.seed : 0x1234567ull;
+    bool pending_fill = false; // fill_site_tensors of the last iteration: accumulators prepared, stream operations not yet issued
 
     for (size_t iter = 0; iter < options.max_iter; ++iter) {
         const double norm = (options.normalize_error && max_sample_value > 0.0) ? max_sample_value : 1.0;
@@ -1574,21 +1612,37 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         if (options.sweep_strategy == 1) is_forward = false;
         else if (options.sweep_strategy == 2) is_forward = (iter % 2 == 0);
 
-        std::vector<IndexSet> extra_i(n_), extra_j(n_);
-        for (size_t p = 0; p < n_; ++p) {
-            extra_i[p].width = p;
-            extra_j[p].width = n_ - p - 1;
-        }
-        if (!options.strictly_nested && !i_set_history.empty()) { // :1675-1685
-            extra_i = i_set_history.back();
-            extra_j = j_set_history.back();
-        }
-        i_set_history.push_back(i_set);
-        j_set_history.push_back(j_set);
-        // only the most recent snapshot is ever read (:1677-1681): cap the memory held by older ones
-        if (i_set_history.size() > 2) {
-            i_set_history.erase(i_set_history.begin());
-            j_set_history.erase(j_set_history.begin());
+        // extras of this iteration: the sets at the start of the previous one (:1675-1685); then the sets as they are now join
+        // the history (:1686-1689).  After a bond chain only codes and counts are current: the entry carries those.
+        long ext_idx = (!options.strictly_nested && !history.empty()) ? (long)history.size() - 1 : -1;
+        {
+            HistEntry cur;
+            cur.serial = ++chain_.hist_serial;
+            if (chain_.digits_stale) {
+                cur.digits_valid = false;
+                cur.cap = chain_.cap;
+                cur.is.resize(n_);
+                cur.js.resize(n_);
+                for (size_t p = 0; p < n_; ++p) {
+                    cur.is[p].width = i_set[p].width;
+                    cur.is[p].count = i_set[p].count;
+                    cur.js[p].width = j_set[p].width;
+                    cur.js[p].count = j_set[p].count;
+                }
+                const ChainTab mi = chain_mirror(chain_.mcur, 0), mj = chain_mirror(chain_.mcur, 1);
+                cur.code.resize(2 * n_ * chain_.cap);
+                std::memcpy(cur.code.data(), mi.code, n_ * chain_.cap * sizeof(uint64_t));
+                std::memcpy(cur.code.data() + n_ * chain_.cap, mj.code, n_ * chain_.cap * sizeof(uint64_t));
+            } else {
+                cur.is = i_set;
+                cur.js = j_set;
+            }
+            history.push_back(std::move(cur));
+            // only the most recent snapshot is ever read (:1677-1681): cap the memory held by older ones
+            if (history.size() > 2) {
+                history.erase(history.begin());
+                if (ext_idx >= 0) --ext_idx;
+            }
         }
         invalidate_site_tensors();
         flush_pivot_errors();
@@ -1603,29 +1657,56 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         const size_t want_k = defer_k > 0 ? (size_t)defer_k : 8;
         const size_t flush_k = nb_ > want_k + 1 ? want_k : nb_ - 1;
         const size_t flush_at_fwd = flush_k, flush_at_bwd = nb_ - 1 - flush_k;
-        if (is_forward) {
-            for (size_t b = 0; b + 1 < n_; ++b) {
-                // bond b+1 reads J_{b+2}, which bond b does not touch: its column side can be built ahead
-                prefetch_.wanted = b + 2 < n_;
-                prefetch_.bond = b + 1;
-                prefetch_.cols = true;
-                prefetch_.extra = prefetch_.wanted ? &extra_j[b + 1] : nullptr;
-                // site b-1 only reads I_{b-1}, J_{b-1}, I_b: final since bond b-1 (forward bonds write I_{b+1}, J_b)
-                prefetch_.fill_site = (fill_ahead && b >= 1) ? (long)(b - 1) : -1;
-                prefetch_.flush_fill = (b == flush_at_fwd);
-                update_pivots(b, true, options, extra_i[b + 1], extra_j[b]);
-            }
+        flush_deferred_fill();
+        // built-in functor, full pivot search: the whole half-sweep is enqueued at once (tci2_chain.hip) ...
+        const bool chained = chain_enqueue(is_forward, options, ext_idx, true);
+        // ... and while the device works on it the host issues fill_site_tensors of the PREVIOUS iteration (its accumulators
+        // were taken from the mirror when that iteration finished; nothing of it touches the main stream)
+        if (pending_fill) {
+            pending_fill = false;
+            for (size_t b = 0; b < n_; ++b) prepare_fill_site(b); // (from the mirror of the previous chain; the new one writes the other mirror)
+            fill_cache_trusted_ = true;
+            fill_no_main_sync_ = true;
+            fill_site_tensors_impl(true);
+            if (!keep_site_tensors) invalidate_site_tensors(); // (the end of that iteration invalidated them, tensorci2.rs:707-708)
+        }
+        if (chained) {
+            chain_finish(options);
         } else {
-            for (size_t b = n_ - 1; b-- > 0;) {
-                // bond b-1 reads I_{b-1}, which bond b does not touch: its row side can be built ahead
-                prefetch_.wanted = b > 0;
-                prefetch_.bond = b - 1;
-                prefetch_.cols = false;
-                prefetch_.extra = prefetch_.wanted ? &extra_i[b] : nullptr;
-                // site b+2 reads I_{b+2}, J_{b+2}, I_{b+3}: final since bond b+1 (backward bonds write I_{b+1}, J_b)
-                prefetch_.fill_site = (fill_ahead && b + 2 < n_) ? (long)(b + 2) : -1;
-                prefetch_.flush_fill = (b == flush_at_bwd);
-                update_pivots(b, false, options, extra_i[b + 1], extra_j[b]);
+            // ... otherwise bond by bond
+            sync_digits();
+            std::vector<IndexSet> no_i(n_), no_j(n_);
+            for (size_t p = 0; p < n_; ++p) {
+                no_i[p].width = p;
+                no_j[p].width = n_ - p - 1;
+            }
+            if (ext_idx >= 0) hist_digits(history[(size_t)ext_idx]);
+            const std::vector<IndexSet>& extra_i = ext_idx >= 0 ? history[(size_t)ext_idx].is : no_i;
+            const std::vector<IndexSet>& extra_j = ext_idx >= 0 ? history[(size_t)ext_idx].js : no_j;
+            if (is_forward) {
+                for (size_t b = 0; b + 1 < n_; ++b) {
+                    // bond b+1 reads J_{b+2}, which bond b does not touch: its column side can be built ahead
+                    prefetch_.wanted = b + 2 < n_;
+                    prefetch_.bond = b + 1;
+                    prefetch_.cols = true;
+                    prefetch_.extra = prefetch_.wanted ? &extra_j[b + 1] : nullptr;
+                    // site b-1 only reads I_{b-1}, J_{b-1}, I_b: final since bond b-1 (forward bonds write I_{b+1}, J_b)
+                    prefetch_.fill_site = (fill_ahead && b >= 1) ? (long)(b - 1) : -1;
+                    prefetch_.flush_fill = (b == flush_at_fwd);
+                    update_pivots(b, true, options, extra_i[b + 1], extra_j[b]);
+                }
+            } else {
+                for (size_t b = n_ - 1; b-- > 0;) {
+                    // bond b-1 reads I_{b-1}, which bond b does not touch: its row side can be built ahead
+                    prefetch_.wanted = b > 0;
+                    prefetch_.bond = b - 1;
+                    prefetch_.cols = false;
+                    prefetch_.extra = prefetch_.wanted ? &extra_i[b] : nullptr;
+                    // site b+2 reads I_{b+2}, J_{b+2}, I_{b+3}: final since bond b+1 (backward bonds write I_{b+1}, J_b)
+                    prefetch_.fill_site = (fill_ahead && b + 2 < n_) ? (long)(b + 2) : -1;
+                    prefetch_.flush_fill = (b == flush_at_bwd);
+                    update_pivots(b, false, options, extra_i[b + 1], extra_j[b]);
+                }
             }
         }
         prefetch_.wanted = false;
@@ -1633,9 +1714,17 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         prep_.valid = false;
         // the cores are not needed by the next half-sweep unless the global pivot search evaluates the TT
         flush_deferred_fill(); // (normally already gone; guarantees the order of consecutive fills)
-        fill_cache_trusted_ = fill_ahead;
-        fill_defer_requested_ = fill_ahead && iter + 1 < options.max_iter;
-        fill_site_tensors_impl(options.nsearch == 0 && !options.strictly_nested);
+        const bool fill_async = options.nsearch == 0 && !options.strictly_nested;
+        if (chained && chain_.digits_stale && fill_async) {
+            // this fill's accumulators (out of the mirror), descriptors and launches go out after the NEXT iteration's chain
+            // has been enqueued (or after the loop): the device is busy with that chain while the host prepares the fill
+            pending_fill = true;
+        } else {
+            fill_cache_trusted_ = fill_ahead && !chained;
+            fill_defer_requested_ = fill_ahead && !chained && iter + 1 < options.max_iter;
+            fill_no_main_sync_ = chained && chain_.digits_stale;
+            fill_site_tensors_impl(fill_async);
+        }
         const double error = max_bond_error();
         errors_hist.push_back(error / norm);
 
@@ -1653,6 +1742,14 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
             termination = reason;
             break;
         }
+    }
+    if (pending_fill) { // the last iteration's fill
+        pending_fill = false;
+        for (size_t b = 0; b < n_; ++b) prepare_fill_site(b);
+        fill_cache_trusted_ = true;
+        fill_no_main_sync_ = true;
+        fill_site_tensors_impl(true);
+        if (!keep_site_tensors) invalidate_site_tensors(); // (the end of that iteration invalidated them, tensorci2.rs:707-708)
     }
     // the cores of the last iteration are complete (deferred solve errors surface here); in pipelined mode the wait
     // is left to the first reader (site_tensor*, evaluate, export_site_tensors_async, the next fill)

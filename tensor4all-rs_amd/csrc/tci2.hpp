@@ -88,6 +88,18 @@ public:
     void make_canonical(double rel_tol, double abs_tol, size_t max_bond_dim);
     void invalidate_site_tensors();
     void flush_pivot_errors() { pivot_errors.clear(); }
+    // the I/J sets (or the history) were changed behind the driver's back (C-ABI setters, conversion): the device-side
+    // tables of the bond chain are re-uploaded before they are used again
+    void mark_sets_changed()
+    {
+        chain_.tables_valid = false;
+        chain_.digits_stale = false; // (the caller has just written digit tables: they are the master copy now)
+    }
+    // statistics of the device-side bond chain: [0] half-sweeps run as a chain [1] bonds run in chains [2] chains that fell back
+    // to the per-bond path part-way [3] half-sweeps that were not eligible
+    std::array<uint64_t, 4> chain_stats{{0, 0, 0, 0}};
+    bool chain_enabled = true;  // false: every half-sweep runs bond by bond (A/B measurements, tests)
+    bool chain_verify = false;  // true: after every chain the device tables are read back and compared with the host's sets
 
     std::vector<double> evaluate(const uint32_t* idx, size_t n_pts); // idx n_sites x n_pts col-major
     double sum();
@@ -101,7 +113,23 @@ public:
     size_t n_;
     std::vector<size_t> local_dims;
     std::vector<IndexSet> i_set, j_set;
-    std::vector<std::vector<IndexSet>> i_set_history, j_set_history;
+    // history of the index sets (tensorci2.rs:1675-1689: the sets at the start of every iteration; only the newest two are ever
+    // read).  After a device-side bond chain the digit tables are not materialised: an entry then carries the codes of the sets.
+    struct HistEntry {
+        std::vector<IndexSet> is, js;   // widths and counts always valid, digit tables only when digits_valid
+        bool digits_valid = true;
+        std::vector<uint64_t> code;     // [2][n][cap] (I then J), copied from the pinned mirror of the device tables
+        size_t cap = 0;
+        uint64_t serial = 0;
+    };
+    std::vector<HistEntry> history;
+    void clear_history()
+    {
+        history.clear();
+        chain_.hist_serial += 16;
+    }
+    // I / J digit tables up to date (after a bond chain only codes and counts are current: decoded here on demand)
+    void sync_digits();
     std::vector<double> bond_errors, pivot_errors;
     double max_sample_value = 0.0;
     std::vector<DevCore> cores;
@@ -193,6 +221,57 @@ private:
     void set_core_zero(size_t site, size_t l, size_t s, size_t r);
     void update_pivot_errors(const std::vector<double>& e);
     std::vector<std::vector<uint32_t>> find_global_pivots(double abs_tol, const TCI2Options& o, uint64_t& rng_state);
+
+    // ---- device-side bond chain (tci2_chain.hip, kernels_chain.hip) ----
+    struct ChainState {
+        bool tables_valid = false;   // device tables == host master copy of I / J (digit tables or mirror)
+        bool digits_stale = false;   // the digit tables of i_set / j_set are older than the mirror (their counts are current)
+        size_t cap = 0;              // entries per site in every table
+        int n_acc = 0;               // accumulators per entry the tables were laid out for
+        uint64_t hist_serial = 0;    // serial number of the newest history entry (advanced by every push)
+        uint64_t snap_serial[2] = {~0ull, ~0ull}; // which history entry a device snapshot slot holds
+        int mcur = 0;                // which of the two pinned mirrors holds the current sets
+        DevBuf<uint64_t> tab;        // [6 families: I, J, snapshot 0 (I, J), snapshot 1 (I, J)] codes + accumulators
+        DevBuf<int> cnt;             // [6][n]
+        PinBuf<uint64_t> mtab;       // [2 mirrors][2 families]: pinned host copies of I, J, written by the device
+        PinBuf<int> mcnt;            // [2][2][n]
+        DevBuf<uint64_t> weights;    // [K][total]
+        DevBuf<int> siteinfo;        // [2][n]: local dimensions, weight offsets
+        bool weights_valid = false;
+        DevBuf<uint64_t> ind, dep;   // independent-side lists of all bonds; dependent-side list of the current bond
+        DevBuf<int> ind_cnt, rowmap;
+        DevBuf<double> pi, spec[2];  // candidate matrix of the first bond; speculative candidate matrices (alternating)
+        DevBuf<char> blocks;         // per-bond result blocks
+        PinBuf<char> hblocks;
+        DevBuf<int> dims;            // per-bond {M, N, poison, lda}
+        PinBuf<int> hdims;
+        // a chain that has been enqueued and not yet finished
+        bool inflight = false;
+        bool forward = true;
+        bool in_optimize = false;
+        long ext_idx = -1;
+        size_t chi = 0;
+        std::vector<size_t> order;
+        std::vector<ChainRrluPlan> plans;
+        std::vector<unsigned> tokens;
+        ChainBlock proto;
+        bool timed = false;
+    } chain_;
+    bool chain_usable(const TCI2Options& options) const;
+    ChainTab chain_tab(int family) const;    // 0: I, 1: J, 2 + 2 s: snapshot s of I, 3 + 2 s: snapshot s of J
+    ChainTab chain_mirror(int which, int family) const; // pinned mirror `which` of family 0 (I) / 1 (J)
+    void chain_layout(size_t cap);
+    void chain_upload_current();
+    void chain_upload_hist(HistEntry& e, int slot);
+    uint64_t code_of(const uint32_t* v, size_t first_site, size_t width, bool prefix) const;
+    void decode_set(IndexSet& s, const uint64_t* codes, size_t first_site, bool prefix) const;
+    void hist_digits(HistEntry& e);
+    // enqueues the whole half-sweep (false: not eligible, nothing was done); chain_finish() waits for it and takes over the
+    // results (falling back to update_pivots for the bonds after one that did not complete)
+    bool chain_enqueue(bool forward, const TCI2Options& options, long ext_idx, bool in_optimize);
+    void chain_finish(const TCI2Options& options);
+    void prepare_fill_site_from_mirror(size_t b);
+    bool fill_no_main_sync_ = false; // the next fill does not depend on work of the main stream (bond chain: no cores written there)
 
     // device scratch
     DevBuf<uint64_t> d_rowacc_, d_colacc_;

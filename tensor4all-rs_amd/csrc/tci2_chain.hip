@@ -1,0 +1,689 @@
+// tci2_chain.hip — the host-free half-sweep of the TCI2 driver ("bond chain").
+//
+// update_pivots (tensorci2.rs:1821-2007) of bond b needs the pivots bond b-1 (forward) / b+1 (backward) selected, so a
+// half-sweep (tensorci2.rs:1695-1725) is a chain of dependent steps.  tci2.hip runs it bond by bond with the host in the loop:
+// build the row / column sets, upload accumulators, three launches, wait, read the permutations.  Here the whole half-sweep
+// is ENQUEUED at once for built-in functors (kernels_chain.hip has the device side):
+//
+//   * the index sets live on the device as tables of (code, accumulators); every rrLU's pivots are gathered into them — and
+//     into a pinned host mirror — by the preparation kernel of the next bond.  The host's master copy of I / J after a chain
+//     IS that mirror: counts are read back, digit tables are decoded from the codes only when somebody asks for them
+//     (sync_digits: getters, the per-bond path, global pivots), the fill accumulators are copied from it;
+//   * between two rrLU launches only the preparation kernel runs (gather + dependent side of the next bond); the side that
+//     does not depend on the chain is built for all bonds by one launch up front, the candidate matrix of bond b is
+//     evaluated speculatively while the rrLU of the previous bond still runs — by that launch's own pass-through workgroups
+//     (the single-XCD kernel launches 8 W workgroups of which 7 W land on the other XCDs and used to return at once) — and
+//     read through a row map; no second stream, no events: two launches per bond;
+//   * launches are planned for upper bounds that follow from the set sizes alone; kernels read the real dimensions on the
+//     device;
+//   * optimize() enqueues the chain of iteration t + 1 before it issues fill_site_tensors of iteration t (two mirrors
+//     alternate), so the host work of the fill overlaps the device's bond updates as well.
+//
+// Nothing here changes a result: the row / column lists are the same lists in the same order, the rrLU kernels are the
+// bit-exact ones of engine.hip (tests/test_gpu_chain.py runs chain, per-bond path and oracle side by side; with set_chain(verify)
+// the decoded mirror is checked against codes and accumulators recomputed on the host and against the device tables).  The LUCI
+// factors of a bond are not built: every caller (sweep2site :746-798, optimize_with_finder :1659-1776) overwrites all site
+// tensors with fill_site_tensors right after the half-sweep.
+//
+// Not eligible (the per-bond path of tci2.hip runs instead): host callbacks, PivotSearchStrategy::Rook, index spaces beyond
+// 63 bits, sets beyond CHAIN_MAX_SET entries, bonds whose upper-bound shape no device-dimension kernel takes
+// (> 1024 rows / columns: the chip-wide kernels), T4A_NO_CHAIN=1, set_chain(false).
+#include "tci2.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace t4a {
+
+namespace {
+size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+} // namespace
+
+bool Tci2::chain_usable(const TCI2Options& options) const
+{
+    static const bool off = std::getenv("T4A_NO_CHAIN") != nullptr;
+    if (off || !chain_enabled || fn_kind_ != FnKind::Builtin || options.pivot_search != 0) return false;
+    long double space = 1.0L;
+    for (size_t d : local_dims) space *= (long double)d;
+    if (space >= 9.0e18L) return false; // codes are 63-bit mixed-radix numbers
+    for (size_t p = 0; p < n_; ++p) {
+        if (i_set[p].count == 0 || j_set[p].count == 0) return false;
+        if (i_set[p].count > (size_t)CHAIN_MAX_SET || j_set[p].count > (size_t)CHAIN_MAX_SET) return false;
+    }
+    return true;
+}
+
+// prefix sets I_p (sites 0 .. width-1): code = v[w-1] + d_{w-1} (v[w-2] + d_{w-2} ( ... )); suffix sets J_p (sites first ..
+// first+width-1): code = v[0] + d_first (v[1] + d_{first+1} ( ... )).  Either way the Kronecker step of kernels_chain.hip is
+// code(child) = s + d * code(parent).
+uint64_t Tci2::code_of(const uint32_t* v, size_t first_site, size_t width, bool prefix) const
+{
+    uint64_t c = 0;
+    if (prefix) {
+        for (size_t s = 0; s < width; ++s) c = (uint64_t)v[s] + (uint64_t)local_dims[first_site + s] * c;
+    } else {
+        for (size_t s = width; s-- > 0;) c = (uint64_t)v[s] + (uint64_t)local_dims[first_site + s] * c;
+    }
+    return c;
+}
+
+// inverse of code_of for a whole set (s.width and s.count are given)
+void Tci2::decode_set(IndexSet& s, const uint64_t* codes, size_t first_site, bool prefix) const
+{
+    const size_t w = s.width;
+    s.d.assign(s.count * w, 0u);
+    for (size_t k = 0; k < s.count; ++k) {
+        uint64_t c = codes[k];
+        uint32_t* v = s.d.data() + k * w;
+        if (prefix) {
+            for (size_t q = w; q-- > 0;) {
+                const uint64_t d = local_dims[first_site + q];
+                v[q] = (uint32_t)(c % d);
+                c /= d;
+            }
+        } else {
+            for (size_t q = 0; q < w; ++q) {
+                const uint64_t d = local_dims[first_site + q];
+                v[q] = (uint32_t)(c % d);
+                c /= d;
+            }
+        }
+    }
+}
+
+ChainTab Tci2::chain_tab(int family) const
+{
+    const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
+    const size_t fam = n_ * cap * (1 + K);
+    ChainTab t;
+    t.code = chain_.tab.get() + (size_t)family * fam;
+    t.acc = t.code + n_ * cap;
+    t.cnt = chain_.cnt.get() + (size_t)family * n_;
+    return t;
+}
+
+ChainTab Tci2::chain_mirror(int which, int family) const
+{
+    const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
+    const size_t fam = n_ * cap * (1 + K);
+    ChainTab t;
+    t.code = chain_.mtab.get() + ((size_t)which * 2 + (size_t)family) * fam;
+    t.acc = t.code + n_ * cap;
+    t.cnt = chain_.mcnt.get() + ((size_t)which * 2 + (size_t)family) * n_;
+    return t;
+}
+
+void Tci2::sync_digits()
+{
+    if (!chain_.digits_stale) return;
+    const size_t cap = chain_.cap;
+    const ChainTab mi = chain_mirror(chain_.mcur, 0), mj = chain_mirror(chain_.mcur, 1);
+    for (size_t p = 0; p < n_; ++p) {
+        if ((size_t)mi.cnt[p] != i_set[p].count || (size_t)mj.cnt[p] != j_set[p].count)
+            throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: mirror counts disagree with the host's sets");
+        decode_set(i_set[p], mi.code + p * cap, 0, true);
+        decode_set(j_set[p], mj.code + p * cap, p + 1, false);
+    }
+    chain_.digits_stale = false;
+}
+
+void Tci2::hist_digits(HistEntry& e)
+{
+    if (e.digits_valid) return;
+    for (size_t p = 0; p < n_; ++p) {
+        decode_set(e.is[p], e.code.data() + p * e.cap, 0, true);
+        decode_set(e.js[p], e.code.data() + (n_ + p) * e.cap, p + 1, false);
+    }
+    e.digits_valid = true;
+}
+
+void Tci2::chain_layout(size_t cap)
+{
+    const int K = fn_dev_.n_acc;
+    if (cap <= chain_.cap && K == chain_.n_acc && chain_.tab.get()) return;
+    sync_digits(); // (the mirror is about to move: the digit tables take over as the master copy)
+    cap = std::max(cap, chain_.cap);
+    chain_.cap = cap;
+    chain_.n_acc = K;
+    const size_t fam = n_ * cap * (1 + (size_t)K);
+    chain_.tab.reserve(6 * fam);
+    chain_.cnt.reserve(6 * n_);
+    chain_.mtab.reserve(4 * fam);
+    chain_.mcnt.reserve(4 * n_);
+    chain_.tables_valid = false;
+    chain_.snap_serial[0] = chain_.snap_serial[1] = ~0ull;
+}
+
+// host sets -> current pinned mirror -> device tables (families 0, 1).  Rare: first use, after the host changed the sets.
+void Tci2::chain_upload_current()
+{
+    const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
+    const size_t fam = n_ * cap * (1 + K);
+    hipStream_t st = eng.stream();
+    const ChainTab mi = chain_mirror(chain_.mcur, 0), mj = chain_mirror(chain_.mcur, 1);
+    if (!chain_.digits_stale) { // (otherwise the mirror already is the master copy)
+        std::vector<uint64_t> a;
+        for (size_t p = 0; p < n_; ++p) {
+            for (int side = 0; side < 2; ++side) {
+                const IndexSet& s = side == 0 ? i_set[p] : j_set[p];
+                const ChainTab& m = side == 0 ? mi : mj;
+                if (s.count > cap) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: index set larger than the device tables");
+                const size_t first = side == 0 ? 0 : p + 1;
+                accumulate(s, first, a);
+                for (size_t k = 0; k < s.count; ++k) m.code[p * cap + k] = code_of(s.at(k), first, s.width, side == 0);
+                std::memcpy(m.acc + p * cap * K, a.data(), a.size() * sizeof(uint64_t));
+                m.cnt[p] = (int)s.count;
+            }
+        }
+    }
+    // the other mirror gets the same content: a chain writes every entry but I_0 and J_{n-1}, which never change
+    const ChainTab oi = chain_mirror(1 - chain_.mcur, 0);
+    std::memcpy(oi.code, mi.code, 2 * fam * sizeof(uint64_t));
+    std::memcpy(oi.cnt, mi.cnt, 2 * n_ * sizeof(int));
+    T4A_HIP(hipMemcpyAsync(chain_tab(0).code, mi.code, 2 * fam * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    T4A_HIP(hipMemcpyAsync(chain_tab(0).cnt, mi.cnt, 2 * n_ * sizeof(int), hipMemcpyHostToDevice, st));
+    T4A_HIP(hipStreamSynchronize(st));
+    chain_.tables_valid = true;
+}
+
+// a history entry -> device snapshot slot (only when the slot that was filled on the device is gone)
+void Tci2::chain_upload_hist(HistEntry& e, int slot)
+{
+    hist_digits(e);
+    const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
+    const size_t fam = n_ * cap * (1 + K);
+    std::vector<uint64_t> buf(2 * fam, 0);
+    std::vector<int> cnt(2 * n_, 0);
+    std::vector<uint64_t> a;
+    for (size_t p = 0; p < n_; ++p)
+        for (int side = 0; side < 2; ++side) {
+            const IndexSet& s = side == 0 ? e.is[p] : e.js[p];
+            if (s.count > cap) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: history set larger than the device tables");
+            const size_t first = side == 0 ? 0 : p + 1;
+            uint64_t* code = buf.data() + (size_t)side * fam;
+            uint64_t* acc = code + n_ * cap;
+            accumulate(s, first, a);
+            for (size_t k = 0; k < s.count; ++k) code[p * cap + k] = code_of(s.at(k), first, s.width, side == 0);
+            std::memcpy(acc + p * cap * K, a.data(), a.size() * sizeof(uint64_t));
+            cnt[(size_t)side * n_ + p] = (int)s.count;
+        }
+    T4A_HIP(hipMemcpy(chain_tab(2 + 2 * slot).code, buf.data(), buf.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    T4A_HIP(hipMemcpy(chain_tab(2 + 2 * slot).cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+}
+
+// accumulators fill_site_tensors needs for site b (J_b, kron(I_b, d_b), I_{b+1}; tensorci2.rs:1101-1145) from the mirror
+void Tci2::prepare_fill_site_from_mirror(size_t b)
+{
+    if (fill_cache_.size() != n_) fill_cache_.assign(n_, FillAcc());
+    if (shard_world > 1 && (b % shard_world) != shard_rank) return;
+    FillAcc& f = fill_cache_[b];
+    f.valid = false;
+    const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
+    const ChainTab mi = chain_mirror(chain_.mcur, 0), mj = chain_mirror(chain_.mcur, 1);
+    const size_t ni = i_set[b].count, nj = j_set[b].count;
+    if (ni == 0 || nj == 0) return;
+    f.accJ.assign(mj.acc + b * cap * K, mj.acc + b * cap * K + nj * K);
+    const size_t d = local_dims[b];
+    f.accK.resize(ni * d * K);
+    for (size_t i = 0; i < ni; ++i)
+        for (size_t s = 0; s < d; ++s)
+            for (size_t k = 0; k < K; ++k)
+                f.accK[(i * d + s) * K + k] = mi.acc[(b * cap + i) * K + k] + weights_[k * total_ + offset_[b] + s];
+    if (b + 1 < n_)
+        f.accI.assign(mi.acc + (b + 1) * cap * K, mi.acc + (b + 1) * cap * K + i_set[b + 1].count * K);
+    else
+        f.accI.clear();
+    f.valid = true;
+}
+
+bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx, bool in_optimize)
+{
+    if (chain_.inflight) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: a chain is already in flight");
+    if (!chain_usable(options)) {
+        ++chain_stats[3];
+        return false;
+    }
+    const size_t nb = n_ - 1;
+    const size_t K = (size_t)fn_dev_.n_acc;
+    const size_t chi = options.max_bond_dim_or_max();
+    hipStream_t st = eng.stream();
+    HistEntry* ext = ext_idx >= 0 ? &history[(size_t)ext_idx] : nullptr;
+
+    // ---- 1. upper bounds of every bond's shape (set sizes only), launch plans ----
+    std::vector<size_t> cI(n_), cJ(n_), eI(n_, 0), eJ(n_, 0);
+    size_t need_cap = 1;
+    bool use_extras = false;
+    for (size_t p = 0; p < n_; ++p) {
+        cI[p] = i_set[p].count;
+        cJ[p] = j_set[p].count;
+        if (ext) {
+            eI[p] = ext->is[p].count;
+            eJ[p] = ext->js[p].count;
+        }
+        use_extras |= eI[p] != 0 || eJ[p] != 0;
+        need_cap = std::max({need_cap, cI[p], cJ[p], eI[p], eJ[p]});
+    }
+    std::vector<size_t> order(nb);
+    for (size_t k = 0; k < nb; ++k) order[k] = forward ? k : nb - 1 - k;
+    std::vector<size_t> dep_ub(nb), ind_ub(nb), lda_ub(nb, 0);
+    std::vector<ChainRrluPlan> plans(nb);
+    size_t Mcap = 1, Ncap = 1, steps_cap = 1, pi_cap = 0, spec_cap = 0, dep_cap = 1, ind_cap = 1;
+    for (size_t k = 0; k < nb; ++k) {
+        const size_t b = order[k];
+        const size_t Mub = cI[b] * local_dims[b] + eI[b + 1];
+        const size_t Nub = cJ[b + 1] * local_dims[b + 1] + eJ[b];
+        const size_t rub = std::max<size_t>(std::min({Mub, Nub, chi}), 1);
+        cI[b + 1] = rub; // bond b writes I_{b+1} and J_b
+        cJ[b] = rub;
+        need_cap = std::max(need_cap, rub);
+        dep_ub[b] = forward ? Mub : Nub; // the kernel's rows are the dependent side in both directions
+        ind_ub[b] = forward ? Nub : Mub;
+        if (dep_ub[b] > 65535 || ind_ub[b] > 65535 || !eng.chain_plan((int)dep_ub[b], (int)ind_ub[b], &plans[b])) {
+            ++chain_stats[3];
+            return false;
+        }
+        plans[b].code += forward ? 0 : 4; // (row-major tie order of the transposed problem)
+        Mcap = std::max(Mcap, Mub);
+        Ncap = std::max(Ncap, Nub);
+        dep_cap = std::max(dep_cap, dep_ub[b]);
+        ind_cap = std::max(ind_cap, ind_ub[b]);
+        steps_cap = std::max(steps_cap, rub);
+        const bool fused = plans[b].kind == 1 && plans[b].fused;
+        if (!fused) {
+            pi_cap = std::max(pi_cap, dep_ub[b] * ind_ub[b]); // (evaluated directly when the previous launch could not speculate)
+            if (k > 0 && plans[order[k - 1]].kind == 2) {
+                const size_t site = forward ? b : b + 1;
+                lda_ub[b] = dep_ub[order[k - 1]] * local_dims[site] + (forward ? eI[b + 1] : eJ[b]);
+                spec_cap = std::max(spec_cap, lda_ub[b] * ind_ub[b]);
+            }
+        }
+    }
+    if (need_cap > (size_t)CHAIN_MAX_SET) {
+        ++chain_stats[3];
+        return false;
+    }
+
+    // ---- 2. buffers ----
+    chain_layout(round_up_sz(need_cap, 64));
+    const size_t cap = chain_.cap;
+    if (!chain_.weights_valid) {
+        chain_.weights.reserve(weights_.size());
+        chain_.siteinfo.reserve(2 * n_);
+        std::vector<int> si(2 * n_);
+        for (size_t p = 0; p < n_; ++p) {
+            si[p] = (int)local_dims[p];
+            si[n_ + p] = (int)offset_[p];
+        }
+        T4A_HIP(hipMemcpyAsync(chain_.weights.get(), weights_.data(), weights_.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(chain_.siteinfo.get(), si.data(), si.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st));
+        chain_.weights_valid = true;
+    }
+    chain_.ind.reserve(nb * ind_cap * (1 + K));
+    chain_.ind_cnt.reserve(nb);
+    chain_.dep.reserve(dep_cap * (1 + K));
+    chain_.rowmap.reserve(dep_cap);
+    if (pi_cap) chain_.pi.reserve(pi_cap);
+    if (spec_cap) {
+        chain_.spec[0].reserve(spec_cap);
+        chain_.spec[1].reserve(spec_cap);
+    }
+    ChainBlock proto;
+    proto.off_piv = 32;
+    proto.off_rp = proto.off_piv + sizeof(double) * steps_cap;
+    proto.off_cp = proto.off_rp + sizeof(int) * Mcap;
+    proto.off_ts = round_up_sz(proto.off_cp + sizeof(int) * Ncap, 8);
+    proto.bytes = proto.off_ts + 16;
+    chain_.blocks.reserve(nb * proto.bytes);
+    chain_.hblocks.reserve(nb * proto.bytes);
+    chain_.dims.reserve(nb * 5 + 2); // {M, N, poison, lda} per bond, then one tile counter per bond (speculative evaluation)
+    chain_.hdims.reserve(nb * 4);
+    const bool timed = eng.prof.enabled;
+
+    // ---- 3. tables: current sets, the extras of this iteration, the snapshot for the next one ----
+    if (!chain_.tables_valid) chain_upload_current();
+    int ext_slot = 0;
+    if (use_extras) {
+        const uint64_t want = ext->serial;
+        if (chain_.snap_serial[0] == want)
+            ext_slot = 0;
+        else if (chain_.snap_serial[1] == want)
+            ext_slot = 1;
+        else {
+            ext_slot = (in_optimize && chain_.snap_serial[0] == chain_.hist_serial) ? 1 : 0;
+            chain_upload_hist(*ext, ext_slot);
+            chain_.snap_serial[ext_slot] = want;
+        }
+    }
+    int snap = -1;
+    if (in_optimize) { // the sets as they are now are the extras of the next iteration (tensorci2.rs:1675-1689): copied by the first kernel
+        snap = use_extras ? 1 - ext_slot : 0;
+        chain_.snap_serial[snap] = chain_.hist_serial;
+    }
+
+    // ---- 4. enqueue the whole half-sweep ----
+    // (result blocks, dims and tile counters are cleared and the snapshot is taken by chain_indep_kernel: one launch instead
+    // of five memset / memcpy operations in front of the chain)
+    for (size_t b = 0; b < nb; ++b) {
+        std::memset(chain_.hblocks.get() + b * proto.bytes, 0, 32);
+        std::memset(chain_.hdims.get() + b * 4, 0xFF, 4 * sizeof(int)); // (-1: not written yet)
+    }
+    auto block_of = [&](size_t b) {
+        ChainBlock k = proto;
+        k.dev = chain_.blocks.get() + b * proto.bytes;
+        k.host = chain_.hblocks.get() + b * proto.bytes;
+        return k;
+    };
+    ChainCommon c;
+    std::memset(&c, 0, sizeof(c));
+    c.I = chain_tab(0);
+    c.J = chain_tab(1);
+    c.HI = chain_tab(2 + 2 * ext_slot);
+    c.HJ = chain_tab(3 + 2 * ext_slot);
+    c.mI = chain_mirror(1 - chain_.mcur, 0); // this chain's results go to the other mirror (the current one may still feed a fill)
+    c.mJ = chain_mirror(1 - chain_.mcur, 1);
+    c.cap = (int)cap;
+    c.K = (int)K;
+    c.w = chain_.weights.get();
+    c.total = (int)total_;
+    c.ldim = chain_.siteinfo.get();
+    c.woff = chain_.siteinfo.get() + n_;
+    c.forward = forward ? 1 : 0;
+    c.use_extras = use_extras ? 1 : 0;
+    c.ind_code = chain_.ind.get();
+    c.ind_acc = chain_.ind.get() + nb * ind_cap;
+    c.ind_cnt = chain_.ind_cnt.get();
+    c.ind_cap = (int)ind_cap;
+    c.dep_code = chain_.dep.get();
+    c.dep_acc = chain_.dep.get() + dep_cap;
+    c.dep_cap = (int)dep_cap;
+    c.rowmap = chain_.rowmap.get();
+    c.dims = chain_.dims.get();
+    c.hdims = chain_.hdims.get();
+    c.n_sites = (int)n_;
+    if (snap >= 0) {
+        c.snap_dst = chain_tab(2 + 2 * snap).code;
+        c.snap_cnt_dst = chain_tab(2 + 2 * snap).cnt;
+        c.snap_words = 2 * n_ * cap * (1 + K);
+    }
+    c.zero_a = reinterpret_cast<uint64_t*>(chain_.blocks.get());
+    c.zero_a_words = nb * proto.bytes / 8;
+    c.zero_b = reinterpret_cast<uint64_t*>(chain_.dims.get());
+    c.zero_b_words = (nb * 5 * sizeof(int) + 7) / 8;
+
+    eng.chain_begin(plans);
+    std::vector<unsigned> tokens(nb, 0u);
+    try {
+        chain_indep_launch(c, (int)nb, st);
+        unsigned* tile_counters = reinterpret_cast<unsigned*>(chain_.dims.get() + nb * 4);
+        bool spec_pending = false; // the previous bond's launch evaluates this bond's candidate matrix
+        for (size_t k = 0; k < nb; ++k) {
+            const size_t b = order[k];
+            const ChainRrluPlan& pl = plans[b];
+            const bool fused = pl.kind == 1 && pl.fused;
+            const bool spec_here = spec_pending && !fused;
+            const ChainBlock blk = block_of(b);
+            ChainPrepArgs pa;
+            std::memset(&pa, 0, sizeof(pa));
+            pa.b = (int)b;
+            pa.do_build = 1;
+            pa.with_rowmap = spec_here ? 1 : 0;
+            pa.prev_b = -1;
+            if (k > 0) {
+                const size_t pb = order[k - 1];
+                const ChainBlock pblk = block_of(pb);
+                pa.prev_b = (int)pb;
+                pa.prev_iresult = reinterpret_cast<const int*>(pblk.dev + 16);
+                pa.prev_rowperm = reinterpret_cast<const int*>(pblk.dev + pblk.off_rp);
+                pa.prev_colperm = reinterpret_cast<const int*>(pblk.dev + pblk.off_cp);
+                pa.prev_token = tokens[pb];
+            }
+            chain_prep_launch(c, pa, st);
+            // nobody speculated on this bond (first bond, or the previous launch was a single workgroup): evaluate it now
+            if (!fused && !spec_here) chain_pi_launch(c, fn_dev_, (int)b, (int)dep_ub[b], (int)ind_ub[b], chain_.pi.get(), st);
+            // the candidate matrix of the NEXT bond rides on this bond's launch when that is a single-XCD launch
+            XcdSpecArgs sp;
+            std::memset(&sp, 0, sizeof(sp));
+            spec_pending = false;
+            if (k + 1 < nb && pl.kind == 2) {
+                const size_t nx = order[k + 1];
+                if (!(plans[nx].kind == 1 && plans[nx].fused)) {
+                    const size_t site = forward ? nx : nx + 1;
+                    const ChainTab& H = forward ? c.HI : c.HJ;
+                    const size_t hsite = forward ? nx + 1 : nx;
+                    sp.out = chain_.spec[(k + 1) & 1].get();
+                    sp.dep_acc = c.dep_acc;
+                    sp.w_site = c.w + offset_[site];
+                    sp.ext_acc = H.acc + hsite * cap * K;
+                    sp.ext_cnt = use_extras ? H.cnt + hsite : nullptr;
+                    sp.ind_acc = c.ind_acc + nx * ind_cap * K;
+                    sp.ind_cnt = c.ind_cnt + nx;
+                    sp.tile_counter = tile_counters + nx;
+                    sp.total = (int)total_;
+                    sp.d = (int)local_dims[site];
+                    sp.fn = fn_dev_;
+                    spec_pending = true;
+                }
+            }
+            FusedPi fp;
+            fp.fn = fn_dev_;
+            fp.d_rowacc = c.dep_acc;
+            fp.d_colacc = c.ind_acc + b * ind_cap * K;
+            fp.host_resident = false;
+            const double* A = fused ? nullptr : (spec_here ? chain_.spec[k & 1].get() : chain_.pi.get());
+            tokens[b] = eng.chain_rrlu(pl, forward, A, spec_here ? c.rowmap : nullptr, fused ? &fp : nullptr, c.dims + b * 4, chi, options.tolerance,
+                                       0.0, blk, spec_pending ? &sp : nullptr);
+        }
+        { // the pivots of the last bond
+            const size_t pb = order[nb - 1];
+            const ChainBlock pblk = block_of(pb);
+            ChainPrepArgs pa;
+            std::memset(&pa, 0, sizeof(pa));
+            pa.do_build = 0;
+            pa.prev_b = (int)pb;
+            pa.prev_iresult = reinterpret_cast<const int*>(pblk.dev + 16);
+            pa.prev_rowperm = reinterpret_cast<const int*>(pblk.dev + pblk.off_rp);
+            pa.prev_colperm = reinterpret_cast<const int*>(pblk.dev + pblk.off_cp);
+            pa.prev_token = tokens[pb];
+            chain_prep_launch(c, pa, st);
+        }
+        T4A_HIP(hipGetLastError());
+    } catch (...) {
+        (void)hipStreamSynchronize(st);
+        eng.chain_end();
+        chain_.tables_valid = false;
+        throw;
+    }
+    chain_.inflight = true;
+    chain_.forward = forward;
+    chain_.in_optimize = in_optimize;
+    chain_.ext_idx = ext_idx;
+    chain_.chi = chi;
+    chain_.order = std::move(order);
+    chain_.plans = std::move(plans);
+    chain_.tokens = std::move(tokens);
+    chain_.proto = proto;
+    chain_.timed = timed;
+    return true;
+}
+
+void Tci2::chain_finish(const TCI2Options& options)
+{
+    if (!chain_.inflight) return;
+    chain_.inflight = false;
+    hipStream_t st = eng.stream();
+    const size_t nb = n_ - 1;
+    const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
+    const bool forward = chain_.forward;
+    const ChainBlock& proto = chain_.proto;
+    const hipError_t sync_err = hipStreamSynchronize(st);
+    eng.chain_end();
+    if (sync_err != hipSuccess) {
+        chain_.tables_valid = false;
+        T4A_HIP(sync_err);
+    }
+    const int mnew = 1 - chain_.mcur;
+    const ChainTab ni = chain_mirror(mnew, 0), nj = chain_mirror(mnew, 1);
+    long failed_k = -1;
+    bool failed_timeout = false;
+    for (size_t k = 0; k < nb; ++k) {
+        const size_t b = chain_.order[k];
+        const int* hd = chain_.hdims.get() + b * 4;
+        const char* hb = chain_.hblocks.get() + b * proto.bytes;
+        const int* hi = reinterpret_cast<const int*>(hb + 16);
+        if (hd[2] != 0 || hd[0] <= 0 || hd[1] <= 0) { // poisoned by its preparation: the previous bond's pivots were not gathered either
+            failed_k = k > 0 ? (long)k - 1 : 0;
+            break;
+        }
+        if (hi[1] != 0 || hi[3] != (int)chain_.tokens[b]) {
+            failed_k = (long)k;
+            failed_timeout = true;
+            break;
+        }
+        if (hi[2] != 0) { // NaN in L or U (matrixlu.rs:614-668): the per-bond path reports it before it touches the sets of this bond
+            failed_k = (long)k;
+            break;
+        }
+    }
+    const size_t done = failed_k < 0 ? nb : (size_t)failed_k;
+    for (size_t k = 0; k < done; ++k) {
+        const size_t b = chain_.order[k];
+        const int* hd = chain_.hdims.get() + b * 4;
+        const char* hb = chain_.hblocks.get() + b * proto.bytes;
+        const int* hi = reinterpret_cast<const int*>(hb + 16);
+        const size_t M = (size_t)hd[0], N = (size_t)hd[1];
+        const int rank = hi[0];
+        double last_error, abs_max;
+        std::memcpy(&last_error, hb, sizeof(double));
+        std::memcpy(&abs_max, hb + 8, sizeof(double));
+        const size_t cnt = (size_t)(rank > 0 ? rank : 1);
+        if ((size_t)ni.cnt[b + 1] != cnt || (size_t)nj.cnt[b] != cnt)
+            throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: gathered pivot count of bond " + std::to_string(b) + " disagrees with its rank");
+        i_set[b + 1].count = cnt; // (digit tables follow on demand: sync_digits)
+        j_set[b].count = cnt;
+        i_set[b + 1].d.clear();
+        j_set[b].d.clear();
+        {   // work model of the factorisation, as Engine::luci counts it
+            double bytes = 8.0 * (double)M * (double)N, flops = 0.0;
+            for (int q = 0; q < rank; ++q) {
+                const double mr = (double)((long)M - q - 1), nr = (double)((long)N - q - 1);
+                bytes += 16.0 * mr * nr;
+                flops += 2.0 * mr * nr + mr;
+            }
+            eng.prof.v[8] += rank;
+            eng.prof.v[9] += bytes;
+            eng.prof.v[10] += flops;
+            eng.prof.v[11] += (double)M * (double)N;
+            if (chain_.timed) { // device-side time stamps of the launch (wall_clock64: 100 MHz)
+                unsigned long long ts[2];
+                std::memcpy(ts, hb + proto.off_ts, sizeof(ts));
+                const float ms = ts[1] > ts[0] ? (float)((double)(ts[1] - ts[0]) * 1e-5) : 0.f;
+                eng.prof.v[0] += ms;
+                eng.prof.v[1] += 1.0;
+                auto& vs = eng.variant_stats_[chain_.plans[b].code];
+                vs[0] += ms;
+                vs[1] += 1.0;
+                vs[2] += bytes;
+                vs[3] += rank;
+            }
+        }
+        if (abs_max > max_sample_value) max_sample_value = abs_max; // update_max_sample_value over Π (tensorci2.rs:2009-2014)
+        last_sweep_shapes[b] = {M, N, (size_t)rank};
+        bond_errors[b] = last_error; // = pivot_errors.back() (tensorci2.rs:2002-2004)
+    }
+    if (done > 0) { // the new mirror becomes the host's copy of the sets; what this chain did not write comes from the old one
+        const ChainTab oi = chain_mirror(chain_.mcur, 0), oj = chain_mirror(chain_.mcur, 1);
+        std::vector<char> wi(n_, 0), wj(n_, 0);
+        for (size_t k = 0; k < done; ++k) {
+            wi[chain_.order[k] + 1] = 1;
+            wj[chain_.order[k]] = 1;
+        }
+        for (size_t p = 0; p < n_; ++p) {
+            if (!wi[p]) {
+                std::memcpy(ni.code + p * cap, oi.code + p * cap, i_set[p].count * sizeof(uint64_t));
+                std::memcpy(ni.acc + p * cap * K, oi.acc + p * cap * K, i_set[p].count * K * sizeof(uint64_t));
+                ni.cnt[p] = oi.cnt[p];
+            }
+            if (!wj[p]) {
+                std::memcpy(nj.code + p * cap, oj.code + p * cap, j_set[p].count * sizeof(uint64_t));
+                std::memcpy(nj.acc + p * cap * K, oj.acc + p * cap * K, j_set[p].count * K * sizeof(uint64_t));
+                nj.cnt[p] = oj.cnt[p];
+            }
+        }
+        chain_.mcur = mnew;
+        chain_.digits_stale = true;
+    }
+    if (failed_k < 0) {
+        ++chain_stats[0];
+        chain_stats[1] += nb;
+        if (chain_verify) { // tests: the mirror decodes to index sets whose codes / accumulators are the mirror's, and equals the device tables
+            sync_digits();
+            std::vector<uint64_t> a;
+            for (size_t p = 0; p < n_; ++p)
+                for (int side = 0; side < 2; ++side) {
+                    const IndexSet& s = side == 0 ? i_set[p] : j_set[p];
+                    const ChainTab& m = side == 0 ? ni : nj;
+                    const size_t first = side == 0 ? 0 : p + 1;
+                    accumulate(s, first, a);
+                    for (size_t k = 0; k < s.count; ++k) {
+                        bool same = m.code[p * cap + k] == code_of(s.at(k), first, s.width, side == 0);
+                        for (size_t q = 0; same && q < K; ++q) same = m.acc[(p * cap + k) * K + q] == a[k * K + q];
+                        if (!same)
+                            throw Error(T4A_GPU_INTERNAL_ERROR, std::string("bond chain: mirror entry of ") + (side == 0 ? "I_" : "J_") +
+                                                                    std::to_string(p) + " does not decode / accumulate consistently");
+                    }
+                }
+            const size_t fam = n_ * cap * (1 + K);
+            std::vector<uint64_t> dev(2 * fam);
+            std::vector<int> dcnt(2 * n_);
+            T4A_HIP(hipMemcpy(dev.data(), chain_tab(0).code, dev.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            T4A_HIP(hipMemcpy(dcnt.data(), chain_tab(0).cnt, dcnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int side = 0; side < 2; ++side)
+                for (size_t p = 0; p < n_; ++p) {
+                    const ChainTab& m = side == 0 ? ni : nj;
+                    bool same = dcnt[(size_t)side * n_ + p] == m.cnt[p];
+                    for (size_t k = 0; same && k < (size_t)m.cnt[p]; ++k) {
+                        same = dev[(size_t)side * fam + p * cap + k] == m.code[p * cap + k];
+                        for (size_t q = 0; same && q < K; ++q)
+                            same = dev[(size_t)side * fam + n_ * cap + (p * cap + k) * K + q] == m.acc[(p * cap + k) * K + q];
+                    }
+                    if (!same)
+                        throw Error(T4A_GPU_INTERNAL_ERROR, std::string("bond chain: device table ") + (side == 0 ? "I_" : "J_") + std::to_string(p) +
+                                                                " differs from its host mirror");
+                }
+        }
+        return;
+    }
+    // a bond did not complete (bounded spin gave up: the placement assumption of the single-XCD kernel failed or another
+    // process holds its compute units; a capacity bound was hit; NaN in the factors): the rest of the half-sweep runs bond by
+    // bond (a NaN is met again there and reported as NaNEncountered like the reference does)
+    ++chain_stats[2];
+    sync_digits();
+    chain_.tables_valid = false;
+    if (failed_timeout && chain_.plans[chain_.order[(size_t)failed_k]].kind == 2) xcd_disable();
+    prep_.valid = false;
+    prefetch_.wanted = false;
+    prefetch_.fill_site = -1;
+    prefetch_.flush_fill = false;
+    invalidate_fill_cache();
+    std::vector<IndexSet> no_i(n_), no_j(n_);
+    for (size_t p = 0; p < n_; ++p) {
+        no_i[p].width = p;
+        no_j[p].width = n_ - p - 1;
+    }
+    const std::vector<IndexSet>* xi = &no_i;
+    const std::vector<IndexSet>* xj = &no_j;
+    if (chain_.ext_idx >= 0) {
+        HistEntry& e = history[(size_t)chain_.ext_idx];
+        hist_digits(e);
+        xi = &e.is;
+        xj = &e.js;
+    }
+    for (size_t k = (size_t)failed_k; k < nb; ++k) {
+        const size_t b = chain_.order[k];
+        update_pivots(b, forward, options, (*xi)[b + 1], (*xj)[b]);
+    }
+}
+
+} // namespace t4a

@@ -643,6 +643,17 @@ class TensorCI2:
         return [dict(code=int(r[0]), ms=float(r[1]), launches=float(r[2]), bytes=float(r[3]), steps=float(r[4])) for r in out[: n.value]]
 
 
+    def set_chain(self, enable=True, verify=False):
+        """Device-side bond chain on / off for this handle; verify: read the device tables back after every chain."""
+        _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0), c_int32(1 if verify else 0)))
+
+    def chain_stats(self):
+        """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible) since the handle was created."""
+        out = np.zeros(4, dtype=np.uint64)
+        _check(_lib.t4a_gpu_tci2_chain_stats(self._h, _p(out)))
+        return dict(half_sweeps=int(out[0]), bonds=int(out[1]), fell_back=int(out[2]), not_eligible=int(out[3]))
+
+
 def crossinterpolate2(f, local_dims, initial_pivots, options):
     """crossinterpolate2 (tensorci2.rs:1513). Returns the optimised TensorCI2; histories via .history()."""
     options.to_c()  # validate before anything else

@@ -1,0 +1,162 @@
+"""The device-side bond chain (tci2_chain.hip / kernels_chain.hip): a whole 2-site half-sweep enqueued at once, index sets as
+device tables, dimensions read on the device.  It must change nothing: every test runs the same problem through the chain,
+through the per-bond host path and through the CPU oracle and compares index sets, errors and cores.
+
+Reference: update_pivots / sweep2site / optimize_with_finder, crates/tensor4all-tensorci/src/tensorci2.rs:746-798, 1626-1802,
+1821-2007; kronecker_i / kronecker_j :1224-1246; the history extras :1675-1689, :1833-1846."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+PARITY = dict(nsearch=0, max_nglobal_pivot=0)
+
+
+@pytest.fixture(scope="module")
+def t4a():
+    import t4a_amd
+    if t4a_amd.device_count() < 1:
+        pytest.fail("no MI355X visible: the product path has no CPU fallback")
+    return t4a_amd
+
+
+def trio(t4a, spec, dims):
+    c = t4a.TensorCI2(dims)       # chain, with the read-back check of the device tables after every half-sweep
+    c.set_function(spec)
+    c.set_chain(True, verify=True)
+    h = t4a.TensorCI2(dims)       # per-bond host path
+    h.set_function(spec)
+    h.set_chain(False)
+    o = ob.OracleTCI2(dims)
+    o.set_function(spec)
+    return c, h, o
+
+
+def assert_same_state(c, h, o, n, cores=True):
+    for p in range(n):
+        assert np.array_equal(c.i_set(p), o.i_set(p)), f"I set of the chain differs from the oracle at site {p}"
+        assert np.array_equal(c.j_set(p), o.j_set(p)), f"J set of the chain differs from the oracle at site {p}"
+        assert np.array_equal(c.i_set(p), h.i_set(p)) and np.array_equal(c.j_set(p), h.j_set(p))
+    assert np.array_equal(c.bond_errors(), h.bond_errors()) and np.array_equal(c.bond_errors(), o.bond_errors())
+    assert c.max_sample_value() == h.max_sample_value() == o.max_sample_value()
+    if cores:
+        for p in range(n):
+            a, b = c.site_tensor(p), h.site_tensor(p)
+            assert a.shape == b.shape and np.array_equal(a, b), f"core {p}: chain and per-bond path differ"
+
+
+@pytest.mark.parametrize("n,chi,iters", [(10, 8, 5), (14, 24, 7), (16, 48, 8)])
+def test_chain_growth_with_history_extras(t4a, n, chi, iters):
+    """Ranks grow over the iterations; from the second one on the previous iteration's sets are merged as extras."""
+    spec = t4a.quantics_osc2d(n, k1=3, k2=5, k3=7, eps=0.1, k4=11, delta=0.3)
+    opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=iters, ncheck_history=10 ** 6, seed=1, **PARITY)
+    c, h, o = trio(t4a, spec, [2] * n)
+    for t in (c, h, o):
+        t.add_global_pivots([[0] * n])
+        t.set_max_sample_value(1.0) if hasattr(t, "set_max_sample_value") else None
+        t.optimize(opts, final_sweep1site=False)
+    assert_same_state(c, h, o, n)
+    assert c.history()[0] == o.history()[0] and np.array_equal(c.history()[1], o.history()[1])
+    assert np.array_equal(c.last_sweep_shapes(), o.last_sweep_shapes())
+    st = c.chain_stats()
+    assert st["half_sweeps"] == iters and st["bonds"] == iters * (n - 1) and st["fell_back"] == 0 and st["not_eligible"] == 0
+    assert h.chain_stats()["half_sweeps"] == 0
+
+
+def test_chain_mixed_local_dimensions(t4a):
+    """Mixed-radix codes: local dimensions 3, 2, 4, 5, 2, 3 (Lorentzian on an uneven grid)."""
+    from t4a_amd.functions import lorentz
+    dims = [3, 2, 4, 5, 2, 3, 4]
+    spec = lorentz(dims)
+    opts = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=12, max_iter=6, ncheck_history=10 ** 6, **PARITY)
+    c, h, o = trio(t4a, spec, dims)
+    piv = [[1, 1, 2, 3, 0, 2, 1]]
+    for t in (c, h, o):
+        t.crossinterpolate2(piv, opts)
+    assert_same_state(c, h, o, len(dims))
+    assert c.chain_stats()["half_sweeps"] >= 2 and c.chain_stats()["fell_back"] == 0
+    pts = np.random.default_rng(3).integers(0, 2, size=(100, len(dims)))
+    assert np.abs(c.evaluate(pts) - o.evaluate(pts)).max() <= 1e-10
+
+
+def test_chain_sweep2site_and_strictly_nested(t4a):
+    n = 12
+    spec = t4a.quantics_trig_exp(n, a=25.0, b=0.5, cc=0.5, cs=1.0)
+    c, h, o = trio(t4a, spec, [2] * n)
+    piv = [[0, 1] * (n // 2)]
+    opts = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=6, **PARITY)
+    for t in (c, h, o):
+        t.add_global_pivots(piv)
+        t.sweep2site(True, opts)
+        t.sweep2site(False, opts)
+        t.sweep2site(True, opts)
+    assert_same_state(c, h, o, n)
+    assert c.chain_stats()["half_sweeps"] == 3
+    nested = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=8, max_iter=4, strictly_nested=True, ncheck_history=10 ** 6, **PARITY)
+    for t in (c, h, o):
+        t.optimize(nested, final_sweep1site=True)
+    assert_same_state(c, h, o, n)
+
+
+def test_chain_survives_host_side_changes_of_the_sets(t4a):
+    """Global pivots, sweep1site and set_index_set change the host's sets behind the chain's back: the tables are re-uploaded."""
+    n = 12
+    spec = t4a.quantics_osc2d(n, k1=3, k2=5, k3=7, eps=0.1, k4=11, delta=0.3)
+    opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=16, max_iter=3, ncheck_history=10 ** 6, **PARITY)
+    c, h, o = trio(t4a, spec, [2] * n)
+    for t in (c, h, o):
+        t.add_global_pivots([[0] * n])
+        t.optimize(opts, final_sweep1site=False)
+        t.add_global_pivots([[1, 0] * (n // 2), [1] * n])
+        t.optimize(opts, final_sweep1site=True)   # ends with a 1-site sweep (host path)
+        t.optimize(opts, final_sweep1site=False)
+    assert_same_state(c, h, o, n)
+    assert c.chain_stats()["fell_back"] == 0 and c.chain_stats()["half_sweeps"] == 9
+
+
+def test_chain_is_skipped_for_callbacks_and_rook(t4a):
+    n = 8
+    f = lambda idx: 1.0 / (1.0 + sum((i + 1) * v for i, v in enumerate(idx)))
+    g = t4a.TensorCI2([3] * n)
+    g.set_function(f)
+    o = ob.OracleTCI2([3] * n)
+    o.set_function(f)
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=10, max_iter=4, **PARITY)
+    g.crossinterpolate2([[0] * n], opts)
+    o.crossinterpolate2([[0] * n], opts)
+    for p in range(n):
+        assert np.array_equal(g.i_set(p), o.i_set(p)) and np.array_equal(g.j_set(p), o.j_set(p))
+    st = g.chain_stats()
+    assert st["half_sweeps"] == 0 and st["not_eligible"] > 0
+
+
+def test_chain_at_cfg3_size_equals_per_bond_path(t4a):
+    """BASELINE.json configs[2] shapes (d = 30, chi = 256): growth to saturation and one more full sweep, chain vs per-bond path,
+    every index set and bond error identical; the mid-chain bonds run on the single-XCD kernel with device-side dimensions."""
+    import bench
+    n = bench.N_SITES
+    spec = bench.patch_spec(0, 1)
+    opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=bench.CHI, max_iter=12, ncheck_history=10 ** 6, seed=42, **PARITY)
+    res = []
+    for chain in (True, False):
+        t = t4a.TensorCI2([2] * n)
+        t.set_function(spec)
+        t.set_chain(chain, verify=chain)
+        t.add_global_pivots([[0] * n])
+        t.set_max_sample_value(1.0)
+        t.optimize(opts, final_sweep1site=False)
+        res.append(t)
+    c, h = res
+    assert max(c.link_dims()) == bench.CHI
+    for p in range(n):
+        assert np.array_equal(c.i_set(p), h.i_set(p)) and np.array_equal(c.j_set(p), h.j_set(p)), p
+    assert np.array_equal(c.bond_errors(), h.bond_errors())
+    assert np.array_equal(c.last_sweep_shapes(), h.last_sweep_shapes())
+    st = c.chain_stats()
+    assert st["half_sweeps"] == 12 and st["fell_back"] == 0 and st["not_eligible"] == 0
+    pts = np.random.default_rng(11).integers(0, 2, size=(300, n))
+    c.fill_site_tensors()   # (optimize invalidates the site tensors at the end of every iteration, tensorci2.rs:707-708)
+    h.fill_site_tensors()
+    assert np.array_equal(c.evaluate(pts), h.evaluate(pts))
