@@ -48,6 +48,14 @@ void pin_free(void* p, size_t got);
 hipStream_t stream_get(int kind); // 0 default priority, 1 highest, 2 lowest; non-blocking streams
 void stream_put(hipStream_t s, int kind);
 int compute_units();
+// Declared as the FIRST member of a handle (destroyed last): once armed — by the handle's destructor, after it has synchronised
+// every stream its buffers were ever used on — the buffers released on this thread until the scope ends go back to the cache
+// without the device-wide synchronisation (which would wait for every other handle's work in flight).
+struct IdleScope {
+    bool armed = false;
+    void arm();
+    ~IdleScope();
+};
 void quiesce();       // device-wide synchronisation, never concurrent with a graph capture on one of our streams
 void capture_begin(); // bracket hipStreamBeginCapture ... hipStreamEndCapture with these
 void capture_end();

@@ -659,7 +659,7 @@ bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
     return true;
 }
 
-void Engine::chain_begin(const std::vector<ChainRrluPlan>& plans)
+void Engine::chain_begin(const std::vector<ChainRrluPlan>& plans, size_t reserve_mailbox_words)
 {
     size_t need = 0;
     int max_w = 0;
@@ -671,7 +671,7 @@ void Engine::chain_begin(const std::vector<ChainRrluPlan>& plans)
         }
     if (need > 0) {
         if (need > d_xkeys_.cap || !d_xticket_.get()) {
-            d_xkeys_.reserve(need);
+            d_xkeys_.reserve(std::max(need, reserve_mailbox_words));
             d_xticket_.reserve(4);
             T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), stream_));
             T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), stream_));

@@ -123,7 +123,7 @@ public:
     // ---- bond chain: launches without a host round trip (dimensions in device memory) ----
     bool chain_plan(int kM, int kN, ChainRrluPlan* out) const;
     // before the first launch of a chain: mailbox capacity for every plan, the XCD (or the whole chip) reserved until chain_end()
-    void chain_begin(const std::vector<ChainRrluPlan>& plans);
+    void chain_begin(const std::vector<ChainRrluPlan>& plans, size_t reserve_mailbox_words = 0);
     // rrLU of one bond: `left` as in RrLUOptions::left_orthogonal; d_a: the kernel's matrix (already transposed for !left; read
     // through d_rowmap with leading dimension d_dims[3] when d_rowmap != nullptr) unless the plan is fused (then `fused` holds
     // the accumulators of the KERNEL's rows and columns); d_dims: {M, N, poison, lda} of the MATRIX on the device.  Returns the

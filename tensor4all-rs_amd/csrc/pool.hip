@@ -35,6 +35,7 @@ constexpr size_t kCacheLimit = (size_t)16 << 30;
 constexpr size_t kPinCacheLimit = (size_t)1 << 30;
 // this thread is recording a graph (it holds g_capture_mu): a release must neither wait for the device (it would invalidate the
 // capture) nor take g_capture_mu again (self-deadlock).  Blocks released meanwhile are parked and handed in at capture_end().
+thread_local int t_idle_scope = 0; // > 0: the releasing handle has synchronised its own streams (IdleScope)
 thread_local bool t_in_capture = false;
 thread_local std::vector<std::pair<void*, size_t>> t_parked_dev, t_parked_pin;
 
@@ -110,6 +111,18 @@ bool quiesce_ok()
 
 void quiesce() { (void)quiesce_ok(); }
 
+void IdleScope::arm()
+{
+    if (!armed) {
+        armed = true;
+        ++t_idle_scope;
+    }
+}
+IdleScope::~IdleScope()
+{
+    if (armed) --t_idle_scope;
+}
+
 void capture_begin()
 {
     g_capture_mu.lock();
@@ -170,8 +183,8 @@ void dev_free(void* p, size_t got)
         (void)hipFree(p);
         return;
     }
-    // the block may still be in use by work in flight (hipFree would have waited for it)
-    const bool idle = quiesce_ok();
+    // the block may still be in use by work in flight (hipFree would have waited for it) — unless its owner vouches for it
+    const bool idle = t_idle_scope > 0 ? true : quiesce_ok();
     const int dev = device_of(p);
     if (idle) {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -227,7 +240,7 @@ void pin_free(void* p, size_t got)
         (void)hipHostFree(p);
         return;
     }
-    const bool idle = quiesce_ok(); // a kernel may still be writing its result mirror / reading accumulators in place
+    const bool idle = t_idle_scope > 0 ? true : quiesce_ok(); // a kernel may still be writing its result mirror / reading accumulators in place
     if (idle) {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_cached_pin_bytes + got <= kPinCacheLimit) {

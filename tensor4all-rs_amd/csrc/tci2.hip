@@ -169,6 +169,9 @@ Tci2::~Tci2()
     if (import_stream_) pool::stream_put(import_stream_, 2); // (synchronises it)
     if (fill_graph_exec_) (void)hipGraphExecDestroy(fill_graph_exec_);
     if (fill_stream_) pool::stream_put(fill_stream_, 2); // (synchronises it)
+    // every buffer of this handle (and of its engine) was only ever used on the three streams that are idle now: the blocks
+    // go back to the process-wide cache without a device-wide synchronisation, which would wait for the other handles' chains
+    if (hipStreamSynchronize(eng.stream()) == hipSuccess) idle_scope_.arm();
 }
 
 void Tci2::set_builtin(int fid, int n_acc, const double* params, const uint64_t* weights)
@@ -1603,6 +1606,21 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
     std::vector<size_t> nglobal_hist;
     termination = T4A_GPU_TCI2_MAX_ITERATIONS;
     uint64_t rng_state = options.has_seed ? options.seed : 0x1234567ull;
+    // bounded rank, built-in functor: site tensors and fill workspaces get their final size now (a buffer that grows goes
+    // through the process-wide cache, which waits for the whole device: once per iteration and buffer while ranks grow)
+    if (fn_kind_ == FnKind::Builtin && options.max_bond_dim != 0 && options.max_bond_dim <= 1024) {
+        const size_t chi = options.max_bond_dim;
+        size_t totA = 0, totB = 0;
+        for (size_t b = 0; b < n_; ++b) {
+            if (shard_world > 1 && (b % shard_world) != shard_rank) continue;
+            cores[b].buf.reserve(std::max<size_t>(chi * local_dims[b] * chi, 1));
+            totA += chi * chi;
+            totB += chi * chi * local_dims[b];
+        }
+        d_fillA_.reserve(std::max<size_t>(totA, 1));
+        d_fillB_.reserve(std::max<size_t>(totB, 1));
+        d_fillpiv_.reserve(std::max<size_t>(n_ * chi, 1));
+    }
     bool pending_fill = false; // fill_site_tensors of the last iteration: accumulators prepared, stream operations not yet issued
 
     for (size_t iter = 0; iter < options.max_iter; ++iter) {

@@ -61,6 +61,7 @@ struct FromTensorTrainOptions { // tensorci/src/conversion.rs:20-36
 };
 
 class Tci2 {
+    pool::IdleScope idle_scope_; // (first member: destroyed last, see ~Tci2)
 public:
     explicit Tci2(const std::vector<size_t>& local_dims);
     ~Tci2();

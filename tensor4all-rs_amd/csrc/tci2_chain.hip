@@ -31,6 +31,7 @@
 #include "tci2.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 
@@ -38,6 +39,11 @@ namespace t4a {
 
 namespace {
 size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+// chains in flight in this process (handles on several host threads: one XCD each).  The speculative candidate matrix rides on
+// the pass-through workgroups of an rrLU launch, i.e. on the OTHER XCDs: fine while those are idle, a nuisance when other
+// handles factorise there (their launches' pass-through workgroups then queue for the few free compute units of every XCD).
+// A chain that is not alone evaluates its candidate matrices directly (8 us more per bond, nobody else disturbed).
+std::atomic<int> g_chains_inflight{0};
 } // namespace
 
 bool Tci2::chain_usable(const TCI2Options& options) const
@@ -305,6 +311,26 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     }
 
     // ---- 2. buffers ----
+    // With a bounded max_bond_dim every buffer is sized for its final shape the first time: a buffer that grows is released
+    // through the process-wide cache, which waits for the whole device (pool.hip) — while ranks grow from scratch that would be
+    // a device-wide stall per iteration and handle, and it is what kept concurrent handles from overlapping.
+    size_t cap_side = 0;
+    {
+        size_t dmax = 1;
+        for (size_t d : local_dims) dmax = std::max(dmax, d);
+        if (chi <= (size_t)CHAIN_MAX_SET && chi * dmax + chi <= 2048) {
+            need_cap = std::max(need_cap, chi);
+            const size_t side = chi * dmax + chi;
+            dep_cap = std::max(dep_cap, side);
+            ind_cap = std::max(ind_cap, side);
+            Mcap = std::max(Mcap, side);
+            Ncap = std::max(Ncap, side);
+            steps_cap = std::max(steps_cap, chi);
+            spec_cap = std::max(spec_cap, (side * dmax + chi) * side);
+            pi_cap = std::max(pi_cap, side * side);
+            cap_side = side;
+        }
+    }
     chain_layout(round_up_sz(need_cap, 64));
     const size_t cap = chain_.cap;
     if (!chain_.weights_valid) {
@@ -412,11 +438,21 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     c.zero_b = reinterpret_cast<uint64_t*>(chain_.dims.get());
     c.zero_b_words = (nb * 5 * sizeof(int) + 7) / 8;
 
-    eng.chain_begin(plans);
+    {
+        size_t reserve_words = 0; // the largest shape this handle can reach: the mailbox is sized once
+        ChainRrluPlan cp;
+        if (cap_side && eng.chain_plan((int)cap_side, (int)cap_side, &cp) && cp.kind == 2)
+            reserve_words = (rrlu_xcd_keys_bytes(cp.xcd) + rrlu_xcd_cols_bytes(cp.xcd, (int)cap_side)) / sizeof(unsigned long long);
+        eng.chain_begin(plans, reserve_words);
+    }
     std::vector<unsigned> tokens(nb, 0u);
+    bool counted = false;
     try {
         chain_indep_launch(c, (int)nb, st);
         unsigned* tile_counters = reinterpret_cast<unsigned*>(chain_.dims.get() + nb * 4);
+        static const bool no_spec = std::getenv("T4A_CHAIN_NO_SPEC") != nullptr;
+        const bool solo = g_chains_inflight.fetch_add(1) == 0 && !no_spec;
+        counted = true;
         bool spec_pending = false; // the previous bond's launch evaluates this bond's candidate matrix
         for (size_t k = 0; k < nb; ++k) {
             const size_t b = order[k];
@@ -446,7 +482,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
             XcdSpecArgs sp;
             std::memset(&sp, 0, sizeof(sp));
             spec_pending = false;
-            if (k + 1 < nb && pl.kind == 2) {
+            if (solo && k + 1 < nb && pl.kind == 2) {
                 const size_t nx = order[k + 1];
                 if (!(plans[nx].kind == 1 && plans[nx].fused)) {
                     const size_t site = forward ? nx : nx + 1;
@@ -492,6 +528,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     } catch (...) {
         (void)hipStreamSynchronize(st);
         eng.chain_end();
+        if (counted) g_chains_inflight.fetch_sub(1);
         chain_.tables_valid = false;
         throw;
     }
@@ -519,6 +556,7 @@ void Tci2::chain_finish(const TCI2Options& options)
     const ChainBlock& proto = chain_.proto;
     const hipError_t sync_err = hipStreamSynchronize(st);
     eng.chain_end();
+    g_chains_inflight.fetch_sub(1);
     if (sync_err != hipSuccess) {
         chain_.tables_valid = false;
         T4A_HIP(sync_err);
