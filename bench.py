@@ -203,6 +203,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = tci.profile()
+    variants_timed = tci.profile_variants()
+    # calibration outside the timed region: the same sweeps with HIP events around every rrLU launch (the timed region uses the
+    # kernels' own start / end stamps: event records between the launches of a chain would be two more packets per bond)
+    ev_ms = {}
+    if world == 1:
+        tci.profile_reset()
+        tci.set_chain(True, event_timing=True)
+        tci.optimize(opts(4), final_sweep1site=False)
+        ev_ms = {v["code"]: v["ms"] / max(v["launches"], 1) for v in tci.profile_variants()}
+        tci.set_chain(True)
     tci.profile_enable(False)
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -220,7 +230,7 @@ def main():
         rrlu_ms_avg = prof["dom_ms"] / max(prof["dom_launches"], 1)
         bytes_per_launch = prof["dom_bytes"] / max(prof["dom_launches"], 1)
         kname = rrlu_kernel_name(prof["dom_code"])
-        variants = tci.profile_variants()
+        variants = variants_timed
         dom = max(variants, key=lambda v: v["ms"]) if variants else None
         dom_steps = dom["steps"] / max(dom["launches"], 1) if dom else float(shapes[N_SITES // 2][2])
         achieved = bytes_per_launch / (rrlu_ms_avg * 1e-3) / 1e9 if rrlu_ms_avg > 0 else 0.0
@@ -252,10 +262,16 @@ def main():
                 "evals_per_sweep": prof["evals"] / steps,
                 "flops_per_sweep": prof["flops"] / steps,
             },
+            # device time of the two kernel families of a sweep (they overlap: fill_site_tensors of one half-sweep runs on its own
+            # stream beside the bond chain of the next, so the two do not add up to ms_per_step).  rrlu_kernel: device-side time
+            # stamps of every rrLU launch (wall_clock64 at the start and the end of rank 0); fill_site_tensors: HIP events on the
+            # fill stream.  The candidate matrices are evaluated inside the rrLU launches (pass-through workgroups) and by
+            # chain_pi_kernel for the first bonds; the LUCI factors are not built (every site tensor comes from the fill).
             "breakdown_ms_per_sweep": {
-                "rrlu_kernel": prof["rrlu_ms"] / steps, "pi_eval_kernel": prof["pi_ms"] / steps,
-                "fill_site_tensors": prof["fill_ms"] / steps, "luci_factors": prof["factor_ms"] / steps,
+                "rrlu_kernel": prof["rrlu_ms"] / steps, "fill_site_tensors": prof["fill_ms"] / steps,
+                "outside_rrlu_kernels": dt_max / steps * 1e3 - prof["rrlu_ms"] / steps,
             },
+            "chain": tci.chain_stats(),
             "roofline": {
                 "kernel": kname + " (full-pivot rank-revealing LU, one launch per bond)",
                 "launches": prof["dom_launches"],
@@ -266,10 +282,14 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(kname),
-                "traffic_source": "profiles/r02_pmc_dominant_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two "
+                "traffic_source": "profiles/r03_pmc_dominant_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two "
                                   "separate passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch "
                                   "(gfx950 FETCH_SIZE correction); null when the kernel name does not match",
                 "avg_launch_ms": rrlu_ms_avg,
+                "avg_launch_ms_source": "device-side time stamps of rank 0 (wall_clock64) in the timed region",
+                "avg_launch_ms_hip_events": ev_ms.get(int(prof["dom_code"])),
+                "avg_launch_ms_hip_events_source": "hipEventRecord around every launch of this instantiation on the handle's stream, two "
+                                                   "extra sweeps after the timed region",
                 # the kernel is a chain of dependent pivot steps; each step needs one key all-gather and one pivot-column
                 # hand-off between the workgroups of one XCD: the honest bound is latency, not bandwidth.  The floor is the
                 # measured cost of exactly that exchange with no arithmetic around it (tools/xcd_bench.hip on MI355X:
@@ -279,6 +299,7 @@ def main():
                     "pivot_steps_per_launch": dom_steps,
                     "us_per_pivot_step": 1e3 * rrlu_ms_avg / max(dom_steps, 1.0),
                     "exchange_floor_us": XCD_EXCHANGE_FLOOR_US,
+                    "exchange_floor_source": "constant: tools/xcd_bench.hip measured on MI355X (profiles/r02_xcd_bench.log), not re-measured by this run",
                 },
                 "latency_frac": XCD_EXCHANGE_FLOOR_US / max(1e3 * rrlu_ms_avg / max(dom_steps, 1.0), 1e-30),
                 # every rrLU instantiation of the timed region, and their time-weighted aggregate
@@ -292,6 +313,9 @@ def main():
                                   "us_per_pivot_step": 1e3 * v["ms"] / max(v["steps"], 1.0)}
                                  for v in sorted(variants, key=lambda v: -v["ms"])],
                 },
+                # the kernels of the sweep that run on the f64 matrix cores (BASELINE.json metric: "... + MFMA %"): flops per
+                # launch from the PMC counters, time from the kernel trace of the same command (committed summaries, like `traffic`)
+                "mfma": mfma_view(),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "streaming model 8MN + sum_k 16(M-k-1)(N-k-1) bytes (BASELINE.md §2); the slab is register "
                         "resident (one XCD), the kernel is bound by the per-pivot exchange and instruction latency",
@@ -392,10 +416,27 @@ def rrlu_kernel_name(code):
     return {-1: "t4a::rrlu_kernel<true>", -2: "t4a::rrlu_kernel<false>"}.get(code, "t4a::rg_* (HBM-resident rrLU)")
 
 
+def mfma_view():
+    """MFMA kernels of the sweep (fill_site_tensors: LU trailing update, triangular solve; GEMM when issued): flops per launch,
+    average time, TF/s and the fraction of the 78.6 TF/s f64 MFMA peak — from profiles/r03_mfma_kernels.json
+    (tools/mfma_summary.py over the rocprofv3 passes of this command)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_mfma_kernels.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    out = {"peak_tflops": d.get("peak_tflops"), "sustained_tflops": d.get("sustained_tflops"), "source": "profiles/r03_mfma_kernels.json",
+           "kernels": {}}
+    for k, v in d.get("kernels", {}).items():
+        out["kernels"][k] = {kk: v.get(kk) for kk in ("launches", "avg_us", "mfma_flops_per_launch", "tflops", "frac_of_peak", "frac_of_sustained")}
+    return out
+
+
 def pmc_traffic(kname):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (bench.py itself cannot run under
     rocprofv3 --pmc); only reported when the summary is for the kernel instantiation that dominated this run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_dominant_kernel.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_dominant_kernel.json")
     try:
         with open(path) as f:
             d = json.load(f)

@@ -694,8 +694,10 @@ t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out 
  * the per-bond path part-way (a launch gave up), out[3] half-sweeps that were not eligible (host callback, rook search, shapes
  * beyond the device-dimension kernels) and ran bond by bond. */
 t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out /* [4] */);
-/* enable == 0: this handle runs every half-sweep bond by bond (A/B measurements, tests).  verify != 0: after every chain the
- * device-side index tables are read back and compared with the host's I / J sets (T4A_GPU_INTERNAL_ERROR on a difference). */
+/* enable == 0: this handle runs every half-sweep bond by bond (A/B measurements, tests).  verify bit 0: after every chain the
+ * device-side index tables are read back and compared with the host's I / J sets (T4A_GPU_INTERNAL_ERROR on a difference);
+ * bit 1: while profiling, the rrLU launches of a chain are timed with HIP events around each launch instead of the kernels' own
+ * time stamps (two more packets per bond on the stream: for calibration runs). */
 t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t verify);
 
 /* Evaluate a built-in function on the device for a batch of full multi-indices (parity check of the

@@ -987,7 +987,8 @@ t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t v
     return guarded([&] {
         T4A_REQUIRE_PTR(h);
         h->impl.chain_enabled = enable != 0;
-        h->impl.chain_verify = verify != 0;
+        h->impl.chain_verify = (verify & 1) != 0;
+        h->impl.chain_event_timing = (verify & 2) != 0;
     });
 }
 

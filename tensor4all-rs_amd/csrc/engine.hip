@@ -41,6 +41,7 @@ namespace {
 constexpr int kXcdSharedMaxW = 28; // single-XCD plans up to this many workgroups leave room for other handles' pass-through workgroups
 std::mutex g_xcd_mutex[8];
 std::atomic<int> g_xcd_next{0};
+std::atomic<int> g_live_engines{0};
 std::atomic<bool> g_xcd_disabled{false};
 } // namespace
 bool xcd_disabled()
@@ -92,6 +93,12 @@ void xcd_census()
 }
 } // namespace
 int xcd_assign() { return g_xcd_next.fetch_add(1, std::memory_order_relaxed) & 7; }
+// A launch has 8 W workgroups of which 7 W pass through the other XCDs and need a free compute unit there for a moment.  While
+// this engine is the only one, a plan may fill all 32 compute units of its XCD (and reserves the whole chip for the launch);
+// as soon as several engines are alive, plans stop at kXcdSharedMaxW workgroups, so that every engine only ever reserves its own
+// XCD — before round 3 a chain with one 29-workgroup plan in it held the chip-wide reservation for its whole half-sweep and
+// eight handles on eight host threads ran one after the other (34.3 ms per patch against 38.6 ms for one alone).
+int xcd_plan_max_w() { return g_live_engines.load(std::memory_order_relaxed) > 1 ? kXcdSharedMaxW : 32; }
 void XcdArbiter::Lock::acquire(int xcc)
 {
     release();
@@ -144,11 +151,13 @@ Engine::Engine()
     static const int xcc_env = std::getenv("T4A_XCD_ID") ? std::atoi(std::getenv("T4A_XCD_ID")) : -1;
     // (T4A_XCD_ID=8: an XCC id no workgroup reports — exercises the fallback to the chip-wide kernel in the tests)
     xcc_ = xcc_env >= 0 ? (xcc_env > 8 ? (xcc_env & 7) : xcc_env) : xcd_assign();
+    g_live_engines.fetch_add(1, std::memory_order_relaxed);
     std::call_once(g_census_once, xcd_census);
 }
 
 Engine::~Engine()
 {
+    g_live_engines.fetch_sub(1, std::memory_order_relaxed);
     if (stream_) pool::stream_put(stream_, 1); // (synchronises it)
 }
 
@@ -218,7 +227,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     RrluXcdPlan xplan;
     static const bool force_reg = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "reg";
     // first choice: all workgroups on one XCD (exchange through that XCD's L2); disabled for good once a launch timed out
-    const bool use_xcd = !huge && !force_lds && !force_global && !force_reg && !xcd_disabled() && rrlu_xcd_make_plan(kM, kN, &xplan);
+    const bool use_xcd = !huge && !force_lds && !force_global && !force_reg && !xcd_disabled() && rrlu_xcd_make_plan(kM, kN, &xplan, false, xcd_plan_max_w());
     const bool use_reg = !use_xcd && !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     bool fuse = false;
     bool xcd_src_transposed = false;
@@ -652,7 +661,7 @@ bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
         *out = pl;
         return true;
     }
-    if (xcd_disabled() || !rrlu_xcd_make_plan(kM, kN, &pl.xcd, true)) return false;
+    if (xcd_disabled() || !rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, xcd_plan_max_w())) return false;
     pl.kind = 2;
     pl.code = 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
     *out = pl;

@@ -49,6 +49,7 @@ struct Profile {
 bool xcd_disabled();
 void xcd_disable();
 int xcd_assign();
+int xcd_plan_max_w();
 struct XcdArbiter {
     class Lock {
     public:

@@ -220,7 +220,9 @@ struct RrluXcdArgs {
 };
 // any_size: take every shape the plan family can hold (the bond chain has no other multi-workgroup kernel); otherwise tiny
 // matrices are left to the single-workgroup plan of the chip-wide kernel
-bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size = false);
+// max_w: most workgroups the plan may use (<= 32 = the compute units of an XCD; fewer when other handles share the chip, see
+// XcdArbiter in engine.hip)
+bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size = false, int max_w = 32);
 size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan);
 size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int M);
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);

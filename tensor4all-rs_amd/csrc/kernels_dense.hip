@@ -10,6 +10,7 @@
 #include "kernels.hpp"
 
 #include <atomic>
+#include <utility>
 #include "common.hpp"
 
 #include <cstdlib>
@@ -558,22 +559,148 @@ __global__ void __launch_bounds__(1024) lu_kernel(const LuProblem* problems)
 // Blocked partial-pivot LU with the forward substitution of the right-hand sides folded in:
 //   A = P^T L U in place,   B <- L^{-1} P B.
 // Right-looking over column panels of width nb; per panel one `lu_panel_kernel` launch (one workgroup per problem
-// factors the m x w panel in LDS) and one `lu_update_kernel` launch (one workgroup per nb-wide column tile of [A | B]:
+// factors the m x w panel in its registers) and one `lu_update_kernel` launch (one workgroup per nb-wide column tile of [A | B]:
 // applies the panel's row swaps, then the w rank-1 updates of its columns with the L panel held in LDS).  Every
 // element sees exactly the update sequence of the unblocked algorithm (k ascending, separately rounded multiply and
 // subtract), so the factors are bitwise those of `lu_kernel` followed by the unit-lower `trsm_left_kernel`.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) lu_panel_kernel(const LuProblem* problems, int kb, int nb)
+// Panel factorisation, round 3: the m x w panel (w <= NB columns, m <= 256 RP rows) lives in the REGISTERS of one 256-thread
+// workgroup — thread t holds rows t + 256 r (r < RP), NB values each, NB * RP = 32 doubles per thread for every panel width —
+// instead of in LDS.  Per column: pivot search by wave shuffles + one four-entry LDS round, the pivot row and row j trade
+// places through two NB-double LDS rows (the pivot row stays there as the broadcast operand of the update), scaling and the
+// rank-1 update of the panel's remaining columns in registers.  Two barriers per column where the LDS-resident version needed
+// six (2.7 us per column, half of fill_site_tensors' device time in round 2).  Same pivots, same operation order per element
+// (separately rounded multiply and subtract, IEEE division): bitwise the factors of the LDS version and of lu_kernel.
+struct PanelShared {
+    double* U;     // [2][NB] pivot rows (alternating)
+    double* V;     // [2][NB] displaced rows
+    double* red_v; // [2][4]
+    int* red_i;    // [2][4]
+};
+
+// one column of the panel; J is a template parameter so that every register index is a compile-time constant (the panel must
+// stay in registers: as a run-time loop the compiler put it into scratch memory)
+template <int NB, int RP, int J>
+__device__ __forceinline__ void lu_panel_column(double (&a)[RP][NB], const PanelShared& sh, const LuProblem& pr, int kb, int m, int w, int tid,
+                                                int& first_bad)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ double red_v[4];
-    __shared__ int red_i[4];
-    __shared__ int piv_s;
-    __shared__ double pivval_s;
+    if (J >= w) return; // (uniform)
+    constexpr int par = J & 1;
+    const int lane = tid & 63, wave = tid >> 6;
+    double* U = sh.U + par * NB;
+    double* V = sh.V + par * NB;
+    // pivot search: largest |a_iJ| over rows i >= J, smallest row index among equals; a NaN never wins
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        const int i = tid + 256 * r;
+        if (i >= J && i < m) {
+            const double v = fabs(a[r][J]);
+            if (v > bv || (v == bv && i < bi)) {
+                bv = v;
+                bi = i;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        sh.red_v[par * 4 + wave] = bv;
+        sh.red_i[par * 4 + wave] = bi;
+    }
+    __syncthreads();
+    double v = sh.red_v[par * 4];
+    int p = sh.red_i[par * 4];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        const double qv = sh.red_v[par * 4 + q];
+        const int qi = sh.red_i[par * 4 + q];
+        if (qv > v || (qv == v && qi < p)) {
+            v = qv;
+            p = qi;
+        }
+    }
+    if (tid == 0) {
+        pr.piv[kb + J] = kb + p;
+        if (!(v > 0.0) && first_bad == 0) first_bad = kb + J + 1;
+    }
+    const int prow = (p < m) ? p : J; // (no finite candidate: the column keeps its order)
+    // the pivot row goes to U (everybody's operand below), row J to V when the two trade places
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        const int i = tid + 256 * r;
+        if (i == prow) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) U[c] = a[r][c];
+        }
+        if (prow != J && i == J) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) V[c] = a[r][c];
+        }
+    }
+    __syncthreads();
+    if (prow != J) {
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+            const int i = tid + 256 * r;
+            if (i == J) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) a[r][c] = U[c];
+            }
+            if (i == prow) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) a[r][c] = V[c];
+            }
+        }
+    }
+    const double piv = U[J];
+    if (piv == 0.0 || piv != piv) return; // singular column: left as it is (uniform)
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        const int i = tid + 256 * r;
+        if (i > J && i < m) {
+            const double l = a[r][J] / piv;
+            a[r][J] = l;
+#pragma unroll
+            for (int c = J + 1; c < NB; ++c) {
+                const double prod = l * U[c];
+                a[r][c] = a[r][c] - prod;
+            }
+        }
+    }
+}
+
+template <int NB, int RP, int... Js>
+__device__ __forceinline__ void lu_panel_columns(double (&a)[RP][NB], const PanelShared& sh, const LuProblem& pr, int kb, int m, int w, int tid,
+                                                 int& first_bad, std::integer_sequence<int, Js...>)
+{
+    (lu_panel_column<NB, RP, Js>(a, sh, pr, kb, m, w, tid, first_bad), ...);
+}
+
+// Panel factorisation, round 3: the m x w panel (w <= NB columns, m <= 256 RP rows) lives in the REGISTERS of one 256-thread
+// workgroup — thread t holds rows t + 256 r (r < RP), NB values each, NB * RP = 32 doubles per thread for every panel width —
+// instead of in LDS.  Per column: pivot search by wave shuffles + one four-entry LDS round, the pivot row and row j trade
+// places through two NB-double LDS rows (the pivot row stays there as the broadcast operand of the update), scaling and the
+// rank-1 update of the panel's remaining columns in registers.  Two barriers per column where the LDS-resident version needed
+// six (2.7 us per column, half of fill_site_tensors' device time in round 2).  Same pivots, same operation order per element
+// (separately rounded multiply and subtract, IEEE division): bitwise the factors of the LDS version and of lu_kernel.
+template <int NB, int RP>
+__global__ void __launch_bounds__(256) lu_panel_kernel(const LuProblem* problems, int kb)
+{
+    __shared__ double U[2 * NB], V[2 * NB];
+    __shared__ double red_v[8];
+    __shared__ int red_i[8];
     const LuProblem pr = problems[blockIdx.x];
     const int n = pr.n;
-    const int tid = threadIdx.x, T = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    const int tid = threadIdx.x;
     if (kb == 0) {
         if (pr.pmax_bits) { // zero-pivot-matrix guard (tensorci2.rs:1154-1157): every |p| < EPS
             const double pmax = __longlong_as_double((long long)*pr.pmax_bits);
@@ -587,80 +714,26 @@ __global__ void __launch_bounds__(256) lu_panel_kernel(const LuProblem* problems
         return;
     }
     if (kb >= n) return;
-    const int m = n - kb, w = (n - kb) < nb ? (n - kb) : nb;
-    const int ldp = m | 1; // odd leading dimension: conflict-free row and column walks
-    double* P = (double*)smem_raw;
+    const int m = n - kb, w = (n - kb) < NB ? (n - kb) : NB;
     double* A = pr.A;
     const int lda = pr.lda;
-    for (int e = tid; e < m * w; e += T) {
-        const int i = e % m, c = e / m;
-        P[(size_t)c * ldp + i] = A[(size_t)(kb + c) * lda + kb + i];
-    }
-    __syncthreads();
-    for (int j = 0; j < w; ++j) {
-        double bv = -1.0;
-        int bi = 0x7fffffff;
-        for (int i = j + tid; i < m; i += T) {
-            const double v = fabs(P[(size_t)j * ldp + i]);
-            if (v > bv || (v == bv && i < bi)) {
-                bv = v;
-                bi = i;
-            }
-        }
+    double a[RP][NB];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(bv, off);
-            const int oi = __shfl_xor(bi, off);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
-            }
-        }
-        if (lane == 0) {
-            red_v[wave] = bv;
-            red_i[wave] = bi;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double v = red_v[0];
-            int idx = red_i[0];
-            for (int q = 1; q < nw; ++q)
-                if (red_v[q] > v || (red_v[q] == v && red_i[q] < idx)) {
-                    v = red_v[q];
-                    idx = red_i[q];
-                }
-            piv_s = idx;
-            pr.piv[kb + j] = kb + idx;
-            if (!(v > 0.0)) {
-                if (pr.info[0] == 0) pr.info[0] = kb + j + 1;
-            }
-        }
-        __syncthreads();
-        const int p = piv_s;
-        if (p != j && p < m)
-            for (int c = tid; c < w; c += T) {
-                const double t = P[(size_t)c * ldp + j];
-                P[(size_t)c * ldp + j] = P[(size_t)c * ldp + p];
-                P[(size_t)c * ldp + p] = t;
-            }
-        __syncthreads();
-        if (tid == 0) pivval_s = P[(size_t)j * ldp + j];
-        __syncthreads();
-        const double piv = pivval_s;
-        if (piv == 0.0 || piv != piv) continue; // singular column: left as it is (info already set)
-        for (int i = j + 1 + tid; i < m; i += T) P[(size_t)j * ldp + i] = P[(size_t)j * ldp + i] / piv;
-        __syncthreads();
-        const int remr = m - j - 1, remc = w - j - 1;
-        for (int e = tid; e < remr * remc; e += T) {
-            const int i = j + 1 + e % remr, c = j + 1 + e / remr;
-            const double prod = P[(size_t)j * ldp + i] * P[(size_t)c * ldp + j];
-            P[(size_t)c * ldp + i] = P[(size_t)c * ldp + i] - prod;
-        }
-        __syncthreads();
+    for (int r = 0; r < RP; ++r) {
+        const int i = tid + 256 * r;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[r][c] = (i < m && c < w) ? A[(size_t)(kb + c) * lda + kb + i] : 0.0;
     }
-    for (int e = tid; e < m * w; e += T) {
-        const int i = e % m, c = e / m;
-        A[(size_t)(kb + c) * lda + kb + i] = P[(size_t)c * ldp + i];
+    int first_bad = 0; // (thread 0) first column without a usable pivot, 1-based
+    PanelShared sh{U, V, red_v, red_i};
+    lu_panel_columns<NB, RP>(a, sh, pr, kb, m, w, tid, first_bad, std::make_integer_sequence<int, NB>{});
+    if (tid == 0 && first_bad != 0 && pr.info[0] == 0) pr.info[0] = first_bad;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        const int i = tid + 256 * r;
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (i < m && c < w) A[(size_t)(kb + c) * lda + kb + i] = a[r][c];
     }
 }
 
@@ -978,20 +1051,18 @@ bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int 
     else return false; // panel does not fit the LDS: the caller falls back to lu_kernel + trsm
     static std::atomic<bool> attr_set{false}; // (launches come from several host threads; setting the attribute twice is harmless)
     if (!attr_set) {
-        // (the panel kernel also has a few static LDS words: stay below the 160 KiB total)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_panel_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_update_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipGetLastError();
         attr_set = true;
     }
     const int ldp = max_n | 1;
-    const size_t lds_panel = (size_t)ldp * nb * 8;
     const size_t lds_update = (size_t)ldp * nb * 8 * 2;
     const int tiles = (max_n + nb - 1) / nb + (max_nrhs + nb - 1) / nb + 1;
     for (int kb = 0; kb < max_n; kb += nb) {
-        hipLaunchKernelGGL(lu_panel_kernel, dim3(n_problems), dim3(256), lds_panel, stream, d_problems, kb, nb);
+        if (nb == 32) hipLaunchKernelGGL((lu_panel_kernel<32, 1>), dim3(n_problems), dim3(256), 0, stream, d_problems, kb);
+        else if (nb == 16) hipLaunchKernelGGL((lu_panel_kernel<16, 2>), dim3(n_problems), dim3(256), 0, stream, d_problems, kb);
+        else hipLaunchKernelGGL((lu_panel_kernel<8, 4>), dim3(n_problems), dim3(256), 0, stream, d_problems, kb);
         // one workgroup per (tile, problem) item; with tickets a few more, so that those which return on the avoided XCD are made up for
         const int items = tiles * n_problems;
         unsigned* tk = tickets ? tickets + kb / nb : nullptr;

@@ -1081,8 +1081,9 @@ int xcd_norm_cpt(int c)
 
 } // namespace
 
-bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size)
+bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size, int max_w)
 {
+    if (max_w < 1 || max_w > 32) max_w = 32;
     if (M < 1 || N < 1 || M > 1024 || N > 1024) return false;
     static const int min_elems = std::getenv("T4A_XCD_MIN") ? std::atoi(std::getenv("T4A_XCD_MIN")) : 64 * 64;
     if (!any_size && (long long)M * N <= (long long)min_elems) return false; // tiny matrices: the single-workgroup plan of the chip-wide kernel
@@ -1102,7 +1103,7 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size)
         if (cpt != c) continue;
         if (cpt_env > 0 && cpt != cpt_env) continue;
         const int w = (N + XWAVES * cpt - 1) / (XWAVES * cpt);
-        if (w > 32) continue;
+        if (w > max_w) continue;
         if (rpt * cpt > XCD_MAX_VALUES) continue;
         const long cost = old_cost ? 24L * rpt * cpt + 250L * ((w * XWAVES + 63) / 64) : (long)cpt;
         if (best_cpt < 0 || cost < best_cost) {
@@ -1113,7 +1114,7 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size)
     }
     if (best_cpt < 0) return false;
     if (w_env > 0) {
-        best_w = w_env > 32 ? 32 : w_env;
+        best_w = w_env > max_w ? max_w : w_env;
         int c = (N + XWAVES * best_w - 1) / (XWAVES * best_w);
         best_cpt = xcd_norm_cpt(c);
         if (best_cpt < 0 || rpt * best_cpt > XCD_MAX_VALUES) return false;

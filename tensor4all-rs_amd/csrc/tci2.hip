@@ -164,6 +164,8 @@ Tci2::Tci2(const std::vector<size_t>& dims) : n_(dims.size()), local_dims(dims) 
 
 Tci2::~Tci2()
 {
+    for (hipEvent_t e : chain_.t0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : chain_.t1) (void)hipEventDestroy(e);
     if (export_event_) (void)hipEventDestroy(export_event_);
     if (import_event_) (void)hipEventDestroy(import_event_);
     if (import_stream_) pool::stream_put(import_stream_, 2); // (synchronises it)

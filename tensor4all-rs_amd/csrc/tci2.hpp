@@ -101,6 +101,8 @@ public:
     std::array<uint64_t, 4> chain_stats{{0, 0, 0, 0}};
     bool chain_enabled = true;  // false: every half-sweep runs bond by bond (A/B measurements, tests)
     bool chain_verify = false;  // true: after every chain the device tables are read back and compared with the host's sets
+    bool chain_event_timing = false; // profiling: rrLU launches of a chain are timed with HIP events around each launch instead of
+                                     // the kernel's own time stamps (two more packets per bond on the stream: calibration runs only)
 
     std::vector<double> evaluate(const uint32_t* idx, size_t n_pts); // idx n_sites x n_pts col-major
     double sum();
@@ -256,7 +258,8 @@ private:
         std::vector<ChainRrluPlan> plans;
         std::vector<unsigned> tokens;
         ChainBlock proto;
-        bool timed = false;
+        bool timed = false, timed_events = false;
+        std::vector<hipEvent_t> t0, t1; // per bond: around the rrLU launch (chain_event_timing)
     } chain_;
     bool chain_usable(const TCI2Options& options) const;
     ChainTab chain_tab(int family) const;    // 0: I, 1: J, 2 + 2 s: snapshot s of I, 3 + 2 s: snapshot s of J

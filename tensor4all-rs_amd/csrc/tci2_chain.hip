@@ -366,6 +366,14 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     chain_.dims.reserve(nb * 5 + 2); // {M, N, poison, lda} per bond, then one tile counter per bond (speculative evaluation)
     chain_.hdims.reserve(nb * 4);
     const bool timed = eng.prof.enabled;
+    const bool timed_events = timed && chain_event_timing;
+    while (timed_events && chain_.t0.size() < nb) {
+        hipEvent_t a = nullptr, b2 = nullptr;
+        T4A_HIP(hipEventCreate(&a));
+        T4A_HIP(hipEventCreate(&b2));
+        chain_.t0.push_back(a);
+        chain_.t1.push_back(b2);
+    }
 
     // ---- 3. tables: current sets, the extras of this iteration, the snapshot for the next one ----
     if (!chain_.tables_valid) chain_upload_current();
@@ -508,8 +516,10 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
             fp.d_colacc = c.ind_acc + b * ind_cap * K;
             fp.host_resident = false;
             const double* A = fused ? nullptr : (spec_here ? chain_.spec[k & 1].get() : chain_.pi.get());
+            if (timed_events) T4A_HIP(hipEventRecord(chain_.t0[b], st));
             tokens[b] = eng.chain_rrlu(pl, forward, A, spec_here ? c.rowmap : nullptr, fused ? &fp : nullptr, c.dims + b * 4, chi, options.tolerance,
                                        0.0, blk, spec_pending ? &sp : nullptr);
+            if (timed_events) T4A_HIP(hipEventRecord(chain_.t1[b], st));
         }
         { // the pivots of the last bond
             const size_t pb = order[nb - 1];
@@ -542,6 +552,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     chain_.tokens = std::move(tokens);
     chain_.proto = proto;
     chain_.timed = timed;
+    chain_.timed_events = timed_events;
     return true;
 }
 
@@ -616,7 +627,8 @@ void Tci2::chain_finish(const TCI2Options& options)
             if (chain_.timed) { // device-side time stamps of the launch (wall_clock64: 100 MHz)
                 unsigned long long ts[2];
                 std::memcpy(ts, hb + proto.off_ts, sizeof(ts));
-                const float ms = ts[1] > ts[0] ? (float)((double)(ts[1] - ts[0]) * 1e-5) : 0.f;
+                float ms = ts[1] > ts[0] ? (float)((double)(ts[1] - ts[0]) * 1e-5) : 0.f;
+                if (chain_.timed_events) T4A_HIP(hipEventElapsedTime(&ms, chain_.t0[b], chain_.t1[b]));
                 eng.prof.v[0] += ms;
                 eng.prof.v[1] += 1.0;
                 auto& vs = eng.variant_stats_[chain_.plans[b].code];

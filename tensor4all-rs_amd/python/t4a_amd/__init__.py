@@ -643,9 +643,10 @@ class TensorCI2:
         return [dict(code=int(r[0]), ms=float(r[1]), launches=float(r[2]), bytes=float(r[3]), steps=float(r[4])) for r in out[: n.value]]
 
 
-    def set_chain(self, enable=True, verify=False):
-        """Device-side bond chain on / off for this handle; verify: read the device tables back after every chain."""
-        _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0), c_int32(1 if verify else 0)))
+    def set_chain(self, enable=True, verify=False, event_timing=False):
+        """Device-side bond chain on / off for this handle; verify: read the device tables back after every chain; event_timing:
+        while profiling, time the rrLU launches with HIP events instead of the kernels' own time stamps."""
+        _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0), c_int32((1 if verify else 0) | (2 if event_timing else 0))))
 
     def chain_stats(self):
         """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible) since the handle was created."""
