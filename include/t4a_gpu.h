@@ -694,6 +694,12 @@ t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out 
  * the per-bond path part-way (a launch gave up), out[3] half-sweeps that were not eligible (host callback, rook search, shapes
  * beyond the device-dimension kernels) and ran bond by bond. */
 t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out /* [4] */);
+/* optimize_with_finder (tensorci2.rs:1626-1802) on up to EIGHT handles at once, driven in lock-step by the calling thread: every
+ * iteration enqueues the half-sweeps of all handles (each on its own XCD), then completes them one after the other.  This is the
+ * per-GPU form of the patch farm (BASELINE.json configs[4]: eight patches per GPU; adaptive_interpolation.rs:171-330 runs the
+ * patches one after the other): results on every handle are exactly those of t4a_gpu_tci2_optimize. */
+t4a_gpu_status t4a_gpu_tci2_optimize_group(t4a_gpu_tci2* const* handles, size_t n_handles, const t4a_gpu_tci2_options* options,
+                                           int32_t final_sweep1site);
 /* enable == 0: this handle runs every half-sweep bond by bond (A/B measurements, tests).  verify bit 0: after every chain the
  * device-side index tables are read back and compared with the host's I / J sets (T4A_GPU_INTERNAL_ERROR on a difference);
  * bit 1: while profiling, the rrLU launches of a chain are timed with HIP events around each launch instead of the kernels' own

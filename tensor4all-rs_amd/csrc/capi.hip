@@ -597,6 +597,20 @@ t4a_gpu_status t4a_gpu_tci2_optimize(t4a_gpu_tci2* h, const t4a_gpu_tci2_options
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_optimize_group(t4a_gpu_tci2* const* handles, size_t n_handles, const t4a_gpu_tci2_options* options,
+                                           int32_t final_sweep1site)
+{
+    return guarded([&] {
+        if (n_handles) T4A_REQUIRE_PTR(handles);
+        std::vector<Tci2*> hs;
+        for (size_t i = 0; i < n_handles; ++i) {
+            T4A_REQUIRE_PTR(handles[i]);
+            hs.push_back(&handles[i]->impl);
+        }
+        Tci2::optimize_group(hs, convert_options(options), final_sweep1site != 0);
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_sweep2site(t4a_gpu_tci2* h, int32_t forward, const t4a_gpu_tci2_options* options)
 {
     return guarded([&] {

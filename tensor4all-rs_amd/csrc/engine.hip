@@ -227,7 +227,8 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     RrluXcdPlan xplan;
     static const bool force_reg = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "reg";
     // first choice: all workgroups on one XCD (exchange through that XCD's L2); disabled for good once a launch timed out
-    const bool use_xcd = !huge && !force_lds && !force_global && !force_reg && !xcd_disabled() && rrlu_xcd_make_plan(kM, kN, &xplan, false, xcd_plan_max_w());
+    const bool use_xcd = !huge && !force_lds && !force_global && !force_reg && !xcd_disabled() &&
+                         (rrlu_xcd_make_plan(kM, kN, &xplan, false, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &xplan, false, 32));
     const bool use_reg = !use_xcd && !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     bool fuse = false;
     bool xcd_src_transposed = false;
@@ -661,7 +662,9 @@ bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
         *out = pl;
         return true;
     }
-    if (xcd_disabled() || !rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, xcd_plan_max_w())) return false;
+    // (shapes that only fit with more than kXcdSharedMaxW workgroups keep their plan: the launch then reserves the whole chip)
+    if (xcd_disabled() || !(rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32)))
+        return false;
     pl.kind = 2;
     pl.code = 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
     *out = pl;

@@ -134,6 +134,7 @@ public:
                         size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec);
     void chain_end();
     int xcc() const { return xcc_; }
+    void set_xcc(int xcc) { xcc_ = xcc & 7; } // (optimize_group: handle i of a group works on XCD i)
 
     // Host work that does not depend on the running factorisation: executed once, after the kernels of the next luci()
     // call have been enqueued and before the host blocks on them (then cleared).

@@ -1594,8 +1594,14 @@ static bool convergence_criterion(const std::vector<size_t>& ranks, const std::v
 }
 
 // optimize_with_finder (tensorci2.rs:1626-1802)
-void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
+// optimize_with_finder (tensorci2.rs:1626-1802) as a resumable run: opt_begin, then per iteration opt_iter_start (prelude + the
+// half-sweep enqueued as a bond chain, without waiting) and opt_iter_finish (the rest of the iteration), then opt_end.  optimize()
+// drives one handle; optimize_group() drives up to eight in lock-step from one host thread — every handle's chain runs on its
+// own XCD, so their bond updates overlap on the device while the host only ever waits for the slowest.
+void Tci2::opt_begin(OptRun& r)
 {
+    const TCI2Options& options = r.options;
+
     options.validate();
     require_fn();
     if (rank() == 0)
@@ -1605,9 +1611,9 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
     if (!keep_site_tensors) fill_wait();
     ranks_hist.clear();
     errors_hist.clear();
-    std::vector<size_t> nglobal_hist;
+    r.nglobal_hist.clear();
     termination = T4A_GPU_TCI2_MAX_ITERATIONS;
-    uint64_t rng_state = options.has_seed ? options.seed : 0x1234567ull;
+    r.rng_state = options.has_seed ? options.seed : 0x1234567ull;
     // bounded rank, built-in functor: site tensors and fill workspaces get their final size now (a buffer that grows goes
     // through the process-wide cache, which waits for the whole device: once per iteration and buffer while ranks grow)
     if (fn_kind_ == FnKind::Builtin && options.max_bond_dim != 0 && options.max_bond_dim <= 1024) {
@@ -1623,11 +1629,20 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         d_fillB_.reserve(std::max<size_t>(totB, 1));
         d_fillpiv_.reserve(std::max<size_t>(n_ * chi, 1));
     }
-    bool pending_fill = false; // fill_site_tensors of the last iteration: accumulators prepared, stream operations not yet issued
+    r.pending_fill = false;
+    r.iter = 0;
+    r.done = false;
 
-    for (size_t iter = 0; iter < options.max_iter; ++iter) {
-        const double norm = (options.normalize_error && max_sample_value > 0.0) ? max_sample_value : 1.0;
-        const double abs_tol = options.tolerance * norm;
+}
+
+bool Tci2::opt_iter_start(OptRun& r)
+{
+    const TCI2Options& options = r.options;
+    if (r.done || r.iter >= options.max_iter) return false;
+    const size_t iter = r.iter;
+    (void)iter;
+        r.norm = (options.normalize_error && max_sample_value > 0.0) ? max_sample_value : 1.0;
+        r.abs_tol = options.tolerance * r.norm;
         bool is_forward = true;
         if (options.sweep_strategy == 1) is_forward = false;
         else if (options.sweep_strategy == 2) is_forward = (iter % 2 == 0);
@@ -1679,11 +1694,28 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         const size_t flush_at_fwd = flush_k, flush_at_bwd = nb_ - 1 - flush_k;
         flush_deferred_fill();
         // built-in functor, full pivot search: the whole half-sweep is enqueued at once (tci2_chain.hip) ...
-        const bool chained = chain_enqueue(is_forward, options, ext_idx, true);
+        r.is_forward = is_forward;
+        r.ext_idx = ext_idx;
+        r.fill_ahead = fill_ahead;
+        r.flush_at_fwd = flush_at_fwd;
+        r.flush_at_bwd = flush_at_bwd;
+        r.chained = chain_enqueue(is_forward, options, ext_idx, true);
+    return true;
+}
+
+void Tci2::opt_iter_finish(OptRun& r)
+{
+    const TCI2Options& options = r.options;
+    const size_t iter = r.iter;
+    const double norm = r.norm, abs_tol = r.abs_tol;
+    const bool is_forward = r.is_forward, chained = r.chained, fill_ahead = r.fill_ahead;
+    const long ext_idx = r.ext_idx;
+    const size_t flush_at_fwd = r.flush_at_fwd, flush_at_bwd = r.flush_at_bwd;
+    do { // (one pass; `break` = the convergence exit of the reference's loop)
         // ... and while the device works on it the host issues fill_site_tensors of the PREVIOUS iteration (its accumulators
         // were taken from the mirror when that iteration finished; nothing of it touches the main stream)
-        if (pending_fill) {
-            pending_fill = false;
+        if (r.pending_fill) {
+            r.pending_fill = false;
             for (size_t b = 0; b < n_; ++b) prepare_fill_site(b); // (from the mirror of the previous chain; the new one writes the other mirror)
             fill_cache_trusted_ = true;
             fill_no_main_sync_ = true;
@@ -1738,7 +1770,7 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         if (chained && chain_.digits_stale && fill_async) {
             // this fill's accumulators (out of the mirror), descriptors and launches go out after the NEXT iteration's chain
             // has been enqueued (or after the loop): the device is busy with that chain while the host prepares the fill
-            pending_fill = true;
+            r.pending_fill = true;
         } else {
             fill_cache_trusted_ = fill_ahead && !chained;
             fill_defer_requested_ = fill_ahead && !chained && iter + 1 < options.max_iter;
@@ -1748,23 +1780,31 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         const double error = max_bond_error();
         errors_hist.push_back(error / norm);
 
-        std::vector<std::vector<uint32_t>> gp = find_global_pivots(abs_tol, options, rng_state);
+        std::vector<std::vector<uint32_t>> gp = find_global_pivots(abs_tol, options, r.rng_state);
         // invalidates the site tensors even for an empty list (tensorci2.rs:707-708) unless the caller opted out
         if (!(gp.empty() && keep_site_tensors)) add_global_pivots(gp);
-        nglobal_hist.push_back(gp.size());
+        r.nglobal_hist.push_back(gp.size());
         ranks_hist.push_back(rank());
         if (options.verbosity > 0)
             std::printf("iteration = %zu, rank = %zu, error = %.2e, maxsamplevalue = %.2e, nglobalpivot = %zu\n", iter + 1,
                         rank(), error / norm, max_sample_value, gp.size());
         int reason;
-        if (convergence_criterion(ranks_hist, errors_hist, nglobal_hist, options.tolerance, options.max_bond_dim_or_max(),
+        if (convergence_criterion(ranks_hist, errors_hist, r.nglobal_hist, options.tolerance, options.max_bond_dim_or_max(),
                                   options.ncheck_history, reason)) {
             termination = reason;
+            r.done = true;
             break;
         }
-    }
-    if (pending_fill) { // the last iteration's fill
-        pending_fill = false;
+    } while (false);
+    ++r.iter;
+}
+
+void Tci2::opt_end(OptRun& r)
+{
+    const TCI2Options& options = r.options;
+    const bool final_sweep1site = r.final_sweep1site;
+    if (r.pending_fill) { // the last iteration's fill
+        r.pending_fill = false;
         for (size_t b = 0; b < n_; ++b) prepare_fill_site(b);
         fill_cache_trusted_ = true;
         fill_no_main_sync_ = true;
@@ -1780,6 +1820,44 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
         const double abs_tol = options.tolerance * norm;
         sweep1site(true, 1e-14, abs_tol, options.max_bond_dim_or_max(), true);
     }
+}
+
+void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
+{
+    OptRun r;
+    r.options = options;
+    r.final_sweep1site = final_sweep1site;
+    opt_begin(r);
+    while (opt_iter_start(r)) opt_iter_finish(r);
+    opt_end(r);
+}
+
+// Up to eight handles (one XCD each) optimised in lock-step by the calling thread: every iteration first enqueues all the bond
+// chains, then finishes them one after the other.  Results are exactly those of optimize() on every handle.
+void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& options, bool final_sweep1site)
+{
+    if (hs.empty()) return;
+    if (hs.size() > 8) throw Error(T4A_GPU_INVALID_ARGUMENT, "optimize_group: at most eight handles (one per XCD)");
+    for (size_t i = 0; i < hs.size(); ++i) {
+        if (!hs[i]) throw Error(T4A_GPU_NULL_POINTER, "optimize_group: null handle");
+        for (size_t j = 0; j < i; ++j)
+            if (hs[j] == hs[i]) throw Error(T4A_GPU_INVALID_ARGUMENT, "optimize_group: a handle appears twice");
+        hs[i]->eng.set_xcc((int)i); // (distinct XCDs: a handle keeps its reservation from enqueue to finish)
+    }
+    std::vector<OptRun> runs(hs.size());
+    for (size_t i = 0; i < hs.size(); ++i) {
+        runs[i].options = options;
+        runs[i].final_sweep1site = final_sweep1site;
+        hs[i]->opt_begin(runs[i]);
+    }
+    for (;;) {
+        std::vector<size_t> active;
+        for (size_t i = 0; i < hs.size(); ++i)
+            if (hs[i]->opt_iter_start(runs[i])) active.push_back(i);
+        if (active.empty()) break;
+        for (size_t i : active) hs[i]->opt_iter_finish(runs[i]);
+    }
+    for (size_t i = 0; i < hs.size(); ++i) hs[i]->opt_end(runs[i]);
 }
 
 // crossinterpolate2 (tensorci2.rs:1513-1563)

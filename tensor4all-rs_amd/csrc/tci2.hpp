@@ -78,6 +78,26 @@ public:
     void add_global_pivots(const std::vector<std::vector<uint32_t>>& pivots);
     void crossinterpolate2(std::vector<std::vector<uint32_t>> initial_pivots, const TCI2Options& options);
     void optimize(const TCI2Options& options, bool final_sweep1site);
+    // the same for up to eight handles at once, in lock-step from the calling thread (one XCD per handle)
+    static void optimize_group(const std::vector<Tci2*>& handles, const TCI2Options& options, bool final_sweep1site);
+    struct OptRun { // one optimize() call in progress
+        TCI2Options options;
+        bool final_sweep1site = false;
+        std::vector<size_t> nglobal_hist;
+        uint64_t rng_state = 0;
+        bool pending_fill = false; // fill_site_tensors of the last iteration: accumulators / stream operations not yet issued
+        size_t iter = 0;
+        bool done = false;
+        // the iteration between opt_iter_start and opt_iter_finish
+        double norm = 1.0, abs_tol = 0.0;
+        bool is_forward = true, chained = false, fill_ahead = false;
+        long ext_idx = -1;
+        size_t flush_at_fwd = 0, flush_at_bwd = 0;
+    };
+    void opt_begin(OptRun& r);
+    bool opt_iter_start(OptRun& r);
+    void opt_iter_finish(OptRun& r);
+    void opt_end(OptRun& r);
     void sweep2site(bool forward, const TCI2Options& options);
     void sweep1site(bool forward, double rel_tol, double abs_tol, size_t max_bond_dim, bool update_tensors);
     void fill_site_tensors();

@@ -655,6 +655,14 @@ class TensorCI2:
         return dict(half_sweeps=int(out[0]), bonds=int(out[1]), fell_back=int(out[2]), not_eligible=int(out[3]))
 
 
+def optimize_group(tcis, options, final_sweep1site=True):
+    """optimize() on up to eight TensorCI2 handles at once, in lock-step from this thread (one XCD per handle): the per-GPU form
+    of the patch farm.  Results on every handle are exactly those of handle.optimize(options, final_sweep1site)."""
+    o = options.to_c()
+    arr = (c_void_p * len(tcis))(*[t._h for t in tcis])
+    _check(_lib.t4a_gpu_tci2_optimize_group(arr, c_size_t(len(tcis)), ctypes.byref(o), c_int32(1 if final_sweep1site else 0)))
+
+
 def crossinterpolate2(f, local_dims, initial_pivots, options):
     """crossinterpolate2 (tensorci2.rs:1513). Returns the optimised TensorCI2; histories via .history()."""
     options.to_c()  # validate before anything else

@@ -160,3 +160,35 @@ def test_chain_at_cfg3_size_equals_per_bond_path(t4a):
     c.fill_site_tensors()   # (optimize invalidates the site tensors at the end of every iteration, tensorci2.rs:707-708)
     h.fill_site_tensors()
     assert np.array_equal(c.evaluate(pts), h.evaluate(pts))
+
+
+def test_optimize_group_equals_optimize_on_every_handle(t4a):
+    """t4a_gpu_tci2_optimize_group: several handles in lock-step from one thread (one XCD each) — the per-GPU form of the patch farm
+    (BASELINE.json configs[4]).  Every handle must end exactly where its own optimize() call ends, also when the handles need
+    different numbers of iterations (different tolerances do not apply: one option set; different functions do)."""
+    import bench
+    n = 16
+    specs = [t4a.quantics_osc2d(n, k1=3 + p, k2=5, k3=7 + 2 * p, eps=0.1 * (p + 1), k4=11, delta=0.3) for p in range(5)]
+    specs.append(t4a.quantics_trig_exp(n))          # converges after a few iterations: drops out of the group early
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=24, max_iter=9, seed=3, **PARITY)
+    solo, grouped = [], []
+    for spec in specs:
+        for dst in (solo, grouped):
+            t = t4a.TensorCI2([2] * n)
+            t.set_function(spec)
+            t.add_global_pivots([[0] * n])
+            dst.append(t)
+    for t in solo:
+        t.optimize(opts, final_sweep1site=True)
+    t4a.optimize_group(grouped, opts, final_sweep1site=True)
+    for k, (a, b) in enumerate(zip(solo, grouped)):
+        for p in range(n):
+            assert np.array_equal(a.i_set(p), b.i_set(p)) and np.array_equal(a.j_set(p), b.j_set(p)), (k, p)
+        assert a.history()[0] == b.history()[0] and np.array_equal(a.history()[1], b.history()[1]), k
+        assert a.termination() == b.termination() and a.max_sample_value() == b.max_sample_value()
+        for p in range(n):
+            assert np.array_equal(a.site_tensor(p), b.site_tensor(p)), (k, p)
+        assert b.chain_stats()["fell_back"] == 0 and b.chain_stats()["half_sweeps"] > 0
+    assert len(set(len(t.history()[0]) for t in grouped)) > 1, "the test wants handles that stop at different iterations"
+    with pytest.raises(t4a.T4aError):
+        t4a.optimize_group([grouped[0], grouped[0]], opts)
