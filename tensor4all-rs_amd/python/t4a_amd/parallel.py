@@ -83,6 +83,102 @@ def run_patch_farm(dist, torch, n_patches, run_patch, device="cpu"):
     return result
 
 
+class PaddedPatchFarm:
+    """Device-resident patch farm (BASELINE.json configs[4]; reference: adaptive_interpolation.rs:171-330 runs one independent
+    crossinterpolate2 per patch and keeps the FIFO patch order when it re-assembles, :303-330).
+
+    Patches are dealt round-robin to the ranks (patch p on rank p % world, FIFO inside a rank).  Every rank writes the cores of
+    its patches into ONE padded device tensor [per_rank, n_sites, cap] (cap = the largest core, e.g. chi * d * chi) plus a small
+    int64 tensor with the (l, s, r) of every core; ONE all_gather_into_tensor moves the payload and one the shapes — nothing is
+    staged through host memory (the host-packed run_patch_farm above moves ~0.5 GB through PCIe for 64 patches x chi 128).
+    The gathered payload stays on the device; `core(p, s)` / `cores(p)` copy single cores out for whoever wants them on the host.
+
+    `export_patches(patches, send)`: the local compute, injected.  `patches` = this rank's patch numbers in FIFO order, `send` =
+    a float64 tensor view [len(patches), n_sites, cap] on `device`; it interpolates the patches, writes their cores (column-major
+    (l, s, r), zero padded) and returns the shapes as a list (per patch) of lists (per site) of (l, s, r).
+    DevicePatchExporter (below) does that with t4a_gpu_tci2_optimize_group — up to eight patches at a time, one XCD each — and
+    device-to-device exports; tests/test_cpu_parallel.py runs the same orchestration on gloo with the CPU oracle."""
+
+    def __init__(self, dist, torch, n_patches, n_sites, cap, device):
+        self.dist, self.torch = dist, torch
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.n_patches, self.n_sites, self.cap = n_patches, n_sites, cap
+        self.per_rank = (n_patches + self.world - 1) // self.world
+        self.mine = patches_of_rank(n_patches, self.rank, self.world)
+        self.send = torch.zeros(self.per_rank * n_sites * cap, dtype=torch.float64, device=device)
+        self.recv = torch.zeros(self.world * self.per_rank * n_sites * cap, dtype=torch.float64, device=device)
+        self.send_dims = torch.zeros(self.per_rank * n_sites * 3, dtype=torch.int64, device=device)
+        self.recv_dims = torch.zeros(self.world * self.per_rank * n_sites * 3, dtype=torch.int64, device=device)
+        self.dims = None
+
+    def run(self, export_patches):
+        torch = self.torch
+        view = self.send.view(self.per_rank, self.n_sites, self.cap)[:len(self.mine)]
+        shapes = export_patches(self.mine, view) if self.mine else []
+        flat = [int(v) for patch in shapes for d in patch for v in d]
+        flat += [0] * (self.per_rank * self.n_sites * 3 - len(flat))
+        self.send_dims.copy_(torch.tensor(flat, dtype=torch.int64), non_blocking=True)
+        if self.world > 1:
+            works = [self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True),
+                     self.dist.all_gather_into_tensor(self.recv_dims, self.send_dims, async_op=True)]
+            for w in works:
+                w.wait()
+        else:
+            self.recv.copy_(self.send)
+            self.recv_dims.copy_(self.send_dims)
+        self.dims = self.recv_dims.cpu().numpy().reshape(self.world, self.per_rank, self.n_sites, 3)
+        return self
+
+    def _slot(self, p):
+        return p % self.world, p // self.world
+
+    def core_dims(self, p, s):
+        r, k = self._slot(p)
+        return tuple(int(v) for v in self.dims[r, k, s])
+
+    def core_device(self, p, s):
+        """Core s of patch p as a device tensor view (l * d * r doubles, column-major (l, s, r))."""
+        r, k = self._slot(p)
+        l, d, rr = self.core_dims(p, s)
+        return self.recv.view(self.world, self.per_rank, self.n_sites, self.cap)[r, k, s, :l * d * rr]
+
+    def core(self, p, s):
+        l, d, rr = self.core_dims(p, s)
+        return self.core_device(p, s).cpu().numpy().reshape((l, d, rr), order="F")
+
+    def cores(self, p):
+        return [self.core(p, s) for s in range(self.n_sites)]
+
+
+class DevicePatchExporter:
+    """export_patches callback of PaddedPatchFarm for device handles: `make_patch(p)` returns a fresh TensorCI2 handle with its
+    function and initial pivots set; the patches of this rank are optimised `group` at a time (<= 8: one XCD each,
+    t4a_gpu_tci2_optimize_group), their site tensors filled and exported device-to-device.  `keep(p, tci)` is called with every
+    finished handle (tests keep a sample for the comparison with the oracle)."""
+
+    def __init__(self, t4a_amd, torch, make_patch, options, group=8, keep=None):
+        self.t4a, self.torch, self.make_patch, self.options, self.group, self.keep = t4a_amd, torch, make_patch, options, max(1, min(group, 8)), keep
+
+    def __call__(self, patches, send):
+        shapes = []
+        stream = self.torch.cuda.current_stream().cuda_stream
+        cap = send.shape[2]
+        for k0 in range(0, len(patches), self.group):
+            chunk = patches[k0:k0 + self.group]
+            tcis = [self.make_patch(p) for p in chunk]
+            self.t4a.optimize_group(tcis, self.options, final_sweep1site=False)
+            for j, (p, t) in enumerate(zip(chunk, tcis)):
+                t.fill_site_tensors()
+                t.export_site_tensors_async(send[k0 + j].data_ptr(), cap, stream)
+                ld, loc = t.link_dims(), t.local_dims
+                shapes.append([_site_dims(ld, loc, s) for s in range(len(loc))])
+                if self.keep is not None:
+                    self.keep(p, t)
+            self.torch.cuda.current_stream().synchronize()  # (the handles of this chunk are released next: their cores must have left)
+        return shapes
+
+
 def sharded_fill(dist, torch, n_sites, fill_my_sites, get_core, set_core, device="cpu"):
     """Site-sharded fill_site_tensors + core all-gather.  fill_my_sites(rank, world) fills the local sites;
     get_core(s) -> array, set_core(s, array) installs a core received from another rank."""

@@ -41,6 +41,26 @@ def _worker(rank, world, port, n_patches, out_dir):
     np.save(os.path.join(out_dir, f"farm_{rank}.npy"),
             np.concatenate([c.ravel(order="F") for pc in cores for c in pc]))
 
+    # the same farm through the padded, device-resident form (parallel.PaddedPatchFarm): one all_gather_into_tensor for the
+    # payload, one for the shapes; the local compute here is the CPU oracle writing into the (CPU) send tensor
+    n_sites = len(_run_patch(0))
+    cap = max(int(np.prod(c.shape)) for q in range(n_patches) for c in _run_patch(q))
+
+    def export_patches(patches, send):
+        shapes = []
+        for k, q in enumerate(patches):
+            cs = _run_patch(q)
+            for s_, c in enumerate(cs):
+                flat = np.asarray(c, dtype=np.float64).ravel(order="F")
+                send[k, s_, :flat.size] = torch.from_numpy(flat.copy())
+            shapes.append([c.shape for c in cs])
+        return shapes
+
+    farm = parallel.PaddedPatchFarm(dist, torch, n_patches, n_sites, cap, "cpu").run(export_patches)
+    for q in range(n_patches):
+        for s_, (a, b) in enumerate(zip(farm.cores(q), cores[q])):
+            assert a.shape == b.shape and np.array_equal(a, b), (q, s_)
+
     # site-sharded fill: every rank holds the same index sets; rank r fills sites s % world == r
     import oracle_binding as ob
     from t4a_amd import TCI2Options

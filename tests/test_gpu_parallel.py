@@ -158,8 +158,8 @@ def test_device_resident_shard_exchange_matches_unsharded_fill(rccl):
 
 def test_cfg5_full_size_64_patches_chi128(rccl):
     """BASELINE.json configs[4] at size on one GPU: 64 static patches (6 leading bits of the d = 30 bench integrand
-    projected, 30 active sites each), per-patch crossinterpolate2 with max_bond_dim = 128, farmed through
-    parallel.run_patch_farm (world size 1 over RCCL).  All 64 patches come back in patch (FIFO) order and tile the domain;
+    projected, 30 active sites each), per-patch TCI2 with max_bond_dim = 128, farmed through the device-resident
+    parallel.PaddedPatchFarm (world size 1 over RCCL), eight patches at a time with t4a_gpu_tci2_optimize_group.  All 64 patches come back in patch (FIFO) order and tile the domain;
     a sample of 8 patches is compared with the CPU oracle: bit-exact I/J sets and bond errors, interpolant values to 1e-10."""
     import torch
     import t4a_amd
@@ -173,32 +173,39 @@ def test_cfg5_full_size_64_patches_chi128(rccl):
     pts = np.random.default_rng(5).integers(0, 2, size=(200, n))
     kept = {}
     order = []
-    sums = {}
 
-    def run_patch(p):
+    def make_patch(p):
         t = t4a_amd.TensorCI2([2] * n)
         t.set_function(bench.patch_spec(p, n_patches))
         t.add_global_pivots([[0] * n])
         t.set_max_sample_value(1.0)
-        t.optimize(opt, final_sweep1site=False)
-        t.fill_site_tensors()
+        return t
+
+    def keep(p, t):
         order.append(p)
         if p in sample:
             kept[p] = t
-        cores = [t.site_tensor(s) for s in range(n)]
-        sums[p] = [float(np.abs(np.asarray(c)).ravel(order="F").sum()) for c in cores]
-        return cores
 
-    farmed = parallel.run_patch_farm(rccl, torch, n_patches, run_patch, device="cuda")
+    # device-resident farm: eight patches at a time in lock-step (one XCD each, t4a_gpu_tci2_optimize_group), cores exported
+    # device-to-device into one padded tensor, ONE all_gather_into_tensor over RCCL for the payload and one for the shapes
+    cap = chi * 2 * chi
+    farm = parallel.PaddedPatchFarm(rccl, torch, n_patches, n, cap, "cuda")
+    farm.run(parallel.DevicePatchExporter(t4a_amd, torch, make_patch, opt, group=8, keep=keep))
+    torch.cuda.synchronize()
     assert order == list(range(n_patches))          # FIFO inside the rank
-    assert len(farmed) == n_patches and all(len(c) == n for c in farmed)
     # every patch reaches the cap (so its interpolant is a truncation, not exact: values are checked against the oracle below),
-    # arrives at ITS place after packing / all-gather / unpacking, and differs from its neighbour
+    # arrives at ITS place after export / all-gather, and differs from its neighbour
+    sums = {}
     for p in range(n_patches):
-        dims = [c.shape[2] for c in farmed[p][:-1]]
+        dims = [farm.core_dims(p, s)[2] for s in range(n - 1)]
         assert max(dims) == chi, f"patch {p}: link dims {dims}"
-        assert [float(np.abs(np.asarray(c)).ravel(order="F").sum()) for c in farmed[p]] == sums[p], f"patch {p} was re-assembled out of order"
+        sums[p] = [float(farm.core_device(p, s).abs().sum().item()) for s in (0, n // 2, n - 1)]
+    for p in range(n_patches):
         assert sums[p] != sums[(p + 1) % n_patches]
+    farmed = {p: farm.cores(p) for p in sample}
+    for p in sample:  # the gathered cores are the handle's cores, bit for bit
+        for s in range(n):
+            assert np.array_equal(farmed[p][s], kept[p].site_tensor(s)), f"patch {p} site {s} changed on its way through the farm"
     # the sample against the oracle
     for p in sample:
         o = ob.OracleTCI2([2] * n)
