@@ -1006,8 +1006,16 @@ void Engine::qr(const double* d_a, int M, int N, double* d_q, double* d_r)
     double* diag = d_ssig_.get();
     double* tau = diag + k;
     double* v0s = tau + k;
-    qr_factor_launch(W, M, N, diag, tau, v0s, stream_);
-    qr_form_launch(W, M, N, diag, tau, v0s, d_q, d_r, stream_);
+    // blocked Householder: explicit reflectors (M x k), triangular factors per panel, two QR_PANEL x max(N, k) scratch blocks
+    const size_t wcols = (size_t)(N > k ? N : k);
+    d_sv_.reserve((size_t)M * k);
+    d_svs_.reserve((size_t)qr_panels(k) * QR_PANEL * QR_PANEL + 2 * (size_t)QR_PANEL * wcols);
+    double* Vall = d_sv_.get();
+    double* Tall = d_svs_.get();
+    double* Wa = Tall + (size_t)qr_panels(k) * QR_PANEL * QR_PANEL;
+    double* Wb = Wa + (size_t)QR_PANEL * wcols;
+    qr_factor_launch(W, M, N, diag, tau, v0s, Vall, Tall, Wa, Wb, stream_);
+    qr_form_launch(W, M, N, diag, Vall, Tall, Wa, Wb, d_q, d_r, stream_);
     T4A_HIP(hipGetLastError());
 }
 

@@ -403,9 +403,14 @@ void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hip
 void svd_finalize_launch(const double* W, int m, const double* V, int n, double* sig_tmp, double* U, double* S,
                          double* Vs, int* d_dead, int* d_ndead, hipStream_t stream);
 void svd_complete_launch(double* U, int m, int n, int* d_dead, double* tmp_m, hipStream_t stream);
-// Householder QR in place: reflectors stay below the diagonal of A, R's diagonal goes to diag[]
-void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double* v0s, hipStream_t stream);
-void qr_form_launch(const double* A, int m, int n, const double* diag, const double* tau, const double* v0s, double* Q,
+// Blocked Householder QR in place (compact WY, panels of QR_PANEL columns): reflectors stay below the diagonal of A, R's diagonal
+// goes to diag[]; Vall (m x k) receives the explicit reflector matrix, Tall (qr_panels(k) blocks of QR_PANEL x QR_PANEL) the
+// triangular factors; W, W2: QR_PANEL x max(n, k) scratch each.
+constexpr int QR_PANEL = 32;
+inline int qr_panels(int k) { return (k + QR_PANEL - 1) / QR_PANEL; }
+void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double* v0s, double* Vall, double* Tall, double* W, double* W2,
+                      hipStream_t stream);
+void qr_form_launch(const double* A, int m, int n, const double* diag, const double* Vall, const double* Tall, double* W, double* W2, double* Q,
                     double* R, hipStream_t stream);
 
 } // namespace t4a

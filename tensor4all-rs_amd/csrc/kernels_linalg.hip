@@ -1,7 +1,7 @@
 // kernels_linalg.hip — thin SVD and thin QR for gfx950:
 //   svd_backend (tensor4all-tensorbackend/src/backend.rs:709-731)  -> one-sided Jacobi (Hestenes), round-robin
 //                                                                     pair ordering, one workgroup per column pair
-//   qr_backend  (tensor4all-tensorbackend/src/backend.rs:742-760)  -> Householder, one workgroup per trailing column
+//   qr_backend  (tensor4all-tensorbackend/src/backend.rs:742-760)  -> blocked Householder (compact WY): panel kernel + GEMMs
 // The reference forwards both to tenferro-rs (faer); values are tolerance-level there (reconstruction 1e-10,
 // backend/tests/mod.rs:58-110), so the contract here is: singular values non-increasing, U/V orthonormal,
 // U diag(S) Vt == A and Q R == A to rounding.
@@ -279,56 +279,72 @@ __global__ void __launch_bounds__(256) nonfinite_kernel(const double* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ QR
-// Step j: every workgroup rebuilds the reflector of column j (read-only) and applies it to its own
-// trailing column c = j + 1 + blockIdx.x; column j itself is left untouched (its R entry goes to diag[]).
-__global__ void __launch_bounds__(256) qr_step_kernel(double* A, int m, int n, int j, double* diag, double* tau,
-                                                      double* v0s)
-{
-    __shared__ double red[4];
-    const double* x = A + (size_t)m * j;
-    double nn = 0.0;
-    for (int i = j + threadIdx.x; i < m; i += blockDim.x) nn += x[i] * x[i];
-    nn = block_sum(nn, red);
-    const double nrm = sqrt(nn);
-    const double x0 = x[j];
-    const double alpha = x0 >= 0.0 ? -nrm : nrm;
-    const double v0 = x0 - alpha;
-    // v.v = v0^2 + (||x||^2 - x0^2); recompute the tail sum directly for accuracy
-    double tail = 0.0;
-    for (int i = j + 1 + threadIdx.x; i < m; i += blockDim.x) tail += x[i] * x[i];
-    tail = block_sum(tail, red);
-    const double vv = v0 * v0 + tail;
-    const double t = (nrm == 0.0) ? 0.0 : 2.0 / vv;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        diag[j] = (nrm == 0.0) ? 0.0 : alpha;
-        tau[j] = t;
-        v0s[j] = v0;
-    }
-    const int c = j + 1 + blockIdx.x;
-    if (c >= n || t == 0.0) return;
-    double* y = A + (size_t)m * c;
-    double dot = 0.0;
-    for (int i = j + threadIdx.x; i < m; i += blockDim.x) dot += (i == j ? v0 : x[i]) * y[i];
-    dot = block_sum(dot, red);
-    const double f = t * dot;
-    for (int i = j + threadIdx.x; i < m; i += blockDim.x) y[i] -= f * (i == j ? v0 : x[i]);
-}
+// Blocked Householder QR, round 3 (qr_backend, tensor4all-tensorbackend/src/backend.rs:742-760; callers
+// tensor4all-simplett/src/compression.rs:229-341).  Same reflectors as qr_step_kernel (alpha = -sign(x0) |x|, v = x - alpha e1
+// unnormalised, tau = 2 / v.v), but QR_NB columns at a time: one workgroup of 16 waves factors the panel — per column one
+// workgroup reduction for the norm, then every wave applies the reflector to "its" remaining panel columns and builds its
+// entries of the compact-WY factor T by wave shuffles (no LDS round per column pair) — and the trailing matrix gets
+// (I - V T V^T)^T in three GEMMs on the f64 matrix cores.  512 x 256: 8 panels x 4 launches instead of 512 launches.
+constexpr int QR_NB = 32;
+constexpr int QR_T = 1024;
 
-// Q <- H_j Q on columns c = j + blockIdx.x (columns left of j are untouched unit vectors)
-__global__ void __launch_bounds__(256) qr_applyq_kernel(const double* __restrict__ A, int m, int j, const double* tau,
-                                                        const double* v0s, double* Q)
+__global__ void __launch_bounds__(QR_T) qr_panel_kernel(double* A, int m, int j0, int w, double* diag, double* tau, double* v0s,
+                                                        double* Vall, double* Tp)
 {
-    __shared__ double red[4];
-    const double t = tau[j];
-    if (t == 0.0) return;
-    const double v0 = v0s[j];
-    const double* x = A + (size_t)m * j;
-    double* y = Q + (size_t)m * (j + blockIdx.x);
-    double dot = 0.0;
-    for (int i = j + threadIdx.x; i < m; i += blockDim.x) dot += (i == j ? v0 : x[i]) * y[i];
-    dot = block_sum(dot, red);
-    const double f = t * dot;
-    for (int i = j + threadIdx.x; i < m; i += blockDim.x) y[i] -= f * (i == j ? v0 : x[i]);
+    __shared__ double red[QR_T / 64];
+    __shared__ double zs[QR_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = QR_T / 64;
+    for (int e = tid; e < QR_NB * QR_NB; e += QR_T) Tp[e] = 0.0;
+    for (int jj = 0; jj < w; ++jj) {
+        const int j = j0 + jj;
+        double* x = A + (size_t)m * j;
+        double* V = Vall + (size_t)m * j;
+        // reflector of column j (rows j .. m-1)
+        double tail = 0.0;
+        for (int i = j + 1 + tid; i < m; i += QR_T) tail += x[i] * x[i];
+        tail = block_sum(tail, red);
+        const double x0 = x[j];
+        const double nrm = sqrt(x0 * x0 + tail);
+        const double alpha = x0 >= 0.0 ? -nrm : nrm;
+        const double v0 = x0 - alpha;
+        const double vv = v0 * v0 + tail;
+        const double t = (nrm == 0.0) ? 0.0 : 2.0 / vv;
+        if (tid == 0) {
+            diag[j] = (nrm == 0.0) ? 0.0 : alpha;
+            tau[j] = t;
+            v0s[j] = v0;
+        }
+        for (int i = tid; i < m; i += QR_T) V[i] = i < j ? 0.0 : (i == j ? v0 : x[i]);
+        __syncthreads(); // V column visible to the whole workgroup
+        if (t != 0.0) {
+            // H_j on the remaining columns of the panel: one wave per column
+            for (int c = j + 1 + wave; c < j0 + w; c += NWV) {
+                double* y = A + (size_t)m * c;
+                double dot = 0.0;
+                for (int i = j + lane; i < m; i += 64) dot += V[i] * y[i];
+                dot = wave_sum(dot);
+                const double f = t * dot;
+                for (int i = j + lane; i < m; i += 64) y[i] -= f * V[i];
+            }
+            // compact WY: T(0:jj, jj) = -tau T(0:jj, 0:jj) (V(:, 0:jj)^T v_jj), T(jj, jj) = tau
+            for (int q = wave; q < jj; q += NWV) {
+                const double* Vq = Vall + (size_t)m * (j0 + q);
+                double dot = 0.0;
+                for (int i = j + lane; i < m; i += 64) dot += Vq[i] * V[i];
+                dot = wave_sum(dot);
+                if (lane == 0) zs[q] = dot;
+            }
+        }
+        __syncthreads();
+        if (tid < jj && t != 0.0) {
+            double acc = 0.0;
+            for (int r = tid; r < jj; ++r) acc += Tp[tid + QR_NB * r] * zs[r];
+            Tp[tid + QR_NB * jj] = -t * acc;
+        }
+        if (tid == 0) Tp[jj + QR_NB * jj] = t;
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(256) qr_extract_r_kernel(const double* __restrict__ A, int m, int n, int k,
@@ -388,25 +404,79 @@ void svd_complete_launch(double* U, int m, int n, int* d_dead, double* tmp_m, hi
     hipLaunchKernelGGL(svd_complete_kernel, dim3(1), dim3(256), 0, stream, U, m, n, d_dead, tmp_m);
 }
 
-void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double* v0s, hipStream_t stream)
+// Blocked factorisation in place (reflectors below the diagonal as before, R above it, its diagonal in diag[]); Vall (m x k)
+// receives the explicit reflector matrix, Tall (ceil(k / QR_NB) blocks of QR_NB x QR_NB) the compact-WY factors, W / W2 are
+// QR_NB x max(n, k) scratch.
+void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double* v0s, double* Vall, double* Tall, double* W, double* W2,
+                      hipStream_t stream)
 {
     const int k = m < n ? m : n;
-    for (int j = 0; j < k; ++j) {
-        const int trailing = n - j - 1;
-        hipLaunchKernelGGL(qr_step_kernel, dim3(trailing > 0 ? trailing : 1), dim3(256), 0, stream, A, m, n, j, diag,
-                           tau, v0s);
+    for (int j0 = 0, pi = 0; j0 < k; j0 += QR_NB, ++pi) {
+        const int w = (k - j0) < QR_NB ? (k - j0) : QR_NB;
+        double* Tp = Tall + (size_t)pi * QR_NB * QR_NB;
+        hipLaunchKernelGGL(qr_panel_kernel, dim3(1), dim3(QR_T), 0, stream, A, m, j0, w, diag, tau, v0s, Vall, Tp);
+        const int n2 = n - j0 - w, mp = m - j0;
+        if (n2 <= 0) continue;
+        const double* Vp = Vall + j0 + (size_t)m * j0; // rows j0 .., columns j0 .. j0 + w - 1 (zero above)
+        double* A2 = A + j0 + (size_t)m * (j0 + w);
+        GemmDesc g;
+        g.batch = 1;
+        g.strideA = g.strideB = g.strideC = 0;
+        // W = Vp^T A2   (w x n2)
+        g.m = w; g.n = n2; g.k = mp;
+        g.A = Vp; g.lda = m; g.transA = 1;
+        g.B = A2; g.ldb = m; g.transB = 0;
+        g.C = W; g.ldc = QR_NB; g.alpha = 1.0; g.beta = 0.0;
+        gemm_launch(g, stream);
+        // W2 = T^T W
+        g.m = w; g.n = n2; g.k = w;
+        g.A = Tp; g.lda = QR_NB; g.transA = 1;
+        g.B = W; g.ldb = QR_NB; g.transB = 0;
+        g.C = W2; g.ldc = QR_NB; g.alpha = 1.0; g.beta = 0.0;
+        gemm_launch(g, stream);
+        // A2 -= Vp W2
+        g.m = mp; g.n = n2; g.k = w;
+        g.A = Vp; g.lda = m; g.transA = 0;
+        g.B = W2; g.ldb = QR_NB; g.transB = 0;
+        g.C = A2; g.ldc = m; g.alpha = -1.0; g.beta = 1.0;
+        gemm_launch(g, stream);
     }
 }
 
-void qr_form_launch(const double* A, int m, int n, const double* diag, const double* tau, const double* v0s, double* Q,
+void qr_form_launch(const double* A, int m, int n, const double* diag, const double* Vall, const double* Tall, double* W, double* W2, double* Q,
                     double* R, hipStream_t stream)
 {
     const int k = m < n ? m : n;
     if (k == 0) return;
     hipLaunchKernelGGL(qr_extract_r_kernel, dim3(n), dim3(256), 0, stream, A, m, n, k, diag, R);
     set_identity_launch(Q, m, k, m, stream);
-    for (int j = k - 1; j >= 0; --j)
-        hipLaunchKernelGGL(qr_applyq_kernel, dim3(k - j), dim3(256), 0, stream, A, m, j, tau, v0s, Q);
+    const int np = (k + QR_NB - 1) / QR_NB;
+    for (int pi = np - 1; pi >= 0; --pi) { // Q <- (I - V T V^T) Q, panels in reverse; columns left of j0 are still unit vectors
+        const int j0 = pi * QR_NB;
+        const int w = (k - j0) < QR_NB ? (k - j0) : QR_NB;
+        const int nq = k - j0, mp = m - j0;
+        const double* Vp = Vall + j0 + (size_t)m * j0;
+        const double* Tp = Tall + (size_t)pi * QR_NB * QR_NB;
+        double* Qs = Q + j0 + (size_t)m * j0;
+        GemmDesc g;
+        g.batch = 1;
+        g.strideA = g.strideB = g.strideC = 0;
+        g.m = w; g.n = nq; g.k = mp;
+        g.A = Vp; g.lda = m; g.transA = 1;
+        g.B = Qs; g.ldb = m; g.transB = 0;
+        g.C = W; g.ldc = QR_NB; g.alpha = 1.0; g.beta = 0.0;
+        gemm_launch(g, stream);
+        g.m = w; g.n = nq; g.k = w;
+        g.A = Tp; g.lda = QR_NB; g.transA = 0;
+        g.B = W; g.ldb = QR_NB; g.transB = 0;
+        g.C = W2; g.ldc = QR_NB; g.alpha = 1.0; g.beta = 0.0;
+        gemm_launch(g, stream);
+        g.m = mp; g.n = nq; g.k = w;
+        g.A = Vp; g.lda = m; g.transA = 0;
+        g.B = W2; g.ldb = QR_NB; g.transB = 0;
+        g.C = Qs; g.ldc = m; g.alpha = -1.0; g.beta = 1.0;
+        gemm_launch(g, stream);
+    }
 }
 
 } // namespace t4a

@@ -30,7 +30,7 @@ def main():
         avg_ns, calls = dur.get(name, (0.0, 0))
         flops = mops * 512.0
         tf = flops / avg_ns / 1e3 if avg_ns > 0 else None
-        short = name.split("(")[0].replace("void ", "").replace("t4a::", "").replace("(anonymous namespace)::", "")
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("t4a::", "").split("(")[0]
         rows[short] = {"kernel": name, "launches": calls, "avg_us": avg_ns / 1e3, "mfma_flops_per_launch": flops,
                        "mfma_instructions_per_launch": float(r.get("SQ_INSTS_MFMA_per_dispatch", 0.0) or 0.0),
                        "tflops": tf, "frac_of_peak": tf / PEAK if tf else None, "frac_of_sustained": tf / SUSTAINED if tf else None}
