@@ -692,10 +692,13 @@ t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out 
 /* Device-side bond chain (the host-free half-sweep of update_pivots, tensorci2.rs:1695-1725 + :1821-2007 for built-in
  * functors): out[0] half-sweeps enqueued as one chain, out[1] bond updates inside such chains, out[2] chains that fell back to
  * the per-bond path part-way (a launch gave up), out[3] half-sweeps that were not eligible (host callback, rook search, shapes
- * beyond the device-dimension kernels) and ran bond by bond. */
-t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out /* [4] */);
+ * beyond the device-dimension kernels) and ran bond by bond, out[4] chained half-sweeps that ran as part of a GROUP chain (one
+ * launch per kernel and bond for all handles of a t4a_gpu_tci2_optimize_group call; counted in out[0] as well). */
+t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out /* [5] */);
 /* optimize_with_finder (tensorci2.rs:1626-1802) on up to EIGHT handles at once, driven in lock-step by the calling thread: every
- * iteration enqueues the half-sweeps of all handles (each on its own XCD), then completes them one after the other.  This is the
+ * iteration enqueues the half-sweeps of all handles — as ONE chain of launches when they line up (same number of sites, built-in
+ * functors: every kernel serves all handles, handle i's rrLU runs on XCD i), otherwise one chain per handle — then completes them
+ * one after the other.  This is the
  * per-GPU form of the patch farm (BASELINE.json configs[4]: eight patches per GPU; adaptive_interpolation.rs:171-330 runs the
  * patches one after the other): results on every handle are exactly those of t4a_gpu_tci2_optimize. */
 t4a_gpu_status t4a_gpu_tci2_optimize_group(t4a_gpu_tci2* const* handles, size_t n_handles, const t4a_gpu_tci2_options* options,

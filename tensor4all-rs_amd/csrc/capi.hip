@@ -992,7 +992,7 @@ t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out)
     return guarded([&] {
         T4A_REQUIRE_PTR(h);
         T4A_REQUIRE_PTR(out);
-        for (int k = 0; k < 4; ++k) out[k] = h->impl.chain_stats[k];
+        for (int k = 0; k < 5; ++k) out[k] = h->impl.chain_stats[k];
     });
 }
 

@@ -696,6 +696,85 @@ void Engine::chain_begin(const std::vector<ChainRrluPlan>& plans, size_t reserve
 
 void Engine::chain_end() { chain_lock_.release(); }
 
+bool Engine::chain_group_plan(int kM, int kN, ChainRrluPlan* out)
+{
+    if (kM < 1 || kN < 1 || kM > 1024 || kN > 1024 || xcd_disabled()) return false;
+    ChainRrluPlan pl;
+    pl.kM = kM;
+    pl.kN = kN;
+    if (!rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32)) return false;
+    pl.kind = 2;
+    pl.code = 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
+    *out = pl;
+    return true;
+}
+
+void Engine::chain_group_reserve(const std::vector<ChainRrluPlan>& plans, size_t reserve_mailbox_words, hipStream_t order_stream)
+{
+    size_t need = 0;
+    for (const ChainRrluPlan& pl : plans)
+        if (pl.kind == 2) need = std::max(need, (rrlu_xcd_keys_bytes(pl.xcd) + rrlu_xcd_cols_bytes(pl.xcd, pl.kM)) / sizeof(unsigned long long));
+    if (need > 0 && (need > d_xkeys_.cap || !d_xticket_.get())) {
+        d_xkeys_.reserve(std::max(need, reserve_mailbox_words));
+        d_xticket_.reserve(4);
+        T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), order_stream));
+        T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), order_stream));
+        xcd_ticket_base_ = 0;
+        xcd_salt_ = 0;
+    }
+}
+
+unsigned Engine::chain_group_args(const ChainRrluPlan& pl, bool left, const double* d_a, const int* d_dims, size_t max_bond_dim, double rel_tol,
+                                  double abs_tol, const ChainBlock& blk, int slot, RrluXcdArgs* out, hipStream_t order_stream)
+{
+    double* d_dres = reinterpret_cast<double*>(blk.dev);
+    int* d_ires = reinterpret_cast<int*>(blk.dev + 16);
+    double* d_pivvals = reinterpret_cast<double*>(blk.dev + blk.off_piv);
+    int* d_rowperm = reinterpret_cast<int*>(blk.dev + blk.off_rp);
+    int* d_colperm = reinterpret_cast<int*>(blk.dev + blk.off_cp);
+    const int mn = pl.kM < pl.kN ? pl.kM : pl.kN;
+    const int max_steps = max_bond_dim < (size_t)mn ? (int)max_bond_dim : mn;
+    if (++xcd_salt_ > 65535u) { // the 16-bit launch salt wraps: stale granules could match again, clear the mailbox
+        T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), order_stream));
+        xcd_salt_ = 1;
+    }
+    RrluXcdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.A = d_a;
+    a.Aout = nullptr;
+    a.urows = nullptr;
+    a.M = pl.kM;
+    a.N = pl.kN;
+    a.max_steps = max_steps;
+    a.rel_tol = rel_tol;
+    a.abs_tol = abs_tol;
+    a.tie_row_major = left ? 0 : 1;
+    a.out_transposed = left ? 0 : 1;
+    a.W = pl.xcd.W;
+    a.xcc = slot;
+    a.ticket = d_xticket_.get();
+    a.ticket_base = xcd_ticket_base_;
+    xcd_ticket_base_ += (unsigned)(pl.xcd.grid / 8);
+    a.row_perm = left ? d_rowperm : d_colperm;
+    a.col_perm = left ? d_colperm : d_rowperm;
+    a.iresult = d_ires;
+    a.dresult = d_dres;
+    a.pivot_vals = d_pivvals;
+    a.keys = d_xkeys_.get();
+    a.salt = xcd_salt_;
+    static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.8;
+    a.spec_frac = xspec;
+    a.stamps = nullptr;
+    a.h_block = reinterpret_cast<unsigned long long*>(blk.host);
+    a.block_u64 = (int)(blk.bytes / 8);
+    a.dims = d_dims;
+    a.dims_swap = left ? 0 : 1;
+    a.rowmap = nullptr;
+    a.ts_u64 = (int)(blk.off_ts / 8);
+    *out = a;
+    return xcd_salt_;
+}
+
 unsigned Engine::chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_a, const int* d_rowmap, const FusedPi* fused, const int* d_dims,
                             size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec)
 {
@@ -708,46 +787,11 @@ unsigned Engine::chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_
     const int max_steps = max_bond_dim < (size_t)mn ? (int)max_bond_dim : mn;
     unsigned token = 0u;
     if (pl.kind == 2) {
-        if (++xcd_salt_ > 65535u) { // the 16-bit launch salt wraps: stale granules could match again, clear the mailbox
-            T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), stream_));
-            xcd_salt_ = 1;
-        }
         RrluXcdArgs a;
-        a.A = d_a;
-        a.Aout = nullptr;
-        a.urows = nullptr;
-        a.M = pl.kM;
-        a.N = pl.kN;
-        a.max_steps = max_steps;
-        a.rel_tol = rel_tol;
-        a.abs_tol = abs_tol;
-        a.tie_row_major = left ? 0 : 1;
-        a.out_transposed = left ? 0 : 1;
-        a.W = pl.xcd.W;
-        a.xcc = xcc_;
-        a.ticket = d_xticket_.get();
-        a.ticket_base = xcd_ticket_base_;
-        xcd_ticket_base_ += (unsigned)(pl.xcd.grid / 8);
-        a.row_perm = left ? d_rowperm : d_colperm;
-        a.col_perm = left ? d_colperm : d_rowperm;
-        a.iresult = d_ires;
-        a.dresult = d_dres;
-        a.pivot_vals = d_pivvals;
-        a.keys = d_xkeys_.get();
-        a.salt = xcd_salt_;
-        static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.8;
-        a.spec_frac = xspec;
-        a.stamps = nullptr;
-        a.h_block = reinterpret_cast<unsigned long long*>(blk.host);
-        a.block_u64 = (int)(blk.bytes / 8);
-        a.dims = d_dims;
-        a.dims_swap = left ? 0 : 1;
+        token = chain_group_args(pl, left, d_a, d_dims, max_bond_dim, rel_tol, abs_tol, blk, xcc_, &a, stream_);
         a.rowmap = d_rowmap;
         if (spec) a.spec = *spec;
-        else std::memset(&a.spec, 0, sizeof(a.spec));
-        a.ts_u64 = (int)(blk.off_ts / 8);
         rrlu_xcd_launch(pl.xcd, a, stream_);
-        token = xcd_salt_;
     } else {
         if (++done_token_ == 0u) ++done_token_;
         RrluRegArgs a;

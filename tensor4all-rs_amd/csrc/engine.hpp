@@ -133,6 +133,17 @@ public:
     unsigned chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_a, const int* d_rowmap, const FusedPi* fused, const int* d_dims,
                         size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec);
     void chain_end();
+    // Group chain (tci2_chain.hip): several handles advance in lock step, one rrLU launch per bond for all of them, handle i on
+    // XCD `slot` i.  chain_group_plan: the single-XCD plan every member uses for a bond (made for the largest upper bounds in
+    // the group; no single-workgroup plans: a small bond costs a group launch, i.e. an eighth of it per handle).
+    // chain_group_reserve: this member's mailbox for the plans (no lock: the group's leader reserves the chip with
+    // chain_group_lock / chain_end).  chain_group_args: the argument block of this member for one bond (advances the member's
+    // salt and ticket base exactly like a launch of its own); the caller launches the assembled blocks with rrlu_xcd_group_launch.
+    static bool chain_group_plan(int kM, int kN, ChainRrluPlan* out);
+    void chain_group_reserve(const std::vector<ChainRrluPlan>& plans, size_t reserve_mailbox_words, hipStream_t order_stream);
+    void chain_group_lock() { chain_lock_.acquire(-1); }
+    unsigned chain_group_args(const ChainRrluPlan& pl, bool left, const double* d_a, const int* d_dims, size_t max_bond_dim, double rel_tol,
+                              double abs_tol, const ChainBlock& blk, int slot, RrluXcdArgs* out, hipStream_t order_stream);
     int xcc() const { return xcc_; }
     void set_xcc(int xcc) { xcc_ = xcc & 7; } // (optimize_group: handle i of a group works on XCD i)
 

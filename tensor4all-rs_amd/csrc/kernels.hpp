@@ -226,6 +226,13 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size = false, i
 size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan);
 size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int M);
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
+// Eight factorisations in one launch, one per XCD (slot x is run by the workgroups that land on XCD x; a slot with xcc = -1 is
+// empty).  All slots share the plan (made for the largest upper-bound shape among them) and the tie order; every slot brings
+// its own mailbox, ticket counter and result block.  kernels_rrlu_xcd_group.hip.
+struct RrluXcdGroupArgs {
+    RrluXcdArgs p[8];
+};
+void rrlu_xcd_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // K1: candidate-matrix build (replaces the Π loop, tensor4all-tensorci/src/tensorci2.rs:1859-1893)
@@ -302,6 +309,23 @@ void chain_indep_launch(const ChainCommon& c, int n_bonds, hipStream_t stream);
 void chain_prep_launch(const ChainCommon& c, const ChainPrepArgs& a, hipStream_t stream);
 // n_dep_ub / n_ind_ub: upper bounds for the launch grid (the kernel reads the real sizes on the device)
 void chain_pi_launch(const ChainCommon& c, const FnDevice& fn, int b, int n_dep_ub, int n_ind_ub, double* out, hipStream_t stream);
+
+// Group chain: up to CHAIN_GROUP_MAX handles (independent interpolations: patches of one farm) advance through their
+// half-sweeps in lock step — ONE launch per kernel and bond for all of them.  The per-handle constants of a half-sweep sit in
+// a device table (one slot per handle), the per-bond arguments travel as small arrays in the kernel arguments; the rrLU launch
+// gives every handle its own XCD (rrlu_xcd_group_launch).  Bond indices and the sweep direction are common to the group.
+constexpr int CHAIN_GROUP_MAX = 8;
+struct ChainGroupSlot {
+    ChainCommon c;
+    FnDevice fn;
+    double* pi;               // candidate matrix buffer of the handle (chain_pi_group_launch writes it)
+};
+struct ChainPrepGroupArgs {
+    ChainPrepArgs a[CHAIN_GROUP_MAX];
+};
+void chain_indep_group_launch(const ChainGroupSlot* d_slots, int n_handles, int n_bonds, hipStream_t stream);
+void chain_prep_group_launch(const ChainGroupSlot* d_slots, const ChainPrepGroupArgs& a, int n_handles, hipStream_t stream);
+void chain_pi_group_launch(const ChainGroupSlot* d_slots, int n_handles, int b, int n_dep_ub, int n_ind_ub, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // Dense helpers

@@ -39,6 +39,15 @@ namespace t4a {
 
 namespace {
 
+__device__ __forceinline__ const char* chain_kernarg_base()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;
+#endif
+}
+
 constexpr int CHAIN_T = 1024;       // threads of a list-building workgroup
 constexpr int CHAIN_HASH = 4096;    // LDS hash slots (tables hold at most CHAIN_MAX_SET = 1024 entries per site)
 
@@ -144,7 +153,7 @@ __device__ int build_side(const uint64_t* __restrict__ pcode, const uint64_t* __
 }
 
 // the independent side of every bond of the half-sweep: blockIdx.x = bond
-__global__ void __launch_bounds__(CHAIN_T) chain_indep_kernel(ChainCommon c)
+__device__ __forceinline__ void chain_indep_body(const ChainCommon& c)
 {
     __shared__ unsigned long long hkeys[CHAIN_HASH];
     __shared__ int wave_sums[CHAIN_T / 64];
@@ -179,8 +188,14 @@ __global__ void __launch_bounds__(CHAIN_T) chain_indep_kernel(ChainCommon c)
     for (size_t i = gtid; i < c.zero_a_words; i += gsz) c.zero_a[i] = 0ull;
     for (size_t i = gtid; i < c.zero_b_words; i += gsz) c.zero_b[i] = 0ull;
 }
+__global__ void __launch_bounds__(CHAIN_T) chain_indep_kernel(ChainCommon c) { chain_indep_body(c); }
+// group chain: blockIdx.y = handle
+__global__ void __launch_bounds__(CHAIN_T) chain_indep_group_kernel(const ChainGroupSlot* __restrict__ slots)
+{
+    chain_indep_body(slots[blockIdx.y].c);
+}
 
-__global__ void __launch_bounds__(CHAIN_T) chain_prep_kernel(ChainCommon c, ChainPrepArgs p)
+__device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const ChainPrepArgs& p)
 {
     __shared__ unsigned long long hkeys[CHAIN_HASH];
     __shared__ int wave_sums[CHAIN_T / 64];
@@ -291,9 +306,19 @@ __global__ void __launch_bounds__(CHAIN_T) chain_prep_kernel(ChainCommon c, Chai
     }
 }
 
+__global__ void __launch_bounds__(CHAIN_T) chain_prep_kernel(ChainCommon c, ChainPrepArgs p) { chain_prep_body(c, p); }
+// group chain: blockIdx.x = handle (a handle that has nothing to do at this bond carries prev_b < 0 and do_build == 0)
+__global__ void __launch_bounds__(CHAIN_T) chain_prep_group_kernel(const ChainGroupSlot* __restrict__ slots, ChainPrepGroupArgs g)
+{
+    // (dynamic index into a by-value argument: read through the kernel-argument segment, not through a private copy)
+    const ChainPrepArgs* pa = reinterpret_cast<const ChainPrepArgs*>(chain_kernarg_base() + sizeof(const ChainGroupSlot*)) + blockIdx.x;
+    (void)g;
+    chain_prep_body(slots[blockIdx.x].c, *pa);
+}
+
 // Candidate matrix of a bond nobody speculated on (first bond of a chain, or the previous launch was a single workgroup):
 // out[j * nd + i] = f(dependent i, independent j)
-__global__ void __launch_bounds__(256) chain_pi_kernel(ChainCommon c, FnDevice fn, int b, double* __restrict__ out)
+__device__ __forceinline__ void chain_pi_body(const ChainCommon& c, const FnDevice& fn, int b, double* __restrict__ out)
 {
     const int* dm = c.dims + (size_t)b * 4;
     if (dm[2] != 0) return;
@@ -313,6 +338,13 @@ __global__ void __launch_bounds__(256) chain_pi_kernel(ChainCommon c, FnDevice f
         }
     }
 }
+__global__ void __launch_bounds__(256) chain_pi_kernel(ChainCommon c, FnDevice fn, int b, double* __restrict__ out) { chain_pi_body(c, fn, b, out); }
+// group chain: blockIdx.z = handle
+__global__ void __launch_bounds__(256) chain_pi_group_kernel(const ChainGroupSlot* __restrict__ slots, int b)
+{
+    const ChainGroupSlot& s = slots[blockIdx.z];
+    chain_pi_body(s.c, s.fn, b, s.pi);
+}
 
 } // namespace
 
@@ -331,6 +363,23 @@ void chain_pi_launch(const ChainCommon& c, const FnDevice& fn, int b, int n_dep_
     if (n_dep_ub <= 0 || n_ind_ub <= 0) return;
     const int gy = n_ind_ub < 2048 ? n_ind_ub : 2048;
     hipLaunchKernelGGL(chain_pi_kernel, dim3((n_dep_ub + 255) / 256, gy), dim3(256), 0, stream, c, fn, b, out);
+}
+
+void chain_indep_group_launch(const ChainGroupSlot* d_slots, int n_handles, int n_bonds, hipStream_t stream)
+{
+    hipLaunchKernelGGL(chain_indep_group_kernel, dim3(n_bonds, n_handles), dim3(CHAIN_T), 0, stream, d_slots);
+}
+
+void chain_prep_group_launch(const ChainGroupSlot* d_slots, const ChainPrepGroupArgs& a, int n_handles, hipStream_t stream)
+{
+    hipLaunchKernelGGL(chain_prep_group_kernel, dim3(n_handles), dim3(CHAIN_T), 0, stream, d_slots, a);
+}
+
+void chain_pi_group_launch(const ChainGroupSlot* d_slots, int n_handles, int b, int n_dep_ub, int n_ind_ub, hipStream_t stream)
+{
+    if (n_dep_ub <= 0 || n_ind_ub <= 0 || n_handles <= 0) return;
+    const int gy = n_ind_ub < 2048 ? n_ind_ub : 2048;
+    hipLaunchKernelGGL(chain_pi_group_kernel, dim3((n_dep_ub + 255) / 256, gy, n_handles), dim3(256), 0, stream, d_slots, b);
 }
 
 } // namespace t4a

@@ -51,6 +51,10 @@ constexpr int XT = 64 * XWAVES;       // threads per workgroup
 constexpr int XCD_MAX_CPT = 4;       // (the key carries the column slot in two bits)
 constexpr int XCD_MAX_VALUES = XWAVES == 4 ? 80 : 40; // matrix entries per thread: beyond this the register file of a 512-thread workgroup spills
 constexpr int BUF_SC1 = 16;  // aux bits of the raw buffer loads: sc1 (L1 bypass, served by the XCD's L2)
+// the RE-loads of the polling loops carry the compiler-only "volatile" bit (bit 31, stripped when the instruction is selected):
+// a raw buffer load is an ordinary memory read to the optimiser, and a loop that only re-reads the same address until a tag
+// matches is a loop-invariant load to it — hoisted, the loop spins on its first answer until the bounded poll gives up
+constexpr int BUF_SC1_RETRY = (int)(16u | 0x80000000u);
 
 __device__ __forceinline__ unsigned xcc_id()
 {
@@ -298,7 +302,7 @@ __device__ __noinline__ void xcd_spec_work(const XcdSpecArgs* spp, int M, int* l
 }
 
 template <int RPT, int CPT, bool ROWMAJOR>
-__global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd_kernel(RrluXcdArgs p)
+__device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = XcdLds<RPT>;
@@ -627,7 +631,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                    kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1_RETRY);
             }
             if (stamp_on) lds_stamps[5] += spins;
             // the full keys: fetched now (every agent stored its own before it could have seen this step's early keys complete...
@@ -677,7 +681,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                                             giveup = true;
                                             break;
                                         }
-                                        kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                                        kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1_RETRY);
                                     }
                                     wv = mk_f64(kx, ky);
                                     wm_ = kz;
@@ -702,7 +706,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                            kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1_RETRY);
                     }
                     double csc = -1.0, cv = 0.0;
                     unsigned cpk = XNOPOS, cmeta = 0u;
@@ -874,7 +878,7 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
                 }
 #pragma unroll
                 for (int j = 0; j < XR; ++j)
-                    if (wave + XWAVES * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * XT * 16, 0, BUF_SC1);
+                    if (wave + XWAVES * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * XT * 16, 0, BUF_SC1_RETRY);
             }
             XSTAMP(12);
             // x / p through the shared refined reciprocal (bitwise the IEEE quotient, see refined_rcp); zeros keep the sign
@@ -1034,6 +1038,12 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
     }
 }
 
+#ifndef T4A_XCD_GROUP_TU
+template <int RPT, int CPT, bool ROWMAJOR>
+__global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd_kernel(RrluXcdArgs p)
+{
+    rrlu_xcd_body<RPT, CPT, ROWMAJOR>(p);
+}
 template <int RPT, int CPT, bool ROWMAJOR> void xcd_launch_tie(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
 {
     static std::once_flag attr_once; // (launches come from several host threads)
@@ -1079,8 +1089,47 @@ int xcd_norm_cpt(int c)
     return c <= XCD_MAX_CPT ? (c < 1 ? 1 : c) : -1;
 }
 
+#else
+// Group launch: eight factorisations, one per XCD.  Every workgroup takes the argument block of the XCD it landed on (read
+// through the kernel-argument segment: scalar loads like those of the by-value argument, no private copy of the array); an
+// empty slot carries xcc = -1, its workgroups return at once.
+template <int RPT, int CPT, bool ROWMAJOR>
+__global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd_group_kernel(RrluXcdGroupArgs g)
+{
+    (void)g;
+    const unsigned x = (unsigned)__builtin_amdgcn_readfirstlane((int)xcc_id()) & 7u;
+    rrlu_xcd_body<RPT, CPT, ROWMAJOR>(*reinterpret_cast<const RrluXcdArgs*>(kernarg_base() + (size_t)x * sizeof(RrluXcdArgs)));
+}
+
+template <int RPT, int CPT, bool ROWMAJOR> void xcd_group_launch_tie(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, hipStream_t stream)
+{
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_xcd_group_kernel<RPT, CPT, ROWMAJOR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL((rrlu_xcd_group_kernel<RPT, CPT, ROWMAJOR>), dim3(plan.grid), dim3(XT), plan.lds_bytes, stream, a);
+}
+template <int RPT, int CPT> void xcd_group_launch_rc(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, bool row_major, hipStream_t stream)
+{
+    if (row_major) xcd_group_launch_tie<RPT, CPT, true>(plan, a, stream);
+    else xcd_group_launch_tie<RPT, CPT, false>(plan, a, stream);
+}
+template <int RPT> void xcd_group_launch_r(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, bool row_major, hipStream_t stream)
+{
+    switch (plan.CPT) {
+    case 1: xcd_group_launch_rc<RPT, 1>(plan, a, row_major, stream); break;
+    case 2: xcd_group_launch_rc<RPT, 2>(plan, a, row_major, stream); break;
+    case 3: if constexpr (RPT * 3 <= XCD_MAX_VALUES) xcd_group_launch_rc<RPT, 3>(plan, a, row_major, stream); break;
+    default: if constexpr (RPT * 4 <= XCD_MAX_VALUES) xcd_group_launch_rc<RPT, 4>(plan, a, row_major, stream); break;
+    }
+}
+
+#endif
+
 } // namespace
 
+#ifndef T4A_XCD_GROUP_TU
 bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size, int max_w)
 {
     if (max_w < 1 || max_w > 32) max_w = 32;
@@ -1155,5 +1204,21 @@ void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t 
 #endif
     }
 }
+#else
+// (this half of the file is compiled as its own translation unit: kernels_rrlu_xcd_group.hip)
+void rrlu_xcd_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, bool tie_row_major, hipStream_t stream)
+{
+    switch (plan.RPT) {
+    case 1: xcd_group_launch_r<1>(plan, a, tie_row_major, stream); break;
+    case 2: xcd_group_launch_r<2>(plan, a, tie_row_major, stream); break;
+    case 3: xcd_group_launch_r<3>(plan, a, tie_row_major, stream); break;
+    case 4: xcd_group_launch_r<4>(plan, a, tie_row_major, stream); break;
+    case 6: xcd_group_launch_r<6>(plan, a, tie_row_major, stream); break;
+    case 8: xcd_group_launch_r<8>(plan, a, tie_row_major, stream); break;
+    case 12: xcd_group_launch_r<12>(plan, a, tie_row_major, stream); break;
+    default: xcd_group_launch_r<16>(plan, a, tie_row_major, stream); break;
+    }
+}
+#endif
 
 } // namespace t4a

@@ -166,6 +166,7 @@ Tci2::~Tci2()
 {
     for (hipEvent_t e : chain_.t0) (void)hipEventDestroy(e);
     for (hipEvent_t e : chain_.t1) (void)hipEventDestroy(e);
+    if (chain_.group_ev) (void)hipEventDestroy(chain_.group_ev);
     if (export_event_) (void)hipEventDestroy(export_event_);
     if (import_event_) (void)hipEventDestroy(import_event_);
     if (import_stream_) pool::stream_put(import_stream_, 2); // (synchronises it)
@@ -1635,7 +1636,7 @@ void Tci2::opt_begin(OptRun& r)
 
 }
 
-bool Tci2::opt_iter_start(OptRun& r)
+bool Tci2::opt_iter_start(OptRun& r, bool defer_launch)
 {
     const TCI2Options& options = r.options;
     if (r.done || r.iter >= options.max_iter) return false;
@@ -1699,7 +1700,7 @@ bool Tci2::opt_iter_start(OptRun& r)
         r.fill_ahead = fill_ahead;
         r.flush_at_fwd = flush_at_fwd;
         r.flush_at_bwd = flush_at_bwd;
-        r.chained = chain_enqueue(is_forward, options, ext_idx, true);
+        r.chained = chain_enqueue(is_forward, options, ext_idx, true, !defer_launch);
     return true;
 }
 
@@ -1852,10 +1853,20 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
     }
     for (;;) {
         std::vector<size_t> active;
+        std::vector<Tci2*> chained;
         for (size_t i = 0; i < hs.size(); ++i)
-            if (hs[i]->opt_iter_start(runs[i])) active.push_back(i);
+            if (hs[i]->opt_iter_start(runs[i], true)) {
+                active.push_back(i);
+                if (runs[i].chained) chained.push_back(hs[i]);
+            }
         if (active.empty()) break;
-        for (size_t i : active) hs[i]->opt_iter_finish(runs[i]);
+        chain_group_launch(chained); // one chain of launches for all of them (or one each when they do not line up)
+        // the chained handles first, the group's leader first of all: it holds the chip until its chain has completed, and a
+        // handle on the per-bond path needs an XCD of its own
+        for (size_t i : active)
+            if (runs[i].chained) hs[i]->opt_iter_finish(runs[i]);
+        for (size_t i : active)
+            if (!runs[i].chained) hs[i]->opt_iter_finish(runs[i]);
     }
     for (size_t i = 0; i < hs.size(); ++i) hs[i]->opt_end(runs[i]);
 }

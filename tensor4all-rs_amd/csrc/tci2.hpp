@@ -95,7 +95,7 @@ public:
         size_t flush_at_fwd = 0, flush_at_bwd = 0;
     };
     void opt_begin(OptRun& r);
-    bool opt_iter_start(OptRun& r);
+    bool opt_iter_start(OptRun& r, bool defer_launch = false); // defer_launch: the chain is prepared, not launched (optimize_group)
     void opt_iter_finish(OptRun& r);
     void opt_end(OptRun& r);
     void sweep2site(bool forward, const TCI2Options& options);
@@ -118,7 +118,7 @@ public:
     }
     // statistics of the device-side bond chain: [0] half-sweeps run as a chain [1] bonds run in chains [2] chains that fell back
     // to the per-bond path part-way [3] half-sweeps that were not eligible
-    std::array<uint64_t, 4> chain_stats{{0, 0, 0, 0}};
+    std::array<uint64_t, 5> chain_stats{{0, 0, 0, 0, 0}};
     bool chain_enabled = true;  // false: every half-sweep runs bond by bond (A/B measurements, tests)
     bool chain_verify = false;  // true: after every chain the device tables are read back and compared with the host's sets
     bool chain_event_timing = false; // profiling: rrLU launches of a chain are timed with HIP events around each launch instead of
@@ -280,6 +280,19 @@ private:
         ChainBlock proto;
         bool timed = false, timed_events = false;
         std::vector<hipEvent_t> t0, t1; // per bond: around the rrLU launch (chain_event_timing)
+        // a half-sweep that has been prepared (plans, buffers, tables, kernel constants) and waits for its launch: on its own
+        // (chain_launch) or together with the chains of other handles (chain_group_launch)
+        bool prepared = false;
+        ChainCommon common;
+        std::vector<size_t> dep_ub, ind_ub;
+        bool use_extras = false;
+        size_t ind_cap = 0, cap_side = 0;
+        double tol = 0.0;
+        hipStream_t wait_stream = nullptr; // the stream whose completion chain_finish waits for (a group chain: the leader's)
+        int group_role = 0;                // 0: a chain of its own, 1: leader of a group chain (holds the chip), 2: member
+        hipEvent_t group_ev = nullptr;     // orders the group's stream behind this handle's own
+        DevBuf<ChainGroupSlot> gslots;     // leader: the per-handle constants of the group's half-sweep
+        PinBuf<ChainGroupSlot> hgslots;
     } chain_;
     bool chain_usable(const TCI2Options& options) const;
     ChainTab chain_tab(int family) const;    // 0: I, 1: J, 2 + 2 s: snapshot s of I, 3 + 2 s: snapshot s of J
@@ -292,7 +305,12 @@ private:
     void hist_digits(HistEntry& e);
     // enqueues the whole half-sweep (false: not eligible, nothing was done); chain_finish() waits for it and takes over the
     // results (falling back to update_pivots for the bonds after one that did not complete)
-    bool chain_enqueue(bool forward, const TCI2Options& options, long ext_idx, bool in_optimize);
+    // launch = false: everything but the launches (chain_.prepared); chain_launch() or chain_group_launch() must follow.
+    bool chain_enqueue(bool forward, const TCI2Options& options, long ext_idx, bool in_optimize, bool launch = true);
+    void chain_launch();
+    // the prepared half-sweeps of several handles as ONE chain of launches (every kernel serves all of them, every handle's
+    // rrLU on its own XCD); falls back to chain_launch() per handle when the chains do not line up
+    static void chain_group_launch(const std::vector<Tci2*>& handles);
     void chain_finish(const TCI2Options& options);
     void prepare_fill_site_from_mirror(size_t b);
     bool fill_no_main_sync_ = false; // the next fill does not depend on work of the main stream (bond chain: no cores written there)

@@ -243,9 +243,9 @@ void Tci2::prepare_fill_site_from_mirror(size_t b)
     f.valid = true;
 }
 
-bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx, bool in_optimize)
+bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx, bool in_optimize, bool launch)
 {
-    if (chain_.inflight) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: a chain is already in flight");
+    if (chain_.inflight || chain_.prepared) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: a chain is already in flight");
     if (!chain_usable(options)) {
         ++chain_stats[3];
         return false;
@@ -296,6 +296,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
         ind_cap = std::max(ind_cap, ind_ub[b]);
         steps_cap = std::max(steps_cap, rub);
         const bool fused = plans[b].kind == 1 && plans[b].fused;
+        if (!launch) pi_cap = std::max(pi_cap, dep_ub[b] * ind_ub[b]); // (a group chain evaluates every candidate matrix directly)
         if (!fused) {
             pi_cap = std::max(pi_cap, dep_ub[b] * ind_ub[b]); // (evaluated directly when the previous launch could not speculate)
             if (k > 0 && plans[order[k - 1]].kind == 2) {
@@ -396,19 +397,13 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
         chain_.snap_serial[snap] = chain_.hist_serial;
     }
 
-    // ---- 4. enqueue the whole half-sweep ----
+    // ---- 4. the kernel constants of the half-sweep ----
     // (result blocks, dims and tile counters are cleared and the snapshot is taken by chain_indep_kernel: one launch instead
     // of five memset / memcpy operations in front of the chain)
     for (size_t b = 0; b < nb; ++b) {
         std::memset(chain_.hblocks.get() + b * proto.bytes, 0, 32);
         std::memset(chain_.hdims.get() + b * 4, 0xFF, 4 * sizeof(int)); // (-1: not written yet)
     }
-    auto block_of = [&](size_t b) {
-        ChainBlock k = proto;
-        k.dev = chain_.blocks.get() + b * proto.bytes;
-        k.host = chain_.hblocks.get() + b * proto.bytes;
-        return k;
-    };
     ChainCommon c;
     std::memset(&c, 0, sizeof(c));
     c.I = chain_tab(0);
@@ -446,6 +441,51 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     c.zero_b = reinterpret_cast<uint64_t*>(chain_.dims.get());
     c.zero_b_words = (nb * 5 * sizeof(int) + 7) / 8;
 
+    chain_.common = c;
+    chain_.prepared = true;
+    chain_.forward = forward;
+    chain_.in_optimize = in_optimize;
+    chain_.ext_idx = ext_idx;
+    chain_.chi = chi;
+    chain_.tol = options.tolerance;
+    chain_.order = std::move(order);
+    chain_.plans = std::move(plans);
+    chain_.dep_ub = std::move(dep_ub);
+    chain_.ind_ub = std::move(ind_ub);
+    chain_.use_extras = use_extras;
+    chain_.ind_cap = ind_cap;
+    chain_.cap_side = cap_side;
+    chain_.proto = proto;
+    chain_.timed = timed;
+    chain_.timed_events = timed_events;
+    chain_.tokens.assign(nb, 0u);
+    if (launch) chain_launch();
+    return true;
+}
+
+// the launches of a prepared half-sweep on this handle's own stream and XCD
+void Tci2::chain_launch()
+{
+    if (!chain_.prepared) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: nothing prepared to launch");
+    chain_.prepared = false;
+    const size_t nb = n_ - 1;
+    const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
+    const bool forward = chain_.forward, use_extras = chain_.use_extras, timed_events = chain_.timed_events;
+    const size_t chi = chain_.chi, ind_cap = chain_.ind_cap, cap_side = chain_.cap_side;
+    const ChainCommon& c = chain_.common;
+    const ChainBlock& proto = chain_.proto;
+    const std::vector<size_t>& order = chain_.order;
+    const std::vector<ChainRrluPlan>& plans = chain_.plans;
+    const std::vector<size_t>& dep_ub = chain_.dep_ub;
+    const std::vector<size_t>& ind_ub = chain_.ind_ub;
+    std::vector<unsigned>& tokens = chain_.tokens;
+    hipStream_t st = eng.stream();
+    auto block_of = [&](size_t b) {
+        ChainBlock k = proto;
+        k.dev = chain_.blocks.get() + b * proto.bytes;
+        k.host = chain_.hblocks.get() + b * proto.bytes;
+        return k;
+    };
     {
         size_t reserve_words = 0; // the largest shape this handle can reach: the mailbox is sized once
         ChainRrluPlan cp;
@@ -453,7 +493,6 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
             reserve_words = (rrlu_xcd_keys_bytes(cp.xcd) + rrlu_xcd_cols_bytes(cp.xcd, (int)cap_side)) / sizeof(unsigned long long);
         eng.chain_begin(plans, reserve_words);
     }
-    std::vector<unsigned> tokens(nb, 0u);
     bool counted = false;
     try {
         chain_indep_launch(c, (int)nb, st);
@@ -517,7 +556,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
             fp.host_resident = false;
             const double* A = fused ? nullptr : (spec_here ? chain_.spec[k & 1].get() : chain_.pi.get());
             if (timed_events) T4A_HIP(hipEventRecord(chain_.t0[b], st));
-            tokens[b] = eng.chain_rrlu(pl, forward, A, spec_here ? c.rowmap : nullptr, fused ? &fp : nullptr, c.dims + b * 4, chi, options.tolerance,
+            tokens[b] = eng.chain_rrlu(pl, forward, A, spec_here ? c.rowmap : nullptr, fused ? &fp : nullptr, c.dims + b * 4, chi, chain_.tol,
                                        0.0, blk, spec_pending ? &sp : nullptr);
             if (timed_events) T4A_HIP(hipEventRecord(chain_.t1[b], st));
         }
@@ -543,30 +582,158 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
         throw;
     }
     chain_.inflight = true;
-    chain_.forward = forward;
-    chain_.in_optimize = in_optimize;
-    chain_.ext_idx = ext_idx;
-    chain_.chi = chi;
-    chain_.order = std::move(order);
-    chain_.plans = std::move(plans);
-    chain_.tokens = std::move(tokens);
-    chain_.proto = proto;
-    chain_.timed = timed;
-    chain_.timed_events = timed_events;
-    return true;
+    chain_.wait_stream = st;
+    chain_.group_role = 0;
+}
+
+// The prepared half-sweeps of several handles as one chain of launches.  Per bond: one preparation kernel (a workgroup per
+// handle), one candidate-matrix kernel, one rrLU launch in which the workgroups of XCD i factorise handle i's matrix — three
+// launches for the whole group instead of two to three per handle, and the host enqueues a group's half-sweep in the time
+// it took for one handle.  No speculation (there are no idle XCDs to do it) and no single-workgroup plans (a small bond costs
+// a group one launch, i.e. an eighth of it per handle).  The handles' results are those of their own chains: same lists, same
+// kernels, same order.
+void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
+{
+    static const bool no_group = std::getenv("T4A_CHAIN_NO_GROUP") != nullptr;
+    const size_t nh = hs.size();
+    if (nh == 0) return;
+    bool ok = nh >= 2 && nh <= (size_t)CHAIN_GROUP_MAX && !no_group;
+    Tci2* lead = hs[0];
+    for (Tci2* h : hs) {
+        if (!h->chain_.prepared) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: a handle of the group has nothing prepared");
+        ok = ok && h->n_ == lead->n_ && h->chain_.forward == lead->chain_.forward && h->chain_.chi == lead->chain_.chi &&
+             h->chain_.tol == lead->chain_.tol && !h->chain_.timed_events;
+    }
+    const size_t nb = lead->n_ - 1;
+    const bool forward = lead->chain_.forward;
+    std::vector<ChainRrluPlan> gplans(nb);
+    size_t side_ub = 0;
+    if (ok) {
+        for (size_t b = 0; b < nb && ok; ++b) {
+            size_t dm = 1, im = 1;
+            for (Tci2* h : hs) {
+                dm = std::max(dm, h->chain_.dep_ub[b]);
+                im = std::max(im, h->chain_.ind_ub[b]);
+            }
+            ok = Engine::chain_group_plan((int)dm, (int)im, &gplans[b]);
+            gplans[b].code += forward ? 0 : 4;
+        }
+        for (Tci2* h : hs) side_ub = std::max(side_ub, h->chain_.cap_side);
+    }
+    if (!ok) {
+        for (Tci2* h : hs) h->chain_launch();
+        return;
+    }
+    hipStream_t st = lead->eng.stream();
+    size_t reserve_words = 0;
+    {
+        ChainRrluPlan cp;
+        if (side_ub && Engine::chain_group_plan((int)side_ub, (int)side_ub, &cp))
+            reserve_words = (rrlu_xcd_keys_bytes(cp.xcd) + rrlu_xcd_cols_bytes(cp.xcd, (int)side_ub)) / sizeof(unsigned long long);
+    }
+    std::vector<char> counted(nh, 0);
+    bool locked = false;
+    try {
+        lead->chain_.gslots.reserve(CHAIN_GROUP_MAX);
+        lead->chain_.hgslots.reserve(CHAIN_GROUP_MAX);
+        for (size_t i = 0; i < nh; ++i) {
+            Tci2* h = hs[i];
+            h->chain_.prepared = false;
+            if (h != lead) { // the group's stream continues behind whatever this handle's own stream still holds
+                if (!h->chain_.group_ev) T4A_HIP(hipEventCreateWithFlags(&h->chain_.group_ev, hipEventDisableTiming));
+                T4A_HIP(hipEventRecord(h->chain_.group_ev, h->eng.stream()));
+                T4A_HIP(hipStreamWaitEvent(st, h->chain_.group_ev, 0));
+            }
+            h->eng.chain_group_reserve(gplans, reserve_words, st);
+            ChainGroupSlot& slot = lead->chain_.hgslots.get()[i];
+            slot.c = h->chain_.common;
+            slot.fn = h->fn_dev_;
+            slot.pi = h->chain_.pi.get();
+            g_chains_inflight.fetch_add(1);
+            counted[i] = 1;
+        }
+        T4A_HIP(hipMemcpyAsync(lead->chain_.gslots.get(), lead->chain_.hgslots.get(), nh * sizeof(ChainGroupSlot), hipMemcpyHostToDevice, st));
+        const ChainGroupSlot* d_slots = lead->chain_.gslots.get();
+        lead->eng.chain_group_lock();
+        locked = true;
+        auto block_of = [&](Tci2* h, size_t b) {
+            ChainBlock k = h->chain_.proto;
+            k.dev = h->chain_.blocks.get() + b * k.bytes;
+            k.host = h->chain_.hblocks.get() + b * k.bytes;
+            return k;
+        };
+        auto prev_of = [&](Tci2* h, size_t pb, ChainPrepArgs& pa) {
+            const ChainBlock pblk = block_of(h, pb);
+            pa.prev_b = (int)pb;
+            pa.prev_iresult = reinterpret_cast<const int*>(pblk.dev + 16);
+            pa.prev_rowperm = reinterpret_cast<const int*>(pblk.dev + pblk.off_rp);
+            pa.prev_colperm = reinterpret_cast<const int*>(pblk.dev + pblk.off_cp);
+            pa.prev_token = h->chain_.tokens[pb];
+        };
+        chain_indep_group_launch(d_slots, (int)nh, (int)nb, st);
+        const std::vector<size_t>& order = lead->chain_.order;
+        for (size_t k = 0; k < nb; ++k) {
+            const size_t b = order[k];
+            ChainPrepGroupArgs pg;
+            std::memset(&pg, 0, sizeof(pg));
+            for (size_t i = 0; i < nh; ++i) {
+                ChainPrepArgs& pa = pg.a[i];
+                pa.b = (int)b;
+                pa.do_build = 1;
+                pa.prev_b = -1;
+                if (k > 0) prev_of(hs[i], order[k - 1], pa);
+            }
+            chain_prep_group_launch(d_slots, pg, (int)nh, st);
+            chain_pi_group_launch(d_slots, (int)nh, (int)b, gplans[b].kM, gplans[b].kN, st);
+            RrluXcdGroupArgs ga;
+            std::memset(&ga, 0, sizeof(ga));
+            for (int x = 0; x < 8; ++x) ga.p[x].xcc = -1; // (an empty slot: its workgroups return at once)
+            for (size_t i = 0; i < nh; ++i) {
+                Tci2* h = hs[i];
+                h->chain_.tokens[b] = h->eng.chain_group_args(gplans[b], forward, h->chain_.pi.get(), h->chain_.common.dims + b * 4, h->chain_.chi,
+                                                              h->chain_.tol, 0.0, block_of(h, b), (int)i, &ga.p[i], st);
+            }
+            rrlu_xcd_group_launch(gplans[b].xcd, ga, !forward, st);
+        }
+        { // the pivots of the last bond
+            ChainPrepGroupArgs pg;
+            std::memset(&pg, 0, sizeof(pg));
+            for (size_t i = 0; i < nh; ++i) prev_of(hs[i], order[nb - 1], pg.a[i]);
+            chain_prep_group_launch(d_slots, pg, (int)nh, st);
+        }
+        T4A_HIP(hipGetLastError());
+    } catch (...) {
+        (void)hipStreamSynchronize(st);
+        if (locked) lead->eng.chain_end();
+        for (size_t i = 0; i < nh; ++i) {
+            if (counted[i]) g_chains_inflight.fetch_sub(1);
+            hs[i]->chain_.prepared = false;
+            hs[i]->chain_.tables_valid = false;
+        }
+        throw;
+    }
+    for (Tci2* h : hs) {
+        h->chain_.plans = gplans;
+        h->chain_.inflight = true;
+        h->chain_.wait_stream = st;
+        h->chain_.group_role = h == lead ? 1 : 2;
+    }
 }
 
 void Tci2::chain_finish(const TCI2Options& options)
 {
     if (!chain_.inflight) return;
     chain_.inflight = false;
-    hipStream_t st = eng.stream();
+    hipStream_t st = chain_.wait_stream ? chain_.wait_stream : eng.stream();
     const size_t nb = n_ - 1;
     const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
     const bool forward = chain_.forward;
     const ChainBlock& proto = chain_.proto;
     const hipError_t sync_err = hipStreamSynchronize(st);
-    eng.chain_end();
+    if (chain_.group_role != 2) eng.chain_end(); // (a member of a group chain holds nothing: the leader reserved the chip)
+    const bool was_group = chain_.group_role != 0;
+    chain_.group_role = 0;
+    chain_.wait_stream = nullptr;
     g_chains_inflight.fetch_sub(1);
     if (sync_err != hipSuccess) {
         chain_.tables_valid = false;
@@ -666,6 +833,7 @@ void Tci2::chain_finish(const TCI2Options& options)
     }
     if (failed_k < 0) {
         ++chain_stats[0];
+        if (was_group) ++chain_stats[4];
         chain_stats[1] += nb;
         if (chain_verify) { // tests: the mirror decodes to index sets whose codes / accumulators are the mirror's, and equals the device tables
             sync_digits();

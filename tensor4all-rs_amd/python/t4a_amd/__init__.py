@@ -649,10 +649,11 @@ class TensorCI2:
         _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0), c_int32((1 if verify else 0) | (2 if event_timing else 0))))
 
     def chain_stats(self):
-        """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible) since the handle was created."""
-        out = np.zeros(4, dtype=np.uint64)
+        """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible, group_half_sweeps) since the handle was created."""
+        out = np.zeros(5, dtype=np.uint64)
         _check(_lib.t4a_gpu_tci2_chain_stats(self._h, _p(out)))
-        return dict(half_sweeps=int(out[0]), bonds=int(out[1]), fell_back=int(out[2]), not_eligible=int(out[3]))
+        return dict(half_sweeps=int(out[0]), bonds=int(out[1]), fell_back=int(out[2]), not_eligible=int(out[3]),
+                    group_half_sweeps=int(out[4]))
 
 
 def optimize_group(tcis, options, final_sweep1site=True):

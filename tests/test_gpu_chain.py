@@ -189,6 +189,57 @@ def test_optimize_group_equals_optimize_on_every_handle(t4a):
         for p in range(n):
             assert np.array_equal(a.site_tensor(p), b.site_tensor(p)), (k, p)
         assert b.chain_stats()["fell_back"] == 0 and b.chain_stats()["half_sweeps"] > 0
+        assert a.chain_stats()["group_half_sweeps"] == 0
+    # while at least two handles are active their half-sweeps run as ONE chain of launches (the last survivor runs alone)
+    assert all(b.chain_stats()["group_half_sweeps"] > 0 for b in grouped)
     assert len(set(len(t.history()[0]) for t in grouped)) > 1, "the test wants handles that stop at different iterations"
     with pytest.raises(t4a.T4aError):
         t4a.optimize_group([grouped[0], grouped[0]], opts)
+
+
+def test_group_chain_with_a_member_on_the_per_bond_path(t4a):
+    """A group in which one handle is not eligible for the device-side chain (chain switched off: it runs bond by bond, on an XCD of
+    its own, after the group's chain has completed) and the others differ in length of run: results equal the handles' own runs."""
+    n = 14
+    specs = [t4a.quantics_osc2d(n, k1=2 + p, k2=3, k3=5 + p, eps=0.2, k4=7, delta=0.4) for p in range(4)]
+    opts = t4a.TCI2Options(tolerance=1e-8, max_bond_dim=20, max_iter=6, seed=5, **PARITY)
+    solo, grouped = [], []
+    for spec in specs:
+        for dst in (solo, grouped):
+            t = t4a.TensorCI2([2] * n)
+            t.set_function(spec)
+            t.add_global_pivots([[0] * n])
+            dst.append(t)
+    grouped[1].set_chain(False)
+    for t in solo:
+        t.optimize(opts, final_sweep1site=False)
+    t4a.optimize_group(grouped, opts, final_sweep1site=False)
+    for k, (a, b) in enumerate(zip(solo, grouped)):
+        for p in range(n):
+            assert np.array_equal(a.i_set(p), b.i_set(p)) and np.array_equal(a.j_set(p), b.j_set(p)), (k, p)
+        assert np.array_equal(a.history()[1], b.history()[1]), k
+    assert grouped[1].chain_stats()["half_sweeps"] == 0
+    assert grouped[0].chain_stats()["group_half_sweeps"] > 0 and grouped[0].chain_stats()["fell_back"] == 0
+
+
+def test_group_chain_mixed_lengths_fall_back_to_own_chains(t4a):
+    """Handles with different numbers of sites do not line up: optimize_group runs one chain per handle (group_half_sweeps stays 0)."""
+    opts = t4a.TCI2Options(tolerance=1e-8, max_bond_dim=16, max_iter=4, seed=5, **PARITY)
+    ts = []
+    for n in (10, 12):
+        t = t4a.TensorCI2([2] * n)
+        t.set_function(t4a.quantics_osc2d(n, k1=3, k2=5, k3=7, eps=0.2, k4=11, delta=0.3))
+        t.add_global_pivots([[0] * n])
+        ts.append(t)
+    ref = []
+    for n in (10, 12):
+        t = t4a.TensorCI2([2] * n)
+        t.set_function(t4a.quantics_osc2d(n, k1=3, k2=5, k3=7, eps=0.2, k4=11, delta=0.3))
+        t.add_global_pivots([[0] * n])
+        t.optimize(opts, final_sweep1site=False)
+        ref.append(t)
+    t4a.optimize_group(ts, opts, final_sweep1site=False)
+    for a, b in zip(ref, ts):
+        for p in range(len(a.link_dims()) + 1):
+            assert np.array_equal(a.i_set(p), b.i_set(p)) and np.array_equal(a.j_set(p), b.j_set(p))
+        assert b.chain_stats()["group_half_sweeps"] == 0 and b.chain_stats()["half_sweeps"] > 0
