@@ -619,6 +619,30 @@ def aux_timings():
         out["cfg5_patch_from_scratch_ms_one_at_a_time"] = t_seq * 1e3
         out["cfg5_patch_from_scratch_ms_eight_side_by_side"] = t_par * 1e3
         out["cfg5_side_by_side_results_identical"] = bool(all(par[p] == seq[p] for p in seq))
+        # the same eight patches through t4a_gpu_tci2_optimize_group: ONE host thread, one chain of launches for all eight
+        # (every kernel serves all handles; handle i's rank-revealing LU runs on XCD i of the same launch)
+        o_grp = t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=chi5, max_iter=11, ncheck_history=10 ** 6, nsearch=0, max_nglobal_pivot=0, seed=42)
+        best, grp = None, {}
+        for _ in range(2):
+            t0 = time.perf_counter()
+            tps = []
+            for p in range(8):
+                tp = t4a_amd.TensorCI2([2] * N_SITES)
+                tp.set_function(patch_spec(p, n_patches))
+                tp.add_global_pivots([[0] * N_SITES])
+                tp.set_max_sample_value(1.0)
+                tps.append(tp)
+            t4a_amd.optimize_group(tps, o_grp, final_sweep1site=False)
+            for p, tp in enumerate(tps):
+                tp.fill_site_tensors()
+                grp[p] = float(tp.sum())
+            dt = (time.perf_counter() - t0) / 8
+            best = dt if best is None else min(best, dt)
+            group_half_sweeps = int(tps[0].chain_stats()["group_half_sweeps"])
+            del tps
+        out["cfg5_patch_from_scratch_ms_group_of_eight"] = best * 1e3
+        out["cfg5_group_results_identical"] = bool(all(grp[p] == seq[p] for p in seq))
+        out["cfg5_group_half_sweeps_per_handle"] = group_half_sweeps
     except Exception as e:  # noqa: BLE001
         out["cfg5_concurrent_error"] = str(e)
     try:

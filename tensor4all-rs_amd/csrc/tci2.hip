@@ -11,6 +11,8 @@
 
 namespace t4a {
 
+extern thread_local double g_chain_wait_seconds; // tci2_chain.hip
+
 // =================================================================================================
 // small device kernels: packing of factor matrices into site tensors (column-major [left, site, right])
 // =================================================================================================
@@ -1851,23 +1853,40 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
         runs[i].final_sweep1site = final_sweep1site;
         hs[i]->opt_begin(runs[i]);
     }
+    static const bool prof = std::getenv("T4A_GROUP_PROF") != nullptr; // host time per phase, printed once per call
+    double t_start = 0.0, t_launch = 0.0, t_finish = 0.0;
+    const double wait0 = g_chain_wait_seconds;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    size_t iters = 0;
     for (;;) {
         std::vector<size_t> active;
         std::vector<Tci2*> chained;
+        const auto ta = now();
         for (size_t i = 0; i < hs.size(); ++i)
             if (hs[i]->opt_iter_start(runs[i], true)) {
                 active.push_back(i);
                 if (runs[i].chained) chained.push_back(hs[i]);
             }
         if (active.empty()) break;
+        const auto tb = now();
         chain_group_launch(chained); // one chain of launches for all of them (or one each when they do not line up)
+        const auto tc = now();
         // the chained handles first, the group's leader first of all: it holds the chip until its chain has completed, and a
         // handle on the per-bond path needs an XCD of its own
         for (size_t i : active)
             if (runs[i].chained) hs[i]->opt_iter_finish(runs[i]);
         for (size_t i : active)
             if (!runs[i].chained) hs[i]->opt_iter_finish(runs[i]);
+        const auto td = now();
+        t_start += secs(ta, tb);
+        t_launch += secs(tb, tc);
+        t_finish += secs(tc, td);
+        ++iters;
     }
+    if (prof)
+        std::fprintf(stderr, "[t4a] optimize_group: %zu handles, %zu iterations: start %.2f ms, launch %.2f ms, finish %.2f ms (of which waiting for the device %.2f ms)\n",
+                     hs.size(), iters, 1e3 * t_start, 1e3 * t_launch, 1e3 * t_finish, 1e3 * (g_chain_wait_seconds - wait0));
     for (size_t i = 0; i < hs.size(); ++i) hs[i]->opt_end(runs[i]);
 }
 

@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -45,6 +46,7 @@ size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // A chain that is not alone evaluates its candidate matrices directly (8 us more per bond, nobody else disturbed).
 std::atomic<int> g_chains_inflight{0};
 } // namespace
+thread_local double g_chain_wait_seconds = 0.0; // time chain_finish spent waiting for the device (T4A_GROUP_PROF, tci2.hip)
 
 bool Tci2::chain_usable(const TCI2Options& options) const
 {
@@ -729,7 +731,9 @@ void Tci2::chain_finish(const TCI2Options& options)
     const size_t K = (size_t)chain_.n_acc, cap = chain_.cap;
     const bool forward = chain_.forward;
     const ChainBlock& proto = chain_.proto;
+    const auto wait_t0 = std::chrono::steady_clock::now();
     const hipError_t sync_err = hipStreamSynchronize(st);
+    g_chain_wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - wait_t0).count();
     if (chain_.group_role != 2) eng.chain_end(); // (a member of a group chain holds nothing: the leader reserved the chip)
     const bool was_group = chain_.group_role != 0;
     chain_.group_role = 0;
