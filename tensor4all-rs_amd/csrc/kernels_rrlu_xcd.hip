@@ -51,10 +51,11 @@ constexpr int XT = 64 * XWAVES;       // threads per workgroup
 constexpr int XCD_MAX_CPT = 4;       // (the key carries the column slot in two bits)
 constexpr int XCD_MAX_VALUES = XWAVES == 4 ? 80 : 40; // matrix entries per thread: beyond this the register file of a 512-thread workgroup spills
 constexpr int BUF_SC1 = 16;  // aux bits of the raw buffer loads: sc1 (L1 bypass, served by the XCD's L2)
-// the RE-loads of the polling loops carry the compiler-only "volatile" bit (bit 31, stripped when the instruction is selected):
-// a raw buffer load is an ordinary memory read to the optimiser, and a loop that only re-reads the same address until a tag
-// matches is a loop-invariant load to it — hoisted, the loop spins on its first answer until the bounded poll gives up
-constexpr int BUF_SC1_RETRY = (int)(16u | 0x80000000u);
+// The RE-loads of the polling loops sit behind a compiler barrier (xcd_poll_again): a raw buffer load is an ordinary memory read to
+// the optimiser, and a loop that only re-reads one address until a tag matches is a loop-invariant load to it — hoisted, the loop
+// spins on its first answer until the bounded poll gives up.  (The intrinsic's compiler-only volatile bit, aux bit 31, also keeps
+// the loads in place but selects system-scope loads, sc0 sc1: the barrier keeps them the same sc1 loads as the first ones.)
+__device__ __forceinline__ void xcd_poll_again() { asm volatile("" ::: "memory"); }
 
 __device__ __forceinline__ unsigned xcc_id()
 {
@@ -625,13 +626,14 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ok &= ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
                 if (__all(ok)) break;
+                xcd_poll_again();
                 if (++spins > XSPIN) {
                     giveup = true;
                     break;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1_RETRY);
+                    kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
             }
             if (stamp_on) lds_stamps[5] += spins;
             // the full keys: fetched now (every agent stored its own before it could have seen this step's early keys complete...
@@ -677,11 +679,12 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
                                         kz = (unsigned)__builtin_amdgcn_readlane((int)kh[j].z, hl);
                                         kw = (unsigned)__builtin_amdgcn_readlane((int)kh[j].w, hl);
                                         if ((kx ^ ky ^ kz ^ kw) == tag) break;
+                                        xcd_poll_again();
                                         if (++spins > XSPIN) {
                                             giveup = true;
                                             break;
                                         }
-                                        kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1_RETRY);
+                                        kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
                                     }
                                     wv = mk_f64(kx, ky);
                                     wm_ = kz;
@@ -700,13 +703,14 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ok &= ((kh[j].x ^ kh[j].y ^ kh[j].z ^ kh[j].w) == tag);
                         if (__all(ok)) break;
+                        xcd_poll_again();
                         if (++spins > XSPIN) {
                             giveup = true;
                             break;
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1_RETRY);
+                            kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
                     }
                     double csc = -1.0, cv = 0.0;
                     unsigned cpk = XNOPOS, cmeta = 0u;
@@ -870,6 +874,7 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
                 for (int j = 0; j < XR; ++j)
                     if (wave + XWAVES * j < RPT) ok &= ((cc[j].x ^ cc[j].y ^ cc[j].z ^ cc[j].w) == tag);
                 if (__all(ok)) break;
+                xcd_poll_again();
                 if (++spins > XSPIN) {
                     atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
                     if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
@@ -878,7 +883,7 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
                 }
 #pragma unroll
                 for (int j = 0; j < XR; ++j)
-                    if (wave + XWAVES * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * XT * 16, 0, BUF_SC1_RETRY);
+                    if (wave + XWAVES * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * XT * 16, 0, BUF_SC1);
             }
             XSTAMP(12);
             // x / p through the shared refined reciprocal (bitwise the IEEE quotient, see refined_rcp); zeros keep the sign
