@@ -911,6 +911,21 @@ rrlu_reg_kernel(RrluRegArgs p)
         if (tid == 0) reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull;
         for (int e = tid; e < p.keys_next_u64; e += T) p.keys_next[e] = 0ull;
     }
+    // bond chain without per-launch host mirror: the device block is copied to the host once, behind the whole chain; it keeps
+    // max |a| and gets the time stamps and the completion token here
+    if (SINGLE && !p.h_block && p.dims) {
+        __syncthreads();
+        if (tid == 0) {
+            if (p.ts_u64 > 0) {
+                unsigned long long* const blk = reinterpret_cast<unsigned long long*>(p.dresult);
+                blk[p.ts_u64] = ts_begin;
+                blk[p.ts_u64 + 1] = wall_clock64();
+            }
+            __threadfence();
+            p.iresult[3] = (int)p.dev_token;
+        }
+        for (int e = tid; e < p.keys_next_u64; e += T) p.keys_next[e] = 0ull;
+    }
 }
 
 template <int RPT, int CPT, bool SINGLE, bool UNI, bool ROWMAJOR>

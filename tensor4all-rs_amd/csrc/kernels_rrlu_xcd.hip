@@ -1041,6 +1041,17 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
         }
         if (stamp_on) p.stamps[19] = __builtin_amdgcn_s_memtime() - t_done; // ... write-out and host mirror
     }
+    // bond chain without per-launch host mirror: the device block is complete as it is (error, max |a|, rank, flags, pivot
+    // values, permutations) and is copied to the host once, behind the whole chain; it only lacks the time stamps and the token
+    if (!p.h_block && p.dims && rank == 0 && tid == 0) {
+        if (p.ts_u64 > 0) {
+            unsigned long long* const blk = reinterpret_cast<unsigned long long*>(p.dresult);
+            blk[p.ts_u64] = ts_begin;
+            blk[p.ts_u64 + 1] = wall_clock64();
+        }
+        __threadfence();
+        p.iresult[3] = (int)p.salt;
+    }
 }
 
 #ifndef T4A_XCD_GROUP_TU

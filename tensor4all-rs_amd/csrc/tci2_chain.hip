@@ -482,10 +482,13 @@ void Tci2::chain_launch()
     const std::vector<size_t>& ind_ub = chain_.ind_ub;
     std::vector<unsigned>& tokens = chain_.tokens;
     hipStream_t st = eng.stream();
+    // result blocks reach the host in ONE copy behind the chain (T4A_CHAIN_HOST_MIRROR=1: every rrLU kernel mirrors its own block
+    // into pinned memory as it ends — stores over PCIe that the kernel's end has to wait for, once per bond)
+    static const bool per_launch_mirror = std::getenv("T4A_CHAIN_HOST_MIRROR") != nullptr;
     auto block_of = [&](size_t b) {
         ChainBlock k = proto;
         k.dev = chain_.blocks.get() + b * proto.bytes;
-        k.host = chain_.hblocks.get() + b * proto.bytes;
+        k.host = per_launch_mirror ? chain_.hblocks.get() + b * proto.bytes : nullptr;
         return k;
     };
     {
@@ -575,6 +578,8 @@ void Tci2::chain_launch()
             pa.prev_token = tokens[pb];
             chain_prep_launch(c, pa, st);
         }
+        if (!per_launch_mirror)
+            T4A_HIP(hipMemcpyAsync(chain_.hblocks.get(), chain_.blocks.get(), nb * proto.bytes, hipMemcpyDeviceToHost, st));
         T4A_HIP(hipGetLastError());
     } catch (...) {
         (void)hipStreamSynchronize(st);
@@ -658,10 +663,11 @@ void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
         const ChainGroupSlot* d_slots = lead->chain_.gslots.get();
         lead->eng.chain_group_lock();
         locked = true;
+        static const bool per_launch_mirror = std::getenv("T4A_CHAIN_HOST_MIRROR") != nullptr;
         auto block_of = [&](Tci2* h, size_t b) {
             ChainBlock k = h->chain_.proto;
             k.dev = h->chain_.blocks.get() + b * k.bytes;
-            k.host = h->chain_.hblocks.get() + b * k.bytes;
+            k.host = per_launch_mirror ? h->chain_.hblocks.get() + b * k.bytes : nullptr;
             return k;
         };
         auto prev_of = [&](Tci2* h, size_t pb, ChainPrepArgs& pa) {
@@ -703,6 +709,9 @@ void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
             for (size_t i = 0; i < nh; ++i) prev_of(hs[i], order[nb - 1], pg.a[i]);
             chain_prep_group_launch(d_slots, pg, (int)nh, st);
         }
+        if (!per_launch_mirror)
+            for (Tci2* h : hs)
+                T4A_HIP(hipMemcpyAsync(h->chain_.hblocks.get(), h->chain_.blocks.get(), nb * h->chain_.proto.bytes, hipMemcpyDeviceToHost, st));
         T4A_HIP(hipGetLastError());
     } catch (...) {
         (void)hipStreamSynchronize(st);
