@@ -442,7 +442,11 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
 #pragma unroll
     for (int q = 0; q < CPT; ++q) u[q] = 0.0;
     double prev_sq = __builtin_huge_val(); // nobody speculates on the first step
-    const double spec_frac = p.spec_frac;
+    // three launch constants of the step loop live in VECTOR registers: left in the kernel arguments they are re-read in every
+    // step (the scalar registers do not hold them across the loop), each time with its load latency exposed — the tolerances
+    // in the middle of the polling wave's stop test, i.e. on the critical path of the step
+    double spec_frac = p.spec_frac, rel_tol_v = p.rel_tol, abs_tol_v = p.abs_tol;
+    asm volatile("" : "+v"(spec_frac), "+v"(rel_tol_v), "+v"(abs_tol_v));
     constexpr unsigned XSPIN = 1u << 20; // bounded spins: a hand-off that does not arrive makes the launch give up
     int dpk = 0; // next diagonal element: row | column << 10 (worked out by the polling wave one step ahead)
 
@@ -754,7 +758,7 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
                 if (!(wsq >= 2.2250738585072014e-308 && wsq < __builtin_huge_val())) pivot_abs = sqrt(mk_f64((unsigned)opaque_v((int)lo32(wsq)), hi32(wsq)));
                 error = pivot_abs;
                 int stop = 0;
-                if (kn > 0 && (pivot_abs < p.rel_tol * max_error || pivot_abs < p.abs_tol)) stop = 1;
+                if (kn > 0 && (pivot_abs < rel_tol_v * max_error || pivot_abs < abs_tol_v)) stop = 1;
                 else if (pivot_abs <= min_pivot_abs) stop = 1;
                 else max_error = fmax(max_error, pivot_abs);
                 // permutation bookkeeping for everybody: who sits at position kn now, and the next diagonal element
