@@ -982,7 +982,7 @@ void Tci2::fill_site_tensors_impl(bool async)
     fill_cache_trusted_ = false;
     static const bool host_prof_fill = std::getenv("T4A_HOST_PROFILE") != nullptr;
     const auto hpf_t0 = std::chrono::steady_clock::now();
-    static double hpf_sec[6] = {0, 0, 0, 0, 0, 0};
+    static double hpf_sec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto hpf_mark = [&](int k, std::chrono::steady_clock::time_point& t) {
         if (!host_prof_fill) return;
         const auto now = std::chrono::steady_clock::now();
@@ -1208,10 +1208,12 @@ void Tci2::fill_site_tensors_impl(bool async)
         const size_t total_bytes = up8(off_pk + bytes_pk);
         h_fillacc_.reserve(total_bytes / 8);
         d_fillacc_.reserve(total_bytes / 8);
+        hpf_mark(5, hpf_t);
         char* hb = reinterpret_cast<char*>(h_fillacc_.get());
         char* db = reinterpret_cast<char*>(d_fillacc_.get());
         const uint64_t* da = d_fillacc_.get();
         std::memcpy(hb, acc_all.data(), bytes_acc);
+        hpf_mark(6, hpf_t);
         std::vector<PiJob> pis;
         int max_M = 0, max_N = 0;
         for (const SiteJob& j : jobs) {
@@ -1254,6 +1256,7 @@ void Tci2::fill_site_tensors_impl(bool async)
             std::memcpy(hb + off_tr + np_ * sizeof(TrsmProblem), tru.data(), np_ * sizeof(TrsmProblem));
         }
         std::memcpy(hb + off_pk, packs.data(), bytes_pk);
+        hpf_mark(7, hpf_t);
         {
             const FnDevice fn = fn_dev_;
             const PiJob* dj = reinterpret_cast<const PiJob*>(db + off_pi);
@@ -1363,6 +1366,9 @@ void Tci2::fill_site_tensors_impl(bool async)
                                  "accumulators %.1f, staging %.1f, issue %.1f)\n",
                          1e3 * acc_ms / calls, hpf_sec[0] / calls, hpf_sec[1] / calls, hpf_sec[2] / calls, hpf_sec[3] / calls,
                          hpf_sec[4] / calls);
+        if (calls % 20 == 0)
+            std::fprintf(stderr, "[host profile]   staging in detail: reserve %.1f, accumulator copy %.1f, job tables %.1f us per call\n",
+                         hpf_sec[5] / calls, hpf_sec[6] / calls, hpf_sec[7] / calls);
     }
     if (!async) fill_wait();
 }
@@ -1631,6 +1637,18 @@ void Tci2::opt_begin(OptRun& r)
         d_fillA_.reserve(std::max<size_t>(totA, 1));
         d_fillB_.reserve(std::max<size_t>(totB, 1));
         d_fillpiv_.reserve(std::max<size_t>(n_ * chi, 1));
+        // the upload arena of a fill (accumulators of J_b, kron(I_b, d_b), I_{b+1} per site, then the job tables): grown once
+        // per iteration it cost every fill a device-wide wait in the middle of the next chain
+        size_t acc_words = 0;
+        for (size_t b = 0; b < n_; ++b) {
+            if (shard_world > 1 && (b % shard_world) != shard_rank) continue;
+            acc_words += chi * (2 + local_dims[b]) * (size_t)fn_dev_.n_acc;
+        }
+        const size_t desc_bytes = n_ * (2 * sizeof(PiJob) + sizeof(LuProblem) + 2 * sizeof(TrsmProblem) + 64) + 256;
+        h_fillacc_.reserve(acc_words + desc_bytes / 8 + 64);
+        d_fillacc_.reserve(acc_words + desc_bytes / 8 + 64);
+        d_fillmax_.reserve(n_ + (n_ + 1) / 2 + (LU_MAX_PANEL_STEPS + 1) / 2);
+        h_fillinfo_.reserve(n_);
     }
     r.pending_fill = false;
     r.iter = 0;
@@ -1706,6 +1724,21 @@ bool Tci2::opt_iter_start(OptRun& r, bool defer_launch)
     return true;
 }
 
+// ... and while the device works on the chain the host issues fill_site_tensors of the PREVIOUS iteration (its accumulators were
+// taken from the mirror when that iteration finished; nothing of it touches the main stream).  Part of opt_iter_finish; a
+// group calls it for every handle before it finishes the first one (the first chain_finish waits for the whole group's chain:
+// whatever the host issues after that no longer overlaps it).
+void Tci2::opt_iter_issue_pending_fill(OptRun& r)
+{
+    if (!r.pending_fill) return;
+    r.pending_fill = false;
+    for (size_t b = 0; b < n_; ++b) prepare_fill_site(b); // (from the mirror of the previous chain; the new one writes the other mirror)
+    fill_cache_trusted_ = true;
+    fill_no_main_sync_ = true;
+    fill_site_tensors_impl(true);
+    if (!keep_site_tensors) invalidate_site_tensors(); // (the end of that iteration invalidated them, tensorci2.rs:707-708)
+}
+
 void Tci2::opt_iter_finish(OptRun& r)
 {
     const TCI2Options& options = r.options;
@@ -1715,16 +1748,7 @@ void Tci2::opt_iter_finish(OptRun& r)
     const long ext_idx = r.ext_idx;
     const size_t flush_at_fwd = r.flush_at_fwd, flush_at_bwd = r.flush_at_bwd;
     do { // (one pass; `break` = the convergence exit of the reference's loop)
-        // ... and while the device works on it the host issues fill_site_tensors of the PREVIOUS iteration (its accumulators
-        // were taken from the mirror when that iteration finished; nothing of it touches the main stream)
-        if (r.pending_fill) {
-            r.pending_fill = false;
-            for (size_t b = 0; b < n_; ++b) prepare_fill_site(b); // (from the mirror of the previous chain; the new one writes the other mirror)
-            fill_cache_trusted_ = true;
-            fill_no_main_sync_ = true;
-            fill_site_tensors_impl(true);
-            if (!keep_site_tensors) invalidate_site_tensors(); // (the end of that iteration invalidated them, tensorci2.rs:707-708)
-        }
+        opt_iter_issue_pending_fill(r);
         if (chained) {
             chain_finish(options);
         } else {
@@ -1854,7 +1878,7 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
         hs[i]->opt_begin(runs[i]);
     }
     static const bool prof = std::getenv("T4A_GROUP_PROF") != nullptr; // host time per phase, printed once per call
-    double t_start = 0.0, t_launch = 0.0, t_finish = 0.0;
+    double t_start = 0.0, t_launch = 0.0, t_finish = 0.0, t_fill = 0.0;
     const double wait0 = g_chain_wait_seconds;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -1875,6 +1899,9 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
         // the chained handles first, the group's leader first of all: it holds the chip until its chain has completed, and a
         // handle on the per-bond path needs an XCD of its own
         for (size_t i : active)
+            if (runs[i].chained) hs[i]->opt_iter_issue_pending_fill(runs[i]); // (all of them while the group's chain still runs)
+        t_fill += secs(tc, now());
+        for (size_t i : active)
             if (runs[i].chained) hs[i]->opt_iter_finish(runs[i]);
         for (size_t i : active)
             if (!runs[i].chained) hs[i]->opt_iter_finish(runs[i]);
@@ -1885,8 +1912,8 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
         ++iters;
     }
     if (prof)
-        std::fprintf(stderr, "[t4a] optimize_group: %zu handles, %zu iterations: start %.2f ms, launch %.2f ms, finish %.2f ms (of which waiting for the device %.2f ms)\n",
-                     hs.size(), iters, 1e3 * t_start, 1e3 * t_launch, 1e3 * t_finish, 1e3 * (g_chain_wait_seconds - wait0));
+        std::fprintf(stderr, "[t4a] optimize_group: %zu handles, %zu iterations: start %.2f ms, launch %.2f ms, finish %.2f ms (of which issuing the previous iteration's fills %.2f ms, waiting for the device %.2f ms)\n",
+                     hs.size(), iters, 1e3 * t_start, 1e3 * t_launch, 1e3 * t_finish, 1e3 * t_fill, 1e3 * (g_chain_wait_seconds - wait0));
     for (size_t i = 0; i < hs.size(); ++i) hs[i]->opt_end(runs[i]);
 }
 

@@ -95,6 +95,7 @@ public:
         size_t flush_at_fwd = 0, flush_at_bwd = 0;
     };
     void opt_begin(OptRun& r);
+    void opt_iter_issue_pending_fill(OptRun& r);
     bool opt_iter_start(OptRun& r, bool defer_launch = false); // defer_launch: the chain is prepared, not launched (optimize_group)
     void opt_iter_finish(OptRun& r);
     void opt_end(OptRun& r);

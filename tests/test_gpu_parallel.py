@@ -6,6 +6,10 @@ import socket
 
 import numpy as np
 import pytest
+# PyTorch-ROCm ships its own HIP runtime; whichever runtime a process loads first serves it.  With torch imported here (at
+# collection time) it is loaded before libt4a_gpu.so in every selection of test files — loaded after it, torch finds the
+# system runtime in place of its own and reports no device.
+import torch  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
