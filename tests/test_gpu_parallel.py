@@ -223,6 +223,10 @@ def test_cfg5_full_size_64_patches_chi128(rccl):
             assert np.array_equal(g.i_set(s), o.i_set(s)), f"patch {p}: I set of site {s}"
             assert np.array_equal(g.j_set(s), o.j_set(s)), f"patch {p}: J set of site {s}"
         assert np.array_equal(g.bond_errors(), o.bond_errors())
+        # ... and the patch really went through the GROUP chain (one chain of launches for its eight handles, its rrLU on one XCD
+        # of a shared launch), never through the per-bond host loop
+        st = g.chain_stats()
+        assert st["group_half_sweeps"] == st["half_sweeps"] > 0 and st["fell_back"] == 0 and st["not_eligible"] == 0, st
         # values: the interpolants agree to 1e-10 of the largest value on random points.  (The raw cores are NOT compared: at a
         # saturated, truncated rank some pivot matrices P are ill conditioned, so T = Pi1 P^-1 moves by ~1e-3 between two
         # correct LU orderings — device blocked/MFMA vs the oracle's unblocked loop — while the train it belongs to does not.)
