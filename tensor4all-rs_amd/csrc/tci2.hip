@@ -3,6 +3,7 @@
 #include "tci2.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -166,6 +167,7 @@ Tci2::Tci2(const std::vector<size_t>& dims) : n_(dims.size()), local_dims(dims) 
 
 Tci2::~Tci2()
 {
+    chain_abort();
     for (hipEvent_t e : chain_.t0) (void)hipEventDestroy(e);
     for (hipEvent_t e : chain_.t1) (void)hipEventDestroy(e);
     if (chain_.group_ev) (void)hipEventDestroy(chain_.group_ev);
@@ -1732,6 +1734,12 @@ void Tci2::opt_iter_issue_pending_fill(OptRun& r)
 {
     if (!r.pending_fill) return;
     r.pending_fill = false;
+    {   // tests only: T4A_TEST_THROW_IN_FILL=n makes the n-th pending fill of the process fail (while a chain is in flight)
+        static const long inject_at = std::getenv("T4A_TEST_THROW_IN_FILL") ? std::atol(std::getenv("T4A_TEST_THROW_IN_FILL")) : 0;
+        static std::atomic<long> issued{0};
+        if (inject_at > 0 && ++issued == inject_at)
+            throw Error(T4A_GPU_INTERNAL_ERROR, "injected failure while issuing fill_site_tensors (T4A_TEST_THROW_IN_FILL)");
+    }
     for (size_t b = 0; b < n_; ++b) prepare_fill_site(b); // (from the mirror of the previous chain; the new one writes the other mirror)
     fill_cache_trusted_ = true;
     fill_no_main_sync_ = true;
@@ -1854,9 +1862,14 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
     OptRun r;
     r.options = options;
     r.final_sweep1site = final_sweep1site;
-    opt_begin(r);
-    while (opt_iter_start(r)) opt_iter_finish(r);
-    opt_end(r);
+    try {
+        opt_begin(r);
+        while (opt_iter_start(r)) opt_iter_finish(r);
+        opt_end(r);
+    } catch (...) {
+        chain_abort(); // (a chain may be in flight: the error came from the fill of the previous iteration)
+        throw;
+    }
 }
 
 // Up to eight handles (one XCD each) optimised in lock-step by the calling thread: every iteration first enqueues all the bond
@@ -1872,6 +1885,7 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
         hs[i]->eng.set_xcc((int)i); // (distinct XCDs: a handle keeps its reservation from enqueue to finish)
     }
     std::vector<OptRun> runs(hs.size());
+    try {
     for (size_t i = 0; i < hs.size(); ++i) {
         runs[i].options = options;
         runs[i].final_sweep1site = final_sweep1site;
@@ -1915,6 +1929,10 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
         std::fprintf(stderr, "[t4a] optimize_group: %zu handles, %zu iterations: start %.2f ms, launch %.2f ms, finish %.2f ms (of which issuing the previous iteration's fills %.2f ms, waiting for the device %.2f ms)\n",
                      hs.size(), iters, 1e3 * t_start, 1e3 * t_launch, 1e3 * t_finish, 1e3 * t_fill, 1e3 * (g_chain_wait_seconds - wait0));
     for (size_t i = 0; i < hs.size(); ++i) hs[i]->opt_end(runs[i]);
+    } catch (...) {
+        for (Tci2* h : hs) h->chain_abort(); // (the leader's abort waits for the group's stream and gives the chip back)
+        throw;
+    }
 }
 
 // crossinterpolate2 (tensorci2.rs:1513-1563)

@@ -313,6 +313,7 @@ private:
     // rrLU on its own XCD); falls back to chain_launch() per handle when the chains do not line up
     static void chain_group_launch(const std::vector<Tci2*>& handles);
     void chain_finish(const TCI2Options& options);
+    void chain_abort() noexcept; // after an exception between launch and finish: wait, release the XCD, drop the chain's results
     void prepare_fill_site_from_mirror(size_t b);
     bool fill_no_main_sync_ = false; // the next fill does not depend on work of the main stream (bond chain: no cores written there)
 

@@ -731,6 +731,27 @@ void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
     }
 }
 
+// An exception left optimize() / optimize_group() between the launch of a chain and its chain_finish (a fill of the previous
+// iteration reporting a singular pivot matrix, a runtime error while issuing it): wait for the chain, give the XCD (or the
+// chip) back and forget its results — the host's sets are those from before the chain (it wrote the OTHER mirror), the device
+// tables are re-uploaded by the next chain.  Without this the handle kept its reservation and every later call on it failed
+// with "a chain is already in flight" while other handles waited for the XCD forever.
+void Tci2::chain_abort() noexcept
+{
+    chain_.prepared = false;
+    if (!chain_.inflight) return;
+    chain_.inflight = false;
+    hipStream_t st = chain_.wait_stream ? chain_.wait_stream : eng.stream();
+    (void)hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    if (chain_.group_role != 2) eng.chain_end();
+    chain_.group_role = 0;
+    chain_.wait_stream = nullptr;
+    g_chains_inflight.fetch_sub(1);
+    chain_.tables_valid = false;
+    chain_.snap_serial[0] = chain_.snap_serial[1] = ~0ull; // (the snapshot taken by the aborted chain is not the history's newest entry any more)
+}
+
 void Tci2::chain_finish(const TCI2Options& options)
 {
     if (!chain_.inflight) return;

@@ -4,10 +4,14 @@ through the per-bond host path and through the CPU oracle and compares index set
 
 Reference: update_pivots / sweep2site / optimize_with_finder, crates/tensor4all-tensorci/src/tensorci2.rs:746-798, 1626-1802,
 1821-2007; kronecker_i / kronecker_j :1224-1246; the history extras :1675-1689, :1833-1846."""
+import os
+
 import numpy as np
 import pytest
 
 import oracle_binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -243,3 +247,63 @@ def test_group_chain_mixed_lengths_fall_back_to_own_chains(t4a):
         for p in range(len(a.link_dims()) + 1):
             assert np.array_equal(a.i_set(p), b.i_set(p)) and np.array_equal(a.j_set(p), b.j_set(p))
         assert b.chain_stats()["group_half_sweeps"] == 0 and b.chain_stats()["half_sweeps"] > 0
+
+
+def test_exception_while_a_chain_is_in_flight_leaves_the_handles_usable(tmp_path):
+    """An error raised between the launch of a bond chain and its completion (here: injected into the issue of the previous
+    iteration's fill_site_tensors, T4A_TEST_THROW_IN_FILL) must not leave the handle with a chain 'in flight' and its XCD — or,
+    for a group, the whole chip — reserved: the failed call reports the error, the same handles then optimise normally and reach
+    the result of handles that never failed.  Runs in a child process (the injection is read once per process)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tensor4all-rs_amd/python")
+import t4a_amd as t4a
+n = 14
+def make(k):
+    t = t4a.TensorCI2([2] * n)
+    t.set_function(t4a.quantics_osc2d(n, k1=3 + k, k2=5, k3=7, eps=0.2, k4=11, delta=0.3))
+    t.add_global_pivots([[0] * n])
+    return t
+opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=20, max_iter=6, seed=3, ncheck_history=10**6, nsearch=0, max_nglobal_pivot=0)
+# 1. one handle: the 2nd pending fill of the process fails while the 3rd iteration's chain runs
+a = make(0)
+try:
+    a.optimize(opts, final_sweep1site=False)
+    print("NO ERROR 1")
+except t4a.T4aError as e:
+    print("error 1:", "injected" in str(e))
+b = make(0)                      # same XCD family, fresh handle: must not wait for a reservation that was never returned
+b.optimize(opts, final_sweep1site=False)
+a.clear_history()
+a2 = make(0)
+a2.optimize(opts, final_sweep1site=False)
+print("fresh equal:", all(np.array_equal(b.i_set(p), a2.i_set(p)) for p in range(n)))
+a.optimize(opts, final_sweep1site=False)   # the handle that failed is usable again
+print("failed handle usable:", a.chain_stats()["half_sweeps"] > 0, max(a.link_dims()) == max(b.link_dims()))
+'''
+    env = dict(os.environ, T4A_TEST_THROW_IN_FILL="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert "error 1: True" in r.stdout, r.stdout + r.stderr
+    assert "fresh equal: True" in r.stdout, r.stdout + r.stderr
+    assert "failed handle usable: True True" in r.stdout, r.stdout + r.stderr
+    # 2. a group: the failure hits a member while the leader holds the chip
+    code2 = code.split("# 1.")[0] + r'''
+hs = [make(k) for k in range(4)]
+try:
+    t4a.optimize_group(hs, opts, final_sweep1site=False)
+    print("NO ERROR 2")
+except t4a.T4aError as e:
+    print("error 2:", "injected" in str(e))
+ref = [make(k) for k in range(4)]
+for t in ref:
+    t.optimize(opts, final_sweep1site=False)       # own chains on own XCDs: would hang if the chip were still reserved
+hs2 = [make(k) for k in range(4)]
+t4a.optimize_group(hs2, opts, final_sweep1site=False)
+print("group after failure equal:", all(np.array_equal(x.i_set(p), y.i_set(p)) for x, y in zip(ref, hs2) for p in range(n)))
+'''
+    env = dict(os.environ, T4A_TEST_THROW_IN_FILL="6")
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert "error 2: True" in r.stdout, r.stdout + r.stderr
+    assert "group after failure equal: True" in r.stdout, r.stdout + r.stderr
