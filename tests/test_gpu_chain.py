@@ -307,3 +307,35 @@ print("group after failure equal:", all(np.array_equal(x.i_set(p), y.i_set(p)) f
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert "error 2: True" in r.stdout, r.stdout + r.stderr
     assert "group after failure equal: True" in r.stdout, r.stdout + r.stderr
+
+
+def test_group_chain_mixed_local_dimensions_and_strict_nesting(t4a):
+    """The group chain with mixed-radix codes (local dimensions 3, 2, 4, 5, 2, 3, 4: the Kronecker step, the parent lookup of the
+    extras and the candidate matrix all depend on the site's dimension) and, in a second group, strictly nested sweeps (no
+    extras): every member against the CPU oracle, not only against its own solo run."""
+    from t4a_amd.functions import lorentz
+    dims = [3, 2, 4, 5, 2, 3, 4]
+    n = len(dims)
+    pivots = [[1, 1, 2, 3, 0, 2, 1], [0, 1, 0, 2, 1, 0, 3], [2, 0, 3, 4, 1, 1, 0]]
+    for strictly in (False, True):
+        opts = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=12, max_iter=6, ncheck_history=10 ** 6, strictly_nested=strictly, **PARITY)
+        spec = lorentz(dims)
+        grouped, oracles = [], []
+        for piv in pivots:
+            g = t4a.TensorCI2(dims)
+            g.set_function(spec)
+            g.add_global_pivots([piv])
+            grouped.append(g)
+            o = ob.OracleTCI2(dims)
+            o.set_function(spec)
+            o.add_global_pivots([piv])
+            o.optimize(opts, final_sweep1site=False)
+            oracles.append(o)
+        t4a.optimize_group(grouped, opts, final_sweep1site=False)
+        for k, (g, o) in enumerate(zip(grouped, oracles)):
+            for p in range(n):
+                assert np.array_equal(g.i_set(p), o.i_set(p)) and np.array_equal(g.j_set(p), o.j_set(p)), (strictly, k, p)
+            assert np.array_equal(g.bond_errors(), o.bond_errors()), (strictly, k)
+            assert g.history()[0] == o.history()[0] and np.array_equal(g.history()[1], o.history()[1]), (strictly, k)
+            st = g.chain_stats()
+            assert st["group_half_sweeps"] > 0 and st["fell_back"] == 0, (strictly, k, st)
