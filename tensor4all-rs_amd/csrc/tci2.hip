@@ -1862,9 +1862,29 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
     OptRun r;
     r.options = options;
     r.final_sweep1site = final_sweep1site;
+    static const bool prof = std::getenv("T4A_OPT_PROF") != nullptr; // host time between two chains (stderr, once per call)
     try {
         opt_begin(r);
-        while (opt_iter_start(r)) opt_iter_finish(r);
+        if (!prof) {
+            while (opt_iter_start(r)) opt_iter_finish(r);
+        } else {
+            double t_start = 0.0, t_finish = 0.0;
+            const double wait0 = g_chain_wait_seconds;
+            size_t iters = 0;
+            for (;;) {
+                const auto ta = std::chrono::steady_clock::now();
+                if (!opt_iter_start(r)) break;
+                const auto tb = std::chrono::steady_clock::now();
+                opt_iter_finish(r);
+                const auto tc = std::chrono::steady_clock::now();
+                t_start += std::chrono::duration<double>(tb - ta).count();
+                t_finish += std::chrono::duration<double>(tc - tb).count();
+                ++iters;
+            }
+            const double wait = g_chain_wait_seconds - wait0;
+            std::fprintf(stderr, "[t4a] optimize: %zu iterations: start (prepare + launch the chain) %.1f us, finish %.1f us of which waiting for the device %.1f us, per iteration\n",
+                         iters, 1e6 * t_start / std::max<size_t>(iters, 1), 1e6 * t_finish / std::max<size_t>(iters, 1), 1e6 * wait / std::max<size_t>(iters, 1));
+        }
         opt_end(r);
     } catch (...) {
         chain_abort(); // (a chain may be in flight: the error came from the fill of the previous iteration)
