@@ -230,7 +230,8 @@ def main():
         rrlu_ms_avg = prof["dom_ms"] / max(prof["dom_launches"], 1)
         bytes_per_launch = prof["dom_bytes"] / max(prof["dom_launches"], 1)
         kname = rrlu_kernel_name(prof["dom_code"])
-        variants = variants_timed
+        variants = [v for v in variants_timed if v["code"] < 10000000]
+        saturated = {int(v["code"]) - 10000000: v for v in variants_timed if v["code"] >= 10000000}  # sub-aggregates, see t4a_gpu.h
         dom = max(variants, key=lambda v: v["ms"]) if variants else None
         dom_steps = dom["steps"] / max(dom["launches"], 1) if dom else float(shapes[N_SITES // 2][2])
         achieved = bytes_per_launch / (rrlu_ms_avg * 1e-3) / 1e9 if rrlu_ms_avg > 0 else 0.0
@@ -302,6 +303,9 @@ def main():
                     "exchange_floor_source": "constant: tools/xcd_bench.hip measured on MI355X (profiles/r02_xcd_bench.log), not re-measured by this run",
                 },
                 "latency_frac": XCD_EXCHANGE_FLOOR_US / max(1e3 * rrlu_ms_avg / max(dom_steps, 1.0), 1e-30),
+                # the launches of this instantiation that ran all chi_max pivot steps (the saturated mid-chain bonds): chain
+                # launches are planned for upper bounds, so the instantiation's average above also contains smaller bonds
+                "saturated_launches": saturated_view(saturated.get(int(prof["dom_code"]))),
                 # every rrLU instantiation of the timed region, and their time-weighted aggregate
                 "all_rrlu_kernels": {
                     "achieved": sum(v["bytes"] for v in variants) / max(sum(v["ms"] for v in variants), 1e-30) / 1e6,
@@ -402,6 +406,15 @@ def site_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier):
                     "shard in the bit-exact mode (SURVEY.md §8e), so N > 1 only shortens the fill",
         }
         print(json.dumps(out), flush=True)
+
+
+def saturated_view(v):
+    if not v or v["launches"] <= 0 or v["ms"] <= 0:
+        return None
+    ms = v["ms"] / v["launches"]
+    by = v["bytes"] / v["launches"]
+    return {"launches": v["launches"], "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by, "achieved": by / (ms * 1e-3) / 1e9,
+            "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "us_per_pivot_step": 1e3 * v["ms"] / max(v["steps"], 1.0)}
 
 
 def rrlu_kernel_name(code):

@@ -686,7 +686,9 @@ t4a_gpu_status t4a_gpu_tci2_profile_reset(t4a_gpu_tci2* h);
 t4a_gpu_status t4a_gpu_tci2_profile_get(const t4a_gpu_tci2* h, double* out /* [T4A_GPU_PROFILE_SLOTS] */);
 /* One row {code, ms, launches, algorithmic bytes, pivot steps} per rrLU kernel instantiation used since the last reset
  * (query-then-fill: out == NULL returns the row count).  code >= 100000: single-XCD kernel,
- * 100000 + RPT*100 + CPT*10 + 4*row_major_ties; otherwise as slot 15 of t4a_gpu_tci2_profile_get. */
+ * 100000 + RPT*100 + CPT*10 + 4*row_major_ties; otherwise as slot 15 of t4a_gpu_tci2_profile_get.  Rows with
+ * code >= 10000000 are SUB-aggregates of row code - 10000000: the launches of a bond chain that ran all max_bond_dim pivot
+ * steps (the saturated bonds of a sweep); they are already contained in their parent row. */
 t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out /* [cap_rows][5] */, size_t cap_rows, size_t* n_rows);
 
 /* Device-side bond chain (the host-free half-sweep of update_pivots, tensorci2.rs:1695-1725 + :1821-2007 for built-in

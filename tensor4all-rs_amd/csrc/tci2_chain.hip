@@ -837,6 +837,13 @@ void Tci2::chain_finish(const TCI2Options& options)
                 vs[1] += 1.0;
                 vs[2] += bytes;
                 vs[3] += rank;
+                if (chain_.chi > 0 && (size_t)rank == chain_.chi) { // sub-aggregate: the launches that ran all max_bond_dim pivot steps
+                    auto& sat = eng.variant_stats_[chain_.plans[b].code + 10000000];
+                    sat[0] += ms;
+                    sat[1] += 1.0;
+                    sat[2] += bytes;
+                    sat[3] += rank;
+                }
             }
         }
         if (abs_max > max_sample_value) max_sample_value = abs_max; // update_max_sample_value over Π (tensorci2.rs:2009-2014)
