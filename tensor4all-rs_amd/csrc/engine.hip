@@ -56,6 +56,24 @@ void xcd_disable()
                              "timed out); the chip-wide kernels take over\n");
 }
 
+// Generation of the single-XCD kernel: 2 (kernels_rrlu_xcd2.hip) unless T4A_XCD_V=1 (A/B measurements).  A launch of the second
+// generation that meets non-finite values gives up with code 2; the caller then runs the first generation for that matrix.
+int xcd_version()
+{
+    static const int v = std::getenv("T4A_XCD_V") ? std::atoi(std::getenv("T4A_XCD_V")) : 2;
+    return v == 1 ? 1 : 2;
+}
+void rrlu_xcd_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream)
+{
+    if (version == 1) rrlu_xcd_launch(plan, args, stream);
+    else rrlu_xcd2_launch(plan, args, stream);
+}
+void rrlu_xcd_group_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream)
+{
+    if (version == 1) rrlu_xcd_group_launch(plan, args, tie_row_major, stream);
+    else rrlu_xcd2_group_launch(plan, args, tie_row_major, stream);
+}
+
 // Placement census (once per process, first Engine): the single-XCD kernel assumes that workgroup b of a grid lands on XCD
 // b % 8 (tools/xcd_bench.hip).  On a partitioned device (CPX / NPS modes), under a CU mask or with fewer than 8 XCCs that does
 // not hold and every launch would spin until its bounded polls give up; better to find out with a 10 us kernel.
@@ -227,6 +245,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     RrluXcdPlan xplan;
     static const bool force_reg = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "reg";
     // first choice: all workgroups on one XCD (exchange through that XCD's L2); disabled for good once a launch timed out
+    const int xcd_v = xcd_retry_v1_ ? 1 : xcd_version();
     const bool use_xcd = !huge && !force_lds && !force_global && !force_reg && !xcd_disabled() &&
                          (rrlu_xcd_make_plan(kM, kN, &xplan, false, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &xplan, false, 32));
     const bool use_reg = !use_xcd && !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
@@ -320,7 +339,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         // a launch has 8 W workgroups of which 7 W pass through the other XCDs and need a free compute unit there for a moment:
         // two handles that each fill (nearly) all 32 compute units of their XCD would block each other's dispatch
         xcd_lock.acquire(xplan.W > kXcdSharedMaxW ? -1 : xcc_);
-        rrlu_xcd_launch(xplan, a, stream_);
+        rrlu_xcd_launch_v(xcd_v, xplan, a, stream_);
         plan_W = xplan.W;
         plan_T = 512;
         plan_code = 100000 + xplan.RPT * 100 + xplan.CPT * 10 + (a.tie_row_major ? 4 : 0);
@@ -523,6 +542,21 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     }
     if (!completed) T4A_HIP(hipStreamSynchronize(stream_));
     xcd_lock.release();
+    if (use_xcd && xcd_v == 2 && reinterpret_cast<const int*>(h_out_.get() + 16)[1] == 2) {
+        // the second-generation kernel met a NaN / an infinity (input or overflow): the first generation implements the
+        // NaN-incumbent rule of matrixlu.rs:480-519; every workgroup of the launch was elected normally, the tickets stay valid
+        T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
+        header_clean_ = false;
+        xcd_retry_v1_ = true;
+        try {
+            LuciResult r1 = luci(d_a_in, M, N, opts, need_factors, want_lu_copy, fused);
+            xcd_retry_v1_ = false;
+            return r1;
+        } catch (...) {
+            xcd_retry_v1_ = false;
+            throw;
+        }
+    }
     if (use_xcd && (reinterpret_cast<const int*>(h_out_.get() + 16)[1] != 0 || reinterpret_cast<const int*>(h_out_.get() + 16)[3] != (int)xcd_salt_)) {
         // the placement assumption of the single-XCD kernel did not hold (or another process holds the compute units):
         // never try it again in this process and run this factorisation with the chip-wide kernels
@@ -791,7 +825,7 @@ unsigned Engine::chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_
         token = chain_group_args(pl, left, d_a, d_dims, max_bond_dim, rel_tol, abs_tol, blk, xcc_, &a, stream_);
         a.rowmap = d_rowmap;
         if (spec) a.spec = *spec;
-        rrlu_xcd_launch(pl.xcd, a, stream_);
+        rrlu_xcd_launch_v(xcd_version(), pl.xcd, a, stream_);
     } else {
         if (++done_token_ == 0u) ++done_token_;
         RrluRegArgs a;

@@ -48,6 +48,9 @@ struct Profile {
 // process-wide arbiter of the persistent multi-workgroup rrLU kernels (engine.hip)
 bool xcd_disabled();
 void xcd_disable();
+int xcd_version(); // generation of the single-XCD rrLU kernel in use (T4A_XCD_V)
+void rrlu_xcd_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
+void rrlu_xcd_group_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
 int xcd_assign();
 int xcd_plan_max_w();
 struct XcdArbiter {
@@ -167,6 +170,7 @@ private:
     unsigned rrlu_salt_ = 0;
     // single-XCD rrLU kernel: elected XCD, mailboxes, monotonic ticket counter
     int xcc_ = 0;
+    bool xcd_retry_v1_ = false; // luci(): this call re-runs a factorisation the second-generation single-XCD kernel gave up on (non-finite values)
     unsigned xcd_salt_ = 0, xcd_ticket_base_ = 0;
     DevBuf<unsigned long long> d_xkeys_; // mailbox of the single-XCD kernel: keys, then column slots
     DevBuf<unsigned> d_xticket_;

@@ -233,6 +233,11 @@ struct RrluXcdGroupArgs {
     RrluXcdArgs p[8];
 };
 void rrlu_xcd_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
+// Second generation of the same kernel (kernels_rrlu_xcd2.hip: one-word record, stop tests and tables off the critical path, no
+// hand-zeroed pivot rows): same plan, arguments and mailbox.  It handles finite matrices only: on a NaN / infinity in the input or
+// an overflow in the trailing block the launch gives up with iresult[1] == 2 and the caller runs the first generation.
+void rrlu_xcd2_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
+void rrlu_xcd2_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // K1: candidate-matrix build (replaces the Π loop, tensor4all-tensorci/src/tensorci2.rs:1859-1893)

@@ -1,0 +1,975 @@
+// kernels_rrlu_xcd2.hip — K2 fast path, round 4: second generation of the single-XCD register-resident full-pivot rrLU.
+//
+// Same contract as kernels_rrlu_xcd.hip (bit-identical to rrlu_mut, tensor4all-core/src/matrixlu.rs:735-819; arg-max semantics
+// matrixlu.rs:480-519; a right-orthogonal factorisation runs as the left-orthogonal one of A^T with the row-major tie order), same
+// placement scheme (8 W workgroups launched, the W that land on the elected XCD take part), same mailbox layout and the same
+// data layout (wave = agent that owns whole columns, lane = rows lane + 64 r).  What changed is the PROTOCOL of a pivot step: the
+// first generation spent ~6 200 cycles per step of which only ~590 are arithmetic — the rest was three serial instruction streams
+// (agents: search; polling wave: pick, stop tests, record; everybody: record decode, tables, pivot row, division).  Here:
+//
+//   * the record that crosses barrier (B) is ONE word: the winning agent.  Every wave fetches the winner's full key
+//     {value, position key, row index, column slot} from the mailbox itself, together with its rows of the winner's column — the
+//     polling wave neither waits for that key nor decodes it for the others;
+//   * the stop tests (matrixlu.rs:757-781) left the critical path: the polling wave evaluates them AFTER barrier (B), while the
+//     other waves divide the column, and publishes the verdict before barrier (C); a stopped step is dropped there, before the
+//     elimination.  The permutation tables are written by the same wave behind its stop test (nothing to undo on a stop);
+//   * the pivot row is never zeroed by hand: l of the pivot row is pivot / pivot = 1.0 exactly, so the rank-1 update itself
+//     leaves exact zeros in the trailing columns (x - 1.0 * x), which is all the self-masking of the first generation needed;
+//   * column positions are not carried in registers: an `active` bit per owned column says whether it is still in the trailing
+//     block, its position comes from an LDS table when a position key is built (normal path: one look-up per step);
+//   * the polling wave owns columns like everybody else but takes no share of the division (seven waves divide);
+//   * NON-FINITE values are not handled here at all: the launch gives up with code 2 (iresult[1]) and the caller runs the
+//     first-generation kernel, which implements the NaN-incumbent rule.  This is exact, not heuristic: a NaN can only appear
+//     in a trailing block after an infinity has (|l| <= 1 under full pivoting, so l * u and a - l * u overflow before anything
+//     becomes NaN), an infinity in the trailing block is some agent's candidate magnitude, and the polling wave sees every
+//     candidate magnitude of every step; NaN / infinity in the INPUT is found while the matrix is loaded and travels in the
+//     first step's keys.  Ties, zeros and subnormal scores are resolved exactly as before (exact sweeps on (v*v, position)).
+#include "kernels_rrlu_xcd_common.hpp"
+
+namespace t4a {
+
+namespace {
+
+// LDS layout of one workgroup (compile-time offsets; the tables are sized for the largest matrix of the plan family)
+template <int RPT> struct Xcd2Lds {
+    static constexpr int LSTR = xcd_lstr(RPT);
+    static constexpr int o_l = 0;                        // double [64][LSTR]: l of row lane + 64 r at lane * LSTR + r
+    static constexpr int o_wd = o_l + 64 * LSTR * 8;     // u64 [2]: largest candidate magnitude (bits) of this workgroup per step parity (T4A_X2_WGSPEC)
+    static constexpr int o_wi = o_wd + 16;               // int [16]: [0] stop verdict [1] give-up (any wave) [3] rank [4..7] record of the step: winning agent | give-up << 30, winner's value lo / hi, meta
+    static constexpr int o_pp = o_wi + 64;               // u64 [2]: iresult / h_block pointers for the give-up paths
+    static constexpr int o_st = o_pp + 16;               // u64 [16] phase stamps (diagnostic builds)
+    static constexpr int o_pv = o_st + 128;              // double [1024] pivot values of this launch
+    static constexpr int o_pr = o_pv + 1024 * 8;         // u16 [1024] position -> row index
+    static constexpr int o_rp = o_pr + 1024 * 2;         // u16 [1024] row index -> position
+    static constexpr int o_pc = o_rp + 1024 * 2;         // u16 [1024] position -> column index
+    static constexpr int o_cp = o_pc + 1024 * 2;         // u16 [1024] column index -> position
+    static constexpr int bytes = o_cp + 1024 * 2;
+};
+static_assert(Xcd2Lds<12>::bytes == (int)xcd_lds_total(12), "plan.lds_bytes must cover the layout");
+
+#ifndef T4A_XCD_STAMP_WAVE
+#define T4A_XCD_STAMP_WAVE 0
+#endif
+// T4A_X2_REC = 1: the polling wave reads the winner's full key and hands it to the other waves in the LDS record (16 bytes);
+// 0: the record is the winning agent alone and every wave fetches the winner's full key from the mailbox itself (232 waves
+// reading one 16-byte granule at the same time: measured slower, the loads queue up in one L2 channel)
+#ifndef T4A_X2_REC
+#define T4A_X2_REC 1
+#endif
+// T4A_X2_WGSPEC = 1: an agent publishes its candidate column speculatively only while its candidate is the largest its workgroup
+// has seen in this step (an LDS atomic maximum per step): the overall winner always is, and the column stores of the others —
+// which queue in front of the polling wave's key loads in the compute unit's memory pipeline — are not issued at all
+#ifndef T4A_X2_WGSPEC
+#define T4A_X2_WGSPEC 0
+#endif
+
+constexpr int X2_DIVW = XWAVES - 1; // waves that divide the pivot column (all but the polling wave)
+
+template <int RPT, int CPT, bool ROWMAJOR>
+__device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
+{
+    static_assert(XWAVES == 8, "the second-generation kernel is written for eight waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using L = Xcd2Lds<RPT>;
+    constexpr int LSTR = L::LSTR;
+    constexpr int MP = 64 * RPT; // rows of a published column slot (rows beyond M carry zeros)
+    double* const lbuf = reinterpret_cast<double*>(smem_raw + L::o_l);
+    int* const ctl = reinterpret_cast<int*>(smem_raw + L::o_wi);
+    unsigned long long* const lds_ptrs = reinterpret_cast<unsigned long long*>(smem_raw + L::o_pp);
+    unsigned long long* const lds_stamps = reinterpret_cast<unsigned long long*>(smem_raw + L::o_st);
+    double* const lds_pivots = reinterpret_cast<double*>(smem_raw + L::o_pv);
+    unsigned short* const posrow = reinterpret_cast<unsigned short*>(smem_raw + L::o_pr);
+    unsigned short* const rowpos = reinterpret_cast<unsigned short*>(smem_raw + L::o_rp);
+    unsigned short* const poscol = reinterpret_cast<unsigned short*>(smem_raw + L::o_pc);
+    unsigned short* const colpos = reinterpret_cast<unsigned short*>(smem_raw + L::o_cp);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long t_entry = (kXcdStamps && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    // ---- election: only the workgroups that landed on the wanted XCD take part ----
+    if (tid == 0) {
+        int rank = -1;
+        if ((int)xcc_id() == p.xcc) {
+            const unsigned t = atomicAdd(p.ticket, 1u) - p.ticket_base;
+            if (t < (unsigned)p.W) rank = (int)t;
+        }
+        ctl[3] = rank;
+        reinterpret_cast<unsigned long long*>(smem_raw + L::o_wd)[0] = 0ull;
+        reinterpret_cast<unsigned long long*>(smem_raw + L::o_wd)[1] = 0ull;
+        ctl[0] = 0;
+        ctl[1] = 0;
+        ctl[2] = 0;
+        lds_ptrs[0] = (unsigned long long)p.iresult;
+        lds_ptrs[1] = (unsigned long long)p.h_block;
+        for (int e = 0; e < 16; ++e) lds_stamps[e] = 0ull;
+    }
+    __syncthreads();
+    const int rank = __builtin_amdgcn_readfirstlane(ctl[3]);
+    if (rank < 0) {
+        // pass-through workgroup (another XCD).  Bond chain: it evaluates its share of the NEXT bond's candidate matrix first
+        if (p.spec.out && p.dims) {
+            const int m_spec = p.dims[2] != 0 ? 0 : (p.dims_swap ? p.dims[1] : p.dims[0]);
+            if (m_spec > 0 && m_spec <= p.M)
+                xcd_spec_work(reinterpret_cast<const XcdSpecArgs*>(kernarg_base() + offsetof(RrluXcdArgs, spec)), m_spec, ctl + 8);
+        }
+        return;
+    }
+    const unsigned long long ts_begin = p.ts_u64 > 0 ? wall_clock64() : 0ull;
+    const unsigned long long t_elected = (kXcdStamps && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int NW = p.W * XWAVES;
+    const int g = rank * XWAVES + wave; // agent id
+    // bond chain: the real dimensions come from device memory (the launch was planned for the upper bounds p.M x p.N: rows
+    // beyond M are padding zeros like those beyond p.M always were, columns beyond N have no owner)
+    int M = p.M, N = p.N, max_steps = p.max_steps;
+    int lda = p.M; // leading dimension of the source matrix
+    if (p.dims) {
+        const int d0 = __builtin_amdgcn_readfirstlane(p.dims[0]), d1 = __builtin_amdgcn_readfirstlane(p.dims[1]);
+        M = p.dims_swap ? d1 : d0;
+        N = p.dims_swap ? d0 : d1;
+        if (M > p.M || N > p.N) M = N = 0; // (cannot happen: the plan is made for upper bounds; never index out of the plan)
+        const int mn = M < N ? M : N;
+        max_steps = max_steps < mn ? max_steps : mn;
+        if (mn <= 0) return; // poisoned bond: nothing to do (no completion token: the next preparation kernel sees that)
+        lda = p.rowmap ? __builtin_amdgcn_readfirstlane(p.dims[3]) : M;
+    }
+    M = __builtin_amdgcn_readfirstlane(M); // (wave-uniform by construction; tell the compiler)
+    N = __builtin_amdgcn_readfirstlane(N);
+    max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+    lda = __builtin_amdgcn_readfirstlane(lda);
+
+    // ---- my columns (per wave): g + NW q; my rows (per lane): lane + 64 r ----
+    unsigned active = 0u; // bit q: column g + NW q exists and is still in the trailing block (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+        if (g + NW * q < N) active |= 1u << q;
+    xvec<RPT> a[CPT]; // ext vectors: the run-time row-slot accesses become s_set_gpr_idx moves
+    double local_sqmax = 0.0;
+    bool bad = false; // a NaN or an infinity among my entries of the input
+    // every load is issued before the first one is consumed (clamped addresses instead of branches): the whole matrix is
+    // one round trip to memory per lane, not RPT * CPT dependent ones
+    int srow[RPT]; // source row of my slot rows (bond chain: through the row map of the speculative candidate matrix)
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = lane + 64 * r;
+        srow[r] = i;
+        if (p.rowmap) srow[r] = p.rowmap[i < M ? i : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = lane + 64 * r;
+            const bool ok = (g + NW * q < N) && i < M;
+            a[q][r] = p.A[ok ? (size_t)(g + NW * q) * lda + srow[r] : (size_t)0];
+        }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = lane + 64 * r;
+            const bool ok = (g + NW * q < N) && i < M;
+            const double v = ok ? a[q][r] : 0.0;
+            const double sqv = v * v; // max sqrt(v*v) == sqrt(max v*v): one square root per lane below
+            if (sqv > local_sqmax) local_sqmax = sqv; // (NaN never enters, like the branchy form)
+            bad |= !((v - v) == 0.0);                 // inf - inf and NaN - NaN are NaN
+            a[q][r] = v;
+        }
+    for (int i = tid; i < M; i += XT) {
+        posrow[i] = (unsigned short)i;
+        rowpos[i] = (unsigned short)i;
+    }
+    for (int j = tid; j < N; j += XT) {
+        poscol[j] = (unsigned short)j;
+        colpos[j] = (unsigned short)j;
+    }
+    for (int e = tid; e < 64 * LSTR; e += XT) lbuf[e] = 0.0;
+    {
+        const double wm = wave_max_f64(sqrt(local_sqmax));
+        if (lane == 0 && wm > 0.0)
+            atomicMax((unsigned long long*)&p.dresult[1], (unsigned long long)__double_as_longlong(wm));
+    }
+    const unsigned wave_bad = __ballot(bad) != 0ull ? 1u : 0u; // travels in the z word of this agent's early keys
+    __syncthreads();
+
+    const bool stamp_on = kXcdStamps && (p.stamps != nullptr) && rank == 0 && tid == 64 * T4A_XCD_STAMP_WAVE;
+    unsigned long long stamp_last = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_loop = stamp_last;
+
+    // one mailbox: [2][NW] early keys (candidate magnitude only), [2][NW] full keys, then [2][NW][MP] column rows (one buffer
+    // resource for every store and load of the exchange)
+    const unsigned k2_base = 2u * (unsigned)NW * 16u;
+    const unsigned cols_base = 4u * (unsigned)NW * 16u;
+    const __amdgpu_buffer_rsrc_t mail =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(cols_base + 2u * (unsigned)NW * (unsigned)MP * 16u), 0x00020000);
+
+    int npiv = 0;
+    double max_error = 0.0;             // kept by the polling waves
+    double error = __builtin_nan("");
+    bool timed_out = false;
+    const double min_pivot_abs = (p.rel_tol == 0.0 && p.abs_tol == 0.0) ? 0.0 : 2.220446049250313e-16;
+    double u[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) u[q] = 0.0;
+    double prev_sq = __builtin_huge_val(); // nobody speculates on the first step
+    // launch constants of the step loop in VECTOR registers (left in the kernel arguments they are re-read in every step)
+    double spec_frac = p.spec_frac, rel_tol_v = p.rel_tol, abs_tol_v = p.abs_tol;
+    asm volatile("" : "+v"(spec_frac), "+v"(rel_tol_v), "+v"(abs_tol_v));
+    constexpr unsigned XSPIN = 1u << 20; // bounded spins: a hand-off that does not arrive makes the launch give up
+
+    // maxima of the untouched matrix for the first arg-max
+    double mq[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        mq[q] = -1.0;
+        if (active & (1u << q)) {
+            double m0 = -1.0, m1 = -1.0;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                if (r & 1) m1 = vmax_abs(m1, a[q][r]);
+                else m0 = vmax_abs(m0, a[q][r]);
+            }
+            mq[q] = vmax(m0, m1);
+        }
+    }
+    // the division of the pivot column is shared by waves 1 .. 7: wave w takes slot rows (w - 1) + 7 j
+    constexpr int XR = (RPT + X2_DIVW - 1) / X2_DIVW;
+    const int sr0 = wave - 1; // first slot row of this wave (-1: the polling wave divides nothing)
+
+    for (int kn = 0; kn < max_steps; ++kn) {
+        const int k = kn - 1; // rows / columns at positions > k form the trailing block searched for pivot kn
+        const int par = kn & 1;
+        const unsigned tag = (p.salt << 16) | (unsigned)(kn + 1);
+        // ---- wave arg-max: (max score, smallest position among the maxima, value there), all wave-uniform ----
+        double m = mq[0];
+#pragma unroll
+        for (int q = 1; q < CPT; ++q) m = vmax(m, mq[q]);
+        const double wmax = wave_max_f64(m);
+        const double sq = wmax * wmax; // the winning score v*v of this agent
+        // ---- early key: the magnitude of the candidate goes out before its position is known.  In the normal case (one
+        // agent holds the largest |v|, its square a normal number) the magnitudes alone decide the winner.  (No candidate: 0,
+        // which sends the pick to the exact path.)  z: this agent met a non-finite input entry (read in the first step only).
+        const int kslot = (par * NW + g) * 16;
+        {
+            const double k1 = (wmax >= 0.0) ? wmax : 0.0;
+            u32x4 kv;
+            kv.x = lo32(k1);
+            kv.y = hi32(k1);
+            kv.z = wave_bad;
+            kv.w = tag ^ kv.x ^ kv.y ^ kv.z;
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0);
+        }
+#if T4A_X2_WGSPEC
+        unsigned long long wg_prev = 0ull; // the largest magnitude this workgroup had seen in this step before mine
+        const unsigned long long wg_mine = (unsigned long long)__double_as_longlong((wmax >= 0.0) ? wmax : 0.0);
+        if (lane == 0)
+            wg_prev = __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(smem_raw + L::o_wd) + par, wg_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+        u32x4 kg[4], kh[4];
+        unsigned wpos = XKEY_NONE;     // position key of the candidate
+        double cval = 0.0;             // its value
+        int cirow = 0, qstar = 0;      // its row index and my column slot
+        if (wmax >= 0.0) {
+            bool done = false;
+            // while v*v is a normal number, distinct |v| have distinct squares, so the equality sweep can compare |v| itself
+            // (and the rows that are already pivoted hold exact zeros in every active column, which cannot match)
+            if ((sq >= 2.2250738585072014e-308) && (sq < __builtin_huge_val())) {
+                unsigned long long bq[CPT];
+                int nhit = 0;
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    bq[q] = __ballot(mq[q] == wmax); // (columns outside the trailing block keep mq = -1)
+                    nhit += __builtin_popcountll(bq[q]);
+                }
+                if (nhit == 1) { // one lane of one column holds the maximum: the normal case
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q)
+                        if (bq[q] != 0ull) {
+                            const int hl = (int)__builtin_ctzll(bq[q]);
+                            // which row slot of that lane: bit RPT - 1 - r of `bits` says slot r holds the maximum
+                            // (compare + add-with-carry per slot: bits = 2 bits + (|a| == wmax))
+                            unsigned bits = 0u;
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r)
+                                asm("v_cmp_eq_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"((double)a[q][r]), "s"(wmax) : "vcc");
+                            const unsigned hb_ = (unsigned)__builtin_amdgcn_readlane((int)bits, hl);
+                            if (__builtin_popcount(hb_) == 1) {
+                                const int rstar = RPT - 1 - (int)__builtin_ctz(hb_);
+                                cirow = hl + 64 * rstar;
+                                const unsigned rp_ = (unsigned)__builtin_amdgcn_readfirstlane((int)rowpos[cirow]);
+                                const unsigned cp_ = (unsigned)__builtin_amdgcn_readfirstlane((int)colpos[g + NW * q]);
+                                wpos = ROWMAJOR ? ((rp_ << 10) | cp_) : ((cp_ << 10) | rp_);
+                                cval = readlane_f64(a[q][rstar], hl);
+                                qstar = q;
+                                done = true;
+                            }
+                        }
+                }
+            }
+            if (!done) {
+                // ties, zero / subnormal scores: exact sweep on the squares (an infinite score ends the launch at the pick)
+                unsigned mypos = XNOPOS;
+                double myval = 0.0;
+                int myrow = 0, myq = 0;
+                const int lane_o = opaque_v(lane), M_o = opaque_s(M); // (nothing of this rare path is hoisted out of the step loop)
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    const bool qhit = (mq[q] >= 0.0) & (mq[q] * mq[q] == sq);
+                    if (__ballot(qhit) != 0ull) {
+                        const unsigned cp_ = colpos[opaque_s(g + NW * q)];
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            const int i = lane_o + 64 * r;
+                            const unsigned rp_ = rowpos[i < M_o ? i : 0];
+                            const unsigned key = ROWMAJOR ? ((rp_ << 10) | cp_) : ((cp_ << 10) | rp_);
+                            const double av = a[q][r];
+                            const double sc = av * av;
+                            const bool hit = qhit & (i < M_o) & ((int)rp_ > k) & (sc == sq);
+                            if (hit && key < mypos) {
+                                mypos = key;
+                                myval = av;
+                                myrow = i;
+                                myq = q;
+                            }
+                        }
+                    }
+                }
+                const unsigned wp = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(mypos));
+                if (wp != XNOPOS) {
+                    const unsigned long long sel = __ballot(mypos == wp);
+                    const int hl = (int)__builtin_ctzll(sel);
+                    wpos = wp;
+                    cval = readlane_f64(myval, hl);
+                    cirow = __builtin_amdgcn_readlane(myrow, hl);
+                    qstar = __builtin_amdgcn_readlane(myq, hl);
+                }
+            }
+        }
+        XSTAMP(1);
+        // ---- full key: value, position, row index, column slot (all fields are wave-uniform) ----
+        {
+            const unsigned meta = wpos | ((unsigned)cirow << 20) | ((unsigned)qstar << 30);
+            u32x4 kv;
+            kv.x = lo32(cval);
+            kv.y = hi32(cval);
+            kv.z = meta;
+            kv.w = tag ^ kv.x ^ kv.y ^ meta;
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, (int)k2_base + kslot, 0, 0);
+        }
+        // the polling wave sweeps the early keys now — they left their agents a whole position search ago, so this first sweep
+        // normally finds them all.  Every lane fetches four keys; lanes beyond NW re-read the last key (a valid duplicate), so
+        // neither the arrival check nor the maximum needs a mask or a count of live groups.
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+        }
+        // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
+        // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
+        // keys have been gathered
+#if T4A_X2_WGSPEC
+        const unsigned long long wg_prev_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wg_prev >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)wg_prev);
+        const bool wg_best = wg_mine >= wg_prev_u;
+#else
+        const bool wg_best = true;
+#endif
+        const bool early_pub = (wave != 0) && wg_best && (wpos != XKEY_NONE) && (sq >= spec_frac * prev_sq); // (the polling wave never stores a column early: those stores would sit in front of its key loads)
+        const int myslot = (int)cols_base + ((par * NW + g) * MP + lane) * 16; // byte offset of my row `lane` in the mailbox
+        if (early_pub) {
+            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag);
+            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag);
+            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag);
+            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag);
+        }
+        XSTAMP(2);
+
+        // ---- wave 0 gathers the NW early keys and names the winner (matrixlu.rs:480-519 across agents) ----
+        if (wave == 0) {
+            unsigned spins = 0;
+            int giveup = 0; // 1: a hand-off did not arrive  2: non-finite values (the caller runs the first-generation kernel)
+            XSTAMP(6);
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ok &= ((kg[j].x ^ kg[j].y ^ kg[j].z ^ kg[j].w) == tag);
+                if (__all(ok)) break;
+                xcd_poll_again();
+                if (++spins > XSPIN) {
+                    giveup = 1;
+                    break;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+            }
+            if (stamp_on) lds_stamps[5] += spins;
+#if T4A_X2_REC
+            // the full keys: fetched now, in flight while the early ones are examined (a late one is fetched again below)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+#endif
+            XSTAMP(8);
+            int wa_ = 0;
+            unsigned wkx = 0u, wky = 0u, wkz = 0u; // the winner's full key (T4A_X2_REC)
+            if (!giveup) {
+                if (kn == 0) { // non-finite entries in the input: met by their owners while the matrix was loaded
+                    unsigned zf = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zf |= kg[j].z;
+                    if (__ballot(zf != 0u) != 0ull) giveup = 2;
+                }
+                // winner over all agents.  Normal case: the largest candidate magnitude, its square a normal number (distinct
+                // |v| <=> distinct scores), held by exactly one early key: one maximum reduction decides.  (A duplicate of the
+                // last key can only push the count above one: then the exact path decides.  No candidate travels as 0.)
+                bool decided = false;
+                double lm = -1.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lm = vmax(lm, mk_f64(kg[j].x, kg[j].y));
+                const double gm = wave_max_f64(lm);
+                const double gsq = gm * gm;
+                if ((gsq >= 2.2250738585072014e-308) && (gsq < __builtin_huge_val())) {
+                    unsigned long long hb[4];
+                    int nh = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hb[j] = __ballot(mk_f64(kg[j].x, kg[j].y) == gm);
+                        nh += __builtin_popcountll(hb[j]);
+                    }
+                    if (nh == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (hb[j] != 0ull) {
+                                const int hl = (int)__builtin_ctzll(hb[j]);
+                                wa_ = hl + 64 * j;
+#if T4A_X2_REC
+                                // the winner's full key: normally long there; otherwise fetched again until it is
+                                for (;;) {
+                                    wkx = (unsigned)__builtin_amdgcn_readlane((int)kh[j].x, hl);
+                                    wky = (unsigned)__builtin_amdgcn_readlane((int)kh[j].y, hl);
+                                    wkz = (unsigned)__builtin_amdgcn_readlane((int)kh[j].z, hl);
+                                    const unsigned kw = (unsigned)__builtin_amdgcn_readlane((int)kh[j].w, hl);
+                                    if ((wkx ^ wky ^ wkz ^ kw) == tag) break;
+                                    xcd_poll_again();
+                                    if (++spins > XSPIN) {
+                                        giveup = 1;
+                                        break;
+                                    }
+                                    kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                                }
+#endif
+                            }
+                        decided = true;
+                    }
+                } else if (!(gsq < __builtin_huge_val())) {
+                    giveup = 2; // an infinite score: overflow in the trailing block (or an infinite input)
+                }
+                XSTAMP(14);
+                if (!decided && !giveup) {
+                    // ties between agents, zero / subnormal scores: exact comparison of (v*v, position key) over the FULL keys;
+                    // an agent without candidate carries value 0 and the largest position key
+#if !T4A_X2_REC
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+#endif
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ok &= ((kh[j].x ^ kh[j].y ^ kh[j].z ^ kh[j].w) == tag);
+                        if (__all(ok)) break;
+                        xcd_poll_again();
+                        if (++spins > XSPIN) {
+                            giveup = 1;
+                            break;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                    }
+                    double csc = -1.0;
+                    unsigned cpk = XNOPOS;
+                    int cag = 0;
+                    u32x4 ckey = kh[0];
+                    const int lane_o = opaque_v(lane);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ag = lane_o + 64 * j;
+                        const unsigned pk = (ag < NW) ? (kh[j].z & 0xFFFFFu) : XNOPOS;
+                        const double v = mk_f64(kh[j].x, kh[j].y);
+                        double sc = v * v;
+                        sc = (ag < NW) ? sc : -2.0;
+                        const bool better = (sc > csc) | ((sc == csc) & (pk < cpk));
+                        csc = better ? sc : csc;
+                        cpk = better ? pk : cpk;
+                        cag = better ? ag : cag;
+                        ckey.x = better ? kh[j].x : ckey.x;
+                        ckey.y = better ? kh[j].y : ckey.y;
+                        ckey.z = better ? kh[j].z : ckey.z;
+                    }
+                    const double gmax = wave_max_f64(csc);
+                    const unsigned gpos = wave_min_u32((csc == gmax) ? cpk : XNOPOS);
+                    const unsigned long long sel = __ballot((csc == gmax) & (cpk == gpos));
+                    const int wl = sel ? (int)__builtin_ctzll(sel) : 0;
+                    wa_ = __builtin_amdgcn_readlane(cag, wl);
+                    wkx = (unsigned)__builtin_amdgcn_readlane((int)ckey.x, wl);
+                    wky = (unsigned)__builtin_amdgcn_readlane((int)ckey.y, wl);
+                    wkz = (unsigned)__builtin_amdgcn_readlane((int)ckey.z, wl);
+                }
+            }
+            if (lane == 0) {
+                if (giveup) {
+                    ctl[1] = giveup;
+                    atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, giveup);
+                    if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = giveup;
+                }
+#if T4A_X2_REC
+                int4 rec;
+                rec.x = wa_ | (giveup << 30);
+                rec.y = (int)wkx;
+                rec.z = (int)wky;
+                rec.w = (int)wkz;
+                *reinterpret_cast<int4*>(ctl + 4) = rec;
+#else
+                ctl[4] = wa_ | (giveup << 30);
+#endif
+            }
+            XSTAMP(9);
+        }
+        __syncthreads(); // (B)
+        XSTAMP(3);
+#if T4A_X2_REC
+        int4 rec; // the record in ONE LDS round trip
+        {
+            int zero = 0;
+            asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rec) : "v"(zero), "n"(L::o_wi + 16) : "memory");
+        }
+        const unsigned recw = (unsigned)__builtin_amdgcn_readfirstlane(rec.x);
+#else
+        int rec1;
+        {
+            int zero = 0;
+            asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rec1) : "v"(zero), "n"(L::o_wi + 16) : "memory");
+        }
+        const unsigned recw = (unsigned)__builtin_amdgcn_readfirstlane(rec1);
+#endif
+        if (recw >> 30) {
+            timed_out = true;
+            break;
+        }
+        const int wag = (int)recw;
+        // the winner did not speculate: its column goes out now
+        if (g == wag && !early_pub) {
+            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag);
+            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag);
+            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag);
+            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag);
+        }
+        // everybody fetches the winner's full key (one granule, the same for all lanes) and — waves 1 .. 7 — its rows of the
+        // winner's column: lane + 64 (sr0 + 7 j)
+#if !T4A_X2_REC
+        const int fk_off = (int)k2_base + (par * NW + wag) * 16;
+        u32x4 fk = __builtin_amdgcn_raw_buffer_load_b128(mail, fk_off, 0, BUF_SC1);
+#endif
+        const int slot_off = (int)cols_base + ((par * NW + wag) * MP + lane + 64 * sr0) * 16;
+        u32x4 cc[XR];
+#pragma unroll
+        for (int j = 0; j < XR; ++j)
+            if (sr0 >= 0 && sr0 + X2_DIVW * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 64 * 16, 0, BUF_SC1);
+        // who sits at position kn now (the polling wave moves them behind its stop test)
+        int rk_ = 0, ck_ = 0;
+        if (wave == 0) {
+            rk_ = posrow[kn];
+            ck_ = poscol[kn];
+#if T4A_X2_WGSPEC
+            if (lane == 0) reinterpret_cast<unsigned long long*>(smem_raw + L::o_wd)[1 - par] = 0ull; // (next step's maximum: nobody touches it between barriers (B) and (C))
+#endif
+        }
+#if T4A_X2_REC
+        const double wval = mk_f64((unsigned)__builtin_amdgcn_readfirstlane(rec.y), (unsigned)__builtin_amdgcn_readfirstlane(rec.z));
+        const unsigned wmeta = (unsigned)__builtin_amdgcn_readfirstlane(rec.w);
+#else
+        {
+            unsigned spins = 0;
+            while ((fk.x ^ fk.y ^ fk.z ^ fk.w) != tag) {
+                xcd_poll_again();
+                if (++spins > XSPIN) {
+                    atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
+                    if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
+                    ctl[1] = 1; // observed by everybody after barrier (C)
+                    break;
+                }
+                fk = __builtin_amdgcn_raw_buffer_load_b128(mail, fk_off, 0, BUF_SC1);
+            }
+        }
+        const double wval = mk_f64((unsigned)__builtin_amdgcn_readfirstlane((int)fk.x), (unsigned)__builtin_amdgcn_readfirstlane((int)fk.y));
+        const unsigned wmeta = (unsigned)__builtin_amdgcn_readfirstlane((int)fk.z);
+#endif
+        const int irow_p = (int)((wmeta >> 20) & 1023u);
+        const int qslot = (int)(wmeta >> 30);
+        XSTAMP(10);
+        // (the shared reciprocal of the pivot does not depend on the column: it is formed while the column travels)
+        const bool p_mid = exp_mid(wval);
+        const double rp = refined_rcp(wval);
+        prev_sq = wval * wval;
+        {
+            // the pivot row: its entries in the columns of the trailing block (and the pivot column) are the finished row kn
+            // of U.  They are broadcast as u and saved to the side buffer.  The row itself is NOT touched: its l is
+            // pivot / pivot = 1.0, so the rank-1 update below leaves exact zeros (x - 1.0 x) in every column that stays in the
+            // trailing block — from then on the row takes part as l = 0 / a = 0 without any row mask.
+            const int ls = irow_p & 63, rs = irow_p >> 6;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q)
+                if (active & (1u << q)) {
+                    u[q] = readlane_f64(a[q][rs], ls);
+                    if (p.urows && lane == ls) p.urows[(unsigned)(kn * N + (g + NW * q))] = u[q];
+                }
+        }
+        if (g == wag) active &= ~(1u << qslot); // the pivot column leaves the trailing block (its registers keep the un-scaled column)
+        if (wave == 0) {
+            // stop tests on the pivot magnitude sqrt(v*v), in the reference's order (matrixlu.rs:757-781); while v*v is a normal
+            // number the square root of the rounded square is |v| itself (the software square root stays on the cold path)
+            const double wsq = wval * wval;
+            double pivot_abs = __builtin_fabs(wval);
+            if (!(wsq >= 2.2250738585072014e-308 && wsq < __builtin_huge_val())) pivot_abs = sqrt(mk_f64((unsigned)opaque_v((int)lo32(wsq)), hi32(wsq)));
+            error = pivot_abs;
+            int stop = 0;
+            if (kn > 0 && (pivot_abs < rel_tol_v * max_error || pivot_abs < abs_tol_v)) stop = 1;
+            else if (pivot_abs <= min_pivot_abs) stop = 1;
+            else max_error = fmax(max_error, pivot_abs);
+            if (lane == 0) {
+                if (stop) {
+                    ctl[0] = 1;
+                } else {
+                    // permutation bookkeeping (swap_rows / swap_cols of the reference as index tables): the row / column that
+                    // sat at position kn moves to the pivot's old position, the pivot's to kn
+                    const unsigned wkey = wmeta & 0xFFFFFu;
+                    const int prp = (int)(ROWMAJOR ? (wkey >> 10) : (wkey & 1023u));
+                    const int pcp = (int)(ROWMAJOR ? (wkey & 1023u) : (wkey >> 10));
+                    const int pc = wag + NW * qslot; // original index of the pivot column
+                    posrow[prp] = (unsigned short)rk_;
+                    posrow[kn] = (unsigned short)irow_p;
+                    rowpos[rk_] = (unsigned short)prp;
+                    rowpos[irow_p] = (unsigned short)kn;
+                    poscol[pcp] = (unsigned short)ck_;
+                    poscol[kn] = (unsigned short)pc;
+                    colpos[ck_] = (unsigned short)pcp;
+                    colpos[pc] = (unsigned short)kn;
+                    lds_pivots[kn] = wval;
+                }
+            }
+        }
+        XSTAMP(11);
+
+        // ---- pivot column -> l = column / pivot, parked in LDS for everybody ----
+        if (sr0 >= 0) {
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < XR; ++j)
+                    if (sr0 + X2_DIVW * j < RPT) ok &= ((cc[j].x ^ cc[j].y ^ cc[j].z ^ cc[j].w) == tag);
+                if (__all(ok)) break;
+                xcd_poll_again();
+                if (++spins > XSPIN) {
+                    atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
+                    if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
+                    ctl[1] = 1; // observed by everybody after barrier (C)
+                    break;
+                }
+#pragma unroll
+                for (int j = 0; j < XR; ++j)
+                    if (sr0 + X2_DIVW * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 64 * 16, 0, BUF_SC1);
+            }
+            XSTAMP(12);
+            // x / p through the shared refined reciprocal (bitwise the IEEE quotient, see refined_rcp); zeros keep the sign
+            // rule through x * rp; anything unusual takes the full division
+            double lq[XR];
+            bool slow = false;
+#pragma unroll
+            for (int j = 0; j < XR; ++j) {
+                lq[j] = 0.0;
+                if (sr0 + X2_DIVW * j < RPT) {
+                    const double x = mk_f64(cc[j].x, cc[j].y);
+                    const double q0 = x * rp;
+                    const double qf = __builtin_fma(__builtin_fma(-wval, q0, x), rp, q0);
+                    lq[j] = (x == 0.0) ? q0 : qf;
+                    slow |= !(p_mid & (exp_mid(x) | (x == 0.0)));
+                }
+            }
+            if (__ballot(slow) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < XR; ++j)
+                    if (sr0 + X2_DIVW * j < RPT) {
+                        const double x = mk_f64(cc[j].x, cc[j].y);
+                        if (!(p_mid & (exp_mid(x) | (x == 0.0)))) lq[j] = x / wval;
+                    }
+            }
+            // (rows pivoted before hold exact zeros in the published column: l = 0; the pivot row gets pivot / pivot = 1;
+            // slot rows beyond M are zeros divided by the pivot)
+#pragma unroll
+            for (int j = 0; j < XR; ++j)
+                if (sr0 + X2_DIVW * j < RPT) lbuf[lane * LSTR + sr0 + X2_DIVW * j] = lq[j];
+        }
+        XSTAMP(4);
+        __syncthreads(); // (C)
+        XSTAMP(13);
+        // the verdicts first (one LDS read in front of the l reads: the wait for it leaves those in flight)
+        int2 fl; // [0] stop verdict [1] give-up
+        {
+            static_assert(L::o_wi % 8 == 0, "the verdict pair is read with one 8-byte LDS load");
+            int zero = 0;
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(fl) : "v"(zero), "n"(L::o_wi) : "memory");
+        }
+        xvec<RPT> l;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) l[r] = lbuf[lane * LSTR + r];
+        {
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fl) : "n"((RPT + 1) / 2) : "memory");
+            if (__builtin_amdgcn_readfirstlane(fl.y)) {
+                timed_out = true;
+                break;
+            }
+            if (__builtin_amdgcn_readfirstlane(fl.x)) break; // stopped: pivot kn is not applied
+        }
+        XSTAMP(7);
+        // =====================================================================================
+        // elimination step kn: the trailing block gets the rank-1 update (update_trailing_submatrix, matrixlu.rs:593-612)
+        // fused with the per-column maxima for the next arg-max; the pivot column keeps its un-scaled entries (L = column /
+        // pivot is formed when the factored matrix is written out — the column is never read again)
+        // =====================================================================================
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            mq[q] = -1.0;
+            if (active & (1u << q)) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) { // in place (see sub_in_place); un-fused, one rounding per operation like the reference
+                    double t = a[q][r];
+                    sub_in_place(t, l[r] * u[q]);
+                    a[q][r] = t;
+                }
+                double m0 = -1.0, m1 = -1.0;
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    if (r & 1) m1 = vmax_abs(m1, a[q][r]);
+                    else m0 = vmax_abs(m0, a[q][r]);
+                }
+                mq[q] = vmax(m0, m1);
+            }
+        }
+        npiv = kn + 1;
+        XSTAMP(0);
+    }
+
+    // ---- results ----
+    const unsigned long long t_done = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+    __syncthreads(); // (a give-up of the last step, the tables of the last applied step)
+    if (ctl[1]) timed_out = true;
+    if (npiv >= (M < N ? M : N)) error = 0.0; // matrixlu.rs:811-813
+    if (rank == 0 && tid == 0) {
+        p.iresult[0] = npiv;
+        p.dresult[0] = error; // tid 0 belongs to the polling wave, which keeps the error
+    }
+    if (stamp_on) {
+        for (int e = 0; e < 16; ++e) p.stamps[e] = lds_stamps[e];
+        p.stamps[16] = t_elected - t_entry; // fixed part of a launch: election ...
+        p.stamps[17] = t_loop - t_elected;  // ... matrix load, tables, first maxima ...
+        p.stamps[18] = t_done - t_loop;     // (the pivot steps)
+    }
+    if (timed_out) return;
+    // permutations: the tables are stable since the last barrier; device block and host mirror are written side by side
+    if (rank == 0) {
+        int* const h_rp = p.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(p.h_block) + (reinterpret_cast<const char*>(p.row_perm) - reinterpret_cast<const char*>(p.dresult))) : nullptr;
+        int* const h_cp = p.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(p.h_block) + (reinterpret_cast<const char*>(p.col_perm) - reinterpret_cast<const char*>(p.dresult))) : nullptr;
+        for (int i = tid; i < M; i += XT) {
+            const int v = posrow[i];
+            p.row_perm[i] = v;
+            if (h_rp) h_rp[i] = v;
+        }
+        for (int j = tid; j < N; j += XT) {
+            const int v = poscol[j];
+            p.col_perm[j] = v;
+            if (h_cp) h_cp[j] = v;
+        }
+        unsigned long long* const h_pv = p.h_block ? p.h_block + (reinterpret_cast<const char*>(p.pivot_vals) - reinterpret_cast<const char*>(p.dresult)) / 8 : nullptr;
+        for (int e = tid; e < npiv; e += XT) {
+            const double v = lds_pivots[e];
+            p.pivot_vals[e] = v;
+            if (h_pv) h_pv[e] = (unsigned long long)__double_as_longlong(v);
+        }
+    }
+    // factored matrix in permuted coordinates: rows of U come from the side buffer (this wave wrote them itself), the rest
+    // (L below the diagonal, the untouched trailing block) from the registers.  (Rows pivoted before hold zeros in the columns
+    // that stayed in the trailing block: those entries are rows of U and come from the side buffer.)
+    int nan_seen = 0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = lane + 64 * r;
+            if (g + NW * q < N && i < M) {
+                const int cp = colpos[g + NW * q], rp = rowpos[i];
+                const bool from_u = (rp < npiv) && (cp >= rp);
+                double v = a[q][r];
+                const bool in_l = (cp < npiv) && (rp > cp);
+                if (in_l) { // scale_column_tail (matrixlu.rs:562-577), deferred: the same division the step itself used
+                    const double pv = lds_pivots[cp];
+                    v = xcd_div(v, pv, refined_rcp(pv), exp_mid(pv));
+                    if (v != v) nan_seen = 1;
+                }
+                if (p.Aout) {
+                    if (from_u)
+                        v = __longlong_as_double((long long)__hip_atomic_load(
+                            reinterpret_cast<const unsigned long long*>(p.urows) + ((size_t)rp * N + (g + NW * q)), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT));
+                    if (p.out_transposed)
+                        p.Aout[(size_t)rp * N + cp] = v;
+                    else
+                        p.Aout[(size_t)cp * M + rp] = v;
+                }
+            }
+        }
+    if (nan_seen) {
+        atomicExch(&p.iresult[2], 1);
+        if (p.h_block) ((volatile int*)p.h_block)[6] = 1;
+    }
+    // host-visible header (the pivot values went to the mirror with the permutations, the two flag words belong to their setters)
+    if (p.h_block && rank == 0 && tid == 0) {
+        p.h_block[0] = (unsigned long long)__double_as_longlong(error);
+        p.h_block[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.dresult) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ((volatile int*)p.h_block)[4] = npiv;
+        // completion token: the host accepts the result only if rank 0 ran to its end in THIS launch (a launch whose
+        // workgroups never met the elected XCD would otherwise leave an all-zero block behind)
+        ((volatile int*)p.h_block)[7] = (int)p.salt;
+        if (p.ts_u64 > 0) {
+            p.h_block[p.ts_u64] = ts_begin;
+            p.h_block[p.ts_u64 + 1] = wall_clock64();
+        }
+        reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull; // clean header for the next launch (every agent's atomicMax is long done)
+        if (p.dims) { // bond chain: the device-side completion token for the next preparation kernel (max |a| stays in the mirror)
+            __threadfence();
+            p.iresult[3] = (int)p.salt;
+        }
+        if (stamp_on) p.stamps[19] = __builtin_amdgcn_s_memtime() - t_done; // ... write-out and host mirror
+    }
+    // bond chain without per-launch host mirror: the device block is complete as it is (error, max |a|, rank, flags, pivot
+    // values, permutations) and is copied to the host once, behind the whole chain; it only lacks the time stamps and the token
+    if (!p.h_block && p.dims && rank == 0 && tid == 0) {
+        if (p.ts_u64 > 0) {
+            unsigned long long* const blk = reinterpret_cast<unsigned long long*>(p.dresult);
+            blk[p.ts_u64] = ts_begin;
+            blk[p.ts_u64 + 1] = wall_clock64();
+        }
+        __threadfence();
+        p.iresult[3] = (int)p.salt;
+    }
+}
+
+#ifndef T4A_XCD_GROUP_TU
+template <int RPT, int CPT, bool ROWMAJOR>
+__global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd2_kernel(RrluXcdArgs p)
+{
+    rrlu_xcd2_body<RPT, CPT, ROWMAJOR>(p);
+}
+template <int RPT, int CPT, bool ROWMAJOR> void xcd2_launch_tie(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    static std::once_flag attr_once; // (launches come from several host threads)
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_xcd2_kernel<RPT, CPT, ROWMAJOR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL((rrlu_xcd2_kernel<RPT, CPT, ROWMAJOR>), dim3(plan.grid), dim3(XT), plan.lds_bytes, stream, a);
+}
+
+template <int RPT, int CPT> void xcd2_launch_rc(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    if (a.tie_row_major) xcd2_launch_tie<RPT, CPT, true>(plan, a, stream);
+    else xcd2_launch_tie<RPT, CPT, false>(plan, a, stream);
+}
+
+template <int RPT> void xcd2_launch_r(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    switch (plan.CPT) {
+    case 1: xcd2_launch_rc<RPT, 1>(plan, a, stream); break;
+    case 2: xcd2_launch_rc<RPT, 2>(plan, a, stream); break;
+    case 3: if constexpr (RPT * 3 <= XCD_MAX_VALUES) xcd2_launch_rc<RPT, 3>(plan, a, stream); break;
+    default: if constexpr (RPT * 4 <= XCD_MAX_VALUES) xcd2_launch_rc<RPT, 4>(plan, a, stream); break;
+    }
+}
+
+#else
+// Group launch: eight factorisations, one per XCD (see rrlu_xcd_group_kernel in kernels_rrlu_xcd.hip)
+template <int RPT, int CPT, bool ROWMAJOR>
+__global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd2_group_kernel(RrluXcdGroupArgs g)
+{
+    (void)g;
+    const unsigned x = (unsigned)__builtin_amdgcn_readfirstlane((int)xcc_id()) & 7u;
+    rrlu_xcd2_body<RPT, CPT, ROWMAJOR>(*reinterpret_cast<const RrluXcdArgs*>(kernarg_base() + (size_t)x * sizeof(RrluXcdArgs)));
+}
+
+template <int RPT, int CPT, bool ROWMAJOR> void xcd2_group_launch_tie(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, hipStream_t stream)
+{
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_xcd2_group_kernel<RPT, CPT, ROWMAJOR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL((rrlu_xcd2_group_kernel<RPT, CPT, ROWMAJOR>), dim3(plan.grid), dim3(XT), plan.lds_bytes, stream, a);
+}
+template <int RPT, int CPT> void xcd2_group_launch_rc(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, bool row_major, hipStream_t stream)
+{
+    if (row_major) xcd2_group_launch_tie<RPT, CPT, true>(plan, a, stream);
+    else xcd2_group_launch_tie<RPT, CPT, false>(plan, a, stream);
+}
+template <int RPT> void xcd2_group_launch_r(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, bool row_major, hipStream_t stream)
+{
+    switch (plan.CPT) {
+    case 1: xcd2_group_launch_rc<RPT, 1>(plan, a, row_major, stream); break;
+    case 2: xcd2_group_launch_rc<RPT, 2>(plan, a, row_major, stream); break;
+    case 3: if constexpr (RPT * 3 <= XCD_MAX_VALUES) xcd2_group_launch_rc<RPT, 3>(plan, a, row_major, stream); break;
+    default: if constexpr (RPT * 4 <= XCD_MAX_VALUES) xcd2_group_launch_rc<RPT, 4>(plan, a, row_major, stream); break;
+    }
+}
+
+#endif
+
+} // namespace
+
+#ifndef T4A_XCD_GROUP_TU
+void rrlu_xcd2_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    switch (plan.RPT) {
+#ifdef T4A_XCD_DEV
+    case 2: xcd2_launch_r<2>(plan, a, stream); break;
+    default: xcd2_launch_r<12>(plan, a, stream); break;
+#else
+    case 1: xcd2_launch_r<1>(plan, a, stream); break;
+    case 2: xcd2_launch_r<2>(plan, a, stream); break;
+    case 3: xcd2_launch_r<3>(plan, a, stream); break;
+    case 4: xcd2_launch_r<4>(plan, a, stream); break;
+    case 6: xcd2_launch_r<6>(plan, a, stream); break;
+    case 8: xcd2_launch_r<8>(plan, a, stream); break;
+    case 12: xcd2_launch_r<12>(plan, a, stream); break;
+    default: xcd2_launch_r<16>(plan, a, stream); break;
+#endif
+    }
+}
+#else
+// (this half of the file is compiled as its own translation unit: kernels_rrlu_xcd2_group.hip)
+void rrlu_xcd2_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, bool tie_row_major, hipStream_t stream)
+{
+    switch (plan.RPT) {
+    case 1: xcd2_group_launch_r<1>(plan, a, tie_row_major, stream); break;
+    case 2: xcd2_group_launch_r<2>(plan, a, tie_row_major, stream); break;
+    case 3: xcd2_group_launch_r<3>(plan, a, tie_row_major, stream); break;
+    case 4: xcd2_group_launch_r<4>(plan, a, tie_row_major, stream); break;
+    case 6: xcd2_group_launch_r<6>(plan, a, tie_row_major, stream); break;
+    case 8: xcd2_group_launch_r<8>(plan, a, tie_row_major, stream); break;
+    case 12: xcd2_group_launch_r<12>(plan, a, tie_row_major, stream); break;
+    default: xcd2_group_launch_r<16>(plan, a, tie_row_major, stream); break;
+    }
+}
+#endif
+
+} // namespace t4a

@@ -701,7 +701,7 @@ void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
                 h->chain_.tokens[b] = h->eng.chain_group_args(gplans[b], forward, h->chain_.pi.get(), h->chain_.common.dims + b * 4, h->chain_.chi,
                                                               h->chain_.tol, 0.0, block_of(h, b), (int)i, &ga.p[i], st);
             }
-            rrlu_xcd_group_launch(gplans[b].xcd, ga, !forward, st);
+            rrlu_xcd_group_launch_v(xcd_version(), gplans[b].xcd, ga, !forward, st);
         }
         { // the pivots of the last bond
             ChainPrepGroupArgs pg;
@@ -788,7 +788,7 @@ void Tci2::chain_finish(const TCI2Options& options)
         }
         if (hi[1] != 0 || hi[3] != (int)chain_.tokens[b]) {
             failed_k = (long)k;
-            failed_timeout = true;
+            failed_timeout = hi[1] != 2; // (2: the second-generation single-XCD kernel met non-finite values: the per-bond path handles them, nothing is wrong with the placement)
             break;
         }
         if (hi[2] != 0) { // NaN in L or U (matrixlu.rs:614-668): the per-bond path reports it before it touches the sets of this bond
