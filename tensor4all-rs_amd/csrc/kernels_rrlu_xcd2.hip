@@ -34,7 +34,7 @@ namespace {
 template <int RPT> struct Xcd2Lds {
     static constexpr int LSTR = xcd_lstr(RPT);
     static constexpr int o_l = 0;                        // double [64][LSTR]: l of row lane + 64 r at lane * LSTR + r
-    static constexpr int o_wd = o_l + 64 * LSTR * 8;     // u64 [2]: largest candidate magnitude (bits) of this workgroup per step parity (T4A_X2_WGSPEC)
+    static constexpr int o_wd = o_l + 64 * LSTR * 8;     // (16 bytes, unused)
     static constexpr int o_wi = o_wd + 16;               // int [16]: [0] stop verdict [1] give-up (any wave) [3] rank [4..7] record of the step: winning agent | give-up << 30, winner's value lo / hi, meta
     static constexpr int o_pp = o_wi + 64;               // u64 [2]: iresult / h_block pointers for the give-up paths
     static constexpr int o_st = o_pp + 16;               // u64 [16] phase stamps (diagnostic builds)
@@ -50,18 +50,32 @@ static_assert(Xcd2Lds<12>::bytes == (int)xcd_lds_total(12), "plan.lds_bytes must
 #ifndef T4A_XCD_STAMP_WAVE
 #define T4A_XCD_STAMP_WAVE 0
 #endif
-// T4A_X2_REC = 1: the polling wave reads the winner's full key and hands it to the other waves in the LDS record (16 bytes);
-// 0: the record is the winning agent alone and every wave fetches the winner's full key from the mailbox itself (232 waves
-// reading one 16-byte granule at the same time: measured slower, the loads queue up in one L2 channel)
-#ifndef T4A_X2_REC
-#define T4A_X2_REC 1
-#endif
-// T4A_X2_WGSPEC = 1: an agent publishes its candidate column speculatively only while its candidate is the largest its workgroup
-// has seen in this step (an LDS atomic maximum per step): the overall winner always is, and the column stores of the others —
-// which queue in front of the polling wave's key loads in the compute unit's memory pipeline — are not issued at all
-#ifndef T4A_X2_WGSPEC
-#define T4A_X2_WGSPEC 0
-#endif
+
+// maximum of a signed 32-bit value over the 64 lanes, in lane 63 (DPP row reductions folded into v_max_i32: lanes without a
+// source keep INT_MIN, the identity).  Non-negative doubles order like their high words first: the reductions of the step loop
+// run on the high word and fall back to the 64-bit comparison only when it does not single out one lane.
+template <int CTRL> __device__ __forceinline__ int dpp_max_i32(int v)
+{
+    const int o = __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xF, 0xF, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = dpp_max_i32<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = dpp_max_i32<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = dpp_max_i32<0x141>(v); // row_half_mirror
+    v = dpp_max_i32<0x140>(v); // row_mirror: every lane of a row holds the row maximum
+    v = dpp_max_i32<0x142>(v); // row_bcast15
+    v = dpp_max_i32<0x143>(v); // row_bcast31 -> lane 63 holds the wave maximum
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// biased exponent of a non-negative double's high word within [600, 1500]: the square is a normal number with room to spare
+__device__ __forceinline__ bool hi_mid(int hi) { return (unsigned)((hi >> 20) - 600) <= 900u; }
+
+// full-key meta word (second generation): bits 0..9 row index of the candidate, 10..11 column slot of the publishing agent,
+// bit 12 the agent has a candidate.  Positions are NOT carried: whoever needs one reads the LDS tables (the polling wave behind
+// its stop test; the exact comparison of the rare paths).
+constexpr unsigned X2_META_VALID = 1u << 12;
 
 constexpr int X2_DIVW = XWAVES - 1; // waves that divide the pivot column (all but the polling wave)
 
@@ -96,8 +110,6 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
             if (t < (unsigned)p.W) rank = (int)t;
         }
         ctl[3] = rank;
-        reinterpret_cast<unsigned long long*>(smem_raw + L::o_wd)[0] = 0ull;
-        reinterpret_cast<unsigned long long*>(smem_raw + L::o_wd)[1] = 0ull;
         ctl[0] = 0;
         ctl[1] = 0;
         ctl[2] = 0;
@@ -245,7 +257,11 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
         double m = mq[0];
 #pragma unroll
         for (int q = 1; q < CPT; ++q) m = vmax(m, mq[q]);
-        const double wmax = wave_max_f64(m);
+        // (m >= 0, or -1 without a column in the trailing block: the high words order like the values)
+        const int whi = wave_max_i32((int)hi32(m));
+        const unsigned long long whb = __ballot((int)hi32(m) == whi);
+        const bool hi_single = __builtin_popcountll(whb) == 1; // one lane holds the largest high word: it holds the maximum
+        const double wmax = hi_single ? readlane_f64(m, (int)__builtin_ctzll(whb)) : wave_max_f64(m);
         const double sq = wmax * wmax; // the winning score v*v of this agent
         // ---- early key: the magnitude of the candidate goes out before its position is known.  In the normal case (one
         // agent holds the largest |v|, its square a normal number) the magnitudes alone decide the winner.  (No candidate: 0,
@@ -260,21 +276,15 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
             kv.w = tag ^ kv.x ^ kv.y ^ kv.z;
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0);
         }
-#if T4A_X2_WGSPEC
-        unsigned long long wg_prev = 0ull; // the largest magnitude this workgroup had seen in this step before mine
-        const unsigned long long wg_mine = (unsigned long long)__double_as_longlong((wmax >= 0.0) ? wmax : 0.0);
-        if (lane == 0)
-            wg_prev = __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(smem_raw + L::o_wd) + par, wg_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
         u32x4 kg[4], kh[4];
-        unsigned wpos = XKEY_NONE;     // position key of the candidate
+        bool has_cand = false;         // this agent has a candidate
         double cval = 0.0;             // its value
         int cirow = 0, qstar = 0;      // its row index and my column slot
         if (wmax >= 0.0) {
             bool done = false;
             // while v*v is a normal number, distinct |v| have distinct squares, so the equality sweep can compare |v| itself
             // (and the rows that are already pivoted hold exact zeros in every active column, which cannot match)
-            if ((sq >= 2.2250738585072014e-308) && (sq < __builtin_huge_val())) {
+            if (hi_mid(whi)) {
                 unsigned long long bq[CPT];
                 int nhit = 0;
 #pragma unroll
@@ -297,9 +307,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                             if (__builtin_popcount(hb_) == 1) {
                                 const int rstar = RPT - 1 - (int)__builtin_ctz(hb_);
                                 cirow = hl + 64 * rstar;
-                                const unsigned rp_ = (unsigned)__builtin_amdgcn_readfirstlane((int)rowpos[cirow]);
-                                const unsigned cp_ = (unsigned)__builtin_amdgcn_readfirstlane((int)colpos[g + NW * q]);
-                                wpos = ROWMAJOR ? ((rp_ << 10) | cp_) : ((cp_ << 10) | rp_);
+                                has_cand = true;
                                 cval = readlane_f64(a[q][rstar], hl);
                                 qstar = q;
                                 done = true;
@@ -339,7 +347,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                 if (wp != XNOPOS) {
                     const unsigned long long sel = __ballot(mypos == wp);
                     const int hl = (int)__builtin_ctzll(sel);
-                    wpos = wp;
+                    has_cand = true;
                     cval = readlane_f64(myval, hl);
                     cirow = __builtin_amdgcn_readlane(myrow, hl);
                     qstar = __builtin_amdgcn_readlane(myq, hl);
@@ -349,7 +357,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
         XSTAMP(1);
         // ---- full key: value, position, row index, column slot (all fields are wave-uniform) ----
         {
-            const unsigned meta = wpos | ((unsigned)cirow << 20) | ((unsigned)qstar << 30);
+            const unsigned meta = (unsigned)cirow | ((unsigned)qstar << 10) | (has_cand ? X2_META_VALID : 0u);
             u32x4 kv;
             kv.x = lo32(cval);
             kv.y = hi32(cval);
@@ -368,13 +376,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
         // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
         // keys have been gathered
-#if T4A_X2_WGSPEC
-        const unsigned long long wg_prev_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wg_prev >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)wg_prev);
-        const bool wg_best = wg_mine >= wg_prev_u;
-#else
-        const bool wg_best = true;
-#endif
-        const bool early_pub = (wave != 0) && wg_best && (wpos != XKEY_NONE) && (sq >= spec_frac * prev_sq); // (the polling wave never stores a column early: those stores would sit in front of its key loads)
+        const bool early_pub = (wave != 0) && has_cand && (sq >= spec_frac * prev_sq); // (the polling wave never stores a column early: those stores would sit in front of its key loads)
         const int myslot = (int)cols_base + ((par * NW + g) * MP + lane) * 16; // byte offset of my row `lane` in the mailbox
         if (early_pub) {
             if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag);
@@ -404,15 +406,13 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                     kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
             }
             if (stamp_on) lds_stamps[5] += spins;
-#if T4A_X2_REC
             // the full keys: fetched now, in flight while the early ones are examined (a late one is fetched again below)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
-#endif
             XSTAMP(8);
             int wa_ = 0;
-            unsigned wkx = 0u, wky = 0u, wkz = 0u; // the winner's full key (T4A_X2_REC)
+            unsigned wkx = 0u, wky = 0u, wkz = 0u; // the winner's full key
             if (!giveup) {
                 if (kn == 0) { // non-finite entries in the input: met by their owners while the matrix was loaded
                     unsigned zf = 0u;
@@ -424,26 +424,42 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                 // |v| <=> distinct scores), held by exactly one early key: one maximum reduction decides.  (A duplicate of the
                 // last key can only push the count above one: then the exact path decides.  No candidate travels as 0.)
                 bool decided = false;
-                double lm = -1.0;
+                // first on the high words alone (early keys are magnitudes: non-negative): one integer reduction; the 64-bit
+                // comparison only when several keys share the largest high word
+                int lh = (int)kg[0].y;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) lm = vmax(lm, mk_f64(kg[j].x, kg[j].y));
-                const double gm = wave_max_f64(lm);
-                const double gsq = gm * gm;
-                if ((gsq >= 2.2250738585072014e-308) && (gsq < __builtin_huge_val())) {
-                    unsigned long long hb[4];
-                    int nh = 0;
+                for (int j = 1; j < 4; ++j) lh = (int)kg[j].y > lh ? (int)kg[j].y : lh;
+                const int ghi = wave_max_i32(lh);
+                unsigned long long hb[4];
+                int nh = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hb[j] = __ballot((int)kg[j].y == ghi);
+                    nh += __builtin_popcountll(hb[j]);
+                }
+                double gm = 0.0, gsq = 0.0;
+                bool in_range = hi_mid(ghi);
+                if (!(in_range && nh == 1)) {
+                    double lm = -1.0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lm = vmax(lm, mk_f64(kg[j].x, kg[j].y));
+                    gm = wave_max_f64(lm);
+                    gsq = gm * gm;
+                    in_range = (gsq >= 2.2250738585072014e-308) && (gsq < __builtin_huge_val());
+                    nh = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         hb[j] = __ballot(mk_f64(kg[j].x, kg[j].y) == gm);
                         nh += __builtin_popcountll(hb[j]);
                     }
+                }
+                if (in_range) {
                     if (nh == 1) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (hb[j] != 0ull) {
                                 const int hl = (int)__builtin_ctzll(hb[j]);
                                 wa_ = hl + 64 * j;
-#if T4A_X2_REC
                                 // the winner's full key: normally long there; otherwise fetched again until it is
                                 for (;;) {
                                     wkx = (unsigned)__builtin_amdgcn_readlane((int)kh[j].x, hl);
@@ -458,22 +474,17 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                                     }
                                     kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
                                 }
-#endif
                             }
                         decided = true;
                     }
                 } else if (!(gsq < __builtin_huge_val())) {
                     giveup = 2; // an infinite score: overflow in the trailing block (or an infinite input)
                 }
+                (void)gm;
                 XSTAMP(14);
                 if (!decided && !giveup) {
                     // ties between agents, zero / subnormal scores: exact comparison of (v*v, position key) over the FULL keys;
                     // an agent without candidate carries value 0 and the largest position key
-#if !T4A_X2_REC
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
-#endif
                     for (;;) {
                         bool ok = true;
 #pragma unroll
@@ -496,7 +507,10 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int ag = lane_o + 64 * j;
-                        const unsigned pk = (ag < NW) ? (kh[j].z & 0xFFFFFu) : XNOPOS;
+                        // position key of the candidate from the tables of this workgroup (every workgroup keeps the same ones)
+                        const unsigned rp_ = rowpos[kh[j].z & 1023u], cp_ = colpos[min(ag + NW * (int)((kh[j].z >> 10) & 3u), N - 1)];
+                        const unsigned pkey = ROWMAJOR ? ((rp_ << 10) | cp_) : ((cp_ << 10) | rp_);
+                        const unsigned pk = ((ag < NW) && (kh[j].z & X2_META_VALID)) ? pkey : XNOPOS;
                         const double v = mk_f64(kh[j].x, kh[j].y);
                         double sc = v * v;
                         sc = (ag < NW) ? sc : -2.0;
@@ -524,36 +538,23 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                     atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, giveup);
                     if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = giveup;
                 }
-#if T4A_X2_REC
                 int4 rec;
                 rec.x = wa_ | (giveup << 30);
                 rec.y = (int)wkx;
                 rec.z = (int)wky;
                 rec.w = (int)wkz;
                 *reinterpret_cast<int4*>(ctl + 4) = rec;
-#else
-                ctl[4] = wa_ | (giveup << 30);
-#endif
             }
             XSTAMP(9);
         }
         __syncthreads(); // (B)
         XSTAMP(3);
-#if T4A_X2_REC
         int4 rec; // the record in ONE LDS round trip
         {
             int zero = 0;
             asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rec) : "v"(zero), "n"(L::o_wi + 16) : "memory");
         }
         const unsigned recw = (unsigned)__builtin_amdgcn_readfirstlane(rec.x);
-#else
-        int rec1;
-        {
-            int zero = 0;
-            asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rec1) : "v"(zero), "n"(L::o_wi + 16) : "memory");
-        }
-        const unsigned recw = (unsigned)__builtin_amdgcn_readfirstlane(rec1);
-#endif
         if (recw >> 30) {
             timed_out = true;
             break;
@@ -568,10 +569,6 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
         }
         // everybody fetches the winner's full key (one granule, the same for all lanes) and — waves 1 .. 7 — its rows of the
         // winner's column: lane + 64 (sr0 + 7 j)
-#if !T4A_X2_REC
-        const int fk_off = (int)k2_base + (par * NW + wag) * 16;
-        u32x4 fk = __builtin_amdgcn_raw_buffer_load_b128(mail, fk_off, 0, BUF_SC1);
-#endif
         const int slot_off = (int)cols_base + ((par * NW + wag) * MP + lane + 64 * sr0) * 16;
         u32x4 cc[XR];
 #pragma unroll
@@ -579,35 +576,17 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
             if (sr0 >= 0 && sr0 + X2_DIVW * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 64 * 16, 0, BUF_SC1);
         // who sits at position kn now (the polling wave moves them behind its stop test)
         int rk_ = 0, ck_ = 0;
+        int prp_ = 0, pcp_ = 0; // ... and where the pivot's row and column sit
         if (wave == 0) {
             rk_ = posrow[kn];
             ck_ = poscol[kn];
-#if T4A_X2_WGSPEC
-            if (lane == 0) reinterpret_cast<unsigned long long*>(smem_raw + L::o_wd)[1 - par] = 0ull; // (next step's maximum: nobody touches it between barriers (B) and (C))
-#endif
+            prp_ = rowpos[rec.w & 1023];
+            pcp_ = colpos[min(wag + NW * ((rec.w >> 10) & 3), N - 1)];
         }
-#if T4A_X2_REC
         const double wval = mk_f64((unsigned)__builtin_amdgcn_readfirstlane(rec.y), (unsigned)__builtin_amdgcn_readfirstlane(rec.z));
         const unsigned wmeta = (unsigned)__builtin_amdgcn_readfirstlane(rec.w);
-#else
-        {
-            unsigned spins = 0;
-            while ((fk.x ^ fk.y ^ fk.z ^ fk.w) != tag) {
-                xcd_poll_again();
-                if (++spins > XSPIN) {
-                    atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, 1);
-                    if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = 1;
-                    ctl[1] = 1; // observed by everybody after barrier (C)
-                    break;
-                }
-                fk = __builtin_amdgcn_raw_buffer_load_b128(mail, fk_off, 0, BUF_SC1);
-            }
-        }
-        const double wval = mk_f64((unsigned)__builtin_amdgcn_readfirstlane((int)fk.x), (unsigned)__builtin_amdgcn_readfirstlane((int)fk.y));
-        const unsigned wmeta = (unsigned)__builtin_amdgcn_readfirstlane((int)fk.z);
-#endif
-        const int irow_p = (int)((wmeta >> 20) & 1023u);
-        const int qslot = (int)(wmeta >> 30);
+        const int irow_p = (int)(wmeta & 1023u);
+        const int qslot = (int)((wmeta >> 10) & 3u);
         XSTAMP(10);
         // (the shared reciprocal of the pivot does not depend on the column: it is formed while the column travels)
         const bool p_mid = exp_mid(wval);
@@ -619,12 +598,18 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
             // pivot / pivot = 1.0, so the rank-1 update below leaves exact zeros (x - 1.0 x) in every column that stays in the
             // trailing block — from then on the row takes part as l = 0 / a = 0 without any row mask.
             const int ls = irow_p & 63, rs = irow_p >> 6;
+            // (all owned columns back to back — one index-mode region; a column that left the trailing block yields a u that
+            // is never used)
+            double ue[CPT];
 #pragma unroll
-            for (int q = 0; q < CPT; ++q)
-                if (active & (1u << q)) {
-                    u[q] = readlane_f64(a[q][rs], ls);
-                    if (p.urows && lane == ls) p.urows[(unsigned)(kn * N + (g + NW * q))] = u[q];
-                }
+            for (int q = 0; q < CPT; ++q) ue[q] = a[q][rs];
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) u[q] = readlane_f64(ue[q], ls);
+            if (p.urows) {
+#pragma unroll
+                for (int q = 0; q < CPT; ++q)
+                    if ((active & (1u << q)) && lane == ls) p.urows[(unsigned)(kn * N + (g + NW * q))] = u[q];
+            }
         }
         if (g == wag) active &= ~(1u << qslot); // the pivot column leaves the trailing block (its registers keep the un-scaled column)
         if (wave == 0) {
@@ -644,9 +629,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                 } else {
                     // permutation bookkeeping (swap_rows / swap_cols of the reference as index tables): the row / column that
                     // sat at position kn moves to the pivot's old position, the pivot's to kn
-                    const unsigned wkey = wmeta & 0xFFFFFu;
-                    const int prp = (int)(ROWMAJOR ? (wkey >> 10) : (wkey & 1023u));
-                    const int pcp = (int)(ROWMAJOR ? (wkey & 1023u) : (wkey >> 10));
+                    const int prp = prp_, pcp = pcp_;
                     const int pc = wag + NW * qslot; // original index of the pivot column
                     posrow[prp] = (unsigned short)rk_;
                     posrow[kn] = (unsigned short)irow_p;
@@ -695,9 +678,12 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                     const double q0 = x * rp;
                     const double qf = __builtin_fma(__builtin_fma(-wval, q0, x), rp, q0);
                     lq[j] = (x == 0.0) ? q0 : qf;
-                    slow |= !(p_mid & (exp_mid(x) | (x == 0.0)));
+                    // |x| <= |pivot| for every entry of the pivot column (full pivoting): with a mid-range pivot only a tiny
+                    // non-zero x can leave the range the fast quotient is proven for
+                    slow |= (__builtin_fabs(x) < 4.909093465297727e-91) & (x != 0.0); // 2^-300
                 }
             }
+            slow |= !p_mid;
             if (__ballot(slow) != 0ull) {
 #pragma unroll
                 for (int j = 0; j < XR; ++j)
