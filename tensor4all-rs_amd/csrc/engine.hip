@@ -117,21 +117,42 @@ int xcd_assign() { return g_xcd_next.fetch_add(1, std::memory_order_relaxed) & 7
 // XCD — before round 3 a chain with one 29-workgroup plan in it held the chip-wide reservation for its whole half-sweep and
 // eight handles on eight host threads ran one after the other (34.3 ms per patch against 38.6 ms for one alone).
 int xcd_plan_max_w() { return g_live_engines.load(std::memory_order_relaxed) > 1 ? kXcdSharedMaxW : 32; }
+// The mutexes are owned per host THREAD with a recursion count (t_xcd_hold): one thread may drive several handles whose
+// reservations overlap in time — optimize_group launches one chain per handle when the chains do not line up, and a handle whose
+// chain fell back runs chip-wide kernels while its siblings still hold their XCDs (that used to self-deadlock on
+// the non-recursive mutexes).  A thread that already holds part of the chip never BLOCKS for the rest: it takes what is free
+// (try_lock) and launches anyway — the arbiter is a performance device, every persistent kernel has bounded spins and a fallback
+// — so two threads that each hold an XCD and both want the whole chip cannot wait for each other either.
+namespace {
+thread_local int t_xcd_hold[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+}
 void XcdArbiter::Lock::acquire(int xcc)
 {
     release();
     if (xcc >= 0) {
-        g_xcd_mutex[xcc & 7].lock();
-        held_ = 1 << (xcc & 7);
+        const int i = xcc & 7;
+        if (t_xcd_hold[i] == 0) g_xcd_mutex[i].lock();
+        ++t_xcd_hold[i];
+        held_ = 1 << i;
     } else {
-        for (int i = 0; i < 8; ++i) g_xcd_mutex[i].lock(); // fixed order: no deadlock between two chip-wide owners
-        held_ = 0xFF;
+        bool holds_some = false;
+        for (int i = 0; i < 8; ++i) holds_some = holds_some || t_xcd_hold[i] > 0;
+        for (int i = 0; i < 8; ++i) { // fixed order: no deadlock between two chip-wide owners that start from nothing
+            if (t_xcd_hold[i] == 0) {
+                if (!holds_some) g_xcd_mutex[i].lock();
+                else if (!g_xcd_mutex[i].try_lock()) continue; // (somebody else's XCD: shared for the time being)
+            }
+            ++t_xcd_hold[i];
+            held_ |= 1 << i;
+        }
     }
 }
 void XcdArbiter::Lock::release()
 {
     for (int i = 7; i >= 0; --i)
-        if (held_ & (1 << i)) g_xcd_mutex[i].unlock();
+        if (held_ & (1 << i)) {
+            if (--t_xcd_hold[i] == 0) g_xcd_mutex[i].unlock();
+        }
     held_ = 0;
 }
 

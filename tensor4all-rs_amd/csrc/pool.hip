@@ -68,6 +68,19 @@ int device_of(const void* p)
     return current_device();
 }
 
+// hipFree / hipHostFree synchronise the device: never while another thread of ours records a graph (g_capture_mu); a thread
+// that is recording itself holds the mutex already and its callers park their blocks instead of coming here (ADVICE round 3:
+// the trim loops and the over-limit frees did not take it)
+template <class F> void free_outside_capture(F&& f)
+{
+    if (t_in_capture) {
+        f();
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_capture_mu);
+    f();
+}
+
 // hands every cached device block of `dev` back to the driver (allocation failure: the cache itself may be what fills the HBM)
 void trim_device_cache(int dev)
 {
@@ -82,7 +95,9 @@ void trim_device_cache(int dev)
             kv.second.clear();
         }
     }
-    for (void* b : blocks) (void)hipFree(b);
+    free_outside_capture([&] {
+        for (void* b : blocks) (void)hipFree(b);
+    });
 }
 
 void trim_pin_cache()
@@ -96,7 +111,9 @@ void trim_pin_cache()
         }
         g_cached_pin_bytes = 0;
     }
-    for (void* b : blocks) (void)hipHostFree(b);
+    free_outside_capture([&] {
+        for (void* b : blocks) (void)hipHostFree(b);
+    });
 }
 
 // device-wide synchronisation outside any graph capture of ours; false when the device reported an (asynchronous) error —
@@ -194,7 +211,7 @@ void dev_free(void* p, size_t got)
             return;
         }
     }
-    (void)hipFree(p); // over the limit, or the device is in an error state: not ours to hand out again
+    free_outside_capture([&] { (void)hipFree(p); }); // over the limit, or the device is in an error state: not ours to hand out again
 }
 
 void* pin_alloc(size_t bytes, size_t* got)
@@ -249,7 +266,7 @@ void pin_free(void* p, size_t got)
             return;
         }
     }
-    (void)hipHostFree(p);
+    free_outside_capture([&] { (void)hipHostFree(p); });
 }
 
 hipStream_t stream_get(int kind)

@@ -185,6 +185,11 @@ void Tci2::set_builtin(int fid, int n_acc, const double* params, const uint64_t*
 {
     if (fid < 0 || fid >= T4A_FN_COUNT) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown built-in function id");
     if (n_acc < 1 || n_acc > T4A_FN_MAX_ACC) throw Error(T4A_GPU_INVALID_ARGUMENT, "n_acc out of range");
+    // after a bond chain the pinned mirror is the master copy of the index sets, with accumulators of the OLD weights laid out
+    // for the old n_acc: decode the digit tables first (as set_callback does), so that everything below re-accumulates from
+    // digits with the new weights
+    sync_digits();
+    invalidate_fill_cache();
     fn_dev_.fid = fid;
     fn_dev_.n_acc = n_acc;
     std::memcpy(fn_dev_.params, params, sizeof(double) * T4A_FN_MAX_PARAMS);
@@ -1629,13 +1634,27 @@ void Tci2::opt_begin(OptRun& r)
     // through the process-wide cache, which waits for the whole device: once per iteration and buffer while ranks grow)
     if (fn_kind_ == FnKind::Builtin && options.max_bond_dim != 0 && options.max_bond_dim <= 1024) {
         const size_t chi = options.max_bond_dim;
-        size_t totA = 0, totB = 0;
+        // what a bond can reach at all: min(chi, product of the local dimensions on either side) — the ends of a train stay small
+        std::vector<size_t> lb(n_ + 1, 1), rb(n_ + 1, 1);
+        for (size_t b = 0; b < n_; ++b) lb[b + 1] = std::min(chi, lb[b] * local_dims[b]);
+        for (size_t b = n_; b-- > 0;) rb[b] = std::min(chi, rb[b + 1] * local_dims[b]);
+        auto bond = [&](size_t b) { return std::min(lb[b], rb[b]); }; // bond b sits left of site b
+        size_t totA = 0, totB = 0, tot_cores = 0;
         for (size_t b = 0; b < n_; ++b) {
             if (shard_world > 1 && (b % shard_world) != shard_rank) continue;
-            cores[b].buf.reserve(std::max<size_t>(chi * local_dims[b] * chi, 1));
-            totA += chi * chi;
-            totB += chi * chi * local_dims[b];
+            const size_t l = bond(b), rr = bond(b + 1);
+            tot_cores += l * local_dims[b] * rr;
+            totA += rr * rr;
+            totB += rr * l * local_dims[b];
         }
+        // ... and only while the whole reservation stays moderate (chi = 1024 over 100 sites is 4 GB per handle,
+        // times eight handles of a group, for a run that may stay at rank 10): beyond that the buffers grow on demand as before
+        const bool presize = (tot_cores + totA + totB) * sizeof(double) <= ((size_t)1 << 30);
+        for (size_t b = 0; presize && b < n_; ++b) {
+            if (shard_world > 1 && (b % shard_world) != shard_rank) continue;
+            cores[b].buf.reserve(std::max<size_t>(bond(b) * local_dims[b] * bond(b + 1), 1));
+        }
+        if (presize) {
         d_fillA_.reserve(std::max<size_t>(totA, 1));
         d_fillB_.reserve(std::max<size_t>(totB, 1));
         d_fillpiv_.reserve(std::max<size_t>(n_ * chi, 1));
@@ -1651,6 +1670,7 @@ void Tci2::opt_begin(OptRun& r)
         d_fillacc_.reserve(acc_words + desc_bytes / 8 + 64);
         d_fillmax_.reserve(n_ + (n_ + 1) / 2 + (LU_MAX_PANEL_STEPS + 1) / 2);
         h_fillinfo_.reserve(n_);
+        }
     }
     r.pending_fill = false;
     r.iter = 0;

@@ -586,6 +586,7 @@ void Tci2::chain_launch()
         eng.chain_end();
         if (counted) g_chains_inflight.fetch_sub(1);
         chain_.tables_valid = false;
+        chain_.snap_serial[0] = chain_.snap_serial[1] = ~0ull; // (the slot claimed for this iteration was never, or only partly, written)
         throw;
     }
     chain_.inflight = true;
@@ -720,6 +721,7 @@ void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
             if (counted[i]) g_chains_inflight.fetch_sub(1);
             hs[i]->chain_.prepared = false;
             hs[i]->chain_.tables_valid = false;
+            hs[i]->chain_.snap_serial[0] = hs[i]->chain_.snap_serial[1] = ~0ull;
         }
         throw;
     }
@@ -738,6 +740,12 @@ void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
 // with "a chain is already in flight" while other handles waited for the XCD forever.
 void Tci2::chain_abort() noexcept
 {
+    if (chain_.prepared) {
+        // chain_enqueue claimed a snapshot slot for this iteration before anything was launched: a chain that
+        // never ran — or only partly — must not leave a slot behind that the next optimize() takes for the history's extras
+        chain_.snap_serial[0] = chain_.snap_serial[1] = ~0ull;
+        chain_.tables_valid = false;
+    }
     chain_.prepared = false;
     if (!chain_.inflight) return;
     chain_.inflight = false;

@@ -201,6 +201,45 @@ def test_optimize_group_equals_optimize_on_every_handle(t4a):
         t4a.optimize_group([grouped[0], grouped[0]], opts)
 
 
+def test_cfg5_patch_in_a_group_with_an_early_finisher_matches_oracle(t4a):
+    """One BASELINE configs[4] patch (patch 17 of 64, chi = 128, 30 active sites) from its single initial pivot through
+    t4a_gpu_tci2_optimize_group, next to a second patch and to a member that converges after a few iterations and drops out of the
+    group: the patch must end where the ORACLE ends — checked after 3, 6 and all 11 iterations (a run of k iterations ends in the
+    state a longer run passes through after its k-th)."""
+    import bench
+    n = bench.N_SITES
+    easy = t4a.quantics_trig_exp(n)
+    for k in (3, 6, 11):
+        opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=128, max_iter=k, ncheck_history=3, seed=42, **PARITY)
+        members = []
+        for spec in (bench.patch_spec(17, 64), bench.patch_spec(40, 64), easy):
+            t = t4a.TensorCI2([2] * n)
+            t.set_function(spec)
+            t.add_global_pivots([[0] * n])
+            t.set_max_sample_value(1.0)
+            members.append(t)
+        t4a.optimize_group(members, opts, final_sweep1site=False)
+        o = ob.OracleTCI2([2] * n)
+        o.set_function(bench.patch_spec(17, 64))
+        o.add_global_pivots([[0] * n])
+        o.set_max_sample_value(1.0)
+        o.optimize(opts, final_sweep1site=False)
+        g = members[0]
+        for p in range(n):
+            assert np.array_equal(g.i_set(p), o.i_set(p)) and np.array_equal(g.j_set(p), o.j_set(p)), (k, p)
+        assert g.link_dims() == o.link_dims() and np.array_equal(g.pivot_errors(), o.pivot_errors()), k
+        assert g.history()[0] == o.history()[0] and np.array_equal(g.history()[1], o.history()[1]), k
+        assert np.array_equal(g.last_sweep_shapes(), o.last_sweep_shapes()), k
+        assert g.chain_stats()["fell_back"] == 0 and g.chain_stats()["group_half_sweeps"] > 0
+    assert len(members[2].history()[0]) < len(members[0].history()[0]), "the test wants a member that stops early"
+    assert max(g.link_dims()) == 128
+    g.fill_site_tensors()
+    o.fill_site_tensors()
+    pts = np.random.default_rng(6).integers(0, 2, size=(300, n))
+    gv, ov = g.evaluate(pts), o.evaluate(pts)
+    assert np.abs(gv - ov).max() <= 1e-10 * max(1.0, np.abs(ov).max())
+
+
 def test_group_chain_with_a_member_on_the_per_bond_path(t4a):
     """A group in which one handle is not eligible for the device-side chain (chain switched off: it runs bond by bond, on an XCD of
     its own, after the group's chain has completed) and the others differ in length of run: results equal the handles' own runs."""

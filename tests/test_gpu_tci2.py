@@ -538,6 +538,75 @@ def test_cfg3_full_size_half_sweep_matches_oracle(t4a):
     assert np.abs(gv - ov).max() <= 1e-10 * scale
 
 
+def test_cfg3_from_scratch_every_iteration_matches_oracle(t4a):
+    """BASELINE configs[2] (the bench workload: d = 30, chi = 256) from the single initial pivot on BOTH sides, compared after
+    every iteration of optimize_with_finder (tensorci2.rs:1626-1802): a run of k iterations ends in the state a longer run passes
+    through after its k-th iteration, so k = 1 .. 10 runs from scratch (forward and backward half-sweeps alternate, history
+    extras, growth through every intermediate rank up to the saturated chi) cover each of them.  I/J sets, link dimensions,
+    pivot / bond errors, the error history and the shapes of the last sweep's candidate matrices are compared exactly; ~10 s of
+    oracle time in all (the saturated iterations cost the CPU ~1.3 s each)."""
+    from t4a_amd.functions import quantics_osc2d
+    n, chi = 30, 256
+    spec = quantics_osc2d(n, k1=37, k2=53, k3=2111, eps=0.5, k4=16411, delta=0.5)  # bench.py workload
+    for k in range(1, 11):
+        opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=k, ncheck_history=20, **PARITY)
+        g, o = both(t4a, spec, [2] * n)
+        for t in (g, o):
+            t.add_global_pivots([[0] * n])
+            t.set_max_sample_value(1.0)
+            t.optimize(opts, final_sweep1site=False)
+        assert_same_sets(g, o, n)
+        assert g.link_dims() == o.link_dims(), k
+        assert np.array_equal(g.pivot_errors(), o.pivot_errors()), k
+        assert np.array_equal(g.bond_errors(), o.bond_errors()), k
+        assert g.history()[0] == o.history()[0] and np.array_equal(g.history()[1], o.history()[1]), k
+        assert np.array_equal(g.last_sweep_shapes(), o.last_sweep_shapes()), k
+        assert g.max_sample_value() == o.max_sample_value() and g.termination() == o.termination(), k
+        st = g.chain_stats()
+        assert st["fell_back"] == 0 and st["not_eligible"] == 0, (k, st)
+    # the last pair ran the ten iterations the other cfg3 tests start from: saturated, and the filled trains agree
+    assert g.link_dims() == [min(2 ** (b + 1), 2 ** (n - b - 1), chi) for b in range(n - 1)]
+    g.fill_site_tensors()
+    o.fill_site_tensors()
+    pts = np.random.default_rng(4).integers(0, 2, size=(300, n))
+    gv, ov = g.evaluate(pts), o.evaluate(pts)
+    assert np.abs(gv - ov).max() <= 1e-10 * max(1.0, np.abs(ov).max())
+
+
+def test_set_function_with_new_weights_after_a_chain(t4a):
+    """optimize -> set_function(other weights, same n_acc) -> optimize must equal a fresh handle that was given the same index
+    sets: after a bond chain the master copy of the sets carries accumulators of the OLD weights."""
+    from t4a_amd.functions import quantics_osc2d
+    n = 14
+    spec_a = quantics_osc2d(n, k1=3, k2=5, k3=7, eps=0.1, k4=11, delta=0.3)
+    spec_b = quantics_osc2d(n, k1=2, k2=7, k3=5, eps=0.2, k4=13, delta=0.4)
+    opts = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=24, max_iter=4, ncheck_history=8, **PARITY)
+    g = t4a.TensorCI2([2] * n)
+    g.set_function(spec_a)
+    g.add_global_pivots([[0] * n])
+    g.optimize(opts, final_sweep1site=False)
+    sets = [(g.i_set(p).copy(), g.j_set(p).copy()) for p in range(n)]
+    g.set_function(spec_b)
+    g.clear_history()
+    g.set_max_sample_value(1.0)
+    g.optimize(opts, final_sweep1site=False)
+    fresh, o = both(t4a, spec_b, [2] * n)
+    for t in (fresh, o):
+        for p in range(n):
+            t.set_index_set(0, p, sets[p][0])
+            t.set_index_set(1, p, sets[p][1])
+        t.clear_history()
+        t.set_max_sample_value(1.0)
+        t.optimize(opts, final_sweep1site=False)
+    assert_same_sets(g, fresh, n)
+    assert_same_sets(g, o, n)
+    assert np.array_equal(g.pivot_errors(), o.pivot_errors())
+    g.fill_site_tensors()
+    o.fill_site_tensors()
+    pts = np.random.default_rng(5).integers(0, 2, size=(200, n))
+    assert np.abs(g.evaluate(pts) - o.evaluate(pts)).max() <= 1e-10 * max(1.0, g.max_sample_value())
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE config 4 size (d = 40, chi_max = 512): candidate matrices 1024..1536 on a side
 # ------------------------------------------------------------------------------------------------
