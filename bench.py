@@ -21,6 +21,7 @@ import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -235,6 +236,7 @@ def main():
         dom = max(variants, key=lambda v: v["ms"]) if variants else None
         dom_steps = dom["steps"] / max(dom["launches"], 1) if dom else float(shapes[N_SITES // 2][2])
         achieved = bytes_per_launch / (rrlu_ms_avg * 1e-3) / 1e9 if rrlu_ms_avg > 0 else 0.0
+        floor_us, floor_src = exchange_floor()
         out = {
             "metric": "TCI2 full-sweep GF/s (d=30, chi=256 fp64)",
             "value": flops_all / dt_max / 1e9,
@@ -247,6 +249,7 @@ def main():
             "full_sweep_sec": dt_max / steps,
             "higher_is_better": True,
             "scaling": "weak",
+            "scaling_note": "N = 1: a single-GPU number, no scaling claim" if world == 1 else "one patch of fixed size per GPU",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -277,13 +280,15 @@ def main():
                 "kernel": kname + " (full-pivot rank-revealing LU, one launch per bond)",
                 "launches": prof["dom_launches"],
                 "share_of_rrlu_time": prof["dom_ms"] / max(prof["rrlu_ms"], 1e-30),
-                "bound": "hbm",
+                "bound": "hbm",  # the nominal roofline of the streaming model (AI 0.125 flop/B); see binding_constraint
+                "binding_constraint": "per-pivot exchange + instruction latency inside one XCD (the slab is register resident: measured "
+                                      "HBM traffic is a few percent of the algorithmic bytes) - compare latency_view / latency_frac",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(kname),
-                "traffic_source": "profiles/r03_pmc_dominant_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two "
+                "traffic_source": os.path.basename(latest_profile("pmc_dominant_kernel.json")) + " (profiles/): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two "
                                   "separate passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch "
                                   "(gfx950 FETCH_SIZE correction); null when the kernel name does not match",
                 "avg_launch_ms": rrlu_ms_avg,
@@ -299,10 +304,10 @@ def main():
                 "latency_view": {
                     "pivot_steps_per_launch": dom_steps,
                     "us_per_pivot_step": 1e3 * rrlu_ms_avg / max(dom_steps, 1.0),
-                    "exchange_floor_us": XCD_EXCHANGE_FLOOR_US,
-                    "exchange_floor_source": "constant: tools/xcd_bench.hip measured on MI355X (profiles/r02_xcd_bench.log), not re-measured by this run",
+                    "exchange_floor_us": floor_us,
+                    "exchange_floor_source": floor_src,
                 },
-                "latency_frac": XCD_EXCHANGE_FLOOR_US / max(1e3 * rrlu_ms_avg / max(dom_steps, 1.0), 1e-30),
+                "latency_frac": floor_us / max(1e3 * rrlu_ms_avg / max(dom_steps, 1.0), 1e-30),
                 # the launches of this instantiation that ran all chi_max pivot steps (the saturated mid-chain bonds): chain
                 # launches are planned for upper bounds, so the instantiation's average above also contains smaller bonds
                 "saturated_launches": saturated_view(saturated.get(int(prof["dom_code"]))),
@@ -335,7 +340,24 @@ def main():
         dist.destroy_process_group()
 
 
-XCD_EXCHANGE_FLOOR_US = 1715 / 2380.0  # tools/xcd_bench.hip, see latency_view
+XCD_EXCHANGE_FLOOR_US = 1715 / 2380.0  # tools/xcd_bench.hip on MI355X, round 2 (profiles/r02_xcd_bench.log): the fallback of exchange_floor()
+
+
+def exchange_floor():
+    """(us, source) of the single-XCD exchange floor: one pivot step's key all-gather + 700-row column hand-off + two barriers
+    between 32 workgroups of one XCD with no arithmetic around it.  Re-measured on THIS box by `tools/xcd_bench floor` (built
+    by __graft_entry__.build()); the round-2 constant when the binary is missing or fails."""
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "xcd_bench")
+    try:
+        out = subprocess.run([exe, "floor"], capture_output=True, text=True, timeout=60).stdout
+        for line in out.splitlines():
+            if line.startswith("floor_ns_per_round="):
+                ns = float(line.split("=", 1)[1])
+                if 100.0 < ns < 1e5:
+                    return ns * 1e-3, "measured by this run: tools/xcd_bench floor (best of 4 launches of 2000 rounds, wall time)"
+    except (OSError, ValueError, subprocess.SubprocessError):
+        pass
+    return XCD_EXCHANGE_FLOOR_US, "constant: tools/xcd_bench.hip measured on MI355X in round 2 (profiles/r02_xcd_bench.log); tools/xcd_bench was not available to this run"
 
 
 def site_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier):
@@ -420,9 +442,13 @@ def saturated_view(v):
 def rrlu_kernel_name(code):
     """Kernel instantiation behind a profile code (include/t4a_gpu.h, t4a_gpu_tci2_profile_variants)."""
     code = int(code)
-    if code >= 100000:
+    if code >= 200000:  # one-workgroup kernel (kernels_rrlu_wg.hip): rows per lane, columns per wave
+        c = code - 200000
+        return "t4a::rrlu_wg_kernel<%d, %d, %s>" % (c // 1000, (c % 1000) // 10, "true" if (c % 10) & 4 else "false")
+    if code >= 100000:  # single-XCD kernel: second generation unless T4A_XCD_V=1
         c = code - 100000
-        return "t4a::rrlu_xcd_kernel<%d, %d, %s>" % (c // 100, (c % 100) // 10, "true" if (c % 10) & 4 else "false")
+        gen = "rrlu_xcd_kernel" if os.environ.get("T4A_XCD_V") == "1" else "rrlu_xcd2_kernel"
+        return "t4a::%s<%d, %d, %s>" % (gen, c // 100, (c % 100) // 10, "true" if (c % 10) & 4 else "false")
     if code >= 0:
         return "t4a::rrlu_reg_kernel<%d, %d, %s, %s, %s>" % (code // 1000, (code % 1000) // 10, "true" if (code % 10) & 2 else "false",
                                                             "true" if (code % 10) & 1 else "false", "true" if (code % 10) & 4 else "false")
@@ -431,25 +457,35 @@ def rrlu_kernel_name(code):
 
 def mfma_view():
     """MFMA kernels of the sweep (fill_site_tensors: LU trailing update, triangular solve; GEMM when issued): flops per launch,
-    average time, TF/s and the fraction of the 78.6 TF/s f64 MFMA peak — from profiles/r03_mfma_kernels.json
+    average time, TF/s and the fraction of the 78.6 TF/s f64 MFMA peak — from the latest profiles/rNN_mfma_kernels.json
     (tools/mfma_summary.py over the rocprofv3 passes of this command)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_mfma_kernels.json")
+    path = latest_profile("mfma_kernels.json")
     try:
         with open(path) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return None
-    out = {"peak_tflops": d.get("peak_tflops"), "sustained_tflops": d.get("sustained_tflops"), "source": "profiles/r03_mfma_kernels.json",
+    out = {"peak_tflops": d.get("peak_tflops"), "sustained_tflops": d.get("sustained_tflops"), "source": "profiles/" + os.path.basename(path) + "",
            "kernels": {}}
     for k, v in d.get("kernels", {}).items():
         out["kernels"][k] = {kk: v.get(kk) for kk in ("launches", "avg_us", "mfma_flops_per_launch", "tflops", "frac_of_peak", "frac_of_sustained")}
     return out
 
 
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one."""
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        names = sorted(n for n in os.listdir(pdir) if n.endswith("_" + suffix) and n[0] == "r" and n[1:3].isdigit())
+    except OSError:
+        names = []
+    return os.path.join(pdir, names[-1]) if names else os.path.join(pdir, "r00_" + suffix)
+
+
 def pmc_traffic(kname):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (bench.py itself cannot run under
     rocprofv3 --pmc); only reported when the summary is for the kernel instantiation that dominated this run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_dominant_kernel.json")
+    path = latest_profile("pmc_dominant_kernel.json")
     try:
         with open(path) as f:
             d = json.load(f)

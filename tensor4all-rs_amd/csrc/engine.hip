@@ -65,12 +65,14 @@ int xcd_version()
 }
 void rrlu_xcd_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream)
 {
-    if (version == 1) rrlu_xcd_launch(plan, args, stream);
+    if (plan.wg) rrlu_wg_launch(plan, args, stream);
+    else if (version == 1) rrlu_xcd_launch(plan, args, stream);
     else rrlu_xcd2_launch(plan, args, stream);
 }
 void rrlu_xcd_group_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream)
 {
-    if (version == 1) rrlu_xcd_group_launch(plan, args, tie_row_major, stream);
+    if (plan.wg) rrlu_wg_group_launch(plan, args, tie_row_major, stream);
+    else if (version == 1) rrlu_xcd_group_launch(plan, args, tie_row_major, stream);
     else rrlu_xcd2_group_launch(plan, args, tie_row_major, stream);
 }
 
@@ -267,8 +269,12 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     static const bool force_reg = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "reg";
     // first choice: all workgroups on one XCD (exchange through that XCD's L2); disabled for good once a launch timed out
     const int xcd_v = xcd_retry_v1_ ? 1 : xcd_version();
-    const bool use_xcd = !huge && !force_lds && !force_global && !force_reg && !xcd_disabled() &&
-                         (rrlu_xcd_make_plan(kM, kN, &xplan, false, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &xplan, false, 32));
+    // matrices that fit one workgroup: the LDS-exchange kernel (not on a retry after non-finite values: it does not handle them)
+    static const long wg_min = std::getenv("T4A_WG_MIN") ? std::atol(std::getenv("T4A_WG_MIN")) : 64;
+    const bool use_wg = !huge && !force_lds && !force_global && !force_reg && !xcd_retry_v1_ && (long)kM * kN > wg_min &&
+                        rrlu_wg_make_plan(kM, kN, &xplan, 0);
+    const bool use_xcd = use_wg || (!huge && !force_lds && !force_global && !force_reg && !xcd_disabled() &&
+                         (rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, 32)));
     const bool use_reg = !use_xcd && !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     bool fuse = false;
     bool xcd_src_transposed = false;
@@ -337,7 +343,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.xcc = xcc_;
         a.ticket = d_xticket_.get();
         a.ticket_base = xcd_ticket_base_;
-        xcd_ticket_base_ += (unsigned)(xplan.grid / 8); // exactly grid / 8 workgroups of a launch land on one XCD
+        if (!xplan.wg) xcd_ticket_base_ += (unsigned)(xplan.grid / 8); // exactly grid / 8 workgroups of a launch land on one XCD (the one-workgroup kernel takes no tickets)
         a.row_perm = left ? d_rowperm : d_colperm;
         a.col_perm = left ? d_colperm : d_rowperm;
         a.iresult = d_ires;
@@ -563,7 +569,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     }
     if (!completed) T4A_HIP(hipStreamSynchronize(stream_));
     xcd_lock.release();
-    if (use_xcd && xcd_v == 2 && reinterpret_cast<const int*>(h_out_.get() + 16)[1] == 2) {
+    if (use_xcd && (xcd_v == 2 || use_wg) && reinterpret_cast<const int*>(h_out_.get() + 16)[1] == 2) {
         // the second-generation kernel met a NaN / an infinity (input or overflow): the first generation implements the
         // NaN-incumbent rule of matrixlu.rs:480-519; every workgroup of the launch was elected normally, the tickets stay valid
         T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
@@ -710,6 +716,16 @@ bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
     pl.kM = kM;
     pl.kN = kN;
     static const bool no_single = std::getenv("T4A_CHAIN_NO_SINGLE") != nullptr;
+    // tiny matrices keep the fused single-workgroup plan (the candidate matrix is built in the registers: no extra launch);
+    // everything else that fits one workgroup takes the LDS-exchange kernel, with 63 more workgroups for the speculative
+    // candidate matrix of the next bond
+    static const long wg_min = std::getenv("T4A_WG_MIN") ? std::atol(std::getenv("T4A_WG_MIN")) : 64;
+    if ((long long)kM * kN > wg_min && rrlu_wg_make_plan(kM, kN, &pl.xcd, 63)) {
+        pl.kind = 2;
+        pl.code = 200000 + pl.xcd.RPT * 1000 + pl.xcd.CPT * 10;
+        *out = pl;
+        return true;
+    }
     if (!no_single && (long long)kM * kN <= 64 * 64 && rrlu_reg_make_plan(kM, kN, num_cus_, &pl.reg) && pl.reg.W == 1) {
         pl.kind = 1;
         pl.fused = pl.reg.RPT * pl.reg.CPT <= RRLU_FUSED_MAX_VALUES;
@@ -757,7 +773,7 @@ bool Engine::chain_group_plan(int kM, int kN, ChainRrluPlan* out)
     ChainRrluPlan pl;
     pl.kM = kM;
     pl.kN = kN;
-    if (!rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32)) return false;
+    if (!rrlu_wg_make_plan(kM, kN, &pl.xcd, 0) && !rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32)) return false;
     pl.kind = 2;
     pl.code = 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
     *out = pl;
@@ -809,7 +825,7 @@ unsigned Engine::chain_group_args(const ChainRrluPlan& pl, bool left, const doub
     a.xcc = slot;
     a.ticket = d_xticket_.get();
     a.ticket_base = xcd_ticket_base_;
-    xcd_ticket_base_ += (unsigned)(pl.xcd.grid / 8);
+    if (!pl.xcd.wg) xcd_ticket_base_ += (unsigned)(pl.xcd.grid / 8); // (the one-workgroup kernel takes no tickets)
     a.row_perm = left ? d_rowperm : d_colperm;
     a.col_perm = left ? d_colperm : d_rowperm;
     a.iresult = d_ires;

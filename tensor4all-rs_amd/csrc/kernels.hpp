@@ -183,6 +183,7 @@ struct RrluXcdPlan {
     int RPT = 1, CPT = 1;   // rows per lane / columns per wave (template parameters)
     int grid = 8;           // launched workgroups = 8 W (blocks b and b + 8 share an XCD)
     size_t lds_bytes = 0;
+    int wg = 0;             // 1: the one-workgroup kernel (kernels_rrlu_wg.hip): RPT rows per lane, CPT columns per WAVE, grid = 1 + speculating workgroups
 };
 struct RrluXcdArgs {
     const double* A;            // M x N input (ld = M)
@@ -238,6 +239,13 @@ void rrlu_xcd_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args
 // an overflow in the trailing block the launch gives up with iresult[1] == 2 and the caller runs the first generation.
 void rrlu_xcd2_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
 void rrlu_xcd2_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
+// One-workgroup kernel (kernels_rrlu_wg.hip): matrices up to 64 x 512 / 128 x 384 in the registers of one compute
+// unit, exchange through its LDS (one barrier per pivot step).  Same arguments and result block; finite matrices only (gives up
+// with iresult[1] == 2 like the second-generation single-XCD kernel).  spec_blocks: workgroups beside the factorising one that
+// evaluate the next bond's candidate matrix (bond chain).  The group launch runs slot x in workgroup x.
+bool rrlu_wg_make_plan(int M, int N, RrluXcdPlan* out, int spec_blocks = 0);
+void rrlu_wg_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
+void rrlu_wg_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // K1: candidate-matrix build (replaces the Π loop, tensor4all-tensorci/src/tensorci2.rs:1859-1893)

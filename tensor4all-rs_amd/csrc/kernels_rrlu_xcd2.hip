@@ -50,27 +50,11 @@ static_assert(Xcd2Lds<12>::bytes == (int)xcd_lds_total(12), "plan.lds_bytes must
 #ifndef T4A_XCD_STAMP_WAVE
 #define T4A_XCD_STAMP_WAVE 0
 #endif
-
-// maximum of a signed 32-bit value over the 64 lanes, in lane 63 (DPP row reductions folded into v_max_i32: lanes without a
-// source keep INT_MIN, the identity).  Non-negative doubles order like their high words first: the reductions of the step loop
-// run on the high word and fall back to the 64-bit comparison only when it does not single out one lane.
-template <int CTRL> __device__ __forceinline__ int dpp_max_i32(int v)
-{
-    const int o = __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xF, 0xF, false);
-    return o > v ? o : v;
-}
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-    v = dpp_max_i32<0xB1>(v);  // quad_perm [1,0,3,2]
-    v = dpp_max_i32<0x4E>(v);  // quad_perm [2,3,0,1]
-    v = dpp_max_i32<0x141>(v); // row_half_mirror
-    v = dpp_max_i32<0x140>(v); // row_mirror: every lane of a row holds the row maximum
-    v = dpp_max_i32<0x142>(v); // row_bcast15
-    v = dpp_max_i32<0x143>(v); // row_bcast31 -> lane 63 holds the wave maximum
-    return __builtin_amdgcn_readlane(v, 63);
-}
-// biased exponent of a non-negative double's high word within [600, 1500]: the square is a normal number with room to spare
-__device__ __forceinline__ bool hi_mid(int hi) { return (unsigned)((hi >> 20) - 600) <= 900u; }
+// T4A_X2_POLLEARLY = 1 (experiment): the polling wave issues its sweep of the early keys in the middle of its own position search
+// (behind the ballots, in front of the slot sweep) instead of behind its full-key store
+#ifndef T4A_X2_POLLEARLY
+#define T4A_X2_POLLEARLY 0
+#endif
 
 // full-key meta word (second generation): bits 0..9 row index of the candidate, 10..11 column slot of the publishing agent,
 // bit 12 the agent has a candidate.  Positions are NOT carried: whoever needs one reads the LDS tables (the polling wave behind
@@ -277,6 +261,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0);
         }
         u32x4 kg[4], kh[4];
+        bool kg_issued = false;
         bool has_cand = false;         // this agent has a candidate
         double cval = 0.0;             // its value
         int cirow = 0, qstar = 0;      // its row index and my column slot
@@ -292,6 +277,14 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                     bq[q] = __ballot(mq[q] == wmax); // (columns outside the trailing block keep mq = -1)
                     nhit += __builtin_popcountll(bq[q]);
                 }
+#if T4A_X2_POLLEARLY
+                if (wave == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                    kg_issued = true;
+                }
+#endif
                 if (nhit == 1) { // one lane of one column holds the maximum: the normal case
 #pragma unroll
                     for (int q = 0; q < CPT; ++q)
@@ -368,7 +361,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
         // the polling wave sweeps the early keys now — they left their agents a whole position search ago, so this first sweep
         // normally finds them all.  Every lane fetches four keys; lanes beyond NW re-read the last key (a valid duplicate), so
         // neither the arrival check nor the maximum needs a mask or a count of live groups.
-        if (wave == 0) {
+        if (wave == 0 && !kg_issued) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
@@ -590,7 +583,8 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
         XSTAMP(10);
         // (the shared reciprocal of the pivot does not depend on the column: it is formed while the column travels)
         const bool p_mid = exp_mid(wval);
-        const double rp = refined_rcp(wval);
+        double rp = refined_rcp(wval);
+        asm volatile("" : "+v"(rp)); // (formed HERE, while the column travels: left to itself the compiler sinks the five dependent operations behind the column wait)
         prev_sq = wval * wval;
         {
             // the pivot row: its entries in the columns of the trailing block (and the pivot column) are the finished row kn

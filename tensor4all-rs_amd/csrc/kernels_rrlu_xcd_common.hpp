@@ -87,6 +87,27 @@ __device__ __forceinline__ double wave_max_f64(double v) // maxNum over the 64 l
     v = vmax(v, dppz_f64<0x143>(v)); // row_bcast31: rows 2, 3 see lane 31 -> lane 63 holds the wave maximum
     return readlane_f64(v, 63);
 }
+// maximum of a signed 32-bit value over the 64 lanes, in lane 63 (DPP row reductions folded into v_max_i32: lanes without a
+// source keep INT_MIN, the identity).  Non-negative doubles order like their high words first: the reductions of the step loop
+// run on the high word and fall back to the 64-bit comparison only when it does not single out one lane.
+template <int CTRL> __device__ __forceinline__ int dpp_max_i32(int v)
+{
+    const int o = __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xF, 0xF, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = dpp_max_i32<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = dpp_max_i32<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = dpp_max_i32<0x141>(v); // row_half_mirror
+    v = dpp_max_i32<0x140>(v); // row_mirror: every lane of a row holds the row maximum
+    v = dpp_max_i32<0x142>(v); // row_bcast15
+    v = dpp_max_i32<0x143>(v); // row_bcast31 -> lane 63 holds the wave maximum
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// biased exponent of a non-negative double's high word within [600, 1500]: the square is a normal number with room to spare
+__device__ __forceinline__ bool hi_mid(int hi) { return (unsigned)((hi >> 20) - 600) <= 900u; }
+
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
     unsigned o;

@@ -804,6 +804,18 @@ void Tci2::chain_finish(const TCI2Options& options)
             break;
         }
     }
+    if (failed_k >= 0) {
+        static const bool dbg = std::getenv("T4A_CHAIN_DEBUG") != nullptr;
+        if (dbg) {
+            const size_t b = chain_.order[(size_t)failed_k];
+            const int* hd = chain_.hdims.get() + b * 4;
+            const int* hi = reinterpret_cast<const int*>(chain_.hblocks.get() + b * proto.bytes + 16);
+            const ChainRrluPlan& pl = chain_.plans[b];
+            std::fprintf(stderr, "[t4a chain] bond %zu (k = %ld of %zu, %s) did not complete: dims %d x %d poisoned %d lda %d | npiv %d flag %d nan %d token %d (want %u) | plan kind %d %d x %d wg %d RPT %d CPT %d W %d\n",
+                         b, failed_k, nb, forward ? "forward" : "backward", hd[0], hd[1], hd[2], hd[3], hi[0], hi[1], hi[2], hi[3], chain_.tokens[b], pl.kind, pl.kM, pl.kN,
+                         pl.xcd.wg, pl.xcd.RPT, pl.xcd.CPT, pl.xcd.W);
+        }
+    }
     const size_t done = failed_k < 0 ? nb : (size_t)failed_k;
     for (size_t k = 0; k < done; ++k) {
         const size_t b = chain_.order[k];

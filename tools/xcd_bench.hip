@@ -8,6 +8,7 @@
 #include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 typedef unsigned long long u64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -223,11 +224,16 @@ int main(int argc, char** argv)
         printf("%-28s G=%4d blocks per XCC:", name, G); for (int i = 0; i < 8; ++i) printf(" %3d", cnt[i]);
         printf("   b~b+8 same-XCC %d/%d  first:", rr, G - 8); for (int i = 0; i < 10 && i < G; ++i) printf(" %u", x[2 * i]); printf("\n");
     };
+    // `xcd_bench floor`: only the exchange of one pivot step (key all-gather + fresh 700-row column + two barriers, no arithmetic) —
+    // what bench.py quotes as the latency floor of the single-XCD rrLU kernel, re-measured on the box it runs on
+    const bool floor_only = argc > 1 && std::string(argv[1]) == "floor";
+    if (!floor_only) {
     do_census(0, 256, "census default stream");
     do_census(0, 64, "census default stream");
     do_census(0, 1024, "census default stream");
+    }
     // CU-masked streams: which XCCs do the workgroups land on?
-    {
+    if (!floor_only) {
         struct MaskCase { const char* name; unsigned m[8]; };
         MaskCase cases[] = {
             {"mask bits 0..31", {0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0}},
@@ -269,6 +275,23 @@ int main(int argc, char** argv)
         for (int i = 0; i < 8; ++i) printf(" %d", xs[i]); printf(" %s\n", e == hipSuccess ? "" : hipGetErrorString(e));
     };
     const int M = 700;
+    if (floor_only) {
+        double best_ns = 1e30;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, 0);
+            run(false, 0, 32, M, 4, 0, 256, 1 + 2 + 4, 0); // key gather + fresh column + barriers
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms * 1e6 / 2000 < best_ns) best_ns = ms * 1e6 / 2000; // (the launch: 2000 rounds; its fixed cost is < 1 %)
+        }
+        printf("floor_ns_per_round=%.1f\n", best_ns);
+        return 0;
+    }
     { hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0); run(false, 0, 32, M, 4, 0, 256, 0, 800); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); printf("  (that launch: %.3f ms wall for 2000 rounds => %.1f ns/round)\n", ms, ms * 1e6 / 2000); }
     run(false, 0, 32, M, 4, 0, 256, 0, 0);              // two barriers only
     run(false, 0, 32, M, 4, 0, 256, 4 + 64, 0);         // static column, sc1 loads
