@@ -352,6 +352,10 @@ struct GemmDesc {
     double* C; int ldc; long long strideC;
     double alpha, beta;
     int batch;
+    // split-K (set by gemm_launch, not by callers): slice s of a problem multiplies k-tiles [s * ktiles_per, ...) and stores its raw
+    // accumulators to partial[(problem * ksplit + s) * m * n + col * m + row]; gemm_splitk_reduce_kernel forms C from them
+    int ksplit = 1;
+    double* partial = nullptr;
 };
 void gemm_launch(const GemmDesc& d, hipStream_t stream);
 

@@ -9,7 +9,10 @@
 // "first maximum of |a_ik|".  Built with -ffp-contract=off so the non-MFMA kernels round like the CPU oracle.
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <utility>
 #include "common.hpp"
 
@@ -65,7 +68,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
         }
     }
     const int m0 = tile_m * GBM, n0 = tile_n * BN;
-    const int bz = blockIdx.z;
+    const int bz = (int)blockIdx.z / d.ksplit, kslice = (int)blockIdx.z - bz * d.ksplit; // (split-K: slices of one problem are neighbours in z)
     const double* A = d.A + (size_t)bz * d.strideA;
     const double* B = d.B + (size_t)bz * d.strideB;
     double* C = d.C + (size_t)bz * d.strideC;
@@ -148,13 +151,22 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
         for (int q = 0; q < NQB; ++q) Bs[buf][bk[q]][bc[q]] = rb[q];
     };
 
-    const int nk = (d.k + GBK - 1) / GBK;
-    if (nk > 0) {
-        load_tile(0);
-        store_tile(0);
+    const int nk_all = (d.k + GBK - 1) / GBK;
+    const int nk_per = (nk_all + d.ksplit - 1) / d.ksplit;
+    const int kt0 = kslice * nk_per;
+    const int nk = (kt0 + nk_per < nk_all ? kt0 + nk_per : nk_all);
+    if (kt0 > 0) { // (split-K: the pointers of the fast path start at this slice's first k-tile)
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) pa[q] += (long long)kt0 * stepA;
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) pb[q] += (long long)kt0 * stepB;
+    }
+    if (nk > kt0) {
+        load_tile(kt0);
+        store_tile(kt0 & 1);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1); // in flight during the MFMAs below
 #pragma unroll
@@ -185,12 +197,33 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmDesc d)
                 const int gm = m0 + wm * 32 + mi * 16 + (lane & 15);
                 const int gn = n0 + wn * WN + ni * 16 + (lane >> 4) + 4 * reg;
                 if (gm < d.m && gn < d.n) {
-                    double* cp = C + (size_t)gn * d.ldc + gm;
-                    double v = d.alpha * acc[mi][ni][reg];
-                    if (d.beta != 0.0) v = v + d.beta * (*cp);
-                    *cp = v;
+                    if (d.ksplit > 1) {
+                        d.partial[((size_t)blockIdx.z * d.n + gn) * d.m + gm] = acc[mi][ni][reg];
+                    } else {
+                        double* cp = C + (size_t)gn * d.ldc + gm;
+                        double v = d.alpha * acc[mi][ni][reg];
+                        if (d.beta != 0.0) v = v + d.beta * (*cp);
+                        *cp = v;
+                    }
                 }
             }
+}
+
+// second pass of a split-K product: C = alpha * sum_s partial[s] + beta * C (slices summed in order: deterministic)
+__global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmDesc d)
+{
+    const size_t mn = (size_t)d.m * d.n;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int bz = blockIdx.y;
+    if (e >= mn) return;
+    const double* p = d.partial + (size_t)bz * d.ksplit * mn + e;
+    double s = 0.0;
+    for (int k = 0; k < d.ksplit; ++k) s += p[(size_t)k * mn];
+    const size_t gn = e / d.m, gm = e - gn * d.m;
+    double* cp = d.C + (size_t)bz * d.strideC + gn * d.ldc + gm;
+    double v = d.alpha * s;
+    if (d.beta != 0.0) v = v + d.beta * (*cp);
+    *cp = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -909,9 +942,38 @@ __global__ void __launch_bounds__(256) tt_eval_kernel(const TtCoreDesc* cores, i
 
 } // namespace
 
+// Workspace of the split-K slices, one per stream (launches on one stream are ordered, so consecutive products reuse it; a stream
+// recycled to another handle still serialises its users).  Grow-only; a buffer that grows is replaced behind the stream's work.
+static double* splitk_workspace(hipStream_t stream, size_t doubles)
+{
+    struct Buf {
+        double* p = nullptr;
+        size_t cap = 0;
+    };
+    static std::mutex mu;
+    static std::map<hipStream_t, Buf> bufs;
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = bufs[stream];
+    if (doubles > b.cap) {
+        if (b.p) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(b.p);
+        }
+        size_t cap = 1;
+        while (cap < doubles) cap <<= 1;
+        if (hipMalloc(reinterpret_cast<void**>(&b.p), cap * sizeof(double)) != hipSuccess) {
+            b.p = nullptr;
+            b.cap = 0;
+            throw Error(T4A_GPU_INTERNAL_ERROR, "split-K workspace allocation failed");
+        }
+        b.cap = cap;
+    }
+    return b.p;
+}
+
 template <int BN> static void gemm_launch_bn(const GemmDesc& d, hipStream_t stream)
 {
-    dim3 grid((d.m + GBM - 1) / GBM, (d.n + BN - 1) / BN, d.batch);
+    dim3 grid((d.m + GBM - 1) / GBM, (d.n + BN - 1) / BN, d.batch * d.ksplit);
     constexpr size_t lds = 2 * sizeof(double) * GBK * ((GBM + GPAD) + (BN + GPAD));
     static std::atomic<bool> attr_set{false}; // (launches come from several host threads; setting the attribute twice is harmless)
     if (!attr_set) {
@@ -928,8 +990,28 @@ void gemm_launch(const GemmDesc& d, hipStream_t stream)
     static const int force_bn = std::getenv("T4A_GEMM_BN") ? std::atoi(std::getenv("T4A_GEMM_BN")) : 0;
     const long long tiles64 = (long long)((d.m + GBM - 1) / GBM) * ((d.n + 63) / 64) * d.batch;
     const bool narrow = force_bn ? force_bn == 32 : (tiles64 < 512 && d.n > 32);
-    if (narrow) gemm_launch_bn<32>(d, stream);
-    else gemm_launch_bn<64>(d, stream);
+    // small outputs leave most of the chip idle (a 256 x 256 result is 32 narrow tiles on 256 compute units): split K over
+    // blockIdx.z and sum the slices in a second pass (a separate launch: the fence of an in-kernel reduction cost more than it
+    // saved, tools/experiments/README.md).  Slices of >= 2 k-tiles, as many as fill the chip twice, at most 16.
+    static const int force_split = std::getenv("T4A_GEMM_KSPLIT") ? std::atoi(std::getenv("T4A_GEMM_KSPLIT")) : 0;
+    const long long tiles = (long long)((d.m + GBM - 1) / GBM) * ((d.n + (narrow ? 31 : 63)) / (narrow ? 32 : 64)) * d.batch;
+    const int ktiles = (d.k + GBK - 1) / GBK;
+    int ksplit = 1;
+    if (force_split > 0) ksplit = force_split;
+    else if (tiles < 256 && ktiles >= 8) ksplit = (int)std::min<long long>(std::min<long long>(16, ktiles / 2), (512 + tiles - 1) / tiles);
+    if (ksplit > ktiles) ksplit = ktiles;
+    if (ksplit <= 1) {
+        if (narrow) gemm_launch_bn<32>(d, stream);
+        else gemm_launch_bn<64>(d, stream);
+        return;
+    }
+    GemmDesc ds = d;
+    ds.ksplit = ksplit;
+    ds.partial = splitk_workspace(stream, (size_t)ksplit * d.batch * d.m * d.n);
+    if (narrow) gemm_launch_bn<32>(ds, stream);
+    else gemm_launch_bn<64>(ds, stream);
+    const size_t mn = (size_t)d.m * d.n;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256), d.batch), dim3(256), 0, stream, ds);
 }
 
 bool luci_factors_small_launch(const double* lu, int M, int N, int rk, const int* row_perm, const int* col_perm, bool left_orth,
