@@ -424,6 +424,20 @@ def site_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier):
                        "n_sites": d4, "local_dim": 2, "chi_max": chi4, "parallelism": f"site-shard x{world}",
                        "gather_bytes_per_half_sweep": int(world * xchg.per_rank * cap * 8)},
             "breakdown_ms_per_sweep": {"rrlu_kernel": prof["rrlu_ms"] / args.steps, "fill_site_tensors_local": prof["fill_ms"] / args.steps},
+            # what shards and what does not, so that a measured N-GPU line can be read against its bound: the bond chain
+            # (replicated_ms: wall time per sweep minus nothing — the fill runs on its own stream behind it) is the same on
+            # every rank; only the fill's device time (sharded_ms at this N, i.e. 1 / N of the whole fill) shrinks.  The fill
+            # overlaps the next half-sweep's chain, so the best case for N -> infinity is the chain alone.
+            "amdahl": {
+                "replicated_ms": prof["rrlu_ms"] / args.steps,
+                "sharded_ms": prof["fill_ms"] / args.steps,
+                "sharded_ms_at_n1": prof["fill_ms"] / args.steps * world,
+                "wall_ms": float(dt_t.item()) / args.steps * 1e3,
+                "speedup_bound_vs_n1": (max(prof["rrlu_ms"], prof["fill_ms"] * world) / max(prof["rrlu_ms"], 1e-30)),
+                "note": "speedup_bound_vs_n1 = max(chain, whole fill) / chain: the fill (device time) hides behind the replicated "
+                        "chain already at N = 1 unless it is longer than the chain, so configs[3] cannot gain more than this from "
+                        "more GPUs in the bit-exact mode; the patch farm (--mode headline, N > 1) is the mode that scales",
+            },
             "note": "value = flops executed by rank 0 (replicated chain + local share of the fill) / wall time; the chain does not "
                     "shard in the bit-exact mode (SURVEY.md §8e), so N > 1 only shortens the fill",
         }

@@ -574,6 +574,10 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         // NaN-incumbent rule of matrixlu.rs:480-519; every workgroup of the launch was elected normally, the tickets stay valid
         T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
         header_clean_ = false;
+        {
+            static const bool dbg = std::getenv("T4A_CHAIN_DEBUG") != nullptr;
+            if (dbg) std::fprintf(stderr, "[t4a luci] %d x %d: the %s kernel met non-finite values, re-running with the first-generation kernel\n", M, N, use_wg ? "one-workgroup" : "single-XCD");
+        }
         xcd_retry_v1_ = true;
         try {
             LuciResult r1 = luci(d_a_in, M, N, opts, need_factors, want_lu_copy, fused);
@@ -1083,16 +1087,23 @@ void Engine::svd(const double* d_a, int M, int N, double* d_u, double* d_s, doub
     set_identity_launch(V, n, n, n, stream_);
     const int max_sweeps = 60;
     int h[4] = {0, 0, 0, 0};
-    if (jacobi_fits_small(m, n)) {
+    static const bool no_block = std::getenv("T4A_SVD_NO_BLOCK") != nullptr;
+    if (no_block && jacobi_fits_small(m, n)) {
         jacobi_small_launch(W, m, V, n, max_sweeps, stream_);
     } else {
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {
             T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int), stream_));
-            jacobi_sweep_launch(W, m, V, n, flags, stream_);
+            // blocked iteration (a tournament over column blocks, the pairs of a block pair inside one workgroup's LDS);
+            // columns too long for the LDS keep the launch-per-round form
+            if (no_block || !jacobi_block_sweep_launch(W, m, V, n, flags, stream_)) jacobi_sweep_launch(W, m, V, n, flags, stream_);
             T4A_HIP(hipMemcpyAsync(h, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
             T4A_HIP(hipStreamSynchronize(stream_));
             if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
-            if (!h[0]) break;
+            if (!h[0]) {
+                static const bool dbg = std::getenv("T4A_SVD_DEBUG") != nullptr;
+                if (dbg) std::fprintf(stderr, "[t4a svd] %d x %d: %d sweeps\n", m, n, sweep + 1);
+                break;
+            }
         }
     }
     // the taller factor (m x n) and the square one (n x n): write straight to the outputs where no transpose is needed

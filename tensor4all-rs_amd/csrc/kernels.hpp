@@ -440,6 +440,9 @@ bool jacobi_fits_small(int m, int n);
 void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream);
 // one full sweep = n-1 tournament rounds, one launch per round; *d_rotated is set when any pair rotated
 void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream);
+// one full sweep of the BLOCKED iteration: a tournament over column blocks, one launch per block round, the pairs of a block pair
+// rotated inside one workgroup's LDS (false: the columns do not fit the LDS, nothing was launched)
+bool jacobi_block_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream);
 // sigma = column norms, sorted non-increasing; U = W / sigma, Vs = V gathered; dead[j] = 1 for sigma == 0
 void svd_finalize_launch(const double* W, int m, const double* V, int n, double* sig_tmp, double* U, double* S,
                          double* Vs, int* d_dead, int* d_ndead, hipStream_t stream);

@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace t4a {
 
@@ -18,6 +19,31 @@ __device__ inline double wave_sum(double v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return __shfl(v, 0, 64);
+}
+
+// Wave sum through DPP row reductions (no LDS crossbar traffic): every lane of the wave ends with the total.
+template <int CTRL> __device__ inline double dpp_mov_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline double wave_sum_dpp(double v)
+{
+    v += dpp_mov_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v); // row_half_mirror
+    v += dpp_mov_f64<0x140>(v); // row_mirror: every lane of a row of 16 holds the row sum
+    // rows -> wave: lanes 15, 31, 47, 63 hold the four row sums
+    const long long b = __double_as_longlong(v);
+    double t = 0.0;
+#pragma unroll
+    for (int l = 15; l < 64; l += 16) {
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+        t += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    return t;
 }
 
 // Sum over the whole workgroup, identical on every thread.  `red` holds one slot per wave.
@@ -169,6 +195,122 @@ __global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, int m, d
     if (use_lds) {
         for (int e = tid; e < m * n; e += T) Wg[e] = W[e];
         for (int e = tid; e < n * n; e += T) Vg[e] = V[e];
+    }
+}
+
+// Block round of the blocked one-sided Jacobi (round 4): the n columns are cut into blocks of `w`; a sweep is a tournament over
+// the BLOCKS (nbp - 1 launches instead of n - 1), and the workgroup of a block pair (I, J) brings its 2 w columns into the LDS
+// and runs a whole local tournament over them there: 2 w - 1 local rounds of w pairs, one WAVE per pair, dot products by
+// wavefront shuffles, one barrier per local round.  The rotations of the block are accumulated in a 2w x 2w matrix Q (LDS) and
+// applied to the rows of V in one pass at the end (V never enters the LDS).
+// LDS: double cols[2 w][m], double Q[2 w][2 w], int idx[2 w].
+template <int BW>
+__global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_kernel(double* __restrict__ W, int m, double* __restrict__ V, int n, int nbp, int round,
+                                                                                     int* rotated)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int w = BW, w2 = 2 * BW;
+    double* const cols = reinterpret_cast<double*>(smem_raw);
+    double* const Q = cols + (size_t)w2 * m;
+    int* const idx = reinterpret_cast<int*>(Q + (size_t)w2 * w2);
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    int bi, bj;
+    rr_pair(nbp, round, blockIdx.x, &bi, &bj);
+    if (tid < w2) {
+        const int c = tid < w ? bi * w + tid : bj * w + (tid - w);
+        idx[tid] = c < n ? c : -1; // (a block beyond the matrix, the tail of the last block: no column)
+    }
+    for (int e = tid; e < w2 * w2; e += T) Q[e] = (e / w2 == e % w2) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int c = wave; c < w2; c += (T >> 6)) {
+        const int gc = idx[c];
+        for (int r = lane; r < m; r += 64) cols[(size_t)c * m + r] = gc >= 0 ? W[(size_t)m * gc + r] : 0.0;
+    }
+    __syncthreads();
+    bool any = false;
+    // every column pair once per sweep: the first block round runs the full local tournament (pairs inside the two blocks and
+    // across them), the others only the w^2 pairs ACROSS the blocks (w local rounds: column k of I with column (k + lr) mod w of J)
+    // — a pair inside a block that was met in every block round kept rotating on rounding noise and the sweeps never ended
+    const int n_local = round == 0 ? w2 - 1 : w;
+    for (int lr = 0; lr < n_local; ++lr) {
+        if (wave < w) {
+            int a, b;
+            if (round == 0) {
+                rr_pair(w2, lr, wave, &a, &b);
+            } else {
+                a = wave;
+                b = w + (wave + lr) % w;
+            }
+            if (idx[a] >= 0 && idx[b] >= 0) {
+                double* const ca = cols + (size_t)a * m;
+                double* const cb = cols + (size_t)b * m;
+                // the two columns stay in registers between the dot products and the rotation (one LDS read and, when the
+                // pair rotates, one write per element and local round); columns longer than 64 * JB_RMAX rows re-read
+                constexpr int JB_RMAX = 16;
+                double xr[JB_RMAX], yr[JB_RMAX];
+                double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+                for (int q = 0; q < JB_RMAX; ++q) {
+                    const int r = lane + 64 * q;
+                    xr[q] = r < m ? ca[r] : 0.0;
+                    yr[q] = r < m ? cb[r] : 0.0;
+                    al += xr[q] * xr[q];
+                    be += yr[q] * yr[q];
+                    ga += xr[q] * yr[q];
+                }
+                for (int r = lane + 64 * JB_RMAX; r < m; r += 64) {
+                    const double x = ca[r], y = cb[r];
+                    al += x * x;
+                    be += y * y;
+                    ga += x * y;
+                }
+                al = wave_sum_dpp(al);
+                be = wave_sum_dpp(be);
+                ga = wave_sum_dpp(ga);
+                const Rot rot = jacobi_rotation(al, be, ga);
+                if (rot.apply) {
+                    any = true;
+#pragma unroll
+                    for (int q = 0; q < JB_RMAX; ++q) {
+                        const int r = lane + 64 * q;
+                        if (r < m) {
+                            ca[r] = rot.c * xr[q] - rot.s * yr[q];
+                            cb[r] = rot.s * xr[q] + rot.c * yr[q];
+                        }
+                    }
+                    for (int r = lane + 64 * JB_RMAX; r < m; r += 64) {
+                        const double x = ca[r], y = cb[r];
+                        ca[r] = rot.c * x - rot.s * y;
+                        cb[r] = rot.s * x + rot.c * y;
+                    }
+                    if (lane < w2) { // column a / b of Q (Q[row][col] at row * w2 + col)
+                        const double x = Q[lane * w2 + a], y = Q[lane * w2 + b];
+                        Q[lane * w2 + a] = rot.c * x - rot.s * y;
+                        Q[lane * w2 + b] = rot.s * x + rot.c * y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (any && lane == 0) *rotated = 1;
+    for (int c = wave; c < w2; c += (T >> 6)) {
+        const int gc = idx[c];
+        if (gc < 0) continue;
+        for (int r = lane; r < m; r += 64) W[(size_t)m * gc + r] = cols[(size_t)c * m + r];
+    }
+    // V(:, block) <- V(:, block) Q: one row of V per thread
+    for (int r = tid; r < n; r += T) {
+        double vin[w2];
+#pragma unroll
+        for (int c = 0; c < w2; ++c) vin[c] = idx[c] >= 0 ? V[(size_t)n * idx[c] + r] : 0.0;
+#pragma unroll
+        for (int c = 0; c < w2; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < w2; ++k) acc += vin[k] * Q[k * w2 + c];
+            if (idx[c] >= 0) V[(size_t)n * idx[c] + r] = acc;
+        }
     }
 }
 
@@ -389,6 +531,34 @@ void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hip
     const int np = n + (n & 1);
     for (int round = 0; round < np - 1; ++round)
         hipLaunchKernelGGL(jacobi_round_kernel, dim3(np / 2), dim3(256), 0, stream, W, m, V, n, np, round, d_rotated);
+}
+
+// Blocked sweep: block width by the rows that fit the LDS next to Q (2 w columns of m doubles), one launch per block round.
+// Returns false when the columns are too long for the LDS (m > 4096): the caller keeps the launch-per-round path.
+bool jacobi_block_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream)
+{
+    static const int w_max = std::getenv("T4A_SVD_BLOCK_W") ? std::atoi(std::getenv("T4A_SVD_BLOCK_W")) : 8;
+    int w = w_max >= 16 ? 16 : (w_max >= 8 ? 8 : (w_max >= 4 ? 4 : 2));
+    while (w > 1 && (size_t)2 * w * m * 8 > (size_t)136 * 1024) w >>= 1;
+    if ((size_t)2 * w * m * 8 > (size_t)136 * 1024) return false;
+    const int nb = (n + w - 1) / w;
+    const int nbp = nb < 2 ? 2 : nb + (nb & 1);
+    const size_t lds = ((size_t)2 * w * m + (size_t)4 * w * w) * 8 + (size_t)2 * w * 4 + 16;
+    int T = 64 * w;
+    if (T < 256) T = 256; // (the extra waves only help with the loads and the V pass)
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int round = 0; round < nbp - 1; ++round)
+            hipLaunchKernelGGL(kern, dim3(nbp / 2), dim3(T), lds, stream, W, m, V, n, nbp, round, d_rotated);
+    };
+    switch (w) {
+    case 16: go(&jacobi_block_kernel<16>); break;
+    case 8: go(&jacobi_block_kernel<8>); break;
+    case 4: go(&jacobi_block_kernel<4>); break;
+    case 2: go(&jacobi_block_kernel<2>); break;
+    default: go(&jacobi_block_kernel<1>); break;
+    }
+    return true;
 }
 
 void svd_finalize_launch(const double* W, int m, const double* V, int n, double* sig_tmp, double* U, double* S,

@@ -902,7 +902,11 @@ void Tci2::issue_fill_ops(std::vector<std::function<void()>>& ops, const std::ve
     static const bool use_graph = std::getenv("T4A_NO_FILL_GRAPH") == nullptr;
     if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.a, st));
     bool done = false;
-    if (use_graph && !fill_graph_broken_) {
+    // (no graph replay on a handle whose cores are exported / imported asynchronously — site-sharded fill, patch farm: with
+    // device-to-device copies of the cores and event waits of other streams between two replays on the fill stream,
+    // `bench.py --mode site-shard` hit GPU memory faults in 25 - 75 % of its runs, with every rrLU kernel generation and with
+    // the bond chain switched off, and in none with T4A_NO_FILL_GRAPH=1; the replay is worth 0.4 % of a cfg3 sweep)
+    if (use_graph && !fill_graph_broken_ && !cores_shared_async_) {
         if (fill_graph_exec_ && sig == fill_graph_sig_) {
             T4A_HIP(hipGraphLaunch(fill_graph_exec_, st));
             done = true;
@@ -1384,6 +1388,7 @@ void Tci2::fill_site_tensors_impl(bool async)
 // fill that is still in flight (same stream) and `consumer` waits for them through an event.
 void Tci2::export_site_tensors_async(double* d_dst, size_t stride, hipStream_t consumer)
 {
+    cores_shared_async_ = true;
     hipStream_t st = fill_inflight_ ? fill_stream_ : eng.stream();
     for (size_t s = 0; s < n_; ++s) {
         const DevCore& c = cores[s];
@@ -1400,6 +1405,7 @@ void Tci2::export_site_tensors_async(double* d_dst, size_t stride, hipStream_t c
 // d_dst + k * stride on the stream of the fill that may still be in flight; `consumer` (the stream of the all-gather) waits.
 void Tci2::export_site_shard_async(double* d_dst, size_t stride, hipStream_t consumer)
 {
+    cores_shared_async_ = true;
     hipStream_t st = fill_inflight_ ? fill_stream_ : eng.stream();
     size_t k = 0;
     for (size_t s = shard_rank; s < n_; s += shard_world, ++k) {
@@ -1421,6 +1427,7 @@ void Tci2::export_site_shard_async(double* d_dst, size_t stride, hipStream_t con
 // the first reader of a core (fill_wait) waits for the import.
 void Tci2::import_site_shard_async(const double* d_src, size_t stride, size_t per_rank, hipStream_t producer)
 {
+    cores_shared_async_ = true;
     if (!import_stream_) import_stream_ = pool::stream_get(2);
     // at most one import in flight: the one of the previous half-sweep is long done (a whole chain of bond updates ago),
     // and with it every read of the receive buffer that the caller is about to reuse
@@ -1638,7 +1645,8 @@ void Tci2::opt_begin(OptRun& r)
         std::vector<size_t> lb(n_ + 1, 1), rb(n_ + 1, 1);
         for (size_t b = 0; b < n_; ++b) lb[b + 1] = std::min(chi, lb[b] * local_dims[b]);
         for (size_t b = n_; b-- > 0;) rb[b] = std::min(chi, rb[b + 1] * local_dims[b]);
-        auto bond = [&](size_t b) { return std::min(lb[b], rb[b]); }; // bond b sits left of site b
+        static const bool old_presize = std::getenv("T4A_OLD_PRESIZE") != nullptr; // (debug: every bond at chi)
+        auto bond = [&](size_t b) { return old_presize ? chi : std::min(lb[b], rb[b]); }; // bond b sits left of site b
         size_t totA = 0, totB = 0, tot_cores = 0;
         for (size_t b = 0; b < n_; ++b) {
             if (shard_world > 1 && (b % shard_world) != shard_rank) continue;

@@ -334,6 +334,7 @@ private:
     EventTimer ev_pi_, ev_fill_;
     hipStream_t fill_stream_ = nullptr, import_stream_ = nullptr;
     bool import_inflight_ = false;
+    bool cores_shared_async_ = false; // an asynchronous export / import of cores was requested on this handle: fills are issued directly, not replayed from a graph (issue_fill_ops)
     hipEvent_t export_event_ = nullptr, import_event_ = nullptr;
     bool fill_inflight_ = false, fill_timed_ = false;
     std::vector<size_t> fill_solved_sites_;
