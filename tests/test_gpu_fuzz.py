@@ -126,6 +126,52 @@ def test_rrlu_special_values_on_multi_workgroup_shapes(t4a, left):
     _same_outcome(t4a, inf1, max_bond_dim=4, **kw)
 
 
+@pytest.mark.parametrize("left", [True, False])
+@pytest.mark.parametrize("shape", [(40, 100), (64, 128), (128, 60), (60, 30), (9, 120), (128, 8)])
+def test_rrlu_special_values_on_one_workgroup_shapes(t4a, left, shape):
+    """The shapes the one-workgroup kernel takes (kernels_rrlu_wg.hip: up to 64 x 128 / 128 x 64 as the kernel sees them, i.e.
+    transposed for a right-orthogonal factorisation) with everything that leaves its fast paths: ties inside a wave and between
+    waves, zero / subnormal / overflowing scores, low rank down to an exactly zero trailing block, all stop rules, quotients
+    outside the shared-reciprocal range, and NaN / inf — which that kernel hands back to the first-generation kernel."""
+    m, n = shape
+    rng = np.random.default_rng(4000 + 10 * m + n)
+    kw = dict(left_orthogonal=left)
+    mn = min(m, n)
+    _same_outcome(t4a, rng.uniform(-1, 1, size=(m, n)), **kw)
+    _same_outcome(t4a, rng.uniform(-1, 1, size=(m, n)), rel_tol=0.0, abs_tol=0.0, **kw)
+    _same_outcome(t4a, rng.uniform(-1, 1, size=(m, n)), max_bond_dim=max(1, mn // 3), rel_tol=1e-3, abs_tol=0.0, **kw)
+    _same_outcome(t4a, rng.uniform(-1, 1, size=(m, n)), rel_tol=0.0, abs_tol=0.3, **kw)
+    # exact ties everywhere: small integers, a signed permutation pattern, constant blocks
+    _same_outcome(t4a, rng.integers(-2, 3, size=(m, n)).astype(float), rel_tol=0.0, abs_tol=0.0, **kw)
+    _same_outcome(t4a, rng.integers(-1, 2, size=(m, n)).astype(float), **kw)
+    ones = np.ones((m, n))
+    _same_outcome(t4a, ones, rel_tol=0.0, abs_tol=0.0, **kw)
+    perm = np.zeros((m, n))
+    perm[rng.permutation(m)[:mn], rng.permutation(n)[:mn]] = rng.choice([-1.0, 1.0], size=mn)
+    _same_outcome(t4a, perm, rel_tol=0.0, abs_tol=0.0, **kw)
+    # low rank: the trailing block becomes exactly zero (integers) / numerically tiny (floats)
+    _same_outcome(t4a, np.outer(np.arange(1, m + 1), np.arange(1, n + 1)).astype(float), rel_tol=0.0, abs_tol=0.0, **kw)
+    r = max(1, mn // 4)
+    _same_outcome(t4a, rng.standard_normal((m, r)) @ rng.standard_normal((r, n)), **kw)
+    _same_outcome(t4a, np.zeros((m, n)), **kw)
+    # scores that underflow to 0 / overflow to +inf, subnormal entries, mixed scales (full division)
+    _same_outcome(t4a, rng.uniform(0.5, 1, size=(m, n)) * 1e-200, max_bond_dim=min(5, mn), rel_tol=0.0, abs_tol=0.0, **kw)
+    big = rng.uniform(-1, 1, size=(m, n))
+    big[m // 2, n // 3] = 1e200
+    big[m // 3, n // 2] = -3e199
+    _same_outcome(t4a, big, max_bond_dim=min(6, mn), rel_tol=0.0, abs_tol=0.0, **kw)
+    _same_outcome(t4a, rng.integers(1, 1000, size=(m, n)).astype(float) * 5e-324 * 1e10, max_bond_dim=min(4, mn), rel_tol=0.0, abs_tol=0.0, **kw)
+    mixed = rng.uniform(-1, 1, size=(m, n))
+    mixed[:, ::3] *= 1e-180
+    mixed[::4, :] *= 1e150
+    _same_outcome(t4a, mixed, max_bond_dim=min(12, mn), rel_tol=0.0, abs_tol=0.0, **kw)
+    # non-finite input: the NaN incumbent on the diagonal stays, NaN / inf elsewhere never win (matrixlu.rs:480-519)
+    for (i, j, v) in [(0, 0, np.nan), (m - 1, n - 1, np.nan), (m // 2, n // 2, np.inf), (0, n - 1, -np.inf)]:
+        bad = rng.uniform(-1, 1, size=(m, n))
+        bad[i, j] = v
+        _same_outcome(t4a, bad, max_bond_dim=min(5, mn), **kw)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_tci2_random_option_combinations_match_oracle(t4a, seed):
     """Random option combinations on built-in functions: index sets, error history and termination equal the oracle's."""
