@@ -939,7 +939,12 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size, int max_w
 }
 
 size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan) { return (size_t)4 * plan.W * XWAVES * 16; } // early keys + full keys, two step parities each
-size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int) { return (size_t)2 * plan.W * XWAVES * (size_t)(64 * plan.RPT) * 16; } // slots are padded to 64 * RPT rows
+size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int)
+{
+    // slots are padded to 64 * RPT rows; T4A_XCD_CSTRIDE (experiment, with a library built with -DT4A_X2_CSTRIDE): sparse slots
+    static const size_t cstride = std::getenv("T4A_XCD_CSTRIDE") ? (size_t)std::atol(std::getenv("T4A_XCD_CSTRIDE")) : 256;
+    return (size_t)2 * plan.W * XWAVES * (size_t)(4 * plan.RPT) * (cstride < 256 ? 256 : cstride);
+}
 
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
 {

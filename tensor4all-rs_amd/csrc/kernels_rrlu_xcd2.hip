@@ -52,6 +52,12 @@ static_assert(Xcd2Lds<12>::bytes == (int)xcd_lds_total(12), "plan.lds_bytes must
 #endif
 // T4A_X2_POLLEARLY = 1 (experiment): the polling wave issues its sweep of the early keys in the middle of its own position search
 // (behind the ballots, in front of the slot sweep) instead of behind its full-key store
+// T4A_X2_CSTRIDE (experiment): byte distance between consecutive 256-byte chunks (16 rows) of a column slot in the mailbox; 256 =
+// contiguous.  A larger stride spreads a column over more L2 channels if the channel interleave is coarser than 256 bytes (the
+// host sizes the mailbox with T4A_XCD_CSTRIDE set to the same value).
+#ifndef T4A_X2_CSTRIDE
+#define T4A_X2_CSTRIDE 256
+#endif
 #ifndef T4A_X2_POLLEARLY
 #define T4A_X2_POLLEARLY 0
 #endif
@@ -198,7 +204,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
     const unsigned k2_base = 2u * (unsigned)NW * 16u;
     const unsigned cols_base = 4u * (unsigned)NW * 16u;
     const __amdgpu_buffer_rsrc_t mail =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(cols_base + 2u * (unsigned)NW * (unsigned)MP * 16u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(cols_base + 2u * (unsigned)NW * (unsigned)(MP / 16) * (unsigned)T4A_X2_CSTRIDE), 0x00020000);
 
     int npiv = 0;
     double max_error = 0.0;             // kept by the polling waves
@@ -370,12 +376,13 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
         // keys have been gathered
         const bool early_pub = (wave != 0) && has_cand && (sq >= spec_frac * prev_sq); // (the polling wave never stores a column early: those stores would sit in front of its key loads)
-        const int myslot = (int)cols_base + ((par * NW + g) * MP + lane) * 16; // byte offset of my row `lane` in the mailbox
+        constexpr int CS = T4A_X2_CSTRIDE, SLOTB = (MP / 16) * CS; // chunk stride / bytes of a column slot
+        const int myslot = (int)cols_base + (par * NW + g) * SLOTB + (lane >> 4) * CS + (lane & 15) * 16; // byte offset of my row `lane` in the mailbox
         if (early_pub) {
-            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag);
-            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag);
-            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag);
-            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag);
+            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag, 4 * CS);
         }
         XSTAMP(2);
 
@@ -555,18 +562,18 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
         const int wag = (int)recw;
         // the winner did not speculate: its column goes out now
         if (g == wag && !early_pub) {
-            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag);
-            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag);
-            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag);
-            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag);
+            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag, 4 * CS);
         }
         // everybody fetches the winner's full key (one granule, the same for all lanes) and — waves 1 .. 7 — its rows of the
         // winner's column: lane + 64 (sr0 + 7 j)
-        const int slot_off = (int)cols_base + ((par * NW + wag) * MP + lane + 64 * sr0) * 16;
+        const int slot_off = (int)cols_base + (par * NW + wag) * SLOTB + ((lane >> 4) + 4 * sr0) * CS + (lane & 15) * 16;
         u32x4 cc[XR];
 #pragma unroll
         for (int j = 0; j < XR; ++j)
-            if (sr0 >= 0 && sr0 + X2_DIVW * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 64 * 16, 0, BUF_SC1);
+            if (sr0 >= 0 && sr0 + X2_DIVW * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 4 * CS, 0, BUF_SC1);
         // who sits at position kn now (the polling wave moves them behind its stop test)
         int rk_ = 0, ck_ = 0;
         int prp_ = 0, pcp_ = 0; // ... and where the pivot's row and column sit
@@ -657,7 +664,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                 }
 #pragma unroll
                 for (int j = 0; j < XR; ++j)
-                    if (sr0 + X2_DIVW * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 64 * 16, 0, BUF_SC1);
+                    if (sr0 + X2_DIVW * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 4 * CS, 0, BUF_SC1);
             }
             XSTAMP(12);
             // x / p through the shared refined reciprocal (bitwise the IEEE quotient, see refined_rcp); zeros keep the sign

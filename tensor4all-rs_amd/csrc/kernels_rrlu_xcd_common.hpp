@@ -228,7 +228,7 @@ template <int N> using xvec = double __attribute__((ext_vector_type(N)));
 // every slot row is written, no row mask).  One instance per column slot (the marker keeps the instances apart: merged, the
 // compiler would first copy the selected column into a common block of registers).
 template <int Q, int RPT>
-__device__ __forceinline__ void xcd_publish_column(const xvec<RPT>& col, __amdgpu_buffer_rsrc_t mail, int myslot, unsigned tag)
+__device__ __forceinline__ void xcd_publish_column(const xvec<RPT>& col, __amdgpu_buffer_rsrc_t mail, int myslot, unsigned tag, int rstride = 1024)
 {
     asm volatile("; column slot %0" ::"n"(Q));
 #pragma unroll
@@ -239,7 +239,7 @@ __device__ __forceinline__ void xcd_publish_column(const xvec<RPT>& col, __amdgp
         gv.y = hi32(av);
         gv.z = 0u;
         gv.w = tag ^ gv.x ^ gv.y;
-        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * 1024, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * rstride, 0, 0);
     }
 }
 
