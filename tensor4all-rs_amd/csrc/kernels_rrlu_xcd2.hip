@@ -58,6 +58,11 @@ static_assert(Xcd2Lds<12>::bytes == (int)xcd_lds_total(12), "plan.lds_bytes must
 #ifndef T4A_X2_CSTRIDE
 #define T4A_X2_CSTRIDE 256
 #endif
+// T4A_X2_DUPLOAD = 1 (measurement only): every dividing wave fetches its rows of the winner's column TWICE — if the step gets slower by
+// about the time the hand-off takes, the hand-off is bound by the L2 serving 29 workgroups the same lines, not by latency
+#ifndef T4A_X2_DUPLOAD
+#define T4A_X2_DUPLOAD 0
+#endif
 #ifndef T4A_X2_POLLEARLY
 #define T4A_X2_POLLEARLY 0
 #endif
@@ -574,6 +579,12 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
 #pragma unroll
         for (int j = 0; j < XR; ++j)
             if (sr0 >= 0 && sr0 + X2_DIVW * j < RPT) cc[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 4 * CS, 0, BUF_SC1);
+#if T4A_X2_DUPLOAD
+        u32x4 cd[XR];
+#pragma unroll
+        for (int j = 0; j < XR; ++j)
+            if (sr0 >= 0 && sr0 + X2_DIVW * j < RPT) cd[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, slot_off + j * X2_DIVW * 4 * CS, 0, BUF_SC1);
+#endif
         // who sits at position kn now (the polling wave moves them behind its stop test)
         int rk_ = 0, ck_ = 0;
         int prp_ = 0, pcp_ = 0; // ... and where the pivot's row and column sit
@@ -654,6 +665,11 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
 #pragma unroll
                 for (int j = 0; j < XR; ++j)
                     if (sr0 + X2_DIVW * j < RPT) ok &= ((cc[j].x ^ cc[j].y ^ cc[j].z ^ cc[j].w) == tag);
+#if T4A_X2_DUPLOAD
+#pragma unroll
+                for (int j = 0; j < XR; ++j)
+                    if (sr0 + X2_DIVW * j < RPT) asm volatile("" ::"v"(cd[j].x), "v"(cd[j].w)); // (the second copy must have arrived too)
+#endif
                 if (__all(ok)) break;
                 xcd_poll_again();
                 if (++spins > XSPIN) {
