@@ -946,29 +946,14 @@ __global__ void __launch_bounds__(256) tt_eval_kernel(const TtCoreDesc* cores, i
 // recycled to another handle still serialises its users).  Grow-only; a buffer that grows is replaced behind the stream's work.
 static double* splitk_workspace(hipStream_t stream, size_t doubles)
 {
-    struct Buf {
-        double* p = nullptr;
-        size_t cap = 0;
-    };
+    // blocks from the process-wide cache (pool.hip): a block that is replaced goes back through pool::dev_free, which waits for
+    // the device outside any graph capture of ours before the block can be handed out again
     static std::mutex mu;
-    static std::map<hipStream_t, Buf> bufs;
+    static auto* const bufs = new std::map<hipStream_t, DevBuf<double>>(); // (never destroyed: no device calls during static destruction)
     std::lock_guard<std::mutex> lk(mu);
-    Buf& b = bufs[stream];
-    if (doubles > b.cap) {
-        if (b.p) {
-            (void)hipStreamSynchronize(stream);
-            (void)hipFree(b.p);
-        }
-        size_t cap = 1;
-        while (cap < doubles) cap <<= 1;
-        if (hipMalloc(reinterpret_cast<void**>(&b.p), cap * sizeof(double)) != hipSuccess) {
-            b.p = nullptr;
-            b.cap = 0;
-            throw Error(T4A_GPU_INTERNAL_ERROR, "split-K workspace allocation failed");
-        }
-        b.cap = cap;
-    }
-    return b.p;
+    DevBuf<double>& b = (*bufs)[stream];
+    b.reserve(doubles);
+    return b.get();
 }
 
 template <int BN> static void gemm_launch_bn(const GemmDesc& d, hipStream_t stream)
