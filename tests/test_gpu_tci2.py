@@ -241,10 +241,11 @@ def test_cfg2_small_problem_parity_and_launch_bound_budget(t4a):
     o.crossinterpolate2([[0] * n], opts)
     assert g.link_dims() == o.link_dims()
     assert_same_sets(g, o, n)
-    # launch-bound regime: three half-sweeps as bond chains + the final one-site sweep, 1.5 ms measured (best of five; 4.4 ms in
-    # round 1, 1.7 ms in round 2).  The bound leaves a factor of two for a loaded box; the 0.5 ms the round-2 review asked for
-    # needs a persistent small-rank kernel and is NOT met.
-    assert best < 3e-3, f"cfg2 time to solution {best * 1e3:.2f} ms"
+    # kernel-bound regime: three half-sweeps as bond chains (19 x (7 us preparation + 6 us rrLU launch) each) + the final one-site
+    # sweep, 1.45 ms measured in round 4 (best of five; 4.4 ms in round 1, 1.7 in round 2, 1.5 in round 3).  The bound is 1.5 x
+    # the measured value (a regression guard, as the round-3 review asked); the 0.5 ms asked for needs the whole half-sweep of a
+    # tiny problem resident in one workgroup's LDS (DESIGN.md sections 8, 10) and is NOT met.
+    assert best < 2.2e-3, f"cfg2 time to solution {best * 1e3:.2f} ms"
 
 
 def test_concurrent_handle_lifecycles(t4a):
