@@ -696,8 +696,8 @@ def aux_timings():
                 tp.set_max_sample_value(1.0)
                 tps.append(tp)
             t4a_amd.optimize_group(tps, o_grp, final_sweep1site=False)
+            t4a_amd.fill_site_tensors_group(tps)  # all eight fills issued, then completed (each on its handle's own stream)
             for p, tp in enumerate(tps):
-                tp.fill_site_tensors()
                 grp[p] = float(tp.sum())
             dt = (time.perf_counter() - t0) / 8
             best = dt if best is None else min(best, dt)

@@ -705,6 +705,11 @@ t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out /* 
  * patches one after the other): results on every handle are exactly those of t4a_gpu_tci2_optimize. */
 t4a_gpu_status t4a_gpu_tci2_optimize_group(t4a_gpu_tci2* const* handles, size_t n_handles, const t4a_gpu_tci2_options* options,
                                            int32_t final_sweep1site);
+/* fill_site_tensors (tensorci2.rs:1065-1186) on several handles at once: the fills of all handles are issued first — each on its
+ * handle's own fill stream, so their kernels share the chip — and completed afterwards, instead of issue + wait handle by handle.
+ * Results on every handle are exactly those of t4a_gpu_tci2_fill_site_tensors; a deferred solve error (singular pivot matrix) of
+ * any handle is reported after all fills have completed. */
+t4a_gpu_status t4a_gpu_tci2_fill_site_tensors_group(t4a_gpu_tci2* const* handles, size_t n_handles);
 /* enable == 0: this handle runs every half-sweep bond by bond (A/B measurements, tests).  verify bit 0: after every chain the
  * device-side index tables are read back and compared with the host's I / J sets (T4A_GPU_INTERNAL_ERROR on a difference);
  * bit 1: while profiling, the rrLU launches of a chain are timed with HIP events around each launch instead of the kernels' own

@@ -611,6 +611,19 @@ t4a_gpu_status t4a_gpu_tci2_optimize_group(t4a_gpu_tci2* const* handles, size_t 
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_fill_site_tensors_group(t4a_gpu_tci2* const* handles, size_t n_handles)
+{
+    return guarded([&] {
+        if (n_handles) T4A_REQUIRE_PTR(handles);
+        std::vector<Tci2*> hs;
+        for (size_t i = 0; i < n_handles; ++i) {
+            T4A_REQUIRE_PTR(handles[i]);
+            hs.push_back(&handles[i]->impl);
+        }
+        Tci2::fill_site_tensors_group(hs);
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_sweep2site(t4a_gpu_tci2* h, int32_t forward, const t4a_gpu_tci2_options* options)
 {
     return guarded([&] {

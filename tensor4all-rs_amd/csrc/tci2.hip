@@ -2,6 +2,8 @@
 // Mirrors crates/tensor4all-tensorci/src/tensorci2.rs function by function (line references inline).
 #include "tci2.hpp"
 
+#include <exception>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -1862,10 +1864,8 @@ void Tci2::opt_iter_finish(OptRun& r)
     ++r.iter;
 }
 
-void Tci2::opt_end(OptRun& r)
+void Tci2::opt_end_issue_fill(OptRun& r)
 {
-    const TCI2Options& options = r.options;
-    const bool final_sweep1site = r.final_sweep1site;
     if (r.pending_fill) { // the last iteration's fill
         r.pending_fill = false;
         for (size_t b = 0; b < n_; ++b) prepare_fill_site(b);
@@ -1874,6 +1874,13 @@ void Tci2::opt_end(OptRun& r)
         fill_site_tensors_impl(true);
         if (!keep_site_tensors) invalidate_site_tensors(); // (the end of that iteration invalidated them, tensorci2.rs:707-708)
     }
+}
+
+void Tci2::opt_end(OptRun& r)
+{
+    const TCI2Options& options = r.options;
+    const bool final_sweep1site = r.final_sweep1site;
+    opt_end_issue_fill(r);
     // the cores of the last iteration are complete (deferred solve errors surface here); in pipelined mode the wait
     // is left to the first reader (site_tensor*, evaluate, export_site_tensors_async, the next fill)
     flush_deferred_fill();
@@ -1976,11 +1983,37 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
     if (prof)
         std::fprintf(stderr, "[t4a] optimize_group: %zu handles, %zu iterations: start %.2f ms, launch %.2f ms, finish %.2f ms (of which issuing the previous iteration's fills %.2f ms, waiting for the device %.2f ms)\n",
                      hs.size(), iters, 1e3 * t_start, 1e3 * t_launch, 1e3 * t_finish, 1e3 * t_fill, 1e3 * (g_chain_wait_seconds - wait0));
+    // the last iteration's fills of ALL handles first (each on its own fill stream), then the waits: handle by handle the device
+    // idled while the host issued the next handle's dozen launches
+    for (size_t i = 0; i < hs.size(); ++i) hs[i]->opt_end_issue_fill(runs[i]);
     for (size_t i = 0; i < hs.size(); ++i) hs[i]->opt_end(runs[i]);
     } catch (...) {
         for (Tci2* h : hs) h->chain_abort(); // (the leader's abort waits for the group's stream and gives the chip back)
         throw;
     }
+}
+
+// fill_site_tensors on several handles: issue all, then complete all (t4a_gpu_tci2_fill_site_tensors_group)
+void Tci2::fill_site_tensors_group(const std::vector<Tci2*>& hs)
+{
+    for (Tci2* h : hs)
+        if (!h) throw Error(T4A_GPU_NULL_POINTER, "fill_site_tensors_group: null handle");
+    std::exception_ptr first_error;
+    for (Tci2* h : hs) {
+        try {
+            h->fill_site_tensors_impl(true); // asynchronous for built-in functors (a host callback fills synchronously)
+        } catch (...) {
+            if (!first_error) first_error = std::current_exception();
+        }
+    }
+    for (Tci2* h : hs) {
+        try {
+            h->fill_wait();
+        } catch (...) {
+            if (!first_error) first_error = std::current_exception();
+        }
+    }
+    if (first_error) std::rethrow_exception(first_error);
 }
 
 // crossinterpolate2 (tensorci2.rs:1513-1563)

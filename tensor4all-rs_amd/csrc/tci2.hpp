@@ -80,6 +80,8 @@ public:
     void optimize(const TCI2Options& options, bool final_sweep1site);
     // the same for up to eight handles at once, in lock-step from the calling thread (one XCD per handle)
     static void optimize_group(const std::vector<Tci2*>& handles, const TCI2Options& options, bool final_sweep1site);
+    // fill_site_tensors of several handles: all fills issued (each on its own fill stream), then all completed
+    static void fill_site_tensors_group(const std::vector<Tci2*>& handles);
     struct OptRun { // one optimize() call in progress
         TCI2Options options;
         bool final_sweep1site = false;
@@ -96,6 +98,7 @@ public:
     };
     void opt_begin(OptRun& r);
     void opt_iter_issue_pending_fill(OptRun& r);
+    void opt_end_issue_fill(OptRun& r); // the last iteration's fill, issued without waiting (first half of opt_end; a group issues all of them first)
     bool opt_iter_start(OptRun& r, bool defer_launch = false); // defer_launch: the chain is prepared, not launched (optimize_group)
     void opt_iter_finish(OptRun& r);
     void opt_end(OptRun& r);

@@ -664,6 +664,13 @@ def optimize_group(tcis, options, final_sweep1site=True):
     _check(_lib.t4a_gpu_tci2_optimize_group(arr, c_size_t(len(tcis)), ctypes.byref(o), c_int32(1 if final_sweep1site else 0)))
 
 
+def fill_site_tensors_group(tcis):
+    """fill_site_tensors() on several TensorCI2 handles at once: all fills issued (each on its handle's own stream), then all
+    completed.  Results are exactly those of handle.fill_site_tensors()."""
+    arr = (c_void_p * len(tcis))(*[t._h for t in tcis])
+    _check(_lib.t4a_gpu_tci2_fill_site_tensors_group(arr, c_size_t(len(tcis))))
+
+
 def crossinterpolate2(f, local_dims, initial_pivots, options):
     """crossinterpolate2 (tensorci2.rs:1513). Returns the optimised TensorCI2; histories via .history()."""
     options.to_c()  # validate before anything else

@@ -240,6 +240,39 @@ def test_cfg5_patch_in_a_group_with_an_early_finisher_matches_oracle(t4a):
     assert np.abs(gv - ov).max() <= 1e-10 * max(1.0, np.abs(ov).max())
 
 
+def test_fill_site_tensors_group_equals_fill_on_every_handle(t4a):
+    """t4a_gpu_tci2_fill_site_tensors_group: the fills of several handles issued first, completed afterwards — site tensors bitwise
+    those of handle.fill_site_tensors(), also for handles of different length and for one with a host callback (which fills
+    synchronously inside the group call)."""
+    specs = [(14, t4a.quantics_osc2d(14, k1=3, k2=5, k3=7, eps=0.1, k4=11, delta=0.3)),
+             (14, t4a.quantics_osc2d(14, k1=2, k2=7, k3=5, eps=0.2, k4=13, delta=0.4)),
+             (10, t4a.quantics_trig_exp(10))]
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=20, max_iter=5, seed=3, **PARITY)
+    solo, grouped = [], []
+    for n, spec in specs:
+        for dst in (solo, grouped):
+            t = t4a.TensorCI2([2] * n)
+            t.set_function(spec)
+            t.add_global_pivots([[0] * n])
+            t.optimize(opts, final_sweep1site=False)
+            dst.append(t)
+    cb = t4a.TensorCI2([3, 2, 3, 2])
+    cb.set_function(lambda idx: 1.0 / (1.0 + sum(int(v) for v in idx)))
+    cb.add_global_pivots([[0, 0, 0, 0]])
+    cb.optimize(opts, final_sweep1site=False)
+    cb2 = t4a.TensorCI2([3, 2, 3, 2])
+    cb2.set_function(lambda idx: 1.0 / (1.0 + sum(int(v) for v in idx)))
+    cb2.add_global_pivots([[0, 0, 0, 0]])
+    cb2.optimize(opts, final_sweep1site=False)
+    for t in solo + [cb]:
+        t.fill_site_tensors()
+    t4a.fill_site_tensors_group(grouped + [cb2])
+    for a, b in zip(solo + [cb], grouped + [cb2]):
+        for p in range(len(a)):
+            assert np.array_equal(a.site_tensor(p), b.site_tensor(p)), p
+    t4a.fill_site_tensors_group([])
+
+
 def test_group_chain_with_a_member_on_the_per_bond_path(t4a):
     """A group in which one handle is not eligible for the device-side chain (chain switched off: it runs bond by bond, on an XCD of
     its own, after the group's chain has completed) and the others differ in length of run: results equal the handles' own runs."""

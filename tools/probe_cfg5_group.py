@@ -40,7 +40,8 @@ for rnd in range(3):
     t0 = time.perf_counter()
     tps = [make(p) for p in range(n)]
     t4a_amd.optimize_group(tps, OPT, final_sweep1site=False)
-    got = {p: finish(tps[p]) for p in range(n)}
+    t4a_amd.fill_site_tensors_group(tps)  # (all fills issued, then completed)
+    got = {p: float(tps[p].sum()) for p in range(n)}
     dt = time.perf_counter() - t0
     del tps
     print(f"optimize_group of {n}, round {rnd}: {dt * 1e3:.1f} ms wall, {dt / n * 1e3:.2f} ms per patch, speed-up {sum(1 for _ in ref) and 0 or 0}"
