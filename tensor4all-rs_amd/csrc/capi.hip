@@ -1009,6 +1009,15 @@ t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out)
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_chain_walks(const t4a_gpu_tci2* h, uint64_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        *out = h->impl.chain_stats_walked;
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t verify)
 {
     return guarded([&] {

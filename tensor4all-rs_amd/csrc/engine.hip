@@ -65,13 +65,15 @@ int xcd_version()
 }
 void rrlu_xcd_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream)
 {
-    if (plan.wg) rrlu_wg_launch(plan, args, stream);
+    if (plan.wg == 2) rrlu_w1_launch(plan, args, stream);
+    else if (plan.wg) rrlu_wg_launch(plan, args, stream);
     else if (version == 1) rrlu_xcd_launch(plan, args, stream);
     else rrlu_xcd2_launch(plan, args, stream);
 }
 void rrlu_xcd_group_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream)
 {
-    if (plan.wg) rrlu_wg_group_launch(plan, args, tie_row_major, stream);
+    if (plan.wg == 2) rrlu_w1_group_launch(plan, args, tie_row_major, stream);
+    else if (plan.wg) rrlu_wg_group_launch(plan, args, tie_row_major, stream);
     else if (version == 1) rrlu_xcd_group_launch(plan, args, tie_row_major, stream);
     else rrlu_xcd2_group_launch(plan, args, tie_row_major, stream);
 }
@@ -272,7 +274,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     // matrices that fit one workgroup: the LDS-exchange kernel (not on a retry after non-finite values: it does not handle them)
     static const long wg_min = std::getenv("T4A_WG_MIN") ? std::atol(std::getenv("T4A_WG_MIN")) : 64;
     const bool use_wg = !huge && !force_lds && !force_global && !force_reg && !xcd_retry_v1_ && (long)kM * kN > wg_min &&
-                        rrlu_wg_make_plan(kM, kN, &xplan, 0);
+                        (rrlu_w1_make_plan(kM, kN, &xplan, 0) || rrlu_wg_make_plan(kM, kN, &xplan, 0));
     const bool use_xcd = use_wg || (!huge && !force_lds && !force_global && !force_reg && !xcd_disabled() &&
                          (rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, 32)));
     const bool use_reg = !use_xcd && !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
@@ -633,7 +635,12 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     if (want_stamps) {
         unsigned long long hs[24];
         T4A_HIP(hipMemcpy(hs, d_stamps_.get(), sizeof(hs), hipMemcpyDeviceToHost));
-        if (use_xcd) {
+        if (use_xcd && xplan.wg == 2) {
+            const double st = hp[0] > 0 ? (double)hp[0] : 1.0;
+            std::fprintf(stderr, "[rrlu stamps w1] M=%d N=%d columns=%d steps=%d cycles/step: search=%.0f stop+divide+clear=%.0f tables=%.0f update=%.0f | launch (cycles): "
+                                 "load+init=%llu steps=%llu write-out=%llu | shader clock %.0f MHz\n",
+                         M, N, xplan.CPT, hp[0], hs[0] / st, hs[1] / st, hs[2] / st, hs[3] / st, hs[16], hs[17], hs[18], hs[21] ? 100.0 * (double)hs[20] / (double)hs[21] : 0.0);
+        } else if (use_xcd) {
             const double st = hp[0] > 0 ? (double)hp[0] : 1.0;
             std::fprintf(stderr, "[rrlu stamps xcd] M=%d N=%d W=%d steps=%d cycles/step: pass=%.0f search=%.0f publish=%.0f | prefetch=%.0f keys=%.0f pick=%.0f slow+stop=%.0f recwr=%.0f barB=%.0f | record=%.0f "
                                  "tables+u=%.0f colwait=%.0f divide=%.0f barC=%.0f lread=%.0f | pollspins=%llu | launch (cycles): election=%llu load+init=%llu steps=%llu write-out=%llu\n",
@@ -724,9 +731,9 @@ bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
     // everything else that fits one workgroup takes the LDS-exchange kernel, with 63 more workgroups for the speculative
     // candidate matrix of the next bond
     static const long wg_min = std::getenv("T4A_WG_MIN") ? std::atol(std::getenv("T4A_WG_MIN")) : 64;
-    if ((long long)kM * kN > wg_min && rrlu_wg_make_plan(kM, kN, &pl.xcd, 63)) {
+    if ((long long)kM * kN > wg_min && (rrlu_w1_make_plan(kM, kN, &pl.xcd, 63) || rrlu_wg_make_plan(kM, kN, &pl.xcd, 63))) {
         pl.kind = 2;
-        pl.code = 200000 + pl.xcd.RPT * 1000 + pl.xcd.CPT * 10;
+        pl.code = (pl.xcd.wg == 2 ? 300000 : 200000) + pl.xcd.RPT * 1000 + pl.xcd.CPT * 10;
         *out = pl;
         return true;
     }
@@ -777,7 +784,7 @@ bool Engine::chain_group_plan(int kM, int kN, ChainRrluPlan* out)
     ChainRrluPlan pl;
     pl.kM = kM;
     pl.kN = kN;
-    if (!rrlu_wg_make_plan(kM, kN, &pl.xcd, 0) && !rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32)) return false;
+    if (!rrlu_w1_make_plan(kM, kN, &pl.xcd, 0) && !rrlu_wg_make_plan(kM, kN, &pl.xcd, 0) && !rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32)) return false;
     pl.kind = 2;
     pl.code = 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
     *out = pl;

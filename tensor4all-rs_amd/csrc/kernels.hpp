@@ -183,7 +183,7 @@ struct RrluXcdPlan {
     int RPT = 1, CPT = 1;   // rows per lane / columns per wave (template parameters)
     int grid = 8;           // launched workgroups = 8 W (blocks b and b + 8 share an XCD)
     size_t lds_bytes = 0;
-    int wg = 0;             // 1: the one-workgroup kernel (kernels_rrlu_wg.hip): RPT rows per lane, CPT columns per WAVE, grid = 1 + speculating workgroups
+    int wg = 0;             // 1: the one-workgroup kernel (kernels_rrlu_wg.hip): RPT rows per lane, CPT columns per WAVE, grid = 1 + speculating workgroups; 2: the one-wave kernel (kernels_rrlu_w1.hip)
 };
 struct RrluXcdArgs {
     const double* A;            // M x N input (ld = M)
@@ -246,6 +246,11 @@ void rrlu_xcd2_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& arg
 bool rrlu_wg_make_plan(int M, int N, RrluXcdPlan* out, int spec_blocks = 0);
 void rrlu_wg_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
 void rrlu_wg_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
+// One-wave kernel (kernels_rrlu_w1.hip): matrices up to 64 x 64 in the registers of ONE wavefront (lane = row), no barrier and
+// no exchange at all.  Plans carry wg = 2, RPT = 1, CPT = register columns.  Same arguments, result block and give-up rule.
+bool rrlu_w1_make_plan(int M, int N, RrluXcdPlan* out, int spec_blocks = 0);
+void rrlu_w1_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
+void rrlu_w1_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // K1: candidate-matrix build (replaces the Π loop, tensor4all-tensorci/src/tensorci2.rs:1859-1893)
@@ -318,6 +323,20 @@ struct ChainPrepArgs {
     const int* prev_colperm;
     unsigned prev_token;
 };
+// The persistent half-sweep (kernels_chain.hip, chain_walk_kernel): one workgroup walks all bonds — preparation, candidate matrix,
+// one-wave rrLU — when every bond's matrix is at most 64 x 64.  Result blocks as the launched chain writes them.
+struct ChainWalkArgs {
+    char* blocks;                       // [n_bonds] packed result blocks (ChainBlock layout)
+    size_t block_bytes, off_piv, off_rp, off_cp, off_ts;
+    double* pi;                         // candidate matrix of the current bond (64 x 64 doubles)
+    int n_bonds;
+    int max_steps;                      // max_bond_dim (clipped to 64)
+    double rel_tol;
+    unsigned token_base;                // bond number k of the half-sweep completes with token token_base + k
+    int timed;                          // device time stamps of every factorisation at off_ts
+    unsigned long long* phase_ticks;    // diagnostic (T4A_WALK_DEBUG): [4] 100 MHz ticks summed over the bonds: preparation, candidate matrix, rrLU, total
+};
+void chain_walk_launch(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, int columns, hipStream_t stream);
 void chain_indep_launch(const ChainCommon& c, int n_bonds, hipStream_t stream);
 void chain_prep_launch(const ChainCommon& c, const ChainPrepArgs& a, hipStream_t stream);
 // n_dep_ub / n_ind_ub: upper bounds for the launch grid (the kernel reads the real sizes on the device)

@@ -34,6 +34,7 @@
 // A bond whose predecessor did not complete (bounded spin gave up, capacity exceeded) is POISONED: dimensions 0, every later
 // kernel of the chain does nothing, the host re-runs the half-sweep from that bond with the per-bond path.
 #include "kernels.hpp"
+#include "kernels_rrlu_w1_body.hpp"
 
 namespace t4a {
 
@@ -346,6 +347,143 @@ __global__ void __launch_bounds__(256) chain_pi_group_kernel(const ChainGroupSlo
     chain_pi_body(s.c, s.fn, b, s.pi);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The persistent half-sweep ("walker"): ONE workgroup walks all bonds of a half-sweep whose matrices fit the one-wave rrLU kernel
+// (at most 64 x 64: BASELINE configs[1], the first iterations of every run).  Per bond: the preparation above, the candidate
+// matrix by all threads, the factorisation by wave 0 (kernels_rrlu_w1_body.hpp) — no launch, no dispatch latency and no
+// end-of-kernel flush between them; the result blocks, dimensions, tables and mirrors are those of the launched chain, so the
+// host's chain_finish does not know the difference.  VERDICT round 3, item 3 (tensorci2.rs:1695-1725).
+//
+// Everything one phase writes and the next one reads goes through global memory inside one kernel: the vector stores of a
+// workgroup are visible to its own later loads (one compute unit, one L1), but uniform loads go through the SCALAR data cache,
+// which knows nothing of them — it is invalidated behind every barrier that separates a producer from a consumer.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void walk_phase_barrier()
+{
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NC, bool FORWARD>
+__global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDevice fn, ChainWalkArgs w)
+{
+    __shared__ __attribute__((aligned(16))) char w1lds[W1Lds<NC, false>::bytes];
+    const int tid = threadIdx.x;
+    const int nb = w.n_bonds;
+    unsigned long long ph[3] = {0ull, 0ull, 0ull};
+    const unsigned long long ph_t0 = w.phase_ticks ? wall_clock64() : 0ull;
+    unsigned long long ph_last = ph_t0;
+    auto phase = [&](int slot) {
+        if (w.phase_ticks) {
+            const unsigned long long now = wall_clock64();
+            ph[slot] += now - ph_last;
+            ph_last = now;
+        }
+    };
+    for (int k = 0; k <= nb; ++k) {
+        const int b = FORWARD ? k : nb - 1 - k;
+        ChainPrepArgs pa;
+        pa.b = b;
+        pa.do_build = k < nb ? 1 : 0; // (behind the last bond: its pivots only)
+        pa.with_rowmap = 0;
+        pa.prev_b = -1;
+        pa.prev_iresult = nullptr;
+        pa.prev_rowperm = nullptr;
+        pa.prev_colperm = nullptr;
+        pa.prev_token = 0u;
+        if (k > 0) {
+            const int pb = FORWARD ? b - 1 : b + 1;
+            const char* pblk = w.blocks + (size_t)pb * w.block_bytes;
+            pa.prev_b = pb;
+            pa.prev_iresult = reinterpret_cast<const int*>(pblk + 16);
+            pa.prev_rowperm = reinterpret_cast<const int*>(pblk + w.off_rp);
+            pa.prev_colperm = reinterpret_cast<const int*>(pblk + w.off_cp);
+            pa.prev_token = w.token_base + (unsigned)(k - 1);
+        }
+        chain_prep_body(c, pa);
+        walk_phase_barrier();
+        phase(0);
+        if (k == nb) break;
+        // ---- the candidate matrix: out[j * nd + i] = f(dependent i, independent j) ----
+        const int* dm = c.dims + (size_t)b * 4;
+        const int d0 = walk_load_i32(dm), d1 = walk_load_i32(dm + 1), poisoned = walk_load_i32(dm + 2);
+        const int nd = FORWARD ? d0 : d1, ni = FORWARD ? d1 : d0;
+        if (poisoned == 0 && nd > 0 && ni > 0 && nd <= 64 && ni <= NC) {
+            const int K = fn.n_acc;
+            const uint64_t* ia = c.ind_acc + (size_t)b * c.ind_cap * K;
+            for (int idx = tid; idx < nd * ni; idx += CHAIN_T) {
+                const int i = idx % nd, j = idx / nd;
+                uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+                for (int q = 0; q < K; ++q) acc[q] = c.dep_acc[(size_t)i * K + q] + ia[(size_t)j * K + q];
+                w.pi[idx] = t4a_fn_value(fn.fid, acc, fn.params);
+            }
+        }
+        walk_phase_barrier();
+        phase(1);
+        // ---- the factorisation: wave 0 (rows = the dependent side in both directions) ----
+        if (tid < 64 && poisoned == 0 && nd > 0 && ni > 0 && nd <= 64 && ni <= NC) {
+            char* blk = w.blocks + (size_t)b * w.block_bytes;
+            RrluXcdArgs a = {};
+            a.A = w.pi;
+            a.Aout = nullptr;
+            a.urows = nullptr;
+            a.M = nd;
+            a.N = ni;
+            a.max_steps = w.max_steps < (nd < ni ? nd : ni) ? w.max_steps : (nd < ni ? nd : ni);
+            a.rel_tol = w.rel_tol;
+            a.abs_tol = 0.0;
+            a.tie_row_major = FORWARD ? 0 : 1;
+            a.out_transposed = FORWARD ? 0 : 1;
+            a.W = 1;
+            a.xcc = 0;
+            a.ticket = nullptr;
+            a.ticket_base = 0u;
+            a.row_perm = reinterpret_cast<int*>(blk + (FORWARD ? w.off_rp : w.off_cp));
+            a.col_perm = reinterpret_cast<int*>(blk + (FORWARD ? w.off_cp : w.off_rp));
+            a.iresult = reinterpret_cast<int*>(blk + 16);
+            a.dresult = reinterpret_cast<double*>(blk);
+            a.pivot_vals = reinterpret_cast<double*>(blk + w.off_piv);
+            a.keys = nullptr;
+            a.salt = w.token_base + (unsigned)k;
+            a.spec_frac = 0.0;
+            a.stamps = nullptr;
+            a.h_block = nullptr;
+            a.block_u64 = 0;
+            a.dims = nullptr; // (the dimensions are known here: no device-side read, the token is written below)
+            a.dims_swap = 0;
+            a.rowmap = nullptr;
+            a.ts_u64 = 0;
+            const unsigned long long t0 = w.timed ? wall_clock64() : 0ull;
+            const int npiv = rrlu_w1_body<NC, !FORWARD, false>(a, w1lds);
+            if (npiv >= 0) {
+                if (w.timed && tid == 0) {
+                    unsigned long long* ts = reinterpret_cast<unsigned long long*>(blk + w.off_ts);
+                    ts[0] = t0;
+                    ts[1] = wall_clock64();
+                }
+                // (the next preparation runs on this compute unit, the host reads behind the end of the kernel: workgroup scope)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (tid == 0) a.iresult[3] = (int)a.salt; // completion token (what the next preparation and the host check)
+            }
+        }
+        walk_phase_barrier();
+        phase(2);
+    }
+    if (w.phase_ticks && tid == 0) {
+        for (int i = 0; i < 3; ++i) w.phase_ticks[i] = ph[i];
+        w.phase_ticks[3] = wall_clock64() - ph_t0;
+    }
+}
+
+template <int NC> void chain_walk_launch_nc(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, hipStream_t stream)
+{
+    if (c.forward) hipLaunchKernelGGL((chain_walk_kernel<NC, true>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+    else hipLaunchKernelGGL((chain_walk_kernel<NC, false>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+}
+
 } // namespace
 
 void chain_indep_launch(const ChainCommon& c, int n_bonds, hipStream_t stream)
@@ -380,6 +518,15 @@ void chain_pi_group_launch(const ChainGroupSlot* d_slots, int n_handles, int b, 
     if (n_dep_ub <= 0 || n_ind_ub <= 0 || n_handles <= 0) return;
     const int gy = n_ind_ub < 2048 ? n_ind_ub : 2048;
     hipLaunchKernelGGL(chain_pi_group_kernel, dim3((n_dep_ub + 255) / 256, gy, n_handles), dim3(256), 0, stream, d_slots, b);
+}
+
+// columns: the largest independent side of the half-sweep (<= 32: beyond that the one-workgroup kernel of the launched chain is
+// faster than one wave); every dependent side <= 64
+void chain_walk_launch(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, int columns, hipStream_t stream)
+{
+    if (columns <= 8) chain_walk_launch_nc<8>(c, fn, w, stream);
+    else if (columns <= 16) chain_walk_launch_nc<16>(c, fn, w, stream);
+    else chain_walk_launch_nc<32>(c, fn, w, stream);
 }
 
 } // namespace t4a

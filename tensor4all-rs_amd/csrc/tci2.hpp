@@ -123,6 +123,7 @@ public:
     // statistics of the device-side bond chain: [0] half-sweeps run as a chain [1] bonds run in chains [2] chains that fell back
     // to the per-bond path part-way [3] half-sweeps that were not eligible
     std::array<uint64_t, 5> chain_stats{{0, 0, 0, 0, 0}};
+    uint64_t chain_stats_walked = 0; // chained half-sweeps that ran as ONE persistent workgroup (kernels_chain.hip, chain_walk_kernel)
     bool chain_enabled = true;  // false: every half-sweep runs bond by bond (A/B measurements, tests)
     bool chain_verify = false;  // true: after every chain the device tables are read back and compared with the host's sets
     bool chain_event_timing = false; // profiling: rrLU launches of a chain are timed with HIP events around each launch instead of
@@ -281,6 +282,9 @@ private:
         std::vector<size_t> order;
         std::vector<ChainRrluPlan> plans;
         std::vector<unsigned> tokens;
+        DevBuf<unsigned long long> walk_dbg; // diagnostic phase times of the persistent half-sweep (T4A_WALK_DEBUG)
+        bool walked = false;         // the chain in flight is a persistent half-sweep
+        unsigned walk_token = 1;     // completion tokens of the persistent half-sweep (bond k of a walk: base + k)
         ChainBlock proto;
         bool timed = false, timed_events = false;
         std::vector<hipEvent_t> t0, t1; // per bond: around the rrLU launch (chain_event_timing)

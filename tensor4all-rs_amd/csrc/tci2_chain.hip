@@ -353,7 +353,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     chain_.ind_cnt.reserve(nb);
     chain_.dep.reserve(dep_cap * (1 + K));
     chain_.rowmap.reserve(dep_cap);
-    if (pi_cap) chain_.pi.reserve(pi_cap);
+    chain_.pi.reserve(std::max<size_t>(pi_cap, 64 * 64)); // (at least what the persistent half-sweep needs)
     if (spec_cap) {
         chain_.spec[0].reserve(spec_cap);
         chain_.spec[1].reserve(spec_cap);
@@ -505,8 +505,43 @@ void Tci2::chain_launch()
         static const bool no_spec = std::getenv("T4A_CHAIN_NO_SPEC") != nullptr;
         const bool solo = g_chains_inflight.fetch_add(1) == 0 && !no_spec;
         counted = true;
+        // every matrix of the half-sweep fits the one-wave kernel: ONE persistent workgroup walks the bonds (kernels_chain.hip)
+        static const bool no_walk = std::getenv("T4A_NO_WALK") != nullptr;
+        size_t walk_cols = 0;
+        bool walk = !no_walk && !timed_events && !per_launch_mirror;
+        for (size_t b = 0; walk && b < nb; ++b) {
+            walk = dep_ub[b] <= 64 && ind_ub[b] <= 32; // (wider: the launched chain's one-workgroup kernel beats one wave)
+            walk_cols = std::max(walk_cols, ind_ub[b]);
+        }
+        if (walk) {
+            ChainWalkArgs w;
+            std::memset(&w, 0, sizeof(w));
+            w.blocks = chain_.blocks.get();
+            w.block_bytes = proto.bytes;
+            w.off_piv = proto.off_piv;
+            w.off_rp = proto.off_rp;
+            w.off_cp = proto.off_cp;
+            w.off_ts = proto.off_ts;
+            w.pi = chain_.pi.get();
+            w.n_bonds = (int)nb;
+            w.max_steps = (int)std::min<size_t>(chi, 64);
+            w.rel_tol = chain_.tol;
+            if (chain_.walk_token > 0xFFFF0000u || chain_.walk_token == 0u) chain_.walk_token = 1u;
+            w.token_base = chain_.walk_token;
+            chain_.walk_token += (unsigned)nb;
+            w.timed = chain_.timed ? 1 : 0;
+            static const bool walk_dbg = std::getenv("T4A_WALK_DEBUG") != nullptr;
+            if (walk_dbg) {
+                chain_.walk_dbg.reserve(4);
+                w.phase_ticks = chain_.walk_dbg.get();
+            }
+            chain_.walked = true;
+            for (size_t k = 0; k < nb; ++k) tokens[order[k]] = w.token_base + (unsigned)k;
+            chain_walk_launch(c, fn_dev_, w, (int)walk_cols, st);
+            ++chain_stats_walked;
+        }
         bool spec_pending = false; // the previous bond's launch evaluates this bond's candidate matrix
-        for (size_t k = 0; k < nb; ++k) {
+        for (size_t k = 0; !walk && k < nb; ++k) {
             const size_t b = order[k];
             const ChainRrluPlan& pl = plans[b];
             const bool fused = pl.kind == 1 && pl.fused;
@@ -565,7 +600,7 @@ void Tci2::chain_launch()
                                        0.0, blk, spec_pending ? &sp : nullptr);
             if (timed_events) T4A_HIP(hipEventRecord(chain_.t1[b], st));
         }
-        { // the pivots of the last bond
+        if (!walk) { // the pivots of the last bond
             const size_t pb = order[nb - 1];
             const ChainBlock pblk = block_of(pb);
             ChainPrepArgs pa;
@@ -781,6 +816,13 @@ void Tci2::chain_finish(const TCI2Options& options)
         chain_.tables_valid = false;
         T4A_HIP(sync_err);
     }
+    if (chain_.walked && chain_.walk_dbg.get() && std::getenv("T4A_WALK_DEBUG")) {
+        unsigned long long t[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(t, chain_.walk_dbg.get(), sizeof(t), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[t4a walk] %zu bonds: preparation %.1f us, candidate matrix %.1f us, rrLU %.1f us, kernel %.1f us\n", nb, t[0] * 0.01, t[1] * 0.01,
+                     t[2] * 0.01, t[3] * 0.01);
+    }
+    chain_.walked = false;
     const int mnew = 1 - chain_.mcur;
     const ChainTab ni = chain_mirror(mnew, 0), nj = chain_mirror(mnew, 1);
     long failed_k = -1;

@@ -649,11 +649,14 @@ class TensorCI2:
         _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0), c_int32((1 if verify else 0) | (2 if event_timing else 0))))
 
     def chain_stats(self):
-        """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible, group_half_sweeps) since the handle was created."""
+        """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible, group_half_sweeps, walked_half_sweeps) since the
+        handle was created (walked: half-sweeps that ran as one persistent workgroup)."""
         out = np.zeros(5, dtype=np.uint64)
         _check(_lib.t4a_gpu_tci2_chain_stats(self._h, _p(out)))
+        walks = ctypes.c_uint64(0)
+        _check(_lib.t4a_gpu_tci2_chain_walks(self._h, ctypes.byref(walks)))
         return dict(half_sweeps=int(out[0]), bonds=int(out[1]), fell_back=int(out[2]), not_eligible=int(out[3]),
-                    group_half_sweeps=int(out[4]))
+                    group_half_sweeps=int(out[4]), walked_half_sweeps=int(walks.value))
 
 
 def optimize_group(tcis, options, final_sweep1site=True):

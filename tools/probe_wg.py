@@ -1,6 +1,6 @@
-"""One-workgroup rrLU kernel against what would run without it (T4A_NO_WG=1): time per pivot step as the SLOPE between a
-factorisation capped at r and one capped at r / 2 steps (the fixed cost of a call drops out), digests of both.
-Usage: python tools/probe_wg.py [M N r]...   (T4A_WG_MAXV=96 lifts the plan limit)"""
+"""One-wave and one-workgroup rrLU kernels against what would run without them (T4A_NO_W1=1, T4A_NO_WG=1): time per pivot step as
+the SLOPE between a factorisation capped at r and one capped at r / 2 steps (the fixed cost of a call drops out), digests of all.
+Usage: python tools/probe_wg.py [M N r]...   (T4A_WG_MAXV=96 lifts the plan limit of the one-workgroup kernel)"""
 import hashlib
 import os
 import subprocess
@@ -32,7 +32,7 @@ def child(M, N, r):
         out.append((min(ts), lu.npivots(), h.hexdigest()[:12]))
     (t1, n1, d1), (t2, n2, d2) = out
     slope = (t1 - t2) / max(n1 - n2, 1) * 1e6
-    print(f"{'nowg' if os.environ.get('T4A_NO_WG') else 'wg  '} M={M} N={N} steps={n1}/{n2} call_us={t1*1e6:.1f}/{t2*1e6:.1f} us_per_step(slope)={slope:.3f} digest={d1}", flush=True)
+    print(f"{'old ' if os.environ.get('T4A_NO_WG') else 'wg  ' if os.environ.get('T4A_NO_W1') else 'w1  '} M={M} N={N} steps={n1}/{n2} call_us={t1*1e6:.1f}/{t2*1e6:.1f} us_per_step(slope)={slope:.3f} digest={d1}", flush=True)
 
 
 if __name__ == "__main__":
@@ -40,10 +40,11 @@ if __name__ == "__main__":
         child(*(int(x) for x in sys.argv[2:5]))
         sys.exit(0)
     args = [int(x) for x in sys.argv[1:]]
-    shapes = [tuple(args[i:i + 3]) for i in range(0, len(args) - 2, 3)] or [(16, 16, 16), (32, 32, 32), (64, 64, 64), (32, 128, 32), (64, 128, 64), (128, 128, 128), (64, 256, 64), (128, 256, 128), (128, 384, 128), (64, 512, 64)]
+    shapes = [tuple(args[i:i + 3]) for i in range(0, len(args) - 2, 3)] or [(8, 8, 8), (16, 16, 16), (32, 32, 32), (64, 32, 32), (32, 64, 32), (64, 64, 64), (32, 128, 32), (64, 128, 64), (128, 128, 128), (64, 256, 64), (128, 256, 128), (128, 384, 128), (64, 512, 64)]
     for (M, N, r) in shapes:
-        for nowg in (0, 1):
+        for extra in ({}, {"T4A_NO_W1": "1"}, {"T4A_NO_W1": "1", "T4A_NO_WG": "1"}):
+            if extra == {} and (M > 64 or N > 64):
+                continue
             env = dict(os.environ)
-            if nowg:
-                env["T4A_NO_WG"] = "1"
+            env.update(extra)
             subprocess.call(["timeout", "120", sys.executable, __file__, "child", str(M), str(N), str(r)], env=env)
