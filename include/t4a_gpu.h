@@ -697,10 +697,13 @@ t4a_gpu_status t4a_gpu_tci2_profile_variants(const t4a_gpu_tci2* h, double* out 
  * beyond the device-dimension kernels) and ran bond by bond, out[4] chained half-sweeps that ran as part of a GROUP chain (one
  * launch per kernel and bond for all handles of a t4a_gpu_tci2_optimize_group call; counted in out[0] as well). */
 t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out /* [5] */);
-/* Chained half-sweeps (counted in chain_stats out[0]) that ran as ONE persistent workgroup walking all bonds — every matrix of the
- * half-sweep at most 64 x 64: small-rank problems and the first iterations of every run (same update_pivots semantics,
- * tensorci2.rs:1695-1725, :1821-2007; one launch per half-sweep instead of three per bond). */
-t4a_gpu_status t4a_gpu_tci2_chain_walks(const t4a_gpu_tci2* h, uint64_t* out);
+/* More of the same: out[0] chained sweeps (2-site half-sweeps counted in chain_stats out[0], and 1-site sweeps) that ran as ONE
+ * persistent workgroup walking all bonds — every matrix of the sweep at most 64 x 32: small-rank problems and the first iterations
+ * of every run (one launch per sweep instead of three per bond); out[1] 1-site sweeps (t4a_gpu_tci2_sweep1site, make_canonical,
+ * the final sweep of optimize: tensorci2.rs:865-1050) that ran as a device-side chain — the independent side of every bond is the
+ * index table itself, the site tensors come from the factored matrices the chain leaves behind; out[2] 1-site sweeps that were
+ * not eligible and ran bond by bond; out[3] chained 1-site sweeps that fell back to the per-bond path part-way. */
+t4a_gpu_status t4a_gpu_tci2_chain_stats_ext(const t4a_gpu_tci2* h, uint64_t* out /* [4] */);
 /* optimize_with_finder (tensorci2.rs:1626-1802) on up to EIGHT handles at once, driven in lock-step by the calling thread: every
  * iteration enqueues the half-sweeps of all handles — as ONE chain of launches when they line up (same number of sites, built-in
  * functors: every kernel serves all handles, handle i's rrLU runs on XCD i), otherwise one chain per handle — then completes them

@@ -1009,12 +1009,12 @@ t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out)
     });
 }
 
-t4a_gpu_status t4a_gpu_tci2_chain_walks(const t4a_gpu_tci2* h, uint64_t* out)
+t4a_gpu_status t4a_gpu_tci2_chain_stats_ext(const t4a_gpu_tci2* h, uint64_t* out)
 {
     return guarded([&] {
         T4A_REQUIRE_PTR(h);
         T4A_REQUIRE_PTR(out);
-        *out = h->impl.chain_stats_walked;
+        for (int k = 0; k < 4; ++k) out[k] = h->impl.chain_stats_ext[k];
     });
 }
 

@@ -858,7 +858,7 @@ unsigned Engine::chain_group_args(const ChainRrluPlan& pl, bool left, const doub
 }
 
 unsigned Engine::chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_a, const int* d_rowmap, const FusedPi* fused, const int* d_dims,
-                            size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec)
+                            size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec, double* d_aout, double* d_urows)
 {
     double* d_dres = reinterpret_cast<double*>(blk.dev);
     int* d_ires = reinterpret_cast<int*>(blk.dev + 16);
@@ -872,6 +872,8 @@ unsigned Engine::chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_
         RrluXcdArgs a;
         token = chain_group_args(pl, left, d_a, d_dims, max_bond_dim, rel_tol, abs_tol, blk, xcc_, &a, stream_);
         a.rowmap = d_rowmap;
+        a.Aout = d_aout;
+        a.urows = d_aout ? d_urows : nullptr;
         if (spec) a.spec = *spec;
         rrlu_xcd_launch_v(xcd_version(), pl.xcd, a, stream_);
     } else {
@@ -879,7 +881,7 @@ unsigned Engine::chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_
         RrluRegArgs a;
         std::memset(&a, 0, sizeof(a));
         a.A = d_a;
-        a.Aout = nullptr;
+        a.Aout = d_aout;
         a.M = pl.kM;
         a.N = pl.kN;
         a.max_steps = max_steps;
@@ -924,13 +926,13 @@ unsigned Engine::chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_
 }
 
 // factors_from_rrlu (matrix_luci.rs:256-279) on the factored matrix in d_lu_ (permuted coordinates).
-void Engine::build_factors(const LuciResult& r, bool left_orth)
+void Engine::build_factors(const LuciResult& r, bool left_orth) { build_factors_from(d_lu_.get(), d_rowperm_ptr_, d_colperm_ptr_, r.M, r.N, r.rank, left_orth); }
+
+void Engine::build_factors_from(const double* lu, const int* d_rowperm_ptr_, const int* d_colperm_ptr_, int M, int N, int rk, bool left_orth)
 {
-    const int M = r.M, N = r.N, rk = r.rank;
     d_left_.reserve((size_t)M * (rk > 0 ? rk : 1));
     d_right_.reserve((size_t)N * (rk > 0 ? rk : 1));
     if (rk == 0) return;
-    const double* lu = d_lu_.get();
     static const bool no_small = std::getenv("T4A_NO_SMALL_FACTORS") != nullptr;
     if (!no_small && luci_factors_small_launch(lu, M, N, rk, d_rowperm_ptr_, d_colperm_ptr_, left_orth, d_left_.get(), d_right_.get(), stream_)) {
         T4A_HIP(hipGetLastError());
@@ -960,6 +962,9 @@ void Engine::build_factors(const LuciResult& r, bool left_orth)
             tp.lower = 0;
             tp.unit_diag = 1; // L11 has a unit diagonal (dividing by 1.0 is exact)
             tp.skip_flag = nullptr;
+            // (the pinned descriptor may still wait for the upload of the previous call: callers that build factors back to back —
+            // the chained 1-site sweep — do not synchronise in between)
+            T4A_HIP(hipStreamSynchronize(stream_));
             *h_trsm_.get() = tp;
             T4A_HIP(hipMemcpyAsync(d_trsm_.get(), h_trsm_.get(), sizeof(TrsmProblem), hipMemcpyHostToDevice, stream_));
             trsm_left_batched_launch(d_trsm_.get(), 1, rk, M - rk, stream_);
@@ -1035,6 +1040,9 @@ void Engine::build_factors(const LuciResult& r, bool left_orth)
             tp.lower = 0;
             tp.unit_diag = 1; // U11 carries a forced unit diagonal (matrixlu.rs:647-651)
             tp.skip_flag = nullptr;
+            // (the pinned descriptor may still wait for the upload of the previous call: callers that build factors back to back —
+            // the chained 1-site sweep — do not synchronise in between)
+            T4A_HIP(hipStreamSynchronize(stream_));
             *h_trsm_.get() = tp;
             T4A_HIP(hipMemcpyAsync(d_trsm_.get(), h_trsm_.get(), sizeof(TrsmProblem), hipMemcpyHostToDevice, stream_));
             trsm_left_batched_launch(d_trsm_.get(), 1, rk, N - rk, stream_);

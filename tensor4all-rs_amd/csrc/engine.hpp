@@ -134,7 +134,7 @@ public:
     // completion token the kernel writes to iresult[3] of the device block (and to int word 7 of the host mirror).
     // spec (single-XCD plans only, may be null): the candidate matrix of the NEXT bond for the launch's pass-through workgroups.
     unsigned chain_rrlu(const ChainRrluPlan& pl, bool left, const double* d_a, const int* d_rowmap, const FusedPi* fused, const int* d_dims,
-                        size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec);
+                        size_t max_bond_dim, double rel_tol, double abs_tol, const ChainBlock& blk, const XcdSpecArgs* spec, double* d_aout = nullptr, double* d_urows = nullptr);
     void chain_end();
     // Group chain (tci2_chain.hip): several handles advance in lock step, one rrLU launch per bond for all of them, handle i on
     // XCD `slot` i.  chain_group_plan: the single-XCD plan every member uses for a bond (made for the largest upper bounds in
@@ -163,6 +163,11 @@ public:
 
 private:
     void build_factors(const LuciResult& r, bool left_orth);
+public:
+    // factors_from_rrlu on a factored matrix that sits somewhere else (the per-bond buffers of a chained 1-site sweep): left() /
+    // right() hold the factors afterwards, on the engine's stream.  d_rowperm / d_colperm: the full permutations on the device.
+    void build_factors_from(const double* d_lu, const int* d_rowperm, const int* d_colperm, int M, int N, int rank, bool left_orth);
+private:
 
     XcdArbiter::Lock chain_lock_;
     hipStream_t stream_ = nullptr;

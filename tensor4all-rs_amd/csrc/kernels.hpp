@@ -293,6 +293,8 @@ struct ChainCommon {
     const int* ldim;          // [n_sites] local dimensions
     const int* woff;          // [n_sites] offset of a site in a weight row
     int forward, use_extras;
+    int one_site;             // 1: a 1-site sweep (tensorci2.rs:918-1050): the independent side of bond b is the table itself — J_b
+                              // sweeping forward, I_{b+1} sweeping backward — without Kronecker product and without extras
     uint64_t* ind_code;       // [n_bonds][ind_cap]     independent side of every bond (columns forward, rows backward)
     uint64_t* ind_acc;        // [n_bonds][ind_cap][K]
     int* ind_cnt;             // [n_bonds]
@@ -331,7 +333,9 @@ struct ChainWalkArgs {
     double* pi;                         // candidate matrix of the current bond (64 x 64 doubles)
     int n_bonds;
     int max_steps;                      // max_bond_dim (clipped to 64)
-    double rel_tol;
+    double rel_tol, abs_tol;
+    double* factors;                    // != nullptr: the factored matrix of bond b (permuted coordinates, original orientation) at factors + b * factors_stride
+    size_t factors_stride;
     unsigned token_base;                // bond number k of the half-sweep completes with token token_base + k
     int timed;                          // device time stamps of every factorisation at off_ts
     unsigned long long* phase_ticks;    // diagnostic (T4A_WALK_DEBUG): [4] 100 MHz ticks summed over the bonds: preparation, candidate matrix, rrLU, total

@@ -164,7 +164,16 @@ __device__ __forceinline__ void chain_indep_body(const ChainCommon& c)
     uint64_t* ocode = c.ind_code + (size_t)b * c.ind_cap;
     uint64_t* oacc = c.ind_acc + (size_t)b * c.ind_cap * K;
     int n;
-    if (c.forward) { // columns: kron(d_{b+1}, J_{b+1}) ∪ HJ_b
+    if (c.one_site) { // 1-site sweep: the table itself (forward: the columns J_b; backward: the rows I_{b+1})
+        const ChainTab& T = c.forward ? c.J : c.I;
+        const int site = c.forward ? b : b + 1;
+        const int np = T.cnt[site];
+        n = (np >= 1 && np <= c.cap && np <= c.ind_cap) ? np : -1;
+        for (int i = threadIdx.x; i < n; i += CHAIN_T) {
+            ocode[i] = T.code[(size_t)site * cap + i];
+            for (int k = 0; k < K; ++k) oacc[(size_t)i * K + k] = T.acc[((size_t)site * cap + i) * K + k];
+        }
+    } else if (c.forward) { // columns: kron(d_{b+1}, J_{b+1}) ∪ HJ_b
         const int np = c.J.cnt[b + 1], ne = c.use_extras ? c.HJ.cnt[b] : 0;
         n = (np >= 1 && np <= c.cap && ne <= c.cap)
                 ? build_side<false>(c.J.code + (size_t)(b + 1) * cap, c.J.acc + (size_t)(b + 1) * cap * K, np, c.ldim[b + 1], c.w, K, c.total,
@@ -367,10 +376,10 @@ __device__ __forceinline__ void walk_phase_barrier()
 }
 __device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NC, bool FORWARD>
+template <int NC, bool FORWARD, bool FACTORS>
 __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDevice fn, ChainWalkArgs w)
 {
-    __shared__ __attribute__((aligned(16))) char w1lds[W1Lds<NC, false>::bytes];
+    __shared__ __attribute__((aligned(16))) char w1lds[W1Lds<NC, FACTORS>::bytes];
     const int tid = threadIdx.x;
     const int nb = w.n_bonds;
     unsigned long long ph[3] = {0ull, 0ull, 0ull};
@@ -428,13 +437,13 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
             char* blk = w.blocks + (size_t)b * w.block_bytes;
             RrluXcdArgs a = {};
             a.A = w.pi;
-            a.Aout = nullptr;
+            a.Aout = FACTORS ? w.factors + (size_t)b * w.factors_stride : nullptr;
             a.urows = nullptr;
             a.M = nd;
             a.N = ni;
             a.max_steps = w.max_steps < (nd < ni ? nd : ni) ? w.max_steps : (nd < ni ? nd : ni);
             a.rel_tol = w.rel_tol;
-            a.abs_tol = 0.0;
+            a.abs_tol = w.abs_tol;
             a.tie_row_major = FORWARD ? 0 : 1;
             a.out_transposed = FORWARD ? 0 : 1;
             a.W = 1;
@@ -457,7 +466,7 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
             a.rowmap = nullptr;
             a.ts_u64 = 0;
             const unsigned long long t0 = w.timed ? wall_clock64() : 0ull;
-            const int npiv = rrlu_w1_body<NC, !FORWARD, false>(a, w1lds);
+            const int npiv = rrlu_w1_body<NC, !FORWARD, FACTORS>(a, w1lds);
             if (npiv >= 0) {
                 if (w.timed && tid == 0) {
                     unsigned long long* ts = reinterpret_cast<unsigned long long*>(blk + w.off_ts);
@@ -480,8 +489,13 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
 
 template <int NC> void chain_walk_launch_nc(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, hipStream_t stream)
 {
-    if (c.forward) hipLaunchKernelGGL((chain_walk_kernel<NC, true>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
-    else hipLaunchKernelGGL((chain_walk_kernel<NC, false>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+    if (w.factors) {
+        if (c.forward) hipLaunchKernelGGL((chain_walk_kernel<NC, true, true>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+        else hipLaunchKernelGGL((chain_walk_kernel<NC, false, true>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+    } else {
+        if (c.forward) hipLaunchKernelGGL((chain_walk_kernel<NC, true, false>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+        else hipLaunchKernelGGL((chain_walk_kernel<NC, false, false>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+    }
 }
 
 } // namespace

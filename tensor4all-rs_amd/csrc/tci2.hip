@@ -849,7 +849,33 @@ void Tci2::sweep1site(bool forward, double rel_tol, double abs_tol, size_t max_b
     fill_wait();
     flush_pivot_errors();
     invalidate_site_tensors();
-    if (forward) {
+    // built-in functor: the whole sweep as one chain on the device (tci2_chain.hip; the independent side of every bond is the
+    // table itself), the site tensors from the factored matrices it leaves behind
+    bool chained = false;
+    static const bool no_chain1 = std::getenv("T4A_NO_CHAIN_1SITE") != nullptr;
+    if (!no_chain1 && n_ >= 2) {
+        TCI2Options o1;
+        o1.tolerance = rel_tol;
+        o1.max_bond_dim = max_bond_dim == std::numeric_limits<size_t>::max() ? 0 : max_bond_dim;
+        o1.pivot_search = 0;
+        o1.nsearch = 0;
+        prep_.valid = false;
+        prefetch_.wanted = false;
+        chain_.one_site = true;
+        chain_.one_factors = update_tensors;
+        chain_.abs_tol = abs_tol;
+        try {
+            chained = chain_enqueue(forward, o1, -1, false);
+            if (chained) chain_finish(o1);
+        } catch (...) {
+            chain_.one_site = false;
+            throw;
+        }
+        chain_.one_site = false;
+    }
+    if (chained) {
+        // (every bond went through the chain or through its per-bond tail)
+    } else if (forward) {
         for (size_t b = 0; b + 1 < n_; ++b) sweep1site_at_bond(b, true, rel_tol, abs_tol, max_bond_dim, update_tensors);
     } else {
         for (size_t b = n_ - 1; b >= 1; --b) sweep1site_at_bond(b, false, rel_tol, abs_tol, max_bond_dim, update_tensors);

@@ -123,7 +123,10 @@ public:
     // statistics of the device-side bond chain: [0] half-sweeps run as a chain [1] bonds run in chains [2] chains that fell back
     // to the per-bond path part-way [3] half-sweeps that were not eligible
     std::array<uint64_t, 5> chain_stats{{0, 0, 0, 0, 0}};
-    uint64_t chain_stats_walked = 0; // chained half-sweeps that ran as ONE persistent workgroup (kernels_chain.hip, chain_walk_kernel)
+    // [0] chained sweeps (2-site half-sweeps and 1-site sweeps) that ran as ONE persistent workgroup (kernels_chain.hip,
+    // chain_walk_kernel) [1] 1-site sweeps (sweep1site) that ran as a chain [2] 1-site sweeps that were not eligible and ran bond
+    // by bond [3] chained 1-site sweeps that fell back to the per-bond path part-way
+    std::array<uint64_t, 4> chain_stats_ext{{0, 0, 0, 0}};
     bool chain_enabled = true;  // false: every half-sweep runs bond by bond (A/B measurements, tests)
     bool chain_verify = false;  // true: after every chain the device tables are read back and compared with the host's sets
     bool chain_event_timing = false; // profiling: rrLU launches of a chain are timed with HIP events around each launch instead of
@@ -282,6 +285,12 @@ private:
         std::vector<size_t> order;
         std::vector<ChainRrluPlan> plans;
         std::vector<unsigned> tokens;
+        // a 1-site sweep as a chain (sweep1site, tensorci2.rs:865-1050): set by sweep1site() around chain_enqueue / chain_finish
+        bool one_site = false;       // the independent side is the table itself, no extras; both tolerances apply
+        bool one_factors = false;    // update_tensors: every bond's factored matrix is kept and its LUCI factor becomes the site tensor
+        double abs_tol = 0.0;
+        DevBuf<double> factors, urows; // [n_bonds][factors_stride] factored matrices; finished rows of U of the bond in flight
+        size_t factors_stride = 0;
         DevBuf<unsigned long long> walk_dbg; // diagnostic phase times of the persistent half-sweep (T4A_WALK_DEBUG)
         bool walked = false;         // the chain in flight is a persistent half-sweep
         unsigned walk_token = 1;     // completion tokens of the persistent half-sweep (bond k of a walk: base + k)

@@ -249,13 +249,15 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
 {
     if (chain_.inflight || chain_.prepared) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: a chain is already in flight");
     if (!chain_usable(options)) {
-        ++chain_stats[3];
+        ++(chain_.one_site ? chain_stats_ext[2] : chain_stats[3]);
         return false;
     }
     const size_t nb = n_ - 1;
     const size_t K = (size_t)fn_dev_.n_acc;
     const size_t chi = options.max_bond_dim_or_max();
     hipStream_t st = eng.stream();
+    const bool one = chain_.one_site;
+    if (one && (ext_idx >= 0 || in_optimize || !launch)) throw Error(T4A_GPU_INTERNAL_ERROR, "bond chain: a 1-site sweep has no extras, no snapshot and no group");
     HistEntry* ext = ext_idx >= 0 ? &history[(size_t)ext_idx] : nullptr;
 
     // ---- 1. upper bounds of every bond's shape (set sizes only), launch plans ----
@@ -279,8 +281,9 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     size_t Mcap = 1, Ncap = 1, steps_cap = 1, pi_cap = 0, spec_cap = 0, dep_cap = 1, ind_cap = 1;
     for (size_t k = 0; k < nb; ++k) {
         const size_t b = order[k];
-        const size_t Mub = cI[b] * local_dims[b] + eI[b + 1];
-        const size_t Nub = cJ[b + 1] * local_dims[b + 1] + eJ[b];
+        // (1-site sweep: the independent side is J_b / I_{b+1} itself, tensorci2.rs:931-944)
+        const size_t Mub = one ? (forward ? cI[b] * local_dims[b] : cI[b + 1]) : cI[b] * local_dims[b] + eI[b + 1];
+        const size_t Nub = one ? (forward ? cJ[b] : cJ[b + 1] * local_dims[b + 1]) : cJ[b + 1] * local_dims[b + 1] + eJ[b];
         const size_t rub = std::max<size_t>(std::min({Mub, Nub, chi}), 1);
         cI[b + 1] = rub; // bond b writes I_{b+1} and J_b
         cJ[b] = rub;
@@ -288,7 +291,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
         dep_ub[b] = forward ? Mub : Nub; // the kernel's rows are the dependent side in both directions
         ind_ub[b] = forward ? Nub : Mub;
         if (dep_ub[b] > 65535 || ind_ub[b] > 65535 || !eng.chain_plan((int)dep_ub[b], (int)ind_ub[b], &plans[b])) {
-            ++chain_stats[3];
+            ++(one ? chain_stats_ext[2] : chain_stats[3]);
             return false;
         }
         plans[b].code += forward ? 0 : 4; // (row-major tie order of the transposed problem)
@@ -309,7 +312,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
         }
     }
     if (need_cap > (size_t)CHAIN_MAX_SET) {
-        ++chain_stats[3];
+        ++(one ? chain_stats_ext[2] : chain_stats[3]);
         return false;
     }
 
@@ -354,6 +357,14 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     chain_.dep.reserve(dep_cap * (1 + K));
     chain_.rowmap.reserve(dep_cap);
     chain_.pi.reserve(std::max<size_t>(pi_cap, 64 * 64)); // (at least what the persistent half-sweep needs)
+    chain_.factors_stride = 0;
+    if (one && chain_.one_factors) {
+        size_t stride = 1;
+        for (size_t b = 0; b < nb; ++b) stride = std::max(stride, dep_ub[b] * ind_ub[b]);
+        chain_.factors_stride = stride;
+        chain_.factors.reserve(nb * stride);
+        chain_.urows.reserve(std::max<size_t>(steps_cap, 1) * std::max(dep_cap, ind_cap));
+    }
     if (spec_cap) {
         chain_.spec[0].reserve(spec_cap);
         chain_.spec[1].reserve(spec_cap);
@@ -422,6 +433,7 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     c.woff = chain_.siteinfo.get() + n_;
     c.forward = forward ? 1 : 0;
     c.use_extras = use_extras ? 1 : 0;
+    c.one_site = one ? 1 : 0;
     c.ind_code = chain_.ind.get();
     c.ind_acc = chain_.ind.get() + nb * ind_cap;
     c.ind_cnt = chain_.ind_cnt.get();
@@ -526,6 +538,9 @@ void Tci2::chain_launch()
             w.n_bonds = (int)nb;
             w.max_steps = (int)std::min<size_t>(chi, 64);
             w.rel_tol = chain_.tol;
+            w.abs_tol = chain_.one_site ? chain_.abs_tol : 0.0;
+            w.factors = chain_.factors_stride ? chain_.factors.get() : nullptr;
+            w.factors_stride = chain_.factors_stride;
             if (chain_.walk_token > 0xFFFF0000u || chain_.walk_token == 0u) chain_.walk_token = 1u;
             w.token_base = chain_.walk_token;
             chain_.walk_token += (unsigned)nb;
@@ -538,7 +553,7 @@ void Tci2::chain_launch()
             chain_.walked = true;
             for (size_t k = 0; k < nb; ++k) tokens[order[k]] = w.token_base + (unsigned)k;
             chain_walk_launch(c, fn_dev_, w, (int)walk_cols, st);
-            ++chain_stats_walked;
+            ++chain_stats_ext[0];
         }
         bool spec_pending = false; // the previous bond's launch evaluates this bond's candidate matrix
         for (size_t k = 0; !walk && k < nb; ++k) {
@@ -597,7 +612,8 @@ void Tci2::chain_launch()
             const double* A = fused ? nullptr : (spec_here ? chain_.spec[k & 1].get() : chain_.pi.get());
             if (timed_events) T4A_HIP(hipEventRecord(chain_.t0[b], st));
             tokens[b] = eng.chain_rrlu(pl, forward, A, spec_here ? c.rowmap : nullptr, fused ? &fp : nullptr, c.dims + b * 4, chi, chain_.tol,
-                                       0.0, blk, spec_pending ? &sp : nullptr);
+                                       chain_.one_site ? chain_.abs_tol : 0.0, blk, spec_pending ? &sp : nullptr,
+                                       chain_.factors_stride ? chain_.factors.get() + b * chain_.factors_stride : nullptr, chain_.urows.get());
             if (timed_events) T4A_HIP(hipEventRecord(chain_.t1[b], st));
         }
         if (!walk) { // the pivots of the last bond
@@ -909,8 +925,16 @@ void Tci2::chain_finish(const TCI2Options& options)
             }
         }
         if (abs_max > max_sample_value) max_sample_value = abs_max; // update_max_sample_value over Π (tensorci2.rs:2009-2014)
-        last_sweep_shapes[b] = {M, N, (size_t)rank};
-        bond_errors[b] = last_error; // = pivot_errors.back() (tensorci2.rs:2002-2004)
+        bond_errors[b] = last_error; // = pivot_errors.back() (tensorci2.rs:2002-2004, :1040-1046)
+        if (chain_.one_site) { // sweep1site_at_bond's tail (tensorci2.rs:1040-1049): the pivot errors of the bond join the running maxima
+            std::vector<double> pe((size_t)rank + 1);
+            const double* pv = reinterpret_cast<const double*>(hb + proto.off_piv);
+            for (int q = 0; q < rank; ++q) pe[(size_t)q] = std::sqrt(pv[q] * pv[q]);
+            pe[(size_t)rank] = last_error;
+            update_pivot_errors(pe);
+        } else {
+            last_sweep_shapes[b] = {M, N, (size_t)rank};
+        }
     }
     if (done > 0) { // the new mirror becomes the host's copy of the sets; what this chain did not write comes from the old one
         const ChainTab oi = chain_mirror(chain_.mcur, 0), oj = chain_mirror(chain_.mcur, 1);
@@ -934,10 +958,38 @@ void Tci2::chain_finish(const TCI2Options& options)
         chain_.mcur = mnew;
         chain_.digits_stale = true;
     }
+    if (chain_.one_site && chain_.factors_stride) {
+        // update_tensors: the LUCI factor of every completed bond becomes its site tensor (tensorci2.rs:1020-1038) — the factored
+        // matrices waited in their per-bond buffers, the permutations in the result blocks
+        for (size_t k = 0; k < done; ++k) {
+            const size_t b = chain_.order[k];
+            const int* hd = chain_.hdims.get() + b * 4;
+            const int rank = reinterpret_cast<const int*>(chain_.hblocks.get() + b * proto.bytes + 16)[0];
+            char* dblk = chain_.blocks.get() + b * proto.bytes;
+            LuciResult lu;
+            lu.M = hd[0];
+            lu.N = hd[1];
+            lu.rank = rank;
+            eng.build_factors_from(chain_.factors.get() + b * chain_.factors_stride, reinterpret_cast<const int*>(dblk + proto.off_rp),
+                                   reinterpret_cast<const int*>(dblk + proto.off_cp), lu.M, lu.N, rank, forward);
+            if (forward) {
+                const size_t left_dim = (b == 0) ? 1 : i_set[b].count;
+                set_core_from_left(b, left_dim, local_dims[b], lu);
+            } else {
+                const size_t site = b + 1;
+                const size_t right_dim = (site == n_ - 1) ? 1 : j_set[site].count;
+                set_core_from_right(site, local_dims[site], right_dim, lu);
+            }
+        }
+    }
     if (failed_k < 0) {
-        ++chain_stats[0];
-        if (was_group) ++chain_stats[4];
-        chain_stats[1] += nb;
+        if (chain_.one_site) {
+            ++chain_stats_ext[1];
+        } else {
+            ++chain_stats[0];
+            if (was_group) ++chain_stats[4];
+            chain_stats[1] += nb;
+        }
         if (chain_verify) { // tests: the mirror decodes to index sets whose codes / accumulators are the mirror's, and equals the device tables
             sync_digits();
             std::vector<uint64_t> a;
@@ -979,7 +1031,7 @@ void Tci2::chain_finish(const TCI2Options& options)
     // a bond did not complete (bounded spin gave up: the placement assumption of the single-XCD kernel failed or another
     // process holds its compute units; a capacity bound was hit; NaN in the factors): the rest of the half-sweep runs bond by
     // bond (a NaN is met again there and reported as NaNEncountered like the reference does)
-    ++chain_stats[2];
+    ++(chain_.one_site ? chain_stats_ext[3] : chain_stats[2]);
     sync_digits();
     chain_.tables_valid = false;
     if (failed_timeout && chain_.plans[chain_.order[(size_t)failed_k]].kind == 2) xcd_disable();
@@ -1003,7 +1055,10 @@ void Tci2::chain_finish(const TCI2Options& options)
     }
     for (size_t k = (size_t)failed_k; k < nb; ++k) {
         const size_t b = chain_.order[k];
-        update_pivots(b, forward, options, (*xi)[b + 1], (*xj)[b]);
+        if (chain_.one_site)
+            sweep1site_at_bond(forward ? b : b + 1, forward, options.tolerance, chain_.abs_tol, options.max_bond_dim_or_max(), chain_.one_factors);
+        else
+            update_pivots(b, forward, options, (*xi)[b + 1], (*xj)[b]);
     }
 }
 

@@ -649,14 +649,16 @@ class TensorCI2:
         _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0), c_int32((1 if verify else 0) | (2 if event_timing else 0))))
 
     def chain_stats(self):
-        """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible, group_half_sweeps, walked_half_sweeps) since the
-        handle was created (walked: half-sweeps that ran as one persistent workgroup)."""
+        """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible, group_half_sweeps) of the 2-site half-sweeps since
+        the handle was created, plus walked_sweeps (sweeps that ran as one persistent workgroup) and one_site_sweeps /
+        one_site_not_eligible / one_site_fell_back for sweep1site."""
         out = np.zeros(5, dtype=np.uint64)
         _check(_lib.t4a_gpu_tci2_chain_stats(self._h, _p(out)))
-        walks = ctypes.c_uint64(0)
-        _check(_lib.t4a_gpu_tci2_chain_walks(self._h, ctypes.byref(walks)))
+        ext = np.zeros(4, dtype=np.uint64)
+        _check(_lib.t4a_gpu_tci2_chain_stats_ext(self._h, _p(ext)))
         return dict(half_sweeps=int(out[0]), bonds=int(out[1]), fell_back=int(out[2]), not_eligible=int(out[3]),
-                    group_half_sweeps=int(out[4]), walked_half_sweeps=int(walks.value))
+                    group_half_sweeps=int(out[4]), walked_sweeps=int(ext[0]), one_site_sweeps=int(ext[1]),
+                    one_site_not_eligible=int(ext[2]), one_site_fell_back=int(ext[3]))
 
 
 def optimize_group(tcis, options, final_sweep1site=True):
