@@ -384,6 +384,25 @@ void gemm_launch(const GemmDesc& d, hipStream_t stream);
 
 // LUCI factors of a small factorisation (rank <= 16, M, N <= 1024) in one launch: lu = factored M x N matrix in permuted coordinates (ld M),
 // left: M x rk (ld M), right: rk x N (ld rk), both in original row / column order.  Returns false when the shape is not taken.
+// The site tensors of a chained forward 1-site sweep (tensorci2.rs:1020-1038) for every bond whose rank is at most 16, in ONE launch
+// behind the chain: job b reads its shape, rank and row permutation where the chain left them on the device, forms
+// left = P_row^T [I_r ; L21 L11^{-1}] exactly like luci_factors_small_kernel and writes it as core[l, s, r] (column-major, R = max(rank, 1)).
+// Bonds of higher rank, poisoned or unfinished bonds are left alone (the host builds those one by one).
+constexpr int LUCI_LEFT_CORES_MAX_JOBS = 80;
+constexpr int LUCI_LEFT_CORES_MAX_RANK = 16;
+struct LeftCoreJob {
+    const double* lu;       // factored matrix (permuted coordinates, ld = rows)
+    const int* dims;        // {rows, columns, poisoned, -}
+    const int* iresult;     // {rank, gave-up code, NaN flag, completion token}
+    const int* row_perm;
+    double* core;           // [L = rows / S][S][R]
+    int S;
+    unsigned token;         // the completion token the bond must carry
+};
+struct LeftCoreJobs {
+    LeftCoreJob j[LUCI_LEFT_CORES_MAX_JOBS];
+};
+void luci_left_cores_batched_launch(const LeftCoreJobs& jobs, int n_jobs, int max_rows, hipStream_t stream);
 bool luci_factors_small_launch(const double* lu, int M, int N, int rk, const int* row_perm, const int* col_perm, bool left_orth,
                                double* left, double* right, hipStream_t stream);
 // out[c + ldo*r] = in[r + ldi*c]  (rows x cols input)

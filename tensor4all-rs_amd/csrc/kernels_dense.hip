@@ -999,6 +999,56 @@ void gemm_launch(const GemmDesc& d, hipStream_t stream)
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256), d.batch), dim3(256), 0, stream, ds);
 }
 
+__global__ void __launch_bounds__(256) luci_left_cores_batched_kernel(LeftCoreJobs jobs)
+{
+    __shared__ double fsm[LUCI_LEFT_CORES_MAX_RANK * LUCI_LEFT_CORES_MAX_RANK]; // fsm[i + rk * j] = lu(i, j), i, j < rk
+    // (dynamic index into a by-value argument: read through the kernel-argument segment, not through a private copy)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const LeftCoreJob& jb = *(reinterpret_cast<const LeftCoreJob*>((const char*)__builtin_amdgcn_kernarg_segment_ptr()) + blockIdx.y);
+#else
+    const LeftCoreJob& jb = jobs.j[blockIdx.y];
+#endif
+    const int M = jb.dims[0];
+    const int rk = jb.iresult[0];
+    if (jb.dims[2] != 0 || M <= 0 || jb.dims[1] <= 0 || jb.iresult[1] != 0 || jb.iresult[3] != (int)jb.token || rk < 0 || rk > LUCI_LEFT_CORES_MAX_RANK) return;
+    if (blockIdx.x * 256 >= M) return;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < rk * rk; e += 256) fsm[e] = jb.lu[(e % rk) + (size_t)M * (e / rk)];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid; // row i (permuted order)
+    if (i >= M) return;
+    const int S = jb.S, L = M / S;
+    const int row = jb.row_perm[i];
+    double* out = jb.core + (row / S) + (size_t)L * (row % S); // core[l, s, r] at l + L (s + S r)
+    const size_t rstride = (size_t)L * S;
+    if (rk == 0) {
+        out[0] = 0.0; // (R = 1: a zero column, tensorci2.rs:1957-1973)
+        return;
+    }
+    if (i < rk) {
+        for (int j = 0; j < rk; ++j) out[rstride * j] = (i == j) ? 1.0 : 0.0;
+    } else { // x L11 = L21(i, :), L11 unit lower: back substitution from the last column (the order of luci_factors_small_kernel)
+        double v[LUCI_LEFT_CORES_MAX_RANK];
+#pragma unroll
+        for (int j = LUCI_LEFT_CORES_MAX_RANK - 1; j >= 0; --j) {
+            if (j < rk) {
+                double x = jb.lu[i + (size_t)M * j];
+#pragma unroll
+                for (int k = j + 1; k < LUCI_LEFT_CORES_MAX_RANK; ++k)
+                    if (k < rk) x = x - v[k] * fsm[k + rk * j];
+                v[j] = x;
+                out[rstride * j] = x;
+            }
+        }
+    }
+}
+
+void luci_left_cores_batched_launch(const LeftCoreJobs& jobs, int n_jobs, int max_rows, hipStream_t stream)
+{
+    if (n_jobs <= 0 || max_rows <= 0) return;
+    hipLaunchKernelGGL(luci_left_cores_batched_kernel, dim3((max_rows + 255) / 256, n_jobs), dim3(256), 0, stream, jobs);
+}
+
 bool luci_factors_small_launch(const double* lu, int M, int N, int rk, const int* row_perm, const int* col_perm, bool left_orth,
                                double* left, double* right, hipStream_t stream)
 {

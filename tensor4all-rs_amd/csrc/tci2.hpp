@@ -291,6 +291,7 @@ private:
         double abs_tol = 0.0;
         DevBuf<double> factors, urows; // [n_bonds][factors_stride] factored matrices; finished rows of U of the bond in flight
         size_t factors_stride = 0;
+        bool cores_batched = false;  // the chain in flight writes the site tensors of its low-rank bonds itself (one launch behind it)
         DevBuf<unsigned long long> walk_dbg; // diagnostic phase times of the persistent half-sweep (T4A_WALK_DEBUG)
         bool walked = false;         // the chain in flight is a persistent half-sweep
         unsigned walk_token = 1;     // completion tokens of the persistent half-sweep (bond k of a walk: base + k)

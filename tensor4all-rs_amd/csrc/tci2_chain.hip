@@ -629,6 +629,32 @@ void Tci2::chain_launch()
             pa.prev_token = tokens[pb];
             chain_prep_launch(c, pa, st);
         }
+        chain_.cores_batched = false;
+        static const bool no_batched_cores = std::getenv("T4A_NO_BATCHED_CORES") != nullptr;
+        if (chain_.one_site && chain_.factors_stride && forward && !no_batched_cores && nb <= (size_t)LUCI_LEFT_CORES_MAX_JOBS) {
+            // the site tensors of every bond of rank <= 16 in one launch behind the chain (kernels_dense.hip): shapes, ranks and
+            // permutations are read where the chain left them; the buffers are sized for the upper bounds
+            LeftCoreJobs jobs;
+            std::memset(&jobs, 0, sizeof(jobs));
+            size_t max_rows = 1;
+            for (size_t b = 0; b < nb; ++b) {
+                const ChainBlock blk = block_of(b);
+                const size_t rub = std::max<size_t>(std::min({dep_ub[b], ind_ub[b], chi}), 1);
+                DevCore& core = cores[b];
+                core.buf.reserve(std::max<size_t>(dep_ub[b] * rub, 1));
+                LeftCoreJob& j = jobs.j[b];
+                j.lu = chain_.factors.get() + b * chain_.factors_stride;
+                j.dims = c.dims + b * 4;
+                j.iresult = reinterpret_cast<const int*>(blk.dev + 16);
+                j.row_perm = reinterpret_cast<const int*>(blk.dev + blk.off_rp);
+                j.core = core.buf.get();
+                j.S = (int)local_dims[b];
+                j.token = tokens[b];
+                max_rows = std::max(max_rows, dep_ub[b]);
+            }
+            luci_left_cores_batched_launch(jobs, (int)nb, (int)max_rows, st);
+            chain_.cores_batched = true;
+        }
         if (!per_launch_mirror)
             T4A_HIP(hipMemcpyAsync(chain_.hblocks.get(), chain_.blocks.get(), nb * proto.bytes, hipMemcpyDeviceToHost, st));
         T4A_HIP(hipGetLastError());
@@ -970,6 +996,13 @@ void Tci2::chain_finish(const TCI2Options& options)
             lu.M = hd[0];
             lu.N = hd[1];
             lu.rank = rank;
+            if (chain_.cores_batched && rank <= LUCI_LEFT_CORES_MAX_RANK) { // already written behind the chain: only the shape is missing
+                DevCore& core = cores[b];
+                core.l = (b == 0) ? 1 : i_set[b].count;
+                core.s = local_dims[b];
+                core.r = std::max<size_t>((size_t)rank, 1);
+                continue;
+            }
             eng.build_factors_from(chain_.factors.get() + b * chain_.factors_stride, reinterpret_cast<const int*>(dblk + proto.off_rp),
                                    reinterpret_cast<const int*>(dblk + proto.off_cp), lu.M, lu.N, rank, forward);
             if (forward) {

@@ -133,6 +133,44 @@ def test_rrlu_special_values_on_one_workgroup_shapes(t4a, left, shape):
     transposed for a right-orthogonal factorisation) with everything that leaves its fast paths: ties inside a wave and between
     waves, zero / subnormal / overflowing scores, low rank down to an exactly zero trailing block, all stop rules, quotients
     outside the shared-reciprocal range, and NaN / inf — which that kernel hands back to the first-generation kernel."""
+    _special_value_suite(t4a, left, shape)
+
+
+@pytest.mark.parametrize("left", [True, False])
+@pytest.mark.parametrize("shape", [(64, 16), (33, 9), (12, 12), (50, 3), (16, 64), (3, 40), (9, 9)])
+def test_rrlu_special_values_on_one_wave_shapes(t4a, left, shape):
+    """The same suite on the shapes the ONE-WAVE kernel takes (kernels_rrlu_w1_body.hpp: at most 64 rows and 16 columns as the
+    kernel sees them — a right-orthogonal factorisation of a 16 x 64 matrix is one): ties inside a lane, between lanes and between
+    register groups, zero / subnormal maxima (the exact sweep with explicit position tests, cleared columns must never win),
+    all stop rules, the factored matrix out of the LDS side buffers, NaN / inf handed back to the first-generation kernel."""
+    _special_value_suite(t4a, left, shape)
+
+
+def test_one_wave_kernel_on_wider_matrices_in_a_child_process():
+    """T4A_W1_MAXN=64 lifts the plan limit so that the 32- and 64-column instantiations of the one-wave kernel (which the
+    persistent half-sweep uses up to 32 columns) run the dense entry point; T4A_WG_MIN=0 sends even the tiniest matrices there."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, 'tests')\n"
+        "import t4a_amd, test_gpu_fuzz as f\n"
+        "rng = np.random.default_rng(77)\n"
+        "for (m, n) in [(64, 64), (40, 32), (64, 20), (7, 33), (2, 2), (1, 5), (5, 1)]:\n"
+        "    for left in (True, False):\n"
+        "        f._same_outcome(t4a_amd, rng.uniform(-1, 1, size=(m, n)), left_orthogonal=left)\n"
+        "        f._same_outcome(t4a_amd, rng.integers(-2, 3, size=(m, n)).astype(float), rel_tol=0.0, abs_tol=0.0, left_orthogonal=left)\n"
+        "        f._same_outcome(t4a_amd, np.outer(np.arange(1, m + 1), np.arange(1, n + 1)).astype(float), rel_tol=0.0, abs_tol=0.0, left_orthogonal=left)\n"
+        "        f._same_outcome(t4a_amd, rng.uniform(-1, 1, size=(m, n)), max_bond_dim=max(1, min(m, n) // 2), rel_tol=1e-3, abs_tol=0.0, left_orthogonal=left)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, T4A_W1_MAXN="64", T4A_WG_MIN="0", PYTHONPATH=os.path.join(root, "tensor4all-rs_amd", "python"))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _special_value_suite(t4a, left, shape):
     m, n = shape
     rng = np.random.default_rng(4000 + 10 * m + n)
     kw = dict(left_orthogonal=left)

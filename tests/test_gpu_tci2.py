@@ -172,6 +172,9 @@ def test_make_canonical_matches_oracle(t4a, max_bond_dim):
     if max_bond_dim is not None:
         assert max(g.link_dims()) <= max_bond_dim
     assert abs(g.sum() - o.sum()) <= 1e-10 * 2 ** n
+    # the three 1-site sweeps ran as device-side chains (forward exact without tensors, backward, forward with tensors)
+    st = g.chain_stats()
+    assert st["one_site_sweeps"] == 3 and st["one_site_fell_back"] == 0 and st["one_site_not_eligible"] == 0
     # argument validation of the reference (validate_nonnegative_finite / validate_positive)
     with pytest.raises(t4a.T4aError):
         g.make_canonical(-1.0, 0.0, None)
@@ -241,11 +244,15 @@ def test_cfg2_small_problem_parity_and_launch_bound_budget(t4a):
     o.crossinterpolate2([[0] * n], opts)
     assert g.link_dims() == o.link_dims()
     assert_same_sets(g, o, n)
-    # kernel-bound regime: three half-sweeps as bond chains (19 x (7 us preparation + 6 us rrLU launch) each) + the final one-site
-    # sweep, 1.45 ms measured in round 4 (best of five; 4.4 ms in round 1, 1.7 in round 2, 1.5 in round 3).  The bound is 1.5 x
-    # the measured value (a regression guard, as the round-3 review asked); the 0.5 ms asked for needs the whole half-sweep of a
-    # tiny problem resident in one workgroup's LDS (DESIGN.md sections 8, 10) and is NOT met.
-    assert best < 2.2e-3, f"cfg2 time to solution {best * 1e3:.2f} ms"
+    assert_cores_close(g, o, n, 1e-10)
+    # every half-sweep of this rank-2 problem, and its final 1-site sweep, ran as ONE persistent workgroup (kernels_chain.hip)
+    st = g.chain_stats()
+    assert st["half_sweeps"] == 3 and st["one_site_sweeps"] == 1 and st["walked_sweeps"] == 4 and st["fell_back"] == 0
+    # kernel-bound regime: three half-sweeps and the final 1-site sweep, each one persistent workgroup walking the 19 bonds
+    # (~5 us preparation + 1.3 us candidate matrix + 2.5 us rrLU per bond) + three fills: 1.05 ms measured at the end of round 4
+    # (best of five; 4.4 ms in round 1, 1.7 in round 2, 1.5 in round 3, 1.45 before the persistent workgroup).  The bound is 1.5 x
+    # the measured value (a regression guard, as the round-3 review asked); the 0.5 ms asked for is NOT met.
+    assert best < 1.6e-3, f"cfg2 time to solution {best * 1e3:.2f} ms"
 
 
 def test_concurrent_handle_lifecycles(t4a):
