@@ -324,6 +324,8 @@ struct ChainPrepArgs {
     const int* prev_rowperm;
     const int* prev_colperm;
     unsigned prev_token;
+    int defer_host_writes;    // 1 (persistent half-sweep): the pinned mirrors and hdims are not written here but in bulk at the end of
+                              // the kernel — a store over PCIe is acknowledged after microseconds, and every barrier waits for it
 };
 // The persistent half-sweep (kernels_chain.hip, chain_walk_kernel): one workgroup walks all bonds — preparation, candidate matrix,
 // one-wave rrLU — when every bond's matrix is at most 64 x 64.  Result blocks as the launched chain writes them.
@@ -338,7 +340,7 @@ struct ChainWalkArgs {
     size_t factors_stride;
     unsigned token_base;                // bond number k of the half-sweep completes with token token_base + k
     int timed;                          // device time stamps of every factorisation at off_ts
-    unsigned long long* phase_ticks;    // diagnostic (T4A_WALK_DEBUG): [4] 100 MHz ticks summed over the bonds: preparation, candidate matrix, rrLU, total
+    unsigned long long* phase_ticks;    // diagnostic (T4A_WALK_DEBUG): [8] 100 MHz ticks summed over the bonds: preparation, candidate matrix, rrLU, total; [4] gather [5] dependent list (inside the preparation)
 };
 void chain_walk_launch(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, int columns, hipStream_t stream);
 void chain_indep_launch(const ChainCommon& c, int n_bonds, hipStream_t stream);

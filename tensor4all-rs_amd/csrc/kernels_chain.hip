@@ -205,8 +205,16 @@ __global__ void __launch_bounds__(CHAIN_T) chain_indep_group_kernel(const ChainG
     chain_indep_body(slots[blockIdx.y].c);
 }
 
-__device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const ChainPrepArgs& p)
+__device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const ChainPrepArgs& p, unsigned long long* dbg = nullptr)
 {
+    unsigned long long dbg_last = dbg ? wall_clock64() : 0ull;
+    auto stamp = [&](int slot) {
+        if (dbg) {
+            const unsigned long long now = wall_clock64();
+            if (threadIdx.x == 0) dbg[slot] += now - dbg_last;
+            dbg_last = now;
+        }
+    };
     __shared__ unsigned long long hkeys[CHAIN_HASH];
     __shared__ int wave_sums[CHAIN_T / 64];
     __shared__ int s_srcpos[CHAIN_MAX_SET];
@@ -244,32 +252,39 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
                     const uint64_t rc = rcode[ri], cc = ccode[ci];
                     c.I.code[oi + k] = rc;
                     c.J.code[oj + k] = cc;
-                    c.mI.code[oi + k] = rc;
-                    c.mJ.code[oj + k] = cc;
+                    if (!p.defer_host_writes) {
+                        c.mI.code[oi + k] = rc;
+                        c.mJ.code[oj + k] = cc;
+                    }
                     for (int q = 0; q < K; ++q) {
                         const uint64_t ra = racc[(size_t)ri * K + q], ca = cacc[(size_t)ci * K + q];
                         c.I.acc[(oi + k) * K + q] = ra;
                         c.J.acc[(oj + k) * K + q] = ca;
-                        c.mI.acc[(oi + k) * K + q] = ra;
-                        c.mJ.acc[(oj + k) * K + q] = ca;
+                        if (!p.defer_host_writes) {
+                            c.mI.acc[(oi + k) * K + q] = ra;
+                            c.mJ.acc[(oj + k) * K + q] = ca;
+                        }
                     }
                     s_srcpos[k] = c.forward ? ri : ci; // position of the new parent in the previous dependent list
                 }
                 if (tid == 0) {
                     c.I.cnt[pb + 1] = cnt;
                     c.J.cnt[pb] = cnt;
-                    c.mI.cnt[pb + 1] = cnt;
-                    c.mJ.cnt[pb] = cnt;
+                    if (!p.defer_host_writes) {
+                        c.mI.cnt[pb + 1] = cnt;
+                        c.mJ.cnt[pb] = cnt;
+                    }
                 }
             }
         }
         __threadfence_block();
         __syncthreads(); // the gather has read the old dependent list and written the tables: the list may be overwritten now
     }
+    stamp(4);
     if (!p.do_build) return;
     const int b = p.b;
     int* dims = c.dims + (size_t)b * 4;
-    int* hdims = c.hdims ? c.hdims + (size_t)b * 4 : nullptr;
+    int* hdims = (c.hdims && !p.defer_host_writes) ? c.hdims + (size_t)b * 4 : nullptr;
     if (s_poison) {
         if (tid == 0) {
             dims[0] = dims[1] = dims[3] = 0;
@@ -300,6 +315,7 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
                                    c.dep_cap, s_srcpos, n_prev_dep, mapped ? c.rowmap : nullptr, hkeys, wave_sums);
         lda = n_prev_dep * c.ldim[b + 1] + ne;
     }
+    stamp(5);
     if (tid == 0) {
         const int ni = c.ind_cnt[b];
         const bool ok = nd > 0 && ni > 0;
@@ -403,6 +419,7 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
         pa.prev_rowperm = nullptr;
         pa.prev_colperm = nullptr;
         pa.prev_token = 0u;
+        pa.defer_host_writes = 1;
         if (k > 0) {
             const int pb = FORWARD ? b - 1 : b + 1;
             const char* pblk = w.blocks + (size_t)pb * w.block_bytes;
@@ -412,7 +429,7 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
             pa.prev_colperm = reinterpret_cast<const int*>(pblk + w.off_cp);
             pa.prev_token = w.token_base + (unsigned)(k - 1);
         }
-        chain_prep_body(c, pa);
+        chain_prep_body(c, pa, w.phase_ticks);
         walk_phase_barrier();
         phase(0);
         if (k == nb) break;
@@ -481,10 +498,34 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
         walk_phase_barrier();
         phase(2);
     }
+    // ---- the host's copies, in bulk: every table this sweep wrote (I_1 .. I_nb, J_0 .. J_{nb-1}) into the pinned mirror, dims into
+    // hdims.  (The gather of a poisoned bond wrote nothing: chain_finish ignores everything from the first poisoned bond on.)
+    {
+        const int K = c.K;
+        const size_t cap = (size_t)c.cap;
+        for (int site = 0; site <= nb; ++site) {
+            for (int fam = 0; fam < 2; ++fam) {
+                if ((fam == 0 && site == 0) || (fam == 1 && site == nb)) continue; // (I_0 and J_{n-1} are never written)
+                const ChainTab& T = fam == 0 ? c.I : c.J;
+                const ChainTab& Mr = fam == 0 ? c.mI : c.mJ;
+                const int cnt = walk_load_i32(T.cnt + site);
+                if (cnt < 0 || cnt > c.cap) continue;
+                for (int e = tid; e < cnt * (1 + K); e += CHAIN_T) {
+                    if (e < cnt) Mr.code[(size_t)site * cap + e] = T.code[(size_t)site * cap + e];
+                    else Mr.acc[(size_t)site * cap * K + (e - cnt)] = T.acc[(size_t)site * cap * K + (e - cnt)];
+                }
+                if (tid == 0) Mr.cnt[site] = cnt;
+            }
+        }
+        if (c.hdims)
+            for (int e = tid; e < nb * 4; e += CHAIN_T)
+                if ((e & 3) != 3) c.hdims[e] = walk_load_i32(c.dims + e);
+    }
     if (w.phase_ticks && tid == 0) {
         for (int i = 0; i < 3; ++i) w.phase_ticks[i] = ph[i];
         w.phase_ticks[3] = wall_clock64() - ph_t0;
     }
+    (void)0;
 }
 
 template <int NC> void chain_walk_launch_nc(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, hipStream_t stream)

@@ -547,7 +547,8 @@ void Tci2::chain_launch()
             w.timed = chain_.timed ? 1 : 0;
             static const bool walk_dbg = std::getenv("T4A_WALK_DEBUG") != nullptr;
             if (walk_dbg) {
-                chain_.walk_dbg.reserve(4);
+                chain_.walk_dbg.reserve(8);
+                T4A_HIP(hipMemsetAsync(chain_.walk_dbg.get(), 0, 8 * sizeof(unsigned long long), st));
                 w.phase_ticks = chain_.walk_dbg.get();
             }
             chain_.walked = true;
@@ -859,10 +860,10 @@ void Tci2::chain_finish(const TCI2Options& options)
         T4A_HIP(sync_err);
     }
     if (chain_.walked && chain_.walk_dbg.get() && std::getenv("T4A_WALK_DEBUG")) {
-        unsigned long long t[4] = {0, 0, 0, 0};
+        unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipMemcpy(t, chain_.walk_dbg.get(), sizeof(t), hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "[t4a walk] %zu bonds: preparation %.1f us, candidate matrix %.1f us, rrLU %.1f us, kernel %.1f us\n", nb, t[0] * 0.01, t[1] * 0.01,
-                     t[2] * 0.01, t[3] * 0.01);
+        std::fprintf(stderr, "[t4a walk] %zu bonds: preparation %.1f us (gather %.1f, dependent list %.1f), candidate matrix %.1f us, rrLU %.1f us, kernel %.1f us\n", nb,
+                     t[0] * 0.01, t[4] * 0.01, t[5] * 0.01, t[1] * 0.01, t[2] * 0.01, t[3] * 0.01);
     }
     chain_.walked = false;
     const int mnew = 1 - chain_.mcur;
