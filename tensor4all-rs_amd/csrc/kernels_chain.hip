@@ -49,7 +49,9 @@ __device__ __forceinline__ const char* chain_kernarg_base()
 #endif
 }
 
-constexpr int CHAIN_T = 1024;       // threads of a list-building workgroup
+constexpr int CHAIN_T = 1024;       // threads of a list-building workgroup (launched chain; the bodies below take the launch's count)
+constexpr int WALK_T = 1024;        // threads of the persistent half-sweep (measured: 256 — one wave per SIMD — is no faster through the short uniform
+                                    // sections between barriers and four times slower through the candidate matrix of a wide bond)
 constexpr int CHAIN_HASH = 4096;    // LDS hash slots (tables hold at most CHAIN_MAX_SET = 1024 entries per site)
 
 __device__ __forceinline__ unsigned chain_hash(unsigned long long c)
@@ -70,7 +72,7 @@ __device__ __forceinline__ int block_scan_flag(bool flag, int* wave_sums, int* t
     if (lane == 0) wave_sums[wave] = __builtin_popcountll(bal);
     __syncthreads();
     int base = 0, tot = 0;
-    for (int w = 0; w < CHAIN_T / 64; ++w) {
+    for (int w = 0; w < (int)blockDim.x / 64; ++w) {
         const int v = wave_sums[w];
         if (w < wave) base += v;
         tot += v;
@@ -95,11 +97,11 @@ __device__ int build_side(const uint64_t* __restrict__ pcode, const uint64_t* __
     const int m0 = np * d;
     if (m0 > ocap) return -1;
     if (ne > 0) {
-        for (int e = tid; e < CHAIN_HASH; e += CHAIN_T) hkeys[e] = 0ull;
+        for (int e = tid; e < CHAIN_HASH; e += (int)blockDim.x) hkeys[e] = 0ull;
         __syncthreads();
     }
     // Kronecker part
-    for (int idx = tid; idx < m0; idx += CHAIN_T) {
+    for (int idx = tid; idx < m0; idx += (int)blockDim.x) {
         const int i = PARENT_OUTER ? idx / d : idx % np;
         const int s = PARENT_OUTER ? idx % d : idx / np;
         const uint64_t c = pcode[i];
@@ -109,7 +111,7 @@ __device__ int build_side(const uint64_t* __restrict__ pcode, const uint64_t* __
     }
     if (ne <= 0) return m0;
     // hash of the parents, then the extras in order (one per thread and round; ne <= CHAIN_T in practice: one round)
-    for (int i = tid; i < np; i += CHAIN_T) {
+    for (int i = tid; i < np; i += (int)blockDim.x) {
         const unsigned long long key = (unsigned long long)pcode[i] + 1ull;
         unsigned h = chain_hash(key);
         for (;;) {
@@ -120,7 +122,7 @@ __device__ int build_side(const uint64_t* __restrict__ pcode, const uint64_t* __
     }
     __syncthreads();
     int count = m0;
-    for (int base = 0; base < ne; base += CHAIN_T) {
+    for (int base = 0; base < ne; base += (int)blockDim.x) {
         const int e = base + tid;
         bool keep = false;
         uint64_t c = 0ull;
@@ -169,7 +171,7 @@ __device__ __forceinline__ void chain_indep_body(const ChainCommon& c)
         const int site = c.forward ? b : b + 1;
         const int np = T.cnt[site];
         n = (np >= 1 && np <= c.cap && np <= c.ind_cap) ? np : -1;
-        for (int i = threadIdx.x; i < n; i += CHAIN_T) {
+        for (int i = threadIdx.x; i < n; i += (int)blockDim.x) {
             ocode[i] = T.code[(size_t)site * cap + i];
             for (int k = 0; k < K; ++k) oacc[(size_t)i * K + k] = T.acc[((size_t)site * cap + i) * K + k];
         }
@@ -190,7 +192,7 @@ __device__ __forceinline__ void chain_indep_body(const ChainCommon& c)
     }
     if (threadIdx.x == 0) c.ind_cnt[b] = n;
     // housekeeping of the new chain (grid-stride over all workgroups): nothing of this is read before this kernel has ended
-    const size_t gtid = (size_t)blockIdx.x * CHAIN_T + threadIdx.x, gsz = (size_t)gridDim.x * CHAIN_T;
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
     if (c.snap_dst) {
         for (size_t i = gtid; i < c.snap_words; i += gsz) c.snap_dst[i] = c.I.code[i]; // (I and J families are adjacent)
         for (size_t i = gtid; i < (size_t)2 * c.n_sites; i += gsz) c.snap_cnt_dst[i] = c.I.cnt[i];
@@ -205,7 +207,23 @@ __global__ void __launch_bounds__(CHAIN_T) chain_indep_group_kernel(const ChainG
     chain_indep_body(slots[blockIdx.y].c);
 }
 
-__device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const ChainPrepArgs& p, unsigned long long* dbg = nullptr)
+// What the persistent half-sweep (chain_walk_kernel below) keeps in the LDS between two bonds instead of reading it back from
+// global memory: a step of the walk is a chain of DEPENDENT loads (result of the previous bond -> its permutations -> the codes of
+// its pivots -> the new list -> its size), each an L2 round trip of ~0.4 us when it goes through memory.
+constexpr int WALK_MAX_BONDS = 128;
+constexpr int WALK_MAX_LIST = 64;
+struct WalkShared {
+    int prev_ires[4];                                   // {rank, gave-up code, NaN flag, token} of the previous bond's rrLU
+    int perm_rp[WALK_MAX_LIST], perm_cp[WALK_MAX_LIST]; // its permutations (rows / columns of the matrix as the host sees it)
+    int np;                                             // parents gathered for this bond (= that rank, at least 1)
+    int pad_;
+    uint64_t par_code[WALK_MAX_LIST], par_acc[WALK_MAX_LIST * T4A_FN_MAX_ACC]; // ... their codes and accumulators
+    uint64_t dep_code[WALK_MAX_LIST], dep_acc[WALK_MAX_LIST * T4A_FN_MAX_ACC]; // the dependent list of the bond in flight
+    int dims[WALK_MAX_BONDS * 4];                       // ChainCommon::dims of the whole sweep (copied out at the end)
+    int ind_cnt[WALK_MAX_BONDS];                        // ChainCommon::ind_cnt (copied in at the start)
+};
+
+__device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const ChainPrepArgs& p, unsigned long long* dbg = nullptr, WalkShared* ws = nullptr)
 {
     unsigned long long dbg_last = dbg ? wall_clock64() : 0ull;
     auto stamp = [&](int slot) {
@@ -247,11 +265,12 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
                 const uint64_t* ccode = c.forward ? c.ind_code + (size_t)pb * c.ind_cap : c.dep_code;
                 const uint64_t* cacc = c.forward ? c.ind_acc + (size_t)pb * c.ind_cap * K : c.dep_acc;
                 const size_t oi = (size_t)(pb + 1) * cap, oj = (size_t)pb * cap;
-                for (int k = tid; k < cnt; k += CHAIN_T) {
+                for (int k = tid; k < cnt; k += (int)blockDim.x) {
                     const int ri = r > 0 ? p.prev_rowperm[k] : 0, ci = r > 0 ? p.prev_colperm[k] : 0;
                     const uint64_t rc = rcode[ri], cc = ccode[ci];
                     c.I.code[oi + k] = rc;
                     c.J.code[oj + k] = cc;
+                    if (ws) ws->par_code[k] = c.forward ? rc : cc; // (the parents of the list that is built next)
                     if (!p.defer_host_writes) {
                         c.mI.code[oi + k] = rc;
                         c.mJ.code[oj + k] = cc;
@@ -260,6 +279,7 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
                         const uint64_t ra = racc[(size_t)ri * K + q], ca = cacc[(size_t)ci * K + q];
                         c.I.acc[(oi + k) * K + q] = ra;
                         c.J.acc[(oj + k) * K + q] = ca;
+                        if (ws) ws->par_acc[(size_t)k * K + q] = c.forward ? ra : ca;
                         if (!p.defer_host_writes) {
                             c.mI.acc[(oi + k) * K + q] = ra;
                             c.mJ.acc[(oj + k) * K + q] = ca;
@@ -268,6 +288,7 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
                     s_srcpos[k] = c.forward ? ri : ci; // position of the new parent in the previous dependent list
                 }
                 if (tid == 0) {
+                    if (ws) ws->np = cnt;
                     c.I.cnt[pb + 1] = cnt;
                     c.J.cnt[pb] = cnt;
                     if (!p.defer_host_writes) {
@@ -300,17 +321,19 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
     // ---- 2. the dependent side of bond b (rows when sweeping forward, columns when sweeping backward) ----
     const bool mapped = p.prev_b >= 0 && p.with_rowmap;
     int nd = -1, lda = 0;
+    // (persistent half-sweep: the parents were gathered a moment ago and wait in the LDS)
+    const bool par_lds = ws != nullptr && p.prev_b >= 0;
     if (c.forward) {
-        const int np = c.I.cnt[b], ne = c.use_extras ? c.HI.cnt[b + 1] : 0;
+        const int np = par_lds ? ws->np : c.I.cnt[b], ne = c.use_extras ? c.HI.cnt[b + 1] : 0;
         if (np >= 1 && np <= c.cap && ne <= c.cap)
-            nd = build_side<true>(c.I.code + (size_t)b * cap, c.I.acc + (size_t)b * cap * K, np, c.ldim[b], c.w, K, c.total, c.woff[b],
+            nd = build_side<true>(par_lds ? ws->par_code : c.I.code + (size_t)b * cap, par_lds ? ws->par_acc : c.I.acc + (size_t)b * cap * K, np, c.ldim[b], c.w, K, c.total, c.woff[b],
                                   c.HI.code + (size_t)(b + 1) * cap, c.HI.acc + (size_t)(b + 1) * cap * K, ne, c.dep_code, c.dep_acc, c.dep_cap,
                                   s_srcpos, n_prev_dep, mapped ? c.rowmap : nullptr, hkeys, wave_sums);
         lda = n_prev_dep * c.ldim[b] + ne;
     } else {
-        const int np = c.J.cnt[b + 1], ne = c.use_extras ? c.HJ.cnt[b] : 0;
+        const int np = par_lds ? ws->np : c.J.cnt[b + 1], ne = c.use_extras ? c.HJ.cnt[b] : 0;
         if (np >= 1 && np <= c.cap && ne <= c.cap)
-            nd = build_side<false>(c.J.code + (size_t)(b + 1) * cap, c.J.acc + (size_t)(b + 1) * cap * K, np, c.ldim[b + 1], c.w, K, c.total,
+            nd = build_side<false>(par_lds ? ws->par_code : c.J.code + (size_t)(b + 1) * cap, par_lds ? ws->par_acc : c.J.acc + (size_t)(b + 1) * cap * K, np, c.ldim[b + 1], c.w, K, c.total,
                                    c.woff[b + 1], c.HJ.code + (size_t)b * cap, c.HJ.acc + (size_t)b * cap * K, ne, c.dep_code, c.dep_acc,
                                    c.dep_cap, s_srcpos, n_prev_dep, mapped ? c.rowmap : nullptr, hkeys, wave_sums);
         lda = n_prev_dep * c.ldim[b + 1] + ne;
@@ -392,10 +415,20 @@ __device__ __forceinline__ void walk_phase_barrier()
 }
 __device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NC, bool FORWARD, bool FACTORS>
-__global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDevice fn, ChainWalkArgs w)
+template <int NC, bool FACTORS> constexpr size_t walk_lds_bytes()
 {
-    __shared__ __attribute__((aligned(16))) char w1lds[W1Lds<NC, FACTORS>::bytes];
+    // [WalkShared][the candidate matrix (64 x NC doubles), later the one-wave kernel's side buffers: the matrix is in registers by then]
+    constexpr size_t w1 = W1Lds<NC, FACTORS>::bytes, pi = (size_t)WALK_MAX_LIST * NC * sizeof(double);
+    return (sizeof(WalkShared) + 15) / 16 * 16 + (w1 > pi ? w1 : pi);
+}
+
+template <int NC, bool FORWARD, bool FACTORS>
+__global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDevice fn, ChainWalkArgs w)
+{
+    extern __shared__ __attribute__((aligned(16))) char walk_lds[];
+    WalkShared* const ws = reinterpret_cast<WalkShared*>(walk_lds);
+    char* const w1lds = walk_lds + (sizeof(WalkShared) + 15) / 16 * 16;
+    double* const pi = reinterpret_cast<double*>(w1lds);
     const int tid = threadIdx.x;
     const int nb = w.n_bonds;
     unsigned long long ph[3] = {0ull, 0ull, 0ull};
@@ -408,6 +441,17 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
             ph_last = now;
         }
     };
+    // the walk's own view of the chain constants: dimensions, sizes of the independent lists and the dependent list live in the LDS
+    ChainCommon cw = c;
+    cw.dims = ws->dims;
+    cw.hdims = nullptr;
+    cw.ind_cnt = ws->ind_cnt;
+    cw.dep_code = ws->dep_code;
+    cw.dep_acc = ws->dep_acc;
+    cw.dep_cap = WALK_MAX_LIST;
+    for (int e = tid; e < nb * 4; e += (int)blockDim.x) ws->dims[e] = 0;
+    for (int e = tid; e < nb; e += (int)blockDim.x) ws->ind_cnt[e] = c.ind_cnt[e];
+    walk_phase_barrier();
     for (int k = 0; k <= nb; ++k) {
         const int b = FORWARD ? k : nb - 1 - k;
         ChainPrepArgs pa;
@@ -421,85 +465,96 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
         pa.prev_token = 0u;
         pa.defer_host_writes = 1;
         if (k > 0) {
-            const int pb = FORWARD ? b - 1 : b + 1;
-            const char* pblk = w.blocks + (size_t)pb * w.block_bytes;
-            pa.prev_b = pb;
-            pa.prev_iresult = reinterpret_cast<const int*>(pblk + 16);
-            pa.prev_rowperm = reinterpret_cast<const int*>(pblk + w.off_rp);
-            pa.prev_colperm = reinterpret_cast<const int*>(pblk + w.off_cp);
+            pa.prev_b = FORWARD ? b - 1 : b + 1;
+            pa.prev_iresult = ws->prev_ires;
+            pa.prev_rowperm = ws->perm_rp;
+            pa.prev_colperm = ws->perm_cp;
             pa.prev_token = w.token_base + (unsigned)(k - 1);
         }
-        chain_prep_body(c, pa, w.phase_ticks);
+        chain_prep_body(cw, pa, w.phase_ticks, ws);
         walk_phase_barrier();
         phase(0);
         if (k == nb) break;
-        // ---- the candidate matrix: out[j * nd + i] = f(dependent i, independent j) ----
-        const int* dm = c.dims + (size_t)b * 4;
-        const int d0 = walk_load_i32(dm), d1 = walk_load_i32(dm + 1), poisoned = walk_load_i32(dm + 2);
+        // ---- the candidate matrix: pi[j * nd + i] = f(dependent i, independent j) ----
+        const int d0 = ws->dims[b * 4], d1 = ws->dims[b * 4 + 1], poisoned = ws->dims[b * 4 + 2];
         const int nd = FORWARD ? d0 : d1, ni = FORWARD ? d1 : d0;
-        if (poisoned == 0 && nd > 0 && ni > 0 && nd <= 64 && ni <= NC) {
+        const bool runs = poisoned == 0 && nd > 0 && ni > 0 && nd <= WALK_MAX_LIST && ni <= NC;
+        if (runs) {
             const int K = fn.n_acc;
             const uint64_t* ia = c.ind_acc + (size_t)b * c.ind_cap * K;
-            for (int idx = tid; idx < nd * ni; idx += CHAIN_T) {
+            for (int idx = tid; idx < nd * ni; idx += (int)blockDim.x) {
                 const int i = idx % nd, j = idx / nd;
                 uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
-                for (int q = 0; q < K; ++q) acc[q] = c.dep_acc[(size_t)i * K + q] + ia[(size_t)j * K + q];
-                w.pi[idx] = t4a_fn_value(fn.fid, acc, fn.params);
+                for (int q = 0; q < K; ++q) acc[q] = ws->dep_acc[(size_t)i * K + q] + ia[(size_t)j * K + q];
+                pi[idx] = t4a_fn_value(fn.fid, acc, fn.params);
             }
         }
         walk_phase_barrier();
         phase(1);
         // ---- the factorisation: wave 0 (rows = the dependent side in both directions) ----
-        if (tid < 64 && poisoned == 0 && nd > 0 && ni > 0 && nd <= 64 && ni <= NC) {
+        if (tid < 64) {
+            int npiv = -2;
             char* blk = w.blocks + (size_t)b * w.block_bytes;
-            RrluXcdArgs a = {};
-            a.A = w.pi;
-            a.Aout = FACTORS ? w.factors + (size_t)b * w.factors_stride : nullptr;
-            a.urows = nullptr;
-            a.M = nd;
-            a.N = ni;
-            a.max_steps = w.max_steps < (nd < ni ? nd : ni) ? w.max_steps : (nd < ni ? nd : ni);
-            a.rel_tol = w.rel_tol;
-            a.abs_tol = w.abs_tol;
-            a.tie_row_major = FORWARD ? 0 : 1;
-            a.out_transposed = FORWARD ? 0 : 1;
-            a.W = 1;
-            a.xcc = 0;
-            a.ticket = nullptr;
-            a.ticket_base = 0u;
-            a.row_perm = reinterpret_cast<int*>(blk + (FORWARD ? w.off_rp : w.off_cp));
-            a.col_perm = reinterpret_cast<int*>(blk + (FORWARD ? w.off_cp : w.off_rp));
-            a.iresult = reinterpret_cast<int*>(blk + 16);
-            a.dresult = reinterpret_cast<double*>(blk);
-            a.pivot_vals = reinterpret_cast<double*>(blk + w.off_piv);
-            a.keys = nullptr;
-            a.salt = w.token_base + (unsigned)k;
-            a.spec_frac = 0.0;
-            a.stamps = nullptr;
-            a.h_block = nullptr;
-            a.block_u64 = 0;
-            a.dims = nullptr; // (the dimensions are known here: no device-side read, the token is written below)
-            a.dims_swap = 0;
-            a.rowmap = nullptr;
-            a.ts_u64 = 0;
-            const unsigned long long t0 = w.timed ? wall_clock64() : 0ull;
-            const int npiv = rrlu_w1_body<NC, !FORWARD, FACTORS>(a, w1lds);
-            if (npiv >= 0) {
-                if (w.timed && tid == 0) {
-                    unsigned long long* ts = reinterpret_cast<unsigned long long*>(blk + w.off_ts);
-                    ts[0] = t0;
-                    ts[1] = wall_clock64();
+            if (runs) {
+                RrluXcdArgs a = {};
+                a.A = pi;
+                a.Aout = FACTORS ? w.factors + (size_t)b * w.factors_stride : nullptr;
+                a.urows = nullptr;
+                a.M = nd;
+                a.N = ni;
+                a.max_steps = w.max_steps < (nd < ni ? nd : ni) ? w.max_steps : (nd < ni ? nd : ni);
+                a.rel_tol = w.rel_tol;
+                a.abs_tol = w.abs_tol;
+                a.tie_row_major = FORWARD ? 0 : 1;
+                a.out_transposed = FORWARD ? 0 : 1;
+                a.W = 1;
+                a.xcc = 0;
+                a.ticket = nullptr;
+                a.ticket_base = 0u;
+                a.row_perm = FORWARD ? ws->perm_rp : ws->perm_cp; // (into the LDS: the next preparation reads them there)
+                a.col_perm = FORWARD ? ws->perm_cp : ws->perm_rp;
+                a.iresult = reinterpret_cast<int*>(blk + 16);
+                a.dresult = reinterpret_cast<double*>(blk);
+                a.pivot_vals = reinterpret_cast<double*>(blk + w.off_piv);
+                a.keys = nullptr;
+                a.salt = w.token_base + (unsigned)k;
+                a.spec_frac = 0.0;
+                a.stamps = nullptr;
+                a.h_block = nullptr;
+                a.block_u64 = 0;
+                a.dims = nullptr; // (the dimensions are known here: no device-side read, the token is written below)
+                a.dims_swap = 0;
+                a.rowmap = nullptr;
+                a.ts_u64 = 0;
+                const unsigned long long t0 = w.timed ? wall_clock64() : 0ull;
+                npiv = rrlu_w1_body<NC, !FORWARD, FACTORS>(a, w1lds);
+                if (npiv >= 0) {
+                    // the host's copy of the permutations (and what build_factors_from reads), the completion token
+                    int* const g_rp = reinterpret_cast<int*>(blk + w.off_rp);
+                    int* const g_cp = reinterpret_cast<int*>(blk + w.off_cp);
+                    if (tid < d0) g_rp[tid] = ws->perm_rp[tid];
+                    if (tid < d1) g_cp[tid] = ws->perm_cp[tid];
+                    if (w.timed && tid == 0) {
+                        unsigned long long* ts = reinterpret_cast<unsigned long long*>(blk + w.off_ts);
+                        ts[0] = t0;
+                        ts[1] = wall_clock64();
+                    }
+                    if (tid == 0) a.iresult[3] = (int)a.salt; // (the host reads the block behind the end of the kernel)
                 }
-                // (the next preparation runs on this compute unit, the host reads behind the end of the kernel: workgroup scope)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (tid == 0) a.iresult[3] = (int)a.salt; // completion token (what the next preparation and the host check)
+            }
+            if (tid == 0) { // what the next preparation checks
+                ws->prev_ires[0] = npiv >= 0 ? npiv : 0;
+                ws->prev_ires[1] = npiv >= 0 ? 0 : 1;
+                ws->prev_ires[2] = 0;
+                ws->prev_ires[3] = npiv >= 0 ? (int)(w.token_base + (unsigned)k) : 0;
             }
         }
         walk_phase_barrier();
         phase(2);
     }
-    // ---- the host's copies, in bulk: every table this sweep wrote (I_1 .. I_nb, J_0 .. J_{nb-1}) into the pinned mirror, dims into
-    // hdims.  (The gather of a poisoned bond wrote nothing: chain_finish ignores everything from the first poisoned bond on.)
+    // ---- the host's copies, in bulk: every table this sweep wrote (I_1 .. I_nb, J_0 .. J_{nb-1}) into the pinned mirror, the
+    // dimensions into global memory and hdims.  (The gather of a poisoned bond wrote nothing: chain_finish ignores everything from
+    // the first poisoned bond on.)
     {
         const int K = c.K;
         const size_t cap = (size_t)c.cap;
@@ -510,32 +565,44 @@ __global__ void __launch_bounds__(CHAIN_T) chain_walk_kernel(ChainCommon c, FnDe
                 const ChainTab& Mr = fam == 0 ? c.mI : c.mJ;
                 const int cnt = walk_load_i32(T.cnt + site);
                 if (cnt < 0 || cnt > c.cap) continue;
-                for (int e = tid; e < cnt * (1 + K); e += CHAIN_T) {
+                for (int e = tid; e < cnt * (1 + K); e += (int)blockDim.x) {
                     if (e < cnt) Mr.code[(size_t)site * cap + e] = T.code[(size_t)site * cap + e];
                     else Mr.acc[(size_t)site * cap * K + (e - cnt)] = T.acc[(size_t)site * cap * K + (e - cnt)];
                 }
                 if (tid == 0) Mr.cnt[site] = cnt;
             }
         }
-        if (c.hdims)
-            for (int e = tid; e < nb * 4; e += CHAIN_T)
-                if ((e & 3) != 3) c.hdims[e] = walk_load_i32(c.dims + e);
+        for (int e = tid; e < nb * 4; e += (int)blockDim.x) {
+            const int v = ws->dims[e];
+            c.dims[e] = v;
+            if (c.hdims && (e & 3) != 3) c.hdims[e] = v;
+        }
     }
     if (w.phase_ticks && tid == 0) {
         for (int i = 0; i < 3; ++i) w.phase_ticks[i] = ph[i];
         w.phase_ticks[3] = wall_clock64() - ph_t0;
     }
-    (void)0;
+}
+
+template <int NC, bool FORWARD, bool FACTORS> void chain_walk_launch_one(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, hipStream_t stream)
+{
+    constexpr size_t lds = walk_lds_bytes<NC, FACTORS>();
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        // (static LDS of the preparation body + this must stay within the 160 KiB of a compute unit: ask for what is needed)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_walk_kernel<NC, FORWARD, FACTORS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    hipLaunchKernelGGL((chain_walk_kernel<NC, FORWARD, FACTORS>), dim3(1), dim3(WALK_T), lds, stream, c, fn, w);
 }
 
 template <int NC> void chain_walk_launch_nc(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, hipStream_t stream)
 {
     if (w.factors) {
-        if (c.forward) hipLaunchKernelGGL((chain_walk_kernel<NC, true, true>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
-        else hipLaunchKernelGGL((chain_walk_kernel<NC, false, true>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+        if (c.forward) chain_walk_launch_one<NC, true, true>(c, fn, w, stream);
+        else chain_walk_launch_one<NC, false, true>(c, fn, w, stream);
     } else {
-        if (c.forward) hipLaunchKernelGGL((chain_walk_kernel<NC, true, false>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
-        else hipLaunchKernelGGL((chain_walk_kernel<NC, false, false>), dim3(1), dim3(CHAIN_T), 0, stream, c, fn, w);
+        if (c.forward) chain_walk_launch_one<NC, true, false>(c, fn, w, stream);
+        else chain_walk_launch_one<NC, false, false>(c, fn, w, stream);
     }
 }
 

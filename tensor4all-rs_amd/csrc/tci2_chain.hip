@@ -520,7 +520,7 @@ void Tci2::chain_launch()
         // every matrix of the half-sweep fits the one-wave kernel: ONE persistent workgroup walks the bonds (kernels_chain.hip)
         static const bool no_walk = std::getenv("T4A_NO_WALK") != nullptr;
         size_t walk_cols = 0;
-        bool walk = !no_walk && !timed_events && !per_launch_mirror;
+        bool walk = !no_walk && !timed_events && !per_launch_mirror && nb <= 128; // (128: WALK_MAX_BONDS, kernels_chain.hip)
         for (size_t b = 0; walk && b < nb; ++b) {
             walk = dep_ub[b] <= 64 && ind_ub[b] <= 32; // (wider: the launched chain's one-workgroup kernel beats one wave)
             walk_cols = std::max(walk_cols, ind_ub[b]);
