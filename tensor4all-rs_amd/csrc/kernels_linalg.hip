@@ -7,6 +7,9 @@
 // U diag(S) Vt == A and Q R == A to rounding.
 #include "kernels.hpp"
 
+#include <cstdlib>
+#include <mutex>
+
 #include <atomic>
 #include <cstdlib>
 
@@ -489,6 +492,93 @@ __global__ void __launch_bounds__(QR_T) qr_panel_kernel(double* A, int m, int j0
     }
 }
 
+// The same panel factorisation with the panel RESIDENT IN THE LDS (rows j0 .. m-1 of the panel's w <= 32 columns: up to 560 rows =
+// 143 KiB of the 160): the global-memory version above pays four to five dependent L2 round trips per column (norm pass, reflector
+// write, rank-1 update of the panel, T column: 7.8 us per column at 512 rows), here a column is two workgroup reductions and one
+// round of wave tasks — task c > jj: H_jj on panel column c (dot product by DPP wave sum, update in place), task q < jj: the dot
+// product V_q^T v_jj for the compact-WY factor.  A (R above the diagonal, the reflector tails below), Vall (explicit reflectors), diag,
+// tau, v0s and T leave the kernel exactly as qr_panel_kernel leaves them.
+constexpr int QR_LDS_MAX_ROWS = 560;
+__global__ void __launch_bounds__(QR_T) qr_panel_lds_kernel(double* A, int m, int j0, int w, double* diag, double* tau, double* v0s, double* Vall, double* Tp)
+{
+    extern __shared__ __attribute__((aligned(16))) double qsm[]; // [QR_NB][ld] panel, [QR_NB * QR_NB] T, [QR_NB] z, [QR_T / 64] red
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = QR_T / 64;
+    const int mp = m - j0;                 // rows of the panel
+    const int ld = mp | 1;                 // (odd leading dimension: the lanes of a wave task walk down a column, tasks sit ld apart)
+    double* const P = qsm;
+    double* const T = P + (size_t)QR_NB * ld;
+    double* const zs = T + QR_NB * QR_NB;
+    double* const red = zs + QR_NB;
+    for (int e = tid; e < QR_NB * QR_NB; e += QR_T) T[e] = 0.0;
+    for (int c = wave; c < w; c += NWV) {
+        const double* src = A + (size_t)m * (j0 + c) + j0;
+        for (int r = lane; r < mp; r += 64) P[(size_t)c * ld + r] = src[r];
+    }
+    __syncthreads();
+    for (int jj = 0; jj < w; ++jj) {
+        double* x = P + (size_t)jj * ld; // rows jj .. mp-1 hold the column below (and on) the diagonal
+        double tail = 0.0;
+        for (int r = jj + 1 + tid; r < mp; r += QR_T) tail += x[r] * x[r];
+        tail = block_sum(tail, red);
+        const double x0 = x[jj];
+        const double nrm = sqrt(x0 * x0 + tail);
+        const double alpha = x0 >= 0.0 ? -nrm : nrm;
+        const double v0 = x0 - alpha;
+        const double vv = v0 * v0 + tail;
+        const double t = (nrm == 0.0) ? 0.0 : 2.0 / vv;
+        __syncthreads(); // (every thread has read x[jj] before it becomes v0)
+        if (tid == 0) {
+            diag[j0 + jj] = (nrm == 0.0) ? 0.0 : alpha;
+            tau[j0 + jj] = t;
+            v0s[j0 + jj] = v0;
+            x[jj] = v0; // the reflector sits in the column from row jj on (R's diagonal entry lives in diag[])
+        }
+        __syncthreads();
+        if (t != 0.0) {
+            // wave tasks: columns jj+1 .. w-1 get H_jj; columns 0 .. jj-1 give z_q = V_q^T v_jj (rows >= jj: v_jj is zero above)
+            for (int task = wave; task < w - 1; task += NWV) {
+                if (task >= jj) {
+                    double* y = P + (size_t)(task + 1) * ld;
+                    double dot = 0.0;
+                    for (int r = jj + lane; r < mp; r += 64) dot += x[r] * y[r];
+                    dot = wave_sum_dpp(dot);
+                    const double f = t * dot;
+                    for (int r = jj + lane; r < mp; r += 64) y[r] -= f * x[r];
+                } else {
+                    const double* vq = P + (size_t)task * ld;
+                    double dot = 0.0;
+                    for (int r = jj + lane; r < mp; r += 64) dot += vq[r] * x[r];
+                    dot = wave_sum_dpp(dot);
+                    if (lane == 0) zs[task] = dot;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < jj && t != 0.0) { // compact WY: T(0:jj, jj) = -tau T(0:jj, 0:jj) z
+            double acc = 0.0;
+            for (int r = tid; r < jj; ++r) acc += T[tid + QR_NB * r] * zs[r];
+            T[tid + QR_NB * jj] = -t * acc;
+        }
+        if (tid == 0) T[jj + QR_NB * jj] = t;
+        __syncthreads();
+    }
+    // write-out: A keeps R above the diagonal and the reflector tails below it (its diagonal entry is not read by anybody: R's
+    // diagonal is diag[]); Vall gets the explicit reflectors, zero above the diagonal
+    for (int c = wave; c < w; c += NWV) {
+        double* dstA = A + (size_t)m * (j0 + c) + j0;
+        double* dstV = Vall + (size_t)m * (j0 + c);
+        const double* col = P + (size_t)c * ld;
+        for (int r = lane; r < mp; r += 64) {
+            const double v = col[r];
+            if (r != c) dstA[r] = v;
+            dstV[j0 + r] = r < c ? 0.0 : v;
+        }
+        for (int r = lane; r < j0; r += 64) dstV[r] = 0.0;
+    }
+    for (int e = tid; e < QR_NB * QR_NB; e += QR_T) Tp[e] = T[e];
+}
+
 __global__ void __launch_bounds__(256) qr_extract_r_kernel(const double* __restrict__ A, int m, int n, int k,
                                                            const double* diag, double* R)
 {
@@ -584,7 +674,18 @@ void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double
     for (int j0 = 0, pi = 0; j0 < k; j0 += QR_NB, ++pi) {
         const int w = (k - j0) < QR_NB ? (k - j0) : QR_NB;
         double* Tp = Tall + (size_t)pi * QR_NB * QR_NB;
-        hipLaunchKernelGGL(qr_panel_kernel, dim3(1), dim3(QR_T), 0, stream, A, m, j0, w, diag, tau, v0s, Vall, Tp);
+        static const bool no_lds_panel = std::getenv("T4A_QR_NO_LDS_PANEL") != nullptr;
+        if (!no_lds_panel && m - j0 <= QR_LDS_MAX_ROWS) {
+            const int ld = (m - j0) | 1;
+            const size_t lds = ((size_t)QR_NB * ld + QR_NB * QR_NB + QR_NB + QR_T / 64) * sizeof(double);
+            static std::once_flag attr_once;
+            std::call_once(attr_once, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qr_panel_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            });
+            hipLaunchKernelGGL(qr_panel_lds_kernel, dim3(1), dim3(QR_T), lds, stream, A, m, j0, w, diag, tau, v0s, Vall, Tp);
+        } else {
+            hipLaunchKernelGGL(qr_panel_kernel, dim3(1), dim3(QR_T), 0, stream, A, m, j0, w, diag, tau, v0s, Vall, Tp);
+        }
         const int n2 = n - j0 - w, mp = m - j0;
         if (n2 <= 0) continue;
         const double* Vp = Vall + j0 + (size_t)m * j0; // rows j0 .., columns j0 .. j0 + w - 1 (zero above)
