@@ -868,6 +868,7 @@ void Tci2::sweep1site(bool forward, double rel_tol, double abs_tol, size_t max_b
             chained = chain_enqueue(forward, o1, -1, false);
             if (chained) chain_finish(o1);
         } catch (...) {
+            chain_abort(); // (nothing may stay in flight, no XCD reserved)
             chain_.one_site = false;
             throw;
         }

@@ -825,6 +825,7 @@ void Tci2::chain_abort() noexcept
         chain_.tables_valid = false;
     }
     chain_.prepared = false;
+    chain_.walked = false;
     if (!chain_.inflight) return;
     chain_.inflight = false;
     hipStream_t st = chain_.wait_stream ? chain_.wait_stream : eng.stream();
