@@ -212,6 +212,8 @@ __global__ void __launch_bounds__(CHAIN_T) chain_indep_group_kernel(const ChainG
 // its pivots -> the new list -> its size), each an L2 round trip of ~0.4 us when it goes through memory.
 constexpr int WALK_MAX_BONDS = 128;
 constexpr int WALK_MAX_LIST = 64;
+constexpr int WALK_MAX_IND = 32;    // entries of an independent list (= columns of the one-wave kernel the walk uses)
+constexpr int WALK_MAX_W = 512;     // weight entries (K x sum of the local dimensions) kept in the LDS
 struct WalkShared {
     int prev_ires[4];                                   // {rank, gave-up code, NaN flag, token} of the previous bond's rrLU
     int perm_rp[WALK_MAX_LIST], perm_cp[WALK_MAX_LIST]; // its permutations (rows / columns of the matrix as the host sees it)
@@ -221,6 +223,12 @@ struct WalkShared {
     uint64_t dep_code[WALK_MAX_LIST], dep_acc[WALK_MAX_LIST * T4A_FN_MAX_ACC]; // the dependent list of the bond in flight
     int dims[WALK_MAX_BONDS * 4];                       // ChainCommon::dims of the whole sweep (copied out at the end)
     int ind_cnt[WALK_MAX_BONDS];                        // ChainCommon::ind_cnt (copied in at the start)
+    // what does not depend on the walk is fetched one bond AHEAD (by the waves that idle while wave 0 factorises), bond b into slot
+    // b & 1: the independent list (the candidate matrix of bond b and the gather of bond b + 1 read it) and the history extras
+    uint64_t ind_code[2][WALK_MAX_IND], ind_acc[2][WALK_MAX_IND * T4A_FN_MAX_ACC];
+    uint64_t ext_code[2][WALK_MAX_LIST], ext_acc[2][WALK_MAX_LIST * T4A_FN_MAX_ACC];
+    int ext_cnt[2];
+    uint64_t w[WALK_MAX_W];
 };
 
 __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const ChainPrepArgs& p, unsigned long long* dbg = nullptr, WalkShared* ws = nullptr)
@@ -260,10 +268,12 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
             } else {
                 n_prev_dep = c.forward ? pm : pn;
                 // forward: rows of the previous bond were its dependent list, columns its independent list; backward: the reverse
-                const uint64_t* rcode = c.forward ? c.dep_code : c.ind_code + (size_t)pb * c.ind_cap;
-                const uint64_t* racc = c.forward ? c.dep_acc : c.ind_acc + (size_t)pb * c.ind_cap * K;
-                const uint64_t* ccode = c.forward ? c.ind_code + (size_t)pb * c.ind_cap : c.dep_code;
-                const uint64_t* cacc = c.forward ? c.ind_acc + (size_t)pb * c.ind_cap * K : c.dep_acc;
+                const uint64_t* const pind_code = ws ? ws->ind_code[pb & 1] : c.ind_code + (size_t)pb * c.ind_cap;
+                const uint64_t* const pind_acc = ws ? ws->ind_acc[pb & 1] : c.ind_acc + (size_t)pb * c.ind_cap * K;
+                const uint64_t* rcode = c.forward ? c.dep_code : pind_code;
+                const uint64_t* racc = c.forward ? c.dep_acc : pind_acc;
+                const uint64_t* ccode = c.forward ? pind_code : c.dep_code;
+                const uint64_t* cacc = c.forward ? pind_acc : c.dep_acc;
                 const size_t oi = (size_t)(pb + 1) * cap, oj = (size_t)pb * cap;
                 for (int k = tid; k < cnt; k += (int)blockDim.x) {
                     const int ri = r > 0 ? p.prev_rowperm[k] : 0, ci = r > 0 ? p.prev_colperm[k] : 0;
@@ -323,18 +333,20 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
     int nd = -1, lda = 0;
     // (persistent half-sweep: the parents were gathered a moment ago and wait in the LDS)
     const bool par_lds = ws != nullptr && p.prev_b >= 0;
+    const uint64_t* const xcode = ws ? ws->ext_code[b & 1] : (c.forward ? c.HI.code + (size_t)(b + 1) * cap : c.HJ.code + (size_t)b * cap);
+    const uint64_t* const xacc = ws ? ws->ext_acc[b & 1] : (c.forward ? c.HI.acc + (size_t)(b + 1) * cap * K : c.HJ.acc + (size_t)b * cap * K);
     if (c.forward) {
-        const int np = par_lds ? ws->np : c.I.cnt[b], ne = c.use_extras ? c.HI.cnt[b + 1] : 0;
+        const int np = par_lds ? ws->np : c.I.cnt[b], ne = c.use_extras ? (ws ? ws->ext_cnt[b & 1] : c.HI.cnt[b + 1]) : 0;
         if (np >= 1 && np <= c.cap && ne <= c.cap)
             nd = build_side<true>(par_lds ? ws->par_code : c.I.code + (size_t)b * cap, par_lds ? ws->par_acc : c.I.acc + (size_t)b * cap * K, np, c.ldim[b], c.w, K, c.total, c.woff[b],
-                                  c.HI.code + (size_t)(b + 1) * cap, c.HI.acc + (size_t)(b + 1) * cap * K, ne, c.dep_code, c.dep_acc, c.dep_cap,
+                                  xcode, xacc, ne, c.dep_code, c.dep_acc, c.dep_cap,
                                   s_srcpos, n_prev_dep, mapped ? c.rowmap : nullptr, hkeys, wave_sums);
         lda = n_prev_dep * c.ldim[b] + ne;
     } else {
-        const int np = par_lds ? ws->np : c.J.cnt[b + 1], ne = c.use_extras ? c.HJ.cnt[b] : 0;
+        const int np = par_lds ? ws->np : c.J.cnt[b + 1], ne = c.use_extras ? (ws ? ws->ext_cnt[b & 1] : c.HJ.cnt[b]) : 0;
         if (np >= 1 && np <= c.cap && ne <= c.cap)
             nd = build_side<false>(par_lds ? ws->par_code : c.J.code + (size_t)(b + 1) * cap, par_lds ? ws->par_acc : c.J.acc + (size_t)(b + 1) * cap * K, np, c.ldim[b + 1], c.w, K, c.total,
-                                   c.woff[b + 1], c.HJ.code + (size_t)b * cap, c.HJ.acc + (size_t)b * cap * K, ne, c.dep_code, c.dep_acc,
+                                   c.woff[b + 1], xcode, xacc, ne, c.dep_code, c.dep_acc,
                                    c.dep_cap, s_srcpos, n_prev_dep, mapped ? c.rowmap : nullptr, hkeys, wave_sums);
         lda = n_prev_dep * c.ldim[b + 1] + ne;
     }
@@ -415,6 +427,34 @@ __device__ __forceinline__ void walk_phase_barrier()
 }
 __device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// the static inputs of bond b (independent list, history extras) into slot b & 1 of the LDS, by threads first .. first + count - 1
+__device__ __forceinline__ void walk_prefetch(const ChainCommon& c, WalkShared* ws, int b, int first, int count)
+{
+    const int t = (int)threadIdx.x - first;
+    if (t < 0 || count <= 0) return;
+    const int K = c.K, slot = b & 1;
+    int ni = ws->ind_cnt[b];
+    ni = ni < 0 ? 0 : (ni > WALK_MAX_IND ? WALK_MAX_IND : ni);
+    const uint64_t* icode = c.ind_code + (size_t)b * c.ind_cap;
+    const uint64_t* iacc = c.ind_acc + (size_t)b * c.ind_cap * K;
+    for (int e = t; e < ni * (1 + K); e += count) {
+        if (e < ni) ws->ind_code[slot][e] = icode[e];
+        else ws->ind_acc[slot][e - ni] = iacc[e - ni];
+    }
+    if (c.use_extras) {
+        const ChainTab& H = c.forward ? c.HI : c.HJ;
+        const int hsite = c.forward ? b + 1 : b;
+        const int ne_raw = H.cnt[hsite];
+        const int ne = ne_raw < 0 ? 0 : (ne_raw > WALK_MAX_LIST ? WALK_MAX_LIST : ne_raw);
+        const size_t cap = (size_t)c.cap;
+        for (int e = t; e < ne * (1 + K); e += count) {
+            if (e < ne) ws->ext_code[slot][e] = H.code[(size_t)hsite * cap + e];
+            else ws->ext_acc[slot][e - ne] = H.acc[(size_t)hsite * cap * K + (e - ne)];
+        }
+        if (t == 0) ws->ext_cnt[slot] = ne_raw;
+    }
+}
+
 template <int NC, bool FACTORS> constexpr size_t walk_lds_bytes()
 {
     // [WalkShared][the candidate matrix (64 x NC doubles), later the one-wave kernel's side buffers: the matrix is in registers by then]
@@ -451,6 +491,15 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
     cw.dep_cap = WALK_MAX_LIST;
     for (int e = tid; e < nb * 4; e += (int)blockDim.x) ws->dims[e] = 0;
     for (int e = tid; e < nb; e += (int)blockDim.x) ws->ind_cnt[e] = c.ind_cnt[e];
+    {   // the functor's weights (K rows of `total` entries), when they fit
+        const int nw = c.K * c.total;
+        if (nw <= WALK_MAX_W) {
+            for (int e = tid; e < nw; e += (int)blockDim.x) ws->w[e] = c.w[e];
+            cw.w = ws->w;
+        }
+    }
+    walk_phase_barrier();
+    walk_prefetch(c, ws, FORWARD ? 0 : nb - 1, 0, (int)blockDim.x); // (the first bond's static inputs: nobody could fetch them ahead)
     walk_phase_barrier();
     for (int k = 0; k <= nb; ++k) {
         const int b = FORWARD ? k : nb - 1 - k;
@@ -481,7 +530,7 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
         const bool runs = poisoned == 0 && nd > 0 && ni > 0 && nd <= WALK_MAX_LIST && ni <= NC;
         if (runs) {
             const int K = fn.n_acc;
-            const uint64_t* ia = c.ind_acc + (size_t)b * c.ind_cap * K;
+            const uint64_t* ia = ws->ind_acc[b & 1];
             for (int idx = tid; idx < nd * ni; idx += (int)blockDim.x) {
                 const int i = idx % nd, j = idx / nd;
                 uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
@@ -491,7 +540,9 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
         }
         walk_phase_barrier();
         phase(1);
-        // ---- the factorisation: wave 0 (rows = the dependent side in both directions) ----
+        // ---- the factorisation: wave 0 (rows = the dependent side in both directions); the other waves fetch the next bond's
+        // static inputs meanwhile (its slot held the previous bond's lists: the gather of this bond was their last reader) ----
+        if (tid >= 64 && k + 1 < nb) walk_prefetch(c, ws, FORWARD ? b + 1 : b - 1, 64, (int)blockDim.x - 64);
         if (tid < 64) {
             int npiv = -2;
             char* blk = w.blocks + (size_t)b * w.block_bytes;
