@@ -626,6 +626,8 @@ def aux_timings():
             best = dt if best is None else min(best, dt)
         out["cfg2_time_to_solution_ms"] = best * 1e3
         out["cfg2_rank"] = int(max(t.link_dims()))
+        st = t.chain_stats()  # (three 2-site half-sweeps + the final 1-site sweep, each ONE persistent workgroup: DESIGN.md section 5.6)
+        out["cfg2_sweeps_chained_walked_one_site"] = [st["half_sweeps"] + st["one_site_sweeps"], st["walked_sweeps"], st["one_site_sweeps"]]
     except Exception as e:  # noqa: BLE001 - auxiliary numbers must never break the bench line
         out["cfg2_error"] = str(e)
     try:

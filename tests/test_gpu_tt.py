@@ -74,8 +74,10 @@ def test_svd_rejects_non_finite_and_empty(t4a):
 
 
 @pytest.mark.parametrize("shape", [(2, 2), (5, 3), (3, 5), (16, 8), (64, 64), (300, 120), (120, 300), (1, 4), (4, 1),
-                                   (512, 256)])
+                                   (512, 256), (700, 200), (560, 33), (561, 40)])
 def test_qr_properties(t4a, shape):
+    """(Panels of at most 560 rows are factorised in the LDS, taller ones in global memory: 700 x 200 starts with the second kind and
+    ends with the first, 560 / 561 rows sit on the limit.)"""
     a = RNG.standard_normal(shape)
     k = min(shape)
     q, r = t4a.qr_backend(a)
