@@ -344,6 +344,8 @@ struct ChainWalkArgs {
 };
 void chain_walk_launch(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, int columns, hipStream_t stream);
 void chain_indep_launch(const ChainCommon& c, int n_bonds, hipStream_t stream);
+// behind a chain whose preparations ran with defer_host_writes: tables -> pinned mirrors, dims -> hdims, in one launch
+void chain_mirror_launch(const ChainCommon& c, int n_bonds, hipStream_t stream);
 void chain_prep_launch(const ChainCommon& c, const ChainPrepArgs& a, hipStream_t stream);
 // n_dep_ub / n_ind_ub: upper bounds for the launch grid (the kernel reads the real sizes on the device)
 void chain_pi_launch(const ChainCommon& c, const FnDevice& fn, int b, int n_dep_ub, int n_ind_ub, double* out, hipStream_t stream);

@@ -408,6 +408,35 @@ __global__ void __launch_bounds__(256) chain_pi_group_kernel(const ChainGroupSlo
 }
 
 
+// The host's copies of what a chain wrote, in bulk behind it: every table (I_1 .. I_nb, J_0 .. J_{nb-1}) into the pinned mirror, the
+// dimensions into hdims.  A preparation that stores into pinned memory itself pays the PCIe write acknowledgement at its kernel's
+// end, on the critical path between two rrLU launches; here it is paid once per half-sweep.  (The gather of a poisoned bond wrote
+// nothing: chain_finish ignores everything from the first poisoned bond on.)
+__device__ __forceinline__ void chain_mirror_body(const ChainCommon& c, int nb)
+{
+    const int K = c.K;
+    const size_t cap = (size_t)c.cap;
+    const int gtid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsz = (int)(gridDim.x * blockDim.x);
+    for (int site = 0; site <= nb; ++site) {
+        for (int fam = 0; fam < 2; ++fam) {
+            if ((fam == 0 && site == 0) || (fam == 1 && site == nb)) continue; // (I_0 and J_{n-1} are never written)
+            const ChainTab& T = fam == 0 ? c.I : c.J;
+            const ChainTab& Mr = fam == 0 ? c.mI : c.mJ;
+            const int cnt = __hip_atomic_load(T.cnt + site, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cnt < 0 || cnt > c.cap) continue;
+            for (int e = gtid; e < cnt * (1 + K); e += gsz) {
+                if (e < cnt) Mr.code[(size_t)site * cap + e] = T.code[(size_t)site * cap + e];
+                else Mr.acc[(size_t)site * cap * K + (e - cnt)] = T.acc[(size_t)site * cap * K + (e - cnt)];
+            }
+            if (gtid == 0) Mr.cnt[site] = cnt;
+        }
+    }
+    if (c.hdims)
+        for (int e = gtid; e < nb * 4; e += gsz)
+            if ((e & 3) != 3) c.hdims[e] = __hip_atomic_load(c.dims + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void __launch_bounds__(1024) chain_mirror_kernel(ChainCommon c, int nb) { chain_mirror_body(c, nb); }
+
 // ------------------------------------------------------------------------------------------------
 // The persistent half-sweep ("walker"): ONE workgroup walks all bonds of a half-sweep whose matrices fit the one-wave rrLU kernel
 // (at most 64 x 64: BASELINE configs[1], the first iterations of every run).  Per bond: the preparation above, the candidate
@@ -603,32 +632,11 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
         walk_phase_barrier();
         phase(2);
     }
-    // ---- the host's copies, in bulk: every table this sweep wrote (I_1 .. I_nb, J_0 .. J_{nb-1}) into the pinned mirror, the
-    // dimensions into global memory and hdims.  (The gather of a poisoned bond wrote nothing: chain_finish ignores everything from
-    // the first poisoned bond on.)
-    {
-        const int K = c.K;
-        const size_t cap = (size_t)c.cap;
-        for (int site = 0; site <= nb; ++site) {
-            for (int fam = 0; fam < 2; ++fam) {
-                if ((fam == 0 && site == 0) || (fam == 1 && site == nb)) continue; // (I_0 and J_{n-1} are never written)
-                const ChainTab& T = fam == 0 ? c.I : c.J;
-                const ChainTab& Mr = fam == 0 ? c.mI : c.mJ;
-                const int cnt = walk_load_i32(T.cnt + site);
-                if (cnt < 0 || cnt > c.cap) continue;
-                for (int e = tid; e < cnt * (1 + K); e += (int)blockDim.x) {
-                    if (e < cnt) Mr.code[(size_t)site * cap + e] = T.code[(size_t)site * cap + e];
-                    else Mr.acc[(size_t)site * cap * K + (e - cnt)] = T.acc[(size_t)site * cap * K + (e - cnt)];
-                }
-                if (tid == 0) Mr.cnt[site] = cnt;
-            }
-        }
-        for (int e = tid; e < nb * 4; e += (int)blockDim.x) {
-            const int v = ws->dims[e];
-            c.dims[e] = v;
-            if (c.hdims && (e & 3) != 3) c.hdims[e] = v;
-        }
-    }
+    // ---- the host's copies, in bulk (chain_mirror_body): tables into the pinned mirror, dimensions into global memory and hdims ----
+    for (int e = tid; e < nb * 4; e += (int)blockDim.x) c.dims[e] = ws->dims[e];
+    __threadfence(); // (the copy below reads counts and dimensions with device-scope loads: every store of the walk is out first)
+    __syncthreads();
+    chain_mirror_body(c, nb);
     if (w.phase_ticks && tid == 0) {
         for (int i = 0; i < 3; ++i) w.phase_ticks[i] = ph[i];
         w.phase_ticks[3] = wall_clock64() - ph_t0;
@@ -700,6 +708,11 @@ void chain_walk_launch(const ChainCommon& c, const FnDevice& fn, const ChainWalk
     if (columns <= 8) chain_walk_launch_nc<8>(c, fn, w, stream);
     else if (columns <= 16) chain_walk_launch_nc<16>(c, fn, w, stream);
     else chain_walk_launch_nc<32>(c, fn, w, stream);
+}
+
+void chain_mirror_launch(const ChainCommon& c, int n_bonds, hipStream_t stream)
+{
+    hipLaunchKernelGGL(chain_mirror_kernel, dim3(8), dim3(1024), 0, stream, c, n_bonds);
 }
 
 } // namespace t4a

@@ -361,6 +361,10 @@ bool Tci2::chain_enqueue(bool forward, const TCI2Options& options, long ext_idx,
     if (one && chain_.one_factors) {
         size_t stride = 1;
         for (size_t b = 0; b < nb; ++b) stride = std::max(stride, dep_ub[b] * ind_ub[b]);
+        if (nb * stride > ((size_t)1 << 27)) { // more than 1 GiB of factored matrices: this sweep runs bond by bond
+            ++chain_stats_ext[2];
+            return false;
+        }
         chain_.factors_stride = stride;
         chain_.factors.reserve(nb * stride);
         chain_.urows.reserve(std::max<size_t>(steps_cap, 1) * std::max(dep_cap, ind_cap));
@@ -556,6 +560,10 @@ void Tci2::chain_launch()
             chain_walk_launch(c, fn_dev_, w, (int)walk_cols, st);
             ++chain_stats_ext[0];
         }
+        // T4A_CHAIN_DEFER_MIRROR=1: the launched chain's preparations leave the pinned mirrors alone and one bulk copy follows the
+        // chain (measured: 21.44 against 21.39 ms per cfg3 sweep — the stores over PCIe are not what a preparation's 8.6 us consist
+        // of, and the extra launch costs what they cost; the persistent half-sweep always copies in bulk)
+        static const bool defer_mirror = std::getenv("T4A_CHAIN_DEFER_MIRROR") != nullptr;
         bool spec_pending = false; // the previous bond's launch evaluates this bond's candidate matrix
         for (size_t k = 0; !walk && k < nb; ++k) {
             const size_t b = order[k];
@@ -567,6 +575,7 @@ void Tci2::chain_launch()
             std::memset(&pa, 0, sizeof(pa));
             pa.b = (int)b;
             pa.do_build = 1;
+            pa.defer_host_writes = defer_mirror ? 1 : 0;
             pa.with_rowmap = spec_here ? 1 : 0;
             pa.prev_b = -1;
             if (k > 0) {
@@ -623,12 +632,14 @@ void Tci2::chain_launch()
             ChainPrepArgs pa;
             std::memset(&pa, 0, sizeof(pa));
             pa.do_build = 0;
+            pa.defer_host_writes = defer_mirror ? 1 : 0;
             pa.prev_b = (int)pb;
             pa.prev_iresult = reinterpret_cast<const int*>(pblk.dev + 16);
             pa.prev_rowperm = reinterpret_cast<const int*>(pblk.dev + pblk.off_rp);
             pa.prev_colperm = reinterpret_cast<const int*>(pblk.dev + pblk.off_cp);
             pa.prev_token = tokens[pb];
             chain_prep_launch(c, pa, st);
+            if (defer_mirror) chain_mirror_launch(c, (int)nb, st);
         }
         chain_.cores_batched = false;
         static const bool no_batched_cores = std::getenv("T4A_NO_BATCHED_CORES") != nullptr;
