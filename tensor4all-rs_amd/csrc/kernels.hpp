@@ -324,6 +324,7 @@ struct ChainPrepArgs {
     const int* prev_rowperm;
     const int* prev_colperm;
     unsigned prev_token;
+    unsigned long long* dbg;  // diagnostic (T4A_PREP_DEBUG): [4] gather [5] dependent list [6] whole body, 100 MHz ticks summed over the calls
     int defer_host_writes;    // 1 (persistent half-sweep): the pinned mirrors and hdims are not written here but in bulk at the end of
                               // the kernel — a store over PCIe is acknowledged after microseconds, and every barrier waits for it
 };

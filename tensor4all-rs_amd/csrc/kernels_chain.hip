@@ -367,7 +367,12 @@ __device__ __forceinline__ void chain_prep_body(const ChainCommon& c, const Chai
     }
 }
 
-__global__ void __launch_bounds__(CHAIN_T) chain_prep_kernel(ChainCommon c, ChainPrepArgs p) { chain_prep_body(c, p); }
+__global__ void __launch_bounds__(CHAIN_T) chain_prep_kernel(ChainCommon c, ChainPrepArgs p)
+{
+    const unsigned long long t0 = p.dbg ? wall_clock64() : 0ull;
+    chain_prep_body(c, p, p.dbg);
+    if (p.dbg && threadIdx.x == 0) p.dbg[6] += wall_clock64() - t0;
+}
 // group chain: blockIdx.x = handle (a handle that has nothing to do at this bond carries prev_b < 0 and do_build == 0)
 __global__ void __launch_bounds__(CHAIN_T) chain_prep_group_kernel(const ChainGroupSlot* __restrict__ slots, ChainPrepGroupArgs g)
 {
@@ -541,6 +546,7 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
         pa.prev_rowperm = nullptr;
         pa.prev_colperm = nullptr;
         pa.prev_token = 0u;
+        pa.dbg = nullptr;
         pa.defer_host_writes = 1;
         if (k > 0) {
             pa.prev_b = FORWARD ? b - 1 : b + 1;

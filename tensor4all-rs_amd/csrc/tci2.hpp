@@ -294,6 +294,7 @@ private:
         bool cores_batched = false;  // the chain in flight writes the site tensors of its low-rank bonds itself (one launch behind it)
         DevBuf<unsigned long long> walk_dbg; // diagnostic phase times of the persistent half-sweep (T4A_WALK_DEBUG)
         bool walked = false;         // the chain in flight is a persistent half-sweep
+        bool prep_dbg = false;       // ... or a launched chain whose preparation kernels stamp their phases (T4A_PREP_DEBUG)
         unsigned walk_token = 1;     // completion tokens of the persistent half-sweep (bond k of a walk: base + k)
         ChainBlock proto;
         bool timed = false, timed_events = false;

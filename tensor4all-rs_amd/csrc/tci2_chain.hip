@@ -564,6 +564,14 @@ void Tci2::chain_launch()
         // chain (measured: 21.44 against 21.39 ms per cfg3 sweep — the stores over PCIe are not what a preparation's 8.6 us consist
         // of, and the extra launch costs what they cost; the persistent half-sweep always copies in bulk)
         static const bool defer_mirror = std::getenv("T4A_CHAIN_DEFER_MIRROR") != nullptr;
+        static const bool want_prep_dbg = std::getenv("T4A_PREP_DEBUG") != nullptr; // phase times of the preparation kernels of this chain
+        unsigned long long* prep_dbg = nullptr;
+        if (want_prep_dbg && !walk) {
+            chain_.walk_dbg.reserve(8);
+            T4A_HIP(hipMemsetAsync(chain_.walk_dbg.get(), 0, 8 * sizeof(unsigned long long), st));
+            prep_dbg = chain_.walk_dbg.get();
+            chain_.prep_dbg = true;
+        }
         bool spec_pending = false; // the previous bond's launch evaluates this bond's candidate matrix
         for (size_t k = 0; !walk && k < nb; ++k) {
             const size_t b = order[k];
@@ -575,6 +583,7 @@ void Tci2::chain_launch()
             std::memset(&pa, 0, sizeof(pa));
             pa.b = (int)b;
             pa.do_build = 1;
+            pa.dbg = prep_dbg;
             pa.defer_host_writes = defer_mirror ? 1 : 0;
             pa.with_rowmap = spec_here ? 1 : 0;
             pa.prev_b = -1;
@@ -878,6 +887,13 @@ void Tci2::chain_finish(const TCI2Options& options)
                      t[0] * 0.01, t[4] * 0.01, t[5] * 0.01, t[1] * 0.01, t[2] * 0.01, t[3] * 0.01);
     }
     chain_.walked = false;
+    if (chain_.prep_dbg && chain_.walk_dbg.get()) {
+        unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpy(t, chain_.walk_dbg.get(), sizeof(t), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[t4a prep] %zu bonds: preparation kernels %.1f us in total: gather %.1f, dependent list %.1f, rest %.1f\n", nb, t[6] * 0.01, t[4] * 0.01,
+                     t[5] * 0.01, (double)(t[6] - t[4] - t[5]) * 0.01);
+    }
+    chain_.prep_dbg = false;
     const int mnew = 1 - chain_.mcur;
     const ChainTab ni = chain_mirror(mnew, 0), nj = chain_mirror(mnew, 1);
     long failed_k = -1;
