@@ -75,7 +75,7 @@ constexpr unsigned X2_META_VALID = 1u << 12;
 constexpr int X2_DIVW = XWAVES - 1; // waves that divide the pivot column (all but the polling wave)
 
 template <int RPT, int CPT, bool ROWMAJOR>
-__device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
+__device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluXcdArgs* pk)
 {
     static_assert(XWAVES == 8, "the second-generation kernel is written for eight waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -766,39 +766,44 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
     }
 
     // ---- results ----
+    // (the launch arguments of the epilogue are read again from the kernel-argument segment: kept from the prologue they would
+    // occupy — i.e. spill — a dozen scalar register pairs across the whole step loop)
+    const RrluXcdArgs* pe_ptr = pk;
+    asm volatile("" : "+s"(pe_ptr));
+    const RrluXcdArgs& pe = *pe_ptr;
     const unsigned long long t_done = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
     __syncthreads(); // (a give-up of the last step, the tables of the last applied step)
     if (ctl[1]) timed_out = true;
     if (npiv >= (M < N ? M : N)) error = 0.0; // matrixlu.rs:811-813
     if (rank == 0 && tid == 0) {
-        p.iresult[0] = npiv;
-        p.dresult[0] = error; // tid 0 belongs to the polling wave, which keeps the error
+        pe.iresult[0] = npiv;
+        pe.dresult[0] = error; // tid 0 belongs to the polling wave, which keeps the error
     }
     if (stamp_on) {
-        for (int e = 0; e < 16; ++e) p.stamps[e] = lds_stamps[e];
-        p.stamps[16] = t_elected - t_entry; // fixed part of a launch: election ...
-        p.stamps[17] = t_loop - t_elected;  // ... matrix load, tables, first maxima ...
-        p.stamps[18] = t_done - t_loop;     // (the pivot steps)
+        for (int e = 0; e < 16; ++e) pe.stamps[e] = lds_stamps[e];
+        pe.stamps[16] = t_elected - t_entry; // fixed part of a launch: election ...
+        pe.stamps[17] = t_loop - t_elected;  // ... matrix load, tables, first maxima ...
+        pe.stamps[18] = t_done - t_loop;     // (the pivot steps)
     }
     if (timed_out) return;
     // permutations: the tables are stable since the last barrier; device block and host mirror are written side by side
     if (rank == 0) {
-        int* const h_rp = p.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(p.h_block) + (reinterpret_cast<const char*>(p.row_perm) - reinterpret_cast<const char*>(p.dresult))) : nullptr;
-        int* const h_cp = p.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(p.h_block) + (reinterpret_cast<const char*>(p.col_perm) - reinterpret_cast<const char*>(p.dresult))) : nullptr;
+        int* const h_rp = pe.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(pe.h_block) + (reinterpret_cast<const char*>(pe.row_perm) - reinterpret_cast<const char*>(pe.dresult))) : nullptr;
+        int* const h_cp = pe.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(pe.h_block) + (reinterpret_cast<const char*>(pe.col_perm) - reinterpret_cast<const char*>(pe.dresult))) : nullptr;
         for (int i = tid; i < M; i += XT) {
             const int v = posrow[i];
-            p.row_perm[i] = v;
+            pe.row_perm[i] = v;
             if (h_rp) h_rp[i] = v;
         }
         for (int j = tid; j < N; j += XT) {
             const int v = poscol[j];
-            p.col_perm[j] = v;
+            pe.col_perm[j] = v;
             if (h_cp) h_cp[j] = v;
         }
-        unsigned long long* const h_pv = p.h_block ? p.h_block + (reinterpret_cast<const char*>(p.pivot_vals) - reinterpret_cast<const char*>(p.dresult)) / 8 : nullptr;
+        unsigned long long* const h_pv = pe.h_block ? pe.h_block + (reinterpret_cast<const char*>(pe.pivot_vals) - reinterpret_cast<const char*>(pe.dresult)) / 8 : nullptr;
         for (int e = tid; e < npiv; e += XT) {
             const double v = lds_pivots[e];
-            p.pivot_vals[e] = v;
+            pe.pivot_vals[e] = v;
             if (h_pv) h_pv[e] = (unsigned long long)__double_as_longlong(v);
         }
     }
@@ -821,51 +826,51 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
                     v = xcd_div(v, pv, refined_rcp(pv), exp_mid(pv));
                     if (v != v) nan_seen = 1;
                 }
-                if (p.Aout) {
+                if (pe.Aout) {
                     if (from_u)
                         v = __longlong_as_double((long long)__hip_atomic_load(
-                            reinterpret_cast<const unsigned long long*>(p.urows) + ((size_t)rp * N + (g + NW * q)), __ATOMIC_RELAXED,
+                            reinterpret_cast<const unsigned long long*>(pe.urows) + ((size_t)rp * N + (g + NW * q)), __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT));
-                    if (p.out_transposed)
-                        p.Aout[(size_t)rp * N + cp] = v;
+                    if (pe.out_transposed)
+                        pe.Aout[(size_t)rp * N + cp] = v;
                     else
-                        p.Aout[(size_t)cp * M + rp] = v;
+                        pe.Aout[(size_t)cp * M + rp] = v;
                 }
             }
         }
     if (nan_seen) {
-        atomicExch(&p.iresult[2], 1);
-        if (p.h_block) ((volatile int*)p.h_block)[6] = 1;
+        atomicExch(&pe.iresult[2], 1);
+        if (pe.h_block) ((volatile int*)pe.h_block)[6] = 1;
     }
     // host-visible header (the pivot values went to the mirror with the permutations, the two flag words belong to their setters)
-    if (p.h_block && rank == 0 && tid == 0) {
-        p.h_block[0] = (unsigned long long)__double_as_longlong(error);
-        p.h_block[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.dresult) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ((volatile int*)p.h_block)[4] = npiv;
+    if (pe.h_block && rank == 0 && tid == 0) {
+        pe.h_block[0] = (unsigned long long)__double_as_longlong(error);
+        pe.h_block[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(pe.dresult) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ((volatile int*)pe.h_block)[4] = npiv;
         // completion token: the host accepts the result only if rank 0 ran to its end in THIS launch (a launch whose
         // workgroups never met the elected XCD would otherwise leave an all-zero block behind)
-        ((volatile int*)p.h_block)[7] = (int)p.salt;
-        if (p.ts_u64 > 0) {
-            p.h_block[p.ts_u64] = ts_begin;
-            p.h_block[p.ts_u64 + 1] = wall_clock64();
+        ((volatile int*)pe.h_block)[7] = (int)pe.salt;
+        if (pe.ts_u64 > 0) {
+            pe.h_block[pe.ts_u64] = ts_begin;
+            pe.h_block[pe.ts_u64 + 1] = wall_clock64();
         }
-        reinterpret_cast<unsigned long long*>(p.dresult)[1] = 0ull; // clean header for the next launch (every agent's atomicMax is long done)
-        if (p.dims) { // bond chain: the device-side completion token for the next preparation kernel (max |a| stays in the mirror)
+        reinterpret_cast<unsigned long long*>(pe.dresult)[1] = 0ull; // clean header for the next launch (every agent's atomicMax is long done)
+        if (pe.dims) { // bond chain: the device-side completion token for the next preparation kernel (max |a| stays in the mirror)
             __threadfence();
-            p.iresult[3] = (int)p.salt;
+            pe.iresult[3] = (int)pe.salt;
         }
-        if (stamp_on) p.stamps[19] = __builtin_amdgcn_s_memtime() - t_done; // ... write-out and host mirror
+        if (stamp_on) pe.stamps[19] = __builtin_amdgcn_s_memtime() - t_done; // ... write-out and host mirror
     }
     // bond chain without per-launch host mirror: the device block is complete as it is (error, max |a|, rank, flags, pivot
     // values, permutations) and is copied to the host once, behind the whole chain; it only lacks the time stamps and the token
-    if (!p.h_block && p.dims && rank == 0 && tid == 0) {
-        if (p.ts_u64 > 0) {
-            unsigned long long* const blk = reinterpret_cast<unsigned long long*>(p.dresult);
-            blk[p.ts_u64] = ts_begin;
-            blk[p.ts_u64 + 1] = wall_clock64();
+    if (!pe.h_block && pe.dims && rank == 0 && tid == 0) {
+        if (pe.ts_u64 > 0) {
+            unsigned long long* const blk = reinterpret_cast<unsigned long long*>(pe.dresult);
+            blk[pe.ts_u64] = ts_begin;
+            blk[pe.ts_u64 + 1] = wall_clock64();
         }
         __threadfence();
-        p.iresult[3] = (int)p.salt;
+        pe.iresult[3] = (int)pe.salt;
     }
 }
 
@@ -873,7 +878,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p)
 template <int RPT, int CPT, bool ROWMAJOR>
 __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd2_kernel(RrluXcdArgs p)
 {
-    rrlu_xcd2_body<RPT, CPT, ROWMAJOR>(p);
+    rrlu_xcd2_body<RPT, CPT, ROWMAJOR>(p, reinterpret_cast<const RrluXcdArgs*>(kernarg_base()));
 }
 template <int RPT, int CPT, bool ROWMAJOR> void xcd2_launch_tie(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
 {
@@ -908,7 +913,8 @@ __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES 
 {
     (void)g;
     const unsigned x = (unsigned)__builtin_amdgcn_readfirstlane((int)xcc_id()) & 7u;
-    rrlu_xcd2_body<RPT, CPT, ROWMAJOR>(*reinterpret_cast<const RrluXcdArgs*>(kernarg_base() + (size_t)x * sizeof(RrluXcdArgs)));
+    const RrluXcdArgs* const slot = reinterpret_cast<const RrluXcdArgs*>(kernarg_base() + (size_t)x * sizeof(RrluXcdArgs));
+    rrlu_xcd2_body<RPT, CPT, ROWMAJOR>(*slot, slot);
 }
 
 template <int RPT, int CPT, bool ROWMAJOR> void xcd2_group_launch_tie(const RrluXcdPlan& plan, const RrluXcdGroupArgs& a, hipStream_t stream)

@@ -257,7 +257,7 @@ __device__ __forceinline__ const char* kernarg_base() // the kernel-argument seg
 }
 // (not inlined, and handed a pointer into the kernel-argument segment rather than a reference to the by-value argument: the
 // step loop of the kernel is bound by its scalar registers, nothing of this path may leak into its register allocation)
-__device__ __noinline__ void xcd_spec_work(const XcdSpecArgs* spp, int M, int* lds_tile)
+__device__ __forceinline__ void xcd_spec_work(const XcdSpecArgs* spp, int M, int* lds_tile)
 {
     const XcdSpecArgs& sp = *spp;
     const int tid = threadIdx.x;
