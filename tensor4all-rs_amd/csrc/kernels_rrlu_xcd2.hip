@@ -156,33 +156,41 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
     bool bad = false; // a NaN or an infinity among my entries of the input
     // every load is issued before the first one is consumed (clamped addresses instead of branches): the whole matrix is
     // one round trip to memory per lane, not RPT * CPT dependent ones
-    int srow[RPT]; // source row of my slot rows (bond chain: through the row map of the speculative candidate matrix)
+    // (Row validity travels as a per-lane BIT MASK and is tested again for every column, behind a compiler barrier: as RPT x CPT
+    // lane masks in scalar register pairs — which is what common-subexpression elimination makes of `i < M` — the validity of the
+    // slab is what spilled the scalar register file of the wide instantiations.)
+    int srow[RPT]; // source row of my slot rows (bond chain: through the row map of the speculative candidate matrix); 0 beyond M
+    unsigned rowmask = 0u;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int i = lane + 64 * r;
-        srow[r] = i;
-        if (p.rowmap) srow[r] = p.rowmap[i < M ? i : 0];
+        const bool rok = i < M;
+        rowmask |= rok ? (1u << r) : 0u;
+        srow[r] = rok ? i : 0;
+        if (p.rowmap) srow[r] = p.rowmap[rok ? i : 0];
     }
 #pragma unroll
-    for (int q = 0; q < CPT; ++q)
+    for (int q = 0; q < CPT; ++q) {
+        const bool cok = g + NW * q < N; // (wave-uniform)
+        const double* const colp = p.A + (cok ? (size_t)(g + NW * q) * lda : (size_t)0);
+        const unsigned rm = (unsigned)opaque_v((int)rowmask);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) a[q][r] = colp[(cok && ((rm >> r) & 1u)) ? srow[r] : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const bool cok = g + NW * q < N;
+        const unsigned rm = (unsigned)opaque_v((int)rowmask);
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const int i = lane + 64 * r;
-            const bool ok = (g + NW * q < N) && i < M;
-            a[q][r] = p.A[ok ? (size_t)(g + NW * q) * lda + srow[r] : (size_t)0];
-        }
-#pragma unroll
-    for (int q = 0; q < CPT; ++q)
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int i = lane + 64 * r;
-            const bool ok = (g + NW * q < N) && i < M;
+            const bool ok = cok && ((rm >> r) & 1u);
             const double v = ok ? a[q][r] : 0.0;
             const double sqv = v * v; // max sqrt(v*v) == sqrt(max v*v): one square root per lane below
             if (sqv > local_sqmax) local_sqmax = sqv; // (NaN never enters, like the branchy form)
             bad |= !((v - v) == 0.0);                 // inf - inf and NaN - NaN are NaN
             a[q][r] = v;
         }
+    }
     for (int i = tid; i < M; i += XT) {
         posrow[i] = (unsigned short)i;
         rowpos[i] = (unsigned short)i;
@@ -771,10 +779,12 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
     const RrluXcdArgs* pe_ptr = pk;
     asm volatile("" : "+s"(pe_ptr));
     const RrluXcdArgs& pe = *pe_ptr;
+    // (and the shape: the row / column masks of the matrix load would otherwise be kept, as scalar register pairs, for the write-out)
+    const int Me = opaque_s(M), Ne = opaque_s(N);
     const unsigned long long t_done = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
     __syncthreads(); // (a give-up of the last step, the tables of the last applied step)
     if (ctl[1]) timed_out = true;
-    if (npiv >= (M < N ? M : N)) error = 0.0; // matrixlu.rs:811-813
+    if (npiv >= (Me < Ne ? Me : Ne)) error = 0.0; // matrixlu.rs:811-813
     if (rank == 0 && tid == 0) {
         pe.iresult[0] = npiv;
         pe.dresult[0] = error; // tid 0 belongs to the polling wave, which keeps the error
@@ -790,12 +800,12 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
     if (rank == 0) {
         int* const h_rp = pe.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(pe.h_block) + (reinterpret_cast<const char*>(pe.row_perm) - reinterpret_cast<const char*>(pe.dresult))) : nullptr;
         int* const h_cp = pe.h_block ? reinterpret_cast<int*>(reinterpret_cast<char*>(pe.h_block) + (reinterpret_cast<const char*>(pe.col_perm) - reinterpret_cast<const char*>(pe.dresult))) : nullptr;
-        for (int i = tid; i < M; i += XT) {
+        for (int i = tid; i < Me; i += XT) {
             const int v = posrow[i];
             pe.row_perm[i] = v;
             if (h_rp) h_rp[i] = v;
         }
-        for (int j = tid; j < N; j += XT) {
+        for (int j = tid; j < Ne; j += XT) {
             const int v = poscol[j];
             pe.col_perm[j] = v;
             if (h_cp) h_cp[j] = v;
@@ -816,7 +826,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int i = lane + 64 * r;
-            if (g + NW * q < N && i < M) {
+            if (g + NW * q < Ne && i < Me) {
                 const int cp = colpos[g + NW * q], rp = rowpos[i];
                 const bool from_u = (rp < npiv) && (cp >= rp);
                 double v = a[q][r];
@@ -829,12 +839,12 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                 if (pe.Aout) {
                     if (from_u)
                         v = __longlong_as_double((long long)__hip_atomic_load(
-                            reinterpret_cast<const unsigned long long*>(pe.urows) + ((size_t)rp * N + (g + NW * q)), __ATOMIC_RELAXED,
+                            reinterpret_cast<const unsigned long long*>(pe.urows) + ((size_t)rp * Ne + (g + NW * q)), __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT));
                     if (pe.out_transposed)
-                        pe.Aout[(size_t)rp * N + cp] = v;
+                        pe.Aout[(size_t)rp * Ne + cp] = v;
                     else
-                        pe.Aout[(size_t)cp * M + rp] = v;
+                        pe.Aout[(size_t)cp * Me + rp] = v;
                 }
             }
         }
