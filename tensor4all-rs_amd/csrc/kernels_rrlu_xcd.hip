@@ -117,32 +117,39 @@ __device__ __forceinline__ void rrlu_xcd_body(const RrluXcdArgs& p)
     double local_sqmax = 0.0;
     // every load is issued before the first one is consumed (clamped addresses instead of branches): the whole matrix is
     // one round trip to memory per lane, not RPT * CPT dependent ones
-    int srow[RPT]; // source row of my slot rows (bond chain: through the row map of the speculative candidate matrix)
+    // (row validity as a per-lane bit mask, tested again for every column behind a compiler barrier: RPT x CPT lane masks in scalar
+    // register pairs are what spilled the scalar register file of the wide instantiations, see kernels_rrlu_xcd2.hip)
+    int srow[RPT]; // source row of my slot rows (bond chain: through the row map of the speculative candidate matrix); 0 beyond M
+    unsigned rowmask = 0u;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int i = lane + 64 * r;
-        srow[r] = i;
-        if (p.rowmap) srow[r] = p.rowmap[i < M ? i : 0];
+        const bool rok = i < M;
+        rowmask |= rok ? (1u << r) : 0u;
+        srow[r] = rok ? i : 0;
+        if (p.rowmap) srow[r] = p.rowmap[rok ? i : 0];
     }
 #pragma unroll
-    for (int q = 0; q < CPT; ++q)
+    for (int q = 0; q < CPT; ++q) {
+        const bool cok = cpos[q] >= 0; // (wave-uniform)
+        const double* const colp = p.A + (cok ? (size_t)(g + NW * q) * lda : (size_t)0);
+        const unsigned rm = (unsigned)opaque_v((int)rowmask);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) a[q][r] = colp[(cok && ((rm >> r) & 1u)) ? srow[r] : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const bool cok = cpos[q] >= 0;
+        const unsigned rm = (unsigned)opaque_v((int)rowmask);
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const int i = lane + 64 * r;
-            const bool ok = cpos[q] >= 0 && i < M;
-            a[q][r] = p.A[ok ? (size_t)(g + NW * q) * lda + srow[r] : (size_t)0];
-        }
-#pragma unroll
-    for (int q = 0; q < CPT; ++q)
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int i = lane + 64 * r;
-            const bool ok = cpos[q] >= 0 && i < M;
+            const bool ok = cok && ((rm >> r) & 1u);
             const double v = ok ? a[q][r] : 0.0;
             const double sqv = v * v; // max sqrt(v*v) == sqrt(max v*v): one square root per lane below
             if (sqv > local_sqmax) local_sqmax = sqv; // (NaN never enters, like the branchy form)
             a[q][r] = v;
         }
+    }
     for (int i = tid; i < M; i += XT) {
         posrow[i] = (unsigned short)i;
         rowpos[i] = (unsigned short)i;
