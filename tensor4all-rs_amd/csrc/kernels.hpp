@@ -341,6 +341,7 @@ struct ChainWalkArgs {
     size_t factors_stride;
     unsigned token_base;                // bond number k of the half-sweep completes with token token_base + k
     int timed;                          // device time stamps of every factorisation at off_ts
+    int lean_prep;                      // 1: the preparation of a bond by one wave out of the LDS (walk_prep_wave0); 0: chain_prep_body (T4A_WALK_OLD_PREP=1)
     unsigned long long* phase_ticks;    // diagnostic (T4A_WALK_DEBUG): [8] 100 MHz ticks summed over the bonds: preparation, candidate matrix, rrLU, total; [4] gather [5] dependent list (inside the preparation)
 };
 void chain_walk_launch(const ChainCommon& c, const FnDevice& fn, const ChainWalkArgs& w, int columns, hipStream_t stream);

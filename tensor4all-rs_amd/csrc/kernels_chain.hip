@@ -461,6 +461,126 @@ __device__ __forceinline__ void walk_phase_barrier()
 }
 __device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// The preparation of a bond of the persistent half-sweep by ONE wave, without a barrier (lists of at most 64 entries: a lane per
+// entry; everything it reads — result and permutations of the previous bond, the old dependent list, the prefetched independent
+// list and extras, the weights — sits in the LDS): the same gather (non_empty_or_first, tensorci2.rs:1813-1819), the same
+// Kronecker order (tensorci2.rs:1224-1246) and the same order-preserving union with the extras (:1837-1846) as chain_prep_body,
+// whose hash and prefix sum over 1 024 threads cost five barriers and ~3 - 4.5 us per bond for lists of a handful of entries.
+// Membership of an extra in the Kronecker part = its parent code is one of the gathered parents (a loop over <= 64 LDS broadcasts).
+template <bool FORWARD>
+__device__ __forceinline__ void walk_prep_wave0(const ChainCommon& c, WalkShared* ws, int b, int prev_b, unsigned prev_token, bool do_build)
+{
+    const int lane = threadIdx.x & 63;
+    const int K = c.K;
+    const size_t cap = (size_t)c.cap;
+    bool poison = false;
+    int np = 0;
+    // ---- 1. pivots of the previous bond -> tables I_{pb+1}, J_{pb}; they are the parents of this bond's dependent list ----
+    if (prev_b >= 0) {
+        const int pb = prev_b;
+        const int pm = ws->dims[pb * 4], pn = ws->dims[pb * 4 + 1];
+        const bool bad = ws->dims[pb * 4 + 2] != 0 || ws->prev_ires[1] != 0 || ws->prev_ires[3] != (int)prev_token || pm <= 0 || pn <= 0;
+        const int r = ws->prev_ires[0];
+        const int cnt = r > 0 ? r : 1;
+        if (bad || cnt > c.cap || cnt > pm || cnt > pn || cnt > WALK_MAX_LIST) {
+            poison = true;
+        } else {
+            const uint64_t* const pind_code = ws->ind_code[pb & 1];
+            const uint64_t* const pind_acc = ws->ind_acc[pb & 1];
+            uint64_t rc = 0, cc = 0, ra[T4A_FN_MAX_ACC] = {0, 0, 0, 0}, ca[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+            if (lane < cnt) {
+                const int ri = r > 0 ? ws->perm_rp[lane] : 0, ci = r > 0 ? ws->perm_cp[lane] : 0;
+                // forward: rows of the previous bond were its dependent list, columns its independent list; backward: the reverse
+                rc = FORWARD ? ws->dep_code[ri] : pind_code[ri];
+                cc = FORWARD ? pind_code[ci] : ws->dep_code[ci];
+                for (int q = 0; q < K; ++q) {
+                    ra[q] = FORWARD ? ws->dep_acc[(size_t)ri * K + q] : pind_acc[(size_t)ri * K + q];
+                    ca[q] = FORWARD ? pind_acc[(size_t)ci * K + q] : ws->dep_acc[(size_t)ci * K + q];
+                }
+            }
+            // (every read of the old dependent list is in registers now: the parents may be written)
+            if (lane < cnt) {
+                const size_t oi = (size_t)(pb + 1) * cap, oj = (size_t)pb * cap;
+                c.I.code[oi + lane] = rc;
+                c.J.code[oj + lane] = cc;
+                ws->par_code[lane] = FORWARD ? rc : cc;
+                for (int q = 0; q < K; ++q) {
+                    c.I.acc[(oi + lane) * K + q] = ra[q];
+                    c.J.acc[(oj + lane) * K + q] = ca[q];
+                    ws->par_acc[(size_t)lane * K + q] = FORWARD ? ra[q] : ca[q];
+                }
+            }
+            if (lane == 0) {
+                c.I.cnt[pb + 1] = cnt;
+                c.J.cnt[pb] = cnt;
+            }
+            np = cnt;
+        }
+    }
+    if (!do_build) return;
+    int* const dims = ws->dims + b * 4;
+    if (poison) {
+        if (lane == 0) {
+            dims[0] = dims[1] = dims[3] = 0;
+            dims[2] = 1;
+        }
+        return;
+    }
+    // ---- 2. the dependent side of bond b: kron(parents, d) then the extras whose parent is not among the parents ----
+    const int site = FORWARD ? b : b + 1;
+    const int d = c.ldim[site], woff = c.woff[site];
+    const ChainTab& PT = FORWARD ? c.I : c.J; // (first bond of the walk: the parents are the table as the previous kernels left it)
+    if (prev_b < 0) {
+        np = PT.cnt[site];
+        if (np >= 1 && np <= WALK_MAX_LIST && lane < np) {
+            ws->par_code[lane] = PT.code[(size_t)site * cap + lane];
+            for (int q = 0; q < K; ++q) ws->par_acc[(size_t)lane * K + q] = PT.acc[((size_t)site * cap + lane) * K + q];
+        }
+    }
+    const int ne = c.use_extras ? ws->ext_cnt[b & 1] : 0;
+    const int m0 = np * d;
+    int nd = -1;
+    if (np >= 1 && np <= c.cap && np <= WALK_MAX_LIST && ne >= 0 && ne <= c.cap && ne <= WALK_MAX_LIST && m0 <= WALK_MAX_LIST) {
+        uint64_t oc = 0, oa[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+        if (lane < m0) { // rows: (parent outer, digit inner), columns: (digit outer, parent inner)
+            const int i = FORWARD ? lane / d : lane % np, sdig = FORWARD ? lane % d : lane / np;
+            oc = (uint64_t)sdig + (uint64_t)d * ws->par_code[i];
+            for (int q = 0; q < K; ++q) oa[q] = ws->par_acc[(size_t)i * K + q] + c.w[(size_t)q * c.total + woff + sdig];
+        }
+        bool keep = false;
+        uint64_t xc = 0;
+        if (lane < ne) {
+            xc = ws->ext_code[b & 1][lane];
+            const uint64_t parent = xc / (uint64_t)d;
+            keep = true;
+            for (int pi = 0; pi < np; ++pi) keep = keep && (ws->par_code[pi] != parent);
+        }
+        const unsigned long long km = __ballot(keep);
+        const int nkeep = __builtin_popcountll(km);
+        if (m0 + nkeep <= WALK_MAX_LIST) {
+            // (the Kronecker part read the parents, not the dependent list: it may be overwritten now)
+            if (lane < m0) {
+                ws->dep_code[lane] = oc;
+                for (int q = 0; q < K; ++q) ws->dep_acc[(size_t)lane * K + q] = oa[q];
+            }
+            if (keep) {
+                const int pos = m0 + __builtin_popcountll(km & ((1ull << lane) - 1ull));
+                ws->dep_code[pos] = xc;
+                for (int q = 0; q < K; ++q) ws->dep_acc[(size_t)pos * K + q] = ws->ext_acc[b & 1][(size_t)lane * K + q];
+            }
+            nd = m0 + nkeep;
+        }
+    }
+    if (lane == 0) {
+        const int ni = ws->ind_cnt[b];
+        const bool ok = nd > 0 && ni > 0;
+        dims[0] = ok ? (FORWARD ? nd : ni) : 0;
+        dims[1] = ok ? (FORWARD ? ni : nd) : 0;
+        dims[2] = ok ? 0 : 1;
+        dims[3] = ok ? nd : 0;
+    }
+}
+
 // the static inputs of bond b (independent list, history extras) into slot b & 1 of the LDS, by threads first .. first + count - 1
 __device__ __forceinline__ void walk_prefetch(const ChainCommon& c, WalkShared* ws, int b, int first, int count)
 {
@@ -555,7 +675,11 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
             pa.prev_colperm = ws->perm_cp;
             pa.prev_token = w.token_base + (unsigned)(k - 1);
         }
-        chain_prep_body(cw, pa, w.phase_ticks, ws);
+        if (w.lean_prep) {
+            if (tid < 64) walk_prep_wave0<FORWARD>(cw, ws, b, pa.prev_b, pa.prev_token, k < nb);
+        } else {
+            chain_prep_body(cw, pa, w.phase_ticks, ws);
+        }
         walk_phase_barrier();
         phase(0);
         if (k == nb) break;

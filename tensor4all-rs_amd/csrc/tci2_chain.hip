@@ -549,6 +549,8 @@ void Tci2::chain_launch()
             w.token_base = chain_.walk_token;
             chain_.walk_token += (unsigned)nb;
             w.timed = chain_.timed ? 1 : 0;
+            static const bool old_prep = std::getenv("T4A_WALK_OLD_PREP") != nullptr;
+            w.lean_prep = old_prep ? 0 : 1;
             static const bool walk_dbg = std::getenv("T4A_WALK_DEBUG") != nullptr;
             if (walk_dbg) {
                 chain_.walk_dbg.reserve(8);
