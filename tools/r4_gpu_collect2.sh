@@ -15,7 +15,7 @@ T4A_WG_MIN=0 T4A_W1_MAXN=64 timeout 900 python tools/probe_wg.py 8 8 8 16 16 16 
 {
 echo "# BASELINE configs[1] (d = 20, cos(10x) exp(-x), tol 1e-8, chi <= 64; rank 2): four solves — phases inside the persistent"
 echo "# half-sweep kernel (T4A_WALK_DEBUG=1), host phases of optimize (T4A_OPT_PROF=1); then the same without the persistent workgroup"
-echo "# (T4A_NO_WALK=1), without the chained 1-site sweep (T4A_NO_CHAIN_1SITE=1), and without both (the state before)"
+echo "# (T4A_NO_WALK=1), without the chained 1-site sweep (T4A_NO_CHAIN_1SITE=1), and without both (the state before); T4A_WALK_OLD_PREP=1: the 1 024-thread preparation inside the walk"
 T4A_WALK_DEBUG=1 T4A_OPT_PROF=1 timeout 120 python3 tools/probe_cfg2_trace.py 2>&1 | tail -14
 echo "# T4A_NO_WALK=1"; T4A_NO_WALK=1 timeout 120 python3 tools/probe_cfg2_trace.py 2>&1 | tail -3
 echo "# T4A_NO_CHAIN_1SITE=1"; T4A_NO_CHAIN_1SITE=1 timeout 120 python3 tools/probe_cfg2_trace.py 2>&1 | tail -3
