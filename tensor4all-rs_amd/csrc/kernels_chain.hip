@@ -453,11 +453,13 @@ __global__ void __launch_bounds__(1024) chain_mirror_kernel(ChainCommon c, int n
 // workgroup are visible to its own later loads (one compute unit, one L1), but uniform loads go through the SCALAR data cache,
 // which knows nothing of them — it is invalidated behind every barrier that separates a producer from a consumer.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void walk_phase_barrier()
+__device__ __forceinline__ void walk_phase_barrier(bool scalar_cache = true)
 {
     __syncthreads();
-    __builtin_amdgcn_s_dcache_inv();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (scalar_cache) { // (not needed once everything that passes from phase to phase sits in the LDS: the one-wave preparation)
+        __builtin_amdgcn_s_dcache_inv();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 }
 __device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -680,7 +682,7 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
         } else {
             chain_prep_body(cw, pa, w.phase_ticks, ws);
         }
-        walk_phase_barrier();
+        walk_phase_barrier(!w.lean_prep);
         phase(0);
         if (k == nb) break;
         // ---- the candidate matrix: pi[j * nd + i] = f(dependent i, independent j) ----
@@ -697,7 +699,7 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
                 pi[idx] = t4a_fn_value(fn.fid, acc, fn.params);
             }
         }
-        walk_phase_barrier();
+        walk_phase_barrier(!w.lean_prep);
         phase(1);
         // ---- the factorisation: wave 0 (rows = the dependent side in both directions); the other waves fetch the next bond's
         // static inputs meanwhile (its slot held the previous bond's lists: the gather of this bond was their last reader) ----
@@ -759,7 +761,7 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
                 ws->prev_ires[3] = npiv >= 0 ? (int)(w.token_base + (unsigned)k) : 0;
             }
         }
-        walk_phase_barrier();
+        walk_phase_barrier(!w.lean_prep);
         phase(2);
     }
     // ---- the host's copies, in bulk (chain_mirror_body): tables into the pinned mirror, dimensions into global memory and hdims ----
