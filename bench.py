@@ -456,6 +456,9 @@ def saturated_view(v):
 def rrlu_kernel_name(code):
     """Kernel instantiation behind a profile code (include/t4a_gpu.h, t4a_gpu_tci2_profile_variants)."""
     code = int(code)
+    if code >= 300000:  # one-wave kernel (kernels_rrlu_w1.hip): register columns; no factored matrix in a 2-site chain
+        c = code - 300000
+        return "t4a::rrlu_w1_kernel<%d, %s, false>" % ((c % 1000) // 10, "true" if (c % 10) & 4 else "false")
     if code >= 200000:  # one-workgroup kernel (kernels_rrlu_wg.hip): rows per lane, columns per wave
         c = code - 200000
         return "t4a::rrlu_wg_kernel<%d, %d, %s>" % (c // 1000, (c % 1000) // 10, "true" if (c % 10) & 4 else "false")
