@@ -21,7 +21,10 @@ constexpr unsigned XNOPOS = 0xFFFFFFFFu;
 constexpr int XWAVES = T4A_XCD_WAVES; // agents (waves) per workgroup.  Measured: 4 (one wave per SIMD) runs every phase 1.5 - 2x slower — a single wave issues one f64 instruction per 8 cycles, two waves per SIMD reach the 4-cycle rate
 constexpr int XT = 64 * XWAVES;       // threads per workgroup
 constexpr int XCD_MAX_CPT = 4;       // (the key carries the column slot in two bits)
-constexpr int XCD_MAX_VALUES = XWAVES == 4 ? 80 : 40; // matrix entries per thread: beyond this the register file of a 512-thread workgroup spills
+#ifndef T4A_XCD_MAXV
+#define T4A_XCD_MAXV 64
+#endif
+constexpr int XCD_MAX_VALUES = XWAVES == 4 ? 80 : T4A_XCD_MAXV; // matrix entries per thread: beyond this the register file of a 512-thread workgroup spills
 constexpr int BUF_SC1 = 16;  // aux bits of the raw buffer loads: sc1 (L1 bypass, served by the XCD's L2)
 // The RE-loads of the polling loops sit behind a compiler barrier (xcd_poll_again): a raw buffer load is an ordinary memory read to
 // the optimiser, and a loop that only re-reads one address until a tag matches is a loop-invariant load to it — hoisted, the loop

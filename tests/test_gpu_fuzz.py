@@ -80,6 +80,24 @@ def _same_outcome(t4a, a, **opts):
 
 
 @pytest.mark.parametrize("left", [True, False])
+@pytest.mark.parametrize("shape", [(1024, 1024), (1000, 900), (1024, 700), (800, 1000), (760, 1024)])
+def test_rrlu_on_the_widest_single_xcd_plans(t4a, left, shape):
+    """Up to 64 matrix entries per lane since the end of round 4 (12 x 4, 16 x 3, 16 x 4 rows x columns per lane: 1024 x 1024 in
+    the registers of one XCD): random, tie-ridden and low-rank matrices at those shapes, rank capped so that the oracle stays
+    fast, against the oracle bitwise."""
+    m, n = shape
+    rng = np.random.default_rng(9000 + m + n)
+    kw = dict(left_orthogonal=left)
+    _same_outcome(t4a, rng.uniform(-1, 1, size=(m, n)), max_bond_dim=48, rel_tol=0.0, abs_tol=0.0, **kw)
+    _same_outcome(t4a, rng.integers(-2, 3, size=(m, n)).astype(float), max_bond_dim=24, rel_tol=0.0, abs_tol=0.0, **kw)
+    r = 20
+    _same_outcome(t4a, rng.standard_normal((m, r)) @ rng.standard_normal((r, n)), max_bond_dim=40, **kw)
+    bad = rng.uniform(-1, 1, size=(m, n))
+    bad[m // 2, n // 2] = np.inf
+    _same_outcome(t4a, bad, max_bond_dim=5, **kw)  # (handed to the first generation at the same plan)
+
+
+@pytest.mark.parametrize("left", [True, False])
 def test_rrlu_special_values_on_multi_workgroup_shapes(t4a, left):
     """Shapes that take the single-XCD kernel (more than 64 x 64 entries, up to 768 x 768) with the values that leave its
     fast paths: scores that overflow to +inf or underflow to 0 (ties between different |v|: exact sweep on the squares,
