@@ -240,6 +240,43 @@ def test_cfg5_patch_in_a_group_with_an_early_finisher_matches_oracle(t4a):
     assert np.abs(gv - ov).max() <= 1e-10 * max(1.0, np.abs(ov).max())
 
 
+@pytest.mark.parametrize("chi", [40, 96])
+def test_chained_one_site_sweep_through_the_launched_chain_matches_oracle(t4a, chi):
+    """The final 1-site sweep of crossinterpolate2 (tensorci2.rs:1781-1794, :865-1050) as a LAUNCHED chain — matrices of 2 chi x chi
+    are too wide for the persistent workgroup: chi = 40 runs the one-workgroup kernel, chi = 96 the single-XCD kernel, both keeping
+    the factored matrix of every bond; ranks above 16 take Engine::build_factors_from bond by bond, the rest the batched launch —
+    and a stand-alone backward + forward sweep1site pair: index sets, errors bitwise, site tensors to 1e-9."""
+    import bench
+    n = bench.N_SITES
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=chi, max_iter=5, nsearch=0, max_nglobal_pivot=0)
+    g = t4a.TensorCI2([2] * n)
+    o = ob.OracleTCI2([2] * n)
+    for t in (g, o):
+        t.set_function(bench.patch_spec(1, 4))
+        t.crossinterpolate2([[0] * n], opts)
+    st = g.chain_stats()
+    assert st["one_site_sweeps"] == 1 and st["one_site_fell_back"] == 0 and st["one_site_not_eligible"] == 0
+    assert st["walked_sweeps"] < st["half_sweeps"] + st["one_site_sweeps"], "the test wants the launched chain"
+    assert max(g.link_dims()) > 16
+
+    def same():
+        for p in range(n):
+            assert np.array_equal(g.i_set(p), o.i_set(p)) and np.array_equal(g.j_set(p), o.j_set(p)), p
+        assert g.link_dims() == o.link_dims()
+        assert np.array_equal(g.bond_errors(), o.bond_errors()) and np.array_equal(g.pivot_errors(), o.pivot_errors())
+        for s_ in range(n):
+            a, b = g.site_tensor(s_), o.site_tensor(s_)
+            assert a.shape == b.shape, s_
+            assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), s_
+
+    same()
+    for t in (g, o):
+        t.sweep1site(False, 1e-10, 1e-13, chi // 2, False)
+        t.sweep1site(True, 1e-10, 1e-13, chi // 2, True)
+    assert g.chain_stats()["one_site_sweeps"] == 3 and g.chain_stats()["one_site_fell_back"] == 0
+    same()
+
+
 def test_fill_site_tensors_group_equals_fill_on_every_handle(t4a):
     """t4a_gpu_tci2_fill_site_tensors_group: the fills of several handles issued first, completed afterwards — site tensors bitwise
     those of handle.fill_site_tensors(), also for handles of different length and for one with a host callback (which fills
