@@ -728,6 +728,14 @@ def aux_timings():
         t.optimize(o4(2), final_sweep1site=False)
         out["cfg4_size_full_sweep_ms"] = (time.perf_counter() - t0) * 1e3
         out["cfg4_size_max_link_dim"] = int(max(t.link_dims()))
+        # the same size through the plain sweep2site API (tensorci2.rs:746-798: no history extras): the mid-chain matrices are
+        # exactly 1024 x 1024, which one XCD holds (the iterations of optimize above merge the extras: ~1450 x 1450, chip-wide kernel)
+        t.sweep2site(True, o4(1))
+        t.sweep2site(False, o4(1))
+        t0 = time.perf_counter()
+        t.sweep2site(True, o4(1))
+        t.sweep2site(False, o4(1))
+        out["cfg4_size_sweep2site_pair_ms"] = (time.perf_counter() - t0) * 1e3
     except Exception as e:  # noqa: BLE001
         out["cfg4_error"] = str(e)
     return out
