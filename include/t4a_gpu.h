@@ -59,6 +59,16 @@ t4a_gpu_status t4a_gpu_set_device(int32_t device);
 /* Library version string. */
 const char* t4a_gpu_version(void);
 
+/* The random stream of the reference's seeded searches: `rand 0.9` `StdRng::seed_from_u64(seed)` followed by
+ * `rng.random_range(0..dims[i])` for i = 0 .. n-1 (tensorci2.rs:1653-1657 + globalpivot.rs:174-180,
+ * adaptive_interpolation.rs:164,472-480, treetci/src/globalpivot.rs:118-122, aci/src/global_guard.rs:71-74).  Host-only (no device
+ * needed): this is what every seeded search of this library draws its starting points from (csrc/stdrng.hpp). */
+t4a_gpu_status t4a_gpu_stdrng_sample(uint64_t seed, const size_t* dims, size_t n, size_t* out /* n */);
+/* One 64-byte ChaCha key-stream block (key: 8 little-endian words, 64-bit block counter, 64-bit stream id, `rounds` = 8 / 12 / 20):
+ * the known-answer hook for the published vectors (RFC 8439 2.3.2; zero-key ChaCha20 / ChaCha12).  `StdRng` is the 12-round stream
+ * with counter 0, stream 0. */
+t4a_gpu_status t4a_gpu_chacha_block(const uint32_t* key8, uint64_t counter, uint64_t stream, int32_t rounds, uint32_t* out16);
+
 /* =====================================================================================
  * Dense kernels (host buffers in, host buffers out; each call is synchronous)
  * ===================================================================================== */
@@ -310,7 +320,7 @@ t4a_gpu_status t4a_gpu_tt_floating_zone(t4a_gpu_tt* tt, t4a_gpu_batch_eval_fn f,
                                         double* error_out);
 /* estimate_true_error(tt, f, nsearch, initial_points, rng) (globalsearch.rs:70-118): floating_zone from every starting point,
  * results sorted by descending error, consecutive duplicates removed.  initial_points: n_sites x n_initial column-major or
- * NULL (then nsearch random points from splitmix64(seed)).  Query-then-fill: *n_out is always set; BUFFER_TOO_SMALL when
+ * NULL (then nsearch random points from StdRng::seed_from_u64(seed), csrc/stdrng.hpp).  Query-then-fill: *n_out is always set; BUFFER_TOO_SMALL when
  * capacity < *n_out (at most nsearch resp. n_initial results). */
 t4a_gpu_status t4a_gpu_tt_estimate_true_error(t4a_gpu_tt* tt, t4a_gpu_batch_eval_fn f, void* ctx, size_t nsearch, const size_t* initial_points,
                                               size_t n_initial, uint64_t seed, size_t* pivots_out /* n_sites x capacity */,

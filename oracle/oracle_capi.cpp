@@ -91,6 +91,33 @@ extern "C" {
 
 const char* oracle_last_error() { return g_last_error.c_str(); }
 
+// ---- the reference's random stream (t4a_oracle_rng.hpp) ----
+int oracle_stdrng_sample(uint64_t seed, const uint64_t* dims, uint64_t n, uint64_t* out)
+{
+    return guarded([&] {
+        OracleStdRng rng(seed);
+        for (uint64_t i = 0; i < n; ++i) out[i] = (uint64_t)rng.range((size_t)dims[i]);
+    });
+}
+int oracle_stdrng_words(uint64_t seed, uint64_t n_u32, uint32_t* out32, uint64_t n_u64, uint64_t* out64)
+{
+    // n_u32 words through next_u32, then n_u64 through next_u64 (exercises the BlockRng buffer edge when n_u32 is odd)
+    return guarded([&] {
+        OracleStdRng rng(seed);
+        for (uint64_t i = 0; i < n_u32; ++i) out32[i] = rng.next_u32();
+        for (uint64_t i = 0; i < n_u64; ++i) out64[i] = rng.next_u64();
+    });
+}
+int oracle_chacha_block(const uint8_t* key32, uint64_t counter, uint64_t stream, int rounds, uint32_t* out16)
+{
+    return guarded([&] {
+        std::array<uint8_t, 32> k{};
+        for (size_t i = 0; i < 32; ++i) k[i] = key32[i];
+        const auto b = OracleStdRng::chacha_block(k, counter, stream, (unsigned)rounds / 2);
+        for (size_t i = 0; i < 16; ++i) out16[i] = b[i];
+    });
+}
+
 // ---- dense kernels ----
 int oracle_rrlu_f64(double* a_inout, uint64_t m, uint64_t n, uint64_t max_bond_dim, double rel_tol, double abs_tol,
                     int left_orthogonal, uint64_t* row_perm, uint64_t* col_perm, uint64_t* npivots, double* last_error)

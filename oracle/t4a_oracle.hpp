@@ -36,6 +36,8 @@
 #include <utility>
 #include <vector>
 
+#include "t4a_oracle_rng.hpp"
+
 namespace t4a_oracle {
 
 using MultiIndex = std::vector<size_t>;
@@ -625,8 +627,9 @@ inline bool convergence_criterion(const std::vector<size_t>& ranks, const std::v
     return false;
 }
 
-// splitmix64 / xoshiro-free tiny RNG for the default global pivot finder.
-// The reference uses rand 0.9 StdRng (third party, not under /root/reference): stream parity unpinned.
+// splitmix64: the stand-in for the streams that are NOT `StdRng` in the reference (treetci proposers: `SmallRng` seeded through a
+// SipHash of the edge; ACI initial guess: `StandardNormal`) — "parity unpinned" there.  Every `StdRng::seed_from_u64` +
+// `random_range` site uses OracleStdRng (t4a_oracle_rng.hpp).
 struct OracleRng {
     uint64_t s;
     explicit OracleRng(uint64_t seed) : s(seed) {}
@@ -1124,7 +1127,7 @@ struct TensorCI2 { // :349-368
 // globalpivot.rs:160-219 DefaultGlobalPivotFinder::find_global_pivots
 inline std::vector<MultiIndex> find_global_pivots(const std::vector<size_t>& local_dims, const SimpleTensorTrain& tt,
                                                   const ScalarFn& f, double abs_tol, size_t nsearch,
-                                                  size_t max_nglobal_pivot, double tol_margin, OracleRng& rng)
+                                                  size_t max_nglobal_pivot, double tol_margin, OracleStdRng& rng)
 {
     const size_t n = local_dims.size();
     std::vector<MultiIndex> initial;
@@ -1179,7 +1182,7 @@ inline OptimizationResult optimize(TensorCI2& tci, const ScalarFn& f, const Batc
     const size_t n = tci.len();
     OptimizationResult res;
     std::vector<size_t> nglobal_hist;
-    OracleRng rng(options.has_seed ? options.seed : 0x1234567ull);
+    OracleStdRng rng(options.has_seed ? options.seed : 0x1234567ull); // tensorci2.rs:1653-1657 (no seed: OS entropy there)
 
     for (size_t iter = 0; iter < options.max_iter; ++iter) {
         const double norm = (options.normalize_error && tci.max_sample_value > 0.0) ? tci.max_sample_value : 1.0;

@@ -497,7 +497,7 @@ inline std::vector<MultiIndex> aci_find_global_pivots(ElementwiseProblem& proble
     const size_t n = problem.len(), K = problem.n_inputs(), nsearch = o.nsearch_global_pivots;
     if (nsearch == 0 || o.max_nglobal_pivot == 0 || n < 2) return {};
     const std::vector<size_t> site_dims = aci_site_dims(problem.solution);
-    OracleRng rng(seed);
+    OracleStdRng rng(seed); // global_guard.rs:71
     std::vector<MultiIndex> starts(nsearch, MultiIndex(n));
     for (auto& s : starts)
         for (size_t q = 0; q < n; ++q) s[q] = rng.range(site_dims[q]);

@@ -65,7 +65,7 @@ inline bool is_compatible(const MultiIndex& pivot, size_t n, const Projector& pr
 
 inline std::vector<MultiIndex> patch_candidates(const std::vector<size_t>& dims, const std::vector<size_t>& active,
                                                 const Projector& pr, const std::vector<MultiIndex>& initial,
-                                                const std::vector<MultiIndex>& recycled, size_t target, OracleRng& rng)
+                                                const std::vector<MultiIndex>& recycled, size_t target, OracleStdRng& rng)
 {
     std::vector<MultiIndex> cand;
     std::set<MultiIndex> seen;
@@ -214,7 +214,7 @@ inline std::vector<SubDomainTT> adaptiveinterpolate(const ScalarFn& f, const Bat
     using namespace patch_detail;
     const std::vector<size_t> patch_order = validate_adaptive_inputs(dims, initial_pivots, options);
     const size_t n = dims.size();
-    OracleRng rng(options.tci_options.has_seed ? options.tci_options.seed : 0);
+    OracleStdRng rng(options.tci_options.has_seed ? options.tci_options.seed : 0); // adaptive_interpolation.rs:164
     struct Pending {
         Projector projector;
         std::vector<MultiIndex> recycled;

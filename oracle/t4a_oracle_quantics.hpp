@@ -220,7 +220,7 @@ inline QuanticsTensorCI2 run(const QuanticsGrid& grid, const std::function<doubl
     } else {
         pivots.push_back(MultiIndex(n_sites, 0));
     }
-    OracleRng rng(options.has_seed ? options.seed : 0x13198A2E03707344ull);
+    OracleStdRng rng(options.has_seed ? options.seed : 0x13198A2E03707344ull);
     for (size_t k = 0; k < options.n_random_init_pivot; ++k) {
         MultiIndex p(n_sites);
         for (size_t s = 0; s < n_sites; ++s) p[s] = rng.range(local_dims[s]);

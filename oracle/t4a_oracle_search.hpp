@@ -31,7 +31,7 @@ inline std::pair<MultiIndex, double> floating_zone(const SimpleTensorTrain& tt, 
             if ((*init)[s] >= local_dims[s]) throw OracleError(ERR_INVALID_ARGUMENT, "initial pivot does not fit local_dims");
         init_p = *init;
     } else {
-        OracleRng rng(seed);
+        OracleStdRng rng(seed);
         for (size_t d : local_dims) init_p.push_back(rng.range(d));
     }
     const size_t max_sweeps = local_dims.size() * 10; // :207-214
@@ -59,7 +59,7 @@ inline std::vector<std::pair<MultiIndex, double>> estimate_true_error(const Simp
     if (initial_points) {
         points = *initial_points;
     } else {
-        OracleRng rng(seed);
+        OracleStdRng rng(seed);
         for (size_t k = 0; k < nsearch; ++k) {
             MultiIndex p;
             for (size_t d : site_dims) p.push_back(rng.range(d));

@@ -782,7 +782,7 @@ inline std::vector<MultiIndex> tree_find_global_pivots(const TreeTCI2& st, const
     if (nsearch == 0 || max_nglobal_pivot == 0) return {};
     const size_t n = st.local_dims.size();
     TreeNetwork net = tree_materialize(st, evaluate, 0);
-    OracleRng rng(seed);
+    OracleStdRng rng(seed); // globalpivot.rs:118
     std::vector<MultiIndex> points;
     for (size_t k = 0; k < nsearch; ++k) {
         MultiIndex start(n);

@@ -20,7 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-source flags.  kernels_dense.hip: keep MFMA accumulators in VGPRs — in AGPR form the compiler moves all of them between the
 # two register files at every k-step of the GEMM loop (32 v_accvgpr reads + writes behind a pipeline drain)
 FILE_FLAGS = {"kernels_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
-HEADERS = ["common.hpp", "kernels.hpp", "kernels_rrlu_xcd_common.hpp", "kernels_rrlu_w1_body.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "globalsearch.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
+HEADERS = ["common.hpp", "stdrng.hpp", "kernels.hpp", "kernels_rrlu_xcd_common.hpp", "kernels_rrlu_w1_body.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "globalsearch.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
            "../../include/t4a_testfunctions.h"]
 
 

@@ -1,5 +1,6 @@
 // aci.hip — see aci.hpp.  Reference: crates/tensor4all-aci/src/{elementwise,state,local,global_guard,random_tt,validation}.rs.
 #include "aci.hpp"
+#include "stdrng.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -598,10 +599,10 @@ std::vector<std::vector<uint32_t>> AciProblem::find_global_pivots(uint64_t seed)
     if (nsearch == 0 || opt_.max_nglobal_pivot == 0 || n < 2) return {};
     std::vector<size_t> site_dims(n);
     for (size_t s = 0; s < n; ++s) site_dims[s] = sol_[s].s;
-    uint64_t rng = seed; // StdRng in the reference ("parity unpinned")
+    StdRng rng(seed); // global_guard.rs:71 (stdrng.hpp)
     std::vector<std::vector<uint32_t>> starts(nsearch, std::vector<uint32_t>(n));
     for (auto& sp : starts)
-        for (size_t q = 0; q < n; ++q) sp[q] = (uint32_t)(splitmix_next(rng) % (uint64_t)site_dims[q]);
+        for (size_t q = 0; q < n; ++q) sp[q] = (uint32_t)rng.random_range(site_dims[q]);
     auto flat = [&](const std::vector<std::vector<uint32_t>>& pts) {
         std::vector<uint32_t> f(pts.size() * n);
         for (size_t p = 0; p < pts.size(); ++p) std::copy(pts[p].begin(), pts[p].end(), f.begin() + p * n);

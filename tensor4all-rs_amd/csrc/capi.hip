@@ -1,6 +1,7 @@
 // capi.hip — extern "C" surface declared in include/t4a_gpu.h.
 // No exception crosses the boundary (tensor4all-capi/src/lib.rs:139-162 convention): every entry point
 // runs inside `guarded`, which stores the message in a thread-local slot and returns a status code.
+#include "stdrng.hpp"
 #include <memory>
 #include <initializer_list>
 #include <mutex>
@@ -167,6 +168,29 @@ t4a_gpu_status t4a_gpu_last_error_message(char* buf, size_t buf_len, size_t* req
     if (buf_len < need) return T4A_GPU_BUFFER_TOO_SMALL;
     std::memcpy(buf, msg.c_str(), need);
     return T4A_GPU_SUCCESS;
+}
+
+t4a_gpu_status t4a_gpu_stdrng_sample(uint64_t seed, const size_t* dims, size_t n, size_t* out)
+{
+    return guarded([&] {
+        if (n == 0) return;
+        T4A_REQUIRE_PTR(dims);
+        T4A_REQUIRE_PTR(out);
+        for (size_t i = 0; i < n; ++i)
+            if (dims[i] == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "random_range(0..0): empty range");
+        StdRng rng(seed);
+        for (size_t i = 0; i < n; ++i) out[i] = rng.random_range(dims[i]);
+    });
+}
+
+t4a_gpu_status t4a_gpu_chacha_block(const uint32_t* key8, uint64_t counter, uint64_t stream, int32_t rounds, uint32_t* out16)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(key8);
+        T4A_REQUIRE_PTR(out16);
+        if (rounds <= 0 || (rounds & 1)) throw Error(T4A_GPU_INVALID_ARGUMENT, "ChaCha rounds must be a positive even number");
+        StdRng::block(key8, counter, (uint32_t)stream, (uint32_t)(stream >> 32), rounds, out16);
+    });
 }
 
 t4a_gpu_status t4a_gpu_device_count(int32_t* out_count)

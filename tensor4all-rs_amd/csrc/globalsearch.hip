@@ -5,9 +5,10 @@
 // The walks are host logic exactly as in the reference; what runs on the GPU is the batched tensor-train evaluation of every
 // site scan (TensorTrain::evaluate_many = TTCache::evaluate_many, bit-identical to the CPU restatement).  The exact function is
 // the caller's batch callback (t4a_gpu_batch_eval_fn): the reference calls f point by point, the values are the same.
-// Random starting points: the reference draws from rand 0.9 (`rng.random_range`, or the thread rng when init_p is None) —
-// "parity unpinned"; here a splitmix64 stream seeded by the caller.
+// Random starting points: the reference draws `rng.random_range(0..d)` from the caller's rng (globalsearch.rs:93-99; the thread rng
+// when init_p is None, :202); here rand 0.9 `StdRng::seed_from_u64(seed)` as restated in stdrng.hpp.
 #include "globalsearch.hpp"
+#include "stdrng.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -15,14 +16,6 @@
 namespace t4a {
 
 namespace {
-uint64_t gs_splitmix(uint64_t& s)
-{
-    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 void check_dims(const TensorTrain& tt, const std::vector<size_t>& local_dims)
 {
     if (local_dims.size() != tt.len())
@@ -46,8 +39,8 @@ std::pair<std::vector<uint32_t>, double> floating_zone(TensorTrain& tt, const Se
             if ((*init_p)[s] >= local_dims[s]) throw Error(T4A_GPU_INVALID_ARGUMENT, "initial pivot does not fit local_dims");
         pivot = *init_p;
     } else {
-        uint64_t st = seed;
-        for (size_t s = 0; s < n; ++s) pivot[s] = (uint32_t)(gs_splitmix(st) % (uint64_t)local_dims[s]);
+        StdRng st(seed);
+        for (size_t s = 0; s < n; ++s) pivot[s] = (uint32_t)st.random_range(local_dims[s]);
     }
     if (n > std::numeric_limits<size_t>::max() / 10) throw Error(T4A_GPU_INVALID_ARGUMENT, "local_dims sweep count overflowed usize");
     const size_t max_sweeps = n * 10;
@@ -106,10 +99,10 @@ std::vector<std::pair<std::vector<uint32_t>, double>> estimate_true_error(Tensor
     if (initial_points) {
         points = *initial_points;
     } else {
-        uint64_t st = seed;
+        StdRng st(seed);
         for (size_t k = 0; k < nsearch; ++k) {
             std::vector<uint32_t> p(site_dims.size());
-            for (size_t s = 0; s < site_dims.size(); ++s) p[s] = (uint32_t)(gs_splitmix(st) % (uint64_t)site_dims[s]);
+            for (size_t s = 0; s < site_dims.size(); ++s) p[s] = (uint32_t)st.random_range(site_dims[s]);
             points.push_back(std::move(p));
         }
     }

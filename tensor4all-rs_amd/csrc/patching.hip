@@ -1,5 +1,6 @@
 // patching.hip — see patching.hpp.  Host queue logic + one device TCI2 per patch.
 #include "patching.hpp"
+#include "stdrng.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -24,17 +25,7 @@ __global__ void __launch_bounds__(256) copy_selector_kernel(double* out, int B, 
     }
 }
 
-struct Rng { // same splitmix64 stream as the global pivot finder; the reference uses rand 0.9 StdRng ("parity unpinned")
-    uint64_t s;
-    uint64_t next()
-    {
-        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    }
-    size_t range(size_t n) { return (size_t)(next() % (uint64_t)n); }
-};
+using Rng = StdRng; // adaptive_interpolation.rs:164: ONE StdRng::seed_from_u64 stream consumed in FIFO patch order (stdrng.hpp)
 
 using Pivot = std::vector<uint32_t>;
 using Projector = std::map<size_t, size_t>;
@@ -124,7 +115,7 @@ std::vector<Pivot> patch_candidates(const std::vector<size_t>& dims, const std::
     const size_t attempts = desired * 20 + 100;
     for (size_t a = 0; a < attempts && cand.size() < desired; ++a) {
         Pivot pv;
-        for (size_t d : ld) pv.push_back((uint32_t)rng.range(d));
+        for (size_t d : ld) pv.push_back((uint32_t)rng.random_range(d));
         if (seen.insert(pv).second) cand.push_back(pv);
     }
     for (size_t flat = 0; flat < point_count && cand.size() < desired; ++flat) {
@@ -313,7 +304,7 @@ std::unique_ptr<PartitionedTT> adaptive_interpolate(const std::vector<size_t>& d
         throw Error(T4A_GPU_INVALID_ARGUMENT, "built-in function weight table has the wrong size");
     std::unique_ptr<PartitionedTT> result(new PartitionedTT(dims));
     hipStream_t st = result->eng.stream();
-    Rng rng{options.tci.has_seed ? options.tci.seed : 0};
+    Rng rng(options.tci.has_seed ? options.tci.seed : 0);
 
     struct Pending {
         Projector projector;

@@ -1,5 +1,6 @@
 // quantics.hip — quantics front end on the TreeTCI driver (see quantics.hpp).
 #include "quantics.hpp"
+#include "stdrng.hpp"
 
 #include <algorithm>
 #include <array>
@@ -232,16 +233,10 @@ void QuanticsTci::run(const std::vector<std::vector<size_t>>* initial_pivots, co
     } else {
         pivots.push_back(std::vector<uint32_t>(n_sites, 0));
     }
-    uint64_t rng = options.has_seed ? options.seed : 0x13198A2E03707344ull;
-    auto next = [&rng]() {
-        uint64_t z = (rng += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    };
+    StdRng rng(options.has_seed ? options.seed : 0x13198A2E03707344ull); // (quantics_tci.rs:464: the thread rng there; any stream will do)
     for (size_t k = 0; k < options.n_random_init_pivot; ++k) {
         std::vector<uint32_t> p(n_sites);
-        for (size_t s = 0; s < n_sites; ++s) p[s] = (uint32_t)(next() % (uint64_t)local_dims[s]);
+        for (size_t s = 0; s < n_sites; ++s) p[s] = (uint32_t)rng.random_range(local_dims[s]);
         pivots.push_back(p);
     }
     if (pivots.empty()) pivots.push_back(std::vector<uint32_t>(n_sites, 0));

@@ -1575,15 +1575,15 @@ double Tci2::sum() // simplett/src/traits.rs:231-275 (host-side: O(n chi^2 d), n
 // =================================================================================================
 // DefaultGlobalPivotFinder::find_global_pivots (tensorci/src/globalpivot.rs:160-219).  All candidate points
 // of all searches are independent (the reference resets the coordinate after each 1-D scan), so f and the
-// TT are evaluated in two batches.  RNG: the reference uses rand 0.9 StdRng (third party) — stream parity
-// is unpinned; splitmix64 here.
-std::vector<std::vector<uint32_t>> Tci2::find_global_pivots(double abs_tol, const TCI2Options& o, uint64_t& rng_state)
+// TT are evaluated in two batches.  RNG: rand 0.9 StdRng + random_range(0..d), restated in stdrng.hpp (initial points are drawn
+// search by search, site by site, exactly as globalpivot.rs:174-180 does).
+std::vector<std::vector<uint32_t>> Tci2::find_global_pivots(double abs_tol, const TCI2Options& o, StdRng& rng)
 {
     std::vector<std::vector<uint32_t>> found;
     if (o.nsearch == 0) return found;
     std::vector<std::vector<uint32_t>> initial(o.nsearch, std::vector<uint32_t>(n_));
     for (auto& p : initial)
-        for (size_t s = 0; s < n_; ++s) p[s] = (uint32_t)(splitmix64(rng_state) % (uint64_t)local_dims[s]);
+        for (size_t s = 0; s < n_; ++s) p[s] = (uint32_t)rng.random_range(local_dims[s]);
     std::vector<uint32_t> idx;
     for (const auto& point : initial)
         for (size_t p = 0; p < n_; ++p)
@@ -1665,7 +1665,7 @@ void Tci2::opt_begin(OptRun& r)
     errors_hist.clear();
     r.nglobal_hist.clear();
     termination = T4A_GPU_TCI2_MAX_ITERATIONS;
-    r.rng_state = options.has_seed ? options.seed : 0x1234567ull;
+    r.rng.reseed(options.has_seed ? options.seed : 0x1234567ull); // (no seed: OS entropy in the reference — any stream will do)
     // bounded rank, built-in functor: site tensors and fill workspaces get their final size now (a buffer that grows goes
     // through the process-wide cache, which waits for the whole device: once per iteration and buffer while ranks grow)
     if (fn_kind_ == FnKind::Builtin && options.max_bond_dim != 0 && options.max_bond_dim <= 1024) {
@@ -1872,7 +1872,7 @@ void Tci2::opt_iter_finish(OptRun& r)
         const double error = max_bond_error();
         errors_hist.push_back(error / norm);
 
-        std::vector<std::vector<uint32_t>> gp = find_global_pivots(abs_tol, options, r.rng_state);
+        std::vector<std::vector<uint32_t>> gp = find_global_pivots(abs_tol, options, r.rng);
         // invalidates the site tensors even for an empty list (tensorci2.rs:707-708) unless the caller opted out
         if (!(gp.empty() && keep_site_tensors)) add_global_pivots(gp);
         r.nglobal_hist.push_back(gp.size());

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "stdrng.hpp"
 #include "rook.hpp"
 #include "tt.hpp"
 
@@ -86,7 +87,7 @@ public:
         TCI2Options options;
         bool final_sweep1site = false;
         std::vector<size_t> nglobal_hist;
-        uint64_t rng_state = 0;
+        StdRng rng;   // rand 0.9 StdRng::seed_from_u64 (tensorci2.rs:1653-1657); one stream for the whole optimisation
         bool pending_fill = false; // fill_site_tensors of the last iteration: accumulators / stream operations not yet issued
         size_t iter = 0;
         bool done = false;
@@ -251,7 +252,7 @@ private:
     void set_core_from_right(size_t site, size_t site_dim, size_t right_dim, const LuciResult& lu);
     void set_core_zero(size_t site, size_t l, size_t s, size_t r);
     void update_pivot_errors(const std::vector<double>& e);
-    std::vector<std::vector<uint32_t>> find_global_pivots(double abs_tol, const TCI2Options& o, uint64_t& rng_state);
+    std::vector<std::vector<uint32_t>> find_global_pivots(double abs_tol, const TCI2Options& o, StdRng& rng);
 
     // ---- device-side bond chain (tci2_chain.hip, kernels_chain.hip) ----
     struct ChainState {

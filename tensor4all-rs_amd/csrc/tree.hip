@@ -1,5 +1,6 @@
 // tree.hip — TreeTCI driver on the gfx950 engine (see tree.hpp).  Reference: crates/tensor4all-treetci/src.
 #include "tree.hpp"
+#include "stdrng.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -660,11 +661,11 @@ std::vector<std::vector<uint32_t>> TreeTci::find_global_pivots(size_t nsearch, s
     if (nsearch == 0 || max_nglobal_pivot == 0) return pivots;
     const size_t n = local_dims.size();
     materialize(0);
-    uint64_t rng = seed;
+    StdRng rng(seed); // globalpivot.rs:118 (stdrng.hpp)
     std::vector<uint32_t> idx;
     for (size_t k = 0; k < nsearch; ++k) {
         std::vector<uint32_t> start(n);
-        for (size_t s = 0; s < n; ++s) start[s] = (uint32_t)(splitmix64(rng) % (uint64_t)local_dims[s]);
+        for (size_t s = 0; s < n; ++s) start[s] = (uint32_t)rng.random_range(local_dims[s]);
         for (size_t s = 0; s < n; ++s)
             for (size_t v = 0; v < local_dims[s]; ++v) {
                 const size_t base = idx.size();

@@ -78,6 +78,25 @@ def version():
     return _lib.t4a_gpu_version().decode()
 
 
+def stdrng_sample(seed, dims):
+    """`StdRng::seed_from_u64(seed)` then `random_range(0..d)` for every d of `dims` (the stream of the reference's seeded searches)."""
+    dims = np.ascontiguousarray(dims, dtype=np.uintp)
+    out = np.zeros(dims.size, dtype=np.uintp)
+    _check(_lib.t4a_gpu_stdrng_sample(ctypes.c_uint64(seed), dims.ctypes.data_as(ctypes.POINTER(c_size_t)), c_size_t(dims.size),
+                                      out.ctypes.data_as(ctypes.POINTER(c_size_t))))
+    return out.astype(np.int64)
+
+
+def chacha_block(key_words, counter, stream, rounds):
+    """One ChaCha block (16 little-endian words) — known-answer hook for the published vectors."""
+    key = np.ascontiguousarray(key_words, dtype=np.uint32)
+    assert key.size == 8
+    out = np.zeros(16, dtype=np.uint32)
+    _check(_lib.t4a_gpu_chacha_block(key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.c_uint64(counter), ctypes.c_uint64(stream),
+                                     c_int32(rounds), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+    return out
+
+
 def _f(a):
     """column-major float64 copy"""
     return np.asfortranarray(np.array(a, dtype=np.float64, copy=True))

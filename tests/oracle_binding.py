@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("T4A_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liborac
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "oracle_capi_tt.cpp", "t4a_oracle.hpp", "t4a_oracle_rook.hpp", "t4a_oracle_patch.hpp",
                                                   "t4a_oracle_tt.hpp", "t4a_oracle_tree.hpp", "t4a_oracle_quantics.hpp", "t4a_oracle_tensor.hpp", "t4a_oracle_aci.hpp",
-                                                  "t4a_oracle_search.hpp")] + [
+                                                  "t4a_oracle_search.hpp", "t4a_oracle_rng.hpp")] + [
         os.path.join(ROOT, "include", "t4a_testfunctions.h")]
     need = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -59,6 +59,28 @@ def _f(a):
 
 def _p(a):
     return a.ctypes.data_as(vp)
+
+
+def stdrng_sample(seed, dims):
+    dims = np.ascontiguousarray(dims, dtype=np.uint64)
+    out = np.zeros(dims.size, dtype=np.uint64)
+    _check(_lib.oracle_stdrng_sample(u64(seed), _p(dims), u64(dims.size), _p(out)))
+    return out.astype(np.int64)
+
+
+def stdrng_words(seed, n_u32, n_u64):
+    a = np.zeros(max(n_u32, 1), dtype=np.uint32)
+    b = np.zeros(max(n_u64, 1), dtype=np.uint64)
+    _check(_lib.oracle_stdrng_words(u64(seed), u64(n_u32), _p(a), u64(n_u64), _p(b)))
+    return a[:n_u32], b[:n_u64]
+
+
+def chacha_block(key_bytes, counter, stream, rounds):
+    key = np.ascontiguousarray(key_bytes, dtype=np.uint8)
+    assert key.size == 32
+    out = np.zeros(16, dtype=np.uint32)
+    _check(_lib.oracle_chacha_block(_p(key), u64(counter), u64(stream), cint(rounds), _p(out)))
+    return out
 
 
 def rrlu(a, max_bond_dim=None, rel_tol=1e-14, abs_tol=0.0, left_orthogonal=True):
