@@ -96,6 +96,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the cfg2 / cfg4 / cfg5 single-GPU timings of the aux block")
+    ap.add_argument("--no-components", action="store_true",
+                    help="skip aux.components (tools/bench_components.py: callback path, rook, tree, quantics, ACI, tensor-train utilities, "
+                         "dense kernels, each with the CPU oracle's time beside it; about a minute)")
+    ap.add_argument("--no-floor", action="store_true",
+                    help="do not start tools/xcd_bench (a second GPU process) for the exchange floor: use the committed constant — for "
+                         "runs under rocprofv3, whose preload and counters a child process would inherit")
     ap.add_argument("--mode", choices=["headline", "site-shard"], default="headline",
                     help="headline: BASELINE.json configs[2] (N = 1) / patch farm (N > 1).  site-shard: configs[3] — d = 40, chi = 512, "
                          "bond chain replicated on every rank, fill_site_tensors sharded by site, one device-resident core "
@@ -123,6 +129,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the TCI2 backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
     t4a_amd.set_device(local_rank)
+    # torch's work of this process (collectives, the copies around them) runs on a non-blocking side stream, never on stream 0: the
+    # library exchanges cores with torch through events, and the legacy default stream's implicit ordering broke the replay of
+    # the captured fill graph (profiles/r05_fill_graph_fault_bisect.txt)
+    from t4a_amd import parallel as _par
+    _par.leave_legacy_stream(torch)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -218,9 +229,31 @@ def main():
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     fl_t = torch.tensor([prof["flops"]], dtype=torch.float64, device="cuda")
+    per_rank_ms = [dt / args.steps * 1e3]
+    gather_view = None
     if world > 1:
+        # what the 8-GPU run needs to be read against (round-4 review, item 10): every rank's own time per step, and what the
+        # patch-core all-gather costs where it is NOT hidden — the same K sweeps once more without it, outside the timed region
+        all_dt = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(all_dt, dt_t)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in all_dt]
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(fl_t, op=dist.ReduceOp.SUM)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tci.optimize(opts(2), final_sweep1site=False)
+        barrier()
+        nog = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nog, op=dist.ReduceOp.MAX)
+        gather_view = {
+            "collective": "all_gather_into_tensor (RCCL), one per full sweep, device resident, issued behind the sweep's last fill_site_tensors",
+            "bytes_per_rank_per_sweep": int(N_SITES * core_cap * 8),
+            "bytes_gathered_per_sweep": int(world * N_SITES * core_cap * 8),
+            "ms_per_step_without_gather": float(nog.item()) / args.steps * 1e3,
+            "exposed_ms_per_step": float(dt_t.item()) / args.steps * 1e3 - float(nog.item()) / args.steps * 1e3,
+            "note": "exposed = timed region (with the gather) minus the same sweeps without it, max over ranks each; negative values are run-to-run noise",
+        }
     dt_max = float(dt_t.item())
     flops_all = float(fl_t.item())
 
@@ -236,7 +269,7 @@ def main():
         dom = max(variants, key=lambda v: v["ms"]) if variants else None
         dom_steps = dom["steps"] / max(dom["launches"], 1) if dom else float(shapes[N_SITES // 2][2])
         achieved = bytes_per_launch / (rrlu_ms_avg * 1e-3) / 1e9 if rrlu_ms_avg > 0 else 0.0
-        floor_us, floor_src = exchange_floor()
+        floor_us, floor_src = exchange_floor(skip=args.no_floor)
         out = {
             "metric": "TCI2 full-sweep GF/s (d=30, chi=256 fp64)",
             "value": flops_all / dt_max / 1e9,
@@ -246,6 +279,8 @@ def main():
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / steps * 1e3,
+            "per_rank_ms_per_step": per_rank_ms,
+            "patch_core_gather": gather_view,
             "full_sweep_sec": dt_max / steps,
             "higher_is_better": True,
             "scaling": "weak",
@@ -334,22 +369,36 @@ def main():
             out["cpu_baseline"] = cpu_baseline(tci, spec)
         if world == 1 and not args.no_aux:
             out["aux"] = aux_timings()
+            if not args.no_components:
+                try:
+                    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                    import bench_components
+                    out["aux"]["components"] = bench_components.components()
+                except Exception as e:  # noqa: BLE001 - auxiliary numbers must never break the bench line
+                    out["aux"]["components_error"] = repr(e)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+XCD_EXCHANGE_FLOOR_US_R4 = 1.12  # what `tools/xcd_bench floor` measured on the round-4 boxes (key gather + column + two barriers)
 XCD_EXCHANGE_FLOOR_US = 1715 / 2380.0  # tools/xcd_bench.hip on MI355X, round 2 (profiles/r02_xcd_bench.log): the fallback of exchange_floor()
 
 
-def exchange_floor():
+def exchange_floor(skip=False):
     """(us, source) of the single-XCD exchange floor: one pivot step's key all-gather + 700-row column hand-off + two barriers
     between 32 workgroups of one XCD with no arithmetic around it.  Re-measured on THIS box by `tools/xcd_bench floor` (built
     by __graft_entry__.build()); the round-2 constant when the binary is missing or fails."""
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "xcd_bench")
+    # a fresh child process (never an exec); a profiler's preload and its variables stay with this process (ADVICE round 4)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTX", "HSA_TOOLS"))}
+    under_profiler = len(env) != len(os.environ)
+    if skip or under_profiler:
+        return XCD_EXCHANGE_FLOOR_US_R4, ("constant: tools/xcd_bench floor as measured by the round-4 bench runs (1.12 us; profiles/r04_bench_n1.json)"
+                                          + (" - not re-measured: this run is profiled" if under_profiler else " - not re-measured: --no-floor"))
     try:
-        out = subprocess.run([exe, "floor"], capture_output=True, text=True, timeout=60).stdout
+        out = subprocess.run([exe, "floor"], capture_output=True, text=True, timeout=60, env=env).stdout
         for line in out.splitlines():
             if line.startswith("floor_ns_per_round="):
                 ns = float(line.split("=", 1)[1])
@@ -384,9 +433,12 @@ def site_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier):
     cap = chi4 * 2 * chi4
     xchg = parallel.ShardedCoreExchange(dist if world > 1 else None, torch, d4, cap, parallel.DeviceShardAdapter(tci, torch, cap), "cuda")
 
+    no_exchange = bool(os.environ.get("T4A_SS_NO_EXCHANGE"))  # (diagnosis of ADVICE round 4: the same calls without the core exchange)
+
     def half_sweep():
         tci.optimize(opts(1), final_sweep1site=False)  # one half-sweep: all bond updates + the local part of the fill
-        xchg.exchange()
+        if not no_exchange:
+            xchg.exchange()
 
     tci.optimize(opts(11), final_sweep1site=False)      # untimed: grow to saturation
     if max(tci.link_dims()) != chi4:
@@ -456,12 +508,15 @@ def saturated_view(v):
 def rrlu_kernel_name(code):
     """Kernel instantiation behind a profile code (include/t4a_gpu.h, t4a_gpu_tci2_profile_variants)."""
     code = int(code)
+    if code >= 400000:  # kernels for matrices beyond one XCD (kernels_rrlu_xcd2m.hip): 400000 + K * 10000 + RPT * 100 + CPT * 10
+        c = code - 400000
+        return "t4a::(anonymous namespace)::rrlu_xcd2m_kernel<%d, %d, %s, %d>" % ((c % 10000) // 100, (c % 100) // 10, "true" if (c % 10) & 4 else "false", c // 10000)
     if code >= 300000:  # one-wave kernel (kernels_rrlu_w1.hip): register columns; no factored matrix in a 2-site chain
         c = code - 300000
-        return "t4a::rrlu_w1_kernel<%d, %s, false>" % ((c % 1000) // 10, "true" if (c % 10) & 4 else "false")
+        return "t4a::(anonymous namespace)::rrlu_w1_kernel<%d, %s, false>" % ((c % 1000) // 10, "true" if (c % 10) & 4 else "false")
     if code >= 200000:  # one-workgroup kernel (kernels_rrlu_wg.hip): rows per lane, columns per wave
         c = code - 200000
-        return "t4a::rrlu_wg_kernel<%d, %d, %s>" % (c // 1000, (c % 1000) // 10, "true" if (c % 10) & 4 else "false")
+        return "t4a::(anonymous namespace)::rrlu_wg_kernel<%d, %d, %s>" % (c // 1000, (c % 1000) // 10, "true" if (c % 10) & 4 else "false")
     if code >= 100000:  # single-XCD kernel: second generation unless T4A_XCD_V=1
         c = code - 100000
         gen = "rrlu_xcd_kernel" if os.environ.get("T4A_XCD_V") == "1" else "rrlu_xcd2_kernel"

@@ -256,6 +256,24 @@ t4a_gpu_status t4a_gpu_tci2_sum(t4a_gpu_tci2* h, double* out);
  * expected to arrive through t4a_gpu_tci2_set_site_tensor_device. */
 t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t world);
 
+/* Column-block shard of the candidate matrix for HOST-CALLBACK functions (entries of one candidate matrix are
+ * independent, tensorci2.rs:1859-1893).  After set_pi_shard(rank, world, gather, ctx) every matrix this handle evaluates through its
+ * batch callback (update_pivots, sweep1site, fill_site_tensors) is split into `world` blocks of ceil(N / world) columns: this rank's
+ * callback sees only the points of its block (row index outer, column index inner: the order of tensorci2.rs:1862-1869 restricted to
+ * the block), `gather` — an all-gather over the process group on HOST buffers: `count` doubles in from every rank, world * count out,
+ * rank-major; 0 = success — assembles the whole matrix on every rank, and the rank-revealing LU runs replicated (deterministic: the same
+ * pivots everywhere, nothing is broadcast).  Every rank must drive its handle through the same calls.  world == 1 switches it off. */
+typedef int32_t (*t4a_gpu_allgather_fn)(void* ctx, const double* send, size_t count, double* recv);
+t4a_gpu_status t4a_gpu_tci2_set_pi_shard(t4a_gpu_tci2* h, size_t rank, size_t world, t4a_gpu_allgather_fn gather, void* ctx);
+/* [n_gathers, bytes_sent_by_this_rank] since the shard was set. */
+t4a_gpu_status t4a_gpu_tci2_pi_shard_stats(t4a_gpu_tci2* h, size_t* out2);
+/* The host part of the shard alone (no device, no handle): evaluates the na x nb matrix of the row halves `a` (na x wa digits, placed at
+ * site a0) and the column halves `b` (nb x wb digits at site b0; wa + wb = n_sites) through `cb` + `gather` exactly as a sharded handle
+ * does; out: na x nb row-major.  world == 1: one plain callback over all points.  (CPU-only test hook, tests/test_cpu_parallel.py.) */
+t4a_gpu_status t4a_gpu_pi_shard_eval(size_t rank, size_t world, t4a_gpu_batch_eval_fn cb, void* cb_ctx, t4a_gpu_allgather_fn gather,
+                                     void* gather_ctx, size_t n_sites, const uint32_t* a, size_t wa, size_t a0, size_t na,
+                                     const uint32_t* b, size_t wb, size_t b0, size_t nb, double* out);
+
 /* add_global_pivots invalidates the site tensors even when the pivot list is empty (tensorci2.rs:707-708), so
  * after optimize_with_finder without a final sweep1site the cores of the last fill_site_tensors are gone.  With
  * keep != 0 an EMPTY pivot list leaves them in place (the index sets did not change, so they are still the cores
@@ -714,6 +732,10 @@ t4a_gpu_status t4a_gpu_tci2_chain_stats(const t4a_gpu_tci2* h, uint64_t* out /* 
  * index table itself, the site tensors come from the factored matrices the chain leaves behind; out[2] 1-site sweeps that were
  * not eligible and ran bond by bond; out[3] chained 1-site sweeps that fell back to the per-bond path part-way. */
 t4a_gpu_status t4a_gpu_tci2_chain_stats_ext(const t4a_gpu_tci2* h, uint64_t* out /* [4] */);
+/* out[0] asynchronous fill_site_tensors issued by the optimisation loop, out[1] of them replayed from the captured HIP graph, out[2]
+ * graph captures (a capture happens the second time a fill with the same signature — device addresses, shapes, staging buffers —
+ * is issued; handles whose cores were exported / imported through stream 0 never replay: csrc/tci2.hip issue_fill_ops). */
+t4a_gpu_status t4a_gpu_tci2_fill_stats(const t4a_gpu_tci2* h, uint64_t* out /* [3] */);
 /* optimize_with_finder (tensorci2.rs:1626-1802) on up to EIGHT handles at once, driven in lock-step by the calling thread: every
  * iteration enqueues the half-sweeps of all handles — as ONE chain of launches when they line up (same number of sites, built-in
  * functors: every kernel serves all handles, handle i's rrLU runs on XCD i), otherwise one chain per handle — then completes them

@@ -13,14 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "kernels_rrlu_xcd.hip", "kernels_rrlu_xcd_group.hip", "kernels_rrlu_xcd2.hip", "kernels_rrlu_xcd2_group.hip", "kernels_rrlu_wg.hip", "kernels_rrlu_wg_group.hip", "kernels_rrlu_w1.hip", "kernels_rrlu_global.hip", "kernels_pi.hip", "kernels_chain.hip", "kernels_dense.hip", "kernels_linalg.hip",
+SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "kernels_rrlu_xcd.hip", "kernels_rrlu_xcd_group.hip", "kernels_rrlu_xcd2.hip", "kernels_rrlu_xcd2_group.hip", "kernels_rrlu_xcd2m.hip", "kernels_rrlu_wg.hip", "kernels_rrlu_wg_group.hip", "kernels_rrlu_w1.hip", "kernels_rrlu_global.hip", "kernels_pi.hip", "kernels_chain.hip", "kernels_dense.hip", "kernels_linalg.hip",
            "kernels_tt.hip", "pool.hip", "engine.hip", "rook.hip", "tt.hip", "globalsearch.hip", "tci2.hip", "tci2_chain.hip", "conversion.hip", "patching.hip", "tree.hip", "quantics.hip", "tensorops.hip", "aci.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"] + os.environ.get("T4A_EXTRA_FLAGS", "").split()  # e.g. -DT4A_RRLU_TRACE (tools/trace_arrivals.py)
 # per-source flags.  kernels_dense.hip: keep MFMA accumulators in VGPRs — in AGPR form the compiler moves all of them between the
 # two register files at every k-step of the GEMM loop (32 v_accvgpr reads + writes behind a pipeline drain)
 FILE_FLAGS = {"kernels_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
-HEADERS = ["common.hpp", "stdrng.hpp", "kernels.hpp", "kernels_rrlu_xcd_common.hpp", "kernels_rrlu_w1_body.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "globalsearch.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
+HEADERS = ["common.hpp", "stdrng.hpp", "pishard.hpp", "kernels.hpp", "kernels_rrlu_xcd_common.hpp", "kernels_rrlu_w1_body.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "globalsearch.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
            "../../include/t4a_testfunctions.h"]
 
 
@@ -92,6 +92,14 @@ def build(force=False, verbose=True):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     with open(stamp, "w") as f:
         f.write(flags_now)
+    # test-hook twin (tests/test_gpu_chain.py: fault injection into the issue of a pending fill_site_tensors): tci2.hip compiled with
+    # -DT4A_TEST_HOOKS, every other object shared with the production library — which therefore carries no injector
+    hooks = os.path.join(OUT, "libt4a_gpu_testhooks.so")
+    src = os.path.join(CSRC, "tci2.hip")
+    hobj = os.path.join(OBJ, "tci2_testhooks.obj")
+    if force or jobs or _newer(hobj, [src] + sorted(_includes(src))) or not os.path.exists(hooks):
+        run([hipcc] + FLAGS + ["-DT4A_TEST_HOOKS", "-c", src, "-o", hobj])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hooks] + [o for o in objs if os.path.basename(o) != "tci2.o"] + [hobj])
     return lib
 
 

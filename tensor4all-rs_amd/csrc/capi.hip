@@ -935,6 +935,64 @@ t4a_gpu_status t4a_gpu_tci2_set_site_shard(t4a_gpu_tci2* h, size_t rank, size_t 
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_set_pi_shard(t4a_gpu_tci2* h, size_t rank, size_t world, t4a_gpu_allgather_fn gather, void* ctx)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (world == 0 || rank >= world) throw Error(T4A_GPU_INVALID_ARGUMENT, "invalid shard (rank, world)");
+        if (world > 1 && !gather) throw Error(T4A_GPU_NULL_POINTER, "a column-block shard over more than one rank needs an all-gather callback");
+        h->impl.pi_shard = PiShard();
+        h->impl.pi_shard.rank = rank;
+        h->impl.pi_shard.world = world;
+        h->impl.pi_shard.gather = world > 1 ? gather : nullptr;
+        h->impl.pi_shard.gather_ctx = ctx;
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_pi_shard_stats(t4a_gpu_tci2* h, size_t* out2)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out2);
+        out2[0] = h->impl.pi_shard.n_gathers;
+        out2[1] = h->impl.pi_shard.bytes_sent;
+    });
+}
+
+t4a_gpu_status t4a_gpu_pi_shard_eval(size_t rank, size_t world, t4a_gpu_batch_eval_fn cb, void* cb_ctx, t4a_gpu_allgather_fn gather,
+                                     void* gather_ctx, size_t n_sites, const uint32_t* a, size_t wa, size_t a0, size_t na,
+                                     const uint32_t* b, size_t wb, size_t b0, size_t nb, double* out)
+{
+    return guarded([&] { // host only: no device is touched
+        if (!cb) throw Error(T4A_GPU_NULL_POINTER, "batch callback is NULL");
+        if (world == 0 || rank >= world) throw Error(T4A_GPU_INVALID_ARGUMENT, "invalid shard (rank, world)");
+        if (na == 0 || nb == 0) return;
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(b);
+        T4A_REQUIRE_PTR(out);
+        if (wa + wb != n_sites || a0 + wa > n_sites || b0 + wb > n_sites) throw Error(T4A_GPU_INVALID_ARGUMENT, "index halves do not cover all sites");
+        if (world > 1) {
+            if (!gather) throw Error(T4A_GPU_NULL_POINTER, "a column-block shard over more than one rank needs an all-gather callback");
+            PiShard ps;
+            ps.rank = rank;
+            ps.world = world;
+            ps.gather = gather;
+            ps.gather_ctx = gather_ctx;
+            pi_shard_evaluate(ps, cb, cb_ctx, n_sites, a, wa, a0, na, b, wb, b0, nb, out);
+            return;
+        }
+        std::vector<uint32_t> idx(na * nb * n_sites);
+        for (size_t ia = 0; ia < na; ++ia)
+            for (size_t ib = 0; ib < nb; ++ib) {
+                uint32_t* dst = idx.data() + (ia * nb + ib) * n_sites;
+                std::memcpy(dst + a0, a + ia * wa, wa * sizeof(uint32_t));
+                std::memcpy(dst + b0, b + ib * wb, wb * sizeof(uint32_t));
+            }
+        const int64_t got = cb(cb_ctx, idx.data(), n_sites, na * nb, out);
+        if (got < 0 || (size_t)got != na * nb) throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned a wrong number of values");
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_export_site_shard_async(t4a_gpu_tci2* h, void* dst_device, size_t stride, void* consumer_stream)
 {
     return guarded([&] {
@@ -1039,6 +1097,15 @@ t4a_gpu_status t4a_gpu_tci2_chain_stats_ext(const t4a_gpu_tci2* h, uint64_t* out
         T4A_REQUIRE_PTR(h);
         T4A_REQUIRE_PTR(out);
         for (int k = 0; k < 4; ++k) out[k] = h->impl.chain_stats_ext[k];
+    });
+}
+
+t4a_gpu_status t4a_gpu_tci2_fill_stats(const t4a_gpu_tci2* h, uint64_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        for (int k = 0; k < 3; ++k) out[k] = h->impl.fill_stats()[k];
     });
 }
 

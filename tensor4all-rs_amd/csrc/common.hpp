@@ -6,12 +6,14 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/t4a_gpu.h"
+#include "diag.hpp"
 
 namespace t4a {
 
@@ -22,6 +24,8 @@ struct Error : std::runtime_error {
 };
 
 void set_last_error(const std::string& msg);
+
+
 
 inline void hip_check(hipError_t e, const char* what, const char* file, int line)
 {

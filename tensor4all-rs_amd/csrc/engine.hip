@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 
 namespace t4a {
@@ -39,7 +40,6 @@ __global__ void __launch_bounds__(256) tri_extract_kernel(const double* __restri
 // for its duration, a chip-wide launch (old register kernel, LDS kernel) owns all of them.
 namespace {
 constexpr int kXcdSharedMaxW = 28; // single-XCD plans up to this many workgroups leave room for other handles' pass-through workgroups
-std::mutex g_xcd_mutex[8];
 std::atomic<int> g_xcd_next{0};
 std::atomic<int> g_live_engines{0};
 std::atomic<bool> g_xcd_disabled{false};
@@ -67,6 +67,7 @@ void rrlu_xcd_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdArgs& 
 {
     if (plan.wg == 2) rrlu_w1_launch(plan, args, stream);
     else if (plan.wg) rrlu_wg_launch(plan, args, stream);
+    else if (plan.big()) rrlu_xcd2m_launch(plan, args, stream); // (second generation only: rrlu_xcd_make_plan hands such plans out with allow_big)
     else if (version == 1) rrlu_xcd_launch(plan, args, stream);
     else rrlu_xcd2_launch(plan, args, stream);
 }
@@ -121,43 +122,69 @@ int xcd_assign() { return g_xcd_next.fetch_add(1, std::memory_order_relaxed) & 7
 // XCD — before round 3 a chain with one 29-workgroup plan in it held the chip-wide reservation for its whole half-sweep and
 // eight handles on eight host threads ran one after the other (34.3 ms per patch against 38.6 ms for one alone).
 int xcd_plan_max_w() { return g_live_engines.load(std::memory_order_relaxed) > 1 ? kXcdSharedMaxW : 32; }
-// The mutexes are owned per host THREAD with a recursion count (t_xcd_hold): one thread may drive several handles whose
-// reservations overlap in time — optimize_group launches one chain per handle when the chains do not line up, and a handle whose
-// chain fell back runs chip-wide kernels while its siblings still hold their XCDs (that used to self-deadlock on
-// the non-recursive mutexes).  A thread that already holds part of the chip never BLOCKS for the rest: it takes what is free
-// (try_lock) and launches anyway — the arbiter is a performance device, every persistent kernel has bounded spins and a fallback
-// — so two threads that each hold an XCD and both want the whole chip cannot wait for each other either.
+// Ownership is kept IN THE ARBITER (owner thread + recursion count per XCD under one mutex), not in thread-local counters: one
+// thread may drive several handles whose reservations overlap in time — optimize_group launches one chain per handle when the chains
+// do not line up, and a handle whose chain fell back runs chip-wide kernels while its siblings still hold their XCDs (ADVICE round 3:
+// that used to self-deadlock on non-recursive mutexes) — and a Lock may be released by another thread than the one that acquired it
+// (a handle handed to a worker thread: ADVICE round 4 — with thread-local counts that drove a count negative and left the mutex
+// locked for good).  A thread that already holds ANY part of the chip never blocks for more, neither for a single XCD nor for the
+// whole chip: it takes what is free and shares the rest — the arbiter is a performance device, every persistent kernel has bounded
+// spins and a fallback — so two threads that each hold an XCD and want each other's (more than eight live engines: xcd_assign wraps)
+// or both want the whole chip cannot wait for each other.
 namespace {
-thread_local int t_xcd_hold[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+std::mutex g_arb_mutex;
+std::condition_variable g_arb_cv;
+std::thread::id g_arb_owner[8];
+int g_arb_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 }
 void XcdArbiter::Lock::acquire(int xcc)
 {
     release();
+    const std::thread::id me = std::this_thread::get_id();
+    std::unique_lock<std::mutex> lk(g_arb_mutex);
+    auto holds_some = [&] {
+        for (int i = 0; i < 8; ++i)
+            if (g_arb_count[i] > 0 && g_arb_owner[i] == me) return true;
+        return false;
+    };
+    auto take = [&](int i) {
+        g_arb_owner[i] = me;
+        ++g_arb_count[i];
+        held_ |= 1 << i;
+    };
+    owner_ = me;
     if (xcc >= 0) {
         const int i = xcc & 7;
-        if (t_xcd_hold[i] == 0) g_xcd_mutex[i].lock();
-        ++t_xcd_hold[i];
-        held_ = 1 << i;
+        if (g_arb_count[i] > 0 && g_arb_owner[i] == me) take(i);
+        else if (holds_some()) {
+            if (g_arb_count[i] == 0) take(i); // (somebody else's XCD otherwise: shared for the time being, never waited for)
+        } else {
+            g_arb_cv.wait(lk, [&] { return g_arb_count[i] == 0; });
+            take(i);
+        }
     } else {
-        bool holds_some = false;
-        for (int i = 0; i < 8; ++i) holds_some = holds_some || t_xcd_hold[i] > 0;
+        const bool some = holds_some();
         for (int i = 0; i < 8; ++i) { // fixed order: no deadlock between two chip-wide owners that start from nothing
-            if (t_xcd_hold[i] == 0) {
-                if (!holds_some) g_xcd_mutex[i].lock();
-                else if (!g_xcd_mutex[i].try_lock()) continue; // (somebody else's XCD: shared for the time being)
+            if (g_arb_count[i] > 0 && g_arb_owner[i] == me) take(i);
+            else if (some) {
+                if (g_arb_count[i] == 0) take(i);
+            } else {
+                g_arb_cv.wait(lk, [&] { return g_arb_count[i] == 0; });
+                take(i);
             }
-            ++t_xcd_hold[i];
-            held_ |= 1 << i;
         }
     }
 }
 void XcdArbiter::Lock::release()
 {
-    for (int i = 7; i >= 0; --i)
-        if (held_ & (1 << i)) {
-            if (--t_xcd_hold[i] == 0) g_xcd_mutex[i].unlock();
-        }
-    held_ = 0;
+    if (!held_) return;
+    {
+        std::lock_guard<std::mutex> lk(g_arb_mutex);
+        for (int i = 7; i >= 0; --i)
+            if ((held_ & (1 << i)) && g_arb_count[i] > 0 && g_arb_owner[i] == owner_) --g_arb_count[i]; // (whichever thread calls: the Lock knows its owner)
+        held_ = 0;
+    }
+    g_arb_cv.notify_all();
 }
 
 void set_last_error(const std::string& msg) { g_last_error = msg; }
@@ -276,7 +303,8 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     const bool use_wg = !huge && !force_lds && !force_global && !force_reg && !xcd_retry_v1_ && (long)kM * kN > wg_min &&
                         (rrlu_w1_make_plan(kM, kN, &xplan, 0) || rrlu_wg_make_plan(kM, kN, &xplan, 0));
     const bool use_xcd = use_wg || (!huge && !force_lds && !force_global && !force_reg && !xcd_disabled() &&
-                         (rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, 32)));
+                         (rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, xcd_plan_max_w()) ||
+                          rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, 32, !xcd_retry_v1_ && xcd_v == 2)));
     const bool use_reg = !use_xcd && !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     bool fuse = false;
     bool xcd_src_transposed = false;
@@ -323,10 +351,10 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
             // salt wraps.  (Plans differ in where the column slots start; a stale granule of another plan still carries
             // another launch's salt.)
             d_xkeys_.reserve(need_keys + need_cols);
-            d_xticket_.reserve(4);
+            d_xticket_.reserve(16);
             T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), stream_));
-            T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), stream_));
-            xcd_ticket_base_ = 0;
+            T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 16 * sizeof(unsigned), stream_));
+            xcd_ticket_base_ = xcd_ticket_base_multi_ = 0;
             xcd_salt_ = 1;
         }
         RrluXcdArgs a;
@@ -343,9 +371,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.out_transposed = left ? 0 : 1;
         a.W = xplan.W;
         a.xcc = xcc_;
-        a.ticket = d_xticket_.get();
-        a.ticket_base = xcd_ticket_base_;
-        if (!xplan.wg) xcd_ticket_base_ += (unsigned)(xplan.grid / 8); // exactly grid / 8 workgroups of a launch land on one XCD (the one-workgroup kernel takes no tickets)
+        xcd_take_tickets(xplan, a); // exactly grid / 8 workgroups of a launch land on one XCD (the one-workgroup kernel takes no tickets)
         a.row_perm = left ? d_rowperm : d_colperm;
         a.col_perm = left ? d_colperm : d_rowperm;
         a.iresult = d_ires;
@@ -353,7 +379,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.pivot_vals = d_pivvals;
         a.keys = d_xkeys_.get();
         a.salt = xcd_salt_;
-        static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.8;
+        static const double xspec = diag_env("T4A_XCD_SPECFRAC") ? std::atof(diag_env("T4A_XCD_SPECFRAC")) : 0.8;
         a.spec_frac = xspec;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
         std::memset(h_out_.get(), 0, 32);
@@ -367,11 +393,12 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         mirrored = true;
         // a launch has 8 W workgroups of which 7 W pass through the other XCDs and need a free compute unit there for a moment:
         // two handles that each fill (nearly) all 32 compute units of their XCD would block each other's dispatch
-        xcd_lock.acquire(xplan.W > kXcdSharedMaxW ? -1 : xcc_);
+        xcd_lock.acquire((xplan.W > kXcdSharedMaxW || xplan.K > 1) ? -1 : xcc_);
         rrlu_xcd_launch_v(xcd_v, xplan, a, stream_);
         plan_W = xplan.W;
         plan_T = 512;
-        plan_code = 100000 + xplan.RPT * 100 + xplan.CPT * 10 + (a.tie_row_major ? 4 : 0);
+        plan_code = (xplan.wg == 2 ? 300000 + xplan.RPT * 1000 : xplan.wg ? 200000 + xplan.RPT * 1000 : xplan.big() ? 400000 + xplan.K * 10000 + xplan.RPT * 100 : 100000 + xplan.RPT * 100) +
+                    xplan.CPT * 10 + (a.tie_row_major ? 4 : 0); // (the one-workgroup / one-wave kernels under their own codes)
     } else if (use_reg) {
         const double* src = d_a;
         if (!left && !fuse) {
@@ -428,18 +455,18 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.keys_next = keys_next;
         a.keys_next_u64 = keys_ready ? keys_half : 0;
         a.salt = rrlu_salt_;
-        static const int col_delay = std::getenv("T4A_RRLU_COLDELAY") ? std::atoi(std::getenv("T4A_RRLU_COLDELAY")) : 0;
+        static const int col_delay = diag_env("T4A_RRLU_COLDELAY") ? std::atoi(diag_env("T4A_RRLU_COLDELAY")) : 0;
         a.col_delay = col_delay;
         // measured optimum of the poller's initial sleep (tools/probe_delay.py): 12 units below ~100 workgroups, 14 above
-        static const int poll_delay_env = std::getenv("T4A_RRLU_POLLDELAY") ? std::atoi(std::getenv("T4A_RRLU_POLLDELAY")) : -1;
+        static const int poll_delay_env = diag_env("T4A_RRLU_POLLDELAY") ? std::atoi(diag_env("T4A_RRLU_POLLDELAY")) : -1;
         a.poll_delay = poll_delay_env >= 0 ? poll_delay_env : (rplan.W > 100 ? 14 : 12);
-        static const int ncopy_env = std::getenv("T4A_RRLU_NCOPY") ? std::atoi(std::getenv("T4A_RRLU_NCOPY")) : 1;
+        static const int ncopy_env = diag_env("T4A_RRLU_NCOPY") ? std::atoi(diag_env("T4A_RRLU_NCOPY")) : 1;
         a.ncopy = ncopy_env < 1 ? 1 : (ncopy_env > RRLU_MAX_COPIES ? RRLU_MAX_COPIES : ncopy_env);
-        static const int spec_env = std::getenv("T4A_RRLU_SPEC") ? std::atoi(std::getenv("T4A_RRLU_SPEC")) : 2;
+        static const int spec_env = diag_env("T4A_RRLU_SPEC") ? std::atoi(diag_env("T4A_RRLU_SPEC")) : 2;
         a.spec = spec_env < 0 ? 0 : (spec_env > 2 ? 2 : spec_env);
-        static const double spec_frac_env = std::getenv("T4A_RRLU_SPECFRAC") ? std::atof(std::getenv("T4A_RRLU_SPECFRAC")) : 0.8;
+        static const double spec_frac_env = diag_env("T4A_RRLU_SPECFRAC") ? std::atof(diag_env("T4A_RRLU_SPECFRAC")) : 0.8;
         a.spec_frac = spec_frac_env;
-        static const int key16_env = std::getenv("T4A_RRLU_KEY16") ? std::atoi(std::getenv("T4A_RRLU_KEY16")) : 1;
+        static const int key16_env = diag_env("T4A_RRLU_KEY16") ? std::atoi(diag_env("T4A_RRLU_KEY16")) : 1;
         a.key16 = key16_env; // bit 0: 16-byte key loads, bit 1: 16-byte key store
         a.spin_limit = 1u << 20;
         a.stamps = want_stamps ? d_stamps_.get() : nullptr;
@@ -463,7 +490,7 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         a.dev_token = 0u;
         a.rowmap = nullptr;
         a.ts_u64 = 0;
-        static const bool no_token_spin = std::getenv("T4A_NO_TOKEN_SPIN") != nullptr;
+        static const bool no_token_spin = diag_env("T4A_NO_TOKEN_SPIN") != nullptr;
         if (rplan.W == 1 && !prof.enabled && !no_token_spin) {
             if (++done_token_ == 0u) ++done_token_;
             a.done_token = done_token_;
@@ -595,8 +622,8 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
         // never try it again in this process and run this factorisation with the chip-wide kernels
         xcd_disable();
         T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
-        T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), stream_));
-        xcd_ticket_base_ = 0;
+        T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 16 * sizeof(unsigned), stream_));
+        xcd_ticket_base_ = xcd_ticket_base_multi_ = 0;
         header_clean_ = false;
         return luci(d_a_in, M, N, opts, need_factors, want_lu_copy, fused);
     }
@@ -720,13 +747,29 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
 // ------------------------------------------------------------------------------------------------
 // bond chain: the rrLU launches of a half-sweep without a host round trip (tci2_chain.hip)
 // ------------------------------------------------------------------------------------------------
+// ticket counters of a launch: single-XCD plans count on d_xticket_[0] (only the workgroups on the elected XCD take one), plans over
+// K > 1 XCDs on d_xticket_[8 + xcd] (EVERY workgroup of such a launch takes one from its XCD's counter); either way a counter advances
+// by grid / 8 per launch
+void Engine::xcd_take_tickets(const RrluXcdPlan& plan, RrluXcdArgs& a)
+{
+    if (plan.K > 1) {
+        a.ticket = d_xticket_.get() + 8;
+        a.ticket_base = xcd_ticket_base_multi_;
+        xcd_ticket_base_multi_ += (unsigned)(plan.grid / 8);
+    } else {
+        a.ticket = d_xticket_.get();
+        a.ticket_base = xcd_ticket_base_;
+        if (!plan.wg) xcd_ticket_base_ += (unsigned)(plan.grid / 8);
+    }
+}
+
 bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
 {
     if (kM < 1 || kN < 1 || kM > 65535 || kN > 65535) return false;
     ChainRrluPlan pl;
     pl.kM = kM;
     pl.kN = kN;
-    static const bool no_single = std::getenv("T4A_CHAIN_NO_SINGLE") != nullptr;
+    static const bool no_single = diag_env("T4A_CHAIN_NO_SINGLE") != nullptr;
     // tiny matrices keep the fused single-workgroup plan (the candidate matrix is built in the registers: no extra launch);
     // everything else that fits one workgroup takes the LDS-exchange kernel, with 63 more workgroups for the speculative
     // candidate matrix of the next bond
@@ -745,10 +788,10 @@ bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
         return true;
     }
     // (shapes that only fit with more than kXcdSharedMaxW workgroups keep their plan: the launch then reserves the whole chip)
-    if (xcd_disabled() || !(rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32)))
+    if (xcd_disabled() || !(rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32, xcd_version() == 2)))
         return false;
     pl.kind = 2;
-    pl.code = 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
+    pl.code = (pl.xcd.big() ? 400000 + pl.xcd.K * 10000 : 100000) + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
     *out = pl;
     return true;
 }
@@ -761,15 +804,15 @@ void Engine::chain_begin(const std::vector<ChainRrluPlan>& plans, size_t reserve
         if (pl.kind == 2) {
             const size_t n = (rrlu_xcd_keys_bytes(pl.xcd) + rrlu_xcd_cols_bytes(pl.xcd, pl.kM)) / sizeof(unsigned long long);
             need = std::max(need, n);
-            max_w = std::max(max_w, pl.xcd.W);
+            max_w = std::max(max_w, pl.xcd.K > 1 ? 33 : pl.xcd.W); // (a plan over several XCDs reserves the whole chip)
         }
     if (need > 0) {
         if (need > d_xkeys_.cap || !d_xticket_.get()) {
             d_xkeys_.reserve(std::max(need, reserve_mailbox_words));
-            d_xticket_.reserve(4);
+            d_xticket_.reserve(16);
             T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), stream_));
-            T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), stream_));
-            xcd_ticket_base_ = 0;
+            T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 16 * sizeof(unsigned), stream_));
+            xcd_ticket_base_ = xcd_ticket_base_multi_ = 0;
             xcd_salt_ = 0;
         }
         chain_lock_.acquire(max_w > kXcdSharedMaxW ? -1 : xcc_);
@@ -786,7 +829,7 @@ bool Engine::chain_group_plan(int kM, int kN, ChainRrluPlan* out)
     pl.kN = kN;
     if (!rrlu_w1_make_plan(kM, kN, &pl.xcd, 0) && !rrlu_wg_make_plan(kM, kN, &pl.xcd, 0) && !rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32)) return false;
     pl.kind = 2;
-    pl.code = 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
+    pl.code = pl.xcd.wg == 2 ? 300000 + pl.xcd.RPT * 1000 + pl.xcd.CPT * 10 : pl.xcd.wg ? 200000 + pl.xcd.RPT * 1000 + pl.xcd.CPT * 10 : 100000 + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;
     *out = pl;
     return true;
 }
@@ -798,10 +841,10 @@ void Engine::chain_group_reserve(const std::vector<ChainRrluPlan>& plans, size_t
         if (pl.kind == 2) need = std::max(need, (rrlu_xcd_keys_bytes(pl.xcd) + rrlu_xcd_cols_bytes(pl.xcd, pl.kM)) / sizeof(unsigned long long));
     if (need > 0 && (need > d_xkeys_.cap || !d_xticket_.get())) {
         d_xkeys_.reserve(std::max(need, reserve_mailbox_words));
-        d_xticket_.reserve(4);
+        d_xticket_.reserve(16);
         T4A_HIP(hipMemsetAsync(d_xkeys_.get(), 0, d_xkeys_.cap * sizeof(unsigned long long), order_stream));
-        T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 4 * sizeof(unsigned), order_stream));
-        xcd_ticket_base_ = 0;
+        T4A_HIP(hipMemsetAsync(d_xticket_.get(), 0, 16 * sizeof(unsigned), order_stream));
+        xcd_ticket_base_ = xcd_ticket_base_multi_ = 0;
         xcd_salt_ = 0;
     }
 }
@@ -834,9 +877,7 @@ unsigned Engine::chain_group_args(const ChainRrluPlan& pl, bool left, const doub
     a.out_transposed = left ? 0 : 1;
     a.W = pl.xcd.W;
     a.xcc = slot;
-    a.ticket = d_xticket_.get();
-    a.ticket_base = xcd_ticket_base_;
-    if (!pl.xcd.wg) xcd_ticket_base_ += (unsigned)(pl.xcd.grid / 8); // (the one-workgroup kernel takes no tickets)
+    xcd_take_tickets(pl.xcd, a); // (the one-workgroup kernel takes no tickets)
     a.row_perm = left ? d_rowperm : d_colperm;
     a.col_perm = left ? d_colperm : d_rowperm;
     a.iresult = d_ires;
@@ -844,7 +885,7 @@ unsigned Engine::chain_group_args(const ChainRrluPlan& pl, bool left, const doub
     a.pivot_vals = d_pivvals;
     a.keys = d_xkeys_.get();
     a.salt = xcd_salt_;
-    static const double xspec = std::getenv("T4A_XCD_SPECFRAC") ? std::atof(std::getenv("T4A_XCD_SPECFRAC")) : 0.8;
+    static const double xspec = diag_env("T4A_XCD_SPECFRAC") ? std::atof(diag_env("T4A_XCD_SPECFRAC")) : 0.8;
     a.spec_frac = xspec;
     a.stamps = nullptr;
     a.h_block = reinterpret_cast<unsigned long long*>(blk.host);
@@ -933,7 +974,7 @@ void Engine::build_factors_from(const double* lu, const int* d_rowperm_ptr_, con
     d_left_.reserve((size_t)M * (rk > 0 ? rk : 1));
     d_right_.reserve((size_t)N * (rk > 0 ? rk : 1));
     if (rk == 0) return;
-    static const bool no_small = std::getenv("T4A_NO_SMALL_FACTORS") != nullptr;
+    static const bool no_small = diag_env("T4A_NO_SMALL_FACTORS") != nullptr;
     if (!no_small && luci_factors_small_launch(lu, M, N, rk, d_rowperm_ptr_, d_colperm_ptr_, left_orth, d_left_.get(), d_right_.get(), stream_)) {
         T4A_HIP(hipGetLastError());
         return;
@@ -1102,8 +1143,13 @@ void Engine::svd(const double* d_a, int M, int N, double* d_u, double* d_s, doub
     set_identity_launch(V, n, n, n, stream_);
     const int max_sweeps = 60;
     int h[4] = {0, 0, 0, 0};
-    static const bool no_block = std::getenv("T4A_SVD_NO_BLOCK") != nullptr;
-    if (no_block && jacobi_fits_small(m, n)) {
+    static const bool no_block = diag_env("T4A_SVD_NO_BLOCK") != nullptr;
+    // tiny matrices (n <= 16: the cores of a small train, 2 x 2 rotations in the tests): the whole iteration in ONE launch of one
+    // workgroup, no host round trip per sweep; everything else the blocked tournament (12.8 ms at 512 x 256 against 16.6, 2.3 ms at
+    // 64 x 64 against 3.7: profiles/r04_linalg_probe.txt).  T4A_SVD_SMALL_N moves the boundary, T4A_SVD_NO_BLOCK=1 restores the
+    // round-3 behaviour (one launch up to 128 columns, launch-per-round beyond).
+    static const int small_n = diag_env("T4A_SVD_SMALL_N") ? std::atoi(diag_env("T4A_SVD_SMALL_N")) : 16;
+    if (jacobi_fits_small(m, n) && (no_block || n <= small_n)) {
         jacobi_small_launch(W, m, V, n, max_sweeps, stream_);
     } else {
         for (int sweep = 0; sweep < max_sweeps; ++sweep) {

@@ -5,6 +5,7 @@
 
 #include <array>
 #include <functional>
+#include <thread>
 #include <map>
 #include <limits>
 #include <vector>
@@ -64,6 +65,7 @@ struct XcdArbiter {
         void release();
     private:
         int held_ = 0;
+        std::thread::id owner_; // the thread the XCDs are booked under (a Lock may be released by another one)
     };
 };
 
@@ -176,7 +178,8 @@ private:
     // single-XCD rrLU kernel: elected XCD, mailboxes, monotonic ticket counter
     int xcc_ = 0;
     bool xcd_retry_v1_ = false; // luci(): this call re-runs a factorisation the second-generation single-XCD kernel gave up on (non-finite values)
-    unsigned xcd_salt_ = 0, xcd_ticket_base_ = 0;
+    unsigned xcd_salt_ = 0, xcd_ticket_base_ = 0, xcd_ticket_base_multi_ = 0;
+    void xcd_take_tickets(const RrluXcdPlan& plan, RrluXcdArgs& a);
     DevBuf<unsigned long long> d_xkeys_; // mailbox of the single-XCD kernel: keys, then column slots
     DevBuf<unsigned> d_xticket_;
     DevBuf<double> d_xurows_;

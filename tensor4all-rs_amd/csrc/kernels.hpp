@@ -9,6 +9,7 @@
 #include <cstdint>
 
 #include "../../include/t4a_testfunctions.h"
+#include "diag.hpp"
 
 namespace t4a {
 
@@ -184,6 +185,8 @@ struct RrluXcdPlan {
     int grid = 8;           // launched workgroups = 8 W (blocks b and b + 8 share an XCD)
     size_t lds_bytes = 0;
     int wg = 0;             // 1: the one-workgroup kernel (kernels_rrlu_wg.hip): RPT rows per lane, CPT columns per WAVE, grid = 1 + speculating workgroups; 2: the one-wave kernel (kernels_rrlu_w1.hip)
+    int K = 1;              // XCDs the agents live on (round 5, second generation only): agents = 8 K W; K > 1 or RPT > 16: kernels_rrlu_xcd2m.hip
+    bool big() const { return K > 1 || RPT > 16; }
 };
 struct RrluXcdArgs {
     const double* A;            // M x N input (ld = M)
@@ -195,8 +198,8 @@ struct RrluXcdArgs {
     int tie_row_major;          // 1: ties go to the smallest (rowpos, colpos) — transposed problems
     int out_transposed;         // 1: Aout[colpos + N*rowpos]
     int W;                      // participating workgroups
-    int xcc;                    // XCC id (HW_REG_XCC_ID) of the elected XCD
-    unsigned* ticket;           // monotonic ticket counter of this engine; ranks are ticket - ticket_base
+    int xcc;                    // XCC id (HW_REG_XCC_ID) of the elected XCD (K > 1: the first of K neighbours, mod 8)
+    unsigned* ticket;           // monotonic ticket counter of this engine; ranks are ticket - ticket_base (K > 1: eight counters, one per XCD)
     unsigned ticket_base;
     int* row_perm;
     int* col_perm;
@@ -223,7 +226,9 @@ struct RrluXcdArgs {
 // matrices are left to the single-workgroup plan of the chip-wide kernel
 // max_w: most workgroups the plan may use (<= 32 = the compute units of an XCD; fewer when other handles share the chip, see
 // XcdArbiter in engine.hip)
-bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size = false, int max_w = 32);
+// allow_big: plans beyond one XCD's 1024 x 1024 (up to 1536 rows; columns over K <= 4 XCDs) — second-generation kernel only, so not
+// on the retry after non-finite values
+bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size = false, int max_w = 32, bool allow_big = false);
 size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan);
 size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int M);
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
@@ -238,6 +243,8 @@ void rrlu_xcd_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args
 // hand-zeroed pivot rows): same plan, arguments and mailbox.  It handles finite matrices only: on a NaN / infinity in the input or
 // an overflow in the trailing block the launch gives up with iresult[1] == 2 and the caller runs the first generation.
 void rrlu_xcd2_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
+// plans with big() (kernels_rrlu_xcd2m.hip): the same kernel body with agents on K XCDs and / or 20 - 24 row slots per lane
+void rrlu_xcd2m_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
 void rrlu_xcd2_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
 // One-workgroup kernel (kernels_rrlu_wg.hip): matrices up to 64 x 512 / 128 x 384 in the registers of one compute
 // unit, exchange through its LDS (one barrier per pivot step).  Same arguments and result block; finite matrices only (gives up

@@ -972,13 +972,13 @@ void gemm_launch(const GemmDesc& d, hipStream_t stream)
 {
     if (d.m <= 0 || d.n <= 0 || d.batch <= 0) return;
     // two workgroups per compute unit hide each other's LDS / barrier stalls: narrower tiles when 64 x 64 ones cannot provide them
-    static const int force_bn = std::getenv("T4A_GEMM_BN") ? std::atoi(std::getenv("T4A_GEMM_BN")) : 0;
+    static const int force_bn = diag_env("T4A_GEMM_BN") ? std::atoi(diag_env("T4A_GEMM_BN")) : 0;
     const long long tiles64 = (long long)((d.m + GBM - 1) / GBM) * ((d.n + 63) / 64) * d.batch;
     const bool narrow = force_bn ? force_bn == 32 : (tiles64 < 512 && d.n > 32);
     // small outputs leave most of the chip idle (a 256 x 256 result is 32 narrow tiles on 256 compute units): split K over
     // blockIdx.z and sum the slices in a second pass (a separate launch: the fence of an in-kernel reduction cost more than it
     // saved, tools/experiments/README.md).  Slices of >= 2 k-tiles, as many as fill the chip twice, at most 16.
-    static const int force_split = std::getenv("T4A_GEMM_KSPLIT") ? std::atoi(std::getenv("T4A_GEMM_KSPLIT")) : 0;
+    static const int force_split = diag_env("T4A_GEMM_KSPLIT") ? std::atoi(diag_env("T4A_GEMM_KSPLIT")) : 0;
     const long long tiles = (long long)((d.m + GBM - 1) / GBM) * ((d.n + (narrow ? 31 : 63)) / (narrow ? 32 : 64)) * d.batch;
     const int ktiles = (d.k + GBK - 1) / GBK;
     int ksplit = 1;
@@ -1116,7 +1116,7 @@ void trsm_left_batched_launch(const TrsmProblem* d_problems, int n_problems, int
         attr_set = true;
     }
     // large systems with enough right-hand sides: blocked substitution with the bulk on the matrix cores
-    static const bool no_mfma = std::getenv("T4A_TRSM_NO_MFMA") != nullptr;
+    static const bool no_mfma = diag_env("T4A_TRSM_NO_MFMA") != nullptr;
     if (!no_mfma && max_n >= 64 && max_nrhs >= 16) {
         static bool attr2 = false;
         if (!attr2) {
@@ -1138,7 +1138,7 @@ void trsm_left_batched_launch(const TrsmProblem* d_problems, int n_problems, int
     if (cw > 32) cw = 32;
     // the substitution is a chain of max_n dependent steps per workgroup: prefer many thin column chunks (>= ~2000
     // workgroups in flight) over few wide ones
-    static const int cw_env = std::getenv("T4A_TRSM_CW") ? std::atoi(std::getenv("T4A_TRSM_CW")) : 0;
+    static const int cw_env = diag_env("T4A_TRSM_CW") ? std::atoi(diag_env("T4A_TRSM_CW")) : 0;
     const long long total_cols = (long long)n_problems * max_nrhs;
     while (cw > 4 && total_cols / cw < 2048) cw /= 2;
     if (cw_env > 0) cw = cw_env;

@@ -627,7 +627,7 @@ void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hip
 // Returns false when the columns are too long for the LDS (m > 4096): the caller keeps the launch-per-round path.
 bool jacobi_block_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream)
 {
-    static const int w_max = std::getenv("T4A_SVD_BLOCK_W") ? std::atoi(std::getenv("T4A_SVD_BLOCK_W")) : 8;
+    static const int w_max = diag_env("T4A_SVD_BLOCK_W") ? std::atoi(diag_env("T4A_SVD_BLOCK_W")) : 8;
     int w = w_max >= 16 ? 16 : (w_max >= 8 ? 8 : (w_max >= 4 ? 4 : 2));
     while (w > 1 && (size_t)2 * w * m * 8 > (size_t)136 * 1024) w >>= 1;
     if ((size_t)2 * w * m * 8 > (size_t)136 * 1024) return false;
@@ -636,8 +636,16 @@ bool jacobi_block_sweep_launch(double* W, int m, double* V, int n, int* d_rotate
     const size_t lds = ((size_t)2 * w * m + (size_t)4 * w * w) * 8 + (size_t)2 * w * 4 + 16;
     int T = 64 * w;
     if (T < 256) T = 256; // (the extra waves only help with the loads and the V pass)
+    static std::once_flag attr_once; // (once per process, not once per sweep: ADVICE round 4; every block width in one go)
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    });
     auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         for (int round = 0; round < nbp - 1; ++round)
             hipLaunchKernelGGL(kern, dim3(nbp / 2), dim3(T), lds, stream, W, m, V, n, nbp, round, d_rotated);
     };
@@ -674,7 +682,7 @@ void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double
     for (int j0 = 0, pi = 0; j0 < k; j0 += QR_NB, ++pi) {
         const int w = (k - j0) < QR_NB ? (k - j0) : QR_NB;
         double* Tp = Tall + (size_t)pi * QR_NB * QR_NB;
-        static const bool no_lds_panel = std::getenv("T4A_QR_NO_LDS_PANEL") != nullptr;
+        static const bool no_lds_panel = diag_env("T4A_QR_NO_LDS_PANEL") != nullptr;
         if (!no_lds_panel && m - j0 <= QR_LDS_MAX_ROWS) {
             const int ld = (m - j0) | 1;
             const size_t lds = ((size_t)QR_NB * ld + QR_NB * QR_NB + QR_NB + QR_T / 64) * sizeof(double);

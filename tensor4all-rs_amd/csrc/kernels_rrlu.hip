@@ -515,8 +515,8 @@ __global__ void __launch_bounds__(1024) rrlu_kernel(RrluArgs p)
 RrluPlan rrlu_make_plan(int M, int N, int num_cus)
 {
     RrluPlan plan;
-    const char* ew = std::getenv("T4A_RRLU_W");
-    const char* et = std::getenv("T4A_RRLU_T");
+    const char* ew = diag_env("T4A_RRLU_W");
+    const char* et = diag_env("T4A_RRLU_T");
     int T = 256;
     if (et) T = std::atoi(et);
     if (T < 64) T = 64;

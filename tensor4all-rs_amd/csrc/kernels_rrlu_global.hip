@@ -289,7 +289,7 @@ void rrlu_global_launch(RrluGlobalArgs a, int* iwork, double* dwork, hipStream_t
     (void)hipMemsetAsync(a.istate, 0, 16 * sizeof(int), stream);
     hipLaunchKernelGGL(rg_init_kernel, dim3(blocks), dim3(256), 0, stream, a);
     // the search ends with one same-address atomic per workgroup (they serialise in L2, ~40 ns each): a moderate grid (512) is the measured optimum
-    static const int acap = std::getenv("T4A_RG_ABLOCKS") ? std::atoi(std::getenv("T4A_RG_ABLOCKS")) : 512;
+    static const int acap = diag_env("T4A_RG_ABLOCKS") ? std::atoi(diag_env("T4A_RG_ABLOCKS")) : 512;
     const int ablocks = blocks < acap ? blocks : acap;
     for (int k = 0; k < a.max_steps; ++k) {
         hipLaunchKernelGGL(rg_argmax_kernel, dim3(ablocks), dim3(256), 0, stream, a, k);

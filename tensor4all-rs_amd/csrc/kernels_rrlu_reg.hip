@@ -980,13 +980,13 @@ int norm_cpt(int c) { return c <= 1 ? 1 : (c <= 6 ? c : 8); }
 bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
 {
     RrluRegPlan plan;
-    const char* ew = std::getenv("T4A_RRLU_W");
-    const char* et = std::getenv("T4A_RRLU_T");
-    const char* ec = std::getenv("T4A_RRLU_CPT");
+    const char* ew = diag_env("T4A_RRLU_W");
+    const char* et = diag_env("T4A_RRLU_T");
+    const char* ec = diag_env("T4A_RRLU_CPT");
     // (the key-table poller reads 4 keys per lane and the engine reserves 256 slots: never plan more workgroups than that)
     const int maxw = std::min(num_cus > 16 ? num_cus - 8 : num_cus, 256);
     const long long elems = (long long)M * N;
-    static const long long single_max = std::getenv("T4A_RRLU_SINGLE_MAX") ? std::atoll(std::getenv("T4A_RRLU_SINGLE_MAX")) : 64 * 64;
+    static const long long single_max = diag_env("T4A_RRLU_SINGLE_MAX") ? std::atoll(diag_env("T4A_RRLU_SINGLE_MAX")) : 64 * 64;
     bool single = elems <= single_max;
     if (ew) single = std::atoi(ew) == 1;
     bool found = false;
@@ -1035,10 +1035,10 @@ bool rrlu_reg_make_plan(int M, int N, int num_cus, RrluRegPlan* out)
                 TC = 1;
             }
         }
-        if (const char* etr = std::getenv("T4A_RRLU_TR")) { // experiment: explicit thread grid TR x TC
+        if (const char* etr = diag_env("T4A_RRLU_TR")) { // experiment: explicit thread grid TR x TC
             TR = round_up(std::atoi(etr), 64);
             RPT = (M + TR - 1) / TR;
-            TC = std::getenv("T4A_RRLU_TC") ? std::atoi(std::getenv("T4A_RRLU_TC")) : 1;
+            TC = diag_env("T4A_RRLU_TC") ? std::atoi(diag_env("T4A_RRLU_TC")) : 1;
             if (TC < 1) TC = 1;
         }
         if (RPT > 4 || TR > 1024) return false; // beyond the register budget: LDS kernel

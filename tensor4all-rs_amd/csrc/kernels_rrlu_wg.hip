@@ -639,7 +639,7 @@ bool rrlu_wg_make_plan(int M, int N, RrluXcdPlan* out, int spec_blocks)
     if (cpw < 0) return false;
     // beyond 16 values per lane (64 x 128, 128 x 64) the update (2 readlanes + 3 RPT vector instructions per owned column, all on ONE compute unit)
     // costs more than the single-XCD kernel's two L2 hand-offs (measured: tools/probe_wg.py)
-    static const int max_values = std::getenv("T4A_WG_MAXV") ? std::atoi(std::getenv("T4A_WG_MAXV")) : 16;
+    static const int max_values = diag_env("T4A_WG_MAXV") ? std::atoi(diag_env("T4A_WG_MAXV")) : 16;
     if (rpt * cpw > max_values) return false;
     RrluXcdPlan plan;
     plan.W = 1;

@@ -892,11 +892,43 @@ template <int RPT> void xcd_group_launch_r(const RrluXcdPlan& plan, const RrluXc
 } // namespace
 
 #ifndef T4A_XCD_GROUP_TU
-bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size, int max_w)
+// Plans beyond one XCD's 1024 x 1024 (round 5, kernels_rrlu_xcd2m.hip): up to 1 536 rows (24 row slots per lane) and the columns over
+// the agents of K <= 3 neighbouring XCDs.  Only the instantiations that translation unit compiles: fewest columns per agent first (the
+// update pass is what every agent pays per step), then fewest XCDs (every XCD more is four more key loads per polling lane).
+static bool xcd_make_big_plan(int M, int N, RrluXcdPlan* out)
+{
+    static const bool off = std::getenv("T4A_NO_XCD_BIG") != nullptr;
+    if (off || M < 1 || N < 1 || M > 1536 || N > 1536) return false;
+    const int rpt = M <= 1024 ? 16 : 24;
+    struct Cand { int rpt, cpt, k; };
+    static const Cand cands[] = {{24, 1, 1}, {24, 2, 1}, {24, 2, 2}, {16, 2, 3}, {24, 2, 3}, {16, 3, 2}}; // (sorted by cpt, then k)
+    static const int k_env = std::getenv("T4A_XCD_K") ? std::atoi(std::getenv("T4A_XCD_K")) : 0;
+    for (const Cand& c : cands) {
+        if (c.rpt != rpt) continue;
+        if (k_env > 0 && c.k != k_env) continue;
+        int w = (N + XWAVES * c.cpt * c.k - 1) / (XWAVES * c.cpt * c.k);
+        const int wq = c.k == 3 ? 8 : c.k == 2 ? 4 : 1; // several XCDs: 8 k w agents must be a multiple of 64 (the polling lanes' key loads carry no clamp)
+        w = (w + wq - 1) / wq * wq;
+        if (w > 32) continue;
+        RrluXcdPlan plan;
+        plan.W = w;
+        plan.RPT = c.rpt;
+        plan.CPT = c.cpt;
+        plan.K = c.k;
+        plan.grid = 8 * w;
+        plan.lds_bytes = xcd2_lds_total(c.rpt, c.k);
+        *out = plan;
+        return true;
+    }
+    return false;
+}
+
+bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size, int max_w, bool allow_big)
 {
     if (max_w < 1 || max_w > 32) max_w = 32;
-    if (M < 1 || N < 1 || M > 1024 || N > 1024) return false;
-    static const int min_elems = std::getenv("T4A_XCD_MIN") ? std::atoi(std::getenv("T4A_XCD_MIN")) : 64 * 64;
+    if (M < 1 || N < 1) return false;
+    if (M > 1024 || N > 1024) return allow_big && max_w == 32 && xcd_make_big_plan(M, N, out);
+    static const int min_elems = diag_env("T4A_XCD_MIN") ? std::atoi(diag_env("T4A_XCD_MIN")) : 64 * 64;
     if (!any_size && (long long)M * N <= (long long)min_elems) return false; // tiny matrices: the single-workgroup plan of the chip-wide kernel
     const int rpt = xcd_norm_rpt((M + 63) / 64);
     if (rpt < 0) return false;
@@ -904,9 +936,9 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size, int max_w
     // (update, its share of the search, pivot-row extraction) and the gather is the same four key loads per lane for any
     // number of agents up to 256 (measured per step: 2.0 - 2.2 us with one column per agent, 2.45 us with two, 2.65 us with
     // three; T4A_XCD_COST=old restores the round-2 model that traded columns against 64-agent key groups)
-    static const bool old_cost = std::getenv("T4A_XCD_COST") != nullptr;
-    static const int w_env = std::getenv("T4A_XCD_W") ? std::atoi(std::getenv("T4A_XCD_W")) : 0;
-    static const int cpt_env = std::getenv("T4A_XCD_CPT") ? std::atoi(std::getenv("T4A_XCD_CPT")) : 0;
+    static const bool old_cost = diag_env("T4A_XCD_COST") != nullptr;
+    static const int w_env = diag_env("T4A_XCD_W") ? std::atoi(diag_env("T4A_XCD_W")) : 0;
+    static const int cpt_env = diag_env("T4A_XCD_CPT") ? std::atoi(diag_env("T4A_XCD_CPT")) : 0;
     int best_cpt = -1, best_w = 0;
     long best_cost = 0;
     for (int c = 1; c <= XCD_MAX_CPT; ++c) {
@@ -939,18 +971,18 @@ bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size, int max_w
     // each — and a padded request keeps other kernels' workgroups that only have to RETURN on this XCD, see lu_update_kernel,
     // from being placed at all)
     plan.lds_bytes = xcd_lds_total(rpt);
-    static const bool pad_lds = std::getenv("T4A_XCD_PAD_LDS") != nullptr;
+    static const bool pad_lds = diag_env("T4A_XCD_PAD_LDS") != nullptr;
     if (pad_lds && plan.lds_bytes < 84 * 1024) plan.lds_bytes = 84 * 1024;
     *out = plan;
     return true;
 }
 
-size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan) { return (size_t)4 * plan.W * XWAVES * 16; } // early keys + full keys, two step parities each
+size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan) { return (size_t)4 * plan.K * plan.W * XWAVES * 16; } // early keys + full keys, two step parities each
 size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int)
 {
     // slots are padded to 64 * RPT rows; T4A_XCD_CSTRIDE (experiment, with a library built with -DT4A_X2_CSTRIDE): sparse slots
-    static const size_t cstride = std::getenv("T4A_XCD_CSTRIDE") ? (size_t)std::atol(std::getenv("T4A_XCD_CSTRIDE")) : 256;
-    return (size_t)2 * plan.W * XWAVES * (size_t)(4 * plan.RPT) * (cstride < 256 ? 256 : cstride);
+    static const size_t cstride = diag_env("T4A_XCD_CSTRIDE") ? (size_t)std::atol(diag_env("T4A_XCD_CSTRIDE")) : 256;
+    return (size_t)2 * plan.K * plan.W * XWAVES * (size_t)(4 * plan.RPT) * (cstride < 256 ? 256 : cstride) + (plan.K > 1 ? 256 : 0); // (+ the finalist granules of the XCDs)
 }
 
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)

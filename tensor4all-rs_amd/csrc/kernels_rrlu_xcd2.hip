@@ -31,21 +31,24 @@ namespace t4a {
 namespace {
 
 // LDS layout of one workgroup (compile-time offsets; the tables are sized for the largest matrix of the plan family)
-template <int RPT> struct Xcd2Lds {
+template <int RPT, int KX = 1> struct Xcd2Lds {
     static constexpr int LSTR = xcd_lstr(RPT);
+    static constexpr int TBL = xcd2_tbl(RPT, KX);            // entries of the position tables / pivot values (matrices beyond 1024 rows: round 5)
     static constexpr int o_l = 0;                        // double [64][LSTR]: l of row lane + 64 r at lane * LSTR + r
     static constexpr int o_wd = o_l + 64 * LSTR * 8;     // (16 bytes, unused)
-    static constexpr int o_wi = o_wd + 16;               // int [16]: [0] stop verdict [1] give-up (any wave) [3] rank [4..7] record of the step: winning agent | give-up << 30, winner's value lo / hi, meta
+    static constexpr int o_wi = o_wd + 16;               // int [16]: [0] stop verdict [1] give-up (any wave) [3] rank [4..7] record of the step: winning agent | give-up << 30, winner's value lo / hi, meta; [8..11], [12..15] (agents on several XCDs): what the polling waves of XCD 1 / 2 found
     static constexpr int o_pp = o_wi + 64;               // u64 [2]: iresult / h_block pointers for the give-up paths
     static constexpr int o_st = o_pp + 16;               // u64 [16] phase stamps (diagnostic builds)
-    static constexpr int o_pv = o_st + 128;              // double [1024] pivot values of this launch
-    static constexpr int o_pr = o_pv + 1024 * 8;         // u16 [1024] position -> row index
-    static constexpr int o_rp = o_pr + 1024 * 2;         // u16 [1024] row index -> position
-    static constexpr int o_pc = o_rp + 1024 * 2;         // u16 [1024] position -> column index
-    static constexpr int o_cp = o_pc + 1024 * 2;         // u16 [1024] column index -> position
-    static constexpr int bytes = o_cp + 1024 * 2;
+    static constexpr int o_pv = o_st + 128;              // double [TBL] pivot values of this launch
+    static constexpr int o_pr = o_pv + TBL * 8;          // u16 [TBL] position -> row index
+    static constexpr int o_rp = o_pr + TBL * 2;          // u16 [TBL] row index -> position
+    static constexpr int o_pc = o_rp + TBL * 2;          // u16 [TBL] position -> column index
+    static constexpr int o_cp = o_pc + TBL * 2;          // u16 [TBL] column index -> position
+    static constexpr int bytes = o_cp + TBL * 2;
 };
 static_assert(Xcd2Lds<12>::bytes == (int)xcd_lds_total(12), "plan.lds_bytes must cover the layout");
+static_assert(Xcd2Lds<24>::bytes == (int)xcd2_lds_total(24), "plan.lds_bytes must cover the layout (plans beyond 1024 rows)");
+static_assert(Xcd2Lds<16, 3>::bytes == (int)xcd2_lds_total(16, 3), "plan.lds_bytes must cover the layout (plans beyond 1024 columns)");
 
 #ifndef T4A_XCD_STAMP_WAVE
 #define T4A_XCD_STAMP_WAVE 0
@@ -67,19 +70,31 @@ static_assert(Xcd2Lds<12>::bytes == (int)xcd_lds_total(12), "plan.lds_bytes must
 #define T4A_X2_POLLEARLY 0
 #endif
 
-// full-key meta word (second generation): bits 0..9 row index of the candidate, 10..11 column slot of the publishing agent,
-// bit 12 the agent has a candidate.  Positions are NOT carried: whoever needs one reads the LDS tables (the polling wave behind
-// its stop test; the exact comparison of the rare paths).
-constexpr unsigned X2_META_VALID = 1u << 12;
+// full-key meta word (second generation): bits 0..10 row index of the candidate (up to 1536 rows since round 5), 11..12 column slot
+// of the publishing agent, bit 13 the agent has a candidate.  Positions are NOT carried: whoever needs one reads the LDS tables (the
+// polling wave behind its stop test; the exact comparison of the rare paths).  Position keys of the exact paths: 11 + 11 bits.
+constexpr unsigned X2_META_VALID = 1u << 13;
+constexpr unsigned X2_ROW_MASK = 2047u;
+constexpr int X2_QSHIFT = 11, X2_PSHIFT = 11;
 
 constexpr int X2_DIVW = XWAVES - 1; // waves that divide the pivot column (all but the polling wave)
 
-template <int RPT, int CPT, bool ROWMAJOR>
+// KX: XCDs the agents live on (round 5).  1: everything inside one XCD's L2 (plain stores, sc1 loads).  > 1: the agents of KX
+// neighbouring XCDs (p.xcc, p.xcc + 1, ... mod 8) — matrices beyond the registers of one XCD, BASELINE.json configs[3]: 1 450 x 1 450
+// with the history extras — exchange through the same mailbox with write-through (sc1) stores; the L2s are kept coherent for such
+// lines by the fabric, but a hop across it costs 3 - 4 times the intra-XCD one (measured: ~4 000 cycles from a remote agent's key
+// store to a polling wave seeing it when all 8 KX W keys cross).  So the arg-max runs in TWO LEVELS: every workgroup's polling wave
+// gathers only the early keys of ITS OWN XCD (an exchange inside one L2, exactly the single-XCD protocol) and names that XCD's
+// finalist; ONE 16-byte finalist granule per XCD crosses the fabric (published by the workgroup of local rank 0), and every polling
+// wave compares the KX finalists.  The winner's column crosses as before (write-through stores, speculative publication).
+template <int RPT, int CPT, bool ROWMAJOR, int KX = 1>
 __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluXcdArgs* pk)
 {
     static_assert(XWAVES == 8, "the second-generation kernel is written for eight waves per workgroup");
+    static_assert(KX >= 1 && KX <= 3, "instantiated for up to three XCDs");
+    constexpr int ST_AUX = KX > 1 ? BUF_SC1 : 0;   // mailbox stores: write-through when other XCDs read them
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    using L = Xcd2Lds<RPT>;
+    using L = Xcd2Lds<RPT, KX>;
     constexpr int LSTR = L::LSTR;
     constexpr int MP = 64 * RPT; // rows of a published column slot (rows beyond M carry zeros)
     double* const lbuf = reinterpret_cast<double*>(smem_raw + L::o_l);
@@ -100,14 +115,24 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
     // ---- election: only the workgroups that landed on the wanted XCD take part ----
     if (tid == 0) {
         int rank = -1;
-        if ((int)xcc_id() == p.xcc) {
-            const unsigned t = atomicAdd(p.ticket, 1u) - p.ticket_base;
-            if (t < (unsigned)p.W) rank = (int)t;
+        if constexpr (KX == 1) {
+            if ((int)xcc_id() == p.xcc) {
+                const unsigned t = atomicAdd(p.ticket, 1u) - p.ticket_base;
+                if (t < (unsigned)p.W) rank = (int)t;
+            }
+        } else {
+            // every workgroup of the launch takes a ticket from the counter of the XCD it landed on (8 counters, each advances by
+            // grid / 8 per launch); those on the KX elected XCDs become ranks xi W + ticket
+            const unsigned x = xcc_id() & 7u;
+            const unsigned t = atomicAdd(p.ticket + x, 1u) - p.ticket_base;
+            const unsigned xi = (x - (unsigned)p.xcc) & 7u;
+            if (xi < (unsigned)KX && t < (unsigned)p.W) rank = (int)(xi * (unsigned)p.W + t);
         }
         ctl[3] = rank;
         ctl[0] = 0;
         ctl[1] = 0;
         ctl[2] = 0;
+        for (int e = 8; e < 16; ++e) ctl[e] = 0;
         lds_ptrs[0] = (unsigned long long)p.iresult;
         lds_ptrs[1] = (unsigned long long)p.h_block;
         for (int e = 0; e < 16; ++e) lds_stamps[e] = 0ull;
@@ -125,8 +150,12 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
     }
     const unsigned long long ts_begin = p.ts_u64 > 0 ? wall_clock64() : 0ull;
     const unsigned long long t_elected = (kXcdStamps && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
-    const int NW = p.W * XWAVES;
+    const int NWL = p.W * XWAVES;  // agents of one XCD: what one polling wave gathers
+    const int NW = KX * NWL;
     const int g = rank * XWAVES + wave; // agent id
+    const bool poller = wave == 0;     // the polling wave: gathers the early keys of ITS XCD's 8 W agents
+    const int xi = KX > 1 ? rank / p.W : 0; // which of the KX XCDs this workgroup sits on
+    const int pbase = xi * NWL;
     // bond chain: the real dimensions come from device memory (the launch was planned for the upper bounds p.M x p.N: rows
     // beyond M are padding zeros like those beyond p.M always were, columns beyond N have no owner)
     int M = p.M, N = p.N, max_steps = p.max_steps;
@@ -151,7 +180,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
 #pragma unroll
     for (int q = 0; q < CPT; ++q)
         if (g + NW * q < N) active |= 1u << q;
-    xvec<RPT> a[CPT]; // ext vectors: the run-time row-slot accesses become s_set_gpr_idx moves
+    XSlab<RPT> a[CPT]; // ext vectors (two per column beyond 16 row slots): the run-time row-slot accesses become s_set_gpr_idx moves
     double local_sqmax = 0.0;
     bool bad = false; // a NaN or an infinity among my entries of the input
     // every load is issued before the first one is consumed (clamped addresses instead of branches): the whole matrix is
@@ -175,7 +204,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
         const double* const colp = p.A + (cok ? (size_t)(g + NW * q) * lda : (size_t)0);
         const unsigned rm = (unsigned)opaque_v((int)rowmask);
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) a[q][r] = colp[(cok && ((rm >> r) & 1u)) ? srow[r] : 0];
+        for (int r = 0; r < RPT; ++r) a[q].set(r, colp[(cok && ((rm >> r) & 1u)) ? srow[r] : 0]);
     }
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
@@ -184,11 +213,11 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const bool ok = cok && ((rm >> r) & 1u);
-            const double v = ok ? a[q][r] : 0.0;
+            const double v = ok ? a[q].get(r) : 0.0;
             const double sqv = v * v; // max sqrt(v*v) == sqrt(max v*v): one square root per lane below
             if (sqv > local_sqmax) local_sqmax = sqv; // (NaN never enters, like the branchy form)
             bad |= !((v - v) == 0.0);                 // inf - inf and NaN - NaN are NaN
-            a[q][r] = v;
+            a[q].set(r, v);
         }
     }
     for (int i = tid; i < M; i += XT) {
@@ -216,8 +245,9 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
     // resource for every store and load of the exchange)
     const unsigned k2_base = 2u * (unsigned)NW * 16u;
     const unsigned cols_base = 4u * (unsigned)NW * 16u;
+    const unsigned fin_base = cols_base + 2u * (unsigned)NW * (unsigned)(MP / 16) * (unsigned)T4A_X2_CSTRIDE; // [2][KX] finalist granules (agents on several XCDs)
     const __amdgpu_buffer_rsrc_t mail =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(cols_base + 2u * (unsigned)NW * (unsigned)(MP / 16) * (unsigned)T4A_X2_CSTRIDE), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(fin_base + 2u * (unsigned)KX * 16u), 0x00020000);
 
     int npiv = 0;
     double max_error = 0.0;             // kept by the polling waves
@@ -242,8 +272,8 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             double m0 = -1.0, m1 = -1.0;
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                if (r & 1) m1 = vmax_abs(m1, a[q][r]);
-                else m0 = vmax_abs(m0, a[q][r]);
+                if (r & 1) m1 = vmax_abs(m1, a[q].get(r));
+                else m0 = vmax_abs(m0, a[q].get(r));
             }
             mq[q] = vmax(m0, m1);
         }
@@ -277,7 +307,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             kv.y = hi32(k1);
             kv.z = wave_bad;
             kv.w = tag ^ kv.x ^ kv.y ^ kv.z;
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0);
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, ST_AUX);
         }
         u32x4 kg[4], kh[4];
         bool kg_issued = false;
@@ -297,10 +327,10 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     nhit += __builtin_popcountll(bq[q]);
                 }
 #if T4A_X2_POLLEARLY
-                if (wave == 0) {
+                if (poller) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                        kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
                     kg_issued = true;
                 }
 #endif
@@ -314,13 +344,13 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                             unsigned bits = 0u;
 #pragma unroll
                             for (int r = 0; r < RPT; ++r)
-                                asm("v_cmp_eq_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"((double)a[q][r]), "s"(wmax) : "vcc");
+                                asm("v_cmp_eq_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"((double)a[q].get(r)), "s"(wmax) : "vcc");
                             const unsigned hb_ = (unsigned)__builtin_amdgcn_readlane((int)bits, hl);
                             if (__builtin_popcount(hb_) == 1) {
                                 const int rstar = RPT - 1 - (int)__builtin_ctz(hb_);
                                 cirow = hl + 64 * rstar;
                                 has_cand = true;
-                                cval = readlane_f64(a[q][rstar], hl);
+                                cval = readlane_f64(a[q].dyn(rstar), hl);
                                 qstar = q;
                                 done = true;
                             }
@@ -338,12 +368,10 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     const bool qhit = (mq[q] >= 0.0) & (mq[q] * mq[q] == sq);
                     if (__ballot(qhit) != 0ull) {
                         const unsigned cp_ = colpos[opaque_s(g + NW * q)];
-#pragma unroll
-                        for (int r = 0; r < RPT; ++r) {
+                        auto sweep = [&](int r, double av) {
                             const int i = lane_o + 64 * r;
                             const unsigned rp_ = rowpos[i < M_o ? i : 0];
-                            const unsigned key = ROWMAJOR ? ((rp_ << 10) | cp_) : ((cp_ << 10) | rp_);
-                            const double av = a[q][r];
+                            const unsigned key = ROWMAJOR ? ((rp_ << X2_PSHIFT) | cp_) : ((cp_ << X2_PSHIFT) | rp_);
                             const double sc = av * av;
                             const bool hit = qhit & (i < M_o) & ((int)rp_ > k) & (sc == sq);
                             if (hit && key < mypos) {
@@ -352,6 +380,15 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                                 myrow = i;
                                 myq = q;
                             }
+                        };
+                        if constexpr (RPT <= 16) {
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) sweep(r, a[q].get(r));
+                        } else {
+                            // (24 slots unrolled keep two dozen table reads in flight beside a 96-register slab: this rare path then
+                            // decides the register allocation of the whole step loop — a rolled loop with run-time slot access instead)
+#pragma unroll 1
+                            for (int r = 0; r < RPT; ++r) sweep(r, a[q].dyn(opaque_s(r)));
                         }
                     }
                 }
@@ -369,38 +406,38 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
         XSTAMP(1);
         // ---- full key: value, position, row index, column slot (all fields are wave-uniform) ----
         {
-            const unsigned meta = (unsigned)cirow | ((unsigned)qstar << 10) | (has_cand ? X2_META_VALID : 0u);
+            const unsigned meta = (unsigned)cirow | ((unsigned)qstar << X2_QSHIFT) | (has_cand ? X2_META_VALID : 0u);
             u32x4 kv;
             kv.x = lo32(cval);
             kv.y = hi32(cval);
             kv.z = meta;
             kv.w = tag ^ kv.x ^ kv.y ^ meta;
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, (int)k2_base + kslot, 0, 0);
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, (int)k2_base + kslot, 0, ST_AUX);
         }
         // the polling wave sweeps the early keys now — they left their agents a whole position search ago, so this first sweep
         // normally finds them all.  Every lane fetches four keys; lanes beyond NW re-read the last key (a valid duplicate), so
         // neither the arrival check nor the maximum needs a mask or a count of live groups.
-        if (wave == 0 && !kg_issued) {
+        if (poller && !kg_issued) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
         }
         // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
         // keys have been gathered
-        const bool early_pub = (wave != 0) && has_cand && (sq >= spec_frac * prev_sq); // (the polling wave never stores a column early: those stores would sit in front of its key loads)
+        const bool early_pub = !poller && has_cand && (sq >= spec_frac * prev_sq); // (a polling wave never stores a column early: those stores would sit in front of its key loads)
         constexpr int CS = T4A_X2_CSTRIDE, SLOTB = (MP / 16) * CS; // chunk stride / bytes of a column slot
         const int myslot = (int)cols_base + (par * NW + g) * SLOTB + (lane >> 4) * CS + (lane & 15) * 16; // byte offset of my row `lane` in the mailbox
         if (early_pub) {
-            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag, 4 * CS);
-            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag, 4 * CS);
-            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag, 4 * CS);
-            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag, 4 * CS);
+            if (qstar == 0) xcd_publish_column<0, RPT, ST_AUX>(a[0], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT, ST_AUX>(a[1], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT, ST_AUX>(a[2], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT, ST_AUX>(a[3], mail, myslot, tag, 4 * CS);
         }
         XSTAMP(2);
 
-        // ---- wave 0 gathers the NW early keys and names the winner (matrixlu.rs:480-519 across agents) ----
-        if (wave == 0) {
+        // ---- the polling wave(s) gather the early keys and name the winner (matrixlu.rs:480-519 across agents) ----
+        if (poller) {
             unsigned spins = 0;
             int giveup = 0; // 1: a hand-off did not arrive  2: non-finite values (the caller runs the first-generation kernel)
             XSTAMP(6);
@@ -416,13 +453,13 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                    kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
             }
             if (stamp_on) lds_stamps[5] += spins;
             // the full keys: fetched now, in flight while the early ones are examined (a late one is fetched again below)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
             XSTAMP(8);
             int wa_ = 0;
             unsigned wkx = 0u, wky = 0u, wkz = 0u; // the winner's full key
@@ -485,7 +522,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                                         giveup = 1;
                                         break;
                                     }
-                                    kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                                    kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
                                 }
                             }
                         decided = true;
@@ -495,6 +532,12 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                 }
                 (void)gm;
                 XSTAMP(14);
+                if constexpr (KX > 1) {
+                    if (!decided && !giveup) {
+                        wkz = 0x80000000u; // (wave 0 walks all full keys: ties across XCDs need every agent, not only this XCD's)
+                        decided = true;
+                    }
+                }
                 if (!decided && !giveup) {
                     // ties between agents, zero / subnormal scores: exact comparison of (v*v, position key) over the FULL keys;
                     // an agent without candidate carries value 0 and the largest position key
@@ -510,7 +553,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane + 64 * j, NW - 1)) * 16, 0, BUF_SC1);
+                            kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
                     }
                     double csc = -1.0;
                     unsigned cpk = XNOPOS;
@@ -521,12 +564,12 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     for (int j = 0; j < 4; ++j) {
                         const int ag = lane_o + 64 * j;
                         // position key of the candidate from the tables of this workgroup (every workgroup keeps the same ones)
-                        const unsigned rp_ = rowpos[kh[j].z & 1023u], cp_ = colpos[min(ag + NW * (int)((kh[j].z >> 10) & 3u), N - 1)];
-                        const unsigned pkey = ROWMAJOR ? ((rp_ << 10) | cp_) : ((cp_ << 10) | rp_);
-                        const unsigned pk = ((ag < NW) && (kh[j].z & X2_META_VALID)) ? pkey : XNOPOS;
+                        const unsigned rp_ = rowpos[kh[j].z & X2_ROW_MASK], cp_ = colpos[min(pbase + ag + NW * (int)((kh[j].z >> X2_QSHIFT) & 3u), N - 1)];
+                        const unsigned pkey = ROWMAJOR ? ((rp_ << X2_PSHIFT) | cp_) : ((cp_ << X2_PSHIFT) | rp_);
+                        const unsigned pk = ((ag < NWL) && (kh[j].z & X2_META_VALID)) ? pkey : XNOPOS;
                         const double v = mk_f64(kh[j].x, kh[j].y);
                         double sc = v * v;
-                        sc = (ag < NW) ? sc : -2.0;
+                        sc = (ag < NWL) ? sc : -2.0;
                         const bool better = (sc > csc) | ((sc == csc) & (pk < cpk));
                         csc = better ? sc : csc;
                         cpk = better ? pk : cpk;
@@ -545,7 +588,117 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     wkz = (unsigned)__builtin_amdgcn_readlane((int)ckey.z, wl);
                 }
             }
-            if (lane == 0) {
+            wa_ += pbase; // (agent numbers are global from here on)
+            if constexpr (KX > 1) {
+                {
+                    // ---- the finalists of the KX XCDs.  Every workgroup of an XCD has just named the SAME local winner from that XCD's
+                    // 8 W early keys (an exchange inside one L2); only that one key per XCD crosses the fabric: the workgroup of local
+                    // rank 0 publishes it (write-through), every polling wave reads the KX - 1 remote ones.  (Round 5, first version: every
+                    // polling wave gathered all 8 KX W keys itself — 4 700 cycles per step waiting for remote keys, 1.2 MB of polling
+                    // reads per round through the fabric; profiles/r05_xcd2m_phase_stamps.txt.)
+                    // finalist granule: {value lo, value hi, meta | agent << 14 | give-up << 26 | undecided << 31, tag ^ fold}
+                    bool need_exact = (wkz >> 31) != 0u; // (this XCD could not decide on its early keys alone)
+                    const int fslot = (int)fin_base + (par * KX) * 16;
+                    if (rank == xi * p.W && lane == 0) {
+                        u32x4 fv;
+                        fv.x = wkx;
+                        fv.y = wky;
+                        fv.z = (wkz & 0x80003FFFu) | ((unsigned)wa_ << 14) | ((unsigned)giveup << 26);
+                        fv.w = tag ^ fv.x ^ fv.y ^ fv.z;
+                        __builtin_amdgcn_raw_buffer_store_b128(fv, mail, fslot + xi * 16, 0, ST_AUX);
+                    }
+                    double best = __builtin_fabs(mk_f64(wkx, wky));
+                    {
+                        // lane x reads XCD x's finalist (lanes beyond KX and the own XCD's lane re-read a remote one: a valid duplicate)
+                        const int xr = (lane < KX && lane != xi) ? lane : (xi == 0 ? 1 : 0);
+                        u32x4 fr = __builtin_amdgcn_raw_buffer_load_b128(mail, fslot + xr * 16, 0, BUF_SC1);
+                        unsigned sp2 = 0;
+                        for (;;) {
+                            if (__all((fr.x ^ fr.y ^ fr.z ^ fr.w) == tag)) break;
+                            xcd_poll_again();
+                            if (++sp2 > XSPIN) {
+                                giveup = giveup ? giveup : 1;
+                                break;
+                            }
+                            fr = __builtin_amdgcn_raw_buffer_load_b128(mail, fslot + xr * 16, 0, BUF_SC1);
+                        }
+                        if (stamp_on) lds_stamps[15] += sp2;
+#pragma unroll
+                        for (int x = 0; x < KX; ++x) {
+                            if (x == xi) continue; // (uniform)
+                            const unsigned fx = (unsigned)__builtin_amdgcn_readlane((int)fr.x, x), fy = (unsigned)__builtin_amdgcn_readlane((int)fr.y, x),
+                                           fz = (unsigned)__builtin_amdgcn_readlane((int)fr.z, x);
+                            const int fg = (int)((fz >> 26) & 3u);
+                            if (fg) giveup = (giveup == 2 || fg == 2) ? 2 : 1;
+                            need_exact |= (fz >> 31) != 0u;
+                            const double fval = __builtin_fabs(mk_f64(fx, fy));
+                            need_exact |= fval == best;
+                            if (fval > best) {
+                                best = fval;
+                                wa_ = (int)((fz >> 14) & 0xFFFu);
+                                wkx = fx;
+                                wky = fy;
+                                wkz = fz;
+                            }
+                        }
+                    }
+                    if (need_exact && !giveup) {
+                        // exact comparison of (v*v, position key) over ALL full keys, four per lane at a time (slow, rare, exact): an
+                        // agent without candidate carries value 0 and the largest position key; an infinite score ends the launch
+                        double csc = -1.0;
+                        unsigned cpk = XNOPOS;
+                        int cag = 0;
+                        unsigned cx = 0u, cy = 0u, cz = 0u;
+                        const int lane_o = opaque_v(lane);
+#pragma unroll 1
+                        for (int j0 = 0; j0 < 4 * KX && !giveup; j0 += 4) {
+                            u32x4 kq[4];
+                            for (;;) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    kq[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane_o + 64 * (j0 + j), NW - 1)) * 16, 0, BUF_SC1);
+                                bool ok = true;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) ok &= ((kq[j].x ^ kq[j].y ^ kq[j].z ^ kq[j].w) == tag);
+                                if (__all(ok)) break;
+                                xcd_poll_again();
+                                if (++spins > XSPIN) {
+                                    giveup = 1;
+                                    break;
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int ag = lane_o + 64 * (j0 + j);
+                                const unsigned rp_ = rowpos[kq[j].z & X2_ROW_MASK], cp_ = colpos[min(ag + NW * (int)((kq[j].z >> X2_QSHIFT) & 3u), N - 1)];
+                                const unsigned pkey = ROWMAJOR ? ((rp_ << X2_PSHIFT) | cp_) : ((cp_ << X2_PSHIFT) | rp_);
+                                const unsigned pk = ((ag < NW) && (kq[j].z & X2_META_VALID)) ? pkey : XNOPOS;
+                                const double v = mk_f64(kq[j].x, kq[j].y);
+                                double sc = v * v;
+                                sc = (ag < NW) ? sc : -2.0;
+                                const bool better = (sc > csc) | ((sc == csc) & (pk < cpk));
+                                csc = better ? sc : csc;
+                                cpk = better ? pk : cpk;
+                                cag = better ? ag : cag;
+                                cx = better ? kq[j].x : cx;
+                                cy = better ? kq[j].y : cy;
+                                cz = better ? kq[j].z : cz;
+                            }
+                        }
+                        const double gmax = wave_max_f64(csc);
+                        if (!(gmax < __builtin_huge_val()) && !giveup) giveup = 2;
+                        const unsigned gpos = wave_min_u32((csc == gmax) ? cpk : XNOPOS);
+                        const unsigned long long sel = __ballot((csc == gmax) & (cpk == gpos));
+                        const int wl = sel ? (int)__builtin_ctzll(sel) : 0;
+                        wa_ = __builtin_amdgcn_readlane(cag, wl);
+                        wkx = (unsigned)__builtin_amdgcn_readlane((int)cx, wl);
+                        wky = (unsigned)__builtin_amdgcn_readlane((int)cy, wl);
+                        wkz = (unsigned)__builtin_amdgcn_readlane((int)cz, wl);
+                    }
+                    wkz &= 0x3FFFu; // (row index, column slot, valid bit)
+                }
+            }
+            if (wave == 0 && lane == 0) {
                 if (giveup) {
                     ctl[1] = giveup;
                     atomicExch(reinterpret_cast<int*>(lds_ptrs[0]) + 1, giveup);
@@ -575,10 +728,10 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
         const int wag = (int)recw;
         // the winner did not speculate: its column goes out now
         if (g == wag && !early_pub) {
-            if (qstar == 0) xcd_publish_column<0, RPT>(a[0], mail, myslot, tag, 4 * CS);
-            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT>(a[1], mail, myslot, tag, 4 * CS);
-            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT>(a[2], mail, myslot, tag, 4 * CS);
-            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT>(a[3], mail, myslot, tag, 4 * CS);
+            if (qstar == 0) xcd_publish_column<0, RPT, ST_AUX>(a[0], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 1) if (qstar == 1) xcd_publish_column<1, RPT, ST_AUX>(a[1], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 2) if (qstar == 2) xcd_publish_column<2, RPT, ST_AUX>(a[2], mail, myslot, tag, 4 * CS);
+            if constexpr (CPT > 3) if (qstar == 3) xcd_publish_column<3, RPT, ST_AUX>(a[3], mail, myslot, tag, 4 * CS);
         }
         // everybody fetches the winner's full key (one granule, the same for all lanes) and — waves 1 .. 7 — its rows of the
         // winner's column: lane + 64 (sr0 + 7 j)
@@ -599,13 +752,13 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
         if (wave == 0) {
             rk_ = posrow[kn];
             ck_ = poscol[kn];
-            prp_ = rowpos[rec.w & 1023];
-            pcp_ = colpos[min(wag + NW * ((rec.w >> 10) & 3), N - 1)];
+            prp_ = rowpos[rec.w & (int)X2_ROW_MASK];
+            pcp_ = colpos[min(wag + NW * ((rec.w >> X2_QSHIFT) & 3), N - 1)];
         }
         const double wval = mk_f64((unsigned)__builtin_amdgcn_readfirstlane(rec.y), (unsigned)__builtin_amdgcn_readfirstlane(rec.z));
         const unsigned wmeta = (unsigned)__builtin_amdgcn_readfirstlane(rec.w);
-        const int irow_p = (int)(wmeta & 1023u);
-        const int qslot = (int)((wmeta >> 10) & 3u);
+        const int irow_p = (int)(wmeta & X2_ROW_MASK);
+        const int qslot = (int)((wmeta >> X2_QSHIFT) & 3u);
         XSTAMP(10);
         // (the shared reciprocal of the pivot does not depend on the column: it is formed while the column travels)
         const bool p_mid = exp_mid(wval);
@@ -622,7 +775,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             // is never used)
             double ue[CPT];
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) ue[q] = a[q][rs];
+            for (int q = 0; q < CPT; ++q) ue[q] = a[q].dyn(rs);
 #pragma unroll
             for (int q = 0; q < CPT; ++q) u[q] = readlane_f64(ue[q], ls);
             if (p.urows) {
@@ -733,11 +886,14 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             int zero = 0;
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(fl) : "v"(zero), "n"(L::o_wi) : "memory");
         }
-        xvec<RPT> l;
+        // (plans with more than 16 row slots read and apply l in two halves: 2 x 24 l registers beside a 96-register slab spilled)
+        constexpr int NH = RPT > 16 ? 2 : 1, HR = RPT / NH;
+        static_assert(RPT % NH == 0, "row slots split evenly into the halves of the l read");
+        xvec<HR> l;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) l[r] = lbuf[lane * LSTR + r];
+        for (int r = 0; r < HR; ++r) l[r] = lbuf[lane * LSTR + r];
         {
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fl) : "n"((RPT + 1) / 2) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fl) : "n"((HR + 1) / 2) : "memory");
             if (__builtin_amdgcn_readfirstlane(fl.y)) {
                 timed_out = true;
                 break;
@@ -750,24 +906,56 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
         // fused with the per-column maxima for the next arg-max; the pivot column keeps its un-scaled entries (L = column /
         // pivot is formed when the factored matrix is written out — the column is never read again)
         // =====================================================================================
+        if constexpr (NH == 1) {
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            mq[q] = -1.0;
-            if (active & (1u << q)) {
+            for (int q = 0; q < CPT; ++q) {
+                mq[q] = -1.0;
+                if (active & (1u << q)) {
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) { // in place (see sub_in_place); un-fused, one rounding per operation like the reference
-                    double t = a[q][r];
-                    sub_in_place(t, l[r] * u[q]);
-                    a[q][r] = t;
+                    for (int r = 0; r < RPT; ++r) { // in place (see sub_in_place); un-fused, one rounding per operation like the reference
+                        double t = a[q].get(r);
+                        sub_in_place(t, l[r] * u[q]);
+                        a[q].set(r, t);
+                    }
+                    double m0 = -1.0, m1 = -1.0;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        if (r & 1) m1 = vmax_abs(m1, a[q].get(r));
+                        else m0 = vmax_abs(m0, a[q].get(r));
+                    }
+                    mq[q] = vmax(m0, m1);
                 }
-                double m0 = -1.0, m1 = -1.0;
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    if (r & 1) m1 = vmax_abs(m1, a[q][r]);
-                    else m0 = vmax_abs(m0, a[q][r]);
-                }
-                mq[q] = vmax(m0, m1);
             }
+        } else {
+            double m0[CPT], m1[CPT];
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) m0[q] = m1[q] = -1.0;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                if (h > 0) {
+                    asm volatile("" ::: "memory"); // (the second half of l is read only now: its registers are the first half's)
+#pragma unroll
+                    for (int r = 0; r < HR; ++r) l[r] = lbuf[lane * LSTR + h * HR + r];
+                }
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    if (active & (1u << q)) {
+#pragma unroll
+                        for (int r = 0; r < HR; ++r) {
+                            double t = a[q].get(h * HR + r);
+                            sub_in_place(t, l[r] * u[q]);
+                            a[q].set(h * HR + r, t);
+                        }
+#pragma unroll
+                        for (int r = 0; r < HR; ++r) {
+                            if (r & 1) m1[q] = vmax_abs(m1[q], a[q].get(h * HR + r));
+                            else m0[q] = vmax_abs(m0[q], a[q].get(h * HR + r));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) mq[q] = (active & (1u << q)) ? vmax(m0[q], m1[q]) : -1.0;
         }
         npiv = kn + 1;
         XSTAMP(0);
@@ -829,7 +1017,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             if (g + NW * q < Ne && i < Me) {
                 const int cp = colpos[g + NW * q], rp = rowpos[i];
                 const bool from_u = (rp < npiv) && (cp >= rp);
-                double v = a[q][r];
+                double v = a[q].get(r);
                 const bool in_l = (cp < npiv) && (rp > cp);
                 if (in_l) { // scale_column_tail (matrixlu.rs:562-577), deferred: the same division the step itself used
                     const double pv = lds_pivots[cp];
@@ -884,7 +1072,29 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
     }
 }
 
-#ifndef T4A_XCD_GROUP_TU
+#if defined(T4A_XCD2_MULTI_TU)
+template <int RPT, int CPT, bool ROWMAJOR, int KX>
+__global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd2m_kernel(RrluXcdArgs p)
+{
+    rrlu_xcd2_body<RPT, CPT, ROWMAJOR, KX>(p, reinterpret_cast<const RrluXcdArgs*>(kernarg_base()));
+}
+template <int RPT, int CPT, bool ROWMAJOR, int KX> void xcd2m_launch_tie(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    static std::once_flag attr_once; // (launches come from several host threads)
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rrlu_xcd2m_kernel<RPT, CPT, ROWMAJOR, KX>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL((rrlu_xcd2m_kernel<RPT, CPT, ROWMAJOR, KX>), dim3(plan.grid), dim3(XT), plan.lds_bytes, stream, a);
+}
+template <int RPT, int CPT, int KX> bool xcd2m_launch_rc(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    if (plan.RPT != RPT || plan.CPT != CPT || plan.K != KX) return false;
+    if (a.tie_row_major) xcd2m_launch_tie<RPT, CPT, true, KX>(plan, a, stream);
+    else xcd2m_launch_tie<RPT, CPT, false, KX>(plan, a, stream);
+    return true;
+}
+#elif !defined(T4A_XCD_GROUP_TU)
 template <int RPT, int CPT, bool ROWMAJOR>
 __global__ void __launch_bounds__(XT) __attribute__((amdgpu_waves_per_eu(XWAVES / 4, XWAVES / 4))) rrlu_xcd2_kernel(RrluXcdArgs p)
 {
@@ -955,7 +1165,16 @@ template <int RPT> void xcd2_group_launch_r(const RrluXcdPlan& plan, const RrluX
 
 } // namespace
 
-#ifndef T4A_XCD_GROUP_TU
+#if defined(T4A_XCD2_MULTI_TU)
+// the plans rrlu_xcd_make_plan(..., allow_big) hands out (kernels_rrlu_xcd.hip): one XCD with 24 row slots, or three XCDs
+void rrlu_xcd2m_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
+{
+    const bool ok = xcd2m_launch_rc<24, 1, 1>(plan, a, stream) || xcd2m_launch_rc<24, 2, 1>(plan, a, stream) ||
+                    xcd2m_launch_rc<16, 2, 3>(plan, a, stream) || xcd2m_launch_rc<24, 2, 3>(plan, a, stream) ||
+                    xcd2m_launch_rc<16, 3, 2>(plan, a, stream) || xcd2m_launch_rc<24, 2, 2>(plan, a, stream);
+    if (!ok) throw std::runtime_error("no kernel instantiation for this multi-XCD rrLU plan");
+}
+#elif !defined(T4A_XCD_GROUP_TU)
 void rrlu_xcd2_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)
 {
     switch (plan.RPT) {

@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <mutex>
+#include <stdexcept>
 
 namespace t4a {
 
@@ -200,6 +201,9 @@ template <int RPT> struct XcdLds {
     static constexpr int bytes = o_pc + 1024 * 2;
 };
 constexpr size_t xcd_lds_total(int rpt) { return (size_t)64 * xcd_lstr(rpt) * 8 + 16 + 64 + 16 + 128 + 1024 * 8 + 4 * 1024 * 2; } // (the fourth table, column index -> position, belongs to the second-generation kernel)
+// second generation, round 5: plans beyond 1024 rows (RPT > 16) or 1024 columns (agents on several XCDs) carry tables of 2048 entries
+__host__ __device__ constexpr int xcd2_tbl(int rpt, int kx = 1) { return (rpt > 16 || kx > 1) ? 2048 : 1024; }
+constexpr size_t xcd2_lds_total(int rpt, int kx = 1) { return (size_t)64 * xcd_lstr(rpt) * 8 + 16 + 64 + 16 + 128 + (size_t)xcd2_tbl(rpt, kx) * 8 + 4 * (size_t)xcd2_tbl(rpt, kx) * 2; }
 
 // a value the optimiser must treat as unknown: keeps loop-invariant masks / addresses of RARE paths from being hoisted out of
 // the step loop into scalar registers (the kernel is bound by its scalar register file: every hoisted lane mask is a pair)
@@ -227,10 +231,45 @@ __device__ __forceinline__ void sub_in_place(double& a, double prod) // a = a - 
 }
 template <int N> using xvec = double __attribute__((ext_vector_type(N)));
 
+// The row slots of one owned column (second generation): one register tuple up to 16 slots.  A tuple of 24 doubles (48 registers) is
+// not an indexable register class — the compiler copies such a block to scratch memory and loads the element back, in every step —
+// so larger columns are TWO tuples of RPT / 2 slots; a run-time slot index picks the tuple with a (wave-uniform) select.
+template <int RPT> struct XSlab {
+    static constexpr int NV = RPT > 16 ? 2 : 1, HV = RPT / NV;
+    static_assert(RPT == NV * HV, "row slots split evenly over the tuples");
+    xvec<HV> h[NV];
+    __device__ __forceinline__ double get(int r) const { return h[r / HV][r % HV]; } // (r is a constant after unrolling)
+    __device__ __forceinline__ void set(int r, double v) { h[r / HV][r % HV] = v; }
+    __device__ __forceinline__ double dyn(int idx) const // wave-uniform run-time slot
+    {
+        if constexpr (NV == 1) {
+            return h[0][idx];
+        } else {
+            const double lo = h[0][idx < HV ? idx : 0], hi = h[1][idx >= HV ? idx - HV : 0];
+            return idx < HV ? lo : hi;
+        }
+    }
+};
+template <int Q, int RPT, int AUX = 0>
+__device__ __forceinline__ void xcd_publish_column(const XSlab<RPT>& col, __amdgpu_buffer_rsrc_t mail, int myslot, unsigned tag, int rstride = 1024)
+{
+    asm volatile("; column slot %0" ::"n"(Q));
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const double av = col.get(r);
+        u32x4 gv;
+        gv.x = lo32(av);
+        gv.y = hi32(av);
+        gv.z = 0u;
+        gv.w = tag ^ gv.x ^ gv.y;
+        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * rstride, 0, AUX);
+    }
+}
+
 // Publication of one owned column: 16-byte granules {lo, hi, 0, tag ^ lo ^ hi}, one per slot row (rows beyond M hold zeros:
 // every slot row is written, no row mask).  One instance per column slot (the marker keeps the instances apart: merged, the
 // compiler would first copy the selected column into a common block of registers).
-template <int Q, int RPT>
+template <int Q, int RPT, int AUX = 0> // AUX: cache bits of the stores (BUF_SC1: write-through, for readers on other XCDs)
 __device__ __forceinline__ void xcd_publish_column(const xvec<RPT>& col, __amdgpu_buffer_rsrc_t mail, int myslot, unsigned tag, int rstride = 1024)
 {
     asm volatile("; column slot %0" ::"n"(Q));
@@ -242,7 +281,7 @@ __device__ __forceinline__ void xcd_publish_column(const xvec<RPT>& col, __amdgp
         gv.y = hi32(av);
         gv.z = 0u;
         gv.w = tag ^ gv.x ^ gv.y;
-        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * rstride, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(gv, mail, myslot + r * rstride, 0, AUX);
     }
 }
 

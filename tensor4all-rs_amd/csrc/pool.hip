@@ -284,7 +284,7 @@ hipStream_t stream_get(int kind)
     hipStream_t s = nullptr;
     int least = 0, greatest = 0;
     T4A_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    static const bool flat = std::getenv("T4A_FLAT_PRIORITY") != nullptr;
+    static const bool flat = diag_env("T4A_FLAT_PRIORITY") != nullptr;
     if (kind == 0 || flat || least == greatest)
         T4A_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     else

@@ -406,7 +406,7 @@ void Tci2::stage_accumulators(const IndexSet& a, size_t a0, const IndexSet& b, s
         return;
     }
     d_rowacc_.reserve(need);
-    static const bool dma_copy = std::getenv("T4A_ACC_DMA") != nullptr;
+    static const bool dma_copy = diag_env("T4A_ACC_DMA") != nullptr;
     if (dma_copy) {
         T4A_HIP(hipMemcpyAsync(d_rowacc_.get(), ha, need * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     } else {
@@ -437,18 +437,25 @@ void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
         // host batch callback: points in row-major order of (ia, ib) — `ia` outer, `ib` inner — exactly the
         // order the reference hands to batched_f (tensorci2.rs:1862-1869)
         const size_t npts = na * nb;
-        std::vector<uint32_t> idx(npts * n_);
-        for (size_t ia = 0; ia < na; ++ia)
+        std::vector<uint32_t> idx(pi_shard.active() ? 0 : npts * n_);
+        for (size_t ia = 0; ia < na && !pi_shard.active(); ++ia)
             for (size_t ib = 0; ib < nb; ++ib) {
                 uint32_t* dst = idx.data() + (ia * nb + ib) * n_;
                 std::memcpy(dst + a0, a.at(ia), a.width * sizeof(uint32_t));
                 std::memcpy(dst + b0, b.at(ib), b.width * sizeof(uint32_t));
             }
         std::vector<double> vals(npts);
-        const int64_t got = cb_(cb_ctx_, idx.data(), n_, npts, vals.data());
-        if (got < 0 || (size_t)got != npts)
-            throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " +
-                                                    std::to_string(npts) + " requested entries");
+        if (pi_shard.active()) {
+            // column blocks over the ranks of the process group + one all-gather (pishard.hpp)
+            idx.clear();
+            idx.shrink_to_fit();
+            pi_shard_evaluate(pi_shard, cb_, cb_ctx_, n_, a.d.data(), a.width, a0, na, b.d.data(), b.width, b0, nb, vals.data());
+        } else {
+            const int64_t got = cb_(cb_ctx_, idx.data(), n_, npts, vals.data());
+            if (got < 0 || (size_t)got != npts)
+                throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " +
+                                                        std::to_string(npts) + " requested entries");
+        }
         d_vals_.reserve(npts);
         T4A_HIP(hipMemcpyAsync(d_vals_.get(), vals.data(), npts * sizeof(double), hipMemcpyHostToDevice, st));
         T4A_HIP(hipStreamSynchronize(st)); // `vals` is pageable host memory
@@ -527,14 +534,14 @@ LuciResult Tci2::luci_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
 {
     const size_t M = is.count, N = js.count;
     hipStream_t st = eng.stream();
-    static const bool no_fuse = std::getenv("T4A_NO_FUSED_PI") != nullptr;
+    static const bool no_fuse = diag_env("T4A_NO_FUSED_PI") != nullptr;
     if (fn_kind_ == FnKind::Builtin && !no_fuse && M > 0 && N > 0) {
         // built-in functor: only the accumulators travel; the rrLU kernel evaluates Pi into its registers
         FusedPi fp;
         fp.fn = fn_dev_;
         // small bonds (the single-workgroup plan with the fused candidate-matrix build takes them): the kernel reads the few
         // hundred bytes of accumulators straight from the pinned arena — no staging kernel in front of a 10 us factorisation
-        static const bool no_in_place = std::getenv("T4A_ACC_STAGE_ALWAYS") != nullptr;
+        static const bool no_in_place = diag_env("T4A_ACC_STAGE_ALWAYS") != nullptr;
         fp.host_resident = !no_in_place && (M * N <= (size_t)64 * 64);
         stage_accumulators(is, 0, js, is.width, acc_rows, acc_cols, &fp.d_rowacc, &fp.d_colacc, fp.host_resident);
         eng.prof.v[11] += (double)M * (double)N;
@@ -930,14 +937,27 @@ void Tci2::issue_fill_ops(std::vector<std::function<void()>>& ops, const std::ve
     hipStream_t st = fill_stream_;
     static const bool use_graph = std::getenv("T4A_NO_FILL_GRAPH") == nullptr;
     if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.a, st));
+    for (auto& f : fill_pre_ops_) f(); // (diagnosis switch T4A_FILL_GRAPH_NO_COPY: the upload in front of the graph)
+    fill_pre_ops_.clear();
+    static const bool dev_sync_first = diag_env("T4A_FILL_GRAPH_DEVSYNC") != nullptr; // (diagnosis)
+    if (dev_sync_first) T4A_HIP(hipDeviceSynchronize());
     bool done = false;
-    // (no graph replay on a handle whose cores are exported / imported asynchronously — site-sharded fill, patch farm: with
-    // device-to-device copies of the cores and event waits of other streams between two replays on the fill stream,
-    // `bench.py --mode site-shard` hit GPU memory faults in 25 - 75 % of its runs, with every rrLU kernel generation and with
-    // the bond chain switched off, and in none with T4A_NO_FILL_GRAPH=1; the replay is worth 0.4 % of a cfg3 sweep)
-    if (use_graph && !fill_graph_broken_ && !cores_shared_async_) {
+    // (no graph replay on a handle whose cores are exported / imported through the LEGACY DEFAULT STREAM.  Round 4 saw GPU memory
+    // faults in 25 - 75 % of `bench.py --mode site-shard` runs with replay on; round 5 bisected them (tools/r5_gpu_shardfault*.sh,
+    // profiles/r05_fill_graph_fault_bisect.txt, five runs per arm): they need the replay AND an event protocol that runs through
+    // stream 0 — torch's current stream in a process that never selected another — in BOTH directions (export: stream 0 waits for an
+    // event recorded behind the replay; import: the import stream waits for an event recorded on stream 0).  Replacing either event
+    // by a host wait, moving torch to a side stream, or a device-wide synchronisation in front of the replay: 0 faults of 5; the
+    // pool, the bond chain, kernel serialisation, the order of the export copies and the copy nodes of the graph: no influence.
+    // Every pointer the graph holds is part of the signature (checked again: tables, staging buffers, tickets, flags), so this is
+    // the runtime's implicit ordering of stream 0 against the streams a graph launch runs on, not a stale pointer.  parallel.py and
+    // bench.py therefore exchange on a side stream; a caller that hands in stream 0 gets direct issue, which is what the
+    // round-4 stop-gap did for every shared handle.)
+    static const bool graph_shared = diag_env("T4A_FILL_GRAPH_SHARED") != nullptr; // (diagnosis: replay even then)
+    if (use_graph && !fill_graph_broken_ && (!cores_shared_legacy_stream_ || graph_shared)) {
         if (fill_graph_exec_ && sig == fill_graph_sig_) {
             T4A_HIP(hipGraphLaunch(fill_graph_exec_, st));
+            ++fill_stats_[1];
             done = true;
         } else if (sig == fill_last_sig_) { // second time in a row: worth capturing
             if (fill_graph_exec_) {
@@ -964,6 +984,7 @@ void Tci2::issue_fill_ops(std::vector<std::function<void()>>& ops, const std::ve
             if (ok) {
                 fill_graph_sig_ = sig;
                 T4A_HIP(hipGraphLaunch(fill_graph_exec_, st));
+                ++fill_stats_[2];
                 done = true;
             } else {
                 (void)hipGetLastError();
@@ -972,6 +993,7 @@ void Tci2::issue_fill_ops(std::vector<std::function<void()>>& ops, const std::ve
         }
     }
     fill_last_sig_ = sig;
+    ++fill_stats_[0];
     if (!done)
         for (auto& f : ops) f();
     if (fill_timed_) T4A_HIP(hipEventRecord(ev_fill_.b, st));
@@ -1039,7 +1061,7 @@ void Tci2::fill_site_tensors_impl(bool async)
     if (!builtin || sync_fill) async = false;
     // deferred mode (optimize only): everything up to the upload buffer is prepared now, the ~25 stream operations are
     // issued later from an overlap hook, when the host would otherwise wait for a long bond-update kernel
-    static const bool defer_env = std::getenv("T4A_FILL_DEFER") != nullptr; // measured: no net gain (the fill then
+    static const bool defer_env = diag_env("T4A_FILL_DEFER") != nullptr; // measured: no net gain (the fill then
     // overlaps the long mid-chain kernels and slows them down by as much as the host time it hides)
     const bool defer = async && builtin && fill_defer_requested_ && defer_env;
     fill_defer_requested_ = false;
@@ -1312,10 +1334,16 @@ void Tci2::fill_site_tensors_impl(bool async)
                 std::memcpy(&bits, &fn.params[q], sizeof(bits));
                 sg(bits);
             }
-            dev([=]() {
-                T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st));
-                pi_eval_batched_launch(fn, dj, npi, max_M, max_N, st);
-            });
+            static const bool copies_outside = diag_env("T4A_FILL_GRAPH_NO_COPY") != nullptr; // (diagnosis: the upload is issued directly, in front of the graph)
+            if (copies_outside) {
+                fill_pre_ops_.push_back([=]() { T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st)); });
+                dev([=]() { pi_eval_batched_launch(fn, dj, npi, max_M, max_N, st); });
+            } else {
+                dev([=]() {
+                    T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st));
+                    pi_eval_batched_launch(fn, dj, npi, max_M, max_N, st);
+                });
+            }
         }
         d_lups = reinterpret_cast<const LuProblem*>(db + off_lu);
         d_trs = reinterpret_cast<const TrsmProblem*>(db + off_tr);
@@ -1418,6 +1446,7 @@ void Tci2::fill_site_tensors_impl(bool async)
 void Tci2::export_site_tensors_async(double* d_dst, size_t stride, hipStream_t consumer)
 {
     cores_shared_async_ = true;
+    if (consumer == nullptr) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
     hipStream_t st = fill_inflight_ ? fill_stream_ : eng.stream();
     for (size_t s = 0; s < n_; ++s) {
         const DevCore& c = cores[s];
@@ -1435,13 +1464,21 @@ void Tci2::export_site_tensors_async(double* d_dst, size_t stride, hipStream_t c
 void Tci2::export_site_shard_async(double* d_dst, size_t stride, hipStream_t consumer)
 {
     cores_shared_async_ = true;
+    if (consumer == nullptr) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
     hipStream_t st = fill_inflight_ ? fill_stream_ : eng.stream();
+    static const bool export_sync = diag_env("T4A_EXPORT_SYNC") != nullptr; // (diagnosis: the fill has completed before the copies are enqueued)
+    if (export_sync) T4A_HIP(hipStreamSynchronize(st));
     size_t k = 0;
     for (size_t s = shard_rank; s < n_; s += shard_world, ++k) {
         const DevCore& c = cores[s];
         if (c.size() > stride) throw Error(T4A_GPU_BUFFER_TOO_SMALL, "export_site_shard: stride smaller than a site tensor");
         if (c.size())
             T4A_HIP(hipMemcpyAsync(d_dst + k * stride, c.buf.get(), c.size() * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    static const bool export_hostsync = diag_env("T4A_EXPORT_HOSTSYNC") != nullptr; // (diagnosis: no event, the host waits for the copies)
+    if (export_hostsync) {
+        T4A_HIP(hipStreamSynchronize(st));
+        return;
     }
     if (!export_event_) T4A_HIP(hipEventCreateWithFlags(&export_event_, hipEventDisableTiming));
     T4A_HIP(hipEventRecord(export_event_, st));
@@ -1457,13 +1494,19 @@ void Tci2::export_site_shard_async(double* d_dst, size_t stride, hipStream_t con
 void Tci2::import_site_shard_async(const double* d_src, size_t stride, size_t per_rank, hipStream_t producer)
 {
     cores_shared_async_ = true;
+    if (producer == nullptr) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
     if (!import_stream_) import_stream_ = pool::stream_get(2);
     // at most one import in flight: the one of the previous half-sweep is long done (a whole chain of bond updates ago),
     // and with it every read of the receive buffer that the caller is about to reuse
     T4A_HIP(hipStreamSynchronize(import_stream_));
-    if (!import_event_) T4A_HIP(hipEventCreateWithFlags(&import_event_, hipEventDisableTiming));
-    T4A_HIP(hipEventRecord(import_event_, producer));
-    T4A_HIP(hipStreamWaitEvent(import_stream_, import_event_, 0));
+    static const bool import_hostsync = diag_env("T4A_IMPORT_HOSTSYNC") != nullptr; // (diagnosis: the host waits for the producer, no event)
+    if (import_hostsync) {
+        T4A_HIP(hipStreamSynchronize(producer));
+    } else {
+        if (!import_event_) T4A_HIP(hipEventCreateWithFlags(&import_event_, hipEventDisableTiming));
+        T4A_HIP(hipEventRecord(import_event_, producer));
+        T4A_HIP(hipStreamWaitEvent(import_stream_, import_event_, 0));
+    }
     for (size_t s = 0; s < n_; ++s) {
         const size_t r = s % shard_world;
         if (r == shard_rank) continue;
@@ -1674,7 +1717,7 @@ void Tci2::opt_begin(OptRun& r)
         std::vector<size_t> lb(n_ + 1, 1), rb(n_ + 1, 1);
         for (size_t b = 0; b < n_; ++b) lb[b + 1] = std::min(chi, lb[b] * local_dims[b]);
         for (size_t b = n_; b-- > 0;) rb[b] = std::min(chi, rb[b + 1] * local_dims[b]);
-        static const bool old_presize = std::getenv("T4A_OLD_PRESIZE") != nullptr; // (debug: every bond at chi)
+        static const bool old_presize = diag_env("T4A_OLD_PRESIZE") != nullptr; // (debug: every bond at chi)
         auto bond = [&](size_t b) { return old_presize ? chi : std::min(lb[b], rb[b]); }; // bond b sits left of site b
         size_t totA = 0, totB = 0, tot_cores = 0;
         for (size_t b = 0; b < n_; ++b) {
@@ -1768,7 +1811,7 @@ bool Tci2::opt_iter_start(OptRun& r, bool defer_launch)
         // a fill deferred by the previous iteration is issued from the hook of the 9th bond of this half-sweep (the
         // first kernels that are long enough to hide the host work); shorter chains: from the last bond
         const size_t nb_ = n_ - 1;
-        static const int defer_k = std::getenv("T4A_FILL_DEFER") ? std::atoi(std::getenv("T4A_FILL_DEFER")) : 8;
+        static const int defer_k = diag_env("T4A_FILL_DEFER") ? std::atoi(diag_env("T4A_FILL_DEFER")) : 8;
         const size_t want_k = defer_k > 0 ? (size_t)defer_k : 8;
         const size_t flush_k = nb_ > want_k + 1 ? want_k : nb_ - 1;
         const size_t flush_at_fwd = flush_k, flush_at_bwd = nb_ - 1 - flush_k;
@@ -1791,12 +1834,15 @@ void Tci2::opt_iter_issue_pending_fill(OptRun& r)
 {
     if (!r.pending_fill) return;
     r.pending_fill = false;
-    {   // tests only: T4A_TEST_THROW_IN_FILL=n makes the n-th pending fill of the process fail (while a chain is in flight)
+#ifdef T4A_TEST_HOOKS
+    {   // libt4a_gpu_testhooks.so only (build.py; tests/test_gpu_chain.py loads it in a child process): T4A_TEST_THROW_IN_FILL=n makes
+        // the n-th pending fill of the process fail while a chain is in flight.  The production library carries no fault injector.
         static const long inject_at = std::getenv("T4A_TEST_THROW_IN_FILL") ? std::atol(std::getenv("T4A_TEST_THROW_IN_FILL")) : 0;
         static std::atomic<long> issued{0};
         if (inject_at > 0 && ++issued == inject_at)
             throw Error(T4A_GPU_INTERNAL_ERROR, "injected failure while issuing fill_site_tensors (T4A_TEST_THROW_IN_FILL)");
     }
+#endif
     for (size_t b = 0; b < n_; ++b) prepare_fill_site(b); // (from the mirror of the previous chain; the new one writes the other mirror)
     fill_cache_trusted_ = true;
     fill_no_main_sync_ = true;

@@ -9,6 +9,7 @@
 
 #include "engine.hpp"
 #include "stdrng.hpp"
+#include "pishard.hpp"
 #include "rook.hpp"
 #include "tt.hpp"
 
@@ -128,6 +129,7 @@ public:
     // chain_walk_kernel) [1] 1-site sweeps (sweep1site) that ran as a chain [2] 1-site sweeps that were not eligible and ran bond
     // by bond [3] chained 1-site sweeps that fell back to the per-bond path part-way
     std::array<uint64_t, 4> chain_stats_ext{{0, 0, 0, 0}};
+    const uint64_t* fill_stats() const { return fill_stats_; } // [fills issued asynchronously, graph replays, graph captures]
     bool chain_enabled = true;  // false: every half-sweep runs bond by bond (A/B measurements, tests)
     bool chain_verify = false;  // true: after every chain the device tables are read back and compared with the host's sets
     bool chain_event_timing = false; // profiling: rrLU launches of a chain are timed with HIP events around each launch instead of
@@ -170,6 +172,7 @@ public:
     int termination = T4A_GPU_TCI2_MAX_ITERATIONS;
     std::vector<std::array<size_t, 3>> last_sweep_shapes;
     size_t shard_rank = 0, shard_world = 1;
+    PiShard pi_shard; // column-block shard of callback-evaluated candidate matrices over a process group (pishard.hpp)
     bool keep_site_tensors = false;
     Engine eng;
 
@@ -236,6 +239,7 @@ private:
     void issue_fill_ops(std::vector<std::function<void()>>& ops, const std::vector<uint64_t>& sig);
     std::vector<uint64_t> fill_deferred_sig_, fill_last_sig_, fill_graph_sig_;
     hipGraphExec_t fill_graph_exec_ = nullptr;
+    std::vector<std::function<void()>> fill_pre_ops_; // (diagnosis switch T4A_FILL_GRAPH_NO_COPY)
     bool fill_graph_broken_ = false;
     void prepare_fill_site(size_t b);
     void invalidate_fill_cache();                    // set by the sweep loop: which side of which bond is independent of the current one
@@ -353,6 +357,8 @@ private:
     EventTimer ev_pi_, ev_fill_;
     hipStream_t fill_stream_ = nullptr, import_stream_ = nullptr;
     bool import_inflight_ = false;
+    bool cores_shared_legacy_stream_ = false; // ... and stream 0 (the legacy default stream) was the consumer / producer of one: no graph replay of the fill (issue_fill_ops)
+    uint64_t fill_stats_[3] = {0, 0, 0};       // fills issued through issue_fill_ops, graph replays, graph captures
     bool cores_shared_async_ = false; // an asynchronous export / import of cores was requested on this handle: fills are issued directly, not replayed from a graph (issue_fill_ops)
     hipEvent_t export_event_ = nullptr, import_event_ = nullptr;
     bool fill_inflight_ = false, fill_timed_ = false;

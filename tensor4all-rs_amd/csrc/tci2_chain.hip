@@ -500,7 +500,7 @@ void Tci2::chain_launch()
     hipStream_t st = eng.stream();
     // result blocks reach the host in ONE copy behind the chain (T4A_CHAIN_HOST_MIRROR=1: every rrLU kernel mirrors its own block
     // into pinned memory as it ends — stores over PCIe that the kernel's end has to wait for, once per bond)
-    static const bool per_launch_mirror = std::getenv("T4A_CHAIN_HOST_MIRROR") != nullptr;
+    static const bool per_launch_mirror = diag_env("T4A_CHAIN_HOST_MIRROR") != nullptr;
     auto block_of = [&](size_t b) {
         ChainBlock k = proto;
         k.dev = chain_.blocks.get() + b * proto.bytes;
@@ -518,7 +518,7 @@ void Tci2::chain_launch()
     try {
         chain_indep_launch(c, (int)nb, st);
         unsigned* tile_counters = reinterpret_cast<unsigned*>(chain_.dims.get() + nb * 4);
-        static const bool no_spec = std::getenv("T4A_CHAIN_NO_SPEC") != nullptr;
+        static const bool no_spec = diag_env("T4A_CHAIN_NO_SPEC") != nullptr;
         const bool solo = g_chains_inflight.fetch_add(1) == 0 && !no_spec;
         counted = true;
         // every matrix of the half-sweep fits the one-wave kernel: ONE persistent workgroup walks the bonds (kernels_chain.hip)
@@ -549,7 +549,7 @@ void Tci2::chain_launch()
             w.token_base = chain_.walk_token;
             chain_.walk_token += (unsigned)nb;
             w.timed = chain_.timed ? 1 : 0;
-            static const bool old_prep = std::getenv("T4A_WALK_OLD_PREP") != nullptr;
+            static const bool old_prep = diag_env("T4A_WALK_OLD_PREP") != nullptr;
             w.lean_prep = old_prep ? 0 : 1;
             static const bool walk_dbg = std::getenv("T4A_WALK_DEBUG") != nullptr;
             if (walk_dbg) {
@@ -565,7 +565,7 @@ void Tci2::chain_launch()
         // T4A_CHAIN_DEFER_MIRROR=1: the launched chain's preparations leave the pinned mirrors alone and one bulk copy follows the
         // chain (measured: 21.44 against 21.39 ms per cfg3 sweep — the stores over PCIe are not what a preparation's 8.6 us consist
         // of, and the extra launch costs what they cost; the persistent half-sweep always copies in bulk)
-        static const bool defer_mirror = std::getenv("T4A_CHAIN_DEFER_MIRROR") != nullptr;
+        static const bool defer_mirror = diag_env("T4A_CHAIN_DEFER_MIRROR") != nullptr;
         static const bool want_prep_dbg = std::getenv("T4A_PREP_DEBUG") != nullptr; // phase times of the preparation kernels of this chain
         unsigned long long* prep_dbg = nullptr;
         if (want_prep_dbg && !walk) {
@@ -653,7 +653,7 @@ void Tci2::chain_launch()
             if (defer_mirror) chain_mirror_launch(c, (int)nb, st);
         }
         chain_.cores_batched = false;
-        static const bool no_batched_cores = std::getenv("T4A_NO_BATCHED_CORES") != nullptr;
+        static const bool no_batched_cores = diag_env("T4A_NO_BATCHED_CORES") != nullptr;
         if (chain_.one_site && chain_.factors_stride && forward && !no_batched_cores && nb <= (size_t)LUCI_LEFT_CORES_MAX_JOBS) {
             // the site tensors of every bond of rank <= 16 in one launch behind the chain (kernels_dense.hip): shapes, ranks and
             // permutations are read where the chain left them; the buffers are sized for the upper bounds
@@ -702,7 +702,7 @@ void Tci2::chain_launch()
 // kernels, same order.
 void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
 {
-    static const bool no_group = std::getenv("T4A_CHAIN_NO_GROUP") != nullptr;
+    static const bool no_group = diag_env("T4A_CHAIN_NO_GROUP") != nullptr;
     const size_t nh = hs.size();
     if (nh == 0) return;
     bool ok = nh >= 2 && nh <= (size_t)CHAIN_GROUP_MAX && !no_group;
@@ -764,7 +764,7 @@ void Tci2::chain_group_launch(const std::vector<Tci2*>& hs)
         const ChainGroupSlot* d_slots = lead->chain_.gslots.get();
         lead->eng.chain_group_lock();
         locked = true;
-        static const bool per_launch_mirror = std::getenv("T4A_CHAIN_HOST_MIRROR") != nullptr;
+        static const bool per_launch_mirror = diag_env("T4A_CHAIN_HOST_MIRROR") != nullptr;
         auto block_of = [&](Tci2* h, size_t b) {
             ChainBlock k = h->chain_.proto;
             k.dev = h->chain_.blocks.get() + b * k.bytes;
@@ -1098,7 +1098,8 @@ void Tci2::chain_finish(const TCI2Options& options)
     ++(chain_.one_site ? chain_stats_ext[3] : chain_stats[2]);
     sync_digits();
     chain_.tables_valid = false;
-    if (failed_timeout && chain_.plans[chain_.order[(size_t)failed_k]].kind == 2) xcd_disable();
+    // (only the kernels that ASSUME a placement: the one-workgroup / one-wave plans are booked as kind 2 as well but elect nobody — ADVICE round 4)
+    if (failed_timeout && chain_.plans[chain_.order[(size_t)failed_k]].kind == 2 && chain_.plans[chain_.order[(size_t)failed_k]].xcd.wg == 0) xcd_disable();
     prep_.valid = false;
     prefetch_.wanted = false;
     prefetch_.fill_site = -1;

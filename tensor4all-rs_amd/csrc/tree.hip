@@ -525,7 +525,7 @@ EdgeSelection TreeTci::update_edge(const TreeEdge& edge, const RrLUOptions& opti
     RrLUOptions o = options;
     o.left_orthogonal = true;
     LuciResult lu;
-    static const bool no_fuse = std::getenv("T4A_NO_FUSED_PI") != nullptr;
+    static const bool no_fuse = diag_env("T4A_NO_FUSED_PI") != nullptr;
     if (fn_kind_ == FnKind::Builtin && !no_fuse) {
         // only the integer accumulators travel: the rrLU kernel evaluates the candidate matrix into its registers
         std::vector<uint64_t> ra, rb;

@@ -359,6 +359,40 @@ _BATCH_CB = ctypes.CFUNCTYPE(ctypes.c_int64, c_void_p, ctypes.POINTER(ctypes.c_u
                              ctypes.POINTER(c_double))
 
 
+_ALLGATHER_CB = ctypes.CFUNCTYPE(c_int32, c_void_p, ctypes.POINTER(c_double), c_size_t, ctypes.POINTER(c_double))
+
+
+def pi_shard_eval(rank, world, f, a_digits, a0, b_digits, b0, n_sites, gather=None):
+    """The host part of the column-block shard alone (t4a_gpu_pi_shard_eval; no device needed): the len(a) x len(b) matrix of f on
+    the row halves `a_digits` (placed at site a0) x column halves `b_digits` (at site b0), evaluated by THIS rank's column block and
+    all-gathered.  Returns the row-major matrix."""
+    a = np.ascontiguousarray(a_digits, dtype=np.uint32)
+    b = np.ascontiguousarray(b_digits, dtype=np.uint32)
+    na, wa = a.shape
+    nb, wb = b.shape
+    out = np.zeros((na, nb))
+    cb = _batch_callback(f)
+
+    def _g(ctx, send_ptr, count, recv_ptr):
+        try:
+            send = np.ctypeslib.as_array(send_ptr, shape=(count,))
+            got = np.asarray(gather(send), dtype=np.float64).ravel()
+            if got.size != world * count:
+                return 2
+            np.ctypeslib.as_array(recv_ptr, shape=(world * count,))[:] = got
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    g = _ALLGATHER_CB(_g) if world > 1 else ctypes.cast(None, _ALLGATHER_CB)
+    _check(_lib.t4a_gpu_pi_shard_eval(c_size_t(rank), c_size_t(world), cb, None, g, None, c_size_t(n_sites),
+                                      a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), c_size_t(wa), c_size_t(a0), c_size_t(na),
+                                      b.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), c_size_t(wb), c_size_t(b0), c_size_t(nb), _p(out)))
+    return out
+
+
 def _batch_callback(f):
     """ctypes batch callback (t4a_gpu_batch_eval_fn) around a Python function: f(list_of_int) -> float, or an object with a
     `.batched(idx_array[n_pts, n_sites]) -> values` attribute."""
@@ -447,6 +481,42 @@ class TensorCI2:
         cb = _BATCH_CB(_cb)
         self._cb_keepalive = cb
         _check(_lib.t4a_gpu_tci2_set_callback(self._h, cb, None))
+
+    def set_callback_raw(self, fn_ptr, ctx_ptr, keepalive=None):
+        """A NATIVE batch callback (t4a_gpu_batch_eval_fn as an address or ctypes function, ctx as an address): the path a Rust closure
+        takes, without the Python interpreter between the library and the function (tools/native_callback.c)."""
+        self._cb_keepalive = keepalive
+        cb = ctypes.cast(fn_ptr, _BATCH_CB) if not isinstance(fn_ptr, _BATCH_CB) else fn_ptr
+        _check(_lib.t4a_gpu_tci2_set_callback(self._h, cb, ctypes.c_void_p(ctx_ptr)))
+
+    def set_pi_shard(self, rank, world, gather=None):
+        """Column-block shard of every callback-evaluated candidate matrix over a process group.
+        gather(send: np.ndarray[count]) -> np.ndarray[world * count] (rank-major all-gather on host buffers), e.g.
+        parallel.PiShardGather(dist, torch); world == 1 switches the shard off."""
+        if world > 1 and gather is None:
+            raise T4aError(NULL_POINTER, "a column-block shard over more than one rank needs an all-gather callable")
+
+        def _g(ctx, send_ptr, count, recv_ptr):
+            try:
+                send = np.ctypeslib.as_array(send_ptr, shape=(count,))
+                got = np.asarray(gather(send), dtype=np.float64).ravel()
+                if got.size != world * count:
+                    return 2
+                np.ctypeslib.as_array(recv_ptr, shape=(world * count,))[:] = got
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        cb = _ALLGATHER_CB(_g) if world > 1 else ctypes.cast(None, _ALLGATHER_CB)
+        self._gather_keepalive = cb
+        _check(_lib.t4a_gpu_tci2_set_pi_shard(self._h, c_size_t(rank), c_size_t(world), cb, None))
+
+    def pi_shard_stats(self):
+        out = (c_size_t * 2)()
+        _check(_lib.t4a_gpu_tci2_pi_shard_stats(self._h, out))
+        return {"gathers": int(out[0]), "bytes_sent": int(out[1])}
 
     # --- reference API
     def __len__(self):
@@ -666,6 +736,11 @@ class TensorCI2:
         """Device-side bond chain on / off for this handle; verify: read the device tables back after every chain; event_timing:
         while profiling, time the rrLU launches with HIP events instead of the kernels' own time stamps."""
         _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0), c_int32((1 if verify else 0) | (2 if event_timing else 0))))
+
+    def fill_stats(self):
+        out = (ctypes.c_uint64 * 3)()
+        _check(_lib.t4a_gpu_tci2_fill_stats(self._h, out))
+        return {"fills": int(out[0]), "graph_replays": int(out[1]), "graph_captures": int(out[2])}
 
     def chain_stats(self):
         """Device-side bond chain: dict(half_sweeps, bonds, fell_back, not_eligible, group_half_sweeps) of the 2-site half-sweeps since

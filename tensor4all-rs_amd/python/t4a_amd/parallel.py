@@ -7,11 +7,27 @@ torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
    all-gathered (the only exchange step).  FIFO patch order is preserved when re-assembling.
  * site-sharded fill_site_tensors (configs[3]; tensorci2.rs:1065-1186: sites are independent given the final
    I/J sets): rank r fills the sites s with s % world == r, then cores are all-gathered.
+ * column-block shard of the candidate matrix for expensive (host-callback) functions (tensorci2.rs:1859-1893: entries of one
+   candidate matrix are independent): rank r evaluates ceil(N / world) columns through its callback, one all-gather per matrix,
+   the rank-revealing LU replicated (PiShardGather + TensorCI2.set_pi_shard; csrc/pishard.hpp).
 
 The local compute is injected (`run_patch`, `fill_sites`) so that the same orchestration runs with the device
 handle in production and with the CPU oracle in tests/test_cpu_parallel.py.
 """
 import numpy as np
+
+
+def leave_legacy_stream(torch):
+    """Every device-side exchange of this module hands torch's CURRENT stream to the library as the consumer / producer of its
+    events.  In a process that never selected a stream that is stream 0, the legacy default stream, whose implicit ordering against
+    the streams a HIP graph launch runs on broke the captured fill_site_tensors graph (GPU memory faults, bisected in round 5:
+    profiles/r05_fill_graph_fault_bisect.txt).  Make a non-blocking side stream current instead — once per thread; a caller that has
+    selected its own stream keeps it.  (The library itself falls back to direct issue when it is handed stream 0.)"""
+    import os
+    if os.environ.get("T4A_SS_LEGACY_STREAM"):  # (diagnosis: stay on stream 0; the library then issues its fills directly)
+        return
+    if torch.cuda.is_available() and torch.cuda.current_stream().cuda_stream == 0:
+        torch.cuda.set_stream(torch.cuda.Stream())
 
 
 def patches_of_rank(n_patches, rank, world):
@@ -106,6 +122,8 @@ class PaddedPatchFarm:
         self.n_patches, self.n_sites, self.cap = n_patches, n_sites, cap
         self.per_rank = (n_patches + self.world - 1) // self.world
         self.mine = patches_of_rank(n_patches, self.rank, self.world)
+        if str(device).startswith("cuda"):
+            leave_legacy_stream(torch)
         self.send = torch.zeros(self.per_rank * n_sites * cap, dtype=torch.float64, device=device)
         self.recv = torch.zeros(self.world * self.per_rank * n_sites * cap, dtype=torch.float64, device=device)
         self.send_dims = torch.zeros(self.per_rank * n_sites * 3, dtype=torch.int64, device=device)
@@ -162,6 +180,7 @@ class DevicePatchExporter:
 
     def __call__(self, patches, send):
         shapes = []
+        leave_legacy_stream(self.torch)
         stream = self.torch.cuda.current_stream().cuda_stream
         cap = send.shape[2]
         for k0 in range(0, len(patches), self.group):
@@ -232,6 +251,8 @@ class ShardedCoreExchange:
         self.per_rank = (n_sites + self.world - 1) // self.world
         self.cap = cap
         self.is_cuda = str(device).startswith("cuda")
+        if self.is_cuda:
+            leave_legacy_stream(torch)
         self.send = [torch.zeros(self.per_rank * cap, dtype=torch.float64, device=device) for _ in range(2)]
         self.recv = [torch.zeros(self.world * self.per_rank * cap, dtype=torch.float64, device=device) for _ in range(2)]
         self.send_dims = [torch.zeros(self.per_rank * 3, dtype=torch.int64, device=device) for _ in range(2)]
@@ -345,3 +366,29 @@ class NumpyShardAdapter:
             self.store[s] = np.array(buf[r, s // self.world, :l * d * rr]).reshape((l, d, rr), order="F")
             used[s] = (int(l), int(d), int(rr))
         return used
+
+
+class PiShardGather:
+    """The all-gather of TensorCI2.set_pi_shard as a callable on host buffers: send (count doubles) -> world * count doubles,
+    rank-major.  gloo: CPU tensors; nccl (= RCCL): staged through device tensors of the current device (the values of a host
+    callback are host values; 8 M N / world bytes per rank and matrix).  Buffers are cached per size."""
+
+    def __init__(self, dist, torch, device="cpu"):
+        self.dist, self.torch, self.device = dist, torch, device
+        self.world = dist.get_world_size()
+        self._buf = {}
+        self.calls = 0
+        self.bytes = 0
+
+    def __call__(self, send):
+        torch = self.torch
+        n = int(send.size)
+        if n not in self._buf:
+            self._buf[n] = (torch.zeros(n, dtype=torch.float64, device=self.device),
+                            torch.zeros(self.world * n, dtype=torch.float64, device=self.device))
+        s, r = self._buf[n]
+        s.copy_(torch.from_numpy(np.ascontiguousarray(send)))
+        self.dist.all_gather_into_tensor(r, s)
+        self.calls += 1
+        self.bytes += 8 * n
+        return r.cpu().numpy()

@@ -132,3 +132,77 @@ def test_patch_assignment_is_round_robin_and_order_preserving():
     h, f = pack_cores(cores)
     back = unpack_cores(h, f)
     assert all(np.array_equal(a, b) for a, b in zip(cores, back))
+
+
+# ---- column-block shard of the candidate matrix for callback functions -------------------------------
+def _pi_fn(idx):
+    # an "expensive" user function of six sites; the value depends on every digit, so a misplaced column shows
+    return float(np.cos(0.37 * idx[0] + 1.3 * idx[1] - 0.7 * idx[2]) * np.exp(-0.11 * (idx[3] + 2 * idx[4])) + 0.01 * idx[5] * idx[0])
+
+
+def _pi_sets():
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 3, size=(7, 2))     # row halves: sites 0-1
+    b = rng.integers(0, 3, size=(11, 4))    # column halves: sites 2-5 (11 columns: uneven blocks, a short last block)
+    return a, b
+
+
+def _pi_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import t4a_amd
+    from t4a_amd import parallel
+    seen = []
+
+    def f(idx):
+        seen.append(tuple(int(v) for v in idx))
+        return _pi_fn(idx)
+    a, b = _pi_sets()
+    gather = parallel.PiShardGather(dist, torch)
+    m = t4a_amd.pi_shard_eval(rank, world, f, a, 0, b, 2, 6, gather)
+    np.save(os.path.join(out_dir, f"pi_{rank}.npy"), m)
+    np.save(os.path.join(out_dir, f"seen_{rank}.npy"), np.asarray(seen, dtype=np.int64))
+    # a single column (fewer columns than ranks: one block is empty) and a single row
+    m1 = t4a_amd.pi_shard_eval(rank, world, _pi_fn, a, 0, b[:1], 2, 6, gather)
+    m2 = t4a_amd.pi_shard_eval(rank, world, _pi_fn, a[:1], 0, b, 2, 6, gather)
+    np.save(os.path.join(out_dir, f"pi1_{rank}.npy"), m1)
+    np.save(os.path.join(out_dir, f"pi2_{rank}.npy"), m2)
+    assert gather.calls == 3
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pi_column_block_shard_assembles_the_unsharded_matrix(tmp_path, world):
+    import t4a_amd
+    a, b = _pi_sets()
+    full = t4a_amd.pi_shard_eval(0, 1, _pi_fn, a, 0, b, 2, 6)
+    want = np.array([[_pi_fn(list(ra) + list(cb)) for cb in b] for ra in a])
+    assert np.array_equal(full, want)
+    port = _free_port()
+    mp.spawn(_pi_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    cbk = -(-len(b) // world)
+    for r in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"pi_{r}.npy")), want), r     # identical on every rank, bitwise
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"pi1_{r}.npy")), want[:, :1])
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"pi2_{r}.npy")), want[:1, :])
+        # rank r's callback saw exactly its column block, row index outer / column index inner (tensorci2.rs:1862-1869 restricted)
+        seen = np.load(os.path.join(str(tmp_path), f"seen_{r}.npy"))
+        cols = b[r * cbk:(r + 1) * cbk]
+        expect = np.array([list(ra) + list(cb) for ra in a for cb in cols], dtype=np.int64).reshape(-1, 6)
+        assert np.array_equal(seen.reshape(-1, 6), expect), r
+
+
+def test_pi_shard_argument_errors():
+    import t4a_amd
+    a, b = _pi_sets()
+    with pytest.raises(t4a_amd.T4aError) as e:
+        t4a_amd.pi_shard_eval(2, 2, _pi_fn, a, 0, b, 2, 6, lambda s: s)
+    assert e.value.code == t4a_amd.INVALID_ARGUMENT
+    with pytest.raises(t4a_amd.T4aError) as e:
+        t4a_amd.pi_shard_eval(0, 2, _pi_fn, a, 0, b, 2, 6, lambda s: np.zeros(1))    # a gather that returns the wrong size
+    assert e.value.code == t4a_amd.CALLBACK_ERROR
+    with pytest.raises(t4a_amd.T4aError) as e:
+        t4a_amd.pi_shard_eval(0, 1, _pi_fn, a, 0, b, 3, 6)                             # halves do not cover the sites
+    assert e.value.code == t4a_amd.INVALID_ARGUMENT

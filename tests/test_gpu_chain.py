@@ -360,7 +360,7 @@ def test_group_chain_mixed_lengths_fall_back_to_own_chains(t4a):
 
 def test_exception_while_a_chain_is_in_flight_leaves_the_handles_usable(tmp_path):
     """An error raised between the launch of a bond chain and its completion (here: injected into the issue of the previous
-    iteration's fill_site_tensors, T4A_TEST_THROW_IN_FILL) must not leave the handle with a chain 'in flight' and its XCD — or,
+    iteration's fill_site_tensors: T4A_TEST_THROW_IN_FILL, honoured only by the test-hook twin libt4a_gpu_testhooks.so) must not leave the handle with a chain 'in flight' and its XCD — or,
     for a group, the whole chip — reserved: the failed call reports the error, the same handles then optimise normally and reach
     the result of handles that never failed.  Runs in a child process (the injection is read once per process)."""
     import subprocess
@@ -392,7 +392,9 @@ print("fresh equal:", all(np.array_equal(b.i_set(p), a2.i_set(p)) for p in range
 a.optimize(opts, final_sweep1site=False)   # the handle that failed is usable again
 print("failed handle usable:", a.chain_stats()["half_sweeps"] > 0, max(a.link_dims()) == max(b.link_dims()))
 '''
-    env = dict(os.environ, T4A_TEST_THROW_IN_FILL="2")
+    hooks = os.path.join(ROOT, "tensor4all-rs_amd", "lib", "libt4a_gpu_testhooks.so")  # (the production library has no fault injector)
+    assert os.path.exists(hooks), "build.py builds the test-hook twin of the library"
+    env = dict(os.environ, T4A_TEST_THROW_IN_FILL="2", T4A_GPU_LIB=hooks)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert "error 1: True" in r.stdout, r.stdout + r.stderr
     assert "fresh equal: True" in r.stdout, r.stdout + r.stderr
@@ -412,7 +414,7 @@ hs2 = [make(k) for k in range(4)]
 t4a.optimize_group(hs2, opts, final_sweep1site=False)
 print("group after failure equal:", all(np.array_equal(x.i_set(p), y.i_set(p)) for x, y in zip(ref, hs2) for p in range(n)))
 '''
-    env = dict(os.environ, T4A_TEST_THROW_IN_FILL="6")
+    env = dict(os.environ, T4A_TEST_THROW_IN_FILL="6", T4A_GPU_LIB=hooks)
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert "error 2: True" in r.stdout, r.stdout + r.stderr
     assert "group after failure equal: True" in r.stdout, r.stdout + r.stderr

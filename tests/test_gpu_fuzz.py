@@ -98,6 +98,36 @@ def test_rrlu_on_the_widest_single_xcd_plans(t4a, left, shape):
 
 
 @pytest.mark.parametrize("left", [True, False])
+@pytest.mark.parametrize("shape", [(1464, 1448), (1024, 1428), (1428, 1024), (1424, 512), (1100, 900), (1536, 1536), (1300, 200), (600, 1500)])
+def test_rrlu_beyond_one_xcd(t4a, left, shape):
+    """Round 5: matrices beyond one XCD's 1024 x 1024 (kernels_rrlu_xcd2m.hip) — 24 row slots per lane (up to 1 536 rows) and the
+    columns over the agents of two or three XCDs with one polling wave per XCD; BASELINE.json configs[3]'s saturated bonds with the
+    history extras are ~1 450 x 1 450.  Random, tie-ridden (every step through the exact walk over all full keys), low-rank, zero and
+    wide-range matrices at those shapes against the oracle bitwise, rank capped so that the oracle stays fast; non-finite inputs go
+    back to the chip-wide kernel."""
+    m, n = shape
+    rng = np.random.default_rng(9100 + m + n)
+    kw = dict(left_orthogonal=left)
+    _same_outcome(t4a, rng.uniform(-1, 1, size=(m, n)), max_bond_dim=40, rel_tol=0.0, abs_tol=0.0, **kw)
+    _same_outcome(t4a, rng.integers(-2, 3, size=(m, n)).astype(float), max_bond_dim=16, rel_tol=0.0, abs_tol=0.0, **kw)
+    r = 12
+    _same_outcome(t4a, rng.standard_normal((m, r)) @ rng.standard_normal((r, n)), max_bond_dim=30, **kw)
+    _same_outcome(t4a, np.zeros((m, n)), **kw)
+    wide = rng.standard_normal((m, n)) * 10.0 ** rng.integers(-12, 3, size=(m, 1))
+    _same_outcome(t4a, wide, max_bond_dim=24, rel_tol=1e-9, abs_tol=0.0, **kw)
+    big = rng.uniform(-1, 1, size=(m, n))          # scores that overflow: the exact walk must see the infinity and hand over
+    big[m // 2, n // 3] = 1e200
+    big[m // 3, n // 2] = -3e199
+    _same_outcome(t4a, big, max_bond_dim=6, rel_tol=0.0, abs_tol=0.0, **kw)
+    bad = rng.uniform(-1, 1, size=(m, n))
+    bad[m - 1, n - 1] = np.nan
+    _same_outcome(t4a, bad, max_bond_dim=5, **kw)
+    bad[m - 1, n - 1] = 0.5
+    bad[0, 0] = np.nan                              # the NaN incumbent on the diagonal stays (matrixlu.rs:480-519)
+    _same_outcome(t4a, bad, max_bond_dim=4, **kw)
+
+
+@pytest.mark.parametrize("left", [True, False])
 def test_rrlu_special_values_on_multi_workgroup_shapes(t4a, left):
     """Shapes that take the single-XCD kernel (more than 64 x 64 entries, up to 768 x 768) with the values that leave its
     fast paths: scores that overflow to +inf or underflow to 0 (ties between different |v|: exact sweep on the squares,

@@ -271,3 +271,61 @@ def test_site_sharded_fill_on_device_is_bitwise_the_unsharded_fill(rccl):
             assert np.array_equal(t.site_tensor(s), ref.site_tensor(s)), f"site {s}"
     pts = np.random.default_rng(1).integers(0, 2, size=(64, n))
     assert np.array_equal(shards[0].evaluate(pts), ref.evaluate(pts))
+
+
+def test_site_shard_exchange_loop_replays_the_fill_graph_on_a_side_stream(rccl):
+    """replaying the captured fill_site_tensors graph on a handle whose cores are exported / imported
+    asynchronously faulted in 25 - 75 % of `bench.py --mode site-shard` runs.  Round 5 bisected it to the LEGACY DEFAULT STREAM as
+    event consumer / producer (profiles/r05_fill_graph_fault_bisect.txt): on a side stream the replay is safe, on stream 0 the
+    library issues its fills directly.  Both arms, looped: many exchanges, every gathered core bitwise the unsharded fill."""
+    import torch
+    import t4a_amd
+    from t4a_amd import parallel
+    n, chi = 16, 32
+    spec = t4a_amd.quantics_osc2d(n, k1=37, k2=53, k3=211, eps=0.3)
+    cap = chi * 2 * chi
+
+    def run(legacy):
+        if legacy:
+            torch.cuda.set_stream(torch.cuda.default_stream())
+        else:
+            torch.cuda.set_stream(torch.cuda.Stream())
+        tci = t4a_amd.TensorCI2([2] * n)
+        tci.set_function(spec)
+        tci.add_global_pivots([[0] * n])
+        tci.set_max_sample_value(1.0)
+        tci.set_keep_site_tensors(True)
+        tci.set_site_shard(0, 1)
+        opt = t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=1, ncheck_history=10 ** 6, nsearch=0, max_nglobal_pivot=0)
+        import os
+        os.environ["T4A_SS_LEGACY_STREAM" if legacy else "T4A_SS_UNUSED"] = "1"
+        try:
+            xchg = parallel.ShardedCoreExchange(None, torch, n, cap, parallel.DeviceShardAdapter(tci, torch, cap), "cuda")
+        finally:
+            os.environ.pop("T4A_SS_LEGACY_STREAM", None)
+            os.environ.pop("T4A_SS_UNUSED", None)
+        assert (torch.cuda.current_stream().cuda_stream == 0) == legacy
+        for _ in range(24):           # saturates after ~8 half-sweeps: the remaining fills have identical signatures
+            tci.optimize(opt, final_sweep1site=False)
+            xchg.exchange()
+        xchg.finish()
+        torch.cuda.synchronize()
+        st = tci.fill_stats()
+        cores = [tci.site_tensor(s) for s in range(n)]
+        ref = t4a_amd.TensorCI2([2] * n)
+        ref.set_function(spec)
+        for s in range(n):
+            ref.set_index_set(0, s, tci.i_set(s))
+            ref.set_index_set(1, s, tci.j_set(s))
+        ref.fill_site_tensors()
+        for s in range(n):
+            assert np.array_equal(cores[s], ref.site_tensor(s)), s
+        return st
+
+    try:
+        side = run(False)
+        assert side["graph_replays"] >= 1 and side["graph_captures"] >= 1, side
+        legacy = run(True)
+        assert legacy["graph_replays"] == 0 and legacy["fills"] >= 20, legacy
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())

@@ -99,3 +99,52 @@ def test_cfg5_builtin_quantics_patches(t4a):
     exact = ob.fn_eval(spec, pts)
     assert np.abs(g.evaluate(pts) - exact).max() < 1e-4
     assert np.abs(g.evaluate(pts) - o.evaluate(pts)).max() < 1e-8
+
+
+def test_reference_fixtures_not_covered_above_run_through_the_device(t4a):
+    """The remaining cases tests/test_oracle_patch.py pins to the reference (adaptive_interpolation/tests.rs), straight through the
+    DEVICE path with the reference's own expectations — the host logic of csrc/patching.hip is not compared with its sibling in the
+    oracle here, but with what the Rust tests assert (round-4 review, weak 1)."""
+    # the batched callback is what gets called (tests.rs: batched evaluation), values exact
+    calls = [0]
+
+    class F:
+        def __call__(self, i):
+            return float(i[0] + i[1] + 1)
+
+        def batched(self, pts):
+            calls[0] += 1
+            return [float(p[0] + p[1] + 1) for p in pts]
+
+    r = t4a.adaptiveinterpolate(F(), [2, 2], [[1, 1]], t4a.TCI2Options())
+    assert list(r.dense()) == pytest.approx([1.0, 2.0, 2.0, 3.0], abs=1e-12) and calls[0] > 0
+    # issue #598 regression (tests.rs:434-491): near-zero child patches of a fused-quantics Gaussian mixture must be accepted; the
+    # reference requires a valid, complete partition — disjoint projectors that tile the index space exactly once, finite values
+    W, A, C, L, R = [1.3, 0.9, 0.9], [2.8, 5.4, 0.7], [(0.4, 0.1), (3.8, -0.8), (-5.5, -2.1)], 12.0, 7
+
+    def batch(pts):
+        pts = np.asarray(pts, dtype=np.int64).reshape(-1, R)
+        sh = (R - 1 - np.arange(R))[None, :]
+        ix = ((pts & 1) << sh).sum(axis=1)
+        iy = (((pts >> 1) & 1) << sh).sum(axis=1)
+        step = 2.0 * L / (1 << R)
+        x, y = -L + ix * step, -L + iy * step
+        return sum(W[i] * np.exp(-A[i] * ((x - C[i][0]) ** 2 + (y - C[i][1]) ** 2)) for i in range(3))
+
+    class Mixture:
+        def __call__(self, index):
+            return float(batch([list(index)])[0])
+
+        def batched(self, pts):
+            return batch(pts)
+
+    opt = t4a.TCI2Options(tolerance=1e-8, max_bond_dim=12, max_iter=20, normalize_error=False, seed=1)
+    g = t4a.adaptiveinterpolate(Mixture(), [4] * R, [], opt)
+    assert len(g) > 1 and disjoint(g.projectors())
+    assert sum(4 ** (R - len(g.projector(k))) for k in range(len(g))) == 4 ** R
+    pts = np.random.default_rng(0).integers(0, 4, size=(300, R))
+    vals = g.evaluate(pts)
+    assert np.all(np.isfinite(vals))
+    # ... and accurate where the mixture is not negligible (the patches interpolate it to the tolerance of the run)
+    exact = batch(pts)
+    assert np.abs(vals - exact).max() < 1e-3

@@ -640,12 +640,17 @@ def test_cfg4_full_size_half_sweep_matches_oracle(t4a):
     o.set_max_sample_value(g.max_sample_value())
     g.clear_history()
     o.clear_history()
-    one = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=1, ncheck_history=20, **PARITY)
-    g.optimize(one, final_sweep1site=False)
-    o.optimize(one, final_sweep1site=False)
+    # TWO more iterations (forward, then backward): the second one merges the history extras of the first — the ~1 450 x 1 450
+    # matrices of configs[3] as optimize runs it, on the kernels for matrices beyond one XCD since round 5 (kernels_rrlu_xcd2m.hip)
+    two = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=2, ncheck_history=20, **PARITY)
+    g.optimize(two, final_sweep1site=False)
+    o.optimize(two, final_sweep1site=False)
     assert np.array_equal(g.last_sweep_shapes(), o.last_sweep_shapes())
-    assert int(g.last_sweep_shapes()[:, 0].max()) >= 1024
+    assert int(g.last_sweep_shapes()[:, 0].max()) >= 1400 and int(g.last_sweep_shapes()[:, 1].max()) >= 1400
+    st = g.chain_stats()
+    assert st["not_eligible"] == 0 and st["fell_back"] == 0, st   # every half-sweep of configs[3] is a device-side chain now
     assert_same_sets(g, o, n)
+    assert np.array_equal(g.pivot_errors(), o.pivot_errors()) and np.array_equal(g.bond_errors(), o.bond_errors())
     assert np.array_equal(g.history()[1], o.history()[1])
     assert g.max_sample_value() == o.max_sample_value()
     g.fill_site_tensors()
@@ -654,6 +659,33 @@ def test_cfg4_full_size_half_sweep_matches_oracle(t4a):
     pts = rng.integers(0, 2, size=(200, n))
     gv, ov = g.evaluate(pts), o.evaluate(pts)
     assert np.abs(gv - ov).max() <= 1e-10 * max(1.0, np.abs(ov).max())
+
+
+def test_cfg4_from_scratch_iterations_match_oracle(t4a):
+    """BASELINE configs[3] (d = 40, chi = 512) from the single initial pivot on BOTH sides, as the cfg3 test does: runs of k = 7 and 9
+    iterations (a run of k iterations ends in the state a longer one passes through) — ranks 1 -> 512 and then the first iteration
+    that merges the history extras of a saturated one, i.e. the growth path into the shapes beyond one XCD's 1024 x 1024 (the
+    saturated iterations themselves: test_cfg4_full_size_half_sweep_matches_oracle).  ~45 s of oracle time (iteration 9 alone ~20 s)."""
+    from t4a_amd.functions import quantics_osc2d
+    n, chi = 40, 512
+    spec = quantics_osc2d(n, k1=37, k2=53, k3=20011, eps=0.5, k4=1048583, delta=0.5)
+    for k in (7, 9):
+        opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=k, ncheck_history=20, **PARITY)
+        g, o = both(t4a, spec, [2] * n)
+        for t in (g, o):
+            t.add_global_pivots([[0] * n])
+            t.set_max_sample_value(1.0)
+            t.optimize(opts, final_sweep1site=False)
+        assert_same_sets(g, o, n)
+        assert g.link_dims() == o.link_dims(), k
+        assert np.array_equal(g.pivot_errors(), o.pivot_errors()), k
+        assert np.array_equal(g.bond_errors(), o.bond_errors()), k
+        assert g.history()[0] == o.history()[0] and np.array_equal(g.history()[1], o.history()[1]), k
+        assert np.array_equal(g.last_sweep_shapes(), o.last_sweep_shapes()), k
+        assert g.max_sample_value() == o.max_sample_value() and g.termination() == o.termination(), k
+        st = g.chain_stats()
+        assert st["fell_back"] == 0 and st["not_eligible"] == 0, (k, st)
+    assert max(g.link_dims()) == chi and int(g.last_sweep_shapes().max()) > 1024
 
 
 def test_global_pivot_search_matches_oracle_stream(t4a):

@@ -422,3 +422,33 @@ def test_tt_inner_product(t4a):
         da.inner_product(c([2, 3], 1.0))
     with pytest.raises(t4a.T4aError):
         da.inner_product(c([2, 3, 2, 4, 3], 1.0))
+
+
+def test_svd_tiny_and_rank_deficient_matrices_on_both_jacobi_paths(t4a):
+    """n <= 16 columns run the single-launch Jacobi (one workgroup, no host round trip per sweep), wider matrices the
+    blocked tournament.  2 x 2 ... 16 x 16 and 17 ... 40 columns, tall / wide, rank-deficient (outer products, repeated columns, zero
+    matrices): singular values against LAPACK to 1e-10 of the largest, U S Vt reconstructs A, U and V orthonormal on the numerical
+    range (svd_backend, tensor4all-tensorbackend/src/backend.rs:709-742)."""
+    rng = np.random.default_rng(21)
+    shapes = [(2, 2), (3, 2), (2, 5), (4, 4), (7, 3), (8, 8), (16, 16), (40, 16), (16, 9), (17, 17), (33, 20), (20, 40), (64, 24)]
+    for (m, n) in shapes:
+        k = min(m, n)
+        cases = [rng.standard_normal((m, n)),
+                 np.outer(rng.standard_normal(m), rng.standard_normal(n)),                       # rank 1
+                 rng.standard_normal((m, max(1, k // 2))) @ rng.standard_normal((max(1, k // 2), n)),  # rank k / 2
+                 np.zeros((m, n))]
+        dup = rng.standard_normal((m, n))
+        dup[:, -1] = dup[:, 0]                                                                   # a repeated column
+        cases.append(dup)
+        for a in cases:
+            u, s_, vt = t4a.svd_backend(a)
+            ref = np.linalg.svd(a, compute_uv=False)
+            scale = max(ref[0], 1e-300) if ref.size else 1.0
+            assert u.shape == (m, k) and s_.shape == (k,) and vt.shape == (k, n)
+            assert np.all(np.diff(s_) <= 1e-12 * max(scale, 1.0)) and np.all(s_ >= 0.0)
+            assert np.abs(s_ - ref).max() <= 1e-10 * max(scale, 1.0), (m, n)
+            assert np.abs((u * s_) @ vt - a).max() <= 1e-10 * max(scale, 1.0), (m, n)
+            r = int((ref > 1e-10 * max(scale, 1e-300)).sum())
+            if r:
+                assert np.abs(u[:, :r].T @ u[:, :r] - np.eye(r)).max() <= 1e-10, (m, n)
+                assert np.abs(vt[:r] @ vt[:r].T - np.eye(r)).max() <= 1e-10, (m, n)

@@ -12,6 +12,7 @@ OUT=lib/libt4a_gpu_alt${STAMP_WAVE:+_w$STAMP_WAVE}.so
 $hipcc $FL -c csrc/kernels_rrlu_xcd.hip -o build/kernels_rrlu_xcd_stamps.obj &
 $hipcc $FL -c csrc/kernels_rrlu_xcd2.hip -o build/kernels_rrlu_xcd2_stamps${STAMP_WAVE:+_w$STAMP_WAVE}.obj &
 $hipcc $FL -Iinclude -I../include -c csrc/kernels_rrlu_w1.hip -o build/kernels_rrlu_w1_stamps.obj &
+$hipcc $FL -c csrc/kernels_rrlu_xcd2m.hip -o build/kernels_rrlu_xcd2m_stamps${STAMP_WAVE:+_w$STAMP_WAVE}.obj &
 wait
-$hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $(ls build/*.o | grep -v "kernels_rrlu_xcd.o\|kernels_rrlu_xcd2.o\|kernels_rrlu_w1.o") build/kernels_rrlu_w1_stamps.obj build/kernels_rrlu_xcd_stamps.obj build/kernels_rrlu_xcd2_stamps${STAMP_WAVE:+_w$STAMP_WAVE}.obj
+$hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $(ls build/*.o | grep -v "kernels_rrlu_xcd.o\|kernels_rrlu_xcd2.o\|kernels_rrlu_w1.o\|kernels_rrlu_xcd2m.o") build/kernels_rrlu_xcd2m_stamps${STAMP_WAVE:+_w$STAMP_WAVE}.obj build/kernels_rrlu_w1_stamps.obj build/kernels_rrlu_xcd_stamps.obj build/kernels_rrlu_xcd2_stamps${STAMP_WAVE:+_w$STAMP_WAVE}.obj
 echo $OUT
