@@ -982,7 +982,7 @@ size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int)
 {
     // slots are padded to 64 * RPT rows; T4A_XCD_CSTRIDE (experiment, with a library built with -DT4A_X2_CSTRIDE): sparse slots
     static const size_t cstride = diag_env("T4A_XCD_CSTRIDE") ? (size_t)std::atol(diag_env("T4A_XCD_CSTRIDE")) : 256;
-    return (size_t)2 * plan.K * plan.W * XWAVES * (size_t)(4 * plan.RPT) * (cstride < 256 ? 256 : cstride) + (plan.K > 1 ? 256 : 0); // (+ the finalist granules of the XCDs)
+    return (size_t)2 * plan.K * plan.W * XWAVES * (size_t)(4 * plan.RPT) * (cstride < 256 ? 256 : cstride) + (plan.K > 1 ? 256 + (size_t)2 * plan.K * plan.W * XWAVES * 16 : 0); // (+ the finalist granules of the XCDs and the write-through copies of the full keys)
 }
 
 void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& a, hipStream_t stream)

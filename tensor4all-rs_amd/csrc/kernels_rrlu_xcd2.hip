@@ -246,8 +246,9 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
     const unsigned k2_base = 2u * (unsigned)NW * 16u;
     const unsigned cols_base = 4u * (unsigned)NW * 16u;
     const unsigned fin_base = cols_base + 2u * (unsigned)NW * (unsigned)(MP / 16) * (unsigned)T4A_X2_CSTRIDE; // [2][KX] finalist granules (agents on several XCDs)
+    const unsigned k3_base = fin_base + 256u;  // [2][NW] write-through copies of the full keys (agents on several XCDs: the exact walk)
     const __amdgpu_buffer_rsrc_t mail =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(fin_base + 2u * (unsigned)KX * 16u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.keys, 0, (int)(k3_base + (KX > 1 ? 2u * (unsigned)NW * 16u : 0u)), 0x00020000);
 
     int npiv = 0;
     double max_error = 0.0;             // kept by the polling waves
@@ -307,7 +308,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             kv.y = hi32(k1);
             kv.z = wave_bad;
             kv.w = tag ^ kv.x ^ kv.y ^ kv.z;
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, ST_AUX);
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, kslot, 0, 0); // (read inside this XCD only: a plain store, also when the agents span several XCDs)
         }
         u32x4 kg[4], kh[4];
         bool kg_issued = false;
@@ -412,7 +413,10 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             kv.y = hi32(cval);
             kv.z = meta;
             kv.w = tag ^ kv.x ^ kv.y ^ meta;
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, (int)k2_base + kslot, 0, ST_AUX);
+            if (lane == 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(kv, mail, (int)k2_base + kslot, 0, 0);
+                if constexpr (KX > 1) __builtin_amdgcn_raw_buffer_store_b128(kv, mail, (int)k3_base + kslot, 0, ST_AUX); // (a write-through copy for the exact walk over all XCDs' full keys)
+            }
         }
         // the polling wave sweeps the early keys now — they left their agents a whole position search ago, so this first sweep
         // normally finds them all.  Every lane fetches four keys; lanes beyond NW re-read the last key (a valid duplicate), so
@@ -456,6 +460,15 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
             }
             if (stamp_on) lds_stamps[5] += spins;
+            // agents on several XCDs: the first read of the REMOTE finalists goes out now — a read across the fabric takes ~2 400 cycles,
+            // and the remote XCDs publish theirs about a pick (~800 cycles) from now: it reaches the memory side after they have
+            u32x4 fr;
+            int xr = 0, fslot = 0;
+            if constexpr (KX > 1) {
+                fslot = (int)fin_base + (par * KX) * 16;
+                xr = (lane < KX && lane != xi) ? lane : (xi == 0 ? 1 : 0); // lane x reads XCD x's finalist (the others a remote duplicate)
+                fr = __builtin_amdgcn_raw_buffer_load_b128(mail, fslot + xr * 16, 0, BUF_SC1);
+            }
             // the full keys: fetched now, in flight while the early ones are examined (a late one is fetched again below)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -598,20 +611,21 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     // reads per round through the fabric; profiles/r05_xcd2m_phase_stamps.txt.)
                     // finalist granule: {value lo, value hi, meta | agent << 14 | give-up << 26 | undecided << 31, tag ^ fold}
                     bool need_exact = (wkz >> 31) != 0u; // (this XCD could not decide on its early keys alone)
-                    const int fslot = (int)fin_base + (par * KX) * 16;
                     if (rank == xi * p.W && lane == 0) {
                         u32x4 fv;
                         fv.x = wkx;
                         fv.y = wky;
                         fv.z = (wkz & 0x80003FFFu) | ((unsigned)wa_ << 14) | ((unsigned)giveup << 26);
                         fv.w = tag ^ fv.x ^ fv.y ^ fv.z;
-                        __builtin_amdgcn_raw_buffer_store_b128(fv, mail, fslot + xi * 16, 0, ST_AUX);
+                        // (two 64-bit atomic exchanges at agent scope instead of a write-through store: an atomic is performed at the
+                        // memory side at once, a store may sit in the write path for a while; a reader that sees one half old fails the
+                        // tag check and polls again)
+                        unsigned long long* const fp = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.keys) + fslot + xi * 16);
+                        (void)__hip_atomic_exchange(fp, ((unsigned long long)fv.y << 32) | fv.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        (void)__hip_atomic_exchange(fp + 1, ((unsigned long long)fv.w << 32) | fv.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     double best = __builtin_fabs(mk_f64(wkx, wky));
                     {
-                        // lane x reads XCD x's finalist (lanes beyond KX and the own XCD's lane re-read a remote one: a valid duplicate)
-                        const int xr = (lane < KX && lane != xi) ? lane : (xi == 0 ? 1 : 0);
-                        u32x4 fr = __builtin_amdgcn_raw_buffer_load_b128(mail, fslot + xr * 16, 0, BUF_SC1);
                         unsigned sp2 = 0;
                         for (;;) {
                             if (__all((fr.x ^ fr.y ^ fr.z ^ fr.w) == tag)) break;
@@ -656,7 +670,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                             for (;;) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
-                                    kq[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + min(lane_o + 64 * (j0 + j), NW - 1)) * 16, 0, BUF_SC1);
+                                    kq[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k3_base + (par * NW + min(lane_o + 64 * (j0 + j), NW - 1)) * 16, 0, BUF_SC1);
                                 bool ok = true;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) ok &= ((kq[j].x ^ kq[j].y ^ kq[j].z ^ kq[j].w) == tag);

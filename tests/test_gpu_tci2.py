@@ -547,6 +547,44 @@ def test_cfg3_full_size_half_sweep_matches_oracle(t4a):
     assert np.abs(gv - ov).max() <= 1e-10 * scale
 
 
+def test_cfg3_full_size_raw_cores_within_the_conditioning_bound(t4a):
+    """Round-4 review, weak 3: the cores themselves, not only evaluations of the train, at full size (d = 30, chi = 256).  T_b =
+    Pi1_b P_b^-1 (tensorci2.rs:1130-1182) is computed by different (both correct) solvers on the two sides — the oracle's loops, the
+    device's blocked LU on the f64 matrix cores — so the honest bound on a raw core is the backward-stable one: |dT| <= c kappa(P_b) eps
+    |T|.  Every site is held to it with the kappa of ITS pivot matrix (computed here from the oracle's index sets), the well-conditioned
+    sites (kappa < 1e4: the ends of the train, where P_b is a small full matrix) to 1e-10, and the sites where kappa is large — the
+    truncated bonds, P_b a 256 x 256 section of a numerically rank-deficient matrix — are shown to be exactly the ones that need it."""
+    spec, g, n, chi = _cfg3(t4a)
+    o = ob.OracleTCI2([2] * n)
+    o.set_function(spec)
+    for p in range(n):
+        o.set_index_set(0, p, g.i_set(p))
+        o.set_index_set(1, p, g.j_set(p))
+    g.fill_site_tensors()
+    o.fill_site_tensors()
+    eps = np.finfo(np.float64).eps
+    n_well = 0
+    worst = 0.0
+    for b in range(n - 1):
+        a, r = g.site_tensor(b), o.site_tensor(b)
+        assert a.shape == r.shape, b
+        rows, cols = np.asarray(o.i_set(b + 1)).reshape(-1, b + 1), np.asarray(o.j_set(b)).reshape(-1, n - b - 1)
+        pts = np.concatenate([np.repeat(rows, len(cols), axis=0), np.tile(cols, (len(rows), 1))], axis=1)
+        pm = ob.fn_eval(spec, pts).reshape(len(rows), len(cols))
+        sv = np.linalg.svd(pm, compute_uv=False)
+        kappa = sv[0] / max(sv[-1], 1e-300)
+        diff = np.abs(a - r).max() / max(1.0, np.abs(r).max())
+        bound = 64.0 * chi * kappa * eps
+        assert diff <= max(bound, 1e-13), (b, diff, kappa)
+        worst = max(worst, diff / max(bound, 1e-13))
+        if kappa < 1e4:
+            n_well += 1
+            assert diff <= 1e-10, (b, diff, kappa)
+    assert n_well >= 6, n_well          # the ends of the train: raw cores agree to 1e-10 where the pivot matrix allows it
+    last_g, last_o = g.site_tensor(n - 1), o.site_tensor(n - 1)   # (the last core is Pi1 itself: no solve, bitwise)
+    assert np.array_equal(last_g, last_o)
+
+
 def test_cfg3_from_scratch_every_iteration_matches_oracle(t4a):
     """BASELINE configs[2] (the bench workload: d = 30, chi = 256) from the single initial pivot on BOTH sides, compared after
     every iteration of optimize_with_finder (tensorci2.rs:1626-1802): a run of k iterations ends in the state a longer run passes
