@@ -736,6 +736,10 @@ t4a_gpu_status t4a_gpu_tci2_chain_stats_ext(const t4a_gpu_tci2* h, uint64_t* out
  * graph captures (a capture happens the second time a fill with the same signature — device addresses, shapes, staging buffers —
  * is issued; handles whose cores were exported / imported through stream 0 never replay: csrc/tci2.hip issue_fill_ops). */
 t4a_gpu_status t4a_gpu_tci2_fill_stats(const t4a_gpu_tci2* h, uint64_t* out /* [3] */);
+/* PivotSearchStrategy::Rook on this handle: out[0] searches that ran device-resident (one launch, one host synchronisation per bond:
+ * built-in functors), out[1] rows / columns they visited, out[2] searches driven from the host (callback functions: one round trip per
+ * visited row / column), out[3] host synchronisations of all searches. */
+t4a_gpu_status t4a_gpu_tci2_rook_stats(const t4a_gpu_tci2* h, uint64_t* out /* [4] */);
 /* optimize_with_finder (tensorci2.rs:1626-1802) on up to EIGHT handles at once, driven in lock-step by the calling thread: every
  * iteration enqueues the half-sweeps of all handles — as ONE chain of launches when they line up (same number of sites, built-in
  * functors: every kernel serves all handles, handle i's rrLU runs on XCD i), otherwise one chain per handle — then completes them

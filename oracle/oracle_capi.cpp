@@ -277,7 +277,7 @@ int oracle_tci2_set_builtin_fn(void* h, int fid, int n_acc, const double* params
         o->f = fn;
         o->has_batched = false;
 #if defined(_OPENMP)
-        o->tci->parallel_eval = true; // built-in functions are pure: candidate matrices and fill sites may use all host threads
+        if (o->tci) o->tci->parallel_eval = true; // (a function holder made by oracle_fn_new has no TCI state)  built-in functions are pure: candidate matrices and fill sites may use all host threads
 #endif
     });
 }

@@ -1100,6 +1100,19 @@ t4a_gpu_status t4a_gpu_tci2_chain_stats_ext(const t4a_gpu_tci2* h, uint64_t* out
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_rook_stats(const t4a_gpu_tci2* h, uint64_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        T4A_REQUIRE_PTR(out);
+        const RookWork& w = h->impl.rook_work();
+        out[0] = w.n_device_searches;
+        out[1] = w.n_device_visits;
+        out[2] = w.n_host_searches;
+        out[3] = w.n_host_syncs;
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_fill_stats(const t4a_gpu_tci2* h, uint64_t* out)
 {
     return guarded([&] {
@@ -1227,6 +1240,9 @@ t4a_gpu_status t4a_gpu_luci_rook_f64(const double* a, size_t m, size_t n, size_t
         src.row = [&](int r, double* d_out) {
             T4A_HIP(hipMemcpyAsync(d_out, d_at + (size_t)r * n, n * sizeof(double), hipMemcpyDeviceToDevice, st));
         };
+        static const bool host_driven = std::getenv("T4A_ROOK_HOST") != nullptr; // (A/B and parity of the two search drivers)
+        if (!host_driven)
+            src.full = [&](double* d_out) { T4A_HIP(hipMemcpyAsync(d_out, d_a, count * sizeof(double), hipMemcpyDeviceToDevice, st)); };
         RrLUOptions o;
         o.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim;
         o.rel_tol = rel_tol;

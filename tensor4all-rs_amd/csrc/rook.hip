@@ -110,6 +110,332 @@ __global__ void __launch_bounds__(256) rook_row_residual_kernel(const double* __
 
 __global__ void rook_set_flag_kernel(int* flags, int idx) { flags[idx] = 1; }
 
+// ------------------------------------------------------------------------------------------------
+// Device-resident rook search (round 5; block_rook.rs:71-118 rook_pivot + :120-190 factorize_lazy): ONE persistent workgroup runs the
+// whole pivot loop on a materialised matrix — per pivot the LU of the k x k pivot block and X = P^-1 A[I, :] (the reference recomputes
+// both from scratch for every pivot), then the alternating column / row arg-max of the residual — and hands back the selection.  The
+// arithmetic is that of the launch-per-visit path below, operation for operation: lu_kernel's right-looking LU with partial pivoting
+// (first maximum of |a_ik|), trsm_left_kernel's column-oriented substitutions (k ascending / descending, separately rounded multiply
+// and subtract), rook_col/row_residual_kernel's j-ascending sums, block_argmax's first strict maximum in ascending index order.
+// ------------------------------------------------------------------------------------------------
+struct RookDenseArgs {
+    const double* A; // M x N, column-major
+    int M, N, max_bond;
+    double rel_tol, abs_tol;
+    double* P;       // kcap x kcap
+    double* X;       // kcap x N
+    double* b;       // kcap
+    double* y;       // kcap
+    int* I;          // kcap selected rows
+    int* J;          // kcap selected columns
+    int* rowsel;     // M
+    int* colsel;     // N
+    int* seen;       // M + N visited flags
+    int* piv;        // kcap
+    double* dres;    // [0] last error [1] sampled max [2] evaluated entries [3 + k] accepted pivot errors
+    int* ires;       // [0] rank [1] info [2] visits
+};
+
+__device__ inline void rook_block_argmax(double bv, int bi, double* s_v, int* s_i, double* out_v, int* out_i)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    __syncthreads(); // (the scratch of the previous reduction has been read)
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_i[wave] = bi;
+    }
+    __syncthreads();
+    double v = s_v[0];
+    int idx = s_i[0];
+    for (int q = 1; q < nw; ++q)
+        if (s_v[q] > v || (s_v[q] == v && s_i[q] < idx)) {
+            v = s_v[q];
+            idx = s_i[q];
+        }
+    *out_v = v;
+    *out_i = idx;
+}
+
+// T x = b in place for ONE right-hand side, column-oriented like trsm_left_kernel (barrier per step)
+__device__ inline void rook_trsm_vec(const double* T, int ldt, int n, bool lower, bool unit, double* b)
+{
+    const int tid = threadIdx.x, NT = blockDim.x;
+    for (int step = 0; step < n; ++step) {
+        const int k = lower ? step : (n - 1 - step);
+        const double* tk = T + (size_t)k * ldt;
+        if (!unit) {
+            if (tid == 0) b[k] = b[k] / tk[k];
+            __syncthreads();
+        }
+        const int lo = lower ? k + 1 : 0;
+        const int cnt = lower ? (n - 1 - k) : k;
+        const double bk = b[k];
+        for (int e = tid; e < cnt; e += NT) {
+            const int i = lo + e;
+            const double prod = tk[i] * bk;
+            b[i] = b[i] - prod;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(1024) rook_dense_kernel(RookDenseArgs a)
+{
+    __shared__ double s_v[16];
+    __shared__ int s_i[16];
+    __shared__ int s_int[8];
+    __shared__ double s_dbl[2];
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int M = a.M, N = a.N;
+    const double* A = a.A;
+    for (int i = tid; i < M; i += NT) a.rowsel[i] = 0;
+    for (int j = tid; j < N; j += NT) a.colsel[j] = 0;
+    for (int e = tid; e < M + N; e += NT) a.seen[e] = 0;
+    if (tid == 0) a.ires[1] = 0;
+    __syncthreads();
+    int k = 0, n_rows_seen = 0, n_cols_seen = 0, visits = 0;
+    double max_error = 0.0, last_error = __builtin_nan(""), evals = 0.0;
+    bool singular = false;
+    while (k < a.max_bond) {
+        // remaining_indices (:63-69): first unselected row / column and how many there are
+        int fr = 0x7fffffff, fc = 0x7fffffff, nr = 0, nc = 0;
+        for (int i = tid; i < M; i += NT)
+            if (!a.rowsel[i]) {
+                fr = i < fr ? i : fr;
+                ++nr;
+            }
+        for (int j = tid; j < N; j += NT)
+            if (!a.colsel[j]) {
+                fc = j < fc ? j : fc;
+                ++nc;
+            }
+        if (tid < 4) s_int[tid] = tid < 2 ? 0x7fffffff : 0;
+        __syncthreads();
+        atomicMin(&s_int[0], fr);
+        atomicMin(&s_int[1], fc);
+        atomicAdd(&s_int[2], nr);
+        atomicAdd(&s_int[3], nc);
+        __syncthreads();
+        const int first_row = s_int[0], first_col = s_int[1], n_rem_rows = s_int[2], n_rem_cols = s_int[3];
+        __syncthreads();
+        if (n_rem_rows == 0 || n_rem_cols == 0) break;
+        if (k > 0) {
+            // factor_step: P = A[I, J] -> LU in place (row swaps applied to X as well); X = P^-1 A[I, :]
+            for (int e = tid; e < k * k; e += NT) a.P[e] = A[(size_t)a.I[e % k] + (size_t)M * a.J[e / k]];
+            for (long long e = tid; e < (long long)k * N; e += NT) a.X[e] = A[(size_t)a.I[e % k] + (size_t)M * (e / k)];
+            __syncthreads();
+            for (int c = 0; c < k; ++c) { // lu_kernel, one column per pass
+                double bv = -1.0;
+                int bi = 0x7fffffff;
+                for (int i = c + tid; i < k; i += NT) {
+                    const double v = fabs(a.P[(size_t)c * k + i]);
+                    if (v > bv || (v == bv && i < bi)) {
+                        bv = v;
+                        bi = i;
+                    }
+                }
+                double gv;
+                int gi;
+                rook_block_argmax(bv, bi, s_v, s_i, &gv, &gi);
+                if (tid == 0) {
+                    a.piv[c] = gi;
+                    if (!(gv > 0.0) && a.ires[1] == 0) a.ires[1] = c + 1;
+                }
+                const int p = gi;
+                if (p != c && p < k) {
+                    for (int q = tid; q < k; q += NT) {
+                        const double t = a.P[(size_t)q * k + c];
+                        a.P[(size_t)q * k + c] = a.P[(size_t)q * k + p];
+                        a.P[(size_t)q * k + p] = t;
+                    }
+                    for (int q = tid; q < N; q += NT) {
+                        const double t = a.X[(size_t)q * k + c];
+                        a.X[(size_t)q * k + c] = a.X[(size_t)q * k + p];
+                        a.X[(size_t)q * k + p] = t;
+                    }
+                }
+                __syncthreads();
+                const double pv = a.P[(size_t)c * k + c];
+                if (pv == 0.0 || pv != pv) {
+                    __syncthreads();
+                    continue;
+                }
+                __syncthreads();
+                for (int i = c + 1 + tid; i < k; i += NT) a.P[(size_t)c * k + i] = a.P[(size_t)c * k + i] / pv;
+                __syncthreads();
+                const int rem = k - c - 1;
+                for (int e = tid; e < rem * rem; e += NT) {
+                    const int i = c + 1 + e % rem, q = c + 1 + e / rem;
+                    const double prod = a.P[(size_t)c * k + i] * a.P[(size_t)q * k + c];
+                    a.P[(size_t)q * k + i] = a.P[(size_t)q * k + i] - prod;
+                }
+                __syncthreads();
+            }
+            singular = a.ires[1] != 0;
+            // L X' = P_swap A[I, :], then U X = X' (trsm_left_kernel over all N right-hand sides)
+            for (int pass = 0; pass < 2; ++pass) {
+                const bool lower = pass == 0;
+                for (int step = 0; step < k; ++step) {
+                    const int kk = lower ? step : (k - 1 - step);
+                    const double* tk = a.P + (size_t)kk * k;
+                    if (!lower) {
+                        const double dkk = tk[kk];
+                        for (int c = tid; c < N; c += NT) a.X[(size_t)c * k + kk] = a.X[(size_t)c * k + kk] / dkk;
+                        __syncthreads();
+                    }
+                    const int lo = lower ? kk + 1 : 0;
+                    const int cnt = lower ? (k - 1 - kk) : kk;
+                    for (long long e = tid; e < (long long)cnt * N; e += NT) {
+                        const int i = lo + (int)(e % cnt), c = (int)(e / cnt);
+                        const double prod = tk[i] * a.X[(size_t)c * k + kk];
+                        a.X[(size_t)c * k + i] = a.X[(size_t)c * k + i] - prod;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        // rook_pivot (:71-118)
+        int cur_col = first_col, cur_row = first_row;
+        double pivot_abs = 0.0;
+        const int max_steps = n_rem_rows + n_rem_cols + 1;
+        for (int it = 0; it < max_steps; ++it) {
+            if (singular) break;
+            ++visits;
+            if (!a.seen[M + cur_col]) { // (uniform: every thread reads the same flag)
+                evals += (double)(M - n_rows_seen);
+                ++n_cols_seen;
+            }
+            __syncthreads();
+            if (tid == 0) a.seen[M + cur_col] = 1;
+            const double* a_c = A + (size_t)M * cur_col;
+            if (k > 0) {
+                for (int j = tid; j < k; j += NT) a.b[j] = a_c[a.I[j]];
+                __syncthreads();
+                if (tid == 0)
+                    for (int j = 0; j < k; ++j) {
+                        const int p = a.piv[j];
+                        if (p != j) {
+                            const double t = a.b[j];
+                            a.b[j] = a.b[p];
+                            a.b[p] = t;
+                        }
+                    }
+                __syncthreads();
+                rook_trsm_vec(a.P, k, k, true, true, a.b);
+                rook_trsm_vec(a.P, k, k, false, false, a.b);
+            }
+            {
+                double bv = -1.0;
+                int bi = 0x7fffffff;
+                for (int i = tid; i < M; i += NT) {
+                    if (a.rowsel[i]) continue;
+                    double acc = 0.0;
+                    for (int j = 0; j < k; ++j) {
+                        const double prod = A[(size_t)i + (size_t)M * a.J[j]] * a.b[j];
+                        acc = acc + prod;
+                    }
+                    const double r = k > 0 ? a_c[i] - acc : a_c[i];
+                    const double v = fabs(r);
+                    if (v > bv) {
+                        bv = v;
+                        bi = i;
+                    }
+                }
+                double gv;
+                int gi;
+                rook_block_argmax(bv, bi, s_v, s_i, &gv, &gi);
+                cur_row = gv < 0.0 ? first_row : gi;
+            }
+            if (!a.seen[cur_row]) {
+                evals += (double)(N - n_cols_seen);
+                ++n_rows_seen;
+            }
+            __syncthreads();
+            if (tid == 0) a.seen[cur_row] = 1;
+            if (k > 0) {
+                for (int j = tid; j < k; j += NT) a.y[j] = A[(size_t)cur_row + (size_t)M * a.J[j]];
+                __syncthreads();
+            }
+            int next_col;
+            {
+                double bv = -1.0;
+                int bi = 0x7fffffff;
+                for (int c = tid; c < N; c += NT) {
+                    if (a.colsel[c]) continue;
+                    double acc = 0.0;
+                    for (int j = 0; j < k; ++j) {
+                        const double prod = a.y[j] * a.X[(size_t)j + (size_t)k * c];
+                        acc = acc + prod;
+                    }
+                    const double arc = A[(size_t)cur_row + (size_t)M * c];
+                    const double r = k > 0 ? arc - acc : arc;
+                    const double v = fabs(r);
+                    if (v > bv) {
+                        bv = v;
+                        bi = c;
+                    }
+                }
+                double gv;
+                int gi;
+                rook_block_argmax(bv, bi, s_v, s_i, &gv, &gi);
+                next_col = gv < 0.0 ? first_col : gi;
+                pivot_abs = gv < 0.0 ? 0.0 : gv;
+            }
+            if (next_col == cur_col) break;
+            cur_col = next_col;
+        }
+        if (singular) break;
+        // factorize_lazy stop rules (:158-176)
+        last_error = pivot_abs;
+        if (k > 0 && (pivot_abs < a.rel_tol * max_error || pivot_abs < a.abs_tol)) break;
+        if (pivot_abs < 2.220446049250313e-16) break;
+        max_error = fmax(max_error, pivot_abs);
+        __syncthreads();
+        if (tid == 0) {
+            a.I[k] = cur_row;
+            a.J[k] = cur_col;
+            a.dres[3 + k] = pivot_abs;
+            a.rowsel[cur_row] = 1;
+            a.colsel[cur_col] = 1;
+        }
+        ++k;
+        __syncthreads();
+    }
+    // what the lazy evaluator would have looked at: the visited rows and columns
+    double mx = 0.0;
+    for (long long e = tid; e < (long long)M * N; e += NT) {
+        const int i = (int)(e % M), c = (int)(e / M);
+        if (a.seen[i] || a.seen[M + c]) {
+            const double v = A[e];
+            const double av = sqrt(v * v);
+            if (av > mx) mx = av;
+        }
+    }
+    {
+        double gv;
+        int gi;
+        rook_block_argmax(mx, tid, s_v, s_i, &gv, &gi);
+        mx = gv;
+    }
+    if (tid == 0) {
+        a.ires[0] = k;
+        a.ires[2] = visits;
+        a.dres[0] = last_error;
+        a.dres[1] = mx;
+        a.dres[2] = evals;
+    }
+    (void)s_dbl;
+}
+
 } // namespace
 
 LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLUOptions& opts, double* sampled_max,
@@ -246,13 +572,73 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
         T4A_HIP(hipMemcpyAsync(hres, w.res.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         T4A_HIP(hipMemcpyAsync(&hinfo, w.info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
         T4A_HIP(hipStreamSynchronize(st));
+        ++w.n_host_syncs;
         if (hinfo != 0)
             throw Error(T4A_GPU_INVALID_ARGUMENT, "residual pivot solve failed: singular pivot matrix in the rook search");
         const int idx = hres[0] < 0.0 ? fallback : (int)hres[0];
         return {idx, hres[1]};
     };
 
-    while ((int)sel_rows.size() < max_bond) {
+    // ---- device-resident search (round 5): sources that can put the whole matrix into device memory run the pivot loop as ONE
+    // persistent launch; the host reads the selection back with a single synchronisation (the launch-per-visit loop below costs two
+    // per visited column / row pair: 54 ms for BASELINE configs[1] against 0.4 ms on one CPU core, tools/bench_components.py)
+    bool device_search = (bool)src.full && kcap <= 256 && (long long)M * N <= (1ll << 24);
+    double device_mx = 0.0;
+    if (device_search) {
+        src.full(w.A.get());
+        transpose_launch(w.A.get(), M, N, M, w.At.get(), N, st); // (the row cache of the factor builders below)
+        w.dres.reserve((size_t)kcap + 4);
+        w.ires.reserve(4);
+        w.seen.reserve((size_t)M + N);
+        RookDenseArgs ka;
+        ka.A = w.A.get();
+        ka.M = M;
+        ka.N = N;
+        ka.max_bond = max_bond;
+        ka.rel_tol = opts.rel_tol;
+        ka.abs_tol = opts.abs_tol;
+        ka.P = w.P.get();
+        ka.X = w.X.get();
+        ka.b = w.vec.get();
+        ka.y = w.vec.get() + kcap;
+        ka.I = w.I.get();
+        ka.J = w.J.get();
+        ka.rowsel = w.rowsel.get();
+        ka.colsel = w.colsel.get();
+        ka.seen = w.seen.get();
+        ka.piv = w.piv.get();
+        ka.dres = w.dres.get();
+        ka.ires = w.ires.get();
+        hipLaunchKernelGGL(rook_dense_kernel, dim3(1), dim3(1024), 0, st, ka);
+        int hi[3] = {0, 0, 0};
+        std::vector<double> hd((size_t)kcap + 3, 0.0);
+        std::vector<int> hI(kcap, 0), hJ(kcap, 0);
+        T4A_HIP(hipMemcpyAsync(hi, w.ires.get(), sizeof(hi), hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipMemcpyAsync(hd.data(), w.dres.get(), hd.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipMemcpyAsync(hI.data(), w.I.get(), sizeof(int) * kcap, hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipMemcpyAsync(hJ.data(), w.J.get(), sizeof(int) * kcap, hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipStreamSynchronize(st));
+        T4A_HIP(hipGetLastError());
+        ++w.n_device_searches;
+        w.n_device_visits += (size_t)hi[2];
+        ++w.n_host_syncs;
+        if (hi[1] != 0)
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "residual pivot solve failed: singular pivot matrix in the rook search");
+        const int rank_d = hi[0];
+        for (int q = 0; q < rank_d; ++q) {
+            sel_rows.push_back(hI[q]);
+            sel_cols.push_back(hJ[q]);
+            accepted.push_back(hd[3 + (size_t)q]);
+            row_sel[hI[q]] = 1;
+            col_sel[hJ[q]] = 1;
+        }
+        last_error = hd[0];
+        device_mx = hd[1];
+        evals = hd[2];
+    } else {
+        ++w.n_host_searches;
+    }
+    while (!device_search && (int)sel_rows.size() < max_bond) {
         const int k = (int)sel_rows.size();
         // remaining_indices (:63-69): ascending, selected ones skipped
         int first_row = -1, first_col = -1, n_rem_rows = 0, n_rem_cols = 0;
@@ -420,6 +806,7 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
     if (hinfo != 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "factor solve failed: singular pivot matrix");
     double mx;
     std::memcpy(&mx, &bits, sizeof(mx));
+    if (device_search) mx = device_mx; // (the visited rows / columns, found by the search kernel itself)
     out.abs_max = mx;
     if (sampled_max && mx > *sampled_max) *sampled_max = mx;
     if (n_evaluated) *n_evaluated += evals;

@@ -16,12 +16,21 @@ struct RookSource {
     int M = 0, N = 0;
     std::function<void(int, double*)> column;
     std::function<void(int, double*)> row;
+    // optional: the WHOLE matrix into device memory (column-major, ld = M) — sources whose entries cost nothing to evaluate on the device
+    // (built-in functors, dense device matrices).  The search then runs as ONE persistent launch on the materialised matrix
+    // (rook_dense_kernel, round 5) instead of one host round trip per visited row / column; what the lazy evaluator WOULD have
+    // evaluated (full rows / columns visited) is still what sampled_max and n_evaluated report.
+    std::function<void(double*)> full;
 };
 
 struct RookWork { // grow-only scratch, reusable across calls
     DevBuf<double> A, At, P, X, vec, res;
     DevBuf<int> I, J, rowsel, colsel, piv, info;
     DevBuf<unsigned long long> maxbits;
+    DevBuf<double> dres;   // device-resident search: [0] last error [1] sampled max [2] evaluated entries [3..] accepted pivot errors
+    DevBuf<int> ires;      // [0] rank [1] LU info (singular pivot block) [2] host syncs saved (visits) [4..] selected rows, then columns
+    DevBuf<int> seen;      // visited flags: rows, then columns
+    size_t n_device_searches = 0, n_device_visits = 0, n_host_searches = 0, n_host_syncs = 0; // statistics
     DevBuf<LuProblem> lup;
     DevBuf<TrsmProblem> trp;
 };

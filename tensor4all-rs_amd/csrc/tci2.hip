@@ -603,6 +603,10 @@ LuciResult Tci2::rook_on_sets(const IndexSet& is, const IndexSet& js, const RrLU
         src.row = [=](int r, double* out) {
             pi_eval_launch(fn_dev_, d_ra + (size_t)r * K, 1, d_rb, (int)N, out, 1, false, nullptr, st);
         };
+        // (a built-in functor costs nothing to evaluate: the search runs device-resident on the materialised matrix, rook.hip)
+        static const bool host_driven = std::getenv("T4A_ROOK_HOST") != nullptr; // (A/B and parity of the two search drivers)
+        if (!host_driven)
+            src.full = [=](double* out) { pi_eval_launch(fn_dev_, d_ra, (int)M, d_rb, (int)N, out, (int)M, false, nullptr, st); };
     } else {
         auto eval_points = [this, st, &is, &js](size_t r0, size_t nr, size_t c0, size_t nc, double* out) {
             const size_t npts = nr * nc;

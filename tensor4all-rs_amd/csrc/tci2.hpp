@@ -129,7 +129,8 @@ public:
     // chain_walk_kernel) [1] 1-site sweeps (sweep1site) that ran as a chain [2] 1-site sweeps that were not eligible and ran bond
     // by bond [3] chained 1-site sweeps that fell back to the per-bond path part-way
     std::array<uint64_t, 4> chain_stats_ext{{0, 0, 0, 0}};
-    const uint64_t* fill_stats() const { return fill_stats_; } // [fills issued asynchronously, graph replays, graph captures]
+    const uint64_t* fill_stats() const { return fill_stats_; }
+    const RookWork& rook_work() const { return rook_work_; } // [fills issued asynchronously, graph replays, graph captures]
     bool chain_enabled = true;  // false: every half-sweep runs bond by bond (A/B measurements, tests)
     bool chain_verify = false;  // true: after every chain the device tables are read back and compared with the host's sets
     bool chain_event_timing = false; // profiling: rrLU launches of a chain are timed with HIP events around each launch instead of

@@ -737,6 +737,11 @@ class TensorCI2:
         while profiling, time the rrLU launches with HIP events instead of the kernels' own time stamps."""
         _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0), c_int32((1 if verify else 0) | (2 if event_timing else 0))))
 
+    def rook_stats(self):
+        out = (ctypes.c_uint64 * 4)()
+        _check(_lib.t4a_gpu_tci2_rook_stats(self._h, out))
+        return {"device_searches": int(out[0]), "device_visits": int(out[1]), "host_searches": int(out[2]), "host_syncs": int(out[3])}
+
     def fill_stats(self):
         out = (ctypes.c_uint64 * 3)()
         _check(_lib.t4a_gpu_tci2_fill_stats(self._h, out))

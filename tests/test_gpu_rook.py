@@ -4,6 +4,7 @@ t4a_gpu_luci_rook_f64, t4a_gpu_luci_blocks_f64 and the TCI2 driver with options.
 The residuals of the rook search go through solve_matrix / mat_mul, which the reference takes from tenferro-rs
 ("parity unpinned" at the bit level).  The device follows the oracle's operation order, so pivot sequences are
 compared exactly on generic inputs and values to 1e-10."""
+import os
 import numpy as np
 import pytest
 
@@ -142,3 +143,42 @@ def test_tci2_rook_builtin_device_function(t4a):
     idx = RNG.integers(0, 2, size=(200, 12))
     exact = ob.fn_eval(spec, idx)
     assert np.abs(g.evaluate(idx) - exact).max() < 1e-6
+
+
+def test_device_resident_search_and_host_driven_search_agree(t4a, tmp_path):
+    """Round 5: sources that can materialise the matrix on the device (built-in functors, dense device matrices) run the whole pivot
+    loop of the rook search as ONE persistent launch (rook_dense_kernel) — one host synchronisation per bond instead of two per visited
+    row / column pair.  Same arithmetic, operation for operation, as the host-driven loop (T4A_ROOK_HOST=1, read once per process:
+    a child process): selected rows / columns, pivot errors and the max_sample_value of the LAZY evaluator (visited rows / columns only)
+    must be identical, and the device-resident run must have needed at least ten times fewer synchronisations."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, json, numpy as np
+sys.path.insert(0, "tensor4all-rs_amd/python")
+import t4a_amd as t4a
+spec = t4a.quantics_osc2d(16, k1=3, k2=5, k3=7, eps=0.3, k4=11, delta=0.2)
+g = t4a.TensorCI2([2] * 16)
+g.set_function(spec)
+opt = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=24, max_iter=5, pivot_search=1, nsearch=0, max_nglobal_pivot=0)
+g.crossinterpolate2([[0] * 16], opt)
+rng = np.random.default_rng(5)
+a = rng.standard_normal((90, 14)) @ rng.standard_normal((14, 70)) + 1e-9 * rng.standard_normal((90, 70))
+r = t4a.matrix_luci_factors_rook(a, max_bond_dim=20, rel_tol=1e-12)
+out = {"sets": [np.asarray(g.i_set(p)).ravel().tolist() + np.asarray(g.j_set(p)).ravel().tolist() for p in range(16)],
+       "pivot_errors": [float(v) for v in g.pivot_errors()], "max_sample": g.max_sample_value(), "stats": g.rook_stats(),
+       "rows": [int(v) for v in r.row_indices], "cols": [int(v) for v in r.col_indices], "perr": [float(v) for v in r.pivot_errors]}
+print("RESULT" + json.dumps(out))
+'''
+    res = {}
+    for name, env in (("device", {}), ("host", {"T4A_ROOK_HOST": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, r.stdout[-2000:] + r.stderr[-3000:]
+        res[name] = __import__("json").loads(line[0][6:])
+    d, h = res["device"], res["host"]
+    assert d["sets"] == h["sets"] and d["rows"] == h["rows"] and d["cols"] == h["cols"]
+    assert d["max_sample"] == h["max_sample"]
+    assert np.allclose(d["pivot_errors"], h["pivot_errors"], rtol=1e-9, atol=0) and np.allclose(d["perr"], h["perr"], rtol=1e-9, atol=0)
+    assert d["stats"]["device_searches"] > 0 and d["stats"]["host_searches"] == 0 and h["stats"]["device_searches"] == 0
+    assert d["stats"]["host_syncs"] * 10 <= h["stats"]["host_syncs"], (d["stats"], h["stats"])
