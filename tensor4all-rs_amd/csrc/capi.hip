@@ -456,14 +456,18 @@ t4a_gpu_status t4a_gpu_solve_f64(const double* a, size_t n, const double* b, siz
         T4A_HIP(hipMemcpyAsync(dlp.get(), &lp, sizeof(lp), hipMemcpyHostToDevice, st));
         T4A_HIP(hipMemcpyAsync(dtp.get(), t, sizeof(t), hipMemcpyHostToDevice, st));
         T4A_HIP(hipStreamSynchronize(st));
-        const bool forward_done = lu_forward_blocked_launch(dlp.get(), 1, (int)n, (int)nrhs, st);
+        // (round 5) blocked LU + one fused launch for both triangular solves; outside its size range the two-step path
+        const bool fused = lu_solve_blocked_launch(dlp.get(), 1, (int)n, (int)nrhs, st);
+        const bool forward_done = fused || lu_forward_blocked_launch(dlp.get(), 1, (int)n, (int)nrhs, st);
         if (!forward_done) lu_batched_launch(dlp.get(), 1, (int)n, st);
         int info = 0;
         T4A_HIP(hipMemcpyAsync(&info, lp.info, sizeof(int), hipMemcpyDeviceToHost, st));
         T4A_HIP(hipStreamSynchronize(st));
         if (info != 0) throw Error(T4A_GPU_SINGULAR_MATRIX, "solve: matrix is singular");
-        if (!forward_done) trsm_left_batched_launch(dtp.get(), 1, (int)n, (int)nrhs, st);
-        trsm_left_batched_launch(dtp.get() + 1, 1, (int)n, (int)nrhs, st);
+        if (!fused) {
+            if (!forward_done) trsm_left_batched_launch(dtp.get(), 1, (int)n, (int)nrhs, st);
+            trsm_left_batched_launch(dtp.get() + 1, 1, (int)n, (int)nrhs, st);
+        }
         T4A_HIP(hipGetLastError());
         download(e, x, e.d_tmp2.get(), bcount);
     });

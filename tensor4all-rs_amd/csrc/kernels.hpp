@@ -448,6 +448,12 @@ void lu_batched_launch(const LuProblem* d_problems, int n_problems, int max_n, h
 constexpr int LU_MAX_PANEL_STEPS = 128;
 bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream, int avoid_xcc = -1,
                                unsigned* tickets = nullptr);
+// Round 5: the whole solve, B <- A^{-1} B: blocked LU of A alone (panel + trailing update of the factor's own column tiles), then ONE
+// launch that gathers the right-hand sides through the composed row permutation and runs both triangular solves with each chunk of
+// columns resident in the LDS (lu_solve_kernel).  Returns false when the sizes are outside its range (nothing was launched: use
+// lu_forward_blocked_launch + the upper trsm_left_batched_launch).  tickets / avoid_xcc as above (the last counter serves the solve).
+bool lu_solve_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream, int avoid_xcc = -1,
+                             unsigned* tickets = nullptr);
 
 // gather rows/cols:  out[i + ldo*j] = in[rows[i] + ldi*cols[j]] (rows/cols may be nullptr = identity)
 void gather_launch(const double* in, int ldi, const int* rows, int nrows, const int* cols, int ncols, double* out,

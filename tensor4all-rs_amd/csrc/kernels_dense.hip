@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(256) lu_panel_kernel(const LuProblem* problems
 // workgroups waiting for that XCD — this kernel's 130 KiB of LDS do not fit next to an rrLU workgroup — and one launch took as
 // long as two factorisations (measured: 1.35 ms instead of 0.2 ms); a workgroup that only has to return gets its slot at once.
 __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problems, int kb, int nb, int tiles, int n_problems, int avoid_xcc,
-                                                        unsigned* ticket)
+                                                        unsigned* ticket, int a_only)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int s_item;
@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problem
     const int t = item % tiles;
     const bool in_a = t < ta;
     const int c0 = in_a ? t * nb : (t - ta) * nb; // first column inside A resp. B
-    if (!in_a && c0 >= nrhs) continue;
+    if (!in_a && (a_only || c0 >= nrhs)) continue; // (a_only: the right-hand sides are solved behind the factorisation, lu_solve_kernel)
     if (in_a && c0 == kb) continue;               // the panel itself
     const int m = n - kb, w = (n - kb) < nb ? (n - kb) : nb;
     const int lim = in_a ? n : nrhs;
@@ -898,6 +898,309 @@ __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problem
         double* g = gcol(c);
         for (int i = tid; i < m; i += T) g[i] = Tt[(size_t)c * ldp + i];
     }
+    } // next work item
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Fused solve behind the blocked LU (round 5): B <- U^{-1} L^{-1} P B for one chunk of CW right-hand sides per workgroup, the chunk
+// resident in the LDS from the row gather to the write-back.  What it replaces: the right-hand-side tiles of lu_update_kernel (two
+// thirds of its work items: row swaps + 32 barrier-separated substitution steps + one launch per panel) and trsm_left_mfma_kernel
+// for the upper solve (its triangular operand came from memory inside the innermost loop, one exposed round trip per 16-row strip).
+//   * rows: the LU's transpositions are composed into ONE permutation first — 32 swaps per group on a private copy of the identity
+//     (one thread per group), then perm[i] = g_1[g_2[... g_G[i]]] by every thread — and the chunk is gathered through it;
+//   * per 16-row diagonal block: the block of the factor goes to the LDS (fetched one block ahead), each WAVE substitutes its own 16
+//     columns in registers (lane = column x row quarter, the solved unknown travels by a quad broadcast: no workgroup barrier inside
+//     a block), then the rows outside the block get  B[rows] -= T[rows, block] X[block]  on the f64 matrix cores; the T strips of a
+//     block are requested before its substitution starts and consumed behind it;
+//   * the upper factor's diagonal enters as a reciprocal (one division per row instead of one per row and column).
+// Values agree with the two-kernel path to rounding (different summation order) — tensor4all-tensorbackend pins `solve` to 1e-10 /
+// 1e-12 on small systems only (backend/tests/mod.rs:58-325); fill_site_tensors (tensorci2.rs:1130-1182) is compared at 1e-10.
+// ------------------------------------------------------------------------------------------------
+constexpr int SVB = 16;      // rows of a diagonal block
+constexpr int SV_MAXS = 8;   // 16-row strips per wave and block held in registers (n <= 512)
+template <int Q> __device__ __forceinline__ double quad_bcast_f64(double v)
+{
+    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6); // quad_perm [Q, Q, Q, Q]
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// one step of the substitution inside a diagonal block: unknown KK (local row) is final, the rows behind it get their update.
+// b[t] = local row 4 g + t of this lane's column; D: the block, column-major with stride SVB + 1; rd: reciprocals of its diagonal
+template <int KK, bool LOWER> __device__ __forceinline__ void solve_block_step(double (&b)[4], const double (&dr)[SVB][4], const double (&rdr)[SVB], int g)
+{
+    constexpr int go = KK >> 2, to = KK & 3;
+    double xk = quad_bcast_f64<go>(b[to]);
+    if (!LOWER) xk = xk * rdr[KK];
+    if (g == go) b[to] = xk;
+    // (D holds zeros outside the strict triangle of this pass: rows that are not behind KK get b - 0 x)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = __builtin_fma(-dr[KK][t], xk, b[t]);
+}
+template <bool LOWER, int... KKs>
+__device__ __forceinline__ void solve_block_steps(double (&b)[4], const double (&dr)[SVB][4], const double (&rdr)[SVB], int g, std::integer_sequence<int, KKs...>)
+{
+    if constexpr (LOWER) (solve_block_step<KKs, true>(b, dr, rdr, g), ...);
+    else (solve_block_step<SVB - 1 - KKs, false>(b, dr, rdr, g), ...);
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lu_solve_kernel(const LuProblem* problems, int cw, int n_problems, int chunks, int avoid_xcc, unsigned* ticket)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int s_item;
+    if (avoid_xcc >= 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((int)(xcc & 0xF) == avoid_xcc) return;
+    }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4; // MFMA roles
+    const int cl = lane >> 2, g = lane & 3;   // substitution roles: column of the wave's group, row quarter
+    const int total_items = chunks * n_problems;
+    bool first = true;
+    for (;;) {
+        __syncthreads(); // (the LDS of the previous item is free)
+        if (tid == 0) s_item = ticket ? (int)atomicAdd(ticket, 1u) : (first ? (int)blockIdx.x : total_items);
+        __syncthreads();
+        first = false;
+        const int item = s_item;
+        if (item >= total_items) break;
+        const LuProblem pr = problems[item / chunks];
+        const int n = pr.n;
+        const int c0 = (item % chunks) * cw;
+        if (n <= 0 || !pr.B || c0 >= pr.nrhs || pr.info[0] == -1) continue; // (flagged by the zero-pivot-matrix guard: the packing writes a zero core)
+        const int cwr = (pr.nrhs - c0) < cw ? (pr.nrhs - c0) : cw;
+        const int ld = n | 1; // odd leading dimension: conflict-free operand reads
+        double* Bs = reinterpret_cast<double*>(smem_raw);            // [cw][ld]
+        double* D = Bs + (size_t)ld * cw + ((ld * cw) & 1);           // [SVB][SVB], 16-byte aligned: a lane's four rows of a column are two 128-bit reads
+        double* rd = D + SVB * SVB;                                   // [SVB]
+        unsigned short* perm_s = reinterpret_cast<unsigned short*>(rd + SVB); // [n]
+        unsigned short* piv_s = perm_s + ((n + 3) & ~3);             // [n]
+        // (pointers that come out of a descriptor in memory are generic to the compiler: flat loads, which count against the LDS
+        // counter as well — every wait for an LDS read would then wait for all outstanding reads of the factor.  Named global.)
+        typedef const double __attribute__((address_space(1)))* gcptr;
+        typedef double __attribute__((address_space(1)))* gptr;
+        const gcptr T = (gcptr)pr.A;
+        const gptr Bg = (gptr)pr.B;
+        const int ldt = pr.lda;
+        // ---- the row permutation of the factorisation (scratch: the chunk's own space, not yet in use) ----
+        {
+            const int G = (n + 31) / 32;
+            unsigned short* gs = reinterpret_cast<unsigned short*>(smem_raw); // [G][n]
+            for (int e = tid; e < G * n; e += 256) gs[e] = (unsigned short)(e % n);
+            for (int i = tid; i < n; i += 256) {
+                const int pv = ((const int __attribute__((address_space(1)))*)pr.piv)[i];
+                piv_s[i] = (unsigned short)((pv >= 0 && pv < n) ? pv : i);
+            }
+            __syncthreads();
+            if (tid < G) {
+                unsigned short* mine = gs + (size_t)tid * n;
+                const int k_hi = (32 * tid + 32) < n ? (32 * tid + 32) : n;
+                for (int k = 32 * tid; k < k_hi; ++k) {
+                    const int pv = piv_s[k];
+                    if (pv != k) {
+                        const unsigned short t = mine[k];
+                        mine[k] = mine[pv];
+                        mine[pv] = t;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                int t = i;
+                for (int j = G - 1; j >= 0; --j) t = gs[(size_t)j * n + t];
+                perm_s[i] = (unsigned short)t;
+            }
+            __syncthreads();
+        }
+        {
+            // gather: two columns per round, all their rows requested before the first one is stored
+            int pi[SV_MAXS];
+#pragma unroll
+            for (int t = 0; t < SV_MAXS; ++t) pi[t] = (lane + 64 * t) < n ? (int)perm_s[lane + 64 * t] : 0;
+            for (int cb = 2 * wave; cb < cw; cb += 8) {
+                double v[2][SV_MAXS];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = cb + h;
+                    const gcptr src = Bg + (size_t)(c0 + (c < cwr ? c : 0)) * pr.ldb;
+#pragma unroll
+                    for (int t = 0; t < SV_MAXS; ++t) v[h][t] = (c < cwr && (lane + 64 * t) < n) ? src[pi[t]] : 0.0;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < SV_MAXS; ++t)
+                        if ((lane + 64 * t) < n) Bs[(size_t)(cb + h) * ld + lane + 64 * t] = v[h][t];
+            }
+        }
+        const int nblk = (n + SVB - 1) / SVB;
+        const int ngroups = cw / 16;
+#ifdef T4A_SOLVE_STAMPS
+        unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define SSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define SSTAMP(k) do {} while (0)
+#endif
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool lower = pass == 0;
+            auto block_range = [&](int blk, int& k0, int& k1) {
+                if (lower) {
+                    k0 = blk * SVB;
+                    k1 = (k0 + SVB) < n ? k0 + SVB : n;
+                } else {
+                    k1 = n - blk * SVB;
+                    k0 = (k1 - SVB) > 0 ? k1 - SVB : 0;
+                }
+            };
+            // element (i, j) = (tid % 16, tid / 16) of a diagonal block, identity outside the matrix / the block
+            auto load_d = [&](int blk) -> double {
+                if (blk >= nblk) return 0.0;
+                int k0, k1;
+                block_range(blk, k0, k1);
+                const int bw = k1 - k0, i = tid & 15, j = tid >> 4;
+                if (i < bw && j < bw) return T[(size_t)(k0 + j) * ldt + k0 + i];
+                return i == j ? 1.0 : 0.0;
+            };
+            double dnext = load_d(0);
+#pragma unroll 1
+            for (int blk = 0; blk < nblk; ++blk) {
+                int k0, k1;
+                block_range(blk, k0, k1);
+                const int bw = k1 - k0;
+                const int r_lo = lower ? k1 : 0, r_hi = lower ? n : k0;
+                // the strips of T this wave applies behind the substitution: requested now.  Addresses are clamped into the matrix
+                // instead of predicated (rows beyond r_hi produce values nobody stores; columns beyond the block meet zeros of X)
+                const int avail = r_hi - r_lo - 16 * wave;
+                const int ns = avail <= 0 ? 0 : ((avail + 63) >> 6) < SV_MAXS ? ((avail + 63) >> 6) : SV_MAXS; // (uniform) strips of this wave
+                double tv[SV_MAXS][4];
+                {
+                    gcptr colp[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int j = (4 * ks + lk) < bw ? (4 * ks + lk) : bw - 1;
+                        colp[ks] = T + (size_t)(k0 + j) * ldt;
+                    }
+                    const int ib = r_lo + 16 * wave + lr;
+#pragma unroll
+                    for (int sp = 0; sp < SV_MAXS; ++sp)
+                        if (sp < ns) {
+                            const int i = (ib + 64 * sp) < n ? (ib + 64 * sp) : n - 1;
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) tv[sp][ks] = colp[ks][i];
+                        }
+                }
+                SSTAMP(0);
+                __syncthreads(); // (1) the previous block's updates of the chunk are complete, its D is no longer read
+                SSTAMP(1);
+                {
+                    // (the substitution multiplies unconditionally: only the strict triangle of this pass enters the LDS copy)
+                    const int i = tid & 15, j = tid >> 4;
+                    D[j * SVB + i] = (lower ? (i > j) : (i < j)) ? dnext : 0.0;
+                    if (i == j) rd[i] = 1.0 / dnext;
+                }
+                dnext = load_d(blk + 1);
+                __syncthreads(); // (2)
+                SSTAMP(2);
+                // ---- substitution inside the block: every wave its own 16-column groups, in registers ----
+                // (this lane's rows of the block and the reciprocals of its diagonal come into registers FIRST: read inside the steps, every
+                // one of the 16 dependent steps would wait for its own LDS round trips)
+                double dr[SVB][4], rdr[SVB];
+                if (wave < ngroups) {
+#pragma unroll
+                    for (int kk = 0; kk < SVB; ++kk) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) dr[kk][t] = D[kk * SVB + 4 * g + t];
+                        rdr[kk] = rd[kk];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                for (int grp = wave; grp < ngroups; grp += 4) {
+                    const int c = 16 * grp + cl;
+                    double b[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int j = 4 * g + t;
+                        b[t] = j < bw ? Bs[(size_t)c * ld + k0 + j] : 0.0;
+                    }
+                    if (lower) solve_block_steps<true>(b, dr, rdr, g, std::make_integer_sequence<int, SVB>{});
+                    else solve_block_steps<false>(b, dr, rdr, g, std::make_integer_sequence<int, SVB>{});
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int j = 4 * g + t;
+                        if (j < bw) Bs[(size_t)c * ld + k0 + j] = b[t];
+                    }
+                }
+                SSTAMP(3);
+                __syncthreads(); // (3)
+                SSTAMP(4);
+                // ---- rows outside the block: Bs[rows, :] -= T[rows, k0:k1] X[k0:k1, :] ("A" = X^T: i' = column, "B" = T^T: j' = row).
+                // One straight-line body per strip count: the MFMA chains of a tile's strips run interleaved, then their results
+                // leave through one batch of LDS reads and one of writes ----
+                if (ns > 0) {
+                    auto tiles = [&](auto nsc) {
+                        constexpr int NS = decltype(nsc)::value;
+                        for (int c0t = 0; c0t < cw; c0t += 16) {
+                            // (the operands of the tile and the values its results are subtracted from: all requested in front of the
+                            // MFMA chains, which run while the second batch is on its way)
+                            double xf[4];
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) {
+                                const int j = 4 * ks + lk;
+                                xf[ks] = j < bw ? Bs[(size_t)(c0t + lr) * ld + k0 + j] : 0.0;
+                            }
+                            double old[NS][4];
+#pragma unroll
+                            for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+                                for (int reg = 0; reg < 4; ++reg) {
+                                    const int i = r_lo + 16 * wave + 64 * sp + lr, c = c0t + lk + 4 * reg;
+                                    old[sp][reg] = i < r_hi ? Bs[(size_t)c * ld + i] : 0.0;
+                                }
+                            double4_t acc[NS];
+#pragma unroll
+                            for (int sp = 0; sp < NS; ++sp) acc[sp] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                                for (int sp = 0; sp < NS; ++sp) acc[sp] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[ks], tv[sp][ks], acc[sp], 0, 0, 0);
+#pragma unroll
+                            for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+                                for (int reg = 0; reg < 4; ++reg) {
+                                    const int i = r_lo + 16 * wave + 64 * sp + lr, c = c0t + lk + 4 * reg;
+                                    if (i < r_hi) Bs[(size_t)c * ld + i] = old[sp][reg] - acc[sp][reg];
+                                }
+                        }
+                    };
+                    switch (ns) {
+                    case 1: tiles(std::integral_constant<int, 1>{}); break;
+                    case 2: tiles(std::integral_constant<int, 2>{}); break;
+                    case 3: tiles(std::integral_constant<int, 3>{}); break;
+                    case 4: tiles(std::integral_constant<int, 4>{}); break;
+                    case 5: tiles(std::integral_constant<int, 5>{}); break;
+                    case 6: tiles(std::integral_constant<int, 6>{}); break;
+                    case 7: tiles(std::integral_constant<int, 7>{}); break;
+                    default: tiles(std::integral_constant<int, 8>{}); break;
+                    }
+                }
+                SSTAMP(5);
+            }
+            __syncthreads();
+        }
+#ifdef T4A_SOLVE_STAMPS
+        if (item == (total_items / 2) && (tid & 63) == 0)
+            printf("[lu_solve stamps] wave %d n=%d cw=%d cycles: tvissue=%llu bar1=%llu dstore+bar2=%llu diag=%llu bar3=%llu mfma=%llu\n", wave, n, cw,
+                   st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5]);
+#endif
+        for (int c = wave; c < cwr; c += 4) {
+            const gptr dst = Bg + (size_t)(c0 + c) * pr.ldb;
+            for (int i = lane; i < n; i += 64) dst[i] = Bs[(size_t)c * ld + i];
+        }
     } // next work item
 }
 
@@ -1185,8 +1488,50 @@ bool lu_forward_blocked_launch(const LuProblem* d_problems, int n_problems, int 
         unsigned* tk = tickets ? tickets + kb / nb : nullptr;
         const int grid = tk ? items + items / 7 + 8 : items;
         hipLaunchKernelGGL(lu_update_kernel, dim3(grid), dim3(256), lds_update, stream, d_problems, kb, nb, tiles, n_problems,
-                           tk ? avoid_xcc : -1, tk);
+                           tk ? avoid_xcc : -1, tk, 0);
     }
+    return true;
+}
+
+bool lu_solve_blocked_launch(const LuProblem* d_problems, int n_problems, int max_n, int max_nrhs, hipStream_t stream, int avoid_xcc,
+                             unsigned* tickets)
+{
+    if (n_problems <= 0 || max_n <= 0) return true;
+    static const bool off = diag_env("T4A_NO_FUSED_SOLVE") != nullptr;
+    if (off || max_n < 32 || max_n > 16 * 4 * SV_MAXS || max_nrhs < 16) return false;
+    int nb;
+    if (max_n <= 256) nb = 32;
+    else nb = 16;
+    static std::once_flag attr_once; // (launches come from several host threads)
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    });
+    const int ldp = max_n | 1;
+    const size_t lds_update = (size_t)ldp * nb * 8 * 2;
+    const int tiles = (max_n + nb - 1) / nb; // the factor's own column tiles only: the right-hand sides are solved behind the factorisation
+    for (int kb = 0; kb < max_n; kb += nb) {
+        if (nb == 32) hipLaunchKernelGGL((lu_panel_kernel<32, 1>), dim3(n_problems), dim3(256), 0, stream, d_problems, kb);
+        else hipLaunchKernelGGL((lu_panel_kernel<16, 2>), dim3(n_problems), dim3(256), 0, stream, d_problems, kb);
+        const int items = tiles * n_problems;
+        unsigned* tk = tickets ? tickets + kb / nb : nullptr;
+        const int grid = tk ? items + items / 7 + 8 : items;
+        hipLaunchKernelGGL(lu_update_kernel, dim3(grid), dim3(256), lds_update, stream, d_problems, kb, nb, tiles, n_problems,
+                           tk ? avoid_xcc : -1, tk, 1);
+    }
+    // chunk width of the right-hand sides: as wide as the LDS takes (fewer, longer workgroups: the triangular factor is read once per chunk)
+    const size_t extra = (size_t)SVB * (SVB + 1) * 8 + SVB * 8 + 2 * (size_t)((max_n + 3) & ~3) * 2 + 64;
+    int cw = 64;
+    while (cw > 16 && (size_t)(max_n | 1) * cw * 8 + extra > 156 * 1024) cw -= 16;
+    if (cw == 48) cw = 32;
+    while (cw > 16 && max_nrhs <= cw / 2) cw /= 2;
+    const size_t lds = (size_t)(max_n | 1) * cw * 8 + extra;
+    const int chunks = (max_nrhs + cw - 1) / cw;
+    const int items = chunks * n_problems;
+    unsigned* tk = tickets ? tickets + (LU_MAX_PANEL_STEPS - 1) : nullptr;
+    const int grid = tk ? items + items / 7 + 8 : items;
+    hipLaunchKernelGGL(lu_solve_kernel, dim3(grid), dim3(256), lds, stream, d_problems, cw, n_problems, chunks, tk ? avoid_xcc : -1, tk);
     return true;
 }
 

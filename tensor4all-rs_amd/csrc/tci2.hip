@@ -1403,11 +1403,14 @@ void Tci2::fill_site_tensors_impl(bool async)
             if (npr) {
                 // blocked LU with the unit-lower forward substitution of the right-hand sides folded in; beyond its size
                 // limit the unblocked kernel + explicit forward solve (bitwise the same result)
-                if (!lu_forward_blocked_launch(d_lups, npr, max_n, max_nrhs, st, avoid_xcc, d_tickets)) {
-                    lu_batched_launch(d_lups, npr, max_n, st);
-                    trsm_left_batched_launch(d_trs, npr, max_n, max_nrhs, st);
+                // (round 5) one fused solve behind the LU of the pivot matrices; outside its size range the two-step path
+                if (!lu_solve_blocked_launch(d_lups, npr, max_n, max_nrhs, st, avoid_xcc, d_tickets)) {
+                    if (!lu_forward_blocked_launch(d_lups, npr, max_n, max_nrhs, st, avoid_xcc, d_tickets)) {
+                        lu_batched_launch(d_lups, npr, max_n, st);
+                        trsm_left_batched_launch(d_trs, npr, max_n, max_nrhs, st);
+                    }
+                    trsm_left_batched_launch(d_trs + npr, npr, max_n, max_nrhs, st);
                 }
-                trsm_left_batched_launch(d_trs + npr, npr, max_n, max_nrhs, st);
             }
             // (3) pack all cores in one launch
             hipLaunchKernelGGL(pack_fill_batched_kernel, dim3(gx, gy), dim3(256), 0, st, d_packs);

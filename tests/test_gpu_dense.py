@@ -190,7 +190,7 @@ def test_trsm(t4a, left_side, lower, trans, unit):
     assert np.abs(t4a.triangular_solve_matrix(l, bb, True, True, False, False) - np.array([[1.0], [2.0]])).max() < 1e-12
 
 
-@pytest.mark.parametrize("n,nrhs", [(2, 1), (10, 3), (100, 40), (256, 512)])
+@pytest.mark.parametrize("n,nrhs", [(2, 1), (10, 3), (100, 40), (256, 512), (32, 16), (33, 17), (64, 64), (200, 100), (300, 70), (500, 33), (512, 1024), (513, 64)])
 def test_solve(t4a, n, nrhs):
     rng = np.random.default_rng(13)
     a = rng.uniform(-1, 1, size=(n, n))

@@ -1,14 +1,13 @@
 #!/bin/bash
-# full GPU suite + default bench line.   usage: tools/r5_gpu_suite.sh OUTDIR
-O=gpurun_out/$1
-mkdir -p $O
-export PYTHONPATH=tensor4all-rs_amd/python
-timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1
-echo "pytest rc=$?" >> $O/pytest.log
-grep -E "passed|failed|error|Error" $O/pytest.log | tail -8
-timeout 900 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err
-python - "$O/bench.json" <<'PY'
-import json, sys
-d = json.load(open(sys.argv[1])); a = d.get("aux", {})
-print(round(d["ms_per_step"], 3), d["value"], d["roofline"]["frac"], {k: (round(v, 2) if isinstance(v, float) else v) for k, v in a.items() if "ms" in k})
-PY
+# whole GPU suite + the default bench line
+O=gpurun_out/suite; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 | tee $O/pytest.log
+timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python3 - <<'P'
+import json
+d = json.loads(open("gpurun_out/suite/bench.json").read().strip().splitlines()[-1])
+print("ms_per_step", d["ms_per_step"], "value", d["value"], "fill", d["breakdown_ms_per_sweep"], "roofline.frac", d["roofline"]["frac"])
+a = d.get("aux", {})
+print({k: v for k, v in a.items() if k != "components"})
+print("cpu_baseline", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("cores"))
+P
