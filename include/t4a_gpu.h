@@ -600,6 +600,22 @@ t4a_gpu_status t4a_gpu_tensor_permute(const t4a_gpu_tensor* h, const int64_t* la
 /* replace label `from` by `to` (DynIndex replacement / priming on the caller's side) */
 t4a_gpu_status t4a_gpu_tensor_relabel(t4a_gpu_tensor* h, int64_t from, int64_t to);
 t4a_gpu_status t4a_gpu_tensor_contract(const t4a_gpu_tensor* a, const t4a_gpu_tensor* b, t4a_gpu_tensor** out);
+/* N-ary contraction of ONE connected tensor network (tensor4all-core/src/defaults/contract.rs:283-298 contract /
+ * contract_with_options; plan :885-941, connectivity :1167-1230): labels that occur in more than one operand are summed unless they
+ * are listed in retain_labels (ContractionOptions::retain_indices: a retained shared label stays as a batch index and connects its
+ * holders); the result carries the labels that occur once or are retained, in order of first appearance.  INVALID_ARGUMENT for no
+ * operands, a retained label nobody has, a disconnected network ("Disconnected tensor network: k components found") or a label with
+ * two dimensions.  One operand: a copy.  The network is reduced pair by pair (smallest intermediate first), every step a batched GEMM. */
+t4a_gpu_status t4a_gpu_tensor_contract_many(const t4a_gpu_tensor* const* tensors, size_t n_tensors, const int64_t* retain_labels,
+                                            size_t n_retain, t4a_gpu_tensor** out);
+/* outer_product (contract.rs:440-447): the explicit product of operands WITHOUT a common label (INVALID_ARGUMENT otherwise) */
+t4a_gpu_status t4a_gpu_tensor_outer_product(const t4a_gpu_tensor* a, const t4a_gpu_tensor* b, t4a_gpu_tensor** out);
+/* tensordot (contract.rs:420-428, idx_tensor.rs:3596-3638): contraction along explicitly paired axes (labels_a[p] of a with
+ * labels_b[p] of b; the labels may differ); result [free axes of a.., free axes of b..].  Errors as the reference's: no pairs, an
+ * index that is not there, an axis named twice, unequal dimensions (INVALID_ARGUMENT); a common label that is not paired
+ * (NOT_IMPLEMENTED: "Batch contraction is not yet implemented"). */
+t4a_gpu_status t4a_gpu_tensor_tensordot(const t4a_gpu_tensor* a, const t4a_gpu_tensor* b, const int64_t* labels_a, const int64_t* labels_b,
+                                        size_t n_pairs, t4a_gpu_tensor** out);
 /* svd_with: u carries [left.., bond_label], s is a rank-1 tensor [bond_label] of singular values, v carries
  * [right.., bond_label_v]; qr_with: q [left.., bond_label], r [bond_label, right..] */
 t4a_gpu_status t4a_gpu_tensor_svd(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t truncate,
@@ -696,6 +712,22 @@ t4a_gpu_status t4a_gpu_aci_problem_frame(t4a_gpu_aci_problem* h, int32_t right, 
                                          size_t* cols, double* out);
 /* per bond: last pivot error and largest sampled operator magnitude (n_sites - 1 entries each) */
 t4a_gpu_status t4a_gpu_aci_problem_errors(const t4a_gpu_aci_problem* h, double* pivot_errors, double* pivot_scales);
+
+/* ---- tensor4all-treeaci: the edge-local step of TreeACI (crates/tensor4all-treeaci/src/local_update.rs:35-262
+ * materialize_and_factor_edge; operator contract elementwise.rs:66,197 / batch.rs) from the candidate frames on: for every input k
+ * row_frames[k] is bond_dims[k] x row_count and col_frames[k] is bond_dims[k] x col_count, column-major (one contiguous frame vector
+ * per candidate, as InputFrameStore::candidate_frames_for_edge returns them).  value_k(row, col) = row_frame . col_frame; the operator
+ * (op_kind / op / user as for t4a_gpu_aci_elementwise; callback batch layout values[input + n_inputs * (row + row_count * col)])
+ * yields the local matrix; MatrixLUCI with max_bond_dim (0 = None), rel_tol = tolerance when scale_tolerance else abs_tol = tolerance.
+ * A zero matrix comes back as the rank-one zero update (rank 1, indices 0, zero factors).  Capacities: row_indices / col_indices
+ * min(row_count, col_count), pivot_errors min(row_count, col_count) + 1 (n_pivot_errors = entries written), left row_count x that,
+ * right that x col_count (column-major, leading dimensions = row_count resp. *rank); local_values row_count x col_count (may be NULL). */
+t4a_gpu_status t4a_gpu_treeaci_local_update_f64(size_t n_inputs, const size_t* bond_dims, const double* const* row_frames,
+                                                const double* const* col_frames, size_t row_count, size_t col_count, int32_t op_kind,
+                                                t4a_gpu_aci_op_fn op, void* user, size_t max_bond_dim, double tolerance,
+                                                int32_t scale_tolerance, int32_t left_orthogonal, size_t* rank, size_t* row_indices,
+                                                size_t* col_indices, double* pivot_errors, size_t* n_pivot_errors, double* left,
+                                                double* right, double* sampled_scale, double* local_values);
 
 /* ---- measurement hooks (bench.py) ---- */
 /* (M, N, rank) of every bond update of the most recent 2-site half-sweep: out is 3 x (n_sites-1). */

@@ -3,6 +3,7 @@
 #include "t4a_oracle_tt.hpp"
 #include "t4a_oracle_tensor.hpp"
 #include "t4a_oracle_aci.hpp"
+#include "t4a_oracle_treeaci.hpp"
 #include "t4a_oracle_search.hpp"
 
 #include <cstring>
@@ -254,6 +255,29 @@ int oracle_tensor_contract(const double* a, const uint64_t* adims, const int64_t
 {
     return guarded([&] {
         DenseTensor o = tensor_contract_pair(make_tensor(a, adims, alabels, ra), make_tensor(b, bdims, blabels, rb));
+        *out_rank = o.dims.size();
+        for (size_t k = 0; k < o.dims.size(); ++k) {
+            out_dims[k] = o.dims[k];
+            out_labels[k] = o.labels[k];
+        }
+        if (out) std::copy(o.data.begin(), o.data.end(), out);
+    });
+}
+// N-ary contraction: operands concatenated (data, dims, labels back to back; ranks[t] axes each).  out may be null (shape query).
+int oracle_tensor_contract_many(uint64_t n_tensors, const double* data, const uint64_t* dims, const int64_t* labels, const uint64_t* ranks,
+                                const int64_t* retain, uint64_t n_retain, double* out, uint64_t* out_dims, int64_t* out_labels,
+                                uint64_t* out_rank)
+{
+    return guarded([&] {
+        std::vector<DenseTensor> ts;
+        size_t dpos = 0, apos = 0;
+        for (size_t t = 0; t < n_tensors; ++t) {
+            DenseTensor x = make_tensor(data + dpos, dims + apos, labels + apos, ranks[t]);
+            dpos += x.size();
+            apos += ranks[t];
+            ts.push_back(std::move(x));
+        }
+        DenseTensor o = tensor_contract_network(ts, std::vector<int64_t>(retain, retain + n_retain));
         *out_rank = o.dims.size();
         for (size_t k = 0; k < o.dims.size(); ++k) {
             out_dims[k] = o.dims[k];
@@ -533,6 +557,35 @@ void oracle_aci_problem_errors(void* h, double* pivot_errors, double* pivot_scal
         pivot_errors[b] = s->p->pivot_errors[b];
         pivot_scales[b] = s->p->pivot_scales[b];
     }
+}
+
+// ---- TreeACI local step (t4a_oracle_treeaci.hpp).  Capacities as for t4a_gpu_treeaci_local_update_f64; batch (may be null): what the
+// operator saw, n_inputs x (row_count * col_count) ----
+int oracle_treeaci_local_update(uint64_t n_inputs, const uint64_t* bond_dims, const double* const* row_frames, const double* const* col_frames,
+                                uint64_t row_count, uint64_t col_count, int op_kind, oracle_aci_op_fn cb, void* user, uint64_t max_bond_dim,
+                                double tolerance, int scale_tolerance, int left_orthogonal, uint64_t* rank, uint64_t* row_indices,
+                                uint64_t* col_indices, double* pivot_errors, uint64_t* n_pivot_errors, double* left, double* right,
+                                double* sampled_scale, double* local_values, double* batch)
+{
+    return guarded([&] {
+        std::vector<size_t> bd(bond_dims, bond_dims + n_inputs);
+        std::vector<const double*> rf(row_frames, row_frames + n_inputs), cf(col_frames, col_frames + n_inputs);
+        const AciOp op = make_aci_op(op_kind, cb, user);
+        TreeAciLocalUpdate u = treeaci_local_update(bd, rf, cf, row_count, col_count, op, max_bond_dim != 0, max_bond_dim, tolerance,
+                                                    scale_tolerance != 0, left_orthogonal != 0);
+        *rank = u.row_indices.size();
+        for (size_t i = 0; i < u.row_indices.size(); ++i) {
+            row_indices[i] = u.row_indices[i];
+            col_indices[i] = u.col_indices[i];
+        }
+        *n_pivot_errors = u.pivot_errors.size();
+        for (size_t i = 0; i < u.pivot_errors.size(); ++i) pivot_errors[i] = u.pivot_errors[i];
+        std::memcpy(left, u.left.a.data(), sizeof(double) * u.left.a.size());
+        std::memcpy(right, u.right.a.data(), sizeof(double) * u.right.a.size());
+        *sampled_scale = u.sampled_scale;
+        if (local_values) std::memcpy(local_values, u.local_values.data(), sizeof(double) * u.local_values.size());
+        if (batch) std::memcpy(batch, u.batch.data(), sizeof(double) * u.batch.size());
+    });
 }
 
 

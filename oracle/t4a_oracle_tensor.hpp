@@ -349,4 +349,116 @@ inline TensorFactorizeResult tensor_factorize(const DenseTensor& t, const std::v
     return o;
 }
 
+
+// ---- N-ary contraction of a connected tensor network (tensor4all-core/src/defaults/contract.rs) ----
+// Restated from the reference text, independently of the device path (which reduces the network pair by pair with GEMMs): validation
+// and result indices as contract_with_options_impl :530-572 / build_contraction_plan :885-941 / find_tensor_connected_components_with_retained
+// :1167-1230 prescribe them, the values by direct summation over every summed label (the reference hands the network to tenferro's
+// einsum: backend-defined summation order, "parity unpinned" at the bit level; its own tests pin exact small-integer cases,
+// contract/tests/mod.rs:173-196, :235-281, :338-392, :410-449).
+struct NetworkContraction {
+    DenseTensor result;
+    size_t components = 1;
+};
+inline DenseTensor tensor_contract_network(const std::vector<DenseTensor>& ts, const std::vector<int64_t>& retain)
+{
+    if (ts.empty()) throw OracleError(ERR_INVALID_ARGUMENT, "No tensors to contract");
+    for (const DenseTensor& t : ts) tensor_validate(t);
+    auto has = [](const DenseTensor& t, int64_t l) { return std::find(t.labels.begin(), t.labels.end(), l) != t.labels.end(); };
+    for (int64_t r : retain) {
+        bool found = false;
+        for (const DenseTensor& t : ts) found = found || has(t, r);
+        if (!found) throw OracleError(ERR_INVALID_ARGUMENT, "Retained index does not appear in the input tensors");
+    }
+    if (ts.size() == 1) return ts[0];
+    const size_t n = ts.size();
+    // connected components by depth-first search over "shares a label" (contractable or retained: both are common labels)
+    std::vector<int> comp(n, -1);
+    int ncomp = 0;
+    for (size_t s0 = 0; s0 < n; ++s0) {
+        if (comp[s0] >= 0) continue;
+        std::vector<size_t> stack{s0};
+        comp[s0] = ncomp;
+        while (!stack.empty()) {
+            const size_t u = stack.back();
+            stack.pop_back();
+            for (size_t v = 0; v < n; ++v) {
+                if (comp[v] >= 0) continue;
+                bool common = false;
+                for (int64_t l : ts[u].labels) common = common || has(ts[v], l);
+                if (common) {
+                    comp[v] = ncomp;
+                    stack.push_back(v);
+                }
+            }
+        }
+        ++ncomp;
+    }
+    if (ncomp > 1) throw OracleError(ERR_INVALID_ARGUMENT, "Disconnected tensor network: " + std::to_string(ncomp) + " components found");
+    // labels in order of first appearance, their sizes and counts
+    std::vector<int64_t> labels;
+    std::vector<size_t> sizes, counts;
+    for (const DenseTensor& t : ts)
+        for (size_t a = 0; a < t.labels.size(); ++a) {
+            const auto it = std::find(labels.begin(), labels.end(), t.labels[a]);
+            if (it == labels.end()) {
+                labels.push_back(t.labels[a]);
+                sizes.push_back(t.dims[a]);
+                counts.push_back(1);
+            } else {
+                const size_t k = (size_t)(it - labels.begin());
+                if (sizes[k] != t.dims[a]) throw OracleError(ERR_INVALID_ARGUMENT, "Internal label shape mismatch");
+                ++counts[k];
+            }
+        }
+    std::vector<size_t> out_pos, sum_pos; // positions in `labels`
+    for (size_t k = 0; k < labels.size(); ++k) {
+        const bool retained = std::find(retain.begin(), retain.end(), labels[k]) != retain.end();
+        (counts[k] == 1 || retained ? out_pos : sum_pos).push_back(k);
+    }
+    DenseTensor out;
+    for (size_t k : out_pos) {
+        out.dims.push_back(sizes[k]);
+        out.labels.push_back(labels[k]);
+    }
+    out.data.assign(out.size(), 0.0);
+    // operand axis -> position in `labels`, operand strides
+    std::vector<std::vector<size_t>> where(n), stride(n);
+    for (size_t t = 0; t < n; ++t) {
+        size_t st = 1;
+        for (size_t a = 0; a < ts[t].labels.size(); ++a) {
+            where[t].push_back((size_t)(std::find(labels.begin(), labels.end(), ts[t].labels[a]) - labels.begin()));
+            stride[t].push_back(st);
+            st *= ts[t].dims[a];
+        }
+    }
+    size_t n_sum = 1;
+    for (size_t k : sum_pos) n_sum *= sizes[k];
+    std::vector<size_t> val(labels.size(), 0);
+    for (size_t o = 0; o < out.data.size(); ++o) {
+        size_t rem = o;
+        for (size_t k : out_pos) {
+            val[k] = rem % sizes[k];
+            rem /= sizes[k];
+        }
+        double acc = 0.0;
+        for (size_t q = 0; q < n_sum; ++q) {
+            size_t r2 = q;
+            for (size_t k : sum_pos) {
+                val[k] = r2 % sizes[k];
+                r2 /= sizes[k];
+            }
+            double prod = 1.0;
+            for (size_t t = 0; t < n; ++t) {
+                size_t off = 0;
+                for (size_t a = 0; a < where[t].size(); ++a) off += val[where[t][a]] * stride[t][a];
+                prod = prod * ts[t].data[off];
+            }
+            acc = acc + prod;
+        }
+        out.data[o] = acc;
+    }
+    return out;
+}
+
 } // namespace t4a_oracle

@@ -732,6 +732,96 @@ void AciProblem::run() // elementwise.rs:126-210
         for (size_t b = 0; b + 1 < n; ++b) local_update(b, true);
 }
 
+TreeAciLocalResult treeaci_local_update(Engine& eng, const std::vector<size_t>& bond_dims, const std::vector<const double*>& row_frames,
+                                        const std::vector<const double*>& col_frames, size_t row_count, size_t col_count, AciOpKind kind,
+                                        const AciHostOp& host_op, size_t max_bond_dim, double tolerance, bool scale_tolerance,
+                                        bool left_orthogonal)
+{
+    const size_t K = bond_dims.size();
+    if (K == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "at least one input is required"); // TreeAciError::NoInputs
+    if (K > (size_t)ACI_MAX_INPUTS) throw Error(T4A_GPU_NOT_IMPLEMENTED, "more than eight inputs are not supported");
+    if (row_frames.size() != K || col_frames.size() != K) throw Error(T4A_GPU_INVALID_ARGUMENT, "one row / column frame block per input");
+    if (kind == AciOpKind::Callback && !host_op) throw Error(T4A_GPU_NULL_POINTER, "operator callback is null");
+    if (row_count == 0 || col_count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "the local matrix has no rows or no columns");
+    if (row_count > 65535 || col_count > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "local blocks above 65535 rows or columns are not supported");
+    const size_t np = row_count * col_count;
+    hipStream_t st = eng.stream();
+    // frames -> device: the row frames transposed into (row_count x bond) factors, the column frames as they are
+    size_t total = 0;
+    for (size_t k = 0; k < K; ++k) total += bond_dims[k] * (2 * row_count + col_count);
+    DevBuf<double> buf, vals;
+    buf.reserve(std::max<size_t>(total, 1));
+    AciPiArgs a{};
+    double* cur = buf.get();
+    for (size_t k = 0; k < K; ++k) {
+        const size_t b = bond_dims[k];
+        if (b > 0x7FFFFFFFull) throw Error(T4A_GPU_INVALID_ARGUMENT, "bond dimension out of range");
+        double* d_rf = cur;                      // bond x row_count, as uploaded
+        double* d_lf = d_rf + b * row_count;     // row_count x bond
+        double* d_cf = d_lf + b * row_count;     // bond x col_count
+        cur = d_cf + b * col_count;
+        if (b) {
+            T4A_HIP(hipMemcpyAsync(d_rf, row_frames[k], b * row_count * sizeof(double), hipMemcpyHostToDevice, st));
+            T4A_HIP(hipMemcpyAsync(d_cf, col_frames[k], b * col_count * sizeof(double), hipMemcpyHostToDevice, st));
+            transpose_launch(d_rf, (int)b, (int)row_count, (int)b, d_lf, (int)row_count, st);
+        }
+        a.lf[k] = d_lf;
+        a.rf[k] = d_cf;
+        a.mid[k] = (int)b;
+    }
+    a.n_inputs = (int)K;
+    a.nrows = (int)row_count;
+    a.ncols = (int)col_count;
+    a.op = (int)kind;
+    double* d_pi = eng.pi(np);
+    a.pi = d_pi;
+    if (kind == AciOpKind::Callback) {
+        vals.reserve(K * np);
+        a.vals = vals.get();
+    }
+    const unsigned blocks = (unsigned)std::min<size_t>((np + 255) / 256, 8192);
+    hipLaunchKernelGGL(aci_pi_kernel, dim3(blocks), dim3(256), 0, st, a);
+    T4A_HIP(hipGetLastError());
+    TreeAciLocalResult out;
+    out.local_values.resize(np);
+    if (kind == AciOpKind::Callback) {
+        std::vector<double> hv(K * np);
+        T4A_HIP(hipMemcpyAsync(hv.data(), vals.get(), hv.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        eng.sync();
+        host_op(hv.data(), K, np, out.local_values.data());
+        T4A_HIP(hipMemcpyAsync(d_pi, out.local_values.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
+        eng.sync();
+    } else {
+        T4A_HIP(hipMemcpyAsync(out.local_values.data(), d_pi, np * sizeof(double), hipMemcpyDeviceToHost, st));
+        eng.sync();
+    }
+    for (double v : out.local_values) out.sampled_scale = std::fmax(out.sampled_scale, std::fabs(v)); // (fold with f64::max: a NaN is dropped)
+    RrLUOptions lo;
+    lo.max_bond_dim = max_bond_dim == 0 ? std::numeric_limits<size_t>::max() : max_bond_dim;
+    lo.rel_tol = scale_tolerance ? tolerance : 0.0;
+    lo.abs_tol = scale_tolerance ? 0.0 : tolerance;
+    lo.left_orthogonal = left_orthogonal;
+    LuciResult r = eng.luci(d_pi, (int)row_count, (int)col_count, lo, true, false);
+    out.pivot_errors = r.pivot_errors;
+    if (r.rank == 0) { // local_update.rs:230-238
+        out.rank = 1;
+        out.row_indices = {0};
+        out.col_indices = {0};
+        out.left.assign(row_count, 0.0);
+        out.right.assign(col_count, 0.0);
+        return out;
+    }
+    out.rank = (size_t)r.rank;
+    out.row_indices.assign(r.row_perm.begin(), r.row_perm.begin() + r.rank);
+    out.col_indices.assign(r.col_perm.begin(), r.col_perm.begin() + r.rank);
+    out.left.resize(row_count * out.rank);
+    out.right.resize(out.rank * col_count);
+    T4A_HIP(hipMemcpyAsync(out.left.data(), eng.left(), out.left.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    T4A_HIP(hipMemcpyAsync(out.right.data(), eng.right(), out.right.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    eng.sync();
+    return out;
+}
+
 std::unique_ptr<TensorTrain> aci_one_site(const std::vector<TensorTrain*>& inputs, AciOpKind kind, const AciHostOp& host_op)
 {
     validate_inputs(inputs);

@@ -98,4 +98,22 @@ private:
 // single-site trains (elementwise.rs:220-254): one operator call over the site points
 std::unique_ptr<TensorTrain> aci_one_site(const std::vector<TensorTrain*>& inputs, AciOpKind kind, const AciHostOp& host_op);
 
+// tensor4all-treeaci local step (local_update.rs:35-262 materialize_and_factor_edge, from the candidate frames on): per input k the
+// candidate values are row_frames[k]^T col_frames[k] (bond_k x row_count and bond_k x col_count, column-major: a candidate's frame
+// vector is contiguous, as candidate_frames_for_edge hands them out), the operator combines the inputs point by point (batch layout
+// values[input + n_inputs * (row + row_count * col)], batch.rs), the local matrix goes through MatrixLUCI.  Everything between the
+// upload of the frames and the download of the factors runs on the device (aci_pi_kernel + the rrLU / factor kernels of the engine).
+struct TreeAciLocalResult {
+    size_t rank = 0;                      // factor rank (1 for a zero matrix: local_update.rs:230-238)
+    std::vector<size_t> row_indices, col_indices;
+    std::vector<double> pivot_errors;     // MatrixLuciFactors::pivot_errors (rank_luci + 1 entries)
+    std::vector<double> left, right;      // row_count x rank, rank x col_count (column-major)
+    double sampled_scale = 0.0;           // max |local value|
+    std::vector<double> local_values;     // row_count x col_count
+};
+TreeAciLocalResult treeaci_local_update(Engine& eng, const std::vector<size_t>& bond_dims, const std::vector<const double*>& row_frames,
+                                        const std::vector<const double*>& col_frames, size_t row_count, size_t col_count, AciOpKind kind,
+                                        const AciHostOp& host_op, size_t max_bond_dim, double tolerance, bool scale_tolerance,
+                                        bool left_orthogonal);
+
 } // namespace t4a

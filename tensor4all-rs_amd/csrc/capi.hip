@@ -2670,6 +2670,105 @@ t4a_gpu_status t4a_gpu_tensor_contract(const t4a_gpu_tensor* a, const t4a_gpu_te
     });
 }
 
+t4a_gpu_status t4a_gpu_tensor_contract_many(const t4a_gpu_tensor* const* tensors, size_t n_tensors, const int64_t* retain_labels,
+                                            size_t n_retain, t4a_gpu_tensor** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        if (n_tensors) T4A_REQUIRE_PTR(tensors);
+        if (n_retain) T4A_REQUIRE_PTR(retain_labels);
+        std::vector<TensorView> views;
+        for (size_t i = 0; i < n_tensors; ++i) {
+            T4A_REQUIRE_PTR(tensors[i]);
+            views.push_back(tensors[i]->view());
+        }
+        const std::vector<int64_t> retain(retain_labels, retain_labels + n_retain);
+        (void)plan_contract_network(views, retain); // (argument errors before the device is touched)
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        OwnedTensor r = tensor_contract_network(dense_engine(), views, retain);
+        auto t = std::make_unique<t4a_gpu_tensor>();
+        t->buf = std::move(r.buf);
+        t->dims = std::move(r.dims);
+        t->labels = std::move(r.labels);
+        *out = t.release();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_outer_product(const t4a_gpu_tensor* a, const t4a_gpu_tensor* b, t4a_gpu_tensor** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(b);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        const TensorView va = a->view(), vb = b->view();
+        for (int64_t l : va.labels)
+            if (std::find(vb.labels.begin(), vb.labels.end(), l) != vb.labels.end())
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "outer_product: the operands share an index; use contract for a contraction");
+        const ContractPlan plan = plan_contract_pair(va, vb); // (no common label: M x 1 times 1 x N)
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        auto t = make_tensor(plan.out_dims, plan.out_labels);
+        tensor_contract_pair(e, va, vb, plan, t->buf.get());
+        e.sync();
+        *out = t.release();
+    });
+}
+
+t4a_gpu_status t4a_gpu_tensor_tensordot(const t4a_gpu_tensor* a, const t4a_gpu_tensor* b, const int64_t* labels_a, const int64_t* labels_b,
+                                        size_t n_pairs, t4a_gpu_tensor** out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(b);
+        T4A_REQUIRE_PTR(out);
+        *out = nullptr;
+        if (n_pairs == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "tensordot: No pairs specified for contraction");
+        T4A_REQUIRE_PTR(labels_a);
+        T4A_REQUIRE_PTR(labels_b);
+        const TensorView va = a->view();
+        TensorView vb = b->view();
+        // prepare_contraction_pairs (index_ops.rs): every pair names one axis of each operand, no axis twice, equal dimensions; a label the
+        // operands have in common that is not paired would be a batch contraction (not implemented in the reference either)
+        std::vector<size_t> ax_a, ax_b;
+        for (size_t p = 0; p < n_pairs; ++p) {
+            const auto ia = std::find(va.labels.begin(), va.labels.end(), labels_a[p]);
+            const auto ib = std::find(vb.labels.begin(), vb.labels.end(), labels_b[p]);
+            if (ia == va.labels.end()) throw Error(T4A_GPU_INVALID_ARGUMENT, "tensordot: Index not found in self tensor");
+            if (ib == vb.labels.end()) throw Error(T4A_GPU_INVALID_ARGUMENT, "tensordot: Index not found in other tensor");
+            const size_t pa = (size_t)(ia - va.labels.begin()), pb = (size_t)(ib - vb.labels.begin());
+            if (std::find(ax_a.begin(), ax_a.end(), pa) != ax_a.end())
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "tensordot: Duplicate axis " + std::to_string(pa) + " in self tensor");
+            if (std::find(ax_b.begin(), ax_b.end(), pb) != ax_b.end())
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "tensordot: Duplicate axis " + std::to_string(pb) + " in other tensor");
+            if (va.dims[pa] != vb.dims[pb])
+                throw Error(T4A_GPU_INVALID_ARGUMENT, "tensordot: Dimension mismatch: self[" + std::to_string(pa) + "]=" + std::to_string(va.dims[pa]) +
+                                                          " != other[" + std::to_string(pb) + "]=" + std::to_string(vb.dims[pb]));
+            ax_a.push_back(pa);
+            ax_b.push_back(pb);
+        }
+        for (size_t i = 0; i < va.labels.size(); ++i)
+            for (size_t j = 0; j < vb.labels.size(); ++j)
+                if (va.labels[i] == vb.labels[j]) {
+                    bool paired = false;
+                    for (size_t p = 0; p < n_pairs; ++p) paired = paired || (ax_a[p] == i && ax_b[p] == j);
+                    if (!paired)
+                        throw Error(T4A_GPU_NOT_IMPLEMENTED,
+                                    "tensordot: Common index found but not in contraction pairs. Batch contraction is not yet implemented.");
+                }
+        // the paired axes of `b` take the labels of their partners; unpaired axes keep theirs (none is shared, checked above)
+        for (size_t p = 0; p < n_pairs; ++p) vb.labels[ax_b[p]] = va.labels[ax_a[p]];
+        const ContractPlan plan = plan_contract_pair(va, vb);
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        auto t = make_tensor(plan.out_dims, plan.out_labels);
+        tensor_contract_pair(e, va, vb, plan, t->buf.get());
+        e.sync();
+        *out = t.release();
+    });
+}
+
 t4a_gpu_status t4a_gpu_tensor_svd(const t4a_gpu_tensor* t, const int64_t* left_labels, size_t n_left, int32_t truncate,
                                   const t4a_gpu_svd_policy* policy, int32_t has_max_bond_dim, size_t max_bond_dim,
                                   int64_t bond_label, int64_t bond_label_v, t4a_gpu_tensor** u, t4a_gpu_tensor** s,
@@ -3188,6 +3287,59 @@ t4a_gpu_status t4a_gpu_aci_problem_new(const t4a_gpu_tt* const* inputs, size_t n
 }
 
 void t4a_gpu_aci_problem_release(t4a_gpu_aci_problem* h) { delete h; }
+
+t4a_gpu_status t4a_gpu_treeaci_local_update_f64(size_t n_inputs, const size_t* bond_dims, const double* const* row_frames,
+                                                const double* const* col_frames, size_t row_count, size_t col_count, int32_t op_kind,
+                                                t4a_gpu_aci_op_fn op, void* user, size_t max_bond_dim, double tolerance,
+                                                int32_t scale_tolerance, int32_t left_orthogonal, size_t* rank, size_t* row_indices,
+                                                size_t* col_indices, double* pivot_errors, size_t* n_pivot_errors, double* left,
+                                                double* right, double* sampled_scale, double* local_values)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(bond_dims);
+        T4A_REQUIRE_PTR(row_frames);
+        T4A_REQUIRE_PTR(col_frames);
+        T4A_REQUIRE_PTR(rank);
+        T4A_REQUIRE_PTR(row_indices);
+        T4A_REQUIRE_PTR(col_indices);
+        T4A_REQUIRE_PTR(pivot_errors);
+        T4A_REQUIRE_PTR(n_pivot_errors);
+        T4A_REQUIRE_PTR(left);
+        T4A_REQUIRE_PTR(right);
+        T4A_REQUIRE_PTR(sampled_scale);
+        if (op_kind < 0 || op_kind > 2) throw Error(T4A_GPU_INVALID_ARGUMENT, "unknown operator kind");
+        checked_mul(row_count, col_count, "local matrix elements");
+        require_int_dims({row_count, col_count}, "local matrix shape");
+        std::vector<size_t> bd(bond_dims, bond_dims + n_inputs);
+        std::vector<const double*> rf(n_inputs), cf(n_inputs);
+        for (size_t k = 0; k < n_inputs; ++k) {
+            if (bd[k] && (!row_frames[k] || !col_frames[k])) throw Error(T4A_GPU_NULL_POINTER, "frame block is null");
+            rf[k] = row_frames[k];
+            cf[k] = col_frames[k];
+        }
+        AciHostOp host;
+        if (op_kind == T4A_GPU_ACI_OP_CALLBACK) {
+            T4A_REQUIRE_PTR(op);
+            host = [op, user](const double* values, size_t ni, size_t npts, double* out) {
+                if (op(user, values, ni, npts, out) != 0) throw Error(T4A_GPU_CALLBACK_ERROR, "elementwise operator callback failed");
+            };
+        }
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        TreeAciLocalResult r = treeaci_local_update(dense_engine(), bd, rf, cf, row_count, col_count, (AciOpKind)op_kind, host, max_bond_dim,
+                                                    tolerance, scale_tolerance != 0, left_orthogonal != 0);
+        *rank = r.rank;
+        for (size_t i = 0; i < r.rank; ++i) {
+            row_indices[i] = r.row_indices[i];
+            col_indices[i] = r.col_indices[i];
+        }
+        *n_pivot_errors = r.pivot_errors.size();
+        for (size_t i = 0; i < r.pivot_errors.size(); ++i) pivot_errors[i] = r.pivot_errors[i];
+        std::copy(r.left.begin(), r.left.end(), left);
+        std::copy(r.right.begin(), r.right.end(), right);
+        *sampled_scale = r.sampled_scale;
+        if (local_values) std::copy(r.local_values.begin(), r.local_values.end(), local_values);
+    });
+}
 
 t4a_gpu_status t4a_gpu_aci_problem_local_update(t4a_gpu_aci_problem* h, size_t bond, int32_t left_orthogonal)
 {

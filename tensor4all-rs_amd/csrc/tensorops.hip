@@ -1,6 +1,8 @@
 // tensorops.hip — see tensorops.hpp.
 #include "tensorops.hpp"
 
+#include <memory>
+
 #include <algorithm>
 #include <cmath>
 
@@ -207,6 +209,216 @@ void tensor_contract_pair(Engine& e, const TensorView& a, const TensorView& b, c
     g.batch = 1;
     gemm_launch(g, e.stream());
     T4A_HIP(hipGetLastError());
+}
+
+NetworkPlan plan_contract_network(const std::vector<TensorView>& ts, const std::vector<int64_t>& retain) // contract.rs:530-572, :885-941
+{
+    if (ts.empty()) throw Error(T4A_GPU_INVALID_ARGUMENT, "No tensors to contract");
+    for (const TensorView& t : ts) validate(t, "contract operand");
+    auto has = [](const TensorView& t, int64_t l) { return std::find(t.labels.begin(), t.labels.end(), l) != t.labels.end(); };
+    for (int64_t r : retain) { // validate_retained_indices_exist :943-959
+        bool found = false;
+        for (const TensorView& t : ts) found = found || has(t, r);
+        if (!found) throw Error(T4A_GPU_INVALID_ARGUMENT, "Retained index " + std::to_string(r) + " does not appear in the input tensors");
+    }
+    NetworkPlan p;
+    if (ts.size() == 1) { // (:539-541: a single operand is returned as it is)
+        p.out_labels = ts[0].labels;
+        p.out_dims = ts[0].dims;
+        return p;
+    }
+    // connected components: operands that share a label (contractable or retained) are joined (:1167-1230)
+    const size_t n = ts.size();
+    std::vector<size_t> parent(n);
+    for (size_t i = 0; i < n; ++i) parent[i] = i;
+    auto find = [&](size_t x) {
+        while (parent[x] != x) x = parent[x] = parent[parent[x]];
+        return x;
+    };
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+            for (int64_t l : ts[i].labels)
+                if (has(ts[j], l)) parent[find(i)] = find(j);
+    size_t components = 0;
+    for (size_t i = 0; i < n; ++i) components += find(i) == i ? 1 : 0;
+    if (components > 1)
+        throw Error(T4A_GPU_INVALID_ARGUMENT, "Disconnected tensor network: " + std::to_string(components) + " components found");
+    // sizes and occurrence counts per label (:728-750, :892-897)
+    std::vector<int64_t> seen;
+    std::vector<size_t> seen_dim, count;
+    for (const TensorView& t : ts)
+        for (size_t a = 0; a < t.labels.size(); ++a) {
+            const auto it = std::find(seen.begin(), seen.end(), t.labels[a]);
+            if (it == seen.end()) {
+                seen.push_back(t.labels[a]);
+                seen_dim.push_back(t.dims[a]);
+                count.push_back(1);
+            } else {
+                const size_t k = (size_t)(it - seen.begin());
+                if (seen_dim[k] != t.dims[a])
+                    throw Error(T4A_GPU_INVALID_ARGUMENT, "Internal label shape mismatch: label " + std::to_string(t.labels[a]) + " has dimensions " +
+                                                              std::to_string(seen_dim[k]) + " and " + std::to_string(t.dims[a]));
+                ++count[k];
+            }
+        }
+    for (size_t k = 0; k < seen.size(); ++k) { // first appearance order is the order of `seen`
+        const bool retained = std::find(retain.begin(), retain.end(), seen[k]) != retain.end();
+        if (count[k] == 1 || retained) {
+            p.out_labels.push_back(seen[k]);
+            p.out_dims.push_back(seen_dim[k]);
+        }
+    }
+    if (p.out_labels.size() > (size_t)TENSOR_MAX_RANK) throw Error(T4A_GPU_NOT_IMPLEMENTED, "contract: result rank too large");
+    return p;
+}
+
+OwnedTensor tensor_contract_network(Engine& e, const std::vector<TensorView>& ts, const std::vector<int64_t>& retain)
+{
+    const NetworkPlan plan = plan_contract_network(ts, retain);
+    hipStream_t st = e.stream();
+    struct Node {
+        TensorView v;
+        std::shared_ptr<DevBuf<double>> own; // null: an input operand
+    };
+    std::vector<Node> work;
+    for (const TensorView& t : ts) work.push_back(Node{t, nullptr});
+    auto has = [](const TensorView& t, int64_t l) { return std::find(t.labels.begin(), t.labels.end(), l) != t.labels.end(); };
+    auto in_out = [&](int64_t l) { return std::find(plan.out_labels.begin(), plan.out_labels.end(), l) != plan.out_labels.end(); };
+    while (work.size() > 1) {
+        // the connected pair with the smallest result (ties: the first such pair)
+        size_t bi = 0, bj = 0;
+        double best = -1.0;
+        for (size_t i = 0; i < work.size(); ++i)
+            for (size_t j = i + 1; j < work.size(); ++j) {
+                bool shares = false;
+                for (int64_t l : work[i].v.labels) shares = shares || has(work[j].v, l);
+                if (!shares) continue;
+                double sz = 1.0;
+                auto needed = [&](int64_t l) {
+                    if (in_out(l)) return true;
+                    for (size_t q = 0; q < work.size(); ++q)
+                        if (q != i && q != j && has(work[q].v, l)) return true;
+                    return false;
+                };
+                for (size_t a = 0; a < work[i].v.labels.size(); ++a) {
+                    const int64_t l = work[i].v.labels[a];
+                    if (!has(work[j].v, l) || needed(l)) sz *= (double)work[i].v.dims[a];
+                }
+                for (size_t a = 0; a < work[j].v.labels.size(); ++a)
+                    if (!has(work[i].v, work[j].v.labels[a])) sz *= (double)work[j].v.dims[a];
+                if (best < 0.0 || sz < best) {
+                    best = sz;
+                    bi = i;
+                    bj = j;
+                }
+            }
+        if (best < 0.0) throw Error(T4A_GPU_INTERNAL_ERROR, "contract: no connected pair left in a connected network");
+        const TensorView& A = work[bi].v;
+        const TensorView& B = work[bj].v;
+        auto needed = [&](int64_t l) {
+            if (in_out(l)) return true;
+            for (size_t q = 0; q < work.size(); ++q)
+                if (q != bi && q != bj && has(work[q].v, l)) return true;
+            return false;
+        };
+        // A -> [free A, summed, batch], B -> [summed, free B, batch]; result [free A, free B, batch]
+        std::vector<size_t> pa_free, pa_sum, pa_batch, pb_sum, pb_free, pb_batch;
+        size_t M = 1, K = 1, N = 1, Bt = 1;
+        for (size_t a = 0; a < A.labels.size(); ++a) {
+            const int64_t l = A.labels[a];
+            if (!has(B, l)) {
+                pa_free.push_back(a);
+                M *= A.dims[a];
+            } else if (needed(l)) {
+                pa_batch.push_back(a);
+                Bt *= A.dims[a];
+            } else {
+                pa_sum.push_back(a);
+                K *= A.dims[a];
+            }
+        }
+        auto pos_in_b = [&](int64_t l) { return (size_t)(std::find(B.labels.begin(), B.labels.end(), l) - B.labels.begin()); };
+        for (size_t a : pa_sum) pb_sum.push_back(pos_in_b(A.labels[a]));
+        for (size_t a : pa_batch) pb_batch.push_back(pos_in_b(A.labels[a]));
+        for (size_t b = 0; b < B.labels.size(); ++b)
+            if (!has(A, B.labels[b])) {
+                pb_free.push_back(b);
+                N *= B.dims[b];
+            }
+        if (M > 0x7FFFFFFFull || N > 0x7FFFFFFFull || K > 0x7FFFFFFFull || Bt > 0x7FFFFFFFull)
+            throw Error(T4A_GPU_NOT_IMPLEMENTED, "contract: fused dimension above 2^31");
+        std::vector<size_t> perm_a, perm_b;
+        perm_a.insert(perm_a.end(), pa_free.begin(), pa_free.end());
+        perm_a.insert(perm_a.end(), pa_sum.begin(), pa_sum.end());
+        perm_a.insert(perm_a.end(), pa_batch.begin(), pa_batch.end());
+        perm_b.insert(perm_b.end(), pb_sum.begin(), pb_sum.end());
+        perm_b.insert(perm_b.end(), pb_free.begin(), pb_free.end());
+        perm_b.insert(perm_b.end(), pb_batch.begin(), pb_batch.end());
+        Node res;
+        for (size_t a : pa_free) {
+            res.v.dims.push_back(A.dims[a]);
+            res.v.labels.push_back(A.labels[a]);
+        }
+        for (size_t b : pb_free) {
+            res.v.dims.push_back(B.dims[b]);
+            res.v.labels.push_back(B.labels[b]);
+        }
+        for (size_t a : pa_batch) {
+            res.v.dims.push_back(A.dims[a]);
+            res.v.labels.push_back(A.labels[a]);
+        }
+        if (res.v.dims.size() > (size_t)TENSOR_MAX_RANK) throw Error(T4A_GPU_NOT_IMPLEMENTED, "contract: intermediate rank too large");
+        res.own = std::make_shared<DevBuf<double>>();
+        res.own->reserve(std::max<size_t>(M * N * Bt, 1));
+        res.v.d_data = res.own->get();
+        if (M * N * Bt > 0) {
+            e.d_tmp.reserve(std::max<size_t>(A.size(), 1));
+            e.d_tmp2.reserve(std::max<size_t>(B.size(), 1));
+            tensor_permute(e, A, perm_a, e.d_tmp.get());
+            tensor_permute(e, B, perm_b, e.d_tmp2.get());
+            GemmDesc g{};
+            g.m = (int)M;
+            g.n = (int)N;
+            g.k = (int)K;
+            g.A = e.d_tmp.get();
+            g.lda = (int)M;
+            g.strideA = (long long)(M * K);
+            g.transA = 0;
+            g.B = e.d_tmp2.get();
+            g.ldb = (int)K;
+            g.strideB = (long long)(K * N);
+            g.transB = 0;
+            g.C = res.own->get();
+            g.ldc = (int)M;
+            g.strideC = (long long)(M * N);
+            g.alpha = 1.0;
+            g.beta = 0.0;
+            g.batch = (int)Bt;
+            gemm_launch(g, st);
+            T4A_HIP(hipGetLastError());
+            e.sync(); // (the permutation scratch is reused by the next step)
+        }
+        work.erase(work.begin() + (long)bj);
+        work.erase(work.begin() + (long)bi);
+        work.push_back(std::move(res));
+    }
+    // into the reference's index order
+    const TensorView& F = work[0].v;
+    OwnedTensor out;
+    out.dims = plan.out_dims;
+    out.labels = plan.out_labels;
+    std::vector<size_t> perm;
+    for (int64_t l : plan.out_labels) {
+        const auto it = std::find(F.labels.begin(), F.labels.end(), l);
+        if (it == F.labels.end()) throw Error(T4A_GPU_INTERNAL_ERROR, "contract: a result index was lost");
+        perm.push_back((size_t)(it - F.labels.begin()));
+    }
+    if (perm.size() != F.labels.size()) throw Error(T4A_GPU_INTERNAL_ERROR, "contract: an index was left uncontracted");
+    out.buf.reserve(std::max<size_t>(F.size(), 1));
+    if (F.dims.empty()) T4A_HIP(hipMemcpyAsync(out.buf.get(), F.d_data, sizeof(double), hipMemcpyDeviceToDevice, st)); // (a scalar)
+    else if (F.size() > 0) tensor_permute(e, F, perm, out.buf.get());
+    e.sync();
+    return out;
 }
 
 UnfoldPlan plan_unfold_split(const TensorView& t, const std::vector<int64_t>& left) // idx_tensor.rs:5278-5345

@@ -48,6 +48,26 @@ ContractPlan plan_contract_pair(const TensorView& a, const TensorView& b);
 // d_out: M x N doubles = the result tensor [free a.., free b..]; uses e.d_tmp / e.d_tmp2 as permutation scratch
 void tensor_contract_pair(Engine& e, const TensorView& a, const TensorView& b, const ContractPlan& plan, double* d_out);
 
+// N-ary contraction of a connected tensor network (defaults/contract.rs:283-298 contract / contract_with_options, plan :885-941,
+// connectivity :1167-1230): every label that occurs in more than one operand is summed unless it is retained; the result carries the
+// labels that occur once, or are retained, in order of first appearance (operands in order, axes in order).  Errors like the
+// reference's: no operands, a retained label that no operand has, operands that fall into several connected components (a retained
+// label connects its holders), a label with two different dimensions.  The network is reduced pair by pair — at every step the
+// connected pair with the smallest result — each step one (batched) GEMM on the f64 matrix cores: a shared label that another
+// operand or the result still needs stays as a batch axis of that step (the reference hands the whole network to tenferro's einsum;
+// summation order is the backend's there as here: values agree to rounding).
+struct OwnedTensor {
+    DevBuf<double> buf;
+    std::vector<size_t> dims;
+    std::vector<int64_t> labels;
+};
+struct NetworkPlan {
+    std::vector<int64_t> out_labels;
+    std::vector<size_t> out_dims;
+};
+NetworkPlan plan_contract_network(const std::vector<TensorView>& ts, const std::vector<int64_t>& retain); // validation + result indices (host only)
+OwnedTensor tensor_contract_network(Engine& e, const std::vector<TensorView>& ts, const std::vector<int64_t>& retain);
+
 struct UnfoldPlan {
     std::vector<size_t> perm;
     std::vector<size_t> left_dims, right_dims;

@@ -1694,6 +1694,16 @@ def tensor_qr(t, labels, left, truncate=True, rtol=None):
     return q[:m * rr].reshape(ld + [rr], order="F"), rf[:rr * n].reshape([rr] + rd, order="F")
 
 
+def contract(tensors, retain=()):
+    """contract / contract_with_options of tensor4all-core (defaults/contract.rs:283-298): ONE connected network of LabelledTensor
+    operands; labels shared by several operands are summed unless listed in `retain` (ContractionOptions::retain_indices)."""
+    arr = (c_void_p * max(len(tensors), 1))(*[t._h for t in tensors])
+    rt = np.asarray(list(retain) or [0], dtype=np.int64)
+    h = c_void_p()
+    _check(_lib.t4a_gpu_tensor_contract_many(arr, c_size_t(len(tensors)), _p(rt), c_size_t(len(retain)), ctypes.byref(h)))
+    return LabelledTensor(_handle=h)
+
+
 class LabelledTensor:
     """Device-resident dense tensor with one integer label per axis (the dense payload of an IdxTensor): contractions and
     factorisations chain on the GPU without host round trips."""
@@ -1750,6 +1760,20 @@ class LabelledTensor:
         return LabelledTensor(_handle=h)
 
     __mul__ = contract
+
+    def outer_product(self, other):
+        """outer_product (defaults/contract.rs:440): operands without a common label"""
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tensor_outer_product(self._h, other._h, ctypes.byref(h)))
+        return LabelledTensor(_handle=h)
+
+    def tensordot(self, other, pairs):
+        """tensordot (defaults/contract.rs:420): pairs = [(label of self, label of other), ...]"""
+        la = np.asarray([p[0] for p in pairs] or [0], dtype=np.int64)
+        lb = np.asarray([p[1] for p in pairs] or [0], dtype=np.int64)
+        h = c_void_p()
+        _check(_lib.t4a_gpu_tensor_tensordot(self._h, other._h, _p(la), _p(lb), c_size_t(len(pairs)), ctypes.byref(h)))
+        return LabelledTensor(_handle=h)
 
     def svd(self, left, bond_label, bond_label_v=None, truncate=True, policy=None, max_bond_dim=None):
         lf = np.asarray(left, dtype=np.int64)
@@ -1844,6 +1868,60 @@ def _aci_op(op):
             return 1
     cb = ACI_OP_FN(tramp)
     return ACI_CALLBACK, cb, (cb, err)
+
+
+class TreeAciLocalUpdate:
+    """LocalUpdateResult of tensor4all-treeaci (local_update.rs:21-33): selected candidates as indices into the candidate lists"""
+
+
+def treeaci_local_update(row_frames, col_frames, op=None, max_bond_dim=None, tolerance=1e-12, scale_tolerance=True,
+                         left_orthogonal=True):
+    """materialize_and_factor_edge (tensor4all-treeaci/src/local_update.rs:35) from the candidate frames on.  row_frames / col_frames:
+    one array per input, shape (bond_k, row_count) / (bond_k, col_count) — column k = the frame vector of candidate k; op: ACI_PRODUCT
+    (default, hadamard_many), ACI_SUM, or a callable values (n_inputs, n_points) -> n_points values."""
+    if op is None:
+        op = ACI_PRODUCT
+    K = len(row_frames)
+    if K != len(col_frames):
+        raise ValueError("one row-frame and one column-frame block per input")
+    rfs = [np.asfortranarray(np.asarray(f, dtype=np.float64)) for f in row_frames]
+    cfs = [np.asfortranarray(np.asarray(f, dtype=np.float64)) for f in col_frames]
+    row_count = rfs[0].shape[1] if K else 0
+    col_count = cfs[0].shape[1] if K else 0
+    for r, c in zip(rfs, cfs):
+        if r.ndim != 2 or c.ndim != 2 or r.shape[0] != c.shape[0] or r.shape[1] != row_count or c.shape[1] != col_count:
+            raise ValueError("opposite input frames have different cut bond dimensions or candidate counts")
+    bd = (c_size_t * max(K, 1))(*[r.shape[0] for r in rfs])
+    rp = (c_void_p * max(K, 1))(*[r.ctypes.data for r in rfs])
+    cp = (c_void_p * max(K, 1))(*[c.ctypes.data for c in cfs])
+    kind, cb, keep = _aci_op(op)
+    cap = max(min(row_count, col_count), 1)
+    rank, npe = c_size_t(0), c_size_t(0)
+    rows, cols = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64)
+    perr = np.zeros(cap + 1)
+    left, right = np.zeros(max(row_count * cap, 1)), np.zeros(max(cap * col_count, 1))
+    scale = c_double(0.0)
+    local = np.zeros(max(row_count * col_count, 1))
+    st = _lib.t4a_gpu_treeaci_local_update_f64(c_size_t(K), bd, rp, cp, c_size_t(row_count), c_size_t(col_count), c_int32(kind), cb, None,
+                                               c_size_t(0 if max_bond_dim is None else int(max_bond_dim)), c_double(tolerance),
+                                               c_int32(1 if scale_tolerance else 0), c_int32(1 if left_orthogonal else 0),
+                                               ctypes.byref(rank), _p(rows), _p(cols), _p(perr), ctypes.byref(npe), _p(left), _p(right),
+                                               ctypes.byref(scale), _p(local))
+    if keep is not None and keep[1]:
+        raise keep[1][0]
+    _check(st)
+    r = TreeAciLocalUpdate()
+    k = int(rank.value)
+    r.rank = k
+    r.row_indices = [int(v) for v in rows[:k]]
+    r.col_indices = [int(v) for v in cols[:k]]
+    r.pivot_errors = perr[:int(npe.value)].copy()
+    r.left = left[:row_count * k].reshape((row_count, k), order="F").copy()
+    r.right = right[:k * col_count].reshape((k, col_count), order="F").copy()
+    r.sampled_scale = float(scale.value)
+    r.row_count, r.col_count = row_count, col_count
+    r.local_values = local[:row_count * col_count].copy()
+    return r
 
 
 def _aci_inputs(inputs, options):

@@ -1131,6 +1131,27 @@ def tensor_contract(a, a_labels, b, b_labels):
     return out.reshape(shape, order="F"), [int(x) for x in ol[:orank.value]]
 
 
+def tensor_contract_many(tensors, labels, retain=()):
+    """contract / contract_with_options (defaults/contract.rs:283-298): tensors = arrays, labels = one label list per array; returns
+    (array, labels)"""
+    parts = [_tensor_args(t, l) for t, l in zip(tensors, labels)]
+    data = np.concatenate([p[0].reshape(-1, order="F") for p in parts]) if parts else np.zeros(1)
+    dims = np.concatenate([p[1] for p in parts]).astype(np.uint64) if parts else np.zeros(1, dtype=np.uint64)
+    labs = np.concatenate([p[2] for p in parts]).astype(np.int64) if parts else np.zeros(1, dtype=np.int64)
+    if len(dims) == 0:
+        dims, labs = np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.int64)
+    ranks = np.asarray([p[0].ndim for p in parts] or [0], dtype=np.uint64)
+    rt = np.asarray(list(retain) or [0], dtype=np.int64)
+    cap = max(int(sum(p[0].ndim for p in parts)), 1)
+    od, ol, orank = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.int64), u64(0)
+    args = (u64(len(parts)), _p(data), _p(dims), _p(labs), _p(ranks), _p(rt), u64(len(retain)))
+    _check_tt(_lib.oracle_tensor_contract_many(*args, None, _p(od), _p(ol), ctypes.byref(orank)))
+    shape = [int(x) for x in od[:orank.value]]
+    out = np.zeros(int(np.prod(shape)) if shape else 1)
+    _check_tt(_lib.oracle_tensor_contract_many(*args, _p(out), _p(od), _p(ol), ctypes.byref(orank)))
+    return out.reshape(shape, order="F"), [int(x) for x in ol[:orank.value]]
+
+
 def svd_retained_rank(s, threshold=1e-12, scale=0, measure=0, rule=0):
     s = np.ascontiguousarray(np.asarray(s, dtype=np.float64))
     return int(_lib.oracle_svd_retained_rank(_p(s) if len(s) else None, u64(len(s)), dbl(threshold), cint(scale), cint(measure), cint(rule)))
@@ -1262,6 +1283,49 @@ def _aci_inputs(inputs):
     tts = [t if isinstance(t, OracleTT) else OracleTT(t) for t in inputs]
     arr = (vp * len(tts))(*[t._h for t in tts])
     return tts, arr
+
+
+class TreeAciLocalUpdate:
+    pass
+
+
+def treeaci_local_update(row_frames, col_frames, op=ACI_PRODUCT, max_bond_dim=None, tolerance=1e-12, scale_tolerance=True,
+                         left_orthogonal=True):
+    """oracle/t4a_oracle_treeaci.hpp (local_update.rs:35-262 from the candidate frames on); arguments as t4a_amd.treeaci_local_update"""
+    K = len(row_frames)
+    rfs = [np.asfortranarray(np.asarray(f, dtype=np.float64)) for f in row_frames]
+    cfs = [np.asfortranarray(np.asarray(f, dtype=np.float64)) for f in col_frames]
+    row_count, col_count = rfs[0].shape[1], cfs[0].shape[1]
+    bd = np.asarray([r.shape[0] for r in rfs], dtype=np.uint64)
+    rp = (vp * K)(*[r.ctypes.data for r in rfs])
+    cp = (vp * K)(*[c.ctypes.data for c in cfs])
+    kind, cb, keep = _aci_op(op)
+    cap = max(min(row_count, col_count), 1)
+    rank, npe = u64(0), u64(0)
+    rows, cols = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64)
+    perr = np.zeros(cap + 1)
+    left, right = np.zeros(max(row_count * cap, 1)), np.zeros(max(cap * col_count, 1))
+    scale = dbl(0.0)
+    local = np.zeros(max(row_count * col_count, 1))
+    batch = np.zeros(max(K * row_count * col_count, 1))
+    _check_tt(_lib.oracle_treeaci_local_update(u64(K), _p(bd), rp, cp, u64(row_count), u64(col_count), cint(kind), cb, None,
+                                               u64(0 if max_bond_dim is None else int(max_bond_dim)), dbl(tolerance),
+                                               cint(1 if scale_tolerance else 0), cint(1 if left_orthogonal else 0), ctypes.byref(rank),
+                                               _p(rows), _p(cols), _p(perr), ctypes.byref(npe), _p(left), _p(right), ctypes.byref(scale),
+                                               _p(local), _p(batch)))
+    r = TreeAciLocalUpdate()
+    k = int(rank.value)
+    r.rank = k
+    r.row_indices = [int(v) for v in rows[:k]]
+    r.col_indices = [int(v) for v in cols[:k]]
+    r.pivot_errors = perr[:int(npe.value)].copy()
+    r.left = left[:row_count * k].reshape((row_count, k), order="F").copy()
+    r.right = right[:k * col_count].reshape((k, col_count), order="F").copy()
+    r.sampled_scale = float(scale.value)
+    r.row_count, r.col_count = row_count, col_count
+    r.local_values = local[:row_count * col_count].copy()
+    r.batch = batch[:K * row_count * col_count].copy()
+    return r
 
 
 class AciResult:

@@ -239,3 +239,78 @@ def test_chain_bridge_between_tensor_trains_and_labelled_tensors(t4a):
         t4a.tensors_to_tensor_train([full, ts[3]])
     with pytest.raises(t4a.T4aError):
         t4a.tensor_train_to_tensors(tt, [10, 11, 12, 13], [20, 21, 10])
+
+
+# ---- N-ary contraction, outer product, tensordot (defaults/contract.rs:283-447; reference cases contract/tests/mod.rs) ----
+def _arange_tensor(shape):
+    return np.arange(int(np.prod(shape)), dtype=np.float64).reshape(shape, order="F")
+
+
+def test_contract_network_reference_cases_on_the_device(t4a):
+    a, b, c, d = _arange_tensor((2, 3)), _arange_tensor((3, 4)), _arange_tensor((4, 5)), _arange_tensor((5, 6))
+    T = t4a.LabelledTensor
+    r = t4a.contract([T(a, [1, 2]), T(b, [2, 3]), T(c, [3, 4])])  # test_contract_three
+    assert r.labels == [1, 4] and np.array_equal(r.to_numpy(), a @ b @ c)
+    r = t4a.contract([T(a, [1, 2]), T(b, [2, 3]), T(c, [3, 4]), T(d, [4, 5])])  # test_contract_four
+    assert r.labels == [1, 5] and np.array_equal(r.to_numpy(), a @ b @ c @ d)
+    r = t4a.contract([T(a, [7, 8])])  # test_contract_single
+    assert r.labels == [7, 8] and np.array_equal(r.to_numpy(), a)
+    with pytest.raises(t4a.T4aError):
+        t4a.contract([])
+    with pytest.raises(t4a.T4aError, match="Disconnected tensor network: 2 components"):
+        t4a.contract([T(a, [1, 2]), T(c, [3, 4])])
+    # retained indices (:235-281, :338-392, :410-449, :394-408)
+    x3 = np.arange(1, 13, dtype=np.float64).reshape((2, 2, 3), order="F")
+    y3 = 0.5 * np.arange(1, 13, dtype=np.float64).reshape((2, 3, 2), order="F")
+    r = t4a.contract([T(x3, [10, 11, 12]), T(y3, [10, 12, 13])], retain=[10])
+    assert r.labels == [10, 11, 13] and np.array_equal(r.to_numpy(), np.einsum("bik,bkj->bij", x3, y3))
+    x = np.array([1.0, 2.0, 3.0, 4.0]).reshape((2, 2), order="F")
+    y = np.array([5.0, 6.0, 7.0, 8.0, 9.0, 10.0]).reshape((2, 3), order="F")
+    z = np.array([11.0, 12.0, 13.0, 14.0]).reshape((2, 2), order="F")
+    r = t4a.contract([T(x, [20, 21]), T(y, [20, 22]), T(z, [20, 23])], retain=[20])
+    assert r.labels == [20, 21, 22, 23] and np.array_equal(r.to_numpy(), np.einsum("bi,bj,bk->bijk", x, y, z))
+    r = t4a.contract([T(x, [40, 41]), T(y, [40, 42])], retain=[40])
+    assert r.labels == [40, 41, 42] and np.array_equal(r.to_numpy(), np.einsum("bi,bj->bij", x, y))
+    with pytest.raises(t4a.T4aError):
+        t4a.contract([T(np.array([1.0, 2.0]), [30]), T(np.array([3.0, 4.0, 5.0]), [31])], retain=[32])
+
+
+def test_contract_network_random_networks_match_the_oracle(t4a):
+    rng = np.random.default_rng(21)
+    T = t4a.LabelledTensor
+    cases = [
+        # a ring of four with two dangling legs, a star with a hyper-edge (label 5 in three operands), a full contraction to a scalar pair
+        ([(3, 4, 2), (4, 5), (5, 6, 3), (6, 3)], [[1, 2, 9], [2, 3], [3, 4, 8], [4, 1]], []),
+        ([(4, 3), (4, 5), (4, 2), (3, 5, 2)], [[5, 1], [5, 2], [5, 3], [1, 2, 3]], []),
+        ([(4, 3), (4, 5), (4, 2)], [[5, 1], [5, 2], [5, 3]], [5]),
+        ([(6, 7), (7, 8), (8, 6)], [[1, 2], [2, 3], [3, 1]], [2]),
+        ([(16, 24, 3), (24, 20), (20, 16, 5)], [[1, 2, 7], [2, 3], [3, 1, 8]], []),
+    ]
+    for shapes, labels, retain in cases:
+        arrs = [rng.standard_normal(s) for s in shapes]
+        want, wl = ob.tensor_contract_many(arrs, labels, retain)
+        got = t4a.contract([T(a, l) for a, l in zip(arrs, labels)], retain=retain)
+        assert got.labels == wl
+        g = got.to_numpy()
+        assert g.shape == want.shape and np.abs(g - want).max() <= 1e-11 * max(1.0, np.abs(want).max())
+
+
+def test_outer_product_and_tensordot(t4a):
+    rng = np.random.default_rng(5)
+    T = t4a.LabelledTensor
+    a, b = rng.standard_normal((3, 4)), rng.standard_normal((2, 5))
+    o = T(a, [1, 2]).outer_product(T(b, [3, 4]))  # test_outer_product_matrix_matrix :198-208
+    assert o.labels == [1, 2, 3, 4] and np.allclose(o.to_numpy(), np.einsum("ij,kl->ijkl", a, b), rtol=0, atol=1e-14)
+    with pytest.raises(t4a.T4aError):
+        T(a, [1, 2]).outer_product(T(b, [2, 4]))
+    c = rng.standard_normal((4, 3, 6))
+    d = T(a, [1, 2]).tensordot(T(c, [7, 8, 9]), [(2, 7), (1, 8)])  # differently labelled axes, paired explicitly
+    assert d.labels == [9] and np.allclose(d.to_numpy(), np.einsum("ij,jik->k", a, c), rtol=0, atol=1e-12)
+    with pytest.raises(t4a.T4aError, match="No pairs"):
+        T(a, [1, 2]).tensordot(T(c, [7, 8, 9]), [])
+    with pytest.raises(t4a.T4aError, match="Dimension mismatch"):
+        T(a, [1, 2]).tensordot(T(c, [7, 8, 9]), [(1, 7)])
+    with pytest.raises(t4a.T4aError, match="Index not found"):
+        T(a, [1, 2]).tensordot(T(c, [7, 8, 9]), [(5, 7)])
+    with pytest.raises(t4a.T4aError, match="Batch contraction"):
+        T(a, [1, 2]).tensordot(T(c, [2, 1, 9]), [(1, 1)])

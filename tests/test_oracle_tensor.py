@@ -118,3 +118,44 @@ def test_factorize_reconstructs_and_is_canonical(alg, canonical):
     if alg != ob.QR:
         l, r, sv = ob.tensor_factorize(t, labels, [3, 1], alg=alg, canonical=canonical, max_bond_dim=3)
         assert l.shape[-1] == 3
+
+
+# ---- N-ary contraction (defaults/contract.rs:283-298; reference cases: contract/tests/mod.rs) ----
+def _arange_tensor(shape):
+    return np.arange(int(np.prod(shape)), dtype=np.float64).reshape(shape, order="F")  # make_test_tensor: data = 0, 1, 2, ... column-major
+
+
+def test_contract_network_reference_cases():
+    a, b, c, d = _arange_tensor((2, 3)), _arange_tensor((3, 4)), _arange_tensor((4, 5)), _arange_tensor((5, 6))
+    r3, l3 = ob.tensor_contract_many([a, b, c], [[1, 2], [2, 3], [3, 4]])  # test_contract_three :173-183
+    assert l3 == [1, 4] and np.array_equal(r3, a @ b @ c)
+    r4, l4 = ob.tensor_contract_many([a, b, c, d], [[1, 2], [2, 3], [3, 4], [4, 5]])  # test_contract_four :185-196
+    assert l4 == [1, 5] and np.array_equal(r4, a @ b @ c @ d)
+    one, lone = ob.tensor_contract_many([a], [[7, 8]])  # test_contract_single :82-87
+    assert lone == [7, 8] and np.array_equal(one, a)
+    with pytest.raises(ob.OracleError):  # test_contract_empty :75-80
+        ob.tensor_contract_many([], [])
+    with pytest.raises(ob.OracleError, match="Disconnected tensor network: 2 components"):  # :98-108, :222-233
+        ob.tensor_contract_many([a, c], [[1, 2], [3, 4]])
+
+
+def test_contract_network_retained_indices_like_the_reference():
+    # test_contract_with_options_retains_shared_batch_index :235-281
+    a = np.arange(1, 13, dtype=np.float64).reshape((2, 2, 3), order="F")
+    b = 0.5 * np.arange(1, 13, dtype=np.float64).reshape((2, 3, 2), order="F")
+    r, labels = ob.tensor_contract_many([a, b], [[10, 11, 12], [10, 12, 13]], retain=[10])
+    assert labels == [10, 11, 13] and np.array_equal(r, np.einsum("bik,bkj->bij", a, b))
+    # test_contract_with_options_supports_three_way_retained_label :338-392
+    x = np.array([1.0, 2.0, 3.0, 4.0]).reshape((2, 2), order="F")
+    y = np.array([5.0, 6.0, 7.0, 8.0, 9.0, 10.0]).reshape((2, 3), order="F")
+    z = np.array([11.0, 12.0, 13.0, 14.0]).reshape((2, 2), order="F")
+    r, labels = ob.tensor_contract_many([x, y, z], [[20, 21], [20, 22], [20, 23]], retain=[20])
+    assert labels == [20, 21, 22, 23] and np.array_equal(r, np.einsum("bi,bj,bk->bijk", x, y, z))
+    # test_contract_with_options_retained_index_connects_components :410-449
+    r, labels = ob.tensor_contract_many([x, y], [[40, 41], [40, 42]], retain=[40])
+    assert labels == [40, 41, 42] and np.array_equal(r, np.einsum("bi,bj->bij", x, y))
+    # a three-way label that is NOT retained is summed over all three operands
+    r, labels = ob.tensor_contract_many([x, y, z], [[20, 21], [20, 22], [20, 23]])
+    assert labels == [21, 22, 23] and np.array_equal(r, np.einsum("bi,bj,bk->ijk", x, y, z))
+    with pytest.raises(ob.OracleError):  # test_contract_with_options_errors_for_missing_retained_index :394-408
+        ob.tensor_contract_many([np.array([1.0, 2.0]), np.array([3.0, 4.0, 5.0])], [[30], [31]], retain=[32])
