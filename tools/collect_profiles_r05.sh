@@ -30,6 +30,9 @@ timeout 300 python3 tools/probe_cfg5_group.py 8 > $O/cfg5_group_probe.txt 2>&1
 timeout 300 python3 tools/probe_cfg5_threads.py 8 > $O/cfg5_threads_probe.txt 2>&1
 timeout 300 python3 tools/probe_cfg5_scratch.py 3 > $O/cfg5_scratch_probe.txt 2>&1
 timeout 300 python3 tools/probe_linalg.py > $O/linalg_probe.txt 2>&1
+timeout 300 python3 tools/probe_fill.py > $O/fill_probe.txt 2>&1
+prof --kernel-trace --stats -d $O/fillstats -o x --output-format csv -- python3 tools/probe_fill.py 30 > $O/fillstats.log 2>&1
+grep "lu_panel\|lu_update\|lu_solve\|trsm\|pi_eval\|pack_fill" $O/fillstats/x_kernel_stats.csv > $O/fill_kernel_stats.csv
 timeout 600 python3 bench.py --mode site-shard --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_site_shard_n1.json
 T4A_XCD_V=1 T4A_NO_WG=1 timeout 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-aux 2>/dev/null | tail -1 > $O/bench_n1_first_generation_kernels.json
 if [ -f tensor4all-rs_amd/lib/libt4a_gpu_alt_w3.so ]; then
@@ -45,5 +48,5 @@ for sh in "1464 1448 256" "1428 1024 256" "1424 512 256"; do
   T4A_GPU_LIB=$GRAFT_REPO_ROOT/tensor4all-rs_amd/lib/libt4a_gpu_alt.so T4A_RRLU_STAMPS=1 timeout 120 python3 tools/probe_xcd.py child $sh 1 2>&1 | grep "stamps xcd" | tail -1
 done > $O/xcd2m_phase_stamps.txt
 # keep only the summaries (the merge back is limited to 64 MiB)
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_sq $O/gemm
+rm -rf $O/fillstats $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_sq $O/gemm
 ls -la $O | head -40
