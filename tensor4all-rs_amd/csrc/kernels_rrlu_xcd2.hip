@@ -69,6 +69,12 @@ static_assert(Xcd2Lds<16, 3>::bytes == (int)xcd2_lds_total(16, 3), "plan.lds_byt
 #ifndef T4A_X2_POLLEARLY
 #define T4A_X2_POLLEARLY 0
 #endif
+// T4A_X2_KHEARLY = 1: the polling wave requests the FULL keys together with every sweep of the early keys instead of behind the
+// successful one — when the winner's position search has finished by then (its full key carries the right tag) the pick does not wait
+// for a second L2 round trip; a stale one is fetched again as before
+#ifndef T4A_X2_KHEARLY
+#define T4A_X2_KHEARLY 0
+#endif
 
 // full-key meta word (second generation): bits 0..10 row index of the candidate (up to 1536 rows since round 5), 11..12 column slot
 // of the publishing agent, bit 13 the agent has a candidate.  Positions are NOT carried: whoever needs one reads the LDS tables (the
@@ -425,6 +431,11 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
+#if T4A_X2_KHEARLY
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
+#endif
         }
         // thresholded speculative publication of the candidate column: pivots shrink slowly, so the next winner is almost
         // always an agent whose candidate is close to the previous pivot; its column is then already in the L2 when the
@@ -458,6 +469,11 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     kg[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
+#if T4A_X2_KHEARLY
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
+#endif
             }
             if (stamp_on) lds_stamps[5] += spins;
             // agents on several XCDs: the first read of the REMOTE finalists goes out now — a read across the fabric takes ~2 400 cycles,
@@ -470,9 +486,11 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                 fr = __builtin_amdgcn_raw_buffer_load_b128(mail, fslot + xr * 16, 0, BUF_SC1);
             }
             // the full keys: fetched now, in flight while the early ones are examined (a late one is fetched again below)
+#if !T4A_X2_KHEARLY
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 kh[j] = __builtin_amdgcn_raw_buffer_load_b128(mail, (int)k2_base + (par * NW + pbase + min(lane + 64 * j, NWL - 1)) * 16, 0, BUF_SC1);
+#endif
             XSTAMP(8);
             int wa_ = 0;
             unsigned wkx = 0u, wky = 0u, wkz = 0u; // the winner's full key
