@@ -75,6 +75,13 @@ static_assert(Xcd2Lds<16, 3>::bytes == (int)xcd2_lds_total(16, 3), "plan.lds_byt
 #ifndef T4A_X2_KHEARLY
 #define T4A_X2_KHEARLY 0
 #endif
+// T4A_X2_FSTAGGER = 1 (agents on several XCDs): the remote finalists are requested THREE times, staggered — when the early keys are
+// complete (as before), when the local winner is known, and behind the publication of the own finalist — and examined oldest first.
+// A read across the fabric takes ~2 400 cycles and samples the memory side somewhere in the middle: a single read issued before the
+// remote XCDs have picked comes back stale and the next one costs another full trip.
+#ifndef T4A_X2_FSTAGGER
+#define T4A_X2_FSTAGGER 1
+#endif
 
 // full-key meta word (second generation): bits 0..10 row index of the candidate (up to 1536 rows since round 5), 11..12 column slot
 // of the publishing agent, bit 13 the agent has a candidate.  Positions are NOT carried: whoever needs one reads the LDS tables (the
@@ -629,6 +636,9 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     // reads per round through the fabric; profiles/r05_xcd2m_phase_stamps.txt.)
                     // finalist granule: {value lo, value hi, meta | agent << 14 | give-up << 26 | undecided << 31, tag ^ fold}
                     bool need_exact = (wkz >> 31) != 0u; // (this XCD could not decide on its early keys alone)
+#if T4A_X2_FSTAGGER
+                    u32x4 fr1 = __builtin_amdgcn_raw_buffer_load_b128(mail, fslot + xr * 16, 0, BUF_SC1);
+#endif
                     if (rank == xi * p.W && lane == 0) {
                         u32x4 fv;
                         fv.x = wkx;
@@ -645,6 +655,13 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     double best = __builtin_fabs(mk_f64(wkx, wky));
                     {
                         unsigned sp2 = 0;
+#if T4A_X2_FSTAGGER
+                        u32x4 fr2 = __builtin_amdgcn_raw_buffer_load_b128(mail, fslot + xr * 16, 0, BUF_SC1);
+                        if (!__all((fr.x ^ fr.y ^ fr.z ^ fr.w) == tag)) {
+                            fr = fr1;
+                            if (!__all((fr.x ^ fr.y ^ fr.z ^ fr.w) == tag)) fr = fr2;
+                        }
+#endif
                         for (;;) {
                             if (__all((fr.x ^ fr.y ^ fr.z ^ fr.w) == tag)) break;
                             xcd_poll_again();
