@@ -135,6 +135,17 @@ t4a_gpu_status t4a_gpu_svd_f64(const double* a, size_t m, size_t n, double* u, d
 /* qr_backend(&a) (backend.rs:742-760): thin QR, q is m x k, r is k x n upper trapezoidal.  Householder. */
 t4a_gpu_status t4a_gpu_qr_f64(const double* a, size_t m, size_t n, double* q, double* r);
 
+/* Randomized rank-k SVD (north_star: "one-sided Jacobi / randomized SVD"; Halko, Martinsson, Tropp 2011, algorithms 4.4 + 5.1 — the
+ * reference itself only has the dense svd_backend above, so this is an ADDITION for truncated factorisations, not a replacement):
+ * Y = A Omega with Omega n x (k + oversample) standard normal (drawn from the library's StdRng stream seeded with `seed`), power_iters
+ * rounds of Y <- A (A^T Q(Y)) with a QR in between, Q = qr(Y), B = Q^T A, thin SVD of the small B by the one-sided Jacobi, U = Q U_B.
+ * Everything between the upload of A and the download of the factors runs on the device (f64-MFMA GEMMs, Householder QR, Jacobi).
+ * u is m x k, s has k entries (non-increasing), vt is k x n.  For a matrix of rank <= k the result is the thin SVD to rounding; for a
+ * decaying spectrum the error is bounded by the usual (1 + 9 sqrt(k + p) sqrt(min(m, n))) sigma_{k+1} of the randomized range finder.
+ * INVALID_ARGUMENT for k == 0, k + oversample > min(m, n) is clamped to min(m, n). */
+t4a_gpu_status t4a_gpu_rsvd_f64(const double* a, size_t m, size_t n, size_t k, size_t oversample, size_t power_iters, uint64_t seed,
+                                double* u, double* s, double* vt);
+
 /* full_piv_lu_matrix(&a) (backend.rs:1022-1037) for a square n x n matrix: P A Q^T = L U with n x n factors;
  * row k of P (Q) carries its 1 in the column of the k-th pivot row (column), which is how
  * core/src/matrixluci/dense.rs:120-139 reads them.  Elimination order = rrlu_mut with zero tolerances. */

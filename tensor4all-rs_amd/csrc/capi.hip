@@ -1285,6 +1285,89 @@ t4a_gpu_status t4a_gpu_svd_f64(const double* a, size_t m, size_t n, double* u, d
     });
 }
 
+t4a_gpu_status t4a_gpu_rsvd_f64(const double* a, size_t m, size_t n, size_t k, size_t oversample, size_t power_iters, uint64_t seed,
+                                double* u, double* s, double* vt)
+{
+    return guarded([&] {
+        const size_t count = checked_mul(m, n, "matrix shape");
+        require_int_dims({m, n}, "matrix shape");
+        if (count == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD of an empty matrix");
+        if (m > 65535 || n > 65535) throw Error(T4A_GPU_NOT_IMPLEMENTED, "svd: dimensions above 65535 are not supported");
+        if (k == 0 || k > std::min(m, n)) throw Error(T4A_GPU_INVALID_ARGUMENT, "rsvd: the rank must be between 1 and min(m, n)");
+        T4A_REQUIRE_PTR(a);
+        T4A_REQUIRE_PTR(u);
+        T4A_REQUIRE_PTR(s);
+        T4A_REQUIRE_PTR(vt);
+        const size_t l = std::min(std::min(m, n), k + oversample); // sketch width
+        // Omega (n x l): standard normals by Box-Muller on the library's StdRng stream
+        std::vector<double> omega(n * l);
+        {
+            StdRng rng(seed);
+            for (size_t i = 0; i < omega.size(); i += 2) {
+                const double u1 = ((double)(rng.next_u64() >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+                const double u2 = (double)(rng.next_u64() >> 11) * (1.0 / 9007199254740992.0);
+                const double rad = std::sqrt(-2.0 * std::log(u1));
+                omega[i] = rad * std::cos(6.283185307179586 * u2);
+                if (i + 1 < omega.size()) omega[i + 1] = rad * std::sin(6.283185307179586 * u2);
+            }
+        }
+        std::lock_guard<std::mutex> lock(g_dense_mutex);
+        Engine& e = dense_engine();
+        hipStream_t st = e.stream();
+        DevBuf<double> dA, dO, dY, dQ, dR, dZ, dB, dUb, dSb, dVt, dU;
+        dA.reserve(count);
+        dO.reserve(n * l);
+        dY.reserve(m * l);
+        dQ.reserve(m * l);
+        dR.reserve(l * std::max(l, n));
+        dZ.reserve(n * l);
+        dB.reserve(l * n);
+        dUb.reserve(l * l);
+        dSb.reserve(l);
+        dVt.reserve(l * n);
+        dU.reserve(m * l);
+        upload(e, dA.get(), a, count);
+        upload(e, dO.get(), omega.data(), omega.size());
+        auto gemm = [&](const double* A_, int lda, bool ta, const double* B_, int ldb, double* C_, int ldc, size_t M_, size_t N_, size_t K_) {
+            GemmDesc g{};
+            g.m = (int)M_;
+            g.n = (int)N_;
+            g.k = (int)K_;
+            g.A = A_;
+            g.lda = lda;
+            g.transA = ta ? 1 : 0;
+            g.B = B_;
+            g.ldb = ldb;
+            g.transB = 0;
+            g.C = C_;
+            g.ldc = ldc;
+            g.alpha = 1.0;
+            g.beta = 0.0;
+            g.batch = 1;
+            gemm_launch(g, st);
+        };
+        gemm(dA.get(), (int)m, false, dO.get(), (int)n, dY.get(), (int)m, m, l, n);      // Y = A Omega
+        e.qr(dY.get(), (int)m, (int)l, dQ.get(), dR.get());                             // Q (m x l)
+        for (size_t it = 0; it < power_iters; ++it) {
+            gemm(dA.get(), (int)m, true, dQ.get(), (int)m, dZ.get(), (int)n, n, l, m);  // Z = A^T Q (n x l)
+            e.qr(dZ.get(), (int)n, (int)l, dO.get(), dR.get());                         // orthonormal basis of Z in dO (n x l)
+            gemm(dA.get(), (int)m, false, dO.get(), (int)n, dY.get(), (int)m, m, l, n); // Y = A Z
+            e.qr(dY.get(), (int)m, (int)l, dQ.get(), dR.get());
+        }
+        gemm(dQ.get(), (int)m, true, dA.get(), (int)m, dB.get(), (int)l, l, n, m);      // B = Q^T A (l x n)
+        e.svd(dB.get(), (int)l, (int)n, dUb.get(), dSb.get(), dVt.get());               // B = Ub S Vt, Ub l x l, Vt l x n
+        gemm(dQ.get(), (int)m, false, dUb.get(), (int)l, dU.get(), (int)m, m, l, l);    // U = Q Ub
+        T4A_HIP(hipGetLastError());
+        download(e, u, dU.get(), m * k);  // the first k columns
+        download(e, s, dSb.get(), k);
+        // the first k rows of Vt (l x n, column-major: strided) -> k x n
+        std::vector<double> hv(l * n);
+        download(e, hv.data(), dVt.get(), l * n);
+        for (size_t j = 0; j < n; ++j)
+            for (size_t i = 0; i < k; ++i) vt[i + k * j] = hv[i + l * j];
+    });
+}
+
 t4a_gpu_status t4a_gpu_qr_f64(const double* a, size_t m, size_t n, double* q, double* r)
 {
     return guarded([&] {

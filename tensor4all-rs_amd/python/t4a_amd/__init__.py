@@ -797,6 +797,19 @@ def svd_backend(a):
     return u, s, vt
 
 
+def randomized_svd(a, rank, oversample=8, power_iters=1, seed=0):
+    """t4a_gpu_rsvd_f64: randomized rank-`rank` SVD (range finder + Jacobi SVD of the small projected matrix): (u, s, vt) with u
+    m x rank, vt rank x n."""
+    a = _f(a)
+    m, n = a.shape
+    u = np.zeros((m, rank), order="F")
+    s = np.zeros(rank)
+    vt = np.zeros((rank, n), order="F")
+    _check(_lib.t4a_gpu_rsvd_f64(_p(a), c_size_t(m), c_size_t(n), c_size_t(rank), c_size_t(oversample), c_size_t(power_iters),
+                                 ctypes.c_uint64(seed), _p(u), _p(s), _p(vt)))
+    return u, s, vt
+
+
 def qr_backend(a):
     """qr_backend (tensorbackend/src/backend.rs:742): thin (q, r)."""
     a = _f(a)

@@ -452,3 +452,32 @@ def test_svd_tiny_and_rank_deficient_matrices_on_both_jacobi_paths(t4a):
             if r:
                 assert np.abs(u[:, :r].T @ u[:, :r] - np.eye(r)).max() <= 1e-10, (m, n)
                 assert np.abs(vt[:r] @ vt[:r].T - np.eye(r)).max() <= 1e-10, (m, n)
+
+
+def test_randomized_svd_against_the_dense_svd(t4a):
+    """t4a_gpu_rsvd_f64 (north_star: "one-sided Jacobi / randomized SVD"): exact to rounding on matrices of rank <= k, and within
+    the range-finder bound on a decaying spectrum; orthonormal factors; argument errors."""
+    rng = np.random.default_rng(17)
+    # rank-20 matrix, k = 20: the thin SVD of the matrix itself
+    a = rng.standard_normal((300, 20)) @ rng.standard_normal((20, 180))
+    u, s, vt = t4a.randomized_svd(a, 20, oversample=8, power_iters=1, seed=3)
+    s_ref = np.linalg.svd(a, compute_uv=False)[:20]
+    assert np.abs(s - s_ref).max() <= 1e-10 * s_ref[0]
+    assert np.abs(u @ np.diag(s) @ vt - a).max() <= 1e-10 * np.abs(a).max() * 20
+    assert np.abs(u.T @ u - np.eye(20)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(20)).max() < 1e-10
+    assert np.all(np.diff(s) <= 1e-12 * s[0])
+    # decaying spectrum sigma_i = 2^-i: rank-12 truncation with two power iterations
+    q1, _ = np.linalg.qr(rng.standard_normal((256, 64)))
+    q2, _ = np.linalg.qr(rng.standard_normal((200, 64)))
+    sig = 2.0 ** -np.arange(64)
+    b = (q1 * sig) @ q2.T
+    u, s, vt = t4a.randomized_svd(b, 12, oversample=10, power_iters=2, seed=5)
+    assert np.abs(s - sig[:12]).max() <= 1e-6 * sig[0]
+    assert np.linalg.norm(u @ np.diag(s) @ vt - b, 2) <= 1.5 * sig[12]
+    # the same seed gives the same factors
+    u2, s2, vt2 = t4a.randomized_svd(b, 12, oversample=10, power_iters=2, seed=5)
+    assert np.array_equal(s, s2) and np.array_equal(u, u2)
+    with pytest.raises(t4a.T4aError):
+        t4a.randomized_svd(a, 0)
+    with pytest.raises(t4a.T4aError):
+        t4a.randomized_svd(a, 181)
