@@ -1119,7 +1119,81 @@ void Engine::lu_permuted_factors(const LuciResult& r, bool left_orth)
     T4A_HIP(hipGetLastError());
 }
 
+// svd_backend: QR-preconditioned one-sided Jacobi (round 5).  For min(M, N) >= 64 the iteration does not run on A but on L = R^T of
+// A' = Q R (A' = A or A^T, the taller orientation): L = U_L S V_L^T gives A' = (Q V_L) S U_L^T.  One-sided Jacobi on the columns of a
+// LOWER triangular factor converges in far fewer sweeps when the spectrum is graded or the matrix is rank deficient — which is what the
+// unfoldings of a tensor train under compression look like (Drmac / Veselic; measured with the cyclic ordering used here on 256 x 128:
+// sigma_i = 2^-i 29 sweeps -> 12, a rank-40 matrix with 10 decades 28 -> 13, Gaussian 11 -> 11) — and every sweep works on n x n
+// instead of m x n.  (Round 4 had tried the iteration on R itself: no gain — it is the TRANSPOSE that helps.)  Costs one Householder QR
+// and one GEMM.  T4A_SVD_NO_PRECOND=1 (diagnostic builds) restores the plain iteration.
 void Engine::svd(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt)
+{
+    if (M <= 0 || N <= 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "svd: empty matrix");
+    static const bool no_precond = diag_env("T4A_SVD_NO_PRECOND") != nullptr;
+    const int kmin = M < N ? M : N;
+    if (no_precond || kmin < 64) {
+        svd_plain(d_a, M, N, d_u, d_s, d_vt);
+        return;
+    }
+    const bool flip = M < N;
+    const int m = flip ? N : M, n = flip ? M : N;
+    {   // (non-finite input: the same error as the plain path, before the QR turns it into something else)
+        d_sflags_.reserve((size_t)n + 4);
+        int* flags = d_sflags_.get();
+        T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, stream_));
+        nonfinite_flag_launch(d_a, (size_t)M * N, flags + 2, stream_);
+        int h[4] = {0, 0, 0, 0};
+        T4A_HIP(hipMemcpyAsync(h, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
+        T4A_HIP(hipStreamSynchronize(stream_));
+        if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
+    }
+    const double* Ap = d_a;
+    if (flip) {
+        d_pa_.reserve((size_t)m * n);
+        transpose_launch(d_a, M, N, M, d_pa_.get(), N, stream_);
+        Ap = d_pa_.get();
+    }
+    d_pq_.reserve((size_t)m * n);
+    d_pr_.reserve((size_t)n * n);
+    d_pl_.reserve((size_t)n * n);
+    d_pul_.reserve((size_t)n * n);
+    d_pvl_.reserve((size_t)n * n);
+    qr(Ap, m, n, d_pq_.get(), d_pr_.get());                              // A' = Q R, Q m x n, R n x n
+    transpose_launch(d_pr_.get(), n, n, n, d_pl_.get(), n, stream_);     // L = R^T
+    svd_plain(d_pl_.get(), n, n, d_pul_.get(), d_s, d_pvl_.get());       // L = U_L S Vt_L
+    // A' = Q L^T = (Q Vt_L^T) S U_L^T
+    auto gemm_nt = [&](const double* A_, int lda, const double* B_, int ldb, double* C_, int ldc, int M_, int N_, int K_) {
+        GemmDesc g{};
+        g.m = M_;
+        g.n = N_;
+        g.k = K_;
+        g.A = A_;
+        g.lda = lda;
+        g.transA = 0;
+        g.B = B_;
+        g.ldb = ldb;
+        g.transB = 1;
+        g.C = C_;
+        g.ldc = ldc;
+        g.alpha = 1.0;
+        g.beta = 0.0;
+        g.batch = 1;
+        gemm_launch(g, stream_);
+    };
+    if (!flip) {
+        gemm_nt(d_pq_.get(), m, d_pvl_.get(), n, d_u, m, m, n, n);       // U = Q Vt_L^T (M x k)
+        transpose_launch(d_pul_.get(), n, n, n, d_vt, n, stream_);       // Vt = U_L^T (k x N)
+    } else {
+        // A = A'^T = U_L S (Q Vt_L^T)^T: U = U_L (M x k, M = n), Vt = (Q Vt_L^T)^T (k x N, N = m)
+        T4A_HIP(hipMemcpyAsync(d_u, d_pul_.get(), sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, stream_));
+        d_pu_.reserve((size_t)m * n);
+        gemm_nt(d_pq_.get(), m, d_pvl_.get(), n, d_pu_.get(), m, m, n, n);
+        transpose_launch(d_pu_.get(), m, n, m, d_vt, n, stream_);
+    }
+    T4A_HIP(hipGetLastError());
+}
+
+void Engine::svd_plain(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt)
 {
     if (M <= 0 || N <= 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "svd: empty matrix");
     const bool flip = M < N;

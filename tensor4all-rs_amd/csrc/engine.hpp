@@ -123,6 +123,7 @@ public:
     // thin SVD (svd_backend, tensorbackend/src/backend.rs:709): d_u M x k, d_s k, d_vt k x N with k = min(M, N);
     // one-sided Jacobi.  Throws INVALID_ARGUMENT for non-finite input.
     void svd(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt);
+    void svd_plain(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt); // the Jacobi iteration on the matrix as it is
     // thin QR (qr_backend, backend.rs:742): d_q M x k, d_r k x N; Householder.
     void qr(const double* d_a, int M, int N, double* d_q, double* d_r);
 
@@ -207,6 +208,8 @@ private:
 #endif
     // SVD / QR workspaces
     DevBuf<double> d_sw_, d_sv_, d_su_, d_svs_, d_ssig_;
+    DevBuf<double> d_pa_, d_pq_, d_pr_, d_pl_, d_pul_, d_pvl_, d_pu_; // QR-preconditioned SVD: A', Q, R, L = R^T, factors of L, U'
+    size_t svd_sweeps_last_ = 0;
     DevBuf<int> d_sflags_;
 };
 

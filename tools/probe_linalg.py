@@ -30,3 +30,21 @@ for (m, n) in [(512, 256), (300, 200), (64, 64)]:
             err = float(np.abs((u * s) @ vt - a).max())
         print(f"{what} {m} x {n}: call {min(ts) * 1e6:9.1f} us (host round trip incl. upload / download), ~{flops / min(ts) / 1e9:7.1f} GF/s, max residual {err:.2e}",
               flush=True)
+
+# graded / rank-deficient inputs (what the unfoldings of a tensor train under compression look like): singular values 2^-i, a rank-40
+# matrix over ten decades, the transposed (wide) orientation
+for label, make in [("sigma_i = 2^-i", lambda m, n: (np.linalg.qr(rng.standard_normal((m, n)))[0] * 2.0 ** -np.arange(n)) @ np.linalg.qr(rng.standard_normal((n, n)))[0]),
+                    ("rank 40, ten decades", lambda m, n: rng.standard_normal((m, 40)) @ np.diag(np.logspace(0, -10, 40)) @ rng.standard_normal((40, n)))]:
+    for (m, n) in [(512, 256), (256, 512)]:
+        a = make(max(m, n), min(m, n))
+        if m < n:
+            a = a.T.copy()
+        t4a_amd.svd_backend(a)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            u, s, vt = t4a_amd.svd_backend(a)
+            ts.append(time.perf_counter() - t0)
+        sref = np.linalg.svd(a, compute_uv=False)
+        print(f"svd {m} x {n} [{label}]: call {min(ts) * 1e6:9.1f} us, max |s - s_numpy| / s_max {np.abs(s - sref).max() / sref[0]:.2e}, "
+              f"max residual {float(np.abs((u * s) @ vt - a).max()):.2e}, |U^T U - I| {float(np.abs(u.T @ u - np.eye(u.shape[1])).max()):.2e}", flush=True)
