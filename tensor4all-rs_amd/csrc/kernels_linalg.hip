@@ -336,20 +336,34 @@ __global__ void __launch_bounds__(256) svd_sort_scatter_kernel(const double* __r
     __shared__ double red[4];
     const int j = blockIdx.x;
     const double sj = sig[j];
-    double cnt = 0.0;
+    double cnt = 0.0, smax = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double si = sig[i];
         if (si > sj || (si == sj && i < j)) cnt += 1.0;
+        smax = si > smax ? si : smax;
     }
     const int rank = (int)block_sum(cnt, red);
+    {
+        __shared__ double smax_s;
+        if (threadIdx.x == 0) smax_s = 0.0;
+        __syncthreads();
+        // (non-negative doubles order like their bit patterns)
+        atomicMax(reinterpret_cast<unsigned long long*>(&smax_s), (unsigned long long)__double_as_longlong(smax));
+        __syncthreads();
+        smax = smax_s;
+    }
+    // a column whose squared norm underflows (|w| <= sqrt(DBL_MIN)) cannot be orthogonalised by the rotations above — their test and
+    // their angles are built from products of squared norms — and its direction is rounding residue (an exactly zero column of A comes
+    // out of the QR preconditioner with entries around 1e-153): it counts as a zero column, its singular value is reported as it is
+    const bool live = sj > 1.4916681462400413e-154 && sj > smax * 1e-100; // (... or lies a hundred decades under the largest one)
     if (threadIdx.x == 0) {
         S[rank] = sj;
-        dead[rank] = sj > 0.0 ? 0 : 1;
-        if (!(sj > 0.0)) atomicAdd(n_dead, 1);
+        dead[rank] = live ? 0 : 1;
+        if (!live) atomicAdd(n_dead, 1);
     }
     const double* w = W + (size_t)m * j;
     double* u = U + (size_t)m * rank;
-    for (int r = threadIdx.x; r < m; r += blockDim.x) u[r] = sj > 0.0 ? w[r] / sj : 0.0;
+    for (int r = threadIdx.x; r < m; r += blockDim.x) u[r] = live ? w[r] / sj : 0.0;
     const double* v = V + (size_t)n * j;
     double* vs = Vs + (size_t)n * rank;
     for (int r = threadIdx.x; r < n; r += blockDim.x) vs[r] = v[r];

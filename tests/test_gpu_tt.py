@@ -481,3 +481,28 @@ def test_randomized_svd_against_the_dense_svd(t4a):
         t4a.randomized_svd(a, 0)
     with pytest.raises(t4a.T4aError):
         t4a.randomized_svd(a, 181)
+
+
+@pytest.mark.parametrize("shape", [(200, 100), (100, 200), (128, 128)])
+def test_preconditioned_svd_on_rank_deficient_and_graded_inputs(t4a, shape):
+    """Engine::svd runs the Jacobi iteration on L = R^T of a Householder QR from 64 columns on (round 5): exact rank deficiency (zero
+    columns / rows, repeated columns), a graded spectrum over twelve decades, both orientations — singular values against LAPACK,
+    orthonormal factors, reconstruction."""
+    rng = np.random.default_rng(31)
+    m, n = shape
+    k = min(m, n)
+    low = rng.standard_normal((m, 30)) @ rng.standard_normal((30, n))
+    low[:, 3] = 0.0
+    low[5, :] = 0.0
+    low[:, 7] = low[:, 8]
+    q1, _ = np.linalg.qr(rng.standard_normal((m, k)))
+    q2, _ = np.linalg.qr(rng.standard_normal((n, k)))
+    graded = (q1 * np.logspace(0, -12, k)) @ q2.T
+    for a in (low, graded):
+        u, s, vt = t4a.svd_backend(a)
+        sref = np.linalg.svd(a, compute_uv=False)
+        assert u.shape == (m, k) and vt.shape == (k, n)
+        assert np.abs(s - sref).max() <= 1e-12 * sref[0]
+        assert np.all(np.diff(s) <= 1e-13 * s[0])
+        assert np.abs((u * s) @ vt - a).max() <= 1e-12 * sref[0] * k
+        assert np.abs(u.T @ u - np.eye(k)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(k)).max() < 1e-10
