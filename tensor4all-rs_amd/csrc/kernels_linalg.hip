@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, int m, d
 // wavefront shuffles, one barrier per local round.  The rotations of the block are accumulated in a 2w x 2w matrix Q (LDS) and
 // applied to the rows of V in one pass at the end (V never enters the LDS).
 // LDS: double cols[2 w][m], double Q[2 w][2 w], int idx[2 w].
-template <int BW>
+template <int BW, int JB_RMAX = 16>
 __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_kernel(double* __restrict__ W, int m, double* __restrict__ V, int n, int nbp, int round,
                                                                                      int* rotated)
 {
@@ -248,8 +248,9 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
                 double* const ca = cols + (size_t)a * m;
                 double* const cb = cols + (size_t)b * m;
                 // the two columns stay in registers between the dot products and the rotation (one LDS read and, when the
-                // pair rotates, one write per element and local round); columns longer than 64 * JB_RMAX rows re-read
-                constexpr int JB_RMAX = 16;
+                // pair rotates, one write per element and local round); columns longer than 64 * JB_RMAX rows re-read.  JB_RMAX is
+                // sized for the column length (round 5: with a fixed 16 a 256-row column — every matrix behind the QR preconditioner
+                // at chi = 256 — executed four times the loads, selects and multiply-adds it needed)
                 double xr[JB_RMAX], yr[JB_RMAX];
                 double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
@@ -663,9 +664,21 @@ bool jacobi_block_sweep_launch(double* W, int m, double* V, int n, int* d_rotate
         for (int round = 0; round < nbp - 1; ++round)
             hipLaunchKernelGGL(kern, dim3(nbp / 2), dim3(T), lds, stream, W, m, V, n, nbp, round, d_rotated);
     };
+    static std::once_flag attr_once2;
+    std::call_once(attr_once2, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    });
     switch (w) {
     case 16: go(&jacobi_block_kernel<16>); break;
-    case 8: go(&jacobi_block_kernel<8>); break;
+    case 8:
+        if (m <= 128) go(&jacobi_block_kernel<8, 2>);
+        else if (m <= 256) go(&jacobi_block_kernel<8, 4>);
+        else if (m <= 512) go(&jacobi_block_kernel<8, 8>);
+        else go(&jacobi_block_kernel<8>);
+        break;
     case 4: go(&jacobi_block_kernel<4>); break;
     case 2: go(&jacobi_block_kernel<2>); break;
     default: go(&jacobi_block_kernel<1>); break;

@@ -1,5 +1,7 @@
 #!/bin/bash
 O=gpurun_out/svd; mkdir -p $O
-timeout 600 python tools/probe_linalg.py 2>&1 | tee $O/linalg_probe.txt
-timeout 900 python -m pytest tests/test_gpu_tt.py tests/test_gpu_tensor.py tests/test_gpu_dense.py -q -x 2>&1 | tail -5
-timeout 900 python tools/bench_components.py --only tt,dense 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('tt','dense') if k in d})[:2500])"
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $O/stats -o x --output-format csv -- python3 tools/probe_linalg.py > $O/stats.log 2>&1 </dev/null
+head -12 $O/stats/x_kernel_stats.csv | cut -c1-200
+python3 tools/trace_idle.py $O/stats/x_kernel_trace.csv 10 2>&1 | head -12
+rm -rf $O/stats
