@@ -225,9 +225,35 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
     }
     for (int e = tid; e < w2 * w2; e += T) Q[e] = (e / w2 == e % w2) ? 1.0 : 0.0;
     __syncthreads();
-    for (int c = wave; c < w2; c += (T >> 6)) {
-        const int gc = idx[c];
-        for (int r = lane; r < m; r += 64) cols[(size_t)c * m + r] = gc >= 0 ? W[(size_t)m * gc + r] : 0.0;
+    {
+        // the block's columns into the LDS: every wave requests all elements of its columns that fit the register window BEFORE it stores
+        // the first one (as a load -> store loop the compiler waits for every element in turn: 2 w m / T dependent memory round trips
+        // at the head of every block round)
+        constexpr int NWV = (BW * 64 < 256 ? 256 : BW * 64) / 64, CPW = (w2 + NWV - 1) / NWV;
+        double tmp[CPW][JB_RMAX];
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            const int c = wave + NWV * k;
+            const int gc = c < w2 ? idx[c] : -1;
+#pragma unroll
+            for (int q = 0; q < JB_RMAX; ++q) {
+                const int r = lane + 64 * q;
+                tmp[k][q] = (gc >= 0 && r < m) ? W[(size_t)m * gc + r] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            const int c = wave + NWV * k;
+            if (c < w2) {
+#pragma unroll
+                for (int q = 0; q < JB_RMAX; ++q) {
+                    const int r = lane + 64 * q;
+                    if (r < m) cols[(size_t)c * m + r] = tmp[k][q];
+                }
+                const int gc = idx[c];
+                for (int r = lane + 64 * JB_RMAX; r < m; r += 64) cols[(size_t)c * m + r] = gc >= 0 ? W[(size_t)m * gc + r] : 0.0;
+            }
+        }
     }
     __syncthreads();
     bool any = false;
