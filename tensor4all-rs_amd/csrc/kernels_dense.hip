@@ -817,15 +817,31 @@ __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problem
     auto gcol = [&](int c) -> double* {
         return in_a ? pr.A + (size_t)(c0 + c) * pr.lda + kb : pr.B + (size_t)(c0 + c) * pr.ldb + kb;
     };
-    for (int c = 0; c < tc; ++c) {
-        double* g = gcol(c);
-        for (int i = tid; i < m; i += T) Tt[(size_t)c * ldp + i] = g[i];
-    }
-    if (!left)
-        for (int e = tid; e < m * w; e += T) {
-            const int i = e % m, c = e / m;
-            L[(size_t)c * ldp + i] = pr.A[(size_t)(kb + c) * pr.lda + kb + i];
+    {
+        // tile and panel into the LDS: a thread requests its row of ALL columns before it stores the first value (round 5: as
+        // load -> store loops these were up to 64 dependent memory round trips at the head of every work item)
+        constexpr int UPD_MAXC = 32; // nb <= 32
+        const double* const tbase = in_a ? pr.A + (size_t)c0 * pr.lda + kb : pr.B + (size_t)c0 * pr.ldb + kb;
+        const size_t tstride = in_a ? (size_t)pr.lda : (size_t)pr.ldb;
+        const double* const lbase = pr.A + (size_t)kb * pr.lda + kb;
+        for (int i = tid; i < m; i += T) {
+            double tv[UPD_MAXC], lv[UPD_MAXC];
+#pragma unroll
+            for (int c = 0; c < UPD_MAXC; ++c) tv[c] = c < tc ? tbase[(size_t)c * tstride + i] : 0.0;
+            if (!left) {
+#pragma unroll
+                for (int c = 0; c < UPD_MAXC; ++c) lv[c] = c < w ? lbase[(size_t)c * pr.lda + i] : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < UPD_MAXC; ++c)
+                if (c < tc) Tt[(size_t)c * ldp + i] = tv[c];
+            if (!left) {
+#pragma unroll
+                for (int c = 0; c < UPD_MAXC; ++c)
+                    if (c < w) L[(size_t)c * ldp + i] = lv[c];
+            }
         }
+    }
     __syncthreads();
     // (a) the panel's row swaps, in order
     if (tid < tc) {
