@@ -613,6 +613,46 @@ struct PanelShared {
 
 // one column of the panel; J is a template parameter so that every register index is a compile-time constant (the panel must
 // stay in registers: as a run-time loop the compiler put it into scratch memory)
+// wave reductions through DPP (row reductions + two row broadcasts; lane 63 holds the result): a 64-lane maximum is six dependent
+// v_max / v_min instead of six ds_bpermute round trips per operand (__shfl_xor).  Lanes without a source keep their own value.
+template <int CTRL> __device__ __forceinline__ int pnl_dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ double pnl_dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = pnl_dpp_i32<CTRL>((int)(b & 0xFFFFFFFFll));
+    const int hi = pnl_dpp_i32<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double pnl_wave_max_f64(double x) // no NaN among the operands
+{
+    x = fmax(x, pnl_dpp_f64<0xB1>(x));  // quad_perm [1,0,3,2]
+    x = fmax(x, pnl_dpp_f64<0x4E>(x));  // quad_perm [2,3,0,1]
+    x = fmax(x, pnl_dpp_f64<0x141>(x)); // row_half_mirror
+    x = fmax(x, pnl_dpp_f64<0x140>(x)); // row_mirror
+    x = fmax(x, pnl_dpp_f64<0x142>(x)); // row_bcast15
+    x = fmax(x, pnl_dpp_f64<0x143>(x)); // row_bcast31
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ int pnl_wave_min_i32(int x)
+{
+    int o;
+    o = pnl_dpp_i32<0xB1>(x);
+    x = o < x ? o : x;
+    o = pnl_dpp_i32<0x4E>(x);
+    x = o < x ? o : x;
+    o = pnl_dpp_i32<0x141>(x);
+    x = o < x ? o : x;
+    o = pnl_dpp_i32<0x140>(x);
+    x = o < x ? o : x;
+    o = pnl_dpp_i32<0x142>(x);
+    x = o < x ? o : x;
+    o = pnl_dpp_i32<0x143>(x);
+    x = o < x ? o : x;
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 template <int NB, int RP, int J>
 __device__ __forceinline__ void lu_panel_column(double (&a)[RP][NB], const PanelShared& sh, const LuProblem& pr, int kb, int m, int w, int tid,
                                                 int& first_bad)
@@ -636,14 +676,12 @@ __device__ __forceinline__ void lu_panel_column(double (&a)[RP][NB], const Panel
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(bv, off);
-        const int oi = __shfl_xor(bi, off);
-        if (ov > bv || (ov == bv && oi < bi)) {
-            bv = ov;
-            bi = oi;
-        }
+    {
+        // (same winner as the shuffle tournament it replaces: the largest |a|, the smallest row among equals)
+        const double wv = pnl_wave_max_f64(bv);
+        const int wi = pnl_wave_min_i32(bv == wv ? bi : 0x7fffffff);
+        bv = wv;
+        bi = wi;
     }
     if (lane == 0) {
         sh.red_v[par * 4 + wave] = bv;
