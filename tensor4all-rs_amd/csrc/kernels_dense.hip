@@ -862,21 +862,22 @@ __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problem
         const double* const tbase = in_a ? pr.A + (size_t)c0 * pr.lda + kb : pr.B + (size_t)c0 * pr.ldb + kb;
         const size_t tstride = in_a ? (size_t)pr.lda : (size_t)pr.ldb;
         const double* const lbase = pr.A + (size_t)kb * pr.lda + kb;
+        // (tile first, then panel: both at once doubled the kernel's registers — 169 — and a workgroup of it no longer fitted beside the
+        // pass-through workgroups of the rrLU launches: the fill beside the chain went from 3 to 7 ms of device time per sweep)
         for (int i = tid; i < m; i += T) {
-            double tv[UPD_MAXC], lv[UPD_MAXC];
+            double tv[UPD_MAXC];
 #pragma unroll
             for (int c = 0; c < UPD_MAXC; ++c) tv[c] = c < tc ? tbase[(size_t)c * tstride + i] : 0.0;
-            if (!left) {
-#pragma unroll
-                for (int c = 0; c < UPD_MAXC; ++c) lv[c] = c < w ? lbase[(size_t)c * pr.lda + i] : 0.0;
-            }
 #pragma unroll
             for (int c = 0; c < UPD_MAXC; ++c)
                 if (c < tc) Tt[(size_t)c * ldp + i] = tv[c];
+            asm volatile("" ::: "memory");
             if (!left) {
 #pragma unroll
+                for (int c = 0; c < UPD_MAXC; ++c) tv[c] = c < w ? lbase[(size_t)c * pr.lda + i] : 0.0;
+#pragma unroll
                 for (int c = 0; c < UPD_MAXC; ++c)
-                    if (c < w) L[(size_t)c * ldp + i] = lv[c];
+                    if (c < w) L[(size_t)c * ldp + i] = tv[c];
             }
         }
     }
