@@ -855,32 +855,52 @@ __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problem
     auto gcol = [&](int c) -> double* {
         return in_a ? pr.A + (size_t)(c0 + c) * pr.lda + kb : pr.B + (size_t)(c0 + c) * pr.ldb + kb;
     };
+#if defined(T4A_UPD_OLD_LOADS)
+    for (int c = 0; c < tc; ++c) {
+        double* g = gcol(c);
+        for (int i = tid; i < m; i += T) Tt[(size_t)c * ldp + i] = g[i];
+    }
+    if (!left)
+        for (int e = tid; e < m * w; e += T) {
+            const int i = e % m, c = e / m;
+            L[(size_t)c * ldp + i] = pr.A[(size_t)(kb + c) * pr.lda + kb + i];
+        }
+#else
     {
         // tile and panel into the LDS: a thread requests its row of ALL columns before it stores the first value (round 5: as
         // load -> store loops these were up to 64 dependent memory round trips at the head of every work item)
-        constexpr int UPD_MAXC = 32; // nb <= 32
         const double* const tbase = in_a ? pr.A + (size_t)c0 * pr.lda + kb : pr.B + (size_t)c0 * pr.ldb + kb;
         const size_t tstride = in_a ? (size_t)pr.lda : (size_t)pr.ldb;
         const double* const lbase = pr.A + (size_t)kb * pr.lda + kb;
-        // (tile first, then panel: both at once doubled the kernel's registers — 169 — and a workgroup of it no longer fitted beside the
-        // pass-through workgroups of the rrLU launches: the fill beside the chain went from 3 to 7 ms of device time per sweep)
+        // (four columns at a time, tile first, then panel.  The kernel must stay inside 96 vector registers: beside a bond chain the
+        // workgroups the dispatcher places on the chain's XCD only have to RETURN (avoid_xcc), but they get their slot at once only if
+        // a wave of this kernel fits next to the rrLU workgroup's two waves per SIMD (2 x 206 of 512 registers).  With all 32 columns of
+        // tile and panel in flight (169 registers, then 107) every launch waited for the running rrLU launch to end: 43 -> 430 us per
+        // launch, the fill beside the chain 2.2 -> 6.2 ms of device time per sweep.)
+        constexpr int UPD_BATCH = 4;
         for (int i = tid; i < m; i += T) {
-            double tv[UPD_MAXC];
+            double tv[UPD_BATCH];
+#pragma unroll 1
+            for (int cb = 0; cb < tc; cb += UPD_BATCH) {
 #pragma unroll
-            for (int c = 0; c < UPD_MAXC; ++c) tv[c] = c < tc ? tbase[(size_t)c * tstride + i] : 0.0;
+                for (int c = 0; c < UPD_BATCH; ++c) tv[c] = (cb + c) < tc ? tbase[(size_t)(cb + c) * tstride + i] : 0.0;
 #pragma unroll
-            for (int c = 0; c < UPD_MAXC; ++c)
-                if (c < tc) Tt[(size_t)c * ldp + i] = tv[c];
-            asm volatile("" ::: "memory");
+                for (int c = 0; c < UPD_BATCH; ++c)
+                    if ((cb + c) < tc) Tt[(size_t)(cb + c) * ldp + i] = tv[c];
+            }
             if (!left) {
+#pragma unroll 1
+                for (int cb = 0; cb < w; cb += UPD_BATCH) {
 #pragma unroll
-                for (int c = 0; c < UPD_MAXC; ++c) tv[c] = c < w ? lbase[(size_t)c * pr.lda + i] : 0.0;
+                    for (int c = 0; c < UPD_BATCH; ++c) tv[c] = (cb + c) < w ? lbase[(size_t)(cb + c) * pr.lda + i] : 0.0;
 #pragma unroll
-                for (int c = 0; c < UPD_MAXC; ++c)
-                    if (c < w) L[(size_t)c * ldp + i] = tv[c];
+                    for (int c = 0; c < UPD_BATCH; ++c)
+                        if ((cb + c) < w) L[(size_t)(cb + c) * ldp + i] = tv[c];
+                }
             }
         }
     }
+#endif
     __syncthreads();
     // (a) the panel's row swaps, in order
     if (tid < tc) {
