@@ -17,13 +17,6 @@ namespace t4a {
 
 namespace {
 
-__device__ inline double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return __shfl(v, 0, 64);
-}
-
 // Wave sum through DPP row reductions (no LDS crossbar traffic): every lane of the wave ends with the total.
 template <int CTRL> __device__ inline double dpp_mov_f64(double v)
 {
@@ -48,6 +41,10 @@ __device__ inline double wave_sum_dpp(double v)
     }
     return t;
 }
+
+// (round 5: the shuffle form — six __shfl_down = twelve ds_bpermute round trips + a broadcast — is gone: block_sum sits in front of
+// every Householder column of the QR panel and of every rank count of the SVD's sort)
+__device__ inline double wave_sum(double v) { return wave_sum_dpp(v); }
 
 // Sum over the whole workgroup, identical on every thread.  `red` holds one slot per wave.
 __device__ inline double block_sum(double v, double* red)
@@ -553,8 +550,15 @@ __global__ void __launch_bounds__(QR_T) qr_panel_lds_kernel(double* A, int m, in
     double* const red = zs + QR_NB;
     for (int e = tid; e < QR_NB * QR_NB; e += QR_T) T[e] = 0.0;
     for (int c = wave; c < w; c += NWV) {
+        // (all rows of a column requested before the first one is stored: up to QR_LDS_MAX_ROWS / 64 = 9 per lane)
         const double* src = A + (size_t)m * (j0 + c) + j0;
-        for (int r = lane; r < mp; r += 64) P[(size_t)c * ld + r] = src[r];
+        double tmp[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) tmp[q] = (lane + 64 * q) < mp ? src[lane + 64 * q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+            if ((lane + 64 * q) < mp) P[(size_t)c * ld + lane + 64 * q] = tmp[q];
+        for (int r = lane + 64 * 9; r < mp; r += 64) P[(size_t)c * ld + r] = src[r];
     }
     __syncthreads();
     for (int jj = 0; jj < w; ++jj) {
