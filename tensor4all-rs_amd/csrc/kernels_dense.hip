@@ -855,17 +855,6 @@ __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problem
     auto gcol = [&](int c) -> double* {
         return in_a ? pr.A + (size_t)(c0 + c) * pr.lda + kb : pr.B + (size_t)(c0 + c) * pr.ldb + kb;
     };
-#if defined(T4A_UPD_OLD_LOADS)
-    for (int c = 0; c < tc; ++c) {
-        double* g = gcol(c);
-        for (int i = tid; i < m; i += T) Tt[(size_t)c * ldp + i] = g[i];
-    }
-    if (!left)
-        for (int e = tid; e < m * w; e += T) {
-            const int i = e % m, c = e / m;
-            L[(size_t)c * ldp + i] = pr.A[(size_t)(kb + c) * pr.lda + kb + i];
-        }
-#else
     {
         // tile and panel into the LDS: a thread requests its row of ALL columns before it stores the first value (round 5: as
         // load -> store loops these were up to 64 dependent memory round trips at the head of every work item)
@@ -900,7 +889,6 @@ __global__ void __launch_bounds__(256) lu_update_kernel(const LuProblem* problem
             }
         }
     }
-#endif
     __syncthreads();
     // (a) the panel's row swaps, in order
     if (tid < tc) {
