@@ -31,11 +31,13 @@ __global__ void pingpong(unsigned long long* flag_a, unsigned long long* flag_b,
     for (int i = 1; i <= iters; ++i) {
         if (w == wa) {
             if (VARIANT == 0) __hip_atomic_store(flag_a, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (VARIANT == 2) (void)__hip_atomic_exchange(flag_a, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else { *((volatile unsigned long long*)flag_a) = (unsigned long long)i; }
             { unsigned sp = 0; while (__hip_atomic_load(flag_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)i) { if (++sp > 2000000u) { cycles[1] = 1; return; } } }
         } else {
             { unsigned sp = 0; while (__hip_atomic_load(flag_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)i) { if (++sp > 2000000u) { cycles[1] = 1; return; } } }
             if (VARIANT == 0) __hip_atomic_store(flag_b, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (VARIANT == 2) (void)__hip_atomic_exchange(flag_b, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else { *((volatile unsigned long long*)flag_b) = (unsigned long long)i; }
         }
     }
@@ -102,7 +104,9 @@ int main()
         hipMemset(d_f, 0, 1 << 20); hipMemset(d_c, 0, 64);
         CK(hipFuncSetAttribute((const void*)pingpong<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         CK(hipFuncSetAttribute((const void*)pingpong<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        CK(hipFuncSetAttribute((const void*)pingpong<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         if (variant == 0) hipLaunchKernelGGL(pingpong<0>, dim3(G), dim3(64), LDS, 0, d_f, d_f + 1024, 0, wb, iters, d_c);
+        else if (variant == 2) hipLaunchKernelGGL(pingpong<2>, dim3(G), dim3(64), LDS, 0, d_f, d_f + 1024, 0, wb, iters, d_c);
         else hipLaunchKernelGGL(pingpong<1>, dim3(G), dim3(64), LDS, 0, d_f, d_f + 1024, 0, wb, iters, d_c);
         unsigned long long c2[2] = {0,0}; CK(hipMemcpy(c2, d_c, 16, hipMemcpyDeviceToHost)); unsigned long long c = c2[0]; if (c2[1]) printf("  [TIMEOUT in kernel] ");
         printf("%-44s round trip %8.1f cycles  (one hop ~%.1f)\n", name, (double)c / iters, (double)c / iters / 2);
@@ -110,7 +114,9 @@ int main()
     };
     run_pp(0, same, "pingpong same-XCD  sc1 store / sc1 load:");
     run_pp(1, same, "pingpong same-XCD  plain store / sc1 load:");
+    run_pp(2, same, "pingpong same-XCD  atomic xchg / sc1 load:");
     run_pp(0, cross, "pingpong cross-XCD sc1 store / sc1 load:");
+    run_pp(2, cross, "pingpong cross-XCD atomic xchg / sc1 load:");
     // broadcast+gather among the blocks of block 0's XCD (variant 1) and among 64 blocks spread over all XCDs (variant 0)
     std::vector<int> member(G, -1); int n = 0;
     for (int i = 0; i < G; ++i) if (x[i] == x[0]) member[i] = n++;
