@@ -30,6 +30,7 @@ timeout 300 python3 tools/probe_cfg5_group.py 8 > $O/cfg5_group_probe.txt 2>&1
 timeout 300 python3 tools/probe_cfg5_threads.py 8 > $O/cfg5_threads_probe.txt 2>&1
 timeout 300 python3 tools/probe_cfg5_scratch.py 3 > $O/cfg5_scratch_probe.txt 2>&1
 timeout 300 python3 tools/probe_linalg.py > $O/linalg_probe.txt 2>&1
+(timeout 120 ./tools/lat_bench; timeout 120 ./tools/hop_bench | grep pingpong) > $O/latencies.txt 2>&1
 timeout 300 python3 tools/probe_fill.py > $O/fill_probe.txt 2>&1
 prof --kernel-trace --stats -d $O/fillstats -o x --output-format csv -- python3 tools/probe_fill.py 30 > $O/fillstats.log 2>&1
 grep "lu_panel\|lu_update\|lu_solve\|trsm\|pi_eval\|pack_fill" $O/fillstats/x_kernel_stats.csv > $O/fill_kernel_stats.csv
