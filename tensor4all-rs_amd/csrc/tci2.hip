@@ -2,6 +2,8 @@
 // Mirrors crates/tensor4all-tensorci/src/tensorci2.rs function by function (line references inline).
 #include "tci2.hpp"
 
+#include <thread>
+
 #include <exception>
 
 #include <algorithm>
@@ -437,28 +439,45 @@ void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
         // host batch callback: points in row-major order of (ia, ib) — `ia` outer, `ib` inner — exactly the
         // order the reference hands to batched_f (tensorci2.rs:1862-1869)
         const size_t npts = na * nb;
-        std::vector<uint32_t> idx(pi_shard.active() ? 0 : npts * n_);
-        for (size_t ia = 0; ia < na && !pi_shard.active(); ++ia)
-            for (size_t ib = 0; ib < nb; ++ib) {
-                uint32_t* dst = idx.data() + (ia * nb + ib) * n_;
-                std::memcpy(dst + a0, a.at(ia), a.width * sizeof(uint32_t));
-                std::memcpy(dst + b0, b.at(ib), b.width * sizeof(uint32_t));
-            }
-        std::vector<double> vals(npts);
+        cb_vals_.reserve(npts); // (pinned, grow-only: the previous upload out of it was synchronised below)
+        double* const vals = cb_vals_.get();
         if (pi_shard.active()) {
             // column blocks over the ranks of the process group + one all-gather (pishard.hpp)
-            idx.clear();
-            idx.shrink_to_fit();
-            pi_shard_evaluate(pi_shard, cb_, cb_ctx_, n_, a.d.data(), a.width, a0, na, b.d.data(), b.width, b0, nb, vals.data());
+            pi_shard_evaluate(pi_shard, cb_, cb_ctx_, n_, a.d.data(), a.width, a0, na, b.d.data(), b.width, b0, nb, vals);
         } else {
-            const int64_t got = cb_(cb_ctx_, idx.data(), n_, npts, vals.data());
+            // the index buffer of the callback: grow-only and filled by a few host threads (round 5: measured on the native callback of
+            // tools/bench_components.py — the backend's share of a cfg3 sweep through a callback was 0.27 s, most of it this buffer)
+            if (cb_idx_cap_ < npts * n_) {
+                cb_idx_cap_ = npts * n_ + npts * n_ / 4;
+                cb_idx_.reset(new uint32_t[cb_idx_cap_]);
+            }
+            uint32_t* const idx = cb_idx_.get();
+            auto fill_rows = [&](size_t ia0, size_t ia1) {
+                for (size_t ia = ia0; ia < ia1; ++ia)
+                    for (size_t ib = 0; ib < nb; ++ib) {
+                        uint32_t* dst = idx + (ia * nb + ib) * n_;
+                        std::memcpy(dst + a0, a.at(ia), a.width * sizeof(uint32_t));
+                        std::memcpy(dst + b0, b.at(ib), b.width * sizeof(uint32_t));
+                    }
+            };
+            const unsigned hw = std::thread::hardware_concurrency();
+            const size_t nthr = (npts * n_ < ((size_t)1 << 21) || hw < 2) ? 1 : std::min<size_t>(std::min<size_t>(8, hw), na);
+            if (nthr <= 1) {
+                fill_rows(0, na);
+            } else {
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < nthr; ++t) pool.emplace_back(fill_rows, na * t / nthr, na * (t + 1) / nthr);
+                fill_rows(0, na / nthr);
+                for (auto& th : pool) th.join();
+            }
+            const int64_t got = cb_(cb_ctx_, idx, n_, npts, vals);
             if (got < 0 || (size_t)got != npts)
                 throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " +
                                                         std::to_string(npts) + " requested entries");
         }
         d_vals_.reserve(npts);
-        T4A_HIP(hipMemcpyAsync(d_vals_.get(), vals.data(), npts * sizeof(double), hipMemcpyHostToDevice, st));
-        T4A_HIP(hipStreamSynchronize(st)); // `vals` is pageable host memory
+        T4A_HIP(hipMemcpyAsync(d_vals_.get(), vals, npts * sizeof(double), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipStreamSynchronize(st)); // (the pinned buffer is reused by the next matrix)
         // vals is (na x nb) row-major == (nb x na) column-major; transpose into the column-major na x nb output
         transpose_launch(d_vals_.get(), (int)nb, (int)na, (int)nb, d_out, (int)na, st);
         if (d_maxbits) absmax_launch(d_out, npts, d_maxbits, st);

@@ -348,6 +348,11 @@ private:
     DevBuf<unsigned long long> d_maxbits_;
     DevBuf<uint32_t> d_idx_;
     DevBuf<double> d_vals_;
+    // host-callback path: the index buffer handed to the callback and the values it returns, grow-only (a 700 x 700 candidate matrix of a
+    // 30-site problem is 59 MB of indices: as a fresh std::vector per bond it was zero-filled and page-faulted in every time)
+    std::unique_ptr<uint32_t[]> cb_idx_;
+    size_t cb_idx_cap_ = 0;
+    PinBuf<double> cb_vals_;
     DevBuf<TtCoreDesc> d_coredesc_;
     // fill_site_tensors scratch
     DevBuf<double> d_fillA_, d_fillB_;
