@@ -321,6 +321,40 @@ def components(quick=False, only="", no_oracle=False):
         except Exception as e:  # noqa: BLE001
             out["dense_error"] = repr(e)
 
+    if want("round5"):
+        # the additions of round 5: the edge-local step of TreeACI, the N-ary tensor-network contraction, the randomized SVD
+        try:
+            res = {}
+            rng = np.random.default_rng(9)
+            bonds, rows, cols = ([48, 32, 40], 512, 384) if not args.quick else ([5, 3], 60, 40)
+            rf = [rng.standard_normal((b, rows)) for b in bonds]
+            cf = [rng.standard_normal((b, cols)) for b in bonds]
+            ms, u = best_of(lambda: t4a_amd.treeaci_local_update(rf, cf, t4a_amd.ACI_PRODUCT, max_bond_dim=128, tolerance=1e-10), 3)
+            r = {"device_ms": ms, "rank": int(u.rank), "workload": f"{len(bonds)} inputs, cut bonds {bonds}, {rows} x {cols} candidates, product operator, cap 128"}
+            if ob is not None:
+                r["oracle_ms"], _ = best_of(lambda: ob.treeaci_local_update(rf, cf, ob.ACI_PRODUCT, max_bond_dim=128, tolerance=1e-10), 1)
+            res["treeaci_local_update"] = ratio(r)
+            d = 48 if not args.quick else 8
+            shapes, labels = [(d, d, 6), (d, d), (d, d, 5), (d, d)], [[1, 2, 9], [2, 3], [3, 4, 8], [4, 1]]
+            arrs = [rng.standard_normal(sh) for sh in shapes]
+            handles = [t4a_amd.LabelledTensor(a_, l_) for a_, l_ in zip(arrs, labels)]
+            ms, _ = best_of(lambda: t4a_amd.contract(handles).to_numpy(), 3)
+            r = {"device_ms": ms, "workload": f"ring of four tensors, bond {d}, two dangling legs (6, 5); operands resident on the device"}
+            if ob is not None:
+                r["oracle_ms"], _ = best_of(lambda: ob.tensor_contract_many(arrs, labels), 1)
+            r["note"] = "the oracle sums directly over every summed label (brute force, written for independence from the device path): not a performance comparison"
+            res["contract_network"] = ratio(r)
+            m, n, k = (512, 256, 32) if not args.quick else (64, 48, 8)
+            q1, _ = np.linalg.qr(rng.standard_normal((m, n)))
+            q2, _ = np.linalg.qr(rng.standard_normal((n, n)))
+            a = (q1 * 2.0 ** -np.arange(n)) @ q2.T
+            ms, _ = best_of(lambda: t4a_amd.randomized_svd(a, k, oversample=8, power_iters=1, seed=1), 3)
+            ms_full, _ = best_of(lambda: t4a_amd.svd_backend(a), 2)
+            res["randomized_svd"] = {"device_ms": ms, "device_full_svd_ms": ms_full, "workload": f"{m} x {n}, sigma_i = 2^-i, rank {k} + 8, one power iteration"}
+            out["round5"] = res
+        except Exception as e:  # noqa: BLE001
+            out["round5_error"] = repr(e)
+
     # what loses to one CPU thread (listed in DESIGN.md section 8)
     slower = []
 
