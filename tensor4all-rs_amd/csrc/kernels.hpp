@@ -275,6 +275,23 @@ struct PiJob {
     int M, N, ld, pad_;
 };
 void pi_eval_batched_launch(const FnDevice& fn, const PiJob* d_jobs, int n_jobs, int max_M, int max_N, hipStream_t stream);
+// all cores of one fill_site_tensors in a single launch (one job per site)
+struct PackJob {
+    const double* src;
+    double* core;
+    const int* info; // null for the last site
+    int ld, L, S, R, last, pad_;
+};
+struct LuProblem;
+// fill_site_tensors of a SMALL problem (every pivot matrix at most 32 x 32, at most 64 right-hand sides: BASELINE configs[1], the first
+// iterations of every run) as ONE launch, one workgroup per site: both evaluations into the LDS, the zero-pivot-matrix guard, the
+// partial-pivot LU and the two substitutions (the arithmetic of lu_kernel + trsm_left_kernel, operation for operation) and the packing
+// of the core — where the general path issues evaluation, panel, update, triangular solve and packing as five dependent launches.
+// jobs: n_jobs sites in order, site k owns pis[2 k] (Pi1^T), pis[2 k + 1] (P^T), lups[k], packs[k]; when last_site != 0 the final job is
+// the last site of the train (one evaluation, no solve).
+constexpr int FILL_SMALL_MAX_N = 32, FILL_SMALL_MAX_RHS = 64;
+void fill_small_launch(const FnDevice& fn, const PiJob* d_pis, const LuProblem* d_lups, const PackJob* d_packs, int n_jobs, int last_site,
+                       hipStream_t stream);
 // count u64 from a pinned (device-visible) host buffer to device memory, as a kernel on `stream`
 void stage_copy_launch(const uint64_t* pinned_src, uint64_t* dst, size_t count, hipStream_t stream);
 // max over a dense buffer of bits(sqrt(v*v)) (host-callback path)

@@ -122,6 +122,187 @@ void pi_eval_batched_launch(const FnDevice& fn, const PiJob* d_jobs, int n_jobs,
     hipLaunchKernelGGL(pi_eval_batched_kernel, grid, dim3(256), 0, stream, fn, d_jobs);
 }
 
+namespace {
+
+struct FillSmallArgs {
+    FnDevice fn;
+    const PiJob* pis;
+    const LuProblem* lups;
+    const PackJob* packs;
+    int n_jobs, last_site;
+};
+
+__global__ void __launch_bounds__(256) fill_small_kernel(FillSmallArgs a)
+{
+    __shared__ double As[FILL_SMALL_MAX_N * FILL_SMALL_MAX_N];   // P^T, n x n, column-major (ld = n)
+    __shared__ double Bs[FILL_SMALL_MAX_N * FILL_SMALL_MAX_RHS]; // Pi1^T, n x nrhs (ld = n); last site: Pi1, ni x nj (ld = ni)
+    __shared__ double red_v[4];
+    __shared__ int red_i[4];
+    __shared__ int piv_s, info_s;
+    __shared__ double pivval_s;
+    const int k = blockIdx.x, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    if (k >= a.n_jobs) return;
+    const bool last = a.last_site && k == a.n_jobs - 1;
+    const int K = a.fn.n_acc;
+    // ---- evaluations (pi_eval_batched_kernel: value = f(row accumulators + column accumulators)) ----
+    double pmax = 0.0;
+    for (int q = 0; q < (last ? 1 : 2); ++q) {
+        const PiJob jb = a.pis[2 * k + q];
+        double* const dst = q == 0 ? Bs : As;
+        double av = 0.0;
+        for (int e = tid; e < jb.M * jb.N; e += T) {
+            const int i = e % jb.M, j = e / jb.M;
+            uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+            for (int c = 0; c < K; ++c) acc[c] = jb.rowacc[(size_t)i * K + c] + jb.colacc[(size_t)j * K + c];
+            const double v = t4a_fn_value(a.fn.fid, acc, a.fn.params);
+            dst[(size_t)j * jb.ld + i] = v;
+            const double av1 = sqrt(v * v);
+            if (av1 > av) av = av1;
+        }
+        if (jb.max_abs_bits) { // max sqrt(v * v) over the pivot matrix (zero-pivot-matrix guard, tensorci2.rs:1154-1157)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(av, off);
+                if (o > av) av = o;
+            }
+            if (lane == 0) red_v[wave] = av;
+            __syncthreads();
+            pmax = fmax(fmax(red_v[0], red_v[1]), fmax(red_v[2], red_v[3]));
+            if (tid == 0 && pmax > 0.0) atomicMax(jb.max_abs_bits, (unsigned long long)__double_as_longlong(pmax));
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const PackJob pk = a.packs[k];
+    const size_t total = (size_t)pk.L * pk.S * pk.R;
+    if (last) { // the last site stores Pi1 itself (tensorci2.rs:1109-1128), R == 1
+        for (size_t e = tid; e < total; e += T) {
+            const int l = (int)(e % pk.L), s_ = (int)((e / pk.L) % pk.S), r = (int)(e / ((size_t)pk.L * pk.S));
+            pk.core[e] = Bs[(size_t)r * pk.ld + (l * pk.S + s_)];
+        }
+        return;
+    }
+    // ---- partial-pivot LU of P^T with the row swaps applied to the right-hand sides (lu_kernel, operation for operation) ----
+    const LuProblem pr = a.lups[k];
+    const int n = pr.n, nrhs = pr.nrhs;
+    if (tid == 0) info_s = (pmax < 2.220446049250313e-16) ? -1 : 0; // every |p| < EPS: zero core
+    __syncthreads();
+    if (info_s == 0) {
+        for (int c = 0; c < n; ++c) {
+            double bv = -1.0;
+            int bi = 0x7fffffff;
+            for (int i = c + tid; i < n; i += T) {
+                const double v = fabs(As[(size_t)c * n + i]);
+                if (v > bv || (v == bv && i < bi)) {
+                    bv = v;
+                    bi = i;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                red_v[wave] = bv;
+                red_i[wave] = bi;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double v = red_v[0];
+                int idx = red_i[0];
+                for (int q = 1; q < (T >> 6); ++q)
+                    if (red_v[q] > v || (red_v[q] == v && red_i[q] < idx)) {
+                        v = red_v[q];
+                        idx = red_i[q];
+                    }
+                piv_s = idx;
+                pr.piv[c] = idx;
+                if (!(v > 0.0) && info_s == 0) info_s = c + 1;
+            }
+            __syncthreads();
+            const int p = piv_s;
+            if (p != c && p < n) {
+                for (int q = tid; q < n; q += T) {
+                    const double t = As[(size_t)q * n + c];
+                    As[(size_t)q * n + c] = As[(size_t)q * n + p];
+                    As[(size_t)q * n + p] = t;
+                }
+                for (int q = tid; q < nrhs; q += T) {
+                    const double t = Bs[(size_t)q * n + c];
+                    Bs[(size_t)q * n + c] = Bs[(size_t)q * n + p];
+                    Bs[(size_t)q * n + p] = t;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) pivval_s = As[(size_t)c * n + c];
+            __syncthreads();
+            const double piv = pivval_s;
+            if (piv == 0.0 || piv != piv) continue; // singular column: left as it is (info already set)
+            for (int i = c + 1 + tid; i < n; i += T) As[(size_t)c * n + i] = As[(size_t)c * n + i] / piv;
+            __syncthreads();
+            const int rem = n - c - 1;
+            for (int e = tid; e < rem * rem; e += T) {
+                const int i = c + 1 + e % rem, q = c + 1 + e / rem;
+                const double prod = As[(size_t)c * n + i] * As[(size_t)q * n + c];
+                As[(size_t)q * n + i] = As[(size_t)q * n + i] - prod;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) pr.info[0] = info_s;
+    __syncthreads();
+    if (info_s == 0) { // (the substitutions skip flagged problems: trsm_left_kernel's skip_flag)
+        // unit-lower, then upper: column-oriented substitution, every element sees its updates in the order of trsm_left_kernel
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool lower = pass == 0;
+            for (int step = 0; step < n; ++step) {
+                const int kk = lower ? step : (n - 1 - step);
+                const double* tk = As + (size_t)kk * n;
+                if (!lower) {
+                    const double dkk = tk[kk];
+                    for (int c = tid; c < nrhs; c += T) Bs[(size_t)c * n + kk] = Bs[(size_t)c * n + kk] / dkk;
+                    __syncthreads();
+                }
+                const int lo = lower ? kk + 1 : 0;
+                const int cnt = lower ? (n - 1 - kk) : kk;
+                for (int e = tid; e < cnt * nrhs; e += T) {
+                    const int i = lo + e % cnt, c = e / cnt;
+                    const double prod = tk[i] * Bs[(size_t)c * n + kk];
+                    Bs[(size_t)c * n + i] = Bs[(size_t)c * n + i] - prod;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // ---- core[l, s, r] = X^T[r + ld (l S + s)] (tensorci2.rs:1167-1181); a numerically zero pivot matrix gives a zero core ----
+    const bool zero = info_s == -1;
+    for (size_t e = tid; e < total; e += T) {
+        const int l = (int)(e % pk.L), s_ = (int)((e / pk.L) % pk.S), r = (int)(e / ((size_t)pk.L * pk.S));
+        pk.core[e] = zero ? 0.0 : Bs[(size_t)(l * pk.S + s_) * pk.ld + r];
+    }
+}
+
+} // namespace
+
+void fill_small_launch(const FnDevice& fn, const PiJob* d_pis, const LuProblem* d_lups, const PackJob* d_packs, int n_jobs, int last_site,
+                       hipStream_t stream)
+{
+    if (n_jobs <= 0) return;
+    FillSmallArgs a;
+    a.fn = fn;
+    a.pis = d_pis;
+    a.lups = d_lups;
+    a.packs = d_packs;
+    a.n_jobs = n_jobs;
+    a.last_site = last_site;
+    hipLaunchKernelGGL(fill_small_kernel, dim3(n_jobs), dim3(256), 0, stream, a);
+}
+
 void absmax_launch(const double* data, size_t count, unsigned long long* max_abs_bits, hipStream_t stream)
 {
     if (count == 0) return;

@@ -66,13 +66,7 @@ __global__ void __launch_bounds__(256) pack_fill_core_kernel(const double* __res
     }
 }
 
-// all cores of one fill_site_tensors in a single launch (blockIdx.y = site job)
-struct PackJob {
-    const double* src;
-    double* core;
-    const int* info; // null for the last site
-    int ld, L, S, R, last, pad_;
-};
+// all cores of one fill_site_tensors in a single launch (blockIdx.y = site job; PackJob: kernels.hpp)
 __global__ void __launch_bounds__(256) pack_fill_batched_kernel(const PackJob* __restrict__ jobs)
 {
     const PackJob j = jobs[blockIdx.y];
@@ -1266,6 +1260,13 @@ void Tci2::fill_site_tensors_impl(bool async)
     const LuProblem* d_lups = nullptr;
     const TrsmProblem* d_trs = nullptr;
     const PackJob* d_packs = nullptr;
+    const PiJob* d_pis = nullptr;
+    // small problems (BASELINE configs[1], the first iterations of every run): evaluation, solve and packing of all sites in ONE
+    // launch (fill_small_kernel) instead of five dependent ones — bitwise the same cores
+    static const bool no_small_fill = diag_env("T4A_NO_SMALL_FILL") != nullptr;
+    bool small_fill = builtin && !no_small_fill;
+    for (const SiteJob& j : jobs)
+        if (j.nj > (size_t)FILL_SMALL_MAX_N || j.ni > (size_t)FILL_SMALL_MAX_RHS) small_fill = false;
     if (builtin) {
         std::vector<uint64_t> acc_all;
         const size_t Kacc = (size_t)fn_dev_.n_acc;
@@ -1362,15 +1363,18 @@ void Tci2::fill_site_tensors_impl(bool async)
                 fill_pre_ops_.push_back([=]() { T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st)); });
                 dev([=]() { pi_eval_batched_launch(fn, dj, npi, max_M, max_N, st); });
             } else {
+                sg((uint64_t)small_fill);
+                const bool small = small_fill;
                 dev([=]() {
                     T4A_HIP(hipMemcpyAsync(db, hb, total_bytes, hipMemcpyHostToDevice, st));
-                    pi_eval_batched_launch(fn, dj, npi, max_M, max_N, st);
+                    if (!small) pi_eval_batched_launch(fn, dj, npi, max_M, max_N, st);
                 });
             }
         }
         d_lups = reinterpret_cast<const LuProblem*>(db + off_lu);
         d_trs = reinterpret_cast<const TrsmProblem*>(db + off_tr);
         d_packs = reinterpret_cast<const PackJob*>(db + off_pk);
+        d_pis = reinterpret_cast<const PiJob*>(db + off_pi);
     } else {
         // host callback: evaluated synchronously through eval_matrix (main stream), then continue on `st`
         for (const SiteJob& j : jobs) {
@@ -1418,7 +1422,17 @@ void Tci2::fill_site_tensors_impl(bool async)
         sg((uint64_t)(uintptr_t)d_packs);
         sg((uint64_t)(uintptr_t)d_info);
         sg((uint64_t)(uintptr_t)hinfo);
+        const FnDevice fn = fn_dev_;
+        const int n_site_jobs = (int)jobs.size(), last_site = jobs.back().last ? 1 : 0;
+        const bool small = small_fill;
+        sg((uint64_t)(uintptr_t)d_pis);
+        sg(((uint64_t)n_site_jobs << 1) | (uint64_t)last_site);
         dev([=]() {
+            if (small) {
+                fill_small_launch(fn, d_pis, d_lups, d_packs, n_site_jobs, last_site, st);
+                T4A_HIP(hipMemcpyAsync(hinfo, d_info, info_bytes, hipMemcpyDeviceToHost, st));
+                return;
+            }
             if (npr) {
                 // blocked LU with the unit-lower forward substitution of the right-hand sides folded in; beyond its size
                 // limit the unblocked kernel + explicit forward solve (bitwise the same result)
