@@ -204,24 +204,38 @@ __global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, int m, d
 // wavefront shuffles, one barrier per local round.  The rotations of the block are accumulated in a 2w x 2w matrix Q (LDS) and
 // applied to the rows of V in one pass at the end (V never enters the LDS).
 // LDS: double cols[2 w][m], double Q[2 w][2 w], int idx[2 w].
+typedef double jb_double2 __attribute__((ext_vector_type(2)));
+typedef double jb_double4 __attribute__((ext_vector_type(4)));
+
 template <int BW, int JB_RMAX = 16>
 __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_kernel(double* __restrict__ W, int m, double* __restrict__ V, int n, int nbp, int round,
                                                                                      int* rotated)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int w = BW, w2 = 2 * BW;
+    static_assert(JB_RMAX % 2 == 0, "the register window holds pairs of rows");
+    // a column in the LDS: ms doubles (m rounded up to even: a lane owns PAIRS of consecutive rows — rows 2 lane + e + 128 qq — and moves
+    // them with 16-byte LDS operations; the padding row of an odd m is zero and stays zero under every rotation)
+    const int ms = (m + 1) & ~1;
     double* const cols = reinterpret_cast<double*>(smem_raw);
-    double* const Q = cols + (size_t)w2 * m;
+    double* const Q = cols + (size_t)w2 * ms;
     int* const idx = reinterpret_cast<int*>(Q + (size_t)w2 * w2);
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+#ifdef T4A_JB_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define JSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define JSTAMP(k) do {} while (0)
+#endif
     int bi, bj;
     rr_pair(nbp, round, blockIdx.x, &bi, &bj);
-    if (tid < w2) {
-        const int c = tid < w ? bi * w + tid : bj * w + (tid - w);
-        idx[tid] = c < n ? c : -1; // (a block beyond the matrix, the tail of the last block: no column)
-    }
+    // global column of local column c (a block beyond the matrix, the tail of the last block: no column)
+    auto gcol = [&](int c) {
+        const int g = c < w ? bi * w + c : bj * w + (c - w);
+        return g < n ? g : -1;
+    };
+    if (tid < w2) idx[tid] = gcol(tid);
     for (int e = tid; e < w2 * w2; e += T) Q[e] = (e / w2 == e % w2) ? 1.0 : 0.0;
-    __syncthreads();
     {
         // the block's columns into the LDS: every wave requests all elements of its columns that fit the register window BEFORE it stores
         // the first one (as a load -> store loop the compiler waits for every element in turn: 2 w m / T dependent memory round trips
@@ -231,10 +245,10 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
             const int c = wave + NWV * k;
-            const int gc = c < w2 ? idx[c] : -1;
+            const int gc = c < w2 ? gcol(c) : -1;
 #pragma unroll
             for (int q = 0; q < JB_RMAX; ++q) {
-                const int r = lane + 64 * q;
+                const int r = 2 * lane + (q & 1) + 128 * (q >> 1);
                 tmp[k][q] = (gc >= 0 && r < m) ? W[(size_t)m * gc + r] : 0.0;
             }
         }
@@ -243,16 +257,17 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
             const int c = wave + NWV * k;
             if (c < w2) {
 #pragma unroll
-                for (int q = 0; q < JB_RMAX; ++q) {
-                    const int r = lane + 64 * q;
-                    if (r < m) cols[(size_t)c * m + r] = tmp[k][q];
+                for (int qq = 0; qq < JB_RMAX / 2; ++qq) {
+                    const int r = 2 * lane + 128 * qq;
+                    if (r < ms) *reinterpret_cast<jb_double2*>(cols + (size_t)c * ms + r) = (jb_double2){tmp[k][2 * qq], tmp[k][2 * qq + 1]};
                 }
-                const int gc = idx[c];
-                for (int r = lane + 64 * JB_RMAX; r < m; r += 64) cols[(size_t)c * m + r] = gc >= 0 ? W[(size_t)m * gc + r] : 0.0;
+                const int gc = gcol(c);
+                for (int r = lane + 64 * JB_RMAX; r < ms; r += 64) cols[(size_t)c * ms + r] = (gc >= 0 && r < m) ? W[(size_t)m * gc + r] : 0.0;
             }
         }
     }
     __syncthreads();
+    JSTAMP(0);
     bool any = false;
     // every column pair once per sweep: the first block round runs the full local tournament (pairs inside the two blocks and
     // across them), the others only the w^2 pairs ACROSS the blocks (w local rounds: column k of I with column (k + lr) mod w of J)
@@ -267,23 +282,30 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
                 a = wave;
                 b = w + (wave + lr) % w;
             }
-            if (idx[a] >= 0 && idx[b] >= 0) {
-                double* const ca = cols + (size_t)a * m;
-                double* const cb = cols + (size_t)b * m;
+            if (gcol(a) >= 0 && gcol(b) >= 0) {
+                double* const ca = cols + (size_t)a * ms;
+                double* const cb = cols + (size_t)b * ms;
                 // the two columns stay in registers between the dot products and the rotation (one LDS read and, when the
                 // pair rotates, one write per element and local round); columns longer than 64 * JB_RMAX rows re-read.  JB_RMAX is
                 // sized for the column length (round 5: with a fixed 16 a 256-row column — every matrix behind the QR preconditioner
                 // at chi = 256 — executed four times the loads, selects and multiply-adds it needed)
-                double xr[JB_RMAX], yr[JB_RMAX];
+                jb_double2 xr[JB_RMAX / 2], yr[JB_RMAX / 2];
                 double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
-                for (int q = 0; q < JB_RMAX; ++q) {
-                    const int r = lane + 64 * q;
-                    xr[q] = r < m ? ca[r] : 0.0;
-                    yr[q] = r < m ? cb[r] : 0.0;
-                    al += xr[q] * xr[q];
-                    be += yr[q] * yr[q];
-                    ga += xr[q] * yr[q];
+                for (int qq = 0; qq < JB_RMAX / 2; ++qq) {
+                    const int r = 2 * lane + 128 * qq;
+                    const bool in = r < ms;
+                    xr[qq] = in ? *reinterpret_cast<const jb_double2*>(ca + r) : (jb_double2){0.0, 0.0};
+                    yr[qq] = in ? *reinterpret_cast<const jb_double2*>(cb + r) : (jb_double2){0.0, 0.0};
+                }
+#pragma unroll
+                for (int qq = 0; qq < JB_RMAX / 2; ++qq) {
+                    al += xr[qq].x * xr[qq].x;
+                    be += yr[qq].x * yr[qq].x;
+                    ga += xr[qq].x * yr[qq].x;
+                    al += xr[qq].y * xr[qq].y;
+                    be += yr[qq].y * yr[qq].y;
+                    ga += xr[qq].y * yr[qq].y;
                 }
                 for (int r = lane + 64 * JB_RMAX; r < m; r += 64) {
                     const double x = ca[r], y = cb[r];
@@ -291,18 +313,21 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
                     be += y * y;
                     ga += x * y;
                 }
+                JSTAMP(1);
                 al = wave_sum_dpp(al);
                 be = wave_sum_dpp(be);
                 ga = wave_sum_dpp(ga);
+                JSTAMP(2);
                 const Rot rot = jacobi_rotation(al, be, ga);
+                JSTAMP(3);
                 if (rot.apply) {
                     any = true;
 #pragma unroll
-                    for (int q = 0; q < JB_RMAX; ++q) {
-                        const int r = lane + 64 * q;
-                        if (r < m) {
-                            ca[r] = rot.c * xr[q] - rot.s * yr[q];
-                            cb[r] = rot.s * xr[q] + rot.c * yr[q];
+                    for (int qq = 0; qq < JB_RMAX / 2; ++qq) {
+                        const int r = 2 * lane + 128 * qq;
+                        if (r < ms) {
+                            *reinterpret_cast<jb_double2*>(ca + r) = (jb_double2){rot.c * xr[qq].x - rot.s * yr[qq].x, rot.c * xr[qq].y - rot.s * yr[qq].y};
+                            *reinterpret_cast<jb_double2*>(cb + r) = (jb_double2){rot.s * xr[qq].x + rot.c * yr[qq].x, rot.s * xr[qq].y + rot.c * yr[qq].y};
                         }
                     }
                     for (int r = lane + 64 * JB_RMAX; r < m; r += 64) {
@@ -310,35 +335,82 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
                         ca[r] = rot.c * x - rot.s * y;
                         cb[r] = rot.s * x + rot.c * y;
                     }
+                    JSTAMP(4);
                     if (lane < w2) { // column a / b of Q (Q[row][col] at row * w2 + col)
                         const double x = Q[lane * w2 + a], y = Q[lane * w2 + b];
                         Q[lane * w2 + a] = rot.c * x - rot.s * y;
                         Q[lane * w2 + b] = rot.s * x + rot.c * y;
                     }
+                    JSTAMP(5);
                 }
             }
         }
         __syncthreads();
+        JSTAMP(6);
     }
     if (any && lane == 0) *rotated = 1;
     for (int c = wave; c < w2; c += (T >> 6)) {
         const int gc = idx[c];
         if (gc < 0) continue;
-        for (int r = lane; r < m; r += 64) W[(size_t)m * gc + r] = cols[(size_t)c * m + r];
+        for (int r = lane; r < m; r += 64) W[(size_t)m * gc + r] = cols[(size_t)c * ms + r];
     }
-    // V(:, block) <- V(:, block) Q: one row of V per thread
-    for (int r = tid; r < n; r += T) {
-        double vin[w2];
+    JSTAMP(7);
+    if constexpr (w2 % 16 == 0) {
+        // V(:, block) <- V(:, block) Q on the f64 matrix cores: a wave per tile of 16 rows, out[r][c] = sum_k V[r][k] Q[k][c] as
+        // v_mfma_f64_16x16x4 with "A" = Q^T (rows = c) and "B" = V^T (columns = r); lane (lr = lane & 15, lk = lane >> 4) holds
+        // out[r0 + lr][ct * 16 + lk + 4 reg].  (Round 5: one row per thread with 2 w x 2 w serial multiply-adds took 13 000 of the 44 600
+        // cycles of a block round at w = 8, half the workgroup idle.)
+        constexpr int KS = w2 / 4, CT = w2 / 16;
+        const int lr = lane & 15, lk = lane >> 4;
+        double qf[CT][KS];
 #pragma unroll
-        for (int c = 0; c < w2; ++c) vin[c] = idx[c] >= 0 ? V[(size_t)n * idx[c] + r] : 0.0;
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int c = 0; c < w2; ++c) {
-            double acc = 0.0;
+            for (int ks = 0; ks < KS; ++ks) qf[ct][ks] = Q[(4 * ks + lk) * w2 + ct * 16 + lr];
+        int gk[KS];
 #pragma unroll
-            for (int k = 0; k < w2; ++k) acc += vin[k] * Q[k * w2 + c];
-            if (idx[c] >= 0) V[(size_t)n * idx[c] + r] = acc;
+        for (int ks = 0; ks < KS; ++ks) gk[ks] = idx[4 * ks + lk];
+        int go[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) go[ct][reg] = idx[ct * 16 + lk + 4 * reg];
+        for (int r0 = 16 * wave; r0 < n; r0 += 16 * (T >> 6)) {
+            const int r = r0 + lr;
+            double vf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) vf[ks] = (gk[ks] >= 0 && r < n) ? V[(size_t)n * gk[ks] + r] : 0.0;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                jb_double4 acc = (jb_double4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[ct][ks], vf[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (go[ct][reg] >= 0 && r < n) V[(size_t)n * go[ct][reg] + r] = acc[reg];
+            }
+        }
+    } else {
+        // V(:, block) <- V(:, block) Q: one row of V per thread
+        for (int r = tid; r < n; r += T) {
+            double vin[w2];
+#pragma unroll
+            for (int c = 0; c < w2; ++c) vin[c] = idx[c] >= 0 ? V[(size_t)n * idx[c] + r] : 0.0;
+#pragma unroll
+            for (int c = 0; c < w2; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < w2; ++k) acc += vin[k] * Q[k * w2 + c];
+                if (idx[c] >= 0) V[(size_t)n * idx[c] + r] = acc;
+            }
         }
     }
+#ifdef T4A_JB_STAMPS
+    JSTAMP(8);
+    if (blockIdx.x == 1 && lane == 0 && (wave == 0 || wave == 3) && round == 3 && *rotated)
+        printf("[jacobi_block stamps] w=%d m=%d n=%d wave %d cycles: load=%llu | lds+dots=%llu sums=%llu rotation=%llu apply=%llu Q=%llu barrier=%llu | writeback=%llu V=%llu\n", w, m, n,
+               wave, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5], st_acc[6], st_acc[7], st_acc[8]);
+#endif
 }
 
 __global__ void __launch_bounds__(256) col_norms_kernel(const double* __restrict__ W, int m, int n, double* sig)
@@ -674,11 +746,12 @@ bool jacobi_block_sweep_launch(double* W, int m, double* V, int n, int* d_rotate
 {
     static const int w_max = diag_env("T4A_SVD_BLOCK_W") ? std::atoi(diag_env("T4A_SVD_BLOCK_W")) : 8;
     int w = w_max >= 16 ? 16 : (w_max >= 8 ? 8 : (w_max >= 4 ? 4 : 2));
-    while (w > 1 && (size_t)2 * w * m * 8 > (size_t)136 * 1024) w >>= 1;
-    if ((size_t)2 * w * m * 8 > (size_t)136 * 1024) return false;
+    const int ms = (m + 1) & ~1; // (a column's stride in the LDS: jacobi_block_kernel)
+    while (w > 1 && (size_t)2 * w * ms * 8 > (size_t)136 * 1024) w >>= 1;
+    if ((size_t)2 * w * ms * 8 > (size_t)136 * 1024) return false;
     const int nb = (n + w - 1) / w;
     const int nbp = nb < 2 ? 2 : nb + (nb & 1);
-    const size_t lds = ((size_t)2 * w * m + (size_t)4 * w * w) * 8 + (size_t)2 * w * 4 + 16;
+    const size_t lds = ((size_t)2 * w * ms + (size_t)4 * w * w) * 8 + (size_t)2 * w * 4 + 16;
     int T = 64 * w;
     if (T < 256) T = 256; // (the extra waves only help with the loads and the V pass)
     static std::once_flag attr_once; // (once per process, not once per sweep: ADVICE round 4; every block width in one go)
@@ -699,10 +772,18 @@ bool jacobi_block_sweep_launch(double* W, int m, double* V, int n, int* d_rotate
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     });
     switch (w) {
-    case 16: go(&jacobi_block_kernel<16>); break;
+    case 16:
+        if (m <= 128) go(&jacobi_block_kernel<16, 2>);
+        else if (m <= 256) go(&jacobi_block_kernel<16, 4>);
+        else if (m <= 512) go(&jacobi_block_kernel<16, 8>);
+        else go(&jacobi_block_kernel<16>);
+        break;
     case 8:
         if (m <= 128) go(&jacobi_block_kernel<8, 2>);
         else if (m <= 256) go(&jacobi_block_kernel<8, 4>);
