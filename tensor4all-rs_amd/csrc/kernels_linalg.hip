@@ -79,21 +79,30 @@ struct Rot {
     double c, s;
     int apply;
 };
-__device__ inline Rot jacobi_rotation(double alpha, double beta, double gamma)
+// A pair rotates when the cosine of the angle between its columns exceeds tol = sqrt(m) * eps — the stopping rule of LAPACK's one-sided
+// Jacobi (dgesvj: "TOL = SQRT(M) * EPS").  Round 5: with tol = eps the last two sweeps of every decomposition found 1 - 200 of the 32 640
+// pairs of a 256-column matrix to rotate (angles of a few eps); singular values and vectors agree to the same 1e-14 either way.
+__device__ inline Rot jacobi_rotation(double alpha, double beta, double gamma, double tol)
 {
     Rot r;
     r.c = 1.0;
     r.s = 0.0;
     r.apply = 0;
-    const double eps = 2.220446049250313e-16;
-    if (gamma == 0.0 || !(fabs(gamma) > eps * sqrt(alpha * beta))) return r;
+    if (gamma == 0.0 || !(fabs(gamma) > tol * sqrt(alpha * beta))) return r;
     const double zeta = (beta - alpha) / (2.0 * gamma);
     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    r.c = 1.0 / sqrt(1.0 + t * t);
+    // c = (1 + t^2)^(-1/2), |t| <= 1: the hardware estimate and two Newton steps (y <- y (3 - x y^2) / 2) instead of a square root and a
+    // division in the longest dependent chain of a local round
+    const double x = 1.0 + t * t;
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    r.c = y;
     r.s = r.c * t;
     r.apply = 1;
     return r;
 }
+__device__ inline double jacobi_tol(int m) { return 2.220446049250313e-16 * sqrt((double)m); }
 
 // One tournament round, one workgroup per pair (large problems).
 __global__ void __launch_bounds__(256) jacobi_round_kernel(double* W, int m, double* V, int n, int np, int round,
@@ -115,7 +124,7 @@ __global__ void __launch_bounds__(256) jacobi_round_kernel(double* W, int m, dou
     a = block_sum(a, red);
     b = block_sum(b, red);
     g = block_sum(g, red);
-    const Rot rot = jacobi_rotation(a, b, g);
+    const Rot rot = jacobi_rotation(a, b, g, jacobi_tol(m));
     if (!rot.apply) return;
     if (threadIdx.x == 0) *rotated = 1;
     for (int r = threadIdx.x; r < m; r += blockDim.x) {
@@ -170,7 +179,7 @@ __global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, int m, d
                 a = wave_sum(a);
                 b = wave_sum(b);
                 g = wave_sum(g);
-                const Rot rot = jacobi_rotation(a, b, g);
+                const Rot rot = jacobi_rotation(a, b, g, jacobi_tol(m));
                 if (!rot.apply) continue;
                 if (lane == 0) s_rot = 1;
                 for (int r = lane; r < m; r += 64) {
@@ -269,14 +278,28 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
     __syncthreads();
     JSTAMP(0);
     bool any = false;
+    const double tol = jacobi_tol(m);
     // every column pair once per sweep: the first block round runs the full local tournament (pairs inside the two blocks and
     // across them), the others only the w^2 pairs ACROSS the blocks (w local rounds: column k of I with column (k + lr) mod w of J)
-    // — a pair inside a block that was met in every block round kept rotating on rounding noise and the sweeps never ended
-    const int n_local = round == 0 ? w2 - 1 : w;
+    // — a pair inside a block that was met in every block round kept rotating on rounding noise and the sweeps never ended.
+    // In those rounds wave k keeps column k of I in its registers from the first local round to the last (nobody else touches it): one
+    // column read and, when the pair rotates, one column written per local round — the LDS moved 64 KB per local round at m = 256, a
+    // quarter of the round's time, with both columns going through it.
+    const bool resident = round != 0;
+    const int n_local = resident ? w : w2 - 1;
+    jb_double2 xr[JB_RMAX / 2];
+    const bool a_valid = wave < w && gcol(wave) >= 0;
+    if (resident && a_valid) {
+#pragma unroll
+        for (int qq = 0; qq < JB_RMAX / 2; ++qq) {
+            const int r = 2 * lane + 128 * qq;
+            xr[qq] = r < ms ? *reinterpret_cast<const jb_double2*>(cols + (size_t)wave * ms + r) : (jb_double2){0.0, 0.0};
+        }
+    }
     for (int lr = 0; lr < n_local; ++lr) {
         if (wave < w) {
             int a, b;
-            if (round == 0) {
+            if (!resident) {
                 rr_pair(w2, lr, wave, &a, &b);
             } else {
                 a = wave;
@@ -285,17 +308,16 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
             if (gcol(a) >= 0 && gcol(b) >= 0) {
                 double* const ca = cols + (size_t)a * ms;
                 double* const cb = cols + (size_t)b * ms;
-                // the two columns stay in registers between the dot products and the rotation (one LDS read and, when the
-                // pair rotates, one write per element and local round); columns longer than 64 * JB_RMAX rows re-read.  JB_RMAX is
-                // sized for the column length (round 5: with a fixed 16 a 256-row column — every matrix behind the QR preconditioner
-                // at chi = 256 — executed four times the loads, selects and multiply-adds it needed)
-                jb_double2 xr[JB_RMAX / 2], yr[JB_RMAX / 2];
+                // the two columns stay in registers between the dot products and the rotation; columns longer than 64 * JB_RMAX rows
+                // re-read their tail.  JB_RMAX is sized for the column length (round 5: with a fixed 16 a 256-row column — every matrix
+                // behind the QR preconditioner at chi = 256 — executed four times the loads, selects and multiply-adds it needed)
+                jb_double2 yr[JB_RMAX / 2];
                 double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
                 for (int qq = 0; qq < JB_RMAX / 2; ++qq) {
                     const int r = 2 * lane + 128 * qq;
                     const bool in = r < ms;
-                    xr[qq] = in ? *reinterpret_cast<const jb_double2*>(ca + r) : (jb_double2){0.0, 0.0};
+                    if (!resident) xr[qq] = in ? *reinterpret_cast<const jb_double2*>(ca + r) : (jb_double2){0.0, 0.0};
                     yr[qq] = in ? *reinterpret_cast<const jb_double2*>(cb + r) : (jb_double2){0.0, 0.0};
                 }
 #pragma unroll
@@ -318,17 +340,20 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
                 be = wave_sum_dpp(be);
                 ga = wave_sum_dpp(ga);
                 JSTAMP(2);
-                const Rot rot = jacobi_rotation(al, be, ga);
+                const Rot rot = jacobi_rotation(al, be, ga, tol);
                 JSTAMP(3);
                 if (rot.apply) {
                     any = true;
 #pragma unroll
                     for (int qq = 0; qq < JB_RMAX / 2; ++qq) {
                         const int r = 2 * lane + 128 * qq;
+                        const jb_double2 xn = (jb_double2){rot.c * xr[qq].x - rot.s * yr[qq].x, rot.c * xr[qq].y - rot.s * yr[qq].y};
+                        const jb_double2 yn = (jb_double2){rot.s * xr[qq].x + rot.c * yr[qq].x, rot.s * xr[qq].y + rot.c * yr[qq].y};
                         if (r < ms) {
-                            *reinterpret_cast<jb_double2*>(ca + r) = (jb_double2){rot.c * xr[qq].x - rot.s * yr[qq].x, rot.c * xr[qq].y - rot.s * yr[qq].y};
-                            *reinterpret_cast<jb_double2*>(cb + r) = (jb_double2){rot.s * xr[qq].x + rot.c * yr[qq].x, rot.s * xr[qq].y + rot.c * yr[qq].y};
+                            if (!resident) *reinterpret_cast<jb_double2*>(ca + r) = xn;
+                            *reinterpret_cast<jb_double2*>(cb + r) = yn;
                         }
+                        xr[qq] = xn;
                     }
                     for (int r = lane + 64 * JB_RMAX; r < m; r += 64) {
                         const double x = ca[r], y = cb[r];
@@ -348,6 +373,14 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
         __syncthreads();
         JSTAMP(6);
     }
+    if (resident && a_valid) { // (the last barrier of the loop is behind every read of this column's tail; the write-out below reads it)
+#pragma unroll
+        for (int qq = 0; qq < JB_RMAX / 2; ++qq) {
+            const int r = 2 * lane + 128 * qq;
+            if (r < ms) *reinterpret_cast<jb_double2*>(cols + (size_t)wave * ms + r) = xr[qq];
+        }
+    }
+    if (resident) __syncthreads();
     if (any && lane == 0) *rotated = 1;
     for (int c = wave; c < w2; c += (T >> 6)) {
         const int gc = idx[c];

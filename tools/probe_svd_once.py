@@ -1,0 +1,15 @@
+"""Five thin SVDs of one Gaussian 512 x 256 matrix (for a kernel trace: rocprofv3 --kernel-trace --stats -- python3 tools/probe_svd_once.py)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tensor4all-rs_amd", "python"))
+import numpy as np
+import t4a_amd
+m, n = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (512, 256)
+a = np.random.default_rng(0).standard_normal((m, n))
+t4a_amd.svd_backend(a)
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    t4a_amd.svd_backend(a)
+    ts.append(time.perf_counter() - t0)
+print(f"svd {m} x {n}: {min(ts) * 1e3:.3f} ms", flush=True)
