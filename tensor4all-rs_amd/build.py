@@ -19,7 +19,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fvisibility=hidden"] + os.environ.get("T4A_EXTRA_FLAGS", "").split()  # e.g. -DT4A_RRLU_TRACE (tools/trace_arrivals.py)
 # per-source flags.  kernels_dense.hip: keep MFMA accumulators in VGPRs — in AGPR form the compiler moves all of them between the
 # two register files at every k-step of the GEMM loop (32 v_accvgpr reads + writes behind a pipeline drain)
-FILE_FLAGS = {"kernels_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# kernels_linalg.hip (Jacobi SVD, Householder QR: compared at tolerances, no pivot decision hangs on a rounding): fused multiply-adds —
+# its one-workgroup kernels are bound by the instructions they issue, a separately rounded multiply and add is two of them
+FILE_FLAGS = {"kernels_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "kernels_linalg.hip": ["-ffp-contract=fast"]}
 HEADERS = ["common.hpp", "stdrng.hpp", "pishard.hpp", "kernels.hpp", "kernels_rrlu_xcd_common.hpp", "kernels_rrlu_w1_body.hpp", "engine.hpp", "tci2.hpp", "tt.hpp", "globalsearch.hpp", "rook.hpp", "patching.hpp", "tree.hpp", "quantics.hpp", "tensorops.hpp", "aci.hpp", "../../include/t4a_gpu.h",
            "../../include/t4a_testfunctions.h"]
 

@@ -729,6 +729,170 @@ __global__ void __launch_bounds__(QR_T) qr_panel_lds_kernel(double* A, int m, in
     for (int e = tid; e < QR_NB * QR_NB; e += QR_T) Tp[e] = T[e];
 }
 
+// Column c of the compact-WY factor in the LDS: T(0:c, c) <- -tau_c T(0:c, 0:c) z with z = T(0:c, c) as the wave tasks left it (raw
+// products V_q^T v_c); one wave, lane = row, every lane reads its terms before any lane writes (program order of one wave).
+__device__ __forceinline__ void qr_t_column(double* T, int c, int lane)
+{
+    const double tc = T[c + QR_NB * c];
+    if (lane < c && tc != 0.0) {
+        double acc = 0.0;
+        for (int r = lane; r < c; ++r) acc += T[lane + QR_NB * r] * T[r + QR_NB * c];
+        T[lane + QR_NB * c] = -tc * acc;
+    }
+}
+
+// Round 5, second version of the LDS-resident panel.  The first one spent 3.9 us per column (125 us per 32-column panel, 1.0 of the
+// 1.7 ms of a 512 x 256 factorisation) in a chain of five barriers: norm of the column by the whole workgroup (two barriers), the
+// diagonal entry replaced by v0 (two barriers), the wave tasks, the column of T (one barrier each).  Here a column is ONE barrier:
+//   * the norm of column jj + 1 is computed by the wave that has just applied H_jj to it (its updated values are in registers): the next
+//     iteration starts from two numbers in the LDS instead of a workgroup reduction;
+//   * the diagonal entry stays in place, v0 lives in its own array and the lane that meets row jj substitutes it;
+//   * a wave runs its two tasks (columns wave and wave + 16 of the 31 others) together: loads, dot products and the two DPP sums interleave;
+//   * the raw products z_q = V_q^T v_jj go straight into the strict upper part of T and wave 15 — the one wave with a single task — turns
+//     column jj - 1 into -tau T z while the others work on column jj.
+// Same reflectors, same T (its column sums in the same order), A / Vall / diag / tau / v0s as qr_panel_kernel leaves them; the norms are
+// summed in a different order (one wave instead of sixteen), i.e. equal to rounding.
+template <int RPL> // rows per lane: ceil((m - j0) / 64) — the workgroup is bound by the instructions its 16 waves issue on one compute unit
+__global__ void __launch_bounds__(QR_T) qr_panel_lds2_kernel(double* A, int m, int j0, int w, double* diag, double* tau, double* v0s, double* Vall, double* Tp)
+{
+    extern __shared__ __attribute__((aligned(16))) double qsm[]; // [QR_NB][ld] panel, [QR_NB * QR_NB] T, [QR_NB] v0, [QR_T / 64] red, [2] next, [QR_NB] R's diagonal
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = QR_T / 64;
+    static_assert(RPL >= 1 && RPL * 64 >= 64 && RPL <= (QR_LDS_MAX_ROWS + 63) / 64, "rows per lane");
+    const int mp = m - j0;
+    const int ld = mp | 1;
+    double* const P = qsm;
+    double* const T = P + (size_t)QR_NB * ld;
+    double* const v0l = T + QR_NB * QR_NB;
+    double* const red = v0l + QR_NB;
+    double* const nxt = red + NWV;
+    double* const dgl = nxt + 2;
+    for (int e = tid; e < QR_NB * QR_NB; e += QR_T) T[e] = 0.0;
+    for (int c = wave; c < w; c += NWV) {
+        const double* src = A + (size_t)m * (j0 + c) + j0;
+        double tmp[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) tmp[q] = (lane + 64 * q) < mp ? src[lane + 64 * q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q)
+            if ((lane + 64 * q) < mp) P[(size_t)c * ld + lane + 64 * q] = tmp[q];
+    }
+    __syncthreads();
+    double tail = 0.0;
+    for (int r = 1 + tid; r < mp; r += QR_T) tail += P[r] * P[r];
+    tail = block_sum(tail, red);
+    double x0 = P[0];
+    for (int jj = 0; jj < w; ++jj) {
+        const double* x = P + (size_t)jj * ld;
+        const double nrm = sqrt(x0 * x0 + tail);
+        const double alpha = x0 >= 0.0 ? -nrm : nrm;
+        const double v0 = x0 - alpha;
+        const double vv = v0 * v0 + tail;
+        const double t = (nrm == 0.0) ? 0.0 : 2.0 / vv;
+        if (tid == 0) { // (into the LDS: a store to global memory here is waited for — vmcnt(0) — in front of the column's barrier)
+            dgl[jj] = (nrm == 0.0) ? 0.0 : alpha;
+            v0l[jj] = v0;
+            T[jj + QR_NB * jj] = t;
+        }
+        // the wave's two tasks: task k < jj reads column k (z_k = V_k^T v_jj), task k >= jj updates column k + 1 with H_jj
+        const int ta = wave, tb = wave + NWV;
+        const bool has_a = ta < w - 1, has_b = tb < w - 1;
+        const int ca = ta < jj ? ta : ta + 1, cb = tb < jj ? tb : tb + 1;
+        const bool next_a = has_a && ta == jj, next_b = has_b && tb == jj; // (the column that comes next: its norm is taken here)
+        if ((t != 0.0 && has_a) || next_a || next_b) {
+            double* const ya = P + (size_t)ca * ld;
+            double* const yb = P + (size_t)(has_b ? cb : ca) * ld;
+            double xv[RPL], va[RPL], vb[RPL];
+            double da = 0.0, db = 0.0;
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                const int r = jj + lane + 64 * q;
+                const bool in = r < mp;
+                xv[q] = in ? x[r] : 0.0;
+                va[q] = in ? ya[r] : 0.0;
+                vb[q] = (in && has_b) ? yb[r] : 0.0;
+            }
+            if (lane == 0) xv[0] = v0; // (row jj: the reflector's head, the LDS still holds the column's own entry there)
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                da += xv[q] * va[q];
+                db += xv[q] * vb[q];
+            }
+            da = wave_sum_dpp(da);
+            db = wave_sum_dpp(db);
+            if (t != 0.0) {
+                if (ta >= jj) {
+                    const double f = t * da;
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        const int r = jj + lane + 64 * q;
+                        va[q] -= f * xv[q];
+                        if (r < mp) ya[r] = va[q];
+                    }
+                } else if (lane == 0) {
+                    T[ta + QR_NB * jj] = da;
+                }
+                if (has_b) {
+                    if (tb >= jj) {
+                        const double f = t * db;
+#pragma unroll
+                        for (int q = 0; q < RPL; ++q) {
+                            const int r = jj + lane + 64 * q;
+                            vb[q] -= f * xv[q];
+                            if (r < mp) yb[r] = vb[q];
+                        }
+                    } else if (lane == 0) {
+                        T[tb + QR_NB * jj] = db;
+                    }
+                }
+            }
+            if (next_a || next_b) { // column jj + 1 as it stands now: its diagonal entry (row jj + 1) and the squared norm below it
+                double sq = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const double v = next_a ? va[q] : vb[q];
+                    if (lane + 64 * q >= 2) sq += v * v;
+                }
+                sq = wave_sum_dpp(sq);
+                const double head = next_a ? va[0] : vb[0];
+                const double h1 = __shfl(head, 1);
+                if (lane == 0) {
+                    nxt[0] = sq;
+                    nxt[1] = h1;
+                }
+            }
+        }
+        if (wave == NWV - 1 && jj >= 1) { // column jj - 1 of T: -tau T(0:c, 0:c) z, z = the raw products stored in that column
+            qr_t_column(T, jj - 1, lane);
+        }
+        __syncthreads();
+        tail = nxt[0];
+        x0 = nxt[1];
+    }
+    if (wave == 0 && w >= 2) { // the last column of T
+        qr_t_column(T, w - 1, lane);
+    }
+    __syncthreads();
+    for (int c = wave; c < w; c += NWV) {
+        double* dstA = A + (size_t)m * (j0 + c) + j0;
+        double* dstV = Vall + (size_t)m * (j0 + c);
+        const double* col = P + (size_t)c * ld;
+        const double vc = v0l[c];
+        for (int r = lane; r < mp; r += 64) {
+            const double v = col[r];
+            if (r != c) dstA[r] = v;
+            dstV[j0 + r] = r < c ? 0.0 : (r == c ? vc : v);
+        }
+        for (int r = lane; r < j0; r += 64) dstV[r] = 0.0;
+    }
+    for (int e = tid; e < QR_NB * QR_NB; e += QR_T) Tp[e] = T[e];
+    if (tid < w) {
+        diag[j0 + tid] = dgl[tid];
+        tau[j0 + tid] = T[tid + QR_NB * tid];
+        v0s[j0 + tid] = v0l[tid];
+    }
+}
+
 __global__ void __launch_bounds__(256) qr_extract_r_kernel(const double* __restrict__ A, int m, int n, int k,
                                                            const double* diag, double* R)
 {
@@ -856,12 +1020,27 @@ void qr_factor_launch(double* A, int m, int n, double* diag, double* tau, double
         static const bool no_lds_panel = diag_env("T4A_QR_NO_LDS_PANEL") != nullptr;
         if (!no_lds_panel && m - j0 <= QR_LDS_MAX_ROWS) {
             const int ld = (m - j0) | 1;
-            const size_t lds = ((size_t)QR_NB * ld + QR_NB * QR_NB + QR_NB + QR_T / 64) * sizeof(double);
+            const size_t lds = ((size_t)QR_NB * ld + QR_NB * QR_NB + QR_NB + QR_T / 64 + 2 + QR_NB) * sizeof(double);
             static std::once_flag attr_once;
             std::call_once(attr_once, [] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qr_panel_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qr_panel_lds2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qr_panel_lds2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qr_panel_lds2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qr_panel_lds2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qr_panel_lds2_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qr_panel_lds2_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             });
-            hipLaunchKernelGGL(qr_panel_lds_kernel, dim3(1), dim3(QR_T), lds, stream, A, m, j0, w, diag, tau, v0s, Vall, Tp);
+            static const bool old_panel = diag_env("T4A_QR_OLD_PANEL") != nullptr; // (the five-barrier version, for comparison)
+            const int rpl = (m - j0 + 63) / 64;
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(1), dim3(QR_T), lds, stream, A, m, j0, w, diag, tau, v0s, Vall, Tp); };
+            if (old_panel) go(&qr_panel_lds_kernel);
+            else if (rpl <= 1) go(&qr_panel_lds2_kernel<1>);
+            else if (rpl <= 2) go(&qr_panel_lds2_kernel<2>);
+            else if (rpl <= 3) go(&qr_panel_lds2_kernel<3>);
+            else if (rpl <= 4) go(&qr_panel_lds2_kernel<4>);
+            else if (rpl <= 6) go(&qr_panel_lds2_kernel<6>);
+            else go(&qr_panel_lds2_kernel<9>);
         } else {
             hipLaunchKernelGGL(qr_panel_kernel, dim3(1), dim3(QR_T), 0, stream, A, m, j0, w, diag, tau, v0s, Vall, Tp);
         }
