@@ -483,6 +483,30 @@ def test_randomized_svd_against_the_dense_svd(t4a):
         t4a.randomized_svd(a, 181)
 
 
+@pytest.mark.parametrize("shape", [(67, 67), (129, 65), (65, 129), (255, 77), (333, 131), (40, 33), (33, 40), (17, 9)])
+def test_svd_and_qr_on_odd_and_ragged_shapes(t4a, shape):
+    """Round 5 kernels: the blocked Jacobi round keeps PAIRS of rows per lane (odd column lengths are padded by a zero row), its last
+    column block is partial when the column count is no multiple of the block width, the V update runs on 16-row MFMA tiles (row counts
+    off a multiple of 16); the QR panel kernel is specialised by rows per lane and its last panel is narrow.  Singular values against
+    LAPACK, orthonormal factors, reconstruction; rank-deficient variant with zero and repeated columns."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    m, n = shape
+    k = min(m, n)
+    full = rng.standard_normal((m, n))
+    low = rng.standard_normal((m, 5)) @ rng.standard_normal((5, n))
+    low[:, 1] = 0.0
+    low[:, n - 1] = low[:, 0]
+    for a in (full, low):
+        u, s, vt = t4a.svd_backend(a)
+        sref = np.linalg.svd(a, compute_uv=False)
+        assert np.abs(s - sref).max() <= 1e-12 * sref[0]
+        assert np.abs((u * s) @ vt - a).max() <= 1e-12 * sref[0] * k
+        assert np.abs(u.T @ u - np.eye(k)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(k)).max() < 1e-10
+        q, r = t4a.qr_backend(a)
+        assert np.abs(q @ r - a).max() <= 1e-12 * sref[0] * k
+        assert np.abs(q.T @ q - np.eye(k)).max() < 1e-11 and np.abs(np.tril(r, -1)).max() == 0.0
+
+
 @pytest.mark.parametrize("shape", [(200, 100), (100, 200), (128, 128)])
 def test_preconditioned_svd_on_rank_deficient_and_graded_inputs(t4a, shape):
     """Engine::svd runs the Jacobi iteration on L = R^T of a Householder QR from 64 columns on (round 5): exact rank deficiency (zero
