@@ -382,6 +382,9 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
     }
     if (resident) __syncthreads();
     if (any && lane == 0) *rotated = 1;
+    // a block pair in which no pair rotated (most of them in the last two sweeps of every decomposition) leaves W and V as they are:
+    // nothing to write back, Q is the identity
+    if (!__syncthreads_or(any ? 1 : 0)) return;
     for (int c = wave; c < w2; c += (T >> 6)) {
         const int gc = idx[c];
         if (gc < 0) continue;
