@@ -26,12 +26,12 @@ int main()
 {
     unsigned long long* d_out;
     double* d_sink;
-    hipMalloc(&d_out, 16);
-    hipMalloc(&d_sink, 8);
+    (void)hipMalloc(&d_out, 16);
+    (void)hipMalloc(&d_sink, 8);
     unsigned long long h[2];
     auto run = [&](int iters, const char* label) {
         hipLaunchKernelGGL(spin_one, dim3(1), dim3(64), 0, 0, iters, d_out, d_sink);
-        hipMemcpy(h, d_out, 16, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, d_out, 16, hipMemcpyDeviceToHost);
         std::printf("%-44s %8d dependent FMAs: %9.1f us, %7.1f s_memtime ticks per us, %5.2f ticks per FMA\n", label, iters, h[1] / 100.0,
                     (double)h[0] / (h[1] / 100.0), (double)h[0] / iters);
     };
