@@ -1265,6 +1265,11 @@ void Tci2::fill_site_tensors_impl(bool async)
     // launch (fill_small_kernel) instead of five dependent ones — bitwise the same cores
     static const bool no_small_fill = diag_env("T4A_NO_SMALL_FILL") != nullptr;
     bool small_fill = builtin && !no_small_fill;
+#ifdef T4A_TEST_HOOKS
+    // libt4a_gpu_testhooks.so only: the general five-launch path for small problems too, so that a test can compare the two bit by bit
+    // (tests/test_gpu_tci2.py::test_small_problem_fill_in_one_launch_is_bitwise_the_general_path)
+    if (std::getenv("T4A_TEST_NO_SMALL_FILL")) small_fill = false;
+#endif
     for (const SiteJob& j : jobs)
         if (j.nj > (size_t)FILL_SMALL_MAX_N || j.ni > (size_t)FILL_SMALL_MAX_RHS) small_fill = false;
     if (builtin) {

@@ -7,11 +7,14 @@ built-in device-functor path is checked against the oracle on the BASELINE confi
 in seconds, and through size-independent properties at the full cfg3 size.
 """
 import math
+import os
 
 import numpy as np
 import pytest
 
 import oracle_binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -741,3 +744,48 @@ def test_global_pivot_search_matches_oracle_stream(t4a):
     ro, eo = o.history()
     assert list(rg) == list(ro) and np.allclose(eg, eo, rtol=1e-9, atol=1e-15)
     assert g.termination() == o.termination()
+
+
+def test_small_problem_fill_in_one_launch_is_bitwise_the_general_path(t4a):
+    """fill_small_kernel (round 5: evaluation, zero-matrix guard, partial-pivot LU, both substitutions and packing of every site of a small
+    problem in ONE launch) claims the arithmetic of lu_kernel + trsm_left_kernel operation for operation: every site tensor of BASELINE
+    configs[1] (rank 2), of a rank-24 run with mixed local dimensions and of a run with a numerically zero pivot matrix must be BITWISE
+    what the general five-launch path produces.  The general path for small problems is only reachable in the test-hook twin of the
+    library (T4A_TEST_NO_SMALL_FILL), so both arms run in child processes on that library."""
+    import hashlib, subprocess, sys
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, "tensor4all-rs_amd/python")
+import numpy as np
+import t4a_amd as t4a
+from t4a_amd.functions import quantics_trig_exp, quantics_osc2d, lorentz
+h = hashlib.sha256()
+def run(spec, dims, opt, pivots):
+    g = t4a.TensorCI2(dims)
+    g.set_function(spec)
+    g.crossinterpolate2(pivots, opt)
+    for s in range(len(dims)):
+        h.update(np.ascontiguousarray(g.site_tensor(s)).tobytes())
+    return g.link_dims()
+o = t4a.TCI2Options(tolerance=1e-8, max_bond_dim=64, max_iter=20, nsearch=0, max_nglobal_pivot=0)
+print("cfg2", max(run(quantics_trig_exp(20), [2] * 20, o, [[0] * 20])))
+o = t4a.TCI2Options(tolerance=1e-10, max_bond_dim=24, max_iter=6, nsearch=0, max_nglobal_pivot=0)
+print("osc", max(run(quantics_osc2d(16), [2] * 16, o, [[0] * 16])))
+dims = [3, 2, 4, 5, 2, 3, 4]
+o = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=16, max_iter=5, nsearch=0, max_nglobal_pivot=0)
+print("mixed", max(run(lorentz(dims), dims, o, [[1, 1, 2, 3, 0, 2, 1]])))
+print("digest", h.hexdigest())
+'''
+    hooks = os.path.join(ROOT, "tensor4all-rs_amd", "lib", "libt4a_gpu_testhooks.so")
+    assert os.path.exists(hooks), "build.py builds the test-hook twin of the library"
+    outs = []
+    for arm in (None, "1"):
+        env = dict(os.environ, T4A_GPU_LIB=hooks)
+        if arm:
+            env["T4A_TEST_NO_SMALL_FILL"] = arm
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+        assert "digest" in r.stdout, r.stdout + r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1], outs
+    ranks = {ln.split()[0]: int(ln.split()[1]) for ln in outs[0].splitlines() if ln.split()[0] in ("cfg2", "osc", "mixed")}
+    assert ranks["cfg2"] == 2 and 8 <= ranks["osc"] <= 24 and ranks["mixed"] >= 2
