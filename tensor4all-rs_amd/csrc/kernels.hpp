@@ -518,6 +518,7 @@ bool jacobi_fits_small(int m, int n);
 void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream);
 // one full sweep = n-1 tournament rounds, one launch per round; *d_rotated is set when any pair rotated
 void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream);
+void jacobi_sweep_end_launch(int* d_flags, hipStream_t stream); // flags [0] rotated [3] converged (kernels_linalg.hip)
 // one full sweep of the BLOCKED iteration: a tournament over column blocks, one launch per block round, the pairs of a block pair
 // rotated inside one workgroup's LDS (false: the columns do not fit the LDS, nothing was launched)
 bool jacobi_block_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream);

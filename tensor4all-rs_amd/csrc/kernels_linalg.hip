@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) jacobi_round_kernel(double* W, int m, dou
                                                            int* rotated)
 {
     __shared__ double red[4];
+    if (rotated[3]) return; // (an earlier sweep of this batch found nothing to rotate: jacobi_sweep_end_kernel)
     int i, j;
     rr_pair(np, round, blockIdx.x, &i, &j);
     if (j >= n) return;
@@ -236,6 +237,7 @@ __global__ void __launch_bounds__(BW * 64 < 256 ? 256 : BW * 64) jacobi_block_ke
 #else
 #define JSTAMP(k) do {} while (0)
 #endif
+    if (rotated[3]) return; // (an earlier sweep of this batch found nothing to rotate: jacobi_sweep_end_kernel)
     int bi, bj;
     rr_pair(nbp, round, blockIdx.x, &bi, &bj);
     // global column of local column c (a block beyond the matrix, the tail of the last block: no column)
@@ -556,6 +558,16 @@ __global__ void __launch_bounds__(256) svd_complete_kernel(double* U, int m, int
         __syncthreads();
         if (threadIdx.x == 0) dead[j] = 0;
         __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64) jacobi_sweep_end_kernel(int* flags)
+{
+    if (threadIdx.x == 0) {
+        if (flags[3] == 0) {
+            if (flags[0] == 0) flags[3] = 1;
+            else flags[0] = 0;
+        }
     }
 }
 
@@ -931,6 +943,14 @@ void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hip
     if (T > 1024) T = 1024;
     hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(T), use_lds ? bytes : 0, stream, W, m, V, n, np, max_sweeps,
                        use_lds);
+}
+
+// flags: [0] a pair rotated in the running sweep [3] converged.  Behind every sweep: a sweep without a rotation sets [3] — every kernel of a
+// later sweep of the same batch returns at once —, otherwise [0] is cleared for the next one.  The host looks at the flags once per BATCH of
+// sweeps instead of once per sweep (a copy and a stream synchronisation: ~50 us each, eleven of them in a 256-column decomposition).
+void jacobi_sweep_end_launch(int* d_flags, hipStream_t stream)
+{
+    hipLaunchKernelGGL(jacobi_sweep_end_kernel, dim3(1), dim3(64), 0, stream, d_flags);
 }
 
 void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream)
