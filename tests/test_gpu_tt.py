@@ -507,6 +507,24 @@ def test_svd_and_qr_on_odd_and_ragged_shapes(t4a, shape):
         assert np.abs(q.T @ q - np.eye(k)).max() < 1e-11 and np.abs(np.tril(r, -1)).max() == 0.0
 
 
+@pytest.mark.parametrize("shape", [(1000, 40), (1025, 33), (2000, 24), (3001, 17), (24, 2000), (9000, 20)])
+def test_svd_and_qr_of_tall_and_skinny_matrices(t4a, shape):
+    """Fewer than 64 columns: no QR preconditioner, the blocked Jacobi works on the long columns themselves — block width 8 with the 1 024-row
+    register window (1 000 rows), narrower blocks with a tail beyond the window (1 025, 2 000, 3 001 rows: block width 8 / 4 / 2), columns too long
+    for the LDS (9 000 rows: one launch per tournament round); the QR panels of more than 560 rows are factorised in global memory."""
+    rng = np.random.default_rng(shape[0] + shape[1])
+    a = rng.standard_normal(shape)
+    k = min(shape)
+    u, s, vt = t4a.svd_backend(a)
+    sref = np.linalg.svd(a, compute_uv=False)
+    assert np.abs(s - sref).max() <= 1e-12 * sref[0]
+    assert np.abs((u * s) @ vt - a).max() <= 1e-12 * sref[0] * k
+    assert np.abs(u.T @ u - np.eye(k)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(k)).max() < 1e-10
+    q, r = t4a.qr_backend(a)
+    assert np.abs(q @ r - a).max() <= 1e-12 * sref[0] * k
+    assert np.abs(q.T @ q - np.eye(k)).max() < 1e-11 and np.abs(np.tril(r, -1)).max() == 0.0
+
+
 @pytest.mark.parametrize("shape", [(200, 100), (100, 200), (128, 128)])
 def test_preconditioned_svd_on_rank_deficient_and_graded_inputs(t4a, shape):
     """Engine::svd runs the Jacobi iteration on L = R^T of a Householder QR from 64 columns on (round 5): exact rank deficiency (zero
