@@ -1734,6 +1734,15 @@ static bool convergence_criterion(const std::vector<size_t>& ranks, const std::v
 }
 
 // optimize_with_finder (tensorci2.rs:1626-1802)
+// T4A_OPT_PROF=1: host time of the pieces of an iteration (microseconds, accumulated; printed by optimize())
+static double g_opt_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+struct OptSeg {
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    explicit OptSeg(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~OptSeg() { g_opt_seg[k] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 // optimize_with_finder (tensorci2.rs:1626-1802) as a resumable run: opt_begin, then per iteration opt_iter_start (prelude + the
 // half-sweep enqueued as a bond chain, without waiting) and opt_iter_finish (the rest of the iteration), then opt_end.  optimize()
 // drives one handle; optimize_group() drives up to eight in lock-step from one host thread — every handle's chain runs on its
@@ -1819,6 +1828,7 @@ bool Tci2::opt_iter_start(OptRun& r, bool defer_launch)
         // the history (:1686-1689).  After a bond chain only codes and counts are current: the entry carries those.
         long ext_idx = (!options.strictly_nested && !history.empty()) ? (long)history.size() - 1 : -1;
         {
+            OptSeg seg_(0);
             HistEntry cur;
             cur.serial = ++chain_.hist_serial;
             if (chain_.digits_stale) {
@@ -1847,11 +1857,14 @@ bool Tci2::opt_iter_start(OptRun& r, bool defer_launch)
                 if (ext_idx >= 0) --ext_idx;
             }
         }
-        invalidate_site_tensors();
-        flush_pivot_errors();
-        last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
-        prep_.valid = false;
-        invalidate_fill_cache();
+        {
+            OptSeg seg_(1);
+            invalidate_site_tensors();
+            flush_pivot_errors();
+            last_sweep_shapes.assign(n_ - 1, {0, 0, 0});
+            prep_.valid = false;
+            invalidate_fill_cache();
+        }
         const bool fill_ahead = fn_kind_ == FnKind::Builtin && options.pivot_search == 0;
         // a fill deferred by the previous iteration is issued from the hook of the 9th bond of this half-sweep (the
         // first kernels that are long enough to hide the host work); shorter chains: from the last bond
@@ -1867,7 +1880,10 @@ bool Tci2::opt_iter_start(OptRun& r, bool defer_launch)
         r.fill_ahead = fill_ahead;
         r.flush_at_fwd = flush_at_fwd;
         r.flush_at_bwd = flush_at_bwd;
-        r.chained = chain_enqueue(is_forward, options, ext_idx, true, !defer_launch);
+        {
+            OptSeg seg_(2);
+            r.chained = chain_enqueue(is_forward, options, ext_idx, true, !defer_launch);
+        }
     return true;
 }
 
@@ -1904,8 +1920,12 @@ void Tci2::opt_iter_finish(OptRun& r)
     const long ext_idx = r.ext_idx;
     const size_t flush_at_fwd = r.flush_at_fwd, flush_at_bwd = r.flush_at_bwd;
     do { // (one pass; `break` = the convergence exit of the reference's loop)
-        opt_iter_issue_pending_fill(r);
+        {
+            OptSeg seg_(3);
+            opt_iter_issue_pending_fill(r);
+        }
         if (chained) {
+            OptSeg seg_(4);
             chain_finish(options);
         } else {
             // ... otherwise bond by bond
@@ -1960,6 +1980,7 @@ void Tci2::opt_iter_finish(OptRun& r)
             fill_no_main_sync_ = chained && chain_.digits_stale;
             fill_site_tensors_impl(fill_async);
         }
+        OptSeg seg_tail_(5);
         const double error = max_bond_error();
         errors_hist.push_back(error / norm);
 
@@ -2034,6 +2055,10 @@ void Tci2::optimize(const TCI2Options& options, bool final_sweep1site)
                 t_finish += std::chrono::duration<double>(tc - tb).count();
                 ++iters;
             }
+            std::fprintf(stderr, "[t4a] optimize segments (us per iteration): history snapshot %.1f, invalidate + flush %.1f, chain_enqueue %.1f | pending fill %.1f, chain_finish incl. the wait %.1f, error + global pivots + convergence %.1f\n",
+                         g_opt_seg[0] / std::max<size_t>(iters, 1), g_opt_seg[1] / std::max<size_t>(iters, 1), g_opt_seg[2] / std::max<size_t>(iters, 1), g_opt_seg[3] / std::max<size_t>(iters, 1),
+                         g_opt_seg[4] / std::max<size_t>(iters, 1), g_opt_seg[5] / std::max<size_t>(iters, 1));
+            for (double& v : g_opt_seg) v = 0.0;
             const double wait = g_chain_wait_seconds - wait0;
             std::fprintf(stderr, "[t4a] optimize: %zu iterations: start (prepare + launch the chain) %.1f us, finish %.1f us of which waiting for the device %.1f us, per iteration\n",
                          iters, 1e6 * t_start / std::max<size_t>(iters, 1), 1e6 * t_finish / std::max<size_t>(iters, 1), 1e6 * wait / std::max<size_t>(iters, 1));
