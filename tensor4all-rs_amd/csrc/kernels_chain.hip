@@ -422,19 +422,22 @@ __device__ __forceinline__ void chain_mirror_body(const ChainCommon& c, int nb)
     const int K = c.K;
     const size_t cap = (size_t)c.cap;
     const int gtid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsz = (int)(gridDim.x * blockDim.x);
-    for (int site = 0; site <= nb; ++site) {
-        for (int fam = 0; fam < 2; ++fam) {
-            if ((fam == 0 && site == 0) || (fam == 1 && site == nb)) continue; // (I_0 and J_{n-1} are never written)
-            const ChainTab& T = fam == 0 ? c.I : c.J;
-            const ChainTab& Mr = fam == 0 ? c.mI : c.mJ;
-            const int cnt = __hip_atomic_load(T.cnt + site, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cnt < 0 || cnt > c.cap) continue;
-            for (int e = gtid; e < cnt * (1 + K); e += gsz) {
-                if (e < cnt) Mr.code[(size_t)site * cap + e] = T.code[(size_t)site * cap + e];
-                else Mr.acc[(size_t)site * cap * K + (e - cnt)] = T.acc[(size_t)site * cap * K + (e - cnt)];
-            }
-            if (gtid == 0) Mr.cnt[site] = cnt;
+    // a WAVE per (site, family): its lanes copy the entries, the count is one load per wave.  (Round 5: as one loop over the 2 (nb + 1)
+    // tables with every thread of the grid reading every count in turn, the copy was 38 dependent device-scope loads long at d = 20 —
+    // ~20 of the 135 us of a persistent half-sweep of configs[1].)
+    const int lane = (int)(threadIdx.x & 63), gwave = gtid >> 6, nwaves = gsz >> 6;
+    for (int pf = gwave; pf < 2 * (nb + 1); pf += nwaves) {
+        const int site = pf >> 1, fam = pf & 1;
+        if ((fam == 0 && site == 0) || (fam == 1 && site == nb)) continue; // (I_0 and J_{n-1} are never written)
+        const ChainTab& T = fam == 0 ? c.I : c.J;
+        const ChainTab& Mr = fam == 0 ? c.mI : c.mJ;
+        const int cnt = __hip_atomic_load(T.cnt + site, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cnt < 0 || cnt > c.cap) continue;
+        for (int e = lane; e < cnt * (1 + K); e += 64) {
+            if (e < cnt) Mr.code[(size_t)site * cap + e] = T.code[(size_t)site * cap + e];
+            else Mr.acc[(size_t)site * cap * K + (e - cnt)] = T.acc[(size_t)site * cap * K + (e - cnt)];
         }
+        if (lane == 0) Mr.cnt[site] = cnt;
     }
     if (c.hdims)
         for (int e = gtid; e < nb * 4; e += gsz)
