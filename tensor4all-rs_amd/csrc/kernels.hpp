@@ -372,6 +372,9 @@ void chain_walk_launch(const ChainCommon& c, const FnDevice& fn, const ChainWalk
 void chain_indep_launch(const ChainCommon& c, int n_bonds, hipStream_t stream);
 // behind a chain whose preparations ran with defer_host_writes: tables -> pinned mirrors, dims -> hdims, in one launch
 void chain_mirror_launch(const ChainCommon& c, int n_bonds, hipStream_t stream);
+// forward 1-site sweep with update_tensors: the LAST site's tensor Pi1 = f(kron(I_{n-1}, d_{n-1}), J_{n-1}) (tensorci2.rs:902-912, fill_tensor
+// :813-850), evaluated from the device tables right behind the chain — core[l + L (s + S r)], L = |I_{n-1}| as the chain left it
+void chain_last_core_launch(const ChainCommon& c, const FnDevice& fn, double* core, int max_entries, hipStream_t stream);
 void chain_prep_launch(const ChainCommon& c, const ChainPrepArgs& a, hipStream_t stream);
 // n_dep_ub / n_ind_ub: upper bounds for the launch grid (the kernel reads the real sizes on the device)
 void chain_pi_launch(const ChainCommon& c, const FnDevice& fn, int b, int n_dep_ub, int n_ind_ub, double* out, hipStream_t stream);

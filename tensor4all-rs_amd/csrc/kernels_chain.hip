@@ -445,6 +445,25 @@ __device__ __forceinline__ void chain_mirror_body(const ChainCommon& c, int nb)
 }
 __global__ void __launch_bounds__(1024) chain_mirror_kernel(ChainCommon c, int nb) { chain_mirror_body(c, nb); }
 
+// the last site's tensor of a forward 1-site sweep, straight from the tables (see kernels.hpp): value = f(acc(I_{n-1}[l]) + w[s] + acc(J_{n-1}[r])),
+// the accumulator sums of pi_eval_kernel over the rows kron(I_{n-1}, d_{n-1}) (parent outer, digit inner) and the columns J_{n-1}
+__global__ void __launch_bounds__(256) chain_last_core_kernel(ChainCommon c, FnDevice fn, double* __restrict__ core, int max_entries)
+{
+    const int site = c.n_sites - 1, K = c.K;
+    const size_t cap = (size_t)c.cap;
+    const int L = c.I.cnt[site], R = c.J.cnt[site], S = c.ldim[site], woff = c.woff[site];
+    if (L < 1 || L > c.cap || R < 1 || R > c.cap || S < 1) return;
+    const long long total = (long long)L * S * R;
+    if (total > (long long)max_entries) return; // (cannot happen: the buffer is sized for the upper bounds of the plan)
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(e % L), s_ = (int)((e / L) % S), r = (int)(e / ((long long)L * S));
+        uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
+        for (int q = 0; q < K; ++q)
+            acc[q] = c.I.acc[((size_t)site * cap + l) * K + q] + c.w[(size_t)q * c.total + woff + s_] + c.J.acc[((size_t)site * cap + r) * K + q];
+        core[e] = t4a_fn_value(fn.fid, acc, fn.params);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The persistent half-sweep ("walker"): ONE workgroup walks all bonds of a half-sweep whose matrices fit the one-wave rrLU kernel
 // (at most 64 x 64: BASELINE configs[1], the first iterations of every run).  Per bond: the preparation above, the candidate
@@ -843,6 +862,12 @@ void chain_walk_launch(const ChainCommon& c, const FnDevice& fn, const ChainWalk
     if (columns <= 8) chain_walk_launch_nc<8>(c, fn, w, stream);
     else if (columns <= 16) chain_walk_launch_nc<16>(c, fn, w, stream);
     else chain_walk_launch_nc<32>(c, fn, w, stream);
+}
+
+void chain_last_core_launch(const ChainCommon& c, const FnDevice& fn, double* core, int max_entries, hipStream_t stream)
+{
+    const int blocks = max_entries > 256 * 64 ? 64 : (max_entries + 255) / 256;
+    hipLaunchKernelGGL(chain_last_core_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, c, fn, core, max_entries);
 }
 
 void chain_mirror_launch(const ChainCommon& c, int n_bonds, hipStream_t stream)

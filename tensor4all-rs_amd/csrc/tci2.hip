@@ -906,17 +906,19 @@ void Tci2::sweep1site(bool forward, double rel_tol, double abs_tol, size_t max_b
         for (size_t b = n_ - 1; b >= 1; --b) sweep1site_at_bond(b, false, rel_tol, abs_tol, max_bond_dim, update_tensors);
     }
     if (update_tensors) { // tensorci2.rs:902-912 + fill_tensor :813-850
-        sync_digits();
         const size_t last = forward ? n_ - 1 : 0;
-        IndexSet rows = kronecker_i(last);
-        const IndexSet& jl = j_set[last];
-        const size_t A = i_set[last].count, S = local_dims[last], C = jl.count;
+        const bool on_device = chained && forward && chain_.last_core_ok; // (evaluated from the tables behind the chain: chain_last_core_kernel)
+        chain_.last_core_ok = false;
+        const size_t A = i_set[last].count, S = local_dims[last], C = j_set[last].count; // (counts are current behind a chain, digits need not be)
         DevCore& c = cores[last];
-        c.buf.reserve(std::max<size_t>(A * S * C, 1));
+        if (!on_device) c.buf.reserve(std::max<size_t>(A * S * C, 1));
         c.l = A;
         c.s = S;
         c.r = C;
-        if (A * S * C > 0) {
+        if (A * S * C > 0 && !on_device) {
+            sync_digits();
+            IndexSet rows = kronecker_i(last);
+            const IndexSet& jl = j_set[last];
             double* d_m = eng.pi(A * S * C);
             eval_matrix(rows, 0, jl, rows.width, d_m, nullptr);
             hipLaunchKernelGGL(pack_left_core_kernel, dim3(blocks_for(c.size())), dim3(256), 0, eng.stream(), d_m,

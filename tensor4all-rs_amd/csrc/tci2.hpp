@@ -298,6 +298,7 @@ private:
         DevBuf<double> factors, urows; // [n_bonds][factors_stride] factored matrices; finished rows of U of the bond in flight
         size_t factors_stride = 0;
         bool cores_batched = false;  // the chain in flight writes the site tensors of its low-rank bonds itself (one launch behind it)
+        bool last_core_launched = false, last_core_ok = false; // forward 1-site chain: the last site's tensor was evaluated behind the chain / the whole chain completed, it is valid
         DevBuf<unsigned long long> walk_dbg; // diagnostic phase times of the persistent half-sweep (T4A_WALK_DEBUG)
         bool walked = false;         // the chain in flight is a persistent half-sweep
         bool prep_dbg = false;       // ... or a launched chain whose preparation kernels stamp their phases (T4A_PREP_DEBUG)

@@ -678,6 +678,20 @@ void Tci2::chain_launch()
             luci_left_cores_batched_launch(jobs, (int)nb, (int)max_rows, st);
             chain_.cores_batched = true;
         }
+        chain_.last_core_launched = false;
+        static const bool no_last_core = diag_env("T4A_NO_CHAIN_LAST_CORE") != nullptr;
+        if (chain_.one_site && chain_.factors_stride && forward && !no_last_core) {
+            // ... and the last site's tensor (tensorci2.rs:902-912): I_{n-1} is final behind the last bond; evaluated from the tables, no
+            // host round trip (accumulators built on the host, staged, evaluated, packed, synchronised: ~50 us of a small solve)
+            const size_t last = n_ - 1;
+            const size_t a_ub = std::max<size_t>(std::min({dep_ub[nb - 1], ind_ub[nb - 1], chi}), 1);
+            const size_t entries = a_ub * local_dims[last] * std::max<size_t>(j_set[last].count, 1);
+            if (entries <= ((size_t)1 << 24)) {
+                cores[last].buf.reserve(entries);
+                chain_last_core_launch(c, fn_dev_, cores[last].buf.get(), (int)entries, st);
+                chain_.last_core_launched = true;
+            }
+        }
         if (!per_launch_mirror)
             T4A_HIP(hipMemcpyAsync(chain_.hblocks.get(), chain_.blocks.get(), nb * proto.bytes, hipMemcpyDeviceToHost, st));
         T4A_HIP(hipGetLastError());
@@ -1046,6 +1060,8 @@ void Tci2::chain_finish(const TCI2Options& options)
             }
         }
     }
+    chain_.last_core_ok = chain_.last_core_launched && failed_k < 0; // (a chain that stopped early left I_{n-1} unfinished: the host path evaluates the last site)
+    chain_.last_core_launched = false;
     if (failed_k < 0) {
         if (chain_.one_site) {
             ++chain_stats_ext[1];
