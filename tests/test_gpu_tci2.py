@@ -255,7 +255,7 @@ def test_cfg2_small_problem_parity_and_launch_bound_budget(t4a):
     # (~5 us preparation + 1.3 us candidate matrix + 2.5 us rrLU per bond) + three fills: 1.05 ms measured at the end of round 4
     # (best of five; 4.4 ms in round 1, 1.7 in round 2, 1.5 in round 3, 1.45 before the persistent workgroup).  The bound is a
     # regression guard (the round-3 review asked for one close to the measured value); the 0.5 ms asked for is NOT met.
-    # (round 5: 0.71 - 0.73 ms measured; 1.5 ms = twice that: one bench run on a shared box once reported twice the usual value as its best of three)
+    # (round 5: 0.69 - 0.73 ms measured; 1.5 ms = twice that: one bench run on a shared box once reported twice the usual value as its best of three)
     assert best < 1.5e-3, f"cfg2 time to solution {best * 1e3:.2f} ms"
 
 
