@@ -128,7 +128,9 @@ t4a_gpu_status t4a_gpu_trsm_f64(const double* a, size_t na, const double* b, siz
 t4a_gpu_status t4a_gpu_solve_f64(const double* a, size_t n, const double* b, size_t nrhs, double* x);
 
 /* svd_backend(&a) (tensorbackend/src/backend.rs:709-731): thin SVD, k = min(m,n); u is m x k, s has k entries in
- * non-increasing order, vt is k x n ("backend convention", simplett/src/compression.rs:254-287).  One-sided Jacobi.
+ * non-increasing order, vt is k x n ("backend convention", simplett/src/compression.rs:254-287).  One-sided Jacobi
+ * (from 64 columns on: on the transposed triangular factor of a Householder QR); a column pair rotates while the cosine of its
+ * angle exceeds sqrt(rows) * eps (LAPACK dgesvj's rule): reconstruction and singular values to ~1e-14 relative to the largest.
  * Returns T4A_GPU_INVALID_ARGUMENT for an empty or non-finite matrix. */
 t4a_gpu_status t4a_gpu_svd_f64(const double* a, size_t m, size_t n, double* u, double* s, double* vt);
 
