@@ -45,9 +45,11 @@ fi
 timeout 600 python3 tools/probe_cfg4_variants.py > $O/cfg4_variants.txt 2>&1
 timeout 300 python3 tools/probe_cfg5_variants.py > $O/cfg5_variants.txt 2>&1
 timeout 1500 python3 tools/bench_components.py > $O/components.json 2> $O/components.err
+if [ -f tensor4all-rs_amd/lib/libt4a_gpu_alt.so ]; then  # (tools/build_stamps_lib.sh)
 for sh in "1464 1448 256" "1428 1024 256" "1424 512 256"; do
   T4A_GPU_LIB=$GRAFT_REPO_ROOT/tensor4all-rs_amd/lib/libt4a_gpu_alt.so T4A_RRLU_STAMPS=1 timeout 120 python3 tools/probe_xcd.py child $sh 1 2>&1 | grep "stamps xcd" | tail -1
 done > $O/xcd2m_phase_stamps.txt
+fi
 # keep only the summaries (the merge back is limited to 64 MiB)
 rm -rf $O/fillstats $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_sq $O/gemm
 ls -la $O | head -40
