@@ -525,6 +525,20 @@ def test_svd_and_qr_of_tall_and_skinny_matrices(t4a, shape):
     assert np.abs(q.T @ q - np.eye(k)).max() < 1e-11 and np.abs(np.tril(r, -1)).max() == 0.0
 
 
+def test_svd_and_qr_are_deterministic(t4a):
+    """The same matrix twice: bitwise the same factors (the blocked Jacobi's tournament is fixed, its sweeps run in batches behind a
+    device-side flag, the QR panel's tasks are assigned statically — no result may depend on which workgroup finishes first)."""
+    rng = np.random.default_rng(77)
+    for shape in [(300, 200), (64, 64), (40, 130), (1025, 33)]:
+        a = rng.standard_normal(shape)
+        u1, s1, v1 = t4a.svd_backend(a)
+        u2, s2, v2 = t4a.svd_backend(a)
+        assert np.array_equal(u1, u2) and np.array_equal(s1, s2) and np.array_equal(v1, v2)
+        q1, r1 = t4a.qr_backend(a)
+        q2, r2 = t4a.qr_backend(a)
+        assert np.array_equal(q1, q2) and np.array_equal(r1, r2)
+
+
 @pytest.mark.parametrize("shape", [(200, 100), (100, 200), (128, 128)])
 def test_preconditioned_svd_on_rank_deficient_and_graded_inputs(t4a, shape):
     """Engine::svd runs the Jacobi iteration on L = R^T of a Householder QR from 64 columns on (round 5): exact rank deficiency (zero
