@@ -228,6 +228,7 @@ struct WalkShared {
     uint64_t ind_code[2][WALK_MAX_IND], ind_acc[2][WALK_MAX_IND * T4A_FN_MAX_ACC];
     uint64_t ext_code[2][WALK_MAX_LIST], ext_acc[2][WALK_MAX_LIST * T4A_FN_MAX_ACC];
     int ext_cnt[2];
+    int ldim[WALK_MAX_BONDS + 1], woff[WALK_MAX_BONDS + 1]; // ChainCommon::ldim / woff (read once per bond by the preparation: a scalar load that misses every time)
     uint64_t w[WALK_MAX_W];
 };
 
@@ -477,10 +478,15 @@ __global__ void __launch_bounds__(256) chain_last_core_kernel(ChainCommon c, FnD
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void walk_phase_barrier(bool scalar_cache = true)
 {
-    __syncthreads();
-    if (scalar_cache) { // (not needed once everything that passes from phase to phase sits in the LDS: the one-wave preparation)
+    if (scalar_cache) {
+        __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+        // (everything that passes from phase to phase sits in the LDS — the one-wave preparation —: the barrier orders the LDS only.  A
+        // full __syncthreads also waits for every outstanding global store — the tables and the result block a bond leaves behind are
+        // written for the host and for later kernels — vmcnt(0): an acknowledgement from the L2, twice per bond)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 __device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -669,6 +675,12 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
     cw.dep_cap = WALK_MAX_LIST;
     for (int e = tid; e < nb * 4; e += (int)blockDim.x) ws->dims[e] = 0;
     for (int e = tid; e < nb; e += (int)blockDim.x) ws->ind_cnt[e] = c.ind_cnt[e];
+    for (int e = tid; e <= nb; e += (int)blockDim.x) { // (nb + 1 sites)
+        ws->ldim[e] = c.ldim[e];
+        ws->woff[e] = c.woff[e];
+    }
+    cw.ldim = ws->ldim;
+    cw.woff = ws->woff;
     {   // the functor's weights (K rows of `total` entries), when they fit
         const int nw = c.K * c.total;
         if (nw <= WALK_MAX_W) {
