@@ -489,6 +489,10 @@ __device__ __forceinline__ void walk_phase_barrier(bool scalar_cache = true)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
+// x / d for 0 <= x < 8192, 1 <= d <= 128 through the single-precision reciprocal (rd = 1.0f / d, correctly rounded): (x + 0.5) / d stays at least
+// 0.5 / 128 away from every integer, three orders of magnitude more than the rounding of two float operations — checked exhaustively on the host.
+// (A run-time 32-bit division is ~35 instructions on this ISA, a 64-bit one well over a hundred: a lone wave pays ~10 cycles for each.)
+__device__ __forceinline__ int walk_div_small(int x, float rd) { return (int)(((float)x + 0.5f) * rd); }
 __device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // The preparation of a bond of the persistent half-sweep by ONE wave, without a barrier (lists of at most 64 entries: a lane per
@@ -573,7 +577,9 @@ __device__ __forceinline__ void walk_prep_wave0(const ChainCommon& c, WalkShared
     if (np >= 1 && np <= c.cap && np <= WALK_MAX_LIST && ne >= 0 && ne <= c.cap && ne <= WALK_MAX_LIST && m0 <= WALK_MAX_LIST) {
         uint64_t oc = 0, oa[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
         if (lane < m0) { // rows: (parent outer, digit inner), columns: (digit outer, parent inner)
-            const int i = FORWARD ? lane / d : lane % np, sdig = FORWARD ? lane % d : lane / np;
+            const int qd = walk_div_small(lane, 1.0f / (float)(FORWARD ? d : np)); // lane / d (forward) or lane / np
+            const int rd_ = lane - qd * (FORWARD ? d : np);
+            const int i = FORWARD ? qd : rd_, sdig = FORWARD ? rd_ : qd;
             oc = (uint64_t)sdig + (uint64_t)d * ws->par_code[i];
             for (int q = 0; q < K; ++q) oa[q] = ws->par_acc[(size_t)i * K + q] + c.w[(size_t)q * c.total + woff + sdig];
         }
@@ -581,9 +587,10 @@ __device__ __forceinline__ void walk_prep_wave0(const ChainCommon& c, WalkShared
         uint64_t xc = 0;
         if (lane < ne) {
             xc = ws->ext_code[b & 1][lane];
-            const uint64_t parent = xc / (uint64_t)d;
+            // xc / d == parent  <=>  parent d <= xc < parent d + d (no 64-bit division; a code times a local dimension does not overflow:
+            // it is the code of a child)
             keep = true;
-            for (int pi = 0; pi < np; ++pi) keep = keep && (ws->par_code[pi] != parent);
+            for (int pi = 0; pi < np; ++pi) keep = keep && !((xc - ws->par_code[pi] * (uint64_t)d) < (uint64_t)d);
         }
         const unsigned long long km = __ballot(keep);
         const int nkeep = __builtin_popcountll(km);
@@ -726,8 +733,9 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
         if (runs) {
             const int K = fn.n_acc;
             const uint64_t* ia = ws->ind_acc[b & 1];
+            const float rnd = 1.0f / (float)nd;
             for (int idx = tid; idx < nd * ni; idx += (int)blockDim.x) {
-                const int i = idx % nd, j = idx / nd;
+                const int j = walk_div_small(idx, rnd), i = idx - j * nd; // (nd <= 64, idx < 64 * 32)
                 uint64_t acc[T4A_FN_MAX_ACC] = {0, 0, 0, 0};
                 for (int q = 0; q < K; ++q) acc[q] = ws->dep_acc[(size_t)i * K + q] + ia[(size_t)j * K + q];
                 pi[idx] = t4a_fn_value(fn.fid, acc, fn.params);
