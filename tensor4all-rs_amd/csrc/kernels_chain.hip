@@ -502,8 +502,9 @@ __device__ __forceinline__ int walk_load_i32(const int* p) { return __hip_atomic
 // whose hash and prefix sum over 1 024 threads cost five barriers and ~3 - 4.5 us per bond for lists of a handful of entries.
 // Membership of an extra in the Kronecker part = its parent code is one of the gathered parents (a loop over <= 64 LDS broadcasts).
 template <bool FORWARD>
-__device__ __forceinline__ void walk_prep_wave0(const ChainCommon& c, WalkShared* ws, int b, int prev_b, unsigned prev_token, bool do_build)
+__device__ __forceinline__ void walk_prep_wave0(const ChainCommon& c, WalkShared* ws, int b, int prev_b, unsigned prev_token, bool do_build, unsigned long long* dbg = nullptr)
 {
+    const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
     const int lane = threadIdx.x & 63;
     const int K = c.K;
     const size_t cap = (size_t)c.cap;
@@ -551,6 +552,8 @@ __device__ __forceinline__ void walk_prep_wave0(const ChainCommon& c, WalkShared
             np = cnt;
         }
     }
+    const unsigned long long dbg_t1 = dbg ? wall_clock64() : 0ull;
+    if (dbg && (threadIdx.x & 63) == 0) dbg[4] += dbg_t1 - dbg_t0; // (T4A_WALK_DEBUG: the gather)
     if (!do_build) return;
     int* const dims = ws->dims + b * 4;
     if (poison) {
@@ -615,7 +618,7 @@ __device__ __forceinline__ void walk_prep_wave0(const ChainCommon& c, WalkShared
         dims[1] = ok ? (FORWARD ? ni : nd) : 0;
         dims[2] = ok ? 0 : 1;
         dims[3] = ok ? nd : 0;
-    }
+    }    if (dbg && lane == 0) dbg[5] += wall_clock64() - dbg_t1; // (T4A_WALK_DEBUG: the dependent list)
 }
 
 // the static inputs of bond b (independent list, history extras) into slot b & 1 of the LDS, by threads first .. first + count - 1
@@ -719,7 +722,7 @@ __global__ void __launch_bounds__(WALK_T) chain_walk_kernel(ChainCommon c, FnDev
             pa.prev_token = w.token_base + (unsigned)(k - 1);
         }
         if (w.lean_prep) {
-            if (tid < 64) walk_prep_wave0<FORWARD>(cw, ws, b, pa.prev_b, pa.prev_token, k < nb);
+            if (tid < 64) walk_prep_wave0<FORWARD>(cw, ws, b, pa.prev_b, pa.prev_token, k < nb, w.phase_ticks);
         } else {
             chain_prep_body(cw, pa, w.phase_ticks, ws);
         }
