@@ -134,6 +134,8 @@ struct RookDenseArgs {
     int* piv;        // kcap
     double* dres;    // [0] last error [1] sampled max [2] evaluated entries [3 + k] accepted pivot errors
     int* ires;       // [0] rank [1] info [2] visits
+    double* packed;  // everything the host reads, in one block: [0 .. kcap + 2] dres, then as ints [0..3] ires, [4 ..] I, [4 + kcap ..] J
+    int kcap;
 };
 
 __device__ inline void rook_block_argmax(double bv, int bi, double* s_v, int* s_i, double* out_v, int* out_i)
@@ -433,6 +435,16 @@ __global__ void __launch_bounds__(1024) rook_dense_kernel(RookDenseArgs a)
         a.dres[1] = mx;
         a.dres[2] = evals;
     }
+    __syncthreads();
+    if (a.packed) { // one block for the host (one copy into pinned memory instead of four into pageable vectors)
+        int* const pi_ = reinterpret_cast<int*>(a.packed + a.kcap + 3);
+        for (int e = tid; e < a.kcap + 3; e += NT) a.packed[e] = (e < 3 + k) ? a.dres[e] : 0.0;
+        if (tid < 3) pi_[tid] = a.ires[tid];
+        for (int e = tid; e < a.kcap; e += NT) {
+            pi_[4 + e] = e < k ? a.I[e] : 0;
+            pi_[4 + a.kcap + e] = e < k ? a.J[e] : 0;
+        }
+    }
     (void)s_dbl;
 }
 
@@ -477,10 +489,13 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
     w.maxbits.reserve(1);
     w.lup.reserve(1);
     w.trp.reserve(4);
-    T4A_HIP(hipMemsetAsync(w.rowsel.get(), 0, sizeof(int) * M, st));
-    T4A_HIP(hipMemsetAsync(w.colsel.get(), 0, sizeof(int) * N, st));
-    T4A_HIP(hipMemsetAsync(w.maxbits.get(), 0, sizeof(unsigned long long), st));
-    T4A_HIP(hipMemsetAsync(w.info.get(), 0, sizeof(int), st));
+    const bool device_search_planned = (bool)src.full && kcap <= 256 && (long long)M * N <= (1ll << 24);
+    if (!device_search_planned) { // (the device-resident search clears its flags itself; lu_kernel sets its own status)
+        T4A_HIP(hipMemsetAsync(w.rowsel.get(), 0, sizeof(int) * M, st));
+        T4A_HIP(hipMemsetAsync(w.colsel.get(), 0, sizeof(int) * N, st));
+        T4A_HIP(hipMemsetAsync(w.maxbits.get(), 0, sizeof(unsigned long long), st));
+        T4A_HIP(hipMemsetAsync(w.info.get(), 0, sizeof(int), st));
+    }
 
     std::vector<char> col_seen(N, 0), row_seen(M, 0), row_sel(M, 0), col_sel(N, 0);
     size_t n_rows_seen = 0, n_cols_seen = 0;
@@ -582,7 +597,7 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
     // ---- device-resident search (round 5): sources that can put the whole matrix into device memory run the pivot loop as ONE
     // persistent launch; the host reads the selection back with a single synchronisation (the launch-per-visit loop below costs two
     // per visited column / row pair: 54 ms for BASELINE configs[1] against 0.4 ms on one CPU core, tools/bench_components.py)
-    bool device_search = (bool)src.full && kcap <= 256 && (long long)M * N <= (1ll << 24);
+    bool device_search = device_search_planned;
     double device_mx = 0.0;
     if (device_search) {
         src.full(w.A.get());
@@ -609,15 +624,19 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
         ka.piv = w.piv.get();
         ka.dres = w.dres.get();
         ka.ires = w.ires.get();
+        const size_t packed_doubles = (size_t)kcap + 3 + ((size_t)4 + 2 * (size_t)kcap + 1) / 2;
+        w.packed.reserve(packed_doubles);
+        w.hpacked.reserve(packed_doubles);
+        ka.packed = w.packed.get();
+        ka.kcap = kcap;
         hipLaunchKernelGGL(rook_dense_kernel, dim3(1), dim3(1024), 0, st, ka);
-        int hi[3] = {0, 0, 0};
-        std::vector<double> hd((size_t)kcap + 3, 0.0);
-        std::vector<int> hI(kcap, 0), hJ(kcap, 0);
-        T4A_HIP(hipMemcpyAsync(hi, w.ires.get(), sizeof(hi), hipMemcpyDeviceToHost, st));
-        T4A_HIP(hipMemcpyAsync(hd.data(), w.dres.get(), hd.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-        T4A_HIP(hipMemcpyAsync(hI.data(), w.I.get(), sizeof(int) * kcap, hipMemcpyDeviceToHost, st));
-        T4A_HIP(hipMemcpyAsync(hJ.data(), w.J.get(), sizeof(int) * kcap, hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipMemcpyAsync(w.hpacked.get(), w.packed.get(), packed_doubles * sizeof(double), hipMemcpyDeviceToHost, st));
         T4A_HIP(hipStreamSynchronize(st));
+        const double* const hd = w.hpacked.get();
+        const int* const hpi = reinterpret_cast<const int*>(hd + kcap + 3);
+        const int hi[3] = {hpi[0], hpi[1], hpi[2]};
+        const int* const hI = hpi + 4;
+        const int* const hJ = hpi + 4 + kcap;
         T4A_HIP(hipGetLastError());
         ++w.n_device_searches;
         w.n_device_visits += (size_t)hi[2];

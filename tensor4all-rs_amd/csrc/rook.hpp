@@ -30,6 +30,8 @@ struct RookWork { // grow-only scratch, reusable across calls
     DevBuf<double> dres;   // device-resident search: [0] last error [1] sampled max [2] evaluated entries [3..] accepted pivot errors
     DevBuf<int> ires;      // [0] rank [1] LU info (singular pivot block) [2] host syncs saved (visits) [4..] selected rows, then columns
     DevBuf<int> seen;      // visited flags: rows, then columns
+    DevBuf<double> packed; // device-resident search: everything the host reads as ONE block (rook_dense_kernel) ...
+    PinBuf<double> hpacked; // ... and its pinned landing place
     size_t n_device_searches = 0, n_device_visits = 0, n_host_searches = 0, n_host_syncs = 0; // statistics
     DevBuf<LuProblem> lup;
     DevBuf<TrsmProblem> trp;

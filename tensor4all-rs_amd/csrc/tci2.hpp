@@ -356,6 +356,7 @@ private:
     PinBuf<double> cb_vals_;
     DevBuf<TtCoreDesc> d_coredesc_;
     // fill_site_tensors scratch
+    PinBuf<uint64_t> h_rookacc_; // rook_on_sets: pinned staging of the row / column accumulators
     DevBuf<double> d_fillA_, d_fillB_;
     DevBuf<int> d_fillpiv_, d_fillinfo_;
     DevBuf<LuProblem> d_lup_;
