@@ -741,6 +741,16 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
             if (!col_sel[j]) out.col_perm[p++] = j;
     }
 
+    // the LU / triangular-solve descriptors of the factor build travel through pinned memory (two copies out of stack variables and a stream
+    // synchronisation before: ~40 us per bond); the staging block is free again behind the synchronisation that ends every search
+    auto upload_descriptors = [&](const LuProblem& lp_, const TrsmProblem* tp_) {
+        w.hdesc.reserve(sizeof(LuProblem) + 2 * sizeof(TrsmProblem));
+        char* const hdp = w.hdesc.get();
+        std::memcpy(hdp, &lp_, sizeof(LuProblem));
+        std::memcpy(hdp + sizeof(LuProblem), tp_, 2 * sizeof(TrsmProblem));
+        T4A_HIP(hipMemcpyAsync(w.lup.get(), hdp, sizeof(LuProblem), hipMemcpyHostToDevice, st));
+        T4A_HIP(hipMemcpyAsync(w.trp.get(), hdp + sizeof(LuProblem), 2 * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
+    };
     // CrossFactors + factors_to_public (factors.rs:58-101, matrix_luci.rs:109-135)
     eng.reserve_factors((size_t)M * std::max(rank, 1), (size_t)std::max(rank, 1) * N);
     if (rank > 0) {
@@ -775,9 +785,7 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
             tp[1] = tp[0];
             tp[1].lower = 0;
             tp[1].unit_diag = 0;
-            T4A_HIP(hipMemcpyAsync(w.lup.get(), &lp, sizeof(lp), hipMemcpyHostToDevice, st));
-            T4A_HIP(hipMemcpyAsync(w.trp.get(), tp, 2 * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
-            T4A_HIP(hipStreamSynchronize(st));
+            upload_descriptors(lp, tp);
             lu_batched_launch(w.lup.get(), 1, k, st);
             trsm_left_batched_launch(w.trp.get() + 0, 1, k, M, st);
             trsm_left_batched_launch(w.trp.get() + 1, 1, k, M, st);
@@ -808,9 +816,7 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
             tp[1] = tp[0];
             tp[1].lower = 0;
             tp[1].unit_diag = 0;
-            T4A_HIP(hipMemcpyAsync(w.lup.get(), &lp, sizeof(lp), hipMemcpyHostToDevice, st));
-            T4A_HIP(hipMemcpyAsync(w.trp.get(), tp, 2 * sizeof(TrsmProblem), hipMemcpyHostToDevice, st));
-            T4A_HIP(hipStreamSynchronize(st));
+            upload_descriptors(lp, tp);
             lu_batched_launch(w.lup.get(), 1, k, st);
             trsm_left_batched_launch(w.trp.get() + 0, 1, k, N, st);
             trsm_left_batched_launch(w.trp.get() + 1, 1, k, N, st);
@@ -818,9 +824,16 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
     }
     unsigned long long bits = 0;
     int hinfo = 0;
-    T4A_HIP(hipMemcpyAsync(&bits, w.maxbits.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
-    T4A_HIP(hipMemcpyAsync(&hinfo, w.info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
-    T4A_HIP(hipStreamSynchronize(st));
+    {   // (into pinned memory; the sampled maximum of a device-resident search came back with its result block)
+        w.hfin.reserve(2);
+        unsigned long long* const hf = w.hfin.get();
+        hf[0] = hf[1] = 0ull;
+        if (!device_search) T4A_HIP(hipMemcpyAsync(hf, w.maxbits.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipMemcpyAsync(hf + 1, w.info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
+        T4A_HIP(hipStreamSynchronize(st));
+        bits = hf[0];
+        std::memcpy(&hinfo, hf + 1, sizeof(int));
+    }
     T4A_HIP(hipGetLastError());
     if (hinfo != 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "factor solve failed: singular pivot matrix");
     double mx;

@@ -32,6 +32,8 @@ struct RookWork { // grow-only scratch, reusable across calls
     DevBuf<int> seen;      // visited flags: rows, then columns
     DevBuf<double> packed; // device-resident search: everything the host reads as ONE block (rook_dense_kernel) ...
     PinBuf<double> hpacked; // ... and its pinned landing place
+    PinBuf<char> hdesc;     // pinned staging of the factor build's LU / triangular-solve descriptors
+    PinBuf<unsigned long long> hfin; // pinned landing place of the final {sampled maximum, LU status}
     size_t n_device_searches = 0, n_device_visits = 0, n_host_searches = 0, n_host_syncs = 0; // statistics
     DevBuf<LuProblem> lup;
     DevBuf<TrsmProblem> trp;
