@@ -441,12 +441,14 @@ void TreeTci::eval_matrix(const IndexSet& rows, const std::vector<size_t>& row_s
         accumulate(rows, row_sites, ra);
         accumulate(cols, col_sites, rb);
         d_acc_.reserve(ra.size() + rb.size());
-        T4A_HIP(hipMemcpyAsync(d_acc_.get(), ra.data(), ra.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        T4A_HIP(hipMemcpyAsync(d_acc_.get() + ra.size(), rb.data(), rb.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        h_acc_.reserve(ra.size() + rb.size());
+        std::memcpy(h_acc_.get(), ra.data(), ra.size() * sizeof(uint64_t));
+        std::memcpy(h_acc_.get() + ra.size(), rb.data(), rb.size() * sizeof(uint64_t));
+        T4A_HIP(hipMemcpyAsync(d_acc_.get(), h_acc_.get(), (ra.size() + rb.size()) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         pi_eval_launch(fn_dev_, d_acc_.get(), (int)nr, d_acc_.get() + ra.size(), (int)nc, d_out,
                        transposed ? (int)nc : (int)nr, transposed, d_maxbits, st);
         T4A_HIP(hipGetLastError());
-        T4A_HIP(hipStreamSynchronize(st)); // ra / rb are pageable
+        T4A_HIP(hipStreamSynchronize(st)); // (the pinned staging block is reused by the next call)
     } else {
         // GlobalIndexBatch (batch.rs): (n_sites, n_points) column-major, rows running fastest (update.rs:218-231)
         const size_t npts = nr * nc;
@@ -534,8 +536,12 @@ EdgeSelection TreeTci::update_edge(const TreeEdge& edge, const RrLUOptions& opti
         t2 = now();
         d_acc_.reserve(ra.size() + rb.size());
         hipStream_t st = eng.stream();
-        T4A_HIP(hipMemcpyAsync(d_acc_.get(), ra.data(), ra.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        T4A_HIP(hipMemcpyAsync(d_acc_.get() + ra.size(), rb.data(), rb.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        // (one copy out of pinned memory — two copies out of pageable vectors cost ~30 us of an edge update; luci() below ends with a
+        // stream synchronisation, the staging block is free again then)
+        h_acc_.reserve(ra.size() + rb.size());
+        std::memcpy(h_acc_.get(), ra.data(), ra.size() * sizeof(uint64_t));
+        std::memcpy(h_acc_.get() + ra.size(), rb.data(), rb.size() * sizeof(uint64_t));
+        T4A_HIP(hipMemcpyAsync(d_acc_.get(), h_acc_.get(), (ra.size() + rb.size()) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         FusedPi fp;
         fp.fn = fn_dev_;
         fp.d_rowacc = d_acc_.get();

@@ -156,6 +156,7 @@ private:
     int msg_total_ = 0;
 
     DevBuf<uint64_t> d_acc_;
+    PinBuf<uint64_t> h_acc_; // pinned staging of the row / column accumulators of a candidate matrix (one copy instead of two pageable ones)
     DevBuf<unsigned long long> d_maxbits_;
     DevBuf<double> d_vals_, d_a_, d_b_, d_c_, d_msg_;
     DevBuf<uint32_t> d_idx_;
