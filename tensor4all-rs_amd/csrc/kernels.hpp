@@ -513,6 +513,72 @@ void tt_env_dot_launch(const double* d_left, const double* d_right, int len, int
                        const uint32_t* d_ir, size_t n_pts, double* d_out, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
+// kernels_small.hip — the small-problem engine (round 6): the WHOLE optimize_with_finder loop of a small TensorCI2 problem
+// (tensorci2.rs:1626-1802: iteration loop, update_pivots chain :1821-2007, fill_site_tensors :1065-1186, convergence_criterion
+// :1407-1437, final sweep1site :1787-1794) in ONE launch.  Index sets, history snapshots and lists live in the LDS, the candidate
+// matrix of a bond in the registers of one wavefront (8 x 8: one entry per lane, 16 x 16: four, 32 x 32: sixteen).
+// When a list or a matrix outgrows the tile the kernel stops at the start of that iteration and hands the state back (tci2_small.hip
+// continues with the general path from there).
+// ------------------------------------------------------------------------------------------------
+constexpr int SMALL_CAP = 16;        // entries per index set
+constexpr int SMALL_TILE = 32;       // candidate matrices up to SMALL_TILE x SMALL_TILE
+constexpr int SMALL_MAX_SITES = 64;
+constexpr int SMALL_MAX_ITER = 64;   // iterations whose errors / ranks the result block holds
+constexpr int SMALL_MAX_W = 512;     // K * total weights
+struct SmallHeader { // travels in the kernel arguments; offsets in bytes from the start of the (pinned) input block
+    int n, K, fid, total;
+    int max_iter, ncheck, sweep_strategy, flags; // flags: 1 normalize_error, 2 strictly_nested, 4 final_sweep1site
+    int max_bond_dim, cap_in, pad0, pad1;        // cap_in: entries per (family, site) in the input tables (<= SMALL_CAP)
+    double tolerance, max_sample_value;
+    double params[T4A_FN_MAX_PARAMS];
+    // ldim[n] woff[n] | w[K*total] | cnt[2n] (I sets then J sets) | code[2n][cap_in] | acc[2n][cap_in][K] | cores[n] (device pointers)
+    int o_ldim, o_woff, o_w, o_cnt, o_code, o_acc, o_cores, bytes;
+};
+// result block (pinned, written by the kernel): header, then arrays at the offsets small_out_layout() gives
+struct SmallOutHeader {
+    int status;      // 1: the whole call completed (incl. the final 1-site sweep when asked for)  2: handed over  3: failed (restart on the general path)
+    int iters_done;  // iterations completed by the kernel (the state handed back is the one at the start of iteration iters_done)
+    int converged, termination, n_pivot_errors, final_done, hist_valid, reason;
+    double max_sample_value;
+    unsigned long long clocks[4];
+};
+struct SmallOutLayout {
+    size_t o_err, o_rank, o_bond, o_pe, o_shapes, o_cdims, o_cnt, o_code, o_hcnt, o_hcode, o_flag, bytes;
+};
+__host__ __device__ inline SmallOutLayout small_out_layout(int n)
+{
+    SmallOutLayout L;
+    size_t o = (sizeof(SmallOutHeader) + 15) / 16 * 16;
+    L.o_err = o;    o += sizeof(double) * SMALL_MAX_ITER;
+    L.o_rank = o;   o += sizeof(int) * SMALL_MAX_ITER;
+    L.o_bond = o;   o += sizeof(double) * (size_t)n;
+    L.o_pe = o;     o += sizeof(double) * (SMALL_TILE + 2);
+    L.o_shapes = o; o += sizeof(int) * 3 * (size_t)n + 4;
+    o = (o + 15) / 16 * 16;
+    L.o_cdims = o;  o += sizeof(int) * 3 * (size_t)n + 4;
+    o = (o + 15) / 16 * 16;
+    L.o_cnt = o;    o += sizeof(int) * 2 * (size_t)n;
+    o = (o + 15) / 16 * 16;
+    L.o_code = o;   o += sizeof(uint64_t) * 2 * (size_t)n * SMALL_CAP;
+    L.o_hcnt = o;   o += sizeof(int) * 2 * (size_t)n;
+    o = (o + 15) / 16 * 16;
+    L.o_hcode = o;  o += sizeof(uint64_t) * 2 * (size_t)n * SMALL_CAP;
+    L.o_flag = o;   o += 16;
+    L.bytes = o;
+    return L;
+}
+struct SmallArgs {
+    SmallHeader h;
+    const char* in;    // the arrays the header points into (pinned host memory, read once)
+    char* out;         // SmallOutHeader + arrays (pinned host memory)
+    double* scratch;   // device: n * SMALL_CAP * dmax * SMALL_CAP doubles (site tensors of the iterations whose cores nobody reads)
+    size_t scratch_stride;
+    unsigned token;    // written to the completion flag
+};
+size_t small_lds_bytes(int n, int K, int total);   // dynamic LDS the launch needs (0: does not fit a compute unit)
+void small_optimize_launch(const SmallArgs& a, int n, int K, int total, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
 // kernels_linalg.hip — one-sided Jacobi SVD and Householder QR building blocks
 // ------------------------------------------------------------------------------------------------
 void nonfinite_flag_launch(const double* data, size_t count, int* d_flag, hipStream_t stream);

@@ -1783,6 +1783,13 @@ void Tci2::opt_begin(OptRun& r)
     r.nglobal_hist.clear();
     termination = T4A_GPU_TCI2_MAX_ITERATIONS;
     r.rng.reseed(options.has_seed ? options.seed : 0x1234567ull); // (no seed: OS entropy in the reference — any stream will do)
+    r.pending_fill = false;
+    r.iter = 0;
+    r.done = false;
+    r.small_complete = false;
+    // small problems: the whole loop in ONE launch (tci2_small.hip); it may finish the call, run the first iterations and hand the
+    // rest back, or decline
+    if (small_engine_run(r) && r.small_complete) return;
     // bounded rank, built-in functor: site tensors and fill workspaces get their final size now (a buffer that grows goes
     // through the process-wide cache, which waits for the whole device: once per iteration and buffer while ranks grow)
     if (fn_kind_ == FnKind::Builtin && options.max_bond_dim != 0 && options.max_bond_dim <= 1024) {
@@ -1826,10 +1833,6 @@ void Tci2::opt_begin(OptRun& r)
         h_fillinfo_.reserve(n_);
         }
     }
-    r.pending_fill = false;
-    r.iter = 0;
-    r.done = false;
-
 }
 
 bool Tci2::opt_iter_start(OptRun& r, bool defer_launch)
@@ -2107,6 +2110,7 @@ void Tci2::optimize_group(const std::vector<Tci2*>& hs, const TCI2Options& optio
     for (size_t i = 0; i < hs.size(); ++i) {
         runs[i].options = options;
         runs[i].final_sweep1site = final_sweep1site;
+        runs[i].allow_small = false; // (the group's point is eight chains side by side: one engine launch per handle would serialise them)
         hs[i]->opt_begin(runs[i]);
     }
     static const bool prof = std::getenv("T4A_GROUP_PROF") != nullptr; // host time per phase, printed once per call

@@ -97,7 +97,18 @@ public:
         bool is_forward = true, chained = false, fill_ahead = false;
         long ext_idx = -1;
         size_t flush_at_fwd = 0, flush_at_bwd = 0;
+        // small-problem engine (tci2_small.hip): offered every run unless the caller drives several handles in lock-step
+        bool allow_small = true;
+        bool small_complete = false; // the engine finished the whole call (iterations and, when asked for, the final 1-site sweep)
     };
+    // the small-problem engine: the whole optimize loop of a small problem in ONE launch (kernels_small.hip)
+    bool small_enabled = true;
+    // [0] optimize calls it completed [1] iterations it ran [2] runs it handed back to the general path [3] calls that were not eligible
+    std::array<uint64_t, 4> small_stats{{0, 0, 0, 0}};
+    uint64_t small_last_clocks_[3] = {0, 0, 0}; // last launch, 100 MHz ticks: input, iterations, final sweep + results
+    int small_last_reason_ = 0;
+    bool small_engine_eligible(const TCI2Options& options) const;
+    bool small_engine_run(OptRun& r);
     void opt_begin(OptRun& r);
     void opt_iter_issue_pending_fill(OptRun& r);
     void opt_end_issue_fill(OptRun& r); // the last iteration's fill, issued without waiting (first half of opt_end; a group issues all of them first)
@@ -342,6 +353,10 @@ private:
     void prepare_fill_site_from_mirror(size_t b);
     bool fill_no_main_sync_ = false; // the next fill does not depend on work of the main stream (bond chain: no cores written there)
 
+    // small-problem engine: input / result blocks (pinned), scratch site tensors
+    PinBuf<char> small_in_, small_out_;
+    DevBuf<double> small_scratch_;
+    unsigned small_token_ = 0;
     // device scratch
     DevBuf<uint64_t> d_rowacc_, d_colacc_;
     PinBuf<uint64_t> h_acc_;

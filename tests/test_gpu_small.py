@@ -1,0 +1,166 @@
+"""GPU parity tests of the small-problem engine (kernels_small.hip / tci2_small.hip): optimize_with_finder of a small problem as ONE
+launch (tensorci2.rs:1626-1802: iteration loop, update_pivots chain, fill_site_tensors, convergence_criterion, final 1-site sweep).
+
+Three runs side by side on the same inputs: the engine, the general device path (set_chain(small_engine=False)) and the CPU oracle.
+Index sets, bond errors, pivot errors, ranks, errors, termination and max_sample_value must be IDENTICAL (bit-exact pivot contract);
+site tensors within 1e-10.  Cases cover a run the engine completes (configs[1]), runs it hands back to the general path when the
+rank outgrows its tiles (configs[2] at reduced depth), both sweep directions, strictly nested sets, local dimensions other than two
+and optimize() without the final sweep.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+PARITY = dict(nsearch=0, max_nglobal_pivot=0)
+
+
+@pytest.fixture(scope="module")
+def t4a():
+    import t4a_amd
+    if t4a_amd.device_count() < 1:
+        pytest.fail("no MI355X visible: the product path has no CPU fallback")
+    return t4a_amd
+
+
+def three(t4a, spec, dims):
+    s = t4a.TensorCI2(dims)
+    s.set_function(spec)
+    g = t4a.TensorCI2(dims)
+    g.set_function(spec)
+    g.set_chain(True, small_engine=False)
+    o = ob.OracleTCI2(dims)
+    o.set_function(spec)
+    return s, g, o
+
+
+def assert_identical(s, g, o, n, core_tol=1e-10, cores=True):
+    for p in range(n):
+        assert np.array_equal(s.i_set(p), o.i_set(p)), f"I set differs from the oracle at site {p}"
+        assert np.array_equal(s.j_set(p), o.j_set(p)), f"J set differs from the oracle at site {p}"
+        assert np.array_equal(s.i_set(p), g.i_set(p)) and np.array_equal(s.j_set(p), g.j_set(p))
+    sr, se = s.history()
+    orr, oe = o.history()
+    gr, ge = g.history()
+    assert sr == orr == gr
+    assert np.array_equal(se, oe) and np.array_equal(se, ge)
+    assert s.termination() == o.termination() == g.termination()
+    assert s.max_sample_value() == o.max_sample_value() == g.max_sample_value()
+    assert np.array_equal(s.bond_errors(), o.bond_errors()) and np.array_equal(s.bond_errors(), g.bond_errors())
+    assert np.array_equal(s.pivot_errors(), o.pivot_errors()) and np.array_equal(s.pivot_errors(), g.pivot_errors())
+    assert np.array_equal(s.last_sweep_shapes(), o.last_sweep_shapes())
+    if cores:
+        for p in range(n):
+            a, b = s.site_tensor(p), o.site_tensor(p)
+            assert a.shape == b.shape, f"core shape differs at site {p}: {a.shape} vs {b.shape}"
+            if a.size:
+                assert np.abs(a - b).max() <= core_tol * max(1.0, np.abs(b).max()), f"core values differ at site {p}"
+
+
+@pytest.mark.parametrize("nbits", [6, 12, 20])
+def test_cfg2_runs_completely_inside_one_launch(t4a, nbits):
+    """BASELINE configs[1] (d = 20) and shorter versions: rank 2, every candidate matrix at most 6 x 6."""
+    from t4a_amd.functions import quantics_trig_exp
+    spec = quantics_trig_exp(nbits)
+    opts = t4a.TCI2Options(tolerance=1e-8, max_bond_dim=64, max_iter=20, seed=42, **PARITY)
+    s, g, o = three(t4a, spec, [2] * nbits)
+    for h in (s, g, o):
+        h.crossinterpolate2([[0] * nbits], opts)
+    assert_identical(s, g, o, nbits)
+    st = s.small_stats()
+    assert st["completed"] == 1 and st["handed_back"] == 0 and st["iterations"] == len(s.history()[0]), st
+    assert g.small_stats()["completed"] == 0
+    rng = np.random.default_rng(5)
+    pts = rng.integers(0, 2, size=(300, nbits))
+    assert np.abs(s.evaluate(pts) - o.evaluate(pts)).max() <= 1e-10
+    assert np.abs(s.evaluate(pts) - ob.fn_eval(spec, pts)).max() <= 1e-6
+
+
+@pytest.mark.parametrize("strategy", [0, 1, 2])
+@pytest.mark.parametrize("nested", [False, True])
+def test_sweep_strategies_and_strictly_nested_sets(t4a, strategy, nested):
+    from t4a_amd.functions import quantics_trig_exp
+    n = 10
+    spec = quantics_trig_exp(n, a=7.0, b=0.5, cc=0.3, cs=1.0)
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=8, max_iter=9, sweep_strategy=strategy, strictly_nested=nested, seed=1, **PARITY)
+    s, g, o = three(t4a, spec, [2] * n)
+    for h in (s, g, o):
+        h.crossinterpolate2([[0] * n, [1] * n], opts)
+    assert_identical(s, g, o, n)
+    assert s.small_stats()["iterations"] >= 1
+
+
+@pytest.mark.parametrize("nsites,maxb,iters", [(10, 4, 6), (12, 16, 8), (14, 32, 7)])
+def test_engine_hands_a_growing_problem_to_the_general_path(t4a, nsites, maxb, iters):
+    """BASELINE configs[2] at reduced depth: the rank grows past the engine's tiles (16 entries per set, 32 x 32 matrices); the first
+    iterations run in the launch, the rest on the bond chain — every observable equals the oracle's and the general path's."""
+    from t4a_amd.functions import quantics_osc2d
+    spec = quantics_osc2d(nsites, k1=3, k2=5, k3=7, eps=0.1, k4=11, delta=0.3)
+    opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=maxb, max_iter=iters, seed=42, **PARITY)
+    s, g, o = three(t4a, spec, [2] * nsites)
+    for h in (s, g, o):
+        h.crossinterpolate2([[0] * nsites], opts)
+    assert_identical(s, g, o, nsites)
+    st = s.small_stats()
+    assert st["iterations"] >= 1, st
+    if maxb >= 16:
+        assert st["handed_back"] == 1 and st["completed"] == 0, st
+    rng = np.random.default_rng(6)
+    pts = rng.integers(0, 2, size=(300, nsites))
+    assert np.abs(s.evaluate(pts) - o.evaluate(pts)).max() <= 1e-10 * max(1.0, s.max_sample_value())
+
+
+def test_local_dimensions_other_than_two(t4a):
+    """Lorentzian on 10^5 (tensorci2/tests/mod.rs:945-1002) and a linear function on mixed dimensions (:397-440)."""
+    from t4a_amd.functions import lorentz, linear_sum
+    spec = lorentz([10] * 5)
+    opts = t4a.TCI2Options(tolerance=1e-8, max_iter=20, **PARITY)
+    s, g, o = three(t4a, spec, [10] * 5)
+    for h in (s, g, o):
+        h.crossinterpolate2([[1] * 5], opts)
+    assert_identical(s, g, o, 5)
+    assert s.small_stats()["iterations"] >= 1
+    dims = [3, 4, 2, 5, 3, 2]
+    spec = linear_sum(dims, scale=0.5, shift=1.0)
+    opts = t4a.TCI2Options(tolerance=1e-10, max_iter=10, **PARITY)
+    s, g, o = three(t4a, spec, dims)
+    for h in (s, g, o):
+        h.crossinterpolate2([[1] * len(dims)], opts)
+    assert_identical(s, g, o, len(dims))
+    assert s.small_stats()["completed"] == 1, s.small_stats()
+    assert max(s.link_dims()) <= 2
+
+
+def test_optimize_without_the_final_sweep_keeps_the_fill_tensors(t4a):
+    from t4a_amd.functions import quantics_trig_exp
+    n = 9
+    spec = quantics_trig_exp(n, a=3.0, b=2.0)
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=6, max_iter=7, **PARITY)
+    s, g, o = three(t4a, spec, [2] * n)
+    for h in (s, g, o):
+        h.add_global_pivots([[0] * n, [1, 0] * 4 + [1]])
+        h.set_max_sample_value(1.0)
+        h.optimize(opts, final_sweep1site=False)
+    assert_identical(s, g, o, n)
+    assert s.small_stats()["completed"] == 1
+    # a second optimize call on the same handle has a history: the general path takes it, results still equal
+    for h in (s, g, o):
+        h.optimize(opts, final_sweep1site=True)
+    assert_identical(s, g, o, n)
+    assert s.small_stats()["completed"] == 1 and s.small_stats()["not_eligible"] >= 1
+
+
+def test_engine_is_not_offered_callbacks_or_global_search(t4a):
+    from t4a_amd.functions import quantics_trig_exp
+    n = 8
+    spec = quantics_trig_exp(n)
+    s = t4a.TensorCI2([2] * n)
+    s.set_function(spec)
+    s.crossinterpolate2([[0] * n], t4a.TCI2Options(tolerance=1e-8, max_bond_dim=8, max_iter=6, nsearch=3, max_nglobal_pivot=2, seed=3))
+    assert s.small_stats()["completed"] == 0 and s.small_stats()["iterations"] == 0
+    c = t4a.TensorCI2([2] * n)
+    c.set_function(lambda idx: float(np.cos(sum(idx) * 0.3)))
+    c.crossinterpolate2([[0] * n], t4a.TCI2Options(tolerance=1e-8, max_bond_dim=8, max_iter=6, **PARITY))
+    assert c.small_stats()["completed"] == 0 and c.small_stats()["iterations"] == 0

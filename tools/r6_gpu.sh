@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage (on the GPU box, through gpurun): tools/r6_gpu.sh STAGE...   — one parametrised launcher for the round-6 measurements.
+# Every stage writes under gpurun_out/r6_<stage>/.
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+for stage in "$@"; do
+  out=gpurun_out/r6_$stage
+  mkdir -p "$out"
+  case $stage in
+    small)      # small-problem engine: parity tests + configs[1] time to solution
+      timeout 900 python -m pytest tests/test_gpu_small.py -x -q > "$out/pytest.log" 2>&1; echo "pytest rc $?" >> "$out/pytest.log"; tail -15 "$out/pytest.log"
+      timeout 300 python tools/probe_cfg2.py > "$out/probe_cfg2.log" 2>&1; cat "$out/probe_cfg2.log" ;;
+    tci)        # every TCI2 / chain test
+      timeout 2400 python -m pytest tests/test_gpu_small.py tests/test_gpu_tci2.py tests/test_gpu_chain.py -x -q > "$out/pytest.log" 2>&1; echo "pytest rc $?" >> "$out/pytest.log"; tail -15 "$out/pytest.log" ;;
+    suite)      # the whole GPU suite
+      timeout 3400 python -m pytest tests -m gpu -x -q > "$out/pytest.log" 2>&1; echo "pytest rc $?" >> "$out/pytest.log"; tail -15 "$out/pytest.log" ;;
+    bench)      # the default bench line
+      timeout 900 python bench.py > "$out/bench.json" 2> "$out/bench.err"; tail -3 "$out/bench.json" ;;
+    components) timeout 900 python tools/bench_components.py > "$out/components.json" 2> "$out/components.err"; tail -5 "$out/components.json" ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
