@@ -802,7 +802,7 @@ t4a_gpu_status t4a_gpu_tci2_fill_site_tensors_group(t4a_gpu_tci2* const* handles
  * device-side index tables are read back and compared with the host's I / J sets (T4A_GPU_INTERNAL_ERROR on a difference);
  * bit 1: while profiling, the rrLU launches of a chain are timed with HIP events around each launch instead of the kernels' own
  * time stamps (two more packets per bond on the stream: for calibration runs);
- * bit 2: the small-problem engine (below) is switched off for this handle. */
+ * bit 2: the small-problem engine (below) is switched off for this handle; bit 3: its launch stamps its phases (diagnostic). */
 t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t verify);
 /* The small-problem engine (round 6): optimize_with_finder (tensorci2.rs:1626-1802) of a small problem — iteration loop, the
  * update_pivots chain (:1821-2007), fill_site_tensors (:1065-1186), convergence_criterion (:1407-1437) and the final 1-site sweep
@@ -812,8 +812,10 @@ t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t v
  * continues.  Results are those of the general path (index sets, errors, ranks bit for bit).
  * out[0] calls the engine completed, [1] iterations it ran, [2] runs handed back, [3] calls that were not eligible,
  * [4..6] device time of the last launch in 100 MHz ticks (input, iterations, final sweep + results), [7] why the last launch handed back
- * (0 it did not, 1 list / matrix beyond the tile, 2 non-finite value, 3 rank beyond 16, 4 fill not representable / singular). */
-t4a_gpu_status t4a_gpu_tci2_small_stats(const t4a_gpu_tci2* h, uint64_t* out /* [8] */);
+ * (0 it did not, 1 list / matrix beyond the tile, 2 non-finite value, 3 rank beyond 16, 4 fill not representable / singular),
+ * [8..15] shader cycles per phase of the last launch when the phase stamps are on (lists, evaluation, pivot steps, gather, factors,
+ * fill, snapshots, convergence + rest). */
+t4a_gpu_status t4a_gpu_tci2_small_stats(const t4a_gpu_tci2* h, uint64_t* out /* [16] */);
 
 /* Evaluate a built-in function on the device for a batch of full multi-indices (parity check of the
  * workload definition itself).  idx: n_sites x n_pts column-major. */

@@ -1134,6 +1134,7 @@ t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t v
         h->impl.chain_verify = (verify & 1) != 0;
         h->impl.chain_event_timing = (verify & 2) != 0;
         h->impl.small_enabled = (verify & 4) == 0;
+        h->impl.small_stamps = (verify & 8) != 0;
     });
 }
 
@@ -1145,6 +1146,7 @@ t4a_gpu_status t4a_gpu_tci2_small_stats(const t4a_gpu_tci2* h, uint64_t* out)
         for (int k = 0; k < 4; ++k) out[k] = h->impl.small_stats[k];
         for (int k = 0; k < 3; ++k) out[4 + k] = h->impl.small_last_clocks_[k];
         out[7] = (uint64_t)h->impl.small_last_reason_;
+        for (int k = 0; k < 8; ++k) out[8 + k] = h->impl.small_last_clocks_[3 + k];
     });
 }
 

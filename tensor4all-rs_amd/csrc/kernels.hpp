@@ -522,12 +522,12 @@ void tt_env_dot_launch(const double* d_left, const double* d_right, int len, int
 // ------------------------------------------------------------------------------------------------
 constexpr int SMALL_CAP = 16;        // entries per index set
 constexpr int SMALL_TILE = 32;       // candidate matrices up to SMALL_TILE x SMALL_TILE
-constexpr int SMALL_MAX_SITES = 64;
+constexpr int SMALL_MAX_SITES = 32;
 constexpr int SMALL_MAX_ITER = 64;   // iterations whose errors / ranks the result block holds
 constexpr int SMALL_MAX_W = 512;     // K * total weights
 struct SmallHeader { // travels in the kernel arguments; offsets in bytes from the start of the (pinned) input block
     int n, K, fid, total;
-    int max_iter, ncheck, sweep_strategy, flags; // flags: 1 normalize_error, 2 strictly_nested, 4 final_sweep1site
+    int max_iter, ncheck, sweep_strategy, flags; // flags: 1 normalize_error, 2 strictly_nested, 4 final_sweep1site, 8 phase stamps
     int max_bond_dim, cap_in, pad0, pad1;        // cap_in: entries per (family, site) in the input tables (<= SMALL_CAP)
     double tolerance, max_sample_value;
     double params[T4A_FN_MAX_PARAMS];
@@ -540,7 +540,7 @@ struct SmallOutHeader {
     int iters_done;  // iterations completed by the kernel (the state handed back is the one at the start of iteration iters_done)
     int converged, termination, n_pivot_errors, final_done, hist_valid, reason;
     double max_sample_value;
-    unsigned long long clocks[4];
+    unsigned long long clocks[12]; // [0..2] 100 MHz ticks: input, loop, results; [3..10] shader cycles per phase when flag 8 is set (lists, evaluation, pivot steps, gather, factors, fill, snapshots, convergence)
 };
 struct SmallOutLayout {
     size_t o_err, o_rank, o_bond, o_pe, o_shapes, o_cdims, o_cnt, o_code, o_hcnt, o_hcode, o_flag, bytes;

@@ -28,52 +28,60 @@ namespace t4a {
 namespace {
 
 constexpr int SC = SMALL_CAP;
+constexpr int SMALL_WAVES = 4;   // wave 0 walks the bonds, waves 1..3 run fill_site_tensors of the previous iteration beside it
+constexpr int SMALL_WORKERS = SMALL_WAVES - 1;
 
-struct SmallLds { // byte offsets into the dynamic LDS
-    size_t tab_bytes, o_cnt, o_code, o_acc; // inside one table copy
-    size_t o_tab, o_params, o_w, o_ldim, o_woff, o_lcode, o_lacc, o_bond, o_shapes, o_err, o_rank, o_pe, o_As, o_Bs, o_fl, o_Af, o_xs, o_pp, o_cdims, bytes;
+// Everything lives in STATIC LDS at compile-time addresses (pointers and layout offsets kept in scalar registers made the first version
+// of this kernel spill scalar registers into vector lanes around every phase); accumulator arrays are laid out for two accumulators.
+constexpr int KS = 2;                      // accumulator stride of every table and list
+constexpr int NS = SMALL_MAX_SITES;
+struct SmallTab {                          // one copy of the index sets: I sets then J sets
+    int cnt[2 * NS];
+    uint64_t code[2 * NS * SC];
+    uint64_t acc[2 * NS * SC * KS];
 };
-__host__ __device__ inline size_t up16(size_t v) { return (v + 15) / 16 * 16; }
-__host__ __device__ inline SmallLds small_lds(int n, int K, int total)
+struct SmallWork {                         // fill_site_tensors workspace of one wave
+    double As[SC * SC];
+    double Bs[SC * 64];
+    uint64_t fl[(64 + 2 * SC) * KS];
+};
+struct SmallStatic {
+    SmallTab tab[3];             // [0] the current sets, [1], [2] the history snapshots (iteration t: slot 1 + t % 2)
+    uint64_t lcode[64];          // the two lists of the bond in flight: rows 0..31, columns 32..63
+    uint64_t lacc[64 * KS];
+    uint64_t w[SMALL_MAX_W];
+    int ldim[NS], woff[NS];
+    double bond[NS];
+    int shapes[3 * NS], cdims[3 * NS];
+    double err[SMALL_MAX_ITER];
+    int rank[SMALL_MAX_ITER];
+    double pe[SMALL_TILE + 2];
+    double Af[SMALL_TILE * SMALL_TILE]; // candidate matrix on its way into the registers (E > 1) / factored matrix of a 1-site bond
+    double xs[SC * 64];
+    int pp[64];
+    int o_ptab[64], o_rpos[64]; // results of an out-of-line bond (tiles beyond 8 x 8)
+    double o_pvabs[64], o_error;
+    SmallWork wk[SMALL_WAVES];
+    unsigned long long ph[8], ph_last;
+    double params[16];
+    double msv;                  // max_sample_value
+    int fid, n, total, n_pe, stamps;
+    // fill jobs: wave 0 publishes job number e (fill of iteration e - 1 from snapshot slot 1 + e % 2) by storing e; every worker
+    // answers in done[w]; fail[w] != 0: a site could not be filled
+    int job, quit, done[SMALL_WAVES], fail[SMALL_WAVES];
+};
+__shared__ SmallStatic SH;
+
+// The scalar stage of the built-in functor (include/t4a_testfunctions.h), ONE copy per kernel: inlined at every evaluation site the
+// four function bodies were most of a 200 000-line kernel.
+__device__ __attribute__((noinline)) double small_fn_value(uint64_t a0, uint64_t a1)
 {
-    SmallLds L;
-    L.o_cnt = 0;
-    L.o_code = up16(sizeof(int) * 2 * (size_t)n);
-    L.o_acc = L.o_code + sizeof(uint64_t) * 2 * (size_t)n * SC;
-    L.tab_bytes = up16(L.o_acc + sizeof(uint64_t) * 2 * (size_t)n * SC * (size_t)K);
-    size_t o = 0;
-    L.o_tab = o;    o += 4 * L.tab_bytes;
-    L.o_params = o; o += sizeof(double) * 16;
-    L.o_w = o;      o += up16(sizeof(uint64_t) * (size_t)K * (size_t)total);
-    L.o_ldim = o;   o += up16(sizeof(int) * (size_t)n);
-    L.o_woff = o;   o += up16(sizeof(int) * (size_t)n);
-    L.o_lcode = o;  o += sizeof(uint64_t) * 64;
-    L.o_lacc = o;   o += sizeof(uint64_t) * 64 * (size_t)K;
-    L.o_bond = o;   o += up16(sizeof(double) * (size_t)n);
-    L.o_shapes = o; o += up16(sizeof(int) * 3 * (size_t)n);
-    L.o_err = o;    o += sizeof(double) * SMALL_MAX_ITER;
-    L.o_rank = o;   o += sizeof(int) * SMALL_MAX_ITER;
-    L.o_pe = o;     o += up16(sizeof(double) * (SMALL_TILE + 2));
-    L.o_As = o;     o += sizeof(double) * SC * SC;
-    L.o_Bs = o;     o += sizeof(double) * SC * 64;
-    L.o_fl = o;     o += sizeof(uint64_t) * (64 + 2 * SC) * (size_t)K;
-    L.o_Af = o;     o += sizeof(double) * SMALL_TILE * SMALL_TILE;
-    L.o_xs = o;     o += sizeof(double) * SC * 64;
-    L.o_pp = o;     o += sizeof(int) * 64;
-    L.o_cdims = o;  o += up16(sizeof(int) * 3 * (size_t)n);
-    L.bytes = o;
-    return L;
+    uint64_t acc[T4A_FN_MAX_ACC] = {a0, a1, 0, 0};
+    double p[T4A_FN_MAX_PARAMS];
+#pragma unroll
+    for (int q = 0; q < T4A_FN_MAX_PARAMS; ++q) p[q] = SH.params[q];
+    return t4a_fn_value(__builtin_amdgcn_readfirstlane(SH.fid), acc, p);
 }
-
-template <int K> struct Tab {
-    int* cnt;
-    uint64_t* code;
-    uint64_t* acc;
-    int n;
-    __device__ __forceinline__ int& c(int f, int p) const { return cnt[f * n + p]; }
-    __device__ __forceinline__ uint64_t* codes(int f, int p) const { return code + (size_t)(f * n + p) * SC; }
-    __device__ __forceinline__ uint64_t* accs(int f, int p) const { return acc + (size_t)(f * n + p) * SC * K; }
-};
 
 __device__ __forceinline__ void wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ int ui(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -85,72 +93,81 @@ __device__ __forceinline__ double bperm_f64(double v, int src_lane)
     const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)hi32(v));
     return mk_f64((unsigned)lo, (unsigned)hi);
 }
+__device__ __forceinline__ uint64_t bperm_u64(uint64_t v, int src_lane)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane_s)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane_s);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane_s);
+    return ((uint64_t)hi << 32) | lo;
+}
+// x / p, bitwise the IEEE quotient: the refined-reciprocal form (kernels_rrlu_xcd_common.hpp) in the common case, the full division
+// sequence behind a wave-uniform branch (as plain selects the compiler evaluated both on every step)
+__device__ __forceinline__ double small_div(double x, double p, double rp, bool p_mid)
+{
+    const double q0 = x * rp;
+    const double qf = __builtin_fma(__builtin_fma(-p, q0, x), rp, q0);
+    double q = (x == 0.0) ? q0 : qf;
+    const bool slow = !(p_mid && (exp_mid(x) || x == 0.0));
+    if (__ballot(slow) != 0ull) {
+        asm volatile("; full division" ::: "memory");
+        if (slow) q = x / p;
+    }
+    return q;
+}
 __device__ __forceinline__ unsigned long long small_clock() { return __builtin_amdgcn_s_memrealtime(); }
 
-// The scalar stage of the built-in functor (include/t4a_testfunctions.h), ONE copy per kernel: inlined at every evaluation site the
-// four function bodies were most of a 200 000-line kernel.
-__device__ __attribute__((noinline)) double small_fn_value(int fid, uint64_t a0, uint64_t a1, const double* params)
+__device__ __forceinline__ void small_stamp(int slot)
 {
-    uint64_t acc[T4A_FN_MAX_ACC] = {a0, a1, 0, 0};
-    double p[T4A_FN_MAX_PARAMS];
-#pragma unroll
-    for (int q = 0; q < T4A_FN_MAX_PARAMS; ++q) p[q] = params[q];
-    return t4a_fn_value(fid, acc, p);
-}
-
-template <int K> struct Ctx {
-    int n, total, fid;
-    char* tab_base;
-    unsigned tab_bytes, tab_o_code, tab_o_acc;
-    const double* params; // LDS copy of the functor's parameters
-    __device__ __forceinline__ Tab<K> tab(int t) const
-    {
-        Tab<K> v;
-        char* base = tab_base + (size_t)t * tab_bytes;
-        v.cnt = reinterpret_cast<int*>(base);
-        v.code = reinterpret_cast<uint64_t*>(base + tab_o_code);
-        v.acc = reinterpret_cast<uint64_t*>(base + tab_o_acc);
-        v.n = n;
-        return v;
+    if (SH.stamps) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) {
+            SH.ph[slot] += now - SH.ph_last;
+            SH.ph_last = now;
+        }
     }
-    uint64_t* w;
-    int *ldim, *woff;
-    uint64_t *lcode, *lacc;
-    double* bond;
-    int* shapes;
-    double *err;
-    int* rank;
-    double* pe;
-    double *As, *Bs;
-    uint64_t* fl;
-    double *Af, *xs;
-    int* pp;
-    int* cdims;
-    double msv;   // max_sample_value (wave-uniform)
-    int n_pe;
-    int reason;
-};
+}
 
 // ---- the two lists of a bond: rows in list slots 0..31, columns in 32..63; lanes 0..31 build the rows, 32..63 the columns -----------
 // 2-site: rows = kron(I_b, d_b) + extras(H.I[b+1]), columns = kron(J_{b+1}, d_{b+1}) + extras(H.J[b]) (tensorci2.rs:1224-1246, :1833-1846);
 // 1-site forward (:918-1050): rows = kron(I_b, d_b), columns = J_b itself.
+// Two LDS round trips: every load whose address does not depend on loaded data first (counts, site data, the parents' and the extras'
+// entries by lane), then the parent of each child through the cross-lane network and the digit's weight.
 template <int K>
-__device__ __forceinline__ bool small_lists(Ctx<K>& c, const Tab<K>& cur, const Tab<K>& hist, bool use_hist, int b, bool one_site, int& M, int& N)
+__device__ __forceinline__ bool small_lists(int hist, bool use_hist, int b, bool one_site, int& M, int& N)
 {
     const int lane = threadIdx.x & 63, half = lane >> 5, t = lane & 31;
+    const int n = ui(SH.n);
     const bool direct = one_site && half;
     const int ps = half ? (direct ? b : b + 1) : b;
-    const int np = cur.c(half, ps);
-    const int d = direct ? 1 : c.ldim[ps], wo = c.woff[ps];
-    const int m0 = np * d;
-    bool ok = np >= 1 && np <= SC && m0 <= SMALL_TILE;
-    const uint64_t* pcode = cur.codes(half, ps);
-    const uint64_t* pacc = cur.accs(half, ps);
-    uint64_t code = 0, acc[K];
+    const int hsite = half ? b : b + 1;
+    const int tt = t < SC ? t : 0;
+    const bool extras = use_hist && !one_site;
+    const int fp = half * n + ps, fh = half * n + hsite;
+    const int np = SH.tab[0].cnt[fp];
+    const int d = direct ? 1 : SH.ldim[ps], wo = SH.woff[ps];
+    const uint64_t mypc = SH.tab[0].code[fp * SC + tt];
+    uint64_t mypa[K], xa[K];
 #pragma unroll
-    for (int q = 0; q < K; ++q) acc[q] = 0;
+    for (int q = 0; q < K; ++q) mypa[q] = SH.tab[0].acc[(fp * SC + tt) * KS + q];
+    int ne = 0;
+    uint64_t xc = 0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) xa[q] = 0;
+    if (extras) {
+        ne = SH.tab[hist].cnt[fh];
+        xc = SH.tab[hist].code[fh * SC + tt];
+#pragma unroll
+        for (int q = 0; q < K; ++q) xa[q] = SH.tab[hist].acc[(fh * SC + tt) * KS + q];
+    }
+    const int m0 = np * d;
+    bool ok = np >= 1 && np <= SC && m0 <= SMALL_TILE && ne >= 0 && ne <= SC;
+    int parent = 0, digit = 0;
     if (ok && t < m0) {
-        int parent, digit;
         if (half) { // (digit outer, parent inner)
             digit = div_small(t, np);
             parent = t - digit * np;
@@ -158,26 +175,24 @@ __device__ __forceinline__ bool small_lists(Ctx<K>& c, const Tab<K>& cur, const 
             parent = div_small(t, d);
             digit = t - parent * d;
         }
-        const uint64_t pc = pcode[parent];
-        code = direct ? pc : (uint64_t)digit + (uint64_t)d * pc;
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] = pacc[parent * K + q] + (direct ? 0ull : c.w[q * c.total + wo + digit]);
     }
-    bool keep = false;
-    uint64_t xc = 0;
-    int ne = 0;
-    const int hsite = half ? b : b + 1;
-    if (use_hist && !one_site) {
-        ne = hist.c(half, hsite);
-        ok = ok && ne >= 0 && ne <= SC;
-        if (ok && t < ne) {
-            xc = hist.codes(half, hsite)[t];
-            keep = true;
-        }
-        const int npmax = ui(max(__builtin_amdgcn_readlane(np, 0), __builtin_amdgcn_readlane(np, 32)));
-        for (int pi = 0; pi < npmax; ++pi) {
-            const uint64_t base = pcode[pi < np ? pi : 0] * (uint64_t)d;
-            if (pi < np && (xc - base) < (uint64_t)d) keep = false; // its parent is among the parents: already in the Kronecker part
+    const uint64_t pc = bperm_u64(mypc, half * 32 + parent);
+    uint64_t acc[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const uint64_t pa = bperm_u64(mypa[q], half * 32 + parent);
+        acc[q] = pa + (direct ? 0ull : SH.w[q * SH.total + wo + digit]);
+    }
+    const uint64_t code = direct ? pc : (uint64_t)digit + (uint64_t)d * pc;
+    bool keep = extras && ok && t < ne;
+    if (extras) { // an extra whose parent is among the parents is already in the Kronecker part
+        const uint64_t mybase = mypc * (uint64_t)d;
+        const int np0 = __builtin_amdgcn_readlane(np, 0), np1 = __builtin_amdgcn_readlane(np, 32);
+        const int npmax = np0 > np1 ? np0 : np1;
+        for (int pi = 0; pi < npmax && pi < SC; ++pi) {
+            const uint64_t b0 = readlane_u64(mybase, pi), b1 = readlane_u64(mybase, 32 + pi);
+            const uint64_t base = half ? b1 : b0;
+            if (pi < np && (xc - base) < (uint64_t)d) keep = false;
         }
     }
     const unsigned long long km = __ballot(keep);
@@ -188,14 +203,14 @@ __device__ __forceinline__ bool small_lists(Ctx<K>& c, const Tab<K>& cur, const 
     ok = ok && tot <= SMALL_TILE;
     if (__ballot(!ok) != 0ull) return false;
     if (t < m0) {
-        c.lcode[half * 32 + t] = code;
+        SH.lcode[half * 32 + t] = code;
 #pragma unroll
-        for (int q = 0; q < K; ++q) c.lacc[(half * 32 + t) * K + q] = acc[q];
+        for (int q = 0; q < K; ++q) SH.lacc[(half * 32 + t) * KS + q] = acc[q];
     }
     if (keep) {
-        c.lcode[half * 32 + pos] = xc;
+        SH.lcode[half * 32 + pos] = xc;
 #pragma unroll
-        for (int q = 0; q < K; ++q) c.lacc[(half * 32 + pos) * K + q] = hist.accs(half, hsite)[t * K + q];
+        for (int q = 0; q < K; ++q) SH.lacc[(half * 32 + pos) * KS + q] = xa[q];
     }
     M = __builtin_amdgcn_readlane(tot, 0);
     N = __builtin_amdgcn_readlane(tot, 32);
@@ -207,10 +222,10 @@ __device__ __forceinline__ bool small_lists(Ctx<K>& c, const Tab<K>& cur, const 
 // E entries per lane: position p = lane + 64 e = i + MR j.  Returns the number of pivots (-1: non-finite values).  Outputs:
 //   ptab: lane k = pivot row of step k, lane 32 + k = pivot column of step k;  pvabs: lane k = sqrt(pivot * pivot) of step k;
 //   error = RrLU::error (matrixlu.rs:758, :811);  rpos_out: position of row `lane` in the reference's permuted order;
-//   with FACT the factored matrix (L scaled below the pivots in the pivot columns, U in the pivot rows) goes to c.Af[i + MR j].
-template <int K, int E>
-__device__ __forceinline__ int small_bond(Ctx<K>& c, const bool LEFT, const bool FACT, int M, int N, int max_bond_dim, double rel_tol, double abs_tol, int& ptab,
-                                          double& pvabs, double& error_out, int& rpos_out)
+//   with `fact` the factored matrix (L scaled below the pivots in the pivot columns, U in the pivot rows) goes to SH.Af[i + MR j].
+template <int K, int E, bool LEFT>
+__device__ __forceinline__ int small_bond(const bool fact, int M, int N, int max_bond_dim, double rel_tol, double abs_tol,
+                                          int& ptab, double& pvabs, double& error_out, int& rpos_out)
 {
     constexpr int MR = E == 1 ? 8 : (E == 4 ? 16 : 32);
     constexpr int LOG_MR = E == 1 ? 3 : (E == 4 ? 4 : 5);
@@ -224,7 +239,7 @@ __device__ __forceinline__ int small_bond(Ctx<K>& c, const bool LEFT, const bool
     {
         uint64_t racc[K];
 #pragma unroll
-        for (int q = 0; q < K; ++q) racc[q] = c.lacc[(i < M ? i : 0) * K + q];
+        for (int q = 0; q < K; ++q) racc[q] = SH.lacc[(i < M ? i : 0) * KS + q];
         double amax = 0.0;
         bool bad = false;
         if (E > 1) { // (rolled: one call site of the functor; the values pass through the LDS block of the factored matrix)
@@ -236,10 +251,10 @@ __device__ __forceinline__ int small_bond(Ctx<K>& c, const bool LEFT, const bool
                 if (__ballot(in) != 0ull) {
                     uint64_t acc[2] = {0, 0};
 #pragma unroll
-                    for (int q = 0; q < K; ++q) acc[q] = racc[q] + c.lacc[(32 + (j < N ? j : 0)) * K + q];
-                    v = small_fn_value(c.fid, acc[0], acc[1], c.params);
+                    for (int q = 0; q < K; ++q) acc[q] = racc[q] + SH.lacc[(32 + (j < N ? j : 0)) * KS + q];
+                    v = small_fn_value(acc[0], acc[1]);
                 }
-                c.Af[lane + 64 * e] = v;
+                SH.Af[lane + 64 * e] = v;
             }
             wsync();
         }
@@ -252,10 +267,10 @@ __device__ __forceinline__ int small_bond(Ctx<K>& c, const bool LEFT, const bool
             if (E == 1) {
                 uint64_t acc[2] = {0, 0};
 #pragma unroll
-                for (int q = 0; q < K; ++q) acc[q] = racc[q] + c.lacc[(32 + (j < N ? j : 0)) * K + q];
-                v = small_fn_value(c.fid, acc[0], acc[1], c.params);
+                for (int q = 0; q < K; ++q) acc[q] = racc[q] + SH.lacc[(32 + (j < N ? j : 0)) * KS + q];
+                v = small_fn_value(acc[0], acc[1]);
             } else {
-                v = c.Af[lane + 64 * e];
+                v = SH.Af[lane + 64 * e];
             }
             v = in ? v : 0.0;
             if (in) inb |= 1u << e;
@@ -266,8 +281,9 @@ __device__ __forceinline__ int small_bond(Ctx<K>& c, const bool LEFT, const bool
         if (__ballot(bad) != 0ull) return -1;
         const double m = wave_max_f64(amax);
         const double am = hi_mid((int)hi32(m)) ? m : uniform_f64(sqrt(m * m));
-        if (am > c.msv) c.msv = am;
+        if (am > SH.msv && lane == 0) SH.msv = am; // (wave-uniform compare: every lane sees the old value)
     }
+    small_stamp(1);
     int rpos = i;
     int npiv = 0;
     double max_error = 0.0, error = __builtin_nan("");
@@ -305,7 +321,7 @@ __device__ __forceinline__ int small_bond(Ctx<K>& c, const bool LEFT, const bool
         int hl, es;
         double wval, pivot_abs;
         const unsigned long long at_max = __ballot(mhi == whi);
-        const unsigned long long multi = __ballot(mhi == whi && cnt_l > 1);
+        const unsigned long long multi = E == 1 ? 0ull : __ballot(mhi == whi && cnt_l > 1);
         if (hi_mid(whi) && multi == 0ull && __builtin_popcountll(at_max) == 1) { // distinct high words: distinct squares, all normal
             hl = (int)__builtin_ctzll(at_max);
             es = E == 1 ? 0 : __builtin_amdgcn_readlane(be, hl);
@@ -365,22 +381,23 @@ __device__ __forceinline__ int small_bond(Ctx<K>& c, const bool LEFT, const bool
         const double rp = refined_rcp(wval);
         const bool pmid = exp_mid(wval);
         // scale_column_tail (:562-577) / scale_row_tail (:579-591): the bitwise IEEE quotient
-        const double l = LEFT ? xcd_div(xcol, wval, rp, pmid) : xcol;
+        double l = xcol;
+        if (LEFT) l = small_div(xcol, wval, rp, pmid);
         const bool row_rest = rowlive && i != pr; // rows behind the new pivot row in the permuted order
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int j = jb + LPC * e;
             const bool in = (inb >> e) & 1u;
             const bool col_rest = cpos[e] >= kn && j != pc;
-            const double u = LEFT ? urow[e] : xcd_div(urow[e], wval, rp, pmid);
-            if (in && row_rest && col_rest) {
-                const double prod = l * u;
-                a[e] = a[e] - prod; // separately rounded (matrixlu.rs:593-612)
-            } else if (LEFT && in && row_rest && j == pc) {
-                a[e] = l;
-            } else if (!LEFT && in && col_rest && i == pr) {
-                a[e] = u;
-            }
+            double u = urow[e];
+            if (!LEFT) u = small_div(urow[e], wval, rp, pmid);
+            const double prod = l * u;
+            const double upd = a[e] - prod; // separately rounded (matrixlu.rs:593-612)
+            double nv = a[e];
+            if (in && row_rest && col_rest) nv = upd;
+            if (LEFT && in && row_rest && j == pc) nv = l;
+            if (!LEFT && in && col_rest && i == pr) nv = u;
+            a[e] = nv;
             // swap_cols as a position table (:541): the column at position kn takes the pivot column's old position
             if (cpos[e] == kn) cpos[e] = pcp;
             else if (j == pc) cpos[e] = kn;
@@ -393,160 +410,190 @@ __device__ __forceinline__ int small_bond(Ctx<K>& c, const bool LEFT, const bool
     if (npiv >= mn) error = 0.0; // matrixlu.rs:811-813
     error_out = error;
     rpos_out = rpos;
-    if (FACT) {
+    if (fact) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) c.Af[lane + 64 * e] = a[e];
+        for (int e = 0; e < E; ++e) SH.Af[lane + 64 * e] = a[e];
     }
     return npiv;
 }
 
+// Tiles beyond 8 x 8 run out of line (their register needs — sixteen entries, positions and masks per lane — stay out of the
+// allocation of the 8 x 8 path, which is the one a small problem lives on); per-lane results travel through the LDS.
+template <int K, int E, bool LEFT>
+__device__ __attribute__((noinline)) int small_bond_big(int fact_, int M_, int N_, int max_bond_dim_, double rel_tol, double abs_tol)
+{
+    int ptab, rpos;
+    double pvabs, error = 0.0;
+    const int r = small_bond<K, E, LEFT>(ui(fact_) != 0, ui(M_), ui(N_), ui(max_bond_dim_), uniform_f64(rel_tol), uniform_f64(abs_tol), ptab, pvabs, error, rpos);
+    const int lane = threadIdx.x & 63;
+    if (r >= 0) {
+        SH.o_ptab[lane] = ptab;
+        SH.o_rpos[lane] = rpos;
+        SH.o_pvabs[lane] = pvabs;
+        if (lane == 0) SH.o_error = error;
+    }
+    wsync();
+    return r;
+}
+
 // pivots -> I_{b+1} (lanes 0..31) and J_b (lanes 32..63) (tensorci2.rs:1934-1940 with non_empty_or_first :1813-1819)
 template <int K>
-__device__ __forceinline__ bool small_gather(Ctx<K>& c, const Tab<K>& cur, int b, int r, int ptab)
+__device__ __forceinline__ bool small_gather(int b, int r, int ptab)
 {
     const int lane = threadIdx.x & 63, half = lane >> 5, t = lane & 31;
     const int cnt = r > 0 ? r : 1;
     if (cnt > SC) return false;
     const int site = half ? b : b + 1;
-    uint64_t code = 0, acc[K];
+    const int fp = half * SH.n + site;
     if (t < cnt) {
         const int src = half * 32 + (r > 0 ? ptab : 0);
-        code = c.lcode[src];
+        SH.tab[0].code[fp * SC + t] = SH.lcode[src];
 #pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] = c.lacc[src * K + q];
-        cur.codes(half, site)[t] = code;
-#pragma unroll
-        for (int q = 0; q < K; ++q) cur.accs(half, site)[t * K + q] = acc[q];
+        for (int q = 0; q < K; ++q) SH.tab[0].acc[(fp * SC + t) * KS + q] = SH.lacc[src * KS + q];
     }
-    if (t == 0) cur.c(half, site) = cnt;
+    if (t == 0) SH.tab[0].cnt[fp] = cnt;
     wsync();
     return true;
 }
 
-// One bond of a half-sweep / of the final 1-site sweep.  Returns false: hand the iteration back.
+// One bond of a half-sweep / of the final 1-site sweep.  Returns 0, or the reason the iteration is handed back.
 template <int K>
-__device__ __forceinline__ bool small_update(Ctx<K>& c, const bool LEFT, const bool ONE, const Tab<K>& cur, const Tab<K>& hist, bool use_hist, int b, int max_bond_dim, double rel_tol,
-                                             double abs_tol, double* core)
+__device__ __forceinline__ int small_update(const int left_, const int one_, int hist_, int use_hist_, int b_, int max_bond_dim_, double rel_tol, double abs_tol,
+                                                      double* core)
 {
     const int lane = threadIdx.x & 63;
+    // (an out-of-line function receives its arguments in vector registers: back to scalars)
+    const bool left = ui(left_) != 0, one = ui(one_) != 0, use_hist = ui(use_hist_) != 0;
+    const int hist = ui(hist_), b = ui(b_), max_bond_dim = ui(max_bond_dim_);
+    rel_tol = uniform_f64(rel_tol);
+    abs_tol = uniform_f64(abs_tol);
     int M, N;
-    if (!small_lists<K>(c, cur, hist, use_hist, b, ONE, M, N)) {
-        c.reason = 1;
-        return false;
-    }
+    if (!small_lists<K>(hist, use_hist, b, one, M, N)) return 1;
+    small_stamp(0);
     int ptab, rpos, r;
     double pvabs, error;
-    const bool FACT = ONE;
-    if (M <= 8 && N <= 8) r = small_bond<K, 1>(c, LEFT, FACT, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
-    else if (M <= 16 && N <= 16) r = small_bond<K, 4>(c, LEFT, FACT, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
-    else r = small_bond<K, 16>(c, LEFT, FACT, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
-    if (r < 0) {
-        c.reason = 2;
-        return false;
+    const int tile = (M <= 8 && N <= 8) ? 0 : ((M <= 16 && N <= 16) ? 1 : 2);
+    if (tile == 0) {
+        if (left) r = small_bond<K, 1, true>(one, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
+        else r = small_bond<K, 1, false>(one, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
+    } else {
+        if (tile == 1) r = left ? small_bond_big<K, 4, true>(one, M, N, max_bond_dim, rel_tol, abs_tol) : small_bond_big<K, 4, false>(one, M, N, max_bond_dim, rel_tol, abs_tol);
+        else r = left ? small_bond_big<K, 16, true>(one, M, N, max_bond_dim, rel_tol, abs_tol) : small_bond_big<K, 16, false>(one, M, N, max_bond_dim, rel_tol, abs_tol);
+        r = ui(r);
+        ptab = SH.o_ptab[lane];
+        rpos = SH.o_rpos[lane];
+        pvabs = SH.o_pvabs[lane];
+        error = uniform_f64(SH.o_error);
     }
-    const int L_b = b == 0 ? 1 : ui(cur.c(0, b)); // (before the gather: I_b is not touched by bond b)
-    if (!small_gather<K>(c, cur, b, r, ptab)) {
-        c.reason = 3;
-        return false;
-    }
-    if (lane == 0) c.bond[b] = error; // (pivot_errors.back(), tensorci2.rs:1942-1949 / :1998)
-    if (!ONE) {
+    if (r < 0) return 2;
+    small_stamp(2);
+    const int L_b = b == 0 ? 1 : ui(SH.tab[0].cnt[b]); // (before the gather: I_b is not touched by bond b)
+    if (!small_gather<K>(b, r, ptab)) return 3;
+    if (lane == 0) SH.bond[b] = error; // (pivot_errors.back(), tensorci2.rs:1942-1949 / :1998)
+    small_stamp(3);
+    if (!one) {
         if (lane == 0) {
-            c.shapes[3 * b] = M;
-            c.shapes[3 * b + 1] = N;
-            c.shapes[3 * b + 2] = r;
+            SH.shapes[3 * b] = M;
+            SH.shapes[3 * b + 1] = N;
+            SH.shapes[3 * b + 2] = r;
         }
-        return true;
+        return 0;
     }
     // ---- 1-site sweep with update_tensors (tensorci2.rs:991-1017): pivot_errors (:801-808), site tensor b = LUCI left factor ----
     {   // update_pivot_errors(factors.pivot_errors): [sqrt(d * d) of the r pivots] + [error]
         const double mine = lane < r ? pvabs : error;
+        const int n_pe = ui(SH.n_pe);
         if (lane <= r) {
-            const double old = lane < c.n_pe ? c.pe[lane] : 0.0;
-            c.pe[lane] = fmax(old, mine);
+            const double old = lane < n_pe ? SH.pe[lane] : 0.0;
+            SH.pe[lane] = fmax(old, mine);
         }
-        if (r + 1 > c.n_pe) c.n_pe = r + 1;
+        if (r + 1 > n_pe && lane == 0) SH.n_pe = r + 1;
     }
     // left = P_row^T [I ; L21 L11^-1] (matrix_luci.rs:206-229): row at permuted position p < r is the unit vector e_p, the others
     // solve x L11 = l_row with L11 unit lower triangular (the scaled pivot columns of the pivot rows)
-    const int MR = (M <= 8 && N <= 8) ? 8 : ((M <= 16 && N <= 16) ? 16 : 32);
-    if ((lane & 31) < r) c.pp[lane] = ptab; // pp[k] pivot row k, pp[32 + k] pivot column k
+    const int MR = tile == 0 ? 8 : (tile == 1 ? 16 : 32);
+    if ((lane & 31) < r) SH.pp[lane] = ptab; // pp[k] pivot row k, pp[32 + k] pivot column k
     wsync();
-    const int S = c.ldim[b];
+    const int S = SH.ldim[b];
     const int R = r > 0 ? r : 1;
     if (lane < M) {
         if (r == 0) {
-            c.xs[lane] = 0.0;
+            SH.xs[lane] = 0.0;
         } else if (rpos < r) {
-            for (int k = 0; k < r; ++k) c.xs[k * 64 + lane] = (k == rpos) ? 1.0 : 0.0;
+            for (int k = 0; k < r; ++k) SH.xs[k * 64 + lane] = (k == rpos) ? 1.0 : 0.0;
         } else {
             for (int k = r - 1; k >= 0; --k) {
-                const int pck = c.pp[32 + k];
-                double s = c.Af[lane + MR * pck];
+                const int pck = SH.pp[32 + k];
+                double s = SH.Af[lane + MR * pck];
                 for (int t = k + 1; t < r; ++t) {
-                    const double prod = c.xs[t * 64 + lane] * c.Af[c.pp[t] + MR * pck];
+                    const double prod = SH.xs[t * 64 + lane] * SH.Af[SH.pp[t] + MR * pck];
                     s = s - prod;
                 }
-                c.xs[k * 64 + lane] = s;
+                SH.xs[k * 64 + lane] = s;
             }
         }
         // t(l, s, k) = left(l S + s, k), column-major [l, s, k] (tensorci2.rs:994-1004)
         const int l = div_small(lane, S), s_ = lane - l * S;
-        for (int k = 0; k < R; ++k) core[l + L_b * (s_ + S * k)] = c.xs[k * 64 + lane];
+        for (int k = 0; k < R; ++k) core[l + L_b * (s_ + S * k)] = SH.xs[k * 64 + lane];
     }
     if (lane == 0) {
-        c.cdims[3 * b] = L_b;
-        c.cdims[3 * b + 1] = S;
-        c.cdims[3 * b + 2] = R;
+        SH.cdims[3 * b] = L_b;
+        SH.cdims[3 * b + 1] = S;
+        SH.cdims[3 * b + 2] = R;
     }
     wsync();
-    return true;
+    small_stamp(4);
+    return 0;
 }
 
-// fill_site_tensors of site b (tensorci2.rs:1065-1186) from table `tb`, one wavefront; the partial-pivot LU and the substitutions of
-// fill_small_kernel (kernels_pi.hip), operation for operation.  Returns false: not representable here / singular.
+// fill_site_tensors of site b (tensorci2.rs:1065-1186) from table copy `tb`, one wavefront, workspace `wk`; the partial-pivot LU and
+// the substitutions of fill_small_kernel (kernels_pi.hip), operation for operation.  Returns false: not representable here / singular.
+// cdims != nullptr: the tensor's dimensions are recorded.
 template <int K>
-__device__ __forceinline__ bool small_fill_site(Ctx<K>& c, const Tab<K>& tb, int b, double* core, int* cdims)
+__device__ __attribute__((noinline)) int small_fill_site(int w_, int tb_, int b_, double* core, int record_dims_)
 {
     const int lane = threadIdx.x & 63;
-    const int n = c.n;
-    const int Lb = ui(tb.c(0, b)), S = c.ldim[b], wo = c.woff[b];
-    const int nj = ui(tb.c(1, b));
+    const int tb = ui(tb_), b = ui(b_);
+    SmallWork& wk = SH.wk[ui(w_)];
+    int* const cdims = ui(record_dims_) ? SH.cdims : nullptr;
+    const int n = ui(SH.n);
+    const int Lb = ui(SH.tab[tb].cnt[b]), S = SH.ldim[b], wo = SH.woff[b];
+    const int nj = ui(SH.tab[tb].cnt[n + b]);
     const int ni = Lb * S;
     if (ni > 64 || ni < 1 || nj < 1 || nj > SC) return false;
-    uint64_t* ka = c.fl;                 // [64][K] kron(I_b, d_b)
-    uint64_t* ja = c.fl + 64 * K;        // [SC][K] J_b
-    uint64_t* ia = c.fl + (64 + SC) * K; // [SC][K] I_{b+1}
+    uint64_t* ka = wk.fl;                 // [64][K] kron(I_b, d_b)
+    uint64_t* ja = wk.fl + 64 * KS;        // [SC][K] J_b
+    uint64_t* ia = wk.fl + (64 + SC) * KS; // [SC][K] I_{b+1}
     if (lane < ni) {
         const int parent = div_small(lane, S), digit = lane - parent * S;
 #pragma unroll
-        for (int q = 0; q < K; ++q) ka[lane * K + q] = tb.accs(0, b)[parent * K + q] + c.w[q * c.total + wo + digit];
+        for (int q = 0; q < K; ++q) ka[lane * KS + q] = SH.tab[tb].acc[(b * SC + parent) * KS + q] + SH.w[q * SH.total + wo + digit];
     }
     if (lane < nj) {
 #pragma unroll
-        for (int q = 0; q < K; ++q) ja[lane * K + q] = tb.accs(1, b)[lane * K + q];
+        for (int q = 0; q < K; ++q) ja[lane * KS + q] = SH.tab[tb].acc[((n + b) * SC + lane) * KS + q];
     }
     const bool last = b == n - 1;
-    const int np = last ? 0 : ui(tb.c(0, b + 1));
+    const int np = last ? 0 : ui(SH.tab[tb].cnt[b + 1]);
     if (!last) {
         if (np != nj) return false;
         if (lane < np) {
 #pragma unroll
-            for (int q = 0; q < K; ++q) ia[lane * K + q] = tb.accs(0, b + 1)[lane * K + q];
+            for (int q = 0; q < K; ++q) ia[lane * KS + q] = SH.tab[tb].acc[((b + 1) * SC + lane) * KS + q];
         }
     }
     wsync();
     const int left_dim = b == 0 ? 1 : Lb;
     if (last) { // :1109-1128: t(l, s, 0) = Pi1(l S + s, 0)
-        if (lane < ni) {
-            uint64_t acc[2] = {0, 0};
+        uint64_t acc[2] = {0, 0};
 #pragma unroll
-            for (int q = 0; q < K; ++q) acc[q] = ka[lane * K + q] + ja[q];
-            const double v = small_fn_value(c.fid, acc[0], acc[1], c.params);
+        for (int q = 0; q < K; ++q) acc[q] = ka[(lane < ni ? lane : 0) * KS + q] + ja[q];
+        const double v = small_fn_value(acc[0], acc[1]);
+        if (lane < ni) {
             const int l = div_small(lane, S), s_ = lane - l * S;
             core[l + left_dim * s_] = v;
         }
-        if (lane == 0) {
+        if (cdims && lane == 0) {
             cdims[3 * b] = left_dim;
             cdims[3 * b + 1] = S;
             cdims[3 * b + 2] = 1;
@@ -554,29 +601,32 @@ __device__ __forceinline__ bool small_fill_site(Ctx<K>& c, const Tab<K>& tb, int
         return true;
     }
     const int nn = nj, nrhs = ni;
-    double* As = c.As; // P^T, nn x nn column-major: As[col * nn + i] = f(I_{b+1}[col], J_b[i])
-    double* Bs = c.Bs; // Pi1^T, nn x nrhs:          Bs[col * nn + i] = f(kron[col], J_b[i])
+    double* As = wk.As; // P^T, nn x nn column-major: As[col * nn + i] = f(I_{b+1}[col], J_b[i])
+    double* Bs = wk.Bs; // Pi1^T, nn x nrhs:          Bs[col * nn + i] = f(kron[col], J_b[i])
     double pm = 0.0;
     bool bad = false;
-    for (int e = lane; e < nn * nn; e += 64) {
-        const int col = div_small(e, nn), i = e - col * nn;
+    // one pass over both matrices: entry e < nn * nn belongs to P^T, the rest to Pi1^T (ONE call of the functor per 64 entries)
+    const int nA = nn * nn, nAll = nA + nn * nrhs;
+    for (int e0 = 0; e0 < nAll; e0 += 64) {
+        const int e = e0 + lane;
+        const bool in = e < nAll;
+        const bool isA = e < nA;
+        const int eb = in ? (isA ? e : e - nA) : 0;
+        const int col = div_small(eb, nn), i = eb - col * nn;
         uint64_t acc[2] = {0, 0};
 #pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] = ia[col * K + q] + ja[i * K + q];
-        const double v = small_fn_value(c.fid, acc[0], acc[1], c.params);
-        As[e] = v;
-        bad |= !((v - v) == 0.0);
-        const double av = sqrt(v * v);
-        if (av > pm) pm = av;
-    }
-    for (int e = lane; e < nn * nrhs; e += 64) {
-        const int col = div_small(e, nn), i = e - col * nn;
-        uint64_t acc[2] = {0, 0};
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] = ka[col * K + q] + ja[i * K + q];
-        const double v = small_fn_value(c.fid, acc[0], acc[1], c.params);
-        Bs[e] = v;
-        bad |= !((v - v) == 0.0);
+        for (int q = 0; q < K; ++q) acc[q] = (isA ? ia[col * KS + q] : ka[col * KS + q]) + ja[i * KS + q];
+        const double v = small_fn_value(acc[0], acc[1]);
+        if (in) {
+            if (isA) {
+                As[eb] = v;
+                const double av = sqrt(v * v);
+                if (av > pm) pm = av;
+            } else {
+                Bs[eb] = v;
+            }
+            bad |= !((v - v) == 0.0);
+        }
     }
     if (__ballot(bad) != 0ull) return false;
     wsync();
@@ -656,7 +706,7 @@ __device__ __forceinline__ bool small_fill_site(Ctx<K>& c, const Tab<K>& tb, int
         const int l = div_small(lane, S), s_ = lane - l * S;
         for (int r = 0; r < nn; ++r) core[l + left_dim * (s_ + S * r)] = zero ? 0.0 : Bs[lane * nn + r];
     }
-    if (lane == 0) {
+    if (cdims && lane == 0) {
         cdims[3 * b] = left_dim;
         cdims[3 * b + 1] = S;
         cdims[3 * b + 2] = nn;
@@ -666,83 +716,84 @@ __device__ __forceinline__ bool small_fill_site(Ctx<K>& c, const Tab<K>& tb, int
 }
 
 template <int K>
-__device__ __forceinline__ void small_copy_tab(const Tab<K>& dst, const Tab<K>& src, int n)
+__device__ __forceinline__ void small_copy_tab(int dst, int src)
 {
     const int lane = threadIdx.x & 63;
-    for (int e = lane; e < 2 * n; e += 64) dst.cnt[e] = src.cnt[e];
+    const int n = ui(SH.n);
+    const int* scnt = SH.tab[src].cnt;
+    for (int e = lane; e < 2 * n; e += 64) SH.tab[dst].cnt[e] = scnt[e];
     for (int e = lane; e < 2 * n * SC; e += 64) {
         const int fp = e / SC, k = e - fp * SC;
-        if (k < src.cnt[fp]) {
-            dst.code[e] = src.code[e];
+        if (k < scnt[fp]) {
+            SH.tab[dst].code[e] = SH.tab[src].code[e];
 #pragma unroll
-            for (int q = 0; q < K; ++q) dst.acc[(size_t)e * K + q] = src.acc[(size_t)e * K + q];
+            for (int q = 0; q < K; ++q) SH.tab[dst].acc[e * KS + q] = SH.tab[src].acc[e * KS + q];
         }
     }
     wsync();
 }
 
-template <int K>
-__device__ __forceinline__ void small_export_tab(const Tab<K>& src, int n, int* g_cnt, uint64_t* g_code)
+__device__ __forceinline__ void small_export_tab(int src, int* g_cnt, uint64_t* g_code)
 {
     const int lane = threadIdx.x & 63;
-    for (int e = lane; e < 2 * n; e += 64) g_cnt[e] = src.cnt[e];
+    const int n = ui(SH.n);
+    const int* scnt = SH.tab[src].cnt;
+    for (int e = lane; e < 2 * n; e += 64) g_cnt[e] = scnt[e];
     for (int e = lane; e < 2 * n * SC; e += 64) {
         const int fp = e / SC, k = e - fp * SC;
-        if (k < src.cnt[fp]) g_code[e] = src.code[e];
+        if (k < scnt[fp]) g_code[e] = SH.tab[src].code[e];
     }
 }
 
+__device__ __forceinline__ int lds_load_acquire(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store_release(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// waves 1 .. SMALL_WORKERS: fill_site_tensors (tensorci2.rs:1065-1186) of the sites w - 1, w - 1 + SMALL_WORKERS, ... for every job
+// wave 0 publishes.  Job e = the fill of iteration e - 1, read from snapshot slot 1 + e % 2 (the sets at the start of iteration e, i.e.
+// the sets iteration e - 1 left behind).  Nobody reads these tensors (the next iteration or the final 1-site sweep overwrites every
+// site tensor; the reference invalidates them, tensorci2.rs:707-708): they go to the scratch block.
 template <int K>
-__global__ void __launch_bounds__(64) small_optimize_kernel(SmallArgs a)
+__device__ __forceinline__ void small_worker(double* scratch, size_t scratch_stride, int w)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63;
+    int next = 1;
+    for (;;) {
+        int job = lds_load_acquire(&SH.job);
+        while (job < next) {
+            if (lds_load_acquire(&SH.quit) != 0) {
+                job = lds_load_acquire(&SH.job);
+                if (job < next) return;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            job = lds_load_acquire(&SH.job);
+        }
+        const int slot = 1 + next % 2;
+        const int n = ui(SH.n);
+        int ok = 1;
+        for (int b = w - 1; b < n && ok; b += SMALL_WORKERS) ok = small_fill_site<K>(w, slot, b, scratch + (size_t)b * scratch_stride, 0);
+        if (!ok && (threadIdx.x & 63) == 0) SH.fail[w] = next;
+        wsync();
+        if ((threadIdx.x & 63) == 0) lds_store_release(&SH.done[w], next);
+        ++next;
+    }
+}
+
+// the slot about to be overwritten was last read by fill job `upto`: every worker must be through with it
+__device__ __forceinline__ void small_wait_jobs(int upto)
+{
+    for (int w = 1; w < SMALL_WAVES; ++w)
+        while (lds_load_acquire(&SH.done[w]) < upto) __builtin_amdgcn_s_sleep(2);
+}
+
+template <int K>
+__global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long t_begin = small_clock();
     const SmallHeader* const hd = &a.h;
     const int n = ui(hd->n), total = ui(hd->total);
-    const SmallLds L = small_lds(n, K, total);
-    Ctx<K> c;
-    c.n = n;
-    c.total = total;
-    c.fid = hd->fid;
-    c.tab_base = lds + L.o_tab;
-    c.tab_bytes = (unsigned)L.tab_bytes;
-    c.tab_o_code = (unsigned)L.o_code;
-    c.tab_o_acc = (unsigned)L.o_acc;
-    {
-        double* pl = reinterpret_cast<double*>(lds + L.o_params);
-        if (lane < T4A_FN_MAX_PARAMS) pl[lane] = hd->params[lane];
-        c.params = pl;
-    }
-    c.w = reinterpret_cast<uint64_t*>(lds + L.o_w);
-    c.ldim = reinterpret_cast<int*>(lds + L.o_ldim);
-    c.woff = reinterpret_cast<int*>(lds + L.o_woff);
-    c.lcode = reinterpret_cast<uint64_t*>(lds + L.o_lcode);
-    c.lacc = reinterpret_cast<uint64_t*>(lds + L.o_lacc);
-    c.bond = reinterpret_cast<double*>(lds + L.o_bond);
-    c.shapes = reinterpret_cast<int*>(lds + L.o_shapes);
-    c.err = reinterpret_cast<double*>(lds + L.o_err);
-    c.rank = reinterpret_cast<int*>(lds + L.o_rank);
-    c.pe = reinterpret_cast<double*>(lds + L.o_pe);
-    c.As = reinterpret_cast<double*>(lds + L.o_As);
-    c.Bs = reinterpret_cast<double*>(lds + L.o_Bs);
-    c.fl = reinterpret_cast<uint64_t*>(lds + L.o_fl);
-    c.Af = reinterpret_cast<double*>(lds + L.o_Af);
-    c.xs = reinterpret_cast<double*>(lds + L.o_xs);
-    c.pp = reinterpret_cast<int*>(lds + L.o_pp);
-    c.cdims = reinterpret_cast<int*>(lds + L.o_cdims);
-    c.n_pe = 0;
-    c.reason = 0;
-    c.msv = hd->max_sample_value;
-    const int max_iter = ui(hd->max_iter), ncheck = ui(hd->ncheck), strategy = ui(hd->sweep_strategy), flags = ui(hd->flags);
-    const int max_bond_dim = ui(hd->max_bond_dim);
-    const double tolerance = hd->tolerance;
-    const bool normalize = flags & 1, strictly_nested = flags & 2, final_sweep = flags & 4;
-    double* const* const cores = reinterpret_cast<double* const*>(a.in + hd->o_cores);
-    const SmallOutLayout OL = small_out_layout(n);
-    SmallOutHeader* const oh = reinterpret_cast<SmallOutHeader*>(a.out);
-
-    // ---- input: site info, weights, the current sets (packed: cnt[f n + p] entries at off[f n + p]) ----
+    const int flags = ui(hd->flags);
+    // ---- input: site info, weights, the current sets; all four waves copy ----
     {
         const int* g_ldim = reinterpret_cast<const int*>(a.in + hd->o_ldim);
         const int* g_woff = reinterpret_cast<const int*>(a.in + hd->o_woff);
@@ -751,30 +802,54 @@ __global__ void __launch_bounds__(64) small_optimize_kernel(SmallArgs a)
         const uint64_t* g_code = reinterpret_cast<const uint64_t*>(a.in + hd->o_code);
         const uint64_t* g_acc = reinterpret_cast<const uint64_t*>(a.in + hd->o_acc);
         const int cap_in = ui(hd->cap_in);
-        for (int e = lane; e < n; e += 64) {
-            c.ldim[e] = g_ldim[e];
-            c.woff[e] = g_woff[e];
-            c.bond[e] = 0.0;
-            c.shapes[3 * e] = c.shapes[3 * e + 1] = c.shapes[3 * e + 2] = 0;
-            c.cdims[3 * e] = c.cdims[3 * e + 1] = c.cdims[3 * e + 2] = 0;
+        const int tid = threadIdx.x, T = 64 * SMALL_WAVES;
+        for (int e = tid; e < n; e += T) {
+            SH.ldim[e] = g_ldim[e];
+            SH.woff[e] = g_woff[e];
+            SH.bond[e] = 0.0;
+            SH.shapes[3 * e] = SH.shapes[3 * e + 1] = SH.shapes[3 * e + 2] = 0;
+            SH.cdims[3 * e] = SH.cdims[3 * e + 1] = SH.cdims[3 * e + 2] = 0;
         }
-        for (int e = lane; e < K * total; e += 64) c.w[e] = g_w[e];
-        const Tab<K> t0 = c.tab(0);
-        for (int e = lane; e < 2 * n; e += 64) t0.cnt[e] = g_cnt[e];
-        for (int e = lane; e < 2 * n * cap_in; e += 64) { // (every slot: no load waits for a count)
+        for (int e = tid; e < K * total; e += T) SH.w[e] = g_w[e];
+        for (int e = tid; e < 2 * n; e += T) SH.tab[0].cnt[e] = g_cnt[e];
+        for (int e = tid; e < 2 * n * cap_in; e += T) { // (every slot: no load waits for a count)
             const int fp = e / cap_in, k = e - fp * cap_in;
-            t0.code[(size_t)fp * SC + k] = g_code[e];
+            SH.tab[0].code[fp * SC + k] = g_code[e];
 #pragma unroll
-            for (int q = 0; q < K; ++q) t0.acc[((size_t)fp * SC + k) * K + q] = g_acc[(size_t)e * K + q];
+            for (int q = 0; q < K; ++q) SH.tab[0].acc[(fp * SC + k) * KS + q] = g_acc[(size_t)e * K + q];
         }
-        wsync();
+        if (tid < T4A_FN_MAX_PARAMS) SH.params[tid] = hd->params[tid];
+        if (tid == 0) {
+            SH.fid = hd->fid;
+            SH.n = n;
+            SH.total = total;
+            SH.n_pe = 0;
+            SH.msv = hd->max_sample_value;
+            SH.stamps = (flags & 8) ? 1 : 0;
+            SH.job = 0;
+            SH.quit = 0;
+            SH.ph_last = (flags & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
+            for (int q = 0; q < SMALL_WAVES; ++q) SH.done[q] = SH.fail[q] = 0;
+            for (int q = 0; q < 8; ++q) SH.ph[q] = 0ull;
+        }
+        __syncthreads();
     }
-    const Tab<K> cur = c.tab(0);
+    if (wave > 0) {
+        small_worker<K>(a.scratch, a.scratch_stride, wave);
+        return;
+    }
     const unsigned long long t_loaded = small_clock();
+    const int max_iter = ui(hd->max_iter), ncheck = ui(hd->ncheck), strategy = ui(hd->sweep_strategy);
+    const int max_bond_dim = ui(hd->max_bond_dim);
+    const double tolerance = hd->tolerance;
+    const bool normalize = flags & 1, strictly_nested = flags & 2, final_sweep = flags & 4;
+    double* const* const cores = reinterpret_cast<double* const*>(a.in + hd->o_cores);
+    int reason = 0;
 
     int iters_done = 0, converged = 0, termination = 2 /* MaxIterations */, final_done = 0, status = 1;
+    int jobs = 0; // fill jobs published
     // One loop runs the iterations (tensorci2.rs:1659-1776) and then, as its last pass, the final 1-site sweep (:1781-1794): the
-    // bond update and the fill have ONE call site each (everything is inlined into this kernel).
+    // bond update has ONE call site.
     bool final_phase = false;
     for (;;) {
         if (!final_phase && (iters_done >= max_iter || converged)) {
@@ -782,7 +857,8 @@ __global__ void __launch_bounds__(64) small_optimize_kernel(SmallArgs a)
             final_phase = true;
         }
         const int iter = iters_done;
-        const double norm = (normalize && c.msv > 0.0) ? c.msv : 1.0;
+        const double msv0 = uniform_f64(SH.msv);
+        const double norm = (normalize && msv0 > 0.0) ? msv0 : 1.0;
         bool forward = true;
         if (!final_phase) {
             if (strategy == 1) forward = false;
@@ -791,30 +867,39 @@ __global__ void __launch_bounds__(64) small_optimize_kernel(SmallArgs a)
         // extras: the sets at the start of the previous iteration (:1675-1685); then the sets as they are join the history (:1686-1689).
         // (The final sweep takes its snapshot into the slot the next iteration would have used: a failure in it hands that state back.)
         const bool use_hist = !final_phase && !strictly_nested && iter > 0;
-        const Tab<K> hist = c.tab(1 + (iter + 2) % 3); // (slot of iteration iter - 1)
-        const Tab<K> snap = c.tab(1 + iter % 3);
-        small_copy_tab<K>(snap, cur, n);
-        const double msv0 = c.msv;
+        const int hist = 1 + (iter + 1) % 2; // (slot of iteration iter - 1)
+        const int snap = 1 + iter % 2;
+        small_stamp(7);
+        // this slot holds the sets at the start of iteration iter - 2, which fill job iter - 2 read
+        if (iter >= 3) small_wait_jobs(iter - 2);
+        small_copy_tab<K>(snap, 0);
+        // fill_site_tensors of the iteration that has just ended (:1065-1186, tensorci2.rs:1727): the sets it left behind are this
+        // snapshot; the other waves run it while this one walks on
+        if (iter > 0) {
+            jobs = iter;
+            if (lane == 0) lds_store_release(&SH.job, jobs);
+        }
+        small_stamp(6);
         const double rel_tol = final_phase ? 1e-14 : tolerance, abs_tol = final_phase ? tolerance * norm : 0.0;
-        if (final_phase) c.n_pe = 0; // flush_pivot_errors (:900)
-        else
-            for (int e = lane; e < n; e += 64) c.shapes[3 * e] = c.shapes[3 * e + 1] = c.shapes[3 * e + 2] = 0;
-        bool ok = true;
-        for (int step = 0; step + 1 < n && ok; ++step) {
+        if (final_phase) {
+            if (lane == 0) SH.n_pe = 0; // flush_pivot_errors (:900)
+        } else {
+            for (int e = lane; e < n; e += 64) SH.shapes[3 * e] = SH.shapes[3 * e + 1] = SH.shapes[3 * e + 2] = 0;
+        }
+        wsync();
+        int why = 0;
+        for (int step = 0; step + 1 < n && why == 0; ++step) {
             const int b = forward ? step : n - 2 - step;
-            ok = small_update<K>(c, forward, final_phase, cur, hist, use_hist, b, max_bond_dim, rel_tol, abs_tol, cores[b]);
+            why = ui(small_update<K>(forward ? 1 : 0, final_phase ? 1 : 0, hist, use_hist ? 1 : 0, b, max_bond_dim, rel_tol, abs_tol, cores[b]));
         }
-        // fill_site_tensors (:1065-1186).  Its tensors are read by nobody when the final 1-site sweep follows (it overwrites every
-        // site tensor): they go to the scratch block then, to the handle's site tensors otherwise.  The final sweep itself only
-        // evaluates the last site's tensor (fill_tensor, :1040-1043).
-        for (int b = final_phase ? n - 1 : 0; b < n && ok; ++b) {
-            double* dst = (final_phase || !final_sweep) ? cores[b] : a.scratch + (size_t)b * a.scratch_stride;
-            ok = small_fill_site<K>(c, cur, b, dst, c.cdims);
-            if (!ok) c.reason = 4;
+        if (why == 0 && final_phase) { // fill_tensor(I_last, J_last) (:1040-1043)
+            if (!ui(small_fill_site<K>(0, 0, n - 1, cores[n - 1], 1))) why = 4;
+            small_stamp(5);
         }
-        if (!ok) { // hand the state at the start of this pass back
-            small_copy_tab<K>(cur, snap, n);
-            c.msv = msv0;
+        if (why != 0) { // hand the state at the start of this pass back
+            small_copy_tab<K>(0, snap);
+            if (lane == 0) SH.msv = msv0;
+            reason = why;
             status = 2;
             break;
         }
@@ -824,14 +909,14 @@ __global__ void __launch_bounds__(64) small_optimize_kernel(SmallArgs a)
             break;
         }
         double error = 0.0;
-        for (int b = 0; b + 1 < n; ++b) error = fmax(error, c.bond[b]);
+        for (int b = 0; b + 1 < n; ++b) error = fmax(error, SH.bond[b]);
         int rk = 0;
-        for (int p = 1; p < n; ++p) rk = max(rk, cur.cnt[p]);
+        for (int p = 1; p < n; ++p) rk = max(rk, SH.tab[0].cnt[p]);
         rk = ui(rk);
         error = uniform_f64(error);
         if (lane == 0) {
-            c.err[iter] = error / norm;
-            c.rank[iter] = rk;
+            SH.err[iter] = error / norm;
+            SH.rank[iter] = rk;
         }
         wsync();
         iters_done = iter + 1;
@@ -840,11 +925,11 @@ __global__ void __launch_bounds__(64) small_optimize_kernel(SmallArgs a)
             bool errors_converged = true, at_max = true;
             int min_rank = 0x7fffffff;
             for (int q = iters_done - ncheck; q < iters_done; ++q) {
-                if (!(c.err[q] < tolerance)) errors_converged = false;
-                if (!(c.rank[q] >= max_bond_dim)) at_max = false;
-                min_rank = min(min_rank, c.rank[q]);
+                if (!(SH.err[q] < tolerance)) errors_converged = false;
+                if (!(SH.rank[q] >= max_bond_dim)) at_max = false;
+                min_rank = min(min_rank, SH.rank[q]);
             }
-            const bool rank_stable = min_rank == c.rank[iters_done - 1];
+            const bool rank_stable = min_rank == SH.rank[iters_done - 1];
             if (at_max) {
                 termination = 1;
                 converged = 1;
@@ -856,50 +941,75 @@ __global__ void __launch_bounds__(64) small_optimize_kernel(SmallArgs a)
             termination = ui(termination);
         }
     }
+    // the fill of the last completed iteration, when no later pass published it (no final sweep, or the loop handed over: `cur` was
+    // restored to what that iteration left behind): snapshot the sets into the free slot first
+    if (jobs < iters_done) {
+        const int snap = 1 + iters_done % 2;
+        if (iters_done >= 3) small_wait_jobs(iters_done - 2);
+        small_copy_tab<K>(snap, 0);
+        jobs = iters_done;
+        if (lane == 0) lds_store_release(&SH.job, jobs);
+    }
+    if (lane == 0) lds_store_release(&SH.quit, 1);
     const unsigned long long t_iters = small_clock();
-    const int hist_slot = iters_done > 0 ? 1 + (iters_done - 1) % 3 : -1;
+    small_wait_jobs(jobs);
+    small_stamp(5);
+    {   // a site that could not be filled (singular pivot matrix, shapes beyond the workspace): the whole call goes to the general
+        // path, which reports what the reference reports
+        int any_fail = 0;
+        for (int w = 1; w < SMALL_WAVES; ++w) any_fail |= SH.fail[w];
+        if (ui(any_fail) != 0) {
+            status = 3;
+            reason = 4;
+        }
+    }
+    // the history entry the host keeps: the sets at the start of the last completed iteration
+    const int hist_slot = iters_done > 0 ? 1 + (iters_done - 1) % 2 : -1;
     // ---- results ----
     wsync();
     {
+        const SmallOutLayout OL = small_out_layout(n);
+        SmallOutHeader* const oh = reinterpret_cast<SmallOutHeader*>(a.out);
         double* g_err = reinterpret_cast<double*>(a.out + OL.o_err);
         int* g_rank = reinterpret_cast<int*>(a.out + OL.o_rank);
         double* g_bond = reinterpret_cast<double*>(a.out + OL.o_bond);
         double* g_pe = reinterpret_cast<double*>(a.out + OL.o_pe);
         int* g_shapes = reinterpret_cast<int*>(a.out + OL.o_shapes);
         int* g_cdims = reinterpret_cast<int*>(a.out + OL.o_cdims);
+        const int n_pe = ui(SH.n_pe);
         for (int e = lane; e < iters_done; e += 64) {
-            g_err[e] = c.err[e];
-            g_rank[e] = c.rank[e];
+            g_err[e] = SH.err[e];
+            g_rank[e] = SH.rank[e];
         }
-        for (int e = lane; e < n; e += 64) g_bond[e] = c.bond[e];
-        for (int e = lane; e < c.n_pe; e += 64) g_pe[e] = c.pe[e];
+        for (int e = lane; e < n; e += 64) g_bond[e] = SH.bond[e];
+        for (int e = lane; e < n_pe; e += 64) g_pe[e] = SH.pe[e];
         for (int e = lane; e < 3 * n; e += 64) {
-            g_shapes[e] = c.shapes[e];
-            g_cdims[e] = c.cdims[e];
+            g_shapes[e] = SH.shapes[e];
+            g_cdims[e] = SH.cdims[e];
         }
-        small_export_tab<K>(cur, n, reinterpret_cast<int*>(a.out + OL.o_cnt), reinterpret_cast<uint64_t*>(a.out + OL.o_code));
-        if (hist_slot >= 0)
-            small_export_tab<K>(c.tab(hist_slot), n, reinterpret_cast<int*>(a.out + OL.o_hcnt), reinterpret_cast<uint64_t*>(a.out + OL.o_hcode));
+        small_export_tab(0, reinterpret_cast<int*>(a.out + OL.o_cnt), reinterpret_cast<uint64_t*>(a.out + OL.o_code));
+        if (hist_slot >= 0) small_export_tab(hist_slot, reinterpret_cast<int*>(a.out + OL.o_hcnt), reinterpret_cast<uint64_t*>(a.out + OL.o_hcode));
         if (lane == 0) {
             oh->status = status;
             oh->iters_done = iters_done;
             oh->converged = converged;
             oh->termination = termination;
-            oh->n_pivot_errors = c.n_pe;
+            oh->n_pivot_errors = n_pe;
             oh->final_done = final_done;
             oh->hist_valid = hist_slot >= 0 ? 1 : 0;
-            oh->reason = c.reason;
-            oh->max_sample_value = c.msv;
+            oh->reason = reason;
+            oh->max_sample_value = SH.msv;
             oh->clocks[0] = t_loaded - t_begin;
             oh->clocks[1] = t_iters - t_loaded;
             oh->clocks[2] = small_clock() - t_iters;
-            oh->clocks[3] = 0ull;
+            for (int q = 0; q < 8; ++q) oh->clocks[3 + q] = SH.ph[q];
+            oh->clocks[11] = 0ull;
         }
-    }
-    __threadfence_system();
-    if (lane == 0) {
-        volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(a.out + OL.o_flag);
-        *flag = a.token;
+        __threadfence_system();
+        if (lane == 0) {
+            volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(a.out + OL.o_flag);
+            *flag = a.token;
+        }
     }
 }
 
@@ -907,22 +1017,16 @@ __global__ void __launch_bounds__(64) small_optimize_kernel(SmallArgs a)
 
 size_t small_lds_bytes(int n, int K, int total)
 {
-    if (n < 2 || n > SMALL_MAX_SITES || K < 1 || K > 2 || total < 1 || K * total > SMALL_MAX_W) return 0;
-    const SmallLds L = small_lds(n, K, total);
-    return L.bytes <= (size_t)150 * 1024 ? L.bytes : 0;
+    // (everything is static LDS: the value only says whether the problem fits the fixed tables)
+    if (n < 2 || n > SMALL_MAX_SITES || K < 1 || K > KS || total < 1 || K * total > SMALL_MAX_W) return 0;
+    return sizeof(SmallStatic);
 }
 
 void small_optimize_launch(const SmallArgs& a, int n, int K, int total, hipStream_t stream)
 {
-    const size_t bytes = small_lds_bytes(n, K, total);
-    if (bytes == 0) throw std::runtime_error("small_optimize_launch: the problem does not fit the small-problem engine");
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_optimize_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_optimize_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    });
-    if (K == 1) hipLaunchKernelGGL(small_optimize_kernel<1>, dim3(1), dim3(64), bytes, stream, a);
-    else hipLaunchKernelGGL(small_optimize_kernel<2>, dim3(1), dim3(64), bytes, stream, a);
+    if (small_lds_bytes(n, K, total) == 0) throw std::runtime_error("small_optimize_launch: the problem does not fit the small-problem engine");
+    if (K == 1) hipLaunchKernelGGL(small_optimize_kernel<1>, dim3(1), dim3(64 * SMALL_WAVES), 0, stream, a);
+    else hipLaunchKernelGGL(small_optimize_kernel<2>, dim3(1), dim3(64 * SMALL_WAVES), 0, stream, a);
 }
 
 } // namespace t4a

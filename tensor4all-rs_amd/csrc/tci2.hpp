@@ -105,7 +105,8 @@ public:
     bool small_enabled = true;
     // [0] optimize calls it completed [1] iterations it ran [2] runs it handed back to the general path [3] calls that were not eligible
     std::array<uint64_t, 4> small_stats{{0, 0, 0, 0}};
-    uint64_t small_last_clocks_[3] = {0, 0, 0}; // last launch, 100 MHz ticks: input, iterations, final sweep + results
+    uint64_t small_last_clocks_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // last launch (SmallOutHeader::clocks)
+    bool small_stamps = false; // the launch stamps its phases (diagnostic: t4a_gpu_tci2_set_chain bit 3)
     int small_last_reason_ = 0;
     bool small_engine_eligible(const TCI2Options& options) const;
     bool small_engine_run(OptRun& r);

@@ -60,7 +60,7 @@ bool Tci2::small_engine_run(OptRun& r)
     h.max_iter = (int)options.max_iter;
     h.ncheck = (int)options.ncheck_history;
     h.sweep_strategy = options.sweep_strategy;
-    h.flags = (options.normalize_error ? 1 : 0) | (options.strictly_nested ? 2 : 0) | (r.final_sweep1site ? 4 : 0);
+    h.flags = (options.normalize_error ? 1 : 0) | (options.strictly_nested ? 2 : 0) | (r.final_sweep1site ? 4 : 0) | (small_stamps ? 8 : 0);
     h.max_bond_dim = (int)std::min<size_t>(options.max_bond_dim_or_max(), (size_t)1 << 30);
     h.cap_in = (int)cap_in;
     h.tolerance = options.tolerance;
@@ -144,10 +144,12 @@ bool Tci2::small_engine_run(OptRun& r)
         if (*flag != a.token) throw Error(T4A_GPU_INTERNAL_ERROR, "small-problem engine: the launch did not complete");
     }
     const SmallOutHeader oh = *reinterpret_cast<const SmallOutHeader*>(out);
-    small_last_clocks_[0] = oh.clocks[0];
-    small_last_clocks_[1] = oh.clocks[1];
-    small_last_clocks_[2] = oh.clocks[2];
+    for (int q = 0; q < 12; ++q) small_last_clocks_[q] = oh.clocks[q];
     small_last_reason_ = oh.reason;
+    if (oh.status == 3) { // a site tensor could not be filled inside the launch: the general path runs the call from the start
+        ++small_stats[2];
+        return false;
+    }
     if (oh.status != 1 && oh.status != 2) throw Error(T4A_GPU_INTERNAL_ERROR, "small-problem engine: unexpected status");
     const size_t iters = (size_t)oh.iters_done;
     if (oh.status == 2 && iters == 0 && !oh.final_done) { // nothing was advanced: the general path starts from the state as it is
@@ -201,7 +203,8 @@ bool Tci2::small_engine_run(OptRun& r)
         for (size_t b = 0; b + 1 < n_; ++b) last_sweep_shapes[b] = {(size_t)sh[3 * b], (size_t)sh[3 * b + 1], (size_t)sh[3 * b + 2]};
     }
     const bool loop_over = r.done || iters >= options.max_iter;
-    const bool cores_valid = oh.status == 1 && (oh.final_done || !r.final_sweep1site);
+    // (without the final sweep the reference leaves every site tensor invalidated: add_global_pivots of the last iteration, tensorci2.rs:707-708)
+    const bool cores_valid = oh.status == 1 && oh.final_done;
     if (oh.final_done) {
         const double* pe = reinterpret_cast<const double*>(out + OL.o_pe);
         pivot_errors.assign(pe, pe + oh.n_pivot_errors);

@@ -732,20 +732,21 @@ class TensorCI2:
         return [dict(code=int(r[0]), ms=float(r[1]), launches=float(r[2]), bytes=float(r[3]), steps=float(r[4])) for r in out[: n.value]]
 
 
-    def set_chain(self, enable=True, verify=False, event_timing=False, small_engine=True):
+    def set_chain(self, enable=True, verify=False, event_timing=False, small_engine=True, small_stamps=False):
         """Device-side bond chain on / off for this handle; verify: read the device tables back after every chain; event_timing:
         while profiling, time the rrLU launches with HIP events instead of the kernels' own time stamps; small_engine=False: the
         one-launch engine for small problems is not offered the handle's optimize calls."""
         _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0),
-                                           c_int32((1 if verify else 0) | (2 if event_timing else 0) | (0 if small_engine else 4))))
+                                           c_int32((1 if verify else 0) | (2 if event_timing else 0) | (0 if small_engine else 4) | (8 if small_stamps else 0))))
 
     def small_stats(self):
         """Small-problem engine (one launch per optimize call): dict(completed, iterations, handed_back, not_eligible,
         device_us=(input, iterations, final sweep + results) of the last launch, reason)."""
-        out = (ctypes.c_uint64 * 8)()
+        out = (ctypes.c_uint64 * 16)()
         _check(_lib.t4a_gpu_tci2_small_stats(self._h, out))
         return {"completed": int(out[0]), "iterations": int(out[1]), "handed_back": int(out[2]), "not_eligible": int(out[3]),
-                "device_us": (out[4] / 100.0, out[5] / 100.0, out[6] / 100.0), "reason": int(out[7])}
+                "device_us": (out[4] / 100.0, out[5] / 100.0, out[6] / 100.0), "reason": int(out[7]),
+                "phase_cycles": dict(zip(("lists", "evaluation", "pivot_steps", "gather", "factors", "fill", "snapshots", "rest"), (int(out[8 + k]) for k in range(8))))}
 
     def rook_stats(self):
         out = (ctypes.c_uint64 * 4)()

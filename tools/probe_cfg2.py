@@ -26,6 +26,11 @@ for name, spec, n, chi in (("cfg2 cos(10x)exp(-x)", quantics_trig_exp(20), 20, 6
         w.crossinterpolate2([[0] * n], opt)
         tw = min(tw, time.perf_counter() - t0)
     print(f"{name}: small engine {g.small_stats()}, without it {tw*1e3:.3f} ms", flush=True)
+    d = t4a_amd.TensorCI2([2] * n)
+    d.set_function(spec)
+    d.set_chain(True, small_stamps=True)
+    d.crossinterpolate2([[0] * n], opt)
+    print(f"{name}: stamped launch {d.small_stats()}", flush=True)
     o = ob.OracleTCI2([2] * n)
     o.set_function(spec)
     t0 = time.perf_counter()
