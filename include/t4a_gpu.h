@@ -58,6 +58,10 @@ t4a_gpu_status t4a_gpu_device_count(int32_t* out_count);
 t4a_gpu_status t4a_gpu_set_device(int32_t device);
 /* Library version string. */
 const char* t4a_gpu_version(void);
+/* 1: the library was built with -DT4A_DIAG_SWITCHES (experiment switches of tools/ are read from the environment), 0: a production
+ * build — every T4A_* experiment variable is a no-op there (a known one found in the environment is reported on stderr once).  The A/B
+ * launchers under tools/ call this and refuse to label a run as a variant on a production build. */
+int32_t t4a_gpu_diag_switches_enabled(void);
 
 /* The random stream of the reference's seeded searches: `rand 0.9` `StdRng::seed_from_u64(seed)` followed by
  * `rng.random_range(0..dims[i])` for i = 0 .. n-1 (tensorci2.rs:1653-1657 + globalpivot.rs:174-180,
@@ -68,6 +72,25 @@ t4a_gpu_status t4a_gpu_stdrng_sample(uint64_t seed, const size_t* dims, size_t n
  * the known-answer hook for the published vectors (RFC 8439 2.3.2; zero-key ChaCha20 / ChaCha12).  `StdRng` is the 12-round stream
  * with counter 0, stream 0. */
 t4a_gpu_status t4a_gpu_chacha_block(const uint32_t* key8, uint64_t counter, uint64_t stream, int32_t rounds, uint32_t* out16);
+/* The reference's two other seeded streams, restated from their published algorithms (csrc/smallrng.hpp), host only:
+ *   - TreeTCI proposers (tensor4all-treetci/src/proposer.rs:344-409): std `DefaultHasher` = SipHash-1-3 with the zero key over
+ *     (seed, tag, edge, history length, pivot counts) -> rand 0.9 `SmallRng::seed_from_u64` (xoshiro256++) -> `random_range` /
+ *     `shuffle`;
+ *   - ACI initial guess (tensor4all-aci/src/random_tt.rs:31,143-150): `ChaCha8Rng::seed_from_u64` + rand_distr `StandardNormal`.
+ * These entry points exist for the known-answer tests (tests/test_cpu_stdrng.py: SipHash paper vector, CPython's zero-key SipHash-2-4,
+ * the xoshiro256++ reference outputs, rand's seed_from_u64(0) vector, the ChaCha8 zero-key key stream). */
+t4a_gpu_status t4a_gpu_siphash(const uint8_t* msg, size_t len, uint64_t k0, uint64_t k1, int32_t c_rounds, int32_t d_rounds, uint64_t* out);
+/* state4 != NULL: the four state words given directly (published vectors); otherwise seed_from_u64(seed) */
+t4a_gpu_status t4a_gpu_smallrng_words(uint64_t seed, const uint64_t* state4, size_t n, uint64_t* out /* n */);
+t4a_gpu_status t4a_gpu_smallrng_sample(uint64_t seed, const size_t* dims, size_t n, size_t* out /* n */);
+/* the permutation `(0..n).collect::<Vec<_>>().shuffle(&mut SmallRng::seed_from_u64(seed))` leaves behind */
+t4a_gpu_status t4a_gpu_smallrng_shuffle(uint64_t seed, size_t n, size_t* out /* n */);
+/* rng_for_edge's hash (proposer.rs:360-387): the u64 the proposer's SmallRng is seeded with */
+t4a_gpu_status t4a_gpu_tree_edge_seed(uint64_t seed, const char* tag, size_t u, size_t v, size_t history_len, size_t n_pivots_i, size_t n_pivots_j,
+                                      uint64_t* out);
+/* n standard normals and / or n_words key-stream words of ChaCha8Rng::seed_from_u64(seed) (each from a fresh generator) */
+t4a_gpu_status t4a_gpu_chacha8_standard_normal(uint64_t seed, size_t n, double* out, size_t n_words, uint32_t* out_words);
+
 
 /* =====================================================================================
  * Dense kernels (host buffers in, host buffers out; each call is synchronous)

@@ -118,6 +118,69 @@ int oracle_chacha_block(const uint8_t* key32, uint64_t counter, uint64_t stream,
     });
 }
 
+// ---- the other two random streams (t4a_oracle_rng2.hpp) ----
+int oracle_siphash(const uint8_t* msg, uint64_t len, uint64_t k0, uint64_t k1, int c_rounds, int d_rounds, uint64_t* out)
+{
+    return guarded([&] { *out = siphash(std::vector<uint8_t>(msg, msg + len), k0, k1, c_rounds, d_rounds); });
+}
+int oracle_smallrng_words(uint64_t seed, const uint64_t* state4, uint64_t n, uint64_t* out)
+{
+    return guarded([&] {
+        OracleSmallRng rng(seed);
+        if (state4)
+            for (int i = 0; i < 4; ++i) rng.s[i] = state4[i];
+        for (uint64_t i = 0; i < n; ++i) out[i] = rng.next_u64();
+    });
+}
+int oracle_smallrng_sample(uint64_t seed, const uint64_t* dims, uint64_t n, uint64_t* out)
+{
+    return guarded([&] {
+        OracleSmallRng rng(seed);
+        for (uint64_t i = 0; i < n; ++i) out[i] = (uint64_t)rng.range((size_t)dims[i]);
+    });
+}
+int oracle_smallrng_shuffle(uint64_t seed, uint64_t n, uint64_t* out)
+{
+    return guarded([&] {
+        std::vector<uint64_t> v(n);
+        for (uint64_t i = 0; i < n; ++i) v[i] = i;
+        OracleSmallRng rng(seed);
+        rng2_shuffle(v, rng);
+        for (uint64_t i = 0; i < n; ++i) out[i] = v[i];
+    });
+}
+int oracle_tree_edge_seed(uint64_t seed, const char* tag, uint64_t u, uint64_t v, uint64_t history_len, uint64_t ni, uint64_t nj, uint64_t* out)
+{
+    return guarded([&] {
+        HashBytes h;
+        h.u64(seed);
+        h.str(tag);
+        h.u64(std::min(u, v));
+        h.u64(std::max(u, v));
+        h.u64(history_len);
+        h.u64(ni);
+        h.u64(nj);
+        *out = h.default_hasher_finish();
+    });
+}
+int oracle_chacha8_standard_normal(uint64_t seed, uint64_t n, double* out, uint64_t n_words, uint32_t* out_words)
+{
+    return guarded([&] {
+        if (n) {
+            OracleChaCha8Rng rng(seed);
+            for (uint64_t i = 0; i < n; ++i) out[i] = oracle_ziggurat().normal(rng);
+        }
+        if (n_words) {
+            OracleChaCha8Rng rng(seed);
+            for (uint64_t i = 0; i < n_words; ++i) out_words[i] = rng.next_u32();
+        }
+    });
+}
+int oracle_chacha8_block(const uint32_t* key8, uint64_t counter, uint32_t* out16)
+{
+    return guarded([&] { OracleChaCha8Rng::block(key8, counter, 8, out16); });
+}
+
 // ---- dense kernels ----
 int oracle_rrlu_f64(double* a_inout, uint64_t m, uint64_t n, uint64_t max_bond_dim, double rel_tol, double abs_tol,
                     int left_orthogonal, uint64_t* row_perm, uint64_t* col_perm, uint64_t* npivots, double* last_error)

@@ -9,7 +9,8 @@
 //     t4a_oracle.hpp: k ascending, separately rounded multiply and add — the device kernels use the same order, so the local
 //     candidate matrices are bit-identical on both sides and the rrLU pivots follow.
 //   * The default initial guess draws standard normals from rand_chacha::ChaCha8Rng and the global guard draws its starting
-//     points from rand::rngs::StdRng (un-vendored crates): "parity unpinned" — a splitmix64 stream (Box-Muller) here.
+//     points from rand::rngs::StdRng (un-vendored crates): both restated from the published algorithms (ChaCha8 + rand_distr's
+//     256-layer ziggurat in t4a_oracle_rng2.hpp; StdRng in t4a_oracle_rng.hpp), pinned to published vectors where they exist.
 //     Runs with an explicit AciOptions::initial_guess and enable_global_guard = false involve no random numbers.
 //   * append_row (state.rs:1343-1359) extends the COLUMN-major buffer of the frame by the new row and re-reads it with one
 //     more row; that is a row append only for frames with one column.  Restated as written.
@@ -19,6 +20,7 @@
 #include <functional>
 
 #include "t4a_oracle_tt.hpp"
+#include "t4a_oracle_rng2.hpp"
 
 namespace t4a_oracle {
 
@@ -118,12 +120,8 @@ inline std::vector<size_t> aci_default_link_dims(const std::vector<SimpleTensorT
     return link;
 }
 
-inline double aci_standard_normal(OracleRng& rng) // scalar.rs sample_standard_normal ("parity unpinned": Box-Muller on splitmix64)
-{
-    const double u1 = ((double)(rng.next() >> 11) + 1.0) * (1.0 / 9007199254740992.0);
-    const double u2 = (double)(rng.next() >> 11) * (1.0 / 9007199254740992.0);
-    return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
-}
+// scalar.rs:8-20 sample_standard_normal: rand_distr StandardNormal (ziggurat) on ChaCha8Rng (t4a_oracle_rng2.hpp)
+inline double aci_standard_normal(OracleChaCha8Rng& rng) { return oracle_ziggurat().normal(rng); }
 
 constexpr size_t ACI_MAX_INITIAL_GUESS_ENTRIES = 10000000; // random_tt.rs:12-13
 
@@ -145,7 +143,7 @@ inline SimpleTensorTrain aci_initial_guess(const std::vector<SimpleTensorTrain>&
         return SimpleTensorTrain::make(g.tensors);
     }
     const std::vector<size_t> link = aci_default_link_dims(inputs, site_dims, o.has_max_bond_dim, o.max_bond_dim);
-    OracleRng rng(o.rng_seed);
+    OracleChaCha8Rng rng(o.rng_seed); // random_tt.rs:31
     std::vector<Tensor3> cores;
     size_t total = 0;
     for (size_t s = 0; s < site_dims.size(); ++s) {

@@ -17,10 +17,10 @@
 // The tree network object (tensor4all-treetn) is a plain per-site dense tensor list here; its evaluation contracts
 // from the leaves towards the root.  Parity: the pivot selection is the bit-exact rrLU of t4a_oracle.hpp; the
 // full-pivot solve of materialize.rs goes through tenferro in the reference ("parity unpinned", tolerance level);
-// the global pivot finder uses rand 0.9 StdRng there ("parity unpinned": splitmix64 here); SimpleProposer /
-// TruncatedDefaultProposer (proposer.rs:90-249, :357-409) draw from rand SmallRng seeded through std DefaultHasher in the
-// reference — both third party / unspecified streams, "parity unpinned": the structure (candidate counts d * chi, ordered
-// sampling without replacement, union with the history) is restated on a splitmix64 stream.
+// the global pivot finder uses rand 0.9 StdRng (t4a_oracle_rng.hpp); SimpleProposer / TruncatedDefaultProposer (proposer.rs:90-249,
+// :357-409) draw from rand 0.9 SmallRng (xoshiro256++) seeded through std DefaultHasher (SipHash-1-3, zero key): restated from the
+// published algorithms in t4a_oracle_rng2.hpp, pinned to published vectors in tests/test_cpu_stdrng.py (the byte layout `Hash` feeds
+// the hasher and the seed -> candidate mapping stay unpinned against the Rust binary: no fixture of the reference fixes them).
 #pragma once
 
 #include <deque>
@@ -28,6 +28,7 @@
 #include <set>
 
 #include "t4a_oracle_tt.hpp"
+#include "t4a_oracle_rng2.hpp"
 
 namespace t4a_oracle {
 
@@ -376,30 +377,33 @@ inline void default_proposer_candidates(const TreeTCI2& st, const TreeEdge& edge
     jcand = side(pq.second, keys.second);
 }
 
-// proposer.rs:357-387 rng_for_edge: one stream per (seed, proposer, edge, history length, current pivot counts)
-inline OracleRng tree_rng_for_edge(const TreeTCI2& st, const TreeEdge& edge, uint64_t seed, uint64_t tag)
+// proposer.rs:360-387 rng_for_edge: DefaultHasher (SipHash-1-3, zero key) over seed, tag, edge, history length and the two pivot
+// counts, then SmallRng::seed_from_u64 (t4a_oracle_rng2.hpp)
+inline OracleSmallRng tree_rng_for_edge(const TreeTCI2& st, const TreeEdge& edge, uint64_t seed, const std::string& tag)
 {
     auto keys = st.graph.subregion_vertices(edge);
     auto ncols = [&](const SubtreeKey& k) {
         auto it = st.ijset.find(k);
         return it == st.ijset.end() ? (uint64_t)0 : (uint64_t)it->second.size();
     };
-    uint64_t h = seed;
-    for (uint64_t v : {tag, ((uint64_t)edge.u << 32) | (uint64_t)edge.v, (uint64_t)st.ijset_history.size(), ncols(keys.first),
-                       ncols(keys.second)}) {
-        OracleRng m(h ^ v);
-        h = m.next();
-    }
-    return OracleRng(h);
+    HashBytes h;
+    h.u64(seed);
+    h.str(tag);
+    h.u64((uint64_t)std::min(edge.u, edge.v)); // TreeTciEdge { u, v } with u <= v (graph.rs:21-35), derived Hash: field order
+    h.u64((uint64_t)std::max(edge.u, edge.v));
+    h.u64((uint64_t)st.ijset_history.size());
+    h.u64(ncols(keys.first));
+    h.u64(ncols(keys.second));
+    return OracleSmallRng(h.default_hasher_finish());
 }
 
 // proposer.rs:389-409 sample_ordered_candidates: `max_size` distinct candidates in their original order
-inline std::vector<MultiIndex> tree_sample_ordered(const std::vector<MultiIndex>& cand, size_t max_size, OracleRng& rng)
+inline std::vector<MultiIndex> tree_sample_ordered(const std::vector<MultiIndex>& cand, size_t max_size, OracleSmallRng& rng)
 {
     if (cand.size() <= max_size) return cand;
     std::vector<size_t> idx(cand.size());
     for (size_t k = 0; k < idx.size(); ++k) idx[k] = k;
-    for (size_t k = idx.size() - 1; k > 0; --k) std::swap(idx[k], idx[rng.range(k + 1)]);
+    rng2_shuffle(idx, rng); // selected_indices.shuffle(rng)
     idx.resize(max_size);
     std::sort(idx.begin(), idx.end());
     std::vector<MultiIndex> out;
@@ -419,7 +423,7 @@ inline void tree_candidates(const TreeTCI2& st, const TreeEdge& edge, std::vecto
     const size_t ichi = st.local_dims[pq.first] * st.pivots_of(keys.first).size();
     const size_t jchi = st.local_dims[pq.second] * st.pivots_of(keys.second).size();
     if (st.proposer == 1) { // SimpleProposer :127-160
-        OracleRng rng = tree_rng_for_edge(st, edge, st.proposer_seed, 0x73696d706c65ull);
+        OracleSmallRng rng = tree_rng_for_edge(st, edge, st.proposer_seed, "simple");
         auto random = [&](const SubtreeKey& key, size_t size) {
             std::vector<MultiIndex> out;
             for (size_t k = 0; k < size; ++k) {
@@ -439,7 +443,7 @@ inline void tree_candidates(const TreeTCI2& st, const TreeEdge& edge, std::vecto
     if (st.proposer == 2) { // TruncatedDefaultProposer :205-249
         std::vector<MultiIndex> di, dj;
         default_proposer_candidates(st, edge, di, dj);
-        OracleRng rng = tree_rng_for_edge(st, edge, st.proposer_seed, 0x7472756e63ull);
+        OracleSmallRng rng = tree_rng_for_edge(st, edge, st.proposer_seed, "truncated_default");
         icand = tree_sample_ordered(di, ichi, rng);
         jcand = tree_sample_ordered(dj, jchi, rng);
         return;

@@ -1,6 +1,7 @@
 // aci.hip — see aci.hpp.  Reference: crates/tensor4all-aci/src/{elementwise,state,local,global_guard,random_tt,validation}.rs.
 #include "aci.hpp"
 #include "stdrng.hpp"
+#include "smallrng.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -67,21 +68,6 @@ void matmul(const double* A, int lda, const double* B, int ldb, double* C, int l
     if (total == 0) return;
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(aci_matmul_kernel, dim3(blocks), dim3(256), 0, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K);
-}
-
-uint64_t splitmix_next(uint64_t& s)
-{
-    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-double standard_normal(uint64_t& s) // scalar.rs sample_standard_normal on ChaCha8 in the reference ("parity unpinned")
-{
-    const double u1 = ((double)(splitmix_next(s) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
-    const double u2 = (double)(splitmix_next(s) >> 11) * (1.0 / 9007199254740992.0);
-    return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
 }
 
 constexpr size_t MAX_GUESS_ENTRIES = 10000000; // random_tt.rs:12-13
@@ -198,7 +184,7 @@ AciProblem::AciProblem(const std::vector<TensorTrain*>& inputs, const TensorTrai
             if (opt_.has_max_bond_dim) d = std::min(d, opt_.max_bond_dim);
             link[b] = std::max<size_t>(std::min(d, m), 1);
         }
-        uint64_t rng = opt_.rng_seed;
+        ChaCha8Rng rng(opt_.rng_seed); // random_tt.rs:31 (smallrng.hpp)
         size_t total = 0;
         std::vector<double> host;
         for (size_t s = 0; s < n; ++s) {
@@ -209,7 +195,7 @@ AciProblem::AciProblem(const std::vector<TensorTrain*>& inputs, const TensorTrai
             total += c.size();
             if (total > MAX_GUESS_ENTRIES) throw Error(T4A_GPU_INVALID_ARGUMENT, "initial guess total size exceeds internal limit");
             host.resize(c.size());
-            for (double& v : host) v = standard_normal(rng);
+            for (double& v : host) v = StandardNormal::sample(rng); // scalar.rs:8-20
             c.buf.reserve(c.size());
             T4A_HIP(hipMemcpyAsync(c.buf.get(), host.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, st));
             eng_.sync();

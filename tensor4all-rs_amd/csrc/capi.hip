@@ -2,6 +2,7 @@
 // No exception crosses the boundary (tensor4all-capi/src/lib.rs:139-162 convention): every entry point
 // runs inside `guarded`, which stores the message in a thread-local slot and returns a status code.
 #include "stdrng.hpp"
+#include "smallrng.hpp"
 #include <memory>
 #include <initializer_list>
 #include <mutex>
@@ -193,6 +194,95 @@ t4a_gpu_status t4a_gpu_chacha_block(const uint32_t* key8, uint64_t counter, uint
     });
 }
 
+// ---- the other two random streams of the reference (smallrng.hpp): known-answer entry points, host only ----
+t4a_gpu_status t4a_gpu_siphash(const uint8_t* msg, size_t len, uint64_t k0, uint64_t k1, int32_t c_rounds, int32_t d_rounds, uint64_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(out);
+        if (len > 0) T4A_REQUIRE_PTR(msg);
+        if (c_rounds == 1 && d_rounds == 3) {
+            SipHasher<1, 3> h(k0, k1);
+            h.write(msg, len);
+            *out = h.finish();
+        } else if (c_rounds == 2 && d_rounds == 4) {
+            SipHasher<2, 4> h(k0, k1);
+            h.write(msg, len);
+            *out = h.finish();
+        } else {
+            throw Error(T4A_GPU_INVALID_ARGUMENT, "SipHash-1-3 or SipHash-2-4");
+        }
+    });
+}
+
+t4a_gpu_status t4a_gpu_smallrng_words(uint64_t seed, const uint64_t* state4, size_t n, uint64_t* out)
+{
+    return guarded([&] {
+        if (n == 0) return;
+        T4A_REQUIRE_PTR(out);
+        SmallRng rng = state4 ? SmallRng::from_state(state4) : SmallRng(seed);
+        for (size_t i = 0; i < n; ++i) out[i] = rng.next_u64();
+    });
+}
+
+t4a_gpu_status t4a_gpu_smallrng_sample(uint64_t seed, const size_t* dims, size_t n, size_t* out)
+{
+    return guarded([&] {
+        if (n == 0) return;
+        T4A_REQUIRE_PTR(dims);
+        T4A_REQUIRE_PTR(out);
+        for (size_t i = 0; i < n; ++i)
+            if (dims[i] == 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "random_range(0..0): empty range");
+        SmallRng rng(seed);
+        for (size_t i = 0; i < n; ++i) out[i] = rng.random_range(dims[i]);
+    });
+}
+
+t4a_gpu_status t4a_gpu_smallrng_shuffle(uint64_t seed, size_t n, size_t* out)
+{
+    return guarded([&] {
+        if (n == 0) return;
+        T4A_REQUIRE_PTR(out);
+        std::vector<size_t> v(n);
+        for (size_t i = 0; i < n; ++i) v[i] = i;
+        SmallRng rng(seed);
+        rng.shuffle(v);
+        for (size_t i = 0; i < n; ++i) out[i] = v[i];
+    });
+}
+
+t4a_gpu_status t4a_gpu_tree_edge_seed(uint64_t seed, const char* tag, size_t u, size_t v, size_t history_len, size_t n_pivots_i, size_t n_pivots_j, uint64_t* out)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(tag);
+        T4A_REQUIRE_PTR(out);
+        DefaultHasher h;
+        h.write_u64(seed);
+        h.write_str(tag, std::strlen(tag));
+        h.write_usize(std::min(u, v));
+        h.write_usize(std::max(u, v));
+        h.write_usize(history_len);
+        h.write_usize(n_pivots_i);
+        h.write_usize(n_pivots_j);
+        *out = h.finish();
+    });
+}
+
+t4a_gpu_status t4a_gpu_chacha8_standard_normal(uint64_t seed, size_t n, double* out, size_t n_words, uint32_t* out_words)
+{
+    return guarded([&] {
+        if (n > 0) {
+            T4A_REQUIRE_PTR(out);
+            ChaCha8Rng rng(seed);
+            for (size_t i = 0; i < n; ++i) out[i] = StandardNormal::sample(rng);
+        }
+        if (n_words > 0) {
+            T4A_REQUIRE_PTR(out_words);
+            ChaCha8Rng rng(seed);
+            for (size_t i = 0; i < n_words; ++i) out_words[i] = rng.next_u32();
+        }
+    });
+}
+
 t4a_gpu_status t4a_gpu_device_count(int32_t* out_count)
 {
     return guarded([&] {
@@ -212,6 +302,22 @@ t4a_gpu_status t4a_gpu_set_device(int32_t device)
 }
 
 const char* t4a_gpu_version(void) { return "t4a-mi355x 0.1.0 (gfx950)"; }
+int32_t t4a_gpu_diag_switches_enabled(void)
+{
+    if (!t4a::kDiagSwitches) {
+        // a known experiment switch in the environment of a production build measures the default path: say so once
+        static const char* const known[] = {"T4A_NO_FUSED_PI", "T4A_NO_SMALL_FILL", "T4A_EXPORT_SYNC", "T4A_FILL_GRAPH_SHARED", "T4A_SVD_NO_PRECOND",
+                                            "T4A_FILL_DEFER", "T4A_OLD_PRESIZE", "T4A_FILL_GRAPH_NO_COPY"};
+        static bool warned = false;
+        if (!warned)
+            for (const char* k : known)
+                if (std::getenv(k)) {
+                    std::fprintf(stderr, "[t4a] %s is set, but this library was built without -DT4A_DIAG_SWITCHES: the switch has NO effect\n", k);
+                    warned = true;
+                }
+    }
+    return t4a::kDiagSwitches ? 1 : 0;
+}
 
 // ------------------------------------------------------------------------------------------------ dense
 t4a_gpu_status t4a_gpu_rrlu_f64(double* a_inout, size_t m, size_t n, size_t max_bond_dim, double rel_tol,
@@ -1135,6 +1241,7 @@ t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t v
         h->impl.chain_event_timing = (verify & 2) != 0;
         h->impl.small_enabled = (verify & 4) == 0;
         h->impl.small_stamps = (verify & 8) != 0;
+        h->impl.fill_graph_relaxed = (verify & 16) != 0;
     });
 }
 

@@ -36,7 +36,11 @@ inline void pi_shard_evaluate(PiShard& ps, t4a_gpu_batch_eval_fn cb, void* cb_ct
     const size_t c0 = ps.rank * cbk < nb ? ps.rank * cbk : nb;
     const size_t c1 = c0 + cbk < nb ? c0 + cbk : nb;
     const size_t mine = c1 - c0;
-    std::vector<double> send(na * cbk, 0.0), recv(W * na * cbk);
+    // One extra slot per rank carries a status: a rank whose callback failed STILL takes part in the all-gather (the others have
+    // entered the collective already: staying away is a hang with gloo / RCCL, not an error), and every rank throws afterwards.
+    const size_t blk = na * cbk + 1;
+    std::vector<double> send(blk, 0.0), recv(W * blk);
+    std::string my_error;
     if (mine > 0) {
         const size_t npts = na * mine;
         std::vector<uint32_t> idx(npts * n_sites);
@@ -48,20 +52,27 @@ inline void pi_shard_evaluate(PiShard& ps, t4a_gpu_batch_eval_fn cb, void* cb_ct
             }
         std::vector<double> vals(npts);
         const int64_t got = cb(cb_ctx, idx.data(), n_sites, npts, vals.data());
-        if (got < 0 || (size_t)got != npts)
-            throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " + std::to_string(npts) +
-                                                    " requested entries (column block " + std::to_string(ps.rank) + " of " + std::to_string(W) + ")");
-        for (size_t ia = 0; ia < na; ++ia) std::memcpy(send.data() + ia * cbk, vals.data() + ia * mine, mine * sizeof(double));
+        if (got < 0 || (size_t)got != npts) {
+            my_error = "batch callback returned " + std::to_string(got) + " values for " + std::to_string(npts) + " requested entries (column block " +
+                       std::to_string(ps.rank) + " of " + std::to_string(W) + ")";
+            send[na * cbk] = 1.0;
+        } else {
+            for (size_t ia = 0; ia < na; ++ia) std::memcpy(send.data() + ia * cbk, vals.data() + ia * mine, mine * sizeof(double));
+        }
     }
     const int32_t st = ps.gather(ps.gather_ctx, send.data(), send.size(), recv.data());
     if (st != 0) throw Error(T4A_GPU_CALLBACK_ERROR, "all-gather callback of the column-block shard failed with status " + std::to_string(st));
     ps.n_gathers += 1;
     ps.bytes_sent += send.size() * sizeof(double);
+    if (!my_error.empty()) throw Error(T4A_GPU_CALLBACK_ERROR, my_error);
+    for (size_t r = 0; r < W; ++r)
+        if (recv[r * blk + na * cbk] != 0.0)
+            throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback failed on rank " + std::to_string(r) + " of the column-block shard (reported through the all-gather)");
     for (size_t r = 0; r < W; ++r) {
         const size_t r0 = r * cbk < nb ? r * cbk : nb;
         const size_t r1 = r0 + cbk < nb ? r0 + cbk : nb;
         for (size_t ia = 0; ia < na; ++ia)
-            if (r1 > r0) std::memcpy(out + ia * nb + r0, recv.data() + (r * na + ia) * cbk, (r1 - r0) * sizeof(double));
+            if (r1 > r0) std::memcpy(out + ia * nb + r0, recv.data() + r * blk + ia * cbk, (r1 - r0) * sizeof(double));
     }
 }
 

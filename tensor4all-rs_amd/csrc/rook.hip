@@ -490,11 +490,13 @@ LuciResult rook_luci(Engine& eng, RookWork& w, const RookSource& src, const RrLU
     w.lup.reserve(1);
     w.trp.reserve(4);
     const bool device_search_planned = (bool)src.full && kcap <= 256 && (long long)M * N <= (1ll << 24);
-    if (!device_search_planned) { // (the device-resident search clears its flags itself; lu_kernel sets its own status)
+    // the status word is ALWAYS cleared: a search that ends with rank 0 runs no LU, yet the final block reads the word — out of
+    // recycled pool memory or a failed earlier call it was undefined
+    T4A_HIP(hipMemsetAsync(w.info.get(), 0, sizeof(int), st));
+    if (!device_search_planned) { // (the device-resident search clears its flags itself)
         T4A_HIP(hipMemsetAsync(w.rowsel.get(), 0, sizeof(int) * M, st));
         T4A_HIP(hipMemsetAsync(w.colsel.get(), 0, sizeof(int) * N, st));
         T4A_HIP(hipMemsetAsync(w.maxbits.get(), 0, sizeof(unsigned long long), st));
-        T4A_HIP(hipMemsetAsync(w.info.get(), 0, sizeof(int), st));
     }
 
     std::vector<char> col_seen(N, 0), row_seen(M, 0), row_sel(M, 0), col_sel(N, 0);

@@ -990,8 +990,13 @@ void Tci2::issue_fill_ops(std::vector<std::function<void()>>& ops, const std::ve
     // the runtime's implicit ordering of stream 0 against the streams a graph launch runs on, not a stale pointer.  parallel.py and
     // bench.py therefore exchange on a side stream; a caller that hands in stream 0 gets direct issue, which is what the
     // round-4 stop-gap did for every shared handle.)
+    // the root cause is NOT identified (the library's streams are non-blocking, so "implicit ordering with stream 0"
+    // does not explain the faults, and no multi-GPU soak of the patch-farm path exists).  The default is therefore the round-4 guard —
+    // no replay on ANY handle whose site tensors are exported / imported asynchronously; the relaxed guard (replay unless the legacy
+    // stream or a blocking stream took part) is an opt-in: t4a_gpu_tci2_set_chain bit 4.  The gain it buys is ~0.4 % of a sweep.
     static const bool graph_shared = diag_env("T4A_FILL_GRAPH_SHARED") != nullptr; // (diagnosis: replay even then)
-    if (use_graph && !fill_graph_broken_ && (!cores_shared_legacy_stream_ || graph_shared)) {
+    const bool shared_ok = !cores_shared_async_ || (fill_graph_relaxed && !cores_shared_legacy_stream_) || graph_shared;
+    if (use_graph && !fill_graph_broken_ && shared_ok) {
         if (fill_graph_exec_ && sig == fill_graph_sig_) {
             T4A_HIP(hipGraphLaunch(fill_graph_exec_, st));
             ++fill_stats_[1];
@@ -1506,12 +1511,24 @@ void Tci2::fill_site_tensors_impl(bool async)
     if (!async) fill_wait();
 }
 
+// the legacy default stream, or a blocking stream (which orders against it exactly like it): no graph replay beside these
+static bool stream_orders_with_legacy(hipStream_t s)
+{
+    if (s == nullptr) return true;
+    unsigned flags = 0;
+    if (hipStreamGetFlags(s, &flags) != hipSuccess) {
+        (void)hipGetLastError();
+        return true; // (unknown: the careful answer)
+    }
+    return (flags & hipStreamNonBlocking) == 0;
+}
+
 // Copies every site tensor to dst + site * stride (doubles) WITHOUT blocking the host: the copies are ordered after a
 // fill that is still in flight (same stream) and `consumer` waits for them through an event.
 void Tci2::export_site_tensors_async(double* d_dst, size_t stride, hipStream_t consumer)
 {
     cores_shared_async_ = true;
-    if (consumer == nullptr) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
+    if (stream_orders_with_legacy(consumer)) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
     hipStream_t st = fill_inflight_ ? fill_stream_ : eng.stream();
     for (size_t s = 0; s < n_; ++s) {
         const DevCore& c = cores[s];
@@ -1529,7 +1546,7 @@ void Tci2::export_site_tensors_async(double* d_dst, size_t stride, hipStream_t c
 void Tci2::export_site_shard_async(double* d_dst, size_t stride, hipStream_t consumer)
 {
     cores_shared_async_ = true;
-    if (consumer == nullptr) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
+    if (stream_orders_with_legacy(consumer)) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
     hipStream_t st = fill_inflight_ ? fill_stream_ : eng.stream();
     static const bool export_sync = diag_env("T4A_EXPORT_SYNC") != nullptr; // (diagnosis: the fill has completed before the copies are enqueued)
     if (export_sync) T4A_HIP(hipStreamSynchronize(st));
@@ -1559,7 +1576,7 @@ void Tci2::export_site_shard_async(double* d_dst, size_t stride, hipStream_t con
 void Tci2::import_site_shard_async(const double* d_src, size_t stride, size_t per_rank, hipStream_t producer)
 {
     cores_shared_async_ = true;
-    if (producer == nullptr) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
+    if (stream_orders_with_legacy(producer)) cores_shared_legacy_stream_ = true; // (see issue_fill_ops)
     if (!import_stream_) import_stream_ = pool::stream_get(2);
     // at most one import in flight: the one of the previous half-sweep is long done (a whole chain of bond updates ago),
     // and with it every read of the receive buffer that the caller is about to reuse

@@ -384,6 +384,9 @@ private:
     bool cores_shared_legacy_stream_ = false; // ... and stream 0 (the legacy default stream) was the consumer / producer of one: no graph replay of the fill (issue_fill_ops)
     uint64_t fill_stats_[3] = {0, 0, 0};       // fills issued through issue_fill_ops, graph replays, graph captures
     bool cores_shared_async_ = false; // an asynchronous export / import of cores was requested on this handle: fills are issued directly, not replayed from a graph (issue_fill_ops)
+public:
+    bool fill_graph_relaxed = false;  // opt-in: replay the fill graph on a handle with shared site tensors unless the legacy / a blocking stream took part
+private:
     hipEvent_t export_event_ = nullptr, import_event_ = nullptr;
     bool fill_inflight_ = false, fill_timed_ = false;
     std::vector<size_t> fill_solved_sites_;

@@ -1,6 +1,7 @@
 // tree.hip — TreeTCI driver on the gfx950 engine (see tree.hpp).  Reference: crates/tensor4all-treetci/src.
 #include "tree.hpp"
 #include "stdrng.hpp"
+#include "smallrng.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -269,14 +270,6 @@ IndexSet union_with_history(const IndexSet& values, const IndexSet* history)
     return out;
 }
 
-uint64_t splitmix64(uint64_t& s)
-{
-    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 } // namespace
 
 void TreeTci::candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) const
@@ -291,15 +284,18 @@ void TreeTci::candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) 
         auto it = ijset.find(k);
         return it == ijset.end() ? (uint64_t)0 : (uint64_t)it->second.count;
     };
-    // rng_for_edge (:357-387): one stream per (seed, proposer, edge, history length, current pivot counts)
-    const uint64_t tag = proposer == 1 ? 0x73696d706c65ull : 0x7472756e63ull;
-    uint64_t h = proposer_seed;
-    for (uint64_t v : {tag, ((uint64_t)edge.u << 32) | (uint64_t)edge.v, (uint64_t)ijset_history.size(), ncols(keys.first),
-                       ncols(keys.second)}) {
-        uint64_t m = h ^ v;
-        h = splitmix64(m);
-    }
-    uint64_t rng = h;
+    // rng_for_edge (:360-387): std DefaultHasher (SipHash-1-3, zero key) over seed, tag, edge { u <= v }, history length and the two
+    // pivot counts, then SmallRng::seed_from_u64 (smallrng.hpp)
+    DefaultHasher hasher;
+    hasher.write_u64(proposer_seed);
+    if (proposer == 1) hasher.write_str("simple", 6);
+    else hasher.write_str("truncated_default", 17);
+    hasher.write_usize(std::min(edge.u, edge.v));
+    hasher.write_usize(std::max(edge.u, edge.v));
+    hasher.write_usize(ijset_history.size());
+    hasher.write_usize((size_t)ncols(keys.first));
+    hasher.write_usize((size_t)ncols(keys.second));
+    SmallRng rng(hasher.finish());
     const size_t ichi = local_dims[edge.u] * pivots_of(keys.first).count;
     const size_t jchi = local_dims[edge.v] * pivots_of(keys.second).count;
     const std::map<SubtreeKey, IndexSet>* history = ijset_history.empty() ? nullptr : &ijset_history.back();
@@ -314,7 +310,7 @@ void TreeTci::candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) 
             out.width = key.size();
             std::vector<uint32_t> c(key.size());
             for (size_t k = 0; k < size; ++k) {
-                for (size_t s = 0; s < key.size(); ++s) c[s] = (uint32_t)(splitmix64(rng) % (uint64_t)local_dims[key[s]]);
+                for (size_t s = 0; s < key.size(); ++s) c[s] = (uint32_t)rng.random_range(local_dims[key[s]]);
                 out.push(c.data());
             }
             return out;
@@ -332,7 +328,7 @@ void TreeTci::candidates(const TreeEdge& edge, IndexSet& left, IndexSet& right) 
             if (cand.count <= max_size) return cand;
             std::vector<size_t> idx(cand.count);
             for (size_t k = 0; k < idx.size(); ++k) idx[k] = k;
-            for (size_t k = idx.size() - 1; k > 0; --k) std::swap(idx[k], idx[(size_t)(splitmix64(rng) % (uint64_t)(k + 1))]);
+            rng.shuffle(idx); // selected_indices.shuffle(rng)
             idx.resize(max_size);
             std::sort(idx.begin(), idx.end());
             IndexSet out;

@@ -78,6 +78,13 @@ def version():
     return _lib.t4a_gpu_version().decode()
 
 
+def diag_switches_enabled():
+    """True when the loaded library was built with -DT4A_DIAG_SWITCHES (the experiment switches of tools/ are read from the environment);
+    on a production build they are no-ops and an A/B arm labelled with one measures the default path."""
+    _lib.t4a_gpu_diag_switches_enabled.restype = ctypes.c_int32
+    return bool(_lib.t4a_gpu_diag_switches_enabled())
+
+
 def stdrng_sample(seed, dims):
     """`StdRng::seed_from_u64(seed)` then `random_range(0..d)` for every d of `dims` (the stream of the reference's seeded searches)."""
     dims = np.ascontiguousarray(dims, dtype=np.uintp)
@@ -95,6 +102,55 @@ def chacha_block(key_words, counter, stream, rounds):
     _check(_lib.t4a_gpu_chacha_block(key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.c_uint64(counter), ctypes.c_uint64(stream),
                                      c_int32(rounds), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
     return out
+
+
+def _vp(a):
+    return a.ctypes.data_as(c_void_p)
+
+
+def siphash(msg, k0=0, k1=0, c_rounds=1, d_rounds=3):
+    """SipHash-c-d of `msg` (std `DefaultHasher` = 1-3 with the zero key): known-answer hook (csrc/smallrng.hpp)."""
+    m = np.frombuffer(bytes(msg), dtype=np.uint8) if len(msg) else np.zeros(1, dtype=np.uint8)
+    out = ctypes.c_uint64(0)
+    _check(_lib.t4a_gpu_siphash(_vp(m), c_size_t(len(msg)), ctypes.c_uint64(k0), ctypes.c_uint64(k1), c_int32(c_rounds), c_int32(d_rounds), ctypes.byref(out)))
+    return int(out.value)
+
+
+def smallrng_words(seed, n, state=None):
+    """n outputs of rand 0.9 `SmallRng` (xoshiro256++): `seed_from_u64(seed)`, or the four state words given directly."""
+    out = np.zeros(max(n, 1), dtype=np.uint64)
+    st = None if state is None else np.ascontiguousarray(state, dtype=np.uint64)
+    _check(_lib.t4a_gpu_smallrng_words(ctypes.c_uint64(seed), None if st is None else _vp(st), c_size_t(n), _vp(out)))
+    return [int(v) for v in out[:n]]
+
+
+def smallrng_sample(seed, dims):
+    dims = np.ascontiguousarray(dims, dtype=np.uintp)
+    out = np.zeros(max(dims.size, 1), dtype=np.uintp)
+    _check(_lib.t4a_gpu_smallrng_sample(ctypes.c_uint64(seed), _vp(dims), c_size_t(dims.size), _vp(out)))
+    return [int(v) for v in out[:dims.size]]
+
+
+def smallrng_shuffle(seed, n):
+    out = np.zeros(max(n, 1), dtype=np.uintp)
+    _check(_lib.t4a_gpu_smallrng_shuffle(ctypes.c_uint64(seed), c_size_t(n), _vp(out)))
+    return [int(v) for v in out[:n]]
+
+
+def tree_edge_seed(seed, tag, u, v, history_len, n_pivots_i, n_pivots_j):
+    """rng_for_edge's hash (tensor4all-treetci/src/proposer.rs:360-387)."""
+    out = ctypes.c_uint64(0)
+    _check(_lib.t4a_gpu_tree_edge_seed(ctypes.c_uint64(seed), tag.encode(), c_size_t(u), c_size_t(v), c_size_t(history_len), c_size_t(n_pivots_i),
+                                       c_size_t(n_pivots_j), ctypes.byref(out)))
+    return int(out.value)
+
+
+def chacha8_standard_normal(seed, n, n_words=0):
+    """(n standard normals, n_words key-stream words) of `ChaCha8Rng::seed_from_u64(seed)` (tensor4all-aci/src/random_tt.rs:31,143-150)."""
+    out = np.zeros(max(n, 1))
+    w = np.zeros(max(n_words, 1), dtype=np.uint32)
+    _check(_lib.t4a_gpu_chacha8_standard_normal(ctypes.c_uint64(seed), c_size_t(n), _vp(out), c_size_t(n_words), _vp(w)))
+    return out[:n], [int(x) for x in w[:n_words]]
 
 
 def _f(a):

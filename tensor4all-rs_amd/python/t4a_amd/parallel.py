@@ -27,7 +27,12 @@ def leave_legacy_stream(torch):
     if os.environ.get("T4A_SS_LEGACY_STREAM"):  # (diagnosis: stay on stream 0; the library then issues its fills directly)
         return
     if torch.cuda.is_available() and torch.cuda.current_stream().cuda_stream == 0:
-        torch.cuda.set_stream(torch.cuda.Stream())
+        #  the side stream is non-blocking: it is ordered behind everything the caller has enqueued on stream 0 so far
+        # (tensor initialisation, the caller's inputs).  Side effect, on purpose and permanent: the thread's current stream changes;
+        # tensors the caller allocated on stream 0 and hands in later should be passed with record_stream() or after a synchronize.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(side)
 
 
 def patches_of_rank(n_patches, rank, world):

@@ -75,6 +75,53 @@ def stdrng_words(seed, n_u32, n_u64):
     return a[:n_u32], b[:n_u64]
 
 
+def siphash(msg, k0=0, k1=0, c_rounds=1, d_rounds=3):
+    m = np.frombuffer(bytes(msg), dtype=np.uint8) if len(msg) else np.zeros(1, dtype=np.uint8)
+    out = np.zeros(1, dtype=np.uint64)
+    _check(_lib.oracle_siphash(_p(m), u64(len(msg)), u64(k0), u64(k1), cint(c_rounds), cint(d_rounds), _p(out)))
+    return int(out[0])
+
+
+def smallrng_words(seed, n, state=None):
+    out = np.zeros(max(n, 1), dtype=np.uint64)
+    st = None if state is None else np.ascontiguousarray(state, dtype=np.uint64)
+    _check(_lib.oracle_smallrng_words(u64(seed), None if st is None else _p(st), u64(n), _p(out)))
+    return [int(v) for v in out[:n]]
+
+
+def smallrng_sample(seed, dims):
+    dims = np.ascontiguousarray(dims, dtype=np.uint64)
+    out = np.zeros(max(dims.size, 1), dtype=np.uint64)
+    _check(_lib.oracle_smallrng_sample(u64(seed), _p(dims), u64(dims.size), _p(out)))
+    return [int(v) for v in out[:dims.size]]
+
+
+def smallrng_shuffle(seed, n):
+    out = np.zeros(max(n, 1), dtype=np.uint64)
+    _check(_lib.oracle_smallrng_shuffle(u64(seed), u64(n), _p(out)))
+    return [int(v) for v in out[:n]]
+
+
+def tree_edge_seed(seed, tag, u, v, history_len, ni, nj):
+    out = np.zeros(1, dtype=np.uint64)
+    _check(_lib.oracle_tree_edge_seed(u64(seed), tag.encode(), u64(u), u64(v), u64(history_len), u64(ni), u64(nj), _p(out)))
+    return int(out[0])
+
+
+def chacha8_standard_normal(seed, n, n_words=0):
+    out = np.zeros(max(n, 1))
+    w = np.zeros(max(n_words, 1), dtype=np.uint32)
+    _check(_lib.oracle_chacha8_standard_normal(u64(seed), u64(n), _p(out), u64(n_words), _p(w)))
+    return out[:n], [int(x) for x in w[:n_words]]
+
+
+def chacha8_block(key_words, counter):
+    key = np.ascontiguousarray(key_words, dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    _check(_lib.oracle_chacha8_block(_p(key), u64(counter), _p(out)))
+    return [int(v) for v in out]
+
+
 def chacha_block(key_bytes, counter, stream, rounds):
     key = np.ascontiguousarray(key_bytes, dtype=np.uint8)
     assert key.size == 32
