@@ -102,10 +102,13 @@ def main():
     ap.add_argument("--no-floor", action="store_true",
                     help="do not start tools/xcd_bench (a second GPU process) for the exchange floor: use the committed constant — for "
                          "runs under rocprofv3, whose preload and counters a child process would inherit")
-    ap.add_argument("--mode", choices=["headline", "site-shard"], default="headline",
+    ap.add_argument("--mode", choices=["headline", "site-shard", "patch-farm", "pi-shard"], default="headline",
                     help="headline: BASELINE.json configs[2] (N = 1) / patch farm (N > 1).  site-shard: configs[3] — d = 40, chi = 512, "
                          "bond chain replicated on every rank, fill_site_tensors sharded by site, one device-resident core "
-                         "all-gather per half-sweep overlapped with the next half-sweep")
+                         "all-gather per half-sweep overlapped with the next half-sweep.  patch-farm: configs[4] as stated — 64 statically "
+                         "projected patches, chi = 128, farmed over the ranks (eight at a time per GPU), ONE all_gather_into_tensor of the "
+                         "padded patch cores; strong scaling.  pi-shard: configs[2] through a native HOST callback, every candidate matrix "
+                         "evaluated by column blocks over the ranks and all-gathered, rrLU replicated (SURVEY.md 8e row 2)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -145,8 +148,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.mode == "site-shard":
-        site_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier)
+    if args.mode in ("site-shard", "patch-farm", "pi-shard"):
+        {"site-shard": site_shard_mode, "patch-farm": patch_farm_mode, "pi-shard": pi_shard_mode}[args.mode](args, world, rank, dist, torch, t4a_amd, barrier)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -494,6 +497,148 @@ def site_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier):
                     "shard in the bit-exact mode (SURVEY.md §8e), so N > 1 only shortens the fill",
         }
         print(json.dumps(out), flush=True)
+
+
+def patch_farm_mode(args, world, rank, dist, torch, t4a_amd, barrier):
+    """BASELINE.json configs[4] as stated: PartitionedTT adaptive patching — 64 statically projected patches (the 6 leading bits of the
+    configs[2] integrand fixed, 30 active sites each), per-patch TCI2 from scratch with chi_max = 128, farmed over the ranks (patch p on
+    rank p % N, FIFO inside a rank: adaptive_interpolation.rs:171-330), eight patches at a time per GPU in lock-step (one XCD each,
+    t4a_gpu_tci2_optimize_group), site tensors exported device to device into ONE padded tensor and moved by ONE all_gather_into_tensor
+    over RCCL.  One step = the whole job (64 patches + the gather).  Strong scaling: the total work is fixed."""
+    from t4a_amd import parallel
+    n_patches, chi, n = 64, 128, N_SITES
+    opt = t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=9, ncheck_history=10 ** 6, nsearch=0, max_nglobal_pivot=0, seed=42)
+
+    def make_patch(p):
+        t = t4a_amd.TensorCI2([2] * n)
+        t.set_function(patch_spec(p, n_patches))
+        t.add_global_pivots([[0] * n])
+        t.set_max_sample_value(1.0)
+        return t
+
+    cap = chi * 2 * chi
+    farm = parallel.PaddedPatchFarm(dist if world > 1 else None, torch, n_patches, n, cap, "cuda")
+    exporter = parallel.DevicePatchExporter(t4a_amd, torch, make_patch, opt, group=8)
+    for _ in range(args.warmup):
+        farm.run(exporter, timed=True)
+    barrier()
+    t0 = time.perf_counter()
+    exp_s = gat_s = 0.0
+    for _ in range(args.steps):
+        farm.run(exporter, timed=True)
+        exp_s += farm.last_export_s
+        gat_s += farm.last_gather_s
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = torch.tensor([dt, exp_s, gat_s], dtype=torch.float64, device="cuda")
+    allr = [torch.zeros_like(stats) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, stats)
+    else:
+        allr = [stats]
+    if rank == 0:
+        per = [[float(v) for v in a.cpu()] for a in allr]
+        wall = max(p[0] for p in per)
+        dims_ok = all(max(farm.core_dims(p, s)[2] for s in range(n - 1)) == chi for p in range(n_patches))
+        print(json.dumps({
+            "metric": "PartitionedTT patch farm: patches/s (64 patches, per-patch TCI2 chi=128 fp64, from scratch, cores gathered)",
+            "value": n_patches * args.steps / wall, "unit": "patches/s", "n_gpus": world, "rccl_world_size": world if world > 1 else 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[4]: 64 statically projected patches of the d=30 interleaved-quantics 2-variable integrand "
+                                   "(6 leading bits fixed), per-patch crossinterpolate2-style optimize (9 iterations from one pivot, chi_max=128, "
+                                   "tol=1e-12, nsearch=0), fill_site_tensors, ONE all_gather_into_tensor of the padded cores",
+                       "n_patches": n_patches, "chi_max": chi, "n_sites": n, "group": 8, "patches_per_rank": farm.per_rank,
+                       "parallelism": f"patch farm x{world}"},
+            "per_rank_ms_per_step": [p[0] / args.steps * 1e3 for p in per],
+            "per_rank_compute_ms_per_step": [p[1] / args.steps * 1e3 for p in per],
+            "exposed_gather_ms_per_step": [p[2] / args.steps * 1e3 for p in per],
+            "gather_bytes_per_step": farm.gather_bytes,
+            "all_patches_reach_chi": bool(dims_ok),
+            "note": "the gather is timed fully exposed (the device is synchronised in front of it); at N = 1 it is a device-to-device copy",
+        }), flush=True)
+
+
+def pi_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier):
+    """SURVEY.md 8e row 2 (tensorci2.rs:1859-1893): the candidate matrix of a HOST-callback function evaluated by column blocks over the
+    ranks, one all-gather per matrix, rrLU replicated (identical pivots on every rank).  Workload: BASELINE configs[2] (d = 30, chi = 256)
+    saturated, the integrand behind tools/native_callback.c (a native t4a_gpu_batch_eval_fn on ONE host thread per rank; its measured cost
+    per point is part of the line).  One step = forward + backward half-sweep incl. fill_site_tensors."""
+    import ctypes
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_components import NativeCallback
+    from t4a_amd import parallel
+    spec = patch_spec(0, 1)
+    tci = t4a_amd.TensorCI2([2] * N_SITES)
+    tci.set_function(spec)
+    tci.add_global_pivots([[0] * N_SITES])
+    tci.set_max_sample_value(1.0)
+
+    def opts(iters):
+        return t4a_amd.TCI2Options(tolerance=1e-12, max_bond_dim=CHI, max_iter=iters, ncheck_history=10 ** 6, nsearch=0, max_nglobal_pivot=0, seed=42)
+
+    tci.optimize(opts(10), final_sweep1site=False)  # untimed, built-in functor: grow to saturation (identical on every rank)
+    if max(tci.link_dims()) != CHI:
+        raise SystemExit(f"rank did not saturate: link dims {tci.link_dims()}")
+    cb = NativeCallback(spec)
+    cb.attach(tci)
+    gather = None
+    if world > 1:
+        gather = parallel.PiShardGather(dist, torch, device="cuda")
+        tci.set_pi_shard(rank, world, gather)
+    # the callback alone: nanoseconds per point on this host
+    rng = np.random.default_rng(0)
+    n_probe = 1 << 18
+    idx = np.ascontiguousarray(rng.integers(0, 2, size=(n_probe, N_SITES)), dtype=np.uint32)
+    buf = np.zeros(n_probe)
+    fn = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p)(cb.fn_addr)
+    t0 = time.perf_counter()
+    fn(cb.ctx_addr, idx.ctypes.data, N_SITES, n_probe, buf.ctypes.data)
+    ns_per_point = (time.perf_counter() - t0) / n_probe * 1e9
+    for _ in range(max(args.warmup, 1)):
+        tci.optimize(opts(2), final_sweep1site=False)
+    tci.profile_enable(True)
+    tci.profile_reset()
+    p0 = cb.ctx.points
+    g0 = getattr(gather, "seconds", 0.0) if gather else 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tci.optimize(opts(2), final_sweep1site=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = tci.profile()
+    points = int(cb.ctx.points - p0)
+    gather_s = (getattr(gather, "seconds", 0.0) - g0) if gather else 0.0
+    stats = torch.tensor([dt, points * ns_per_point * 1e-9, gather_s, prof["rrlu_ms"] * 1e-3, float(points)], dtype=torch.float64, device="cuda")
+    allr = [torch.zeros_like(stats) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, stats)
+    else:
+        allr = [stats]
+    if rank == 0:
+        per = [[float(v) for v in a.cpu()] for a in allr]
+        wall = max(p[0] for p in per)
+        total_points = sum(p[4] for p in per)
+        print(json.dumps({
+            "metric": "TCI2 full sweep through a host callback, candidate matrices sharded by column blocks (d=30, chi=256 fp64): sweeps/s",
+            "value": args.steps / wall, "unit": "sweeps/s", "n_gpus": world, "rccl_world_size": world if world > 1 else 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2] integrand behind a native host batch callback (tools/native_callback.c, one host "
+                                   "thread per rank), saturated chi=256; every candidate matrix evaluated by column blocks over the ranks, one "
+                                   "all-gather per matrix, rrLU replicated; one step = forward + backward half-sweep incl. fill_site_tensors",
+                       "n_sites": N_SITES, "chi_max": CHI, "parallelism": f"pi column-block shard x{world}",
+                       "callback_ns_per_point_one_thread": ns_per_point},
+            "per_rank_ms_per_step": [p[0] / args.steps * 1e3 for p in per],
+            "callback_ms_per_step": [p[1] / args.steps * 1e3 for p in per],
+            "gather_ms_per_step": [p[2] / args.steps * 1e3 for p in per],
+            "rrlu_ms_per_step": [p[3] / args.steps * 1e3 for p in per],
+            "callback_points_per_step_all_ranks": total_points / args.steps,
+            "gather_note": "PiShardGather stages every matrix through a host buffer, a device tensor, RCCL and back (the callback's values are "
+                           "host values): fine for an expensive f, the dominant overhead for a cheap one",
+        }), flush=True)
 
 
 def saturated_view(v):

@@ -135,10 +135,17 @@ class PaddedPatchFarm:
         self.recv_dims = torch.zeros(self.world * self.per_rank * n_sites * 3, dtype=torch.int64, device=device)
         self.dims = None
 
-    def run(self, export_patches):
+    def run(self, export_patches, timed=False):
+        """timed=True (bench.py --mode patch-farm): the device is synchronised between the local compute and the gather, and
+        last_export_s / last_gather_s hold the two wall times (the gather is then fully exposed: nothing overlaps it)."""
+        import time
         torch = self.torch
         view = self.send.view(self.per_rank, self.n_sites, self.cap)[:len(self.mine)]
+        t0 = time.perf_counter()
         shapes = export_patches(self.mine, view) if self.mine else []
+        if timed and str(self.send.device).startswith("cuda"):
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
         flat = [int(v) for patch in shapes for d in patch for v in d]
         flat += [0] * (self.per_rank * self.n_sites * 3 - len(flat))
         self.send_dims.copy_(torch.tensor(flat, dtype=torch.int64), non_blocking=True)
@@ -151,6 +158,10 @@ class PaddedPatchFarm:
             self.recv.copy_(self.send)
             self.recv_dims.copy_(self.send_dims)
         self.dims = self.recv_dims.cpu().numpy().reshape(self.world, self.per_rank, self.n_sites, 3)
+        if timed and str(self.send.device).startswith("cuda"):
+            torch.cuda.synchronize()
+        self.last_export_s, self.last_gather_s = t1 - t0, time.perf_counter() - t1
+        self.gather_bytes = int(self.recv.numel() * 8 + self.recv_dims.numel() * 8)
         return self
 
     def _slot(self, p):
@@ -391,9 +402,13 @@ class PiShardGather:
         if n not in self._buf:
             self._buf[n] = (torch.zeros(n, dtype=torch.float64, device=self.device),
                             torch.zeros(self.world * n, dtype=torch.float64, device=self.device))
+        import time
+        t0 = time.perf_counter()
         s, r = self._buf[n]
         s.copy_(torch.from_numpy(np.ascontiguousarray(send)))
         self.dist.all_gather_into_tensor(r, s)
         self.calls += 1
         self.bytes += 8 * n
-        return r.cpu().numpy()
+        out = r.cpu().numpy()  # (staged through host + device copies per matrix: fine for an expensive f)
+        self.seconds = getattr(self, "seconds", 0.0) + (time.perf_counter() - t0)
+        return out

@@ -48,3 +48,35 @@ def test_bench_site_shard_mode_single_gpu():
         am = line["amdahl"]
         assert am["replicated_ms"] > 0 and am["sharded_ms"] > 0 and am["speedup_bound_vs_n1"] >= 1.0
         assert line["scaling"] == "strong"
+
+
+def _one_line(argv, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_patch_farm_mode_single_gpu():
+    """`--mode patch-farm` (BASELINE.json configs[4] as stated: 64 statically projected patches, chi = 128, PaddedPatchFarm +
+    DevicePatchExporter(group = 8), one all_gather_into_tensor) at N = 1: one JSON line with the per-rank times, the gathered bytes
+    and the exposed gather time; every patch reaches chi.  No scaling claim at N = 1."""
+    line = _one_line(["--mode", "patch-farm", "--gpus", "1", "--steps", "1", "--warmup", "1"])
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["unit"] == "patches/s"
+    assert line["config"]["n_patches"] == 64 and line["config"]["chi_max"] == 128 and line["config"]["group"] == 8
+    assert line["all_patches_reach_chi"] is True
+    assert len(line["per_rank_ms_per_step"]) == 1 and line["per_rank_ms_per_step"][0] > 0
+    assert line["gather_bytes_per_step"] >= 64 * 30 * 128 * 2 * 128 * 8
+    assert 0 <= line["exposed_gather_ms_per_step"][0] < line["ms_per_step"]
+    assert abs(line["value"] - 64 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def test_bench_pi_shard_mode_single_gpu():
+    """`--mode pi-shard` (candidate matrices of a host callback by column blocks, rrLU replicated) at N = 1: the
+    unsharded callback path with its three costs side by side — the user function, the (absent) gather, the rrLU kernels."""
+    line = _one_line(["--mode", "pi-shard", "--gpus", "1", "--steps", "1", "--warmup", "1"])
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["chi_max"] == 256
+    assert line["callback_ms_per_step"][0] > 0 and line["rrlu_ms_per_step"][0] > 0 and line["gather_ms_per_step"][0] == 0.0
+    assert line["callback_points_per_step_all_ranks"] > 1e7
+    assert line["callback_ms_per_step"][0] < line["ms_per_step"]

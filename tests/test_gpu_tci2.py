@@ -731,9 +731,10 @@ def test_cfg4_from_scratch_iterations_match_oracle(t4a):
 
 
 def test_global_pivot_search_matches_oracle_stream(t4a):
-    """DefaultGlobalPivotFinder (globalpivot.rs:160-219) with nsearch > 0: the reference draws from rand 0.9 StdRng
-    ("parity unpinned"); device and oracle share one splitmix64 stream, so with a seed they must add the same
-    global pivots and end in the same state."""
+    """DefaultGlobalPivotFinder (globalpivot.rs:160-219) with nsearch > 0: the reference draws from rand 0.9 StdRng; device
+    (csrc/stdrng.hpp) and oracle (oracle/t4a_oracle_rng.hpp) each restate that generator (ChaCha12 + PCG32 seed expansion + Canon
+    range sampling, pinned to the published cipher vectors in tests/test_cpu_stdrng.py), so with a seed they must add the same
+    global pivots and end in the same state — errors included, bit for bit (they are pivot magnitudes of the bit-exact rrLU)."""
     from t4a_amd.functions import lorentz
     spec = lorentz([5] * 5)
     g, o = both(t4a, spec, [5] * 5)
@@ -743,7 +744,7 @@ def test_global_pivot_search_matches_oracle_stream(t4a):
     assert_same_sets(g, o, 5)
     rg, eg = g.history()
     ro, eo = o.history()
-    assert list(rg) == list(ro) and np.allclose(eg, eo, rtol=1e-9, atol=1e-15)
+    assert list(rg) == list(ro) and np.array_equal(eg, eo)
     assert g.termination() == o.termination()
 
 
@@ -764,6 +765,7 @@ h = hashlib.sha256()
 def run(spec, dims, opt, pivots):
     g = t4a.TensorCI2(dims)
     g.set_function(spec)
+    g.set_chain(True, small_engine=False)  # (round 6: the one-launch engine would run both arms and make the comparison empty)
     g.crossinterpolate2(pivots, opt)
     for s in range(len(dims)):
         h.update(np.ascontiguousarray(g.site_tensor(s)).tobytes())
