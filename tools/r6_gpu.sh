@@ -14,6 +14,11 @@ for stage in "$@"; do
       timeout 2400 python -m pytest tests/test_gpu_small.py tests/test_gpu_tci2.py tests/test_gpu_chain.py -x -q > "$out/pytest.log" 2>&1; echo "pytest rc $?" >> "$out/pytest.log"; tail -15 "$out/pytest.log" ;;
     suite)      # the whole GPU suite
       timeout 3400 python -m pytest tests -m gpu -x -q > "$out/pytest.log" 2>&1; echo "pytest rc $?" >> "$out/pytest.log"; tail -15 "$out/pytest.log" ;;
+    rng)        # the streams changed in round 6 (tree proposers, ACI initial guess), ADVICE fixes, the new bench modes
+      timeout 3000 python -m pytest tests/test_gpu_bench_cli.py tests/test_gpu_tree.py tests/test_gpu_aci.py tests/test_gpu_quantics.py tests/test_gpu_tci2.py tests/test_gpu_rook.py tests/test_gpu_parallel.py tests/test_gpu_pishard.py -x -q > "$out/pytest.log" 2>&1; echo "pytest rc $?" >> "$out/pytest.log"; tail -15 "$out/pytest.log" ;;
+    modes)      # N = 1 numbers of the two multi-GPU modes
+      timeout 900 python bench.py --mode patch-farm --steps 5 --warmup 1 > "$out/patch_farm.json" 2> "$out/patch_farm.err"; tail -2 "$out/patch_farm.json"
+      timeout 900 python bench.py --mode pi-shard --steps 2 --warmup 1 > "$out/pi_shard.json" 2> "$out/pi_shard.err"; tail -2 "$out/pi_shard.json" ;;
     bench)      # the default bench line
       timeout 900 python bench.py > "$out/bench.json" 2> "$out/bench.err"; tail -3 "$out/bench.json" ;;
     components) timeout 900 python tools/bench_components.py > "$out/components.json" 2> "$out/components.err"; tail -5 "$out/components.json" ;;
