@@ -527,7 +527,7 @@ constexpr int SMALL_MAX_ITER = 64;   // iterations whose errors / ranks the resu
 constexpr int SMALL_MAX_W = 512;     // K * total weights
 struct SmallHeader { // travels in the kernel arguments; offsets in bytes from the start of the (pinned) input block
     int n, K, fid, total;
-    int max_iter, ncheck, sweep_strategy, flags; // flags: 1 normalize_error, 2 strictly_nested, 4 final_sweep1site, 8 phase stamps
+    int max_iter, ncheck, sweep_strategy, flags; // flags: 1 normalize_error, 2 strictly_nested, 4 final_sweep1site, 8 phase stamps, 16 PivotSearchStrategy::Rook
     int max_bond_dim, cap_in, pad0, pad1;        // cap_in: entries per (family, site) in the input tables (<= SMALL_CAP)
     double tolerance, max_sample_value;
     double params[T4A_FN_MAX_PARAMS];

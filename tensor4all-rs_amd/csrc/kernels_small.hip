@@ -65,7 +65,7 @@ struct SmallStatic {
     unsigned long long ph[8], ph_last;
     double params[16];
     double msv;                  // max_sample_value
-    int fid, n, total, n_pe, stamps;
+    int fid, n, total, n_pe, stamps, rook, rook_bonds, rook_visits;
     // fill jobs: wave 0 publishes job number e (fill of iteration e - 1 from snapshot slot 1 + e % 2) by storing e; every worker
     // answers in done[w]; fail[w] != 0: a site could not be filled
     int job, quit, done[SMALL_WAVES], fail[SMALL_WAVES];
@@ -436,6 +436,283 @@ __device__ __attribute__((noinline)) int small_bond_big(int fact_, int M_, int N
     return r;
 }
 
+// ---- PivotSearchStrategy::Rook (tensorci2.rs:1904-1929; matrixluci/block_rook.rs:71-190) for a candidate matrix that fits the tile ----
+// The lazy evaluator exists to avoid evaluating f; a built-in functor costs nothing, so the matrix is materialised in the LDS (SH.Af,
+// leading dimension 32) and ONE wavefront runs factorize_lazy on it with the arithmetic of rook_dense_kernel (rook.hip), operation for
+// operation: per accepted pivot the LU of the k x k pivot block with partial pivoting (first maximum of |a_ik|) and X = P^-1 A[I, :]
+// by column-oriented substitutions (separately rounded multiply and subtract), the alternating column / row arg-max of the residual
+// with j-ascending sums and first strict maxima.  max_sample_value only sees the rows and columns the lazy evaluator would have
+// visited (tensorci2.rs:2035-2142).  Returns the rank, -1 for non-finite values, -2 for a singular pivot block (handed back).
+// Results: SH.o_ptab (lane k: row of pivot k, lane 32 + k: column), SH.o_pvabs (accepted pivot errors), SH.o_error (pivot_errors.back()).
+template <int K>
+__device__ __attribute__((noinline)) int small_bond_rook(int M_, int N_, int max_bond_dim_, double rel_tol, double abs_tol)
+{
+    const int lane = threadIdx.x & 63;
+    const int M = ui(M_), N = ui(N_);
+    rel_tol = uniform_f64(rel_tol);
+    abs_tol = uniform_f64(abs_tol);
+    constexpr int LD = SMALL_TILE; // leading dimension of A in the LDS
+    double* const A = SH.Af;
+    // ---- Pi, compactly: entry p = i + M j of the M N entries in lane p % 64 of pass p / 64 ----
+    {
+        bool bad = false;
+        const int total = M * N;
+        for (int p0 = 0; p0 < total; p0 += 64) {
+            const int p = p0 + lane;
+            const bool in = p < total;
+            const int j = div_small(in ? p : 0, M), i = (in ? p : 0) - j * M;
+            uint64_t acc[2] = {0, 0};
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = SH.lacc[i * KS + q] + SH.lacc[(32 + j) * KS + q];
+            const double v = small_fn_value(acc[0], acc[1]);
+            if (in) {
+                A[i + LD * j] = v;
+                bad |= !((v - v) == 0.0);
+            }
+        }
+        if (__ballot(bad) != 0ull) return -1;
+        wsync();
+    }
+    double* const P = SH.wk[0].As;   // k x k, leading dimension SC
+    double* const X = SH.wk[0].Bs;   // k x N, leading dimension SC
+    double* const bv = SH.xs;        // k
+    double* const yv = SH.xs + 64;   // k
+    int* const I = SH.pp;            // selected rows
+    int* const J = SH.pp + 16;       // selected columns
+    int* const piv = SH.pp + 32;
+    const int full_rank = M < N ? M : N;
+    const int max_bond = ui(max_bond_dim_) < full_rank ? ui(max_bond_dim_) : full_rank;
+    unsigned rowsel = 0u, colsel = 0u, seen_r = 0u, seen_c = 0u;
+    const unsigned rmask = M >= 32 ? 0xFFFFFFFFu : ((1u << M) - 1u), cmask = N >= 32 ? 0xFFFFFFFFu : ((1u << N) - 1u);
+    int k = 0, visits = 0;
+    double max_error = 0.0, last_error = __builtin_nan("");
+    double accepted = 0.0; // lane q: accepted pivot error q
+    int ptab = 0;
+    while (k < max_bond && k < SC) {
+        const unsigned rem_r = ~rowsel & rmask, rem_c = ~colsel & cmask;
+        if (rem_r == 0u || rem_c == 0u) break;
+        const int first_row = __builtin_ctz(rem_r), first_col = __builtin_ctz(rem_c);
+        const int n_rem_rows = __builtin_popcount(rem_r), n_rem_cols = __builtin_popcount(rem_c);
+        if (k > 0) {
+            // factor_step: P = A[I, J] -> LU in place (row swaps applied to X as well); X = P^-1 A[I, :]
+            for (int e = lane; e < k * k; e += 64) {
+                const int c = div_small(e, k), r = e - c * k;
+                P[c * SC + r] = A[I[r] + LD * J[c]];
+            }
+            for (int e = lane; e < k * N; e += 64) {
+                const int c = div_small(e, k), r = e - c * k;
+                X[c * SC + r] = A[I[r] + LD * c];
+            }
+            wsync();
+            int info = 0;
+            for (int c = 0; c < k; ++c) {
+                double bvv = -1.0;
+                int bi = 0x7fffffff;
+                if (lane >= c && lane < k) {
+                    bvv = fabs(P[c * SC + lane]);
+                    bi = lane;
+                }
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) { // (k <= 16)
+                    const double ov = __shfl_xor(bvv, off);
+                    const int oi = __shfl_xor(bi, off);
+                    if (ov > bvv || (ov == bvv && oi < bi)) {
+                        bvv = ov;
+                        bi = oi;
+                    }
+                }
+                const int p = __builtin_amdgcn_readlane(bi, 0);
+                const double gv = readlane_f64(bvv, 0);
+                if (lane == 0) piv[c] = p;
+                if (!(gv > 0.0) && info == 0) info = c + 1;
+                if (p != c && p < k) {
+                    if (lane < k) {
+                        const double t0 = P[lane * SC + c];
+                        P[lane * SC + c] = P[lane * SC + p];
+                        P[lane * SC + p] = t0;
+                    }
+                    if (lane < N) {
+                        const double t0 = X[lane * SC + c];
+                        X[lane * SC + c] = X[lane * SC + p];
+                        X[lane * SC + p] = t0;
+                    }
+                }
+                wsync();
+                const double pv = P[c * SC + c];
+                if (pv == 0.0 || pv != pv) continue;
+                if (lane > c && lane < k) P[c * SC + lane] = P[c * SC + lane] / pv;
+                wsync();
+                const int rem = k - c - 1;
+                for (int e = lane; e < rem * rem; e += 64) {
+                    const int qq = div_small(e, rem);
+                    const int i = c + 1 + (e - qq * rem), q = c + 1 + qq;
+                    const double prod = P[c * SC + i] * P[q * SC + c];
+                    P[q * SC + i] = P[q * SC + i] - prod;
+                }
+                wsync();
+            }
+            if (info != 0) return -2;
+            // L X' = P_swap A[I, :], then U X = X': a lane per right-hand side, every element sees its updates in trsm_left_kernel's order
+            if (lane < N) {
+                double* x = X + lane * SC;
+                for (int kk = 0; kk < k; ++kk) {
+                    const double xk = x[kk];
+                    for (int i = kk + 1; i < k; ++i) {
+                        const double prod = P[kk * SC + i] * xk;
+                        x[i] = x[i] - prod;
+                    }
+                }
+                for (int kk = k - 1; kk >= 0; --kk) {
+                    const double xk = x[kk] / P[kk * SC + kk];
+                    x[kk] = xk;
+                    for (int i = 0; i < kk; ++i) {
+                        const double prod = P[kk * SC + i] * xk;
+                        x[i] = x[i] - prod;
+                    }
+                }
+            }
+            wsync();
+        }
+        // rook_pivot (:71-118)
+        int cur_col = first_col, cur_row = first_row;
+        double pivot_abs = 0.0;
+        const int max_steps = n_rem_rows + n_rem_cols + 1;
+        for (int it = 0; it < max_steps; ++it) {
+            ++visits;
+            seen_c |= 1u << cur_col;
+            if (k > 0) {
+                if (lane < k) bv[lane] = A[I[lane] + LD * cur_col];
+                wsync();
+                if (lane == 0)
+                    for (int j = 0; j < k; ++j) {
+                        const int p = piv[j];
+                        if (p != j) {
+                            const double t0 = bv[j];
+                            bv[j] = bv[p];
+                            bv[p] = t0;
+                        }
+                    }
+                wsync();
+                // unit lower, then upper, column-oriented (rook_trsm_vec)
+                for (int step = 0; step < k; ++step) {
+                    const double bk = bv[step];
+                    if (lane > step && lane < k) {
+                        const double prod = P[step * SC + lane] * bk;
+                        bv[lane] = bv[lane] - prod;
+                    }
+                    wsync();
+                }
+                for (int step = k - 1; step >= 0; --step) {
+                    if (lane == 0) bv[step] = bv[step] / P[step * SC + step];
+                    wsync();
+                    const double bk = bv[step];
+                    if (lane < step) {
+                        const double prod = P[step * SC + lane] * bk;
+                        bv[lane] = bv[lane] - prod;
+                    }
+                    wsync();
+                }
+            }
+            {   // residual of column cur_col over the remaining rows: first maximum of |r|
+                double v = -1.0;
+                if (lane < M && !((rowsel >> lane) & 1u)) {
+                    double acc = 0.0;
+                    for (int j = 0; j < k; ++j) {
+                        const double prod = A[lane + LD * J[j]] * bv[j];
+                        acc = acc + prod;
+                    }
+                    const double ac = A[lane + LD * cur_col];
+                    const double r = k > 0 ? ac - acc : ac;
+                    v = fabs(r);
+                }
+                double g = v;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) g = fmax(g, __shfl_xor(g, off));
+                const double gv = readlane_f64(g, 0);
+                const unsigned long long hit = __ballot(v == gv && v >= 0.0);
+                cur_row = (gv < 0.0 || hit == 0ull) ? first_row : (int)__builtin_ctzll(hit);
+            }
+            seen_r |= 1u << cur_row;
+            if (k > 0) {
+                if (lane < k) yv[lane] = A[cur_row + LD * J[lane]];
+                wsync();
+            }
+            int next_col;
+            {
+                double v = -1.0;
+                if (lane < N && !((colsel >> lane) & 1u)) {
+                    double acc = 0.0;
+                    for (int j = 0; j < k; ++j) {
+                        const double prod = yv[j] * X[lane * SC + j];
+                        acc = acc + prod;
+                    }
+                    const double arc = A[cur_row + LD * lane];
+                    const double r = k > 0 ? arc - acc : arc;
+                    v = fabs(r);
+                }
+                double g = v;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) g = fmax(g, __shfl_xor(g, off));
+                const double gv = readlane_f64(g, 0);
+                const unsigned long long hit = __ballot(v == gv && v >= 0.0);
+                next_col = (gv < 0.0 || hit == 0ull) ? first_col : (int)__builtin_ctzll(hit);
+                pivot_abs = gv < 0.0 ? 0.0 : gv;
+            }
+            if (next_col == cur_col) break;
+            cur_col = next_col;
+        }
+        // factorize_lazy stop rules (:158-176)
+        last_error = pivot_abs;
+        if (k > 0 && (pivot_abs < rel_tol * max_error || pivot_abs < abs_tol)) break;
+        if (pivot_abs < 2.220446049250313e-16) break;
+        max_error = fmax(max_error, pivot_abs);
+        if (lane == 0) {
+            I[k] = cur_row;
+            J[k] = cur_col;
+        }
+        if (lane == k) {
+            accepted = pivot_abs;
+            ptab = cur_row;
+        }
+        if (lane == 32 + k) ptab = cur_col;
+        rowsel |= 1u << cur_row;
+        colsel |= 1u << cur_col;
+        ++k;
+        wsync();
+    }
+    if (k >= full_rank) last_error = 0.0;                                       // :178-184
+    else if (k == max_bond && k > 0) last_error = readlane_f64(accepted, k - 1);
+    // what the lazy evaluator looked at: the visited rows and columns (max sqrt(v * v) over them)
+    {
+        double mx = 0.0;
+        for (int p0 = 0; p0 < M * N; p0 += 64) {
+            const int p = p0 + lane;
+            if (p < M * N) {
+                const int j = div_small(p, M), i = p - j * M;
+                if (((seen_r >> i) & 1u) || ((seen_c >> j) & 1u)) {
+                    const double v = A[i + LD * j];
+                    const double av = sqrt(v * v);
+                    if (av > mx) mx = av;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+        const double am = readlane_f64(mx, 0);
+        if (am > SH.msv && lane == 0) SH.msv = am;
+    }
+    SH.o_ptab[lane] = ptab;
+    SH.o_rpos[lane] = 0;
+    SH.o_pvabs[lane] = accepted;
+    if (lane == 0) {
+        SH.o_error = last_error;
+        SH.rook_bonds += 1;
+        SH.rook_visits += visits;
+    }
+    wsync();
+    return k;
+}
+
 // pivots -> I_{b+1} (lanes 0..31) and J_b (lanes 32..63) (tensorci2.rs:1934-1940 with non_empty_or_first :1813-1819)
 template <int K>
 __device__ __forceinline__ bool small_gather(int b, int r, int ptab)
@@ -473,7 +750,14 @@ __device__ __forceinline__ int small_update(const int left_, const int one_, int
     int ptab, rpos, r;
     double pvabs, error;
     const int tile = (M <= 8 && N <= 8) ? 0 : ((M <= 16 && N <= 16) ? 1 : 2);
-    if (tile == 0) {
+    if (!one && ui(SH.rook) != 0) {
+        r = ui(small_bond_rook<K>(M, N, max_bond_dim, rel_tol, abs_tol));
+        if (r == -2) return 5;
+        ptab = SH.o_ptab[lane];
+        rpos = 0;
+        pvabs = SH.o_pvabs[lane];
+        error = uniform_f64(SH.o_error);
+    } else if (tile == 0) {
         if (left) r = small_bond<K, 1, true>(one, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
         else r = small_bond<K, 1, false>(one, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
     } else {
@@ -826,6 +1110,9 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
             SH.n_pe = 0;
             SH.msv = hd->max_sample_value;
             SH.stamps = (flags & 8) ? 1 : 0;
+            SH.rook = (flags & 16) ? 1 : 0;
+            SH.rook_bonds = 0;
+            SH.rook_visits = 0;
             SH.job = 0;
             SH.quit = 0;
             SH.ph_last = (flags & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1003,7 +1290,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
             oh->clocks[1] = t_iters - t_loaded;
             oh->clocks[2] = small_clock() - t_iters;
             for (int q = 0; q < 8; ++q) oh->clocks[3 + q] = SH.ph[q];
-            oh->clocks[11] = 0ull;
+            oh->clocks[11] = ((unsigned long long)(unsigned)SH.rook_bonds << 32) | (unsigned)SH.rook_visits;
         }
         __threadfence_system();
         if (lane == 0) {

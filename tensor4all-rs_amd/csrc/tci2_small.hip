@@ -15,6 +15,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace t4a {
@@ -22,7 +23,11 @@ namespace t4a {
 bool Tci2::small_engine_eligible(const TCI2Options& options) const
 {
     if (!small_enabled || !chain_enabled || chain_verify || chain_event_timing) return false;
-    if (fn_kind_ != FnKind::Builtin || fn_dev_.n_acc > 2 || options.pivot_search != 0) return false;
+    if (fn_kind_ != FnKind::Builtin || fn_dev_.n_acc > 2 || (options.pivot_search != 0 && options.pivot_search != 1)) return false;
+    if (options.pivot_search == 1) {
+        static const bool rook_host = std::getenv("T4A_ROOK_HOST") != nullptr; // (A/B of the search drivers: rook.hip's host-driven loop is asked for)
+        if (rook_host) return false;
+    }
     if (!(options.nsearch == 0 || options.max_nglobal_pivot == 0)) return false;
     if (!history.empty() || shard_world != 1 || keep_site_tensors || pi_shard.active()) return false;
     if (n_ > (size_t)SMALL_MAX_SITES || options.max_iter > (size_t)SMALL_MAX_ITER || options.ncheck_history > (size_t)SMALL_MAX_ITER) return false;
@@ -60,7 +65,7 @@ bool Tci2::small_engine_run(OptRun& r)
     h.max_iter = (int)options.max_iter;
     h.ncheck = (int)options.ncheck_history;
     h.sweep_strategy = options.sweep_strategy;
-    h.flags = (options.normalize_error ? 1 : 0) | (options.strictly_nested ? 2 : 0) | (r.final_sweep1site ? 4 : 0) | (small_stamps ? 8 : 0);
+    h.flags = (options.normalize_error ? 1 : 0) | (options.strictly_nested ? 2 : 0) | (r.final_sweep1site ? 4 : 0) | (small_stamps ? 8 : 0) | (options.pivot_search == 1 ? 16 : 0);
     h.max_bond_dim = (int)std::min<size_t>(options.max_bond_dim_or_max(), (size_t)1 << 30);
     h.cap_in = (int)cap_in;
     h.tolerance = options.tolerance;
@@ -146,6 +151,8 @@ bool Tci2::small_engine_run(OptRun& r)
     const SmallOutHeader oh = *reinterpret_cast<const SmallOutHeader*>(out);
     for (int q = 0; q < 12; ++q) small_last_clocks_[q] = oh.clocks[q];
     small_last_reason_ = oh.reason;
+    rook_work_.n_device_searches += (size_t)(oh.clocks[11] >> 32); // rook bonds the launch ran device-resident
+    rook_work_.n_device_visits += (size_t)(oh.clocks[11] & 0xFFFFFFFFull);
     if (oh.status == 3) { // a site tensor could not be filled inside the launch: the general path runs the call from the start
         ++small_stats[2];
         return false;

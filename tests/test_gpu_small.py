@@ -163,3 +163,37 @@ def test_engine_is_not_offered_callbacks_or_global_search(t4a):
     c.set_function(lambda idx: float(np.cos(sum(idx) * 0.3)))
     c.crossinterpolate2([[0] * n], t4a.TCI2Options(tolerance=1e-8, max_bond_dim=8, max_iter=6, **PARITY))
     assert c.small_stats()["completed"] == 0 and c.small_stats()["iterations"] == 0
+
+
+@pytest.mark.parametrize("nbits,maxb", [(8, 8), (12, 16), (20, 64)])
+def test_rook_pivot_search_inside_the_launch(t4a, nbits, maxb):
+    """PivotSearchStrategy::Rook (tensorci2.rs:1904-1929, matrixluci/block_rook.rs:71-190) on a small problem: the candidate matrix is
+    materialised in the LDS and factorize_lazy runs on it inside the launch (a built-in functor costs nothing to evaluate) with the
+    arithmetic of rook_dense_kernel; max_sample_value sees only the rows and columns the lazy evaluator would have visited.  Engine,
+    general device path (device-resident search per bond) and oracle agree on every observable."""
+    from t4a_amd.functions import quantics_trig_exp
+    spec = quantics_trig_exp(nbits)
+    opts = t4a.TCI2Options(tolerance=1e-8, max_bond_dim=maxb, max_iter=8, pivot_search=1, seed=42, **PARITY)
+    s, g, o = three(t4a, spec, [2] * nbits)
+    o.set_pivot_search(1)
+    for h in (s, g, o):
+        h.crossinterpolate2([[0] * nbits], opts)
+    assert_identical(s, g, o, nbits, core_tol=1e-8)
+    st = s.small_stats()
+    assert st["completed"] == 1 and st["handed_back"] == 0, st
+    assert s.rook_stats()["device_searches"] >= (nbits - 1) * st["iterations"] and s.rook_stats()["host_searches"] == 0
+    pts = np.random.default_rng(3).integers(0, 2, size=(200, nbits))
+    assert np.abs(s.evaluate(pts) - ob.fn_eval(spec, pts)).max() <= 1e-6
+
+
+def test_rook_growing_problem_is_handed_over(t4a):
+    from t4a_amd.functions import quantics_osc2d
+    n = 12
+    spec = quantics_osc2d(n, k1=3, k2=5, k3=7, eps=0.3, k4=11, delta=0.2)
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=24, max_iter=5, pivot_search=1, **PARITY)
+    s, g, o = three(t4a, spec, [2] * n)
+    o.set_pivot_search(1)
+    for h in (s, g, o):
+        h.crossinterpolate2([[0] * n], opts)
+    assert_identical(s, g, o, n, core_tol=1e-8)
+    assert s.small_stats()["iterations"] >= 1

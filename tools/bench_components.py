@@ -166,7 +166,7 @@ def components(quick=False, only="", no_oracle=False):
                     t.set_function(spec)
                     t.crossinterpolate2([[0] * d], opt)
                     return t
-                ms_rook, t = best_of(lambda: run(o), 2)
+                ms_rook, t = best_of(lambda: run(o), 3)
                 ms_full, tf = best_of(lambda: run(of), 2)
                 r = {"device_rook_ms": ms_rook, "device_full_ms": ms_full, "rank_rook": int(max(t.link_dims())), "rank_full": int(max(tf.link_dims()))}
                 if ob is not None:
