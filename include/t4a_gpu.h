@@ -825,8 +825,16 @@ t4a_gpu_status t4a_gpu_tci2_fill_site_tensors_group(t4a_gpu_tci2* const* handles
  * device-side index tables are read back and compared with the host's I / J sets (T4A_GPU_INTERNAL_ERROR on a difference);
  * bit 1: while profiling, the rrLU launches of a chain are timed with HIP events around each launch instead of the kernels' own
  * time stamps (two more packets per bond on the stream: for calibration runs);
- * bit 2: the small-problem engine (below) is switched off for this handle; bit 3: its launch stamps its phases (diagnostic). */
+ * bit 2: the small-problem engine (below) is switched off for this handle; bit 3: its launch stamps its phases (diagnostic);
+ * bit 4: opt-in to the relaxed guard of the captured fill_site_tensors graph — replay also on a handle whose site tensors are exported /
+ * imported asynchronously, unless the legacy default stream or a blocking stream took part (default: never on such a handle). */
 t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t verify);
+/* Opt-in (default 1): the points of ONE candidate matrix (tensorci2.rs:1859-1893) are split into n_threads contiguous blocks and the host
+ * callback is called for the blocks CONCURRENTLY from n_threads host threads (idx / out pointing into the block).  This is outside the
+ * reference's contract — it calls `f` / `batched_f` sequentially from one thread on purpose (docs/design/adaptive-tci-interpolation.md:9-11)
+ * — so only for callbacks that are thread safe; values, pivots and results are bitwise those of n_threads == 1.  Matrices below 16 384
+ * points stay on the calling thread. */
+t4a_gpu_status t4a_gpu_tci2_set_callback_threads(t4a_gpu_tci2* h, size_t n_threads);
 /* The small-problem engine (round 6): optimize_with_finder (tensorci2.rs:1626-1802) of a small problem — iteration loop, the
  * update_pivots chain (:1821-2007), fill_site_tensors (:1065-1186), convergence_criterion (:1407-1437) and the final 1-site sweep
  * (:1781-1794) — as ONE launch, index sets in the LDS, every candidate matrix (up to 32 x 32) in the registers of one wavefront.

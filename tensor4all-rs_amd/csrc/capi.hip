@@ -1245,6 +1245,15 @@ t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t v
     });
 }
 
+t4a_gpu_status t4a_gpu_tci2_set_callback_threads(t4a_gpu_tci2* h, size_t n_threads)
+{
+    return guarded([&] {
+        T4A_REQUIRE_PTR(h);
+        if (n_threads < 1 || n_threads > 256) throw Error(T4A_GPU_INVALID_ARGUMENT, "callback threads: between 1 and 256");
+        h->impl.callback_threads = n_threads;
+    });
+}
+
 t4a_gpu_status t4a_gpu_tci2_small_stats(const t4a_gpu_tci2* h, uint64_t* out)
 {
     return guarded([&] {

@@ -63,6 +63,12 @@ static_assert(Xcd2Lds<16, 3>::bytes == (int)xcd2_lds_total(16, 3), "plan.lds_byt
 #endif
 // T4A_X2_DUPLOAD = 1 (measurement only): every dividing wave fetches its rows of the winner's column TWICE — if the step gets slower by
 // about the time the hand-off takes, the hand-off is bound by the L2 serving 29 workgroups the same lines, not by latency
+// T4A_X2_NOBARB = 1 (experiment): barrier (B) is replaced by a step tag inside the record: the polling wave's
+// lane 0 stores the record with the tag, every other wave spins on the record in the LDS.  (Safe: a record of step kn exists only after
+// every agent's early key of step kn, i.e. after every wave of this workgroup has finished reading the previous step's l.)
+#ifndef T4A_X2_NOBARB
+#define T4A_X2_NOBARB 0
+#endif
 #ifndef T4A_X2_DUPLOAD
 #define T4A_X2_DUPLOAD 0
 #endif
@@ -754,7 +760,7 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
                     if (lds_ptrs[1]) reinterpret_cast<volatile int*>(lds_ptrs[1])[5] = giveup;
                 }
                 int4 rec;
-                rec.x = wa_ | (giveup << 30);
+                rec.x = wa_ | (giveup << 30) | (T4A_X2_NOBARB ? ((((kn & 0x7F) + 1)) << 16) : 0);
                 rec.y = (int)wkx;
                 rec.z = (int)wky;
                 rec.w = (int)wkz;
@@ -762,14 +768,23 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             }
             XSTAMP(9);
         }
+#if !T4A_X2_NOBARB
         __syncthreads(); // (B)
+#endif
         XSTAMP(3);
         int4 rec; // the record in ONE LDS round trip
         {
             int zero = 0;
+#if T4A_X2_NOBARB
+            for (;;) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rec) : "v"(zero), "n"(L::o_wi + 16) : "memory");
+                if (((__builtin_amdgcn_readfirstlane(rec.x) >> 16) & 0xFF) == ((kn & 0x7F) + 1)) break;
+            }
+#else
             asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rec) : "v"(zero), "n"(L::o_wi + 16) : "memory");
+#endif
         }
-        const unsigned recw = (unsigned)__builtin_amdgcn_readfirstlane(rec.x);
+        const unsigned recw = (unsigned)__builtin_amdgcn_readfirstlane(rec.x) & (T4A_X2_NOBARB ? 0xC000FFFFu : 0xFFFFFFFFu);
         if (recw >> 30) {
             timed_out = true;
             break;

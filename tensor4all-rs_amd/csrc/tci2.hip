@@ -480,10 +480,30 @@ void Tci2::eval_matrix(const IndexSet& a, size_t a0, const IndexSet& b, size_t b
                 fill_rows(0, na / nthr);
                 for (auto& th : pool) th.join();
             }
-            const int64_t got = cb_(cb_ctx_, idx, n_, npts, vals);
-            if (got < 0 || (size_t)got != npts)
-                throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " +
-                                                        std::to_string(npts) + " requested entries");
+            // opt-in (t4a_gpu_tci2_set_callback_threads): the point list of ONE candidate matrix split over host threads that call the
+            // user function concurrently — outside the reference's contract (it calls f sequentially on one thread on purpose,
+            // docs/design/adaptive-tci-interpolation.md:9-11), so only for callbacks that are thread safe.  Same points, same values.
+            const size_t cthr = (callback_threads <= 1 || npts < ((size_t)1 << 14)) ? 1 : std::min<size_t>(callback_threads, npts >> 12);
+            if (cthr <= 1) {
+                const int64_t got = cb_(cb_ctx_, idx, n_, npts, vals);
+                if (got < 0 || (size_t)got != npts)
+                    throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned " + std::to_string(got) + " values for " +
+                                                            std::to_string(npts) + " requested entries");
+            } else {
+                std::vector<int64_t> got(cthr, 0);
+                auto call = [&](size_t t) {
+                    const size_t p0 = npts * t / cthr, p1 = npts * (t + 1) / cthr;
+                    got[t] = cb_(cb_ctx_, idx + p0 * n_, n_, p1 - p0, vals + p0) - (int64_t)(p1 - p0);
+                };
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < cthr; ++t) pool.emplace_back(call, t);
+                call(0);
+                for (auto& th : pool) th.join();
+                for (size_t t = 0; t < cthr; ++t)
+                    if (got[t] != 0)
+                        throw Error(T4A_GPU_CALLBACK_ERROR, "batch callback returned a wrong number of values for block " + std::to_string(t) + " of " +
+                                                                std::to_string(cthr) + " (callback threads)");
+            }
         }
         d_vals_.reserve(npts);
         T4A_HIP(hipMemcpyAsync(d_vals_.get(), vals, npts * sizeof(double), hipMemcpyHostToDevice, st));

@@ -187,6 +187,7 @@ public:
     size_t shard_rank = 0, shard_world = 1;
     PiShard pi_shard; // column-block shard of callback-evaluated candidate matrices over a process group (pishard.hpp)
     bool keep_site_tensors = false;
+    size_t callback_threads = 1; // opt-in: host threads that evaluate one candidate matrix through the callback concurrently
     Engine eng;
 
 private:

@@ -448,6 +448,45 @@ def test_callback_path_matches_oracle_bitwise_pivots(t4a):
     assert_cores_close(g, o, 4, 1e-10)
 
 
+def test_native_callback_path_at_size_and_callback_threads(t4a):
+    """The route a real closure takes, at a size where every kernel family of the per-bond path is exercised (d = 18, chi = 48: matrices up to
+    ~140 x 140): the integrand behind a NATIVE host batch callback (tools/native_callback.c — same arithmetic as the
+    built-in functor, so the oracle's built-in run is the reference), pivots bit-exact, values to 1e-10.  Then the opt-in
+    t4a_gpu_tci2_set_callback_threads: four host threads evaluate every candidate matrix concurrently — index sets, errors and site
+    tensors must be BITWISE those of one thread."""
+    sys_path = os.path.join(ROOT, "tools")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from bench_components import NativeCallback
+    from t4a_amd.functions import quantics_osc2d
+    n, chi = 18, 48
+    spec = quantics_osc2d(n, k1=3, k2=5, k3=7, eps=0.1, k4=11, delta=0.3)
+    opts = t4a.TCI2Options(tolerance=1e-12, max_bond_dim=chi, max_iter=7, seed=42, **PARITY)
+    o = ob.OracleTCI2([2] * n)
+    o.set_function(spec)
+    o.crossinterpolate2([[0] * n], opts)
+    runs = []
+    for threads in (1, 4):
+        g = t4a.TensorCI2([2] * n)
+        cb = NativeCallback(spec)
+        cb.attach(g)
+        g.set_callback_threads(threads)
+        g.crossinterpolate2([[0] * n], opts)
+        assert cb.ctx.calls > 0 and g.small_stats()["iterations"] == 0   # (a callback never runs in the one-launch engine)
+        runs.append(g)
+    g1, g4 = runs
+    assert_same_sets(g1, o, n)
+    assert g1.history()[0] == o.history()[0] and np.array_equal(g1.history()[1], o.history()[1])
+    assert max(g1.link_dims()) == chi
+    pts = np.random.default_rng(8).integers(0, 2, size=(300, n))
+    assert np.abs(g1.evaluate(pts) - o.evaluate(pts)).max() <= 1e-10 * max(1.0, g1.max_sample_value())
+    for p in range(n):
+        assert np.array_equal(g1.i_set(p), g4.i_set(p)) and np.array_equal(g1.j_set(p), g4.j_set(p))
+        assert np.array_equal(g1.site_tensor(p).view(np.uint64), g4.site_tensor(p).view(np.uint64)), f"site {p}: four threads changed a value"
+    assert np.array_equal(g1.history()[1], g4.history()[1]) and g1.max_sample_value() == g4.max_sample_value()
+
+
 def test_batch_callback_length_is_checked(t4a):
     # :557-589 — a callback returning a wrong number of values is an error, not a crash
     f = lambda idx: float(idx[0] + 2 * idx[1])

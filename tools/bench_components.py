@@ -122,6 +122,13 @@ def components(quick=False, only="", no_oracle=False):
             t.optimize(o(2), final_sweep1site=False)
             cb_ms = (time.perf_counter() - t0) * 1e3
             calls, points = cb.ctx.calls - c0, cb.ctx.points - p0
+            # opt-in: eight host threads evaluate every candidate matrix concurrently (t4a_gpu_tci2_set_callback_threads)
+            t.set_callback_threads(8)
+            t.optimize(o(2), final_sweep1site=False)
+            t0 = time.perf_counter()
+            t.optimize(o(2), final_sweep1site=False)
+            cb8_ms = (time.perf_counter() - t0) * 1e3
+            t.set_callback_threads(1)
             # the callback alone on the same number of points (what no backend can remove)
             rng = np.random.default_rng(0)
             n_probe = min(int(points), 1 << 20)
@@ -133,7 +140,7 @@ def components(quick=False, only="", no_oracle=False):
             per_point_ns = (time.perf_counter() - t0) / n_probe * 1e9
             out["callback_sweep"] = {
                 "workload": f"d={d} chi={chi} interleaved 2-variable integrand, saturated full sweep (2 iterations of optimize incl. fill_site_tensors)",
-                "builtin_functor_ms": builtin_ms, "native_callback_ms": cb_ms, "callback_calls": int(calls), "callback_points": int(points),
+                "builtin_functor_ms": builtin_ms, "native_callback_ms": cb_ms, "native_callback_ms_8_callback_threads": cb8_ms, "callback_calls": int(calls), "callback_points": int(points),
                 "callback_ns_per_point_one_thread": per_point_ns, "callback_alone_ms": per_point_ns * points * 1e-6,
                 "threads": int(os.environ.get("T4A_CB_THREADS", "1")), "link_dims_max": int(max(t.link_dims())),
                 "note": "native_callback_ms - callback_alone_ms is what the backend adds around a user function: per-bond path (no device chain), "

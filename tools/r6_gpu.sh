@@ -19,6 +19,14 @@ for stage in "$@"; do
     modes)      # N = 1 numbers of the two multi-GPU modes
       timeout 900 python bench.py --mode patch-farm --steps 5 --warmup 1 > "$out/patch_farm.json" 2> "$out/patch_farm.err"; tail -2 "$out/patch_farm.json"
       timeout 900 python bench.py --mode pi-shard --steps 2 --warmup 1 > "$out/pi_shard.json" 2> "$out/pi_shard.err"; tail -2 "$out/pi_shard.json" ;;
+    ab)         # A/B of a variant library against the default one: AB_LIB=tensor4all-rs_amd/lib/libt4a_gpu_<name>.so tools/r6_gpu.sh ab
+      for arm in default variant default variant; do
+        if [ $arm = variant ]; then export T4A_GPU_LIB=$PWD/${AB_LIB}; else unset T4A_GPU_LIB; fi
+        timeout 600 python bench.py --no-aux --no-components --no-cpu-baseline --steps 20 --warmup 3 2>> "$out/ab.err" | python -c "import sys, json; d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$arm', round(d['ms_per_step'], 3), 'ms per sweep,', round(d['roofline']['latency_view']['us_per_pivot_step'], 4), 'us per pivot step')" | tee -a "$out/ab.log"
+      done
+      export T4A_GPU_LIB=$PWD/${AB_LIB}
+      timeout 1200 python -m pytest tests/test_gpu_dense.py tests/test_gpu_fuzz.py -x -q -k "rrlu or luci" > "$out/variant_pytest.log" 2>&1; echo "variant pytest rc $?" | tee -a "$out/ab.log"; tail -3 "$out/variant_pytest.log"
+      unset T4A_GPU_LIB ;;
     bench)      # the default bench line
       timeout 900 python bench.py > "$out/bench.json" 2> "$out/bench.err"; tail -3 "$out/bench.json" ;;
     components) timeout 900 python tools/bench_components.py > "$out/components.json" 2> "$out/components.err"; tail -5 "$out/components.json" ;;
