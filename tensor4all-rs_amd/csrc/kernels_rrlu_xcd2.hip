@@ -779,6 +779,9 @@ __device__ __forceinline__ void rrlu_xcd2_body(const RrluXcdArgs& p, const RrluX
             for (;;) {
                 asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rec) : "v"(zero), "n"(L::o_wi + 16) : "memory");
                 if (((__builtin_amdgcn_readfirstlane(rec.x) >> 16) & 0xFF) == ((kn & 0x7F) + 1)) break;
+#if T4A_X2_NOBARB > 1
+                __builtin_amdgcn_s_sleep(T4A_X2_NOBARB - 1); // (spinning waves take issue slots from the polling wave on their SIMD)
+#endif
             }
 #else
             asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rec) : "v"(zero), "n"(L::o_wi + 16) : "memory");
