@@ -197,3 +197,65 @@ def test_rook_growing_problem_is_handed_over(t4a):
         h.crossinterpolate2([[0] * n], opts)
     assert_identical(s, g, o, n, core_tol=1e-8)
     assert s.small_stats()["iterations"] >= 1
+
+
+def _fuzz_case(t4a, seed):
+    """One random small problem: function family, local dimensions, initial pivots and options drawn from `seed`."""
+    from t4a_amd.functions import quantics_trig_exp, quantics_osc2d, lorentz, linear_sum
+    rng = np.random.default_rng(seed)
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        n = int(rng.integers(4, 15))
+        dims = [2] * n
+        spec = quantics_trig_exp(n, a=float(rng.uniform(1, 30)), b=float(rng.uniform(0, 3)), cc=float(rng.uniform(-1, 1)), cs=float(rng.uniform(-1, 1)))
+    elif kind == 1:
+        n = 2 * int(rng.integers(2, 7))
+        dims = [2] * n
+        spec = quantics_osc2d(n, k1=int(rng.integers(1, 9)), k2=int(rng.integers(1, 9)), k3=int(rng.integers(1, 9)), eps=float(rng.uniform(0, 0.5)),
+                              k4=int(rng.integers(0, 5)), delta=float(rng.uniform(0, 0.5)))
+    elif kind == 2:
+        n = int(rng.integers(3, 8))
+        dims = [int(v) for v in rng.integers(2, 5, size=n)]
+        spec = lorentz(dims, coeff=float(rng.uniform(0.5, 2)))
+    else:
+        n = int(rng.integers(3, 9))
+        dims = [int(v) for v in rng.integers(2, 6, size=n)]
+        spec = linear_sum(dims, scale=float(rng.uniform(0.1, 2)), shift=float(rng.uniform(-1, 1)), site_weights=[int(v) for v in rng.integers(1, 4, size=n)])
+    opts = dict(tolerance=float(rng.choice([1e-3, 1e-6, 1e-9, 1e-12])), max_iter=int(rng.integers(1, 9)),
+                max_bond_dim=None if rng.random() < 0.4 else int(rng.integers(1, 9)), ncheck_history=int(rng.integers(1, 5)),
+                sweep_strategy=int(rng.integers(0, 3)), strictly_nested=bool(rng.random() < 0.3), normalize_error=bool(rng.random() < 0.7),
+                pivot_search=int(rng.random() < 0.25), nsearch=0 if rng.random() < 0.7 else 4, max_nglobal_pivot=0)
+    n_piv = int(rng.integers(1, 4))
+    pivots = [[int(rng.integers(0, d)) for d in dims] for _ in range(n_piv)]
+    if kind == 3:
+        pivots[0] = [d - 1 for d in dims]  # (a linear function may vanish at a random point: keep one pivot away from zero)
+    return spec, dims, opts, pivots, bool(rng.random() < 0.75)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("T4A_FUZZ_N", "60"))))  # (T4A_FUZZ_N=1000: the soak of profiles/r06_small_engine_fuzz.txt)
+def test_fuzz_engine_general_path_and_oracle_agree(t4a, seed):
+    """Random small problems — four function families, local dimensions 2 .. 5, one to three initial pivots, every option that changes the
+    control flow (tolerance, iteration cap, rank cap, history length of the convergence test, sweep direction, strictly nested sets, error
+    normalisation, pivot search strategy, with and without the final 1-site sweep): the launch, the general device path and the oracle
+    must agree on every observable, whether the launch completes the call or hands it back."""
+    spec, dims, opts, pivots, final = _fuzz_case(t4a, seed)
+    n = len(dims)
+    o_opts = t4a.TCI2Options(**opts)
+    s, g, o = three(t4a, spec, dims)
+    o.set_pivot_search(opts["pivot_search"])
+    results = []
+    for h in (s, g, o):
+        try:
+            h.add_global_pivots(pivots)
+            h.set_max_sample_value(1.0)
+            h.optimize(o_opts, final_sweep1site=final)
+            results.append(None)
+        except Exception as e:  # noqa: BLE001 - all three must fail alike
+            results.append(type(e).__name__)
+    assert results[0] == results[1], results
+    if results[0] is not None or results[2] is not None:
+        assert results[1] is not None and results[2] is not None, results
+        return
+    assert_identical(s, g, o, n, core_tol=1e-8 if opts["pivot_search"] else 1e-10)
+    st = s.small_stats()
+    assert st["completed"] + st["handed_back"] + st["not_eligible"] >= 1, st

@@ -309,6 +309,14 @@ def components(quick=False, only="", no_oracle=False):
                     r = {"device_ms": ms}
                     if fo is not None:
                         r["oracle_ms"], _ = best_of(lambda: fo(a), 1)
+                    # a LAPACK-class CPU path beside the oracle's plain restatement: numpy on ONE thread
+                    # (threadpoolctl) — the honest number to hold the device against, not part of the ratio the loser list is built from
+                    try:
+                        from threadpoolctl import threadpool_limits
+                        with threadpool_limits(limits=1):
+                            r["numpy_lapack_one_thread_ms"], _ = best_of((lambda: np.linalg.svd(a, full_matrices=False)) if name == "svd" else (lambda: np.linalg.qr(a)), 5)
+                    except Exception:  # noqa: BLE001
+                        pass
                     res[f"{name}_{m}x{n}"] = ratio(r)
             n = 512 if not args.quick else 64
             a, b = rng.standard_normal((n, n)) + n * np.eye(n), rng.standard_normal((n, 2 * n))
