@@ -680,6 +680,9 @@ __device__ __attribute__((noinline)) int small_bond_rook(int M_, int N_, int max
         ++k;
         wsync();
     }
+    // the pivot block and X are sized for SMALL_CAP pivots: a search that would go on beyond them is not representable here — the
+    // iteration is handed back (conservative: the reference might have stopped at the next pivot by its tolerance)
+    if (k >= SC && k < max_bond) return -3;
     if (k >= full_rank) last_error = 0.0;                                       // :178-184
     else if (k == max_bond && k > 0) last_error = readlane_f64(accepted, k - 1);
     // what the lazy evaluator looked at: the visited rows and columns (max sqrt(v * v) over them)
@@ -753,6 +756,7 @@ __device__ __forceinline__ int small_update(const int left_, const int one_, int
     if (!one && ui(SH.rook) != 0) {
         r = ui(small_bond_rook<K>(M, N, max_bond_dim, rel_tol, abs_tol));
         if (r == -2) return 5;
+        if (r == -3) return 3;
         ptab = SH.o_ptab[lane];
         rpos = 0;
         pvabs = SH.o_pvabs[lane];
