@@ -827,7 +827,9 @@ t4a_gpu_status t4a_gpu_tci2_fill_site_tensors_group(t4a_gpu_tci2* const* handles
  * time stamps (two more packets per bond on the stream: for calibration runs);
  * bit 2: the small-problem engine (below) is switched off for this handle; bit 3: its launch stamps its phases (diagnostic);
  * bit 4: opt-in to the relaxed guard of the captured fill_site_tensors graph — replay also on a handle whose site tensors are exported /
- * imported asynchronously, unless the legacy default stream or a blocking stream took part (default: never on such a handle). */
+ * imported asynchronously, unless the legacy default stream or a blocking stream took part (default: never on such a handle);
+ * bit 5: the small-problem engine keeps candidate matrices up to 32 x 32 (default 16 x 16: measured, the larger tile is slower than the
+ * general path, so growing runs are handed over early). */
 t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t verify);
 /* Opt-in (default 1): the points of ONE candidate matrix (tensorci2.rs:1859-1893) are split into n_threads contiguous blocks and the host
  * callback is called for the blocks CONCURRENTLY from n_threads host threads (idx / out pointing into the block).  This is outside the
@@ -837,9 +839,9 @@ t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t v
 t4a_gpu_status t4a_gpu_tci2_set_callback_threads(t4a_gpu_tci2* h, size_t n_threads);
 /* The small-problem engine (round 6): optimize_with_finder (tensorci2.rs:1626-1802) of a small problem — iteration loop, the
  * update_pivots chain (:1821-2007), fill_site_tensors (:1065-1186), convergence_criterion (:1407-1437) and the final 1-site sweep
- * (:1781-1794) — as ONE launch, index sets in the LDS, every candidate matrix (up to 32 x 32) in the registers of one wavefront.
+ * (:1781-1794) — as ONE launch, index sets in the LDS, every candidate matrix (up to 16 x 16; 32 x 32 on request) in the registers of one wavefront.
  * Offered every t4a_gpu_tci2_optimize / _crossinterpolate2 call on a built-in functor without global pivot search; when a set
- * outgrows 16 entries or a matrix 32 x 32 the launch hands the state at the start of that iteration back and the general path
+ * outgrows 16 entries or a matrix its tile the launch hands the state at the start of that iteration back and the general path
  * continues.  Results are those of the general path (index sets, errors, ranks bit for bit).
  * out[0] calls the engine completed, [1] iterations it ran, [2] runs handed back, [3] calls that were not eligible,
  * [4..6] device time of the last launch in 100 MHz ticks (input, iterations, final sweep + results), [7] why the last launch handed back

@@ -1242,6 +1242,7 @@ t4a_gpu_status t4a_gpu_tci2_set_chain(t4a_gpu_tci2* h, int32_t enable, int32_t v
         h->impl.small_enabled = (verify & 4) == 0;
         h->impl.small_stamps = (verify & 8) != 0;
         h->impl.fill_graph_relaxed = (verify & 16) != 0;
+        h->impl.small_tile_max = (verify & 32) ? 32 : 16;
     });
 }
 

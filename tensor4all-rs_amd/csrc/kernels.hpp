@@ -528,7 +528,7 @@ constexpr int SMALL_MAX_W = 512;     // K * total weights
 struct SmallHeader { // travels in the kernel arguments; offsets in bytes from the start of the (pinned) input block
     int n, K, fid, total;
     int max_iter, ncheck, sweep_strategy, flags; // flags: 1 normalize_error, 2 strictly_nested, 4 final_sweep1site, 8 phase stamps, 16 PivotSearchStrategy::Rook
-    int max_bond_dim, cap_in, pad0, pad1;        // cap_in: entries per (family, site) in the input tables (<= SMALL_CAP)
+    int max_bond_dim, cap_in, tile_max, pad1;    // cap_in: entries per (family, site) in the input tables (<= SMALL_CAP); tile_max: rows / columns of a candidate matrix the launch takes (16 or 32)
     double tolerance, max_sample_value;
     double params[T4A_FN_MAX_PARAMS];
     // ldim[n] woff[n] | w[K*total] | cnt[2n] (I sets then J sets) | code[2n][cap_in] | acc[2n][cap_in][K] | cores[n] (device pointers)

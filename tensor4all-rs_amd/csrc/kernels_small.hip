@@ -60,7 +60,7 @@ struct SmallStatic {
     double xs[SC * 64];
     int pp[64];
     int o_ptab[64], o_rpos[64]; // results of an out-of-line bond (tiles beyond 8 x 8)
-    double o_pvabs[64], o_error;
+    double o_pvabs[64], o_error, o_am; // (o_am: max sqrt(v * v) the bond sampled)
     SmallWork wk[SMALL_WAVES];
     unsigned long long ph[8], ph_last;
     double params[16];
@@ -121,9 +121,10 @@ __device__ __forceinline__ double small_div(double x, double p, double rp, bool 
 }
 __device__ __forceinline__ unsigned long long small_clock() { return __builtin_amdgcn_s_memrealtime(); }
 
-__device__ __forceinline__ void small_stamp(int slot)
+// (`on` comes from the kernel arguments: as a flag in the LDS every call site cost the walking wave an LDS round trip)
+__device__ __forceinline__ void small_stamp(bool on, int slot)
 {
-    if (SH.stamps) {
+    if (on) {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
         if ((threadIdx.x & 63) == 0) {
             SH.ph[slot] += now - SH.ph_last;
@@ -138,10 +139,9 @@ __device__ __forceinline__ void small_stamp(int slot)
 // Two LDS round trips: every load whose address does not depend on loaded data first (counts, site data, the parents' and the extras'
 // entries by lane), then the parent of each child through the cross-lane network and the digit's weight.
 template <int K>
-__device__ __forceinline__ bool small_lists(int hist, bool use_hist, int b, bool one_site, int& M, int& N)
+__device__ __forceinline__ bool small_lists(const int n, const int total, const int tile_max, int hist, bool use_hist, int b, bool one_site, int& M, int& N)
 {
     const int lane = threadIdx.x & 63, half = lane >> 5, t = lane & 31;
-    const int n = ui(SH.n);
     const bool direct = one_site && half;
     const int ps = half ? (direct ? b : b + 1) : b;
     const int hsite = half ? b : b + 1;
@@ -165,7 +165,7 @@ __device__ __forceinline__ bool small_lists(int hist, bool use_hist, int b, bool
         for (int q = 0; q < K; ++q) xa[q] = SH.tab[hist].acc[(fh * SC + tt) * KS + q];
     }
     const int m0 = np * d;
-    bool ok = np >= 1 && np <= SC && m0 <= SMALL_TILE && ne >= 0 && ne <= SC;
+    bool ok = np >= 1 && np <= SC && m0 <= tile_max && ne >= 0 && ne <= SC;
     int parent = 0, digit = 0;
     if (ok && t < m0) {
         if (half) { // (digit outer, parent inner)
@@ -181,7 +181,7 @@ __device__ __forceinline__ bool small_lists(int hist, bool use_hist, int b, bool
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         const uint64_t pa = bperm_u64(mypa[q], half * 32 + parent);
-        acc[q] = pa + (direct ? 0ull : SH.w[q * SH.total + wo + digit]);
+        acc[q] = pa + (direct ? 0ull : SH.w[q * total + wo + digit]);
     }
     const uint64_t code = direct ? pc : (uint64_t)digit + (uint64_t)d * pc;
     bool keep = extras && ok && t < ne;
@@ -200,7 +200,7 @@ __device__ __forceinline__ bool small_lists(int hist, bool use_hist, int b, bool
     const int nkeep = __builtin_popcount(kmh);
     const int pos = m0 + __builtin_popcount(kmh & ((1u << t) - 1u));
     const int tot = m0 + nkeep;
-    ok = ok && tot <= SMALL_TILE;
+    ok = ok && tot <= tile_max;
     if (__ballot(!ok) != 0ull) return false;
     if (t < m0) {
         SH.lcode[half * 32 + t] = code;
@@ -224,7 +224,7 @@ __device__ __forceinline__ bool small_lists(int hist, bool use_hist, int b, bool
 //   error = RrLU::error (matrixlu.rs:758, :811);  rpos_out: position of row `lane` in the reference's permuted order;
 //   with `fact` the factored matrix (L scaled below the pivots in the pivot columns, U in the pivot rows) goes to SH.Af[i + MR j].
 template <int K, int E, bool LEFT>
-__device__ __forceinline__ int small_bond(const bool fact, int M, int N, int max_bond_dim, double rel_tol, double abs_tol,
+__device__ __forceinline__ int small_bond(const bool stamps, const bool fact, int M, int N, int max_bond_dim, double rel_tol, double abs_tol, double& am_out,
                                           int& ptab, double& pvabs, double& error_out, int& rpos_out)
 {
     constexpr int MR = E == 1 ? 8 : (E == 4 ? 16 : 32);
@@ -281,9 +281,9 @@ __device__ __forceinline__ int small_bond(const bool fact, int M, int N, int max
         if (__ballot(bad) != 0ull) return -1;
         const double m = wave_max_f64(amax);
         const double am = hi_mid((int)hi32(m)) ? m : uniform_f64(sqrt(m * m));
-        if (am > SH.msv && lane == 0) SH.msv = am; // (wave-uniform compare: every lane sees the old value)
+        am_out = am;
     }
-    small_stamp(1);
+    small_stamp(stamps, 1);
     int rpos = i;
     int npiv = 0;
     double max_error = 0.0, error = __builtin_nan("");
@@ -423,14 +423,17 @@ template <int K, int E, bool LEFT>
 __device__ __attribute__((noinline)) int small_bond_big(int fact_, int M_, int N_, int max_bond_dim_, double rel_tol, double abs_tol)
 {
     int ptab, rpos;
-    double pvabs, error = 0.0;
-    const int r = small_bond<K, E, LEFT>(ui(fact_) != 0, ui(M_), ui(N_), ui(max_bond_dim_), uniform_f64(rel_tol), uniform_f64(abs_tol), ptab, pvabs, error, rpos);
+    double pvabs, error = 0.0, am = 0.0;
+    const int r = small_bond<K, E, LEFT>(false, ui(fact_) != 0, ui(M_), ui(N_), ui(max_bond_dim_), uniform_f64(rel_tol), uniform_f64(abs_tol), am, ptab, pvabs, error, rpos);
     const int lane = threadIdx.x & 63;
     if (r >= 0) {
         SH.o_ptab[lane] = ptab;
         SH.o_rpos[lane] = rpos;
         SH.o_pvabs[lane] = pvabs;
-        if (lane == 0) SH.o_error = error;
+        if (lane == 0) {
+            SH.o_error = error;
+            SH.o_am = am;
+        }
     }
     wsync();
     return r;
@@ -702,7 +705,7 @@ __device__ __attribute__((noinline)) int small_bond_rook(int M_, int N_, int max
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
         const double am = readlane_f64(mx, 0);
-        if (am > SH.msv && lane == 0) SH.msv = am;
+        if (lane == 0) SH.o_am = am;
     }
     SH.o_ptab[lane] = ptab;
     SH.o_rpos[lane] = 0;
@@ -738,8 +741,8 @@ __device__ __forceinline__ bool small_gather(int b, int r, int ptab)
 
 // One bond of a half-sweep / of the final 1-site sweep.  Returns 0, or the reason the iteration is handed back.
 template <int K>
-__device__ __forceinline__ int small_update(const int left_, const int one_, int hist_, int use_hist_, int b_, int max_bond_dim_, double rel_tol, double abs_tol,
-                                                      double* core)
+__device__ __forceinline__ int small_update(const int n, const int total, const int tile_max, const bool stamps, const bool rook, const int left_, const int one_, int hist_, int use_hist_,
+                                            int b_, int max_bond_dim_, double rel_tol, double abs_tol, double& msv, double* core)
 {
     const int lane = threadIdx.x & 63;
     // (an out-of-line function receives its arguments in vector registers: back to scalars)
@@ -748,12 +751,12 @@ __device__ __forceinline__ int small_update(const int left_, const int one_, int
     rel_tol = uniform_f64(rel_tol);
     abs_tol = uniform_f64(abs_tol);
     int M, N;
-    if (!small_lists<K>(hist, use_hist, b, one, M, N)) return 1;
-    small_stamp(0);
+    if (!small_lists<K>(n, total, tile_max, hist, use_hist, b, one, M, N)) return 1;
+    small_stamp(stamps, 0);
     int ptab, rpos, r;
-    double pvabs, error;
+    double pvabs, error, am = 0.0;
     const int tile = (M <= 8 && N <= 8) ? 0 : ((M <= 16 && N <= 16) ? 1 : 2);
-    if (!one && ui(SH.rook) != 0) {
+    if (!one && rook) {
         r = ui(small_bond_rook<K>(M, N, max_bond_dim, rel_tol, abs_tol));
         if (r == -2) return 5;
         if (r == -3) return 3;
@@ -761,9 +764,10 @@ __device__ __forceinline__ int small_update(const int left_, const int one_, int
         rpos = 0;
         pvabs = SH.o_pvabs[lane];
         error = uniform_f64(SH.o_error);
+        am = uniform_f64(SH.o_am);
     } else if (tile == 0) {
-        if (left) r = small_bond<K, 1, true>(one, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
-        else r = small_bond<K, 1, false>(one, M, N, max_bond_dim, rel_tol, abs_tol, ptab, pvabs, error, rpos);
+        if (left) r = small_bond<K, 1, true>(stamps, one, M, N, max_bond_dim, rel_tol, abs_tol, am, ptab, pvabs, error, rpos);
+        else r = small_bond<K, 1, false>(stamps, one, M, N, max_bond_dim, rel_tol, abs_tol, am, ptab, pvabs, error, rpos);
     } else {
         if (tile == 1) r = left ? small_bond_big<K, 4, true>(one, M, N, max_bond_dim, rel_tol, abs_tol) : small_bond_big<K, 4, false>(one, M, N, max_bond_dim, rel_tol, abs_tol);
         else r = left ? small_bond_big<K, 16, true>(one, M, N, max_bond_dim, rel_tol, abs_tol) : small_bond_big<K, 16, false>(one, M, N, max_bond_dim, rel_tol, abs_tol);
@@ -772,13 +776,15 @@ __device__ __forceinline__ int small_update(const int left_, const int one_, int
         rpos = SH.o_rpos[lane];
         pvabs = SH.o_pvabs[lane];
         error = uniform_f64(SH.o_error);
+        am = uniform_f64(SH.o_am);
     }
     if (r < 0) return 2;
-    small_stamp(2);
+    if (am > msv) msv = am; // update_max_sample_value (tensorci2.rs:2009-2014)
+    small_stamp(stamps, 2);
     const int L_b = b == 0 ? 1 : ui(SH.tab[0].cnt[b]); // (before the gather: I_b is not touched by bond b)
     if (!small_gather<K>(b, r, ptab)) return 3;
     if (lane == 0) SH.bond[b] = error; // (pivot_errors.back(), tensorci2.rs:1942-1949 / :1998)
-    small_stamp(3);
+    small_stamp(stamps, 3);
     if (!one) {
         if (lane == 0) {
             SH.shapes[3 * b] = M;
@@ -830,7 +836,7 @@ __device__ __forceinline__ int small_update(const int left_, const int one_, int
         SH.cdims[3 * b + 2] = R;
     }
     wsync();
-    small_stamp(4);
+    small_stamp(stamps, 4);
     return 0;
 }
 
@@ -1112,7 +1118,6 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
             SH.n = n;
             SH.total = total;
             SH.n_pe = 0;
-            SH.msv = hd->max_sample_value;
             SH.stamps = (flags & 8) ? 1 : 0;
             SH.rook = (flags & 16) ? 1 : 0;
             SH.rook_bonds = 0;
@@ -1136,6 +1141,9 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
     const bool normalize = flags & 1, strictly_nested = flags & 2, final_sweep = flags & 4;
     double* const* const cores = reinterpret_cast<double* const*>(a.in + hd->o_cores);
     int reason = 0;
+    const bool stamps = (flags & 8) != 0, rook = (flags & 16) != 0;
+    double msv = hd->max_sample_value;
+    const int tile_max = ui(hd->tile_max);
 
     int iters_done = 0, converged = 0, termination = 2 /* MaxIterations */, final_done = 0, status = 1;
     int jobs = 0; // fill jobs published
@@ -1148,7 +1156,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
             final_phase = true;
         }
         const int iter = iters_done;
-        const double msv0 = uniform_f64(SH.msv);
+        const double msv0 = msv;
         const double norm = (normalize && msv0 > 0.0) ? msv0 : 1.0;
         bool forward = true;
         if (!final_phase) {
@@ -1160,7 +1168,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
         const bool use_hist = !final_phase && !strictly_nested && iter > 0;
         const int hist = 1 + (iter + 1) % 2; // (slot of iteration iter - 1)
         const int snap = 1 + iter % 2;
-        small_stamp(7);
+        small_stamp(stamps, 7);
         // this slot holds the sets at the start of iteration iter - 2, which fill job iter - 2 read
         if (iter >= 3) small_wait_jobs(iter - 2);
         small_copy_tab<K>(snap, 0);
@@ -1170,7 +1178,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
             jobs = iter;
             if (lane == 0) lds_store_release(&SH.job, jobs);
         }
-        small_stamp(6);
+        small_stamp(stamps, 6);
         const double rel_tol = final_phase ? 1e-14 : tolerance, abs_tol = final_phase ? tolerance * norm : 0.0;
         if (final_phase) {
             if (lane == 0) SH.n_pe = 0; // flush_pivot_errors (:900)
@@ -1181,15 +1189,15 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
         int why = 0;
         for (int step = 0; step + 1 < n && why == 0; ++step) {
             const int b = forward ? step : n - 2 - step;
-            why = ui(small_update<K>(forward ? 1 : 0, final_phase ? 1 : 0, hist, use_hist ? 1 : 0, b, max_bond_dim, rel_tol, abs_tol, cores[b]));
+            why = ui(small_update<K>(n, total, tile_max, stamps, rook, forward ? 1 : 0, final_phase ? 1 : 0, hist, use_hist ? 1 : 0, b, max_bond_dim, rel_tol, abs_tol, msv, cores[b]));
         }
         if (why == 0 && final_phase) { // fill_tensor(I_last, J_last) (:1040-1043)
             if (!ui(small_fill_site<K>(0, 0, n - 1, cores[n - 1], 1))) why = 4;
-            small_stamp(5);
+            small_stamp(stamps, 5);
         }
         if (why != 0) { // hand the state at the start of this pass back
             small_copy_tab<K>(0, snap);
-            if (lane == 0) SH.msv = msv0;
+            msv = msv0;
             reason = why;
             status = 2;
             break;
@@ -1244,7 +1252,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
     if (lane == 0) lds_store_release(&SH.quit, 1);
     const unsigned long long t_iters = small_clock();
     small_wait_jobs(jobs);
-    small_stamp(5);
+    small_stamp(stamps, 5);
     {   // a site that could not be filled (singular pivot matrix, shapes beyond the workspace): the whole call goes to the general
         // path, which reports what the reference reports
         int any_fail = 0;
@@ -1289,7 +1297,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) small_optimize_kernel(SmallA
             oh->final_done = final_done;
             oh->hist_valid = hist_slot >= 0 ? 1 : 0;
             oh->reason = reason;
-            oh->max_sample_value = SH.msv;
+            oh->max_sample_value = msv;
             oh->clocks[0] = t_loaded - t_begin;
             oh->clocks[1] = t_iters - t_loaded;
             oh->clocks[2] = small_clock() - t_iters;

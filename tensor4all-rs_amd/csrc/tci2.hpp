@@ -106,6 +106,10 @@ public:
     // [0] optimize calls it completed [1] iterations it ran [2] runs it handed back to the general path [3] calls that were not eligible
     std::array<uint64_t, 4> small_stats{{0, 0, 0, 0}};
     uint64_t small_last_clocks_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // last launch (SmallOutHeader::clocks)
+    // candidate matrices up to this many rows / columns stay in the launch.  Default 16: measured (profiles/r06_small_engine_reach.txt), the
+    // 32 x 32 tile (sixteen entries per lane) is slower than the general path — a rank-8 run completes in 2.1 ms inside the launch against
+    // 1.64 ms outside — so runs that grow past rank ~5 are handed over early; t4a_gpu_tci2_set_chain bit 5 selects 32.
+    int small_tile_max = 16;
     bool small_stamps = false; // the launch stamps its phases (diagnostic: t4a_gpu_tci2_set_chain bit 3)
     int small_last_reason_ = 0;
     bool small_engine_eligible(const TCI2Options& options) const;

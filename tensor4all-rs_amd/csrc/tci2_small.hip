@@ -68,6 +68,7 @@ bool Tci2::small_engine_run(OptRun& r)
     h.flags = (options.normalize_error ? 1 : 0) | (options.strictly_nested ? 2 : 0) | (r.final_sweep1site ? 4 : 0) | (small_stamps ? 8 : 0) | (options.pivot_search == 1 ? 16 : 0);
     h.max_bond_dim = (int)std::min<size_t>(options.max_bond_dim_or_max(), (size_t)1 << 30);
     h.cap_in = (int)cap_in;
+    h.tile_max = small_tile_max;
     h.tolerance = options.tolerance;
     h.max_sample_value = max_sample_value;
     std::memcpy(h.params, fn_dev_.params, sizeof(h.params));

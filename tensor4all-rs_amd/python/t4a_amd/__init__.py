@@ -788,13 +788,13 @@ class TensorCI2:
         return [dict(code=int(r[0]), ms=float(r[1]), launches=float(r[2]), bytes=float(r[3]), steps=float(r[4])) for r in out[: n.value]]
 
 
-    def set_chain(self, enable=True, verify=False, event_timing=False, small_engine=True, small_stamps=False, fill_graph_relaxed=False):
+    def set_chain(self, enable=True, verify=False, event_timing=False, small_engine=True, small_stamps=False, fill_graph_relaxed=False, small_tile32=False):
         """Device-side bond chain on / off for this handle; verify: read the device tables back after every chain; event_timing:
         while profiling, time the rrLU launches with HIP events instead of the kernels' own time stamps; small_engine=False: the
         one-launch engine for small problems is not offered the handle's optimize calls."""
         _check(_lib.t4a_gpu_tci2_set_chain(self._h, c_int32(1 if enable else 0),
                                            c_int32((1 if verify else 0) | (2 if event_timing else 0) | (0 if small_engine else 4) | (8 if small_stamps else 0)
-                                                   | (16 if fill_graph_relaxed else 0))))
+                                                   | (16 if fill_graph_relaxed else 0) | (32 if small_tile32 else 0))))
 
     def set_callback_threads(self, n):
         """Opt-in: evaluate one candidate matrix through the host callback on n host threads at once (thread-safe NATIVE callbacks only;
