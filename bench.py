@@ -662,9 +662,9 @@ def rrlu_kernel_name(code):
     if code >= 200000:  # one-workgroup kernel (kernels_rrlu_wg.hip): rows per lane, columns per wave
         c = code - 200000
         return "t4a::(anonymous namespace)::rrlu_wg_kernel<%d, %d, %s>" % (c // 1000, (c % 1000) // 10, "true" if (c % 10) & 4 else "false")
-    if code >= 100000:  # single-XCD kernel: second generation unless T4A_XCD_V=1
+    if code >= 100000:  # single-XCD kernel (second generation; the first was retired in round 6)
         c = code - 100000
-        gen = "rrlu_xcd_kernel" if os.environ.get("T4A_XCD_V") == "1" else "rrlu_xcd2_kernel"
+        gen = "rrlu_xcd2_kernel"
         return "t4a::%s<%d, %d, %s>" % (gen, c // 100, (c % 100) // 10, "true" if (c % 10) & 4 else "false")
     if code >= 0:
         return "t4a::rrlu_reg_kernel<%d, %d, %s, %s, %s>" % (code // 1000, (code % 1000) // 10, "true" if (code % 10) & 2 else "false",

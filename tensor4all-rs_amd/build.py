@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "kernels_rrlu_xcd.hip", "kernels_rrlu_xcd_group.hip", "kernels_rrlu_xcd2.hip", "kernels_rrlu_xcd2_group.hip", "kernels_rrlu_xcd2m.hip", "kernels_rrlu_wg.hip", "kernels_rrlu_wg_group.hip", "kernels_rrlu_w1.hip", "kernels_rrlu_global.hip", "kernels_pi.hip", "kernels_chain.hip", "kernels_small.hip", "kernels_dense.hip", "kernels_linalg.hip",
+SOURCES = ["kernels_rrlu.hip", "kernels_rrlu_reg.hip", "rrlu_xcd_plan.hip", "kernels_rrlu_xcd2.hip", "kernels_rrlu_xcd2_group.hip", "kernels_rrlu_xcd2m.hip", "kernels_rrlu_wg.hip", "kernels_rrlu_wg_group.hip", "kernels_rrlu_w1.hip", "kernels_rrlu_global.hip", "kernels_pi.hip", "kernels_chain.hip", "kernels_small.hip", "kernels_dense.hip", "kernels_linalg.hip",
            "kernels_tt.hip", "pool.hip", "engine.hip", "rook.hip", "tt.hip", "globalsearch.hip", "tci2.hip", "tci2_chain.hip", "tci2_small.hip", "conversion.hip", "patching.hip", "tree.hip", "quantics.hip", "tensorops.hip", "aci.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"] + os.environ.get("T4A_EXTRA_FLAGS", "").split()  # e.g. -DT4A_RRLU_TRACE (tools/trace_arrivals.py)

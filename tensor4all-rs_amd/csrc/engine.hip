@@ -56,26 +56,20 @@ void xcd_disable()
                              "timed out); the chip-wide kernels take over\n");
 }
 
-// Generation of the single-XCD kernel: 2 (kernels_rrlu_xcd2.hip) unless T4A_XCD_V=1 (A/B measurements).  A launch of the second
-// generation that meets non-finite values gives up with code 2; the caller then runs the first generation for that matrix.
-int xcd_version()
-{
-    static const int v = std::getenv("T4A_XCD_V") ? std::atoi(std::getenv("T4A_XCD_V")) : 2;
-    return v == 1 ? 1 : 2;
-}
+// The single-XCD kernel is kernels_rrlu_xcd2.hip (the first generation was retired in round 6).  A launch that meets non-finite values
+// gives up with code 2; the caller then runs the chip-wide kernels for that matrix (they implement the NaN-incumbent rule).
+int xcd_version() { return 2; }
 void rrlu_xcd_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream)
 {
     if (plan.wg == 2) rrlu_w1_launch(plan, args, stream);
     else if (plan.wg) rrlu_wg_launch(plan, args, stream);
     else if (plan.big()) rrlu_xcd2m_launch(plan, args, stream); // (second generation only: rrlu_xcd_make_plan hands such plans out with allow_big)
-    else if (version == 1) rrlu_xcd_launch(plan, args, stream);
     else rrlu_xcd2_launch(plan, args, stream);
 }
 void rrlu_xcd_group_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream)
 {
     if (plan.wg == 2) rrlu_w1_group_launch(plan, args, tie_row_major, stream);
     else if (plan.wg) rrlu_wg_group_launch(plan, args, tie_row_major, stream);
-    else if (version == 1) rrlu_xcd_group_launch(plan, args, tie_row_major, stream);
     else rrlu_xcd2_group_launch(plan, args, tie_row_major, stream);
 }
 
@@ -297,14 +291,16 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     RrluXcdPlan xplan;
     static const bool force_reg = std::getenv("T4A_RRLU_IMPL") != nullptr && std::string(std::getenv("T4A_RRLU_IMPL")) == "reg";
     // first choice: all workgroups on one XCD (exchange through that XCD's L2); disabled for good once a launch timed out
-    const int xcd_v = xcd_retry_v1_ ? 1 : xcd_version();
+    // (a retry after non-finite values: none of the register kernels of this family — they hand such matrices back — but the chip-wide
+    // register / LDS / global kernels below, which implement the NaN-incumbent rule)
+    const int xcd_v = xcd_version();
     // matrices that fit one workgroup: the LDS-exchange kernel (not on a retry after non-finite values: it does not handle them)
     static const long wg_min = std::getenv("T4A_WG_MIN") ? std::atol(std::getenv("T4A_WG_MIN")) : 64;
     const bool use_wg = !huge && !force_lds && !force_global && !force_reg && !xcd_retry_v1_ && (long)kM * kN > wg_min &&
                         (rrlu_w1_make_plan(kM, kN, &xplan, 0) || rrlu_wg_make_plan(kM, kN, &xplan, 0));
     const bool use_xcd = use_wg || (!huge && !force_lds && !force_global && !force_reg && !xcd_disabled() &&
-                         (rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, xcd_plan_max_w()) ||
-                          rrlu_xcd_make_plan(kM, kN, &xplan, xcd_retry_v1_, 32, !xcd_retry_v1_ && xcd_v == 2)));
+                         !xcd_retry_v1_ &&
+                         (rrlu_xcd_make_plan(kM, kN, &xplan, false, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &xplan, false, 32, true)));
     const bool use_reg = !use_xcd && !huge && !force_lds && !force_global && rrlu_reg_make_plan(kM, kN, num_cus_, &rplan);
     bool fuse = false;
     bool xcd_src_transposed = false;
@@ -599,13 +595,14 @@ LuciResult Engine::luci(const double* d_a, int M, int N, const RrLUOptions& opts
     if (!completed) T4A_HIP(hipStreamSynchronize(stream_));
     xcd_lock.release();
     if (use_xcd && (xcd_v == 2 || use_wg) && reinterpret_cast<const int*>(h_out_.get() + 16)[1] == 2) {
-        // the second-generation kernel met a NaN / an infinity (input or overflow): the first generation implements the
-        // NaN-incumbent rule of matrixlu.rs:480-519; every workgroup of the launch was elected normally, the tickets stay valid
+        // the kernel met a NaN / an infinity (input or overflow): the chip-wide kernels implement the NaN-incumbent rule of
+        // matrixlu.rs:480-519 (the first-generation single-XCD kernel, kept for this case until round 5, is gone); every workgroup of the
+        // launch was elected normally, the tickets stay valid
         T4A_HIP(hipMemsetAsync(d_out_.get(), 0, 32, stream_));
         header_clean_ = false;
         {
             static const bool dbg = std::getenv("T4A_CHAIN_DEBUG") != nullptr;
-            if (dbg) std::fprintf(stderr, "[t4a luci] %d x %d: the %s kernel met non-finite values, re-running with the first-generation kernel\n", M, N, use_wg ? "one-workgroup" : "single-XCD");
+            if (dbg) std::fprintf(stderr, "[t4a luci] %d x %d: the %s kernel met non-finite values, re-running with the chip-wide kernels\n", M, N, use_wg ? "one-workgroup" : "single-XCD");
         }
         xcd_retry_v1_ = true;
         try {
@@ -788,7 +785,7 @@ bool Engine::chain_plan(int kM, int kN, ChainRrluPlan* out) const
         return true;
     }
     // (shapes that only fit with more than kXcdSharedMaxW workgroups keep their plan: the launch then reserves the whole chip)
-    if (xcd_disabled() || !(rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32, xcd_version() == 2)))
+    if (xcd_disabled() || !(rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, xcd_plan_max_w()) || rrlu_xcd_make_plan(kM, kN, &pl.xcd, true, 32, true)))
         return false;
     pl.kind = 2;
     pl.code = (pl.xcd.big() ? 400000 + pl.xcd.K * 10000 : 100000) + pl.xcd.RPT * 100 + pl.xcd.CPT * 10;

@@ -49,7 +49,7 @@ struct Profile {
 // process-wide arbiter of the persistent multi-workgroup rrLU kernels (engine.hip)
 bool xcd_disabled();
 void xcd_disable();
-int xcd_version(); // generation of the single-XCD rrLU kernel in use (T4A_XCD_V)
+int xcd_version(); // generation of the single-XCD rrLU kernel (2: kernels_rrlu_xcd2.hip; the first generation was retired in round 6)
 void rrlu_xcd_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
 void rrlu_xcd_group_launch_v(int version, const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
 int xcd_assign();
@@ -178,7 +178,7 @@ private:
     unsigned rrlu_salt_ = 0;
     // single-XCD rrLU kernel: elected XCD, mailboxes, monotonic ticket counter
     int xcc_ = 0;
-    bool xcd_retry_v1_ = false; // luci(): this call re-runs a factorisation the second-generation single-XCD kernel gave up on (non-finite values)
+    bool xcd_retry_v1_ = false; // luci(): this call re-runs a factorisation a register kernel gave up on (non-finite values) on the chip-wide kernels
     unsigned xcd_salt_ = 0, xcd_ticket_base_ = 0, xcd_ticket_base_multi_ = 0;
     void xcd_take_tickets(const RrluXcdPlan& plan, RrluXcdArgs& a);
     DevBuf<unsigned long long> d_xkeys_; // mailbox of the single-XCD kernel: keys, then column slots

@@ -231,14 +231,12 @@ struct RrluXcdArgs {
 bool rrlu_xcd_make_plan(int M, int N, RrluXcdPlan* out, bool any_size = false, int max_w = 32, bool allow_big = false);
 size_t rrlu_xcd_keys_bytes(const RrluXcdPlan& plan);
 size_t rrlu_xcd_cols_bytes(const RrluXcdPlan& plan, int M);
-void rrlu_xcd_launch(const RrluXcdPlan& plan, const RrluXcdArgs& args, hipStream_t stream);
 // Eight factorisations in one launch, one per XCD (slot x is run by the workgroups that land on XCD x; a slot with xcc = -1 is
 // empty).  All slots share the plan (made for the largest upper-bound shape among them) and the tie order; every slot brings
 // its own mailbox, ticket counter and result block.  kernels_rrlu_xcd_group.hip.
 struct RrluXcdGroupArgs {
     RrluXcdArgs p[8];
 };
-void rrlu_xcd_group_launch(const RrluXcdPlan& plan, const RrluXcdGroupArgs& args, bool tie_row_major, hipStream_t stream);
 // Second generation of the same kernel (kernels_rrlu_xcd2.hip: one-word record, stop tests and tables off the critical path, no
 // hand-zeroed pivot rows): same plan, arguments and mailbox.  It handles finite matrices only: on a NaN / infinity in the input or
 // an overflow in the trailing block the launch gives up with iresult[1] == 2 and the caller runs the first generation.
