@@ -22,7 +22,8 @@ namespace t4a {
 
 bool Tci2::small_engine_eligible(const TCI2Options& options) const
 {
-    if (!small_enabled || !chain_enabled || chain_verify || chain_event_timing) return false;
+    static const bool no_chain = std::getenv("T4A_NO_CHAIN") != nullptr; // (the documented "everything bond by bond" fallback switches the engine off too)
+    if (no_chain || !small_enabled || !chain_enabled || chain_verify || chain_event_timing) return false;
     if (fn_kind_ != FnKind::Builtin || fn_dev_.n_acc > 2 || (options.pivot_search != 0 && options.pivot_search != 1)) return false;
     if (options.pivot_search == 1) {
         static const bool rook_host = std::getenv("T4A_ROOK_HOST") != nullptr; // (A/B of the search drivers: rook.hip's host-driven loop is asked for)
