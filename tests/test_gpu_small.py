@@ -261,3 +261,42 @@ def test_fuzz_engine_general_path_and_oracle_agree(t4a, seed):
     assert_identical(s, g, o, n, core_tol=1e-8 if opts["pivot_search"] else 1e-10)
     st = s.small_stats()
     assert st["completed"] + st["handed_back"] + st["not_eligible"] >= 1, st
+
+
+def test_engine_on_several_host_threads_at_once(t4a):
+    """Eight host threads, each with its own handles, run engine solves at the same time (one launch per solve, static LDS of a whole compute
+    unit per launch, pinned result blocks per handle): every result equals the single-threaded one."""
+    import threading
+    from t4a_amd.functions import quantics_trig_exp
+    n = 16
+    specs = [quantics_trig_exp(n, a=3.0 + k, b=0.5 + 0.1 * k, cc=1.0, cs=0.2 * k) for k in range(8)]
+    opts = t4a.TCI2Options(tolerance=1e-9, max_bond_dim=32, max_iter=12, **PARITY)
+
+    def solve(spec):
+        g = t4a.TensorCI2([2] * n)
+        g.set_function(spec)
+        g.crossinterpolate2([[0] * n], opts)
+        assert g.small_stats()["completed"] == 1
+        return ([np.asarray(g.i_set(p)).tobytes() + np.asarray(g.j_set(p)).tobytes() for p in range(n)], np.asarray(g.history()[1]).tobytes(),
+                [g.site_tensor(p).tobytes() for p in range(n)])
+
+    ref = [solve(s) for s in specs]
+    out, errors = {}, []
+
+    def work(k):
+        try:
+            for _ in range(25):
+                out[k] = solve(specs[k])
+                if out[k] != ref[k]:
+                    errors.append((k, "result differs"))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert all(out[k] == ref[k] for k in range(8))
