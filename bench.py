@@ -593,9 +593,11 @@ def pi_shard_mode(args, world, rank, dist, torch, t4a_amd, barrier):
     idx = np.ascontiguousarray(rng.integers(0, 2, size=(n_probe, N_SITES)), dtype=np.uint32)
     buf = np.zeros(n_probe)
     fn = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p)(cb.fn_addr)
-    t0 = time.perf_counter()
-    fn(cb.ctx_addr, idx.ctypes.data, N_SITES, n_probe, buf.ctypes.data)
-    ns_per_point = (time.perf_counter() - t0) / n_probe * 1e9
+    ns_per_point = float("inf")
+    for _ in range(3):  # (best of three: the estimate callback_ms = points x this must not exceed the wall time it is compared with)
+        t0 = time.perf_counter()
+        fn(cb.ctx_addr, idx.ctypes.data, N_SITES, n_probe, buf.ctypes.data)
+        ns_per_point = min(ns_per_point, (time.perf_counter() - t0) / n_probe * 1e9)
     for _ in range(max(args.warmup, 1)):
         tci.optimize(opts(2), final_sweep1site=False)
     tci.profile_enable(True)

@@ -79,4 +79,6 @@ def test_bench_pi_shard_mode_single_gpu():
     assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["chi_max"] == 256
     assert line["callback_ms_per_step"][0] > 0 and line["rrlu_ms_per_step"][0] > 0 and line["gather_ms_per_step"][0] == 0.0
     assert line["callback_points_per_step_all_ranks"] > 1e7
-    assert line["callback_ms_per_step"][0] < line["ms_per_step"]
+    # (callback_ms is an ESTIMATE: points x the per-point cost calibrated on a probe batch; it is most of the step, and noise of the probe
+    # may push it a few per cent past the measured wall time)
+    assert 0.5 * line["ms_per_step"] < line["callback_ms_per_step"][0] < 1.25 * line["ms_per_step"]
