@@ -1128,7 +1128,8 @@ void Engine::svd(const double* d_a, int M, int N, double* d_u, double* d_s, doub
     if (M <= 0 || N <= 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "svd: empty matrix");
     static const bool no_precond = diag_env("T4A_SVD_NO_PRECOND") != nullptr;
     const int kmin = M < N ? M : N;
-    if (no_precond || kmin < 64) {
+    // (matrices whose W and V fit one workgroup's LDS: the one-launch iteration of svd_plain, no QR in front — round 6)
+    if (no_precond || kmin < 64 || jacobi_fits_groups(M < N ? N : M, kmin)) {
         svd_plain(d_a, M, N, d_u, d_s, d_vt);
         return;
     }
@@ -1203,15 +1204,23 @@ void Engine::svd_plain(const double* d_a, int M, int N, double* d_u, double* d_s
     d_sflags_.reserve((size_t)n + 4);
     int* flags = d_sflags_.get(); // [0] rotated [1] n_dead [2] non-finite, [4..] dead[n]
     T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int) * ((size_t)n + 4), stream_));
-    nonfinite_flag_launch(d_a, (size_t)M * N, flags + 2, stream_);
+    // W and V of up to 96 columns fit one workgroup's LDS together: the whole iteration in ONE launch, sixteen lanes per column pair
+    // (jacobi_groups_kernel; a 64 x 64 call 0.65 ms, of which the kernel 0.54, against 1.39 ms through QR + blocked tournament, 1.17 ms
+    // for the blocked tournament alone and 2.23 ms for jacobi_small_kernel — profiles/r06_svd_small.txt; the kernel checks the input for
+    // Inf / NaN itself and starts V from the identity).  T4A_SVD_NO_GROUPS=1 restores the round-5 routes.
+    static const bool no_groups = diag_env("T4A_SVD_NO_GROUPS") != nullptr;
+    const bool groups = !no_groups && jacobi_fits_groups(m, n);
+    if (!groups) nonfinite_flag_launch(d_a, (size_t)M * N, flags + 2, stream_);
     double* W = d_sw_.get();
     if (flip)
         transpose_launch(d_a, M, N, M, W, N, stream_);
     else
         T4A_HIP(hipMemcpyAsync(W, d_a, sizeof(double) * (size_t)M * N, hipMemcpyDeviceToDevice, stream_));
     double* V = d_sv_.get();
-    fill_launch(V, (size_t)n * n, 0.0, stream_);
-    set_identity_launch(V, n, n, n, stream_);
+    if (!groups) {
+        fill_launch(V, (size_t)n * n, 0.0, stream_);
+        set_identity_launch(V, n, n, n, stream_);
+    }
     const int max_sweeps = 60;
     int h[4] = {0, 0, 0, 0};
     static const bool no_block = diag_env("T4A_SVD_NO_BLOCK") != nullptr;
@@ -1220,7 +1229,10 @@ void Engine::svd_plain(const double* d_a, int M, int N, double* d_u, double* d_s
     // 64 x 64 against 3.7: profiles/r04_linalg_probe.txt).  T4A_SVD_SMALL_N moves the boundary, T4A_SVD_NO_BLOCK=1 restores the
     // round-3 behaviour (one launch up to 128 columns, launch-per-round beyond).
     static const int small_n = diag_env("T4A_SVD_SMALL_N") ? std::atoi(diag_env("T4A_SVD_SMALL_N")) : 16;
-    if (jacobi_fits_small(m, n) && (no_block || n <= small_n)) {
+    if (groups) {
+        if (!jacobi_groups_launch(W, m, V, n, max_sweeps, flags + 2, stream_))
+            throw Error(T4A_GPU_INTERNAL_ERROR, "svd: jacobi_fits_groups and jacobi_groups_launch disagree");
+    } else if (jacobi_fits_small(m, n) && (no_block || n <= small_n)) {
         jacobi_small_launch(W, m, V, n, max_sweeps, stream_);
     } else {
         // sweeps in batches of two: the kernels of a sweep behind a converged one return at once (flags[3], jacobi_sweep_end_kernel), the
@@ -1250,6 +1262,10 @@ void Engine::svd_plain(const double* d_a, int M, int N, double* d_u, double* d_s
     T4A_HIP(hipMemcpyAsync(h, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
     T4A_HIP(hipStreamSynchronize(stream_));
     if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
+    if (groups) {
+        static const bool dbg = std::getenv("T4A_SVD_DEBUG") != nullptr;
+        if (dbg) std::fprintf(stderr, "[t4a svd] %d x %d: one launch, converged within %d sweeps\n", m, n, h[3]);
+    }
     if (h[1] > 0) svd_complete_launch(Ubig, m, n, flags + 4, d_ssig_.get() + n, stream_);
     if (flip)
         transpose_launch(Ubig, m, n, m, d_vt, n, stream_); // Vt (M x N) = U'^T, U' is N x M

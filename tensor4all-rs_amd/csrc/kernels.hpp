@@ -583,6 +583,10 @@ void nonfinite_flag_launch(const double* data, size_t count, int* d_flag, hipStr
 bool jacobi_fits_small(int m, int n);
 // all sweeps inside one workgroup (m >= n, n <= 128)
 void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream);
+// all sweeps inside one workgroup, a group of 8 or 16 lanes per column pair, W and V in the LDS (m >= n, n <= 96; see jg_plan);
+// V is an output only, d_nonfinite[0] is set for an Inf / NaN input, d_nonfinite[1] receives the sweep count
+bool jacobi_fits_groups(int m, int n);
+bool jacobi_groups_launch(double* W, int m, double* V, int n, int max_sweeps, int* d_nonfinite, hipStream_t stream);
 // one full sweep = n-1 tournament rounds, one launch per round; *d_rotated is set when any pair rotated
 void jacobi_sweep_launch(double* W, int m, double* V, int n, int* d_rotated, hipStream_t stream);
 void jacobi_sweep_end_launch(int* d_flags, hipStream_t stream); // flags [0] rotated [3] converged (kernels_linalg.hip)

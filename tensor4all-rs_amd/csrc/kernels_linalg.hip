@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include <atomic>
 #include <cstdlib>
@@ -205,6 +206,197 @@ __global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, int m, d
     if (use_lds) {
         for (int e = tid; e < m * n; e += T) Wg[e] = W[e];
         for (int e = tid; e < n * n; e += T) Vg[e] = V[e];
+    }
+}
+
+// Sum over an aligned group of G = 8 or 16 lanes (DPP inside a row of 16, no readlane): every lane of the group ends with bitwise the same
+// total (the two operands of every addition are the same pair of partial sums in every lane, in either order).
+template <int G> __device__ inline double group_sum(double v)
+{
+    v += dpp_mov_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v); // row_half_mirror: the sum of 8 lanes
+    if (G == 16) v += dpp_mov_f64<0x140>(v); // row_mirror
+    return v;
+}
+
+// jacobi_rotation with the divisions and square roots replaced by the hardware reciprocal / reciprocal-square-root estimates and Newton
+// steps (the rotation arithmetic is the longest dependent chain of a round of jacobi_groups_kernel).  The ANGLE (zeta, t) is computed to
+// ~2^-46: an error there leaves a residual inner product of that relative size, which the next sweep removes; the COSINE keeps both
+// Newton steps (c^2 + s^2 = 1 to rounding: every rotation stays orthogonal).  Out-of-range intermediates (|zeta| > 1e154, subnormal
+// gamma) surface as a NaN and mean "no rotation", as the threshold test does for an overflowing alpha * beta.
+__device__ inline Rot jacobi_rotation_fast(double alpha, double beta, double gamma, double tol)
+{
+    Rot r;
+    r.c = 1.0;
+    r.s = 0.0;
+    r.apply = 0;
+    if (gamma == 0.0) return r;
+    const double ab = alpha * beta;
+    const double sq = ab == 0.0 ? 0.0 : ab * __builtin_amdgcn_rsq(ab); // sqrt(alpha beta) to 2^-23: a threshold
+    if (!(fabs(gamma) > tol * sq)) return r;
+    const double den = 2.0 * gamma;
+    double rd = __builtin_amdgcn_rcp(den);
+    rd = rd * (2.0 - den * rd);
+    const double zeta = (beta - alpha) * rd;
+    const double x = 1.0 + zeta * zeta;
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    const double d2 = fabs(zeta) + x * y; // |zeta| + sqrt(1 + zeta^2) >= 1
+    double rt = __builtin_amdgcn_rcp(d2);
+    rt = rt * (2.0 - d2 * rt);
+    const double t = zeta >= 0.0 ? rt : -rt;
+    const double x2 = 1.0 + t * t;
+    double c = __builtin_amdgcn_rsq(x2);
+    c = c * (1.5 - 0.5 * x2 * c * c);
+    c = c * (1.5 - 0.5 * x2 * c * c);
+    const double sn = c * t;
+    if (!(c == c) || !(sn == sn)) return r;
+    r.c = c;
+    r.s = sn;
+    r.apply = 1;
+    return r;
+}
+
+// Whole Jacobi iteration inside one workgroup, a GROUP OF G = 16 LANES per column pair (round 6; matrices up to 96 columns whose W and V
+// fit the LDS together).  jacobi_small_kernel gives a pair a whole wave: three 64-lane sums with readlanes and the scalar rotation
+// arithmetic replicated over 64 lanes made a round of a 64 x 64 matrix 3.3 us (2.2 ms per decomposition, slower than the blocked
+// tournament's 1.2 ms).  Here a wave carries four pairs: a lane owns the rows sub, sub + 16, ... of its pair's two columns (MR of W, VR
+// of V, in registers from the dot products to the rotation: one LDS round trip per round), the three dot products are 16-lane DPP sums and
+// the rotation arithmetic is executed once per wave.  Measured (profiles/r06_svd_small.txt): 0.85 us per round at 64 x 64 (10 sweeps of 63
+// rounds in 536 us), 0.72 us with one wave per SIMD (32 columns).  A model that fits, not a measurement: every round reads and writes
+// all of W and V — 2 * 8 * (m + n) * n bytes, 128 KB at 64 x 64, >= 1000 cycles of a compute unit's 128 B / clock LDS port before bank
+// conflicts — and issues ~200 instructions per wave on two waves per SIMD (~1600 cycles); both are of the order of the measured round.
+// Eight lanes per pair (half the waves, 1.7 x fewer instructions per round) measured SLOWER at every size (64 x 64: 776 against 727 us
+// per call): G stays a parameter, only 16 is instantiated.
+// V starts as the identity in the LDS (never read from memory); a non-finite input sets *nonfinite and leaves W untouched.
+// LDS: double W[np][ldw], double V[np][ldv]: the launcher picks the instantiation whose column lengths cover m and n, the padding rows
+// are zero and stay zero under rotations, so no loop carries a bound.
+// LDS stride of a column of `rows` rows in jacobi_groups_kernel<16, MR, VR> (see there); the two largest instantiations fill the LDS
+// without the extra rows.
+__host__ __device__ constexpr int jg_stride(int rows, int MR, int VR)
+{
+    return rows + ((rows % 32 == 0 && !(MR == 14 && VR == 4) && !(MR == 6 && VR == 6)) ? 16 : 0);
+}
+
+template <int G, int MR, int VR>
+__global__ void __launch_bounds__(768) jacobi_groups_kernel(double* Wg, int m, double* Vg, int n, int np, int max_sweeps, int* nonfinite)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int s_rot[3];
+    __shared__ int s_bad;
+    // a column's stride in the LDS: G MR (G VR) rows, m <= G MR, n <= G VR, the padding is zero; a stride that is a multiple of 32 doubles
+    // would start every column on bank 0 (the four groups of a wave read four columns at once), so such strides get 16 more where the LDS
+    // has the room (jg_stride)
+    constexpr int ldw = jg_stride(G * MR, MR, VR), ldv = jg_stride(G * VR, MR, VR);
+    double* W = (double*)smem_raw;
+    double* V = W + (size_t)np * ldw;
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (tid == 0) {
+        s_rot[0] = s_rot[1] = s_rot[2] = 0;
+        s_bad = 0;
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int e = tid; e < np * ldw; e += T) {
+        const int c = e / ldw, r = e - c * ldw;
+        double x = 0.0;
+        if (c < n && r < m) {
+            x = Wg[(size_t)c * m + r];
+            if (!(fabs(x) <= 1.79769313486231570e308)) bad = 1;
+        }
+        W[e] = x;
+    }
+    for (int e = tid; e < np * ldv; e += T) {
+        const int c = e / ldv, r = e - c * ldv;
+        V[e] = (c == r && c < n) ? 1.0 : 0.0;
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) *nonfinite = 1;
+        return;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int PW = 64 / G;              // pairs per wave
+    const int sub = lane & (G - 1);
+    const int k = wave * PW + lane / G;      // the pair slot of this group of lanes
+    const int q = np - 1;
+    const bool slot = k < np / 2;
+    const double tol = jacobi_tol(m);
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        // three flags in rotation: sweep s sets [s % 3], reads it behind its last barrier, and clears [(s + 1) % 3] for the next sweep
+        // (a thread still reading [s % 3] can be overtaken by the next sweep's first round, never by the sweep after that)
+        if (tid == 0) s_rot[(sweep + 1) % 3] = 0;
+        int* rotated = &s_rot[sweep % 3];
+        for (int round = 0; round < q; ++round) {
+            // circle method (rr_pair) without the divisions: round < q and k < q
+            int x, y;
+            if (k == 0) {
+                x = q;
+                y = round;
+            } else {
+                x = round + k;
+                if (x >= q) x -= q;
+                y = round - k;
+                if (y < 0) y += q;
+            }
+            const int i = x < y ? x : y, j = x < y ? y : x;
+            if (slot && j < n) {
+                double* wi = W + (size_t)i * ldw + sub;
+                double* wj = W + (size_t)j * ldw + sub;
+                double* vi = V + (size_t)i * ldv + sub;
+                double* vj = V + (size_t)j * ldv + sub;
+                double xv[MR], yv[MR], vx[VR], vy[VR];
+#pragma unroll
+                for (int t = 0; t < MR; ++t) {
+                    xv[t] = wi[G * t];
+                    yv[t] = wj[G * t];
+                }
+#pragma unroll
+                for (int t = 0; t < VR; ++t) {
+                    vx[t] = vi[G * t];
+                    vy[t] = vj[G * t];
+                }
+                double a = 0.0, b = 0.0, g = 0.0;
+#pragma unroll
+                for (int t = 0; t < MR; ++t) {
+                    a += xv[t] * xv[t];
+                    b += yv[t] * yv[t];
+                    g += xv[t] * yv[t];
+                }
+                a = group_sum<G>(a);
+                b = group_sum<G>(b);
+                g = group_sum<G>(g);
+                const Rot rot = jacobi_rotation_fast(a, b, g, tol);
+                if (rot.apply) {
+                    if (sub == 0) *rotated = 1;
+#pragma unroll
+                    for (int t = 0; t < MR; ++t) {
+                        wi[G * t] = rot.c * xv[t] - rot.s * yv[t];
+                        wj[G * t] = rot.s * xv[t] + rot.c * yv[t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < VR; ++t) {
+                        vi[G * t] = rot.c * vx[t] - rot.s * vy[t];
+                        vj[G * t] = rot.s * vx[t] + rot.c * vy[t];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (!*rotated) {
+            if (tid == 0) nonfinite[1] = sweep + 1; // (flags[3]: the sweep count, for T4A_SVD_DEBUG)
+            break;
+        }
+    }
+    for (int e = tid; e < n * m; e += T) {
+        const int c = e / m, r = e - c * m;
+        Wg[e] = W[(size_t)c * ldw + r];
+    }
+    for (int e = tid; e < n * n; e += T) {
+        const int c = e / n, r = e - c * n;
+        Vg[e] = V[(size_t)c * ldv + r];
     }
 }
 
@@ -943,6 +1135,62 @@ void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hip
     if (T > 1024) T = 1024;
     hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(T), use_lds ? bytes : 0, stream, W, m, V, n, np, max_sweeps,
                        use_lds);
+}
+
+// One workgroup, sixteen lanes per column pair (jacobi_groups_kernel): W (m x n, m >= n) and V together in the LDS.
+// The instantiation <16, MR, VR> for a shape: V columns of 32 rows for n <= 32, of 64 for n <= 64, of 96 for n <= 96; W columns of
+// 32 / 64 / 128 / 224 rows (n <= 64) or 96 rows (n <= 96: all the LDS holds).
+namespace {
+struct JgPlan {
+    int MR, VR;
+};
+bool jg_plan(int m, int n, JgPlan* p)
+{
+    if (n < 2 || m < n) return false;
+    if (n <= 32) {
+        *p = JgPlan{m <= 32 ? 2 : (m <= 64 ? 4 : (m <= 128 ? 8 : 14)), 2};
+        return m <= 224;
+    }
+    if (n <= 64) {
+        *p = JgPlan{m <= 64 ? 4 : (m <= 128 ? 8 : 14), 4};
+        return m <= 224;
+    }
+    *p = JgPlan{6, 6};
+    return n <= 96 && m <= 96;
+}
+} // namespace
+bool jacobi_fits_groups(int m, int n)
+{
+    JgPlan p;
+    return jg_plan(m, n, &p);
+}
+
+// V is an OUTPUT only (the kernel starts from the identity); *d_nonfinite is set (and W left as it was) when W holds an Inf or a NaN;
+// d_nonfinite[1] receives the number of sweeps.  false: the shape has no instantiation (jacobi_fits_groups), nothing was launched.
+bool jacobi_groups_launch(double* W, int m, double* V, int n, int max_sweeps, int* d_nonfinite, hipStream_t stream)
+{
+    JgPlan p;
+    if (!jg_plan(m, n, &p)) return false;
+    const int np = n + (n & 1);
+    const int waves = (np / 2 + 3) / 4;
+    const size_t lds = (size_t)np * (jg_stride(16 * p.MR, p.MR, p.VR) + jg_stride(16 * p.VR, p.MR, p.VR)) * 8; // <= 147 KB by construction
+    auto go = [&](auto kern) {
+        // (idempotent, a few hundred nanoseconds: set on every launch rather than once per instantiation and process)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), lds, stream, W, m, V, n, np, max_sweeps, d_nonfinite);
+    };
+    switch (p.VR * 100 + p.MR) {
+    case 202: go(&jacobi_groups_kernel<16, 2, 2>); break;
+    case 204: go(&jacobi_groups_kernel<16, 4, 2>); break;
+    case 208: go(&jacobi_groups_kernel<16, 8, 2>); break;
+    case 214: go(&jacobi_groups_kernel<16, 14, 2>); break;
+    case 404: go(&jacobi_groups_kernel<16, 4, 4>); break;
+    case 408: go(&jacobi_groups_kernel<16, 8, 4>); break;
+    case 414: go(&jacobi_groups_kernel<16, 14, 4>); break;
+    case 606: go(&jacobi_groups_kernel<16, 6, 6>); break;
+    default: return false;
+    }
+    return true;
 }
 
 // flags: [0] a pair rotated in the running sweep [3] converged.  Behind every sweep: a sweep without a rotation sets [3] — every kernel of a

@@ -539,6 +539,52 @@ def test_svd_and_qr_are_deterministic(t4a):
         assert np.array_equal(q1, q2) and np.array_equal(r1, r2)
 
 
+@pytest.mark.parametrize("shape", [(2, 2), (32, 32), (33, 33), (64, 32), (65, 32), (128, 31), (129, 17), (224, 32), (225, 32),   # V columns of 32
+                                   (64, 64), (64, 33), (65, 64), (128, 64), (129, 63), (224, 64), (225, 64), (48, 200),              # V columns of 64
+                                   (65, 65), (96, 96), (96, 65), (97, 96), (97, 65), (90, 81), (81, 90)])                            # 96 / beyond
+def test_svd_one_launch_route_instantiations_and_their_edges(t4a, shape):
+    """Round 6: matrices of up to 96 columns whose W and V fit one workgroup's LDS run the whole Jacobi iteration in one launch, sixteen
+    lanes per column pair (jacobi_groups_kernel, eight instantiations by column length: V of 32 / 64 / 96 rows, W of 32 / 64 / 128 / 224
+    / 96 rows), without the QR preconditioner.  Every instantiation, the shapes on both sides of every limit (225 rows, 97 rows next to
+    more than 64 columns: the blocked tournament takes over), both orientations; a random matrix, a spectrum graded over twelve decades,
+    exact rank deficiency (zero column, zero row, repeated column), the zero matrix, a non-finite entry; bitwise repeatability.
+    svd_backend, tensor4all-tensorbackend/src/backend.rs:709-731; reconstruction tolerance of the reference's tests 1e-10
+    (backend/tests/mod.rs:58-110)."""
+    rng = np.random.default_rng(shape[0] * 977 + shape[1])
+    m, n = shape
+    k = min(m, n)
+    q1, _ = np.linalg.qr(rng.standard_normal((m, k)))
+    q2, _ = np.linalg.qr(rng.standard_normal((n, k)))
+    graded = (q1 * np.logspace(0, -12, k)) @ q2.T
+    low = rng.standard_normal((m, max(1, k // 3))) @ rng.standard_normal((max(1, k // 3), n))
+    low[:, 0] = 0.0
+    low[m - 1, :] = 0.0
+    if n > 2:
+        low[:, n - 1] = low[:, 1]
+    for a in (rng.standard_normal((m, n)), graded, low):
+        u, s, vt = t4a.svd_backend(a)
+        sref = np.linalg.svd(a, compute_uv=False)
+        assert u.shape == (m, k) and s.shape == (k,) and vt.shape == (k, n)
+        assert np.abs(s - sref).max() <= 1e-12 * sref[0]
+        assert np.all(s >= 0.0) and np.all(np.diff(s) <= 1e-13 * s[0])
+        assert np.abs((u * s) @ vt - a).max() <= 1e-12 * sref[0] * k
+        assert np.abs(u.T @ u - np.eye(k)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(k)).max() < 1e-10
+        u2, s2, vt2 = t4a.svd_backend(a)
+        assert np.array_equal(u, u2) and np.array_equal(s, s2) and np.array_equal(vt, vt2)
+    u, s, vt = t4a.svd_backend(np.zeros((m, n)))
+    assert np.all(s == 0.0)
+    assert np.abs(u.T @ u - np.eye(k)).max() < 1e-12 and np.abs(vt @ vt.T - np.eye(k)).max() < 1e-12
+    for bad_value in (np.nan, np.inf, -np.inf):
+        bad = rng.standard_normal((m, n))
+        bad[m - 1, n // 2] = bad_value
+        with pytest.raises(t4a.T4aError) as e:
+            t4a.svd_backend(bad)
+        assert e.value.code == t4a.INVALID_ARGUMENT
+    # (the handle is usable after the error)
+    u, s, vt = t4a.svd_backend(np.eye(m, n))
+    assert np.abs(s - 1.0).max() < 1e-15
+
+
 @pytest.mark.parametrize("shape", [(200, 100), (100, 200), (128, 128)])
 def test_preconditioned_svd_on_rank_deficient_and_graded_inputs(t4a, shape):
     """Engine::svd runs the Jacobi iteration on L = R^T of a Householder QR from 64 columns on (round 5): exact rank deficiency (zero
