@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -1126,25 +1127,55 @@ void Engine::lu_permuted_factors(const LuciResult& r, bool left_orth)
 void Engine::svd(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt)
 {
     if (M <= 0 || N <= 0) throw Error(T4A_GPU_INVALID_ARGUMENT, "svd: empty matrix");
+    const int kmin = M < N ? M : N, kmax = M < N ? N : M;
+    static const bool no_groups = diag_env("T4A_SVD_NO_GROUPS") != nullptr;
+    if (!no_groups && jacobi_fits_groups(kmax, kmin)) { // one launch: the kernel checks and scales its input itself (svd_plain)
+        svd_plain(d_a, M, N, d_u, d_s, d_vt);
+        return;
+    }
+    // One pass over the input: Inf / NaN (the reference's error, before a QR turns it into something else) and the largest magnitude.
+    // The pair test of the Jacobi rotations forms alpha * beta (two squared column norms): from |a| ~ 1e77 on it overflowed, no pair
+    // rotated and the factors came back non-orthogonal WITHOUT an error (tools/soak_svd_small.py, round 6; the Householder norms of the
+    // QR in front overflow from 1e154 on).  As LAPACK does, a matrix whose largest entry is outside 2^-200 .. 2^200 is decomposed as
+    // 2^e (A 2^-e): the scaling is exact, U and V are those of A, the singular values are scaled back.  Matrices in the usual range
+    // take the same path as before, bit for bit.
+    d_sflags_.reserve((size_t)kmin + 8);
+    d_sabs_.reserve(1);
+    int* flags = d_sflags_.get();
+    T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, stream_));
+    T4A_HIP(hipMemsetAsync(d_sabs_.get(), 0, sizeof(unsigned long long), stream_));
+    nonfinite_absmax_launch(d_a, (size_t)M * N, flags + 2, d_sabs_.get(), stream_);
+    int h[4] = {0, 0, 0, 0};
+    unsigned long long bits = 0;
+    T4A_HIP(hipMemcpyAsync(h, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
+    T4A_HIP(hipMemcpyAsync(&bits, d_sabs_.get(), sizeof(bits), hipMemcpyDeviceToHost, stream_));
+    T4A_HIP(hipStreamSynchronize(stream_));
+    if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
+    double amax;
+    std::memcpy(&amax, &bits, sizeof(amax));
+    int e = 0;
+    if (amax > 0.0 && (amax > 0x1p200 || amax < 0x1p-200)) e = std::ilogb(amax);
+    if (e == 0) {
+        svd_in_range(d_a, M, N, d_u, d_s, d_vt);
+        return;
+    }
+    d_sscaled_.reserve((size_t)M * N);
+    scale_pow2_launch(d_sscaled_.get(), d_a, (size_t)M * N, -e, stream_);
+    svd_in_range(d_sscaled_.get(), M, N, d_u, d_s, d_vt);
+    scale_pow2_launch(d_s, d_s, (size_t)kmin, e, stream_);
+    T4A_HIP(hipGetLastError());
+}
+
+void Engine::svd_in_range(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt)
+{
     static const bool no_precond = diag_env("T4A_SVD_NO_PRECOND") != nullptr;
     const int kmin = M < N ? M : N;
-    // (matrices whose W and V fit one workgroup's LDS: the one-launch iteration of svd_plain, no QR in front — round 6)
-    if (no_precond || kmin < 64 || jacobi_fits_groups(M < N ? N : M, kmin)) {
+    if (no_precond || kmin < 64) {
         svd_plain(d_a, M, N, d_u, d_s, d_vt);
         return;
     }
     const bool flip = M < N;
     const int m = flip ? N : M, n = flip ? M : N;
-    {   // (non-finite input: the same error as the plain path, before the QR turns it into something else)
-        d_sflags_.reserve((size_t)n + 4);
-        int* flags = d_sflags_.get();
-        T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, stream_));
-        nonfinite_flag_launch(d_a, (size_t)M * N, flags + 2, stream_);
-        int h[4] = {0, 0, 0, 0};
-        T4A_HIP(hipMemcpyAsync(h, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
-        T4A_HIP(hipStreamSynchronize(stream_));
-        if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
-    }
     const double* Ap = d_a;
     if (flip) {
         d_pa_.reserve((size_t)m * n);
@@ -1201,9 +1232,9 @@ void Engine::svd_plain(const double* d_a, int M, int N, double* d_u, double* d_s
     d_su_.reserve((size_t)m * n);
     d_svs_.reserve((size_t)n * n);
     d_ssig_.reserve((size_t)n + m);
-    d_sflags_.reserve((size_t)n + 4);
-    int* flags = d_sflags_.get(); // [0] rotated [1] n_dead [2] non-finite, [4..] dead[n]
-    T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int) * ((size_t)n + 4), stream_));
+    d_sflags_.reserve((size_t)n + 8);
+    int* flags = d_sflags_.get(); // [0] rotated [1] n_dead [2] non-finite [3] converged / sweep count [4] scale exponent, [8..] dead[n]
+    T4A_HIP(hipMemsetAsync(flags, 0, sizeof(int) * ((size_t)n + 8), stream_));
     // W and V of up to 96 columns fit one workgroup's LDS together: the whole iteration in ONE launch, sixteen lanes per column pair
     // (jacobi_groups_kernel; a 64 x 64 call 0.65 ms, of which the kernel 0.54, against 1.39 ms through QR + blocked tournament, 1.17 ms
     // for the blocked tournament alone and 2.23 ms for jacobi_small_kernel — profiles/r06_svd_small.txt; the kernel checks the input for
@@ -1258,15 +1289,19 @@ void Engine::svd_plain(const double* d_a, int M, int N, double* d_u, double* d_s
     // the taller factor (m x n) and the square one (n x n): write straight to the outputs where no transpose is needed
     double* Ubig = flip ? d_su_.get() : d_u;   // m x n
     double* Vsq = flip ? d_u : d_svs_.get();   // n x n
-    svd_finalize_launch(W, m, V, n, d_ssig_.get(), Ubig, d_s, Vsq, flags + 4, flags + 1, stream_);
-    T4A_HIP(hipMemcpyAsync(h, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
+    svd_finalize_launch(W, m, V, n, d_ssig_.get(), Ubig, d_s, Vsq, flags + 8, flags + 1, stream_);
+    int h5[5] = {0, 0, 0, 0, 0};
+    T4A_HIP(hipMemcpyAsync(h5, flags, sizeof(int) * 5, hipMemcpyDeviceToHost, stream_));
     T4A_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < 4; ++i) h[i] = h5[i];
     if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
+    // (the one-launch kernel iterated on 2^-e A and left W that way: U = W / sigma does not see the factor, the singular values do)
+    if (groups && h5[4] != 0) scale_pow2_launch(d_s, d_s, (size_t)n, h5[4], stream_);
     if (groups) {
         static const bool dbg = std::getenv("T4A_SVD_DEBUG") != nullptr;
         if (dbg) std::fprintf(stderr, "[t4a svd] %d x %d: one launch, converged within %d sweeps\n", m, n, h[3]);
     }
-    if (h[1] > 0) svd_complete_launch(Ubig, m, n, flags + 4, d_ssig_.get() + n, stream_);
+    if (h[1] > 0) svd_complete_launch(Ubig, m, n, flags + 8, d_ssig_.get() + n, stream_);
     if (flip)
         transpose_launch(Ubig, m, n, m, d_vt, n, stream_); // Vt (M x N) = U'^T, U' is N x M
     else

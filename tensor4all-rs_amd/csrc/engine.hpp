@@ -124,6 +124,7 @@ public:
     // one-sided Jacobi.  Throws INVALID_ARGUMENT for non-finite input.
     void svd(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt);
     void svd_plain(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt); // the Jacobi iteration on the matrix as it is
+    void svd_in_range(const double* d_a, int M, int N, double* d_u, double* d_s, double* d_vt); // svd() behind the scaling of its input
     // thin QR (qr_backend, backend.rs:742): d_q M x k, d_r k x N; Householder.
     void qr(const double* d_a, int M, int N, double* d_q, double* d_r);
 
@@ -211,6 +212,8 @@ private:
     DevBuf<double> d_pa_, d_pq_, d_pr_, d_pl_, d_pul_, d_pvl_, d_pu_; // QR-preconditioned SVD: A', Q, R, L = R^T, factors of L, U'
     size_t svd_sweeps_last_ = 0;
     DevBuf<int> d_sflags_;
+    DevBuf<unsigned long long> d_sabs_; // largest magnitude of an SVD input (bit pattern)
+    DevBuf<double> d_sscaled_;          // the input scaled by a power of two (only when its largest entry is outside 2^-200 .. 2^200)
 };
 
 // triangle extraction helper kernels (engine.hip)

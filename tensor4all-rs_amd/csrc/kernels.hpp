@@ -580,11 +580,15 @@ void small_optimize_launch(const SmallArgs& a, int n, int K, int total, hipStrea
 // kernels_linalg.hip — one-sided Jacobi SVD and Householder QR building blocks
 // ------------------------------------------------------------------------------------------------
 void nonfinite_flag_launch(const double* data, size_t count, int* d_flag, hipStream_t stream);
+// the same pass also returns the largest magnitude (bit pattern of the double, *d_absmax_bits zeroed by the caller)
+void nonfinite_absmax_launch(const double* data, size_t count, int* d_flag, unsigned long long* d_absmax_bits, hipStream_t stream);
+void scale_pow2_launch(double* dst, const double* src, size_t count, int e, hipStream_t stream); // dst = src * 2^e, exact
 bool jacobi_fits_small(int m, int n);
 // all sweeps inside one workgroup (m >= n, n <= 128)
 void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream);
 // all sweeps inside one workgroup, a group of 8 or 16 lanes per column pair, W and V in the LDS (m >= n, n <= 96; see jg_plan);
-// V is an output only, d_nonfinite[0] is set for an Inf / NaN input, d_nonfinite[1] receives the sweep count
+// V is an output only, d_nonfinite[0] is set for an Inf / NaN input, d_nonfinite[1] receives the sweep count, d_nonfinite[2] the exponent e
+// when the kernel iterated on (and returns) 2^-e W
 bool jacobi_fits_groups(int m, int n);
 bool jacobi_groups_launch(double* W, int m, double* V, int n, int max_sweeps, int* d_nonfinite, hipStream_t stream);
 // one full sweep = n-1 tournament rounds, one launch per round; *d_rotated is set when any pair rotated

@@ -285,6 +285,7 @@ __global__ void __launch_bounds__(768) jacobi_groups_kernel(double* Wg, int m, d
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int s_rot[3];
     __shared__ int s_bad;
+    __shared__ unsigned long long s_amax;
     // a column's stride in the LDS: G MR (G VR) rows, m <= G MR, n <= G VR, the padding is zero; a stride that is a multiple of 32 doubles
     // would start every column on bank 0 (the four groups of a wave read four columns at once), so such strides get 16 more where the LDS
     // has the room (jg_stride)
@@ -295,15 +296,19 @@ __global__ void __launch_bounds__(768) jacobi_groups_kernel(double* Wg, int m, d
     if (tid == 0) {
         s_rot[0] = s_rot[1] = s_rot[2] = 0;
         s_bad = 0;
+        s_amax = 0ull;
     }
     __syncthreads();
     int bad = 0;
+    double mx = 0.0;
     for (int e = tid; e < np * ldw; e += T) {
         const int c = e / ldw, r = e - c * ldw;
         double x = 0.0;
         if (c < n && r < m) {
             x = Wg[(size_t)c * m + r];
-            if (!(fabs(x) <= 1.79769313486231570e308)) bad = 1;
+            const double ax = fabs(x);
+            if (!(ax <= 1.79769313486231570e308)) bad = 1;
+            else if (ax > mx) mx = ax;
         }
         W[e] = x;
     }
@@ -312,10 +317,24 @@ __global__ void __launch_bounds__(768) jacobi_groups_kernel(double* Wg, int m, d
         V[e] = (c == r && c < n) ? 1.0 : 0.0;
     }
     if (bad) s_bad = 1;
+    if (mx > 0.0) atomicMax(&s_amax, (unsigned long long)__double_as_longlong(mx));
     __syncthreads();
     if (s_bad) {
         if (tid == 0) *nonfinite = 1;
         return;
+    }
+    // a matrix whose largest entry is far from 1 is scaled by a power of two (exact) for the iteration: alpha * beta in the pair test overflows
+    // from |a| ~ 1e77 on (see nonfinite_absmax_kernel).  W goes back SCALED (the column norms of the finalisation would overflow the same
+    // way) and nonfinite[2] tells the caller the exponent to put back on the singular values; matrices in the usual range are not touched
+    int scale_e = 0;
+    {
+        const double amax = __longlong_as_double((long long)s_amax);
+        if (amax > 0.0 && (amax > 0x1p200 || amax < 0x1p-200)) scale_e = ilogb(amax);
+    }
+    if (tid == 0) nonfinite[2] = scale_e;
+    if (scale_e != 0) {
+        for (int e = tid; e < np * ldw; e += T) W[e] = ldexp(W[e], -scale_e);
+        __syncthreads();
     }
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int PW = 64 / G;              // pairs per wave
@@ -392,7 +411,7 @@ __global__ void __launch_bounds__(768) jacobi_groups_kernel(double* Wg, int m, d
     }
     for (int e = tid; e < n * m; e += T) {
         const int c = e / m, r = e - c * m;
-        Wg[e] = W[(size_t)c * ldw + r];
+        Wg[e] = W[(size_t)c * ldw + r]; // (still scaled by 2^-scale_e: the caller scales the singular values back)
     }
     for (int e = tid; e < n * n; e += T) {
         const int c = e / n, r = e - c * n;
@@ -773,6 +792,34 @@ __global__ void __launch_bounds__(256) nonfinite_kernel(const double* __restrict
     if (bad) *flag = 1;
 }
 
+// Inf / NaN flag and the largest magnitude in one pass (*absmax_bits zeroed by the caller: the bit pattern of a non-negative double orders
+// like its value).  Engine::svd scales a matrix whose largest entry is far from 1 by a power of two (exact) before the iteration: the
+// pair test of the Jacobi rotations forms alpha * beta, the product of two squared column norms, which overflows from |a| ~ 1e77 on —
+// no pair rotated and the factors came back non-orthogonal without an error (found by tools/soak_svd_small.py, round 6).
+__global__ void __launch_bounds__(256) nonfinite_absmax_kernel(const double* __restrict__ data, size_t count, int* flag,
+                                                               unsigned long long* absmax_bits)
+{
+    __shared__ unsigned long long s_max;
+    if (threadIdx.x == 0) s_max = 0ull;
+    __syncthreads();
+    int bad = 0;
+    double mx = 0.0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+        const double v = fabs(data[e]);
+        if (!(v <= 1.79769313486231570e308)) bad = 1;
+        else if (v > mx) mx = v;
+    }
+    if (bad) *flag = 1;
+    if (mx > 0.0) atomicMax(&s_max, (unsigned long long)__double_as_longlong(mx));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(absmax_bits, s_max);
+}
+
+__global__ void __launch_bounds__(256) scale_pow2_kernel(double* dst, const double* src, size_t count, int e)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = ldexp(src[i], e);
+}
+
 // ------------------------------------------------------------------------------------------------ QR
 // Blocked Householder QR, round 3 (qr_backend, tensor4all-tensorbackend/src/backend.rs:742-760; callers
 // tensor4all-simplett/src/compression.rs:229-341).  Same reflectors as qr_step_kernel (alpha = -sign(x0) |x|, v = x - alpha e1
@@ -1118,6 +1165,23 @@ void nonfinite_flag_launch(const double* data, size_t count, int* d_flag, hipStr
     hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, data, count, d_flag);
 }
 
+void nonfinite_absmax_launch(const double* data, size_t count, int* d_flag, unsigned long long* d_absmax_bits, hipStream_t stream)
+{
+    if (count == 0) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(nonfinite_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, data, count, d_flag, d_absmax_bits);
+}
+
+// dst[i] = src[i] * 2^e (exact; dst may be src)
+void scale_pow2_launch(double* dst, const double* src, size_t count, int e, hipStream_t stream)
+{
+    if (count == 0) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(scale_pow2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, count, e);
+}
+
 bool jacobi_fits_small(int m, int n) { return n <= 128 && m <= 2048; }
 
 void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream)
@@ -1166,7 +1230,7 @@ bool jacobi_fits_groups(int m, int n)
 }
 
 // V is an OUTPUT only (the kernel starts from the identity); *d_nonfinite is set (and W left as it was) when W holds an Inf or a NaN;
-// d_nonfinite[1] receives the number of sweeps.  false: the shape has no instantiation (jacobi_fits_groups), nothing was launched.
+// d_nonfinite[1] receives the number of sweeps, d_nonfinite[2] the exponent e when the kernel iterated on 2^-e W (W comes back that way).  false: the shape has no instantiation (jacobi_fits_groups), nothing was launched.
 bool jacobi_groups_launch(double* W, int m, double* V, int n, int max_sweeps, int* d_nonfinite, hipStream_t stream)
 {
     JgPlan p;

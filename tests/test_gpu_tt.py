@@ -585,6 +585,32 @@ def test_svd_one_launch_route_instantiations_and_their_edges(t4a, shape):
     assert np.abs(s - 1.0).max() < 1e-15
 
 
+@pytest.mark.parametrize("scale", [1e120, 1e-120, 1e250, 1e-250, 2.0 ** 201, 2.0 ** -201, 2.0 ** 199])
+def test_svd_of_matrices_far_from_unit_scale(t4a, scale):
+    """Round 6 (found by tools/soak_svd_small.py): the pair test of the Jacobi rotations forms alpha * beta, the product of two squared
+    column norms — from |a| ~ 1e77 on it overflowed, no pair rotated and U / V came back non-orthogonal WITHOUT an error; below 1e-77 the
+    product underflowed.  A matrix whose largest entry is outside 2^-200 .. 2^200 is now scaled by a power of two (exact) and the singular
+    values are scaled back (Engine::svd for the blocked and QR-preconditioned routes, inside jacobi_groups_kernel for the one-launch
+    route).  Every route, both orientations, both sides of the threshold; singular values against LAPACK relative to the largest."""
+    rng = np.random.default_rng(5)
+    for (m, n) in [(40, 20), (20, 40), (64, 64), (96, 96), (1000, 40), (40, 1000), (200, 100), (100, 200), (300, 70)]:
+        a = rng.standard_normal((m, n)) * scale
+        k = min(m, n)
+        u, s, vt = t4a.svd_backend(a)
+        sref = np.linalg.svd(a, compute_uv=False)
+        assert np.all(np.isfinite(s)) and np.all(np.isfinite(u)) and np.all(np.isfinite(vt))
+        assert np.abs(s / sref[0] - sref / sref[0]).max() <= 1e-12, (m, n)
+        assert np.abs(u.T @ u - np.eye(k)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(k)).max() < 1e-10, (m, n)
+        assert np.abs(((u * (s / sref[0])) @ vt) - a / sref[0]).max() <= 1e-12 * k, (m, n)
+    # one huge entry in an otherwise ordinary matrix, and a zero matrix next to the scaling logic
+    a = rng.standard_normal((50, 30))
+    a[7, 3] = scale
+    u, s, vt = t4a.svd_backend(a)
+    sref = np.linalg.svd(a, compute_uv=False)
+    assert np.abs(s / sref[0] - sref / sref[0]).max() <= 1e-12
+    assert np.abs(u.T @ u - np.eye(30)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(30)).max() < 1e-10
+
+
 @pytest.mark.parametrize("shape", [(200, 100), (100, 200), (128, 128)])
 def test_preconditioned_svd_on_rank_deficient_and_graded_inputs(t4a, shape):
     """Engine::svd runs the Jacobi iteration on L = R^T of a Householder QR from 64 columns on (round 5): exact rank deficiency (zero
