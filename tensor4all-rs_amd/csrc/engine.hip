@@ -1153,8 +1153,7 @@ void Engine::svd(const double* d_a, int M, int N, double* d_u, double* d_s, doub
     if (h[2]) throw Error(T4A_GPU_INVALID_ARGUMENT, "SVD computation failed: non-finite input");
     double amax;
     std::memcpy(&amax, &bits, sizeof(amax));
-    int e = 0;
-    if (amax > 0.0 && (amax > 0x1p200 || amax < 0x1p-200)) e = std::ilogb(amax);
+    const int e = pow2_scale_exponent(amax);
     if (e == 0) {
         svd_in_range(d_a, M, N, d_u, d_s, d_vt);
         return;
@@ -1316,7 +1315,14 @@ void Engine::qr(const double* d_a, int M, int N, double* d_q, double* d_r)
     d_sw_.reserve((size_t)M * N);
     d_ssig_.reserve((size_t)3 * k);
     double* W = d_sw_.get();
-    T4A_HIP(hipMemcpyAsync(W, d_a, sizeof(double) * (size_t)M * N, hipMemcpyDeviceToDevice, stream_));
+    // The copy the factorisation works on is 2^-e A for a matrix whose largest entry is outside 2^-200 .. 2^200 (the Householder norms are
+    // sums of squares: entries of 1e-200 made every column "zero" and R came back 0 without an error — tools/soak_dense_small.py, round
+    // 6); e is found and applied on the device (this routine has no host synchronisation), Q is that of A and R gets the factor back.
+    d_sflags_.reserve(8);
+    d_sabs_.reserve(1);
+    T4A_HIP(hipMemsetAsync(d_sabs_.get(), 0, sizeof(unsigned long long), stream_));
+    nonfinite_absmax_launch(d_a, (size_t)M * N, d_sflags_.get() + 5, d_sabs_.get(), stream_); // (the Inf / NaN flag is not used here)
+    scale_pow2_dev_launch(W, d_a, (size_t)M * N, d_sabs_.get(), -1, stream_);
     double* diag = d_ssig_.get();
     double* tau = diag + k;
     double* v0s = tau + k;
@@ -1330,6 +1336,7 @@ void Engine::qr(const double* d_a, int M, int N, double* d_q, double* d_r)
     double* Wb = Wa + (size_t)QR_PANEL * wcols;
     qr_factor_launch(W, M, N, diag, tau, v0s, Vall, Tall, Wa, Wb, stream_);
     qr_form_launch(W, M, N, diag, Vall, Tall, Wa, Wb, d_q, d_r, stream_);
+    scale_pow2_dev_launch(d_r, d_r, (size_t)k * N, d_sabs_.get(), +1, stream_);
     T4A_HIP(hipGetLastError());
 }
 

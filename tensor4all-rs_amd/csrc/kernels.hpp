@@ -583,6 +583,12 @@ void nonfinite_flag_launch(const double* data, size_t count, int* d_flag, hipStr
 // the same pass also returns the largest magnitude (bit pattern of the double, *d_absmax_bits zeroed by the caller)
 void nonfinite_absmax_launch(const double* data, size_t count, int* d_flag, unsigned long long* d_absmax_bits, hipStream_t stream);
 void scale_pow2_launch(double* dst, const double* src, size_t count, int e, hipStream_t stream); // dst = src * 2^e, exact
+// The exponent Engine::svd / Engine::qr scale their input by (2^-e A is decomposed, the factor goes back on S / R): 0 for a largest
+// magnitude inside 2^-200 .. 2^200 and for a zero matrix.  Squared column norms — the Jacobi pair test's alpha * beta, the Householder
+// norms — overflow from ~1e77 / ~1e154 on and underflow below ~1e-154: without the scaling such inputs gave wrong factors and no error.
+__host__ __device__ inline int pow2_scale_exponent(double amax) { return (amax > 0.0 && (amax > 0x1p200 || amax < 0x1p-200)) ? ilogb(amax) : 0; }
+// dst = src * 2^(sign * e) with e = pow2_scale_exponent of the magnitude nonfinite_absmax_launch left in *d_absmax_bits (device side)
+void scale_pow2_dev_launch(double* dst, const double* src, size_t count, const unsigned long long* d_absmax_bits, int sign, hipStream_t stream);
 bool jacobi_fits_small(int m, int n);
 // all sweeps inside one workgroup (m >= n, n <= 128)
 void jacobi_small_launch(double* W, int m, double* V, int n, int max_sweeps, hipStream_t stream);

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(768) jacobi_groups_kernel(double* Wg, int m, d
     int scale_e = 0;
     {
         const double amax = __longlong_as_double((long long)s_amax);
-        if (amax > 0.0 && (amax > 0x1p200 || amax < 0x1p-200)) scale_e = ilogb(amax);
+        scale_e = pow2_scale_exponent(amax);
     }
     if (tid == 0) nonfinite[2] = scale_e;
     if (scale_e != 0) {
@@ -815,6 +815,17 @@ __global__ void __launch_bounds__(256) nonfinite_absmax_kernel(const double* __r
     if (threadIdx.x == 0 && s_max) atomicMax(absmax_bits, s_max);
 }
 
+// dst = src * 2^(sign * e), e from the largest magnitude a previous nonfinite_absmax_kernel left in *absmax_bits (no host round trip: the
+// QR has none); e = 0 is a plain copy, and nothing at all when dst == src.
+__global__ void __launch_bounds__(256) scale_pow2_dev_kernel(double* dst, const double* src, size_t count, const unsigned long long* absmax_bits,
+                                                             int sign)
+{
+    const int e = sign * pow2_scale_exponent(__longlong_as_double((long long)*absmax_bits));
+    if (e == 0 && dst == src) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = e != 0 ? ldexp(src[i], e) : src[i];
+}
+
 __global__ void __launch_bounds__(256) scale_pow2_kernel(double* dst, const double* src, size_t count, int e)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = ldexp(src[i], e);
@@ -1180,6 +1191,14 @@ void scale_pow2_launch(double* dst, const double* src, size_t count, int e, hipS
     size_t blocks = (count + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(scale_pow2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, count, e);
+}
+
+void scale_pow2_dev_launch(double* dst, const double* src, size_t count, const unsigned long long* d_absmax_bits, int sign, hipStream_t stream)
+{
+    if (count == 0) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(scale_pow2_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, count, d_absmax_bits, sign);
 }
 
 bool jacobi_fits_small(int m, int n) { return n <= 128 && m <= 2048; }

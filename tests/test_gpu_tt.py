@@ -611,6 +611,28 @@ def test_svd_of_matrices_far_from_unit_scale(t4a, scale):
     assert np.abs(u.T @ u - np.eye(30)).max() < 1e-10 and np.abs(vt @ vt.T - np.eye(30)).max() < 1e-10
 
 
+@pytest.mark.parametrize("scale", [1e-200, 1e-250, 1e200, 1e250, 2.0 ** -201, 2.0 ** 201, 2.0 ** 199, 1.0])
+def test_qr_of_matrices_far_from_unit_scale(t4a, scale):
+    """Round 6 (found by tools/soak_dense_small.py): the Householder column norms are sums of squares — with entries of 1e-200 every
+    column was "zero" and qr_backend returned R = 0 (Q R = 0, no error); from ~1e154 on the squares overflow.  Engine::qr now factorises
+    2^-e A for a matrix whose largest entry is outside 2^-200 .. 2^200 (exact, found and applied on the device) and puts the factor back on
+    R.  Panels factorised in the LDS and in global memory (more than 560 rows), wide and tall; Q R = A relative to the largest entry, Q
+    orthonormal, R upper triangular; the R of a scaled matrix is the scaled R, bit for bit, when the factor is a power of two."""
+    rng = np.random.default_rng(9)
+    for (m, n) in [(40, 20), (20, 40), (64, 64), (300, 120), (120, 300), (700, 60), (1, 5), (5, 1)]:
+        a0 = rng.standard_normal((m, n))
+        a = a0 * scale
+        k = min(m, n)
+        q, r = t4a.qr_backend(a)
+        assert np.all(np.isfinite(q)) and np.all(np.isfinite(r)), (m, n)
+        amax = np.abs(a).max()
+        assert np.abs(q @ (r / amax) - a / amax).max() <= 1e-13 * k, (m, n)
+        assert np.abs(q.T @ q - np.eye(k)).max() < 1e-11 and np.abs(np.tril(r, -1)).max() == 0.0, (m, n)
+        if scale in (2.0 ** -201, 2.0 ** 201, 2.0 ** 199):
+            q0, r0 = t4a.qr_backend(a0)
+            assert np.array_equal(q, q0) and np.array_equal(r, r0 * scale), (m, n)
+
+
 @pytest.mark.parametrize("shape", [(200, 100), (100, 200), (128, 128)])
 def test_preconditioned_svd_on_rank_deficient_and_graded_inputs(t4a, shape):
     """Engine::svd runs the Jacobi iteration on L = R^T of a Householder QR from 64 columns on (round 5): exact rank deficiency (zero
