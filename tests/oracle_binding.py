@@ -296,17 +296,30 @@ class OracleTCI2:
                 cint(0 if o.seed is None else 1), u64(0 if o.seed is None else o.seed)]
 
     def set_pivot_search(self, strategy):
+        """The oracle takes the pivot search strategy (tensorci2.rs:73-170 `pivot_search`) from the HANDLE, not from the options it is
+        handed (`_opt_args` has no such field)."""
         _check(_lib.oracle_tci2_set_pivot_search(vp(self._h), cint(strategy)))
+        self._pivot_search = int(strategy)
+
+    def _check_strategy(self, o):
+        # options that ask for Rook on a handle still set to Full would be compared against a device run of a different algorithm
+        # without anyone noticing (tests/soak/soak_tci2_general.py did exactly that in its first version): refuse
+        want = int(getattr(o, "pivot_search", 0) or 0)
+        if want != 0 and getattr(self, "_pivot_search", 0) != want:
+            raise ValueError("the options ask for pivot_search=%d but this oracle handle is set to %d: call set_pivot_search first"
+                             % (want, getattr(self, "_pivot_search", 0)))
 
     def add_global_pivots(self, pivots):
         piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), len(self.local_dims)))
         _check(_lib.oracle_tci2_add_global_pivots(vp(self._h), _p(piv), u64(len(pivots))))
 
     def crossinterpolate2(self, pivots, o):
+        self._check_strategy(o)
         piv = np.ascontiguousarray(np.asarray(pivots, dtype=np.uint64).reshape(len(pivots), len(self.local_dims)))
         _check(_lib.oracle_tci2_crossinterpolate2(vp(self._h), _p(piv), u64(len(pivots)), *self._opt_args(o)))
 
     def optimize(self, o, final_sweep1site=True):
+        self._check_strategy(o)
         _check(_lib.oracle_tci2_optimize(vp(self._h), *self._opt_args(o), cint(int(final_sweep1site))))
 
     def sweep2site(self, forward, o):
