@@ -223,6 +223,52 @@ def test_compress_truncates_larger_train(t4a, method):
     assert np.abs(tt.full_tensor() - full).max() < 1e-9 * np.abs(full).max()
 
 
+def test_rank_zero_bond_matrix_is_refused_by_lu_and_ci_compress_and_by_conversion(t4a):
+    """DESIGN.md section 2, "a known device / oracle difference".  rrlu_mut stops at `p <= EPS` — an ABSOLUTE 2.2e-16 — before the first
+    pivot (matrixlu.rs:735-819), and `factorize` hands the LU / CI pivot count through unclamped (compression.rs:165-227; only the SVD branch
+    has `rank.max(1)`, :305): a bond matrix whose largest entry is <= 2.2e-16 — an identically zero core, or a train holding values of
+    1e-20 — means bond dimension 0 and 0-row products in the un-vendored backend.  No test of the reference goes there.  The oracle follows
+    that reading (link dimensions 0: the train becomes the zero function, values of 1e-20 included); the DEVICE refuses: INVALID_ARGUMENT,
+    the train still a train of the same tensor (cores in front of the refused bond may have been re-factored), the handle usable.  SVD compression of the same trains is the oracle's, and so is everything for a train with a
+    zero slice but bond matrices above the threshold."""
+    rng = np.random.default_rng(3)
+    zero_core = [np.zeros((1, 1, 4)), rng.uniform(-1, 1, (4, 3, 4)), rng.uniform(-1, 1, (4, 2, 1))]
+    zero_mid = [rng.uniform(-1, 1, (1, 3, 4)), np.zeros((4, 3, 4)), rng.uniform(-1, 1, (4, 2, 1))]
+    tiny = [rng.uniform(-1, 1, (1, 3, 4)) * 1e-20, rng.uniform(-1, 1, (4, 3, 4)), rng.uniform(-1, 1, (4, 2, 1))]
+    for cores in (zero_core, zero_mid, tiny):
+        full = ob.OracleTT(cores).full_tensor()
+        for method in (0, 1):
+            g = t4a.SimpleTensorTrain(cores)
+            with pytest.raises(t4a.T4aError) as e:
+                g.compress(method=method, tolerance=1e-10)
+            assert e.value.code == t4a.INVALID_ARGUMENT and "zero bond matrix" in str(e.value)
+            # (like the reference's in-place compress behind `?`, the sweep may have re-factored the cores in front of the refused bond:
+            #  the train is still a valid train of the SAME tensor, not necessarily the same cores)
+            assert len(g.link_dims()) == 2 and 0 not in g.link_dims()
+            assert np.abs(g.full_tensor() - full).max() <= 1e-14 * max(np.abs(full).max(), 1e-300)
+            o = ob.OracleTT(cores)
+            o.compress(method=method, tolerance=1e-10)
+            assert 0 in o.link_dims()
+        g = t4a.SimpleTensorTrain(cores)
+        g.compress(method=2, tolerance=1e-10)
+        o = ob.OracleTT(cores)
+        o.compress(method=2, tolerance=1e-10)
+        assert g.link_dims() == o.link_dims() and 0 not in g.link_dims()
+        assert np.abs(g.full_tensor() - full).max() <= 1e-12 * max(np.abs(full).max(), 1e-300)
+    with pytest.raises(t4a.T4aError) as e:
+        t4a.TensorCI2.from_tensor_train(t4a.SimpleTensorTrain(zero_core))
+    assert e.value.code == t4a.INVALID_ARGUMENT
+    part = [rng.uniform(-1, 1, (1, 3, 4)), rng.uniform(-1, 1, (4, 3, 4)), rng.uniform(-1, 1, (4, 2, 1))]
+    part[1][:, 1, :] = 0.0
+    for method in (0, 1, 2):
+        g = t4a.SimpleTensorTrain(part)
+        g.compress(method=method, tolerance=1e-10)
+        o = ob.OracleTT(part)
+        o.compress(method=method, tolerance=1e-10)
+        assert g.link_dims() == o.link_dims()
+        assert np.abs(g.full_tensor() - o.full_tensor()).max() < 1e-10
+
+
 # ---------------------------------------------------------------------------------------------- a17
 def test_evaluate_many_reference_cases(t4a):
     tt = t4a.SimpleTensorTrain.constant([2, 3, 2], 2.0)
