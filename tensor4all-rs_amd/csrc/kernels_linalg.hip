@@ -1257,20 +1257,25 @@ bool jacobi_groups_launch(double* W, int m, double* V, int n, int max_sweeps, in
     const int np = n + (n & 1);
     const int waves = (np / 2 + 3) / 4;
     const size_t lds = (size_t)np * (jg_stride(16 * p.MR, p.MR, p.VR) + jg_stride(16 * p.VR, p.MR, p.VR)) * 8; // <= 147 KB by construction
-    auto go = [&](auto kern) {
-        // (idempotent, a few hundred nanoseconds: set on every launch rather than once per instantiation and process)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    // the dynamic-LDS limit of an instantiation is raised once per process (launches come from several host threads: setting it twice is
+    // harmless, the flag only saves the runtime call)
+    static std::atomic<bool> attr_set[8];
+    auto go = [&](auto kern, int id) {
+        if (!attr_set[id].load(std::memory_order_acquire)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            attr_set[id].store(true, std::memory_order_release);
+        }
         hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), lds, stream, W, m, V, n, np, max_sweeps, d_nonfinite);
     };
     switch (p.VR * 100 + p.MR) {
-    case 202: go(&jacobi_groups_kernel<16, 2, 2>); break;
-    case 204: go(&jacobi_groups_kernel<16, 4, 2>); break;
-    case 208: go(&jacobi_groups_kernel<16, 8, 2>); break;
-    case 214: go(&jacobi_groups_kernel<16, 14, 2>); break;
-    case 404: go(&jacobi_groups_kernel<16, 4, 4>); break;
-    case 408: go(&jacobi_groups_kernel<16, 8, 4>); break;
-    case 414: go(&jacobi_groups_kernel<16, 14, 4>); break;
-    case 606: go(&jacobi_groups_kernel<16, 6, 6>); break;
+    case 202: go(&jacobi_groups_kernel<16, 2, 2>, 0); break;
+    case 204: go(&jacobi_groups_kernel<16, 4, 2>, 1); break;
+    case 208: go(&jacobi_groups_kernel<16, 8, 2>, 2); break;
+    case 214: go(&jacobi_groups_kernel<16, 14, 2>, 3); break;
+    case 404: go(&jacobi_groups_kernel<16, 4, 4>, 4); break;
+    case 408: go(&jacobi_groups_kernel<16, 8, 4>, 5); break;
+    case 414: go(&jacobi_groups_kernel<16, 14, 4>, 6); break;
+    case 606: go(&jacobi_groups_kernel<16, 6, 6>, 7); break;
     default: return false;
     }
     return true;
