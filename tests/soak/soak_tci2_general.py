@@ -18,6 +18,7 @@ import oracle_binding as ob  # noqa: E402
 from t4a_amd.functions import lorentz, quantics_osc2d, quantics_trig_exp  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+ROOK_SHARE = float(os.environ.get("T4A_SOAK_ROOK_SHARE", "0.25"))  # (1.0: every case with PivotSearchStrategy::Rook)
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 fails = 0
 t_dev = t_orc = 0.0
@@ -39,7 +40,7 @@ for case in range(N):
         d = int(rng.integers(8, 25))
         dims = [2] * d
         spec = quantics_trig_exp(d)
-    rook = bool(rng.random() < 0.25)
+    rook = bool(rng.random() < ROOK_SHARE)
     opt = t4a.TCI2Options(tolerance=float(10.0 ** rng.integers(-12, -5)), max_iter=int(rng.integers(2, 8)),
                           max_bond_dim=(None if rng.random() < 0.15 else int(rng.integers(8, 40 if rook else 100))),
                           pivot_search=1 if rook else 0,
@@ -95,6 +96,6 @@ for case in range(N):
     except Exception as exc:  # noqa: BLE001 (a soak reports and goes on)
         fails += 1
         print(f"FAIL {ctx}: exception {type(exc).__name__}: {exc}", flush=True)
-print(f"{N} cases from seed {seed0}: {fails} failures; largest link dimension {max_rank_seen}; device {t_dev:.1f} s, oracle {t_orc:.1f} s, "
+print(f"{N} cases from seed {seed0} (Rook share {ROOK_SHARE}): {fails} failures; largest link dimension {max_rank_seen}; device {t_dev:.1f} s, oracle {t_orc:.1f} s, "
       f"total {time.perf_counter() - t0:.1f} s", flush=True)
 sys.exit(1 if fails else 0)
