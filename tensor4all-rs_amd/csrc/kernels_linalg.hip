@@ -263,22 +263,16 @@ __device__ inline Rot jacobi_rotation_fast(double alpha, double beta, double gam
 // arithmetic replicated over 64 lanes made a round of a 64 x 64 matrix 3.3 us (2.2 ms per decomposition, slower than the blocked
 // tournament's 1.2 ms).  Here a wave carries four pairs: a lane owns the rows sub, sub + 16, ... of its pair's two columns (MR of W, VR
 // of V, in registers from the dot products to the rotation: one LDS round trip per round), the three dot products are 16-lane DPP sums and
-// the rotation arithmetic is executed once per wave.  Measured (profiles/r06_svd_small.txt): 0.85 us per round at 64 x 64 (10 sweeps of 63
-// rounds in 536 us), 0.72 us with one wave per SIMD (32 columns).  A model that fits, not a measurement: every round reads and writes
-// all of W and V — 2 * 8 * (m + n) * n bytes, 128 KB at 64 x 64, >= 1000 cycles of a compute unit's 128 B / clock LDS port before bank
-// conflicts — and issues ~200 instructions per wave on two waves per SIMD (~1600 cycles); both are of the order of the measured round.
-// Eight lanes per pair (half the waves, 1.7 x fewer instructions per round) measured SLOWER at every size (64 x 64: 776 against 727 us
-// per call): G stays a parameter, only 16 is instantiated.
+// the rotation arithmetic is executed once per wave.  Measured (profiles/r06_svd_small.txt sections 3 and 9): 0.85 us = 2 043 cycles per round
+// at 64 x 64 (10 sweeps of 63 rounds in 536 us).  Hardware counters over that kernel: VALU issue 55 % of a SIMD's time plus 20 % for LDS
+// instructions, the LDS array busy 43 % (880 cycles per round: all of W and V cross it twice), SQ_LDS_BANK_CONFLICT 0, the rest dependency
+// stalls and barriers — bound by instruction issue of two waves per SIMD (three at 96 columns: 59 % + 27 %, LDS array 60 %; one at 32
+// columns: 38 % + 10 %, half the time stalled).  Eight lanes per pair (half the waves, 1.7 x fewer instructions per round) measured
+// SLOWER at every size (64 x 64: 776 against 727 us per call: with one wave per SIMD the stalls no longer overlap): G stays a parameter,
+// only 16 is instantiated.
 // V starts as the identity in the LDS (never read from memory); a non-finite input sets *nonfinite and leaves W untouched.
 // LDS: double W[np][ldw], double V[np][ldv]: the launcher picks the instantiation whose column lengths cover m and n, the padding rows
 // are zero and stay zero under rotations, so no loop carries a bound.
-// LDS stride of a column of `rows` rows in jacobi_groups_kernel<16, MR, VR> (see there); the two largest instantiations fill the LDS
-// without the extra rows.
-__host__ __device__ constexpr int jg_stride(int rows, int MR, int VR)
-{
-    return rows + ((rows % 32 == 0 && !(MR == 14 && VR == 4) && !(MR == 6 && VR == 6)) ? 16 : 0);
-}
-
 template <int G, int MR, int VR>
 __global__ void __launch_bounds__(768) jacobi_groups_kernel(double* Wg, int m, double* Vg, int n, int np, int max_sweeps, int* nonfinite)
 {
@@ -286,10 +280,10 @@ __global__ void __launch_bounds__(768) jacobi_groups_kernel(double* Wg, int m, d
     __shared__ int s_rot[3];
     __shared__ int s_bad;
     __shared__ unsigned long long s_amax;
-    // a column's stride in the LDS: G MR (G VR) rows, m <= G MR, n <= G VR, the padding is zero; a stride that is a multiple of 32 doubles
-    // would start every column on bank 0 (the four groups of a wave read four columns at once), so such strides get 16 more where the LDS
-    // has the room (jg_stride)
-    constexpr int ldw = jg_stride(G * MR, MR, VR), ldv = jg_stride(G * VR, MR, VR);
+    // a column's stride in the LDS: G MR (G VR) rows, m <= G MR, n <= G VR, the padding rows are zero.  (No bank staggering: a group reads
+    // 16 consecutive doubles and a ds_read_b64 only conflicts inside a group of 16 lanes — SQ_LDS_BANK_CONFLICT is 0 for every instantiation;
+    // an earlier version padded the strides for nothing.)
+    constexpr int ldw = G * MR, ldv = G * VR;
     double* W = (double*)smem_raw;
     double* V = W + (size_t)np * ldw;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -1256,7 +1250,7 @@ bool jacobi_groups_launch(double* W, int m, double* V, int n, int max_sweeps, in
     if (!jg_plan(m, n, &p)) return false;
     const int np = n + (n & 1);
     const int waves = (np / 2 + 3) / 4;
-    const size_t lds = (size_t)np * (jg_stride(16 * p.MR, p.MR, p.VR) + jg_stride(16 * p.VR, p.MR, p.VR)) * 8; // <= 147 KB by construction
+    const size_t lds = (size_t)np * 16 * (p.MR + p.VR) * 8; // <= 144 KB by construction
     // the dynamic-LDS limit of an instantiation is raised once per process (launches come from several host threads: setting it twice is
     // harmless, the flag only saves the runtime call)
     static std::atomic<bool> attr_set[8];
