@@ -12,6 +12,7 @@ import numpy as np  # noqa: E402
 import t4a_amd  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+BIG = int(os.environ.get("T4A_SOAK_BIG", "1"))  # (T4A_SOAK_BIG=4: shapes up to four times larger — QR panels beyond 560 rows, larger LU plans)
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 scales = [1.0, 1.0, 1.0, 1e-120, 1e120, 1e-200, 1e150]
 fails = 0
@@ -31,8 +32,8 @@ for case in range(N):
     rng = np.random.default_rng(seed0 + case)
     scale = scales[case % len(scales)]
     # ---- QR
-    m = int(rng.integers(1, 260))
-    n = int(rng.integers(1, 260))
+    m = int(rng.integers(1, 260 * BIG))
+    n = int(rng.integers(1, 260 * BIG))
     k = min(m, n)
     kind = case % 4
     if kind == 0:
@@ -57,7 +58,7 @@ for case in range(N):
         note("qr |Q^T Q - I|", float(np.abs(q.T @ q - np.eye(k)).max()), 1e-11, info)
         note("qr tril(R)", float(np.abs(np.tril(r, -1)).max()), 0.0, info)
     # ---- solve (well conditioned: a random orthogonal matrix times a mild diagonal) and triangular solves
-    ns = int(rng.integers(1, 200))
+    ns = int(rng.integers(1, 200 * BIG))
     nrhs = int(rng.integers(1, 64))
     qq, _ = np.linalg.qr(rng.standard_normal((ns, ns)))
     A = (qq * rng.uniform(0.5, 2.0, ns)) @ np.linalg.qr(rng.standard_normal((ns, ns)))[0] * scale
@@ -81,7 +82,7 @@ for case in range(N):
             if ok:
                 note("trsm |x - x_ref| / |x|", float(np.abs(xt - X).max() / np.abs(X).max()), 1e-10, info + f" lower {lower} trans {transpose_a}")
     # ---- mat_mul against numpy (the reference's own tests use exact small-integer products; here: relative to |A| |B| k)
-    mm, kk, nn = (int(rng.integers(1, 300)) for _ in range(3))
+    mm, kk, nn = (int(rng.integers(1, 300 * BIG)) for _ in range(3))
     sa = scale if abs(np.log10(scale)) <= 120 else 1.0  # (the product of two 1e150 matrices is not representable)
     Am = rng.standard_normal((mm, kk)) * sa
     Bm = rng.standard_normal((kk, nn)) / sa
