@@ -14,14 +14,19 @@ import t4a_amd  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+BIG = bool(int(os.environ.get("T4A_SOAK_BIG", "0")))
 kinds = ["gaussian", "graded", "low_rank", "clustered", "column_scaled", "tiny", "huge", "orthogonal"]
 worst = {"s": 0.0, "rec": 0.0, "u": 0.0, "v": 0.0}
 fails = 0
 t0 = time.perf_counter()
 for case in range(N):
     rng = np.random.default_rng(seed0 + case)
-    n = int(rng.integers(2, 101))                      # columns: the route takes up to 96
-    m = int(rng.integers(n, min(240, 3 * n + 8) + 1))  # rows: up to 224 (n <= 64) / 96 (n > 64) stay on the route, the rest next to it
+    if BIG:
+        n = int(rng.integers(90, 420))                     # (T4A_SOAK_BIG=1: the blocked and the QR-preconditioned routes)
+        m = int(rng.integers(n, min(900, 3 * n) + 1))
+    else:
+        n = int(rng.integers(2, 101))                      # columns: the route takes up to 96
+        m = int(rng.integers(n, min(240, 3 * n + 8) + 1))  # rows: up to 224 (n <= 64) / 96 (n > 64) stay on the route, the rest next to it
     if rng.integers(0, 2):
         m, n = n, m
     k = min(m, n)
